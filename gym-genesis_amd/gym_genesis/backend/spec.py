@@ -1,0 +1,231 @@
+"""ctypes mirror of include/mirigid.h (MirSceneSpec and friends) plus a small
+builder API used to describe a scene the way the reference's tasks do with
+``scene.add_entity`` (/root/reference/gym_genesis/tasks/franka/cube_pick.py:50-54).
+
+Pure host-side data: no physics here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence
+
+MIR_VERSION = 1
+MIR_MAX_BODY = 16
+MIR_MAX_DOF = 16
+MIR_MAX_Q = 18
+MIR_MAX_GEOM = 24
+MIR_MAX_PAIR = 64
+MIR_MAX_CONTACT = 20
+MIR_MAX_GRIP = 4
+
+JNT_FIXED, JNT_REVOLUTE, JNT_PRISMATIC, JNT_FREE = 0, 1, 2, 3
+GEOM_PLANE, GEOM_BOX = 0, 1
+CTRL_NONE, CTRL_POSITION = 0, 1
+
+DEFAULT_SOLREF = (0.02, 1.0)
+DEFAULT_SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)
+
+
+class MirBodySpec(C.Structure):
+    _fields_ = [
+        ("parent", C.c_int32),
+        ("jtype", C.c_int32),
+        ("pos", C.c_double * 3),
+        ("quat", C.c_double * 4),
+        ("axis", C.c_double * 3),
+        ("mass", C.c_double),
+        ("ipos", C.c_double * 3),
+        ("inertia", C.c_double * 6),
+    ]
+
+
+class MirDofSpec(C.Structure):
+    _fields_ = [
+        ("limited", C.c_int32),
+        ("ctrl_mode", C.c_int32),
+        ("range", C.c_double * 2),
+        ("armature", C.c_double),
+        ("damping", C.c_double),
+        ("kp", C.c_double),
+        ("kv", C.c_double),
+        ("frc_range", C.c_double * 2),
+        ("solref", C.c_double * 2),
+        ("solimp", C.c_double * 5),
+    ]
+
+
+class MirGeomSpec(C.Structure):
+    _fields_ = [
+        ("body", C.c_int32),
+        ("type", C.c_int32),
+        ("contype", C.c_int32),
+        ("conaffinity", C.c_int32),
+        ("size", C.c_double * 3),
+        ("pos", C.c_double * 3),
+        ("quat", C.c_double * 4),
+        ("friction", C.c_double),
+        ("solref", C.c_double * 2),
+        ("solimp", C.c_double * 5),
+    ]
+
+
+class MirOptions(C.Structure):
+    _fields_ = [
+        ("dt", C.c_double),
+        ("gravity", C.c_double * 3),
+        ("tolerance", C.c_double),
+        ("ls_tolerance", C.c_double),
+        ("iterations", C.c_int32),
+        ("ls_iterations", C.c_int32),
+        ("enable_collision", C.c_int32),
+        ("enable_joint_limit", C.c_int32),
+        ("enable_self_collision", C.c_int32),
+        ("enable_adjacent_collision", C.c_int32),
+        ("max_contacts", C.c_int32),
+        ("implicit_damping", C.c_int32),
+    ]
+
+
+class MirTaskSpec(C.Structure):
+    _fields_ = [
+        ("eef_body", C.c_int32),
+        ("obj_body", C.c_int32),
+        ("n_grip", C.c_int32),
+        ("grip_dof", C.c_int32 * MIR_MAX_GRIP),
+        ("reward_z", C.c_double),
+    ]
+
+
+class MirSceneSpec(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("version", C.c_int32),
+        ("nbody", C.c_int32),
+        ("ndof", C.c_int32),
+        ("ngeom", C.c_int32),
+        ("_pad", C.c_int32),
+        ("opt", MirOptions),
+        ("task", MirTaskSpec),
+        ("body", MirBodySpec * MIR_MAX_BODY),
+        ("dof", MirDofSpec * MIR_MAX_DOF),
+        ("geom", MirGeomSpec * MIR_MAX_GEOM),
+    ]
+
+
+class MirDims(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32),
+        ("nbody", C.c_int32),
+        ("nq", C.c_int32),
+        ("nv", C.c_int32),
+        ("ngeom", C.c_int32),
+        ("npair", C.c_int32),
+        ("agent_dim", C.c_int32),
+        ("env_dim", C.c_int32),
+    ]
+
+
+def quat_normalize(q: Sequence[float]) -> tuple:
+    n = math.sqrt(sum(x * x for x in q))
+    return tuple(x / n for x in q)
+
+
+def box_inertia(mass: float, half: Sequence[float]) -> tuple:
+    """Solid-box inertia about its centre, (xx, yy, zz, xy, xz, yz)."""
+    x, y, z = (2 * h for h in half)
+    return (mass * (y * y + z * z) / 12, mass * (x * x + z * z) / 12, mass * (x * x + y * y) / 12, 0.0, 0.0, 0.0)
+
+
+class SceneBuilder:
+    """Accumulates bodies / dofs / geoms, then emits a MirSceneSpec.
+
+    Body 0 is the world.  Names are kept host-side only (``get_link`` lookups).
+    """
+
+    def __init__(self):
+        self.bodies: List[dict] = [dict(name="world", parent=0, jtype=JNT_FIXED, pos=(0, 0, 0), quat=(1, 0, 0, 0),
+                                        axis=(0, 0, 1), mass=0.0, ipos=(0, 0, 0), inertia=(0,) * 6)]
+        self.dofs: List[dict] = []
+        self.geoms: List[dict] = []
+        self.dof_names: List[str] = []
+        self.opt = dict(dt=0.01, gravity=(0.0, 0.0, -9.81), tolerance=1e-8, ls_tolerance=0.01, iterations=50,
+                        ls_iterations=50, enable_collision=1, enable_joint_limit=1, enable_self_collision=0,
+                        enable_adjacent_collision=0, max_contacts=MIR_MAX_CONTACT, implicit_damping=1)
+        self.task = dict(eef_body=0, obj_body=0, grip_dof=(), reward_z=0.1)
+
+    # -- bodies -----------------------------------------------------------------------------
+    def add_body(self, name: str, parent: str | int, pos=(0, 0, 0), quat=(1, 0, 0, 0), jtype=JNT_FIXED,
+                 axis=(0, 0, 1), mass=0.0, ipos=(0, 0, 0), inertia=(0,) * 6, joint_name: Optional[str] = None,
+                 **dof_kw) -> int:
+        pidx = parent if isinstance(parent, int) else self.body_index(parent)
+        idx = len(self.bodies)
+        self.bodies.append(dict(name=name, parent=pidx, jtype=jtype, pos=tuple(pos), quat=quat_normalize(quat),
+                                axis=tuple(axis), mass=float(mass), ipos=tuple(ipos), inertia=tuple(inertia)))
+        ndof = {JNT_FIXED: 0, JNT_REVOLUTE: 1, JNT_PRISMATIC: 1, JNT_FREE: 6}[jtype]
+        for k in range(ndof):
+            d = dict(limited=0, ctrl_mode=CTRL_NONE, range=(0.0, 0.0), armature=0.0, damping=0.0, kp=0.0, kv=0.0,
+                     frc_range=(-1e30, 1e30), solref=DEFAULT_SOLREF, solimp=DEFAULT_SOLIMP)
+            if jtype != JNT_FREE:
+                d.update(dof_kw)
+            self.dofs.append(d)
+            self.dof_names.append(joint_name or name if ndof == 1 else f"{name}/{k}")
+        return idx
+
+    def body_index(self, name: str) -> int:
+        for i, b in enumerate(self.bodies):
+            if b["name"] == name:
+                return i
+        raise KeyError(name)
+
+    def dof_index(self, joint_name: str) -> int:
+        return self.dof_names.index(joint_name)
+
+    # -- geoms ------------------------------------------------------------------------------
+    def add_geom(self, body: str | int, gtype: int, size=(0, 0, 0), pos=(0, 0, 0), quat=(1, 0, 0, 0),
+                 friction=1.0, contype=1, conaffinity=1, solref=DEFAULT_SOLREF, solimp=DEFAULT_SOLIMP) -> int:
+        bidx = body if isinstance(body, int) else self.body_index(body)
+        self.geoms.append(dict(body=bidx, type=gtype, size=tuple(size), pos=tuple(pos), quat=quat_normalize(quat),
+                               friction=float(friction), contype=contype, conaffinity=conaffinity,
+                               solref=tuple(solref), solimp=tuple(solimp)))
+        return len(self.geoms) - 1
+
+    # -- emit -------------------------------------------------------------------------------
+    def build(self) -> MirSceneSpec:
+        if len(self.bodies) > MIR_MAX_BODY or len(self.dofs) > MIR_MAX_DOF or len(self.geoms) > MIR_MAX_GEOM:
+            raise ValueError("scene exceeds MIR_MAX_* capacity")
+        s = MirSceneSpec()
+        s.struct_size = C.sizeof(MirSceneSpec)
+        s.version = MIR_VERSION
+        s.nbody, s.ndof, s.ngeom = len(self.bodies), len(self.dofs), len(self.geoms)
+        o = self.opt
+        s.opt.dt = o["dt"]
+        s.opt.gravity[:] = o["gravity"]
+        for k in ("tolerance", "ls_tolerance", "iterations", "ls_iterations", "enable_collision", "enable_joint_limit",
+                  "enable_self_collision", "enable_adjacent_collision", "max_contacts", "implicit_damping"):
+            setattr(s.opt, k, o[k])
+        t = self.task
+        s.task.eef_body, s.task.obj_body = t["eef_body"], t["obj_body"]
+        s.task.n_grip = len(t["grip_dof"])
+        for i, g in enumerate(t["grip_dof"]):
+            s.task.grip_dof[i] = g
+        s.task.reward_z = t["reward_z"]
+        for i, b in enumerate(self.bodies):
+            sb = s.body[i]
+            sb.parent, sb.jtype, sb.mass = b["parent"], b["jtype"], b["mass"]
+            sb.pos[:], sb.quat[:], sb.axis[:] = b["pos"], b["quat"], b["axis"]
+            sb.ipos[:], sb.inertia[:] = b["ipos"], b["inertia"]
+        for i, d in enumerate(self.dofs):
+            sd = s.dof[i]
+            sd.limited, sd.ctrl_mode = d["limited"], d["ctrl_mode"]
+            sd.range[:] = d["range"]
+            sd.armature, sd.damping, sd.kp, sd.kv = d["armature"], d["damping"], d["kp"], d["kv"]
+            sd.frc_range[:] = d["frc_range"]
+            sd.solref[:], sd.solimp[:] = d["solref"], d["solimp"]
+        for i, g in enumerate(self.geoms):
+            sg = s.geom[i]
+            sg.body, sg.type, sg.contype, sg.conaffinity = g["body"], g["type"], g["contype"], g["conaffinity"]
+            sg.size[:], sg.pos[:], sg.quat[:] = g["size"], g["pos"], g["quat"]
+            sg.friction = g["friction"]
+            sg.solref[:], sg.solimp[:] = g["solref"], g["solimp"]
+        return s

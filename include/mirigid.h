@@ -1,0 +1,211 @@
+/*
+ * mirigid.h — C ABI of libmirigid.so, the MI355X-native batched rigid-body
+ * step backend that sits behind gym-genesis's env.step() hot path.
+ *
+ * The reference (huggingface/gym-genesis) has NO FFI for this path: every
+ * FLOP of env.step() runs inside the external `genesis-world` package through
+ * its Python object API.  The entry points below are therefore the C-level
+ * restatement of exactly those Genesis calls the reference makes on the path
+ * (file:line cited per function, paths relative to /root/reference):
+ *
+ *   gs.Scene(...) + add_entity + scene.build(n_envs=B)
+ *        gym_genesis/tasks/franka/cube_pick.py:34-68      -> mir_create
+ *   cube.set_pos / cube.set_quat / franka.set_qpos(zero_velocity=True)
+ *        gym_genesis/tasks/franka/cube_pick.py:96-102     -> mir_reset
+ *   franka.control_dofs_position(target, dofs_idx)
+ *        gym_genesis/tasks/franka/cube_pick.py:104-105,123-124 -> mir_set_pd_targets
+ *   scene.step()
+ *        gym_genesis/tasks/franka/cube_pick.py:107,125 ; gym_genesis/env.py:60 -> mir_step
+ *   step() = control + scene.step() + compute_reward() + get_obs() + (reward==1)
+ *        gym_genesis/tasks/franka/cube_pick.py:122-181 ; gym_genesis/env.py:61-69 -> mir_step_fused
+ *   link.get_pos / link.get_quat / entity.get_dofs_position / get_qpos
+ *        gym_genesis/tasks/franka/cube_pick.py:140-146    -> mir_get_links / mir_get_state
+ *
+ * Conventions
+ *   - All device buffers are caller-owned raw device pointers (torch
+ *     tensor.data_ptr()), row-major (B, D), float32 unless stated.  Nothing
+ *     is retained past the call.  Internal state is SoA (D, B) in HBM.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  No
+ *     entry point synchronises the device.
+ *   - Quaternions are wxyz (Genesis convention, cube_pick.py:94).
+ *   - Return 0 on success, negative MIR_E_* on error; text in mir_last_error().
+ *   - The scene description (MirSceneSpec) is plain host data in doubles.
+ */
+#ifndef MIRIGID_H
+#define MIRIGID_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIR_VERSION 1
+
+/* capacity limits of the spec (and of the kernels' LDS arenas) */
+#define MIR_MAX_BODY 16 /* including world = body 0 */
+#define MIR_MAX_DOF 16  /* nv */
+#define MIR_MAX_Q 18    /* nq */
+#define MIR_MAX_GEOM 24
+#define MIR_MAX_PAIR 64    /* candidate geom pairs after static filtering */
+#define MIR_MAX_CONTACT 20 /* contacts kept per env per step (plane-box <= 4, box-box <= 8 per pair) */
+#define MIR_MAX_GRIP 4
+
+/* error codes */
+#define MIR_OK 0
+#define MIR_E_INVALID (-1) /* bad argument / spec */
+#define MIR_E_CAPACITY (-2) /* spec exceeds MIR_MAX_* */
+#define MIR_E_HIP (-3)      /* HIP runtime error */
+#define MIR_E_NODEVICE (-4) /* no gfx950 device visible */
+
+/* joint types (one joint per body, anchored at the body origin) */
+#define MIR_JNT_FIXED 0
+#define MIR_JNT_REVOLUTE 1
+#define MIR_JNT_PRISMATIC 2
+#define MIR_JNT_FREE 3 /* qpos = pos3 + quat4(wxyz); qvel = world lin3 + world ang3 */
+
+/* geom types */
+#define MIR_GEOM_PLANE 0 /* z = 0 plane of its body frame, normal +z */
+#define MIR_GEOM_BOX 1   /* size = half extents */
+
+/* dof control modes */
+#define MIR_CTRL_NONE 0
+#define MIR_CTRL_POSITION 1 /* tau = kp (target - q) - kv qd, clamped (control_dofs_position) */
+
+typedef struct MirBodySpec {
+  int32_t parent; /* index < own index; 0 = world */
+  int32_t jtype;  /* MIR_JNT_* */
+  double pos[3];  /* frame in parent (FREE: initial world pose) */
+  double quat[4]; /* wxyz */
+  double axis[3]; /* joint axis in body frame (REVOLUTE / PRISMATIC) */
+  double mass;
+  double ipos[3];    /* COM in body frame */
+  double inertia[6]; /* about COM, body axes: xx yy zz xy xz yz */
+} MirBodySpec;
+
+typedef struct MirDofSpec {
+  int32_t limited;   /* joint range active */
+  int32_t ctrl_mode; /* MIR_CTRL_* */
+  double range[2];
+  double armature;
+  double damping;
+  double kp, kv;
+  double frc_range[2];
+  double solref[2]; /* timeconst, dampratio (limit constraint) */
+  double solimp[5]; /* dmin dmax width mid power */
+} MirDofSpec;
+
+typedef struct MirGeomSpec {
+  int32_t body;
+  int32_t type; /* MIR_GEOM_* */
+  int32_t contype;
+  int32_t conaffinity;
+  double size[3];
+  double pos[3];  /* in body frame */
+  double quat[4]; /* wxyz */
+  double friction;
+  double solref[2];
+  double solimp[5];
+} MirGeomSpec;
+
+typedef struct MirOptions {
+  double dt;         /* cube_pick.py:45 -> 0.01 */
+  double gravity[3]; /* (0,0,-9.81) */
+  double tolerance;  /* Newton scaled-improvement / gradient tolerance */
+  double ls_tolerance;
+  int32_t iterations; /* max Newton iterations */
+  int32_t ls_iterations;
+  int32_t enable_collision;
+  int32_t enable_joint_limit;
+  int32_t enable_self_collision;     /* geoms of one articulated entity may collide */
+  int32_t enable_adjacent_collision; /* parent/child link geoms may collide */
+  int32_t max_contacts;              /* <= MIR_MAX_CONTACT */
+  int32_t implicit_damping;          /* M += dt (damping + kv) on the diagonal */
+} MirOptions;
+
+/* what the fused step extracts (reference get_obs / compute_reward) */
+typedef struct MirTaskSpec {
+  int32_t eef_body;               /* franka.get_link("hand"), cube_pick.py:68 */
+  int32_t obj_body;               /* cube */
+  int32_t n_grip;                 /* gripper dofs appended to agent_pos */
+  int32_t grip_dof[MIR_MAX_GRIP]; /* dof indices (cube_pick.py:142 -> 7,8) */
+  double reward_z;                /* reward = obj_z > reward_z (cube_pick.py:134 -> 0.1) */
+} MirTaskSpec;
+
+typedef struct MirSceneSpec {
+  int32_t struct_size; /* = sizeof(MirSceneSpec), ABI check */
+  int32_t version;     /* = MIR_VERSION */
+  int32_t nbody, ndof, ngeom, _pad;
+  MirOptions opt;
+  MirTaskSpec task;
+  MirBodySpec body[MIR_MAX_BODY];
+  MirDofSpec dof[MIR_MAX_DOF]; /* in body order: 1 per REVOLUTE/PRISMATIC, 6 per FREE */
+  MirGeomSpec geom[MIR_MAX_GEOM];
+} MirSceneSpec;
+
+typedef struct MirScene* MirHandle;
+
+/* sizes of the batched state vectors for a created scene */
+typedef struct MirDims {
+  int32_t num_envs, nbody, nq, nv, ngeom, npair, agent_dim, env_dim;
+} MirDims;
+
+int mir_version(void);
+int mir_spec_sizeof(void);
+const char* mir_last_error(void);
+
+/* gs.Scene + add_entity + scene.build(n_envs): compile spec, allocate SoA state
+ * for num_envs on device_id, set state to the spec's initial pose. */
+int mir_create(const MirSceneSpec* spec, int32_t num_envs, int32_t device_id, MirHandle* out);
+int mir_destroy(MirHandle h);
+int mir_get_dims(MirHandle h, MirDims* out);
+
+/* derived model constants, for parity tests (host doubles; arrays sized nv / nbody) */
+int mir_get_model_consts(MirHandle h, double* dof_invweight0, double* body_invweight0, double* meaninertia);
+
+/* cube.set_pos/set_quat + franka.set_qpos(zero_velocity=True) (+ PD targets = qpos).
+ * obj_pos (B,3) / obj_quat (B,4): world pose of task.obj_body; arm_qpos (B,n_arm):
+ * values for every non-FREE joint in body order.  All velocities and the solver
+ * warm start are zeroed.  env_mask (B) u8 nullable: reset only envs with mask!=0. */
+int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const float* arm_qpos,
+              const uint8_t* env_mask, void* stream);
+
+/* control_dofs_position over all position-controlled dofs, in dof order: tgt (B,nu) */
+int mir_set_pd_targets(MirHandle h, const float* tgt, void* stream);
+
+/* scene.step() x n_steps */
+int mir_step(MirHandle h, int32_t n_steps, void* stream);
+
+/* FrankaCubePickBatch.step + GenesisEnv.step in one launch:
+ * targets <- action (B,nu); one physics step; agent_pos (B,7+n_grip) =
+ * [eef_pos3, eef_quat4, grip_q]; env_state (B,11) = [obj_pos3, obj_quat4,
+ * eef-obj 3, |eef-obj| 1]; reward (B) f32 = obj_z > reward_z; terminated (B) u8 =
+ * reward == 1.  action may be NULL (keep current targets). */
+int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward,
+                   uint8_t* terminated, void* stream);
+
+/* get_obs() without stepping */
+int mir_get_obs(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated,
+                void* stream);
+
+/* full simulation state; any pointer may be NULL.  qpos (B,nq) qvel (B,nv)
+ * target (B,nu) warmstart (B,nv) */
+int mir_get_state(MirHandle h, float* qpos, float* qvel, float* target, float* warmstart, void* stream);
+int mir_set_state(MirHandle h, const float* qpos, const float* qvel, const float* target,
+                  const float* warmstart, void* stream);
+
+/* link.get_pos / get_quat for all bodies: pos (B,nbody,3) quat (B,nbody,4) */
+int mir_get_links(MirHandle h, float* pos, float* quat, void* stream);
+
+/* per-env diagnostics of the last step: ncon (B) i32, nefc (B) i32, niter (B) i32; nullable */
+int mir_get_diag(MirHandle h, int32_t* ncon, int32_t* nefc, int32_t* niter, void* stream);
+
+/* stage outputs of one forward-dynamics evaluation at the current state (no
+ * integration), for per-stage parity tests: M (B,nv,nv), qfrc_bias (B,nv),
+ * qacc_smooth (B,nv), qacc (B,nv); nullable */
+int mir_forward(MirHandle h, float* M, float* qfrc_bias, float* qacc_smooth, float* qacc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRIGID_H */

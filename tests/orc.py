@@ -1,0 +1,140 @@
+"""ctypes driver for the CPU oracle (oracle/liborc64.so / liborc32.so).
+
+Lives under tests/ on purpose: the oracle is test infrastructure and the
+product package never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+(F_QPOS, F_QVEL, F_TARGET, F_QACC_WS, F_XPOS, F_XQUAT, F_XIPOS, F_M, F_MT, F_QFRC_BIAS, F_QFRC_SMOOTH,
+ F_QACC_SMOOTH, F_QACC, F_CPOS, F_CDIST, F_CFRAME, F_J, F_AREF, F_EFCD, F_EFCFORCE, F_DOF_INVWEIGHT0,
+ F_BODY_INVWEIGHT0, F_MEANINERTIA, F_QFRC_ACT, F_QFRC_PASSIVE, F_EFCPOS) = range(26)
+
+
+def build_oracle() -> None:
+    """Compile the oracle with its committed Makefile if the .so files are missing/stale."""
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+
+
+_libs = {}
+
+
+def load(f32: bool = False):
+    key = "32" if f32 else "64"
+    if key not in _libs:
+        path = os.path.join(ORACLE_DIR, f"liborc{key}.so")
+        src = os.path.join(ORACLE_DIR, "orc_rigid.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            build_oracle()
+        lib = C.CDLL(path)
+        lib.orc_read.restype = C.c_int
+        lib.orc_compile.restype = C.c_int
+        _libs[key] = lib
+    return _libs[key]
+
+
+class Oracle:
+    """One compiled model + a batch of per-env data blocks."""
+
+    def __init__(self, spec, num_envs: int = 1, f32: bool = False):
+        self.lib = load(f32)
+        self.spec = spec
+        self.B = num_envs
+        self.model = C.create_string_buffer(self.lib.orc_sizeof_model())
+        rc = self.lib.orc_compile(C.byref(spec), self.model)
+        if rc != 0:
+            raise RuntimeError(f"orc_compile failed: {rc}")
+        self.dsize = self.lib.orc_sizeof_data()
+        self.data = C.create_string_buffer(self.dsize * num_envs)
+        self._dptr = C.addressof(self.data)
+        for e in range(num_envs):
+            self.lib.orc_init_data(self.model, C.c_void_p(self._dptr + e * self.dsize))
+        # dims via a first read
+        self.nq = len(self.read(F_QPOS))
+        self.nv = len(self.read(F_QVEL))
+        self.nbody = spec.nbody
+        self.n_grip = spec.task.n_grip
+        self.nu = sum(1 for i in range(spec.ndof) if spec.dof[i].ctrl_mode == 1)
+        self.u_dofs = [i for i in range(spec.ndof) if spec.dof[i].ctrl_mode == 1]
+
+    def d(self, e: int = 0):
+        return C.c_void_p(self._dptr + e * self.dsize)
+
+    # ---- single-env accessors ------------------------------------------------------------
+    def read(self, field: int, e: int = 0) -> np.ndarray:
+        out = np.zeros(4096, dtype=np.float64)
+        n = self.lib.orc_read(self.model, self.d(e), field, out.ctypes.data_as(C.c_void_p))
+        if n < 0:
+            raise KeyError(field)
+        return out[:n].copy()
+
+    def write(self, field: int, val, e: int = 0) -> None:
+        v = np.ascontiguousarray(val, dtype=np.float64)
+        self.lib.orc_write(self.model, self.d(e), field, v.ctypes.data_as(C.c_void_p))
+
+    def counts(self, e: int = 0):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self.lib.orc_counts(self.d(e), C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def fk(self, e: int = 0):
+        self.lib.orc_fk(self.model, self.d(e))
+
+    def forward(self, e: int = 0):
+        self.lib.orc_forward(self.model, self.d(e))
+
+    def step(self, e: Optional[int] = None):
+        for i in (range(self.B) if e is None else [e]):
+            self.lib.orc_step(self.model, self.d(i))
+
+    def aba(self, e: int = 0) -> np.ndarray:
+        out = np.zeros(self.nv)
+        self.lib.orc_aba(self.model, self.d(e), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    # ---- batched, mirroring the C ABI ----------------------------------------------------
+    def reset(self, obj_pos, obj_quat, arm_qpos):
+        obj_pos = np.ascontiguousarray(obj_pos, dtype=np.float64).reshape(self.B, 3)
+        obj_quat = np.ascontiguousarray(obj_quat, dtype=np.float64).reshape(self.B, 4)
+        arm_qpos = np.ascontiguousarray(arm_qpos, dtype=np.float64).reshape(self.B, -1)
+        for e in range(self.B):
+            self.lib.orc_reset(self.model, self.d(e), obj_pos[e].ctypes.data_as(C.c_void_p),
+                               obj_quat[e].ctypes.data_as(C.c_void_p), arm_qpos[e].ctypes.data_as(C.c_void_p))
+
+    def set_targets(self, tgt):
+        tgt = np.ascontiguousarray(tgt, dtype=np.float64).reshape(self.B, -1)
+        for e in range(self.B):
+            self.lib.orc_set_targets(self.model, self.d(e), tgt[e].ctypes.data_as(C.c_void_p))
+
+    def step_batch(self, action=None, nthreads: int = 0):
+        a = None
+        if action is not None:
+            a = np.ascontiguousarray(action, dtype=np.float32)
+        self.lib.orc_step_batch(self.model, self.data, C.c_int(self.B),
+                                a.ctypes.data_as(C.c_void_p) if a is not None else None, C.c_int(nthreads))
+
+    def get_obs(self):
+        ad = 7 + self.n_grip
+        agent = np.zeros((self.B, ad))
+        env = np.zeros((self.B, 11))
+        rew = np.zeros(self.B)
+        term = np.zeros(self.B, dtype=np.uint8)
+        for e in range(self.B):
+            self.lib.orc_get_obs(self.model, self.d(e), agent[e].ctypes.data_as(C.c_void_p),
+                                 env[e].ctypes.data_as(C.c_void_p), rew[e:e + 1].ctypes.data_as(C.c_void_p),
+                                 term[e:e + 1].ctypes.data_as(C.c_void_p))
+        return agent, env, rew, term
+
+    def state(self):
+        q = np.stack([self.read(F_QPOS, e) for e in range(self.B)])
+        v = np.stack([self.read(F_QVEL, e) for e in range(self.B)])
+        return q, v
