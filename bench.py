@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the CubePick-v0 hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1] / BASELINE.md §3): GenesisEnv(task="cube_pick", robot="franka",
+num_envs=4096 per GPU, enable_pixels=False); reset(seed=0); a fresh a_t ~ U(-1,1)^(B x 9) float32
+per step (generated on the device BEFORE the timed region: inputs are resident in HBM); one
+fused hot-path launch per step (control + scene.step + reward + observations); reset-all every
+200 steps (TimeLimit parity).  Env axis sharded across ranks (weak scaling: 4096 envs per GPU);
+with N > 1 every step's packed observation rows are all-gathered over RCCL, overlapped with the
+next step's physics.
+
+One JSON line on rank 0: value = total env-steps / wall time (max over ranks) of exactly K steps.
+Extra objects: "roofline" (HBM; algorithmic 489 B per env-step) and
+"cpu_baseline" (the float32 CPU port of the oracle, OpenMP over all host cores; rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "gym-genesis_amd")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+ENVS_PER_GPU = 4096
+EPISODE_STEPS = 200
+ALGO_BYTES_PER_ENV_STEP = 489.0  # 55 f32 read + 67 f32 + 1 B written
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ROW_STRIDE = 24
+
+
+def cpu_baseline(budget_s: float = 12.0):
+    """Time the float32 CPU port of the oracle (oracle/liborc32.so) on all host cores, same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    from gym_genesis.backend import models
+
+    cores = os.cpu_count() or 1
+    B = ENVS_PER_GPU
+    spec = models.franka_cube_pick_scene().build()
+    o = orc.Oracle(spec, B, f32=True)
+    rng = np.random.RandomState(0)
+    pos = np.stack([rng.uniform(0.45, 0.80, B), rng.uniform(-0.25, 0.25, B), np.full(B, 0.02)], 1).astype(np.float32)
+    o.reset(pos, np.tile(np.array([0, 0, 0, 1.0], np.float32), (B, 1)), np.tile(np.array(models.FRANKA_HOME, np.float32), (B, 1)))
+    acts = np.random.default_rng(1234).uniform(-1, 1, (64, B, 9)).astype(np.float32)
+    for k in range(3):  # thread-pool / page-fault warm-up
+        o.step_batch(acts[k], cores)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and steps < 2000:
+        o.step_batch(acts[steps % 64], cores)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": steps * B / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps x {B} envs, same random-action workload, float32 C port of the oracle, OpenMP over envs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL observation gather")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gym_genesis.env import GenesisEnv
+    from gym_genesis.sharding import gather_rows  # noqa: F401  (collective lives there)
+
+    B = args.envs_per_gpu
+    K, W = args.steps, args.warmup
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B * world, enable_pixels=False, shard=(rank, world))
+    task = env._env
+    env.reset(seed=0)
+
+    # inputs resident in HBM before the timed region: one fresh action batch per step
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_act = min(W + K, 4096)
+    actions = torch.empty((n_act, B, 9), dtype=torch.float32, device=dev)
+    for i in range(0, n_act, 256):
+        actions[i:i + 256].uniform_(-1.0, 1.0, generator=gen)
+
+    gather = world > 1 and not args.no_gather
+    rows = [torch.zeros((B, ROW_STRIDE), dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.empty((B * world, ROW_STRIDE), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
+    pending = [None, None]
+    launches = 0
+
+    def one_step(t: int):
+        nonlocal launches
+        a = actions[t % n_act]
+        if gather:
+            s = t & 1
+            if pending[s] is not None:
+                pending[s].wait()      # stream-level: the buffer's previous gather has drained
+            task._mir.step_packed(a, rows[s])
+            pending[s] = dist.all_gather_into_tensor(gathered[s], rows[s], async_op=True)  # overlaps the next step
+        else:
+            task.step_raw(a)
+        launches += 1
+        if (t + 1) % EPISODE_STEPS == 0:  # reset-all, as gymnasium's TimeLimit(200) makes the README loop do
+            task.reset()
+            launches += 1
+
+    def sync_all():
+        for p in pending:
+            if p is not None:
+                p.wait()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for t in range(W):
+        one_step(t)
+    sync_all()
+    launches = 0
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for t in range(W, W + K):
+        one_step(t)
+    ev1.record()
+    sync_all()
+    wall = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall_max = float(wall_t.item())
+
+    # end-to-end env.step() (with the API's per-step D->H `terminated` copy), reported beside the hot path
+    api_steps = 200
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for t in range(api_steps):
+        env.step(actions[t % n_act])
+    torch.cuda.synchronize(dev)
+    api_rate = api_steps * B * world / (time.perf_counter() - t1)
+
+    if rank == 0:
+        value = K * B * world / wall_max
+        launch_us = gpu_ms * 1e3 / max(launches, 1)  # HIP events on the launching stream, per step-kernel launch
+        achieved = ALGO_BYTES_PER_ENV_STEP * B / (launch_us * 1e-6) / 1e9
+        out = {
+            "metric": "env-steps/sec (num_envs x sim-steps/sec), CubePick-v0 @ num_envs=4096",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": wall_max * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "CubePick-v0 robot=franka state-only obs, U(-1,1) joint-target actions, reset-all every 200 steps",
+                       "num_envs_per_gpu": B, "global_num_envs": B * world, "parallelism": f"env-axis shard x{world}",
+                       "obs_gather": "rccl all_gather per step, overlapped" if gather else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "mir_step_kernel", "kernel_us": launch_us,
+                         "note": "489 algorithmic B/env-step x 4096 envs per launch; the path is latency/occupancy-bound, not HBM-bound (SURVEY.md 8d)"},
+            "env_step_api_rate": api_rate,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

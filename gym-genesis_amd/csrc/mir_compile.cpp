@@ -1,0 +1,339 @@
+// mir_compile.cpp — host-side compile of a MirSceneSpec into the float32 DevModel.
+//
+// Restates what the reference obtains from scene.build()
+// (/root/reference/gym_genesis/tasks/franka/cube_pick.py:65): topology tables, the
+// static collision-pair filter and the constraint-regularisation constants
+// (inverse weights at the reference pose, mean inertia) that the soft-constraint
+// model needs.  Host double precision, run once.
+//
+// The joint-space inertia at qpos0 is assembled from body Jacobians
+// (M = sum_b m Jv^T Jv + Jw^T I Jw), not by the CRB recursion the kernels use.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "mir_model.h"
+
+namespace {
+
+struct V3 {
+  double x, y, z;
+};
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+struct Q4 {
+  double w, x, y, z;
+};
+inline Q4 qmul(Q4 a, Q4 b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+inline V3 qrot(Q4 q, V3 v) {
+  V3 u{q.x, q.y, q.z};
+  V3 t = 2.0 * cross(u, v);
+  return v + q.w * t + cross(u, t);
+}
+struct M3 {
+  double m[3][3];
+};
+inline M3 q2m(Q4 q) {
+  M3 R;
+  V3 c0 = qrot(q, {1, 0, 0}), c1 = qrot(q, {0, 1, 0}), c2 = qrot(q, {0, 0, 1});
+  R.m[0][0] = c0.x; R.m[1][0] = c0.y; R.m[2][0] = c0.z;
+  R.m[0][1] = c1.x; R.m[1][1] = c1.y; R.m[2][1] = c1.z;
+  R.m[0][2] = c2.x; R.m[1][2] = c2.y; R.m[2][2] = c2.z;
+  return R;
+}
+
+int fail(char* err, int code, const char* msg) {
+  if (err) snprintf(err, 255, "%s", msg);
+  return code;
+}
+
+// nearest ancestor-or-self that carries a joint (welded chains collapse onto it); 0 = world-welded
+int moving_link(const DevModel& m, int b) {
+  while (b > 0 && m.b_jtype[b] == MIR_JNT_FIXED) b = m.b_parent[b];
+  return b;
+}
+
+}  // namespace
+
+int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, char* err) {
+  if (!sp || !out) return fail(err, MIR_E_INVALID, "null spec");
+  if (sp->struct_size != (int)sizeof(MirSceneSpec) || sp->version != MIR_VERSION)
+    return fail(err, MIR_E_INVALID, "MirSceneSpec size/version mismatch (ABI)");
+  if (sp->nbody < 1 || sp->nbody > MIR_MAX_BODY || sp->ndof > MIR_MAX_DOF || sp->ngeom > MIR_MAX_GEOM || sp->ndof < 0 ||
+      sp->ngeom < 0)
+    return fail(err, MIR_E_CAPACITY, "scene exceeds MIR_MAX_BODY/DOF/GEOM");
+  // The device model is float32, so the scene that is actually simulated is the float32-rounded
+  // one: derive every constant (inverse weights, mean inertia) from those same rounded values.
+  MirSceneSpec rounded = *sp;
+  {
+    auto r32 = [](double& v) { v = (double)(float)v; };
+    for (int b = 0; b < rounded.nbody; b++) {
+      MirBodySpec& s = rounded.body[b];
+      for (double& v : s.pos) r32(v);
+      for (double& v : s.quat) r32(v);
+      for (double& v : s.axis) r32(v);
+      for (double& v : s.ipos) r32(v);
+      for (double& v : s.inertia) r32(v);
+      r32(s.mass);
+    }
+    for (int i = 0; i < rounded.ndof; i++) {
+      MirDofSpec& s = rounded.dof[i];
+      r32(s.armature); r32(s.damping); r32(s.kp); r32(s.kv);
+      for (double& v : s.range) r32(v);
+      for (double& v : s.solref) r32(v);
+      for (double& v : s.solimp) r32(v);
+    }
+    r32(rounded.opt.dt);
+    for (double& v : rounded.opt.gravity) r32(v);
+  }
+  sp = &rounded;
+  DevModel& m = *out;
+  memset(&m, 0, sizeof m);
+  const int nb = sp->nbody;
+  m.nbody = nb;
+  m.ngeom = sp->ngeom;
+  m.dt = (float)sp->opt.dt;
+  m.gx = (float)sp->opt.gravity[0]; m.gy = (float)sp->opt.gravity[1]; m.gz = (float)sp->opt.gravity[2];
+  m.tolerance = (float)sp->opt.tolerance;
+  m.ls_tolerance = (float)sp->opt.ls_tolerance;
+  m.iterations = sp->opt.iterations;
+  m.ls_iterations = sp->opt.ls_iterations;
+  m.enable_collision = sp->opt.enable_collision;
+  m.enable_joint_limit = sp->opt.enable_joint_limit;
+  m.max_contacts = sp->opt.max_contacts;
+  if (m.max_contacts > MIR_MAX_CONTACT || m.max_contacts < 0) return fail(err, MIR_E_CAPACITY, "max_contacts > MIR_MAX_CONTACT");
+
+  // ---- topology --------------------------------------------------------------------------
+  int nv = 0, nq = 0, narm = 0;
+  for (int b = 0; b < nb; b++) {
+    const MirBodySpec& s = sp->body[b];
+    int jt = b == 0 ? MIR_JNT_FIXED : s.jtype;
+    if (b > 0 && (s.parent < 0 || s.parent >= b)) return fail(err, MIR_E_INVALID, "body parent must precede the body");
+    if (jt == MIR_JNT_FREE && s.parent != 0) return fail(err, MIR_E_INVALID, "free joint must hang off the world");
+    m.b_parent[b] = b == 0 ? -1 : s.parent;
+    m.b_jtype[b] = jt;
+    m.b_dofadr[b] = nv;
+    m.b_qadr[b] = nq;
+    m.b_root[b] = b == 0 ? 0 : (s.parent == 0 ? b : m.b_root[s.parent]);
+    int nd = jt == MIR_JNT_FREE ? 6 : (jt == MIR_JNT_FIXED ? 0 : 1);
+    m.b_static[b] = b == 0 ? 1 : (nd == 0 && m.b_static[s.parent]);
+    for (int k = 0; k < 3; k++) { m.b_pos[b][k] = (float)s.pos[k]; m.b_axis[b][k] = (float)s.axis[k]; m.b_ipos[b][k] = (float)s.ipos[k]; }
+    for (int k = 0; k < 4; k++) m.b_quat[b][k] = (float)s.quat[k];
+    for (int k = 0; k < 6; k++) m.b_inertia[b][k] = (float)s.inertia[k];
+    m.b_mass[b] = (float)s.mass;
+    uint32_t inherited = (b > 0 && s.parent > 0) ? m.b_dofmask[s.parent] : 0u;
+    if (nv + nd > MIR_MAX_DOF) return fail(err, MIR_E_CAPACITY, "too many dofs");
+    for (int k = 0; k < nd; k++) {
+      int i = nv + k;
+      m.d_body[i] = b;
+      m.d_qadr[i] = nq + k;
+      m.d_armidx[i] = -1;
+      if (jt == MIR_JNT_FREE) {
+        m.d_kind[i] = k < 3 ? 2 : 3;
+        m.d_axis_k[i] = k % 3;
+        // velocity "before" dof i: ancestors + (for rotations) the three translations only
+        m.d_premask[i] = inherited | (k < 3 ? ((1u << k) - 1u) << nv : 7u << nv);
+      } else {
+        m.d_kind[i] = jt == MIR_JNT_REVOLUTE ? 0 : 1;
+        m.d_premask[i] = inherited;
+        m.d_armidx[i] = narm++;
+      }
+      m.d_ancmask[i] = inherited | (((1u << (k + 1)) - 1u) << nv);
+    }
+    m.b_dofmask[b] = inherited | (nd ? (((1u << nd) - 1u) << nv) : 0u);
+    nv += nd;
+    nq += jt == MIR_JNT_FREE ? 7 : nd;
+  }
+  if (nv != sp->ndof) return fail(err, MIR_E_INVALID, "ndof does not match the joints");
+  if (nq > MIR_MAX_Q) return fail(err, MIR_E_CAPACITY, "nq > MIR_MAX_Q");
+  m.nv = nv; m.nq = nq; m.n_arm_q = narm;
+  m.qstride = (MIR_MAX_Q + 3) & ~3;
+  for (int b = 0; b < nb; b++) {
+    uint32_t sub = 1u << b;
+    for (int c = b + 1; c < nb; c++) {
+      int a = m.b_parent[c];
+      while (a > b) a = m.b_parent[a];
+      if (a == b && b > 0) sub |= 1u << c;
+    }
+    m.b_submask[b] = sub;
+  }
+
+  // ---- dof parameters -------------------------------------------------------------------
+  int nu = 0;
+  for (int i = 0; i < nv; i++) {
+    const MirDofSpec& s = sp->dof[i];
+    m.d_limited[i] = s.limited && m.d_kind[i] < 2;
+    m.d_ctrl[i] = s.ctrl_mode;
+    m.d_uadr[i] = s.ctrl_mode == MIR_CTRL_POSITION ? nu++ : -1;
+    m.d_lo[i] = (float)s.range[0]; m.d_hi[i] = (float)s.range[1];
+    m.d_damping[i] = (float)s.damping; m.d_kp[i] = (float)s.kp; m.d_kv[i] = (float)s.kv;
+    m.d_frclo[i] = (float)fmax(s.frc_range[0], -3.0e38); m.d_frchi[i] = (float)fmin(s.frc_range[1], 3.0e38);
+    m.d_armature[i] = (float)s.armature;
+    double add = s.armature;
+    if (sp->opt.implicit_damping) add += sp->opt.dt * (s.damping + (s.ctrl_mode == MIR_CTRL_POSITION ? s.kv : 0.0));
+    m.d_mdiag[i] = (float)add;
+    double dmax = fmin(fmax(s.solimp[1], 1e-4), 0.9999);
+    double tc = fmax(s.solref[0], 2 * sp->opt.dt), dr = s.solref[1];
+    m.d_k[i] = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr));
+    m.d_b[i] = (float)(2.0 / (dmax * tc));
+    for (int k = 0; k < 5; k++) m.d_solimp[i][k] = (float)s.solimp[k];
+  }
+  m.nu = nu;
+
+  // ---- task -----------------------------------------------------------------------------
+  m.eef_body = sp->task.eef_body; m.obj_body = sp->task.obj_body; m.n_grip = sp->task.n_grip;
+  if (m.eef_body < 0 || m.eef_body >= nb || m.obj_body < 0 || m.obj_body >= nb || m.n_grip < 0 || m.n_grip > MIR_MAX_GRIP)
+    return fail(err, MIR_E_INVALID, "task body / gripper indices out of range");
+  m.obj_qadr = m.b_jtype[m.obj_body] == MIR_JNT_FREE ? m.b_qadr[m.obj_body] : -1;
+  for (int k = 0; k < m.n_grip; k++) {
+    int d = sp->task.grip_dof[k];
+    if (d < 0 || d >= nv) return fail(err, MIR_E_INVALID, "grip dof out of range");
+    m.grip_qadr[k] = m.d_qadr[d];
+  }
+  m.reward_z = (float)sp->task.reward_z;
+
+  // ---- geoms + static pair filter ---------------------------------------------------------
+  for (int g = 0; g < sp->ngeom; g++) {
+    const MirGeomSpec& s = sp->geom[g];
+    if (s.body < 0 || s.body >= nb) return fail(err, MIR_E_INVALID, "geom body out of range");
+    if (s.type != MIR_GEOM_PLANE && s.type != MIR_GEOM_BOX) return fail(err, MIR_E_INVALID, "unsupported geom type");
+    m.g_body[g] = s.body; m.g_type[g] = s.type;
+    for (int k = 0; k < 3; k++) { m.g_size[g][k] = (float)s.size[k]; m.g_pos[g][k] = (float)s.pos[k]; }
+    for (int k = 0; k < 4; k++) m.g_quat[g][k] = (float)s.quat[k];
+    m.g_friction[g] = (float)s.friction;
+    for (int k = 0; k < 2; k++) m.g_solref[g][k] = (float)s.solref[k];
+    for (int k = 0; k < 5; k++) m.g_solimp[g][k] = (float)s.solimp[k];
+  }
+  int np = 0;
+  for (int ga = 0; ga < sp->ngeom; ga++)
+    for (int gb = ga + 1; gb < sp->ngeom; gb++) {
+      int a = ga, b = gb;
+      if (m.g_type[b] == MIR_GEOM_PLANE) { a = gb; b = ga; }
+      if (m.g_type[b] == MIR_GEOM_PLANE) continue;
+      int ba = m.g_body[a], bb = m.g_body[b];
+      if (ba == bb || (m.b_static[ba] && m.b_static[bb])) continue;
+      const MirGeomSpec &sa = sp->geom[a], &sb = sp->geom[b];
+      if (!((sa.contype & sb.conaffinity) || (sb.contype & sa.conaffinity))) continue;
+      if (!sp->opt.enable_adjacent_collision) {
+        int la = moving_link(m, ba), lb = moving_link(m, bb);
+        if (la == lb) continue;
+        int pa = la > 0 ? moving_link(m, m.b_parent[la]) : -1;
+        int pb = lb > 0 ? moving_link(m, m.b_parent[lb]) : -1;
+        if ((pa == lb && lb > 0) || (pb == la && la > 0)) continue;
+      }
+      if (!sp->opt.enable_self_collision && ba > 0 && bb > 0 && m.b_root[ba] == m.b_root[bb]) continue;
+      if (np >= MIR_MAX_PAIR) return fail(err, MIR_E_CAPACITY, "too many candidate collision pairs");
+      m.p_g1[np] = a; m.p_g2[np] = b; np++;
+    }
+  m.npair = np;
+
+  // ---- constants at qpos0: M from body Jacobians, inverse weights ----------------------------
+  std::vector<Q4> xq(nb);
+  std::vector<V3> xp(nb), xc(nb);
+  xq[0] = {1, 0, 0, 0}; xp[0] = {0, 0, 0}; xc[0] = {0, 0, 0};
+  for (int b = 1; b < nb; b++) {
+    const MirBodySpec& s = sp->body[b];
+    int p = s.parent;
+    Q4 ql{s.quat[0], s.quat[1], s.quat[2], s.quat[3]};
+    V3 pl{s.pos[0], s.pos[1], s.pos[2]};
+    if (s.jtype == MIR_JNT_FREE) { xq[b] = ql; xp[b] = pl; }  // qpos0 = spec pose, joint value 0 elsewhere
+    else { xq[b] = qmul(xq[p], ql); xp[b] = xp[p] + qrot(xq[p], pl); }
+    xc[b] = xp[b] + qrot(xq[b], {s.ipos[0], s.ipos[1], s.ipos[2]});
+  }
+  // per-dof world axis / anchor
+  std::vector<V3> ax(nv), an(nv);
+  for (int i = 0; i < nv; i++) {
+    int b = m.d_body[i];
+    const MirBodySpec& s = sp->body[b];
+    if (m.d_kind[i] < 2) ax[i] = qrot(xq[b], {s.axis[0], s.axis[1], s.axis[2]});
+    else { V3 e{0, 0, 0}; (&e.x)[m.d_axis_k[i]] = 1; ax[i] = e; }
+    an[i] = xp[b];
+  }
+  auto jac = [&](int b, V3 pt, int i, V3& jv, V3& jw) {  // column i of the Jacobian of point pt on body b
+    jv = {0, 0, 0}; jw = {0, 0, 0};
+    if (!(m.b_dofmask[b] >> i & 1u)) return;
+    if (m.d_kind[i] == 0 || m.d_kind[i] == 3) { jw = ax[i]; jv = cross(ax[i], pt - an[i]); }
+    else jv = ax[i];
+  };
+  std::vector<double> M(nv * nv, 0.0);
+  for (int b = 1; b < nb; b++) {
+    const MirBodySpec& s = sp->body[b];
+    M3 R = q2m(xq[b]);
+    double Ib[3][3] = {{s.inertia[0], s.inertia[3], s.inertia[4]}, {s.inertia[3], s.inertia[1], s.inertia[5]}, {s.inertia[4], s.inertia[5], s.inertia[2]}};
+    double Iw[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        double t = 0;
+        for (int k = 0; k < 3; k++)
+          for (int l = 0; l < 3; l++) t += R.m[r][k] * Ib[k][l] * R.m[c][l];
+        Iw[r][c] = t;
+      }
+    for (int i = 0; i < nv; i++) {
+      V3 vi, wi;
+      jac(b, xc[b], i, vi, wi);
+      V3 Iwi{Iw[0][0] * wi.x + Iw[0][1] * wi.y + Iw[0][2] * wi.z, Iw[1][0] * wi.x + Iw[1][1] * wi.y + Iw[1][2] * wi.z,
+             Iw[2][0] * wi.x + Iw[2][1] * wi.y + Iw[2][2] * wi.z};
+      for (int j = 0; j < nv; j++) {
+        V3 vj, wj;
+        jac(b, xc[b], j, vj, wj);
+        M[i * nv + j] += s.mass * dot(vi, vj) + dot(Iwi, wj);
+      }
+    }
+  }
+  for (int i = 0; i < nv; i++) M[i * nv + i] += sp->dof[i].armature;
+  // invert by Gauss-Jordan (SPD, tiny)
+  std::vector<double> A(M), Inv(nv * nv, 0.0);
+  for (int i = 0; i < nv; i++) Inv[i * nv + i] = 1;
+  for (int c = 0; c < nv; c++) {
+    double p = A[c * nv + c];
+    if (!(p > 1e-12)) return fail(err, MIR_E_INVALID, "joint-space inertia at qpos0 is not positive definite");
+    for (int j = 0; j < nv; j++) { A[c * nv + j] /= p; Inv[c * nv + j] /= p; }
+    for (int r = 0; r < nv; r++)
+      if (r != c) {
+        double f = A[r * nv + c];
+        if (f != 0)
+          for (int j = 0; j < nv; j++) { A[r * nv + j] -= f * A[c * nv + j]; Inv[r * nv + j] -= f * Inv[c * nv + j]; }
+      }
+  }
+  double tr = 0;
+  for (int i = 0; i < nv; i++) tr += M[i * nv + i];
+  double meaninertia = nv ? tr / nv : 1.0;
+  HostConsts local;
+  HostConsts& H = hc ? *hc : local;
+  memset(&H, 0, sizeof H);
+  H.meaninertia = meaninertia;
+  for (int b = 1; b < nb; b++) {
+    int da = m.b_dofadr[b];
+    if (m.b_jtype[b] == MIR_JNT_FREE) {
+      double t = (Inv[da * nv + da] + Inv[(da + 1) * nv + da + 1] + Inv[(da + 2) * nv + da + 2]) / 3;
+      double r = (Inv[(da + 3) * nv + da + 3] + Inv[(da + 4) * nv + da + 4] + Inv[(da + 5) * nv + da + 5]) / 3;
+      for (int k = 0; k < 3; k++) { H.dof_invweight0[da + k] = t; H.dof_invweight0[da + 3 + k] = r; }
+    } else if (m.b_jtype[b] != MIR_JNT_FIXED)
+      H.dof_invweight0[da] = Inv[da * nv + da];
+    if (m.b_static[b]) continue;
+    double t = 0;
+    for (int i = 0; i < nv; i++) {
+      V3 vi, wi;
+      jac(b, xc[b], i, vi, wi);
+      for (int j = 0; j < nv; j++) {
+        V3 vj, wj;
+        jac(b, xc[b], j, vj, wj);
+        t += dot(vi, vj) * Inv[i * nv + j];
+      }
+    }
+    H.body_invweight0[b] = fmax(t / 3, 1e-15);
+  }
+  for (int i = 0; i < nv; i++) m.d_invweight0[i] = (float)H.dof_invweight0[i];
+  for (int b = 0; b < nb; b++) m.b_invweight0[b] = (float)H.body_invweight0[b];
+  m.meaninertia = (float)meaninertia;
+  m.solver_scale = (float)(1.0 / (meaninertia * (nv > 1 ? nv : 1)));
+  return MIR_OK;
+}

@@ -1,0 +1,61 @@
+// mir_model.h — compiled (float32) device model shared by host compile code and the HIP kernels.
+//
+// A MirSceneSpec (include/mirigid.h) is compiled once per mir_create() into this POD,
+// uploaded to HBM and read by every workgroup (it is a few KB and L2/L1 resident).
+// Lane ownership in the kernels is "lane i of a 16-lane env group = dof i = body i",
+// so everything here is laid out as 16-wide per-dof / per-body columns that a lane
+// pulls into registers once per launch.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/mirigid.h"
+
+#define MIR_G 16 /* lanes per env group; requires nbody, nv <= 16 */
+
+static_assert(MIR_MAX_BODY <= MIR_G && MIR_MAX_DOF <= MIR_G, "lane ownership needs nbody, nv <= group width");
+static_assert(MIR_MAX_GEOM <= 2 * MIR_G, "two geoms per lane");
+static_assert(MIR_MAX_PAIR <= 4 * MIR_G, "four pairs per lane");
+
+struct DevModel {
+  // sizes / options
+  int32_t nbody, nv, nq, ngeom, npair, nu, qstride, max_contacts;
+  int32_t iterations, ls_iterations, enable_collision, enable_joint_limit;
+  float dt, gx, gy, gz, tolerance, ls_tolerance, meaninertia, solver_scale;
+  // task extraction
+  int32_t eef_body, obj_body, n_grip, obj_qadr;
+  int32_t grip_qadr[MIR_MAX_GRIP];
+  float reward_z;
+  int32_t n_arm_q; /* number of scalar joints (arm_qpos width) */
+  // ---- per body (index = lane) ----
+  int32_t b_parent[MIR_G], b_jtype[MIR_G], b_dofadr[MIR_G], b_qadr[MIR_G], b_root[MIR_G], b_static[MIR_G];
+  uint32_t b_dofmask[MIR_G];  /* dofs that move body b (ancestors + own) */
+  uint32_t b_submask[MIR_G];  /* bodies in the subtree of b, including b (same tree only) */
+  float b_pos[MIR_G][3], b_quat[MIR_G][4], b_axis[MIR_G][3], b_ipos[MIR_G][3], b_inertia[MIR_G][6];
+  float b_mass[MIR_G], b_invweight0[MIR_G];
+  // ---- per dof (index = lane) ----
+  int32_t d_body[MIR_G], d_limited[MIR_G], d_ctrl[MIR_G], d_uadr[MIR_G], d_qadr[MIR_G], d_kind[MIR_G];
+  /* d_kind: 0 revolute, 1 prismatic, 2 free-translation k, 3 free-rotation k; d_axis_k = k for free dofs */
+  int32_t d_axis_k[MIR_G], d_armidx[MIR_G]; /* index into arm_qpos for scalar joints, else -1 */
+  uint32_t d_premask[MIR_G]; /* dofs whose velocity is "before" dof i (for cdof_dot) */
+  uint32_t d_ancmask[MIR_G]; /* ancestor-or-self dofs j <= i (non-zero pattern of M row i) */
+  float d_lo[MIR_G], d_hi[MIR_G], d_damping[MIR_G], d_kp[MIR_G], d_kv[MIR_G], d_frclo[MIR_G], d_frchi[MIR_G];
+  float d_mdiag[MIR_G];   /* armature + dt (damping + kv) if implicit */
+  float d_armature[MIR_G];
+  float d_invweight0[MIR_G];
+  float d_solimp[MIR_G][5], d_k[MIR_G], d_b[MIR_G]; /* limit-row spring/damper from solref (tc clamped to 2 dt) */
+  // ---- per geom ----
+  int32_t g_body[MIR_MAX_GEOM], g_type[MIR_MAX_GEOM];
+  float g_size[MIR_MAX_GEOM][3], g_pos[MIR_MAX_GEOM][3], g_quat[MIR_MAX_GEOM][4], g_friction[MIR_MAX_GEOM];
+  float g_solref[MIR_MAX_GEOM][2], g_solimp[MIR_MAX_GEOM][5];
+  // ---- candidate pairs (static filter applied) ----
+  int32_t p_g1[MIR_MAX_PAIR], p_g2[MIR_MAX_PAIR];
+};
+
+struct HostConsts {
+  double dof_invweight0[MIR_MAX_DOF];
+  double body_invweight0[MIR_MAX_BODY];
+  double meaninertia;
+};
+
+// Compile a scene spec.  Returns MIR_OK or a MIR_E_* code and fills err (<=255 chars).
+int mir_compile_model(const MirSceneSpec* spec, DevModel* out, HostConsts* hc, char* err);

@@ -1,0 +1,36 @@
+// mir_step.h — launch arguments of the fused step kernel (shared by mir_step.hip and mir_api.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mir_model.h"
+
+struct StepArgs {
+  const DevModel* model;
+  float* qpos;    // (B, qstride)
+  float* qvel;    // (B, 16)
+  float* target;  // (B, 16) indexed by dof
+  float* qacc_ws; // (B, 16)
+  const float* action;  // (B, nu) or null
+  float* agent_pos;     // (B, 7+n_grip) or null
+  float* env_state;     // (B, 11) or null
+  float* reward;        // (B) or null
+  uint8_t* terminated;  // (B) or null
+  int32_t* diag;        // (B, 4): ncon, nefc, niter, flags; or null
+  // debug / per-stage parity outputs (mir_forward), all nullable
+  float* out_M;         // (B, nv, nv)
+  float* out_bias;      // (B, nv)
+  float* out_qas;       // (B, nv)
+  float* out_qacc;      // (B, nv)
+  float* out_xpos;      // (B, nbody, 3)
+  float* out_xquat;     // (B, nbody, 4)
+  float* rows;          // (B, row_stride) packed [agent | env_state | reward | terminated] or null
+  int row_stride;
+  int B;
+  int mode;     // 0: full steps; 1: forward dynamics only (mir_forward); 2: kinematics + outputs only
+  int n_steps;  // mode 0 only
+};
+
+
+// enqueue the fused kernel on `stream`; returns a hipError_t as int
+extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipStream_t stream);

@@ -1,0 +1,189 @@
+"""ctypes binding of libmirigid.so (include/mirigid.h) and a thin torch-facing wrapper.
+
+There is deliberately NO CPU fallback: if the HIP library is missing or no GPU is
+visible, creating a scene raises.  PyTorch is used only to own device buffers and
+to supply the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .spec import MirDims, MirSceneSpec
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libmirigid.so"))
+
+_lib = None
+
+
+class MirError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    """Load libmirigid.so (built in-tree by ``make -C gym-genesis_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MirError(f"{LIB_PATH} not found: build it with `make -C gym-genesis_amd/csrc` "
+                       "(python __graft_entry__.py build); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.mir_version.restype = C.c_int
+    lib.mir_spec_sizeof.restype = C.c_int
+    lib.mir_last_error.restype = C.c_char_p
+    lib.mir_create.argtypes = [C.POINTER(MirSceneSpec), i32, i32, C.POINTER(vp)]
+    lib.mir_destroy.argtypes = [vp]
+    lib.mir_get_dims.argtypes = [vp, C.POINTER(MirDims)]
+    lib.mir_get_model_consts.argtypes = [vp, vp, vp, vp]
+    lib.mir_reset.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mir_set_pd_targets.argtypes = [vp, vp, vp]
+    lib.mir_step.argtypes = [vp, i32, vp]
+    lib.mir_step_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.mir_step_packed.argtypes = [vp, vp, vp, i32, vp]
+    lib.mir_step_packed.restype = C.c_int
+    lib.mir_get_obs.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mir_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mir_set_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mir_get_links.argtypes = [vp, vp, vp, vp]
+    lib.mir_get_diag.argtypes = [vp, vp, vp, vp, vp]
+    lib.mir_forward.argtypes = [vp, vp, vp, vp, vp, vp]
+    for name in ("mir_create", "mir_destroy", "mir_get_dims", "mir_get_model_consts", "mir_reset", "mir_set_pd_targets",
+                 "mir_step", "mir_step_fused", "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links",
+                 "mir_get_diag", "mir_forward"):
+        getattr(lib, name).restype = C.c_int
+    if lib.mir_spec_sizeof() != C.sizeof(MirSceneSpec) or lib.mir_version() != 1:
+        raise MirError("libmirigid.so ABI mismatch with gym_genesis.backend.spec (rebuild the library)")
+    _lib = lib
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class MirScene:
+    """A compiled, batched scene living on one GPU (``scene.build(n_envs=B)``)."""
+
+    def __init__(self, spec: MirSceneSpec, num_envs: int, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise MirError("no HIP device visible: gym_genesis (MI355X backend) has no CPU path")
+        self.lib = load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.spec = spec
+        h = C.c_void_p()
+        rc = self.lib.mir_create(C.byref(spec), int(num_envs), self.device.index or 0, C.byref(h))
+        self._check(rc)
+        self.h = h
+        d = MirDims()
+        self._check(self.lib.mir_get_dims(self.h, C.byref(d)))
+        self.num_envs, self.nbody, self.nq, self.nv = d.num_envs, d.nbody, d.nq, d.nv
+        self.ngeom, self.npair, self.agent_dim, self.env_dim = d.ngeom, d.npair, d.agent_dim, d.env_dim
+        self.nu = sum(1 for i in range(spec.ndof) if spec.dof[i].ctrl_mode == 1)
+        self.n_arm = sum(1 for b in range(1, spec.nbody) if spec.body[b].jtype in (1, 2))
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise MirError(f"libmirigid error {rc}: {self.lib.mir_last_error().decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _f32(self, t, cols: int) -> torch.Tensor:
+        """Accept torch (any device) or NumPy, return a contiguous f32 device tensor (B, cols)."""
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if t.shape != (self.num_envs, cols):
+            raise ValueError(f"expected shape {(self.num_envs, cols)}, got {tuple(t.shape)}")
+        return t
+
+    def empty(self, *shape, dtype=torch.float32) -> torch.Tensor:
+        return torch.empty((self.num_envs, *shape), dtype=dtype, device=self.device)
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.mir_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- C ABI, one method per entry point -------------------------------------------------------
+    def model_consts(self):
+        dw = np.zeros(self.nv)
+        bw = np.zeros(self.nbody)
+        mi = C.c_double()
+        self._check(self.lib.mir_get_model_consts(self.h, dw.ctypes.data_as(C.c_void_p), bw.ctypes.data_as(C.c_void_p),
+                                                  C.cast(C.byref(mi), C.c_void_p)))
+        return dw, bw, mi.value
+
+    def reset(self, obj_pos, obj_quat, arm_qpos, env_mask: Optional[torch.Tensor] = None) -> None:
+        p = self._f32(obj_pos, 3)
+        q = self._f32(obj_quat, 4)
+        a = self._f32(arm_qpos, self.n_arm)
+        mk = None
+        if env_mask is not None:
+            mk = torch.as_tensor(env_mask).to(device=self.device, dtype=torch.uint8).contiguous()
+        self._check(self.lib.mir_reset(self.h, _ptr(p), _ptr(q), _ptr(a), _ptr(mk), self._stream()))
+
+    def set_pd_targets(self, tgt) -> None:
+        t = self._f32(tgt, self.nu)
+        self._check(self.lib.mir_set_pd_targets(self.h, _ptr(t), self._stream()))
+
+    def step(self, n_steps: int = 1) -> None:
+        self._check(self.lib.mir_step(self.h, int(n_steps), self._stream()))
+
+    def step_fused(self, action, agent_pos, env_state, reward, terminated) -> None:
+        """Raw launch: all arguments are preallocated device tensors (action may be None)."""
+        self._check(self.lib.mir_step_fused(self.h, _ptr(action), _ptr(agent_pos), _ptr(env_state), _ptr(reward),
+                                            _ptr(terminated), self._stream()))
+
+    def step_packed(self, action, rows: torch.Tensor) -> None:
+        """One step; all outputs in one (B, row_stride) float32 row tensor (see mir_step_packed)."""
+        self._check(self.lib.mir_step_packed(self.h, _ptr(action), _ptr(rows), int(rows.stride(0)), self._stream()))
+
+    def get_obs(self):
+        agent, env = self.empty(self.agent_dim), self.empty(self.env_dim)
+        rew, term = self.empty(), self.empty(dtype=torch.uint8)
+        self._check(self.lib.mir_get_obs(self.h, _ptr(agent), _ptr(env), _ptr(rew), _ptr(term), self._stream()))
+        return agent, env, rew, term
+
+    def get_state(self):
+        q, v = self.empty(self.nq), self.empty(self.nv)
+        t, w = self.empty(self.nu), self.empty(self.nv)
+        self._check(self.lib.mir_get_state(self.h, _ptr(q), _ptr(v), _ptr(t), _ptr(w), self._stream()))
+        return q, v, t, w
+
+    def set_state(self, qpos=None, qvel=None, target=None, warmstart=None) -> None:
+        q = None if qpos is None else self._f32(qpos, self.nq)
+        v = None if qvel is None else self._f32(qvel, self.nv)
+        t = None if target is None else self._f32(target, self.nu)
+        w = None if warmstart is None else self._f32(warmstart, self.nv)
+        self._check(self.lib.mir_set_state(self.h, _ptr(q), _ptr(v), _ptr(t), _ptr(w), self._stream()))
+
+    def get_links(self):
+        pos, quat = self.empty(self.nbody, 3), self.empty(self.nbody, 4)
+        self._check(self.lib.mir_get_links(self.h, _ptr(pos), _ptr(quat), self._stream()))
+        return pos, quat
+
+    def get_diag(self):
+        a, b, c = (self.empty(dtype=torch.int32) for _ in range(3))
+        self._check(self.lib.mir_get_diag(self.h, _ptr(a), _ptr(b), _ptr(c), self._stream()))
+        return a, b, c
+
+    def forward(self):
+        M, bias = self.empty(self.nv, self.nv), self.empty(self.nv)
+        qas, qacc = self.empty(self.nv), self.empty(self.nv)
+        self._check(self.lib.mir_forward(self.h, _ptr(M), _ptr(bias), _ptr(qas), _ptr(qacc), self._stream()))
+        return M, bias, qas, qacc

@@ -1,0 +1,127 @@
+"""GenesisEnv — the gymnasium.Env adapter, backed by the MI355X rigid-body backend.
+
+Contract restated from /root/reference/gym_genesis/env.py:13-125:
+  ctor kwargs (17-29), ``metadata`` (15), ``reset`` -> (obs, {"is_success": [False]*B}) (48-57),
+  ``step`` -> (obs, reward, terminated np.bool_ (B,), truncated zeros (B,), {"is_success"}) (61-69),
+  ``render`` (97-98), ``push`` (59-60), accessors (84-95), task lookup by (robot, task, batched)
+  raising NotImplementedError(key) for unknown combinations (100-125).
+
+Positions taken on the reference's defects: ``terminated`` is derived
+from the reward whatever its array type (C-1); ``get_robot``/``get_cube`` return the task's
+robot / cube under whichever attribute name the task uses (C-3).
+"""
+from __future__ import annotations
+
+import importlib
+import warnings
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from ._gym import Env
+
+# (robot, task, batched) -> "module:Class" ; resolved lazily so importing gym_genesis stays light
+_TASKS = {
+    ("franka", "cube_pick", True): "gym_genesis.tasks.franka.cube_pick:FrankaCubePickBatch",
+}
+
+
+class GenesisEnv(Env):
+    metadata = {"render_modes": ["rgb_array"], "render_fps": 50}
+
+    def __init__(self, task, robot="so101", enable_pixels=False, observation_height=480, observation_width=640,
+                 num_envs=1, env_spacing=(1.0, 1.0), render_mode=None, camera_capture_mode="per_env",
+                 strip_environment_state=True, shard: Optional[Tuple[int, int]] = None):
+        super().__init__()
+        self.task = task
+        self.robot = robot
+        self.enable_pixels = enable_pixels
+        self.observation_height = observation_height
+        self.observation_width = observation_width
+        self.env_spacing = env_spacing
+        self.render_mode = render_mode
+        self.camera_capture_mode = camera_capture_mode
+        self.strip_environment_state = strip_environment_state
+        self._shard = shard
+        self.num_envs = num_envs
+        self._env = self._make_env_task(task)
+        self.num_envs = self._env.num_envs  # local shard size when sharded
+        self.observation_space = self._env.observation_space
+        self.action_space = self._env.action_space
+        self.scene = None
+
+    # ---- gymnasium API ------------------------------------------------------------------------
+    def reset(self, seed=None, options=None):
+        super().reset(seed=seed)
+        if seed is not None:
+            self._env.seed(seed)
+        observation = self._env.reset()
+        return observation, {"is_success": [False] * self.num_envs}
+
+    def step(self, action):
+        _, reward, _, observation = self._env.step(action)
+        term_dev = getattr(self._env, "terminated_device", None)
+        if term_dev is not None:
+            is_success = term_dev.bool()                   # written by the same kernel as the reward
+        elif isinstance(reward, torch.Tensor):
+            is_success = reward == 1
+        else:
+            is_success = torch.as_tensor(np.asarray(reward) == 1)
+        terminated = is_success.detach().cpu().numpy().astype(bool)  # the one D->H sync the API mandates
+        truncated = np.zeros(self.num_envs, dtype=bool)
+        return observation, reward, terminated, truncated, {"is_success": is_success}
+
+    def render(self):
+        return self._env.cam.render()[0] if self.enable_pixels else None
+
+    def close(self):
+        pass
+
+    # ---- extras the reference exposes ---------------------------------------------------------
+    def push(self):
+        self._env.scene.step()
+
+    def save_video(self, save_video: bool = False, file_name: str = "episode.mp4", fps=60):
+        if self.enable_pixels and save_video:
+            warnings.warn("Calling `save_video()` stops the camera recording; no further frames can be recorded.",
+                          stacklevel=2)
+            self._env.cam.stop_recording(save_to_filename=file_name, fps=fps)
+
+    def get_obs(self):
+        return self._env.get_obs()
+
+    def get_cams(self):
+        return self._env.get_cams()
+
+    def get_cube(self):
+        for name in ("cube_1", "cube"):
+            if hasattr(self._env, name):
+                return getattr(self._env, name)
+        raise AttributeError("task has no cube")
+
+    def get_robot(self):
+        for name in ("so_101", "franka"):
+            if hasattr(self._env, name):
+                return getattr(self._env, name)
+        raise AttributeError("task has no robot")
+
+    # ---- task factory -------------------------------------------------------------------------
+    def _make_env_task(self, task_name):
+        key = (self.robot, task_name, self.num_envs > 0)
+        if key not in _TASKS:
+            raise NotImplementedError(key)
+        mod, cls = _TASKS[key].split(":")
+        ctor = getattr(importlib.import_module(mod), cls)
+        kwargs = dict(
+            enable_pixels=self.enable_pixels,
+            observation_height=self.observation_height,
+            observation_width=self.observation_width,
+            num_envs=self.num_envs,
+            env_spacing=self.env_spacing,
+            camera_capture_mode=self.camera_capture_mode,
+            strip_environment_state=self.strip_environment_state,
+        )
+        if self._shard is not None:
+            kwargs["shard"] = self._shard
+        return ctor(**kwargs)

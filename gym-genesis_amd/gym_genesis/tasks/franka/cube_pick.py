@@ -1,0 +1,160 @@
+"""Batched Franka cube-pick task on the MI355X backend.
+
+Behavioural contract restated from the reference task
+(/root/reference/gym_genesis/tasks/franka/cube_pick.py:21-181):
+  * scene: plane + Panda (9 dofs) + 4 cm cube at (0.65, 0, 0.02), dt = 0.01      (:37-54)
+  * reset(): cube x ~ U(0.45, 0.80), y ~ U(-0.25, 0.25) from the task RandomState, drawn x
+    first then y, z = 0.02; cube quaternion (0,0,0,1) wxyz; arm at the home pose with zero
+    velocity; PD targets = home; ONE physics step; returns get_obs()               (:86-112)
+  * step(a): PD targets <- a[:, :7] (rad) and a[:, 7:] (m), unscaled and unclipped; one
+    physics step; returns (None, reward, None, obs)                                (:122-128)
+  * reward = float32(cube_z > 0.1)                                                 (:130-135)
+  * obs: agent_pos (B,9) = [eef pos3, eef quat4 wxyz, finger q2]; environment_state (B,11) =
+    [cube pos3, cube quat4, eef - cube 3, |eef - cube| 1]; torch float32 on device (:137-152)
+
+Differences by design: control + step + reward + observation extraction are ONE kernel
+launch (mir_step_fused) instead of ~20 launches and two host syncs, and ``reward`` is a
+torch tensor on the device (its values equal the reference's NumPy array).
+"""
+from __future__ import annotations
+
+import random
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..._gym import spaces
+from ...backend import models
+from ...backend.lib import MirScene
+from ..views import EntityView, SceneView
+
+AGENT_DIM = len(models.FRANKA_JOINTS)
+ENV_DIM = 11
+
+
+class FrankaCubePickBatch:
+    def __init__(self, enable_pixels, observation_height, observation_width, num_envs, env_spacing,
+                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None):
+        self.enable_pixels = enable_pixels
+        self.observation_height = observation_height
+        self.observation_width = observation_width
+        self.camera_capture_mode = camera_capture_mode
+        self.strip_environment_state = strip_environment_state
+        self.env_spacing = env_spacing
+        # env-axis shard: this process owns envs [lo, hi) of the global batch
+        self.global_num_envs = int(num_envs)
+        rank, world = shard if shard is not None else (0, 1)
+        self.shard_lo = self.global_num_envs * rank // world
+        self.shard_hi = self.global_num_envs * (rank + 1) // world
+        self.num_envs = self.shard_hi - self.shard_lo
+        self._random = np.random.RandomState()
+        self._build_scene()
+        self.observation_space = self._make_obs_space()
+        self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(AGENT_DIM,), dtype=np.float32)
+
+    # ---- scene ------------------------------------------------------------------------------
+    def _build_scene(self):
+        if self.enable_pixels:
+            raise NotImplementedError("enable_pixels=True needs the batched rasteriser (SURVEY.md 8f-2), not built yet")
+        builder = models.franka_cube_pick_scene()
+        self._builder = builder
+        self._mir = MirScene(builder.build(), self.num_envs)
+        B, dev = self.num_envs, self._mir.device
+        self.device = dev
+        self.scene = SceneView(self._mir, env_spacing=self.env_spacing, global_num_envs=self.global_num_envs,
+                               offset=self.shard_lo)
+        self.franka = EntityView(self._mir, builder, root="link0", dof_names=models.FRANKA_JOINTS)
+        self.cube = EntityView(self._mir, builder, root="cube", dof_names=())
+        self.eef = self.franka.get_link("hand")
+        self.motors_dof = np.arange(7)
+        self.fingers_dof = np.arange(7, 9)
+        # persistent device buffers: one set, rewritten by every fused step
+        self._agent = torch.empty((B, AGENT_DIM), dtype=torch.float32, device=dev)
+        self._envst = torch.empty((B, ENV_DIM), dtype=torch.float32, device=dev)
+        self._reward = torch.empty((B,), dtype=torch.float32, device=dev)
+        self._term = torch.empty((B,), dtype=torch.uint8, device=dev)
+        self._home = torch.tensor(models.FRANKA_HOME, dtype=torch.float32, device=dev).repeat(B, 1)
+        self._quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=torch.float32, device=dev).repeat(B, 1)
+
+    def _make_obs_space(self):
+        box = lambda n: spaces.Box(low=-np.inf, high=np.inf, shape=(n,), dtype=np.float32)  # noqa: E731
+        if self.enable_pixels:
+            return spaces.Dict({
+                "agent_pos": box(AGENT_DIM),
+                "pixels": spaces.Box(low=0, high=255, shape=(self.observation_height, self.observation_width, 3),
+                                     dtype=np.uint8),
+            })
+        return spaces.Dict({"agent_pos": box(AGENT_DIM), "environment_state": box(ENV_DIM)})
+
+    def get_cams(self):
+        if not self.enable_pixels:
+            raise ValueError("Cameras are not enabled. Set `enable_pixels=True` when creating the environment.")
+        return self.cam
+
+    # ---- episode control --------------------------------------------------------------------
+    def seed(self, seed):
+        np.random.seed(seed)
+        random.seed(seed)
+        self._random = np.random.RandomState(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed)
+        self.action_space.seed(seed)
+
+    def sample_spawn(self) -> np.ndarray:
+        """Cube spawn positions for the GLOBAL batch (so a sharded run draws the same stream as an
+        unsharded one), float32 (B_global, 3)."""
+        Bg = self.global_num_envs
+        x = self._random.uniform(0.45, 0.80, size=(Bg,))
+        y = self._random.uniform(-0.25, 0.25, size=(Bg,))
+        z = np.full((Bg,), 0.02)
+        return np.stack([x, y, z], axis=1).astype(np.float32)
+
+    def reset(self):
+        pos = torch.from_numpy(self.sample_spawn()[self.shard_lo:self.shard_hi]).to(self.device)
+        self._mir.reset(pos, self._quat, self._home)  # set_pos/set_quat/set_qpos(zero_velocity) + PD targets = home
+        self._mir.step(1)                             # the reference consumes one physics step in reset()
+        return self.get_obs()
+
+    def step(self, action):
+        a = self._as_action(action)
+        # fresh output tensors per call, like the reference (callers may keep old observations)
+        mir = self._mir
+        self._agent, self._envst = mir.empty(AGENT_DIM), mir.empty(ENV_DIM)
+        self._reward, self._term = mir.empty(), mir.empty(dtype=torch.uint8)
+        mir.step_fused(a, self._agent, self._envst, self._reward, self._term)
+        return None, self._reward, None, self._pack_obs()
+
+    def step_raw(self, action_dev: torch.Tensor) -> None:
+        """Hot path without any Python-side packing: `action_dev` is a contiguous float32 (B,9) device tensor."""
+        self._mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)
+
+    def compute_reward(self):
+        self._refresh()
+        return self._reward
+
+    def get_obs(self):
+        self._refresh()
+        return self._pack_obs()
+
+    # ---- helpers ----------------------------------------------------------------------------
+    def _as_action(self, action) -> torch.Tensor:
+        if not isinstance(action, torch.Tensor):
+            action = torch.as_tensor(np.asarray(action))
+        a = action.to(device=self.device, dtype=torch.float32).contiguous()
+        if a.shape != (self.num_envs, AGENT_DIM):
+            raise ValueError(f"action must have shape {(self.num_envs, AGENT_DIM)}, got {tuple(a.shape)}")
+        return a
+
+    def _refresh(self):
+        agent, env, rew, term = self._mir.get_obs()
+        self._agent, self._envst, self._reward, self._term = agent, env, rew, term
+
+    def _pack_obs(self):
+        obs = {"agent_pos": self._agent, "environment_state": self._envst}
+        return obs
+
+    @property
+    def terminated_device(self) -> torch.Tensor:
+        return self._term

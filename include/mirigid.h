@@ -184,6 +184,12 @@ int mir_step(MirHandle h, int32_t n_steps, void* stream);
 int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward,
                    uint8_t* terminated, void* stream);
 
+/* Same step, but every output of an env lands in ONE packed float32 row
+ * rows[e*row_stride + ...] = [agent_pos (7+n_grip) | env_state (11) | reward | terminated(0/1)]
+ * so a sharded run gathers all per-step outputs with a single collective
+ * (row_stride >= 7+n_grip+13, in floats). */
+int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream);
+
 /* get_obs() without stepping */
 int mir_get_obs(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated,
                 void* stream);

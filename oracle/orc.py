@@ -1,7 +1,7 @@
 """ctypes driver for the CPU oracle (oracle/liborc64.so / liborc32.so).
 
-Lives under tests/ on purpose: the oracle is test infrastructure and the
-product package never imports it.
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (gym-genesis_amd/) never imports it.
 """
 from __future__ import annotations
 
@@ -12,12 +12,11 @@ from typing import Optional
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_DIR = os.path.dirname(os.path.abspath(__file__))
 
 (F_QPOS, F_QVEL, F_TARGET, F_QACC_WS, F_XPOS, F_XQUAT, F_XIPOS, F_M, F_MT, F_QFRC_BIAS, F_QFRC_SMOOTH,
  F_QACC_SMOOTH, F_QACC, F_CPOS, F_CDIST, F_CFRAME, F_J, F_AREF, F_EFCD, F_EFCFORCE, F_DOF_INVWEIGHT0,
- F_BODY_INVWEIGHT0, F_MEANINERTIA, F_QFRC_ACT, F_QFRC_PASSIVE, F_EFCPOS) = range(26)
+ F_BODY_INVWEIGHT0, F_MEANINERTIA, F_QFRC_ACT, F_QFRC_PASSIVE, F_EFCPOS, F_DBG_IMP, F_DBG_GN, F_DBG_ALPHA) = range(29)
 
 
 def build_oracle() -> None:

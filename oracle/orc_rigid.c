@@ -30,6 +30,7 @@
 #define MINVAL ((real)1e-15)
 #define MINIMP ((real)0.0001)
 #define MAXIMP ((real)0.9999)
+#define F32(x) ((real)(float)(x)) /* the product stores model constants, dt and gravity in float32: same inputs */
 
 /* ------------------------------------------------------------------ small math */
 static void v3set(real* o, real a, real b, real c) { o[0] = a; o[1] = b; o[2] = c; }
@@ -247,9 +248,9 @@ static void orc_crb(const OrcModel* m, OrcData* d) {
 static void orc_rne(const OrcModel* m, OrcData* d) {
   memset(d->cvel[0], 0, sizeof d->cvel[0]);
   d->cacc[0][0] = d->cacc[0][1] = d->cacc[0][2] = 0;
-  d->cacc[0][3] = -(real)m->opt.gravity[0];
-  d->cacc[0][4] = -(real)m->opt.gravity[1];
-  d->cacc[0][5] = -(real)m->opt.gravity[2];
+  d->cacc[0][3] = -F32(m->opt.gravity[0]);
+  d->cacc[0][4] = -F32(m->opt.gravity[1]);
+  d->cacc[0][5] = -F32(m->opt.gravity[2]);
   for (int b = 1; b < m->nbody; b++) {
     int p = m->parent[b], da = m->dofadr[b];
     real* cv = d->cvel[b];
@@ -293,7 +294,7 @@ static void orc_rne(const OrcModel* m, OrcData* d) {
 
 /* ------------------------------------------------------------------ smooth dynamics */
 static void orc_smooth(const OrcModel* m, OrcData* d) {
-  const real dt = (real)m->opt.dt;
+  const real dt = F32(m->opt.dt);
   for (int i = 0; i < m->nv; i++) {
     d->qfrc_passive[i] = -m->damping[i] * d->qvel[i];
     real f = 0;
@@ -538,7 +539,7 @@ static void imp_kb(const OrcModel* m, const real* solref, const real* solimp, re
   else y = 1 - (real)pow((double)((1 - x) / (1 - mid)), (double)power) * (1 - mid);
   *imp = dmin + y * (dmax - dmin);
   real tc = solref[0], dr = solref[1];
-  if (tc < 2 * (real)m->opt.dt) tc = 2 * (real)m->opt.dt;
+  if (tc < 2 * F32(m->opt.dt)) tc = 2 * F32(m->opt.dt);
   *k = 1 / (dmax * dmax * tc * tc * dr * dr);
   *b = 2 / (dmax * tc);
 }
@@ -652,6 +653,11 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
   }
   const real scale = 1 / (m->meaninertia * (real)(nv > 1 ? nv : 1));
   const real tol = (real)m->opt.tolerance;
+  /* rounding floor of the gradient Ma - qfrc_smooth - J^T f in this precision: below it Newton
+   * steps no longer change qacc, so stop (never binding in float64 before tol is) */
+  real gfloor = 0;
+  for (int i = 0; i < nv; i++) gfloor += Ma[i] * Ma[i] + d->qfrc_smooth[i] * d->qfrc_smooth[i];
+  gfloor = 16 * (sizeof(real) == 4 ? (real)5.96e-8 : (real)1.11e-16) * (real)sqrt((double)gfloor);
   for (int it = 0; it < m->opt.iterations; it++) {
     /* gradient, forces, Hessian */
     real H[ORC_NV][ORC_NV], L[ORC_NV][ORC_NV];
@@ -672,7 +678,8 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
     }
     real gn = 0;
     for (int i = 0; i < nv; i++) gn += grad[i] * grad[i];
-    if (scale * (real)sqrt((double)gn) < tol) break;
+    if (it < 64) d->dbg_gn[it] = scale * (real)sqrt((double)gn);
+    if (scale * (real)sqrt((double)gn) < tol || (real)sqrt((double)gn) < gfloor) break;
     chol(nv, H, L);
     chol_solve(nv, L, grad, s);
     for (int i = 0; i < nv; i++) s[i] = -s[i];
@@ -715,6 +722,7 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
     for (int i = 0; i < nv; i++) { d->qacc[i] += alpha * s[i]; Ma[i] += alpha * Mv[i]; }
     for (int r = 0; r < n; r++) jar[r] += alpha * jv[r];
     d->niter = it + 1;
+    if (it < 64) { d->dbg_imp[it] = scale * imp; d->dbg_alpha[it] = alpha; }
     if (scale * imp < tol) break;
   }
   for (int r = 0; r < n; r++) d->efcforce[r] = jar[r] < 0 ? -d->efcD[r] * jar[r] : 0;
@@ -732,7 +740,7 @@ void orc_forward(const OrcModel* m, OrcData* d) {
 }
 
 static void orc_integrate(const OrcModel* m, OrcData* d) {
-  const real dt = (real)m->opt.dt;
+  const real dt = F32(m->opt.dt);
   for (int i = 0; i < m->nv; i++) d->qvel[i] += dt * d->qacc[i];
   for (int b = 1; b < m->nbody; b++) {
     int da = m->dofadr[b], qa = m->qadr[b];
@@ -770,10 +778,10 @@ int orc_compile(const MirSceneSpec* sp, OrcModel* m) {
     const MirBodySpec* s = &sp->body[b];
     m->parent[b] = b == 0 ? -1 : s->parent;
     m->jtype[b] = b == 0 ? MIR_JNT_FIXED : s->jtype;
-    for (int k = 0; k < 3; k++) { m->pos[b][k] = (real)s->pos[k]; m->axis[b][k] = (real)s->axis[k]; m->ipos[b][k] = (real)s->ipos[k]; }
-    for (int k = 0; k < 4; k++) m->quat[b][k] = (real)s->quat[k];
-    for (int k = 0; k < 6; k++) m->inertia[b][k] = (real)s->inertia[k];
-    m->mass[b] = (real)s->mass;
+    for (int k = 0; k < 3; k++) { m->pos[b][k] = F32(s->pos[k]); m->axis[b][k] = F32(s->axis[k]); m->ipos[b][k] = F32(s->ipos[k]); }
+    for (int k = 0; k < 4; k++) m->quat[b][k] = F32(s->quat[k]);
+    for (int k = 0; k < 6; k++) m->inertia[b][k] = F32(s->inertia[k]);
+    m->mass[b] = F32(s->mass);
     m->dofadr[b] = nv; m->qadr[b] = nq;
     int nd = 0, nqq = 0;
     if (m->jtype[b] == MIR_JNT_REVOLUTE || m->jtype[b] == MIR_JNT_PRISMATIC) { nd = 1; nqq = 1; }
@@ -796,8 +804,8 @@ int orc_compile(const MirSceneSpec* sp, OrcModel* m) {
       m->dof_qadr[i] = nq + k; /* meaningful for scalar joints */
     }
     if (m->jtype[b] == MIR_JNT_FREE) {
-      for (int k = 0; k < 3; k++) m->qpos0[nq + k] = (real)s->pos[k];
-      for (int k = 0; k < 4; k++) m->qpos0[nq + 3 + k] = (real)s->quat[k];
+      for (int k = 0; k < 3; k++) m->qpos0[nq + k] = F32(s->pos[k]);
+      for (int k = 0; k < 4; k++) m->qpos0[nq + 3 + k] = F32(s->quat[k]);
     }
     nv += nd; nq += nqq;
   }
@@ -808,22 +816,22 @@ int orc_compile(const MirSceneSpec* sp, OrcModel* m) {
     const MirDofSpec* s = &sp->dof[i];
     m->dof_limited[i] = s->limited; m->dof_ctrl[i] = s->ctrl_mode;
     m->dof_uadr[i] = s->ctrl_mode == MIR_CTRL_POSITION ? nu++ : -1;
-    m->range[i][0] = (real)s->range[0]; m->range[i][1] = (real)s->range[1];
-    m->armature[i] = (real)s->armature; m->damping[i] = (real)s->damping;
-    m->kp[i] = (real)s->kp; m->kv[i] = (real)s->kv;
-    m->frc[i][0] = (real)s->frc_range[0]; m->frc[i][1] = (real)s->frc_range[1];
-    for (int k = 0; k < 2; k++) m->dsolref[i][k] = (real)s->solref[k];
-    for (int k = 0; k < 5; k++) m->dsolimp[i][k] = (real)s->solimp[k];
+    m->range[i][0] = F32(s->range[0]); m->range[i][1] = F32(s->range[1]);
+    m->armature[i] = F32(s->armature); m->damping[i] = F32(s->damping);
+    m->kp[i] = F32(s->kp); m->kv[i] = F32(s->kv);
+    m->frc[i][0] = F32(s->frc_range[0]); m->frc[i][1] = F32(s->frc_range[1]);
+    for (int k = 0; k < 2; k++) m->dsolref[i][k] = F32(s->solref[k]);
+    for (int k = 0; k < 5; k++) m->dsolimp[i][k] = F32(s->solimp[k]);
   }
   m->nu = nu;
   for (int g = 0; g < sp->ngeom; g++) {
     const MirGeomSpec* s = &sp->geom[g];
     m->gbody[g] = s->body; m->gtype[g] = s->type;
-    for (int k = 0; k < 3; k++) { m->gsize[g][k] = (real)s->size[k]; m->gpos[g][k] = (real)s->pos[k]; }
-    for (int k = 0; k < 4; k++) m->gquat[g][k] = (real)s->quat[k];
-    m->gfriction[g] = (real)s->friction;
-    for (int k = 0; k < 2; k++) m->gsolref[g][k] = (real)s->solref[k];
-    for (int k = 0; k < 5; k++) m->gsolimp[g][k] = (real)s->solimp[k];
+    for (int k = 0; k < 3; k++) { m->gsize[g][k] = F32(s->size[k]); m->gpos[g][k] = F32(s->pos[k]); }
+    for (int k = 0; k < 4; k++) m->gquat[g][k] = F32(s->quat[k]);
+    m->gfriction[g] = F32(s->friction);
+    for (int k = 0; k < 2; k++) m->gsolref[g][k] = F32(s->solref[k]);
+    for (int k = 0; k < 5; k++) m->gsolimp[g][k] = F32(s->solimp[k]);
   }
   /* candidate pairs: ordered (g1<g2), planes first in a pair */
   int np = 0;
@@ -980,6 +988,9 @@ int orc_read(const OrcModel* m, const OrcData* d, int field, double* out) {
     case ORC_F_DOF_INVWEIGHT0: return cp(out, m->dof_invweight0, nv);
     case ORC_F_BODY_INVWEIGHT0: return cp(out, m->body_invweight0, m->nbody);
     case ORC_F_MEANINERTIA: out[0] = (double)m->meaninertia; return 1;
+    case ORC_F_DBG_IMP: return cp(out, d->dbg_imp, d->niter < 64 ? d->niter : 64);
+    case ORC_F_DBG_GN: return cp(out, d->dbg_gn, d->niter < 64 ? d->niter : 64);
+    case ORC_F_DBG_ALPHA: return cp(out, d->dbg_alpha, d->niter < 64 ? d->niter : 64);
   }
   return -1;
 }
@@ -1078,7 +1089,7 @@ void orc_aba(const OrcModel* m, OrcData* d, double* qacc_out) {
    * repeating the reduction (cheap, clarity over speed) */
   real acc[ORC_NB][6];
   memset(acc, 0, sizeof acc);
-  acc[0][3] = -(real)m->opt.gravity[0]; acc[0][4] = -(real)m->opt.gravity[1]; acc[0][5] = -(real)m->opt.gravity[2];
+  acc[0][3] = -F32(m->opt.gravity[0]); acc[0][4] = -F32(m->opt.gravity[1]); acc[0][5] = -F32(m->opt.gravity[2]);
   for (int b = 1; b < nb; b++) {
     int p = m->parent[b], da = m->dofadr[b], nd = m->ndof[b];
     real a[6];

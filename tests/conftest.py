@@ -5,7 +5,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "gym-genesis_amd")
-for p in (PKG, os.path.join(ROOT, "tests"), ROOT):
+for p in (PKG, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
