@@ -279,6 +279,15 @@ int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_s
   return launch(h, a, stream);
 }
 
+/* debug aid (not part of the drop-in surface): one step with phase timestamps from block 0 */
+int mir_debug_profile_step(MirHandle h, unsigned long long* prof16, void* stream) {
+  if (check(h) || !prof16) return set_err(MIR_E_INVALID, "mir_debug_profile_step: null argument");
+  DeviceGuard guard(h->device);
+  StepArgs a = base_args(h);
+  a.prof = prof16;
+  return launch(h, a, stream);
+}
+
 int mir_get_obs(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);

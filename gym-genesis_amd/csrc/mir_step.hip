@@ -2,21 +2,26 @@
 //
 // What it replaces: scene.step() + get_obs() + compute_reward() of the reference
 // (/root/reference/gym_genesis/tasks/franka/cube_pick.py:122-181, env.py:61-69), i.e. the
-// Genesis rigid solver pipeline restated in SURVEY.md App. A.
+// Genesis rigid-solver pipeline restated in SURVEY.md App. A.
 //
 // Mapping to CDNA4
-//   * workgroup = ONE wave64 = 4 envs x 16 lanes.  Inside an env group, lane i is
-//     "dof i", "body i", "contact i" or "geom i / i+16" depending on the phase, so every
-//     per-dof / per-body model constant lives in that lane's registers.
-//   * all per-env working data (poses, motion subspaces, mass matrix, contact rows,
-//     Newton Hessian) lives in LDS; a step reads ~0.25 KB and writes ~0.3 KB of HBM per env.
-//   * kinematic-tree recursions (velocities, accelerations, composite inertias, subtree
-//     forces) are evaluated as mask-driven sums over ancestors / descendants, so they are
-//     single phases with no depth-serial chain of barriers.
-//   * single-wave workgroups: __syncthreads() is a wave-level LDS fence (no s_barrier
-//     traffic between waves), cross-lane reductions are 16-wide xor shuffles.
-//   * state is stored env-major (B, D): with 16 lanes per env a wave touches 4 contiguous
-//     64-byte rows, the coalesced pattern for this lane mapping.
+//   * workgroup = ONE wave64 = 4 envs x 16 lanes; a 16-lane env group is exactly one DPP "row".
+//     Inside a group lane i is "dof i", "body i", "contact i" or "geom i / i+16" depending on the
+//     phase, so per-dof / per-body / per-contact solver state is lane-private (registers).
+//   * cross-lane traffic inside a group uses DPP: row_ror adds for reductions and row_newbcast
+//     for broadcasts (a few cycles each, no LDS round trip).
+//   * the two dense solves per Newton iteration (M^-1 f, H^-1 g) are Gauss-Jordan eliminations
+//     on register-resident matrix rows (lane i = row i), the pivot row travelling by
+//     row_newbcast: no LDS, no sqrt, no forward/back substitution chains.
+//   * kinematic-tree recursions are mask-driven sums over ancestors / descendants: single
+//     phases, no depth-serial chain of barriers; the parent table is a 64-bit register.
+//   * per-env working data that other lanes must see (poses, motion subspaces, M, contact
+//     Jacobians) lives in ~8 KB of LDS per env, phase-aliased, so 4 workgroups (16 envs) fit a CU
+//     and all 4096 envs of the headline batch are co-resident on the 256 CUs.
+//   * single-wave workgroups: LDS accesses of a wave execute in order, so phases are separated
+//     by a compiler-level fence only (WSYNC), never an s_barrier.
+//   * HBM state is env-major (B, D): with 16 lanes per env a wave touches 4 contiguous 64-byte
+//     rows, the coalesced pattern for this lane mapping.  ~0.25 KB read + ~0.3 KB written per env-step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,10 +29,26 @@
 #include "mir_step.h"
 
 #define G MIR_G
-#define EPB 4 /* envs per block */
-#define MST 17 /* padded row stride of 16x16 matrices in LDS (bank-conflict free column walks) */
+#define EPB 4       /* envs per block */
+#define MAXCON MIR_MAX_CONTACT
+#define JST 52      /* floats per contact in Jb: 3 rows x 16 + 4 pad -> conflict-free ds_read_b128 across contact lanes */
+#define MSTR 20     /* row stride of M in LDS (floats): 16-byte aligned rows, conflict-free b128 row reads */
+static_assert(MAXCON == G, "lane c owns contact c");
+
+// wave-level phase separator: LDS operations of one wave execute in order, so only the compiler
+// must be kept from moving LDS accesses across the phase boundary
+#define WSYNC()                                              \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+// optional phase timestamps (debug): block 0, thread 0 records the shader clock at phase boundaries
+#define STAMP(k) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
 
 namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct V3 {
   float x, y, z;
@@ -40,6 +61,11 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y 
 __device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 __device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 __device__ __forceinline__ void st3(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+// 16-byte LDS accesses (arrays below are padded to 4 floats per element for these)
+__device__ __forceinline__ f4 ldv(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ void stv(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+__device__ __forceinline__ V3 ld3v(const float* p) { f4 v = ldv(p); return {v.x, v.y, v.z}; }
+__device__ __forceinline__ void st3v(float* p, V3 a, float w = 0.0f) { stv(p, f4{a.x, a.y, a.z, w}); }
 
 struct Q4 {
   float w, x, y, z;
@@ -54,16 +80,17 @@ __device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
   return v + q.w * t + cross(u, t);
 }
 __device__ __forceinline__ Q4 ld4(const float* p) { return {p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ Q4 ld4v(const float* p) { f4 v = ldv(p); return {v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ void st4(float* p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+__device__ __forceinline__ void st4v(float* p, Q4 q) { stv(p, f4{q.w, q.x, q.y, q.z}); }
 __device__ __forceinline__ Q4 qnormalize(Q4 q) {
   float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
   if (n < 1e-15f) return {1, 0, 0, 0};
   float s = 1.0f / n;
   return {q.w * s, q.x * s, q.y * s, q.z * s};
 }
-// row-major rotation matrix as three rows
 struct M3 {
-  V3 r0, r1, r2;
+  V3 r0, r1, r2;  // rows
 };
 __device__ __forceinline__ M3 q2m(Q4 q) {
   float w = q.w, x = q.x, y = q.y, z = q.z;
@@ -78,14 +105,50 @@ __device__ __forceinline__ V3 mcol(const M3& R, int k) {
 }
 __device__ __forceinline__ V3 mmul(const M3& R, V3 v) { return {dot(R.r0, v), dot(R.r1, v), dot(R.r2, v)}; }
 
-// sum over the 16 lanes of an env group (result in every lane)
-__device__ __forceinline__ float gsum(float v) {
-  v += __shfl_xor(v, 1, G);
-  v += __shfl_xor(v, 2, G);
-  v += __shfl_xor(v, 4, G);
-  v += __shfl_xor(v, 8, G);
+// ---- DPP cross-lane primitives over one 16-lane row (= one env group).  Must be executed with all
+// lanes of the wave active (convergent code): an inactive source lane would feed garbage.
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {  // value of lane K of the row, in every lane of the row
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float gsum(float v) {  // all-reduce sum over the row
+  v += row_ror<1>(v);
+  v += row_ror<2>(v);
+  v += row_ror<4>(v);
+  v += row_ror<8>(v);
   return v;
 }
+__device__ __forceinline__ int gsumi(int v) { return (int)(gsum((float)v) + 0.5f); }
+
+// ---- Gauss-Jordan solve A x = b on register rows: lane i holds row i of the SPD matrix A in
+// a[0..15] and b_i in b; on return b = x_i.  Rows >= nv must be identity rows.  15 pivots, each:
+// one reciprocal, (16-k) row_newbcast + fma pairs.  No pivoting needed (SPD).
+template <int K>
+struct GJ {
+  static __device__ __forceinline__ void run(float (&a)[G], float& b, int lane) {
+    const float pk = row_bcast<K>(a[K]);
+    float inv = __builtin_amdgcn_rcpf(pk);
+    inv = inv * (2.0f - pk * inv);  // one Newton step: full float accuracy
+    const bool isk = lane == K;
+    const float f = a[K] * inv;
+#pragma unroll
+    for (int j = K + 1; j < G - 1; j++) {
+      const float rj = row_bcast<K>(a[j]);
+      a[j] = isk ? a[j] * inv : fmaf(-f, rj, a[j]);
+    }
+    const float rb = row_bcast<K>(b);
+    b = isk ? b * inv : fmaf(-f, rb, b);
+    GJ<K + 1>::run(a, b, lane);
+  }
+};
+template <>
+struct GJ<G - 1> {
+  static __device__ __forceinline__ void run(float (&)[G], float&, int) {}
+};
 
 // spatial inertia {m, h, I(xx yy zz xy xz yz)} applied to motion {w, v} -> force {t, f}
 struct Inert {
@@ -93,7 +156,10 @@ struct Inert {
   V3 h;
   float xx, yy, zz, xy, xz, yz;
 };
-__device__ __forceinline__ Inert ldI(const float* p) { return {p[0], {p[1], p[2], p[3]}, p[4], p[5], p[6], p[7], p[8], p[9]}; }
+__device__ __forceinline__ Inert ldI(const float* p) {
+  f4 a = ldv(p), b = ldv(p + 4), c = ldv(p + 8);
+  return {a.x, {a.y, a.z, a.w}, b.x, b.y, b.z, b.w, c.x, c.y};
+}
 __device__ __forceinline__ void imul(const Inert& I, V3 w, V3 v, V3& t, V3& f) {
   V3 Iw = {I.xx * w.x + I.xy * w.y + I.xz * w.z, I.xy * w.x + I.yy * w.y + I.yz * w.z, I.xz * w.x + I.yz * w.y + I.zz * w.z};
   t = Iw + cross(I.h, v);
@@ -101,38 +167,50 @@ __device__ __forceinline__ void imul(const Inert& I, V3 w, V3 v, V3& t, V3& f) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-env LDS working set
-template <int MAXCON>
+// per-env LDS working set (~8 KB).  Three phase-local scratch areas share storage:
+//   dyn  (FK .. smooth dynamics)   overlays   contact arrays + Jb
+//   col  (collision detection)     overlays   Jb
+struct DynScratch {
+  float lpos[G][4], lquat[G][4];
+  float cddq[G][8];               // cdof_dot * qvel: ang(3) pad lin(3) pad
+  float cinert[G][12], crb[G][12];
+  float cvel[G][8], cfrc[G][8];
+};
+struct ColScratch {
+  float gpos[MIR_MAX_GEOM][4], gquat[MIR_MAX_GEOM][4];
+  int cand[G];
+  float stage[G][8][4];           // narrowphase output per candidate pair: pos, dist
+  float snorm[G][4];
+};
+struct ContactArrays {
+  float cpos[MAXCON][4];          // pos, dist
+  float cfrm[MAXCON][12];         // normal, t1, t2 (4-padded)
+  float cmeta[MAXCON][4];         // mu, D, k*imp*dist stash / unused, b stash
+  float cref[MAXCON][8];          // reference points of body1 / body2 trees (4-padded)
+  unsigned cmask[MAXCON][4];      // dof masks of body1, body2, chunk mask, pad
+  float cfb[MAXCON][4];           // per-iteration base forces (n, t1, t2), active-row flags (as int bits)
+};
 struct EnvLds {
   float qpos[20], qvel[G], target[G], qacc_ws[G], qacc[G];
-  float lpos[G][3], lquat[G][4];
-  float xpos[G][3], xquat[G][4];
-  float cdof[G][6], cddq[G][6];
-  float cinert[G][10], crb[G][10];
-  float cvel[G][6], cfrc[G][6];
-  float M[G][MST], H[G][MST];
-  float qfs[G], qas[G], grad[G], srch[G], Ma[G], Mv[G];
-  // collision
-  float gpos[MIR_MAX_GEOM][3], gquat[MIR_MAX_GEOM][4];
-  int cand[G];                 // candidate pair ids after the broadphase (ordered)
-  int ccount[G];               // contacts produced by candidate k
-  float stage[G][8][4];        // narrowphase output per candidate: pos, dist
-  float snorm[G][3];           // normal per candidate
-  int ncon, ncand, nlim_dummy, niter;
-  // contacts
-  float cpos[MAXCON][3], cnrm[MAXCON][3], ct1[MAXCON][3], ct2[MAXCON][3];
-  float cdist[MAXCON], cmu[MAXCON], cD[MAXCON];
-  int cb1[MAXCON], cb2[MAXCON];
-  float caref[MAXCON][4], cjar[MAXCON][4], cjv[MAXCON][4];
-  float cfb[MAXCON][3], cW[MAXCON][6];
-  float Jb[MAXCON][3][MST];
-  // joint-limit rows (lane i = dof i)
-  float lsign[G], lD[G], laref[G], ljar[G], ljv[G], lf[G];
+  float qas[G], srch[G];
+  float xpos[G][4], xquat[G][4];
+  float cdof[G][8];               // ang(3) pad lin(3) pad
+  float M[G][MSTR];
+  int ncon, ncand, pad0, pad1;
+  union {
+    DynScratch dyn;
+    struct {
+      ContactArrays con;
+      union {
+        float Jb[MAXCON][JST];
+        ColScratch col;
+      };
+    };
+  };
 };
 
 // ---------------------------------------------------------------------------------------------
 // narrowphase primitives (one lane per candidate pair)
-
 struct BoxG {
   V3 p;
   V3 a0, a1, a2;  // world axes
@@ -185,8 +263,9 @@ __device__ int plane_box(V3 pp, const M3& Rp, const BoxG& bx, float (*out)[4], V
   return k;
 }
 
-// box-box by separating axes + reference-face clipping; normal from A to B; up to 8 points
-__device__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4], V3& nout) {
+// box-box by separating axes + reference-face clipping; normal from A to B; up to 8 points.
+// Rare (only when bounding spheres overlap) and register-hungry: kept out of line.
+__device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4], V3& nout) {
   V3 t = B.p - A.p;
   float best = -1e30f;
   int code = -1;
@@ -234,7 +313,6 @@ __device__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4], V3& nout) 
     out[0][0] = pos.x; out[0][1] = pos.y; out[0][2] = pos.z; out[0][3] = best;
     return 1;
   }
-  // reference / incident boxes
   const bool refA = code < 3;
   const BoxG& R = refA ? A : B;
   const BoxG& I = refA ? B : A;
@@ -309,88 +387,75 @@ __device__ __forceinline__ float impedance(float dmin, float dmax, float width, 
   return dmin + y * (dmax - dmin);
 }
 
-// in-place Cholesky of the nv x nv SPD matrix A (LDS, row stride MST) by the 16 lanes of a group,
-// lane = row.  Lower triangle holds L on exit.
-__device__ __forceinline__ void group_chol(float (*A)[MST], int nv, int lane) {
-  for (int k = 0; k < nv; k++) {
-    float akk = A[k][k];
-    float piv = sqrtf(fmaxf(akk, 1e-30f));
-    float lik = 0.0f;
-    if (lane > k && lane < nv) lik = A[lane][k] / piv;
-    __syncthreads();
-    if (lane == k) A[k][k] = piv;
-    if (lane > k && lane < nv) A[lane][k] = lik;
-    __syncthreads();
-    if (lane > k && lane < nv) {
-      for (int j = k + 1; j <= lane; j++) A[lane][j] -= lik * A[j][k];
-    }
-    __syncthreads();
-  }
-}
-// solve L L^T x = b; x, b in LDS vectors (x may alias b); lane = row
-__device__ __forceinline__ void group_cholsolve(float (*L)[MST], int nv, int lane, float* x) {
-  for (int k = 0; k < nv; k++) {
-    float yk = x[k] / L[k][k];
-    __syncthreads();
-    if (lane == k) x[k] = yk;
-    if (lane > k && lane < nv) x[lane] -= L[lane][k] * yk;
-    __syncthreads();
-  }
-  for (int k = nv - 1; k >= 0; k--) {
-    float xk = x[k] / L[k][k];
-    __syncthreads();
-    if (lane == k) x[k] = xk;
-    if (lane < k) x[lane] -= L[k][lane] * xk;
-    __syncthreads();
-  }
-}
-
+// body-lane constants needed by forward kinematics
+struct BodyK {
+  int jtype, qadr;
+  V3 pos, axis;
+  Q4 quat;
+};
 
 // forward kinematics of one env group: local joint transforms, then every body composes its own
-// ancestor chain (leaf -> root) independently; two phases, no depth-serial barriers
-template <int MAXCON>
-__device__ __forceinline__ void group_fk(EnvLds<MAXCON>& S, const DevModel* __restrict__ m, int lane, int nb, int b_parent,
-                                         int b_jtype, int b_qadr, V3 b_pos, Q4 b_quat, V3 b_axis) {
+// ancestor chain (leaf -> root) independently; two phases, no depth-serial barriers.  `parents`
+// packs the 16 parent indices, 4 bits each.
+__device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t parents, const BodyK& k) {
   if (lane > 0 && lane < nb) {
-    Q4 ql = b_quat;
-    V3 pl = b_pos;
-    if (b_jtype == MIR_JNT_REVOLUTE) {
-      float ang = S.qpos[b_qadr], sn, cs;
+    Q4 ql = k.quat;
+    V3 pl = k.pos;
+    if (k.jtype == MIR_JNT_REVOLUTE) {
+      float ang = S.qpos[k.qadr], sn, cs;
       sincosf(0.5f * ang, &sn, &cs);
-      ql = qmul(b_quat, Q4{cs, b_axis.x * sn, b_axis.y * sn, b_axis.z * sn});
-    } else if (b_jtype == MIR_JNT_PRISMATIC) {
-      pl = b_pos + qrot(b_quat, S.qpos[b_qadr] * b_axis);
-    } else if (b_jtype == MIR_JNT_FREE) {
-      pl = ld3(&S.qpos[b_qadr]);
-      ql = qnormalize(ld4(&S.qpos[b_qadr + 3]));
+      ql = qmul(k.quat, Q4{cs, k.axis.x * sn, k.axis.y * sn, k.axis.z * sn});
+    } else if (k.jtype == MIR_JNT_PRISMATIC) {
+      pl = k.pos + qrot(k.quat, S.qpos[k.qadr] * k.axis);
+    } else if (k.jtype == MIR_JNT_FREE) {
+      pl = ld3(&S.qpos[k.qadr]);
+      ql = qnormalize(ld4(&S.qpos[k.qadr + 3]));
     }
-    st3(S.lpos[lane], pl);
-    st4(S.lquat[lane], ql);
+    st3v(S.dyn.lpos[lane], pl);
+    st4v(S.dyn.lquat[lane], ql);
   } else if (lane == 0) {
-    st3(S.lpos[0], v3(0, 0, 0));
-    st4(S.lquat[0], Q4{1, 0, 0, 0});
+    st3v(S.dyn.lpos[0], v3(0, 0, 0));
+    st4v(S.dyn.lquat[0], Q4{1, 0, 0, 0});
   }
-  __syncthreads();
+  WSYNC();
   if (lane < nb) {
-    V3 P = ld3(S.lpos[lane]);
-    Q4 Qx = ld4(S.lquat[lane]);
-    int anc = lane > 0 ? b_parent : -1;
+    V3 P = ld3v(S.dyn.lpos[lane]);
+    Q4 Qx = ld4v(S.dyn.lquat[lane]);
+    int anc = lane > 0 ? (int)((parents >> (4 * lane)) & 15u) : 0;
     while (anc > 0) {
-      Q4 qa = ld4(S.lquat[anc]);
-      P = ld3(S.lpos[anc]) + qrot(qa, P);
+      Q4 qa = ld4v(S.dyn.lquat[anc]);
+      P = ld3v(S.dyn.lpos[anc]) + qrot(qa, P);
       Qx = qmul(qa, Qx);
-      anc = m->b_parent[anc];
+      anc = (int)((parents >> (4 * anc)) & 15u);
     }
-    st3(S.xpos[lane], P);
-    st4(S.xquat[lane], Qx);
+    st3v(S.xpos[lane], P);
+    st4v(S.xquat[lane], Qx);
   }
-  __syncthreads();
+  WSYNC();
+}
+
+// dot of a register row with a 16-float LDS vector (4 broadcast b128 reads)
+__device__ __forceinline__ float rowdot(const float (&r)[G], const float* x) {
+  f4 x0 = ldv(x), x1 = ldv(x + 4), x2 = ldv(x + 8), x3 = ldv(x + 12);
+  return r[0] * x0.x + r[1] * x0.y + r[2] * x0.z + r[3] * x0.w + r[4] * x1.x + r[5] * x1.y + r[6] * x1.z + r[7] * x1.w +
+         r[8] * x2.x + r[9] * x2.y + r[10] * x2.z + r[11] * x2.w + r[12] * x3.x + r[13] * x3.y + r[14] * x3.z + r[15] * x3.w;
+}
+// the three base-row dots (normal, t1, t2) of contact Jacobian block `jb` with a 16-float LDS vector
+__device__ __forceinline__ void jdot3(const float* jb, const float* x, float& dn, float& d1, float& d2) {
+  dn = d1 = d2 = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    f4 xv = ldv(x + 4 * q);
+    f4 a = ldv(jb + 4 * q), b = ldv(jb + 16 + 4 * q), c = ldv(jb + 32 + 4 * q);
+    dn += a.x * xv.x + a.y * xv.y + a.z * xv.z + a.w * xv.w;
+    d1 += b.x * xv.x + b.y * xv.y + b.z * xv.z + b.w * xv.w;
+    d2 += c.x * xv.x + c.y * xv.y + c.z * xv.z + c.w * xv.w;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int MAXCON>
 __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
-  __shared__ EnvLds<MAXCON> s_env[EPB];
+  __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
   const DevModel* __restrict__ m = a.model;
   const int tid = threadIdx.x;
   const int lane = tid & (G - 1);
@@ -398,23 +463,30 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   const int env_raw = blockIdx.x * EPB + grp;
   const bool valid = env_raw < a.B;
   const int env = valid ? env_raw : a.B - 1;
-  EnvLds<MAXCON>& S = s_env[grp];
+  EnvLds& S = s_env[grp];
 
-  const int nb = m->nbody, nv = m->nv, nq = m->nq, qst = m->qstride;
+  const int nb = m->nbody, nv = m->nv, qst = m->qstride;
   const float dt = m->dt;
 
   // ---- per-lane model constants (lane = body = dof) -------------------------------------------
   const bool isbody = lane < nb && lane > 0;
   const bool isdof = lane < nv;
-  const int b_parent = m->b_parent[lane], b_jtype = m->b_jtype[lane], b_qadr = m->b_qadr[lane], b_dofadr = m->b_dofadr[lane];
+  uint64_t parents = 0;
+  for (int b = 1; b < nb; b++) parents |= (uint64_t)(m->b_parent[b] & 15) << (4 * b);
+  BodyK bk;
+  bk.jtype = m->b_jtype[lane]; bk.qadr = m->b_qadr[lane];
+  bk.pos = ld3(m->b_pos[lane]); bk.axis = ld3(m->b_axis[lane]); bk.quat = ld4(m->b_quat[lane]);
   const int b_root = m->b_root[lane];
   const uint32_t b_dofmask = m->b_dofmask[lane], b_submask = m->b_submask[lane];
-  const V3 b_pos = ld3(m->b_pos[lane]), b_axis = ld3(m->b_axis[lane]), b_ipos = ld3(m->b_ipos[lane]);
-  const Q4 b_quat = ld4(m->b_quat[lane]);
+  const V3 b_ipos = ld3(m->b_ipos[lane]);
   const float b_mass = m->b_mass[lane];
-  const int d_body = m->d_body[lane], d_kind = m->d_kind[lane], d_qadr = m->d_qadr[lane], d_axis_k = m->d_axis_k[lane];
-  const uint32_t d_premask = m->d_premask[lane], d_ancmask = m->d_ancmask[lane];
-  const int d_ctrl = m->d_ctrl[lane], d_uadr = m->d_uadr[lane], d_limited = m->d_limited[lane];
+  const int d_body = isdof ? m->d_body[lane] : 0;
+  const int d_kind = m->d_kind[lane], d_qadr = m->d_qadr[lane], d_axis_k = m->d_axis_k[lane];
+  const int d_root = m->b_root[d_body];
+  const V3 d_axis = ld3(m->b_axis[d_body]);
+  const uint32_t d_premask = m->d_premask[lane], d_ancmask = m->d_ancmask[lane], d_submask = m->b_submask[d_body];
+  const int d_ctrl = m->d_ctrl[lane], d_uadr = m->d_uadr[lane];
+  const bool d_limited = isdof && m->d_limited[lane] && m->enable_joint_limit;
   const float d_damping = m->d_damping[lane], d_kp = m->d_kp[lane], d_kv = m->d_kv[lane];
   const float d_frclo = m->d_frclo[lane], d_frchi = m->d_frchi[lane], d_mdiag = m->d_mdiag[lane];
 
@@ -428,19 +500,21 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     S.target[lane] = tg;
     if (a.action && valid) a.target[(size_t)env * G + lane] = tg;
   }
-  if (lane == 0) { S.ncon = 0; S.ncand = 0; S.niter = 0; }
-  __syncthreads();
+  if (lane == 0) { S.ncon = 0; S.ncand = 0; }
+  WSYNC();
 
   const int nsteps = a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0);
   for (int step = 0; step < nsteps; step++) {
+    STAMP(0);
     // ======================= forward kinematics =================================================
-    group_fk(S, m, lane, nb, b_parent, b_jtype, b_qadr, b_pos, b_quat, b_axis);
+    group_fk(S, lane, nb, parents, bk);
+    STAMP(1);
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
     if (isdof) {
       V3 ang = v3(0, 0, 0), lin = v3(0, 0, 0);
-      V3 r = ld3(S.xpos[m->b_root[d_body]]) - ld3(S.xpos[d_body]);
+      V3 r = ld3v(S.xpos[d_root]) - ld3v(S.xpos[d_body]);
       if (d_kind < 2) {
-        V3 ax = qrot(ld4(S.xquat[d_body]), ld3(m->b_axis[d_body]));
+        V3 ax = qrot(ld4v(S.xquat[d_body]), d_axis);
         if (d_kind == 0) { ang = ax; lin = cross(ax, r); }
         else lin = ax;
       } else {
@@ -448,14 +522,12 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         if (d_kind == 2) lin = e;
         else { ang = e; lin = cross(e, r); }
       }
-      st3(&S.cdof[lane][0], ang);
-      st3(&S.cdof[lane][3], lin);
+      st3v(&S.cdof[lane][0], ang);
+      st3v(&S.cdof[lane][4], lin);
     }
     if (isbody) {
-      Q4 q = ld4(S.xquat[lane]);
-      M3 R = q2m(q);
+      M3 R = q2m(ld4v(S.xquat[lane]));
       const float* ib = m->b_inertia[lane];
-      // W = R Ib R^T
       float Ib[3][3] = {{ib[0], ib[3], ib[4]}, {ib[3], ib[1], ib[5]}, {ib[4], ib[5], ib[2]}};
       float Rm[3][3] = {{R.r0.x, R.r0.y, R.r0.z}, {R.r1.x, R.r1.y, R.r1.z}, {R.r2.x, R.r2.y, R.r2.z}};
       float T[3][3], W[3][3];
@@ -467,69 +539,62 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) W[i][j] = T[i][0] * Rm[j][0] + T[i][1] * Rm[j][1] + T[i][2] * Rm[j][2];
-      V3 xip = ld3(S.xpos[lane]) + mmul(R, b_ipos);
-      V3 r = xip - ld3(S.xpos[b_root]);
+      V3 r = ld3v(S.xpos[lane]) + mmul(R, b_ipos) - ld3v(S.xpos[b_root]);
       float rr = dot(r, r);
-      float* c = S.cinert[lane];
-      c[0] = b_mass; c[1] = b_mass * r.x; c[2] = b_mass * r.y; c[3] = b_mass * r.z;
-      c[4] = W[0][0] + b_mass * (rr - r.x * r.x);
-      c[5] = W[1][1] + b_mass * (rr - r.y * r.y);
-      c[6] = W[2][2] + b_mass * (rr - r.z * r.z);
-      c[7] = W[0][1] - b_mass * r.x * r.y;
-      c[8] = W[0][2] - b_mass * r.x * r.z;
-      c[9] = W[1][2] - b_mass * r.y * r.z;
+      float* c = S.dyn.cinert[lane];
+      stv(c, f4{b_mass, b_mass * r.x, b_mass * r.y, b_mass * r.z});
+      stv(c + 4, f4{W[0][0] + b_mass * (rr - r.x * r.x), W[1][1] + b_mass * (rr - r.y * r.y), W[2][2] + b_mass * (rr - r.z * r.z),
+                    W[0][1] - b_mass * r.x * r.y});
+      stv(c + 8, f4{W[0][2] - b_mass * r.x * r.z, W[1][2] - b_mass * r.y * r.z, 0.0f, 0.0f});
     } else {
-#pragma unroll
-      for (int k = 0; k < 10; k++) S.cinert[lane][k] = 0.0f;
+      float* c = S.dyn.cinert[lane];
+      stv(c, f4{0, 0, 0, 0}); stv(c + 4, f4{0, 0, 0, 0}); stv(c + 8, f4{0, 0, 0, 0});
     }
-    __syncthreads();
+    WSYNC();
 
     // ======================= velocities, composite inertias =====================================
     {
-      // lane = dof: cdof_dot * qvel, with "velocity before this dof" from the pre-mask
-      V3 pw = v3(0, 0, 0), pv = v3(0, 0, 0);
-      if (isdof) {
+      if (isdof) {  // lane = dof: cdof_dot * qvel, "velocity before this dof" from the pre-mask
+        V3 pw = v3(0, 0, 0), pv = v3(0, 0, 0);
         uint32_t mk = d_premask;
         while (mk) {
           int j = __ffs(mk) - 1;
           mk &= mk - 1;
           float qd = S.qvel[j];
-          pw = pw + qd * ld3(&S.cdof[j][0]);
-          pv = pv + qd * ld3(&S.cdof[j][3]);
+          pw = pw + qd * ld3v(&S.cdof[j][0]);
+          pv = pv + qd * ld3v(&S.cdof[j][4]);
         }
-        V3 cw = ld3(&S.cdof[lane][0]), cv = ld3(&S.cdof[lane][3]);
+        V3 cw = ld3v(&S.cdof[lane][0]), cv = ld3v(&S.cdof[lane][4]);
         float qd = S.qvel[lane];
-        st3(&S.cddq[lane][0], qd * cross(pw, cw));
-        st3(&S.cddq[lane][3], qd * (cross(pw, cv) + cross(pv, cw)));
+        st3v(&S.dyn.cddq[lane][0], qd * cross(pw, cw));
+        st3v(&S.dyn.cddq[lane][4], qd * (cross(pw, cv) + cross(pv, cw)));
       }
-      // lane = body: cvel, crb
       V3 w = v3(0, 0, 0), v = v3(0, 0, 0);
-      float acc[10];
-#pragma unroll
-      for (int k = 0; k < 10; k++) acc[k] = 0.0f;
-      if (isbody) {
+      f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0;
+      if (isbody) {  // lane = body: cvel, composite inertia over the subtree
         uint32_t mk = b_dofmask;
         while (mk) {
           int j = __ffs(mk) - 1;
           mk &= mk - 1;
           float qd = S.qvel[j];
-          w = w + qd * ld3(&S.cdof[j][0]);
-          v = v + qd * ld3(&S.cdof[j][3]);
+          w = w + qd * ld3v(&S.cdof[j][0]);
+          v = v + qd * ld3v(&S.cdof[j][4]);
         }
         uint32_t sm = b_submask;
         while (sm) {
           int c = __ffs(sm) - 1;
           sm &= sm - 1;
-#pragma unroll
-          for (int k = 0; k < 10; k++) acc[k] += S.cinert[c][k];
+          const float* p = S.dyn.cinert[c];
+          c0 += ldv(p); c1 += ldv(p + 4); c2 += ldv(p + 8);
         }
       }
-      st3(&S.cvel[lane][0], w);
-      st3(&S.cvel[lane][3], v);
-#pragma unroll
-      for (int k = 0; k < 10; k++) S.crb[lane][k] = acc[k];
+      st3v(&S.dyn.cvel[lane][0], w);
+      st3v(&S.dyn.cvel[lane][4], v);
+      float* p = S.dyn.crb[lane];
+      stv(p, c0); stv(p + 4, c1); stv(p + 8, c2);
     }
-    __syncthreads();
+    WSYNC();
+    STAMP(2);
 
     // ======================= body forces (RNE, qacc=0) and mass matrix rows =======================
     {
@@ -540,85 +605,98 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         while (mk) {
           int j = __ffs(mk) - 1;
           mk &= mk - 1;
-          aw = aw + ld3(&S.cddq[j][0]);
-          av = av + ld3(&S.cddq[j][3]);
+          aw = aw + ld3v(&S.dyn.cddq[j][0]);
+          av = av + ld3v(&S.dyn.cddq[j][4]);
         }
-        Inert I = ldI(S.cinert[lane]);
-        V3 w = ld3(&S.cvel[lane][0]), v = ld3(&S.cvel[lane][3]);
+        Inert I = ldI(S.dyn.cinert[lane]);
+        V3 w = ld3v(&S.dyn.cvel[lane][0]), v = ld3v(&S.dyn.cvel[lane][4]);
         V3 ta, fa, tv, fv;
         imul(I, aw, av, ta, fa);
         imul(I, w, v, tv, fv);
         t = ta + cross(w, tv) + cross(v, fv);
         f = fa + cross(w, fv);
       }
-      st3(&S.cfrc[lane][0], t);
-      st3(&S.cfrc[lane][3], f);
-      // mass matrix row (lane = dof i): M[i][j] = cdof_j . (crb_body(i) cdof_i), j in ancestors-or-self
+      st3v(&S.dyn.cfrc[lane][0], t);
+      st3v(&S.dyn.cfrc[lane][4], f);
+      // zero this lane's row of M, then (after the fence) fill the tree-sparse entries
 #pragma unroll
-      for (int j = 0; j < G; j++) S.M[lane][j] = 0.0f;
+      for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{0, 0, 0, 0});
     }
-    __syncthreads();
-    if (isdof) {
-      Inert I = ldI(S.crb[d_body]);
+    WSYNC();
+    if (isdof) {  // M[i][j] = cdof_j . (crb_body(i) cdof_i), j over ancestors-or-self
+      Inert I = ldI(S.dyn.crb[d_body]);
       V3 bt, bf;
-      imul(I, ld3(&S.cdof[lane][0]), ld3(&S.cdof[lane][3]), bt, bf);
+      imul(I, ld3v(&S.cdof[lane][0]), ld3v(&S.cdof[lane][4]), bt, bf);
       uint32_t mk = d_ancmask;
       while (mk) {
         int j = __ffs(mk) - 1;
         mk &= mk - 1;
-        float val = dot(ld3(&S.cdof[j][0]), bt) + dot(ld3(&S.cdof[j][3]), bf);
+        float val = dot(ld3v(&S.cdof[j][0]), bt) + dot(ld3v(&S.cdof[j][4]), bf);
         if (j == lane) val += d_mdiag;
         S.M[lane][j] = val;
         S.M[j][lane] = val;
       }
     }
     // bias + smooth force (lane = dof)
-    float qfrc_bias = 0.0f;
+    float qfrc_bias = 0.0f, qfs = 0.0f;
     if (isdof) {
       V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
-      uint32_t sm = m->b_submask[d_body];
+      uint32_t sm = d_submask;
       while (sm) {
         int c = __ffs(sm) - 1;
         sm &= sm - 1;
-        t = t + ld3(&S.cfrc[c][0]);
-        f = f + ld3(&S.cfrc[c][3]);
+        t = t + ld3v(&S.dyn.cfrc[c][0]);
+        f = f + ld3v(&S.dyn.cfrc[c][4]);
       }
-      qfrc_bias = dot(ld3(&S.cdof[lane][0]), t) + dot(ld3(&S.cdof[lane][3]), f);
+      qfrc_bias = dot(ld3v(&S.cdof[lane][0]), t) + dot(ld3v(&S.cdof[lane][4]), f);
       float qd = S.qvel[lane];
       float fa = 0.0f;
       if (d_ctrl == MIR_CTRL_POSITION) {
         fa = d_kp * (S.target[lane] - S.qpos[d_qadr]) - d_kv * qd;
         fa = fminf(fmaxf(fa, d_frclo), d_frchi);
       }
-      float qs = -d_damping * qd + fa - qfrc_bias;
-      S.qfs[lane] = qs;
-      S.qas[lane] = qs;
-    } else {
-      S.qfs[lane] = 0.0f;
-      S.qas[lane] = 0.0f;
+      qfs = -d_damping * qd + fa - qfrc_bias;
     }
-    __syncthreads();
+    WSYNC();
+    STAMP(3);
+    // qacc_smooth = Mt^-1 qfrc_smooth: Gauss-Jordan on register rows
+    float mrow[G];
+    {
+      f4 r0 = ldv(&S.M[lane][0]), r1 = ldv(&S.M[lane][4]), r2 = ldv(&S.M[lane][8]), r3 = ldv(&S.M[lane][12]);
+      mrow[0] = r0.x; mrow[1] = r0.y; mrow[2] = r0.z; mrow[3] = r0.w; mrow[4] = r1.x; mrow[5] = r1.y; mrow[6] = r1.z; mrow[7] = r1.w;
+      mrow[8] = r2.x; mrow[9] = r2.y; mrow[10] = r2.z; mrow[11] = r2.w; mrow[12] = r3.x; mrow[13] = r3.y; mrow[14] = r3.z; mrow[15] = r3.w;
+    }
     if (a.out_M && valid && isdof && step == 0) {
-      for (int j = 0; j < nv; j++) a.out_M[((size_t)env * nv + lane) * nv + j] = S.M[lane][j] - (j == lane ? d_mdiag - m->d_armature[lane] : 0.0f);
+#pragma unroll
+      for (int j = 0; j < G; j++)
+        if (j < nv) a.out_M[((size_t)env * nv + lane) * nv + j] = mrow[j] - (j == lane ? d_mdiag - m->d_armature[lane] : 0.0f);
     }
     if (a.out_bias && valid && isdof && step == 0) a.out_bias[(size_t)env * nv + lane] = qfrc_bias;
-    // qacc_smooth = Mt^-1 qfrc_smooth : factor a copy (H) and solve in place in qas
+    float qas;
+    {
+      float arow[G];
 #pragma unroll
-    for (int j = 0; j < G; j++) S.H[lane][j] = S.M[lane][j];
-    __syncthreads();
-    group_chol(S.H, nv, lane);
-    group_cholsolve(S.H, nv, lane, S.qas);
-    if (a.out_qas && valid && isdof && step == 0) a.out_qas[(size_t)env * nv + lane] = S.qas[lane];
+      for (int j = 0; j < G; j++) arow[j] = isdof ? mrow[j] : (j == lane ? 1.0f : 0.0f);
+      qas = isdof ? qfs : 0.0f;
+      GJ<0>::run(arow, qas, lane);
+    }
+    S.qas[lane] = qas;
+    S.qacc[lane] = qas;
+    if (a.out_qas && valid && isdof && step == 0) a.out_qas[(size_t)env * nv + lane] = qas;
+    WSYNC();  // dyn scratch is dead from here on
+    STAMP(4);
 
     // ======================= collision detection ================================================
     if (lane == 0) { S.ncon = 0; S.ncand = 0; }
     for (int g = lane; g < m->ngeom; g += G) {
       int gb = m->g_body[g];
-      Q4 qb = ld4(S.xquat[gb]);
-      st3(S.gpos[g], ld3(S.xpos[gb]) + qrot(qb, ld3(m->g_pos[g])));
-      st4(S.gquat[g], qmul(qb, ld4(m->g_quat[g])));
+      Q4 qb = ld4v(S.xquat[gb]);
+      st3v(S.col.gpos[g], ld3v(S.xpos[gb]) + qrot(qb, ld3(m->g_pos[g])));
+      st4v(S.col.gquat[g], qmul(qb, ld4(m->g_quat[g])));
     }
-    __syncthreads();
+    WSYNC();
+    int mycount = 0;
+    int myp = 0;
     if (m->enable_collision) {
       // broadphase: bounding test per static candidate pair, ordered compaction of survivors
       int base = 0;
@@ -628,321 +706,294 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         if (p < m->npair) {
           int g1 = m->p_g1[p], g2 = m->p_g2[p];
           V3 h2 = ld3(m->g_size[g2]);
-          M3 R2 = q2m(ld4(S.gquat[g2]));
-          V3 c2 = ld3(S.gpos[g2]);
+          M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+          V3 c2 = ld3v(S.col.gpos[g2]);
           if (m->g_type[g1] == MIR_GEOM_PLANE) {
-            V3 n = mcol(q2m(ld4(S.gquat[g1])), 2);
+            V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
             float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
-            hit = dot(c2 - ld3(S.gpos[g1]), n) - ext < 0.0f;
+            hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
           } else {
             V3 h1 = ld3(m->g_size[g1]);
-            float r1 = sqrtf(dot(h1, h1)), r2 = sqrtf(dot(h2, h2));
-            V3 dc = c2 - ld3(S.gpos[g1]);
-            float rs = r1 + r2;
+            float rs = sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
+            V3 dc = c2 - ld3v(S.col.gpos[g1]);
             hit = dot(dc, dc) <= rs * rs;
           }
         }
         unsigned long long bal = __ballot(hit);
         uint32_t gm = (uint32_t)(bal >> (grp * G)) & 0xffffu;
         int pos = base + __popc(gm & ((1u << lane) - 1u));
-        if (hit && pos < G) S.cand[pos] = p;
+        if (hit && pos < G) S.col.cand[pos] = p;
         base += __popc(gm);
       }
-      if (lane == 0) S.ncand = base < G ? base : G;
-      __syncthreads();
+      const int ncand = base < G ? base : G;
+      if (lane == 0) S.ncand = ncand;
+      WSYNC();
       // narrowphase: lane k handles candidate k
-      const int ncand = S.ncand;
-      int mycount = 0;
       if (lane < ncand) {
-        int p = S.cand[lane];
+        int p = S.col.cand[lane];
+        myp = p;
         int g1 = m->p_g1[p], g2 = m->p_g2[p];
-        M3 R2 = q2m(ld4(S.gquat[g2]));
-        BoxG B2 = {ld3(S.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(m->g_size[g2])};
+        M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+        BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(m->g_size[g2])};
         V3 n = v3(0, 0, 1);
+        M3 R1 = q2m(ld4v(S.col.gquat[g1]));
         if (m->g_type[g1] == MIR_GEOM_PLANE) {
-          M3 R1 = q2m(ld4(S.gquat[g1]));
-          mycount = plane_box(ld3(S.gpos[g1]), R1, B2, S.stage[lane], n);
+          mycount = plane_box(ld3v(S.col.gpos[g1]), R1, B2, S.col.stage[lane], n);
         } else {
-          M3 R1 = q2m(ld4(S.gquat[g1]));
-          BoxG B1 = {ld3(S.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(m->g_size[g1])};
-          mycount = box_box(B1, B2, S.stage[lane], n);
+          BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(m->g_size[g1])};
+          mycount = box_box(B1, B2, S.col.stage[lane], n);
         }
-        st3(S.snorm[lane], n);
+        st3v(S.col.snorm[lane], n);
       }
-      // ordered compaction of contact points (exclusive prefix over candidates, 16-wide scan)
+    }
+    // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
+    const int maxc = m->max_contacts < MAXCON ? m->max_contacts : MAXCON;
+    {
       int incl = mycount;
 #pragma unroll
       for (int o = 1; o < G; o <<= 1) {
         int up = __shfl_up(incl, o, G);
         if (lane >= o) incl += up;
       }
-      int off = incl - mycount;
-      int total = __shfl(incl, G - 1, G);
-      const int maxc = m->max_contacts < MAXCON ? m->max_contacts : MAXCON;
+      const int off = incl - mycount;
+      const int total = __shfl(incl, G - 1, G);
       if (lane == 0) S.ncon = total < maxc ? total : maxc;
-      if (lane < ncand) {
-        int p = S.cand[lane];
-        int g1 = m->p_g1[p], g2 = m->p_g2[p];
-        V3 n = ld3(S.snorm[lane]);
-        // contact frame (same construction as the oracle)
-        V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);
+      if (mycount > 0) {
+        const int g1 = m->p_g1[myp], g2 = m->p_g2[myp];
+        const V3 n = ld3v(S.col.snorm[lane]);
+        V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
         t1 = t1 - dot(n, t1) * n;
         t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
-        V3 t2 = cross(n, t1);
-        float mu = fmaxf(m->g_friction[g1], m->g_friction[g2]);
-        float sr0 = 0.5f * (m->g_solref[g1][0] + m->g_solref[g2][0]), sr1 = 0.5f * (m->g_solref[g1][1] + m->g_solref[g2][1]);
+        const V3 t2 = cross(n, t1);
+        const float mu = fmaxf(m->g_friction[g1], m->g_friction[g2]);
+        const float sr0 = 0.5f * (m->g_solref[g1][0] + m->g_solref[g2][0]), sr1 = 0.5f * (m->g_solref[g1][1] + m->g_solref[g2][1]);
         float si[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) si[k] = 0.5f * (m->g_solimp[g1][k] + m->g_solimp[g2][k]);
-        int b1 = m->g_body[g1], b2 = m->g_body[g2];
-        float wsum = m->b_invweight0[b1] + m->b_invweight0[b2];
-        float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
-        float tc = fmaxf(sr0, 2.0f * dt);
-        float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
+        const int b1 = m->g_body[g1], b2 = m->g_body[g2];
+        const float wsum = m->b_invweight0[b1] + m->b_invweight0[b2];
+        const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
+        const float tc = fmaxf(sr0, 2.0f * dt);
+        const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
+        const uint32_t dm1 = m->b_dofmask[b1], dm2 = m->b_dofmask[b2];
+        const uint32_t inv = dm1 | dm2;
+        const uint32_t chunks = ((inv & 0xfu) ? 1u : 0u) | ((inv & 0xf0u) ? 2u : 0u) | ((inv & 0xf00u) ? 4u : 0u) | ((inv & 0xf000u) ? 8u : 0u);
+        const V3 ref1 = ld3v(S.xpos[m->b_root[b1]]), ref2 = ld3v(S.xpos[m->b_root[b2]]);
+        // staging lives in col scratch, which does not overlap the contact arrays
         for (int c = 0; c < mycount; c++) {
-          int k = off + c;
+          const int k = off + c;
           if (k >= maxc) break;
-          float dist = S.stage[lane][c][3];
-          st3(S.cpos[k], ld3(S.stage[lane][c]));
-          st3(S.cnrm[k], n); st3(S.ct1[k], t1); st3(S.ct2[k], t2);
-          S.cdist[k] = dist; S.cmu[k] = mu; S.cb1[k] = b1; S.cb2[k] = b2;
-          float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
-          float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
-          S.cD[k] = 1.0f / Rr;
-          // aref needs the row velocities: store -k*imp*dist now, velocity term added after Jb is built
-          S.caref[k][0] = -kk * imp * dist;
-          S.caref[k][1] = bb;  // stash b
+          const f4 pd = ldv(S.col.stage[lane][c]);
+          const float dist = pd.w;
+          stv(S.con.cpos[k], pd);
+          st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
+          const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
+          const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
+          stv(S.con.cmeta[k], f4{mu, 1.0f / Rr, -kk * imp * dist, bb});
+          st3v(&S.con.cref[k][0], ref1); st3v(&S.con.cref[k][4], ref2);
+          S.con.cmask[k][0] = dm1; S.con.cmask[k][1] = dm2; S.con.cmask[k][2] = chunks; S.con.cmask[k][3] = 0u;
         }
       }
-      __syncthreads();
     }
+    WSYNC();  // col scratch is dead from here on (Jb may overwrite it)
     const int ncon = S.ncon;
+    STAMP(5);
 
     // ======================= constraint rows ======================================================
-    // contact base Jacobians: lane = dof; Jb[c][r][i], r = normal, t1, t2
+    // contact base Jacobians: lane = dof; Jb[c][r*16 + i], r = normal, t1, t2
     for (int c = 0; c < ncon; c++) {
       float jn = 0.0f, j1 = 0.0f, j2 = 0.0f;
-      if (isdof) {
-        int b1 = S.cb1[c], b2 = S.cb2[c];
-        const bool in2 = m->b_dofmask[b2] >> lane & 1u, in1 = m->b_dofmask[b1] >> lane & 1u;
-        const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f);  // a dof moving both bodies cancels
-        const int bref = in2 ? b2 : b1;
-        if (sgn != 0.0f) {
-          V3 r = ld3(S.cpos[c]) - ld3(S.xpos[m->b_root[bref]]);
-          V3 vel = cross(ld3(&S.cdof[lane][0]), r) + ld3(&S.cdof[lane][3]);
-          jn = sgn * dot(vel, ld3(S.cnrm[c]));
-          j1 = sgn * dot(vel, ld3(S.ct1[c]));
-          j2 = sgn * dot(vel, ld3(S.ct2[c]));
-        }
+      const uint32_t dm1 = S.con.cmask[c][0], dm2 = S.con.cmask[c][1];
+      const bool in2 = dm2 >> lane & 1u, in1 = dm1 >> lane & 1u;
+      const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f);  // a dof moving both bodies cancels
+      if (sgn != 0.0f) {
+        V3 r = ld3v(S.con.cpos[c]) - ld3v(&S.con.cref[c][in2 ? 4 : 0]);
+        V3 vel = cross(ld3v(&S.cdof[lane][0]), r) + ld3v(&S.cdof[lane][4]);
+        jn = sgn * dot(vel, ld3v(&S.con.cfrm[c][0]));
+        j1 = sgn * dot(vel, ld3v(&S.con.cfrm[c][4]));
+        j2 = sgn * dot(vel, ld3v(&S.con.cfrm[c][8]));
       }
-      S.Jb[c][0][lane] = jn; S.Jb[c][1][lane] = j1; S.Jb[c][2][lane] = j2;
+      float* jb = &S.Jb[c][0];
+      jb[lane] = jn; jb[16 + lane] = j1; jb[32 + lane] = j2;
     }
-    // joint-limit rows: lane = dof
-    {
-      float sgn = 0.0f, D = 0.0f, aref = 0.0f;
-      if (isdof && d_limited && m->enable_joint_limit) {
-        float q = S.qpos[d_qadr];
-        float dlo = q - m->d_lo[lane], dhi = m->d_hi[lane] - q;
-        float pos = 0.0f;
-        if (dlo < 0.0f) { pos = dlo; sgn = 1.0f; }
-        else if (dhi < 0.0f) { pos = dhi; sgn = -1.0f; }
-        if (sgn != 0.0f) {
-          const float* si = m->d_solimp[lane];
-          float imp = impedance(si[0], si[1], si[2], si[3], si[4], pos);
-          float Rr = fmaxf((1.0f - imp) / imp * m->d_invweight0[lane], 1e-15f);
-          D = 1.0f / Rr;
-          aref = -m->d_b[lane] * (sgn * S.qvel[lane]) - m->d_k[lane] * imp * pos;
-        }
+    // joint-limit rows: lane = dof, lane-private
+    float lsg = 0.0f, lD = 0.0f, laref = 0.0f;
+    if (d_limited) {
+      float q = S.qpos[d_qadr];
+      float dlo = q - m->d_lo[lane], dhi = m->d_hi[lane] - q;
+      float pos = 0.0f;
+      if (dlo < 0.0f) { pos = dlo; lsg = 1.0f; }
+      else if (dhi < 0.0f) { pos = dhi; lsg = -1.0f; }
+      if (lsg != 0.0f) {
+        const float* si = m->d_solimp[lane];
+        float imp = impedance(si[0], si[1], si[2], si[3], si[4], pos);
+        float Rr = fmaxf((1.0f - imp) / imp * m->d_invweight0[lane], 1e-15f);
+        lD = 1.0f / Rr;
+        laref = -m->d_b[lane] * (lsg * S.qvel[lane]) - m->d_k[lane] * imp * pos;
       }
-      S.lsign[lane] = sgn; S.lD[lane] = D; S.laref[lane] = aref;
     }
-    __syncthreads();
-    // contact reference accelerations (lane = contact): aref_r = -b (J_r qvel) - k imp dist
-    if (lane < ncon) {
-      float vn = 0.0f, v1 = 0.0f, v2 = 0.0f;
-      for (int i = 0; i < nv; i++) {
-        float qd = S.qvel[i];
-        vn += S.Jb[lane][0][i] * qd; v1 += S.Jb[lane][1][i] * qd; v2 += S.Jb[lane][2][i] * qd;
-      }
-      float base = S.caref[lane][0], bb = S.caref[lane][1], mu = S.cmu[lane];
-      S.caref[lane][0] = base - bb * (vn + mu * v1);
-      S.caref[lane][1] = base - bb * (vn - mu * v1);
-      S.caref[lane][2] = base - bb * (vn + mu * v2);
-      S.caref[lane][3] = base - bb * (vn - mu * v2);
+    WSYNC();
+    // contact rows, lane = contact, lane-private: aref_r = -b (J_r qvel) - k imp dist
+    const bool iscon = lane < ncon;
+    float cmu = 0.0f, cD = 0.0f;
+    float aref[4] = {0, 0, 0, 0}, jar[4] = {0, 0, 0, 0};
+    if (iscon) {
+      float vn, v1, v2;
+      jdot3(&S.Jb[lane][0], S.qvel, vn, v1, v2);
+      f4 mt = ldv(S.con.cmeta[lane]);
+      cmu = mt.x; cD = mt.y;
+      const float base = mt.z, bb = mt.w;
+      aref[0] = base - bb * (vn + cmu * v1);
+      aref[1] = base - bb * (vn - cmu * v1);
+      aref[2] = base - bb * (vn + cmu * v2);
+      aref[3] = base - bb * (vn - cmu * v2);
     }
-    __syncthreads();
+    STAMP(6);
 
     // ======================= primal Newton solve ====================================================
-    const float lsg = S.lsign[lane];
     const uint32_t limmask = (uint32_t)(__ballot(lsg != 0.0f) >> (grp * G)) & 0xffffu;
     const int nefc = 4 * ncon + __popc(limmask);
     bool done = nefc == 0;
-    if (isdof) S.qacc[lane] = S.qas[lane];
-    __syncthreads();
-    if (!done) {
-      // warm start: cost(ws) vs cost(qacc_smooth)
-      float dq = isdof ? S.qacc_ws[lane] - S.qas[lane] : 0.0f;
+    float qacc = qas, Ma = 0.0f, ljar = 0.0f;
+    {
+      // warm start: cost(ws) vs cost(qacc_smooth); Gauss part 1/2 dq^T Mt dq
+      const float ws = S.qacc_ws[lane];
+      const float dq = isdof ? ws - qas : 0.0f;
       S.srch[lane] = dq;
-      __syncthreads();
-      float c_ws = 0.0f, c_sm = 0.0f;
-      if (isdof) {
-        float tsum = 0.0f;
-        for (int j = 0; j < nv; j++) tsum += S.M[lane][j] * S.srch[j];
-        c_ws += 0.5f * tsum * dq;
-        if (lsg != 0.0f) {
-          float js = lsg * S.qas[lane] - S.laref[lane], jw = lsg * S.qacc_ws[lane] - S.laref[lane];
-          if (js < 0.0f) c_sm += 0.5f * S.lD[lane] * js * js;
-          if (jw < 0.0f) c_ws += 0.5f * S.lD[lane] * jw * jw;
-        }
+      WSYNC();
+      float c_ws = 0.5f * rowdot(mrow, S.srch) * dq, c_sm = 0.0f;
+      const float ljs = lsg * qas - laref, ljw = lsg * ws - laref;
+      if (lsg != 0.0f) {
+        if (ljs < 0.0f) c_sm += 0.5f * lD * ljs * ljs;
+        if (ljw < 0.0f) c_ws += 0.5f * lD * ljw * ljw;
       }
-      if (lane < ncon) {
-        float sn = 0, s1 = 0, s2 = 0, wn = 0, w1 = 0, w2 = 0;
-        for (int i = 0; i < nv; i++) {
-          float as = S.qas[i], aw = S.qacc_ws[i];
-          float jn = S.Jb[lane][0][i], j1 = S.Jb[lane][1][i], j2 = S.Jb[lane][2][i];
-          sn += jn * as; s1 += j1 * as; s2 += j2 * as;
-          wn += jn * aw; w1 += j1 * aw; w2 += j2 * aw;
-        }
-        float mu = S.cmu[lane], D = S.cD[lane];
-        float xs[4] = {sn + mu * s1, sn - mu * s1, sn + mu * s2, sn - mu * s2};
-        float xw[4] = {wn + mu * w1, wn - mu * w1, wn + mu * w2, wn - mu * w2};
+      float js[4] = {0, 0, 0, 0}, jw[4] = {0, 0, 0, 0};
+      if (iscon) {
+        float sn, s1, s2, wn, w1, w2;
+        jdot3(&S.Jb[lane][0], S.qas, sn, s1, s2);
+        jdot3(&S.Jb[lane][0], S.qacc_ws, wn, w1, w2);
+        js[0] = sn + cmu * s1 - aref[0]; js[1] = sn - cmu * s1 - aref[1]; js[2] = sn + cmu * s2 - aref[2]; js[3] = sn - cmu * s2 - aref[3];
+        jw[0] = wn + cmu * w1 - aref[0]; jw[1] = wn - cmu * w1 - aref[1]; jw[2] = wn + cmu * w2 - aref[2]; jw[3] = wn - cmu * w2 - aref[3];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          float js = xs[r] - S.caref[lane][r], jw = xw[r] - S.caref[lane][r];
-          if (js < 0.0f) c_sm += 0.5f * D * js * js;
-          if (jw < 0.0f) c_ws += 0.5f * D * jw * jw;
+          if (js[r] < 0.0f) c_sm += 0.5f * cD * js[r] * js[r];
+          if (jw[r] < 0.0f) c_ws += 0.5f * cD * jw[r] * jw[r];
         }
       }
       c_ws = gsum(c_ws);
       c_sm = gsum(c_sm);
-      if (isdof) S.qacc[lane] = c_ws < c_sm ? S.qacc_ws[lane] : S.qas[lane];
+      const bool usews = c_ws < c_sm;
+      qacc = usews ? ws : qas;
+      ljar = usews ? ljw : ljs;
+#pragma unroll
+      for (int r = 0; r < 4; r++) jar[r] = usews ? jw[r] : js[r];
+      WSYNC();
+      S.qacc[lane] = qacc;
+      WSYNC();
+      Ma = isdof ? rowdot(mrow, S.qacc) : 0.0f;
     }
-    __syncthreads();
-    // Ma, jar at the starting point
-    {
-      float ma = 0.0f;
-      if (isdof)
-        for (int j = 0; j < nv; j++) ma += S.M[lane][j] * S.qacc[j];
-      S.Ma[lane] = ma;
-      S.ljar[lane] = lsg != 0.0f ? lsg * S.qacc[lane] - S.laref[lane] : 0.0f;
-      if (lane < ncon) {
-        float xn = 0, x1 = 0, x2 = 0;
-        for (int i = 0; i < nv; i++) {
-          float ai = S.qacc[i];
-          xn += S.Jb[lane][0][i] * ai; x1 += S.Jb[lane][1][i] * ai; x2 += S.Jb[lane][2][i] * ai;
-        }
-        float mu = S.cmu[lane];
-        S.cjar[lane][0] = xn + mu * x1 - S.caref[lane][0];
-        S.cjar[lane][1] = xn - mu * x1 - S.caref[lane][1];
-        S.cjar[lane][2] = xn + mu * x2 - S.caref[lane][2];
-        S.cjar[lane][3] = xn - mu * x2 - S.caref[lane][3];
-      }
-    }
-    __syncthreads();
+    STAMP(7);
     int niter = 0;
     const float tol = m->tolerance, scale = m->solver_scale;
     // float32 rounding floor of the gradient Ma - qfrc_smooth - J^T f: below it a Newton step no
     // longer changes qacc, so iterating further is noise (same rule as the oracle, with float eps)
-    const float gfloor = 16.0f * 5.96e-8f * sqrtf(gsum(isdof ? S.Ma[lane] * S.Ma[lane] + S.qfs[lane] * S.qfs[lane] : 0.0f));
+    const float gfloor = 16.0f * 5.96e-8f * sqrtf(gsum(Ma * Ma + qfs * qfs));
     for (int it = 0; it < m->iterations; it++) {
       if (!__any(!done)) break;
-      // forces and per-contact 3x3 weights
-      if (lane < ncon) {
-        float D = S.cD[lane], mu = S.cmu[lane];
-        float f[4], act[4];
+      // ---- forces of the active rows; base-force triple and active flags to LDS for the dof lanes
+      float lact = (lsg != 0.0f && ljar < 0.0f) ? lD : 0.0f;
+      const float lf = -lact * ljar;
+      if (iscon) {
+        float f[4];
+        unsigned bits = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          float x = S.cjar[lane][r];
-          act[r] = x < 0.0f ? D : 0.0f;
-          f[r] = -act[r] * x;
+          const bool on = jar[r] < 0.0f;
+          f[r] = on ? -cD * jar[r] : 0.0f;
+          bits |= on ? (1u << r) : 0u;
         }
-        S.cfb[lane][0] = f[0] + f[1] + f[2] + f[3];
-        S.cfb[lane][1] = mu * (f[0] - f[1]);
-        S.cfb[lane][2] = mu * (f[2] - f[3]);
-        S.cW[lane][0] = act[0] + act[1] + act[2] + act[3];      // nn
-        S.cW[lane][1] = mu * (act[0] - act[1]);                  // n t1
-        S.cW[lane][2] = mu * (act[2] - act[3]);                  // n t2
-        S.cW[lane][3] = mu * mu * (act[0] + act[1]);             // t1 t1
-        S.cW[lane][4] = mu * mu * (act[2] + act[3]);             // t2 t2
-        S.cW[lane][5] = 0.0f;                                    // t1 t2
+        stv(S.con.cfb[lane], f4{f[0] + f[1] + f[2] + f[3], cmu * (f[0] - f[1]), cmu * (f[2] - f[3]), (float)bits});
       }
-      float lact = 0.0f;
-      {
-        float x = S.ljar[lane];
-        lact = (lsg != 0.0f && x < 0.0f) ? S.lD[lane] : 0.0f;
-        S.lf[lane] = -lact * x;
-      }
-      __syncthreads();
-      // gradient and Hessian row (lane = dof)
+      WSYNC();
+      // ---- gradient and Hessian row (lane = dof): H = Mt + J^T D_active J, built per contact from
+      // the 3x3 weight of its pyramid in (n, t1, t2) coordinates
       float g = 0.0f;
       float hrow[G];
 #pragma unroll
-      for (int j = 0; j < G; j++) hrow[j] = S.M[lane][j];
-      if (isdof) {
-        g = S.Ma[lane] - S.qfs[lane] - lsg * S.lf[lane];
+      for (int j = 0; j < G; j++) hrow[j] = isdof ? mrow[j] + (j == lane ? lact : 0.0f) : (j == lane ? 1.0f : 0.0f);
+      if (isdof) g = Ma - qfs - lsg * lf;
+      if (a.prof && blockIdx.x == 0 && grp == 0 && it == 0) {  // debug: pre-contact rows
+        float* tr = reinterpret_cast<float*>(a.prof + 16 + 64) + 416;
 #pragma unroll
-        for (int j = 0; j < G; j++) hrow[j] += j == lane ? lact : 0.0f;  // limit rows are +-e_i: diagonal only
-        for (int c = 0; c < ncon; c++) {
-          float jn = S.Jb[c][0][lane], j1 = S.Jb[c][1][lane], j2 = S.Jb[c][2][lane];
-          g -= jn * S.cfb[c][0] + j1 * S.cfb[c][1] + j2 * S.cfb[c][2];
-          float w0 = S.cW[c][0], w1 = S.cW[c][1], w2 = S.cW[c][2], w3 = S.cW[c][3], w4 = S.cW[c][4];
-          float tn = jn * w0 + j1 * w1 + j2 * w2;
-          float t1 = jn * w1 + j1 * w3;
-          float t2 = jn * w2 + j2 * w4;
-          if (tn != 0.0f || t1 != 0.0f || t2 != 0.0f) {
+        for (int j = 0; j < G; j++) tr[lane * 16 + j] = hrow[j];
+      }
+      for (int c = 0; c < ncon; c++) {
+        const float* jb = &S.Jb[c][0];
+        const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
+        const f4 fb = ldv(S.con.cfb[c]);
+        const f4 mt = ldv(S.con.cmeta[c]);
+        g -= jn * fb.x + j1 * fb.y + j2 * fb.z;
+        const unsigned bits = (unsigned)fb.w;
+        const float mu = mt.x, D = mt.y;
+        const float a0 = (bits & 1u) ? D : 0.0f, a1 = (bits & 2u) ? D : 0.0f, a2 = (bits & 4u) ? D : 0.0f, a3 = (bits & 8u) ? D : 0.0f;
+        const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
+        const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
+        const unsigned chunks = S.con.cmask[c][2];
 #pragma unroll
-            for (int j = 0; j < G; j++) hrow[j] += tn * S.Jb[c][0][j] + t1 * S.Jb[c][1][j] + t2 * S.Jb[c][2][j];
+        for (int q = 0; q < 4; q++) {
+          if (chunks >> q & 1u) {  // group-uniform: only 4-dof chunks this contact touches
+            const f4 xn = ldv(jb + 4 * q), x1 = ldv(jb + 16 + 4 * q), x2 = ldv(jb + 32 + 4 * q);
+            hrow[4 * q + 0] += tn * xn.x + t1 * x1.x + t2 * x2.x;
+            hrow[4 * q + 1] += tn * xn.y + t1 * x1.y + t2 * x2.y;
+            hrow[4 * q + 2] += tn * xn.z + t1 * x1.z + t2 * x2.z;
+            hrow[4 * q + 3] += tn * xn.w + t1 * x1.w + t2 * x2.w;
           }
         }
       }
-      float gn = gsum(g * g);
-      if (!done && (scale * sqrtf(gn) < tol || sqrtf(gn) < gfloor)) done = true;
-#pragma unroll
-      for (int j = 0; j < G; j++) S.H[lane][j] = hrow[j];
-      S.grad[lane] = g;
-      S.srch[lane] = g;
-      __syncthreads();
+      if (!isdof) g = 0.0f;
+      const float gn = sqrtf(gsum(g * g));
+      if (!done && (scale * gn < tol || gn < gfloor)) done = true;
       if (!__any(!done)) break;
-      group_chol(S.H, nv, lane);
-      group_cholsolve(S.H, nv, lane, S.srch);
-      if (isdof) S.srch[lane] = -S.srch[lane];
-      __syncthreads();
-      // Mv, jv
-      float mv = 0.0f, sv = isdof ? S.srch[lane] : 0.0f;
-      if (isdof)
-        for (int j = 0; j < nv; j++) mv += S.M[lane][j] * S.srch[j];
-      S.Mv[lane] = mv;
-      float ljv = lsg * sv;
-      float jv[4] = {0, 0, 0, 0}, jr[4] = {0, 0, 0, 0}, cD = 0.0f;
-      if (lane < ncon) {
-        float xn = 0, x1 = 0, x2 = 0;
-        for (int i = 0; i < nv; i++) {
-          float si = S.srch[i];
-          xn += S.Jb[lane][0][i] * si; x1 += S.Jb[lane][1][i] * si; x2 += S.Jb[lane][2][i] * si;
-        }
-        float mu = S.cmu[lane];
-        jv[0] = xn + mu * x1; jv[1] = xn - mu * x1; jv[2] = xn + mu * x2; jv[3] = xn - mu * x2;
+      if (a.prof && blockIdx.x == 0 && grp == 0 && it == 0) {  // debug: H rows and gradient of env 0
+        float* tr = reinterpret_cast<float*>(a.prof + 16 + 64);
 #pragma unroll
-        for (int r = 0; r < 4; r++) jr[r] = S.cjar[lane][r];
-        cD = S.cD[lane];
+        for (int j = 0; j < G; j++) tr[lane * 16 + j] = hrow[j];
+        tr[256 + lane] = g;
+        tr[288 + lane * 4 + 0] = jar[0]; tr[288 + lane * 4 + 1] = jar[1]; tr[288 + lane * 4 + 2] = jar[2]; tr[288 + lane * 4 + 3] = jar[3];
+        tr[352 + lane] = ljar; tr[368 + lane] = lact; tr[384 + lane] = lsg;
+        tr[400 + lane] = lane < ncon ? ldv(S.con.cfb[lane]).w : -1.0f;
       }
-      const float ljar = S.ljar[lane], lD = lsg != 0.0f ? S.lD[lane] : 0.0f;
-      // exact line search: safeguarded Newton on phi'(alpha)
-      float A = gsum(sv * mv), Bq = gsum(sv * (S.Ma[lane] - S.qfs[lane]));
+      // ---- Newton direction: H s = -g
+      float sv = -g;
+      GJ<0>::run(hrow, sv, lane);
+      if (!isdof) sv = 0.0f;
+      if (a.prof && blockIdx.x == 0 && grp == 0 && it == 0) reinterpret_cast<float*>(a.prof + 16 + 64)[272 + lane] = sv;
+      S.srch[lane] = sv;
+      WSYNC();
+      const float mv = isdof ? rowdot(mrow, S.srch) : 0.0f;
+      const float ljv = lsg * sv;
+      float jv[4] = {0, 0, 0, 0};
+      if (iscon) {
+        float xn, x1, x2;
+        jdot3(&S.Jb[lane][0], S.srch, xn, x1, x2);
+        jv[0] = xn + cmu * x1; jv[1] = xn - cmu * x1; jv[2] = xn + cmu * x2; jv[3] = xn - cmu * x2;
+      }
+      // ---- exact line search on the piecewise-quadratic phi(alpha): safeguarded Newton on phi'
+      const float A = gsum(sv * mv), Bq = gsum(sv * (Ma - qfs));
       float alpha = 0.0f, lo = 0.0f, hi = -1.0f, g0 = 0.0f;
       bool lsdone = done;
       for (int ls = 0; ls < m->ls_iterations; ls++) {
         float pg = 0.0f, ph = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          float x = jr[r] + alpha * jv[r];
+          const float x = jar[r] + alpha * jv[r];
           if (x < 0.0f) { pg += cD * jv[r] * x; ph += cD * jv[r] * jv[r]; }
         }
         {
-          float x = ljar + alpha * ljv;
+          const float x = ljar + alpha * ljv;
           if (x < 0.0f) { pg += lD * ljv * x; ph += lD * ljv * ljv; }
         }
-        float gg = gsum(pg) + alpha * A + Bq, hh = gsum(ph) + A;
+        const float gg = gsum(pg) + alpha * A + Bq, hh = gsum(ph) + A;
         if (!lsdone) {
           if (ls == 0) { g0 = gg; if (g0 >= 0.0f) lsdone = true; }
           if (!lsdone && fabsf(gg) <= 1e-6f * fabsf(g0)) lsdone = true;
@@ -956,54 +1007,56 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         }
         if (!__any(!lsdone)) break;
       }
-      // improvement from the 1-D model, then the update
+      // ---- improvement from the 1-D model, then the update
       float pim = 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        float x0 = jr[r], x1 = jr[r] + alpha * jv[r];
+        const float x0 = jar[r], x1 = jar[r] + alpha * jv[r];
         pim -= (x1 < 0.0f ? 0.5f * cD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * cD * x0 * x0 : 0.0f);
       }
       {
-        float x0 = ljar, x1 = ljar + alpha * ljv;
+        const float x0 = ljar, x1 = ljar + alpha * ljv;
         pim -= (x1 < 0.0f ? 0.5f * lD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * lD * x0 * x0 : 0.0f);
       }
-      float improvement = gsum(pim) - (0.5f * alpha * alpha * A + alpha * Bq);
+      const float improvement = gsum(pim) - (0.5f * alpha * alpha * A + alpha * Bq);
+      if (a.prof && blockIdx.x == 0 && tid == 0 && it < 16) {  // debug trace of env 0
+        float* tr = reinterpret_cast<float*>(a.prof + 16) + it * 8;
+        tr[0] = gn; tr[1] = alpha; tr[2] = improvement; tr[3] = A; tr[4] = Bq; tr[5] = g0; tr[6] = done ? 1.0f : 0.0f; tr[7] = gfloor;
+      }
       if (!done) {
-        if (isdof) { S.qacc[lane] += alpha * sv; S.Ma[lane] += alpha * mv; }
-        S.ljar[lane] = ljar + alpha * ljv;
-        if (lane < ncon) {
+        qacc += alpha * sv;
+        Ma += alpha * mv;
+        ljar += alpha * ljv;
 #pragma unroll
-          for (int r = 0; r < 4; r++) S.cjar[lane][r] = jr[r] + alpha * jv[r];
-        }
+        for (int r = 0; r < 4; r++) jar[r] += alpha * jv[r];
         niter = it + 1;
         if (scale * improvement < tol) done = true;
       }
-      __syncthreads();
+      WSYNC();
     }
-    if (a.out_qacc && valid && isdof && step == 0) a.out_qacc[(size_t)env * nv + lane] = S.qacc[lane];
+    if (a.out_qacc && valid && isdof && step == 0) a.out_qacc[(size_t)env * nv + lane] = qacc;
     if (a.diag && valid && lane == 0) {
       a.diag[(size_t)env * 4 + 0] = ncon;
       a.diag[(size_t)env * 4 + 1] = nefc;
       a.diag[(size_t)env * 4 + 2] = niter;
       a.diag[(size_t)env * 4 + 3] = S.ncand;
     }
+    STAMP(8);
     if (a.mode != 0) break;
 
     // ======================= integrate ==============================================================
-    __syncthreads();
+    WSYNC();
     if (isdof) {
-      float acc = S.qacc[lane];
-      float qd = S.qvel[lane] + dt * acc;
-      S.qvel[lane] = qd;
-      S.qacc_ws[lane] = acc;
+      S.qvel[lane] += dt * qacc;
+      S.qacc_ws[lane] = qacc;
     }
-    __syncthreads();
+    WSYNC();
     if (isdof) {
-      float qd = S.qvel[lane];
+      const float qd = S.qvel[lane];
       if (d_kind < 2) S.qpos[d_qadr] += dt * qd;
       else if (d_kind == 2) S.qpos[m->b_qadr[d_body] + d_axis_k] += dt * qd;
       else if (d_axis_k == 0) {
-        int da = m->b_dofadr[d_body], qa = m->b_qadr[d_body];
+        const int da = m->b_dofadr[d_body], qa = m->b_qadr[d_body];
         V3 w = v3(S.qvel[da + 3], S.qvel[da + 4], S.qvel[da + 5]);
         float wn = sqrtf(dot(w, w));
         float ang = wn * dt;
@@ -1012,16 +1065,17 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
           sincosf(0.5f * ang, &sn, &cs);
           V3 ax = (1.0f / wn) * w;
           Q4 dq = {cs, ax.x * sn, ax.y * sn, ax.z * sn};
-          Q4 qn = qnormalize(qmul(dq, ld4(&S.qpos[qa + 3])));
-          st4(&S.qpos[qa + 3], qn);
+          st4(&S.qpos[qa + 3], qnormalize(qmul(dq, ld4(&S.qpos[qa + 3]))));
         }
       }
     }
-    __syncthreads();
+    WSYNC();
   }  // steps
+  STAMP(9);
 
   // ======================= final kinematics for observations =========================================
-  if (a.mode != 1) group_fk(S, m, lane, nb, b_parent, b_jtype, b_qadr, b_pos, b_quat, b_axis);
+  if (a.mode != 1) group_fk(S, lane, nb, parents, bk);
+  STAMP(10);
   if (!valid) return;
   // ---- store state ---------------------------------------------------------------------------------
   if (a.mode == 0) {
@@ -1031,64 +1085,45 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   }
   // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
   const int eb = m->eef_body, ob = m->obj_body;
-  if (a.agent_pos) {
-    const int ad = 7 + m->n_grip;
-    if (lane < ad) {
-      float v;
-      if (lane < 3) v = S.xpos[eb][lane];
-      else if (lane < 7) v = S.xquat[eb][lane - 3];
-      else v = S.qpos[m->grip_qadr[lane - 7]];
-      a.agent_pos[(size_t)env * ad + lane] = v;
-    }
-  }
-  if (a.env_state && lane < 11) {
-    float v;
-    V3 df = ld3(S.xpos[eb]) - ld3(S.xpos[ob]);
-    if (lane < 3) v = S.xpos[ob][lane];
-    else if (lane < 7) v = S.xquat[ob][lane - 3];
-    else if (lane < 10) v = lane == 7 ? df.x : (lane == 8 ? df.y : df.z);
-    else v = sqrtf(dot(df, df));
-    a.env_state[(size_t)env * 11 + lane] = v;
-  }
+  const int ad = 7 + m->n_grip;
+  const V3 pe = ld3v(S.xpos[eb]), po = ld3v(S.xpos[ob]);
+  const V3 df = pe - po;
+  const float rew = po.z > m->reward_z ? 1.0f : 0.0f;
+  // column c of the packed row [agent_pos | env_state | reward | terminated]
+  auto column = [&](int c) -> float {
+    if (c < 3) return S.xpos[eb][c];
+    if (c < 7) return S.xquat[eb][c - 3];
+    if (c < ad) return S.qpos[m->grip_qadr[c - 7]];
+    const int k = c - ad;
+    if (k < 3) return S.xpos[ob][k];
+    if (k < 7) return S.xquat[ob][k - 3];
+    if (k < 10) return k == 7 ? df.x : (k == 8 ? df.y : df.z);
+    if (k == 10) return sqrtf(dot(df, df));
+    return rew;  // k == 11 reward, k == 12 terminated
+  };
+  if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
+  if (a.env_state && lane < 11) a.env_state[(size_t)env * 11 + lane] = column(ad + lane);
   if (lane == 0) {
-    float r = S.xpos[ob][2] > m->reward_z ? 1.0f : 0.0f;
-    if (a.reward) a.reward[env] = r;
-    if (a.terminated) a.terminated[env] = r == 1.0f ? 1 : 0;
+    if (a.reward) a.reward[env] = rew;
+    if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
   }
-  // packed row per env for the sharded gather: [agent_pos | env_state | reward | terminated], float32
   if (a.rows) {
-    const int ad = 7 + m->n_grip;
     float* row = a.rows + (size_t)env * a.row_stride;
-    V3 df = ld3(S.xpos[eb]) - ld3(S.xpos[ob]);
-    for (int c = lane; c < ad + 13; c += G) {
-      float v;
-      if (c < 3) v = S.xpos[eb][c];
-      else if (c < 7) v = S.xquat[eb][c - 3];
-      else if (c < ad) v = S.qpos[m->grip_qadr[c - 7]];
-      else {
-        int k = c - ad;
-        if (k < 3) v = S.xpos[ob][k];
-        else if (k < 7) v = S.xquat[ob][k - 3];
-        else if (k < 10) v = k == 7 ? df.x : (k == 8 ? df.y : df.z);
-        else if (k == 10) v = sqrtf(dot(df, df));
-        else v = S.xpos[ob][2] > m->reward_z ? 1.0f : 0.0f;  // k == 11 reward, k == 12 terminated
-      }
-      row[c] = v;
-    }
+    for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
   }
   if (a.out_xpos && lane < nb) {
-    st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3(S.xpos[lane]));
-    st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4(S.xquat[lane]));
+    st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3v(S.xpos[lane]));
+    st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));
   }
 }
 
 }  // namespace
 
-// launcher used by the C ABI (mir_api.cpp)
+// launcher used by the C ABI (mir_api.hip)
 extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipStream_t stream) {
   StepArgs a = *args;
   int blocks = (a.B + EPB - 1) / EPB;
   (void)max_contacts_lds;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(mir_step_kernel<MIR_MAX_CONTACT>), dim3(blocks), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(mir_step_kernel, dim3(blocks), dim3(64), 0, stream, a);
   return (int)hipGetLastError();
 }

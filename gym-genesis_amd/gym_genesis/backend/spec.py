@@ -12,11 +12,11 @@ from typing import List, Optional, Sequence
 
 MIR_VERSION = 1
 MIR_MAX_BODY = 16
-MIR_MAX_DOF = 16
+MIR_MAX_DOF = 15
 MIR_MAX_Q = 18
 MIR_MAX_GEOM = 24
 MIR_MAX_PAIR = 64
-MIR_MAX_CONTACT = 20
+MIR_MAX_CONTACT = 16
 MIR_MAX_GRIP = 4
 
 JNT_FIXED, JNT_REVOLUTE, JNT_PRISMATIC, JNT_FREE = 0, 1, 2, 3

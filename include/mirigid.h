@@ -44,11 +44,11 @@ extern "C" {
 
 /* capacity limits of the spec (and of the kernels' LDS arenas) */
 #define MIR_MAX_BODY 16 /* including world = body 0 */
-#define MIR_MAX_DOF 16  /* nv */
+#define MIR_MAX_DOF 15  /* nv (one lane of a 16-lane env group stays free for the solver) */
 #define MIR_MAX_Q 18    /* nq */
 #define MIR_MAX_GEOM 24
 #define MIR_MAX_PAIR 64    /* candidate geom pairs after static filtering */
-#define MIR_MAX_CONTACT 20 /* contacts kept per env per step (plane-box <= 4, box-box <= 8 per pair) */
+#define MIR_MAX_CONTACT 16 /* contacts kept per env per step (plane-box <= 4, box-box <= 8 per pair) */
 #define MIR_MAX_GRIP 4
 
 /* error codes */

@@ -31,8 +31,9 @@ def load(f32: bool = False):
     key = "32" if f32 else "64"
     if key not in _libs:
         path = os.path.join(ORACLE_DIR, f"liborc{key}.so")
-        src = os.path.join(ORACLE_DIR, "orc_rigid.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        srcs = [os.path.join(ORACLE_DIR, "orc_rigid.c"), os.path.join(ORACLE_DIR, "orc_rigid.h"),
+                os.path.join(ORACLE_DIR, "..", "include", "mirigid.h")]
+        if not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(s) for s in srcs):
             build_oracle()
         lib = C.CDLL(path)
         lib.orc_read.restype = C.c_int

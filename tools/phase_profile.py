@@ -1,0 +1,68 @@
+"""Developer tool: phase-level shader-clock deltas of the fused step kernel (block 0) and the
+kernel's launch-to-launch time as a function of the batch size.  Needs a GPU."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "gym-genesis_amd")]
+from gym_genesis.backend import models  # noqa: E402
+from gym_genesis.backend.lib import MirScene  # noqa: E402
+
+PHASES = ["fk", "cdof+cinert+vel+crb", "rne+M+bias", "gj smooth solve", "collide", "rows (Jb, limits, aref)", "newton init",
+          "newton iterations", "integrate", "final fk"]
+
+
+def setup(B, warm=30):
+    spec = models.franka_cube_pick_scene().build()
+    sc = MirScene(spec, B)
+    rng = np.random.RandomState(0)
+    pos = np.stack([rng.uniform(.45, .8, B), rng.uniform(-.25, .25, B), np.full(B, .02)], 1).astype(np.float32)
+    sc.reset(pos, np.tile(np.array([0, 0, 0, 1], np.float32), (B, 1)), np.tile(np.array(models.FRANKA_HOME, np.float32), (B, 1)))
+    g = torch.Generator(device=sc.device).manual_seed(1)
+    acts = torch.empty((64, B, 9), device=sc.device).uniform_(-1, 1, generator=g)
+    bufs = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    for t in range(warm):
+        sc.step_fused(acts[t % 64], *bufs)
+    torch.cuda.synchronize()
+    return sc, acts, bufs
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    sc, acts, bufs = setup(B)
+    sc.lib.mir_debug_profile_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    sc.lib.mir_debug_profile_step.restype = C.c_int
+    acc = np.zeros(10)
+    n = 20
+    for k in range(n):
+        sc.set_pd_targets(acts[k % 64])
+        prof = torch.zeros(16, dtype=torch.int64, device=sc.device)
+        sc._check(sc.lib.mir_debug_profile_step(sc.h, C.c_void_p(prof.data_ptr()), sc._stream()))
+        p = prof.cpu().numpy().astype(np.float64)
+        acc += np.diff(p[:11])
+    acc /= n
+    print(f"B={B}: phase cycles (block 0, shader clock; avg of {n} steps)")
+    for name, c in zip(PHASES, acc):
+        print(f"  {name:14s} {c:9.0f} cyc  {100 * c / acc.sum():5.1f}%")
+    print(f"  total          {acc.sum():9.0f} cyc")
+    nc, ne, ni = (x.cpu().numpy() for x in sc.get_diag())
+    print(f"  ncon mean {nc.mean():.2f} nefc mean {ne.mean():.2f} niter mean {ni.mean():.2f} max {ni.max()}")
+    for Bx in (256, 1024, 2048, 4096, 8192, 16384, 65536):
+        s2, a2, b2 = setup(Bx, warm=20)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K = 300
+        for t in range(K):
+            s2.step_fused(a2[t % 64], *b2)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        print(f"  B={Bx:6d}: {dt * 1e6:8.1f} us/step  {Bx / dt / 1e6:8.2f} M env-steps/s")
+
+
+if __name__ == "__main__":
+    main()
