@@ -922,11 +922,6 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
 #pragma unroll
       for (int j = 0; j < G; j++) hrow[j] = isdof ? mrow[j] + (j == lane ? lact : 0.0f) : (j == lane ? 1.0f : 0.0f);
       if (isdof) g = Ma - qfs - lsg * lf;
-      if (a.prof && blockIdx.x == 0 && grp == 0 && it == 0) {  // debug: pre-contact rows
-        float* tr = reinterpret_cast<float*>(a.prof + 16 + 64) + 416;
-#pragma unroll
-        for (int j = 0; j < G; j++) tr[lane * 16 + j] = hrow[j];
-      }
       for (int c = 0; c < ncon; c++) {
         const float* jb = &S.Jb[c][0];
         const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
@@ -954,20 +949,10 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       const float gn = sqrtf(gsum(g * g));
       if (!done && (scale * gn < tol || gn < gfloor)) done = true;
       if (!__any(!done)) break;
-      if (a.prof && blockIdx.x == 0 && grp == 0 && it == 0) {  // debug: H rows and gradient of env 0
-        float* tr = reinterpret_cast<float*>(a.prof + 16 + 64);
-#pragma unroll
-        for (int j = 0; j < G; j++) tr[lane * 16 + j] = hrow[j];
-        tr[256 + lane] = g;
-        tr[288 + lane * 4 + 0] = jar[0]; tr[288 + lane * 4 + 1] = jar[1]; tr[288 + lane * 4 + 2] = jar[2]; tr[288 + lane * 4 + 3] = jar[3];
-        tr[352 + lane] = ljar; tr[368 + lane] = lact; tr[384 + lane] = lsg;
-        tr[400 + lane] = lane < ncon ? ldv(S.con.cfb[lane]).w : -1.0f;
-      }
       // ---- Newton direction: H s = -g
       float sv = -g;
       GJ<0>::run(hrow, sv, lane);
       if (!isdof) sv = 0.0f;
-      if (a.prof && blockIdx.x == 0 && grp == 0 && it == 0) reinterpret_cast<float*>(a.prof + 16 + 64)[272 + lane] = sv;
       S.srch[lane] = sv;
       WSYNC();
       const float mv = isdof ? rowdot(mrow, S.srch) : 0.0f;
@@ -1019,10 +1004,6 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         pim -= (x1 < 0.0f ? 0.5f * lD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * lD * x0 * x0 : 0.0f);
       }
       const float improvement = gsum(pim) - (0.5f * alpha * alpha * A + alpha * Bq);
-      if (a.prof && blockIdx.x == 0 && tid == 0 && it < 16) {  // debug trace of env 0
-        float* tr = reinterpret_cast<float*>(a.prof + 16) + it * 8;
-        tr[0] = gn; tr[1] = alpha; tr[2] = improvement; tr[3] = A; tr[4] = Bq; tr[5] = g0; tr[6] = done ? 1.0f : 0.0f; tr[7] = gfloor;
-      }
       if (!done) {
         qacc += alpha * sv;
         Ma += alpha * mv;
