@@ -43,7 +43,10 @@ def cpu_baseline(budget_s: float = 12.0):
     import orc
     from gym_genesis.backend import models
 
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))  # cores this process may actually use
+    except AttributeError:
+        cores = os.cpu_count() or 1
     B = ENVS_PER_GPU
     spec = models.franka_cube_pick_scene().build()
     o = orc.Oracle(spec, B, f32=True)
@@ -164,6 +167,12 @@ def main():
 
     if rank == 0:
         value = K * B * world / wall_max
+        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/, measured offline on this kernel)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1", "pmc_hbm_traffic.json")) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch_uncorrected"] if B == ENVS_PER_GPU else None
+        except (OSError, KeyError, ValueError):
+            pass
         launch_us = gpu_ms * 1e3 / max(launches, 1)  # HIP events on the launching stream, per step-kernel launch
         achieved = ALGO_BYTES_PER_ENV_STEP * B / (launch_us * 1e-6) / 1e9
         out = {
@@ -183,7 +192,7 @@ def main():
                        "num_envs_per_gpu": B, "global_num_envs": B * world, "parallelism": f"env-axis shard x{world}",
                        "obs_gather": "rccl all_gather per step, overlapped" if gather else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "mir_step_kernel", "kernel_us": launch_us,
+                         "traffic": traffic, "kernel": "mir_step_kernel", "kernel_us": launch_us,
                          "note": "489 algorithmic B/env-step x 4096 envs per launch; the path is latency/occupancy-bound, not HBM-bound (SURVEY.md 8d)"},
             "env_step_api_rate": api_rate,
         }

@@ -1,0 +1,80 @@
+"""Test double for gym_genesis.backend.lib.MirScene that drives the CPU ORACLE.
+
+Lives under tests/ and is only ever monkeypatched in by tests: it lets the host-side logic
+(GenesisEnv, task classes, registry, sharding) run in the CPU-only test tier.  The product has
+no such path: without a GPU, the real MirScene raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import orc
+
+
+class OracleScene:
+    def __init__(self, spec, num_envs, device=None):
+        self.spec = spec
+        self.o = orc.Oracle(spec, int(num_envs))
+        self.device = torch.device("cpu")
+        self.num_envs = int(num_envs)
+        self.nq, self.nv, self.nbody = self.o.nq, self.o.nv, spec.nbody
+        self.nu = self.o.nu
+        self.agent_dim, self.env_dim = 7 + spec.task.n_grip, 11
+        self.n_arm = sum(1 for b in range(1, spec.nbody) if spec.body[b].jtype in (1, 2))
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty((self.num_envs, *shape), dtype=dtype)
+
+    @staticmethod
+    def _np(t):
+        return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+    def reset(self, obj_pos, obj_quat, arm_qpos, env_mask=None):
+        assert env_mask is None
+        self.o.reset(self._np(obj_pos), self._np(obj_quat), self._np(arm_qpos))
+
+    def set_pd_targets(self, tgt):
+        self.o.set_targets(self._np(tgt))
+
+    def step(self, n_steps=1):
+        for _ in range(n_steps):
+            self.o.step_batch(None)
+
+    def _fill(self, agent_pos, env_state, reward, terminated):
+        a, e, r, t = self.o.get_obs()
+        agent_pos.copy_(torch.from_numpy(a.astype(np.float32)))
+        env_state.copy_(torch.from_numpy(e.astype(np.float32)))
+        reward.copy_(torch.from_numpy(r.astype(np.float32)))
+        terminated.copy_(torch.from_numpy(t))
+
+    def step_fused(self, action, agent_pos, env_state, reward, terminated):
+        self.o.step_batch(None if action is None else self._np(action).astype(np.float32))
+        self._fill(agent_pos, env_state, reward, terminated)
+
+    def step_packed(self, action, rows):
+        bufs = (self.empty(self.agent_dim), self.empty(self.env_dim), self.empty(), self.empty(dtype=torch.uint8))
+        self.step_fused(action, *bufs)
+        rows[:, :self.agent_dim] = bufs[0]
+        rows[:, self.agent_dim:self.agent_dim + 11] = bufs[1]
+        rows[:, self.agent_dim + 11] = bufs[2]
+        rows[:, self.agent_dim + 12] = bufs[3].float()
+
+    def get_obs(self):
+        bufs = (self.empty(self.agent_dim), self.empty(self.env_dim), self.empty(), self.empty(dtype=torch.uint8))
+        self._fill(*bufs)
+        return bufs
+
+    def get_state(self):
+        q, v = self.o.state()
+        tgt = np.stack([self.o.read(orc.F_TARGET, e)[self.o.u_dofs] for e in range(self.num_envs)])
+        ws = np.stack([self.o.read(orc.F_QACC_WS, e) for e in range(self.num_envs)])
+        return tuple(torch.from_numpy(x.astype(np.float32)) for x in (q, v, tgt, ws))
+
+    def get_links(self):
+        pos = np.stack([self.o.read(orc.F_XPOS, e).reshape(-1, 3) for e in range(self.num_envs)])
+        quat = np.stack([self.o.read(orc.F_XQUAT, e).reshape(-1, 4) for e in range(self.num_envs)])
+        return torch.from_numpy(pos.astype(np.float32)), torch.from_numpy(quat.astype(np.float32))
+
+    def close(self):
+        pass

@@ -1,0 +1,186 @@
+"""CPU-tier tests: C-ABI surface, golden fixtures derived from the reference's own logic, and
+the host-side drop-in API (registry, GenesisEnv, task) on an oracle-backed test double.
+No GPU compute is called here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import gym_genesis
+from gym_genesis import _gym
+from gym_genesis.backend import lib as mirlib
+from gym_genesis.backend import models, spec as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mirigid.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(mir_\w+)\s*\(", hdr, flags=re.M))
+    assert {"mir_create", "mir_destroy", "mir_reset", "mir_set_pd_targets", "mir_step", "mir_step_fused", "mir_step_packed",
+            "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links", "mir_last_error", "mir_version"} <= declared
+    lib = mirlib.load_library()
+    for name in declared:
+        assert hasattr(lib, name), f"libmirigid.so does not export {name}"
+    assert lib.mir_version() == S.MIR_VERSION
+    assert lib.mir_spec_sizeof() == C.sizeof(S.MirSceneSpec)
+
+
+def test_no_cpu_fallback_create_fails_loudly_without_gpu(franka_spec):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mirlib.MirError):
+        mirlib.MirScene(franka_spec, 4)
+    lib = mirlib.load_library()
+    h = C.c_void_p()
+    rc = lib.mir_create(C.byref(franka_spec), 4, 0, C.byref(h))
+    assert rc == -4 and b"no usable HIP device" in lib.mir_last_error()  # MIR_E_NODEVICE
+
+
+def test_spec_validation_errors(franka_spec):
+    lib = mirlib.load_library()
+    h = C.c_void_p()
+    bad = S.MirSceneSpec.from_buffer_copy(franka_spec)
+    bad.struct_size = 1
+    assert lib.mir_create(C.byref(bad), 4, 0, C.byref(h)) == -1 and b"ABI" in lib.mir_last_error()
+    bad = S.MirSceneSpec.from_buffer_copy(franka_spec)
+    bad.opt.max_contacts = 1000
+    assert lib.mir_create(C.byref(bad), 4, 0, C.byref(h)) == -2
+    assert lib.mir_create(C.byref(franka_spec), 0, 0, C.byref(h)) == -1
+
+
+# ---------------------------------------------------------------- golden fixtures (reference logic)
+def test_reset_rng_stream_matches_golden_fixture(monkeypatch):
+    import fake_scene
+    from gym_genesis.tasks.franka import cube_pick
+
+    monkeypatch.setattr(cube_pick, "MirScene", fake_scene.OracleScene)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reset_rng.json")))
+    for key, g in gold.items():
+        if g["B"] > 64:
+            continue
+        task = cube_pick.FrankaCubePickBatch(False, 480, 640, g["B"], (1.0, 1.0), "global", True)
+        task.seed(g["seed"])
+        pos = task.sample_spawn()
+        assert pos.dtype == np.float32
+        assert np.array_equal(pos[:4], np.array(g["first_rows_f32"], np.float32)[:g["B"]])
+        assert np.array_equal(pos[-1], np.array(g["last_row_f32"], np.float32))
+        assert task._random.uniform(0.45, 0.80, size=(g["B"],))[0] == g["second_reset_x0_f64"]
+    # SURVEY.md 8c-1 literal
+    rs = np.random.RandomState(0)
+    assert np.allclose(rs.uniform(0.45, 0.80, size=(4,)), [0.64208473, 0.70031628, 0.66096718, 0.64070911])
+
+
+def test_reference_constants():
+    """Constants the reference spells out (file:line in models.py / cube_pick.py docstrings)."""
+    assert models.FRANKA_HOME == (0.0, -0.4, 0.0, -2.2, 0.0, 2.0, 0.8, 0.04, 0.04)  # cube_pick.py:100
+    assert models.FRANKA_JOINTS[7:] == ("finger_joint1", "finger_joint2")            # cube_pick.py:15-16
+    sb = models.franka_cube_pick_scene()
+    sp = sb.build()
+    assert sp.opt.dt == 0.01                                                           # cube_pick.py:45
+    cube = sp.body[sp.task.obj_body]
+    assert tuple(cube.pos) == (0.65, 0.0, 0.02)                                        # cube_pick.py:53
+    g = [sp.geom[i] for i in range(sp.ngeom) if sp.geom[i].body == sp.task.obj_body][0]
+    assert tuple(g.size) == (0.02, 0.02, 0.02)                                         # 0.04^3 box, cube_pick.py:53
+    assert sp.task.reward_z == 0.1 and sb.bodies[sp.task.eef_body]["name"] == "hand"   # cube_pick.py:134, :68
+    assert [sp.task.grip_dof[i] for i in range(2)] == [7, 8]                           # cube_pick.py:142
+
+
+# ---------------------------------------------------------------- drop-in API on the test double
+@pytest.fixture
+def env(monkeypatch):
+    import fake_scene
+    from gym_genesis.tasks.franka import cube_pick
+
+    monkeypatch.setattr(cube_pick, "MirScene", fake_scene.OracleScene)
+    from gym_genesis.env import GenesisEnv
+
+    return GenesisEnv(task="cube_pick", robot="franka", num_envs=3, enable_pixels=False)
+
+
+def test_env_reset_step_contract(env):
+    B = 3
+    obs, info = env.reset(seed=0)
+    assert info == {"is_success": [False] * B}                                         # env.py:56
+    assert set(obs) == {"agent_pos", "environment_state"}
+    assert obs["agent_pos"].shape == (B, 9) and obs["environment_state"].shape == (B, 11)
+    assert obs["agent_pos"].dtype == torch.float32
+    assert env.observation_space["agent_pos"].shape == (9,) and env.action_space.shape == (9,)  # per-env spaces
+    # reset consumed exactly one physics step (cube_pick.py:107): cube fell g dt^2 below the spawn height?  it rests on
+    # the plane at z=0.02, so after one step it has sunk by less than a millimetre and reads (0,0,0,1) as set (cube_pick.py:94)
+    es = obs["environment_state"].numpy()
+    assert np.allclose(es[:, 3:7], [0, 0, 0, 1], atol=1e-6) and (np.abs(es[:, 2] - 0.02) < 1e-3).all()
+    assert np.allclose(es[:, 0], [0.64208473, 0.70031628, 0.66096718][:B], atol=1e-6)  # golden x stream, seed 0
+    # privileged features: diff = eef - cube, dist = |diff| (cube_pick.py:147-148)
+    ap = obs["agent_pos"].numpy()
+    assert np.allclose(es[:, 7:10], ap[:, :3] - es[:, :3], atol=1e-6)
+    assert np.allclose(es[:, 10], np.linalg.norm(es[:, 7:10], axis=1), atol=1e-6)
+    assert np.allclose(ap[:, 7:9], 0.04, atol=1e-4)
+    # step with NumPy actions as the README loop does (README.md:34)
+    act = np.stack([env.action_space.sample() for _ in range(B)])
+    obs2, reward, terminated, truncated, info = env.step(act)
+    assert isinstance(terminated, np.ndarray) and terminated.dtype == bool and terminated.shape == (B,)
+    assert isinstance(truncated, np.ndarray) and truncated.dtype == bool and not truncated.any()  # env.py:65
+    assert reward.shape == (B,) and reward.dtype == torch.float32
+    assert np.array_equal(terminated, reward.numpy() == 1) and np.array_equal(info["is_success"].numpy(), terminated)
+    assert obs2["agent_pos"] is not obs["agent_pos"]  # fresh tensors per step
+    # torch actions are accepted too (pick_cube_state.py:53)
+    env.step(torch.as_tensor(act))
+    with pytest.raises(ValueError):
+        env.step(act[:2])
+
+
+def test_env_accessors_and_errors(env):
+    from gym_genesis.env import GenesisEnv
+
+    assert env.render() is None                                                         # env.py:98 (pixels disabled)
+    with pytest.raises(ValueError):
+        env.get_cams()                                                                  # cube_pick.py:70-71
+    env.reset(seed=1)
+    robot, cube = env.get_robot(), env.get_cube()
+    assert robot.get_dofs_position().shape == (3, 9) and cube.get_pos().shape == (3, 3)
+    hand = robot.get_link("hand")
+    assert torch.allclose(hand.get_pos(), env.get_obs()["agent_pos"][:, :3])
+    z0 = float(cube.get_pos()[0, 2])
+    env.push()                                                                          # env.py:59-60 -> scene.step()
+    assert abs(float(cube.get_pos()[0, 2]) - z0) < 1e-3
+    with pytest.raises(NotImplementedError) as ei:
+        GenesisEnv(task="cube", robot="franka", num_envs=2)                             # env.py:122-123
+    assert ei.value.args[0] == ("franka", "cube", True)
+    assert GenesisEnv.metadata == {"render_modes": ["rgb_array"], "render_fps": 50}     # env.py:15
+
+
+def test_seeded_reset_is_deterministic(env):
+    a, _ = env.reset(seed=42)
+    b, _ = env.reset(seed=42)
+    assert torch.equal(a["environment_state"], b["environment_state"])
+    c, _ = env.reset()  # continues the stream
+    assert not torch.equal(a["environment_state"][:, :2], c["environment_state"][:, :2])
+
+
+def test_registry_ids_and_defaults(monkeypatch):
+    import fake_scene
+    from gym_genesis.tasks.franka import cube_pick
+
+    monkeypatch.setattr(cube_pick, "MirScene", fake_scene.OracleScene)
+    if _gym.HAVE_GYMNASIUM:
+        pytest.skip("real gymnasium registry")
+    reg = _gym._REGISTRY
+    assert set(reg) >= {"gym_genesis/CubePick-v0", "gym_genesis/CubeStack-v0"}          # __init__.py:4,22
+    e = reg["gym_genesis/CubePick-v0"]
+    assert e["max_episode_steps"] == 200 and e["entry_point"] == "gym_genesis.env:GenesisEnv"
+    assert e["kwargs"] == dict(task="cube_pick", robot="so101", enable_pixels=False, num_envs=10, observation_height=480,
+                               observation_width=640, env_spacing=(1.0, 1.0), camera_capture_mode="global",
+                               strip_environment_state=True)                            # __init__.py:8-18
+    env = gym_genesis.make("gym_genesis/CubePick-v0", robot="franka", num_envs=2)
+    env.reset(seed=0)
+    act = np.zeros((2, 9), np.float32)
+    for t in range(200):
+        obs, rew, term, trunc, info = env.step(act)
+    assert trunc is True  # TimeLimit(200) replaces truncated at the 200th step (gymnasium behaviour)
+    assert env.unwrapped.num_envs == 2
