@@ -17,8 +17,8 @@ struct MirScene {
   DevModel hm;      // host copy of the compiled model
   HostConsts hc;
   DevModel* dm;     // device copy
-  float *qpos, *qvel, *target, *qacc_ws;
-  int32_t* diag;
+  float *qpos, *qvel, *target, *qacc_ws, *poses;
+  int32_t *diag, *fkvalid;
 };
 
 namespace {
@@ -60,7 +60,7 @@ __global__ void k_fill_rows(float* dst, const float* row, int stride, int B) {
 }
 
 __global__ void k_reset(const DevModel* __restrict__ m, float* qpos, float* qvel, float* target, float* ws,
-                        const float* obj_pos, const float* obj_quat, const float* arm_qpos, const uint8_t* mask, int B) {
+                        const float* obj_pos, const float* obj_quat, const float* arm_qpos, const uint8_t* mask, int32_t* fkvalid, int B) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int e = (int)(i / MIR_G), c = (int)(i % MIR_G);
   if (e >= B) return;
@@ -68,6 +68,7 @@ __global__ void k_reset(const DevModel* __restrict__ m, float* qpos, float* qvel
   const int qst = m->qstride;
   qvel[(long)e * MIR_G + c] = 0.0f;
   ws[(long)e * MIR_G + c] = 0.0f;
+  if (c == 0) fkvalid[e] = 0;  // cached link poses no longer match qpos
   if (c < m->nv) {
     int ai = m->d_armidx[c];
     if (ai >= 0 && arm_qpos) {
@@ -92,11 +93,12 @@ __global__ void k_set_targets(const DevModel* __restrict__ m, float* target, con
 
 // dir 0: internal -> external (get); 1: external -> internal (set)
 __global__ void k_copy_state(const DevModel* __restrict__ m, float* iq, float* iv, float* it, float* iw, float* eq, float* ev,
-                             float* et, float* ew, int B, int dir) {
+                             float* et, float* ew, int32_t* fkvalid, int B, int dir) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int e = (int)(i / 32), c = (int)(i % 32);
   if (e >= B) return;
   const int qst = m->qstride, nq = m->nq, nv = m->nv, nu = m->nu;
+  if (dir && eq && c == 0) fkvalid[e] = 0;
   if (eq && c < nq) {
     if (dir) iq[(long)e * qst + c] = eq[(long)e * nq + c];
     else eq[(long)e * nq + c] = iq[(long)e * qst + c];
@@ -131,6 +133,7 @@ StepArgs base_args(MirScene* h) {
   memset(&a, 0, sizeof a);
   a.model = h->dm;
   a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
+  a.poses = h->poses; a.fkvalid = h->fkvalid;
   a.diag = h->diag;
   a.B = h->B;
   a.n_steps = 1;
@@ -182,7 +185,8 @@ int mir_create(const MirSceneSpec* spec, int32_t num_envs, int32_t device_id, Mi
   hipError_t e;
   if ((e = hipMalloc((void**)&h->dm, sizeof(DevModel))) != hipSuccess || (e = hipMalloc((void**)&h->qpos, B * qst * sizeof(float))) != hipSuccess ||
       (e = hipMalloc((void**)&h->qvel, B * MIR_G * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->target, B * MIR_G * sizeof(float))) != hipSuccess ||
-      (e = hipMalloc((void**)&h->qacc_ws, B * MIR_G * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->diag, B * 4 * sizeof(int32_t))) != hipSuccess) {
+      (e = hipMalloc((void**)&h->qacc_ws, B * MIR_G * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->diag, B * 4 * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->poses, B * 2 * MIR_G * 4 * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->fkvalid, B * sizeof(int32_t))) != hipSuccess) {
     mir_destroy(h);
     return hip_fail(e, "hipMalloc");
   }
@@ -202,6 +206,8 @@ int mir_create(const MirSceneSpec* spec, int32_t num_envs, int32_t device_id, Mi
   HIPCHK(hipMemset(h->target, 0, B * MIR_G * sizeof(float)));
   HIPCHK(hipMemset(h->qacc_ws, 0, B * MIR_G * sizeof(float)));
   HIPCHK(hipMemset(h->diag, 0, B * 4 * sizeof(int32_t)));
+  HIPCHK(hipMemset(h->poses, 0, B * 2 * MIR_G * 4 * sizeof(float)));
+  HIPCHK(hipMemset(h->fkvalid, 0, B * sizeof(int32_t)));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipFree(drow));
   *out = h;
@@ -217,6 +223,8 @@ int mir_destroy(MirHandle h) {
   if (h->target) (void)hipFree(h->target);
   if (h->qacc_ws) (void)hipFree(h->qacc_ws);
   if (h->diag) (void)hipFree(h->diag);
+  if (h->poses) (void)hipFree(h->poses);
+  if (h->fkvalid) (void)hipFree(h->fkvalid);
   delete h;
   return MIR_OK;
 }
@@ -240,7 +248,7 @@ int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const fl
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_reset, dim3(nblk((long)h->B * MIR_G)), dim3(TPB), 0, (hipStream_t)stream, h->dm, h->qpos, h->qvel, h->target,
-                     h->qacc_ws, obj_pos, obj_quat, arm_qpos, env_mask, h->B);
+                     h->qacc_ws, obj_pos, obj_quat, arm_qpos, env_mask, h->fkvalid, h->B);
   HIPCHK(hipGetLastError());
   return MIR_OK;
 }
@@ -301,7 +309,7 @@ int mir_get_state(MirHandle h, float* qpos, float* qvel, float* target, float* w
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_copy_state, dim3(nblk((long)h->B * 32)), dim3(TPB), 0, (hipStream_t)stream, h->dm, h->qpos, h->qvel, h->target,
-                     h->qacc_ws, qpos, qvel, target, warmstart, h->B, 0);
+                     h->qacc_ws, qpos, qvel, target, warmstart, h->fkvalid, h->B, 0);
   HIPCHK(hipGetLastError());
   return MIR_OK;
 }
@@ -310,7 +318,7 @@ int mir_set_state(MirHandle h, const float* qpos, const float* qvel, const float
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_copy_state, dim3(nblk((long)h->B * 32)), dim3(TPB), 0, (hipStream_t)stream, h->dm, h->qpos, h->qvel, h->target,
-                     h->qacc_ws, (float*)qpos, (float*)qvel, (float*)target, (float*)warmstart, h->B, 1);
+                     h->qacc_ws, (float*)qpos, (float*)qvel, (float*)target, (float*)warmstart, h->fkvalid, h->B, 1);
   HIPCHK(hipGetLastError());
   return MIR_OK;
 }

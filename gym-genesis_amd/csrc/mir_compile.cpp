@@ -335,5 +335,25 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
   for (int b = 0; b < nb; b++) m.b_invweight0[b] = (float)H.body_invweight0[b];
   m.meaninertia = (float)meaninertia;
   m.solver_scale = (float)(1.0 / (meaninertia * (nv > 1 ? nv : 1)));
+
+  // ---- packed lookup tables for the kernel's LDS copy ---------------------------------------
+  ModelTab& t = m.tab;
+  for (int g = 0; g < m.ngeom; g++) {
+    for (int k = 0; k < 3; k++) { t.g_pos[g][k] = m.g_pos[g][k]; t.g_size[g][k] = m.g_size[g][k]; }
+    t.g_pos[g][3] = m.g_friction[g];
+    for (int k = 0; k < 4; k++) t.g_quat[g][k] = m.g_quat[g][k];
+    t.g_info[g][0] = m.g_body[g]; t.g_info[g][1] = m.g_type[g];
+    t.g_sol[g][0] = m.g_solref[g][0]; t.g_sol[g][1] = m.g_solref[g][1];
+    for (int k = 0; k < 5; k++) t.g_sol[g][2 + k] = m.g_solimp[g][k];
+  }
+  for (int p = 0; p < m.npair; p++) t.pair[p] = m.p_g1[p] | (m.p_g2[p] << 8);
+  for (int b = 0; b < nb; b++) {
+    t.b_info[b][0] = (int32_t)m.b_dofmask[b]; t.b_info[b][1] = m.b_root[b]; t.b_info[b][2] = m.b_qadr[b]; t.b_info[b][3] = m.b_dofadr[b];
+    t.b_invw[b] = m.b_invweight0[b];
+  }
+  for (int i = 0; i < nv; i++) {
+    t.d_lim[i][0] = m.d_lo[i]; t.d_lim[i][1] = m.d_hi[i]; t.d_lim[i][2] = m.d_invweight0[i]; t.d_lim[i][3] = m.d_k[i]; t.d_lim[i][4] = m.d_b[i];
+    for (int k = 0; k < 5; k++) t.d_lim[i][5 + k] = m.d_solimp[i][k];
+  }
   return MIR_OK;
 }

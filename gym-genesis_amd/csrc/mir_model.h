@@ -16,7 +16,24 @@ static_assert(MIR_MAX_BODY <= MIR_G && MIR_MAX_DOF <= MIR_G, "lane ownership nee
 static_assert(MIR_MAX_GEOM <= 2 * MIR_G, "two geoms per lane");
 static_assert(MIR_MAX_PAIR <= 4 * MIR_G, "four pairs per lane");
 
+// Tables that the step kernel looks up with a *dynamic* index (geom, pair, contact body, limit
+// constants).  Packed so a workgroup copies them into LDS with 16-byte loads once per launch:
+// dependent lookups then cost an LDS round trip (~64 cycles) instead of an L2 one (~500+).
+struct ModelTab {
+  float g_pos[MIR_MAX_GEOM][4];   // xyz in body frame, w = friction
+  float g_quat[MIR_MAX_GEOM][4];  // wxyz in body frame
+  float g_size[MIR_MAX_GEOM][4];  // half extents, w unused
+  int32_t g_info[MIR_MAX_GEOM][4];  // body, type, 0, 0
+  float g_sol[MIR_MAX_GEOM][8];   // solref[2], solimp[5], 0
+  int32_t pair[MIR_MAX_PAIR];     // g1 | g2 << 8
+  int32_t b_info[MIR_G][4];       // dofmask, root, qadr, dofadr
+  float b_invw[MIR_G];            // body_invweight0
+  float d_lim[MIR_G][12];         // lo, hi, invweight0, k, b, solimp[5], 0, 0
+};
+static_assert(sizeof(ModelTab) % 16 == 0, "ModelTab is copied with 16-byte accesses");
+
 struct DevModel {
+  ModelTab tab;  // first member: 16-byte aligned with the allocation
   // sizes / options
   int32_t nbody, nv, nq, ngeom, npair, nu, qstride, max_contacts;
   int32_t iterations, ls_iterations, enable_collision, enable_joint_limit;

@@ -11,6 +11,8 @@ struct StepArgs {
   float* qvel;    // (B, 16)
   float* target;  // (B, 16) indexed by dof
   float* qacc_ws; // (B, 16)
+  float* poses;   // (B, 2, 16, 4): link positions then quaternions of the current qpos (FK cache)
+  int32_t* fkvalid; // (B): poses[env] match qpos[env]
   const float* action;  // (B, nu) or null
   float* agent_pos;     // (B, 7+n_grip) or null
   float* env_state;     // (B, 11) or null

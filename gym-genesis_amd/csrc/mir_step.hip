@@ -115,6 +115,10 @@ template <int K>
 __device__ __forceinline__ float row_bcast(float v) {  // value of lane K of the row, in every lane of the row
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, false));
 }
+template <int N>
+__device__ __forceinline__ float row_shr(float v) {  // lane i reads lane i-N of its row, 0 shifted in
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float gsum(float v) {  // all-reduce sum over the row
   v += row_ror<1>(v);
   v += row_ror<2>(v);
@@ -456,8 +460,14 @@ __device__ __forceinline__ void jdot3(const float* jb, const float* x, float& dn
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
+  __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
   const DevModel* __restrict__ m = a.model;
   const int tid = threadIdx.x;
+  {
+    const f4* src = reinterpret_cast<const f4*>(&m->tab);
+    f4* dst = reinterpret_cast<f4*>(&T);
+    for (int i = tid; i < (int)(sizeof(ModelTab) / 16); i += 64) dst[i] = src[i];
+  }
   const int lane = tid & (G - 1);
   const int grp = tid >> 4;
   const int env_raw = blockIdx.x * EPB + grp;
@@ -466,6 +476,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   EnvLds& S = s_env[grp];
 
   const int nb = m->nbody, nv = m->nv, qst = m->qstride;
+  const int ngeom = m->ngeom, npair = m->npair, max_contacts = m->max_contacts, enable_collision = m->enable_collision;
   const float dt = m->dt;
 
   // ---- per-lane model constants (lane = body = dof) -------------------------------------------
@@ -480,6 +491,9 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   const uint32_t b_dofmask = m->b_dofmask[lane], b_submask = m->b_submask[lane];
   const V3 b_ipos = ld3(m->b_ipos[lane]);
   const float b_mass = m->b_mass[lane];
+  float ib[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) ib[k] = m->b_inertia[lane][k];
   const int d_body = isdof ? m->d_body[lane] : 0;
   const int d_kind = m->d_kind[lane], d_qadr = m->d_qadr[lane], d_axis_k = m->d_axis_k[lane];
   const int d_root = m->b_root[d_body];
@@ -503,12 +517,23 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   if (lane == 0) { S.ncon = 0; S.ncand = 0; }
   WSYNC();
 
+  // ======================= forward kinematics =================================================
+  // Link poses of the current qpos are persisted in HBM by the previous launch (the end-of-step FK
+  // that produced its observations); reuse them unless reset / set_state invalidated this env.
+  STAMP(0);
+  {
+    const bool cached = a.fkvalid[env] != 0;
+    if (cached && lane < nb) {
+      const float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
+      stv(S.xpos[lane], *reinterpret_cast<const f4*>(p));
+      stv(S.xquat[lane], *reinterpret_cast<const f4*>(p + 4 * G));
+    }
+    WSYNC();
+    if (__any(!cached)) group_fk(S, lane, nb, parents, bk);  // recomputing a cached env is bit-identical
+  }
+  STAMP(1);
   const int nsteps = a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0);
   for (int step = 0; step < nsteps; step++) {
-    STAMP(0);
-    // ======================= forward kinematics =================================================
-    group_fk(S, lane, nb, parents, bk);
-    STAMP(1);
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
     if (isdof) {
       V3 ang = v3(0, 0, 0), lin = v3(0, 0, 0);
@@ -527,7 +552,6 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     }
     if (isbody) {
       M3 R = q2m(ld4v(S.xquat[lane]));
-      const float* ib = m->b_inertia[lane];
       float Ib[3][3] = {{ib[0], ib[3], ib[4]}, {ib[3], ib[1], ib[5]}, {ib[4], ib[5], ib[2]}};
       float Rm[3][3] = {{R.r0.x, R.r0.y, R.r0.z}, {R.r1.x, R.r1.y, R.r1.z}, {R.r2.x, R.r2.y, R.r2.z}};
       float T[3][3], W[3][3];
@@ -688,32 +712,34 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
 
     // ======================= collision detection ================================================
     if (lane == 0) { S.ncon = 0; S.ncand = 0; }
-    for (int g = lane; g < m->ngeom; g += G) {
-      int gb = m->g_body[g];
+    for (int g = lane; g < ngeom; g += G) {
+      int gb = T.g_info[g][0];
       Q4 qb = ld4v(S.xquat[gb]);
-      st3v(S.col.gpos[g], ld3v(S.xpos[gb]) + qrot(qb, ld3(m->g_pos[g])));
-      st4v(S.col.gquat[g], qmul(qb, ld4(m->g_quat[g])));
+      st3v(S.col.gpos[g], ld3v(S.xpos[gb]) + qrot(qb, ld3v(T.g_pos[g])));
+      st4v(S.col.gquat[g], qmul(qb, ld4v(T.g_quat[g])));
     }
     WSYNC();
+    STAMP(11);
     int mycount = 0;
     int myp = 0;
-    if (m->enable_collision) {
+    if (enable_collision) {
       // broadphase: bounding test per static candidate pair, ordered compaction of survivors
       int base = 0;
-      for (int p0 = 0; p0 < m->npair; p0 += G) {
+      for (int p0 = 0; p0 < npair; p0 += G) {
         int p = p0 + lane;
         bool hit = false;
-        if (p < m->npair) {
-          int g1 = m->p_g1[p], g2 = m->p_g2[p];
-          V3 h2 = ld3(m->g_size[g2]);
+        if (p < npair) {
+          const int pr = T.pair[p];
+          const int g1 = pr & 255, g2 = pr >> 8;
+          V3 h2 = ld3v(T.g_size[g2]);
           M3 R2 = q2m(ld4v(S.col.gquat[g2]));
           V3 c2 = ld3v(S.col.gpos[g2]);
-          if (m->g_type[g1] == MIR_GEOM_PLANE) {
+          if (T.g_info[g1][1] == MIR_GEOM_PLANE) {
             V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
             float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
             hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
           } else {
-            V3 h1 = ld3(m->g_size[g1]);
+            V3 h1 = ld3v(T.g_size[g1]);
             float rs = sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
             V3 dc = c2 - ld3v(S.col.gpos[g1]);
             hit = dot(dc, dc) <= rs * rs;
@@ -728,57 +754,61 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       const int ncand = base < G ? base : G;
       if (lane == 0) S.ncand = ncand;
       WSYNC();
+      STAMP(12);
       // narrowphase: lane k handles candidate k
       if (lane < ncand) {
         int p = S.col.cand[lane];
         myp = p;
-        int g1 = m->p_g1[p], g2 = m->p_g2[p];
+        const int pr = T.pair[p];
+        const int g1 = pr & 255, g2 = pr >> 8;
         M3 R2 = q2m(ld4v(S.col.gquat[g2]));
-        BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(m->g_size[g2])};
+        BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
         V3 n = v3(0, 0, 1);
         M3 R1 = q2m(ld4v(S.col.gquat[g1]));
-        if (m->g_type[g1] == MIR_GEOM_PLANE) {
+        if (T.g_info[g1][1] == MIR_GEOM_PLANE) {
           mycount = plane_box(ld3v(S.col.gpos[g1]), R1, B2, S.col.stage[lane], n);
         } else {
-          BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(m->g_size[g1])};
+          BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
           mycount = box_box(B1, B2, S.col.stage[lane], n);
         }
         st3v(S.col.snorm[lane], n);
       }
     }
+    STAMP(13);
     // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
-    const int maxc = m->max_contacts < MAXCON ? m->max_contacts : MAXCON;
+    const int maxc = max_contacts < MAXCON ? max_contacts : MAXCON;
     {
-      int incl = mycount;
-#pragma unroll
-      for (int o = 1; o < G; o <<= 1) {
-        int up = __shfl_up(incl, o, G);
-        if (lane >= o) incl += up;
-      }
+      // inclusive prefix sum over the row by DPP shifts (zeros shifted in), total from lane 15
+      float inclf = (float)mycount;
+      inclf += row_shr<1>(inclf);
+      inclf += row_shr<2>(inclf);
+      inclf += row_shr<4>(inclf);
+      inclf += row_shr<8>(inclf);
+      const int incl = (int)inclf;
       const int off = incl - mycount;
-      const int total = __shfl(incl, G - 1, G);
+      const int total = (int)row_bcast<15>(inclf);
       if (lane == 0) S.ncon = total < maxc ? total : maxc;
       if (mycount > 0) {
-        const int g1 = m->p_g1[myp], g2 = m->p_g2[myp];
+        const int pr = T.pair[myp];
+        const int g1 = pr & 255, g2 = pr >> 8;
         const V3 n = ld3v(S.col.snorm[lane]);
         V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
         t1 = t1 - dot(n, t1) * n;
         t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
         const V3 t2 = cross(n, t1);
-        const float mu = fmaxf(m->g_friction[g1], m->g_friction[g2]);
-        const float sr0 = 0.5f * (m->g_solref[g1][0] + m->g_solref[g2][0]), sr1 = 0.5f * (m->g_solref[g1][1] + m->g_solref[g2][1]);
-        float si[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) si[k] = 0.5f * (m->g_solimp[g1][k] + m->g_solimp[g2][k]);
-        const int b1 = m->g_body[g1], b2 = m->g_body[g2];
-        const float wsum = m->b_invweight0[b1] + m->b_invweight0[b2];
+        const float mu = fmaxf(T.g_pos[g1][3], T.g_pos[g2][3]);
+        const f4 s1a = ldv(&T.g_sol[g1][0]), s1b = ldv(&T.g_sol[g1][4]), s2a = ldv(&T.g_sol[g2][0]), s2b = ldv(&T.g_sol[g2][4]);
+        const float sr0 = 0.5f * (s1a.x + s2a.x), sr1 = 0.5f * (s1a.y + s2a.y);
+        const float si[5] = {0.5f * (s1a.z + s2a.z), 0.5f * (s1a.w + s2a.w), 0.5f * (s1b.x + s2b.x), 0.5f * (s1b.y + s2b.y), 0.5f * (s1b.z + s2b.z)};
+        const int b1 = T.g_info[g1][0], b2 = T.g_info[g2][0];
+        const float wsum = T.b_invw[b1] + T.b_invw[b2];
         const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
         const float tc = fmaxf(sr0, 2.0f * dt);
         const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
-        const uint32_t dm1 = m->b_dofmask[b1], dm2 = m->b_dofmask[b2];
+        const uint32_t dm1 = (uint32_t)T.b_info[b1][0], dm2 = (uint32_t)T.b_info[b2][0];
         const uint32_t inv = dm1 | dm2;
         const uint32_t chunks = ((inv & 0xfu) ? 1u : 0u) | ((inv & 0xf0u) ? 2u : 0u) | ((inv & 0xf00u) ? 4u : 0u) | ((inv & 0xf000u) ? 8u : 0u);
-        const V3 ref1 = ld3v(S.xpos[m->b_root[b1]]), ref2 = ld3v(S.xpos[m->b_root[b2]]);
+        const V3 ref1 = ld3v(S.xpos[T.b_info[b1][1]]), ref2 = ld3v(S.xpos[T.b_info[b2][1]]);
         // staging lives in col scratch, which does not overlap the contact arrays
         for (int c = 0; c < mycount; c++) {
           const int k = off + c;
@@ -820,16 +850,17 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     float lsg = 0.0f, lD = 0.0f, laref = 0.0f;
     if (d_limited) {
       float q = S.qpos[d_qadr];
-      float dlo = q - m->d_lo[lane], dhi = m->d_hi[lane] - q;
+      const f4 l0 = ldv(&T.d_lim[lane][0]);  // lo, hi, invweight0, k
+      float dlo = q - l0.x, dhi = l0.y - q;
       float pos = 0.0f;
       if (dlo < 0.0f) { pos = dlo; lsg = 1.0f; }
       else if (dhi < 0.0f) { pos = dhi; lsg = -1.0f; }
       if (lsg != 0.0f) {
-        const float* si = m->d_solimp[lane];
-        float imp = impedance(si[0], si[1], si[2], si[3], si[4], pos);
-        float Rr = fmaxf((1.0f - imp) / imp * m->d_invweight0[lane], 1e-15f);
+        const f4 l1 = ldv(&T.d_lim[lane][4]), l2 = ldv(&T.d_lim[lane][8]);  // b, solimp[0..2] | solimp[3..4]
+        float imp = impedance(l1.y, l1.z, l1.w, l2.x, l2.y, pos);
+        float Rr = fmaxf((1.0f - imp) / imp * l0.z, 1e-15f);
         lD = 1.0f / Rr;
-        laref = -m->d_b[lane] * (lsg * S.qvel[lane]) - m->d_k[lane] * imp * pos;
+        laref = -l1.x * (lsg * S.qvel[lane]) - l0.w * imp * pos;
       }
     }
     WSYNC();
@@ -915,44 +946,53 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         stv(S.con.cfb[lane], f4{f[0] + f[1] + f[2] + f[3], cmu * (f[0] - f[1]), cmu * (f[2] - f[3]), (float)bits});
       }
       WSYNC();
-      // ---- gradient and Hessian row (lane = dof): H = Mt + J^T D_active J, built per contact from
-      // the 3x3 weight of its pyramid in (n, t1, t2) coordinates
-      float g = 0.0f;
+      if (it == 0) STAMP(16);
+      // ---- gradient first (cheap): convergence is decided before any Hessian work
+      float g = isdof ? Ma - qfs - lsg * lf : 0.0f;
+      for (int c = 0; c < ncon; c++) {
+        const float* jb = &S.Jb[c][0];
+        const f4 fb = ldv(S.con.cfb[c]);
+        g -= jb[lane] * fb.x + jb[16 + lane] * fb.y + jb[32 + lane] * fb.z;
+      }
+      if (!isdof) g = 0.0f;
+      if (it == 0) STAMP(17);
+      const float gn = sqrtf(gsum(g * g));
+      if (!done && (scale * gn < tol || gn < gfloor)) done = true;
+      if (it == 0) STAMP(14);
+      if (!__any(!done)) break;
+      // ---- Hessian row (lane = dof): H = Mt + J^T D_active J, built per contact from the 3x3 weight
+      // of its pyramid in (n, t1, t2) coordinates
       float hrow[G];
 #pragma unroll
       for (int j = 0; j < G; j++) hrow[j] = isdof ? mrow[j] + (j == lane ? lact : 0.0f) : (j == lane ? 1.0f : 0.0f);
-      if (isdof) g = Ma - qfs - lsg * lf;
       for (int c = 0; c < ncon; c++) {
         const float* jb = &S.Jb[c][0];
         const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
         const f4 fb = ldv(S.con.cfb[c]);
         const f4 mt = ldv(S.con.cmeta[c]);
-        g -= jn * fb.x + j1 * fb.y + j2 * fb.z;
         const unsigned bits = (unsigned)fb.w;
         const float mu = mt.x, D = mt.y;
         const float a0 = (bits & 1u) ? D : 0.0f, a1 = (bits & 2u) ? D : 0.0f, a2 = (bits & 4u) ? D : 0.0f, a3 = (bits & 8u) ? D : 0.0f;
         const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
         const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
-        const unsigned chunks = S.con.cmask[c][2];
+        // all twelve 16-byte row reads are issued back to back (one wait), no per-chunk branches
+        f4 xn[4], x1[4], x2[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { xn[q] = ldv(jb + 4 * q); x1[q] = ldv(jb + 16 + 4 * q); x2[q] = ldv(jb + 32 + 4 * q); }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          if (chunks >> q & 1u) {  // group-uniform: only 4-dof chunks this contact touches
-            const f4 xn = ldv(jb + 4 * q), x1 = ldv(jb + 16 + 4 * q), x2 = ldv(jb + 32 + 4 * q);
-            hrow[4 * q + 0] += tn * xn.x + t1 * x1.x + t2 * x2.x;
-            hrow[4 * q + 1] += tn * xn.y + t1 * x1.y + t2 * x2.y;
-            hrow[4 * q + 2] += tn * xn.z + t1 * x1.z + t2 * x2.z;
-            hrow[4 * q + 3] += tn * xn.w + t1 * x1.w + t2 * x2.w;
-          }
+          hrow[4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
+          hrow[4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
+          hrow[4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
+          hrow[4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
         }
       }
-      if (!isdof) g = 0.0f;
-      const float gn = sqrtf(gsum(g * g));
-      if (!done && (scale * gn < tol || gn < gfloor)) done = true;
-      if (!__any(!done)) break;
+      if (it == 0) STAMP(18);
       // ---- Newton direction: H s = -g
       float sv = -g;
       GJ<0>::run(hrow, sv, lane);
       if (!isdof) sv = 0.0f;
+      if (it == 0) STAMP(15);
       S.srch[lane] = sv;
       WSYNC();
       const float mv = isdof ? rowdot(mrow, S.srch) : 0.0f;
@@ -963,6 +1003,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         jdot3(&S.Jb[lane][0], S.srch, xn, x1, x2);
         jv[0] = xn + cmu * x1; jv[1] = xn - cmu * x1; jv[2] = xn + cmu * x2; jv[3] = xn - cmu * x2;
       }
+      if (it == 0) STAMP(19);
       // ---- exact line search on the piecewise-quadratic phi(alpha): safeguarded Newton on phi'
       const float A = gsum(sv * mv), Bq = gsum(sv * (Ma - qfs));
       float alpha = 0.0f, lo = 0.0f, hi = -1.0f, g0 = 0.0f;
@@ -992,6 +1033,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         }
         if (!__any(!lsdone)) break;
       }
+      if (it == 0) STAMP(20);
       // ---- improvement from the 1-D model, then the update
       float pim = 0.0f;
 #pragma unroll
@@ -1014,6 +1056,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         if (scale * improvement < tol) done = true;
       }
       WSYNC();
+      if (it == 0) STAMP(21);
     }
     if (a.out_qacc && valid && isdof && step == 0) a.out_qacc[(size_t)env * nv + lane] = qacc;
     if (a.diag && valid && lane == 0) {
@@ -1035,9 +1078,9 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     if (isdof) {
       const float qd = S.qvel[lane];
       if (d_kind < 2) S.qpos[d_qadr] += dt * qd;
-      else if (d_kind == 2) S.qpos[m->b_qadr[d_body] + d_axis_k] += dt * qd;
+      else if (d_kind == 2) S.qpos[T.b_info[d_body][2] + d_axis_k] += dt * qd;
       else if (d_axis_k == 0) {
-        const int da = m->b_dofadr[d_body], qa = m->b_qadr[d_body];
+        const int da = T.b_info[d_body][3], qa = T.b_info[d_body][2];
         V3 w = v3(S.qvel[da + 3], S.qvel[da + 4], S.qvel[da + 5]);
         float wn = sqrtf(dot(w, w));
         float ang = wn * dt;
@@ -1051,13 +1094,18 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       }
     }
     WSYNC();
+    STAMP(9);
+    // kinematics of the new state: observations of this step, and the next step's starting poses
+    group_fk(S, lane, nb, parents, bk);
   }  // steps
-  STAMP(9);
-
-  // ======================= final kinematics for observations =========================================
-  if (a.mode != 1) group_fk(S, lane, nb, parents, bk);
   STAMP(10);
   if (!valid) return;
+  if (lane < nb) {
+    float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
+    *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
+    *reinterpret_cast<f4*>(p + 4 * G) = ldv(S.xquat[lane]);
+  }
+  if (lane == 0) a.fkvalid[env] = 1;
   // ---- store state ---------------------------------------------------------------------------------
   if (a.mode == 0) {
     for (int i = lane; i < qst; i += G) a.qpos[(size_t)env * qst + i] = S.qpos[i];

@@ -38,21 +38,30 @@ def main():
     sc.lib.mir_debug_profile_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     sc.lib.mir_debug_profile_step.restype = C.c_int
     acc = np.zeros(10)
+    sub = np.zeros(7)
+    nw = np.zeros(8)
     n = 20
     for k in range(n):
         sc.set_pd_targets(acts[k % 64])
-        prof = torch.zeros(16, dtype=torch.int64, device=sc.device)
+        prof = torch.zeros(32, dtype=torch.int64, device=sc.device)
         sc._check(sc.lib.mir_debug_profile_step(sc.h, C.c_void_p(prof.data_ptr()), sc._stream()))
         p = prof.cpu().numpy().astype(np.float64)
         acc += np.diff(p[:11])
+        nw += np.array([p[16]-p[7], p[17]-p[16], p[14]-p[17], p[18]-p[14], p[15]-p[18], p[19]-p[15], p[20]-p[19], p[21]-p[20]])
+        sub += np.array([p[11]-p[4], p[12]-p[11], p[13]-p[12], p[5]-p[13], p[14]-p[7], p[15]-p[14], p[8]-p[15]])
     acc /= n
+    nw /= n
+    sub /= n
     print(f"B={B}: phase cycles (block 0, shader clock; avg of {n} steps)")
     for name, c in zip(PHASES, acc):
         print(f"  {name:14s} {c:9.0f} cyc  {100 * c / acc.sum():5.1f}%")
     print(f"  total          {acc.sum():9.0f} cyc")
+    print("  collide split: geoms %.0f | broadphase %.0f | narrowphase %.0f | compaction+contacts %.0f" % (sub[0], sub[1], sub[2], sub[3]))
+    print("  newton it0 split: forces+H build %.0f | gsum+GJ %.0f | rest of iteration(s) %.0f" % (sub[4], sub[5], sub[6]))
+    print("  newton it0 fine: forces/cfb %.0f | gradient loop %.0f | gsum+check %.0f | H build %.0f | GJ %.0f | mv+jv %.0f | line search %.0f | improvement+update %.0f" % tuple(nw))
     nc, ne, ni = (x.cpu().numpy() for x in sc.get_diag())
     print(f"  ncon mean {nc.mean():.2f} nefc mean {ne.mean():.2f} niter mean {ni.mean():.2f} max {ni.max()}")
-    for Bx in (256, 1024, 2048, 4096, 8192, 16384, 65536):
+    for Bx in (256, 4096, 65536):
         s2, a2, b2 = setup(Bx, warm=20)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
