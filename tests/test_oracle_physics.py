@@ -319,3 +319,30 @@ def test_reward_threshold_is_strict_float32():
         _, env, r, t = o.get_obs()
         assert r[0] == want and t[0] == want
         assert env.shape == (1, 11)
+
+
+def test_scripted_grasp_lifts_cube_and_reward_flips_at_threshold():
+    """App. D-7: symmetric finger closure keeps the cube in place, the lift raises it, and the
+    reward / terminated flag flips exactly when the cube's z exceeds 0.1 (cube_pick.py:134, env.py:63)."""
+    import json
+    import os
+
+    G_ = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "grasp_targets.json")))
+    B = len(G_["cube_xy"])
+    o = orc.Oracle(make().build(), B)
+    pos = np.array([[x, y, 0.02] for x, y in G_["cube_xy"]], np.float32)
+    o.reset(pos, np.tile([0, 0, 0, 1.0], (B, 1)), np.tile(HOME, (B, 1)))
+    T = np.array(G_["targets"], np.float32)
+    flipped = np.zeros(B, bool)
+    for s, name in enumerate(G_["stages"]):
+        for k in range(G_["steps_per_stage"]):
+            o.step_batch(T[:, s])
+            a, e, r, term = o.get_obs()
+            assert np.array_equal(r == 1, np.float32(e[:, 2]) > np.float32(0.1)) and np.array_equal(term.astype(bool), r == 1)
+            flipped |= r == 1
+        if name == "close":
+            assert np.abs(e[:, :2] - pos[:, :2]).max() < 2e-3  # squeezed symmetrically: the cube stays put
+            assert all(o.counts(i)[0] >= 8 for i in range(B))  # plane + two finger pads
+    assert flipped.all() and (e[:, 2] > 0.2).all()             # every env picked its cube up
+    assert np.abs(a[:, 7] - a[:, 8]).max() < 1e-3               # fingers closed symmetrically on the 4 cm cube
+    assert np.abs(a[:, 7] - 0.0185).max() < 2e-3
