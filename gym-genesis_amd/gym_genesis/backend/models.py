@@ -102,3 +102,60 @@ def franka_cube_pick_scene(cube_size=0.04, cube_pos=(0.65, 0.0, 0.02), cube_rho=
     sb.task = dict(eef_body=sb.body_index("hand"), obj_body=sb.body_index("cube"),
                    grip_dof=(sb.dof_index("finger_joint1"), sb.dof_index("finger_joint2")), reward_z=0.1)
     return sb
+
+
+# ------------------------------------------------------------------------------------------------
+# SO-101 pick scene (BASELINE.json configs[3]; reference: tasks/so101/cube_pick.py + tasks/utils.py:428-590)
+#
+# The SO-101 MJCF lives in an un-vendored git submodule (/root/reference/.gitmodules:1-3, directory
+# empty), so the arm is RE-STATED from the public SO-ARM100/SO-101 description (UPSTREAM-RECALL,
+# unverified; parity unpinned either way): six revolute joints -- shoulder_pan (z), shoulder_lift,
+# elbow_flex, wrist_flex (y), wrist_roll (x), gripper jaw (z) -- link offsets of roughly
+# 0.062 / 0.054 / 0.113 / 0.135 / 0.061 / 0.098 m, link masses 0.08-0.15 kg, STS3215 servo joint
+# defaults (armature 0.028, damping 0.6).  Collision meshes are replaced by boxes.
+# What IS taken from the reference: the x4 scale and mount pose (utils.py:559-568), the island slab
+# top height 0.7000313 (utils.py:571-578) with its +-0.915 x +-0.401 m extent,
+# the cube size / spawn height top+0.02+0.001 (utils.py:581-586), friction 5 on robot and cube
+# (so101/cube_pick.py:38-39), kp 1000 / kv 200 on the five arm dofs (:41-42), dt 0.01.
+SO101_JOINTS = ("joint1", "joint2", "joint3", "joint4", "joint5", "joint6")  # so101/cube_pick.py:7-14
+ISLAND_TOP_Z = 0.7000312834978104  # literal at examples/franka/stack_cube_one_image.py:38
+SO101_SCALE = 4.0
+
+# name, parent, pos in parent (unscaled), axis, range, mass (unscaled), box half extents, box centre
+_SO101_LINKS = (
+    ("shoulder", "so101_base", (0.0388, 0.0, 0.0624), (0, 0, 1), (-1.92, 1.92), 0.100, (0.025, 0.025, 0.027), (0.0, 0.0, 0.027)),
+    ("upper_arm", "shoulder", (0.0, 0.0, 0.0542), (0, 1, 0), (-1.745, 1.745), 0.103, (0.018, 0.018, 0.0563), (0.0, 0.0, 0.0563)),
+    ("lower_arm", "upper_arm", (0.0, 0.0, 0.1126), (0, 1, 0), (-1.69, 1.69), 0.104, (0.0675, 0.016, 0.016), (0.0675, 0.0, 0.0)),
+    ("wrist", "lower_arm", (0.1349, 0.0, 0.0), (0, 1, 0), (-1.658, 1.658), 0.079, (0.0305, 0.015, 0.015), (0.0305, 0.0, 0.0)),
+    ("gripper", "wrist", (0.0611, 0.0, 0.0), (1, 0, 0), (-2.74, 2.84), 0.087, (0.025, 0.02, 0.012), (0.025, 0.0, 0.0)),
+    ("jaw", "gripper", (0.03, 0.012, 0.0), (0, 0, 1), (-0.17, 1.745), 0.012, (0.034, 0.004, 0.01), (0.036, 0.006, 0.0)),
+)
+
+
+def so101_cube_pick_scene(cube_size=0.04, cube_pos=(-0.3, 0.0, ISLAND_TOP_Z + 0.021), cube_rho=200.0) -> SceneBuilder:
+    sb = SceneBuilder()
+    s = SO101_SCALE
+    fr = 5.0
+    sb.add_geom(0, GEOM_PLANE)                                                        # kitchen floor, z = 0
+    sb.add_geom(0, GEOM_BOX, size=(0.915, 0.401, 0.05), pos=(0.0, 0.0, ISLAND_TOP_Z - 0.05))  # island slab (static)
+    sb.add_body("so101_base", 0, pos=(-0.5, 0.0, 0.7), mass=0.147 * s ** 3, ipos=(0.0, 0.0, 0.03 * s),
+                inertia=box_inertia(0.147 * s ** 3, (0.04 * s, 0.04 * s, 0.03 * s)))
+    sb.add_geom("so101_base", GEOM_BOX, size=(0.04 * s, 0.04 * s, 0.03 * s), pos=(0.0, 0.0, 0.03 * s + 0.002), friction=fr)
+    for i, (name, parent, pos, axis, rng, mass, half, centre) in enumerate(_SO101_LINKS):
+        m = mass * s ** 3
+        hs = tuple(h * s for h in half)
+        cs = tuple(c * s for c in centre)
+        arm = i < 5
+        sb.add_body(name, parent, pos=tuple(p * s for p in pos), jtype=JNT_REVOLUTE, axis=axis, mass=m, ipos=cs,
+                    inertia=box_inertia(m, hs), joint_name=SO101_JOINTS[i], limited=1, range=rng, armature=0.028, damping=0.6,
+                    ctrl_mode=CTRL_POSITION, kp=1000.0 if arm else 100.0, kv=200.0 if arm else 10.0, frc_range=(-1e30, 1e30))
+        sb.add_geom(name, GEOM_BOX, size=hs, pos=cs, friction=fr)
+    # fixed finger of the gripper, opposite the moving jaw
+    sb.add_geom("gripper", GEOM_BOX, size=(0.034 * s, 0.004 * s, 0.01 * s), pos=(0.066 * s, -0.018 * s, 0.0), friction=fr)
+    h = cube_size / 2
+    mass = cube_rho * cube_size ** 3
+    sb.add_body("cube", 0, pos=cube_pos, quat=(1, 0, 0, 0), jtype=JNT_FREE, mass=mass, inertia=box_inertia(mass, (h, h, h)))
+    sb.add_geom("cube", GEOM_BOX, size=(h, h, h), friction=fr)
+    # eef link "gripper" (so101/cube_pick.py:37), gripper dof = joint6 (:36,:120), reward z > 0.1 (:112)
+    sb.task = dict(eef_body=sb.body_index("gripper"), obj_body=sb.body_index("cube"), grip_dof=(sb.dof_index("joint6"),), reward_z=0.1)
+    return sb

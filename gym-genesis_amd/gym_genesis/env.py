@@ -24,6 +24,7 @@ from ._gym import Env
 # (robot, task, batched) -> "module:Class" ; resolved lazily so importing gym_genesis stays light
 _TASKS = {
     ("franka", "cube_pick", True): "gym_genesis.tasks.franka.cube_pick:FrankaCubePickBatch",
+    ("so101", "cube_pick", True): "gym_genesis.tasks.so101.cube_pick:CubePick",
 }
 
 

@@ -1,0 +1,122 @@
+"""SO-101 cube-pick task on the MI355X backend (BASELINE.json configs[3]).
+
+Contract restated from /root/reference/gym_genesis/tasks/so101/cube_pick.py:18-158 and the scene
+builder /root/reference/gym_genesis/tasks/utils.py:428-590:
+  * kitchen island slab (top z = 0.70003), SO-101 x4 at (-0.5, 0, 0.7), 4 cm cube on the slab  (utils.py:543-587)
+  * friction 5 on robot and cube, kp 1000 / kv 200 on the five arm dofs                   (cube_pick.py:38-42)
+  * reset(): x ~ U(-0.32, -0.28), y ~ U(-0.05, 0.05), z = island_top + 0.021; cube quat (1,0,0,0);
+    arm qpos = targets = 0; NO physics step                                                 (:58-83)
+  * step(a): targets <- a[:5] (arm) and a[5:] (gripper); one physics step                  (:100-106)
+  * reward = float32(cube_z > 0.1) -- with the cube resting on a 0.70 m slab this is 1 from the
+    first step on; reproduced literally                                                     (:108-113)
+  * obs: agent_pos = [eef pos3, eef quat4, gripper q1] (8 values although the declared space says
+    6), environment_state = [cube pos3, quat4, eef-cube 3, dist 1] (11, declared 10)       (:115-132, :45-56)
+
+Position taken on the reference's defect C-2: the reference class is unbatched although
+the registry routes the batched key to it; here every quantity carries the env axis (B, .), and
+B = 1 draws the same RNG stream as the reference.  The arm model is re-stated (see backend/models.py).
+"""
+from __future__ import annotations
+
+import random
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..._gym import spaces
+from ...backend import models
+from ...backend.lib import MirScene
+from ..views import EntityView, SceneView
+
+AGENT_DIM = len(models.SO101_JOINTS)  # declared space shape, as in the reference (cube_pick.py:15)
+ENV_DIM = 10                          # declared space shape (cube_pick.py:16)
+AGENT_OBS, ENV_OBS = 8, 11            # what get_obs() actually returns
+
+
+class CubePick:
+    def __init__(self, enable_pixels, observation_height, observation_width, num_envs, env_spacing,
+                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None):
+        self.enable_pixels = enable_pixels
+        self.observation_height = observation_height
+        self.observation_width = observation_width
+        self.camera_capture_mode = camera_capture_mode
+        self.strip_environment_state = strip_environment_state
+        self.global_num_envs = int(num_envs)
+        rank, world = shard if shard is not None else (0, 1)
+        self.shard_lo = self.global_num_envs * rank // world
+        self.shard_hi = self.global_num_envs * (rank + 1) // world
+        self.num_envs = self.shard_hi - self.shard_lo
+        self._random = np.random.RandomState()
+        if enable_pixels:
+            raise NotImplementedError("enable_pixels=True needs the batched rasteriser (SURVEY.md 8f-2), not built yet")
+        builder = models.so101_cube_pick_scene()
+        self._builder = builder
+        self._mir = MirScene(builder.build(), self.num_envs)
+        self.device = self._mir.device
+        self.island_top_z = models.ISLAND_TOP_Z
+        self.scene = SceneView(self._mir, env_spacing=env_spacing, global_num_envs=self.global_num_envs, offset=self.shard_lo)
+        self.so_101 = EntityView(self._mir, builder, root="so101_base", dof_names=models.SO101_JOINTS)
+        self.cube = EntityView(self._mir, builder, root="cube", dof_names=())
+        self.eef = self.so_101.get_link("gripper")
+        self.motors_dof = np.arange(5)
+        self.fingers_dof = np.array([5])
+        box = lambda n: spaces.Box(low=-np.inf, high=np.inf, shape=(n,), dtype=np.float32)  # noqa: E731
+        self.observation_space = spaces.Dict({"agent_pos": box(AGENT_DIM), "environment_state": box(ENV_DIM)})
+        self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(AGENT_DIM,), dtype=np.float32)
+        B, dev = self.num_envs, self.device
+        self._zero = torch.zeros((B, AGENT_DIM), dtype=torch.float32, device=dev)
+        self._quat = torch.tensor([[1.0, 0.0, 0.0, 0.0]], dtype=torch.float32, device=dev).repeat(B, 1)
+        self._agent, self._envst = self._mir.empty(AGENT_OBS), self._mir.empty(ENV_OBS)
+        self._reward, self._term = self._mir.empty(), self._mir.empty(dtype=torch.uint8)
+
+    def get_cams(self):
+        if not self.enable_pixels:
+            raise ValueError("Cameras are not enabled. Set `enable_pixels=True` when creating the environment.")
+        return self.cam
+
+    def seed(self, seed):
+        np.random.seed(seed)
+        random.seed(seed)
+        self._random = np.random.RandomState(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed)
+        self.action_space.seed(seed)
+
+    def sample_spawn(self) -> np.ndarray:
+        Bg = self.global_num_envs
+        x = self._random.uniform(-0.32, -0.28, size=(Bg,))
+        y = self._random.uniform(-0.05, 0.05, size=(Bg,))
+        z = np.full((Bg,), self.island_top_z + 0.02 + 0.001)
+        return np.stack([x, y, z], axis=1).astype(np.float32)
+
+    def reset(self):
+        pos = torch.from_numpy(self.sample_spawn()[self.shard_lo:self.shard_hi]).to(self.device)
+        self._mir.reset(pos, self._quat, self._zero)  # no scene.step() here (so101/cube_pick.py:81)
+        return self.get_obs()
+
+    def step(self, action):
+        if not isinstance(action, torch.Tensor):
+            action = torch.as_tensor(np.asarray(action))
+        a = action.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, AGENT_DIM).contiguous()
+        mir = self._mir
+        self._agent, self._envst = mir.empty(AGENT_OBS), mir.empty(ENV_OBS)
+        self._reward, self._term = mir.empty(), mir.empty(dtype=torch.uint8)
+        mir.step_fused(a, self._agent, self._envst, self._reward, self._term)
+        return None, self._reward, None, {"agent_pos": self._agent, "environment_state": self._envst}
+
+    def step_raw(self, action_dev: torch.Tensor) -> None:
+        self._mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)
+
+    def compute_reward(self):
+        self.get_obs()
+        return self._reward
+
+    def get_obs(self):
+        self._agent, self._envst, self._reward, self._term = self._mir.get_obs()
+        return {"agent_pos": self._agent, "environment_state": self._envst}
+
+    @property
+    def terminated_device(self) -> torch.Tensor:
+        return self._term

@@ -281,3 +281,57 @@ def test_shard_invariance_bit_exact(franka_spec):
     qb = big.get_state()[0]
     qs = torch.cat([parts[0].get_state()[0], parts[1].get_state()[0]])
     assert torch.equal(qb, qs)
+
+
+# ---------------------------------------------------------------- SO-101 (alternate articulation, cfg 4)
+def test_so101_scene_parity():
+    """Six revolute joints about z/y/x axes, static slab support (box-box with a world-fixed box),
+    friction 5: per-stage forward dynamics at random states and a 300-step PD-tracked rollout."""
+    spec = models.so101_cube_pick_scene().build()
+    B = 16
+    rng = np.random.default_rng(3)
+    sc, o = _scene(spec, B), orc.Oracle(spec, B)
+    assert (sc.nq, sc.nv, sc.nu, sc.agent_dim) == (13, 12, 6, 8)
+    dw, bw, mi = sc.model_consts()
+    assert np.allclose(dw, o.read(orc.F_DOF_INVWEIGHT0), rtol=1e-9) and np.allclose(bw, o.read(orc.F_BODY_INVWEIGHT0), rtol=1e-9, atol=1e-15)
+    # random states: stages
+    q = np.zeros((B, 13), np.float32)
+    q[:, :6] = rng.uniform(-1.0, 1.0, (B, 6))
+    q[:, 6:9] = rng.uniform(-0.2, 0.2, (B, 3)) + [-0.3, 0, 1.0]
+    qt = rng.normal(size=(B, 4))
+    q[:, 9:13] = qt / np.linalg.norm(qt, axis=1, keepdims=True)
+    v = rng.uniform(-1, 1, (B, 12)).astype(np.float32)
+    tgt = rng.uniform(-1, 1, (B, 6)).astype(np.float32)
+    sc.set_state(qpos=q, qvel=v, target=tgt, warmstart=np.zeros((B, 12), np.float32))
+    M, bias, qas, qacc = (t.cpu().numpy().astype(np.float64) for t in sc.forward())
+    o.set_targets(tgt)
+    for e in range(B):
+        o.write(orc.F_QPOS, q[e], e)
+        o.write(orc.F_QVEL, v[e], e)
+        o.forward(e)
+        Mo = o.read(orc.F_M, e).reshape(12, 12)
+        assert np.abs(M[e] - Mo).max() < 2e-5 * np.abs(Mo).max()
+        bo = o.read(orc.F_QFRC_BIAS, e)
+        assert np.abs(bias[e] - bo).max() < 2e-5 * max(1.0, np.abs(bo).max())
+        qo = o.read(orc.F_QACC, e)
+        assert np.abs(qacc[e] - qo).max() < 2e-4 * max(1.0, np.abs(qo).max())
+    # rollout from the task's reset state with smooth targets
+    pos = np.stack([rng.uniform(-0.32, -0.28, B), rng.uniform(-0.05, 0.05, B), np.full(B, models.ISLAND_TOP_Z + 0.021)], 1).astype(np.float32)
+    quat = np.tile(np.array([1, 0, 0, 0], np.float32), (B, 1))
+    arm = np.zeros((B, 6), np.float32)
+    sc.reset(pos, quat, arm)
+    o.reset(pos, quat, arm)
+    bufs = (sc.empty(sc.agent_dim), sc.empty(sc.env_dim), sc.empty(), sc.empty(dtype=torch.uint8))
+    ph = rng.uniform(0, 2 * np.pi, (B, 6))
+    wq = 0.0
+    for t in range(300):
+        a = (0.4 * np.sin(2 * np.pi * t / 150.0 + ph)).astype(np.float32)
+        sc.step_fused(torch.as_tensor(a, device=sc.device), *bufs)
+        o.step_batch(a)
+        if t % 25 == 24:
+            qh = sc.get_state()[0].cpu().numpy()
+            wq = max(wq, np.abs(qh - o.state()[0]).max())
+            _check_obs(sc, o, bufs, 2e-5)
+    print(f"so101 300 steps: qpos L-inf {wq:.3e}")
+    assert wq < 1e-4
+    assert (bufs[3].cpu().numpy() == 1).all()  # cube on the 0.70 m slab: reward threshold 0.1 fires (reference quirk)

@@ -184,3 +184,27 @@ def test_registry_ids_and_defaults(monkeypatch):
         obs, rew, term, trunc, info = env.step(act)
     assert trunc is True  # TimeLimit(200) replaces truncated at the 200th step (gymnasium behaviour)
     assert env.unwrapped.num_envs == 2
+
+
+# ---------------------------------------------------------------- SO-101 pick (registry default robot)
+def test_so101_pick_contract(monkeypatch):
+    import fake_scene
+    from gym_genesis.tasks.so101 import cube_pick as so
+
+    monkeypatch.setattr(so, "MirScene", fake_scene.OracleScene)
+    env = gym_genesis.make("gym_genesis/CubePick-v0", num_envs=2).unwrapped if not _gym.HAVE_GYMNASIUM else None
+    if env is None:
+        pytest.skip("real gymnasium registry")
+    assert type(env._env).__name__ == "CubePick" and env.robot == "so101"               # registry default robot (__init__.py:10)
+    obs, info = env.reset(seed=0)
+    rs = np.random.RandomState(0)
+    x = rs.uniform(-0.32, -0.28, size=(2,)); y = rs.uniform(-0.05, 0.05, size=(2,))     # so101/cube_pick.py:61-62
+    es = obs["environment_state"].numpy()
+    assert obs["agent_pos"].shape == (2, 8) and es.shape == (2, 11)                     # eef 7 + gripper 1 ; 11
+    assert np.allclose(es[:, 0], x, atol=1e-6) and np.allclose(es[:, 1], y, atol=1e-6)
+    assert np.allclose(es[:, 2], models.ISLAND_TOP_Z + 0.021, atol=1e-6)                # no physics step in reset (:81)
+    assert np.allclose(es[:, 3:7], [1, 0, 0, 0])                                        # quat (1,0,0,0) (:68)
+    assert env.observation_space["agent_pos"].shape == (6,) and env.action_space.shape == (6,)  # declared spaces (:45-56)
+    obs, reward, terminated, truncated, info = env.step(np.zeros((2, 6), np.float32))
+    assert terminated.all() and (reward == 1).all()  # cube z ~0.72 > 0.1: the reference's threshold fires at once (:112)
+    assert env.get_robot() is env._env.so_101 and env.get_cube() is env._env.cube
