@@ -117,6 +117,16 @@ class FrankaCubePickBatch:
         self._mir.step(1)                             # the reference consumes one physics step in reset()
         return self.get_obs()
 
+    def reset_masked(self, env_mask):
+        """Per-env reset without touching the other envs (the reference can only reset
+        all envs at once, README.md:41-43).  `env_mask`: (B,) bool/uint8 tensor or array, device or host.
+        Draws one spawn per env from the task RandomState exactly like reset() (so the host stream
+        advances identically whether or not an env is selected); masked envs get the home pose, zero
+        velocity and PD targets = home.  No physics step is consumed: the other envs must not advance."""
+        pos = torch.from_numpy(self.sample_spawn()[self.shard_lo:self.shard_hi]).to(self.device)
+        self._mir.reset(pos, self._quat, self._home, env_mask=env_mask)
+        return self.get_obs()
+
     def step(self, action):
         a = self._as_action(action)
         # fresh output tensors per call, like the reference (callers may keep old observations)

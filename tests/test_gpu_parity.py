@@ -335,3 +335,31 @@ def test_so101_scene_parity():
     print(f"so101 300 steps: qpos L-inf {wq:.3e}")
     assert wq < 1e-4
     assert (bufs[3].cpu().numpy() == 1).all()  # cube on the 0.70 m slab: reward threshold 0.1 fires (reference quirk)
+
+
+def test_masked_reset_leaves_other_envs_bit_identical():
+    """mir_reset(env_mask): selected envs return to the reset state, the rest keep their state bit for bit."""
+    from gym_genesis.env import GenesisEnv
+
+    B = 8
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
+    env.reset(seed=5)
+    task = env._env
+    acts = np.random.default_rng(0).uniform(-1, 1, (20, B, 9)).astype(np.float32)
+    for t in range(20):
+        env.step(acts[t])
+    before = [x.clone() for x in task._mir.get_state()]
+    mask = torch.tensor([1, 0, 0, 1, 0, 0, 0, 1], dtype=torch.uint8)
+    obs = task.reset_masked(mask)
+    after = task._mir.get_state()
+    keep = ~mask.bool().to(after[0].device)
+    for a, b in zip(after, before):
+        assert torch.equal(a[keep], b[keep])
+    sel = mask.bool().to(after[0].device)
+    assert torch.equal(after[0][sel][:, :9], torch.tensor(models.FRANKA_HOME, device=after[0].device).repeat(3, 1))
+    assert (after[1][sel] == 0).all() and (after[3][sel] == 0).all()
+    assert torch.equal(after[2][sel], torch.tensor(models.FRANKA_HOME, device=after[0].device).repeat(3, 1))
+    assert torch.allclose(obs["environment_state"][sel][:, 2], torch.tensor(0.02, device=sel.device)) and torch.allclose(
+        obs["environment_state"][sel][:, 3:7], torch.tensor([0.0, 0, 0, 1], device=sel.device))
+    # the stepped-on envs and the fresh ones keep running together
+    env.step(acts[0])
