@@ -126,6 +126,13 @@ __device__ __forceinline__ float gsum(float v) {  // all-reduce sum over the row
   v += row_ror<8>(v);
   return v;
 }
+__device__ __forceinline__ float gmaxf(float v) {  // all-reduce max over the row
+  v = fmaxf(v, row_ror<1>(v));
+  v = fmaxf(v, row_ror<2>(v));
+  v = fmaxf(v, row_ror<4>(v));
+  v = fmaxf(v, row_ror<8>(v));
+  return v;
+}
 __device__ __forceinline__ int gsumi(int v) { return (int)(gsum((float)v) + 0.5f); }
 
 // ---- Gauss-Jordan solve A x = b on register rows: lane i holds row i of the SPD matrix A in
@@ -183,6 +190,7 @@ struct DynScratch {
 struct ColScratch {
   float gpos[MIR_MAX_GEOM][4], gquat[MIR_MAX_GEOM][4];
   int cand[G];
+  int cmap[G];                    // contact slot -> candidate lane * 8 + point index
   float stage[G][8][4];           // narrowphase output per candidate pair: pos, dist
   float snorm[G][4];
 };
@@ -222,50 +230,6 @@ struct BoxG {
 };
 __device__ __forceinline__ V3 bax(const BoxG& b, int k) { return k == 0 ? b.a0 : (k == 1 ? b.a1 : b.a2); }
 __device__ __forceinline__ float bh(const BoxG& b, int k) { return k == 0 ? b.h.x : (k == 1 ? b.h.y : b.h.z); }
-
-// plane z=0 of frame (pp, Rp) vs box; writes up to 4 points {pos, dist}; returns count
-__device__ int plane_box(V3 pp, const M3& Rp, const BoxG& bx, float (*out)[4], V3& n) {
-  n = mcol(Rp, 2);
-  V3 eu = mcol(Rp, 0), ev = mcol(Rp, 1);
-  float d[8], u[8], v[8];
-  int cnt = 0;
-#pragma unroll
-  for (int c = 0; c < 8; c++) {
-    V3 w = bx.p + ((c & 1) ? bx.h.x : -bx.h.x) * bx.a0 + ((c & 2) ? bx.h.y : -bx.h.y) * bx.a1 + ((c & 4) ? bx.h.z : -bx.h.z) * bx.a2;
-    V3 rel = w - pp;
-    d[c] = dot(rel, n);
-    u[c] = dot(rel, eu);
-    v[c] = dot(rel, ev);
-    cnt += d[c] < 0.0f;
-  }
-  if (cnt == 0) return 0;
-  // support extremes (+u, -u, +v, -v; first index wins ties) among penetrating corners when > 4 penetrate
-  int p0 = -1, p1 = -1, p2 = -1, p3 = -1;
-  if (cnt > 4) {
-    float uM = -3e38f, um = 3e38f, vM = -3e38f, vm = 3e38f;
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-      if (d[c] < 0.0f) {
-        if (u[c] > uM) { uM = u[c]; p0 = c; }
-        if (u[c] < um) { um = u[c]; p1 = c; }
-        if (v[c] > vM) { vM = v[c]; p2 = c; }
-        if (v[c] < vm) { vm = v[c]; p3 = c; }
-      }
-    }
-  }
-  int k = 0;
-#pragma unroll
-  for (int c = 0; c < 8; c++) {
-    bool keep = d[c] < 0.0f && (cnt <= 4 || c == p0 || c == p1 || c == p2 || c == p3);
-    if (keep && k < 4) {
-      V3 w = bx.p + ((c & 1) ? bx.h.x : -bx.h.x) * bx.a0 + ((c & 2) ? bx.h.y : -bx.h.y) * bx.a1 + ((c & 4) ? bx.h.z : -bx.h.z) * bx.a2;
-      V3 pos = w - (0.5f * d[c]) * n;
-      out[k][0] = pos.x; out[k][1] = pos.y; out[k][2] = pos.z; out[k][3] = d[c];
-      k++;
-    }
-  }
-  return k;
-}
 
 // box-box by separating axes + reference-face clipping; normal from A to B; up to 8 points.
 // Rare (only when bounding spheres overlap) and register-hungry: kept out of line.
@@ -463,6 +427,8 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
   const DevModel* __restrict__ m = a.model;
   const int tid = threadIdx.x;
+  STAMP(24);
+  if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[26] = __builtin_amdgcn_s_memrealtime();
   {
     const f4* src = reinterpret_cast<const f4*>(&m->tab);
     f4* dst = reinterpret_cast<f4*>(&T);
@@ -721,7 +687,6 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     WSYNC();
     STAMP(11);
     int mycount = 0;
-    int myp = 0;
     if (enable_collision) {
       // broadphase: bounding test per static candidate pair, ordered compaction of survivors
       int base = 0;
@@ -755,23 +720,59 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       if (lane == 0) S.ncand = ncand;
       WSYNC();
       STAMP(12);
-      // narrowphase: lane k handles candidate k
+      // narrowphase, plane-box: one candidate at a time, its 8 box corners on lanes 0..7 of the group
+      // (wave-uniform loop: the DPP/ballot selection below needs all lanes present)
+      for (int k = 0; k < G; k++) {
+        const bool act = k < ncand;
+        if (!__any(act)) break;
+        const int pr = act ? T.pair[S.col.cand[k]] : 0;
+        const int g1 = pr & 255, g2 = pr >> 8;
+        const bool isplane = act && T.g_info[g1][1] == MIR_GEOM_PLANE;
+        if (!__any(isplane)) continue;
+        const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
+        const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
+        const M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+        const V3 h = ld3v(T.g_size[g2]);
+        const int c = lane & 7;
+        const V3 w = ld3v(S.col.gpos[g2]) + ((c & 1) ? h.x : -h.x) * mcol(R2, 0) + ((c & 2) ? h.y : -h.y) * mcol(R2, 1) +
+                     ((c & 4) ? h.z : -h.z) * mcol(R2, 2);
+        const V3 rel = w - ld3v(S.col.gpos[g1]);
+        const float d = dot(rel, n), u = dot(rel, eu), v = dot(rel, ev);
+        const bool pen = isplane && lane < 8 && d < 0.0f;
+        const uint32_t penm = (uint32_t)(__ballot(pen) >> (grp * G)) & 0xffu;
+        const int cnt = __popc(penm);
+        // support extremes (+u, -u, +v, -v; lowest corner index wins ties) when more than 4 corners penetrate
+        const float uM = gmaxf(pen ? u : -3e38f), um = -gmaxf(pen ? -u : -3e38f);
+        const float vM = gmaxf(pen ? v : -3e38f), vm = -gmaxf(pen ? -v : -3e38f);
+        const uint32_t e0 = (uint32_t)(__ballot(pen && u == uM) >> (grp * G)) & 0xffu, e1 = (uint32_t)(__ballot(pen && u == um) >> (grp * G)) & 0xffu;
+        const uint32_t e2 = (uint32_t)(__ballot(pen && v == vM) >> (grp * G)) & 0xffu, e3 = (uint32_t)(__ballot(pen && v == vm) >> (grp * G)) & 0xffu;
+        const uint32_t ext = (e0 & -e0) | (e1 & -e1) | (e2 & -e2) | (e3 & -e3);
+        const uint32_t keepm = cnt <= 4 ? penm : ext;
+        const bool keep = (keepm >> lane & 1u) && lane < 8;
+        const int slot = __popc(keepm & ((1u << lane) - 1u));
+        if (keep && slot < 4) {
+          const V3 pos = w - (0.5f * d) * n;
+          stv(S.col.stage[k][slot], f4{pos.x, pos.y, pos.z, d});
+        }
+        if (lane == k && isplane) {
+          mycount = min(__popc(keepm), 4);
+          st3v(S.col.snorm[k], n);
+        }
+      }
+      // narrowphase, box-box: one lane per candidate (rare: only when bounding spheres overlap)
       if (lane < ncand) {
-        int p = S.col.cand[lane];
-        myp = p;
+        const int p = S.col.cand[lane];
         const int pr = T.pair[p];
         const int g1 = pr & 255, g2 = pr >> 8;
-        M3 R2 = q2m(ld4v(S.col.gquat[g2]));
-        BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
-        V3 n = v3(0, 0, 1);
-        M3 R1 = q2m(ld4v(S.col.gquat[g1]));
-        if (T.g_info[g1][1] == MIR_GEOM_PLANE) {
-          mycount = plane_box(ld3v(S.col.gpos[g1]), R1, B2, S.col.stage[lane], n);
-        } else {
+        if (T.g_info[g1][1] != MIR_GEOM_PLANE) {
+          M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+          BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
+          M3 R1 = q2m(ld4v(S.col.gquat[g1]));
           BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
+          V3 n = v3(0, 0, 1);
           mycount = box_box(B1, B2, S.col.stage[lane], n);
+          st3v(S.col.snorm[lane], n);
         }
-        st3v(S.col.snorm[lane], n);
       }
     }
     STAMP(13);
@@ -788,10 +789,22 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       const int off = incl - mycount;
       const int total = (int)row_bcast<15>(inclf);
       if (lane == 0) S.ncon = total < maxc ? total : maxc;
-      if (mycount > 0) {
-        const int pr = T.pair[myp];
+      const int ncon_new = total < maxc ? total : maxc;
+      STAMP(22);
+      // candidate lanes publish which (candidate, point) fills each contact slot ...
+      for (int c = 0; c < mycount; c++)
+        if (off + c < maxc) S.col.cmap[off + c] = lane * 8 + c;
+      WSYNC();
+      STAMP(23);
+      // ... and every contact is then finished by its own lane, in parallel (staging lives in col
+      // scratch, which does not overlap the contact arrays)
+      if (lane < ncon_new) {
+        const int k = lane;
+        const int mp = S.col.cmap[k];
+        const int cl = mp >> 3, ci = mp & 7;
+        const int pr = T.pair[S.col.cand[cl]];
         const int g1 = pr & 255, g2 = pr >> 8;
-        const V3 n = ld3v(S.col.snorm[lane]);
+        const V3 n = ld3v(S.col.snorm[cl]);
         V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
         t1 = t1 - dot(n, t1) * n;
         t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
@@ -809,20 +822,15 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         const uint32_t inv = dm1 | dm2;
         const uint32_t chunks = ((inv & 0xfu) ? 1u : 0u) | ((inv & 0xf0u) ? 2u : 0u) | ((inv & 0xf00u) ? 4u : 0u) | ((inv & 0xf000u) ? 8u : 0u);
         const V3 ref1 = ld3v(S.xpos[T.b_info[b1][1]]), ref2 = ld3v(S.xpos[T.b_info[b2][1]]);
-        // staging lives in col scratch, which does not overlap the contact arrays
-        for (int c = 0; c < mycount; c++) {
-          const int k = off + c;
-          if (k >= maxc) break;
-          const f4 pd = ldv(S.col.stage[lane][c]);
-          const float dist = pd.w;
-          stv(S.con.cpos[k], pd);
-          st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
-          const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
-          const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
-          stv(S.con.cmeta[k], f4{mu, 1.0f / Rr, -kk * imp * dist, bb});
-          st3v(&S.con.cref[k][0], ref1); st3v(&S.con.cref[k][4], ref2);
-          S.con.cmask[k][0] = dm1; S.con.cmask[k][1] = dm2; S.con.cmask[k][2] = chunks; S.con.cmask[k][3] = 0u;
-        }
+        const f4 pd = ldv(S.col.stage[cl][ci]);
+        const float dist = pd.w;
+        stv(S.con.cpos[k], pd);
+        st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
+        const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
+        const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
+        stv(S.con.cmeta[k], f4{mu, 1.0f / Rr, -kk * imp * dist, bb});
+        st3v(&S.con.cref[k][0], ref1); st3v(&S.con.cref[k][4], ref2);
+        S.con.cmask[k][0] = dm1; S.con.cmask[k][1] = dm2; S.con.cmask[k][2] = chunks; S.con.cmask[k][3] = 0u;
       }
     }
     WSYNC();  // col scratch is dead from here on (Jb may overwrite it)
@@ -929,6 +937,14 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     // float32 rounding floor of the gradient Ma - qfrc_smooth - J^T f: below it a Newton step no
     // longer changes qacc, so iterating further is noise (same rule as the oracle, with float eps)
     const float gfloor = 16.0f * 5.96e-8f * sqrtf(gsum(Ma * Ma + qfs * qfs));
+    // Hessian row kept across iterations: H = Mt + J^T D_active J is updated incrementally, only rows
+    // whose active flag flipped since the previous iteration contribute a (signed) delta
+    float hkeep[G];
+#pragma unroll
+    for (int j = 0; j < G; j++) hkeep[j] = isdof ? mrow[j] : (j == lane ? 1.0f : 0.0f);
+    float oldlact = 0.0f;
+    unsigned prevbits = 0u;  // contact lane: flags written in the previous iteration
+    float gprev = 0.0f;
     for (int it = 0; it < m->iterations; it++) {
       if (!__any(!done)) break;
       // ---- forces of the active rows; base-force triple and active flags to LDS for the dof lanes
@@ -943,7 +959,9 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
           f[r] = on ? -cD * jar[r] : 0.0f;
           bits |= on ? (1u << r) : 0u;
         }
-        stv(S.con.cfb[lane], f4{f[0] + f[1] + f[2] + f[3], cmu * (f[0] - f[1]), cmu * (f[2] - f[3]), (float)bits});
+        // w = new flags | previous flags << 4, as an exactly representable small float
+        stv(S.con.cfb[lane], f4{f[0] + f[1] + f[2] + f[3], cmu * (f[0] - f[1]), cmu * (f[2] - f[3]), (float)(bits | (prevbits << 4))});
+        prevbits = bits;
       }
       WSYNC();
       if (it == 0) STAMP(16);
@@ -960,19 +978,23 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       if (!done && (scale * gn < tol || gn < gfloor)) done = true;
       if (it == 0) STAMP(14);
       if (!__any(!done)) break;
-      // ---- Hessian row (lane = dof): H = Mt + J^T D_active J, built per contact from the 3x3 weight
-      // of its pyramid in (n, t1, t2) coordinates
-      float hrow[G];
+      // ---- Hessian row (lane = dof): incremental update of H = Mt + J^T D_active J; per contact the
+      // change enters through the 3x3 weight of its pyramid in (n, t1, t2) coordinates, which is
+      // linear in the per-row activity, so flipped rows contribute +-D and unchanged contacts nothing
 #pragma unroll
-      for (int j = 0; j < G; j++) hrow[j] = isdof ? mrow[j] + (j == lane ? lact : 0.0f) : (j == lane ? 1.0f : 0.0f);
+      for (int j = 0; j < G; j++) hkeep[j] += j == lane ? lact - oldlact : 0.0f;
+      oldlact = lact;
       for (int c = 0; c < ncon; c++) {
         const float* jb = &S.Jb[c][0];
-        const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
         const f4 fb = ldv(S.con.cfb[c]);
+        const unsigned both = (unsigned)fb.w;
+        const unsigned bits = both & 15u, old = both >> 4;
+        if (bits == old) continue;  // group-uniform
+        const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
         const f4 mt = ldv(S.con.cmeta[c]);
-        const unsigned bits = (unsigned)fb.w;
         const float mu = mt.x, D = mt.y;
-        const float a0 = (bits & 1u) ? D : 0.0f, a1 = (bits & 2u) ? D : 0.0f, a2 = (bits & 4u) ? D : 0.0f, a3 = (bits & 8u) ? D : 0.0f;
+        const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
+        const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
         const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
         const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
         // all twelve 16-byte row reads are issued back to back (one wait), no per-chunk branches
@@ -981,12 +1003,15 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         for (int q = 0; q < 4; q++) { xn[q] = ldv(jb + 4 * q); x1[q] = ldv(jb + 16 + 4 * q); x2[q] = ldv(jb + 32 + 4 * q); }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          hrow[4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
-          hrow[4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
-          hrow[4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
-          hrow[4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
+          hkeep[4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
+          hkeep[4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
+          hkeep[4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
+          hkeep[4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
         }
       }
+      float hrow[G];
+#pragma unroll
+      for (int j = 0; j < G; j++) hrow[j] = hkeep[j];
       if (it == 0) STAMP(18);
       // ---- Newton direction: H s = -g
       float sv = -g;
@@ -1034,18 +1059,28 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         if (!__any(!lsdone)) break;
       }
       if (it == 0) STAMP(20);
-      // ---- improvement from the 1-D model, then the update
+      // ---- improvement from the 1-D model, then the update.  Row-cost differences are formed as
+      // 1/2 D d (2 x0 + d) with d = alpha jv, never as a difference of squares: a step below the
+      // resolution of jar must yield a (correctly) tiny improvement, not an absorbed one
       float pim = 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const float x0 = jar[r], x1 = jar[r] + alpha * jv[r];
-        pim -= (x1 < 0.0f ? 0.5f * cD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * cD * x0 * x0 : 0.0f);
+        const float x0 = jar[r], d = alpha * jv[r], x1 = x0 + d;
+        pim -= (x0 < 0.0f && x1 < 0.0f) ? 0.5f * cD * d * (2.0f * x0 + d)
+               : ((x1 < 0.0f ? 0.5f * cD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * cD * x0 * x0 : 0.0f));
       }
       {
-        const float x0 = ljar, x1 = ljar + alpha * ljv;
-        pim -= (x1 < 0.0f ? 0.5f * lD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * lD * x0 * x0 : 0.0f);
+        const float x0 = ljar, d = alpha * ljv, x1 = x0 + d;
+        pim -= (x0 < 0.0f && x1 < 0.0f) ? 0.5f * lD * d * (2.0f * x0 + d)
+               : ((x1 < 0.0f ? 0.5f * lD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * lD * x0 * x0 : 0.0f));
       }
       const float improvement = gsum(pim) - (0.5f * alpha * alpha * A + alpha * Bq);
+      // float32 resolution: if no dof's acceleration changes, or the gradient has stopped shrinking
+      // within a few floors of its rounding level, further iterations are noise
+      const float moved = gsum((isdof && qacc + alpha * sv != qacc) ? 1.0f : 0.0f);
+      const bool stagnant = it > 0 && gn > 0.5f * gprev && gn < 4.0f * gfloor;
+      gprev = gn;
+      if (!done && (moved == 0.0f || stagnant)) { done = true; niter = it + 1; }
       if (!done) {
         qacc += alpha * sv;
         Ma += alpha * mv;
@@ -1054,6 +1089,16 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         for (int r = 0; r < 4; r++) jar[r] += alpha * jv[r];
         niter = it + 1;
         if (scale * improvement < tol) done = true;
+      }
+      {
+        // if the step crossed no row boundary, phi is one quadratic along it and the new gradient is
+        // exactly (1 - alpha) g: decide convergence now instead of paying another gradient pass
+        float crossed = (ljar - alpha * ljv < 0.0f) != (ljar < 0.0f) && lsg != 0.0f ? 1.0f : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) crossed += ((jar[r] - alpha * jv[r] < 0.0f) != (jar[r] < 0.0f)) ? 1.0f : 0.0f;
+        const float ncross = gsum(done ? 0.0f : crossed);
+        const float gnew = fabsf(1.0f - alpha) * gn;
+        if (!done && ncross == 0.0f && (scale * gnew < tol || gnew < gfloor)) done = true;
       }
       WSYNC();
       if (it == 0) STAMP(21);
@@ -1143,6 +1188,15 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   if (a.out_xpos && lane < nb) {
     st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3v(S.xpos[lane]));
     st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));
+  }
+  STAMP(25);
+  if (a.prof && threadIdx.x == 0) {  // debug: wall-clock (100 MHz) exit time of block 0 and of the last block
+    const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0) a.prof[27] = tnow;
+    if ((blockIdx.x & 7) == 0) {  // same XCD as block 0: the realtime counters of different XCDs are not aligned
+      atomicMax(&a.prof[28], tnow);
+      atomicMin(&a.prof[29], tnow);
+    }
   }
 }
 

@@ -24,7 +24,8 @@
  * Conventions
  *   - All device buffers are caller-owned raw device pointers (torch
  *     tensor.data_ptr()), row-major (B, D), float32 unless stated.  Nothing
- *     is retained past the call.  Internal state is SoA (D, B) in HBM.
+ *     is retained past the call.  Internal state is env-major
+ *     rows (B, D) in HBM (one 64-byte-aligned row group per env).
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  No
  *     entry point synchronises the device.
  *   - Quaternions are wxyz (Genesis convention, cube_pick.py:94).
@@ -154,7 +155,7 @@ int mir_version(void);
 int mir_spec_sizeof(void);
 const char* mir_last_error(void);
 
-/* gs.Scene + add_entity + scene.build(n_envs): compile spec, allocate SoA state
+/* gs.Scene + add_entity + scene.build(n_envs): compile spec, allocate env-major state
  * for num_envs on device_id, set state to the spec's initial pose. */
 int mir_create(const MirSceneSpec* spec, int32_t num_envs, int32_t device_id, MirHandle* out);
 int mir_destroy(MirHandle h);

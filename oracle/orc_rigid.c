@@ -658,6 +658,7 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
   real gfloor = 0;
   for (int i = 0; i < nv; i++) gfloor += Ma[i] * Ma[i] + d->qfrc_smooth[i] * d->qfrc_smooth[i];
   gfloor = 16 * (sizeof(real) == 4 ? (real)5.96e-8 : (real)1.11e-16) * (real)sqrt((double)gfloor);
+  real gprev = 0;
   for (int it = 0; it < m->opt.iterations; it++) {
     /* gradient, forces, Hessian */
     real H[ORC_NV][ORC_NV], L[ORC_NV][ORC_NV];
@@ -712,12 +713,22 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
       if (an == alpha) break;
       alpha = an;
     }
-    /* improvement from the 1-D model (well conditioned) */
+    /* improvement from the 1-D model; row-cost differences as 1/2 D dx (2 x0 + dx), never as a
+     * difference of squares (a step below the resolution of jar must give a tiny improvement) */
     real imp = -((real)0.5 * alpha * alpha * A + alpha * Bq);
     for (int r = 0; r < n; r++) {
-      real x0 = jar[r], x1 = jar[r] + alpha * jv[r];
-      real c0 = x0 < 0 ? (real)0.5 * d->efcD[r] * x0 * x0 : 0, c1 = x1 < 0 ? (real)0.5 * d->efcD[r] * x1 * x1 : 0;
-      imp -= c1 - c0;
+      real x0 = jar[r], dx = alpha * jv[r], x1 = x0 + dx;
+      if (x0 < 0 && x1 < 0) imp -= (real)0.5 * d->efcD[r] * dx * (2 * x0 + dx);
+      else imp -= (x1 < 0 ? (real)0.5 * d->efcD[r] * x1 * x1 : 0) - (x0 < 0 ? (real)0.5 * d->efcD[r] * x0 * x0 : 0);
+    }
+    /* resolution of this precision: no dof moves, or the gradient stopped shrinking near its floor */
+    {
+      int moved = 0;
+      for (int i = 0; i < nv; i++) moved |= (d->qacc[i] + alpha * s[i] != d->qacc[i]);
+      real gnorm = (real)sqrt((double)gn);
+      int stagnant = it > 0 && gnorm > (real)0.5 * gprev && gnorm < 4 * gfloor;
+      gprev = gnorm;
+      if (!moved || stagnant) { d->niter = it + 1; break; }
     }
     for (int i = 0; i < nv; i++) { d->qacc[i] += alpha * s[i]; Ma[i] += alpha * Mv[i]; }
     for (int r = 0; r < n; r++) jar[r] += alpha * jv[r];
