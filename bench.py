@@ -9,8 +9,9 @@ num_envs=4096 per GPU, enable_pixels=False); reset(seed=0); a fresh a_t ~ U(-1,1
 per step (generated on the device BEFORE the timed region: inputs are resident in HBM); one
 fused hot-path launch per step (control + scene.step + reward + observations); reset-all every
 200 steps (TimeLimit parity).  Env axis sharded across ranks (weak scaling: 4096 envs per GPU);
-with N > 1 every step's packed observation rows are all-gathered over RCCL, overlapped with the
-next step's physics.
+with N > 1 the packed observation/reward rows are all-gathered over RCCL in rollout chunks of
+--gather-every steps (default 8; 1 = every step), double-buffered so a chunk's gather overlaps the
+next chunk's physics.
 
 One JSON line on rank 0: value = total env-steps / wall time (max over ranks) of exactly K steps.
 Extra objects: "roofline" (HBM; algorithmic 489 B per env-step) and
@@ -80,8 +81,11 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL observation gather")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL observation gather")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N>1: all-gather the packed rows of this many consecutive steps in one collective (1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true", help="exercise the RCCL gather path even with one rank (plumbing check)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,9 +99,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    use_pg = world > 1 or args.force_gather
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from gym_genesis.env import GenesisEnv
     from gym_genesis.sharding import gather_rows  # noqa: F401  (collective lives there)
@@ -115,21 +121,42 @@ def main():
     for i in range(0, n_act, 256):
         actions[i:i + 256].uniform_(-1.0, 1.0, generator=gen)
 
-    gather = world > 1 and not args.no_gather
-    rows = [torch.zeros((B, ROW_STRIDE), dtype=torch.float32, device=dev) for _ in range(2)]
-    gathered = [torch.empty((B * world, ROW_STRIDE), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
+    gather = use_pg and not args.no_gather
+    # One collective per step costs ~60 us of host time in torch.distributed (measured at world_size 1), more than the
+    # 41 us step itself, so rows are gathered in chunks of S steps: the host then stays ahead of the GPU.
+    S = max(1, args.gather_every)
+    rows = [torch.zeros((S, B, ROW_STRIDE), dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.empty((world * S, B, ROW_STRIDE), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
     pending = [None, None]
     launches = 0
+    filled = 0  # steps written into the current chunk
+
+    chunk = 0
+
+    def flush():
+        """All-gather the rows written so far in the current chunk (async: overlaps the next chunk's physics)."""
+        nonlocal filled, chunk
+        if gather and filled:
+            s = chunk & 1
+            if filled == S:
+                pending[s] = dist.all_gather_into_tensor(gathered[s], rows[s], async_op=True)
+            else:  # partial chunk at the end of a run
+                pending[s] = dist.all_gather_into_tensor(gathered[s][:world * filled], rows[s][:filled], async_op=True)
+            chunk += 1
+            filled = 0
 
     def one_step(t: int):
-        nonlocal launches
+        nonlocal launches, filled, chunk
         a = actions[t % n_act]
         if gather:
-            s = t & 1
-            if pending[s] is not None:
+            s = chunk & 1
+            if filled == 0 and pending[s] is not None:
                 pending[s].wait()      # stream-level: the buffer's previous gather has drained
-            task._mir.step_packed(a, rows[s])
-            pending[s] = dist.all_gather_into_tensor(gathered[s], rows[s], async_op=True)  # overlaps the next step
+                pending[s] = None
+            task._mir.step_packed(a, rows[s][filled])
+            filled += 1
+            if filled == S:
+                flush()
         else:
             task.step_raw(a)
         launches += 1
@@ -138,11 +165,12 @@ def main():
             launches += 1
 
     def sync_all():
+        flush()
         for p in pending:
             if p is not None:
                 p.wait()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -161,7 +189,7 @@ def main():
     gpu_ms = ev0.elapsed_time(ev1)
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall_max = float(wall_t.item())
 
@@ -173,6 +201,15 @@ def main():
         env.step(actions[t % n_act])
     torch.cuda.synchronize(dev)
     api_rate = api_steps * B * world / (time.perf_counter() - t1)
+
+    # device-resident episode loop: fused step + on-device truncation/termination/re-spawn, no host sync
+    task.enable_autoreset(max_episode_steps=EPISODE_STEPS)
+    torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
+    for t in range(api_steps):
+        task.step_autoreset(actions[t % n_act])
+    torch.cuda.synchronize(dev)
+    loop_rate = api_steps * B * world / (time.perf_counter() - t2)
 
     if rank == 0:
         value = K * B * world / wall_max
@@ -199,16 +236,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": "CubePick-v0 robot=franka state-only obs, U(-1,1) joint-target actions, reset-all every 200 steps",
                        "num_envs_per_gpu": B, "global_num_envs": B * world, "parallelism": f"env-axis shard x{world}",
-                       "obs_gather": "rccl all_gather per step, overlapped" if gather else "none"},
+                       "obs_gather": f"rccl all_gather of {S}-step row chunks, overlapped with the next chunk" if gather else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "mir_step_kernel", "kernel_us": launch_us,
                          "note": "489 algorithmic B/env-step x 4096 envs per launch; the path is latency/occupancy-bound, not HBM-bound (SURVEY.md 8d)"},
             "env_step_api_rate": api_rate,
+            "device_autoreset_loop_rate": loop_rate,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -83,6 +83,46 @@ __global__ void k_reset(const DevModel* __restrict__ m, float* qpos, float* qvel
   }
 }
 
+// Episode bookkeeping + re-spawn of finished envs, all on the device (no host round trip).
+// 16 consecutive threads serve one env (same wave): every thread reads the env's counters before lane c==0 rewrites them.
+__global__ void k_autoreset(const DevModel* __restrict__ m, float* qpos, float* qvel, float* target, float* ws, const uint8_t* terminated,
+                            int32_t* episode_len, int max_len, const float* spawn_pool, int pool_len, int32_t* cursor,
+                            const float* obj_quat, const float* arm_qpos, uint8_t* truncated_out, uint8_t* done_out, int32_t* fkvalid, int B) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int e = (int)(i / MIR_G), c = (int)(i % MIR_G);
+  if (e >= B) return;
+  const int len = episode_len[e] + 1;
+  const bool term = terminated && terminated[e];
+  const bool trunc = !term && max_len > 0 && len >= max_len;
+  const bool done = term || trunc;
+  const int cur = cursor[e];
+  __builtin_amdgcn_wave_barrier();
+  if (c == 0) {
+    episode_len[e] = done ? 0 : len;
+    if (done) cursor[e] = cur + 1;
+    if (truncated_out) truncated_out[e] = trunc;
+    if (done_out) done_out[e] = done;
+  }
+  if (!done) return;
+  const int qst = m->qstride;
+  qvel[(long)e * MIR_G + c] = 0.0f;
+  ws[(long)e * MIR_G + c] = 0.0f;
+  if (c == 0) fkvalid[e] = 0;
+  if (c < m->nv) {
+    int ai = m->d_armidx[c];
+    if (ai >= 0) {
+      float v = arm_qpos[(long)e * m->n_arm_q + ai];
+      qpos[(long)e * qst + m->d_qadr[c]] = v;
+      target[(long)e * MIR_G + c] = v;
+    }
+  }
+  if (m->obj_qadr >= 0) {
+    const float* sp = spawn_pool + ((long)(cur % pool_len) * B + e) * 3;
+    if (c < 3) qpos[(long)e * qst + m->obj_qadr + c] = sp[c];
+    if (c >= 3 && c < 7) qpos[(long)e * qst + m->obj_qadr + c] = obj_quat[(long)e * 4 + (c - 3)];
+  }
+}
+
 __global__ void k_set_targets(const DevModel* __restrict__ m, float* target, const float* tgt, int B) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int e = (int)(i / MIR_G), c = (int)(i % MIR_G);
@@ -249,6 +289,18 @@ int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const fl
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_reset, dim3(nblk((long)h->B * MIR_G)), dim3(TPB), 0, (hipStream_t)stream, h->dm, h->qpos, h->qvel, h->target,
                      h->qacc_ws, obj_pos, obj_quat, arm_qpos, env_mask, h->fkvalid, h->B);
+  HIPCHK(hipGetLastError());
+  return MIR_OK;
+}
+
+int mir_autoreset(MirHandle h, const uint8_t* terminated, int32_t* episode_len, int32_t max_len, const float* spawn_pool, int32_t pool_len,
+                  int32_t* cursor, const float* obj_quat, const float* arm_qpos, uint8_t* truncated_out, uint8_t* done_out, void* stream) {
+  if (check(h)) return MIR_E_INVALID;
+  if (!episode_len || !spawn_pool || !cursor || !obj_quat || !arm_qpos || pool_len <= 0) return set_err(MIR_E_INVALID, "mir_autoreset: null argument");
+  DeviceGuard guard(h->device);
+  hipLaunchKernelGGL(k_autoreset, dim3(nblk((long)h->B * MIR_G)), dim3(TPB), 0, (hipStream_t)stream, h->dm, h->qpos, h->qvel, h->target,
+                     h->qacc_ws, terminated, episode_len, max_len, spawn_pool, pool_len, cursor, obj_quat, arm_qpos, truncated_out, done_out,
+                     h->fkvalid, h->B);
   HIPCHK(hipGetLastError());
   return MIR_OK;
 }

@@ -43,6 +43,7 @@ def load_library() -> C.CDLL:
     lib.mir_get_dims.argtypes = [vp, C.POINTER(MirDims)]
     lib.mir_get_model_consts.argtypes = [vp, vp, vp, vp]
     lib.mir_reset.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mir_autoreset.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.mir_set_pd_targets.argtypes = [vp, vp, vp]
     lib.mir_step.argtypes = [vp, i32, vp]
     lib.mir_step_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -54,7 +55,7 @@ def load_library() -> C.CDLL:
     lib.mir_get_links.argtypes = [vp, vp, vp, vp]
     lib.mir_get_diag.argtypes = [vp, vp, vp, vp, vp]
     lib.mir_forward.argtypes = [vp, vp, vp, vp, vp, vp]
-    for name in ("mir_create", "mir_destroy", "mir_get_dims", "mir_get_model_consts", "mir_reset", "mir_set_pd_targets",
+    for name in ("mir_create", "mir_destroy", "mir_get_dims", "mir_get_model_consts", "mir_reset", "mir_autoreset", "mir_set_pd_targets",
                  "mir_step", "mir_step_fused", "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links",
                  "mir_get_diag", "mir_forward"):
         getattr(lib, name).restype = C.c_int
@@ -136,6 +137,14 @@ class MirScene:
         if env_mask is not None:
             mk = torch.as_tensor(env_mask).to(device=self.device, dtype=torch.uint8).contiguous()
         self._check(self.lib.mir_reset(self.h, _ptr(p), _ptr(q), _ptr(a), _ptr(mk), self._stream()))
+
+    def autoreset(self, terminated, episode_len, max_len: int, spawn_pool, cursor, obj_quat, arm_qpos,
+                  truncated_out=None, done_out=None) -> None:
+        """Device-side episode bookkeeping + re-spawn of finished envs (mir_autoreset); every argument is a
+        preallocated device tensor of the dtype the header names."""
+        self._check(self.lib.mir_autoreset(self.h, _ptr(terminated), _ptr(episode_len), int(max_len), _ptr(spawn_pool),
+                                           int(spawn_pool.shape[0]), _ptr(cursor), _ptr(obj_quat), _ptr(arm_qpos),
+                                           _ptr(truncated_out), _ptr(done_out), self._stream()))
 
     def set_pd_targets(self, tgt) -> None:
         t = self._f32(tgt, self.nu)

@@ -127,6 +127,33 @@ class FrankaCubePickBatch:
         self._mir.reset(pos, self._quat, self._home, env_mask=env_mask)
         return self.get_obs()
 
+    # ---- device-resident episode loop --------------------------------------
+    def enable_autoreset(self, max_episode_steps: int = 200, pool_len: int = 64):
+        """Keep the whole episode loop on the device: after every step_autoreset() the envs whose episode
+        ended (terminated, or `max_episode_steps` reached) are re-spawned by one small kernel, without the
+        D->H read of `terminated` and the reset-all the reference's loop needs (README.md:41-43).
+        Spawn positions come from the task RandomState as in reset() (x block then y block per draw),
+        `pool_len` draws ahead; env e's k-th re-spawn uses draw k % pool_len."""
+        B, dev = self.num_envs, self.device
+        pool = np.stack([self.sample_spawn()[self.shard_lo:self.shard_hi] for _ in range(pool_len)])
+        self._spawn_pool = torch.from_numpy(pool).to(dev).contiguous()
+        self._cursor = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self._episode_len = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self._truncated = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self._done = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self._max_episode_steps = int(max_episode_steps)
+
+    def step_autoreset(self, action_dev: torch.Tensor):
+        """One fused step, then device-side bookkeeping.  Returns device tensors (agent_pos, environment_state,
+        reward, terminated u8, truncated u8) of THIS step (the terminal observation for envs that just ended);
+        those envs start their next step from the re-spawned state, whose first observation is therefore one
+        physics step after the spawn, as after reset() (cube_pick.py:107)."""
+        mir = self._mir
+        mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)
+        mir.autoreset(self._term, self._episode_len, self._max_episode_steps, self._spawn_pool, self._cursor,
+                      self._quat, self._home, self._truncated, self._done)
+        return self._agent, self._envst, self._reward, self._term, self._truncated
+
     def step(self, action):
         a = self._as_action(action)
         # fresh output tensors per call, like the reference (callers may keep old observations)

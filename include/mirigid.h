@@ -171,6 +171,20 @@ int mir_get_model_consts(MirHandle h, double* dof_invweight0, double* body_invwe
 int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const float* arm_qpos,
               const uint8_t* env_mask, void* stream);
 
+/* Device-side episode bookkeeping and re-spawn.  The reference can only reset the
+ * whole batch from the host after a D->H read of `terminated` (README.md:41-43, env.py:64,
+ * cube_pick.py:86-112); this call keeps the loop on the device.  Per env:
+ *   episode_len += 1;  truncated = !terminated && max_len > 0 && episode_len >= max_len;
+ *   done = terminated || truncated.
+ * Done envs are reset exactly as mir_reset does (arm_qpos, zero velocity, PD targets = arm_qpos,
+ * object at spawn_pool[cursor % pool_len][env] with obj_quat), episode_len = 0, cursor += 1.
+ * spawn_pool (pool_len,B,3) f32: spawn positions drawn ahead by the caller (the task's host
+ * RandomState stays the source of randomness).  terminated (B) u8 nullable; episode_len, cursor (B)
+ * i32 in/out; truncated_out, done_out (B) u8 nullable.  No physics step is consumed. */
+int mir_autoreset(MirHandle h, const uint8_t* terminated, int32_t* episode_len, int32_t max_len,
+                  const float* spawn_pool, int32_t pool_len, int32_t* cursor, const float* obj_quat,
+                  const float* arm_qpos, uint8_t* truncated_out, uint8_t* done_out, void* stream);
+
 /* control_dofs_position over all position-controlled dofs, in dof order: tgt (B,nu) */
 int mir_set_pd_targets(MirHandle h, const float* tgt, void* stream);
 

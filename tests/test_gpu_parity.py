@@ -365,3 +365,57 @@ def test_masked_reset_leaves_other_envs_bit_identical():
         obs["environment_state"][sel][:, 3:7], torch.tensor([0.0, 0, 0, 1], device=sel.device))
     # the stepped-on envs and the fresh ones keep running together
     env.step(acts[0])
+
+
+@pytest.mark.gpu
+def test_device_autoreset_equals_host_driven_masked_reset():
+    """mir_autoreset (episode counters, truncation, re-spawn from the pre-drawn pool, all on the device) gives
+    bit-identical states and flags to the host-driven loop: read `terminated`, count steps, mir_reset(env_mask)."""
+    from gym_genesis.env import GenesisEnv
+
+    B, MAXLEN, P = 16, 7, 4
+    envs = []
+    for _ in range(2):
+        env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
+        env.reset(seed=11)
+        env._env.enable_autoreset(max_episode_steps=MAXLEN, pool_len=P)
+        envs.append(env._env)
+    dev_task, host_task = envs
+    assert torch.equal(dev_task._spawn_pool, host_task._spawn_pool)
+    # stagger the episode clocks and lift two cubes so `terminated` fires at different times as well
+    start = torch.arange(B, dtype=torch.int32) % 5
+    dev_task._episode_len.copy_(start)
+    host_len = start.numpy().copy()
+    host_cur = np.zeros(B, np.int64)
+    for task in envs:
+        qpos, qvel, tgt, ws = task._mir.get_state()
+        qpos[3, 11] = 0.6
+        qpos[9, 11] = 0.12
+        task._mir.set_state(qpos=qpos)
+    pool = host_task._spawn_pool.cpu().numpy()
+    acts = torch.as_tensor(np.random.default_rng(3).uniform(-1, 1, (40, B, 9)).astype(np.float32)).to(dev_task.device)
+    n_term = n_trunc = 0
+    for t in range(40):
+        agent, envst, rew, term, trunc = dev_task.step_autoreset(acts[t])
+        host_task.step_raw(acts[t])
+        h_term = host_task._term.cpu().numpy().astype(bool)
+        host_len += 1
+        h_trunc = ~h_term & (host_len >= MAXLEN)
+        h_done = h_term | h_trunc
+        assert np.array_equal(term.cpu().numpy().astype(bool), h_term) and np.array_equal(trunc.cpu().numpy().astype(bool), h_trunc)
+        assert np.array_equal(dev_task._done.cpu().numpy().astype(bool), h_done)
+        assert torch.equal(agent, host_task._agent) and torch.equal(envst, host_task._envst) and torch.equal(rew, host_task._reward)
+        if h_done.any():
+            pos = pool[host_cur % P, np.arange(B)]
+            host_task._mir.reset(torch.from_numpy(pos).to(host_task.device), host_task._quat, host_task._home,
+                                 env_mask=torch.from_numpy(h_done.astype(np.uint8)))
+            host_cur += h_done
+            host_len[h_done] = 0
+        n_term += int(h_term.sum())
+        n_trunc += int(h_trunc.sum())
+        for a, b in zip(dev_task._mir.get_state(), host_task._mir.get_state()):
+            assert torch.equal(a, b), f"step {t}"
+        assert np.array_equal(dev_task._episode_len.cpu().numpy(), host_len)
+        assert np.array_equal(dev_task._cursor.cpu().numpy(), host_cur)
+    assert n_term >= 2 and n_trunc >= 3 * B
+    print(f"autoreset: {n_term} terminations, {n_trunc} truncations, device == host-driven bit for bit")
