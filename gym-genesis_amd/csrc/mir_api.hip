@@ -9,17 +9,8 @@
 #include <new>
 
 #include "mir_model.h"
+#include "mir_scene.h"
 #include "mir_step.h"
-
-struct MirScene {
-  int device;
-  int B;
-  DevModel hm;      // host copy of the compiled model
-  HostConsts hc;
-  DevModel* dm;     // device copy
-  float *qpos, *qvel, *target, *qacc_ws, *poses;
-  int32_t *diag, *fkvalid;
-};
 
 namespace {
 
@@ -193,6 +184,14 @@ int check(MirHandle h) {
 
 }  // namespace
 
+int mir_set_error(int code, const char* msg) { return set_err(code, "%s", msg); }
+
+int mir_refresh_poses(MirScene* h, void* stream) {
+  StepArgs a = base_args(h);
+  a.mode = 2; a.diag = nullptr;
+  return launch(h, a, stream);
+}
+
 extern "C" {
 
 int mir_version(void) { return MIR_VERSION; }
@@ -265,6 +264,7 @@ int mir_destroy(MirHandle h) {
   if (h->diag) (void)hipFree(h->diag);
   if (h->poses) (void)hipFree(h->poses);
   if (h->fkvalid) (void)hipFree(h->fkvalid);
+  if (h->prims) (void)hipFree(h->prims);
   delete h;
   return MIR_OK;
 }

@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .spec import MirDims, MirSceneSpec
+from .spec import MirCameraSpec, MirDims, MirSceneSpec, MirVisualSpec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libmirigid.so"))
@@ -55,11 +55,14 @@ def load_library() -> C.CDLL:
     lib.mir_get_links.argtypes = [vp, vp, vp, vp]
     lib.mir_get_diag.argtypes = [vp, vp, vp, vp, vp]
     lib.mir_forward.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mir_render.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), i32, vp, vp, vp]
+    lib.mir_render.restype = C.c_int
+    lib.mir_visual_sizeof.restype = C.c_int
     for name in ("mir_create", "mir_destroy", "mir_get_dims", "mir_get_model_consts", "mir_reset", "mir_autoreset", "mir_set_pd_targets",
                  "mir_step", "mir_step_fused", "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links",
                  "mir_get_diag", "mir_forward"):
         getattr(lib, name).restype = C.c_int
-    if lib.mir_spec_sizeof() != C.sizeof(MirSceneSpec) or lib.mir_version() != 1:
+    if lib.mir_spec_sizeof() != C.sizeof(MirSceneSpec) or lib.mir_version() != 1 or lib.mir_visual_sizeof() != C.sizeof(MirVisualSpec):
         raise MirError("libmirigid.so ABI mismatch with gym_genesis.backend.spec (rebuild the library)")
     _lib = lib
     return lib
@@ -196,3 +199,17 @@ class MirScene:
         qas, qacc = self.empty(self.nv), self.empty(self.nv)
         self._check(self.lib.mir_forward(self.h, _ptr(M), _ptr(bias), _ptr(qas), _ptr(qacc), self._stream()))
         return M, bias, qas, qacc
+
+    def render(self, cam: MirCameraSpec, vis: MirVisualSpec, mode: int = 0, env_offset: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """RGB8 images of the current state (mir_render): (B,H,W,3) per-env, or (H,W,3) in global mode."""
+        shape = (cam.height, cam.width, 3) if mode == 1 else (self.num_envs, cam.height, cam.width, 3)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.uint8 or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous uint8 tensor of shape {shape}")
+        off = None
+        if env_offset is not None:
+            off = self._f32(env_offset, 3)
+        self._check(self.lib.mir_render(self.h, C.byref(cam), C.byref(vis), int(mode), _ptr(off), _ptr(out), self._stream()))
+        return out

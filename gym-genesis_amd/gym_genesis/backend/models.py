@@ -73,6 +73,7 @@ def franka_cube_pick_scene(cube_size=0.04, cube_pos=(0.65, 0.0, 0.02), cube_rho=
     # ground plane (gs.morphs.Plane, cube_pick.py:50)
     sb.add_geom(0, GEOM_PLANE)
     # Panda (cube_pick.py:51)
+    white, dark = (0.92, 0.92, 0.9), (0.18, 0.18, 0.2)
     sb.add_body("link0", 0, mass=0.629769, ipos=(-0.041018, -0.00014, 0.049974),
                 inertia=(0.00315, 0.00388, 0.004285, 8.2904e-7, 0.00015, 8.2299e-6))
     for i, (name, parent, pos, quat, rng, mass, com, inertia) in enumerate(_PANDA_LINKS):
@@ -88,16 +89,19 @@ def franka_cube_pick_scene(cube_size=0.04, cube_pos=(0.65, 0.0, 0.02), cube_rho=
                     range=(0.0, 0.04), armature=0.1, damping=1.0, ctrl_mode=CTRL_POSITION, kp=FRANKA_KP[7 + k],
                     kv=FRANKA_KV[7 + k], frc_range=(-FRANKA_FRC[7 + k], FRANKA_FRC[7 + k]))
     for body, half, centre in _PANDA_BOXES:
-        sb.add_geom(body, GEOM_BOX, size=half, pos=centre)
+        sb.add_geom(body, GEOM_BOX, size=half, pos=centre, rgb=dark if body == "hand" else white)
     for finger in ("left_finger", "right_finger"):
-        sb.add_geom(finger, GEOM_BOX, size=_FINGER_BODY_BOX[0], pos=_FINGER_BODY_BOX[1])
-        sb.add_geom(finger, GEOM_BOX, size=_FINGER_PAD_BOX[0], pos=_FINGER_PAD_BOX[1])
+        sb.add_geom(finger, GEOM_BOX, size=_FINGER_BODY_BOX[0], pos=_FINGER_BODY_BOX[1], rgb=dark)
+        sb.add_geom(finger, GEOM_BOX, size=_FINGER_PAD_BOX[0], pos=_FINGER_PAD_BOX[1], rgb=dark)
     # cube (gs.morphs.Box, cube_pick.py:52-54); Genesis rigid material default density 200 kg/m^3
     h = cube_size / 2
     mass = cube_rho * cube_size ** 3
     sb.add_body("cube", 0, pos=cube_pos, quat=(1, 0, 0, 0), jtype=JNT_FREE, mass=mass,
                 inertia=box_inertia(mass, (h, h, h)))
-    sb.add_geom("cube", GEOM_BOX, size=(h, h, h))
+    sb.add_geom("cube", GEOM_BOX, size=(h, h, h), rgb=(0.85, 0.2, 0.15))
+    # visual-only pedestal of the fixed base link (never collides: contype = conaffinity = 0); appended last so
+    # the indices of the colliding geoms and the candidate-pair order are unchanged
+    sb.add_geom("link0", GEOM_BOX, size=(0.09, 0.08, 0.07), pos=(-0.04, 0.0, 0.07), contype=0, conaffinity=0, rgb=white)
     # task extraction (cube_pick.py:66-68,134,142)
     sb.task = dict(eef_body=sb.body_index("hand"), obj_body=sb.body_index("cube"),
                    grip_dof=(sb.dof_index("finger_joint1"), sb.dof_index("finger_joint2")), reward_z=0.1)
@@ -137,7 +141,7 @@ def so101_cube_pick_scene(cube_size=0.04, cube_pos=(-0.3, 0.0, ISLAND_TOP_Z + 0.
     s = SO101_SCALE
     fr = 5.0
     sb.add_geom(0, GEOM_PLANE)                                                        # kitchen floor, z = 0
-    sb.add_geom(0, GEOM_BOX, size=(0.915, 0.401, 0.05), pos=(0.0, 0.0, ISLAND_TOP_Z - 0.05))  # island slab (static)
+    sb.add_geom(0, GEOM_BOX, size=(0.915, 0.401, 0.05), pos=(0.0, 0.0, ISLAND_TOP_Z - 0.05), rgb=(0.75, 0.72, 0.68))  # island slab (static)
     sb.add_body("so101_base", 0, pos=(-0.5, 0.0, 0.7), mass=0.147 * s ** 3, ipos=(0.0, 0.0, 0.03 * s),
                 inertia=box_inertia(0.147 * s ** 3, (0.04 * s, 0.04 * s, 0.03 * s)))
     sb.add_geom("so101_base", GEOM_BOX, size=(0.04 * s, 0.04 * s, 0.03 * s), pos=(0.0, 0.0, 0.03 * s + 0.002), friction=fr)
@@ -155,7 +159,7 @@ def so101_cube_pick_scene(cube_size=0.04, cube_pos=(-0.3, 0.0, ISLAND_TOP_Z + 0.
     h = cube_size / 2
     mass = cube_rho * cube_size ** 3
     sb.add_body("cube", 0, pos=cube_pos, quat=(1, 0, 0, 0), jtype=JNT_FREE, mass=mass, inertia=box_inertia(mass, (h, h, h)))
-    sb.add_geom("cube", GEOM_BOX, size=(h, h, h), friction=fr)
+    sb.add_geom("cube", GEOM_BOX, size=(h, h, h), friction=fr, rgb=(0.85, 0.2, 0.15))
     # eef link "gripper" (so101/cube_pick.py:37), gripper dof = joint6 (:36,:120), reward z > 0.1 (:112)
     sb.task = dict(eef_body=sb.body_index("gripper"), obj_body=sb.body_index("cube"), grip_dof=(sb.dof_index("joint6"),), reward_z=0.1)
     return sb

@@ -126,6 +126,42 @@ class MirDims(C.Structure):
     ]
 
 
+class MirCameraSpec(C.Structure):
+    """scene.add_camera(res=(W,H), pos, lookat, fov) (reference cube_pick.py:56-63)."""
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("pos", C.c_double * 3),
+        ("lookat", C.c_double * 3),
+        ("up", C.c_double * 3),
+        ("fov_deg", C.c_double),
+    ]
+
+
+class MirVisualSpec(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("_pad", C.c_int32),
+        ("geom_rgb", (C.c_double * 3) * MIR_MAX_GEOM),
+        ("light_dir", C.c_double * 3),
+        ("ambient", C.c_double),
+        ("diffuse", C.c_double),
+        ("sky_rgb", C.c_double * 3),
+        ("checker_rgb", (C.c_double * 3) * 2),
+        ("checker_size", C.c_double),
+    ]
+
+
+RENDER_PER_ENV, RENDER_GLOBAL = 0, 1
+
+
+def make_camera(width, height, pos, lookat, fov, up=(0.0, 0.0, 1.0)) -> MirCameraSpec:
+    c = MirCameraSpec()
+    c.width, c.height, c.fov_deg = int(width), int(height), float(fov)
+    c.pos[:], c.lookat[:], c.up[:] = [float(v) for v in pos], [float(v) for v in lookat], [float(v) for v in up]
+    return c
+
+
 def quat_normalize(q: Sequence[float]) -> tuple:
     n = math.sqrt(sum(x * x for x in q))
     return tuple(x / n for x in q)
@@ -183,12 +219,26 @@ class SceneBuilder:
 
     # -- geoms ------------------------------------------------------------------------------
     def add_geom(self, body: str | int, gtype: int, size=(0, 0, 0), pos=(0, 0, 0), quat=(1, 0, 0, 0),
-                 friction=1.0, contype=1, conaffinity=1, solref=DEFAULT_SOLREF, solimp=DEFAULT_SOLIMP) -> int:
+                 friction=1.0, contype=1, conaffinity=1, solref=DEFAULT_SOLREF, solimp=DEFAULT_SOLIMP,
+                 rgb=(0.8, 0.8, 0.8)) -> int:
         bidx = body if isinstance(body, int) else self.body_index(body)
         self.geoms.append(dict(body=bidx, type=gtype, size=tuple(size), pos=tuple(pos), quat=quat_normalize(quat),
                                friction=float(friction), contype=contype, conaffinity=conaffinity,
-                               solref=tuple(solref), solimp=tuple(solimp)))
+                               solref=tuple(solref), solimp=tuple(solimp), rgb=tuple(rgb)))
         return len(self.geoms) - 1
+
+    def visual(self, light_dir=(0.3, -0.4, 0.85), ambient=0.35, diffuse=0.65, sky_rgb=(0.55, 0.7, 0.9),
+               checker_rgb=((0.82, 0.82, 0.82), (0.42, 0.42, 0.45)), checker_size=0.5) -> "MirVisualSpec":
+        """Appearance used by mir_render: per-geom albedo from add_geom(rgb=...), one directional light."""
+        v = MirVisualSpec()
+        v.struct_size = C.sizeof(MirVisualSpec)
+        for i, g in enumerate(self.geoms):
+            v.geom_rgb[i][:] = g["rgb"]
+        v.light_dir[:] = light_dir
+        v.ambient, v.diffuse, v.checker_size = ambient, diffuse, checker_size
+        v.sky_rgb[:] = sky_rgb
+        v.checker_rgb[0][:], v.checker_rgb[1][:] = checker_rgb[0], checker_rgb[1]
+        return v
 
     # -- emit -------------------------------------------------------------------------------
     def build(self) -> MirSceneSpec:

@@ -27,7 +27,7 @@ import torch
 from ..._gym import spaces
 from ...backend import models
 from ...backend.lib import MirScene
-from ..views import EntityView, SceneView
+from ..views import CameraView, EntityView, SceneView
 
 AGENT_DIM = len(models.FRANKA_JOINTS)
 ENV_DIM = 11
@@ -55,8 +55,8 @@ class FrankaCubePickBatch:
 
     # ---- scene ------------------------------------------------------------------------------
     def _build_scene(self):
-        if self.enable_pixels:
-            raise NotImplementedError("enable_pixels=True needs the batched rasteriser (SURVEY.md 8f-2), not built yet")
+        if self.enable_pixels and self.camera_capture_mode not in ("per_env", "global"):
+            raise ValueError(f"Unknown camera_capture_mode: {self.camera_capture_mode}")  # cube_pick.py:177-178
         builder = models.franka_cube_pick_scene()
         self._builder = builder
         self._mir = MirScene(builder.build(), self.num_envs)
@@ -67,6 +67,9 @@ class FrankaCubePickBatch:
         self.franka = EntityView(self._mir, builder, root="link0", dof_names=models.FRANKA_JOINTS)
         self.cube = EntityView(self._mir, builder, root="cube", dof_names=())
         self.eef = self.franka.get_link("hand")
+        if self.enable_pixels:  # cube_pick.py:55-63
+            self.cam = CameraView(self._mir, builder, self.scene, res=(self.observation_width, self.observation_height),
+                                  pos=(3.5, 0.0, 2.5), lookat=(0, 0, 0.5), fov=30)
         self.motors_dof = np.arange(7)
         self.fingers_dof = np.arange(7, 9)
         # persistent device buffers: one set, rewritten by every fused step
@@ -190,6 +193,19 @@ class FrankaCubePickBatch:
 
     def _pack_obs(self):
         obs = {"agent_pos": self._agent, "environment_state": self._envst}
+        if self.enable_pixels:  # cube_pick.py:159-180
+            if self.strip_environment_state is True:
+                del obs["environment_state"]
+            if self.camera_capture_mode == "per_env":
+                # one batched launch: env i alone, camera at envs_offset[i] + (3.5, 0, 2.5) looking at
+                # envs_offset[i] + (0, 0, 0.5) == the fixed pose in env i's own frame.  uint8 (B, H, W, 3) ON DEVICE
+                # (the reference stacks B host arrays; np.asarray(pixels.cpu()) has its layout and dtype).
+                pixels = self.cam.render_envs()
+            elif self.camera_capture_mode == "global":
+                pixels = self.cam.render_global()  # (H, W, 3)
+            else:
+                raise ValueError(f"Unknown camera_capture_mode: {self.camera_capture_mode}")
+            obs["pixels"] = pixels
         return obs
 
     @property

@@ -70,6 +70,58 @@ class EntityView:
         self._mir.set_pd_targets(tgt)
 
 
+class CameraView:
+    """``scene.add_camera(res, pos, lookat, fov)`` + ``cam.set_pose`` + ``cam.render()``
+    (/root/reference/gym_genesis/tasks/franka/cube_pick.py:56-63,166-176; /root/reference/gym_genesis/env.py:97-98).
+    ``render()`` draws ALL envs of this process at their grid offsets from the camera's current pose, like the
+    reference's single shared scene, and returns ``(rgb, None, None, None)`` with ``rgb`` a NumPy uint8 (H, W, 3)
+    array (Genesis returns rgb, depth, segmentation, normal).  ``render_envs()`` is the batched per-env image
+    tensor used for the ``pixels`` observation: one launch instead of the reference's B renders."""
+
+    def __init__(self, mir, builder, scene, res, pos, lookat, fov, up=(0.0, 0.0, 1.0)):
+        from ..backend.spec import make_camera
+
+        self._mir, self._scene = mir, scene
+        self.res = (int(res[0]), int(res[1]))
+        self.fov = float(fov)
+        self._make = make_camera
+        self._vis = builder.visual()
+        self._up = tuple(up)
+        self._home = (tuple(float(v) for v in pos), tuple(float(v) for v in lookat))
+        self.set_pose(pos=pos, lookat=lookat)
+        self._offsets = torch.as_tensor(np.ascontiguousarray(scene.envs_offset, dtype=np.float32), device=mir.device)
+
+    def set_pose(self, pos=None, lookat=None) -> None:
+        if pos is not None:
+            self.pos = tuple(float(v) for v in np.asarray(pos).ravel())
+        if lookat is not None:
+            self.lookat = tuple(float(v) for v in np.asarray(lookat).ravel())
+
+    def _spec(self, pos, lookat):
+        return self._make(self.res[0], self.res[1], pos, lookat, self.fov, self._up)
+
+    def render_global(self) -> torch.Tensor:
+        """(H, W, 3) uint8 device tensor: every env at its grid offset, camera at its current pose."""
+        return self._mir.render(self._spec(self.pos, self.lookat), self._vis, mode=1, env_offset=self._offsets)
+
+    def render_envs(self, pos=None, lookat=None, out=None) -> torch.Tensor:
+        """(B, H, W, 3) uint8 device tensor: env i alone, seen from `pos` -> `lookat` relative to the env's origin
+        (defaults: the pose the camera was created with)."""
+        return self._mir.render(self._spec(self._home[0] if pos is None else pos, self._home[1] if lookat is None else lookat),
+                                self._vis, mode=0, out=out)
+
+    def render(self, rgb=True, depth=False, segmentation=False, normal=False):
+        if depth or segmentation or normal:
+            raise NotImplementedError("only the rgb output of cam.render() is on the reference's path (env.py:98)")
+        return self.render_global().cpu().numpy(), None, None, None
+
+    def start_recording(self) -> None:  # cube_stack_kitchen_batch.py:111-113; video encoding is out of scope
+        self._recording = True
+
+    def stop_recording(self, save_to_filename=None, fps=60) -> None:
+        raise NotImplementedError("video recording (env.py:70-79) is outside the env.step() hot path (SURVEY.md 8)")
+
+
 class SceneView:
     def __init__(self, mir, env_spacing=(1.0, 1.0), global_num_envs=None, offset=0):
         self._mir = mir

@@ -226,6 +226,43 @@ int mir_get_diag(MirHandle h, int32_t* ncon, int32_t* nefc, int32_t* niter, void
  * qacc_smooth (B,nv), qacc (B,nv); nullable */
 int mir_forward(MirHandle h, float* M, float* qfrc_bias, float* qacc_smooth, float* qacc, void* stream);
 
+/* ---- cameras / pixels (BASELINE.json configs[4]) ---------------------------------
+ * scene.add_camera(res=(W,H), pos, lookat, fov)   gym_genesis/tasks/franka/cube_pick.py:56-63
+ * cam.set_pose(pos, lookat) + cam.render()[0]      gym_genesis/tasks/franka/cube_pick.py:166-176,
+ *                                                  gym_genesis/env.py:97-98
+ * The reference renders through Genesis's OpenGL rasteriser over mesh assets that are not in the
+ * reference tree; here the image is formed from the scene's own collision primitives (boxes, planes)
+ * by a tiled HIP kernel: pinhole camera (vertical fov, +z up, pixel-centre sampling, row 0 = top),
+ * nearest primitive per pixel, Lambert shading from one directional light, a checker on planes. */
+typedef struct MirCameraSpec {
+  int32_t width, height; /* res=(W,H) */
+  double pos[3], lookat[3], up[3];
+  double fov_deg; /* vertical field of view, degrees */
+} MirCameraSpec;
+
+typedef struct MirVisualSpec {
+  int32_t struct_size; /* = sizeof(MirVisualSpec) */
+  int32_t _pad;
+  double geom_rgb[MIR_MAX_GEOM][3]; /* albedo per geom, 0..1 */
+  double light_dir[3];              /* direction TOWARDS the light (normalised by the library) */
+  double ambient, diffuse;          /* colour = albedo * (ambient + diffuse * max(0, n.l)) */
+  double sky_rgb[3];                /* rays that hit nothing */
+  double checker_rgb[2][3];         /* plane geoms: albedo of the two checker colours */
+  double checker_size;              /* checker cell edge, metres */
+} MirVisualSpec;
+
+#define MIR_RENDER_PER_ENV 0 /* one image per env, camera pose relative to the env (cube_pick.py:166-171) */
+#define MIR_RENDER_GLOBAL 1  /* one image of all envs placed at env_offset (cube_pick.py:174-176) */
+
+int mir_visual_sizeof(void);
+
+/* Render RGB8 images of the current state.  mode PER_ENV: pixels (B,H,W,3) u8, env e drawn alone
+ * as seen from `cam` in its own frame (env_offset ignored).  mode GLOBAL: pixels (H,W,3) u8, every env
+ * drawn displaced by env_offset[e] (B,3 f32 device, NULL = all zero); plane geoms are drawn once.
+ * cam / vis are host structs (copied into the launch).  pixels is a device pointer. */
+int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, int32_t mode, const float* env_offset,
+               uint8_t* pixels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,7 @@ def load(f32: bool = False):
     key = "32" if f32 else "64"
     if key not in _libs:
         path = os.path.join(ORACLE_DIR, f"liborc{key}.so")
-        srcs = [os.path.join(ORACLE_DIR, "orc_rigid.c"), os.path.join(ORACLE_DIR, "orc_rigid.h"),
+        srcs = [os.path.join(ORACLE_DIR, "orc_rigid.c"), os.path.join(ORACLE_DIR, "orc_render.c"), os.path.join(ORACLE_DIR, "orc_rigid.h"),
                 os.path.join(ORACLE_DIR, "..", "include", "mirigid.h")]
         if not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(s) for s in srcs):
             build_oracle()
@@ -138,3 +138,21 @@ class Oracle:
         q = np.stack([self.read(F_QPOS, e) for e in range(self.B)])
         v = np.stack([self.read(F_QVEL, e) for e in range(self.B)])
         return q, v
+
+
+def render_image(spec, cam, vis, xpos, xquat, offsets=None, want_depth=False):
+    """Brute-force float64 ray cast of one image (orc_render.c).  xpos (nenv,nbody,3), xquat (nenv,nbody,4)."""
+    lib = load(False)
+    xpos = np.ascontiguousarray(xpos, dtype=np.float64)
+    xquat = np.ascontiguousarray(xquat, dtype=np.float64)
+    nenv = xpos.shape[0]
+    out = np.zeros((cam.height, cam.width, 3), dtype=np.uint8)
+    depth = np.zeros((cam.height, cam.width)) if want_depth else None
+    off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
+    lib.orc_render_image.restype = C.c_int
+    rc = lib.orc_render_image(C.byref(spec), C.byref(cam), C.byref(vis), C.c_int(nenv), xpos.ctypes.data_as(C.c_void_p),
+                              xquat.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p) if off is not None else None,
+                              out.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p) if want_depth else None)
+    if rc != 0:
+        raise RuntimeError(f"orc_render_image failed: {rc}")
+    return (out, depth) if want_depth else out

@@ -1,0 +1,129 @@
+"""GPU parity of the tiled rasteriser (mir_render, through the C ABI) against the float64 brute-force ray
+caster of the oracle (oracle/orc_render.c) on the same link poses.
+
+Bar: uint8 RGB, every pixel within 1 LSB of the oracle, except pixels where the two disagree on WHICH surface is
+nearest (silhouette / checker-edge pixels whose ray passes within float32 rounding of an edge); those are counted
+and must stay below 0.05 % of the image.
+"""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from gym_genesis.backend import models
+from gym_genesis.backend.spec import make_camera
+
+pytestmark = pytest.mark.gpu
+
+HOME = np.array(models.FRANKA_HOME, dtype=np.float32)
+
+
+def _stepped_scene(builder, B, steps=30, seed=0):
+    from gym_genesis.backend.lib import MirScene
+
+    sc = MirScene(builder.build(), B)
+    rng = np.random.RandomState(seed)
+    pos = np.stack([rng.uniform(0.45, 0.80, B), rng.uniform(-0.25, 0.25, B), np.full(B, 0.02)], 1).astype(np.float32)
+    sc.reset(pos, np.tile(np.array([0, 0, 0, 1], np.float32), (B, 1)), np.tile(HOME, (B, 1)))
+    acts = torch.as_tensor(rng.uniform(-1, 1, (steps, B, 9)).astype(np.float32), device=sc.device)
+    for t in range(steps):
+        sc.set_pd_targets(acts[t])
+        sc.step(1)
+    return sc
+
+
+def _compare(img, ref, max_bad_frac=5e-4):
+    d = np.abs(img.astype(np.int16) - ref.astype(np.int16)).max(axis=-1)
+    bad = d > 1
+    assert bad.mean() <= max_bad_frac, f"{bad.sum()} pixels differ by more than 1 LSB ({bad.mean():.2e} of the image)"
+    return int(bad.sum()), int(d.max())
+
+
+@pytest.mark.parametrize("res", [(640, 480), (128, 96)])
+def test_per_env_images_match_oracle(res):
+    B = 6
+    builder = models.franka_cube_pick_scene()
+    sc = _stepped_scene(builder, B)
+    cam = make_camera(res[0], res[1], (3.5, 0.0, 2.5), (0, 0, 0.5), 30)
+    vis = builder.visual()
+    img = sc.render(cam, vis, mode=0).cpu().numpy()
+    assert img.shape == (B, res[1], res[0], 3) and img.dtype == np.uint8
+    xpos, xquat = (t.cpu().numpy() for t in sc.get_links())
+    total_bad = 0
+    for e in range(B):
+        ref = orc.render_image(builder.build(), cam, vis, xpos[e:e + 1], xquat[e:e + 1])
+        nbad, _ = _compare(img[e], ref)
+        total_bad += nbad
+        assert len(np.unique(ref.reshape(-1, 3), axis=0)) > 6  # robot, cube, both checker colours are in view
+    # different envs show different images (cube spawn + random actions)
+    assert not np.array_equal(img[0], img[1])
+
+
+def test_close_camera_and_odd_resolution():
+    """Primitives that straddle the camera plane / fill the screen, W not a multiple of 4 (scalar store path),
+    H not a multiple of the tile height."""
+    B = 3
+    builder = models.franka_cube_pick_scene()
+    sc = _stepped_scene(builder, B, steps=5)
+    vis = builder.visual()
+    for cam in (make_camera(202, 77, (0.9, 0.3, 0.6), (0.3, 0.0, 0.4), 70), make_camera(64, 64, (0.3, 0.0, 0.05), (0.65, 0.0, 0.0), 100),
+                make_camera(96, 40, (0.0, 0.0, 3.0), (0.4, 0.0, 0.0), 45, up=(1.0, 0.0, 0.0))):
+        img = sc.render(cam, vis, mode=0).cpu().numpy()
+        xpos, xquat = (t.cpu().numpy() for t in sc.get_links())
+        for e in range(B):
+            ref = orc.render_image(builder.build(), cam, vis, xpos[e:e + 1], xquat[e:e + 1])
+            _compare(img[e], ref, max_bad_frac=2e-3)
+
+
+def test_global_image_matches_oracle():
+    """One image of all envs at their grid offsets (camera_capture_mode='global', cube_pick.py:174-176); B large
+    enough that a tile's primitive list needs several LDS rounds."""
+    B = 400
+    builder = models.franka_cube_pick_scene()
+    sc = _stepped_scene(builder, B, steps=3)
+    cam = make_camera(320, 240, (14.0, -3.0, 9.0), (0, 0, 0.5), 40)
+    vis = builder.visual()
+    side = int(np.ceil(np.sqrt(B)))
+    idx = np.arange(B)
+    off = np.stack([(idx % side - (side - 1) / 2) * 1.0, (idx // side - (side - 1) / 2) * 1.0, np.zeros(B)], 1).astype(np.float32)
+    img = sc.render(cam, vis, mode=1, env_offset=torch.as_tensor(off, device=sc.device)).cpu().numpy()
+    assert img.shape == (240, 320, 3)
+    xpos, xquat = (t.cpu().numpy() for t in sc.get_links())
+    ref = orc.render_image(builder.build(), cam, vis, xpos, xquat, offsets=off)
+    _compare(img, ref, max_bad_frac=3e-3)  # hundreds of small silhouettes: more edge pixels per image
+
+
+def test_render_is_deterministic_and_does_not_disturb_physics():
+    B = 8
+    builder = models.franka_cube_pick_scene()
+    sc = _stepped_scene(builder, B, steps=4)
+    q0, v0, _, _ = (t.clone() for t in sc.get_state())
+    cam = make_camera(160, 120, (3.5, 0.0, 2.5), (0, 0, 0.5), 30)
+    vis = builder.visual()
+    a = sc.render(cam, vis).clone()
+    b = sc.render(cam, vis)
+    assert torch.equal(a, b)
+    q1, v1, _, _ = sc.get_state()
+    assert torch.equal(q0, q1) and torch.equal(v0, v1)
+
+
+def test_pixels_observation_through_the_env():
+    """GenesisEnv(enable_pixels=True): obs keys / shapes / dtypes of the reference (cube_pick.py:73-84,159-180)."""
+    from gym_genesis.env import GenesisEnv
+
+    B, H, W = 5, 96, 128
+    for mode, shape in (("per_env", (B, H, W, 3)), ("global", (H, W, 3))):
+        env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, observation_height=H,
+                         observation_width=W, camera_capture_mode=mode)
+        obs, _ = env.reset(seed=0)
+        assert set(obs) == {"agent_pos", "pixels"}  # strip_environment_state=True (env.py:28)
+        assert tuple(obs["pixels"].shape) == shape and obs["pixels"].dtype == torch.uint8
+        obs, reward, terminated, truncated, info = env.step(np.zeros((B, 9), np.float32))
+        assert tuple(obs["pixels"].shape) == shape
+        frame = env.render()
+        assert isinstance(frame, np.ndarray) and frame.shape == (H, W, 3) and frame.dtype == np.uint8
+        assert env.observation_space["pixels"].shape == (H, W, 3)
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=2, enable_pixels=False)
+    assert env.render() is None
+    with pytest.raises(ValueError):
+        env.get_cams()
