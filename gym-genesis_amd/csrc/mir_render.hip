@@ -61,21 +61,31 @@ struct SetupArgs {
   Cam cam;
   float light[3];
   float rgb[MIR_MAX_GEOM][3];
+  float chk[2][3];
+  float amb, dif, inv_chk;
   int B, ngeom, global_mode;
 };
 
 struct PixArgs {
   const float* prims;
   uint8_t* pixels;
-  int W, H, nprim;  // primitives per image
+  int W, H, nprim;       // primitives per image
   float x0, dx, y0, dy;  // image-plane coordinates of pixel (i, j): x0 + i dx, y0 + j dy
-  float amb, dif, inv_chk;
-  float sky[3], chk[2][3];
+  unsigned sky;          // packed RGB8
 };
 
-// ---- per-(env, geom) primitive record ------------------------------------------------------------
-//  [0..2] o'  [3] type | [4..6] F' [7] xmin | [8..10] R' [11] xmax | [12..14] U' [15] ymin |
-//  [16..18] half extents [19] ymax | [20..22] albedo | [24..26] a_k . light
+__device__ __forceinline__ unsigned to_u8(float c) {
+  return (unsigned)(fminf(fmaxf(c, 0.0f), 1.0f) * 255.0f + 0.5f);
+}
+__device__ __forceinline__ float pack_rgb(const float* alb, float shade) {
+  return __uint_as_float(to_u8(alb[0] * shade) | to_u8(alb[1] * shade) << 8 | to_u8(alb[2] * shade) << 16);
+}
+
+// ---- per-(env, geom) primitive record (8 quads; every colour is final: albedo x shade, packed RGB8) ----
+//  q0 o' | type      q1 F' | xmin      q2 R' | xmax      q3 U' | ymin      q4 half extents | ymax
+//  box  : q5 = colours of the faces +x +y +z -x, q6 = -y -z
+//  plane: q5 = Nu0 NuX NuY colour(even cell), q6 = Nv0 NvX NvY colour(odd cell), with the hit point's checker
+//         coordinate u/2 = (Nu0 + x NuX + y NuY) / d'z  (perspective-correct ratio of two affine functions)
 __global__ void k_render_setup(SetupArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.B * a.ngeom) return;
@@ -103,7 +113,12 @@ __global__ void k_render_setup(SetupArgs a) {
   const V3 L = {a.light[0], a.light[1], a.light[2]};
   const V3 rel = cp - c;
   const V3 h = {m->g_size[g][0], m->g_size[g][1], m->g_size[g][2]};
+  const V3 o = {dot(ax[0], rel), dot(ax[1], rel), dot(ax[2], rel)};
+  const V3 F = {dot(ax[0], cf), dot(ax[1], cf), dot(ax[2], cf)}, R = {dot(ax[0], cr), dot(ax[1], cr), dot(ax[2], cr)};
+  const V3 U = {dot(ax[0], cu), dot(ax[1], cu), dot(ax[2], cu)};
+  const float lk[3] = {dot(ax[0], L), dot(ax[1], L), dot(ax[2], L)};
   int xmin = 0, xmax = a.cam.W - 1, ymin = 0, ymax = a.cam.H - 1;
+  f4 q5, q6;
   if (type == MIR_GEOM_BOX) {
     float pxmin = 3e38f, pxmax = -3e38f, pymin = 3e38f, pymax = -3e38f;
     int behind = 0;
@@ -122,46 +137,55 @@ __global__ void k_render_setup(SetupArgs a) {
       xmin = max(0, (int)fmaxf(floorf(pxmin) - 1.0f, -1.0f)); xmax = min(a.cam.W - 1, (int)fminf(ceilf(pxmax) + 1.0f, 1e9f));
       ymin = max(0, (int)fmaxf(floorf(pymin) - 1.0f, -1.0f)); ymax = min(a.cam.H - 1, (int)fminf(ceilf(pymax) + 1.0f, 1e9f));
     }  // straddling the camera plane: keep the full screen
-  } else if (a.global_mode && e > 0) {
-    xmin = 1; xmax = 0; ymin = 1; ymax = 0;  // an unbounded plane is drawn once (env 0's)
+    const float* alb = a.rgb[g];
+    q5 = f4{pack_rgb(alb, a.amb + a.dif * fmaxf(lk[0], 0.0f)), pack_rgb(alb, a.amb + a.dif * fmaxf(lk[1], 0.0f)),
+            pack_rgb(alb, a.amb + a.dif * fmaxf(lk[2], 0.0f)), pack_rgb(alb, a.amb + a.dif * fmaxf(-lk[0], 0.0f))};
+    q6 = f4{pack_rgb(alb, a.amb + a.dif * fmaxf(-lk[1], 0.0f)), pack_rgb(alb, a.amb + a.dif * fmaxf(-lk[2], 0.0f)), 0.0f, 0.0f};
+  } else {
+    if (a.global_mode && e > 0) { xmin = 1; xmax = 0; ymin = 1; ymax = 0; }  // an unbounded plane is drawn once (env 0's)
+    const float nl = o.z < 0.0f ? -lk[2] : lk[2];  // the side of the plane the camera is on
+    const float sh = a.amb + a.dif * fmaxf(nl, 0.0f);
+    const float s = 0.5f * a.inv_chk;
+    q5 = f4{s * (o.x * F.z - o.z * F.x), s * (o.x * R.z - o.z * R.x), s * (o.x * U.z - o.z * U.x), pack_rgb(a.chk[0], sh)};
+    q6 = f4{s * (o.y * F.z - o.z * F.y), s * (o.y * R.z - o.z * R.y), s * (o.y * U.z - o.z * U.y), pack_rgb(a.chk[1], sh)};
   }
-  float* o = a.prims + (size_t)i * PREC;
-  f4* o4 = reinterpret_cast<f4*>(o);
-  o4[0] = f4{dot(ax[0], rel), dot(ax[1], rel), dot(ax[2], rel), __int_as_float(type)};
-  o4[1] = f4{dot(ax[0], cf), dot(ax[1], cf), dot(ax[2], cf), __int_as_float(xmin)};
-  o4[2] = f4{dot(ax[0], cr), dot(ax[1], cr), dot(ax[2], cr), __int_as_float(xmax)};
-  o4[3] = f4{dot(ax[0], cu), dot(ax[1], cu), dot(ax[2], cu), __int_as_float(ymin)};
+  f4* o4 = reinterpret_cast<f4*>(a.prims + (size_t)i * PREC);
+  o4[0] = f4{o.x, o.y, o.z, __int_as_float(type)};
+  o4[1] = f4{F.x, F.y, F.z, __int_as_float(xmin)};
+  o4[2] = f4{R.x, R.y, R.z, __int_as_float(xmax)};
+  o4[3] = f4{U.x, U.y, U.z, __int_as_float(ymin)};
   o4[4] = f4{h.x, h.y, h.z, __int_as_float(ymax)};
-  o4[5] = f4{a.rgb[g][0], a.rgb[g][1], a.rgb[g][2], 0.0f};
-  o4[6] = f4{dot(ax[0], L), dot(ax[1], L), dot(ax[2], L), 0.0f};
+  o4[5] = q5;
+  o4[6] = q6;
   o4[7] = f4{0, 0, 0, 0};
 }
 
-__device__ __forceinline__ unsigned to_u8(float c) {
-  return (unsigned)(fminf(fmaxf(c, 0.0f), 1.0f) * 255.0f + 0.5f);
-}
-
 // ---- pixels --------------------------------------------------------------------------------------
+// 256 threads = 4 waves side by side; a wave owns a 32-pixel-wide column of the 128 x 32 tile and walks it in
+// four 32 x 8 regions (lane = 4 consecutive pixels of one of the 8 rows).  Primitive records are read with
+// wave-uniform addresses straight from global memory (scalar loads); LDS holds only the tile's id list.
 __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
-  __shared__ __attribute__((aligned(16))) f4 s_rec[RCAP][5];  // o'|type, F'|xmin, R'|xmax, U'|ymin, h|ymax
   __shared__ int s_ids[256];
   __shared__ int s_wcnt[4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, img = blockIdx.z;
-  const int px = tx0 + 4 * (tid & 31);
-  const int prow = ty0 + (tid >> 5);  // rows prow, prow + 8, prow + 16, prow + 24
+  const int wx0 = tx0 + 32 * wv;              // this wave's column
+  const int px = wx0 + 4 * (lane & 7);
+  const int prow = ty0 + (lane >> 3);         // rows prow, prow + 8, prow + 16, prow + 24
   const float* __restrict__ prims = a.prims + (size_t)img * a.nprim * PREC;
   const int txmax = min(tx0 + TW, a.W) - 1, tymax = min(ty0 + TH, a.H) - 1;
 
   float best[4][4];
-  int code[4][4];
+  unsigned col[4][4];
 #pragma unroll
   for (int r = 0; r < 4; r++)
 #pragma unroll
-    for (int p = 0; p < 4; p++) { best[r][p] = 3e38f; code[r][p] = -1; }
-  float xs[4];
+    for (int p = 0; p < 4; p++) { best[r][p] = 3e38f; col[r][p] = a.sky; }
+  float xs[4], ysr[4];
 #pragma unroll
   for (int p = 0; p < 4; p++) xs[p] = a.x0 + (float)(px + p) * a.dx;
+#pragma unroll
+  for (int r = 0; r < 4; r++) ysr[r] = a.y0 + (float)(prow + 8 * r) * a.dy;
 
   for (int base = 0; base < a.nprim; base += 256) {
     // ---- cull this chunk of primitives against the tile; ordered compaction of the survivors
@@ -173,6 +197,7 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
       hit = xmin <= txmax && xmax >= tx0 && ymin <= tymax && ymax >= ty0;
     }
     const unsigned long long bal = __ballot(hit);
+    if (base) __syncthreads();  // the previous chunk's list is still being read
     if (lane == 0) s_wcnt[wv] = __popcll(bal);
     __syncthreads();
     int off = 0, total = 0;
@@ -184,103 +209,73 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
     }
     if (hit) s_ids[off + __popcll(bal & ((1ull << lane) - 1ull))] = pi;
     __syncthreads();
-    for (int r0 = 0; r0 < total; r0 += RCAP) {
-      const int nrec = min(RCAP, total - r0);
-      // cooperative copy of the surviving records (first 5 quads of each) into LDS
-      for (int q = tid; q < nrec * 5; q += 256) {
-        const int k = q / 5, j = q - 5 * k;
-        s_rec[k][j] = reinterpret_cast<const f4*>(prims + (size_t)s_ids[r0 + k] * PREC)[j];
-      }
-      __syncthreads();
-      for (int k = 0; k < nrec; k++) {
-        const f4 ro = s_rec[k][0], rf = s_rec[k][1], rr = s_rec[k][2], ru = s_rec[k][3], rh = s_rec[k][4];
-        const int id = s_ids[r0 + k];
-        const int xmin = __float_as_int(rf.w), xmax = __float_as_int(rr.w), ymin = __float_as_int(ru.w), ymax = __float_as_int(rh.w);
-        const bool isbox = __float_as_int(ro.w) == MIR_GEOM_BOX;
+    for (int k = 0; k < total; k++) {
+      const int id = __builtin_amdgcn_readfirstlane(s_ids[k]);
+      const f4* __restrict__ rec = reinterpret_cast<const f4*>(prims + (size_t)id * PREC);
+      const f4 ro = rec[0], rf = rec[1], rr = rec[2], ru = rec[3], rh = rec[4], q5 = rec[5], q6 = rec[6];
+      const int xmin = __float_as_int(rf.w), xmax = __float_as_int(rr.w), ymin = __float_as_int(ru.w), ymax = __float_as_int(rh.w);
+      if (xmax < wx0 || xmin > wx0 + 31) continue;  // wave-uniform column cull
+      if (__float_as_int(ro.w) == MIR_GEOM_BOX) {
+        const float ax = -rh.x - ro.x, bx = rh.x - ro.x, ay = -rh.y - ro.y, by = rh.y - ro.y, az = -rh.z - ro.z, bz = rh.z - ro.z;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          // wave-uniform row cull: this wave's two rows of iteration r
-          const int wy = ty0 + 8 * r + 2 * wv;
-          if (ymax < wy || ymin > wy + 1) continue;
-          const int y = prow + 8 * r;
-          const float ys = a.y0 + (float)y * a.dy;
-          const float bx = fmaf(ys, ru.x, rf.x), by = fmaf(ys, ru.y, rf.y), bz = fmaf(ys, ru.z, rf.z);
+          const int wy = ty0 + 8 * r;  // wave-uniform region cull: rows wy .. wy + 7
+          if (ymax < wy || ymin > wy + 7) continue;
+          const float ex = fmaf(ysr[r], ru.x, rf.x), ey = fmaf(ysr[r], ru.y, rf.y), ez = fmaf(ysr[r], ru.z, rf.z);
 #pragma unroll
           for (int p = 0; p < 4; p++) {
-            const float dxp = fmaf(xs[p], rr.x, bx), dyp = fmaf(xs[p], rr.y, by), dzp = fmaf(xs[p], rr.z, bz);
-            float t;
-            int face;
-            bool ok;
-            if (isbox) {
-              const float ix = __builtin_amdgcn_rcpf(dxp), iy = __builtin_amdgcn_rcpf(dyp), iz = __builtin_amdgcn_rcpf(dzp);
-              const float ax1 = (-rh.x - ro.x) * ix, ax2 = (rh.x - ro.x) * ix;
-              const float ay1 = (-rh.y - ro.y) * iy, ay2 = (rh.y - ro.y) * iy;
-              const float az1 = (-rh.z - ro.z) * iz, az2 = (rh.z - ro.z) * iz;
-              const float nx = fminf(ax1, ax2), ny = fminf(ay1, ay2), nz = fminf(az1, az2);
-              const float tn = fmaxf(fmaxf(nx, ny), nz);
-              const float tf = fminf(fminf(fmaxf(ax1, ax2), fmaxf(ay1, ay2)), fmaxf(az1, az2));
-              ok = tn <= tf && tn > 1e-6f && px + p >= xmin && px + p <= xmax;
-              t = tn;
-              face = tn == nx ? 0 : (tn == ny ? 1 : 2);
-              const float dk = face == 0 ? dxp : (face == 1 ? dyp : dzp);
-              face |= dk > 0.0f ? 4 : 0;  // bit 2: the ray travels along +axis, so the face normal is -axis
-            } else {
-              t = -ro.z * __builtin_amdgcn_rcpf(dzp);
-              ok = t > 1e-6f && t < 1e30f;
-              face = 2 | (ro.z < 0.0f ? 4 : 0);
+            const float dxp = fmaf(xs[p], rr.x, ex), dyp = fmaf(xs[p], rr.y, ey), dzp = fmaf(xs[p], rr.z, ez);
+            const float ix = __builtin_amdgcn_rcpf(dxp), iy = __builtin_amdgcn_rcpf(dyp), iz = __builtin_amdgcn_rcpf(dzp);
+            const float x1 = ax * ix, x2 = bx * ix, y1 = ay * iy, y2 = by * iy, z1 = az * iz, z2 = bz * iz;
+            const float nx = fminf(x1, x2), ny = fminf(y1, y2), nz = fminf(z1, z2);
+            const float tn = fmaxf(fmaxf(nx, ny), nz);
+            const float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+            if (tn <= tf && tn > 1e-6f && tn < best[r][p]) {
+              best[r][p] = tn;
+              // the face whose slab entry is the latest; the ray enters through the face opposing its direction
+              const float cx = dxp > 0.0f ? q5.w : q5.x, cy = dyp > 0.0f ? q6.x : q5.y, cz = dzp > 0.0f ? q6.y : q5.z;
+              col[r][p] = __float_as_uint(tn == nx ? cx : (tn == ny ? cy : cz));
             }
-            if (ok && t < best[r][p]) { best[r][p] = t; code[r][p] = id * 8 + face; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float ez = fmaf(ysr[r], ru.z, rf.z), eu = fmaf(ysr[r], q5.z, q5.x), ev = fmaf(ysr[r], q6.z, q6.x);
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            const float iz = __builtin_amdgcn_rcpf(fmaf(xs[p], rr.z, ez));
+            const float t = -ro.z * iz;
+            const float fu = __builtin_amdgcn_fractf(fmaf(xs[p], q5.y, eu) * iz), fv = __builtin_amdgcn_fractf(fmaf(xs[p], q6.y, ev) * iz);
+            if (t > 1e-6f && t < best[r][p]) {
+              best[r][p] = t;
+              col[r][p] = __float_as_uint((fu >= 0.5f) != (fv >= 0.5f) ? q6.w : q5.w);
+            }
           }
         }
       }
-      __syncthreads();
     }
   }
 
-  // ---- deferred shading + packed RGB8 store -------------------------------------------------------
+  // ---- packed RGB8 store: 4 pixels = 3 dwords per lane ---------------------------------------------
   const bool fast = (a.W & 3) == 0;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int y = prow + 8 * r;
     if (y >= a.H || px >= a.W) continue;
-    const float ys = a.y0 + (float)y * a.dy;
-    unsigned cr[4], cg[4], cb[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      float R = a.sky[0], Gc = a.sky[1], Bc = a.sky[2];
-      const int cd = code[r][p];
-      if (cd >= 0) {
-        const int id = cd >> 3, k = cd & 3;
-        const f4* rec = reinterpret_cast<const f4*>(prims + (size_t)id * PREC);
-        const f4 ro = rec[0];
-        f4 alb = rec[5];
-        const f4 lk = rec[6];
-        float nl = k == 0 ? lk.x : (k == 1 ? lk.y : lk.z);
-        nl = (cd & 4) ? -nl : nl;
-        if (__float_as_int(ro.w) == MIR_GEOM_PLANE) {
-          const f4 rf = rec[1], rr = rec[2], ru = rec[3];
-          const float t = best[r][p];
-          const float dxp = fmaf(xs[p], rr.x, fmaf(ys, ru.x, rf.x)), dyp = fmaf(xs[p], rr.y, fmaf(ys, ru.y, rf.y));
-          const float hu = fmaf(t, dxp, ro.x), hv = fmaf(t, dyp, ro.y);
-          const int par = ((int)floorf(hu * a.inv_chk) + (int)floorf(hv * a.inv_chk)) & 1;
-          alb = f4{a.chk[par][0], a.chk[par][1], a.chk[par][2], 0.0f};
-        }
-        const float sh = a.amb + a.dif * fmaxf(nl, 0.0f);
-        R = alb.x * sh; Gc = alb.y * sh; Bc = alb.z * sh;
-      }
-      cr[p] = to_u8(R); cg[p] = to_u8(Gc); cb[p] = to_u8(Bc);
-    }
     uint8_t* dst = a.pixels + (((size_t)img * a.H + y) * a.W + px) * 3;
+    const unsigned c0 = col[r][0], c1 = col[r][1], c2 = col[r][2], c3 = col[r][3];
     if (fast) {
       u3 v;
-      v.x = cr[0] | cg[0] << 8 | cb[0] << 16 | cr[1] << 24;
-      v.y = cg[1] | cb[1] << 8 | cr[2] << 16 | cg[2] << 24;
-      v.z = cb[2] | cr[3] << 8 | cg[3] << 16 | cb[3] << 24;
+      v.x = c0 | c1 << 24;
+      v.y = c1 >> 8 | c2 << 16;
+      v.z = c2 >> 16 | c3 << 8;
       __builtin_nontemporal_store(v, reinterpret_cast<u3*>(dst));
     } else {
+      const unsigned cc[4] = {c0, c1, c2, c3};
 #pragma unroll
       for (int p = 0; p < 4; p++)
-        if (px + p < a.W) { dst[3 * p] = (uint8_t)cr[p]; dst[3 * p + 1] = (uint8_t)cg[p]; dst[3 * p + 2] = (uint8_t)cb[p]; }
+        if (px + p < a.W) { dst[3 * p] = (uint8_t)cc[p]; dst[3 * p + 1] = (uint8_t)(cc[p] >> 8); dst[3 * p + 2] = (uint8_t)(cc[p] >> 16); }
     }
   }
 }
@@ -338,6 +333,8 @@ extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisual
     for (int k = 0; k < 3; k++) sa.light[k] = (float)L[k];
     for (int g = 0; g < ng; g++)
       for (int k = 0; k < 3; k++) sa.rgb[g][k] = (float)vis->geom_rgb[g][k];
+    sa.amb = (float)vis->ambient; sa.dif = (float)vis->diffuse; sa.inv_chk = (float)(1.0 / vis->checker_size);
+    for (int k = 0; k < 3; k++) { sa.chk[0][k] = (float)vis->checker_rgb[0][k]; sa.chk[1][k] = (float)vis->checker_rgb[1][k]; }
     sa.B = B; sa.ngeom = ng; sa.global_mode = mode == MIR_RENDER_GLOBAL;
     hipLaunchKernelGGL(k_render_setup, dim3((B * ng + 255) / 256), dim3(256), 0, st, sa);
     PixArgs pa;
@@ -346,8 +343,10 @@ extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisual
     pa.nprim = mode == MIR_RENDER_GLOBAL ? B * ng : ng;
     pa.dx = (float)(2.0 * tx / cam->width); pa.x0 = (float)(-tx + tx / cam->width);
     pa.dy = (float)(-2.0 * ty / cam->height); pa.y0 = (float)(ty - ty / cam->height);
-    pa.amb = (float)vis->ambient; pa.dif = (float)vis->diffuse; pa.inv_chk = (float)(1.0 / vis->checker_size);
-    for (int k = 0; k < 3; k++) { pa.sky[k] = (float)vis->sky_rgb[k]; pa.chk[0][k] = (float)vis->checker_rgb[0][k]; pa.chk[1][k] = (float)vis->checker_rgb[1][k]; }
+    {
+      auto u8 = [](double c) { return (unsigned)(std::fmin(std::fmax(c, 0.0), 1.0) * 255.0 + 0.5); };
+      pa.sky = u8(vis->sky_rgb[0]) | u8(vis->sky_rgb[1]) << 8 | u8(vis->sky_rgb[2]) << 16;
+    }
     const int nimg = mode == MIR_RENDER_GLOBAL ? 1 : B;
     hipLaunchKernelGGL(mir_render_kernel, dim3((cam->width + TW - 1) / TW, (cam->height + TH - 1) / TH, nimg), dim3(256), 0, st, pa);
     hipError_t e = hipGetLastError();
