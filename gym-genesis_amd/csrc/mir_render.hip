@@ -23,19 +23,27 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "mir_model.h"
 #include "mir_scene.h"
 
 #define TW 128   /* tile width, pixels  */
-#define TH 32    /* tile height, pixels */
+#ifndef TH
+#define TH 160  /* rows per workgroup strip (multiple of 32): walked as 128 x 32 sub-tiles */
+#endif
 #define RCAP 64  /* primitive records resident in LDS per round */
 #define PREC 32  /* floats per primitive record */
+#ifndef MIR_RENDER_NT
+#define MIR_RENDER_NT 0 /* 1: nontemporal pixel stores */
+#endif
 
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef f4 __attribute__((address_space(4))) cf4;  // constant address space: uniform reads become scalar loads
 typedef unsigned u3 __attribute__((ext_vector_type(3)));
 
 struct V3 {
@@ -72,8 +80,10 @@ struct PixArgs {
   int W, H, nprim;       // primitives per image
   float x0, dx, y0, dy;  // image-plane coordinates of pixel (i, j): x0 + i dx, y0 + j dy
   unsigned sky;          // packed RGB8
+  int th;                // rows per workgroup strip (multiple of 32)
 };
 
+__device__ __forceinline__ f2 rcp2(f2 v) { return f2{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; }
 __device__ __forceinline__ unsigned to_u8(float c) {
   return (unsigned)(fminf(fmaxf(c, 0.0f), 1.0f) * 255.0f + 0.5f);
 }
@@ -161,121 +171,153 @@ __global__ void k_render_setup(SetupArgs a) {
 }
 
 // ---- pixels --------------------------------------------------------------------------------------
-// 256 threads = 4 waves side by side; a wave owns a 32-pixel-wide column of the 128 x 32 tile and walks it in
-// four 32 x 8 regions (lane = 4 consecutive pixels of one of the 8 rows).  Primitive records are read with
-// wave-uniform addresses straight from global memory (scalar loads); LDS holds only the tile's id list.
+// 256 threads = 4 waves side by side; a workgroup walks a 128-pixel-wide strip of `th` rows in 128 x 32 sub-tiles.
+// Per sub-tile: the image's primitives are culled against it (ordered ballot compaction into an LDS id list), then
+// every listed primitive is tested on the wave's 32 x 32 column (4 regions of 32 x 8; lane = 4 consecutive pixels of
+// one row; wave-uniform region cull), then the 4 regions are stored as packed RGB8, one global_store_dwordx3 per
+// lane and region.  The wave does NOT wait for those stores: it goes on to the next sub-tile, so the write traffic
+// of one sub-tile drains under the arithmetic of the next (a workgroup per sub-tile serialises the two: measured
+// 240 us of arithmetic + 150 us of stores = 390 us).  Primitive records are read with wave-uniform addresses
+// straight from global memory (scalar loads, amortised over 16 pixels per lane); LDS holds only the id list.
 __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
   __shared__ int s_ids[256];
   __shared__ int s_wcnt[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, img = blockIdx.z;
+  const int tx0 = blockIdx.x * TW, sy0 = blockIdx.y * a.th, img = blockIdx.z;
   const int wx0 = tx0 + 32 * wv;              // this wave's column
   const int px = wx0 + 4 * (lane & 7);
-  const int prow = ty0 + (lane >> 3);         // rows prow, prow + 8, prow + 16, prow + 24
   const float* __restrict__ prims = a.prims + (size_t)img * a.nprim * PREC;
-  const int txmax = min(tx0 + TW, a.W) - 1, tymax = min(ty0 + TH, a.H) - 1;
+  const int txmax = min(tx0 + TW, a.W) - 1, symax = min(sy0 + a.th, a.H) - 1;
+  const bool fast = (a.W & 3) == 0;
+  const bool onechunk = a.nprim <= 256;
+  int total = 0;
+  f2 xs[2];  // pixel pairs feed the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32)
+  xs[0] = f2{a.x0 + (float)px * a.dx, a.x0 + (float)(px + 1) * a.dx};
+  xs[1] = f2{a.x0 + (float)(px + 2) * a.dx, a.x0 + (float)(px + 3) * a.dx};
 
-  float best[4][4];
-  unsigned col[4][4];
+  for (int ty0 = sy0; ty0 <= symax; ty0 += 32) {
+    const int tymax = min(ty0 + 31, symax);
+    const int prow = ty0 + (lane >> 3);  // rows prow, prow + 8, prow + 16, prow + 24
+    f2 best[4][2];
+    unsigned col[4][4];
+    float ysr[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++)
+    for (int r = 0; r < 4; r++) {
+      best[r][0] = best[r][1] = f2{3e38f, 3e38f};
+      ysr[r] = a.y0 + (float)(prow + 8 * r) * a.dy;
 #pragma unroll
-    for (int p = 0; p < 4; p++) { best[r][p] = 3e38f; col[r][p] = a.sky; }
-  float xs[4], ysr[4];
-#pragma unroll
-  for (int p = 0; p < 4; p++) xs[p] = a.x0 + (float)(px + p) * a.dx;
-#pragma unroll
-  for (int r = 0; r < 4; r++) ysr[r] = a.y0 + (float)(prow + 8 * r) * a.dy;
-
-  for (int base = 0; base < a.nprim; base += 256) {
-    // ---- cull this chunk of primitives against the tile; ordered compaction of the survivors
-    const int pi = base + tid;
-    bool hit = false;
-    if (pi < a.nprim) {
-      const float* rec = prims + (size_t)pi * PREC;
-      const int xmin = __float_as_int(rec[7]), xmax = __float_as_int(rec[11]), ymin = __float_as_int(rec[15]), ymax = __float_as_int(rec[19]);
-      hit = xmin <= txmax && xmax >= tx0 && ymin <= tymax && ymax >= ty0;
+      for (int p = 0; p < 4; p++) col[r][p] = a.sky;
     }
-    const unsigned long long bal = __ballot(hit);
-    if (base) __syncthreads();  // the previous chunk's list is still being read
-    if (lane == 0) s_wcnt[wv] = __popcll(bal);
-    __syncthreads();
-    int off = 0, total = 0;
+    for (int base = 0; base < a.nprim; base += 256) {
+      // ---- cull this chunk of primitives; ordered compaction of the survivors.  With a single chunk (every per-env
+      // image) the list is built ONCE per strip, against the strip: no vector load is issued after the first pixel
+      // stores, so no s_waitcnt vmcnt ever has to drain them
+      if (!onechunk || ty0 == sy0) {
+        const int cy0 = onechunk ? sy0 : ty0, cy1 = onechunk ? symax : tymax;
+        const int pi = base + tid;
+        bool hit = false;
+        if (pi < a.nprim) {
+          const float* rec = prims + (size_t)pi * PREC;
+          const int xmin = __float_as_int(rec[7]), xmax = __float_as_int(rec[11]), ymin = __float_as_int(rec[15]), ymax = __float_as_int(rec[19]);
+          hit = xmin <= txmax && xmax >= tx0 && ymin <= cy1 && ymax >= cy0;
+        }
+        const unsigned long long bal = __ballot(hit);
+        __syncthreads();  // the previous list is no longer being read
+        if (lane == 0) s_wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        total = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int c = s_wcnt[k];
-      off += k < wv ? c : 0;
-      total += c;
-    }
-    if (hit) s_ids[off + __popcll(bal & ((1ull << lane) - 1ull))] = pi;
-    __syncthreads();
-    for (int k = 0; k < total; k++) {
-      const int id = __builtin_amdgcn_readfirstlane(s_ids[k]);
-      const f4* __restrict__ rec = reinterpret_cast<const f4*>(prims + (size_t)id * PREC);
-      const f4 ro = rec[0], rf = rec[1], rr = rec[2], ru = rec[3], rh = rec[4], q5 = rec[5], q6 = rec[6];
-      const int xmin = __float_as_int(rf.w), xmax = __float_as_int(rr.w), ymin = __float_as_int(ru.w), ymax = __float_as_int(rh.w);
-      if (xmax < wx0 || xmin > wx0 + 31) continue;  // wave-uniform column cull
-      if (__float_as_int(ro.w) == MIR_GEOM_BOX) {
-        const float ax = -rh.x - ro.x, bx = rh.x - ro.x, ay = -rh.y - ro.y, by = rh.y - ro.y, az = -rh.z - ro.z, bz = rh.z - ro.z;
+        for (int k = 0; k < 4; k++) {
+          const int c = s_wcnt[k];
+          off += k < wv ? c : 0;
+          total += c;
+        }
+        if (hit) s_ids[off + __popcll(bal & ((1ull << lane) - 1ull))] = pi;
+        __syncthreads();
+      }
+      for (int k = 0; k < total; k++) {
+        const int id = __builtin_amdgcn_readfirstlane(s_ids[k]);
+        // constant address space => s_load_dwordx4 into SGPRs (the records were written by the previous kernel); a
+        // plain global_load here would also tie the record fetch to the outstanding pixel stores through vmcnt
+        const cf4* rec = (const cf4*)(uintptr_t)(prims + (size_t)id * PREC);
+        const f4 ro = rec[0], rf = rec[1], rr = rec[2], ru = rec[3], rh = rec[4], q5 = rec[5], q6 = rec[6];
+        const int xmin = __float_as_int(rf.w), xmax = __float_as_int(rr.w), ymin = __float_as_int(ru.w), ymax = __float_as_int(rh.w);
+        if (xmax < wx0 || xmin > wx0 + 31 || ymax < ty0 || ymin > tymax) continue;  // wave-uniform column / sub-tile cull
+        if (__float_as_int(ro.w) == MIR_GEOM_BOX) {
+          const float ax = -rh.x - ro.x, bx = rh.x - ro.x, ay = -rh.y - ro.y, by = rh.y - ro.y, az = -rh.z - ro.z, bz = rh.z - ro.z;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int wy = ty0 + 8 * r;  // wave-uniform region cull: rows wy .. wy + 7
-          if (ymax < wy || ymin > wy + 7) continue;
-          const float ex = fmaf(ysr[r], ru.x, rf.x), ey = fmaf(ysr[r], ru.y, rf.y), ez = fmaf(ysr[r], ru.z, rf.z);
+          for (int r = 0; r < 4; r++) {
+            const int wy = ty0 + 8 * r;  // wave-uniform region cull: rows wy .. wy + 7
+            if (ymax < wy || ymin > wy + 7) continue;
+            const float ex = fmaf(ysr[r], ru.x, rf.x), ey = fmaf(ysr[r], ru.y, rf.y), ez = fmaf(ysr[r], ru.z, rf.z);
 #pragma unroll
-          for (int p = 0; p < 4; p++) {
-            const float dxp = fmaf(xs[p], rr.x, ex), dyp = fmaf(xs[p], rr.y, ey), dzp = fmaf(xs[p], rr.z, ez);
-            const float ix = __builtin_amdgcn_rcpf(dxp), iy = __builtin_amdgcn_rcpf(dyp), iz = __builtin_amdgcn_rcpf(dzp);
-            const float x1 = ax * ix, x2 = bx * ix, y1 = ay * iy, y2 = by * iy, z1 = az * iz, z2 = bz * iz;
-            const float nx = fminf(x1, x2), ny = fminf(y1, y2), nz = fminf(z1, z2);
-            const float tn = fmaxf(fmaxf(nx, ny), nz);
-            const float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
-            if (tn <= tf && tn > 1e-6f && tn < best[r][p]) {
-              best[r][p] = tn;
-              // the face whose slab entry is the latest; the ray enters through the face opposing its direction
-              const float cx = dxp > 0.0f ? q5.w : q5.x, cy = dyp > 0.0f ? q6.x : q5.y, cz = dzp > 0.0f ? q6.y : q5.z;
-              col[r][p] = __float_as_uint(tn == nx ? cx : (tn == ny ? cy : cz));
+            for (int h = 0; h < 2; h++) {
+              const f2 dxp = xs[h] * rr.x + ex, dyp = xs[h] * rr.y + ey, dzp = xs[h] * rr.z + ez;
+              const f2 ix = rcp2(dxp), iy = rcp2(dyp), iz = rcp2(dzp);
+              const f2 x1 = ix * ax, x2 = ix * bx, y1 = iy * ay, y2 = iy * by, z1 = iz * az, z2 = iz * bz;
+#pragma unroll
+              for (int q = 0; q < 2; q++) {
+                const float nx = fminf(x1[q], x2[q]), ny = fminf(y1[q], y2[q]), nz = fminf(z1[q], z2[q]);
+                const float tn = fmaxf(fmaxf(nx, ny), nz);
+                const float tf = fminf(fminf(fmaxf(x1[q], x2[q]), fmaxf(y1[q], y2[q])), fmaxf(z1[q], z2[q]));
+                const bool upd = tn <= tf && tn > 1e-6f && tn < best[r][h][q];
+                // the face whose slab entry is the latest; the ray enters through the face opposing its direction
+                const float cx = dxp[q] > 0.0f ? q5.w : q5.x, cy = dyp[q] > 0.0f ? q6.x : q5.y, cz = dzp[q] > 0.0f ? q6.y : q5.z;
+                const unsigned c = __float_as_uint(tn == nx ? cx : (tn == ny ? cy : cz));
+                best[r][h][q] = upd ? tn : best[r][h][q];
+                col[r][2 * h + q] = upd ? c : col[r][2 * h + q];
+              }
             }
           }
-        }
-      } else {
+        } else {
+          const unsigned ceven = __float_as_uint(q5.w), codd = __float_as_uint(q6.w);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float ez = fmaf(ysr[r], ru.z, rf.z), eu = fmaf(ysr[r], q5.z, q5.x), ev = fmaf(ysr[r], q6.z, q6.x);
+          for (int r = 0; r < 4; r++) {
+            const float ez = fmaf(ysr[r], ru.z, rf.z), eu = fmaf(ysr[r], q5.z, q5.x), ev = fmaf(ysr[r], q6.z, q6.x);
 #pragma unroll
-          for (int p = 0; p < 4; p++) {
-            const float iz = __builtin_amdgcn_rcpf(fmaf(xs[p], rr.z, ez));
-            const float t = -ro.z * iz;
-            const float fu = __builtin_amdgcn_fractf(fmaf(xs[p], q5.y, eu) * iz), fv = __builtin_amdgcn_fractf(fmaf(xs[p], q6.y, ev) * iz);
-            if (t > 1e-6f && t < best[r][p]) {
-              best[r][p] = t;
-              col[r][p] = __float_as_uint((fu >= 0.5f) != (fv >= 0.5f) ? q6.w : q5.w);
+            for (int h = 0; h < 2; h++) {
+              const f2 iz = rcp2(xs[h] * rr.z + ez);
+              const f2 t = iz * (-ro.z);
+              const f2 u = (xs[h] * q5.y + eu) * iz, v = (xs[h] * q6.y + ev) * iz;
+#pragma unroll
+              for (int q = 0; q < 2; q++) {
+                const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
+                const bool upd = t[q] > 1e-6f && t[q] < best[r][h][q];
+                best[r][h][q] = upd ? t[q] : best[r][h][q];
+                col[r][2 * h + q] = upd ? (odd ? codd : ceven) : col[r][2 * h + q];
+              }
             }
           }
         }
       }
     }
-  }
-
-  // ---- packed RGB8 store: 4 pixels = 3 dwords per lane ---------------------------------------------
-  const bool fast = (a.W & 3) == 0;
+    // ---- packed RGB8 store: 4 pixels = 3 dwords per lane and region; not waited for.  The address is a uniform
+    // 64-bit image base plus a 32-bit per-lane byte offset (saddr + voffset form, no 64-bit multiplies per store)
+    uint8_t* __restrict__ ibase = a.pixels + (size_t)img * a.H * a.W * 3;
+    unsigned boff = ((unsigned)prow * (unsigned)a.W + (unsigned)px) * 3u;
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int y = prow + 8 * r;
-    if (y >= a.H || px >= a.W) continue;
-    uint8_t* dst = a.pixels + (((size_t)img * a.H + y) * a.W + px) * 3;
-    const unsigned c0 = col[r][0], c1 = col[r][1], c2 = col[r][2], c3 = col[r][3];
-    if (fast) {
-      u3 v;
-      v.x = c0 | c1 << 24;
-      v.y = c1 >> 8 | c2 << 16;
-      v.z = c2 >> 16 | c3 << 8;
-      __builtin_nontemporal_store(v, reinterpret_cast<u3*>(dst));
-    } else {
-      const unsigned cc[4] = {c0, c1, c2, c3};
+    for (int r = 0; r < 4; r++, boff += 24u * (unsigned)a.W) {
+      const int y = prow + 8 * r;
+      if (y > symax || px >= a.W) continue;
+      uint8_t* dst = ibase + boff;
+      const unsigned c0 = col[r][0], c1 = col[r][1], c2 = col[r][2], c3 = col[r][3];
+      if (fast) {
+        u3 v;
+        v.x = c0 | c1 << 24;
+        v.y = c1 >> 8 | c2 << 16;
+        v.z = c2 >> 16 | c3 << 8;
+#if MIR_RENDER_NT
+        __builtin_nontemporal_store(v, reinterpret_cast<u3*>(dst));
+#else
+        *reinterpret_cast<u3*>(dst) = v;
+#endif
+      } else {
+        const unsigned cc[4] = {c0, c1, c2, c3};
 #pragma unroll
-      for (int p = 0; p < 4; p++)
-        if (px + p < a.W) { dst[3 * p] = (uint8_t)cc[p]; dst[3 * p + 1] = (uint8_t)(cc[p] >> 8); dst[3 * p + 2] = (uint8_t)(cc[p] >> 16); }
+        for (int p = 0; p < 4; p++)
+          if (px + p < a.W) { dst[3 * p] = (uint8_t)cc[p]; dst[3 * p + 1] = (uint8_t)(cc[p] >> 8); dst[3 * p + 2] = (uint8_t)(cc[p] >> 16); }
+      }
     }
   }
 }
@@ -347,8 +389,10 @@ extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisual
       auto u8 = [](double c) { return (unsigned)(std::fmin(std::fmax(c, 0.0), 1.0) * 255.0 + 0.5); };
       pa.sky = u8(vis->sky_rgb[0]) | u8(vis->sky_rgb[1]) << 8 | u8(vis->sky_rgb[2]) << 16;
     }
+    pa.th = TH;
+    { const char* d = getenv("MIR_RENDER_TH"); if (d && atoi(d) >= 8) pa.th = (atoi(d) + 31) / 32 * 32; }
     const int nimg = mode == MIR_RENDER_GLOBAL ? 1 : B;
-    hipLaunchKernelGGL(mir_render_kernel, dim3((cam->width + TW - 1) / TW, (cam->height + TH - 1) / TH, nimg), dim3(256), 0, st, pa);
+    hipLaunchKernelGGL(mir_render_kernel, dim3((cam->width + TW - 1) / TW, (cam->height + pa.th - 1) / pa.th, nimg), dim3(256), 0, st, pa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) rc = mir_set_error(MIR_E_HIP, hipGetErrorString(e));
   } while (0);

@@ -1,5 +1,6 @@
-import sys, time, torch, numpy as np
-sys.path.insert(0, "gym-genesis_amd"); sys.path.insert(0, "oracle")
+import os, sys, time, torch, numpy as np
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "gym-genesis_amd"))
 from gym_genesis.backend import models
 from gym_genesis.backend.lib import MirScene
 from gym_genesis.backend.spec import make_camera
