@@ -14,8 +14,9 @@ with N > 1 the packed observation/reward rows are all-gathered over RCCL in roll
 next chunk's physics.
 
 One JSON line on rank 0: value = total env-steps / wall time (max over ranks) of exactly K steps.
-Extra objects: "roofline" (HBM; algorithmic 489 B per env-step) and
-"cpu_baseline" (the float32 CPU port of the oracle, OpenMP over all host cores; rank 0, N=1 only).
+Extra objects: "roofline" (HBM; algorithmic 489 B per env-step), "cpu_baseline" (the float32 CPU port
+of the oracle, OpenMP over all host cores; rank 0, N=1 only) and "pixels" (secondary: BASELINE configs[4], the tiled
+rasteriser at 1024 x 480 x 640, HBM-write roofline; rank 0, N=1 only).
 """
 from __future__ import annotations
 
@@ -75,6 +76,50 @@ def cpu_baseline(budget_s: float = 12.0):
             "sample": f"{steps} steps x {B} envs, same random-action workload, float32 C port of the oracle, OpenMP over envs"}
 
 
+def pixels_bench(dev, renders: int = 30):
+    """BASELINE.json configs[4]: CubePick-v0, 1024 envs, enable_pixels=True, per-env 480x640 RGB8 images rendered by
+    the tiled HIP rasteriser (mir_render) from the state resident in HBM; one step + one render per iteration is NOT
+    what is timed here -- only the render launches (setup + pixel kernels), with HIP events on the launching stream.
+    Algorithmic bytes = B*H*W*3 written once (cfg 5: 943 MB/step, HBM-write-bound)."""
+    from gym_genesis.env import GenesisEnv
+
+    B, H, W = 1024, 480, 640
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, observation_height=H, observation_width=W,
+                     camera_capture_mode="per_env")
+    task = env._env
+    env.reset(seed=0)
+    gen = torch.Generator(device=dev).manual_seed(99)
+    for _ in range(20):  # move the arms apart so the images differ
+        task.step_raw(torch.empty((B, 9), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen))
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        task.cam.render_envs(out=out)
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(renders):
+        task.cam.render_envs(out=out)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us = ev0.elapsed_time(ev1) * 1e3 / renders
+    nbytes = float(B * H * W * 3)
+    achieved = nbytes / (us * 1e-6) / 1e9
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1", "render_pmc.json")) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    del out, env
+    torch.cuda.empty_cache()
+    return {"workload": "CubePick-v0 robot=franka enable_pixels=True per_env 480x640 RGB8, num_envs=1024 (BASELINE configs[4])",
+            "env_frames_per_s": B / (us * 1e-6), "us_per_render": us, "dtype": "u8 out / f32 rays",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "mir_render_kernel",
+                         "note": "algorithmic bytes = 1024x480x640x3 written once per render; time = whole mir_render call "
+                                 "(FK refresh + primitive setup + pixel kernel), HIP events"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +130,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N>1: all-gather the packed rows of this many consecutive steps in one collective (1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pixels", action="store_true", help="skip the secondary pixels (configs[4]) measurement")
     ap.add_argument("--force-gather", action="store_true", help="exercise the RCCL gather path even with one rank (plumbing check)")
     args = ap.parse_args()
 
@@ -243,6 +289,8 @@ def main():
             "env_step_api_rate": api_rate,
             "device_autoreset_loop_rate": loop_rate,
         }
+        if world == 1 and not args.no_pixels:
+            out["pixels"] = pixels_bench(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

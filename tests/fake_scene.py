@@ -76,5 +76,13 @@ class OracleScene:
         quat = np.stack([self.o.read(orc.F_XQUAT, e).reshape(-1, 4) for e in range(self.num_envs)])
         return torch.from_numpy(pos.astype(np.float32)), torch.from_numpy(quat.astype(np.float32))
 
+    def render(self, cam, vis, mode=0, env_offset=None, out=None):
+        xpos, xquat = (t.numpy().astype(np.float64) for t in self.get_links())
+        if mode == 1:
+            off = None if env_offset is None else self._np(env_offset).astype(np.float64)
+            return torch.from_numpy(orc.render_image(self.spec, cam, vis, xpos, xquat, offsets=off))
+        return torch.from_numpy(np.stack([orc.render_image(self.spec, cam, vis, xpos[e:e + 1], xquat[e:e + 1])
+                                          for e in range(self.num_envs)]))
+
     def close(self):
         pass

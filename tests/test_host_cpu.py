@@ -23,12 +23,14 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "mirigid.h")).read()
     declared = set(re.findall(r"^(?:int|const char\*)\s+(mir_\w+)\s*\(", hdr, flags=re.M))
     assert {"mir_create", "mir_destroy", "mir_reset", "mir_set_pd_targets", "mir_step", "mir_step_fused", "mir_step_packed",
-            "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links", "mir_last_error", "mir_version"} <= declared
+            "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links", "mir_last_error", "mir_version", "mir_render",
+            "mir_visual_sizeof", "mir_autoreset"} <= declared
     lib = mirlib.load_library()
     for name in declared:
         assert hasattr(lib, name), f"libmirigid.so does not export {name}"
     assert lib.mir_version() == S.MIR_VERSION
     assert lib.mir_spec_sizeof() == C.sizeof(S.MirSceneSpec)
+    assert lib.mir_visual_sizeof() == C.sizeof(S.MirVisualSpec)
 
 
 def test_no_cpu_fallback_create_fails_loudly_without_gpu(franka_spec):
@@ -153,6 +155,35 @@ def test_env_accessors_and_errors(env):
         GenesisEnv(task="cube", robot="franka", num_envs=2)                             # env.py:122-123
     assert ei.value.args[0] == ("franka", "cube", True)
     assert GenesisEnv.metadata == {"render_modes": ["rgb_array"], "render_fps": 50}     # env.py:15
+
+
+def test_pixels_contract_on_the_test_double(monkeypatch):
+    """enable_pixels=True: obs keys, shapes, dtypes and error behaviour of the reference (cube_pick.py:70-84,159-180,
+    env.py:97-98), host logic only (the images come from the oracle ray caster through the test double)."""
+    import fake_scene
+    from gym_genesis.env import GenesisEnv
+    from gym_genesis.tasks.franka import cube_pick
+
+    monkeypatch.setattr(cube_pick, "MirScene", fake_scene.OracleScene)
+    B, H, W = 2, 24, 32
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, observation_height=H, observation_width=W,
+                     camera_capture_mode="per_env")
+    obs, _ = env.reset(seed=0)
+    assert set(obs) == {"agent_pos", "pixels"}                                           # strip_environment_state default
+    assert tuple(obs["pixels"].shape) == (B, H, W, 3) and obs["pixels"].dtype == torch.uint8
+    assert env.observation_space["pixels"].shape == (H, W, 3) and env.observation_space["pixels"].dtype == np.uint8
+    frame = env.render()                                                                 # env.py:98: cam.render()[0]
+    assert isinstance(frame, np.ndarray) and frame.shape == (H, W, 3) and frame.dtype == np.uint8
+    assert env.get_cams() is env._env.cam                                                # cube_pick.py:69-72
+    env2 = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, observation_height=H, observation_width=W,
+                      camera_capture_mode="global", strip_environment_state=False)
+    obs2, _ = env2.reset(seed=0)
+    assert set(obs2) == {"agent_pos", "environment_state", "pixels"} and tuple(obs2["pixels"].shape) == (H, W, 3)
+    with pytest.raises(ValueError):
+        GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, camera_capture_mode="bogus")  # cube_pick.py:177-178
+    # the camera sits at (3.5, 0, 2.5) looking at (0, 0, 0.5) with fov 30 (cube_pick.py:57-62)
+    cam = env._env.cam
+    assert cam.pos == (3.5, 0.0, 2.5) and cam.lookat == (0.0, 0.0, 0.5) and cam.fov == 30.0 and cam.res == (W, H)
 
 
 def test_seeded_reset_is_deterministic(env):

@@ -20,15 +20,21 @@ for d in ("prof_render_write", "prof_render_fetch", "prof_render_sq", "prof_rend
     for f in glob.glob(os.path.join("gpurun_out", d, "**", "*counter_collection.csv"), recursive=True):
         acc = {}
         for r in csv.DictReader(open(f)):
-            if "mir_render_kernel" not in r.get("Kernel_Name", ""):
+            kn = r.get("Kernel_Name", "")
+            if "mir_render_kernel" not in kn and "fill" not in kn.lower():
                 continue
-            grid = r.get("Grid_Size", "")
+            grid = ("render " if "mir_render_kernel" in kn else "fill ") + r.get("Grid_Size", "")
             key = (r["Counter_Name"], grid)
             acc.setdefault(key, {}).setdefault(int(r.get("Dispatch_Id", 0)), 0.0)
             acc[key][int(r.get("Dispatch_Id", 0))] += float(r["Counter_Value"])
         for (name, grid), v in acc.items():
             vals = sorted(v.values())
             out.setdefault(f"grid={grid}", {})[name] = {"launches": len(vals), "median": vals[len(vals) // 2]}
+# HBM bytes per full-resolution render launch (largest render grid): KB as rocprofv3 reports them, FETCH_SIZE uncorrected
+big = max((k for k in out if k.startswith("grid=render")), key=lambda k: int(k.split()[-1]), default=None)
+if big and "WRITE_SIZE" in out[big] and "FETCH_SIZE" in out[big]:
+    out["hbm_bytes_per_launch"] = 1024.0 * (out[big]["WRITE_SIZE"]["median"] + out[big]["FETCH_SIZE"]["median"])
+    out["algorithmic_bytes_per_launch"] = 1024 * 480 * 640 * 3
 print(json.dumps(out, indent=1))
 PY
 rm -rf gpurun_out/prof_render_write gpurun_out/prof_render_fetch gpurun_out/prof_render_sq gpurun_out/prof_render_sq2

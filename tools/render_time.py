@@ -24,3 +24,12 @@ for (W, H) in ((640, 480), (128, 96)):
     ms = ev0.elapsed_time(ev1) / n
     gb = B * H * W * 3 / 1e9
     print(f"B={B} {W}x{H}: {ms*1e3:.1f} us/render  {gb/ms*1e3:.0f} GB/s written  {B/ms*1e3:.0f} env-frames/s")
+    # calibration: a plain device fill of the same buffer (what the write path sustains; WRITE_SIZE per known byte count)
+    flat = out.view(-1).view(torch.int32)
+    for _ in range(3): flat.fill_(7)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(n): flat.fill_(7)
+    ev1.record(); torch.cuda.synchronize()
+    msf = ev0.elapsed_time(ev1) / n
+    print(f"    torch fill_ of the same {gb*1e3:.0f} MB: {msf*1e3:.1f} us  {gb/msf*1e3:.0f} GB/s")
