@@ -11,6 +11,7 @@
 #include "mir_model.h"
 #include "mir_scene.h"
 #include "mir_step.h"
+#include "mir_step64.h"
 
 namespace {
 
@@ -44,43 +45,53 @@ struct DeviceGuard {
 constexpr int TPB = 256;
 inline int nblk(long n) { return (int)((n + TPB - 1) / TPB); }
 
-// ---- plumbing kernels (one thread per (env, column); rows are contiguous -> coalesced) -----------
+// ---- plumbing kernels: 64 threads per env, thread c = compact dof / qpos column c.  Both step kernels are
+// served through the PlumbTab maps (16-lane kernel: lane == dof, rows of 16; wave kernel: lane map, rows of 64).
+constexpr int PW = 64;
 __global__ void k_fill_rows(float* dst, const float* row, int stride, int B) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (long)B * stride) dst[i] = row[i % stride];
 }
 
-__global__ void k_reset(const DevModel* __restrict__ m, float* qpos, float* qvel, float* target, float* ws,
-                        const float* obj_pos, const float* obj_quat, const float* arm_qpos, const uint8_t* mask, int32_t* fkvalid, int B) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  int e = (int)(i / MIR_G), c = (int)(i % MIR_G);
-  if (e >= B) return;
-  if (mask && !mask[e]) return;
-  const int qst = m->qstride;
-  qvel[(long)e * MIR_G + c] = 0.0f;
-  ws[(long)e * MIR_G + c] = 0.0f;
+__device__ __forceinline__ void reset_env(const PlumbTab* __restrict__ t, int e, int c, float* qpos, float* qvel, float* target, float* ws,
+                                          const float* free_pos, const float* free_quat, const float* arm_qpos, int32_t* fkvalid) {
+  const int qst = t->qst, vst = t->vst;
+  if (c < vst) {
+    qvel[(long)e * vst + c] = 0.0f;
+    ws[(long)e * vst + c] = 0.0f;
+  }
   if (c == 0) fkvalid[e] = 0;  // cached link poses no longer match qpos
-  if (c < m->nv) {
-    int ai = m->d_armidx[c];
+  if (c < t->nv) {
+    int ai = t->d_armidx[c];
     if (ai >= 0 && arm_qpos) {
-      float v = arm_qpos[(long)e * m->n_arm_q + ai];
-      qpos[(long)e * qst + m->d_qadr[c]] = v;
-      target[(long)e * MIR_G + c] = v;
+      float v = arm_qpos[(long)e * t->narm + ai];
+      qpos[(long)e * qst + t->d_qadr[c]] = v;
+      target[(long)e * vst + t->d_lane[c]] = v;
     }
   }
-  if (m->obj_qadr >= 0) {
-    if (c < 3 && obj_pos) qpos[(long)e * qst + m->obj_qadr + c] = obj_pos[(long)e * 3 + c];
-    if (c >= 3 && c < 7 && obj_quat) qpos[(long)e * qst + m->obj_qadr + c] = obj_quat[(long)e * 4 + (c - 3)];
+  if (c < 7 * t->nfree) {
+    const int k = c / 7, j = c - 7 * k;
+    if (j < 3 && free_pos) qpos[(long)e * qst + t->free_qadr[k] + j] = free_pos[((long)e * t->nfree + k) * 3 + j];
+    if (j >= 3 && free_quat) qpos[(long)e * qst + t->free_qadr[k] + j] = free_quat[((long)e * t->nfree + k) * 4 + (j - 3)];
   }
 }
 
+__global__ void k_reset(const PlumbTab* __restrict__ t, float* qpos, float* qvel, float* target, float* ws, const float* obj_pos,
+                        const float* obj_quat, const float* arm_qpos, const uint8_t* mask, int32_t* fkvalid, int B) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int e = (int)(i / PW), c = (int)(i % PW);
+  if (e >= B) return;
+  if (mask && !mask[e]) return;
+  reset_env(t, e, c, qpos, qvel, target, ws, obj_pos, obj_quat, arm_qpos, fkvalid);
+}
+
 // Episode bookkeeping + re-spawn of finished envs, all on the device (no host round trip).
-// 16 consecutive threads serve one env (same wave): every thread reads the env's counters before lane c==0 rewrites them.
-__global__ void k_autoreset(const DevModel* __restrict__ m, float* qpos, float* qvel, float* target, float* ws, const uint8_t* terminated,
+// The 64 consecutive threads of an env are one wave: every thread reads the env's counters before lane c==0 rewrites them.
+__global__ void k_autoreset(const PlumbTab* __restrict__ t, float* qpos, float* qvel, float* target, float* ws, const uint8_t* terminated,
                             int32_t* episode_len, int max_len, const float* spawn_pool, int pool_len, int32_t* cursor,
                             const float* obj_quat, const float* arm_qpos, uint8_t* truncated_out, uint8_t* done_out, int32_t* fkvalid, int B) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  int e = (int)(i / MIR_G), c = (int)(i % MIR_G);
+  int e = (int)(i / PW), c = (int)(i % PW);
   if (e >= B) return;
   const int len = episode_len[e] + 1;
   const bool term = terminated && terminated[e];
@@ -95,58 +106,45 @@ __global__ void k_autoreset(const DevModel* __restrict__ m, float* qpos, float* 
     if (done_out) done_out[e] = done;
   }
   if (!done) return;
-  const int qst = m->qstride;
-  qvel[(long)e * MIR_G + c] = 0.0f;
-  ws[(long)e * MIR_G + c] = 0.0f;
-  if (c == 0) fkvalid[e] = 0;
-  if (c < m->nv) {
-    int ai = m->d_armidx[c];
-    if (ai >= 0) {
-      float v = arm_qpos[(long)e * m->n_arm_q + ai];
-      qpos[(long)e * qst + m->d_qadr[c]] = v;
-      target[(long)e * MIR_G + c] = v;
-    }
-  }
-  if (m->obj_qadr >= 0) {
-    const float* sp = spawn_pool + ((long)(cur % pool_len) * B + e) * 3;
-    if (c < 3) qpos[(long)e * qst + m->obj_qadr + c] = sp[c];
-    if (c >= 3 && c < 7) qpos[(long)e * qst + m->obj_qadr + c] = obj_quat[(long)e * 4 + (c - 3)];
-  }
+  // spawn_pool is (pool_len, B, nfree, 3): the draw of this env is a contiguous (nfree, 3) slab at row offset e within its draw
+  const float* sp = spawn_pool + (long)(cur % pool_len) * B * t->nfree * 3;
+  reset_env(t, e, c, qpos, qvel, target, ws, sp, obj_quat, arm_qpos, fkvalid);
 }
 
-__global__ void k_set_targets(const DevModel* __restrict__ m, float* target, const float* tgt, int B) {
+__global__ void k_set_targets(const PlumbTab* __restrict__ t, float* target, const float* tgt, int B) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  int e = (int)(i / MIR_G), c = (int)(i % MIR_G);
-  if (e >= B || c >= m->nv) return;
-  int u = m->d_uadr[c];
-  if (u >= 0) target[(long)e * MIR_G + c] = tgt[(long)e * m->nu + u];
+  int e = (int)(i / PW), c = (int)(i % PW);
+  if (e >= B || c >= t->nv) return;
+  int u = t->d_uadr[c];
+  if (u >= 0) target[(long)e * t->vst + t->d_lane[c]] = tgt[(long)e * t->nu + u];
 }
 
 // dir 0: internal -> external (get); 1: external -> internal (set)
-__global__ void k_copy_state(const DevModel* __restrict__ m, float* iq, float* iv, float* it, float* iw, float* eq, float* ev,
+__global__ void k_copy_state(const PlumbTab* __restrict__ t, float* iq, float* iv, float* it, float* iw, float* eq, float* ev,
                              float* et, float* ew, int32_t* fkvalid, int B, int dir) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  int e = (int)(i / 32), c = (int)(i % 32);
+  int e = (int)(i / PW), c = (int)(i % PW);
   if (e >= B) return;
-  const int qst = m->qstride, nq = m->nq, nv = m->nv, nu = m->nu;
+  const int qst = t->qst, vst = t->vst, nq = t->nq, nv = t->nv, nu = t->nu;
   if (dir && eq && c == 0) fkvalid[e] = 0;
   if (eq && c < nq) {
     if (dir) iq[(long)e * qst + c] = eq[(long)e * nq + c];
     else eq[(long)e * nq + c] = iq[(long)e * qst + c];
   }
   if (c < nv) {
+    const int l = t->d_lane[c];
     if (ev) {
-      if (dir) iv[(long)e * MIR_G + c] = ev[(long)e * nv + c];
-      else ev[(long)e * nv + c] = iv[(long)e * MIR_G + c];
+      if (dir) iv[(long)e * vst + l] = ev[(long)e * nv + c];
+      else ev[(long)e * nv + c] = iv[(long)e * vst + l];
     }
     if (ew) {
-      if (dir) iw[(long)e * MIR_G + c] = ew[(long)e * nv + c];
-      else ew[(long)e * nv + c] = iw[(long)e * MIR_G + c];
+      if (dir) iw[(long)e * vst + l] = ew[(long)e * nv + c];
+      else ew[(long)e * nv + c] = iw[(long)e * vst + l];
     }
-    int u = m->d_uadr[c];
+    int u = t->d_uadr[c];
     if (et && u >= 0) {
-      if (dir) it[(long)e * MIR_G + c] = et[(long)e * nu + u];
-      else et[(long)e * nu + u] = it[(long)e * MIR_G + c];
+      if (dir) it[(long)e * vst + l] = et[(long)e * nu + u];
+      else et[(long)e * nu + u] = it[(long)e * vst + l];
     }
   }
 }
@@ -159,21 +157,46 @@ __global__ void k_get_diag(const int32_t* diag, int32_t* ncon, int32_t* nefc, in
   if (niter) niter[e] = diag[(long)e * 4 + 2];
 }
 
-StepArgs base_args(MirScene* h) {
-  StepArgs a;
-  memset(&a, 0, sizeof a);
-  a.model = h->dm;
-  a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
-  a.poses = h->poses; a.fkvalid = h->fkvalid;
-  a.diag = h->diag;
-  a.B = h->B;
-  a.n_steps = 1;
-  return a;
-}
+// launch arguments common to both kernels
+struct Outs {
+  const float* action = nullptr;
+  float *agent_pos = nullptr, *env_state = nullptr, *reward = nullptr;
+  uint8_t* terminated = nullptr;
+  float *out_M = nullptr, *out_bias = nullptr, *out_qas = nullptr, *out_qacc = nullptr, *out_xpos = nullptr, *out_xquat = nullptr;
+  float* rows = nullptr;
+  int row_stride = 0, mode = 0, n_steps = 1;
+  bool diag = true;
+  unsigned long long* prof = nullptr;  // 16-lane kernel only (debug)
+};
 
-int launch(MirScene* h, const StepArgs& a, void* stream) {
-  int rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
-  if (rc != 0) return hip_fail((hipError_t)rc, "mir_step_kernel launch");
+int launch(MirScene* h, const Outs& o, void* stream) {
+  int rc;
+  if (h->kernel == 16) {
+    StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.model = h->dm;
+    a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
+    a.poses = h->poses; a.fkvalid = h->fkvalid;
+    a.diag = o.diag ? h->diag : nullptr;
+    a.B = h->B;
+    a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
+    a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
+    a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
+    rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
+  } else {
+    StepArgs64 a;
+    memset(&a, 0, sizeof a);
+    a.model = h->dm64;
+    a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
+    a.poses = h->poses; a.fkvalid = h->fkvalid;
+    a.diag = o.diag ? h->diag : nullptr;
+    a.B = h->B;
+    a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
+    a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
+    a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps;
+    rc = mir_launch_step64(&a, (hipStream_t)stream);
+  }
+  if (rc != 0) return hip_fail((hipError_t)rc, "step kernel launch");
   return MIR_OK;
 }
 
@@ -187,9 +210,9 @@ int check(MirHandle h) {
 int mir_set_error(int code, const char* msg) { return set_err(code, "%s", msg); }
 
 int mir_refresh_poses(MirScene* h, void* stream) {
-  StepArgs a = base_args(h);
-  a.mode = 2; a.diag = nullptr;
-  return launch(h, a, stream);
+  Outs o;
+  o.mode = 2; o.diag = false;
+  return launch(h, o, stream);
 }
 
 extern "C" {
@@ -206,10 +229,68 @@ int mir_create(const MirSceneSpec* spec, int32_t num_envs, int32_t device_id, Mi
   if (!h) return set_err(MIR_E_INVALID, "out of host memory");
   memset(h, 0, sizeof *h);
   char err[256] = "";
+  // the 16-lanes-per-env kernel when the scene fits it, else the wave-per-env kernel
   int rc = mir_compile_model(spec, &h->hm, &h->hc, err);
+  h->kernel = 16;
+  if (rc == MIR_E_CAPACITY) {
+    rc = mir_compile_model64(spec, &h->hm64, &h->hc, err);
+    h->kernel = 64;
+  }
   if (rc != MIR_OK) {
     delete h;
     return set_err(rc, "mir_create: %s", err);
+  }
+  // storage maps + geometry table shared by the plumbing kernels and the rasteriser
+  PlumbTab& t = h->pt;
+  GeomTab gt;
+  memset(&gt, 0, sizeof gt);
+  float row[K64_QSTRIDE] = {0};  // qpos0: free bodies at their spec pose, scalar joints at 0
+  if (h->kernel == 16) {
+    const DevModel& m = h->hm;
+    h->nbody = m.nbody; h->nv = m.nv; h->nq = m.nq; h->nu = m.nu; h->ngeom = m.ngeom; h->npair = m.npair;
+    h->agent_dim = 7 + m.n_grip; h->env_dim = 11;
+    t.nv = m.nv; t.nq = m.nq; t.nu = m.nu; t.nfree = m.nfree; t.narm = m.n_arm_q; t.qst = m.qstride; t.vst = MIR_G; t.pst = MIR_G;
+    for (int i = 0; i < m.nv; i++) { t.d_lane[i] = i; t.d_uadr[i] = m.d_uadr[i]; t.d_armidx[i] = m.d_armidx[i]; t.d_qadr[i] = m.d_qadr[i]; }
+    for (int k = 0; k < m.nfree; k++) t.free_qadr[k] = m.free_qadr[k];
+    gt.ngeom = m.ngeom;
+    for (int g = 0; g < m.ngeom; g++) {
+      gt.g_body[g] = m.g_body[g]; gt.g_type[g] = m.g_type[g];
+      for (int k = 0; k < 3; k++) { gt.g_size[g][k] = m.g_size[g][k]; gt.g_pos[g][k] = m.g_pos[g][k]; }
+      for (int k = 0; k < 4; k++) gt.g_quat[g][k] = m.g_quat[g][k];
+    }
+    for (int b = 1; b < m.nbody; b++)
+      if (m.b_jtype[b] == MIR_JNT_FREE) {
+        for (int k = 0; k < 3; k++) row[m.b_qadr[b] + k] = m.b_pos[b][k];
+        for (int k = 0; k < 4; k++) row[m.b_qadr[b] + 3 + k] = m.b_quat[b][k];
+      }
+  } else {
+    const DevModel64& m = h->hm64;
+    h->nbody = m.nbody; h->nv = m.nv; h->nq = m.nq; h->nu = m.nu; h->ngeom = m.ngeom; h->npair = m.npair;
+    h->agent_dim = m.agent_dim; h->env_dim = m.env_dim;
+    t.nv = m.nv; t.nq = m.nq; t.nu = m.nu; t.nfree = m.nfree; t.narm = m.n_arm_q; t.qst = K64_QSTRIDE; t.vst = W64; t.pst = K64_MAX_BODY;
+    int narm = 0, nfree = 0;
+    for (int l = 0; l < W64; l++) {
+      const int i = m.d_dof[l];
+      if (i < 0) continue;
+      t.d_lane[i] = l; t.d_uadr[i] = m.d_uadr[l]; t.d_qadr[i] = m.d_qadr[l]; t.d_armidx[i] = -1;
+    }
+    for (int b = 1; b < m.nbody; b++) {  // arm_qpos / free-body order = body order
+      if (m.b_jtype[b] == MIR_JNT_FREE) {
+        t.free_qadr[nfree++] = m.b_qadr[b];
+        for (int k = 0; k < 3; k++) row[m.b_qadr[b] + k] = m.b_pos[b][k];
+        for (int k = 0; k < 4; k++) row[m.b_qadr[b] + 3 + k] = m.b_quat[b][k];
+      } else if (m.b_jtype[b] != MIR_JNT_FIXED) {
+        for (int i = 0; i < m.nv; i++)
+          if (t.d_qadr[i] == m.b_qadr[b]) t.d_armidx[i] = narm;
+        narm++;
+      }
+    }
+    gt.ngeom = m.ngeom;
+    for (int g = 0; g < m.ngeom; g++) {
+      gt.g_body[g] = m.g_body[g]; gt.g_type[g] = m.g_type[g];
+      for (int k = 0; k < 3; k++) { gt.g_size[g][k] = m.g_size[g][k]; gt.g_pos[g][k] = m.g_pos[g][k]; }
+      for (int k = 0; k < 4; k++) gt.g_quat[g][k] = m.g_quat[g][k];
+    }
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) {
@@ -220,32 +301,30 @@ int mir_create(const MirSceneSpec* spec, int32_t num_envs, int32_t device_id, Mi
   h->B = num_envs;
   DeviceGuard guard(device_id);
   const size_t B = (size_t)num_envs;
-  const int qst = h->hm.qstride;
+  const size_t qst = t.qst, vst = t.vst, pst = t.pst;
   hipError_t e;
-  if ((e = hipMalloc((void**)&h->dm, sizeof(DevModel))) != hipSuccess || (e = hipMalloc((void**)&h->qpos, B * qst * sizeof(float))) != hipSuccess ||
-      (e = hipMalloc((void**)&h->qvel, B * MIR_G * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->target, B * MIR_G * sizeof(float))) != hipSuccess ||
-      (e = hipMalloc((void**)&h->qacc_ws, B * MIR_G * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->diag, B * 4 * sizeof(int32_t))) != hipSuccess ||
-      (e = hipMalloc((void**)&h->poses, B * 2 * MIR_G * 4 * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->fkvalid, B * sizeof(int32_t))) != hipSuccess) {
+  if ((e = hipMalloc((void**)&h->dm, sizeof(DevModel))) != hipSuccess || (e = hipMalloc((void**)&h->dm64, sizeof(DevModel64))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->dpt, sizeof(PlumbTab))) != hipSuccess || (e = hipMalloc((void**)&h->dgeom, sizeof(GeomTab))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->qpos, B * qst * sizeof(float))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->qvel, B * vst * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->target, B * vst * sizeof(float))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->qacc_ws, B * vst * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->diag, B * 4 * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->poses, B * 2 * pst * 4 * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->fkvalid, B * sizeof(int32_t))) != hipSuccess) {
     mir_destroy(h);
     return hip_fail(e, "hipMalloc");
   }
   HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(DevModel), hipMemcpyHostToDevice));
-  // initial state: qpos0 (free bodies at their spec pose, scalar joints at 0), everything else 0
-  float row[32] = {0};
-  for (int b = 1; b < h->hm.nbody; b++)
-    if (h->hm.b_jtype[b] == MIR_JNT_FREE) {
-      for (int k = 0; k < 3; k++) row[h->hm.b_qadr[b] + k] = h->hm.b_pos[b][k];
-      for (int k = 0; k < 4; k++) row[h->hm.b_qadr[b] + 3 + k] = h->hm.b_quat[b][k];
-    }
+  HIPCHK(hipMemcpy(h->dm64, &h->hm64, sizeof(DevModel64), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->dpt, &h->pt, sizeof(PlumbTab), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->dgeom, &gt, sizeof(GeomTab), hipMemcpyHostToDevice));
   float* drow = nullptr;
   HIPCHK(hipMalloc((void**)&drow, sizeof row));
   HIPCHK(hipMemcpy(drow, row, sizeof row, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_fill_rows, dim3(nblk((long)B * qst)), dim3(TPB), 0, 0, h->qpos, drow, qst, num_envs);
-  HIPCHK(hipMemset(h->qvel, 0, B * MIR_G * sizeof(float)));
-  HIPCHK(hipMemset(h->target, 0, B * MIR_G * sizeof(float)));
-  HIPCHK(hipMemset(h->qacc_ws, 0, B * MIR_G * sizeof(float)));
+  hipLaunchKernelGGL(k_fill_rows, dim3(nblk((long)B * qst)), dim3(TPB), 0, 0, h->qpos, drow, (int)qst, num_envs);
+  HIPCHK(hipMemset(h->qvel, 0, B * vst * sizeof(float)));
+  HIPCHK(hipMemset(h->target, 0, B * vst * sizeof(float)));
+  HIPCHK(hipMemset(h->qacc_ws, 0, B * vst * sizeof(float)));
   HIPCHK(hipMemset(h->diag, 0, B * 4 * sizeof(int32_t)));
-  HIPCHK(hipMemset(h->poses, 0, B * 2 * MIR_G * 4 * sizeof(float)));
+  HIPCHK(hipMemset(h->poses, 0, B * 2 * pst * 4 * sizeof(float)));
   HIPCHK(hipMemset(h->fkvalid, 0, B * sizeof(int32_t)));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipFree(drow));
@@ -257,6 +336,9 @@ int mir_destroy(MirHandle h) {
   if (!h) return MIR_OK;
   DeviceGuard guard(h->device);
   if (h->dm) (void)hipFree(h->dm);
+  if (h->dm64) (void)hipFree(h->dm64);
+  if (h->dpt) (void)hipFree(h->dpt);
+  if (h->dgeom) (void)hipFree(h->dgeom);
   if (h->qpos) (void)hipFree(h->qpos);
   if (h->qvel) (void)hipFree(h->qvel);
   if (h->target) (void)hipFree(h->target);
@@ -271,15 +353,16 @@ int mir_destroy(MirHandle h) {
 
 int mir_get_dims(MirHandle h, MirDims* out) {
   if (check(h) || !out) return set_err(MIR_E_INVALID, "mir_get_dims: null argument");
-  out->num_envs = h->B; out->nbody = h->hm.nbody; out->nq = h->hm.nq; out->nv = h->hm.nv;
-  out->ngeom = h->hm.ngeom; out->npair = h->hm.npair; out->agent_dim = 7 + h->hm.n_grip; out->env_dim = 11;
+  out->num_envs = h->B; out->nbody = h->nbody; out->nq = h->nq; out->nv = h->nv;
+  out->ngeom = h->ngeom; out->npair = h->npair; out->agent_dim = h->agent_dim; out->env_dim = h->env_dim;
+  out->nfree = h->pt.nfree; out->kernel = h->kernel;
   return MIR_OK;
 }
 
 int mir_get_model_consts(MirHandle h, double* dof_invweight0, double* body_invweight0, double* meaninertia) {
   if (check(h)) return MIR_E_INVALID;
-  if (dof_invweight0) memcpy(dof_invweight0, h->hc.dof_invweight0, sizeof(double) * h->hm.nv);
-  if (body_invweight0) memcpy(body_invweight0, h->hc.body_invweight0, sizeof(double) * h->hm.nbody);
+  if (dof_invweight0) memcpy(dof_invweight0, h->hc.dof_invweight0, sizeof(double) * h->nv);
+  if (body_invweight0) memcpy(body_invweight0, h->hc.body_invweight0, sizeof(double) * h->nbody);
   if (meaninertia) *meaninertia = h->hc.meaninertia;
   return MIR_OK;
 }
@@ -287,7 +370,7 @@ int mir_get_model_consts(MirHandle h, double* dof_invweight0, double* body_invwe
 int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const float* arm_qpos, const uint8_t* env_mask, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);
-  hipLaunchKernelGGL(k_reset, dim3(nblk((long)h->B * MIR_G)), dim3(TPB), 0, (hipStream_t)stream, h->dm, h->qpos, h->qvel, h->target,
+  hipLaunchKernelGGL(k_reset, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, obj_pos, obj_quat, arm_qpos, env_mask, h->fkvalid, h->B);
   HIPCHK(hipGetLastError());
   return MIR_OK;
@@ -298,7 +381,7 @@ int mir_autoreset(MirHandle h, const uint8_t* terminated, int32_t* episode_len, 
   if (check(h)) return MIR_E_INVALID;
   if (!episode_len || !spawn_pool || !cursor || !obj_quat || !arm_qpos || pool_len <= 0) return set_err(MIR_E_INVALID, "mir_autoreset: null argument");
   DeviceGuard guard(h->device);
-  hipLaunchKernelGGL(k_autoreset, dim3(nblk((long)h->B * MIR_G)), dim3(TPB), 0, (hipStream_t)stream, h->dm, h->qpos, h->qvel, h->target,
+  hipLaunchKernelGGL(k_autoreset, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, terminated, episode_len, max_len, spawn_pool, pool_len, cursor, obj_quat, arm_qpos, truncated_out, done_out,
                      h->fkvalid, h->B);
   HIPCHK(hipGetLastError());
@@ -308,7 +391,7 @@ int mir_autoreset(MirHandle h, const uint8_t* terminated, int32_t* episode_len, 
 int mir_set_pd_targets(MirHandle h, const float* tgt, void* stream) {
   if (check(h) || !tgt) return set_err(MIR_E_INVALID, "mir_set_pd_targets: null argument");
   DeviceGuard guard(h->device);
-  hipLaunchKernelGGL(k_set_targets, dim3(nblk((long)h->B * MIR_G)), dim3(TPB), 0, (hipStream_t)stream, h->dm, h->target, tgt, h->B);
+  hipLaunchKernelGGL(k_set_targets, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->target, tgt, h->B);
   HIPCHK(hipGetLastError());
   return MIR_OK;
 }
@@ -317,50 +400,50 @@ int mir_step(MirHandle h, int32_t n_steps, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   if (n_steps <= 0) return MIR_OK;
   DeviceGuard guard(h->device);
-  StepArgs a = base_args(h);
-  a.n_steps = n_steps;
-  return launch(h, a, stream);
+  Outs o;
+  o.n_steps = n_steps;
+  return launch(h, o, stream);
 }
 
 int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);
-  StepArgs a = base_args(h);
-  a.action = action; a.agent_pos = agent_pos; a.env_state = env_state; a.reward = reward; a.terminated = terminated;
-  return launch(h, a, stream);
+  Outs o;
+  o.action = action; o.agent_pos = agent_pos; o.env_state = env_state; o.reward = reward; o.terminated = terminated;
+  return launch(h, o, stream);
 }
 
 int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream) {
   if (check(h) || !rows) return set_err(MIR_E_INVALID, "mir_step_packed: null argument");
-  if (row_stride < 7 + h->hm.n_grip + 13) return set_err(MIR_E_INVALID, "mir_step_packed: row_stride too small");
+  if (row_stride < h->agent_dim + h->env_dim + 2) return set_err(MIR_E_INVALID, "mir_step_packed: row_stride too small");
   DeviceGuard guard(h->device);
-  StepArgs a = base_args(h);
-  a.action = action; a.rows = rows; a.row_stride = row_stride;
-  return launch(h, a, stream);
+  Outs o;
+  o.action = action; o.rows = rows; o.row_stride = row_stride;
+  return launch(h, o, stream);
 }
 
-/* debug aid (not part of the drop-in surface): one step with phase timestamps from block 0 */
+/* debug aid (not part of the drop-in surface): one step of the 16-lane kernel with phase timestamps from block 0 */
 int mir_debug_profile_step(MirHandle h, unsigned long long* prof16, void* stream) {
-  if (check(h) || !prof16) return set_err(MIR_E_INVALID, "mir_debug_profile_step: null argument");
+  if (check(h) || !prof16 || h->kernel != 16) return set_err(MIR_E_INVALID, "mir_debug_profile_step: null argument / not the 16-lane kernel");
   DeviceGuard guard(h->device);
-  StepArgs a = base_args(h);
-  a.prof = prof16;
-  return launch(h, a, stream);
+  Outs o;
+  o.prof = prof16;
+  return launch(h, o, stream);
 }
 
 int mir_get_obs(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);
-  StepArgs a = base_args(h);
-  a.mode = 2; a.diag = nullptr;
-  a.agent_pos = agent_pos; a.env_state = env_state; a.reward = reward; a.terminated = terminated;
-  return launch(h, a, stream);
+  Outs o;
+  o.mode = 2; o.diag = false;
+  o.agent_pos = agent_pos; o.env_state = env_state; o.reward = reward; o.terminated = terminated;
+  return launch(h, o, stream);
 }
 
 int mir_get_state(MirHandle h, float* qpos, float* qvel, float* target, float* warmstart, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);
-  hipLaunchKernelGGL(k_copy_state, dim3(nblk((long)h->B * 32)), dim3(TPB), 0, (hipStream_t)stream, h->dm, h->qpos, h->qvel, h->target,
+  hipLaunchKernelGGL(k_copy_state, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, qpos, qvel, target, warmstart, h->fkvalid, h->B, 0);
   HIPCHK(hipGetLastError());
   return MIR_OK;
@@ -369,7 +452,7 @@ int mir_get_state(MirHandle h, float* qpos, float* qvel, float* target, float* w
 int mir_set_state(MirHandle h, const float* qpos, const float* qvel, const float* target, const float* warmstart, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);
-  hipLaunchKernelGGL(k_copy_state, dim3(nblk((long)h->B * 32)), dim3(TPB), 0, (hipStream_t)stream, h->dm, h->qpos, h->qvel, h->target,
+  hipLaunchKernelGGL(k_copy_state, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, (float*)qpos, (float*)qvel, (float*)target, (float*)warmstart, h->fkvalid, h->B, 1);
   HIPCHK(hipGetLastError());
   return MIR_OK;
@@ -378,10 +461,10 @@ int mir_set_state(MirHandle h, const float* qpos, const float* qvel, const float
 int mir_get_links(MirHandle h, float* pos, float* quat, void* stream) {
   if (check(h) || !pos || !quat) return set_err(MIR_E_INVALID, "mir_get_links: null argument");
   DeviceGuard guard(h->device);
-  StepArgs a = base_args(h);
-  a.mode = 2; a.diag = nullptr;
-  a.out_xpos = pos; a.out_xquat = quat;
-  return launch(h, a, stream);
+  Outs o;
+  o.mode = 2; o.diag = false;
+  o.out_xpos = pos; o.out_xquat = quat;
+  return launch(h, o, stream);
 }
 
 int mir_get_diag(MirHandle h, int32_t* ncon, int32_t* nefc, int32_t* niter, void* stream) {
@@ -395,10 +478,10 @@ int mir_get_diag(MirHandle h, int32_t* ncon, int32_t* nefc, int32_t* niter, void
 int mir_forward(MirHandle h, float* M, float* qfrc_bias, float* qacc_smooth, float* qacc, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);
-  StepArgs a = base_args(h);
-  a.mode = 1;
-  a.out_M = M; a.out_bias = qfrc_bias; a.out_qas = qacc_smooth; a.out_qacc = qacc;
-  return launch(h, a, stream);
+  Outs o;
+  o.mode = 1;
+  o.out_M = M; o.out_bias = qfrc_bias; o.out_qas = qacc_smooth; o.out_qacc = qacc;
+  return launch(h, o, stream);
 }
 
 }  // extern "C"

@@ -63,37 +63,170 @@ int moving_link(const DevModel& m, int b) {
 
 }  // namespace
 
+// Constants of the soft-constraint model at the reference pose qpos0 (free bodies at their spec pose, scalar
+// joints at 0): joint-space inertia from body Jacobians, its inverse, per-dof and per-body inverse weights, mean
+// inertia.  Works on the spec alone (no kernel-specific layout), so both device models share it.
+int mir_host_consts(const MirSceneSpec* sp, HostConsts* out, char* err) {
+  const int nb = sp->nbody;
+  std::vector<int> dofadr(nb, 0), ndof(nb, 0), parent(nb, -1), is_static(nb, 0);
+  int nv = 0;
+  for (int b = 0; b < nb; b++) {
+    int jt = b == 0 ? MIR_JNT_FIXED : sp->body[b].jtype;
+    parent[b] = b == 0 ? -1 : sp->body[b].parent;
+    dofadr[b] = nv;
+    ndof[b] = jt == MIR_JNT_FREE ? 6 : (jt == MIR_JNT_FIXED ? 0 : 1);
+    is_static[b] = b == 0 ? 1 : (ndof[b] == 0 && is_static[parent[b]]);
+    nv += ndof[b];
+  }
+  std::vector<int> dbody(nv), dkind(nv), daxk(nv);
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < ndof[b]; k++) {
+      int i = dofadr[b] + k;
+      dbody[i] = b;
+      if (sp->body[b].jtype == MIR_JNT_FREE) { dkind[i] = k < 3 ? 2 : 3; daxk[i] = k % 3; }
+      else { dkind[i] = sp->body[b].jtype == MIR_JNT_REVOLUTE ? 0 : 1; daxk[i] = 0; }
+    }
+  auto moves = [&](int i, int b) {  // does dof i move body b (is dof i's body an ancestor-or-self of b)?
+    int db = dbody[i];
+    while (b > 0) {
+      if (b == db) return true;
+      b = parent[b];
+    }
+    return false;
+  };
+  std::vector<Q4> xq(nb);
+  std::vector<V3> xp(nb), xc(nb);
+  xq[0] = {1, 0, 0, 0}; xp[0] = {0, 0, 0}; xc[0] = {0, 0, 0};
+  for (int b = 1; b < nb; b++) {
+    const MirBodySpec& s = sp->body[b];
+    int p = s.parent;
+    Q4 ql{s.quat[0], s.quat[1], s.quat[2], s.quat[3]};
+    V3 pl{s.pos[0], s.pos[1], s.pos[2]};
+    if (s.jtype == MIR_JNT_FREE) { xq[b] = ql; xp[b] = pl; }  // qpos0 = spec pose, joint value 0 elsewhere
+    else { xq[b] = qmul(xq[p], ql); xp[b] = xp[p] + qrot(xq[p], pl); }
+    xc[b] = xp[b] + qrot(xq[b], {s.ipos[0], s.ipos[1], s.ipos[2]});
+  }
+  // per-dof world axis / anchor
+  std::vector<V3> ax(nv), an(nv);
+  for (int i = 0; i < nv; i++) {
+    int b = dbody[i];
+    const MirBodySpec& s = sp->body[b];
+    if (dkind[i] < 2) ax[i] = qrot(xq[b], {s.axis[0], s.axis[1], s.axis[2]});
+    else { V3 e{0, 0, 0}; (&e.x)[daxk[i]] = 1; ax[i] = e; }
+    an[i] = xp[b];
+  }
+  auto jac = [&](int b, V3 pt, int i, V3& jv, V3& jw) {  // column i of the Jacobian of point pt on body b
+    jv = {0, 0, 0}; jw = {0, 0, 0};
+    if (!moves(i, b)) return;
+    if (dkind[i] == 0 || dkind[i] == 3) { jw = ax[i]; jv = cross(ax[i], pt - an[i]); }
+    else jv = ax[i];
+  };
+  std::vector<double> M(nv * nv, 0.0);
+  for (int b = 1; b < nb; b++) {
+    const MirBodySpec& s = sp->body[b];
+    M3 R = q2m(xq[b]);
+    double Ib[3][3] = {{s.inertia[0], s.inertia[3], s.inertia[4]}, {s.inertia[3], s.inertia[1], s.inertia[5]}, {s.inertia[4], s.inertia[5], s.inertia[2]}};
+    double Iw[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        double t = 0;
+        for (int k = 0; k < 3; k++)
+          for (int l = 0; l < 3; l++) t += R.m[r][k] * Ib[k][l] * R.m[c][l];
+        Iw[r][c] = t;
+      }
+    for (int i = 0; i < nv; i++) {
+      V3 vi, wi;
+      jac(b, xc[b], i, vi, wi);
+      V3 Iwi{Iw[0][0] * wi.x + Iw[0][1] * wi.y + Iw[0][2] * wi.z, Iw[1][0] * wi.x + Iw[1][1] * wi.y + Iw[1][2] * wi.z,
+             Iw[2][0] * wi.x + Iw[2][1] * wi.y + Iw[2][2] * wi.z};
+      for (int j = 0; j < nv; j++) {
+        V3 vj, wj;
+        jac(b, xc[b], j, vj, wj);
+        M[i * nv + j] += s.mass * dot(vi, vj) + dot(Iwi, wj);
+      }
+    }
+  }
+  for (int i = 0; i < nv; i++) M[i * nv + i] += sp->dof[i].armature;
+  // invert by Gauss-Jordan (SPD, tiny)
+  std::vector<double> A(M), Inv(nv * nv, 0.0);
+  for (int i = 0; i < nv; i++) Inv[i * nv + i] = 1;
+  for (int c = 0; c < nv; c++) {
+    double p = A[c * nv + c];
+    if (!(p > 1e-12)) return fail(err, MIR_E_INVALID, "joint-space inertia at qpos0 is not positive definite");
+    for (int j = 0; j < nv; j++) { A[c * nv + j] /= p; Inv[c * nv + j] /= p; }
+    for (int r = 0; r < nv; r++)
+      if (r != c) {
+        double f = A[r * nv + c];
+        if (f != 0)
+          for (int j = 0; j < nv; j++) { A[r * nv + j] -= f * A[c * nv + j]; Inv[r * nv + j] -= f * Inv[c * nv + j]; }
+      }
+  }
+  double tr = 0;
+  for (int i = 0; i < nv; i++) tr += M[i * nv + i];
+  HostConsts& H = *out;
+  memset(&H, 0, sizeof H);
+  H.meaninertia = nv ? tr / nv : 1.0;
+  for (int b = 1; b < nb; b++) {
+    int da = dofadr[b];
+    if (sp->body[b].jtype == MIR_JNT_FREE) {
+      double t = (Inv[da * nv + da] + Inv[(da + 1) * nv + da + 1] + Inv[(da + 2) * nv + da + 2]) / 3;
+      double r = (Inv[(da + 3) * nv + da + 3] + Inv[(da + 4) * nv + da + 4] + Inv[(da + 5) * nv + da + 5]) / 3;
+      for (int k = 0; k < 3; k++) { H.dof_invweight0[da + k] = t; H.dof_invweight0[da + 3 + k] = r; }
+    } else if (sp->body[b].jtype != MIR_JNT_FIXED)
+      H.dof_invweight0[da] = Inv[da * nv + da];
+    if (is_static[b]) continue;
+    double t = 0;
+    for (int i = 0; i < nv; i++) {
+      V3 vi, wi;
+      jac(b, xc[b], i, vi, wi);
+      for (int j = 0; j < nv; j++) {
+        V3 vj, wj;
+        jac(b, xc[b], j, vj, wj);
+        t += dot(vi, vj) * Inv[i * nv + j];
+      }
+    }
+    H.body_invweight0[b] = fmax(t / 3, 1e-15);
+  }
+  return MIR_OK;
+}
+
+// Float32-round every model constant of a spec in place: the device models are float32, so the scene that is
+// actually simulated is the rounded one and every derived constant must come from the same rounded values.
+void mir_round_spec(MirSceneSpec* rounded) {
+  auto r32 = [](double& v) { v = (double)(float)v; };
+  for (int b = 0; b < rounded->nbody; b++) {
+    MirBodySpec& s = rounded->body[b];
+    for (double& v : s.pos) r32(v);
+    for (double& v : s.quat) r32(v);
+    for (double& v : s.axis) r32(v);
+    for (double& v : s.ipos) r32(v);
+    for (double& v : s.inertia) r32(v);
+    r32(s.mass);
+  }
+  for (int i = 0; i < rounded->ndof; i++) {
+    MirDofSpec& s = rounded->dof[i];
+    r32(s.armature); r32(s.damping); r32(s.kp); r32(s.kv);
+    for (double& v : s.range) r32(v);
+    for (double& v : s.solref) r32(v);
+    for (double& v : s.solimp) r32(v);
+  }
+  r32(rounded->opt.dt);
+  for (double& v : rounded->opt.gravity) r32(v);
+}
+
 int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, char* err) {
   if (!sp || !out) return fail(err, MIR_E_INVALID, "null spec");
   if (sp->struct_size != (int)sizeof(MirSceneSpec) || sp->version != MIR_VERSION)
     return fail(err, MIR_E_INVALID, "MirSceneSpec size/version mismatch (ABI)");
-  if (sp->nbody < 1 || sp->nbody > MIR_MAX_BODY || sp->ndof > MIR_MAX_DOF || sp->ngeom > MIR_MAX_GEOM || sp->ndof < 0 ||
+  if (sp->nbody < 1 || sp->nbody > K16_MAX_BODY || sp->ndof > K16_MAX_DOF || sp->ngeom > K16_MAX_GEOM || sp->ndof < 0 ||
       sp->ngeom < 0)
-    return fail(err, MIR_E_CAPACITY, "scene exceeds MIR_MAX_BODY/DOF/GEOM");
+    return fail(err, MIR_E_CAPACITY, "scene exceeds K16_MAX_BODY/DOF/GEOM");
+  if (sp->task.obj2_body >= 0 || sp->task.reward_mode != MIR_REWARD_LIFT || sp->task.agent_mode != MIR_AGENT_EEF)
+    return fail(err, MIR_E_CAPACITY, "the 16-lane kernel extracts only the pick-task observation layout");
   // The device model is float32, so the scene that is actually simulated is the float32-rounded
   // one: derive every constant (inverse weights, mean inertia) from those same rounded values.
   MirSceneSpec rounded = *sp;
-  {
-    auto r32 = [](double& v) { v = (double)(float)v; };
-    for (int b = 0; b < rounded.nbody; b++) {
-      MirBodySpec& s = rounded.body[b];
-      for (double& v : s.pos) r32(v);
-      for (double& v : s.quat) r32(v);
-      for (double& v : s.axis) r32(v);
-      for (double& v : s.ipos) r32(v);
-      for (double& v : s.inertia) r32(v);
-      r32(s.mass);
-    }
-    for (int i = 0; i < rounded.ndof; i++) {
-      MirDofSpec& s = rounded.dof[i];
-      r32(s.armature); r32(s.damping); r32(s.kp); r32(s.kv);
-      for (double& v : s.range) r32(v);
-      for (double& v : s.solref) r32(v);
-      for (double& v : s.solimp) r32(v);
-    }
-    r32(rounded.opt.dt);
-    for (double& v : rounded.opt.gravity) r32(v);
-  }
+  mir_round_spec(&rounded);
   sp = &rounded;
   DevModel& m = *out;
   memset(&m, 0, sizeof m);
@@ -109,7 +242,7 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
   m.enable_collision = sp->opt.enable_collision;
   m.enable_joint_limit = sp->opt.enable_joint_limit;
   m.max_contacts = sp->opt.max_contacts;
-  if (m.max_contacts > MIR_MAX_CONTACT || m.max_contacts < 0) return fail(err, MIR_E_CAPACITY, "max_contacts > MIR_MAX_CONTACT");
+  if (m.max_contacts > K16_MAX_CONTACT || m.max_contacts < 0) return fail(err, MIR_E_CAPACITY, "max_contacts > K16_MAX_CONTACT");
 
   // ---- topology --------------------------------------------------------------------------
   int nv = 0, nq = 0, narm = 0;
@@ -130,7 +263,7 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     for (int k = 0; k < 6; k++) m.b_inertia[b][k] = (float)s.inertia[k];
     m.b_mass[b] = (float)s.mass;
     uint32_t inherited = (b > 0 && s.parent > 0) ? m.b_dofmask[s.parent] : 0u;
-    if (nv + nd > MIR_MAX_DOF) return fail(err, MIR_E_CAPACITY, "too many dofs");
+    if (nv + nd > K16_MAX_DOF) return fail(err, MIR_E_CAPACITY, "too many dofs");
     for (int k = 0; k < nd; k++) {
       int i = nv + k;
       m.d_body[i] = b;
@@ -149,13 +282,17 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
       m.d_ancmask[i] = inherited | (((1u << (k + 1)) - 1u) << nv);
     }
     m.b_dofmask[b] = inherited | (nd ? (((1u << nd) - 1u) << nv) : 0u);
+    if (jt == MIR_JNT_FREE) {
+      if (m.nfree >= MIR_MAX_FREE) return fail(err, MIR_E_CAPACITY, "more than MIR_MAX_FREE free bodies");
+      m.free_qadr[m.nfree++] = nq;
+    }
     nv += nd;
     nq += jt == MIR_JNT_FREE ? 7 : nd;
   }
   if (nv != sp->ndof) return fail(err, MIR_E_INVALID, "ndof does not match the joints");
-  if (nq > MIR_MAX_Q) return fail(err, MIR_E_CAPACITY, "nq > MIR_MAX_Q");
+  if (nq > K16_MAX_Q) return fail(err, MIR_E_CAPACITY, "nq > K16_MAX_Q");
   m.nv = nv; m.nq = nq; m.n_arm_q = narm;
-  m.qstride = (MIR_MAX_Q + 3) & ~3;
+  m.qstride = (K16_MAX_Q + 3) & ~3;
   for (int b = 0; b < nb; b++) {
     uint32_t sub = 1u << b;
     for (int c = b + 1; c < nb; c++) {
@@ -230,111 +367,22 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
         if ((pa == lb && lb > 0) || (pb == la && la > 0)) continue;
       }
       if (!sp->opt.enable_self_collision && ba > 0 && bb > 0 && m.b_root[ba] == m.b_root[bb]) continue;
-      if (np >= MIR_MAX_PAIR) return fail(err, MIR_E_CAPACITY, "too many candidate collision pairs");
+      if (np >= K16_MAX_PAIR) return fail(err, MIR_E_CAPACITY, "too many candidate collision pairs");
       m.p_g1[np] = a; m.p_g2[np] = b; np++;
     }
   m.npair = np;
 
   // ---- constants at qpos0: M from body Jacobians, inverse weights ----------------------------
-  std::vector<Q4> xq(nb);
-  std::vector<V3> xp(nb), xc(nb);
-  xq[0] = {1, 0, 0, 0}; xp[0] = {0, 0, 0}; xc[0] = {0, 0, 0};
-  for (int b = 1; b < nb; b++) {
-    const MirBodySpec& s = sp->body[b];
-    int p = s.parent;
-    Q4 ql{s.quat[0], s.quat[1], s.quat[2], s.quat[3]};
-    V3 pl{s.pos[0], s.pos[1], s.pos[2]};
-    if (s.jtype == MIR_JNT_FREE) { xq[b] = ql; xp[b] = pl; }  // qpos0 = spec pose, joint value 0 elsewhere
-    else { xq[b] = qmul(xq[p], ql); xp[b] = xp[p] + qrot(xq[p], pl); }
-    xc[b] = xp[b] + qrot(xq[b], {s.ipos[0], s.ipos[1], s.ipos[2]});
-  }
-  // per-dof world axis / anchor
-  std::vector<V3> ax(nv), an(nv);
-  for (int i = 0; i < nv; i++) {
-    int b = m.d_body[i];
-    const MirBodySpec& s = sp->body[b];
-    if (m.d_kind[i] < 2) ax[i] = qrot(xq[b], {s.axis[0], s.axis[1], s.axis[2]});
-    else { V3 e{0, 0, 0}; (&e.x)[m.d_axis_k[i]] = 1; ax[i] = e; }
-    an[i] = xp[b];
-  }
-  auto jac = [&](int b, V3 pt, int i, V3& jv, V3& jw) {  // column i of the Jacobian of point pt on body b
-    jv = {0, 0, 0}; jw = {0, 0, 0};
-    if (!(m.b_dofmask[b] >> i & 1u)) return;
-    if (m.d_kind[i] == 0 || m.d_kind[i] == 3) { jw = ax[i]; jv = cross(ax[i], pt - an[i]); }
-    else jv = ax[i];
-  };
-  std::vector<double> M(nv * nv, 0.0);
-  for (int b = 1; b < nb; b++) {
-    const MirBodySpec& s = sp->body[b];
-    M3 R = q2m(xq[b]);
-    double Ib[3][3] = {{s.inertia[0], s.inertia[3], s.inertia[4]}, {s.inertia[3], s.inertia[1], s.inertia[5]}, {s.inertia[4], s.inertia[5], s.inertia[2]}};
-    double Iw[3][3];
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) {
-        double t = 0;
-        for (int k = 0; k < 3; k++)
-          for (int l = 0; l < 3; l++) t += R.m[r][k] * Ib[k][l] * R.m[c][l];
-        Iw[r][c] = t;
-      }
-    for (int i = 0; i < nv; i++) {
-      V3 vi, wi;
-      jac(b, xc[b], i, vi, wi);
-      V3 Iwi{Iw[0][0] * wi.x + Iw[0][1] * wi.y + Iw[0][2] * wi.z, Iw[1][0] * wi.x + Iw[1][1] * wi.y + Iw[1][2] * wi.z,
-             Iw[2][0] * wi.x + Iw[2][1] * wi.y + Iw[2][2] * wi.z};
-      for (int j = 0; j < nv; j++) {
-        V3 vj, wj;
-        jac(b, xc[b], j, vj, wj);
-        M[i * nv + j] += s.mass * dot(vi, vj) + dot(Iwi, wj);
-      }
-    }
-  }
-  for (int i = 0; i < nv; i++) M[i * nv + i] += sp->dof[i].armature;
-  // invert by Gauss-Jordan (SPD, tiny)
-  std::vector<double> A(M), Inv(nv * nv, 0.0);
-  for (int i = 0; i < nv; i++) Inv[i * nv + i] = 1;
-  for (int c = 0; c < nv; c++) {
-    double p = A[c * nv + c];
-    if (!(p > 1e-12)) return fail(err, MIR_E_INVALID, "joint-space inertia at qpos0 is not positive definite");
-    for (int j = 0; j < nv; j++) { A[c * nv + j] /= p; Inv[c * nv + j] /= p; }
-    for (int r = 0; r < nv; r++)
-      if (r != c) {
-        double f = A[r * nv + c];
-        if (f != 0)
-          for (int j = 0; j < nv; j++) { A[r * nv + j] -= f * A[c * nv + j]; Inv[r * nv + j] -= f * Inv[c * nv + j]; }
-      }
-  }
-  double tr = 0;
-  for (int i = 0; i < nv; i++) tr += M[i * nv + i];
-  double meaninertia = nv ? tr / nv : 1.0;
   HostConsts local;
   HostConsts& H = hc ? *hc : local;
-  memset(&H, 0, sizeof H);
-  H.meaninertia = meaninertia;
-  for (int b = 1; b < nb; b++) {
-    int da = m.b_dofadr[b];
-    if (m.b_jtype[b] == MIR_JNT_FREE) {
-      double t = (Inv[da * nv + da] + Inv[(da + 1) * nv + da + 1] + Inv[(da + 2) * nv + da + 2]) / 3;
-      double r = (Inv[(da + 3) * nv + da + 3] + Inv[(da + 4) * nv + da + 4] + Inv[(da + 5) * nv + da + 5]) / 3;
-      for (int k = 0; k < 3; k++) { H.dof_invweight0[da + k] = t; H.dof_invweight0[da + 3 + k] = r; }
-    } else if (m.b_jtype[b] != MIR_JNT_FIXED)
-      H.dof_invweight0[da] = Inv[da * nv + da];
-    if (m.b_static[b]) continue;
-    double t = 0;
-    for (int i = 0; i < nv; i++) {
-      V3 vi, wi;
-      jac(b, xc[b], i, vi, wi);
-      for (int j = 0; j < nv; j++) {
-        V3 vj, wj;
-        jac(b, xc[b], j, vj, wj);
-        t += dot(vi, vj) * Inv[i * nv + j];
-      }
-    }
-    H.body_invweight0[b] = fmax(t / 3, 1e-15);
+  {
+    int rc = mir_host_consts(sp, &H, err);
+    if (rc != MIR_OK) return rc;
   }
   for (int i = 0; i < nv; i++) m.d_invweight0[i] = (float)H.dof_invweight0[i];
   for (int b = 0; b < nb; b++) m.b_invweight0[b] = (float)H.body_invweight0[b];
-  m.meaninertia = (float)meaninertia;
-  m.solver_scale = (float)(1.0 / (meaninertia * (nv > 1 ? nv : 1)));
+  m.meaninertia = (float)H.meaninertia;
+  m.solver_scale = (float)(1.0 / (H.meaninertia * (nv > 1 ? nv : 1)));
 
   // ---- packed lookup tables for the kernel's LDS copy ---------------------------------------
   ModelTab& t = m.tab;

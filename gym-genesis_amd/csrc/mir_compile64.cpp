@@ -1,0 +1,220 @@
+// mir_compile64.cpp — host-side compile of a MirSceneSpec into the lane-mapped DevModel64 of the
+// wave-per-env kernel (mir_model64.h): kinematic trees are packed into the four 16-lane blocks, every mask is
+// expressed in lane space, the static collision-pair filter and the soft-constraint constants are the same as
+// for the 16-lane model (mir_compile.cpp).  Host double precision, run once per mir_create.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "mir_model64.h"
+
+namespace {
+int fail(char* err, int code, const char* msg) {
+  if (err) snprintf(err, 255, "%s", msg);
+  return code;
+}
+}  // namespace
+
+int mir_compile_model64(const MirSceneSpec* sp0, DevModel64* out, HostConsts* hc, char* err) {
+  if (!sp0 || !out) return fail(err, MIR_E_INVALID, "null spec");
+  if (sp0->struct_size != (int)sizeof(MirSceneSpec) || sp0->version != MIR_VERSION)
+    return fail(err, MIR_E_INVALID, "MirSceneSpec size/version mismatch (ABI)");
+  if (sp0->nbody < 1 || sp0->nbody > K64_MAX_BODY || sp0->nbody > MIR_MAX_BODY || sp0->ndof > MIR_MAX_DOF || sp0->ngeom > MIR_MAX_GEOM ||
+      sp0->ndof < 0 || sp0->ngeom < 0)
+    return fail(err, MIR_E_CAPACITY, "scene exceeds MIR_MAX_BODY/DOF/GEOM");
+  MirSceneSpec rounded = *sp0;
+  mir_round_spec(&rounded);
+  const MirSceneSpec* sp = &rounded;
+  DevModel64& m = *out;
+  memset(&m, 0, sizeof m);
+  const int nb = sp->nbody;
+  m.nbody = nb;
+  m.ngeom = sp->ngeom;
+  m.dt = (float)sp->opt.dt;
+  m.gx = (float)sp->opt.gravity[0]; m.gy = (float)sp->opt.gravity[1]; m.gz = (float)sp->opt.gravity[2];
+  m.tolerance = (float)sp->opt.tolerance;
+  m.ls_tolerance = (float)sp->opt.ls_tolerance;
+  m.iterations = sp->opt.iterations;
+  m.ls_iterations = sp->opt.ls_iterations;
+  m.enable_collision = sp->opt.enable_collision;
+  m.enable_joint_limit = sp->opt.enable_joint_limit;
+  m.max_contacts = sp->opt.max_contacts;
+  if (m.max_contacts > MIR_MAX_CONTACT || m.max_contacts < 0) return fail(err, MIR_E_CAPACITY, "max_contacts > MIR_MAX_CONTACT");
+
+  // ---- topology in compact dof order ---------------------------------------------------------
+  std::vector<int> ndof(nb, 0), dofadr(nb, 0), tree_ndof(nb, 0), tree_lane(nb, -1), tree_next(nb, 0);
+  int nv = 0, nq = 0, narm = 0, nfree = 0;
+  for (int b = 0; b < nb; b++) {
+    const MirBodySpec& s = sp->body[b];
+    int jt = b == 0 ? MIR_JNT_FIXED : s.jtype;
+    if (b > 0 && (s.parent < 0 || s.parent >= b)) return fail(err, MIR_E_INVALID, "body parent must precede the body");
+    if (jt == MIR_JNT_FREE && s.parent != 0) return fail(err, MIR_E_INVALID, "free joint must hang off the world");
+    m.b_parent[b] = b == 0 ? -1 : s.parent;
+    m.b_jtype[b] = jt;
+    m.b_qadr[b] = nq;
+    m.b_root[b] = b == 0 ? 0 : (s.parent == 0 ? b : m.b_root[s.parent]);
+    ndof[b] = jt == MIR_JNT_FREE ? 6 : (jt == MIR_JNT_FIXED ? 0 : 1);
+    dofadr[b] = nv;
+    m.b_static[b] = b == 0 ? 1 : (ndof[b] == 0 && m.b_static[s.parent]);
+    for (int k = 0; k < 3; k++) { m.b_pos[b][k] = (float)s.pos[k]; m.b_axis[b][k] = (float)s.axis[k]; m.b_ipos[b][k] = (float)s.ipos[k]; }
+    for (int k = 0; k < 4; k++) m.b_quat[b][k] = (float)s.quat[k];
+    for (int k = 0; k < 6; k++) m.b_inertia[b][k] = (float)s.inertia[k];
+    m.b_mass[b] = (float)s.mass;
+    tree_ndof[m.b_root[b]] += ndof[b];
+    nv += ndof[b];
+    nq += jt == MIR_JNT_FREE ? 7 : ndof[b];
+    if (jt == MIR_JNT_FREE) nfree++;
+  }
+  if (nv != sp->ndof) return fail(err, MIR_E_INVALID, "ndof does not match the joints");
+  if (nq > MIR_MAX_Q || nq > K64_QSTRIDE) return fail(err, MIR_E_CAPACITY, "nq > MIR_MAX_Q");
+  if (nfree > MIR_MAX_FREE) return fail(err, MIR_E_CAPACITY, "more than MIR_MAX_FREE free bodies");
+  m.nv = nv; m.nq = nq; m.nfree = nfree;
+
+  // ---- pack trees into 16-lane blocks (first fit, in root order; a tree never straddles a block) -----
+  {
+    int blk = 0, fill = 0;
+    for (int r = 1; r < nb; r++) {
+      if (m.b_root[r] != r || tree_ndof[r] == 0) continue;
+      if (tree_ndof[r] > K64_BLOCK_DOF) return fail(err, MIR_E_CAPACITY, "a kinematic tree has more than 15 dofs");
+      if (fill + tree_ndof[r] > K64_BLOCK_DOF) { blk++; fill = 0; }
+      if (blk >= W64 / 16) return fail(err, MIR_E_CAPACITY, "the scene's trees do not fit four 15-dof blocks");
+      tree_lane[r] = blk * 16 + fill;
+      tree_next[r] = tree_lane[r];
+      fill += tree_ndof[r];
+    }
+  }
+  std::vector<int> lane_of_dof(nv, -1);
+  for (int l = 0; l < W64; l++) { m.d_dof[l] = -1; m.d_uadr[l] = -1; }
+  for (int b = 1; b < nb; b++) {
+    int r = m.b_root[b];
+    m.b_block[b] = tree_lane[r] >= 0 ? tree_lane[r] / 16 : -1;
+    m.b_dofadr[b] = tree_next[r];
+    uint64_t inherited = m.b_parent[b] > 0 ? m.b_dofmask[m.b_parent[b]] : 0ull;
+    const int la = tree_next[r];
+    for (int k = 0; k < ndof[b]; k++) {
+      const int l = la + k, i = dofadr[b] + k;
+      lane_of_dof[i] = l;
+      m.d_dof[l] = i;
+      m.d_body[l] = b;
+      m.d_qadr[l] = m.b_qadr[b] + k;
+      if (m.b_jtype[b] == MIR_JNT_FREE) {
+        m.d_kind[l] = k < 3 ? 2 : 3;
+        m.d_axis_k[l] = k % 3;
+        m.d_premask[l] = inherited | (k < 3 ? ((1ull << k) - 1ull) << la : 7ull << la);
+      } else {
+        m.d_kind[l] = m.b_jtype[b] == MIR_JNT_REVOLUTE ? 0 : 1;
+        m.d_premask[l] = inherited;
+        m.arm_qadr[narm++] = m.b_qadr[b];
+      }
+      m.d_ancmask[l] = inherited | (((1ull << (k + 1)) - 1ull) << la);
+      m.lanemask |= 1ull << l;
+    }
+    m.b_dofmask[b] = inherited | (ndof[b] ? (((1ull << ndof[b]) - 1ull) << la) : 0ull);
+    tree_next[r] += ndof[b];
+  }
+  m.b_block[0] = -1;
+  m.n_arm_q = narm;
+  for (int b = 0; b < nb; b++) {
+    uint32_t sub = 1u << b;
+    for (int c = b + 1; c < nb; c++) {
+      int a = m.b_parent[c];
+      while (a > b) a = m.b_parent[a];
+      if (a == b && b > 0) sub |= 1u << c;
+    }
+    m.b_submask[b] = sub;
+  }
+
+  // ---- dof parameters (lane-indexed) -------------------------------------------------------------
+  int nu = 0;
+  for (int i = 0; i < nv; i++) {
+    const MirDofSpec& s = sp->dof[i];
+    const int l = lane_of_dof[i];
+    m.d_limited[l] = s.limited && m.d_kind[l] < 2;
+    m.d_ctrl[l] = s.ctrl_mode;
+    m.d_uadr[l] = s.ctrl_mode == MIR_CTRL_POSITION ? nu++ : -1;
+    m.d_lo[l] = (float)s.range[0]; m.d_hi[l] = (float)s.range[1];
+    m.d_damping[l] = (float)s.damping; m.d_kp[l] = (float)s.kp; m.d_kv[l] = (float)s.kv;
+    m.d_frclo[l] = (float)fmax(s.frc_range[0], -3.0e38); m.d_frchi[l] = (float)fmin(s.frc_range[1], 3.0e38);
+    m.d_armature[l] = (float)s.armature;
+    double add = s.armature;
+    if (sp->opt.implicit_damping) add += sp->opt.dt * (s.damping + (s.ctrl_mode == MIR_CTRL_POSITION ? s.kv : 0.0));
+    m.d_mdiag[l] = (float)add;
+    double dmax = fmin(fmax(s.solimp[1], 1e-4), 0.9999);
+    double tc = fmax(s.solref[0], 2 * sp->opt.dt), dr = s.solref[1];
+    m.d_k[l] = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr));
+    m.d_b[l] = (float)(2.0 / (dmax * tc));
+    for (int k = 0; k < 5; k++) m.d_solimp[l][k] = (float)s.solimp[k];
+  }
+  m.nu = nu;
+
+  // ---- task -----------------------------------------------------------------------------------------
+  const MirTaskSpec& t = sp->task;
+  m.eef_body = t.eef_body; m.obj_body = t.obj_body; m.obj2_body = t.obj2_body; m.n_grip = t.n_grip;
+  m.reward_mode = t.reward_mode; m.agent_mode = t.agent_mode;
+  if (m.eef_body < 0 || m.eef_body >= nb || m.obj_body < 0 || m.obj_body >= nb || m.obj2_body >= nb || m.n_grip < 0 || m.n_grip > MIR_MAX_GRIP)
+    return fail(err, MIR_E_INVALID, "task body / gripper indices out of range");
+  if (t.reward_mode == MIR_REWARD_STACK && t.obj2_body < 0) return fail(err, MIR_E_INVALID, "MIR_REWARD_STACK needs task.obj2_body");
+  if (t.reward_mode != MIR_REWARD_LIFT && t.reward_mode != MIR_REWARD_STACK) return fail(err, MIR_E_INVALID, "unknown task.reward_mode");
+  if (t.agent_mode != MIR_AGENT_EEF && t.agent_mode != MIR_AGENT_QPOS) return fail(err, MIR_E_INVALID, "unknown task.agent_mode");
+  for (int k = 0; k < m.n_grip; k++) {
+    int d = t.grip_dof[k];
+    if (d < 0 || d >= nv) return fail(err, MIR_E_INVALID, "grip dof out of range");
+    m.grip_qadr[k] = m.d_qadr[lane_of_dof[d]];
+  }
+  m.reward_z = (float)t.reward_z; m.reward_xy = (float)t.reward_xy; m.reward_dz = (float)t.reward_dz;
+  m.agent_dim = t.agent_mode == MIR_AGENT_QPOS ? narm : 7 + m.n_grip;
+  m.env_dim = t.obj2_body >= 0 ? 14 : 11;
+
+  // ---- geoms + static pair filter (same rules as mir_compile.cpp) -----------------------------------
+  for (int g = 0; g < sp->ngeom; g++) {
+    const MirGeomSpec& s = sp->geom[g];
+    if (s.body < 0 || s.body >= nb) return fail(err, MIR_E_INVALID, "geom body out of range");
+    if (s.type != MIR_GEOM_PLANE && s.type != MIR_GEOM_BOX) return fail(err, MIR_E_INVALID, "unsupported geom type");
+    m.g_body[g] = s.body; m.g_type[g] = s.type;
+    for (int k = 0; k < 3; k++) { m.g_size[g][k] = (float)s.size[k]; m.g_pos[g][k] = (float)s.pos[k]; }
+    m.g_pos[g][3] = (float)s.friction;
+    for (int k = 0; k < 4; k++) m.g_quat[g][k] = (float)s.quat[k];
+    m.g_sol[g][0] = (float)s.solref[0]; m.g_sol[g][1] = (float)s.solref[1];
+    for (int k = 0; k < 5; k++) m.g_sol[g][2 + k] = (float)s.solimp[k];
+  }
+  auto moving_link = [&](int b) {
+    while (b > 0 && m.b_jtype[b] == MIR_JNT_FIXED) b = m.b_parent[b];
+    return b;
+  };
+  int np = 0;
+  for (int ga = 0; ga < sp->ngeom; ga++)
+    for (int gb = ga + 1; gb < sp->ngeom; gb++) {
+      int a = ga, b = gb;
+      if (m.g_type[b] == MIR_GEOM_PLANE) { a = gb; b = ga; }
+      if (m.g_type[b] == MIR_GEOM_PLANE) continue;
+      int ba = m.g_body[a], bb = m.g_body[b];
+      if (ba == bb || (m.b_static[ba] && m.b_static[bb])) continue;
+      const MirGeomSpec &sa = sp->geom[a], &sb = sp->geom[b];
+      if (!((sa.contype & sb.conaffinity) || (sb.contype & sa.conaffinity))) continue;
+      if (!sp->opt.enable_adjacent_collision) {
+        int la = moving_link(ba), lb = moving_link(bb);
+        if (la == lb) continue;
+        int pa = la > 0 ? moving_link(m.b_parent[la]) : -1;
+        int pb = lb > 0 ? moving_link(m.b_parent[lb]) : -1;
+        if ((pa == lb && lb > 0) || (pb == la && la > 0)) continue;
+      }
+      if (!sp->opt.enable_self_collision && ba > 0 && bb > 0 && m.b_root[ba] == m.b_root[bb]) continue;
+      if (np >= MIR_MAX_PAIR) return fail(err, MIR_E_CAPACITY, "too many candidate collision pairs");
+      m.pair[np++] = a | (b << 8);
+    }
+  m.npair = np;
+
+  // ---- constants at qpos0 (shared helper, compact order) -> lanes ------------------------------------
+  HostConsts local;
+  HostConsts& H = hc ? *hc : local;
+  {
+    int rc = mir_host_consts(sp, &H, err);
+    if (rc != MIR_OK) return rc;
+  }
+  for (int i = 0; i < nv; i++) m.d_invweight0[lane_of_dof[i]] = (float)H.dof_invweight0[i];
+  for (int b = 0; b < nb; b++) m.b_invweight0[b] = (float)H.body_invweight0[b];
+  m.meaninertia = (float)H.meaninertia;
+  m.solver_scale = (float)(1.0 / (H.meaninertia * (nv > 1 ? nv : 1)));
+  return MIR_OK;
+}

@@ -1,0 +1,308 @@
+// mir_dev.h — device-side helpers shared by the two step kernels (mir_step.hip: 16 lanes per env;
+// mir_step64.hip: one wave per env): small vector / quaternion algebra, DPP primitives over one 16-lane row,
+// the register-row Gauss-Jordan solve of a 16-wide block, spatial inertia products, the box-box narrowphase and
+// the soft-constraint impedance.  Everything is in an anonymous namespace (one copy per translation unit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mirigid.h"
+
+#ifndef G
+#define G 16 /* lanes per DPP row = width of a dof block */
+#endif
+
+// wave-level phase separator: LDS operations of one wave execute in order, so only the compiler
+// must be kept from moving LDS accesses across the phase boundary
+#define WSYNC()                                              \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+// 16-byte LDS accesses (arrays below are padded to 4 floats per element for these)
+__device__ __forceinline__ f4 ldv(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ void stv(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+__device__ __forceinline__ V3 ld3v(const float* p) { f4 v = ldv(p); return {v.x, v.y, v.z}; }
+__device__ __forceinline__ void st3v(float* p, V3 a, float w = 0.0f) { stv(p, f4{a.x, a.y, a.z, w}); }
+
+struct Q4 {
+  float w, x, y, z;
+};
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
+  V3 u = {q.x, q.y, q.z};
+  V3 t = 2.0f * cross(u, v);
+  return v + q.w * t + cross(u, t);
+}
+__device__ __forceinline__ Q4 ld4(const float* p) { return {p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ Q4 ld4v(const float* p) { f4 v = ldv(p); return {v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void st4(float* p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+__device__ __forceinline__ void st4v(float* p, Q4 q) { stv(p, f4{q.w, q.x, q.y, q.z}); }
+__device__ __forceinline__ Q4 qnormalize(Q4 q) {
+  float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  if (n < 1e-15f) return {1, 0, 0, 0};
+  float s = 1.0f / n;
+  return {q.w * s, q.x * s, q.y * s, q.z * s};
+}
+struct M3 {
+  V3 r0, r1, r2;  // rows
+};
+__device__ __forceinline__ M3 q2m(Q4 q) {
+  float w = q.w, x = q.x, y = q.y, z = q.z;
+  M3 R;
+  R.r0 = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)};
+  R.r1 = {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)};
+  R.r2 = {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+  return R;
+}
+__device__ __forceinline__ V3 mcol(const M3& R, int k) {
+  return k == 0 ? v3(R.r0.x, R.r1.x, R.r2.x) : (k == 1 ? v3(R.r0.y, R.r1.y, R.r2.y) : v3(R.r0.z, R.r1.z, R.r2.z));
+}
+__device__ __forceinline__ V3 mmul(const M3& R, V3 v) { return {dot(R.r0, v), dot(R.r1, v), dot(R.r2, v)}; }
+
+// ---- DPP cross-lane primitives over one 16-lane row (= one env group).  Must be executed with all
+// lanes of the wave active (convergent code): an inactive source lane would feed garbage.
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {  // value of lane K of the row, in every lane of the row
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ float row_shr(float v) {  // lane i reads lane i-N of its row, 0 shifted in
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float gsum(float v) {  // all-reduce sum over the row
+  v += row_ror<1>(v);
+  v += row_ror<2>(v);
+  v += row_ror<4>(v);
+  v += row_ror<8>(v);
+  return v;
+}
+__device__ __forceinline__ float gmaxf(float v) {  // all-reduce max over the row
+  v = fmaxf(v, row_ror<1>(v));
+  v = fmaxf(v, row_ror<2>(v));
+  v = fmaxf(v, row_ror<4>(v));
+  v = fmaxf(v, row_ror<8>(v));
+  return v;
+}
+__device__ __forceinline__ int gsumi(int v) { return (int)(gsum((float)v) + 0.5f); }
+
+// ---- Gauss-Jordan solve A x = b on register rows: lane i holds row i of the SPD matrix A in
+// a[0..15] and b_i in b; on return b = x_i.  Rows >= nv must be identity rows.  15 pivots, each:
+// one reciprocal, (16-k) row_newbcast + fma pairs.  No pivoting needed (SPD).
+template <int K>
+struct GJ {
+  static __device__ __forceinline__ void run(float (&a)[G], float& b, int lane) {
+    const float pk = row_bcast<K>(a[K]);
+    float inv = __builtin_amdgcn_rcpf(pk);
+    inv = inv * (2.0f - pk * inv);  // one Newton step: full float accuracy
+    const bool isk = lane == K;
+    const float f = a[K] * inv;
+#pragma unroll
+    for (int j = K + 1; j < G - 1; j++) {
+      const float rj = row_bcast<K>(a[j]);
+      a[j] = isk ? a[j] * inv : fmaf(-f, rj, a[j]);
+    }
+    const float rb = row_bcast<K>(b);
+    b = isk ? b * inv : fmaf(-f, rb, b);
+    GJ<K + 1>::run(a, b, lane);
+  }
+};
+template <>
+struct GJ<G - 1> {
+  static __device__ __forceinline__ void run(float (&)[G], float&, int) {}
+};
+
+// spatial inertia {m, h, I(xx yy zz xy xz yz)} applied to motion {w, v} -> force {t, f}
+struct Inert {
+  float m;
+  V3 h;
+  float xx, yy, zz, xy, xz, yz;
+};
+__device__ __forceinline__ Inert ldI(const float* p) {
+  f4 a = ldv(p), b = ldv(p + 4), c = ldv(p + 8);
+  return {a.x, {a.y, a.z, a.w}, b.x, b.y, b.z, b.w, c.x, c.y};
+}
+__device__ __forceinline__ void imul(const Inert& I, V3 w, V3 v, V3& t, V3& f) {
+  V3 Iw = {I.xx * w.x + I.xy * w.y + I.xz * w.z, I.xy * w.x + I.yy * w.y + I.yz * w.z, I.xz * w.x + I.yz * w.y + I.zz * w.z};
+  t = Iw + cross(I.h, v);
+  f = I.m * v - cross(I.h, w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// narrowphase primitives (one lane per candidate pair)
+struct BoxG {
+  V3 p;
+  V3 a0, a1, a2;  // world axes
+  V3 h;
+};
+__device__ __forceinline__ V3 bax(const BoxG& b, int k) { return k == 0 ? b.a0 : (k == 1 ? b.a1 : b.a2); }
+__device__ __forceinline__ float bh(const BoxG& b, int k) { return k == 0 ? b.h.x : (k == 1 ? b.h.y : b.h.z); }
+
+// box-box by separating axes + reference-face clipping; normal from A to B; up to 8 points.
+// Rare (only when bounding spheres overlap) and register-hungry: kept out of line.
+__device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4], V3& nout) {
+  V3 t = B.p - A.p;
+  float best = -1e30f;
+  int code = -1;
+  V3 bestL = v3(0, 0, 1);
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    V3 L = c < 3 ? bax(A, c) : bax(B, c - 3);
+    float ra = A.h.x * fabsf(dot(A.a0, L)) + A.h.y * fabsf(dot(A.a1, L)) + A.h.z * fabsf(dot(A.a2, L));
+    float rb = B.h.x * fabsf(dot(B.a0, L)) + B.h.y * fabsf(dot(B.a1, L)) + B.h.z * fabsf(dot(B.a2, L));
+    float s = fabsf(dot(t, L)) - (ra + rb);
+    if (s > 0.0f) return 0;
+    if (s > best) { best = s; code = c; bestL = L; }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      V3 L = cross(bax(A, i), bax(B, j));
+      float len = sqrtf(dot(L, L));
+      if (len < 1e-3f) continue;
+      L = (1.0f / len) * L;
+      float ra = A.h.x * fabsf(dot(A.a0, L)) + A.h.y * fabsf(dot(A.a1, L)) + A.h.z * fabsf(dot(A.a2, L));
+      float rb = B.h.x * fabsf(dot(B.a0, L)) + B.h.y * fabsf(dot(B.a1, L)) + B.h.z * fabsf(dot(B.a2, L));
+      float s = fabsf(dot(t, L)) - (ra + rb);
+      if (s > 0.0f) return 0;
+      if (s * 1.05f > best && s > best + 1e-6f) { best = s; code = 6 + i * 3 + j; bestL = L; }
+    }
+  V3 n = dot(t, bestL) < 0.0f ? -1.0f * bestL : bestL;
+  nout = n;
+  if (code >= 6) {
+    int i = (code - 6) / 3, j = (code - 6) % 3;
+    V3 PA = A.p, PB = B.p;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (k != i) PA = PA + (dot(n, bax(A, k)) > 0.0f ? bh(A, k) : -bh(A, k)) * bax(A, k);
+      if (k != j) PB = PB + (dot(n, bax(B, k)) > 0.0f ? -bh(B, k) : bh(B, k)) * bax(B, k);
+    }
+    V3 ua = bax(A, i), ub = bax(B, j), dd = PB - PA;
+    float uaub = dot(ua, ub), q1 = dot(ua, dd), q2 = -dot(ub, dd), den = 1.0f - uaub * uaub;
+    float alpha = 0.0f, beta = 0.0f;
+    if (den > 1e-6f) { alpha = (q1 + uaub * q2) / den; beta = (uaub * q1 + q2) / den; }
+    PA = PA + alpha * ua;
+    PB = PB + beta * ub;
+    V3 pos = 0.5f * (PA + PB);
+    out[0][0] = pos.x; out[0][1] = pos.y; out[0][2] = pos.z; out[0][3] = best;
+    return 1;
+  }
+  const bool refA = code < 3;
+  const BoxG& R = refA ? A : B;
+  const BoxG& I = refA ? B : A;
+  int k = refA ? code : code - 3;
+  V3 nr = refA ? n : -1.0f * n;
+  int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+  V3 fc = R.p + bh(R, k) * nr;
+  float a0 = fabsf(dot(nr, I.a0)), a1 = fabsf(dot(nr, I.a1)), a2 = fabsf(dot(nr, I.a2));
+  int jb = 0;
+  float mx = a0;
+  if (a1 > mx) { mx = a1; jb = 1; }
+  if (a2 > mx) { mx = a2; jb = 2; }
+  float sj = dot(nr, bax(I, jb)) > 0.0f ? -1.0f : 1.0f;
+  int j1 = (jb + 1) % 3, j2 = (jb + 2) % 3;
+  V3 ic = I.p + (sj * bh(I, jb)) * bax(I, jb);
+  V3 e1 = bax(R, k1), e2 = bax(R, k2);
+  float h1 = bh(R, k1), h2 = bh(R, k2);
+  float px[9], py[9], pz[9], qx[9], qy[9], qz[9];
+  int np = 4;
+  {
+    const float sx[4] = {1, -1, -1, 1}, sy[4] = {1, 1, -1, -1};
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      V3 w = ic + (sx[v] * bh(I, j1)) * bax(I, j1) + (sy[v] * bh(I, j2)) * bax(I, j2);
+      V3 rel = w - fc;
+      px[v] = dot(rel, e1); py[v] = dot(rel, e2); pz[v] = dot(rel, nr);
+    }
+  }
+  for (int e = 0; e < 4; e++) {
+    const int ax = e >> 1;
+    const float sg = (e & 1) ? -1.0f : 1.0f;
+    const float lim = ax == 0 ? h1 : h2;
+    int nn = 0;
+    for (int v = 0; v < np; v++) {
+      int w = v + 1 == np ? 0 : v + 1;
+      float pc = ax == 0 ? px[v] : py[v], qc = ax == 0 ? px[w] : py[w];
+      float dp = sg * pc - lim, dq = sg * qc - lim;
+      if (dp <= 0.0f && nn < 9) { qx[nn] = px[v]; qy[nn] = py[v]; qz[nn] = pz[v]; nn++; }
+      if ((dp <= 0.0f) != (dq <= 0.0f) && nn < 9) {
+        float u = dp / (dp - dq);
+        qx[nn] = px[v] + u * (px[w] - px[v]); qy[nn] = py[v] + u * (py[w] - py[v]); qz[nn] = pz[v] + u * (pz[w] - pz[v]);
+        nn++;
+      }
+    }
+    np = nn;
+    for (int v = 0; v < np; v++) { px[v] = qx[v]; py[v] = qy[v]; pz[v] = qz[v]; }
+    if (np == 0) return 0;
+  }
+  int cnt = 0;
+  for (int v = 0; v < np && cnt < 8; v++) {
+    if (pz[v] < 0.0f) {
+      V3 w = fc + px[v] * e1 + py[v] * e2 + (0.5f * pz[v]) * nr;
+      out[cnt][0] = w.x; out[cnt][1] = w.y; out[cnt][2] = w.z; out[cnt][3] = pz[v];
+      cnt++;
+    }
+  }
+  return cnt;
+}
+
+// MuJoCo-style impedance from solimp at |pos|
+__device__ __forceinline__ float impedance(float dmin, float dmax, float width, float mid, float power, float pos) {
+  dmin = fminf(fmaxf(dmin, 1e-4f), 0.9999f);
+  dmax = fminf(fmaxf(dmax, 1e-4f), 0.9999f);
+  width = fmaxf(width, 1e-15f);
+  mid = fminf(fmaxf(mid, 1e-4f), 0.9999f);
+  power = fmaxf(power, 1.0f);
+  float x = fabsf(pos) / width, y;
+  if (x >= 1.0f) y = 1.0f;
+  else if (x <= 0.0f) y = 0.0f;
+  else if (x <= mid) y = (power == 2.0f ? (x / mid) * (x / mid) : powf(x / mid, power)) * mid;
+  else { float r = (1.0f - x) / (1.0f - mid); y = 1.0f - (power == 2.0f ? r * r : powf(r, power)) * (1.0f - mid); }
+  return dmin + y * (dmax - dmin);
+}
+
+// dot of a register row with a 16-float LDS vector (4 broadcast b128 reads)
+__device__ __forceinline__ float rowdot(const float (&r)[G], const float* x) {
+  f4 x0 = ldv(x), x1 = ldv(x + 4), x2 = ldv(x + 8), x3 = ldv(x + 12);
+  return r[0] * x0.x + r[1] * x0.y + r[2] * x0.z + r[3] * x0.w + r[4] * x1.x + r[5] * x1.y + r[6] * x1.z + r[7] * x1.w +
+         r[8] * x2.x + r[9] * x2.y + r[10] * x2.z + r[11] * x2.w + r[12] * x3.x + r[13] * x3.y + r[14] * x3.z + r[15] * x3.w;
+}
+// the three base-row dots (normal, t1, t2) of contact Jacobian block `jb` with a 16-float LDS vector
+__device__ __forceinline__ void jdot3(const float* jb, const float* x, float& dn, float& d1, float& d2) {
+  dn = d1 = d2 = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    f4 xv = ldv(x + 4 * q);
+    f4 a = ldv(jb + 4 * q), b = ldv(jb + 16 + 4 * q), c = ldv(jb + 32 + 4 * q);
+    dn += a.x * xv.x + a.y * xv.y + a.z * xv.z + a.w * xv.w;
+    d1 += b.x * xv.x + b.y * xv.y + b.z * xv.z + b.w * xv.w;
+    d2 += c.x * xv.x + c.y * xv.y + c.z * xv.z + c.w * xv.w;
+  }
+}
+
+}  // namespace

@@ -12,20 +12,29 @@
 
 #define MIR_G 16 /* lanes per env group; requires nbody, nv <= 16 */
 
-static_assert(MIR_MAX_BODY <= MIR_G && MIR_MAX_DOF <= MIR_G, "lane ownership needs nbody, nv <= group width");
-static_assert(MIR_MAX_GEOM <= 2 * MIR_G, "two geoms per lane");
-static_assert(MIR_MAX_PAIR <= 4 * MIR_G, "four pairs per lane");
+/* capacity of the 16-lanes-per-env kernel (its LDS arenas and lane ownership); larger scenes take the
+ * wave-per-env kernel (mir_model64.h) */
+#define K16_MAX_BODY 16
+#define K16_MAX_DOF 15 /* one lane of a 16-lane env group stays free for the solver */
+#define K16_MAX_Q 18
+#define K16_MAX_GEOM 24
+#define K16_MAX_PAIR 64
+#define K16_MAX_CONTACT 16
+
+static_assert(K16_MAX_BODY <= MIR_G && K16_MAX_DOF <= MIR_G, "lane ownership needs nbody, nv <= group width");
+static_assert(K16_MAX_GEOM <= 2 * MIR_G, "two geoms per lane");
+static_assert(K16_MAX_PAIR <= 4 * MIR_G, "four pairs per lane");
 
 // Tables that the step kernel looks up with a *dynamic* index (geom, pair, contact body, limit
 // constants).  Packed so a workgroup copies them into LDS with 16-byte loads once per launch:
 // dependent lookups then cost an LDS round trip (~64 cycles) instead of an L2 one (~500+).
 struct ModelTab {
-  float g_pos[MIR_MAX_GEOM][4];   // xyz in body frame, w = friction
-  float g_quat[MIR_MAX_GEOM][4];  // wxyz in body frame
-  float g_size[MIR_MAX_GEOM][4];  // half extents, w unused
-  int32_t g_info[MIR_MAX_GEOM][4];  // body, type, 0, 0
-  float g_sol[MIR_MAX_GEOM][8];   // solref[2], solimp[5], 0
-  int32_t pair[MIR_MAX_PAIR];     // g1 | g2 << 8
+  float g_pos[K16_MAX_GEOM][4];   // xyz in body frame, w = friction
+  float g_quat[K16_MAX_GEOM][4];  // wxyz in body frame
+  float g_size[K16_MAX_GEOM][4];  // half extents, w unused
+  int32_t g_info[K16_MAX_GEOM][4];  // body, type, 0, 0
+  float g_sol[K16_MAX_GEOM][8];   // solref[2], solimp[5], 0
+  int32_t pair[K16_MAX_PAIR];     // g1 | g2 << 8
   int32_t b_info[MIR_G][4];       // dofmask, root, qadr, dofadr
   float b_invw[MIR_G];            // body_invweight0
   float d_lim[MIR_G][12];         // lo, hi, invweight0, k, b, solimp[5], 0, 0
@@ -61,11 +70,13 @@ struct DevModel {
   float d_invweight0[MIR_G];
   float d_solimp[MIR_G][5], d_k[MIR_G], d_b[MIR_G]; /* limit-row spring/damper from solref (tc clamped to 2 dt) */
   // ---- per geom ----
-  int32_t g_body[MIR_MAX_GEOM], g_type[MIR_MAX_GEOM];
-  float g_size[MIR_MAX_GEOM][3], g_pos[MIR_MAX_GEOM][3], g_quat[MIR_MAX_GEOM][4], g_friction[MIR_MAX_GEOM];
-  float g_solref[MIR_MAX_GEOM][2], g_solimp[MIR_MAX_GEOM][5];
+  int32_t g_body[K16_MAX_GEOM], g_type[K16_MAX_GEOM];
+  float g_size[K16_MAX_GEOM][3], g_pos[K16_MAX_GEOM][3], g_quat[K16_MAX_GEOM][4], g_friction[K16_MAX_GEOM];
+  float g_solref[K16_MAX_GEOM][2], g_solimp[K16_MAX_GEOM][5];
   // ---- candidate pairs (static filter applied) ----
-  int32_t p_g1[MIR_MAX_PAIR], p_g2[MIR_MAX_PAIR];
+  int32_t p_g1[K16_MAX_PAIR], p_g2[K16_MAX_PAIR];
+  // ---- free bodies in body order (reset / re-spawn poses) ----
+  int32_t nfree, free_qadr[MIR_MAX_FREE];
 };
 
 struct HostConsts {
@@ -74,5 +85,9 @@ struct HostConsts {
   double meaninertia;
 };
 
-// Compile a scene spec.  Returns MIR_OK or a MIR_E_* code and fills err (<=255 chars).
+// Compile a scene spec for the 16-lane kernel.  Returns MIR_OK, MIR_E_CAPACITY if the scene does not fit this
+// kernel's limits (the caller then tries the wave-per-env model), or another MIR_E_* code; fills err (<=255 chars).
 int mir_compile_model(const MirSceneSpec* spec, DevModel* out, HostConsts* hc, char* err);
+// shared host-side helpers (mir_compile.cpp)
+int mir_host_consts(const MirSceneSpec* spec, HostConsts* out, char* err);
+void mir_round_spec(MirSceneSpec* spec);

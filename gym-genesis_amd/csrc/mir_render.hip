@@ -62,8 +62,9 @@ struct Cam {
 };
 
 struct SetupArgs {
-  const DevModel* model;
-  const float* poses;       // (B, 2, 16, 4) FK cache
+  const GeomTab* geom;
+  const float* poses;       // (B, 2, pst, 4) FK cache
+  int pst;                  // bodies per env in the pose cache
   const float* env_offset;  // (B, 3) or null
   float* prims;             // (B, ngeom, PREC)
   Cam cam;
@@ -100,11 +101,11 @@ __global__ void k_render_setup(SetupArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.B * a.ngeom) return;
   const int e = i / a.ngeom, g = i % a.ngeom;
-  const DevModel* __restrict__ m = a.model;
+  const GeomTab* __restrict__ m = a.geom;
   const int b = m->g_body[g], type = m->g_type[g];
-  const float* pp = a.poses + ((size_t)e * 2 * MIR_G + b) * 4;
+  const float* pp = a.poses + ((size_t)e * 2 * a.pst + b) * 4;
   const V3 xp = {pp[0], pp[1], pp[2]};
-  const float* qq = pp + 4 * MIR_G;
+  const float* qq = pp + 4 * a.pst;
   const float bw = qq[0], bx = qq[1], by = qq[2], bz = qq[3];
   // geom frame in the world: c = xpos + R(xquat) g_pos (+ env offset), q = xquat * g_quat
   const V3 gp = {m->g_pos[g][0], m->g_pos[g][1], m->g_pos[g][2]};
@@ -357,7 +358,7 @@ extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisual
   if (prev != h->device) (void)hipSetDevice(h->device);
   int rc = MIR_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int ng = h->hm.ngeom, B = h->B;
+  const int ng = h->ngeom, B = h->B;
   do {
     if (!h->prims) {
       hipError_t e = hipMalloc((void**)&h->prims, (size_t)B * ng * PREC * sizeof(float));
@@ -366,7 +367,7 @@ extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisual
     if ((rc = mir_refresh_poses(h, stream)) != MIR_OK) break;
     SetupArgs sa;
     memset(&sa, 0, sizeof sa);
-    sa.model = h->dm; sa.poses = h->poses; sa.env_offset = env_offset; sa.prims = h->prims;
+    sa.geom = h->dgeom; sa.poses = h->poses; sa.pst = h->pt.pst; sa.env_offset = env_offset; sa.prims = h->prims;
     const double ty = std::tan(0.5 * cam->fov_deg * M_PI / 180.0), tx = ty * (double)cam->width / (double)cam->height;
     for (int k = 0; k < 3; k++) { sa.cam.pos[k] = (float)cam->pos[k]; sa.cam.f[k] = (float)f[k]; sa.cam.r[k] = (float)r[k]; sa.cam.u[k] = (float)u[k]; }
     sa.cam.tanx = (float)tx; sa.cam.tany = (float)ty; sa.cam.W = cam->width; sa.cam.H = cam->height;

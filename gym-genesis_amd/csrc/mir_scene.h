@@ -3,13 +3,21 @@
 #include <stdint.h>
 
 #include "mir_model.h"
+#include "mir_model64.h"
 
 struct MirScene {
   int device;
   int B;
-  DevModel hm;      // host copy of the compiled model
+  int kernel;       // 16: 16-lanes-per-env kernel (DevModel); 64: wave-per-env kernel (DevModel64)
+  DevModel hm;      // host copy of the compiled model (kernel 16)
+  DevModel64 hm64;  // host copy of the compiled model (kernel 64)
   HostConsts hc;
-  DevModel* dm;     // device copy
+  PlumbTab pt;      // dof-order <-> storage maps (host copy)
+  int nbody, nv, nq, nu, ngeom, npair, agent_dim, env_dim;
+  DevModel* dm;     // device copies
+  DevModel64* dm64;
+  PlumbTab* dpt;
+  GeomTab* dgeom;
   float *qpos, *qvel, *target, *qacc_ws, *poses;
   int32_t *diag, *fkvalid;
   float* prims;     // render primitives (B, ngeom, 32) f32, allocated by the first mir_render

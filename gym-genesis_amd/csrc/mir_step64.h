@@ -1,0 +1,36 @@
+// mir_step64.h — launch arguments of the wave-per-env step kernel (shared by mir_step64.hip and mir_api.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mir_model64.h"
+
+struct StepArgs64 {
+  const DevModel64* model;
+  float* qpos;     // (B, 64)
+  float* qvel;     // (B, 64) indexed by lane
+  float* target;   // (B, 64) indexed by lane
+  float* qacc_ws;  // (B, 64) indexed by lane
+  float* poses;    // (B, 2, 32, 4): link positions then quaternions of the current qpos (FK cache)
+  int32_t* fkvalid;  // (B)
+  const float* action;  // (B, nu) or null
+  float* agent_pos;     // (B, agent_dim) or null
+  float* env_state;     // (B, env_dim) or null
+  float* reward;        // (B) or null
+  uint8_t* terminated;  // (B) or null
+  int32_t* diag;        // (B, 4): ncon, nefc, niter, ncand; or null
+  // per-stage parity outputs (mir_forward), all nullable; compact dof order
+  float* out_M;     // (B, nv, nv)
+  float* out_bias;  // (B, nv)
+  float* out_qas;   // (B, nv)
+  float* out_qacc;  // (B, nv)
+  float* out_xpos;  // (B, nbody, 3)
+  float* out_xquat; // (B, nbody, 4)
+  float* rows;      // (B, row_stride) packed [agent | env_state | reward | terminated] or null
+  int row_stride;
+  int B;
+  int mode;     // 0: full steps; 1: forward dynamics only; 2: kinematics + outputs only
+  int n_steps;  // mode 0 only
+};
+
+extern "C" int mir_launch_step64(const StepArgs64* args, hipStream_t stream);

@@ -1,0 +1,971 @@
+// mir_step64.hip — the env.step() hot path for scenes beyond the 16-lane kernel: ONE WAVE PER ENV.
+//
+// What it replaces: scene.step() + get_obs() + compute_reward() of the reference's five-cube stack tasks
+// (/root/reference/gym_genesis/tasks/franka/cube_stack_kitchen_batch.py:131-160,
+//  /root/reference/gym_genesis/tasks/so101/cube_stack_batch.py:135-181; scene at tasks/utils.py:239-426,593-794):
+// arm + five free cubes on the kitchen-island slab, 36-39 dofs, up to 64 contacts.  Same formulation as
+// mir_step.hip: CRB mass matrix + RNE bias, PD torques, box/plane narrowphase, pyramidal soft
+// contacts, primal Newton with exact line search, semi-implicit Euler.
+//
+// Mapping to CDNA4
+//   * workgroup = one wave64 = one env.  The 64 lanes are four BLOCKS of 16 = the four DPP rows; a kinematic tree
+//     never straddles a block (arm in block 0, two cubes per later block: mir_compile64.cpp), so the joint-space
+//     inertia is block-diagonal: M rows are 16 wide, and M^-1 f is FOUR independent register-row Gauss-Jordan
+//     solves running side by side on row_newbcast DPP (the 16-lane kernel's solver, unchanged).
+//   * a contact touches at most two trees => at most two blocks: its Jacobian is stored as two dense 16-wide
+//     segments (3 base rows n, t1, t2 each) tagged with their block ids.  J x / J^T f / J^T D J touch only those
+//     segments; the Hessian row of a lane lives in 64 registers and a wave-uniform switch on the block id keeps
+//     every register index static.
+//   * the Newton system H = M + J^T D J couples blocks, so H^-1 g is a dense Gauss-Jordan over the 64 register
+//     rows with the pivot row travelling by v_readlane (SGPR broadcast); padding lanes are skipped wave-uniformly.
+//   * lane i is also body i (< 32), geom i, candidate pair i (4 passes), contact i: per-row solver state stays
+//     lane-private; wave-wide reductions are a DPP row reduction + 4 v_readlane.
+//   * ~47 KB of LDS per env (phase-aliased like the 16-lane kernel) -> 3 envs per CU.  First correct path for the
+//     stack tasks; DESIGN.md lists what is still slow.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mir_model64.h"
+#include "mir_step64.h"
+
+#define G 16
+#include "mir_dev.h"
+#define NL W64
+#define NB K64_MAX_BODY
+#define MAXC MIR_MAX_CONTACT
+#define JSEG 52 /* floats per contact segment: 3 rows x 16 + 4 pad */
+#define MSTR 20 /* row stride of the block-diagonal M rows in LDS */
+static_assert(MAXC == NL, "lane c owns contact c");
+static_assert(MIR_MAX_GEOM <= NL && MIR_MAX_PAIR <= 4 * NL, "lane ownership of geoms / pairs");
+
+namespace {
+
+__device__ __forceinline__ float rl(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ float wsum(float v) {  // all-reduce over the wave: row reduction, then the four row sums
+  v = gsum(v);
+  return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
+}
+__device__ __forceinline__ float wmaxf(float v) {
+  v = gmaxf(v);
+  return fmaxf(fmaxf(rl(v, 0), rl(v, 16)), fmaxf(rl(v, 32), rl(v, 48)));
+}
+
+// Dense Gauss-Jordan over the 64 register rows (lane i = row i of the SPD matrix, b_i the right-hand side; on
+// return b = x_i).  Rows / columns of padding lanes are identity and are skipped (wave-uniform `act` mask).
+template <int K>
+struct GJW {
+  static __device__ __forceinline__ void run(float (&a)[NL], float& b, int lane, uint64_t act) {
+    if ((act >> K) & 1ull) {
+      const float pk = rl(a[K], K);
+      float inv = __builtin_amdgcn_rcpf(pk);
+      inv = inv * (2.0f - pk * inv);
+      const bool isk = lane == K;
+      const float f = a[K] * inv;
+#pragma unroll
+      for (int j = K + 1; j < NL; j++) {
+        const float rj = rl(a[j], K);
+        a[j] = isk ? a[j] * inv : fmaf(-f, rj, a[j]);
+      }
+      const float rb = rl(b, K);
+      b = isk ? b * inv : fmaf(-f, rb, b);
+    }
+    GJW<K + 1>::run(a, b, lane, act);
+  }
+};
+template <>
+struct GJW<NL> {
+  static __device__ __forceinline__ void run(float (&)[NL], float&, int, uint64_t) {}
+};
+
+// h[16 BLK + k] += tn Jn[k] + t1 J1[k] + t2 J2[k] over one 16-wide segment (static register indices)
+template <int BLK>
+__device__ __forceinline__ void hupd(float (&h)[NL], const float* seg, float tn, float t1, float t2) {
+  f4 xn[4], x1[4], x2[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { xn[q] = ldv(seg + 4 * q); x1[q] = ldv(seg + 16 + 4 * q); x2[q] = ldv(seg + 32 + 4 * q); }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    h[16 * BLK + 4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
+    h[16 * BLK + 4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
+    h[16 * BLK + 4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
+    h[16 * BLK + 4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
+  }
+}
+__device__ __forceinline__ void hupd_blk(float (&h)[NL], int blk, const float* seg, float tn, float t1, float t2) {
+  switch (blk) {  // wave-uniform
+    case 0: hupd<0>(h, seg, tn, t1, t2); break;
+    case 1: hupd<1>(h, seg, tn, t1, t2); break;
+    case 2: hupd<2>(h, seg, tn, t1, t2); break;
+    default: hupd<3>(h, seg, tn, t1, t2); break;
+  }
+}
+
+struct Dyn64 {
+  float lpos[NB][4], lquat[NB][4];
+  float cddq[NL][8];
+  float cinert[NB][12], crb[NB][12];
+  float cvel[NB][8], cfrc[NB][8];
+};
+struct Col64 {
+  float gpos[MIR_MAX_GEOM][4], gquat[MIR_MAX_GEOM][4];
+  int cand[NL];
+  int cmap[NL];          // contact slot -> candidate * 8 + point index
+  int ccount[NL];        // points found per candidate
+  float stage[NL][8][4];  // narrowphase output per candidate pair: pos, dist
+  float snorm[NL][4];
+};
+struct Con64 {
+  float cpos[MAXC][4];    // pos, dist
+  float cfrm[MAXC][12];   // normal, t1, t2 (4-padded)
+  float cmeta[MAXC][4];   // mu, D, -k imp dist, b
+  float cref[MAXC][8];    // reference points of body1 / body2 trees
+  unsigned cmask[MAXC][4];  // lane masks of body1 (lo, hi), body2 (lo, hi)
+  int cblk[MAXC][4];      // block of segment 0, of segment 1 (-1 = none), pad, pad
+  float cfb[MAXC][4];     // per-iteration base forces (n, t1, t2), active-row flags
+};
+struct Env64 {
+  float qpos[K64_QSTRIDE], qvel[NL], target[NL], qacc_ws[NL], qacc[NL];
+  float qas[NL], srch[NL];
+  float xpos[NB][4], xquat[NB][4];
+  float cdof[NL][8];
+  float M[NL][MSTR];  // block-diagonal: row of lane i holds the 16 columns of its own block
+  int parent[NB];
+  int ncon, ncand, pad0, pad1;
+  union {
+    Dyn64 dyn;
+    struct {
+      Con64 con;
+      union {
+        float Jb[MAXC][2][JSEG];
+        Col64 col;
+      };
+    };
+  };
+};
+
+struct BodyK64 {
+  int jtype, qadr;
+  V3 pos, axis;
+  Q4 quat;
+};
+
+__device__ __forceinline__ void wave_fk(Env64& S, int lane, int nb, const BodyK64& k) {
+  if (lane > 0 && lane < nb) {
+    Q4 ql = k.quat;
+    V3 pl = k.pos;
+    if (k.jtype == MIR_JNT_REVOLUTE) {
+      float ang = S.qpos[k.qadr], sn, cs;
+      sincosf(0.5f * ang, &sn, &cs);
+      ql = qmul(k.quat, Q4{cs, k.axis.x * sn, k.axis.y * sn, k.axis.z * sn});
+    } else if (k.jtype == MIR_JNT_PRISMATIC) {
+      pl = k.pos + qrot(k.quat, S.qpos[k.qadr] * k.axis);
+    } else if (k.jtype == MIR_JNT_FREE) {
+      pl = ld3(&S.qpos[k.qadr]);
+      ql = qnormalize(ld4(&S.qpos[k.qadr + 3]));
+    }
+    st3v(S.dyn.lpos[lane], pl);
+    st4v(S.dyn.lquat[lane], ql);
+  } else if (lane == 0) {
+    st3v(S.dyn.lpos[0], v3(0, 0, 0));
+    st4v(S.dyn.lquat[0], Q4{1, 0, 0, 0});
+  }
+  WSYNC();
+  if (lane < nb) {
+    V3 P = ld3v(S.dyn.lpos[lane]);
+    Q4 Qx = ld4v(S.dyn.lquat[lane]);
+    int anc = lane > 0 ? S.parent[lane] : 0;
+    while (anc > 0) {
+      Q4 qa = ld4v(S.dyn.lquat[anc]);
+      P = ld3v(S.dyn.lpos[anc]) + qrot(qa, P);
+      Qx = qmul(qa, Qx);
+      anc = S.parent[anc];
+    }
+    st3v(S.xpos[lane], P);
+    st4v(S.xquat[lane], Qx);
+  }
+  WSYNC();
+}
+
+// dot of the three base rows of one Jacobian segment with a 16-float LDS vector
+__device__ __forceinline__ void segdot3(const float* seg, const float* x, float& dn, float& d1, float& d2) {
+  float an, a1, a2;
+  jdot3(seg, x, an, a1, a2);
+  dn += an; d1 += a1; d2 += a2;
+}
+// J_c x for contact c: both segments against their blocks of the 64-float LDS vector x
+__device__ __forceinline__ void condot3(const Env64& S, int c, const float* x, float& dn, float& d1, float& d2) {
+  dn = d1 = d2 = 0.0f;
+  const int b0 = S.con.cblk[c][0], b1 = S.con.cblk[c][1];
+  if (b0 >= 0) segdot3(&S.Jb[c][0][0], x + 16 * b0, dn, d1, d2);
+  if (b1 >= 0) segdot3(&S.Jb[c][1][0], x + 16 * b1, dn, d1, d2);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
+  __shared__ __attribute__((aligned(16))) Env64 S;
+  const DevModel64* __restrict__ m = a.model;
+  const int lane = threadIdx.x;
+  const int blk = lane >> 4, l16 = lane & 15;
+  const int env = blockIdx.x;  // grid = B exactly
+
+  const int nb = m->nbody, nv = m->nv, nq = m->nq;
+  const int ngeom = m->ngeom, npair = m->npair, max_contacts = m->max_contacts, enable_collision = m->enable_collision;
+  const float dt = m->dt;
+  const uint64_t lanemask = m->lanemask;
+
+  // ---- per-lane model constants (lane = body = dof slot) ------------------------------------------
+  const bool isbody = lane < nb && lane > 0;
+  const bool isdof = (lanemask >> lane) & 1ull;
+  const int bl = lane < NB ? lane : 0;  // body index this lane may own
+  BodyK64 bk;
+  bk.jtype = m->b_jtype[bl]; bk.qadr = m->b_qadr[bl];
+  bk.pos = ld3(m->b_pos[bl]); bk.axis = ld3(m->b_axis[bl]); bk.quat = ld4(m->b_quat[bl]);
+  const int b_root = m->b_root[bl];
+  const uint64_t b_dofmask = m->b_dofmask[bl];
+  const uint32_t b_submask = m->b_submask[bl];
+  const V3 b_ipos = ld3(m->b_ipos[bl]);
+  const float b_mass = m->b_mass[bl];
+  float ib[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) ib[k] = m->b_inertia[bl][k];
+  const int d_body = isdof ? m->d_body[lane] : 0;
+  const int d_kind = m->d_kind[lane], d_qadr = m->d_qadr[lane], d_axis_k = m->d_axis_k[lane];
+  const int d_root = m->b_root[d_body];
+  const V3 d_axis = ld3(m->b_axis[d_body]);
+  const uint64_t d_premask = m->d_premask[lane], d_ancmask = m->d_ancmask[lane];
+  const uint32_t d_submask = m->b_submask[d_body];
+  const int d_ctrl = m->d_ctrl[lane], d_uadr = m->d_uadr[lane];
+  const bool d_limited = isdof && m->d_limited[lane] && m->enable_joint_limit;
+  const float d_damping = m->d_damping[lane], d_kp = m->d_kp[lane], d_kv = m->d_kv[lane];
+  const float d_frclo = m->d_frclo[lane], d_frchi = m->d_frchi[lane], d_mdiag = m->d_mdiag[lane];
+  const int d_qbase = m->b_qadr[d_body], d_lbase = m->b_dofadr[d_body];
+
+  // ---- load state -----------------------------------------------------------------------------
+  S.qpos[lane] = a.qpos[(size_t)env * K64_QSTRIDE + lane];
+  S.qvel[lane] = a.qvel[(size_t)env * NL + lane];
+  S.qacc_ws[lane] = a.qacc_ws[(size_t)env * NL + lane];
+  {
+    float tg = a.target[(size_t)env * NL + lane];
+    if (a.action && isdof && d_uadr >= 0) tg = a.action[(size_t)env * m->nu + d_uadr];
+    S.target[lane] = tg;
+    if (a.action) a.target[(size_t)env * NL + lane] = tg;
+  }
+  if (lane < NB) S.parent[lane] = lane < nb ? m->b_parent[lane] : 0;
+  if (lane == 0) { S.ncon = 0; S.ncand = 0; }
+  WSYNC();
+
+  // ======================= forward kinematics (FK cache as in the 16-lane kernel) ====================
+  {
+    const bool cached = a.fkvalid[env] != 0;  // wave-uniform
+    if (cached) {
+      if (lane < nb) {
+        const float* p = a.poses + ((size_t)env * 2 * NB + lane) * 4;
+        stv(S.xpos[lane], *reinterpret_cast<const f4*>(p));
+        stv(S.xquat[lane], *reinterpret_cast<const f4*>(p + 4 * NB));
+      }
+      WSYNC();
+    } else {
+      wave_fk(S, lane, nb, bk);
+    }
+  }
+  const int nsteps = a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0);
+  for (int step = 0; step < nsteps; step++) {
+    // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
+    if (isdof) {
+      V3 ang = v3(0, 0, 0), lin = v3(0, 0, 0);
+      V3 r = ld3v(S.xpos[d_root]) - ld3v(S.xpos[d_body]);
+      if (d_kind < 2) {
+        V3 ax = qrot(ld4v(S.xquat[d_body]), d_axis);
+        if (d_kind == 0) { ang = ax; lin = cross(ax, r); }
+        else lin = ax;
+      } else {
+        V3 e = v3(d_axis_k == 0, d_axis_k == 1, d_axis_k == 2);
+        if (d_kind == 2) lin = e;
+        else { ang = e; lin = cross(e, r); }
+      }
+      st3v(&S.cdof[lane][0], ang);
+      st3v(&S.cdof[lane][4], lin);
+    } else {
+      st3v(&S.cdof[lane][0], v3(0, 0, 0));
+      st3v(&S.cdof[lane][4], v3(0, 0, 0));
+    }
+    if (lane < NB) {
+      float* c = S.dyn.cinert[lane];
+      if (isbody) {
+        M3 R = q2m(ld4v(S.xquat[lane]));
+        float Ib[3][3] = {{ib[0], ib[3], ib[4]}, {ib[3], ib[1], ib[5]}, {ib[4], ib[5], ib[2]}};
+        float Rm[3][3] = {{R.r0.x, R.r0.y, R.r0.z}, {R.r1.x, R.r1.y, R.r1.z}, {R.r2.x, R.r2.y, R.r2.z}};
+        float T[3][3], W[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) T[i][j] = Rm[i][0] * Ib[0][j] + Rm[i][1] * Ib[1][j] + Rm[i][2] * Ib[2][j];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) W[i][j] = T[i][0] * Rm[j][0] + T[i][1] * Rm[j][1] + T[i][2] * Rm[j][2];
+        V3 r = ld3v(S.xpos[lane]) + mmul(R, b_ipos) - ld3v(S.xpos[b_root]);
+        float rr = dot(r, r);
+        stv(c, f4{b_mass, b_mass * r.x, b_mass * r.y, b_mass * r.z});
+        stv(c + 4, f4{W[0][0] + b_mass * (rr - r.x * r.x), W[1][1] + b_mass * (rr - r.y * r.y), W[2][2] + b_mass * (rr - r.z * r.z),
+                      W[0][1] - b_mass * r.x * r.y});
+        stv(c + 8, f4{W[0][2] - b_mass * r.x * r.z, W[1][2] - b_mass * r.y * r.z, 0.0f, 0.0f});
+      } else {
+        stv(c, f4{0, 0, 0, 0}); stv(c + 4, f4{0, 0, 0, 0}); stv(c + 8, f4{0, 0, 0, 0});
+      }
+    }
+    WSYNC();
+
+    // ======================= velocities, composite inertias =====================================
+    {
+      if (isdof) {  // lane = dof: cdof_dot * qvel, "velocity before this dof" from the pre-mask
+        V3 pw = v3(0, 0, 0), pv = v3(0, 0, 0);
+        uint64_t mk = d_premask;
+        while (mk) {
+          int j = __ffsll((unsigned long long)mk) - 1;
+          mk &= mk - 1;
+          float qd = S.qvel[j];
+          pw = pw + qd * ld3v(&S.cdof[j][0]);
+          pv = pv + qd * ld3v(&S.cdof[j][4]);
+        }
+        V3 cw = ld3v(&S.cdof[lane][0]), cv = ld3v(&S.cdof[lane][4]);
+        float qd = S.qvel[lane];
+        st3v(&S.dyn.cddq[lane][0], qd * cross(pw, cw));
+        st3v(&S.dyn.cddq[lane][4], qd * (cross(pw, cv) + cross(pv, cw)));
+      } else {
+        st3v(&S.dyn.cddq[lane][0], v3(0, 0, 0));
+        st3v(&S.dyn.cddq[lane][4], v3(0, 0, 0));
+      }
+      if (lane < NB) {
+        V3 w = v3(0, 0, 0), v = v3(0, 0, 0);
+        f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0;
+        if (isbody) {  // lane = body: cvel, composite inertia over the subtree
+          uint64_t mk = b_dofmask;
+          while (mk) {
+            int j = __ffsll((unsigned long long)mk) - 1;
+            mk &= mk - 1;
+            float qd = S.qvel[j];
+            w = w + qd * ld3v(&S.cdof[j][0]);
+            v = v + qd * ld3v(&S.cdof[j][4]);
+          }
+          uint32_t sm = b_submask;
+          while (sm) {
+            int c = __ffs(sm) - 1;
+            sm &= sm - 1;
+            const float* p = S.dyn.cinert[c];
+            c0 += ldv(p); c1 += ldv(p + 4); c2 += ldv(p + 8);
+          }
+        }
+        st3v(&S.dyn.cvel[lane][0], w);
+        st3v(&S.dyn.cvel[lane][4], v);
+        float* p = S.dyn.crb[lane];
+        stv(p, c0); stv(p + 4, c1); stv(p + 8, c2);
+      }
+    }
+    WSYNC();
+
+    // ======================= body forces (RNE, qacc=0) and mass matrix rows =======================
+    {
+      if (lane < NB) {
+        V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
+        if (isbody) {
+          V3 aw = v3(0, 0, 0), av = v3(-m->gx, -m->gy, -m->gz);
+          uint64_t mk = b_dofmask;
+          while (mk) {
+            int j = __ffsll((unsigned long long)mk) - 1;
+            mk &= mk - 1;
+            aw = aw + ld3v(&S.dyn.cddq[j][0]);
+            av = av + ld3v(&S.dyn.cddq[j][4]);
+          }
+          Inert I = ldI(S.dyn.cinert[lane]);
+          V3 w = ld3v(&S.dyn.cvel[lane][0]), v = ld3v(&S.dyn.cvel[lane][4]);
+          V3 ta, fa, tv, fv;
+          imul(I, aw, av, ta, fa);
+          imul(I, w, v, tv, fv);
+          t = ta + cross(w, tv) + cross(v, fv);
+          f = fa + cross(w, fv);
+        }
+        st3v(&S.dyn.cfrc[lane][0], t);
+        st3v(&S.dyn.cfrc[lane][4], f);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{0, 0, 0, 0});
+    }
+    WSYNC();
+    if (isdof) {  // M[i][j] = cdof_j . (crb_body(i) cdof_i), j over ancestors-or-self (same tree => same block)
+      Inert I = ldI(S.dyn.crb[d_body]);
+      V3 bt, bf;
+      imul(I, ld3v(&S.cdof[lane][0]), ld3v(&S.cdof[lane][4]), bt, bf);
+      uint64_t mk = d_ancmask;
+      while (mk) {
+        int j = __ffsll((unsigned long long)mk) - 1;
+        mk &= mk - 1;
+        float val = dot(ld3v(&S.cdof[j][0]), bt) + dot(ld3v(&S.cdof[j][4]), bf);
+        if (j == lane) val += d_mdiag;
+        S.M[lane][j & 15] = val;
+        S.M[j][l16] = val;
+      }
+    }
+    float qfrc_bias = 0.0f, qfs = 0.0f;
+    if (isdof) {
+      V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
+      uint32_t sm = d_submask;
+      while (sm) {
+        int c = __ffs(sm) - 1;
+        sm &= sm - 1;
+        t = t + ld3v(&S.dyn.cfrc[c][0]);
+        f = f + ld3v(&S.dyn.cfrc[c][4]);
+      }
+      qfrc_bias = dot(ld3v(&S.cdof[lane][0]), t) + dot(ld3v(&S.cdof[lane][4]), f);
+      float qd = S.qvel[lane];
+      float fa = 0.0f;
+      if (d_ctrl == MIR_CTRL_POSITION) {
+        fa = d_kp * (S.target[lane] - S.qpos[d_qadr]) - d_kv * qd;
+        fa = fminf(fmaxf(fa, d_frclo), d_frchi);
+      }
+      qfs = -d_damping * qd + fa - qfrc_bias;
+    }
+    WSYNC();
+    // qacc_smooth = Mt^-1 qfrc_smooth: four block solves side by side (Gauss-Jordan on 16-wide register rows)
+    float mrow[G];
+    {
+      f4 r0 = ldv(&S.M[lane][0]), r1 = ldv(&S.M[lane][4]), r2 = ldv(&S.M[lane][8]), r3 = ldv(&S.M[lane][12]);
+      mrow[0] = r0.x; mrow[1] = r0.y; mrow[2] = r0.z; mrow[3] = r0.w; mrow[4] = r1.x; mrow[5] = r1.y; mrow[6] = r1.z; mrow[7] = r1.w;
+      mrow[8] = r2.x; mrow[9] = r2.y; mrow[10] = r2.z; mrow[11] = r2.w; mrow[12] = r3.x; mrow[13] = r3.y; mrow[14] = r3.z; mrow[15] = r3.w;
+    }
+    if (a.out_M && isdof && step == 0) {  // parity output in compact dof order (M is block-diagonal)
+      const int di = m->d_dof[lane];
+      for (int j = 0; j < nv; j++) a.out_M[((size_t)env * nv + di) * nv + j] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const int dj = m->d_dof[16 * blk + j];
+        if (dj >= 0) a.out_M[((size_t)env * nv + di) * nv + dj] = mrow[j] - (j == l16 ? d_mdiag - m->d_armature[lane] : 0.0f);
+      }
+    }
+    if (a.out_bias && isdof && step == 0) a.out_bias[(size_t)env * nv + m->d_dof[lane]] = qfrc_bias;
+    float qas;
+    {
+      float arow[G];
+#pragma unroll
+      for (int j = 0; j < G; j++) arow[j] = isdof ? mrow[j] : (j == l16 ? 1.0f : 0.0f);
+      qas = isdof ? qfs : 0.0f;
+      GJ<0>::run(arow, qas, l16);
+    }
+    S.qas[lane] = qas;
+    S.qacc[lane] = qas;
+    if (a.out_qas && isdof && step == 0) a.out_qas[(size_t)env * nv + m->d_dof[lane]] = qas;
+    WSYNC();  // dyn scratch is dead from here on
+
+    // ======================= collision detection ================================================
+    if (lane == 0) { S.ncon = 0; S.ncand = 0; }
+    if (lane < ngeom) {
+      const int gb = m->g_body[lane];
+      Q4 qb = ld4v(S.xquat[gb]);
+      st3v(S.col.gpos[lane], ld3v(S.xpos[gb]) + qrot(qb, ld3(m->g_pos[lane])));
+      st4v(S.col.gquat[lane], qmul(qb, ld4(m->g_quat[lane])));
+    }
+    S.col.ccount[lane] = 0;
+    WSYNC();
+    int mycount = 0;
+    int ncand = 0;
+    if (enable_collision) {
+      // broadphase: bounding test per static candidate pair, ordered compaction of survivors (lane = pair)
+      int base = 0;
+      for (int p0 = 0; p0 < npair; p0 += NL) {
+        int p = p0 + lane;
+        bool hit = false;
+        if (p < npair) {
+          const int pr = m->pair[p];
+          const int g1 = pr & 255, g2 = pr >> 8;
+          V3 h2 = ld3(m->g_size[g2]);
+          M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+          V3 c2 = ld3v(S.col.gpos[g2]);
+          if (m->g_type[g1] == MIR_GEOM_PLANE) {
+            V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
+            float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
+            hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
+          } else {
+            V3 h1 = ld3(m->g_size[g1]);
+            float rs = sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
+            V3 dc = c2 - ld3v(S.col.gpos[g1]);
+            hit = dot(dc, dc) <= rs * rs;
+          }
+        }
+        const unsigned long long bal = __ballot(hit);
+        int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && pos < NL) S.col.cand[pos] = p;
+        base += __popcll(bal);
+      }
+      ncand = base < NL ? base : NL;
+      if (lane == 0) S.ncand = ncand;
+      WSYNC();
+      // narrowphase, plane-box: DPP row r takes candidates r, r + 4, ...; the 8 box corners on lanes 0..7 of the row
+      for (int k0 = 0; k0 < ncand; k0 += 4) {
+        const int k = k0 + blk;
+        const bool act = k < ncand;
+        const int pr = act ? m->pair[S.col.cand[k]] : 0;
+        const int g1 = pr & 255, g2 = pr >> 8;
+        const bool isplane = act && m->g_type[g1] == MIR_GEOM_PLANE;
+        if (!__any(isplane)) continue;
+        const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
+        const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
+        const M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+        const V3 h = ld3(m->g_size[g2]);
+        const int c = lane & 7;
+        const V3 w = ld3v(S.col.gpos[g2]) + ((c & 1) ? h.x : -h.x) * mcol(R2, 0) + ((c & 2) ? h.y : -h.y) * mcol(R2, 1) +
+                     ((c & 4) ? h.z : -h.z) * mcol(R2, 2);
+        const V3 rel = w - ld3v(S.col.gpos[g1]);
+        const float d = dot(rel, n), u = dot(rel, eu), v = dot(rel, ev);
+        const bool pen = isplane && l16 < 8 && d < 0.0f;
+        const uint32_t penm = (uint32_t)(__ballot(pen) >> (blk * G)) & 0xffu;
+        const int cnt = __popc(penm);
+        // support extremes (+u, -u, +v, -v; lowest corner index wins ties) when more than 4 corners penetrate
+        const float uM = gmaxf(pen ? u : -3e38f), um = -gmaxf(pen ? -u : -3e38f);
+        const float vM = gmaxf(pen ? v : -3e38f), vm = -gmaxf(pen ? -v : -3e38f);
+        const uint32_t e0 = (uint32_t)(__ballot(pen && u == uM) >> (blk * G)) & 0xffu, e1 = (uint32_t)(__ballot(pen && u == um) >> (blk * G)) & 0xffu;
+        const uint32_t e2 = (uint32_t)(__ballot(pen && v == vM) >> (blk * G)) & 0xffu, e3 = (uint32_t)(__ballot(pen && v == vm) >> (blk * G)) & 0xffu;
+        const uint32_t ext = (e0 & -e0) | (e1 & -e1) | (e2 & -e2) | (e3 & -e3);
+        const uint32_t keepm = cnt <= 4 ? penm : ext;
+        const bool keep = (keepm >> l16 & 1u) && l16 < 8;
+        const int slot = __popc(keepm & ((1u << l16) - 1u));
+        if (isplane && keep && slot < 4) {
+          const V3 pos = w - (0.5f * d) * n;
+          stv(S.col.stage[k][slot], f4{pos.x, pos.y, pos.z, d});
+        }
+        if (isplane && l16 == 0) {
+          S.col.ccount[k] = min(__popc(keepm), 4);
+          st3v(S.col.snorm[k], n);
+        }
+      }
+      WSYNC();
+      mycount = S.col.ccount[lane];
+      // narrowphase, box-box: one lane per candidate
+      if (lane < ncand) {
+        const int pr = m->pair[S.col.cand[lane]];
+        const int g1 = pr & 255, g2 = pr >> 8;
+        if (m->g_type[g1] != MIR_GEOM_PLANE) {
+          M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+          BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(m->g_size[g2])};
+          M3 R1 = q2m(ld4v(S.col.gquat[g1]));
+          BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(m->g_size[g1])};
+          V3 n = v3(0, 0, 1);
+          mycount = box_box(B1, B2, S.col.stage[lane], n);
+          st3v(S.col.snorm[lane], n);
+        }
+      }
+    }
+    // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
+    const int maxc = max_contacts < MAXC ? max_contacts : MAXC;
+    int ncon;
+    {
+      float inclf = (float)mycount;
+      inclf += row_shr<1>(inclf);
+      inclf += row_shr<2>(inclf);
+      inclf += row_shr<4>(inclf);
+      inclf += row_shr<8>(inclf);
+      const float r0 = rl(inclf, 15), r1 = rl(inclf, 31), r2 = rl(inclf, 47), r3 = rl(inclf, 63);
+      const float rowbase = blk == 0 ? 0.0f : (blk == 1 ? r0 : (blk == 2 ? r0 + r1 : r0 + r1 + r2));
+      const int incl = (int)(inclf + rowbase);
+      const int off = incl - mycount;
+      const int total = (int)(r0 + r1 + r2 + r3);
+      ncon = total < maxc ? total : maxc;
+      if (lane == 0) S.ncon = ncon;
+      for (int c = 0; c < mycount; c++)
+        if (off + c < maxc) S.col.cmap[off + c] = lane * 8 + c;
+      WSYNC();
+      // every contact is finished by its own lane (staging lives in col scratch, disjoint from the contact arrays)
+      if (lane < ncon) {
+        const int k = lane;
+        const int mp = S.col.cmap[k];
+        const int cl = mp >> 3, ci = mp & 7;
+        const int pr = m->pair[S.col.cand[cl]];
+        const int g1 = pr & 255, g2 = pr >> 8;
+        const V3 n = ld3v(S.col.snorm[cl]);
+        V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
+        t1 = t1 - dot(n, t1) * n;
+        t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
+        const V3 t2 = cross(n, t1);
+        const float mu = fmaxf(m->g_pos[g1][3], m->g_pos[g2][3]);
+        const float* s1 = m->g_sol[g1];
+        const float* s2 = m->g_sol[g2];
+        const float sr0 = 0.5f * (s1[0] + s2[0]), sr1 = 0.5f * (s1[1] + s2[1]);
+        const float si[5] = {0.5f * (s1[2] + s2[2]), 0.5f * (s1[3] + s2[3]), 0.5f * (s1[4] + s2[4]), 0.5f * (s1[5] + s2[5]), 0.5f * (s1[6] + s2[6])};
+        const int b1 = m->g_body[g1], b2 = m->g_body[g2];
+        const float wsumw = m->b_invweight0[b1] + m->b_invweight0[b2];
+        const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
+        const float tc = fmaxf(sr0, 2.0f * dt);
+        const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
+        const uint64_t dm1 = m->b_dofmask[b1], dm2 = m->b_dofmask[b2];
+        const int k1 = m->b_block[b1], k2 = m->b_block[b2];
+        const int sg0 = k1 >= 0 ? k1 : k2, sg1 = (k1 >= 0 && k2 >= 0 && k2 != k1) ? k2 : -1;
+        const V3 ref1 = ld3v(S.xpos[m->b_root[b1]]), ref2 = ld3v(S.xpos[m->b_root[b2]]);
+        const f4 pd = ldv(S.col.stage[cl][ci]);
+        const float dist = pd.w;
+        stv(S.con.cpos[k], pd);
+        st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
+        const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
+        const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsumw * (1.0f + mu * mu), 1e-15f);
+        stv(S.con.cmeta[k], f4{mu, 1.0f / Rr, -kk * imp * dist, bb});
+        st3v(&S.con.cref[k][0], ref1); st3v(&S.con.cref[k][4], ref2);
+        S.con.cmask[k][0] = (unsigned)dm1; S.con.cmask[k][1] = (unsigned)(dm1 >> 32);
+        S.con.cmask[k][2] = (unsigned)dm2; S.con.cmask[k][3] = (unsigned)(dm2 >> 32);
+        S.con.cblk[k][0] = sg0; S.con.cblk[k][1] = sg1; S.con.cblk[k][2] = 0; S.con.cblk[k][3] = 0;
+      }
+    }
+    WSYNC();  // col scratch is dead from here on (Jb may overwrite it)
+
+    // ======================= constraint rows ======================================================
+    // contact base Jacobians: lane = dof writes its entry of the segment its block owns (zeros included, so a
+    // segment is always fully defined)
+    for (int c = 0; c < ncon; c++) {
+      const int sg0 = S.con.cblk[c][0], sg1 = S.con.cblk[c][1];
+      const int myseg = blk == sg0 ? 0 : (blk == sg1 ? 1 : -1);
+      if (myseg < 0) continue;
+      float jn = 0.0f, j1 = 0.0f, j2 = 0.0f;
+      const uint64_t dm1 = (uint64_t)S.con.cmask[c][0] | ((uint64_t)S.con.cmask[c][1] << 32);
+      const uint64_t dm2 = (uint64_t)S.con.cmask[c][2] | ((uint64_t)S.con.cmask[c][3] << 32);
+      const bool in2 = dm2 >> lane & 1ull, in1 = dm1 >> lane & 1ull;
+      const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f);  // a dof moving both bodies cancels
+      if (sgn != 0.0f) {
+        V3 r = ld3v(S.con.cpos[c]) - ld3v(&S.con.cref[c][in2 ? 4 : 0]);
+        V3 vel = cross(ld3v(&S.cdof[lane][0]), r) + ld3v(&S.cdof[lane][4]);
+        jn = sgn * dot(vel, ld3v(&S.con.cfrm[c][0]));
+        j1 = sgn * dot(vel, ld3v(&S.con.cfrm[c][4]));
+        j2 = sgn * dot(vel, ld3v(&S.con.cfrm[c][8]));
+      }
+      float* jb = &S.Jb[c][myseg][0];
+      jb[l16] = jn; jb[16 + l16] = j1; jb[32 + l16] = j2;
+    }
+    // joint-limit rows: lane = dof, lane-private
+    float lsg = 0.0f, lD = 0.0f, laref = 0.0f;
+    if (d_limited) {
+      float q = S.qpos[d_qadr];
+      float dlo = q - m->d_lo[lane], dhi = m->d_hi[lane] - q;
+      float pos = 0.0f;
+      if (dlo < 0.0f) { pos = dlo; lsg = 1.0f; }
+      else if (dhi < 0.0f) { pos = dhi; lsg = -1.0f; }
+      if (lsg != 0.0f) {
+        const float* si = m->d_solimp[lane];
+        float imp = impedance(si[0], si[1], si[2], si[3], si[4], pos);
+        float Rr = fmaxf((1.0f - imp) / imp * m->d_invweight0[lane], 1e-15f);
+        lD = 1.0f / Rr;
+        laref = -m->d_b[lane] * (lsg * S.qvel[lane]) - m->d_k[lane] * imp * pos;
+      }
+    }
+    WSYNC();
+    // contact rows, lane = contact, lane-private: aref_r = -b (J_r qvel) - k imp dist
+    const bool iscon = lane < ncon;
+    float cmu = 0.0f, cD = 0.0f;
+    float aref[4] = {0, 0, 0, 0}, jar[4] = {0, 0, 0, 0};
+    if (iscon) {
+      float vn, v1, v2;
+      condot3(S, lane, S.qvel, vn, v1, v2);
+      f4 mt = ldv(S.con.cmeta[lane]);
+      cmu = mt.x; cD = mt.y;
+      const float base = mt.z, bb = mt.w;
+      aref[0] = base - bb * (vn + cmu * v1);
+      aref[1] = base - bb * (vn - cmu * v1);
+      aref[2] = base - bb * (vn + cmu * v2);
+      aref[3] = base - bb * (vn - cmu * v2);
+    }
+
+    // ======================= primal Newton solve ====================================================
+    const unsigned long long limmask = __ballot(lsg != 0.0f);
+    const int nefc = 4 * ncon + __popcll(limmask);
+    bool done = nefc == 0;
+    float qacc = qas, Ma = 0.0f, ljar = 0.0f;
+    const float* xblk_srch = &S.srch[16 * blk];
+    const float* xblk_qacc = &S.qacc[16 * blk];
+    {
+      // warm start: cost(ws) vs cost(qacc_smooth); Gauss part 1/2 dq^T Mt dq
+      const float ws = S.qacc_ws[lane];
+      const float dq = isdof ? ws - qas : 0.0f;
+      S.srch[lane] = dq;
+      WSYNC();
+      float c_ws = isdof ? 0.5f * rowdot(mrow, xblk_srch) * dq : 0.0f, c_sm = 0.0f;
+      const float ljs = lsg * qas - laref, ljw = lsg * ws - laref;
+      if (lsg != 0.0f) {
+        if (ljs < 0.0f) c_sm += 0.5f * lD * ljs * ljs;
+        if (ljw < 0.0f) c_ws += 0.5f * lD * ljw * ljw;
+      }
+      float js[4] = {0, 0, 0, 0}, jw[4] = {0, 0, 0, 0};
+      if (iscon) {
+        float sn, s1, s2, wn, w1, w2;
+        condot3(S, lane, S.qas, sn, s1, s2);
+        condot3(S, lane, S.qacc_ws, wn, w1, w2);
+        js[0] = sn + cmu * s1 - aref[0]; js[1] = sn - cmu * s1 - aref[1]; js[2] = sn + cmu * s2 - aref[2]; js[3] = sn - cmu * s2 - aref[3];
+        jw[0] = wn + cmu * w1 - aref[0]; jw[1] = wn - cmu * w1 - aref[1]; jw[2] = wn + cmu * w2 - aref[2]; jw[3] = wn - cmu * w2 - aref[3];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (js[r] < 0.0f) c_sm += 0.5f * cD * js[r] * js[r];
+          if (jw[r] < 0.0f) c_ws += 0.5f * cD * jw[r] * jw[r];
+        }
+      }
+      c_ws = wsum(c_ws);
+      c_sm = wsum(c_sm);
+      const bool usews = c_ws < c_sm;
+      qacc = usews ? ws : qas;
+      ljar = usews ? ljw : ljs;
+#pragma unroll
+      for (int r = 0; r < 4; r++) jar[r] = usews ? jw[r] : js[r];
+      WSYNC();
+      S.qacc[lane] = qacc;
+      WSYNC();
+      Ma = isdof ? rowdot(mrow, xblk_qacc) : 0.0f;
+    }
+    int niter = 0;
+    const float tol = m->tolerance, scale = m->solver_scale;
+    const float gfloor = 16.0f * 5.96e-8f * sqrtf(wsum(Ma * Ma + qfs * qfs));
+    // Hessian row kept across iterations (incremental update, as in the 16-lane kernel); 64 registers
+    float hkeep[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) hkeep[j] = j == lane ? 1.0f : 0.0f;
+    if (isdof) {
+#pragma unroll
+      for (int bq = 0; bq < 4; bq++)
+        if (bq == blk) {
+#pragma unroll
+          for (int j = 0; j < G; j++) hkeep[16 * bq + j] = mrow[j];
+        }
+    }
+    float oldlact = 0.0f;
+    unsigned prevbits = 0u;
+    float gprev = 0.0f;
+    for (int it = 0; it < m->iterations; it++) {
+      if (done) break;  // wave-uniform: one env per wave
+      float lact = (lsg != 0.0f && ljar < 0.0f) ? lD : 0.0f;
+      const float lf = -lact * ljar;
+      if (iscon) {
+        float f[4];
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const bool on = jar[r] < 0.0f;
+          f[r] = on ? -cD * jar[r] : 0.0f;
+          bits |= on ? (1u << r) : 0u;
+        }
+        stv(S.con.cfb[lane], f4{f[0] + f[1] + f[2] + f[3], cmu * (f[0] - f[1]), cmu * (f[2] - f[3]), (float)(bits | (prevbits << 4))});
+        prevbits = bits;
+      }
+      WSYNC();
+      // ---- gradient first (cheap): convergence is decided before any Hessian work
+      float g = isdof ? Ma - qfs - lsg * lf : 0.0f;
+      for (int c = 0; c < ncon; c++) {
+        const int sg0 = S.con.cblk[c][0], sg1 = S.con.cblk[c][1];
+        const int myseg = blk == sg0 ? 0 : (blk == sg1 ? 1 : -1);
+        if (myseg < 0) continue;
+        const float* jb = &S.Jb[c][myseg][0];
+        const f4 fb = ldv(S.con.cfb[c]);
+        g -= jb[l16] * fb.x + jb[16 + l16] * fb.y + jb[32 + l16] * fb.z;
+      }
+      if (!isdof) g = 0.0f;
+      const float gn = sqrtf(wsum(g * g));
+      if (scale * gn < tol || gn < gfloor) { done = true; break; }
+      // ---- Hessian row (lane = dof): incremental update of H = Mt + J^T D_active J
+#pragma unroll
+      for (int j = 0; j < NL; j++) hkeep[j] += j == lane ? lact - oldlact : 0.0f;
+      oldlact = lact;
+      for (int c = 0; c < ncon; c++) {
+        const f4 fb = ldv(S.con.cfb[c]);
+        const unsigned both = (unsigned)fb.w;
+        const unsigned bits = both & 15u, old = both >> 4;
+        if (bits == old) continue;  // wave-uniform
+        const int sg0 = __builtin_amdgcn_readfirstlane(S.con.cblk[c][0]), sg1 = __builtin_amdgcn_readfirstlane(S.con.cblk[c][1]);
+        const int myseg = blk == sg0 ? 0 : (blk == sg1 ? 1 : -1);
+        float jn = 0.0f, j1 = 0.0f, j2 = 0.0f;
+        if (myseg >= 0) {
+          const float* jb = &S.Jb[c][myseg][0];
+          jn = jb[l16]; j1 = jb[16 + l16]; j2 = jb[32 + l16];
+        }
+        const f4 mt = ldv(S.con.cmeta[c]);
+        const float mu = mt.x, D = mt.y;
+        const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
+        const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
+        const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
+        const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
+        if (sg0 >= 0) hupd_blk(hkeep, sg0, &S.Jb[c][0][0], tn, t1, t2);
+        if (sg1 >= 0) hupd_blk(hkeep, sg1, &S.Jb[c][1][0], tn, t1, t2);
+      }
+      float hrow[NL];
+#pragma unroll
+      for (int j = 0; j < NL; j++) hrow[j] = hkeep[j];
+      // ---- Newton direction: H s = -g (dense over the wave)
+      float sv = -g;
+      GJW<0>::run(hrow, sv, lane, lanemask);
+      if (!isdof) sv = 0.0f;
+      S.srch[lane] = sv;
+      WSYNC();
+      const float mv = isdof ? rowdot(mrow, xblk_srch) : 0.0f;
+      const float ljv = lsg * sv;
+      float jv[4] = {0, 0, 0, 0};
+      if (iscon) {
+        float xn, x1, x2;
+        condot3(S, lane, S.srch, xn, x1, x2);
+        jv[0] = xn + cmu * x1; jv[1] = xn - cmu * x1; jv[2] = xn + cmu * x2; jv[3] = xn - cmu * x2;
+      }
+      // ---- exact line search on the piecewise-quadratic phi(alpha): safeguarded Newton on phi'
+      const float A = wsum(sv * mv), Bq = wsum(sv * (Ma - qfs));
+      float alpha = 0.0f, lo = 0.0f, hi = -1.0f, g0 = 0.0f;
+      bool lsdone = false;
+      for (int ls = 0; ls < m->ls_iterations; ls++) {
+        float pg = 0.0f, ph = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float x = jar[r] + alpha * jv[r];
+          if (x < 0.0f) { pg += cD * jv[r] * x; ph += cD * jv[r] * jv[r]; }
+        }
+        {
+          const float x = ljar + alpha * ljv;
+          if (x < 0.0f) { pg += lD * ljv * x; ph += lD * ljv * ljv; }
+        }
+        const float gg = wsum(pg) + alpha * A + Bq, hh = wsum(ph) + A;
+        if (ls == 0) { g0 = gg; if (g0 >= 0.0f) lsdone = true; }
+        if (!lsdone && fabsf(gg) <= 1e-6f * fabsf(g0)) lsdone = true;
+        if (!lsdone) {
+          if (gg < 0.0f) lo = alpha; else hi = alpha;
+          float an = alpha - gg / hh;
+          if (hi >= 0.0f && (an <= lo || an >= hi)) an = 0.5f * (lo + hi);
+          if (an == alpha) lsdone = true;
+          alpha = an;
+        }
+        if (lsdone) break;  // wave-uniform
+      }
+      // ---- improvement from the 1-D model, then the update (row-cost differences as 1/2 D d (2 x0 + d))
+      float pim = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float x0 = jar[r], d = alpha * jv[r], x1 = x0 + d;
+        pim -= (x0 < 0.0f && x1 < 0.0f) ? 0.5f * cD * d * (2.0f * x0 + d)
+               : ((x1 < 0.0f ? 0.5f * cD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * cD * x0 * x0 : 0.0f));
+      }
+      {
+        const float x0 = ljar, d = alpha * ljv, x1 = x0 + d;
+        pim -= (x0 < 0.0f && x1 < 0.0f) ? 0.5f * lD * d * (2.0f * x0 + d)
+               : ((x1 < 0.0f ? 0.5f * lD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * lD * x0 * x0 : 0.0f));
+      }
+      const float improvement = wsum(pim) - (0.5f * alpha * alpha * A + alpha * Bq);
+      const float moved = wsum((isdof && qacc + alpha * sv != qacc) ? 1.0f : 0.0f);
+      const bool stagnant = it > 0 && gn > 0.5f * gprev && gn < 4.0f * gfloor;
+      gprev = gn;
+      niter = it + 1;
+      if (moved == 0.0f || stagnant) { done = true; }
+      if (!done) {
+        qacc += alpha * sv;
+        Ma += alpha * mv;
+        ljar += alpha * ljv;
+#pragma unroll
+        for (int r = 0; r < 4; r++) jar[r] += alpha * jv[r];
+        if (scale * improvement < tol) done = true;
+      }
+      if (!done) {
+        // if the step crossed no row boundary the new gradient is exactly (1 - alpha) g
+        float crossed = (ljar - alpha * ljv < 0.0f) != (ljar < 0.0f) && lsg != 0.0f ? 1.0f : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) crossed += ((jar[r] - alpha * jv[r] < 0.0f) != (jar[r] < 0.0f)) ? 1.0f : 0.0f;
+        const float ncross = wsum(crossed);
+        const float gnew = fabsf(1.0f - alpha) * gn;
+        if (ncross == 0.0f && (scale * gnew < tol || gnew < gfloor)) done = true;
+      }
+      WSYNC();
+    }
+    if (a.out_qacc && isdof && step == 0) a.out_qacc[(size_t)env * nv + m->d_dof[lane]] = qacc;
+    if (a.diag && lane == 0) {
+      a.diag[(size_t)env * 4 + 0] = ncon;
+      a.diag[(size_t)env * 4 + 1] = nefc;
+      a.diag[(size_t)env * 4 + 2] = niter;
+      a.diag[(size_t)env * 4 + 3] = ncand;
+    }
+    if (a.mode != 0) break;
+
+    // ======================= integrate ==============================================================
+    WSYNC();
+    if (isdof) {
+      S.qvel[lane] += dt * qacc;
+      S.qacc_ws[lane] = qacc;
+    }
+    WSYNC();
+    if (isdof) {
+      const float qd = S.qvel[lane];
+      if (d_kind < 2) S.qpos[d_qadr] += dt * qd;
+      else if (d_kind == 2) S.qpos[d_qbase + d_axis_k] += dt * qd;
+      else if (d_axis_k == 0) {
+        V3 w = v3(S.qvel[d_lbase + 3], S.qvel[d_lbase + 4], S.qvel[d_lbase + 5]);
+        float wn = sqrtf(dot(w, w));
+        float ang = wn * dt;
+        if (ang > 1e-15f) {
+          float sn, cs;
+          sincosf(0.5f * ang, &sn, &cs);
+          V3 ax = (1.0f / wn) * w;
+          Q4 dq = {cs, ax.x * sn, ax.y * sn, ax.z * sn};
+          st4(&S.qpos[d_qbase + 3], qnormalize(qmul(dq, ld4(&S.qpos[d_qbase + 3]))));
+        }
+      }
+    }
+    WSYNC();
+    // kinematics of the new state: observations of this step, and the next step's starting poses
+    wave_fk(S, lane, nb, bk);
+  }  // steps
+  if (lane < nb) {
+    float* p = a.poses + ((size_t)env * 2 * NB + lane) * 4;
+    *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
+    *reinterpret_cast<f4*>(p + 4 * NB) = ldv(S.xquat[lane]);
+  }
+  if (lane == 0) a.fkvalid[env] = 1;
+  // ---- store state ---------------------------------------------------------------------------------
+  if (a.mode == 0) {
+    a.qpos[(size_t)env * K64_QSTRIDE + lane] = S.qpos[lane];
+    a.qvel[(size_t)env * NL + lane] = S.qvel[lane];
+    a.qacc_ws[(size_t)env * NL + lane] = S.qacc_ws[lane];
+  }
+  (void)nq;
+  // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
+  const int eb = m->eef_body, ob = m->obj_body, ob2 = m->obj2_body;
+  const int ad = m->agent_dim, ed = m->env_dim;
+  const V3 pe = ld3v(S.xpos[eb]), po = ld3v(S.xpos[ob]);
+  const V3 df = pe - po;
+  float rew;
+  if (m->reward_mode == MIR_REWARD_STACK) {
+    const V3 p2 = ld3v(S.xpos[ob2]);
+    const float dx = po.x - p2.x, dy = po.y - p2.y;
+    rew = (sqrtf(dx * dx + dy * dy) < m->reward_xy && po.z - p2.z > m->reward_dz) ? 1.0f : 0.0f;
+  } else {
+    rew = po.z > m->reward_z ? 1.0f : 0.0f;
+  }
+  // column c of the packed row [agent_pos | env_state | reward | terminated]
+  auto column = [&](int c) -> float {
+    if (c < ad) {
+      if (m->agent_mode == MIR_AGENT_QPOS) return S.qpos[m->arm_qadr[c]];
+      if (c < 3) return S.xpos[eb][c];
+      if (c < 7) return S.xquat[eb][c - 3];
+      return S.qpos[m->grip_qadr[c - 7]];
+    }
+    const int k = c - ad;
+    if (k < 3) return S.xpos[ob][k];
+    if (k < 7) return S.xquat[ob][k - 3];
+    if (k < 10) return k == 7 ? df.x : (k == 8 ? df.y : df.z);
+    if (k == 10) return sqrtf(dot(df, df));
+    if (k < ed) return S.xpos[ob2][k - 11];
+    return rew;  // k == ed reward, k == ed + 1 terminated
+  };
+  if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
+  if (a.env_state && lane < ed) a.env_state[(size_t)env * ed + lane] = column(ad + lane);
+  if (lane == 0) {
+    if (a.reward) a.reward[env] = rew;
+    if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
+  }
+  if (a.rows && lane < ad + ed + 2) a.rows[(size_t)env * a.row_stride + lane] = column(lane);
+  if (a.out_xpos && lane < nb) {
+    st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3v(S.xpos[lane]));
+    st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));
+  }
+}
+
+}  // namespace
+
+extern "C" int mir_launch_step64(const StepArgs64* args, hipStream_t stream) {
+  StepArgs64 a = *args;
+  hipLaunchKernelGGL(mir_step64_kernel, dim3(a.B), dim3(64), 0, stream, a);
+  return (int)hipGetLastError();
+}

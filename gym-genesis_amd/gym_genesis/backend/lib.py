@@ -62,7 +62,7 @@ def load_library() -> C.CDLL:
                  "mir_step", "mir_step_fused", "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links",
                  "mir_get_diag", "mir_forward"):
         getattr(lib, name).restype = C.c_int
-    if lib.mir_spec_sizeof() != C.sizeof(MirSceneSpec) or lib.mir_version() != 1 or lib.mir_visual_sizeof() != C.sizeof(MirVisualSpec):
+    if lib.mir_spec_sizeof() != C.sizeof(MirSceneSpec) or lib.mir_version() != 2 or lib.mir_visual_sizeof() != C.sizeof(MirVisualSpec):
         raise MirError("libmirigid.so ABI mismatch with gym_genesis.backend.spec (rebuild the library)")
     _lib = lib
     return lib
@@ -89,6 +89,7 @@ class MirScene:
         self._check(self.lib.mir_get_dims(self.h, C.byref(d)))
         self.num_envs, self.nbody, self.nq, self.nv = d.num_envs, d.nbody, d.nq, d.nv
         self.ngeom, self.npair, self.agent_dim, self.env_dim = d.ngeom, d.npair, d.agent_dim, d.env_dim
+        self.nfree, self.kernel = d.nfree, d.kernel
         self.nu = sum(1 for i in range(spec.ndof) if spec.dof[i].ctrl_mode == 1)
         self.n_arm = sum(1 for b in range(1, spec.nbody) if spec.body[b].jtype in (1, 2))
 
@@ -100,14 +101,22 @@ class MirScene:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _f32(self, t, cols: int) -> torch.Tensor:
-        """Accept torch (any device) or NumPy, return a contiguous f32 device tensor (B, cols)."""
+    def _f32(self, t, *cols: int) -> torch.Tensor:
+        """Accept torch (any device) or NumPy, return a contiguous f32 device tensor (B, *cols)."""
         if not isinstance(t, torch.Tensor):
             t = torch.as_tensor(np.asarray(t))
         t = t.to(device=self.device, dtype=torch.float32).contiguous()
-        if t.shape != (self.num_envs, cols):
-            raise ValueError(f"expected shape {(self.num_envs, cols)}, got {tuple(t.shape)}")
+        if t.shape != (self.num_envs, *cols):
+            raise ValueError(f"expected shape {(self.num_envs, *cols)}, got {tuple(t.shape)}")
         return t
+
+    def _free(self, t, k: int) -> torch.Tensor:
+        """Free-body poses: (B, nfree, k); (B, k) is accepted when the scene has one free body."""
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        if t.dim() == 2 and self.nfree == 1:
+            t = t.unsqueeze(1)
+        return self._f32(t, self.nfree, k)
 
     def empty(self, *shape, dtype=torch.float32) -> torch.Tensor:
         return torch.empty((self.num_envs, *shape), dtype=dtype, device=self.device)
@@ -133,8 +142,8 @@ class MirScene:
         return dw, bw, mi.value
 
     def reset(self, obj_pos, obj_quat, arm_qpos, env_mask: Optional[torch.Tensor] = None) -> None:
-        p = self._f32(obj_pos, 3)
-        q = self._f32(obj_quat, 4)
+        p = self._free(obj_pos, 3)   # all free bodies in body order (one for the pick scenes)
+        q = self._free(obj_quat, 4)
         a = self._f32(arm_qpos, self.n_arm)
         mk = None
         if env_mask is not None:

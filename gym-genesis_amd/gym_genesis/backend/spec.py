@@ -10,14 +10,19 @@ import ctypes as C
 import math
 from typing import List, Optional, Sequence
 
-MIR_VERSION = 1
-MIR_MAX_BODY = 16
-MIR_MAX_DOF = 15
-MIR_MAX_Q = 18
-MIR_MAX_GEOM = 24
-MIR_MAX_PAIR = 64
-MIR_MAX_CONTACT = 16
+MIR_VERSION = 2
+MIR_MAX_BODY = 32
+MIR_MAX_DOF = 48
+MIR_MAX_Q = 56
+MIR_MAX_GEOM = 40
+MIR_MAX_PAIR = 256
+MIR_MAX_CONTACT = 64
 MIR_MAX_GRIP = 4
+MIR_MAX_FREE = 8
+# limits of the 16-lanes-per-env kernel (the pick tasks); larger scenes run on the wave-per-env kernel
+K16_MAX_CONTACT = 16
+REWARD_LIFT, REWARD_STACK = 0, 1
+AGENT_EEF, AGENT_QPOS = 0, 1
 
 JNT_FIXED, JNT_REVOLUTE, JNT_PRISMATIC, JNT_FREE = 0, 1, 2, 3
 GEOM_PLANE, GEOM_BOX = 0, 1
@@ -94,6 +99,12 @@ class MirTaskSpec(C.Structure):
         ("n_grip", C.c_int32),
         ("grip_dof", C.c_int32 * MIR_MAX_GRIP),
         ("reward_z", C.c_double),
+        ("obj2_body", C.c_int32),
+        ("reward_mode", C.c_int32),
+        ("agent_mode", C.c_int32),
+        ("_pad", C.c_int32),
+        ("reward_xy", C.c_double),
+        ("reward_dz", C.c_double),
     ]
 
 
@@ -123,6 +134,8 @@ class MirDims(C.Structure):
         ("npair", C.c_int32),
         ("agent_dim", C.c_int32),
         ("env_dim", C.c_int32),
+        ("nfree", C.c_int32),
+        ("kernel", C.c_int32),
     ]
 
 
@@ -187,7 +200,7 @@ class SceneBuilder:
         self.dof_names: List[str] = []
         self.opt = dict(dt=0.01, gravity=(0.0, 0.0, -9.81), tolerance=1e-8, ls_tolerance=0.01, iterations=50,
                         ls_iterations=50, enable_collision=1, enable_joint_limit=1, enable_self_collision=0,
-                        enable_adjacent_collision=0, max_contacts=MIR_MAX_CONTACT, implicit_damping=1)
+                        enable_adjacent_collision=0, max_contacts=K16_MAX_CONTACT, implicit_damping=1)
         self.task = dict(eef_body=0, obj_body=0, grip_dof=(), reward_z=0.1)
 
     # -- bodies -----------------------------------------------------------------------------
@@ -260,6 +273,10 @@ class SceneBuilder:
         for i, g in enumerate(t["grip_dof"]):
             s.task.grip_dof[i] = g
         s.task.reward_z = t["reward_z"]
+        s.task.obj2_body = t.get("obj2_body", -1)
+        s.task.reward_mode = t.get("reward_mode", REWARD_LIFT)
+        s.task.agent_mode = t.get("agent_mode", AGENT_EEF)
+        s.task.reward_xy, s.task.reward_dz = t.get("reward_xy", 0.05), t.get("reward_dz", 0.03)
         for i, b in enumerate(self.bodies):
             sb = s.body[i]
             sb.parent, sb.jtype, sb.mass = b["parent"], b["jtype"], b["mass"]

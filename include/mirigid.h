@@ -41,16 +41,20 @@
 extern "C" {
 #endif
 
-#define MIR_VERSION 1
+#define MIR_VERSION 2
 
-/* capacity limits of the spec (and of the kernels' LDS arenas) */
-#define MIR_MAX_BODY 16 /* including world = body 0 */
-#define MIR_MAX_DOF 15  /* nv (one lane of a 16-lane env group stays free for the solver) */
-#define MIR_MAX_Q 18    /* nq */
-#define MIR_MAX_GEOM 24
-#define MIR_MAX_PAIR 64    /* candidate geom pairs after static filtering */
-#define MIR_MAX_CONTACT 16 /* contacts kept per env per step (plane-box <= 4, box-box <= 8 per pair) */
+/* capacity limits of the spec.  Two step kernels sit behind the ABI: scenes with nv <= 15, nbody <= 16,
+ * ngeom <= 24, <= 64 candidate pairs and max_contacts <= 16 (the pick tasks) run on the 16-lanes-per-env kernel
+ * (4 envs per wave); anything larger (the 5-cube stack tasks) on the wave-per-env kernel, whose limits these are.
+ * Every kinematic tree must have <= 16 dofs. */
+#define MIR_MAX_BODY 32 /* including world = body 0 */
+#define MIR_MAX_DOF 48  /* nv */
+#define MIR_MAX_Q 56    /* nq */
+#define MIR_MAX_GEOM 40
+#define MIR_MAX_PAIR 256   /* candidate geom pairs after static filtering */
+#define MIR_MAX_CONTACT 64 /* contacts kept per env per step (plane-box <= 4, box-box <= 8 per pair) */
 #define MIR_MAX_GRIP 4
+#define MIR_MAX_FREE 8     /* free bodies (cubes) */
 
 /* error codes */
 #define MIR_OK 0
@@ -124,13 +128,26 @@ typedef struct MirOptions {
   int32_t implicit_damping;          /* M += dt (damping + kv) on the diagonal */
 } MirOptions;
 
+/* reward rules */
+#define MIR_REWARD_LIFT 0  /* obj_z > reward_z                                   (cube_pick.py:130-135) */
+#define MIR_REWARD_STACK 1 /* |obj.xy - obj2.xy| < reward_xy && obj.z - obj2.z > reward_dz
+                              (cube_stack_batch.py:143-153, cube_stack_kitchen_batch.py:138-146) */
+/* agent_pos layouts */
+#define MIR_AGENT_EEF 0  /* [eef pos3, eef quat4, grip q...]                    (cube_pick.py:140-151) */
+#define MIR_AGENT_QPOS 1 /* qpos of every scalar joint, body order               (cube_stack_batch.py:169) */
+
 /* what the fused step extracts (reference get_obs / compute_reward) */
 typedef struct MirTaskSpec {
   int32_t eef_body;               /* franka.get_link("hand"), cube_pick.py:68 */
-  int32_t obj_body;               /* cube */
-  int32_t n_grip;                 /* gripper dofs appended to agent_pos */
+  int32_t obj_body;               /* cube / cube_1 */
+  int32_t n_grip;                 /* gripper dofs appended to agent_pos (MIR_AGENT_EEF) */
   int32_t grip_dof[MIR_MAX_GRIP]; /* dof indices (cube_pick.py:142 -> 7,8) */
-  double reward_z;                /* reward = obj_z > reward_z (cube_pick.py:134 -> 0.1) */
+  double reward_z;                /* MIR_REWARD_LIFT threshold (cube_pick.py:134 -> 0.1) */
+  int32_t obj2_body;              /* cube_2, or -1: env_state gets obj2 pos3 appended (11 -> 14 columns) */
+  int32_t reward_mode;            /* MIR_REWARD_* */
+  int32_t agent_mode;             /* MIR_AGENT_* */
+  int32_t _pad;
+  double reward_xy, reward_dz;    /* MIR_REWARD_STACK thresholds (0.05, 0.03) */
 } MirTaskSpec;
 
 typedef struct MirSceneSpec {
@@ -149,6 +166,7 @@ typedef struct MirScene* MirHandle;
 /* sizes of the batched state vectors for a created scene */
 typedef struct MirDims {
   int32_t num_envs, nbody, nq, nv, ngeom, npair, agent_dim, env_dim;
+  int32_t nfree, kernel; /* free bodies; 16 = 16-lanes-per-env kernel, 64 = wave-per-env kernel */
 } MirDims;
 
 int mir_version(void);
@@ -165,7 +183,8 @@ int mir_get_dims(MirHandle h, MirDims* out);
 int mir_get_model_consts(MirHandle h, double* dof_invweight0, double* body_invweight0, double* meaninertia);
 
 /* cube.set_pos/set_quat + franka.set_qpos(zero_velocity=True) (+ PD targets = qpos).
- * obj_pos (B,3) / obj_quat (B,4): world pose of task.obj_body; arm_qpos (B,n_arm):
+ * obj_pos (B,nfree,3) / obj_quat (B,nfree,4): world poses of ALL free bodies in body order (the pick scenes
+ * have one, task.obj_body; the stack scenes five: cube_stack_kitchen_batch.py:70-96); arm_qpos (B,n_arm):
  * values for every non-FREE joint in body order.  All velocities and the solver
  * warm start are zeroed.  env_mask (B) u8 nullable: reset only envs with mask!=0. */
 int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const float* arm_qpos,
@@ -177,8 +196,8 @@ int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const fl
  *   episode_len += 1;  truncated = !terminated && max_len > 0 && episode_len >= max_len;
  *   done = terminated || truncated.
  * Done envs are reset exactly as mir_reset does (arm_qpos, zero velocity, PD targets = arm_qpos,
- * object at spawn_pool[cursor % pool_len][env] with obj_quat), episode_len = 0, cursor += 1.
- * spawn_pool (pool_len,B,3) f32: spawn positions drawn ahead by the caller (the task's host
+ * free bodies at spawn_pool[cursor % pool_len][env] with obj_quat), episode_len = 0, cursor += 1.
+ * spawn_pool (pool_len,B,nfree,3) f32, obj_quat (B,nfree,4): spawn poses drawn ahead by the caller (the task's host
  * RandomState stays the source of randomness).  terminated (B) u8 nullable; episode_len, cursor (B)
  * i32 in/out; truncated_out, done_out (B) u8 nullable.  No physics step is consumed. */
 int mir_autoreset(MirHandle h, const uint8_t* terminated, int32_t* episode_len, int32_t max_len,
@@ -192,17 +211,17 @@ int mir_set_pd_targets(MirHandle h, const float* tgt, void* stream);
 int mir_step(MirHandle h, int32_t n_steps, void* stream);
 
 /* FrankaCubePickBatch.step + GenesisEnv.step in one launch:
- * targets <- action (B,nu); one physics step; agent_pos (B,7+n_grip) =
- * [eef_pos3, eef_quat4, grip_q]; env_state (B,11) = [obj_pos3, obj_quat4,
- * eef-obj 3, |eef-obj| 1]; reward (B) f32 = obj_z > reward_z; terminated (B) u8 =
- * reward == 1.  action may be NULL (keep current targets). */
+ * targets <- action (B,nu); one physics step; agent_pos (B,agent_dim) = [eef_pos3, eef_quat4, grip_q]
+ * (MIR_AGENT_EEF) or the scalar-joint qpos (MIR_AGENT_QPOS); env_state (B,env_dim) = [obj_pos3, obj_quat4,
+ * eef-obj 3, |eef-obj| 1] (+ obj2_pos3 when task.obj2_body >= 0); reward (B) f32 by task.reward_mode;
+ * terminated (B) u8 = reward == 1.  action may be NULL (keep current targets). */
 int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward,
                    uint8_t* terminated, void* stream);
 
 /* Same step, but every output of an env lands in ONE packed float32 row
- * rows[e*row_stride + ...] = [agent_pos (7+n_grip) | env_state (11) | reward | terminated(0/1)]
+ * rows[e*row_stride + ...] = [agent_pos (agent_dim) | env_state (env_dim) | reward | terminated(0/1)]
  * so a sharded run gathers all per-step outputs with a single collective
- * (row_stride >= 7+n_grip+13, in floats). */
+ * (row_stride >= agent_dim + env_dim + 2, in floats). */
 int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream);
 
 /* get_obs() without stepping */

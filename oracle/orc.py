@@ -63,6 +63,10 @@ class Oracle:
         self.nv = len(self.read(F_QVEL))
         self.nbody = spec.nbody
         self.n_grip = spec.task.n_grip
+        self.nfree = sum(1 for b in range(1, spec.nbody) if spec.body[b].jtype == 3)
+        n_arm = sum(1 for b in range(1, spec.nbody) if spec.body[b].jtype in (1, 2))
+        self.agent_dim = n_arm if spec.task.agent_mode == 1 else 7 + spec.task.n_grip
+        self.env_dim = 14 if spec.task.obj2_body >= 0 else 11
         self.nu = sum(1 for i in range(spec.ndof) if spec.dof[i].ctrl_mode == 1)
         self.u_dofs = [i for i in range(spec.ndof) if spec.dof[i].ctrl_mode == 1]
 
@@ -103,8 +107,9 @@ class Oracle:
 
     # ---- batched, mirroring the C ABI ----------------------------------------------------
     def reset(self, obj_pos, obj_quat, arm_qpos):
-        obj_pos = np.ascontiguousarray(obj_pos, dtype=np.float64).reshape(self.B, 3)
-        obj_quat = np.ascontiguousarray(obj_quat, dtype=np.float64).reshape(self.B, 4)
+        """obj_pos (B, nfree, 3) / obj_quat (B, nfree, 4): poses of all free bodies in body order ((B,3)/(B,4) with one)."""
+        obj_pos = np.ascontiguousarray(obj_pos, dtype=np.float64).reshape(self.B, self.nfree * 3)
+        obj_quat = np.ascontiguousarray(obj_quat, dtype=np.float64).reshape(self.B, self.nfree * 4)
         arm_qpos = np.ascontiguousarray(arm_qpos, dtype=np.float64).reshape(self.B, -1)
         for e in range(self.B):
             self.lib.orc_reset(self.model, self.d(e), obj_pos[e].ctypes.data_as(C.c_void_p),
@@ -123,9 +128,8 @@ class Oracle:
                                 a.ctypes.data_as(C.c_void_p) if a is not None else None, C.c_int(nthreads))
 
     def get_obs(self):
-        ad = 7 + self.n_grip
-        agent = np.zeros((self.B, ad))
-        env = np.zeros((self.B, 11))
+        agent = np.zeros((self.B, self.agent_dim))
+        env = np.zeros((self.B, self.env_dim))
         rew = np.zeros(self.B)
         term = np.zeros(self.B, dtype=np.uint8)
         for e in range(self.B):

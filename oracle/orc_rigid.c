@@ -922,15 +922,15 @@ void orc_init_data(const OrcModel* m, OrcData* d) {
   orc_fk(m, d);
 }
 
+/* obj_pos (nfree,3) / obj_quat (nfree,4): poses of ALL free bodies in body order (mir_reset) */
 void orc_reset(const OrcModel* m, OrcData* d, const double* obj_pos, const double* obj_quat, const double* arm_qpos) {
-  int ia = 0;
+  int ia = 0, nf = 0;
   for (int b = 1; b < m->nbody; b++) {
     int qa = m->qadr[b];
     if (m->jtype[b] == MIR_JNT_FREE) {
-      if (b == m->task.obj_body) {
-        for (int k = 0; k < 3; k++) d->qpos[qa + k] = (real)(float)obj_pos[k];
-        for (int k = 0; k < 4; k++) d->qpos[qa + 3 + k] = (real)(float)obj_quat[k];
-      }
+      for (int k = 0; k < 3; k++) d->qpos[qa + k] = (real)(float)obj_pos[nf * 3 + k];
+      for (int k = 0; k < 4; k++) d->qpos[qa + 3 + k] = (real)(float)obj_quat[nf * 4 + k];
+      nf++;
     } else if (m->ndof[b] == 1) {
       d->qpos[qa] = (real)(float)arm_qpos[ia];
       d->target[m->dofadr[b]] = (real)(float)arm_qpos[ia];
@@ -947,11 +947,19 @@ void orc_set_targets(const OrcModel* m, OrcData* d, const double* tgt) {
     if (m->dof_uadr[i] >= 0) d->target[i] = (real)tgt[m->dof_uadr[i]];
 }
 
+/* agent_pos: [eef pos3, eef quat4, grip q] (MIR_AGENT_EEF) or the scalar-joint qpos in body order (MIR_AGENT_QPOS);
+ * env_state: [obj pos3, obj quat4, eef-obj 3, |eef-obj|] (+ obj2 pos3 when task.obj2_body >= 0) */
 void orc_get_obs(const OrcModel* m, const OrcData* d, double* agent_pos, double* env_state, double* reward, unsigned char* terminated) {
-  int e = m->task.eef_body, o = m->task.obj_body;
-  for (int k = 0; k < 3; k++) agent_pos[k] = (double)d->xpos[e][k];
-  for (int k = 0; k < 4; k++) agent_pos[3 + k] = (double)d->xquat[e][k];
-  for (int k = 0; k < m->task.n_grip; k++) agent_pos[7 + k] = (double)d->qpos[m->dof_qadr[m->task.grip_dof[k]]];
+  int e = m->task.eef_body, o = m->task.obj_body, o2 = m->task.obj2_body;
+  if (m->task.agent_mode == MIR_AGENT_QPOS) {
+    int ia = 0;
+    for (int b = 1; b < m->nbody; b++)
+      if (m->jtype[b] != MIR_JNT_FREE && m->ndof[b] == 1) agent_pos[ia++] = (double)d->qpos[m->qadr[b]];
+  } else {
+    for (int k = 0; k < 3; k++) agent_pos[k] = (double)d->xpos[e][k];
+    for (int k = 0; k < 4; k++) agent_pos[3 + k] = (double)d->xquat[e][k];
+    for (int k = 0; k < m->task.n_grip; k++) agent_pos[7 + k] = (double)d->qpos[m->dof_qadr[m->task.grip_dof[k]]];
+  }
   double nn = 0;
   for (int k = 0; k < 3; k++) env_state[k] = (double)d->xpos[o][k];
   for (int k = 0; k < 4; k++) env_state[3 + k] = (double)d->xquat[o][k];
@@ -961,9 +969,18 @@ void orc_get_obs(const OrcModel* m, const OrcData* d, double* agent_pos, double*
     nn += df * df;
   }
   env_state[10] = sqrt(nn);
-  /* reward compared in float32 as the reference does (cube_pick.py:132-134) */
-  float z = (float)d->xpos[o][2];
-  *reward = z > (float)m->task.reward_z ? 1.0 : 0.0;
+  if (o2 >= 0)
+    for (int k = 0; k < 3; k++) env_state[11 + k] = (double)d->xpos[o2][k];
+  if (m->task.reward_mode == MIR_REWARD_STACK) {
+    /* compared in float32 as the reference does on its float32 tensors (cube_stack_batch.py:143-153) */
+    float dx = (float)d->xpos[o][0] - (float)d->xpos[o2][0], dy = (float)d->xpos[o][1] - (float)d->xpos[o2][1];
+    float dz = (float)d->xpos[o][2] - (float)d->xpos[o2][2];
+    *reward = (sqrtf(dx * dx + dy * dy) < (float)m->task.reward_xy && dz > (float)m->task.reward_dz) ? 1.0 : 0.0;
+  } else {
+    /* reward compared in float32 as the reference does (cube_pick.py:132-134) */
+    float z = (float)d->xpos[o][2];
+    *reward = z > (float)m->task.reward_z ? 1.0 : 0.0;
+  }
   *terminated = *reward == 1.0;
 }
 

@@ -33,12 +33,21 @@ typedef float real;
 typedef double real;
 #endif
 
+#ifdef ORC_SMALL /* pick-task capacities: keeps the per-env block of the timed float32 port small and cache-resident */
+#define ORC_NB 16
+#define ORC_NV 15
+#define ORC_NQ 18
+#define ORC_NG 24
+#define ORC_NP 64
+#define ORC_NC 16
+#else
 #define ORC_NB MIR_MAX_BODY
 #define ORC_NV MIR_MAX_DOF
 #define ORC_NQ MIR_MAX_Q
 #define ORC_NG MIR_MAX_GEOM
 #define ORC_NP MIR_MAX_PAIR
 #define ORC_NC MIR_MAX_CONTACT
+#endif
 #define ORC_NEFC (4 * ORC_NC + ORC_NV)
 
 typedef struct OrcModel {
