@@ -19,8 +19,8 @@ from __future__ import annotations
 
 import math
 
-from .spec import (CTRL_POSITION, GEOM_BOX, GEOM_PLANE, JNT_FREE, JNT_PRISMATIC, JNT_REVOLUTE, SceneBuilder,
-                   box_inertia)
+from .spec import (AGENT_QPOS, CTRL_POSITION, GEOM_BOX, GEOM_PLANE, JNT_FREE, JNT_PRISMATIC, JNT_REVOLUTE, MIR_MAX_CONTACT,
+                   REWARD_STACK, SceneBuilder, box_inertia)
 
 # reference: cube_pick.py:7-17
 FRANKA_JOINTS = ("joint1", "joint2", "joint3", "joint4", "joint5", "joint6", "joint7", "finger_joint1",
@@ -68,40 +68,54 @@ _FINGER_BODY_BOX = ((0.0105, 0.0085, 0.0268), (0.0, 0.0145, 0.0268))
 _FINGER_PAD_BOX = ((0.0085, 0.004, 0.0085), (0.0, 0.0055, 0.0445))
 
 
+def _add_franka(sb: SceneBuilder, pos=(0.0, 0.0, 0.0), scale=1.0) -> None:
+    """The Panda (bodies, joints, collision boxes) mounted at `pos`, uniformly scaled like gs.morphs.MJCF(scale=...):
+    lengths x s, masses x s^3, inertias x s^5, prismatic ranges x s; joint-level constants (armature, damping,
+    PD gains, force ranges) and revolute ranges unchanged."""
+    s = float(scale)
+    s3, s5 = s ** 3, s ** 5
+    sc = lambda v: tuple(x * s for x in v)  # noqa: E731
+    white, dark = (0.92, 0.92, 0.9), (0.18, 0.18, 0.2)
+    sb.add_body("link0", 0, pos=pos, mass=0.629769 * s3, ipos=sc((-0.041018, -0.00014, 0.049974)),
+                inertia=tuple(v * s5 for v in (0.00315, 0.00388, 0.004285, 8.2904e-7, 0.00015, 8.2299e-6)))
+    for i, (name, parent, lpos, quat, rng, mass, com, inertia) in enumerate(_PANDA_LINKS):
+        sb.add_body(name, parent, pos=sc(lpos), quat=quat, jtype=JNT_REVOLUTE, axis=(0, 0, 1), mass=mass * s3, ipos=sc(com),
+                    inertia=tuple(v * s5 for v in inertia), joint_name=FRANKA_JOINTS[i], limited=1, range=rng, armature=0.1,
+                    damping=1.0, ctrl_mode=CTRL_POSITION, kp=FRANKA_KP[i], kv=FRANKA_KV[i],
+                    frc_range=(-FRANKA_FRC[i], FRANKA_FRC[i]))
+    sb.add_body("hand", "link7", pos=sc((0, 0, 0.107)), quat=(0.9238795, 0, 0, -0.3826834), mass=0.73 * s3,
+                ipos=sc((-0.01, 0, 0.03)), inertia=tuple(v * s5 for v in (0.001, 0.0025, 0.0017, 0, 0, 0)))
+    for k, (name, quat) in enumerate((("left_finger", (1, 0, 0, 0)), ("right_finger", (0, 0, 0, 1)))):
+        sb.add_body(name, "hand", pos=sc((0, 0, 0.0584)), quat=quat, jtype=JNT_PRISMATIC, axis=(0, 1, 0), mass=0.015 * s3,
+                    inertia=tuple(v * s5 for v in (2.375e-6, 2.375e-6, 7.5e-7, 0, 0, 0)), joint_name=FRANKA_JOINTS[7 + k], limited=1,
+                    range=(0.0, 0.04 * s), armature=0.1, damping=1.0, ctrl_mode=CTRL_POSITION, kp=FRANKA_KP[7 + k],
+                    kv=FRANKA_KV[7 + k], frc_range=(-FRANKA_FRC[7 + k], FRANKA_FRC[7 + k]))
+    for body, half, centre in _PANDA_BOXES:
+        sb.add_geom(body, GEOM_BOX, size=sc(half), pos=sc(centre), rgb=dark if body == "hand" else white)
+    for finger in ("left_finger", "right_finger"):
+        sb.add_geom(finger, GEOM_BOX, size=sc(_FINGER_BODY_BOX[0]), pos=sc(_FINGER_BODY_BOX[1]), rgb=dark)
+        sb.add_geom(finger, GEOM_BOX, size=sc(_FINGER_PAD_BOX[0]), pos=sc(_FINGER_PAD_BOX[1]), rgb=dark)
+
+
+def _add_cube(sb: SceneBuilder, name: str, pos, size=0.04, rho=200.0, friction=1.0, rgb=(0.85, 0.2, 0.15)) -> None:
+    """gs.morphs.Box(size=size^3) as a free body; Genesis rigid material default density 200 kg/m^3."""
+    h = size / 2
+    mass = rho * size ** 3
+    sb.add_body(name, 0, pos=pos, quat=(1, 0, 0, 0), jtype=JNT_FREE, mass=mass, inertia=box_inertia(mass, (h, h, h)))
+    sb.add_geom(name, GEOM_BOX, size=(h, h, h), friction=friction, rgb=rgb)
+
+
 def franka_cube_pick_scene(cube_size=0.04, cube_pos=(0.65, 0.0, 0.02), cube_rho=200.0) -> SceneBuilder:
     sb = SceneBuilder()
     # ground plane (gs.morphs.Plane, cube_pick.py:50)
     sb.add_geom(0, GEOM_PLANE)
     # Panda (cube_pick.py:51)
-    white, dark = (0.92, 0.92, 0.9), (0.18, 0.18, 0.2)
-    sb.add_body("link0", 0, mass=0.629769, ipos=(-0.041018, -0.00014, 0.049974),
-                inertia=(0.00315, 0.00388, 0.004285, 8.2904e-7, 0.00015, 8.2299e-6))
-    for i, (name, parent, pos, quat, rng, mass, com, inertia) in enumerate(_PANDA_LINKS):
-        sb.add_body(name, parent, pos=pos, quat=quat, jtype=JNT_REVOLUTE, axis=(0, 0, 1), mass=mass, ipos=com,
-                    inertia=inertia, joint_name=FRANKA_JOINTS[i], limited=1, range=rng, armature=0.1, damping=1.0,
-                    ctrl_mode=CTRL_POSITION, kp=FRANKA_KP[i], kv=FRANKA_KV[i],
-                    frc_range=(-FRANKA_FRC[i], FRANKA_FRC[i]))
-    sb.add_body("hand", "link7", pos=(0, 0, 0.107), quat=(0.9238795, 0, 0, -0.3826834), mass=0.73,
-                ipos=(-0.01, 0, 0.03), inertia=(0.001, 0.0025, 0.0017, 0, 0, 0))
-    for k, (name, quat) in enumerate((("left_finger", (1, 0, 0, 0)), ("right_finger", (0, 0, 0, 1)))):
-        sb.add_body(name, "hand", pos=(0, 0, 0.0584), quat=quat, jtype=JNT_PRISMATIC, axis=(0, 1, 0), mass=0.015,
-                    inertia=(2.375e-6, 2.375e-6, 7.5e-7, 0, 0, 0), joint_name=FRANKA_JOINTS[7 + k], limited=1,
-                    range=(0.0, 0.04), armature=0.1, damping=1.0, ctrl_mode=CTRL_POSITION, kp=FRANKA_KP[7 + k],
-                    kv=FRANKA_KV[7 + k], frc_range=(-FRANKA_FRC[7 + k], FRANKA_FRC[7 + k]))
-    for body, half, centre in _PANDA_BOXES:
-        sb.add_geom(body, GEOM_BOX, size=half, pos=centre, rgb=dark if body == "hand" else white)
-    for finger in ("left_finger", "right_finger"):
-        sb.add_geom(finger, GEOM_BOX, size=_FINGER_BODY_BOX[0], pos=_FINGER_BODY_BOX[1], rgb=dark)
-        sb.add_geom(finger, GEOM_BOX, size=_FINGER_PAD_BOX[0], pos=_FINGER_PAD_BOX[1], rgb=dark)
-    # cube (gs.morphs.Box, cube_pick.py:52-54); Genesis rigid material default density 200 kg/m^3
-    h = cube_size / 2
-    mass = cube_rho * cube_size ** 3
-    sb.add_body("cube", 0, pos=cube_pos, quat=(1, 0, 0, 0), jtype=JNT_FREE, mass=mass,
-                inertia=box_inertia(mass, (h, h, h)))
-    sb.add_geom("cube", GEOM_BOX, size=(h, h, h), rgb=(0.85, 0.2, 0.15))
+    _add_franka(sb)
+    # cube (gs.morphs.Box, cube_pick.py:52-54)
+    _add_cube(sb, "cube", cube_pos, size=cube_size, rho=cube_rho)
     # visual-only pedestal of the fixed base link (never collides: contype = conaffinity = 0); appended last so
     # the indices of the colliding geoms and the candidate-pair order are unchanged
-    sb.add_geom("link0", GEOM_BOX, size=(0.09, 0.08, 0.07), pos=(-0.04, 0.0, 0.07), contype=0, conaffinity=0, rgb=white)
+    sb.add_geom("link0", GEOM_BOX, size=(0.09, 0.08, 0.07), pos=(-0.04, 0.0, 0.07), contype=0, conaffinity=0, rgb=(0.92, 0.92, 0.9))
     # task extraction (cube_pick.py:66-68,134,142)
     sb.task = dict(eef_body=sb.body_index("hand"), obj_body=sb.body_index("cube"),
                    grip_dof=(sb.dof_index("finger_joint1"), sb.dof_index("finger_joint2")), reward_z=0.1)
@@ -162,4 +176,77 @@ def so101_cube_pick_scene(cube_size=0.04, cube_pos=(-0.3, 0.0, ISLAND_TOP_Z + 0.
     sb.add_geom("cube", GEOM_BOX, size=(h, h, h), friction=fr, rgb=(0.85, 0.2, 0.15))
     # eef link "gripper" (so101/cube_pick.py:37), gripper dof = joint6 (:36,:120), reward z > 0.1 (:112)
     sb.task = dict(eef_body=sb.body_index("gripper"), obj_body=sb.body_index("cube"), grip_dof=(sb.dof_index("joint6"),), reward_z=0.1)
+    return sb
+
+
+
+# ------------------------------------------------------------------------------------------------
+# Stack scenes (gym_genesis/CubeStack-v0): arm + FIVE free cubes on the kitchen-island slab
+# (/root/reference/gym_genesis/tasks/utils.py:239-426 build_house, :593-794 build_house_task_cube_stack).
+# Only what carries physics on the hot path is restated: floor plane, island slab (top z = ISLAND_TOP_Z, the
+# decomposed island mesh replaced by its top slab), the robot, cube_1 (red, picked), cube_2 (green, target) and three
+# distractor cubes (the reference places them with the unseeded global np.random at build time, utils.py:411-423 /
+# :777-789; every reset() re-draws them, so fixed build positions are used here).  Walls, fridge, ceiling lamp and
+# the stove are visual-only in the reference (collision=False).
+STACK_CUBES = ("cube_1", "cube_2", "distractor_1", "distractor_2", "distractor_3")
+_STACK_CUBE_XY = ((0.1, 0.0), (-0.1, 0.05), (0.2, -0.15), (-0.2, -0.2), (0.05, 0.2))   # utils.py:395,404 for the first two
+_STACK_CUBE_RGB = ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.2, 0.4, 0.9), (0.9, 0.8, 0.2), (0.7, 0.3, 0.8))
+STACK_CUBE_Z = ISLAND_TOP_Z + 0.02 + 0.001  # utils.py:388-395: island_top_z + 0.02 + z_offset
+
+
+def _stack_common(sb: SceneBuilder, friction=1.0) -> None:
+    for name, (x, y), rgb in zip(STACK_CUBES, _STACK_CUBE_XY, _STACK_CUBE_RGB):
+        _add_cube(sb, name, (x, y, STACK_CUBE_Z), friction=friction, rgb=rgb)
+    sb.opt["max_contacts"] = MIR_MAX_CONTACT  # five resting cubes alone are 20 contact points
+
+
+def franka_cube_stack_scene() -> SceneBuilder:
+    """build_house (utils.py:239-426): Panda MJCF at (-0.5, 0, 0.7), scale 0.6 (:370-377); PD gains / force ranges as
+    reset() sets them (cube_stack_kitchen_batch.py:101-106) -- the same arrays the pick scene uses."""
+    sb = SceneBuilder()
+    sb.add_geom(0, GEOM_PLANE)                                                        # kitchen floor, z = 0
+    sb.add_geom(0, GEOM_BOX, size=(0.915, 0.401, 0.05), pos=(0.0, 0.0, ISLAND_TOP_Z - 0.05), rgb=(0.75, 0.72, 0.68))
+    _add_franka(sb, pos=(-0.5, 0.0, 0.7), scale=0.6)
+    _stack_common(sb)
+    sb.task = dict(eef_body=sb.body_index("hand"), obj_body=sb.body_index("cube_1"), obj2_body=sb.body_index("cube_2"),
+                   grip_dof=(sb.dof_index("finger_joint1"), sb.dof_index("finger_joint2")), reward_z=0.1,
+                   reward_mode=REWARD_STACK, reward_xy=0.05, reward_dz=0.03)          # cube_stack_kitchen_batch.py:138-146
+    return sb
+
+
+# SO-101 stack variant: so101_old_calib.xml scaled 1.3, yaw 90 deg, at (-0.5, 0, 0.7) (utils.py:730-744).  The MJCF is in
+# an empty submodule, so the chain of the pick scene is reused; what the "old calibration" changes is where the joint
+# zeros are, and the reference only tells us that deg (0, -177, 165, 72, -83, 0) is its home pose
+# (cube_stack_batch.py:106).  The zero offsets are therefore CHOSEN so that this home pose is the folded rest pose
+# SO101_STACK_REST of the re-stated chain (arm tucked above its base, clear of the slab); joint ranges move with them.
+SO101_STACK_HOME_DEG = (0.0, -177.0, 165.0, 72.0, -83.0, 0.0)
+SO101_STACK_REST = (0.0, -0.9, 1.3, 0.3, 0.0, 0.0)   # same pose in the pick chain's own joint angles (clear of the slab: tools scan)
+
+
+def so101_cube_stack_scene() -> SceneBuilder:
+    sb = SceneBuilder()
+    s = 1.3
+    sb.add_geom(0, GEOM_PLANE)
+    sb.add_geom(0, GEOM_BOX, size=(0.915, 0.401, 0.05), pos=(0.0, 0.0, ISLAND_TOP_Z - 0.05), rgb=(0.75, 0.72, 0.68))
+    yaw = math.radians(90.0)
+    sb.add_body("so101_base", 0, pos=(-0.5, 0.0, 0.7), quat=(math.cos(yaw / 2), 0.0, 0.0, math.sin(yaw / 2)), mass=0.147 * s ** 3,
+                ipos=(0.0, 0.0, 0.03 * s), inertia=box_inertia(0.147 * s ** 3, (0.04 * s, 0.04 * s, 0.03 * s)))
+    sb.add_geom("so101_base", GEOM_BOX, size=(0.04 * s, 0.04 * s, 0.03 * s), pos=(0.0, 0.0, 0.03 * s + 0.002))
+    for i, (name, parent, pos, axis, rng, mass, half, centre) in enumerate(_SO101_LINKS):
+        m = mass * s ** 3
+        hs = tuple(h * s for h in half)
+        cs = tuple(c * s for c in centre)
+        arm = i < 5
+        # joint zero offset: model angle = q + q0, baked into the body frame as a rotation about the joint axis
+        q0 = SO101_STACK_REST[i] - math.radians(SO101_STACK_HOME_DEG[i])
+        quat = (math.cos(q0 / 2),) + tuple(a * math.sin(q0 / 2) for a in axis)
+        sb.add_body(name, parent, pos=tuple(p * s for p in pos), quat=quat, jtype=JNT_REVOLUTE, axis=axis, mass=m, ipos=cs,
+                    inertia=box_inertia(m, hs), joint_name=SO101_JOINTS[i], limited=1, range=(rng[0] - q0, rng[1] - q0), armature=0.028,
+                    damping=0.6, ctrl_mode=CTRL_POSITION, kp=1000.0 if arm else 100.0, kv=200.0 if arm else 10.0, frc_range=(-1e30, 1e30))
+        sb.add_geom(name, GEOM_BOX, size=hs, pos=cs)
+    sb.add_geom("gripper", GEOM_BOX, size=(0.034 * s, 0.004 * s, 0.01 * s), pos=(0.066 * s, -0.018 * s, 0.0))  # fixed finger
+    _stack_common(sb)
+    # eef = link "gripper", agent_pos = so_101.get_qpos() (cube_stack_batch.py:37,169), stack reward (:143-153)
+    sb.task = dict(eef_body=sb.body_index("gripper"), obj_body=sb.body_index("cube_1"), obj2_body=sb.body_index("cube_2"), grip_dof=(),
+                   reward_z=0.1, reward_mode=REWARD_STACK, reward_xy=0.05, reward_dz=0.03, agent_mode=AGENT_QPOS)
     return sb

@@ -25,6 +25,8 @@ from ._gym import Env
 _TASKS = {
     ("franka", "cube_pick", True): "gym_genesis.tasks.franka.cube_pick:FrankaCubePickBatch",
     ("so101", "cube_pick", True): "gym_genesis.tasks.so101.cube_pick:CubePick",
+    ("so101", "cube_stack", True): "gym_genesis.tasks.so101.cube_stack_batch:CubeStackBatch",
+    ("franka", "cube_stack", True): "gym_genesis.tasks.franka.cube_stack_kitchen_batch:FrankaCubeStackKitchenBatch",
 }
 
 

@@ -1,0 +1,64 @@
+"""Batched SO-101 cube-stack task on the MI355X backend (gym_genesis/CubeStack-v0, the registry's default robot).
+
+Behavioural contract restated from /root/reference/gym_genesis/tasks/so101/cube_stack_batch.py:25-226 and the scene
+builder /root/reference/gym_genesis/tasks/utils.py:593-794:
+  * scene: island slab, SO-101 x1.3 yawed 90 deg at (-0.5, 0, 0.7), five 4 cm cubes on the slab             (utils.py:714-789)
+  * reset(): z = island_top + 0.021, all cube quats (0,0,0,1); per env, IN A PYTHON LOOP, scalar draws
+    x1 ~ U(-0.3,-0.1), y1 ~ U(-0.1,0.1), x2, y2 likewise, rejected and re-drawn until |p1 - p2| >= 0.06; then per
+    distractor xd ~ U(-0.35,0) (B), yd ~ U(-0.2,0.2) (B); arm at deg2rad(0,-177,165,72,-83,0), zero velocity,
+    PD targets = home; ONE physics step                                                                       (:65-118)
+  * step(a): targets <- a[:, :5], a[:, 5:]; one physics step                                                  (:135-141)
+  * reward = float32(|cube1.xy - cube2.xy| < 0.05 and cube1.z - cube2.z > 0.03), a torch tensor               (:144-153)
+  * obs: agent_pos (B,6) = so_101.get_qpos(); environment_state (B,14)                                        (:155-177)
+The declared environment_state space says 10 (:16) although 14 values are returned; reproduced as declared.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from ...backend import models
+from ..stack_common import StackTaskBase
+
+AGENT_DIM = len(models.SO101_JOINTS)
+ENV_DIM = 10  # declared (cube_stack_batch.py:16); get_obs() returns 14 columns
+
+
+class CubeStackBatch(StackTaskBase):
+    AGENT_DIM = AGENT_DIM
+    ENV_DIM = ENV_DIM
+    ROBOT_ROOT = "so101_base"
+    JOINTS = models.SO101_JOINTS
+    EEF_LINK = "gripper"
+
+    def _scene_builder(self):
+        return models.so101_cube_stack_scene()
+
+    def _set_robot(self, view):
+        self.so_101 = view
+        self.motors_dof = np.arange(5)
+        self.fingers_dof = np.array([5])
+
+    def _home_qpos(self):
+        return tuple(math.radians(d) for d in models.SO101_STACK_HOME_DEG)  # cube_stack_batch.py:106
+
+    def sample_spawn(self) -> np.ndarray:
+        Bg, r = self.global_num_envs, self._random
+        z = self.island_top_z + 0.02 + 0.001
+        p1, p2 = np.zeros((Bg, 3)), np.zeros((Bg, 3))
+        for e in range(Bg):  # rejection sampling, scalar draws (:72-86)
+            while True:
+                x1 = r.uniform(-0.3, -0.1)
+                y1 = r.uniform(-0.1, 0.1)
+                x2 = r.uniform(-0.3, -0.1)
+                y2 = r.uniform(-0.1, 0.1)
+                if ((x2 - x1) ** 2 + (y2 - y1) ** 2) ** 0.5 >= 0.06:
+                    p1[e], p2[e] = (x1, y1, z), (x2, y2, z)
+                    break
+        cols = [p1, p2]
+        for _ in range(3):  # distractors (:97-103)
+            x = r.uniform(-0.35, 0.0, size=(Bg,))
+            y = r.uniform(-0.2, 0.2, size=(Bg,))
+            cols.append(np.stack([x, y, np.full(Bg, z)], axis=1))
+        return np.stack(cols, axis=1).astype(np.float32)

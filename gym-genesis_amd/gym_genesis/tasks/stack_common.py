@@ -1,0 +1,141 @@
+"""Shared machinery of the two batched cube-stack tasks (gym_genesis/CubeStack-v0) on the MI355X backend.
+
+The reference implements them as two near-identical classes
+(/root/reference/gym_genesis/tasks/franka/cube_stack_kitchen_batch.py:27-224,
+ /root/reference/gym_genesis/tasks/so101/cube_stack_batch.py:25-226); what differs between them -- robot, spawn
+distributions and their RNG draw order, home pose, agent_pos layout, reward dtype -- stays in the subclasses, which
+cite the reference line by line.  Everything here is plumbing: scene creation on the wave-per-env kernel, the fused
+step, observation packing and the env-axis shard.
+"""
+from __future__ import annotations
+
+import random
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from .._gym import spaces
+from ..backend import models
+from ..backend.lib import MirScene
+from .views import EntityView, SceneView
+
+ENV_OBS = 14  # [cube1 pos3, cube1 quat4, eef - cube1 3, |eef - cube1| 1, cube2 pos3]
+
+
+class StackTaskBase:
+    AGENT_DIM = 0          # declared action / agent_pos width
+    ENV_DIM = ENV_OBS      # declared environment_state width
+    ROBOT_ROOT = ""
+    JOINTS: Tuple[str, ...] = ()
+    EEF_LINK = ""
+
+    def __init__(self, enable_pixels, observation_height, observation_width, num_envs, env_spacing, camera_capture_mode,
+                 strip_environment_state, shard: Optional[Tuple[int, int]] = None):
+        self.enable_pixels = enable_pixels
+        self.observation_height = observation_height
+        self.observation_width = observation_width
+        self.camera_capture_mode = camera_capture_mode
+        self.strip_environment_state = strip_environment_state
+        self.env_spacing = env_spacing
+        self.global_num_envs = int(num_envs)
+        rank, world = shard if shard is not None else (0, 1)
+        self.shard_lo = self.global_num_envs * rank // world
+        self.shard_hi = self.global_num_envs * (rank + 1) // world
+        self.num_envs = self.shard_hi - self.shard_lo
+        self._random = np.random.RandomState()
+        if enable_pixels:
+            raise NotImplementedError("enable_pixels=True for the stack tasks (top / side / wrist cameras) is not built yet")
+        builder = self._scene_builder()
+        self._builder = builder
+        self._mir = MirScene(builder.build(), self.num_envs)
+        self.device = self._mir.device
+        self.island_top_z = models.ISLAND_TOP_Z
+        self.scene = SceneView(self._mir, env_spacing=env_spacing, global_num_envs=self.global_num_envs, offset=self.shard_lo)
+        robot = EntityView(self._mir, builder, root=self.ROBOT_ROOT, dof_names=self.JOINTS)
+        self._set_robot(robot)
+        self.cube_1 = EntityView(self._mir, builder, root="cube_1", dof_names=())
+        self.cube_2 = EntityView(self._mir, builder, root="cube_2", dof_names=())
+        self.distractor_cubes = [EntityView(self._mir, builder, root=n, dof_names=()) for n in models.STACK_CUBES[2:]]
+        self.eef = robot.get_link(self.EEF_LINK)
+        self.observation_space = self._make_obs_space()
+        self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(self.AGENT_DIM,), dtype=np.float32)
+        B, dev = self.num_envs, self.device
+        self._home = torch.tensor(self._home_qpos(), dtype=torch.float32, device=dev).repeat(B, 1)
+        self._quat = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=torch.float32, device=dev).repeat(B, len(models.STACK_CUBES), 1)
+        self._agent, self._envst = self._mir.empty(self._mir.agent_dim), self._mir.empty(ENV_OBS)
+        self._reward, self._term = self._mir.empty(), self._mir.empty(dtype=torch.uint8)
+
+    # ---- provided by the subclasses -----------------------------------------------------------
+    def _scene_builder(self):
+        raise NotImplementedError
+
+    def _set_robot(self, view):
+        raise NotImplementedError
+
+    def _home_qpos(self):
+        raise NotImplementedError
+
+    def sample_spawn(self) -> np.ndarray:
+        """Cube spawn positions of the GLOBAL batch, float32 (B_global, 5, 3), drawn in the reference's order."""
+        raise NotImplementedError
+
+    # ---- reference surface ------------------------------------------------------------------------
+    def _make_obs_space(self):
+        box = lambda n: spaces.Box(low=-np.inf, high=np.inf, shape=(n,), dtype=np.float32)  # noqa: E731
+        if self.enable_pixels:
+            return spaces.Dict({
+                "agent_pos": box(self.AGENT_DIM),
+                "pixels": spaces.Box(low=0, high=255, shape=(self.observation_height, self.observation_width, 3), dtype=np.uint8),
+            })
+        return spaces.Dict({"agent_pos": box(self.AGENT_DIM), "environment_state": box(self.ENV_DIM)})
+
+    def get_cams(self):
+        if not self.enable_pixels:
+            raise ValueError("Cameras are not enabled. Set `enable_pixels=True` when creating the environment.")
+        return self.cam_top, self.cam_side, self.cam_wrist
+
+    def seed(self, seed):
+        np.random.seed(seed)
+        random.seed(seed)
+        self._random = np.random.RandomState(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed)
+        self.action_space.seed(seed)
+
+    def reset(self):
+        pos = torch.from_numpy(self.sample_spawn()[self.shard_lo:self.shard_hi]).to(self.device)
+        self._mir.reset(pos, self._quat, self._home)  # set_pos/set_quat x5 + set_qpos(zero_velocity) + PD targets = home
+        self._mir.step(1)                             # both references consume one physics step in reset()
+        return self.get_obs()
+
+    def step(self, action):
+        if not isinstance(action, torch.Tensor):
+            action = torch.as_tensor(np.asarray(action))
+        a = action.to(device=self.device, dtype=torch.float32).contiguous()
+        if a.shape != (self.num_envs, self.AGENT_DIM):
+            raise ValueError(f"action must have shape {(self.num_envs, self.AGENT_DIM)}, got {tuple(a.shape)}")
+        mir = self._mir
+        self._agent, self._envst = mir.empty(mir.agent_dim), mir.empty(ENV_OBS)
+        self._reward, self._term = mir.empty(), mir.empty(dtype=torch.uint8)
+        mir.step_fused(a, self._agent, self._envst, self._reward, self._term)
+        return None, self._reward, None, self._pack_obs()
+
+    def step_raw(self, action_dev: torch.Tensor) -> None:
+        self._mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)
+
+    def compute_reward(self):
+        self.get_obs()
+        return self._reward
+
+    def get_obs(self):
+        self._agent, self._envst, self._reward, self._term = self._mir.get_obs()
+        return self._pack_obs()
+
+    def _pack_obs(self):
+        return {"agent_pos": self._agent, "environment_state": self._envst}
+
+    @property
+    def terminated_device(self) -> torch.Tensor:
+        return self._term

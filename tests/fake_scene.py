@@ -20,7 +20,8 @@ class OracleScene:
         self.num_envs = int(num_envs)
         self.nq, self.nv, self.nbody = self.o.nq, self.o.nv, spec.nbody
         self.nu = self.o.nu
-        self.agent_dim, self.env_dim = 7 + spec.task.n_grip, 11
+        self.agent_dim, self.env_dim = self.o.agent_dim, self.o.env_dim
+        self.nfree, self.kernel = self.o.nfree, 0
         self.n_arm = sum(1 for b in range(1, spec.nbody) if spec.body[b].jtype in (1, 2))
 
     def empty(self, *shape, dtype=torch.float32):
@@ -56,9 +57,9 @@ class OracleScene:
         bufs = (self.empty(self.agent_dim), self.empty(self.env_dim), self.empty(), self.empty(dtype=torch.uint8))
         self.step_fused(action, *bufs)
         rows[:, :self.agent_dim] = bufs[0]
-        rows[:, self.agent_dim:self.agent_dim + 11] = bufs[1]
-        rows[:, self.agent_dim + 11] = bufs[2]
-        rows[:, self.agent_dim + 12] = bufs[3].float()
+        rows[:, self.agent_dim:self.agent_dim + self.env_dim] = bufs[1]
+        rows[:, self.agent_dim + self.env_dim] = bufs[2]
+        rows[:, self.agent_dim + self.env_dim + 1] = bufs[3].float()
 
     def get_obs(self):
         bufs = (self.empty(self.agent_dim), self.empty(self.env_dim), self.empty(), self.empty(dtype=torch.uint8))

@@ -1,0 +1,235 @@
+"""GPU parity of the wave-per-env step kernel (mir_step64, through the C ABI) against the float64 CPU oracle on the
+five-cube stack scenes (gym_genesis/CubeStack-v0; Franka x0.6 in the kitchen, SO-101 x1.3).
+
+Tolerances (fp32 kernel vs fp64 oracle), as for the pick kernel (tests/test_gpu_parity.py):
+  * per-stage forward dynamics: 2e-5 relative to the row scale (M, bias), 5e-5 / 2e-4 (qacc_smooth / qacc)
+  * joint state: teacher-forced one-step L-inf < 5e-6 / 5e-4; free-running rollouts L-inf < 1e-4 on contractive scenarios
+  * reward / terminated masks: bit-exact
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import orc
+from gym_genesis.backend import models
+
+pytestmark = pytest.mark.gpu
+
+Z = models.STACK_CUBE_Z
+
+
+def _scene(spec, B):
+    from gym_genesis.backend.lib import MirScene
+
+    return MirScene(spec, B)
+
+
+def _spawn(B, seed):
+    """Five cubes per env on the slab, far enough apart not to touch (0.12 m grid cells, jittered)."""
+    rng = np.random.RandomState(seed)
+    cells = np.array([(x, y) for x in (-0.3, -0.15, 0.0, 0.15, 0.3) for y in (-0.24, -0.08, 0.08, 0.24)])
+    pos = np.zeros((B, 5, 3), np.float32)
+    for e in range(B):
+        pick = cells[rng.permutation(len(cells))[:5]] + rng.uniform(-0.03, 0.03, (5, 2))
+        pos[e, :, :2] = pick
+        pos[e, :, 2] = Z
+    return pos
+
+
+def _home(name):
+    return np.asarray(models.FRANKA_HOME if name == "franka" else np.radians(models.SO101_STACK_HOME_DEG), np.float32)
+
+
+def _builder(name):
+    return models.franka_cube_stack_scene() if name == "franka" else models.so101_cube_stack_scene()
+
+
+def _reset_both(sc, o, B, name, seed=0, pos=None):
+    pos = _spawn(B, seed) if pos is None else pos
+    quat = np.tile(np.array([0, 0, 0, 1], np.float32), (B, 5, 1))
+    arm = np.tile(_home(name), (B, 1))
+    sc.reset(pos, quat, arm)
+    o.reset(pos, quat, arm)
+    return pos
+
+
+@pytest.mark.parametrize("name,dims", [("franka", (44, 39, 17, 9, 9, 14)), ("so101", (41, 36, 13, 6, 6, 14))])
+def test_model_constants_and_dims(name, dims):
+    spec = _builder(name).build()
+    sc = _scene(spec, 3)
+    o = orc.Oracle(spec, 1)
+    assert sc.kernel == 64 and sc.nfree == 5
+    assert (sc.nq, sc.nv, sc.nbody, sc.nu, sc.agent_dim, sc.env_dim) == dims
+    dw, bw, mi = sc.model_consts()
+    assert np.allclose(dw, o.read(orc.F_DOF_INVWEIGHT0), rtol=1e-9)
+    assert np.allclose(bw, o.read(orc.F_BODY_INVWEIGHT0), rtol=1e-9, atol=1e-15)
+    assert abs(mi - o.read(orc.F_MEANINERTIA)[0]) < 1e-9
+
+
+def _random_states(name, B, rng):
+    nq, nv, na = (44, 39, 9) if name == "franka" else (41, 36, 6)
+    q = np.zeros((B, nq), np.float32)
+    home = _home(name)
+    q[:, :na] = home + rng.uniform(-0.4, 0.4, (B, na)) * (np.abs(home) > -1)
+    if name == "franka":
+        q[:, 7:9] = rng.uniform(0.0, 0.024, (B, 2))
+    pos = _spawn(B, 3)
+    for k in range(5):
+        a = na + 7 * k
+        q[:, a:a + 3] = pos[:, k] + np.array([0, 0, 1.0]) * rng.uniform(-0.0005, 0.2, (B, 1))
+        qt = rng.normal(size=(B, 4))
+        qt[: B // 2] = [0, 0, 0, 1]  # half of the envs keep the cubes flat (resting contacts), half tumble in the air
+        q[:, a + 3:a + 7] = qt / np.linalg.norm(qt, axis=1, keepdims=True)
+    q[: B // 2, na + 2::7] = Z - 0.0013  # 0.3 mm into the slab
+    v = rng.uniform(-1, 1, (B, nv)).astype(np.float32)
+    tgt = (home + rng.uniform(-0.5, 0.5, (B, na))).astype(np.float32)
+    return q, v, tgt
+
+
+@pytest.mark.parametrize("name", ["franka", "so101"])
+def test_forward_dynamics_stages_match_oracle(name):
+    B = 24
+    spec = _builder(name).build()
+    rng = np.random.default_rng(0)
+    q, v, tgt = _random_states(name, B, rng)
+    sc = _scene(spec, B)
+    nv = sc.nv
+    sc.set_state(qpos=q, qvel=v, target=tgt, warmstart=np.zeros((B, nv), np.float32))
+    M, bias, qas, qacc = (t.cpu().numpy().astype(np.float64) for t in sc.forward())
+    pos, quat = (t.cpu().numpy() for t in sc.get_links())
+    ncon = sc.get_diag()[0].cpu().numpy()
+    o = orc.Oracle(spec, B)
+    for e in range(B):
+        o.write(orc.F_QPOS, q[e], e)
+        o.write(orc.F_QVEL, v[e], e)
+    o.set_targets(tgt)
+    worst = 0.0
+    for e in range(B):
+        o.forward(e)
+        Mo = o.read(orc.F_M, e).reshape(nv, nv)
+        assert np.abs(M[e] - Mo).max() < 2e-5 * np.abs(Mo).max()
+        bo = o.read(orc.F_QFRC_BIAS, e)
+        assert np.abs(bias[e] - bo).max() < 2e-5 * max(1.0, np.abs(bo).max())
+        ao = o.read(orc.F_QACC_SMOOTH, e)
+        assert np.abs(qas[e] - ao).max() < 5e-5 * max(1.0, np.abs(ao).max())
+        assert ncon[e] == o.counts(e)[0]
+        qo = o.read(orc.F_QACC, e)
+        worst = max(worst, np.abs(qacc[e] - qo).max() / max(1.0, np.abs(qo).max()))
+        assert np.abs(pos[e] - o.read(orc.F_XPOS, e).reshape(-1, 3)).max() < 2e-6
+        assert np.abs(quat[e] - o.read(orc.F_XQUAT, e).reshape(-1, 4)).max() < 2e-6
+    assert (ncon[: B // 2] >= 20).all()
+    assert worst < 5e-4, worst
+    print(f"{name}: constrained qacc rel err {worst:.2e}")
+
+
+def _check_obs(sc, o, bufs, tol):
+    agent, env, rew, term = bufs
+    ao, eo, ro, to = o.get_obs()
+    assert np.abs(agent.cpu().numpy() - ao).max() < tol
+    assert np.abs(env.cpu().numpy() - eo).max() < tol
+    assert np.array_equal(rew.cpu().numpy(), ro.astype(np.float32))
+    assert np.array_equal(term.cpu().numpy(), to)
+
+
+def _rollout(name, B, T, actions, seed, tol_q, tol_v=None, teacher_forced=False, pos=None):
+    spec = _builder(name).build()
+    sc = _scene(spec, B)
+    o = orc.Oracle(spec, B)
+    _reset_both(sc, o, B, name, seed, pos)
+    bufs = (sc.empty(sc.agent_dim), sc.empty(sc.env_dim), sc.empty(), sc.empty(dtype=torch.uint8))
+    worst_q = worst_v = 0.0
+    for t in range(T):
+        a = actions(t)
+        at = None if a is None else torch.as_tensor(a, device=sc.device)
+        if teacher_forced:
+            qo, vo = o.state()
+            ws = np.stack([o.read(orc.F_QACC_WS, e) for e in range(B)])
+            sc.set_state(qpos=qo.astype(np.float32), qvel=vo.astype(np.float32), warmstart=ws.astype(np.float32))
+        sc.step_fused(at, *bufs)
+        o.step_batch(a)
+        if teacher_forced or t % 20 == 19 or t == T - 1:
+            q, v, _, _ = (x.cpu().numpy() for x in sc.get_state())
+            qo, vo = o.state()
+            worst_q = max(worst_q, np.abs(q - qo).max())
+            worst_v = max(worst_v, np.abs(v - vo).max())
+            _check_obs(sc, o, bufs, max(2 * tol_q, 2e-5))
+    assert worst_q < tol_q, f"joint position L-inf {worst_q}"
+    if tol_v is not None:
+        assert worst_v < tol_v, f"joint velocity L-inf {worst_v}"
+    return worst_q, worst_v, sc, o
+
+
+@pytest.mark.parametrize("name", ["franka", "so101"])
+def test_rollout_home_pose_five_resting_cubes(name):
+    """Arm holds its home pose, five cubes rest on the slab (20 contacts): 400 free-running steps, L-inf < 1e-4."""
+    wq, wv, sc, o = _rollout(name, 8, 400, lambda t: None, seed=0, tol_q=1e-4, tol_v=1e-3)
+    ncon = sc.get_diag()[0].cpu().numpy()
+    assert (ncon == 20).all()
+    print(f"{name} home pose + 5 resting cubes, 400 steps: qpos L-inf {wq:.3e}, qvel L-inf {wv:.3e}")
+
+
+@pytest.mark.parametrize("name", ["franka", "so101"])
+def test_smooth_targets_free_running(name):
+    B, T = 8, 300
+    home = _home(name).astype(np.float64)
+    na = len(home)
+    amp = np.full(na, 0.25)
+    if name == "franka":
+        amp[7:] = 0.008
+    ph = np.random.default_rng(7).uniform(0, 2 * np.pi, (B, na))
+
+    def act(t):
+        a = home + amp * np.sin(2 * np.pi * t / 150.0 + ph)
+        if name == "franka":
+            a[:, 7:] = 0.012 + amp[7:] * np.sin(2 * np.pi * t / 100.0 + ph[:, 7:])
+        return a.astype(np.float32)
+
+    wq, wv, _, _ = _rollout(name, B, T, act, seed=2, tol_q=1e-4, tol_v=2e-3)
+    print(f"{name} smooth targets, {T} steps: qpos L-inf {wq:.3e}, qvel L-inf {wv:.3e}")
+
+
+@pytest.mark.parametrize("name", ["franka", "so101"])
+def test_random_actions_teacher_forced(name):
+    """Fresh U(-1,1) joint targets around the home pose every step (saturated torques, limits active, the arm sweeping
+    through the cubes): every step checked from the oracle's own state."""
+    B, T = 16, 200
+    home = _home(name)
+    acts = (home + np.random.default_rng(5).uniform(-1, 1, (T, B, len(home)))).astype(np.float32)
+    wq, wv, sc, _ = _rollout(name, B, T, lambda t: acts[t], seed=1, tol_q=5e-6, tol_v=5e-4, teacher_forced=True)
+    print(f"{name} random actions, teacher-forced: one-step qpos L-inf {wq:.3e}, qvel L-inf {wv:.3e}")
+
+
+def test_stacked_cube_holds_and_reward_flips_bit_exact():
+    """cube_1 dropped onto cube_2 (box-box face contact on top of plane-box contacts): the stack settles, the reward
+    flips to 1 in the same step as in the oracle, terminated masks bit-exact along the way."""
+    B = 4
+    far = [(0.2, -0.15, Z), (-0.2, -0.2, Z), (0.05, 0.2, Z)]
+    pos = np.array([[(-0.1 + 0.01 * e, 0.05, Z + 0.0405 + 0.01 * e), (-0.1, 0.05, Z)] + far for e in range(B)], np.float32)
+    wq, wv, sc, o = _rollout("franka", B, 150, lambda t: None, seed=0, tol_q=2e-4, tol_v=5e-3, pos=pos)
+    rew = sc.get_obs()[2].cpu().numpy()
+    assert rew.sum() >= 2  # the centred drops end stacked; the masks were compared bit-exact at every check
+    print(f"stacked cube: qpos L-inf {wq:.3e}, rewards {rew}")
+
+
+def test_env_api_and_sharded_equivalence():
+    from gym_genesis.env import GenesisEnv
+
+    B = 6
+    env = GenesisEnv(task="cube_stack", robot="franka", num_envs=B)
+    obs, _ = env.reset(seed=3)
+    assert obs["agent_pos"].shape == (B, 9) and obs["environment_state"].shape == (B, 14) and obs["agent_pos"].is_cuda
+    acts = np.random.default_rng(0).uniform(-0.3, 0.3, (10, B, 9)).astype(np.float32) + np.asarray(models.FRANKA_HOME, np.float32)
+    for t in range(10):
+        obs, reward, terminated, truncated, info = env.step(acts[t])
+    full = torch.cat([obs["agent_pos"], obs["environment_state"]], 1).cpu().numpy()
+    parts = []
+    for r in range(2):
+        es = GenesisEnv(task="cube_stack", robot="franka", num_envs=B, shard=(r, 2))
+        es.reset(seed=3)
+        lo, hi = es._env.shard_lo, es._env.shard_hi
+        for t in range(10):
+            o_s, *_ = es.step(acts[t][lo:hi])
+        parts.append(torch.cat([o_s["agent_pos"], o_s["environment_state"]], 1).cpu().numpy())
+    assert np.array_equal(full, np.concatenate(parts))  # N shards == one batch, bit-exact
