@@ -193,7 +193,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.B = h->B;
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
-    a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps;
+    a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
     rc = mir_launch_step64(&a, (hipStream_t)stream);
   }
   if (rc != 0) return hip_fail((hipError_t)rc, "step kernel launch");
@@ -422,9 +422,9 @@ int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_s
   return launch(h, o, stream);
 }
 
-/* debug aid (not part of the drop-in surface): one step of the 16-lane kernel with phase timestamps from block 0 */
+/* debug aid (not part of the drop-in surface): one step with phase timestamps (shader clock) from block 0; 32 slots */
 int mir_debug_profile_step(MirHandle h, unsigned long long* prof16, void* stream) {
-  if (check(h) || !prof16 || h->kernel != 16) return set_err(MIR_E_INVALID, "mir_debug_profile_step: null argument / not the 16-lane kernel");
+  if (check(h) || !prof16) return set_err(MIR_E_INVALID, "mir_debug_profile_step: null argument");
   DeviceGuard guard(h->device);
   Outs o;
   o.prof = prof16;

@@ -26,6 +26,7 @@ struct StepArgs64 {
   float* out_qacc;  // (B, nv)
   float* out_xpos;  // (B, nbody, 3)
   float* out_xquat; // (B, nbody, 4)
+  unsigned long long* prof;  // debug: phase timestamps (shader clock) of env 0, or null
   float* rows;      // (B, row_stride) packed [agent | env_state | reward | terminated] or null
   int row_stride;
   int B;

@@ -35,7 +35,9 @@
 #define MAXC MIR_MAX_CONTACT
 #define JSEG 52 /* floats per contact segment: 3 rows x 16 + 4 pad */
 #define MSTR 20 /* row stride of the block-diagonal M rows in LDS */
-static_assert(MAXC == NL, "lane c owns contact c");
+#define HSTR 68 /* row stride of the dense Hessian in LDS */
+#define STAMP(k) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
+static_assert(MAXC <= NL, "lane c owns contact c");
 static_assert(MIR_MAX_GEOM <= NL && MIR_MAX_PAIR <= 4 * NL, "lane ownership of geoms / pairs");
 
 namespace {
@@ -53,53 +55,67 @@ __device__ __forceinline__ float wmaxf(float v) {
 }
 
 // Dense Gauss-Jordan over the 64 register rows (lane i = row i of the SPD matrix, b_i the right-hand side; on
-// return b = x_i).  Rows / columns of padding lanes are identity and are skipped (wave-uniform `act` mask).
-template <int K>
-struct GJW {
-  static __device__ __forceinline__ void run(float (&a)[NL], float& b, int lane, uint64_t act) {
-    if ((act >> K) & 1ull) {
-      const float pk = rl(a[K], K);
-      float inv = __builtin_amdgcn_rcpf(pk);
-      inv = inv * (2.0f - pk * inv);
-      const bool isk = lane == K;
-      const float f = a[K] * inv;
-#pragma unroll
-      for (int j = K + 1; j < NL; j++) {
-        const float rj = rl(a[j], K);
-        a[j] = isk ? a[j] * inv : fmaf(-f, rj, a[j]);
-      }
-      const float rb = rl(b, K);
-      b = isk ? b * inv : fmaf(-f, rb, b);
-    }
-    GJW<K + 1>::run(a, b, lane, act);
-  }
-};
-template <>
-struct GJW<NL> {
-  static __device__ __forceinline__ void run(float (&)[NL], float&, int, uint64_t) {}
-};
-
-// h[16 BLK + k] += tn Jn[k] + t1 J1[k] + t2 J2[k] over one 16-wide segment (static register indices)
+// return b = x_i).  The pivot loop is ROLLED per block (a fully unrolled 64-pivot elimination is ~10 k instructions,
+// more than the instruction cache, and with one wave per SIMD nothing hides the fetch misses): pivot K of block BLK
+// only touches columns >= 16 BLK (row K is already zero to the left), so each block has a static column range; the
+// own-row entry a[K] is picked by a wave-uniform switch.  One readlane + one fma per column: with
+// f = (1 - 1/p) on the pivot row and a_iK / p elsewhere, a[j] -= f * pivotrow[j] both scales the pivot row and
+// eliminates the others.  Padding lanes (identity rows) are skipped through the wave-uniform `act` mask.
+__device__ __forceinline__ float rlv(float v, int src) {  // src wave-uniform (SGPR lane select)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
 template <int BLK>
-__device__ __forceinline__ void hupd(float (&h)[NL], const float* seg, float tn, float t1, float t2) {
-  f4 xn[4], x1[4], x2[4];
+__device__ __forceinline__ void gj_block(float (&a)[NL], float& b, int lane, uint64_t act, unsigned comp) {
+#pragma nounroll
+  for (int kk = 0; kk < 16; kk++) {
+    const int K = __builtin_amdgcn_readfirstlane(16 * BLK + kk);
+    if (!((act >> K) & 1ull)) continue;
+    float aK;
+    switch (kk) {  // wave-uniform
+      case 0: aK = a[16 * BLK + 0]; break;
+      case 1: aK = a[16 * BLK + 1]; break;
+      case 2: aK = a[16 * BLK + 2]; break;
+      case 3: aK = a[16 * BLK + 3]; break;
+      case 4: aK = a[16 * BLK + 4]; break;
+      case 5: aK = a[16 * BLK + 5]; break;
+      case 6: aK = a[16 * BLK + 6]; break;
+      case 7: aK = a[16 * BLK + 7]; break;
+      case 8: aK = a[16 * BLK + 8]; break;
+      case 9: aK = a[16 * BLK + 9]; break;
+      case 10: aK = a[16 * BLK + 10]; break;
+      case 11: aK = a[16 * BLK + 11]; break;
+      case 12: aK = a[16 * BLK + 12]; break;
+      case 13: aK = a[16 * BLK + 13]; break;
+      case 14: aK = a[16 * BLK + 14]; break;
+      default: aK = a[16 * BLK + 15]; break;
+    }
+    const float pk = rlv(aK, K);
+    float inv = __builtin_amdgcn_rcpf(pk);
+    inv = inv * (2.0f - pk * inv);
+    const float f = lane == K ? 1.0f - inv : aK * inv;
+    // column blocks outside this block's connected component hold zeros in the pivot row: skipped (wave-uniform);
+    // pivot-row entries are fetched eight at a time so the readlane -> fma SGPR dependencies overlap
 #pragma unroll
-  for (int q = 0; q < 4; q++) { xn[q] = ldv(seg + 4 * q); x1[q] = ldv(seg + 16 + 4 * q); x2[q] = ldv(seg + 32 + 4 * q); }
+    for (int bj = BLK; bj < 4; bj++) {
+      if (!((comp >> (4 * BLK + bj)) & 1u)) continue;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    h[16 * BLK + 4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
-    h[16 * BLK + 4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
-    h[16 * BLK + 4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
-    h[16 * BLK + 4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
+      for (int j0 = 16 * bj; j0 < 16 * bj + 16; j0 += 8) {
+        float r[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) r[t] = rlv(a[j0 + t], K);
+#pragma unroll
+        for (int t = 0; t < 8; t++) a[j0 + t] = fmaf(-f, r[t], a[j0 + t]);
+      }
+    }
+    b = fmaf(-f, rlv(b, K), b);
   }
 }
-__device__ __forceinline__ void hupd_blk(float (&h)[NL], int blk, const float* seg, float tn, float t1, float t2) {
-  switch (blk) {  // wave-uniform
-    case 0: hupd<0>(h, seg, tn, t1, t2); break;
-    case 1: hupd<1>(h, seg, tn, t1, t2); break;
-    case 2: hupd<2>(h, seg, tn, t1, t2); break;
-    default: hupd<3>(h, seg, tn, t1, t2); break;
-  }
+// comp: bit 4 b + b' set when blocks b and b' are in one connected component of the contact coupling graph
+__device__ __forceinline__ void gj_wave(float (&a)[NL], float& b, int lane, uint64_t act, unsigned comp) {
+  gj_block<0>(a, b, lane, act, comp);
+  gj_block<1>(a, b, lane, act, comp);
+  gj_block<2>(a, b, lane, act, comp);
+  gj_block<3>(a, b, lane, act, comp);
 }
 
 struct Dyn64 {
@@ -125,24 +141,26 @@ struct Con64 {
   int cblk[MAXC][4];      // block of segment 0, of segment 1 (-1 = none), pad, pad
   float cfb[MAXC][4];     // per-iteration base forces (n, t1, t2), active-row flags
 };
+struct DynM64 {
+  Dyn64 dyn;
+  float M[NL][MSTR];  // block-diagonal: row of lane i holds the 16 columns of its own block (dead once mrow is loaded)
+};
 struct Env64 {
   float qpos[K64_QSTRIDE], qvel[NL], target[NL], qacc_ws[NL], qacc[NL];
   float qas[NL], srch[NL];
   float xpos[NB][4], xquat[NB][4];
   float cdof[NL][8];
-  float M[NL][MSTR];  // block-diagonal: row of lane i holds the 16 columns of its own block
   int parent[NB];
   int ncon, ncand, pad0, pad1;
+  // three phase-local areas share storage: dynamics scratch + M (FK .. smooth solve), collision scratch, and the
+  // dense Newton Hessian (row i = lane i, stride HSTR: a 16-lane group's b128 accesses cover all 64 banks)
   union {
-    Dyn64 dyn;
-    struct {
-      Con64 con;
-      union {
-        float Jb[MAXC][2][JSEG];
-        Col64 col;
-      };
-    };
+    DynM64 dm;
+    Col64 col;
+    float H[NL][HSTR];
   };
+  Con64 con;
+  float Jb[MAXC][2][JSEG];
 };
 
 struct BodyK64 {
@@ -165,20 +183,20 @@ __device__ __forceinline__ void wave_fk(Env64& S, int lane, int nb, const BodyK6
       pl = ld3(&S.qpos[k.qadr]);
       ql = qnormalize(ld4(&S.qpos[k.qadr + 3]));
     }
-    st3v(S.dyn.lpos[lane], pl);
-    st4v(S.dyn.lquat[lane], ql);
+    st3v(S.dm.dyn.lpos[lane], pl);
+    st4v(S.dm.dyn.lquat[lane], ql);
   } else if (lane == 0) {
-    st3v(S.dyn.lpos[0], v3(0, 0, 0));
-    st4v(S.dyn.lquat[0], Q4{1, 0, 0, 0});
+    st3v(S.dm.dyn.lpos[0], v3(0, 0, 0));
+    st4v(S.dm.dyn.lquat[0], Q4{1, 0, 0, 0});
   }
   WSYNC();
   if (lane < nb) {
-    V3 P = ld3v(S.dyn.lpos[lane]);
-    Q4 Qx = ld4v(S.dyn.lquat[lane]);
+    V3 P = ld3v(S.dm.dyn.lpos[lane]);
+    Q4 Qx = ld4v(S.dm.dyn.lquat[lane]);
     int anc = lane > 0 ? S.parent[lane] : 0;
     while (anc > 0) {
-      Q4 qa = ld4v(S.dyn.lquat[anc]);
-      P = ld3v(S.dyn.lpos[anc]) + qrot(qa, P);
+      Q4 qa = ld4v(S.dm.dyn.lquat[anc]);
+      P = ld3v(S.dm.dyn.lpos[anc]) + qrot(qa, P);
       Qx = qmul(qa, Qx);
       anc = S.parent[anc];
     }
@@ -242,6 +260,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   const float d_frclo = m->d_frclo[lane], d_frchi = m->d_frchi[lane], d_mdiag = m->d_mdiag[lane];
   const int d_qbase = m->b_qadr[d_body], d_lbase = m->b_dofadr[d_body];
 
+  STAMP(0);
   // ---- load state -----------------------------------------------------------------------------
   S.qpos[lane] = a.qpos[(size_t)env * K64_QSTRIDE + lane];
   S.qvel[lane] = a.qvel[(size_t)env * NL + lane];
@@ -270,6 +289,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       wave_fk(S, lane, nb, bk);
     }
   }
+  STAMP(1);
   const int nsteps = a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0);
   for (int step = 0; step < nsteps; step++) {
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       st3v(&S.cdof[lane][4], v3(0, 0, 0));
     }
     if (lane < NB) {
-      float* c = S.dyn.cinert[lane];
+      float* c = S.dm.dyn.cinert[lane];
       if (isbody) {
         M3 R = q2m(ld4v(S.xquat[lane]));
         float Ib[3][3] = {{ib[0], ib[3], ib[4]}, {ib[3], ib[1], ib[5]}, {ib[4], ib[5], ib[2]}};
@@ -318,6 +338,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     }
     WSYNC();
 
+    STAMP(2);
     // ======================= velocities, composite inertias =====================================
     {
       if (isdof) {  // lane = dof: cdof_dot * qvel, "velocity before this dof" from the pre-mask
@@ -332,11 +353,11 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         }
         V3 cw = ld3v(&S.cdof[lane][0]), cv = ld3v(&S.cdof[lane][4]);
         float qd = S.qvel[lane];
-        st3v(&S.dyn.cddq[lane][0], qd * cross(pw, cw));
-        st3v(&S.dyn.cddq[lane][4], qd * (cross(pw, cv) + cross(pv, cw)));
+        st3v(&S.dm.dyn.cddq[lane][0], qd * cross(pw, cw));
+        st3v(&S.dm.dyn.cddq[lane][4], qd * (cross(pw, cv) + cross(pv, cw)));
       } else {
-        st3v(&S.dyn.cddq[lane][0], v3(0, 0, 0));
-        st3v(&S.dyn.cddq[lane][4], v3(0, 0, 0));
+        st3v(&S.dm.dyn.cddq[lane][0], v3(0, 0, 0));
+        st3v(&S.dm.dyn.cddq[lane][4], v3(0, 0, 0));
       }
       if (lane < NB) {
         V3 w = v3(0, 0, 0), v = v3(0, 0, 0);
@@ -354,18 +375,19 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
           while (sm) {
             int c = __ffs(sm) - 1;
             sm &= sm - 1;
-            const float* p = S.dyn.cinert[c];
+            const float* p = S.dm.dyn.cinert[c];
             c0 += ldv(p); c1 += ldv(p + 4); c2 += ldv(p + 8);
           }
         }
-        st3v(&S.dyn.cvel[lane][0], w);
-        st3v(&S.dyn.cvel[lane][4], v);
-        float* p = S.dyn.crb[lane];
+        st3v(&S.dm.dyn.cvel[lane][0], w);
+        st3v(&S.dm.dyn.cvel[lane][4], v);
+        float* p = S.dm.dyn.crb[lane];
         stv(p, c0); stv(p + 4, c1); stv(p + 8, c2);
       }
     }
     WSYNC();
 
+    STAMP(3);
     // ======================= body forces (RNE, qacc=0) and mass matrix rows =======================
     {
       if (lane < NB) {
@@ -376,26 +398,26 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
           while (mk) {
             int j = __ffsll((unsigned long long)mk) - 1;
             mk &= mk - 1;
-            aw = aw + ld3v(&S.dyn.cddq[j][0]);
-            av = av + ld3v(&S.dyn.cddq[j][4]);
+            aw = aw + ld3v(&S.dm.dyn.cddq[j][0]);
+            av = av + ld3v(&S.dm.dyn.cddq[j][4]);
           }
-          Inert I = ldI(S.dyn.cinert[lane]);
-          V3 w = ld3v(&S.dyn.cvel[lane][0]), v = ld3v(&S.dyn.cvel[lane][4]);
+          Inert I = ldI(S.dm.dyn.cinert[lane]);
+          V3 w = ld3v(&S.dm.dyn.cvel[lane][0]), v = ld3v(&S.dm.dyn.cvel[lane][4]);
           V3 ta, fa, tv, fv;
           imul(I, aw, av, ta, fa);
           imul(I, w, v, tv, fv);
           t = ta + cross(w, tv) + cross(v, fv);
           f = fa + cross(w, fv);
         }
-        st3v(&S.dyn.cfrc[lane][0], t);
-        st3v(&S.dyn.cfrc[lane][4], f);
+        st3v(&S.dm.dyn.cfrc[lane][0], t);
+        st3v(&S.dm.dyn.cfrc[lane][4], f);
       }
 #pragma unroll
-      for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{0, 0, 0, 0});
+      for (int q = 0; q < 4; q++) stv(&S.dm.M[lane][4 * q], f4{0, 0, 0, 0});
     }
     WSYNC();
     if (isdof) {  // M[i][j] = cdof_j . (crb_body(i) cdof_i), j over ancestors-or-self (same tree => same block)
-      Inert I = ldI(S.dyn.crb[d_body]);
+      Inert I = ldI(S.dm.dyn.crb[d_body]);
       V3 bt, bf;
       imul(I, ld3v(&S.cdof[lane][0]), ld3v(&S.cdof[lane][4]), bt, bf);
       uint64_t mk = d_ancmask;
@@ -404,8 +426,8 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         mk &= mk - 1;
         float val = dot(ld3v(&S.cdof[j][0]), bt) + dot(ld3v(&S.cdof[j][4]), bf);
         if (j == lane) val += d_mdiag;
-        S.M[lane][j & 15] = val;
-        S.M[j][l16] = val;
+        S.dm.M[lane][j & 15] = val;
+        S.dm.M[j][l16] = val;
       }
     }
     float qfrc_bias = 0.0f, qfs = 0.0f;
@@ -415,8 +437,8 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       while (sm) {
         int c = __ffs(sm) - 1;
         sm &= sm - 1;
-        t = t + ld3v(&S.dyn.cfrc[c][0]);
-        f = f + ld3v(&S.dyn.cfrc[c][4]);
+        t = t + ld3v(&S.dm.dyn.cfrc[c][0]);
+        f = f + ld3v(&S.dm.dyn.cfrc[c][4]);
       }
       qfrc_bias = dot(ld3v(&S.cdof[lane][0]), t) + dot(ld3v(&S.cdof[lane][4]), f);
       float qd = S.qvel[lane];
@@ -428,10 +450,11 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       qfs = -d_damping * qd + fa - qfrc_bias;
     }
     WSYNC();
+    STAMP(4);
     // qacc_smooth = Mt^-1 qfrc_smooth: four block solves side by side (Gauss-Jordan on 16-wide register rows)
     float mrow[G];
     {
-      f4 r0 = ldv(&S.M[lane][0]), r1 = ldv(&S.M[lane][4]), r2 = ldv(&S.M[lane][8]), r3 = ldv(&S.M[lane][12]);
+      f4 r0 = ldv(&S.dm.M[lane][0]), r1 = ldv(&S.dm.M[lane][4]), r2 = ldv(&S.dm.M[lane][8]), r3 = ldv(&S.dm.M[lane][12]);
       mrow[0] = r0.x; mrow[1] = r0.y; mrow[2] = r0.z; mrow[3] = r0.w; mrow[4] = r1.x; mrow[5] = r1.y; mrow[6] = r1.z; mrow[7] = r1.w;
       mrow[8] = r2.x; mrow[9] = r2.y; mrow[10] = r2.z; mrow[11] = r2.w; mrow[12] = r3.x; mrow[13] = r3.y; mrow[14] = r3.z; mrow[15] = r3.w;
     }
@@ -458,6 +481,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     if (a.out_qas && isdof && step == 0) a.out_qas[(size_t)env * nv + m->d_dof[lane]] = qas;
     WSYNC();  // dyn scratch is dead from here on
 
+    STAMP(5);
     // ======================= collision detection ================================================
     if (lane == 0) { S.ncon = 0; S.ncand = 0; }
     if (lane < ngeom) {
@@ -501,6 +525,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       ncand = base < NL ? base : NL;
       if (lane == 0) S.ncand = ncand;
       WSYNC();
+      STAMP(6);
       // narrowphase, plane-box: DPP row r takes candidates r, r + 4, ...; the 8 box corners on lanes 0..7 of the row
       for (int k0 = 0; k0 < ncand; k0 += 4) {
         const int k = k0 + blk;
@@ -541,6 +566,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       }
       WSYNC();
       mycount = S.col.ccount[lane];
+      STAMP(7);
       // narrowphase, box-box: one lane per candidate
       if (lane < ncand) {
         const int pr = m->pair[S.col.cand[lane]];
@@ -556,6 +582,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         }
       }
     }
+    STAMP(8);
     // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
     const int maxc = max_contacts < MAXC ? max_contacts : MAXC;
     int ncon;
@@ -616,6 +643,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     }
     WSYNC();  // col scratch is dead from here on (Jb may overwrite it)
 
+    STAMP(9);
     // ======================= constraint rows ======================================================
     // contact base Jacobians: lane = dof writes its entry of the segment its block owns (zeros included, so a
     // segment is always fully defined)
@@ -671,6 +699,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       aref[3] = base - bb * (vn - cmu * v2);
     }
 
+    STAMP(10);
     // ======================= primal Newton solve ====================================================
     const unsigned long long limmask = __ballot(lsg != 0.0f);
     const int nefc = 4 * ncon + __popcll(limmask);
@@ -715,20 +744,43 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       WSYNC();
       Ma = isdof ? rowdot(mrow, xblk_qacc) : 0.0f;
     }
+    STAMP(11);
     int niter = 0;
     const float tol = m->tolerance, scale = m->solver_scale;
     const float gfloor = 16.0f * 5.96e-8f * sqrtf(wsum(Ma * Ma + qfs * qfs));
-    // Hessian row kept across iterations (incremental update, as in the 16-lane kernel); 64 registers
-    float hkeep[NL];
+    // which blocks can ever be coupled this step: contacts spanning two blocks, closed transitively (wave-uniform)
+    unsigned comp = 0x8421u;  // every block with itself
+    {
+      unsigned mine = 0u;
+      if (iscon) {
+        const int s0 = S.con.cblk[lane][0], s1 = S.con.cblk[lane][1];
+        if (s0 >= 0 && s1 >= 0) mine = (1u << (4 * s0 + s1)) | (1u << (4 * s1 + s0));
+      }
 #pragma unroll
-    for (int j = 0; j < NL; j++) hkeep[j] = j == lane ? 1.0f : 0.0f;
-    if (isdof) {
+      for (int bit = 0; bit < 16; bit++)
+        if (__ballot((mine >> bit) & 1u)) comp |= 1u << bit;
 #pragma unroll
-      for (int bq = 0; bq < 4; bq++)
-        if (bq == blk) {
+      for (int round = 0; round < 2; round++)
 #pragma unroll
-          for (int j = 0; j < G; j++) hkeep[16 * bq + j] = mrow[j];
-        }
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if ((comp >> (4 * p + q)) & 1u) comp |= ((comp >> (4 * q)) & 15u) << (4 * p);
+    }
+    // Dense Hessian H = Mt + J^T D_active J in LDS, kept across iterations and updated incrementally (only rows whose
+    // active flag flipped contribute, as in the 16-lane kernel).  Initial rows: Mt in the lane's own block, identity on
+    // padding lanes.  (The collision scratch this overlays is dead: the barrier above separates its last read.)
+    {
+      float* hr = &S.H[lane][0];
+#pragma unroll
+      for (int q = 0; q < 16; q++) stv(hr + 4 * q, f4{0, 0, 0, 0});
+      if (isdof) {
+        float* hb = hr + 16 * blk;
+#pragma unroll
+        for (int q = 0; q < 4; q++) stv(hb + 4 * q, f4{mrow[4 * q], mrow[4 * q + 1], mrow[4 * q + 2], mrow[4 * q + 3]});
+      } else {
+        hr[lane] = 1.0f;
+      }
     }
     float oldlact = 0.0f;
     unsigned prevbits = 0u;
@@ -763,38 +815,59 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       if (!isdof) g = 0.0f;
       const float gn = sqrtf(wsum(g * g));
       if (scale * gn < tol || gn < gfloor) { done = true; break; }
-      // ---- Hessian row (lane = dof): incremental update of H = Mt + J^T D_active J
-#pragma unroll
-      for (int j = 0; j < NL; j++) hkeep[j] += j == lane ? lact - oldlact : 0.0f;
+      if (it == 0) STAMP(12);
+      // ---- Hessian rows (lane = dof): incremental update of H = Mt + J^T D_active J in LDS
+      if (lact != oldlact) S.H[lane][lane] += lact - oldlact;
       oldlact = lact;
       for (int c = 0; c < ncon; c++) {
         const f4 fb = ldv(S.con.cfb[c]);
         const unsigned both = (unsigned)fb.w;
         const unsigned bits = both & 15u, old = both >> 4;
         if (bits == old) continue;  // wave-uniform
-        const int sg0 = __builtin_amdgcn_readfirstlane(S.con.cblk[c][0]), sg1 = __builtin_amdgcn_readfirstlane(S.con.cblk[c][1]);
+        const int sg0 = S.con.cblk[c][0], sg1 = S.con.cblk[c][1];
         const int myseg = blk == sg0 ? 0 : (blk == sg1 ? 1 : -1);
-        float jn = 0.0f, j1 = 0.0f, j2 = 0.0f;
-        if (myseg >= 0) {
-          const float* jb = &S.Jb[c][myseg][0];
-          jn = jb[l16]; j1 = jb[16 + l16]; j2 = jb[32 + l16];
-        }
+        if (myseg < 0) continue;  // only the rows of the (at most two) blocks the contact touches change
+        const float* jb = &S.Jb[c][myseg][0];
+        const float jn = jb[l16], j1 = jb[16 + l16], j2 = jb[32 + l16];
         const f4 mt = ldv(S.con.cmeta[c]);
         const float mu = mt.x, D = mt.y;
         const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
         const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
         const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
         const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
-        if (sg0 >= 0) hupd_blk(hkeep, sg0, &S.Jb[c][0][0], tn, t1, t2);
-        if (sg1 >= 0) hupd_blk(hkeep, sg1, &S.Jb[c][1][0], tn, t1, t2);
+#pragma unroll
+        for (int sgi = 0; sgi < 2; sgi++) {
+          const int bs = sgi == 0 ? sg0 : sg1;
+          if (bs < 0) continue;
+          float* hb = &S.H[lane][16 * bs];
+          const float* seg = &S.Jb[c][sgi][0];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const f4 xn = ldv(seg + 4 * q), x1 = ldv(seg + 16 + 4 * q), x2 = ldv(seg + 32 + 4 * q);
+            f4 hq = ldv(hb + 4 * q);
+            hq.x += tn * xn.x + t1 * x1.x + t2 * x2.x;
+            hq.y += tn * xn.y + t1 * x1.y + t2 * x2.y;
+            hq.z += tn * xn.z + t1 * x1.z + t2 * x2.z;
+            hq.w += tn * xn.w + t1 * x1.w + t2 * x2.w;
+            stv(hb + 4 * q, hq);
+          }
+        }
       }
       float hrow[NL];
+      {
+        const float* hr = &S.H[lane][0];
 #pragma unroll
-      for (int j = 0; j < NL; j++) hrow[j] = hkeep[j];
+        for (int q = 0; q < 16; q++) {
+          const f4 v = ldv(hr + 4 * q);
+          hrow[4 * q] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
+        }
+      }
+      if (it == 0) STAMP(13);
       // ---- Newton direction: H s = -g (dense over the wave)
       float sv = -g;
-      GJW<0>::run(hrow, sv, lane, lanemask);
+      gj_wave(hrow, sv, lane, lanemask, comp);
       if (!isdof) sv = 0.0f;
+      if (it == 0) STAMP(14);
       S.srch[lane] = sv;
       WSYNC();
       const float mv = isdof ? rowdot(mrow, xblk_srch) : 0.0f;
@@ -832,6 +905,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         }
         if (lsdone) break;  // wave-uniform
       }
+      if (it == 0) STAMP(15);
       // ---- improvement from the 1-D model, then the update (row-cost differences as 1/2 D d (2 x0 + d))
       float pim = 0.0f;
 #pragma unroll
@@ -870,6 +944,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       }
       WSYNC();
     }
+    STAMP(16);
     if (a.out_qacc && isdof && step == 0) a.out_qacc[(size_t)env * nv + m->d_dof[lane]] = qacc;
     if (a.diag && lane == 0) {
       a.diag[(size_t)env * 4 + 0] = ncon;
@@ -904,9 +979,11 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       }
     }
     WSYNC();
+    STAMP(17);
     // kinematics of the new state: observations of this step, and the next step's starting poses
     wave_fk(S, lane, nb, bk);
   }  // steps
+  STAMP(18);
   if (lane < nb) {
     float* p = a.poses + ((size_t)env * 2 * NB + lane) * 4;
     *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
@@ -960,6 +1037,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3v(S.xpos[lane]));
     st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));
   }
+  STAMP(19);
 }
 
 }  // namespace

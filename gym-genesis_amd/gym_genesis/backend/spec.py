@@ -16,7 +16,7 @@ MIR_MAX_DOF = 48
 MIR_MAX_Q = 56
 MIR_MAX_GEOM = 40
 MIR_MAX_PAIR = 256
-MIR_MAX_CONTACT = 64
+MIR_MAX_CONTACT = 48
 MIR_MAX_GRIP = 4
 MIR_MAX_FREE = 8
 # limits of the 16-lanes-per-env kernel (the pick tasks); larger scenes run on the wave-per-env kernel

@@ -52,7 +52,7 @@ extern "C" {
 #define MIR_MAX_Q 56    /* nq */
 #define MIR_MAX_GEOM 40
 #define MIR_MAX_PAIR 256   /* candidate geom pairs after static filtering */
-#define MIR_MAX_CONTACT 64 /* contacts kept per env per step (plane-box <= 4, box-box <= 8 per pair) */
+#define MIR_MAX_CONTACT 48 /* contacts kept per env per step (plane-box <= 4, box-box <= 8 per pair) */
 #define MIR_MAX_GRIP 4
 #define MIR_MAX_FREE 8     /* free bodies (cubes) */
 

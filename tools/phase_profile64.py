@@ -1,0 +1,28 @@
+"""Phase timing of the wave-per-env kernel (shader clock of env 0): GPU probe for the stack tasks."""
+import ctypes as C, os, sys
+import numpy as np, torch
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "gym-genesis_amd"))
+from gym_genesis.env import GenesisEnv
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+env = GenesisEnv(task="cube_stack", robot="franka", num_envs=B)
+env.reset(seed=0)
+task = env._env; sc = task._mir
+sc.lib.mir_debug_profile_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+sc.lib.mir_debug_profile_step.restype = C.c_int
+home = task._home
+for t in range(10): task.step_raw(home)
+names = ["load", "fk/cache", "cdof+cinert", "vel+crb", "rne+M", "smooth solve", "geom+broad", "plane-box", "box-box", "compact+finish", "J + limit rows",
+         "warm start", "grad(it0)", "hessian(it0)", "GJ64(it0)", "linesearch(it0)", "rest of newton", "integrate", "fk", "store+obs"]
+acc = np.zeros(19)
+n = 20
+for r in range(n):
+    prof = torch.zeros(32, dtype=torch.int64, device=sc.device)
+    sc._check(sc.lib.mir_debug_profile_step(sc.h, C.c_void_p(prof.data_ptr()), sc._stream()))
+    torch.cuda.synchronize()
+    p = prof.cpu().numpy().astype(np.float64)
+    acc += np.diff(p[:20])
+acc /= n
+for nm, c in zip(names[1:], acc):
+    print(f"{nm:18s} {c:9.0f} cycles")
+print(f"{'total':18s} {acc.sum():9.0f} cycles; diag: ncon {sc.get_diag()[0][0].item()} niter {sc.get_diag()[2][0].item()}")
