@@ -164,7 +164,20 @@ __device__ __forceinline__ float bh(const BoxG& b, int k) { return k == 0 ? b.h.
 
 // box-box by separating axes + reference-face clipping; normal from A to B; up to 8 points.
 // Rare (only when bounding spheres overlap) and register-hungry: kept out of line.
-__device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4], V3& nout) {
+// Polygon workspace of the clipping stage (6 arrays x 9 floats, dynamically indexed).  PolyScratch keeps it in
+// private memory (the 16-lane kernel: the routine is rare there and its LDS is full); PolyLds places element k of this
+// lane at base[k * 64], a lane-interleaved, bank-conflict-free LDS area (the wave kernel runs the routine every step
+// for the cube-slab pairs, where scratch round trips dominated).
+struct PolyScratch {
+  float a[6][9];
+  __device__ __forceinline__ float& at(int arr, int i) { return a[arr][i]; }
+};
+struct PolyLds {
+  float* base;  // already offset by the lane index
+  __device__ __forceinline__ float& at(int arr, int i) { return base[(arr * 9 + i) * 64]; }
+};
+template <class Poly>
+__device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4], V3& nout, Poly P) {
   V3 t = B.p - A.p;
   float best = -1e30f;
   int code = -1;
@@ -229,16 +242,33 @@ __device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4
   V3 ic = I.p + (sj * bh(I, jb)) * bax(I, jb);
   V3 e1 = bax(R, k1), e2 = bax(R, k2);
   float h1 = bh(R, k1), h2 = bh(R, k2);
-  float px[9], py[9], pz[9], qx[9], qy[9], qz[9];
   int np = 4;
   {
     const float sx[4] = {1, -1, -1, 1}, sy[4] = {1, 1, -1, -1};
+    float vx[4], vy[4], vz[4];
+    bool inside = true;
 #pragma unroll
     for (int v = 0; v < 4; v++) {
       V3 w = ic + (sx[v] * bh(I, j1)) * bax(I, j1) + (sy[v] * bh(I, j2)) * bax(I, j2);
       V3 rel = w - fc;
-      px[v] = dot(rel, e1); py[v] = dot(rel, e2); pz[v] = dot(rel, nr);
+      vx[v] = dot(rel, e1); vy[v] = dot(rel, e2); vz[v] = dot(rel, nr);
+      inside = inside && fabsf(vx[v]) <= h1 && fabsf(vy[v]) <= h2;
     }
+    if (inside) {
+      // the whole incident face lies over the reference face (a cube resting on the slab): clipping against the four
+      // edges would hand back the same four vertices in the same order, so emit them from registers
+      int cnt = 0;
+#pragma unroll
+      for (int v = 0; v < 4; v++)
+        if (vz[v] < 0.0f) {
+          V3 w = fc + vx[v] * e1 + vy[v] * e2 + (0.5f * vz[v]) * nr;
+          out[cnt][0] = w.x; out[cnt][1] = w.y; out[cnt][2] = w.z; out[cnt][3] = vz[v];
+          cnt++;
+        }
+      return cnt;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) { P.at(0, v) = vx[v]; P.at(1, v) = vy[v]; P.at(2, v) = vz[v]; }
   }
   for (int e = 0; e < 4; e++) {
     const int ax = e >> 1;
@@ -247,24 +277,24 @@ __device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4
     int nn = 0;
     for (int v = 0; v < np; v++) {
       int w = v + 1 == np ? 0 : v + 1;
-      float pc = ax == 0 ? px[v] : py[v], qc = ax == 0 ? px[w] : py[w];
+      float pc = ax == 0 ? P.at(0, v) : P.at(1, v), qc = ax == 0 ? P.at(0, w) : P.at(1, w);
       float dp = sg * pc - lim, dq = sg * qc - lim;
-      if (dp <= 0.0f && nn < 9) { qx[nn] = px[v]; qy[nn] = py[v]; qz[nn] = pz[v]; nn++; }
+      if (dp <= 0.0f && nn < 9) { P.at(3, nn) = P.at(0, v); P.at(4, nn) = P.at(1, v); P.at(5, nn) = P.at(2, v); nn++; }
       if ((dp <= 0.0f) != (dq <= 0.0f) && nn < 9) {
         float u = dp / (dp - dq);
-        qx[nn] = px[v] + u * (px[w] - px[v]); qy[nn] = py[v] + u * (py[w] - py[v]); qz[nn] = pz[v] + u * (pz[w] - pz[v]);
+        P.at(3, nn) = P.at(0, v) + u * (P.at(0, w) - P.at(0, v)); P.at(4, nn) = P.at(1, v) + u * (P.at(1, w) - P.at(1, v)); P.at(5, nn) = P.at(2, v) + u * (P.at(2, w) - P.at(2, v));
         nn++;
       }
     }
     np = nn;
-    for (int v = 0; v < np; v++) { px[v] = qx[v]; py[v] = qy[v]; pz[v] = qz[v]; }
+    for (int v = 0; v < np; v++) { P.at(0, v) = P.at(3, v); P.at(1, v) = P.at(4, v); P.at(2, v) = P.at(5, v); }
     if (np == 0) return 0;
   }
   int cnt = 0;
   for (int v = 0; v < np && cnt < 8; v++) {
-    if (pz[v] < 0.0f) {
-      V3 w = fc + px[v] * e1 + py[v] * e2 + (0.5f * pz[v]) * nr;
-      out[cnt][0] = w.x; out[cnt][1] = w.y; out[cnt][2] = w.z; out[cnt][3] = pz[v];
+    if (P.at(2, v) < 0.0f) {
+      V3 w = fc + P.at(0, v) * e1 + P.at(1, v) * e2 + (0.5f * P.at(2, v)) * nr;
+      out[cnt][0] = w.x; out[cnt][1] = w.y; out[cnt][2] = w.z; out[cnt][3] = P.at(2, v);
       cnt++;
     }
   }

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
           M3 R1 = q2m(ld4v(S.col.gquat[g1]));
           BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
           V3 n = v3(0, 0, 1);
-          mycount = box_box(B1, B2, S.col.stage[lane], n);
+          mycount = box_box(B1, B2, S.col.stage[lane], n, PolyScratch());
           st3v(S.col.snorm[lane], n);
         }
       }

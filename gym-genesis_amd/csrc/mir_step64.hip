@@ -140,6 +140,8 @@ struct Con64 {
   unsigned cmask[MAXC][4];  // lane masks of body1 (lo, hi), body2 (lo, hi)
   int cblk[MAXC][4];      // block of segment 0, of segment 1 (-1 = none), pad, pad
   float cfb[MAXC][4];     // per-iteration base forces (n, t1, t2), active-row flags
+  int blist[4][MAXC];     // per block: the contacts that touch it, as contact * 2 + segment, ascending
+  int bcount[4];
 };
 struct DynM64 {
   Dyn64 dyn;
@@ -577,7 +579,8 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
           M3 R1 = q2m(ld4v(S.col.gquat[g1]));
           BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(m->g_size[g1])};
           V3 n = v3(0, 0, 1);
-          mycount = box_box(B1, B2, S.col.stage[lane], n);
+          // clipping workspace: the contact-Jacobian area is not written before the contacts are finished
+          mycount = box_box(B1, B2, S.col.stage[lane], n, PolyLds{&S.Jb[0][0][0] + lane});
           st3v(S.col.snorm[lane], n);
         }
       }
@@ -641,16 +644,30 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         S.con.cblk[k][0] = sg0; S.con.cblk[k][1] = sg1; S.con.cblk[k][2] = 0; S.con.cblk[k][3] = 0;
       }
     }
-    WSYNC();  // col scratch is dead from here on (Jb may overwrite it)
+    WSYNC();  // col scratch is dead from here on
+    // per-block contact lists (lane = contact; ordered ballot compaction): every later loop of a dof lane runs over
+    // the contacts that touch ITS block only, and the four blocks (DPP rows) walk their lists side by side
+    {
+      const bool isc = lane < ncon;
+      const int s0 = isc ? S.con.cblk[lane][0] : -1, s1 = isc ? S.con.cblk[lane][1] : -1;
+#pragma unroll
+      for (int bq = 0; bq < 4; bq++) {
+        const bool touch = isc && (s0 == bq || s1 == bq);
+        const unsigned long long bal = __ballot(touch);
+        if (touch) S.con.blist[bq][__popcll(bal & ((1ull << lane) - 1ull))] = lane * 2 + (s0 == bq ? 0 : 1);
+        if (lane == 0) S.con.bcount[bq] = __popcll(bal);
+      }
+    }
+    WSYNC();
+    const int nmine = S.con.bcount[blk];  // contacts touching this lane's block
 
     STAMP(9);
     // ======================= constraint rows ======================================================
     // contact base Jacobians: lane = dof writes its entry of the segment its block owns (zeros included, so a
     // segment is always fully defined)
-    for (int c = 0; c < ncon; c++) {
-      const int sg0 = S.con.cblk[c][0], sg1 = S.con.cblk[c][1];
-      const int myseg = blk == sg0 ? 0 : (blk == sg1 ? 1 : -1);
-      if (myseg < 0) continue;
+    for (int kq = 0; kq < nmine; kq++) {
+      const int eq = S.con.blist[blk][kq];
+      const int c = eq >> 1, myseg = eq & 1;
       float jn = 0.0f, j1 = 0.0f, j2 = 0.0f;
       const uint64_t dm1 = (uint64_t)S.con.cmask[c][0] | ((uint64_t)S.con.cmask[c][1] << 32);
       const uint64_t dm2 = (uint64_t)S.con.cmask[c][2] | ((uint64_t)S.con.cmask[c][3] << 32);
@@ -804,12 +821,10 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       WSYNC();
       // ---- gradient first (cheap): convergence is decided before any Hessian work
       float g = isdof ? Ma - qfs - lsg * lf : 0.0f;
-      for (int c = 0; c < ncon; c++) {
-        const int sg0 = S.con.cblk[c][0], sg1 = S.con.cblk[c][1];
-        const int myseg = blk == sg0 ? 0 : (blk == sg1 ? 1 : -1);
-        if (myseg < 0) continue;
-        const float* jb = &S.Jb[c][myseg][0];
-        const f4 fb = ldv(S.con.cfb[c]);
+      for (int kq = 0; kq < nmine; kq++) {
+        const int eq = S.con.blist[blk][kq];
+        const float* jb = &S.Jb[eq >> 1][eq & 1][0];
+        const f4 fb = ldv(S.con.cfb[eq >> 1]);
         g -= jb[l16] * fb.x + jb[16 + l16] * fb.y + jb[32 + l16] * fb.z;
       }
       if (!isdof) g = 0.0f;
@@ -819,14 +834,14 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       // ---- Hessian rows (lane = dof): incremental update of H = Mt + J^T D_active J in LDS
       if (lact != oldlact) S.H[lane][lane] += lact - oldlact;
       oldlact = lact;
-      for (int c = 0; c < ncon; c++) {
+      for (int kq = 0; kq < nmine; kq++) {  // only the rows of the (at most two) blocks a contact touches change
+        const int eq = S.con.blist[blk][kq];
+        const int c = eq >> 1, myseg = eq & 1;
         const f4 fb = ldv(S.con.cfb[c]);
         const unsigned both = (unsigned)fb.w;
         const unsigned bits = both & 15u, old = both >> 4;
-        if (bits == old) continue;  // wave-uniform
+        if (bits == old) continue;
         const int sg0 = S.con.cblk[c][0], sg1 = S.con.cblk[c][1];
-        const int myseg = blk == sg0 ? 0 : (blk == sg1 ? 1 : -1);
-        if (myseg < 0) continue;  // only the rows of the (at most two) blocks the contact touches change
         const float* jb = &S.Jb[c][myseg][0];
         const float jn = jb[l16], j1 = jb[16 + l16], j2 = jb[32 + l16];
         const f4 mt = ldv(S.con.cmeta[c]);
@@ -853,19 +868,30 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
           }
         }
       }
-      float hrow[NL];
-      {
+      if (it == 0) STAMP(13);
+      // ---- Newton direction: H s = -g.  When no contact couples two blocks this step (comp = identity: the arm is
+      // not touching a cube and no two cubes of different blocks touch), H is block-diagonal like M and the four
+      // blocks are solved side by side by the 16-wide DPP Gauss-Jordan; otherwise dense over the wave.
+      float sv = -g;
+      if (comp == 0x8421u) {
+        float hb[G];
+        const float* hr = &S.H[lane][16 * blk];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const f4 v = ldv(hr + 4 * q);
+          hb[4 * q] = v.x; hb[4 * q + 1] = v.y; hb[4 * q + 2] = v.z; hb[4 * q + 3] = v.w;
+        }
+        GJ<0>::run(hb, sv, l16);
+      } else {
+        float hrow[NL];
         const float* hr = &S.H[lane][0];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
           const f4 v = ldv(hr + 4 * q);
           hrow[4 * q] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
         }
+        gj_wave(hrow, sv, lane, lanemask, comp);
       }
-      if (it == 0) STAMP(13);
-      // ---- Newton direction: H s = -g (dense over the wave)
-      float sv = -g;
-      gj_wave(hrow, sv, lane, lanemask, comp);
       if (!isdof) sv = 0.0f;
       if (it == 0) STAMP(14);
       S.srch[lane] = sv;
