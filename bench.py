@@ -120,6 +120,41 @@ def pixels_bench(dev, renders: int = 30):
                                  "(FK refresh + primitive setup + pixel kernel), HIP events"}}
 
 
+def stack_bench(dev, steps: int = 300):
+    """Secondary: gym_genesis/CubeStack-v0 (robot=franka: Panda x0.6 + five free cubes on the island slab, 39 dofs) at 4096
+    envs on the wave-per-env kernel (mir_step64).  Fresh PD targets = home + U(-1,1) per step, resident in HBM; one fused
+    launch per step; HIP events on the launching stream.  Algorithmic bytes per env-step, same accounting as SURVEY.md 8d:
+    read qpos 44 + qvel 39 + action 9 + warm start 39 = 131 f32, write qpos 44 + qvel 39 + warm start 39 + obs 23 + reward 1
+    = 146 f32 + 1 B mask => 1109 B."""
+    from gym_genesis.env import GenesisEnv
+
+    B = ENVS_PER_GPU
+    env = GenesisEnv(task="cube_stack", robot="franka", num_envs=B, enable_pixels=False)
+    task = env._env
+    env.reset(seed=0)
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    acts = task._home[0] + torch.empty((256, B, 9), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
+    for t in range(30):
+        task.step_raw(acts[t])
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for t in range(steps):
+        task.step_raw(acts[t % 256])
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us = ev0.elapsed_time(ev1) * 1e3 / steps
+    ncon, _, niter = (x.float().mean().item() for x in task._mir.get_diag())
+    algo = 1109.0
+    achieved = algo * B / (us * 1e-6) / 1e9
+    del env
+    return {"workload": "CubeStack-v0 robot=franka (39 dofs, 5 cubes) state-only obs, home + U(-1,1) joint targets, num_envs=4096",
+            "env_steps_per_s": B / (us * 1e-6), "us_per_step": us, "mean_contacts": ncon, "mean_newton_iterations": niter,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "mir_step64_kernel",
+                         "note": "1109 algorithmic B/env-step; one wave per env, 3 envs per CU: latency/occupancy-bound like the pick kernel"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +166,7 @@ def main():
                     help="N>1: all-gather the packed rows of this many consecutive steps in one collective (1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pixels", action="store_true", help="skip the secondary pixels (configs[4]) measurement")
+    ap.add_argument("--no-stack", action="store_true", help="skip the secondary CubeStack-v0 measurement")
     ap.add_argument("--force-gather", action="store_true", help="exercise the RCCL gather path even with one rank (plumbing check)")
     args = ap.parse_args()
 
@@ -291,6 +327,8 @@ def main():
         }
         if world == 1 and not args.no_pixels:
             out["pixels"] = pixels_bench(dev)
+        if world == 1 and not args.no_stack:
+            out["stack"] = stack_bench(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
