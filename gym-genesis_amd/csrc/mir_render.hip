@@ -31,7 +31,7 @@
 
 #define TW 128   /* tile width, pixels  */
 #ifndef TH
-#define TH 160  /* rows per workgroup strip (multiple of 32): walked as 128 x 32 sub-tiles */
+#define TH 96   /* rows per workgroup strip (multiple of 32): walked as 128 x 32 sub-tiles */
 #endif
 #define RCAP 64  /* primitive records resident in LDS per round */
 #define PREC 32  /* floats per primitive record */
@@ -66,6 +66,10 @@ struct SetupArgs {
   const float* poses;       // (B, 2, pst, 4) FK cache
   int pst;                  // bodies per env in the pose cache
   const float* env_offset;  // (B, 3) or null
+  const float* cam_pos;     // (B, 3) per-env camera position, or null (use cam)
+  const float* cam_look;    // (B, 3) per-env look-at point
+  const float* cam_up;      // (B, 3) per-env up hint, or null (use up0)
+  float up0[3];
   float* prims;             // (B, ngeom, PREC)
   Cam cam;
   float light[3];
@@ -119,8 +123,19 @@ __global__ void k_render_setup(SetupArgs a) {
   const V3 ax[3] = {{1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)},
                     {2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)},
                     {2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)}};  // world axes (columns of R)
-  const V3 cp = {a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]}, cf = {a.cam.f[0], a.cam.f[1], a.cam.f[2]};
-  const V3 cr = {a.cam.r[0], a.cam.r[1], a.cam.r[2]}, cu = {a.cam.u[0], a.cam.u[1], a.cam.u[2]};
+  V3 cp = {a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]}, cf = {a.cam.f[0], a.cam.f[1], a.cam.f[2]};
+  V3 cr = {a.cam.r[0], a.cam.r[1], a.cam.r[2]}, cu = {a.cam.u[0], a.cam.u[1], a.cam.u[2]};
+  if (a.cam_pos) {  // per-env camera (wrist cameras): the same look-at construction as the host does for `cam`
+    cp = V3{a.cam_pos[e * 3], a.cam_pos[e * 3 + 1], a.cam_pos[e * 3 + 2]};
+    V3 d = V3{a.cam_look[e * 3], a.cam_look[e * 3 + 1], a.cam_look[e * 3 + 2]} - cp;
+    cf = (1.0f / sqrtf(fmaxf(dot(d, d), 1e-30f))) * d;
+    V3 up = a.cam_up ? V3{a.cam_up[e * 3], a.cam_up[e * 3 + 1], a.cam_up[e * 3 + 2]} : V3{a.up0[0], a.up0[1], a.up0[2]};
+    V3 rr = cross(cf, up);
+    if (dot(rr, rr) < 1e-12f) rr = cross(cf, V3{0.0f, 1.0f, 0.0f});  // view parallel to up: fall back to +y, then +x
+    if (dot(rr, rr) < 1e-12f) rr = cross(cf, V3{1.0f, 0.0f, 0.0f});
+    cr = (1.0f / sqrtf(dot(rr, rr))) * rr;
+    cu = cross(cr, cf);
+  }
   const V3 L = {a.light[0], a.light[1], a.light[2]};
   const V3 rel = cp - c;
   const V3 h = {m->g_size[g][0], m->g_size[g][1], m->g_size[g][2]};
@@ -337,22 +352,30 @@ void cross3(const double* a, const double* b, double* o) {
 
 extern "C" int mir_visual_sizeof(void) { return (int)sizeof(MirVisualSpec); }
 
-extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, int32_t mode, const float* env_offset,
-                          uint8_t* pixels, void* stream) {
+// shared body of mir_render / mir_render_cams: cam_pos == null -> one camera (cam->pos / lookat / up) for all images
+static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, int32_t mode, const float* env_offset,
+                       const float* cam_pos, const float* cam_look, const float* cam_up, uint8_t* pixels, void* stream) {
   if (!h || !cam || !vis || !pixels) return mir_set_error(MIR_E_INVALID, "mir_render: null argument");
   if (vis->struct_size != (int)sizeof(MirVisualSpec)) return mir_set_error(MIR_E_INVALID, "mir_render: MirVisualSpec size mismatch");
   if (cam->width <= 0 || cam->height <= 0 || !(cam->fov_deg > 0.0 && cam->fov_deg < 180.0))
     return mir_set_error(MIR_E_INVALID, "mir_render: bad camera (res / fov)");
   if (mode != MIR_RENDER_PER_ENV && mode != MIR_RENDER_GLOBAL) return mir_set_error(MIR_E_INVALID, "mir_render: unknown mode");
   if (!(vis->checker_size > 0.0)) return mir_set_error(MIR_E_INVALID, "mir_render: checker_size must be > 0");
-  double f[3], r[3], u[3], d[3] = {cam->lookat[0] - cam->pos[0], cam->lookat[1] - cam->pos[1], cam->lookat[2] - cam->pos[2]};
-  norm3(d, f);
-  double rr[3];
-  cross3(f, cam->up, rr);
-  norm3(rr, r);
-  cross3(r, f, u);
-  if (f[0] == 0 && f[1] == 0 && f[2] == 0) return mir_set_error(MIR_E_INVALID, "mir_render: camera pos == lookat");
-  if (r[0] == 0 && r[1] == 0 && r[2] == 0) return mir_set_error(MIR_E_INVALID, "mir_render: view direction parallel to up");
+  double f[3] = {1, 0, 0}, r[3] = {0, 1, 0}, u[3] = {0, 0, 1};
+  if (!cam_pos) {
+    double d[3] = {cam->lookat[0] - cam->pos[0], cam->lookat[1] - cam->pos[1], cam->lookat[2] - cam->pos[2]};
+    norm3(d, f);
+    if (f[0] == 0 && f[1] == 0 && f[2] == 0) return mir_set_error(MIR_E_INVALID, "mir_render: camera pos == lookat");
+    double rr[3];
+    cross3(f, cam->up, rr);
+    if (rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] < 1e-24) {  // view parallel to up (a top-down camera with up = +z:
+      const double ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};           // cube_stack_kitchen_batch.py:175): fall back to +y, then +x
+      cross3(f, ey, rr);
+      if (rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] < 1e-24) cross3(f, ex, rr);
+    }
+    norm3(rr, r);
+    cross3(r, f, u);
+  }
   int prev = -1;
   (void)hipGetDevice(&prev);
   if (prev != h->device) (void)hipSetDevice(h->device);
@@ -368,6 +391,8 @@ extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisual
     SetupArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.geom = h->dgeom; sa.poses = h->poses; sa.pst = h->pt.pst; sa.env_offset = env_offset; sa.prims = h->prims;
+    sa.cam_pos = cam_pos; sa.cam_look = cam_look; sa.cam_up = cam_up;
+    for (int k = 0; k < 3; k++) sa.up0[k] = (float)cam->up[k];
     const double ty = std::tan(0.5 * cam->fov_deg * M_PI / 180.0), tx = ty * (double)cam->width / (double)cam->height;
     for (int k = 0; k < 3; k++) { sa.cam.pos[k] = (float)cam->pos[k]; sa.cam.f[k] = (float)f[k]; sa.cam.r[k] = (float)r[k]; sa.cam.u[k] = (float)u[k]; }
     sa.cam.tanx = (float)tx; sa.cam.tany = (float)ty; sa.cam.W = cam->width; sa.cam.H = cam->height;
@@ -391,7 +416,6 @@ extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisual
       pa.sky = u8(vis->sky_rgb[0]) | u8(vis->sky_rgb[1]) << 8 | u8(vis->sky_rgb[2]) << 16;
     }
     pa.th = TH;
-    { const char* d = getenv("MIR_RENDER_TH"); if (d && atoi(d) >= 8) pa.th = (atoi(d) + 31) / 32 * 32; }
     const int nimg = mode == MIR_RENDER_GLOBAL ? 1 : B;
     hipLaunchKernelGGL(mir_render_kernel, dim3((cam->width + TW - 1) / TW, (cam->height + pa.th - 1) / pa.th, nimg), dim3(256), 0, st, pa);
     hipError_t e = hipGetLastError();
@@ -399,4 +423,15 @@ extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisual
   } while (0);
   if (prev != h->device && prev >= 0) (void)hipSetDevice(prev);
   return rc;
+}
+
+extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, int32_t mode, const float* env_offset,
+                          uint8_t* pixels, void* stream) {
+  return render_impl(h, cam, vis, mode, env_offset, nullptr, nullptr, nullptr, pixels, stream);
+}
+
+extern "C" int mir_render_cams(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, const float* cam_pos, const float* cam_lookat,
+                               const float* cam_up, uint8_t* pixels, void* stream) {
+  if (!cam_pos || !cam_lookat) return mir_set_error(MIR_E_INVALID, "mir_render_cams: null camera arrays");
+  return render_impl(h, cam, vis, MIR_RENDER_PER_ENV, nullptr, cam_pos, cam_lookat, cam_up, pixels, stream);
 }

@@ -58,6 +58,8 @@ def load_library() -> C.CDLL:
     lib.mir_render.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), i32, vp, vp, vp]
     lib.mir_render.restype = C.c_int
     lib.mir_visual_sizeof.restype = C.c_int
+    lib.mir_render_cams.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), vp, vp, vp, vp, vp]
+    lib.mir_render_cams.restype = C.c_int
     for name in ("mir_create", "mir_destroy", "mir_get_dims", "mir_get_model_consts", "mir_reset", "mir_autoreset", "mir_set_pd_targets",
                  "mir_step", "mir_step_fused", "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links",
                  "mir_get_diag", "mir_forward"):
@@ -221,4 +223,15 @@ class MirScene:
         if env_offset is not None:
             off = self._f32(env_offset, 3)
         self._check(self.lib.mir_render(self.h, C.byref(cam), C.byref(vis), int(mode), _ptr(off), _ptr(out), self._stream()))
+        return out
+
+    def render_cams(self, cam: MirCameraSpec, vis: MirVisualSpec, cam_pos, cam_lookat, cam_up=None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(B,H,W,3) RGB8 images, env i seen from its own camera cam_pos[i] -> cam_lookat[i] (mir_render_cams)."""
+        shape = (self.num_envs, cam.height, cam.width, 3)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        p, l = self._f32(cam_pos, 3), self._f32(cam_lookat, 3)
+        u = None if cam_up is None else self._f32(cam_up, 3)
+        self._check(self.lib.mir_render_cams(self.h, C.byref(cam), C.byref(vis), _ptr(p), _ptr(l), _ptr(u), _ptr(out), self._stream()))
         return out

@@ -17,6 +17,7 @@ a torch tensor on the device (the reference returns NumPy, which its own Genesis
 from __future__ import annotations
 
 import numpy as np
+import torch
 
 from ...backend import models
 from ..stack_common import StackTaskBase
@@ -31,6 +32,19 @@ class FrankaCubeStackKitchenBatch(StackTaskBase):
     ROBOT_ROOT = "link0"
     JOINTS = models.FRANKA_JOINTS
     EEF_LINK = "hand"
+
+    # cameras as created (utils.py:312-336) and as posed per env in get_obs() (cube_stack_kitchen_batch.py:175-182)
+    CAM_TOP = ((0.0, 0.0, 1.5), (0.0, 0.0, 0.0), 40.0)
+    CAM_SIDE = ((1.0, 0.0, 0.5), (0.0, 0.0, 0.5), 40.0)
+    CAM_WRIST = ((0.4, 0.0, 0.7), (0.0, 0.0, 1.0), 90.0)
+    PER_ENV_TOP = ((0.0, 0.0, 2.0), (0.0, 0.0, 0.5))
+    PER_ENV_SIDE = ((1.5, 0.0, 0.8), (0.0, 0.0, 0.5))
+
+    def _wrist_camera(self):
+        # "wrist view (approximation, fixed offset)": at the hand link, looking along +x (:185-192)
+        pos = self.eef.get_pos()
+        look = pos + torch.tensor([0.1, 0.0, 0.0], device=pos.device)
+        return pos, look, None, False
 
     def _scene_builder(self):
         return models.franka_cube_stack_scene()

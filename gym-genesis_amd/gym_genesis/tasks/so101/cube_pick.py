@@ -27,7 +27,7 @@ import torch
 from ..._gym import spaces
 from ...backend import models
 from ...backend.lib import MirScene
-from ..views import EntityView, SceneView
+from ..views import CameraView, EntityView, SceneView
 
 AGENT_DIM = len(models.SO101_JOINTS)  # declared space shape, as in the reference (cube_pick.py:15)
 ENV_DIM = 10                          # declared space shape (cube_pick.py:16)
@@ -48,8 +48,8 @@ class CubePick:
         self.shard_hi = self.global_num_envs * (rank + 1) // world
         self.num_envs = self.shard_hi - self.shard_lo
         self._random = np.random.RandomState()
-        if enable_pixels:
-            raise NotImplementedError("enable_pixels=True needs the batched rasteriser (SURVEY.md 8f-2), not built yet")
+        if enable_pixels and camera_capture_mode not in ("per_env", "global"):
+            raise ValueError(f"Unknown camera_capture_mode: {camera_capture_mode}")  # so101/cube_pick.py:154-155
         builder = models.so101_cube_pick_scene()
         self._builder = builder
         self._mir = MirScene(builder.build(), self.num_envs)
@@ -59,10 +59,21 @@ class CubePick:
         self.so_101 = EntityView(self._mir, builder, root="so101_base", dof_names=models.SO101_JOINTS)
         self.cube = EntityView(self._mir, builder, root="cube", dof_names=())
         self.eef = self.so_101.get_link("gripper")
+        if enable_pixels:
+            # The reference reads self.cam here but its scene builder only creates cam_top / cam_side / cam_wrist
+            # (utils.py:499-525; AttributeError).  Intent implemented: one camera posed like get_obs() poses it,
+            # envs_offset[i] + (3.5, 0, 2.5) -> envs_offset[i] + (0, 0, 0.5) (so101/cube_pick.py:139-147), fov 30 as in the
+            # Franka pick task this code was copied from (franka/cube_pick.py:56-63).
+            self.cam = CameraView(self._mir, builder, self.scene, res=(observation_width, observation_height),
+                                  pos=(3.5, 0.0, 2.5), lookat=(0, 0, 0.5), fov=30)
         self.motors_dof = np.arange(5)
         self.fingers_dof = np.array([5])
         box = lambda n: spaces.Box(low=-np.inf, high=np.inf, shape=(n,), dtype=np.float32)  # noqa: E731
-        self.observation_space = spaces.Dict({"agent_pos": box(AGENT_DIM), "environment_state": box(ENV_DIM)})
+        if enable_pixels:  # so101/cube_pick.py:45-50
+            self.observation_space = spaces.Dict({"agent_pos": box(AGENT_DIM), "pixels": spaces.Box(
+                low=0, high=255, shape=(observation_height, observation_width, 3), dtype=np.uint8)})
+        else:
+            self.observation_space = spaces.Dict({"agent_pos": box(AGENT_DIM), "environment_state": box(ENV_DIM)})
         self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(AGENT_DIM,), dtype=np.float32)
         B, dev = self.num_envs, self.device
         self._zero = torch.zeros((B, AGENT_DIM), dtype=torch.float32, device=dev)
@@ -104,7 +115,7 @@ class CubePick:
         self._agent, self._envst = mir.empty(AGENT_OBS), mir.empty(ENV_OBS)
         self._reward, self._term = mir.empty(), mir.empty(dtype=torch.uint8)
         mir.step_fused(a, self._agent, self._envst, self._reward, self._term)
-        return None, self._reward, None, {"agent_pos": self._agent, "environment_state": self._envst}
+        return None, self._reward, None, self._pack_obs()
 
     def step_raw(self, action_dev: torch.Tensor) -> None:
         self._mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)
@@ -115,7 +126,15 @@ class CubePick:
 
     def get_obs(self):
         self._agent, self._envst, self._reward, self._term = self._mir.get_obs()
-        return {"agent_pos": self._agent, "environment_state": self._envst}
+        return self._pack_obs()
+
+    def _pack_obs(self):
+        obs = {"agent_pos": self._agent, "environment_state": self._envst}
+        if self.enable_pixels:  # so101/cube_pick.py:134-157
+            if self.strip_environment_state is True:
+                del obs["environment_state"]
+            obs["pixels"] = self.cam.render_envs() if self.camera_capture_mode == "per_env" else self.cam.render_global()
+        return obs
 
     @property
     def terminated_device(self) -> torch.Tensor:

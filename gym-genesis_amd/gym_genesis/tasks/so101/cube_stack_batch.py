@@ -17,6 +17,7 @@ from __future__ import annotations
 import math
 
 import numpy as np
+import torch
 
 from ...backend import models
 from ..stack_common import StackTaskBase
@@ -31,6 +32,29 @@ class CubeStackBatch(StackTaskBase):
     ROBOT_ROOT = "so101_base"
     JOINTS = models.SO101_JOINTS
     EEF_LINK = "gripper"
+
+    # cameras as created (utils.py:668-696) and as posed per env in get_obs() (cube_stack_batch.py:185-196); this task
+    # renders per env whatever camera_capture_mode says (:181-222)
+    CAM_TOP = ((0.0, 0.0, 1.5), (0.0, 0.0, 0.0), 40.0)
+    CAM_SIDE = ((1.0, 0.0, 0.5), (0.0, 0.0, 0.5), 30.0)
+    CAM_WRIST = ((0.4, 0.0, 0.7), (0.0, 0.0, 1.0), 70.0)
+    PER_ENV_TOP = ((-0.05, 0.0, 1.8), (-0.2, 0.0, 0.5))
+    PER_ENV_SIDE = ((0.07, -1.0, 1.6), (-0.08, 0.0, 0.7))
+    PIXELS_ALWAYS_PER_ENV = True
+
+    def _wrist_camera(self):
+        # camera frame = gripper rotation * Rx(-pi/2 + 0.8), at gripper pos + (0.09, 0, -0.08); an OpenGL camera looks
+        # along its -z with +y up; the image is then rotated by 180 degrees (:199-213)
+        pos = self.eef.get_pos() + torch.tensor([0.09, 0.0, -0.08], device=self.device)
+        w, x, y, z = self.eef.get_quat().unbind(1)
+        R = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], 1),
+                         torch.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], 1),
+                         torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1)], 1)  # (B,3,3)
+        a = -math.pi / 2 + 0.8
+        Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, math.cos(a), -math.sin(a)], [0.0, math.sin(a), math.cos(a)]], device=self.device)
+        Rc = R @ Rx
+        fwd, up = -Rc[:, :, 2], Rc[:, :, 1]
+        return pos, pos + fwd, up.contiguous(), True
 
     def _scene_builder(self):
         return models.so101_cube_stack_scene()

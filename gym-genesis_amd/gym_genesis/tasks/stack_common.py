@@ -18,7 +18,7 @@ import torch
 from .._gym import spaces
 from ..backend import models
 from ..backend.lib import MirScene
-from .views import EntityView, SceneView
+from .views import CameraView, EntityView, SceneView
 
 ENV_OBS = 14  # [cube1 pos3, cube1 quat4, eef - cube1 3, |eef - cube1| 1, cube2 pos3]
 
@@ -44,8 +44,8 @@ class StackTaskBase:
         self.shard_hi = self.global_num_envs * (rank + 1) // world
         self.num_envs = self.shard_hi - self.shard_lo
         self._random = np.random.RandomState()
-        if enable_pixels:
-            raise NotImplementedError("enable_pixels=True for the stack tasks (top / side / wrist cameras) is not built yet")
+        if enable_pixels and camera_capture_mode not in ("per_env", "global"):
+            raise ValueError(f"Unknown camera_capture_mode: {camera_capture_mode}")
         builder = self._scene_builder()
         self._builder = builder
         self._mir = MirScene(builder.build(), self.num_envs)
@@ -58,6 +58,11 @@ class StackTaskBase:
         self.cube_2 = EntityView(self._mir, builder, root="cube_2", dof_names=())
         self.distractor_cubes = [EntityView(self._mir, builder, root=n, dof_names=()) for n in models.STACK_CUBES[2:]]
         self.eef = robot.get_link(self.EEF_LINK)
+        if enable_pixels:  # utils.py:310-337 / :668-696 -- top, side (observation resolution) and wrist (always 640x480)
+            res = (self.observation_width, self.observation_height)
+            mk = lambda res_, cfg: CameraView(self._mir, builder, self.scene, res=res_, pos=cfg[0], lookat=cfg[1], fov=cfg[2])  # noqa: E731
+            self.cam_top, self.cam_side = mk(res, self.CAM_TOP), mk(res, self.CAM_SIDE)
+            self.cam_wrist = mk((640, 480), self.CAM_WRIST)
         self.observation_space = self._make_obs_space()
         self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(self.AGENT_DIM,), dtype=np.float32)
         B, dev = self.num_envs, self.device
@@ -133,8 +138,35 @@ class StackTaskBase:
         self._agent, self._envst, self._reward, self._term = self._mir.get_obs()
         return self._pack_obs()
 
+    # cameras: (creation pos, creation lookat, fov) and the per-env poses of the reference's get_obs()
+    CAM_TOP = CAM_SIDE = CAM_WRIST = ((0.0, 0.0, 1.0), (0.0, 0.0, 0.0), 40.0)
+    PER_ENV_TOP = PER_ENV_SIDE = ((0.0, 0.0, 1.0), (0.0, 0.0, 0.0))
+    PIXELS_ALWAYS_PER_ENV = False
+
+    def _wrist_camera(self):
+        """-> (pos (B,3), lookat (B,3), up (B,3) or None, rotate_180) of the link-mounted wrist camera."""
+        raise NotImplementedError
+
+    def _pixels(self):
+        if self.PIXELS_ALWAYS_PER_ENV or self.camera_capture_mode == "per_env":
+            pos, look, up, rot = self._wrist_camera()
+            wrist = self.cam_wrist.render_cams(pos, look, up)
+            if rot:
+                wrist = torch.flip(wrist, dims=(1, 2))  # np.rot90(img, k=2)
+            return {"top": self.cam_top.render_envs(*self.PER_ENV_TOP), "side": self.cam_side.render_envs(*self.PER_ENV_SIDE),
+                    "wrist": wrist}
+        if self.camera_capture_mode == "global":
+            return {"top": self.cam_top.render_global(), "side": self.cam_side.render_global(), "wrist": self.cam_wrist.render_global()}
+        raise ValueError(f"Unknown camera_capture_mode: {self.camera_capture_mode}")
+
     def _pack_obs(self):
-        return {"agent_pos": self._agent, "environment_state": self._envst}
+        obs = {"agent_pos": self._agent, "environment_state": self._envst}
+        if self.enable_pixels:
+            if self.strip_environment_state:
+                del obs["environment_state"]
+            # dict of uint8 device tensors, (B,H,W,3) each (per_env) or (H,W,3) (global); the reference stacks host arrays
+            obs["pixels"] = self._pixels()
+        return obs
 
     @property
     def terminated_device(self) -> torch.Tensor:

@@ -110,6 +110,11 @@ class CameraView:
         return self._mir.render(self._spec(self._home[0] if pos is None else pos, self._home[1] if lookat is None else lookat),
                                 self._vis, mode=0, out=out)
 
+    def render_cams(self, pos, lookat, up=None) -> torch.Tensor:
+        """(B, H, W, 3) uint8 device tensor: env i seen from its OWN camera pos[i] -> lookat[i] (B,3 tensors in the env's
+        frame; the link-mounted wrist cameras)."""
+        return self._mir.render_cams(self._spec(self._home[0], self._home[1]), self._vis, pos, lookat, up)
+
     def render(self, rgb=True, depth=False, segmentation=False, normal=False):
         if depth or segmentation or normal:
             raise NotImplementedError("only the rgb output of cam.render() is on the reference's path (env.py:98)")

@@ -282,6 +282,13 @@ int mir_visual_sizeof(void);
 int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, int32_t mode, const float* env_offset,
                uint8_t* pixels, void* stream);
 
+/* Per-env images from PER-ENV cameras (the wrist cameras that follow a link:
+ * gym_genesis/tasks/franka/cube_stack_kitchen_batch.py:185-192, gym_genesis/tasks/so101/cube_stack_batch.py:199-213).
+ * cam gives res / fov / default up; cam_pos, cam_lookat (B,3) f32 device, in the env's own frame; cam_up (B,3) nullable.
+ * A view direction parallel to the up hint falls back to up = +y, then +x (also in mir_render). */
+int mir_render_cams(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, const float* cam_pos, const float* cam_lookat,
+                    const float* cam_up, uint8_t* pixels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

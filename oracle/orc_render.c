@@ -77,6 +77,11 @@ int orc_render_image(const MirSceneSpec* spec, const MirCameraSpec* cam, const M
   double f[3] = {cam->lookat[0] - cam->pos[0], cam->lookat[1] - cam->pos[1], cam->lookat[2] - cam->pos[2]}, r[3], u[3];
   norm3(f);
   cross3(f, cam->up, r);
+  if (dot3(r, r) < 1e-24) { /* view parallel to up: fall back to +y, then +x (include/mirigid.h, mir_render_cams) */
+    const double ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};
+    cross3(f, ey, r);
+    if (dot3(r, r) < 1e-24) cross3(f, ex, r);
+  }
   norm3(r);
   cross3(r, f, u);
   const double ty = tan(0.5 * cam->fov_deg * M_PI / 180.0), tx = ty * (double)W / (double)H;

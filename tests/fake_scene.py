@@ -85,5 +85,17 @@ class OracleScene:
         return torch.from_numpy(np.stack([orc.render_image(self.spec, cam, vis, xpos[e:e + 1], xquat[e:e + 1])
                                           for e in range(self.num_envs)]))
 
+    def render_cams(self, cam, vis, cam_pos, cam_lookat, cam_up=None, out=None):
+        from gym_genesis.backend.spec import make_camera
+
+        xpos, xquat = (t.numpy().astype(np.float64) for t in self.get_links())
+        P, L = self._np(cam_pos), self._np(cam_lookat)
+        U = None if cam_up is None else self._np(cam_up)
+        imgs = []
+        for e in range(self.num_envs):
+            c = make_camera(cam.width, cam.height, P[e], L[e], cam.fov_deg, up=tuple(cam.up) if U is None else U[e])
+            imgs.append(orc.render_image(self.spec, c, vis, xpos[e:e + 1], xquat[e:e + 1]))
+        return torch.from_numpy(np.stack(imgs))
+
     def close(self):
         pass

@@ -141,3 +141,30 @@ def test_so101_stack_home_pose_is_clear_of_the_slab():
     assert o.counts()[0] == 20  # only the cubes touch the slab
     agent, _, _, _ = o.get_obs()
     assert np.abs(agent[0] - home).max() < 5e-3 and math.isfinite(agent.sum())
+
+
+@pytest.mark.parametrize("robot,mode", [("franka", "per_env"), ("franka", "global"), ("so101", "global")])
+def test_stack_pixels_contract_on_the_test_double(monkeypatch, robot, mode):
+    """enable_pixels=True: obs["pixels"] is a dict of the three views (cube_stack_kitchen_batch.py:169-222,
+    so101/cube_stack_batch.py:181-224); wrist camera fixed at 640x480 (utils.py:331,688); SO-101 renders per env whatever
+    the capture mode."""
+    import fake_scene
+    from gym_genesis.env import GenesisEnv
+    from gym_genesis.tasks import stack_common
+    from gym_genesis.tasks import views
+
+    monkeypatch.setattr(stack_common, "MirScene", fake_scene.OracleScene)
+    B, H, W = 2, 12, 16
+    env = GenesisEnv(task="cube_stack", robot=robot, num_envs=B, enable_pixels=True, observation_height=H, observation_width=W,
+                     camera_capture_mode=mode)
+    task = env._env
+    task.cam_wrist.res = (32, 24)  # keep the float64 ray caster quick in the CPU tier (the product keeps 640x480)
+    obs, _ = env.reset(seed=1)
+    assert set(obs) == {"agent_pos", "pixels"} and set(obs["pixels"]) == {"top", "side", "wrist"}
+    per_env = mode == "per_env" or robot == "so101"
+    lead = (B,) if per_env else ()
+    assert tuple(obs["pixels"]["top"].shape) == lead + (H, W, 3) and tuple(obs["pixels"]["side"].shape) == lead + (H, W, 3)
+    assert tuple(obs["pixels"]["wrist"].shape) == lead + (24, 32, 3) and obs["pixels"]["wrist"].dtype == torch.uint8
+    assert env.get_cams() == (task.cam_top, task.cam_side, task.cam_wrist)
+    assert task.cam_top.fov == 40.0 and task.cam_wrist.fov == (90.0 if robot == "franka" else 70.0)
+    assert len(np.unique(obs["pixels"]["top"].numpy().reshape(-1, 3), axis=0)) >= 3  # slab, floor, cubes in the top view
