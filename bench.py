@@ -155,6 +155,32 @@ def stack_bench(dev, steps: int = 300):
                          "note": "1109 algorithmic B/env-step; one wave per env, 3 envs per CU: latency/occupancy-bound like the pick kernel"}}
 
 
+def ik_bench(dev, calls: int = 200):
+    """Secondary: the batched IK the reference's expert policies call once per env.step()
+    (examples/franka/pick_cube_state.py:46-51): hand pose targets above the cube, 4096 envs, seed = current state."""
+    from gym_genesis.env import GenesisEnv
+
+    B = ENVS_PER_GPU
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
+    obs, _ = env.reset(seed=0)
+    task = env._env
+    target = (obs["environment_state"][:, :3] + torch.tensor([0.0, 0.0, 0.25], device=dev)).contiguous()
+    quat = torch.tensor([0.0, 1.0, 0.0, 0.0], device=dev).repeat(B, 1)
+    hand = task.eef.idx
+    for _ in range(5):
+        q, err = task._mir.inverse_kinematics(hand, target, quat, return_error=True)
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(calls):
+        task._mir.inverse_kinematics(hand, target, quat)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us = ev0.elapsed_time(ev1) * 1e3 / calls
+    return {"workload": "robot.inverse_kinematics(hand, pos, quat) from the home pose, num_envs=4096, <= 32 damped-least-squares iterations",
+            "env_solves_per_s": B / (us * 1e-6), "us_per_call": us, "converged_frac": float(((err[:, 0] < 5e-4) & (err[:, 1] < 5e-3)).float().mean().item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,6 +355,7 @@ def main():
             out["pixels"] = pixels_bench(dev)
         if world == 1 and not args.no_stack:
             out["stack"] = stack_bench(dev)
+            out["ik"] = ik_bench(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -1,0 +1,249 @@
+// mir_ik.hip — batched damped-least-squares inverse kinematics.
+//
+// What it replaces: robot.inverse_kinematics(link, pos, quat, ...) of the reference's expert policies
+// (/root/reference/examples/franka/pick_cube_state.py:46-51, stack_cube_state.py:78-83), called once per env.step()
+// in those loops, i.e. on the callers' side of the hot path.  The algorithm is defined in include/mirigid.h.
+//
+// Mapping: like the pick kernel, 16 lanes per env (4 envs per wave64, one DPP row each); lane j owns element j of the
+// kinematic chain world -> link (<= 16 bodies): its local joint transform, its world pose (each lane composes its own
+// prefix of the chain: no depth-serial barriers), its Jacobian column.  J J^T + lambda^2 I (6 x 6, symmetric: 21 DPP row
+// reductions) ends up in every lane's registers and each lane solves it redundantly (Cholesky, fully unrolled), so the
+// update dq_j = J_j . y needs no further communication.  The chain description travels in the kernel arguments
+// (built on the host per call: the link is a run-time argument).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+
+#include "mir_model.h"
+#include "mir_scene.h"
+
+#define G 16
+#include "mir_dev.h"
+
+namespace {
+
+struct IkChain {
+  int n;                       // bodies on the chain (root first)
+  int jtype[G], qcol[G];       // joint type; column of the joint in the (B, n_arm) arrays, -1 for fixed links
+  float pos[G][3], quat[G][4], axis[G][3], lo[G], hi[G];
+  int limited[G];
+};
+
+struct IkArgs {
+  IkChain ch;
+  const float* target_pos;   // (B,3)
+  const float* target_quat;  // (B,4) or null
+  const float* init_qpos;    // (B,n_arm) or null
+  const float* scene_qpos;   // scene state row (B, qst) used when init_qpos is null
+  int qst, n_arm;
+  int arm_qadr[MIR_MAX_DOF]; // qpos address of scalar joint k in the scene row
+  float* qpos_out;           // (B,n_arm)
+  float* err_out;            // (B,2) or null
+  int B, max_iters, respect_limits;
+  float damping2, pos_tol, rot_tol, max_step;
+};
+
+struct IkLds {
+  float lpos[G][4], lquat[G][4];
+  float xpos[G][4], xquat[G][4];
+};
+
+__device__ __forceinline__ Q4 qconj(Q4 q) { return {q.w, -q.x, -q.y, -q.z}; }
+
+__global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
+  __shared__ __attribute__((aligned(16))) IkLds s_env[4];
+  const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4;
+  const int env_raw = blockIdx.x * 4 + grp;
+  const bool valid = env_raw < a.B;
+  const int env = valid ? env_raw : a.B - 1;
+  IkLds& S = s_env[grp];
+  const int n = a.ch.n;
+  const bool onchain = lane < n;
+  const int jt = onchain ? a.ch.jtype[lane] : MIR_JNT_FIXED, qc = onchain ? a.ch.qcol[lane] : -1;
+  const V3 bpos = ld3(a.ch.pos[lane]), baxis = ld3(a.ch.axis[lane]);
+  const Q4 bquat = ld4(a.ch.quat[lane]);
+  const bool moving = onchain && qc >= 0 && (jt == MIR_JNT_REVOLUTE || jt == MIR_JNT_PRISMATIC);
+  const float lo = a.ch.lo[lane], hi = a.ch.hi[lane];
+  const bool lim = moving && a.ch.limited[lane] && a.respect_limits;
+  // seed: every scalar joint (the result keeps the seed outside the chain)
+  for (int k = lane; k < a.n_arm; k += G) {
+    const float v = a.init_qpos ? a.init_qpos[(size_t)env * a.n_arm + k] : a.scene_qpos[(size_t)env * a.qst + a.arm_qadr[k]];
+    if (valid) a.qpos_out[(size_t)env * a.n_arm + k] = v;
+  }
+  float q = 0.0f;
+  if (moving) q = a.init_qpos ? a.init_qpos[(size_t)env * a.n_arm + qc] : a.scene_qpos[(size_t)env * a.qst + a.arm_qadr[qc]];
+  const V3 tp = ld3(a.target_pos + (size_t)env * 3);
+  const bool userot = a.target_quat != nullptr;
+  const Q4 tq = userot ? qnormalize(ld4(a.target_quat + (size_t)env * 4)) : Q4{1, 0, 0, 0};
+  bool done = false;
+  float epn = 0.0f, ern = 0.0f;
+  for (int it = 0; it <= a.max_iters; it++) {
+    // ---- local transform of my chain element, then my own prefix of the chain
+    if (onchain) {
+      Q4 ql = bquat;
+      V3 pl = bpos;
+      if (jt == MIR_JNT_REVOLUTE) {
+        float sn, cs;
+        sincosf(0.5f * q, &sn, &cs);
+        ql = qmul(bquat, Q4{cs, baxis.x * sn, baxis.y * sn, baxis.z * sn});
+      } else if (jt == MIR_JNT_PRISMATIC) {
+        pl = bpos + qrot(bquat, q * baxis);
+      }
+      st3v(S.lpos[lane], pl);
+      st4v(S.lquat[lane], ql);
+    }
+    WSYNC();
+    if (onchain) {
+      V3 P = ld3v(S.lpos[0]);
+      Q4 Qx = ld4v(S.lquat[0]);
+      for (int i = 1; i <= lane; i++) {
+        P = P + qrot(Qx, ld3v(S.lpos[i]));
+        Qx = qmul(Qx, ld4v(S.lquat[i]));
+      }
+      st3v(S.xpos[lane], P);
+      st4v(S.xquat[lane], Qx);
+    }
+    WSYNC();
+    // ---- task-space error (every lane, redundantly)
+    const V3 pe = ld3v(S.xpos[n - 1]);
+    const Q4 qe = ld4v(S.xquat[n - 1]);
+    const V3 ep = tp - pe;
+    V3 er = v3(0, 0, 0);
+    if (userot) {
+      Q4 d = qmul(tq, qconj(qe));  // rotation taking the current frame to the target, world axes
+      if (d.w < 0.0f) d = Q4{-d.w, -d.x, -d.y, -d.z};
+      const float sn = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+      const float ang = 2.0f * atan2f(sn, d.w);
+      const float k = sn > 1e-9f ? ang / sn : 2.0f;
+      er = v3(k * d.x, k * d.y, k * d.z);
+    }
+    epn = sqrtf(dot(ep, ep));
+    ern = sqrtf(dot(er, er));
+    if (!done && epn < a.pos_tol && ern < a.rot_tol) done = true;
+    if (it == a.max_iters) break;
+    if (!__any(!done)) break;
+    // ---- my Jacobian column (joint frame = my world pose)
+    V3 jv = v3(0, 0, 0), jw = v3(0, 0, 0);
+    if (moving) {
+      const V3 axw = qrot(ld4v(S.xquat[lane]), baxis);
+      if (jt == MIR_JNT_REVOLUTE) { jw = axw; jv = cross(axw, pe - ld3v(S.xpos[lane])); }
+      else jv = axw;
+    }
+    const float J[6] = {jv.x, jv.y, jv.z, userot ? jw.x : 0.0f, userot ? jw.y : 0.0f, userot ? jw.z : 0.0f};
+    // ---- A = J J^T + lambda^2 I in every lane
+    float A[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c <= r; c++) {
+        const float v = gsum(J[r] * J[c]) + (r == c ? a.damping2 : 0.0f);
+        A[r][c] = v;
+        A[c][r] = v;
+      }
+    // ---- y = A^-1 e (Cholesky, SPD by the damping)
+    const float e[6] = {ep.x, ep.y, ep.z, er.x, er.y, er.z};
+    float L[6][6], y[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c <= r; c++) {
+        float sacc = A[r][c];
+#pragma unroll
+        for (int k = 0; k < c; k++) sacc -= L[r][k] * L[c][k];
+        L[r][c] = r == c ? sqrtf(fmaxf(sacc, 1e-30f)) : sacc / L[c][c];
+      }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      float sacc = e[r];
+#pragma unroll
+      for (int k = 0; k < r; k++) sacc -= L[r][k] * y[k];
+      y[r] = sacc / L[r][r];
+    }
+#pragma unroll
+    for (int r = 5; r >= 0; r--) {
+      float sacc = y[r];
+#pragma unroll
+      for (int k = r + 1; k < 6; k++) sacc -= L[k][r] * y[k];
+      y[r] = sacc / L[r][r];
+    }
+    float dq = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 6; r++) dq += J[r] * y[r];
+    const float big = gmaxf(fabsf(dq));
+    const float sc = big > a.max_step ? a.max_step / big : 1.0f;
+    if (moving && !done) {
+      q += sc * dq;
+      if (lim) q = fminf(fmaxf(q, lo), hi);
+    }
+    WSYNC();
+  }
+  if (valid && moving) a.qpos_out[(size_t)env * a.n_arm + qc] = q;
+  if (valid && a.err_out && lane == 0) {
+    a.err_out[(size_t)env * 2] = epn;
+    a.err_out[(size_t)env * 2 + 1] = ern;
+  }
+}
+
+}  // namespace
+
+extern "C" int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_pos, const float* target_quat, const float* init_qpos,
+                                      const MirIkOptions* opt, float* qpos_out, float* err_out, void* stream) {
+  if (!h || !target_pos || !qpos_out) return mir_set_error(MIR_E_INVALID, "mir_inverse_kinematics: null argument");
+  if (link_body <= 0 || link_body >= h->nbody) return mir_set_error(MIR_E_INVALID, "mir_inverse_kinematics: link out of range");
+  IkArgs a;
+  memset(&a, 0, sizeof a);
+  // chain world -> link from whichever model serves the scene
+  int chain[MIR_MAX_BODY], n = 0;
+  auto parent = [&](int b) { return h->kernel == 16 ? h->hm.b_parent[b] : h->hm64.b_parent[b]; };
+  for (int b = link_body; b > 0; b = parent(b)) {
+    if (n >= G) return mir_set_error(MIR_E_CAPACITY, "mir_inverse_kinematics: chain longer than 16 bodies");
+    chain[n++] = b;
+  }
+  a.ch.n = n;
+  // column of each scalar joint in the (B, n_arm) arrays = its rank among the scalar joints in body order
+  int col_of_body[MIR_MAX_BODY];
+  int narm = 0;
+  for (int b = 1; b < h->nbody; b++) {
+    const int jt = h->kernel == 16 ? h->hm.b_jtype[b] : h->hm64.b_jtype[b];
+    col_of_body[b] = (jt == MIR_JNT_REVOLUTE || jt == MIR_JNT_PRISMATIC) ? narm++ : -1;
+    if (col_of_body[b] >= 0) a.arm_qadr[col_of_body[b]] = h->kernel == 16 ? h->hm.b_qadr[b] : h->hm64.b_qadr[b];
+  }
+  for (int i = 0; i < n; i++) {
+    const int b = chain[n - 1 - i];
+    int jt;
+    if (h->kernel == 16) {
+      const DevModel& m = h->hm;
+      jt = m.b_jtype[b];
+      for (int k = 0; k < 3; k++) { a.ch.pos[i][k] = m.b_pos[b][k]; a.ch.axis[i][k] = m.b_axis[b][k]; }
+      for (int k = 0; k < 4; k++) a.ch.quat[i][k] = m.b_quat[b][k];
+      if (col_of_body[b] >= 0) { const int d = m.b_dofadr[b]; a.ch.lo[i] = m.d_lo[d]; a.ch.hi[i] = m.d_hi[d]; a.ch.limited[i] = m.d_limited[d]; }
+    } else {
+      const DevModel64& m = h->hm64;
+      jt = m.b_jtype[b];
+      for (int k = 0; k < 3; k++) { a.ch.pos[i][k] = m.b_pos[b][k]; a.ch.axis[i][k] = m.b_axis[b][k]; }
+      for (int k = 0; k < 4; k++) a.ch.quat[i][k] = m.b_quat[b][k];
+      if (col_of_body[b] >= 0) { const int d = m.b_dofadr[b]; a.ch.lo[i] = m.d_lo[d]; a.ch.hi[i] = m.d_hi[d]; a.ch.limited[i] = m.d_limited[d]; }
+    }
+    if (jt == MIR_JNT_FREE) return mir_set_error(MIR_E_INVALID, "mir_inverse_kinematics: the link hangs off a free body");
+    a.ch.jtype[i] = jt;
+    a.ch.qcol[i] = col_of_body[b];
+  }
+  MirIkOptions o = {32, 1, 0.05, 5e-4, 5e-3, 0.5};
+  if (opt) {
+    o = *opt;
+    if (o.max_iters <= 0 || !(o.damping > 0.0) || !(o.max_step > 0.0)) return mir_set_error(MIR_E_INVALID, "mir_inverse_kinematics: bad options");
+  }
+  a.target_pos = target_pos; a.target_quat = target_quat; a.init_qpos = init_qpos; a.scene_qpos = h->qpos;
+  a.qst = h->pt.qst; a.n_arm = narm; a.qpos_out = qpos_out; a.err_out = err_out; a.B = h->B;
+  a.max_iters = o.max_iters; a.respect_limits = o.respect_joint_limit;
+  a.damping2 = (float)(o.damping * o.damping); a.pos_tol = (float)o.pos_tol; a.rot_tol = (float)o.rot_tol; a.max_step = (float)o.max_step;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != h->device) (void)hipSetDevice(h->device);
+  hipLaunchKernelGGL(mir_ik_kernel, dim3((h->B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  if (prev != h->device && prev >= 0) (void)hipSetDevice(prev);
+  if (e != hipSuccess) return mir_set_error(MIR_E_HIP, hipGetErrorString(e));
+  return MIR_OK;
+}

@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .spec import MirCameraSpec, MirDims, MirSceneSpec, MirVisualSpec
+from .spec import IK_DEFAULTS, MirCameraSpec, MirDims, MirIkOptions, MirSceneSpec, MirVisualSpec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libmirigid.so"))
@@ -60,6 +60,8 @@ def load_library() -> C.CDLL:
     lib.mir_visual_sizeof.restype = C.c_int
     lib.mir_render_cams.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), vp, vp, vp, vp, vp]
     lib.mir_render_cams.restype = C.c_int
+    lib.mir_inverse_kinematics.argtypes = [vp, i32, vp, vp, vp, C.POINTER(MirIkOptions), vp, vp, vp]
+    lib.mir_inverse_kinematics.restype = C.c_int
     for name in ("mir_create", "mir_destroy", "mir_get_dims", "mir_get_model_consts", "mir_reset", "mir_autoreset", "mir_set_pd_targets",
                  "mir_step", "mir_step_fused", "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links",
                  "mir_get_diag", "mir_forward"):
@@ -235,3 +237,15 @@ class MirScene:
         u = None if cam_up is None else self._f32(cam_up, 3)
         self._check(self.lib.mir_render_cams(self.h, C.byref(cam), C.byref(vis), _ptr(p), _ptr(l), _ptr(u), _ptr(out), self._stream()))
         return out
+
+    def inverse_kinematics(self, link_body: int, pos, quat=None, init_qpos=None, return_error: bool = False, **opts):
+        """Batched damped-least-squares IK (mir_inverse_kinematics): (B, n_arm) joint positions that bring body
+        `link_body` to pos (B,3) / quat (B,4 wxyz, optional).  Seed = init_qpos or the scene's current joint positions."""
+        p = self._f32(pos, 3)
+        q = None if quat is None else self._f32(quat, 4)
+        init = None if init_qpos is None else self._f32(init_qpos, self.n_arm)
+        o = MirIkOptions(**{**IK_DEFAULTS, **opts})
+        out, err = self.empty(self.n_arm), self.empty(2)
+        self._check(self.lib.mir_inverse_kinematics(self.h, int(link_body), _ptr(p), _ptr(q), _ptr(init), C.byref(o), _ptr(out), _ptr(err),
+                                                    self._stream()))
+        return (out, err) if return_error else out

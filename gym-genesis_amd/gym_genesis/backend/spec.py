@@ -165,6 +165,19 @@ class MirVisualSpec(C.Structure):
     ]
 
 
+class MirIkOptions(C.Structure):
+    _fields_ = [
+        ("max_iters", C.c_int32),
+        ("respect_joint_limit", C.c_int32),
+        ("damping", C.c_double),
+        ("pos_tol", C.c_double),
+        ("rot_tol", C.c_double),
+        ("max_step", C.c_double),
+    ]
+
+
+IK_DEFAULTS = dict(max_iters=32, respect_joint_limit=1, damping=0.05, pos_tol=5e-4, rot_tol=5e-3, max_step=0.5)
+
 RENDER_PER_ENV, RENDER_GLOBAL = 0, 1
 
 

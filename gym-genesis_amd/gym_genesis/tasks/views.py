@@ -60,6 +60,47 @@ class EntityView:
     def get_qpos(self) -> torch.Tensor:
         return self.get_dofs_position()
 
+    def inverse_kinematics(self, link, pos=None, quat=None, init_qpos=None, envs_idx=None, return_error=False, **opts):
+        """``robot.inverse_kinematics(link=eef, pos=(B,3), quat=(B,4), init_qpos=..., envs_idx=...)`` -> (B, n_dofs)
+        (/root/reference/examples/franka/pick_cube_state.py:46-51).  One batched launch for all envs; `envs_idx` selects
+        the rows returned (and addressed by pos / quat / init_qpos) as in Genesis.  `pos` is required (a quat-only target
+        is not on the reference's path)."""
+        if pos is None:
+            raise ValueError("inverse_kinematics needs a target position")
+        mir = self._mir
+        B = mir.num_envs
+        idx = None if envs_idx is None else torch.as_tensor(envs_idx, device=mir.device).long().reshape(-1)
+
+        def full(t, k):
+            if t is None:
+                return None
+            t = torch.as_tensor(t, dtype=torch.float32, device=mir.device).reshape(-1, k)
+            if idx is None or t.shape[0] == B:
+                return t
+            out = torch.zeros((B, k), dtype=torch.float32, device=mir.device)
+            out[idx] = t
+            return out
+
+        p, q = full(pos, 3), full(quat, 4)
+        if q is not None and idx is not None and q.shape[0] == B:
+            q = q.clone()
+            q[:, 0] += (q.abs().sum(1) == 0).float()  # unaddressed rows: identity, so normalisation stays finite
+        init = None
+        if init_qpos is not None:
+            cur = mir.get_state()[0][:, :mir.n_arm].clone()
+            cur[:, self._qcols] = full(init_qpos, len(self._qcols)) if (idx is None or torch.as_tensor(init_qpos).shape[0] == B) else cur[:, self._qcols]
+            if idx is not None and torch.as_tensor(init_qpos).reshape(-1, len(self._qcols)).shape[0] != B:
+                cur[idx[:, None], torch.as_tensor(self._qcols, device=mir.device)[None, :]] = torch.as_tensor(
+                    init_qpos, dtype=torch.float32, device=mir.device).reshape(-1, len(self._qcols))
+            init = cur
+        res = mir.inverse_kinematics(link.idx, p, q, init, return_error=return_error, **opts)
+        qout, err = (res if return_error else (res, None))
+        qout = qout[:, self._qcols]
+        if idx is not None:
+            qout = qout[idx]
+            err = None if err is None else err[idx]
+        return (qout, err) if return_error else qout
+
     def control_dofs_position(self, position, dofs_idx_local=None) -> None:
         """PD targets for a subset of this entity's dofs (others keep their current target)."""
         tgt = self._mir.get_state()[2]

@@ -289,6 +289,30 @@ int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, 
 int mir_render_cams(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, const float* cam_pos, const float* cam_lookat,
                     const float* cam_up, uint8_t* pixels, void* stream);
 
+/* ---- batched inverse kinematics ---------------------------------------------------
+ * robot.inverse_kinematics(link=eef, pos=(B,3), quat=(B,4), init_qpos=..., envs_idx=...) -> (B, n_dofs)
+ *      examples/franka/pick_cube_state.py:46-51, examples/franka/stack_cube_state.py:78-83
+ * Genesis's IK lives in the external package; this is a damped-least-squares solver on the scene's own kinematics,
+ * defined here and restated independently by the oracle (oracle/orc_rigid.c: orc_ik):
+ *   repeat up to max_iters:  e = [p* - p ; rotvec(q* q^-1)]   (rotation part dropped when target_quat == NULL);
+ *     stop the env when |e_pos| < pos_tol and |e_rot| < rot_tol;  J = 6 x n geometric Jacobian of the link's chain;
+ *     dq = J^T (J J^T + damping^2 I)^-1 e, scaled down so that max |dq_i| <= max_step;  q += dq;
+ *     q clamped to the joint ranges (respect_joint_limit).
+ * Only the scalar joints on the chain world -> link move; every other entry of the result is the seed. */
+typedef struct MirIkOptions {
+  int32_t max_iters;           /* default 32 */
+  int32_t respect_joint_limit; /* default 1 */
+  double damping;              /* default 0.05 */
+  double pos_tol, rot_tol;     /* defaults 5e-4 m, 5e-3 rad */
+  double max_step;             /* default 0.5 rad (or m) per iteration */
+} MirIkOptions;
+
+/* target_pos (B,3), target_quat (B,4 wxyz) nullable, init_qpos (B,n_arm) nullable (NULL = the scene's current joint
+ * positions), opt nullable (defaults); qpos_out (B,n_arm) = every scalar joint in body order; err_out (B,2) nullable =
+ * final |e_pos|, |e_rot|.  The scene state is not modified. */
+int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_pos, const float* target_quat, const float* init_qpos,
+                           const MirIkOptions* opt, float* qpos_out, float* err_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

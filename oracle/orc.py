@@ -138,6 +138,21 @@ class Oracle:
                                  term[e:e + 1].ctypes.data_as(C.c_void_p))
         return agent, env, rew, term
 
+    def ik(self, link: int, target_pos, target_quat=None, init_q=None, max_iters=32, damping=0.05, pos_tol=5e-4, rot_tol=5e-3,
+           max_step=0.5, respect_limits=True):
+        """Damped-least-squares IK of include/mirigid.h on the oracle's own kinematics, one env at a time.
+        target_pos (B,3), target_quat (B,4) or None, init_q (B,n_arm).  Returns (q (B,n_arm), err (B,2))."""
+        tp = np.ascontiguousarray(target_pos, dtype=np.float64).reshape(self.B, 3)
+        tq = None if target_quat is None else np.ascontiguousarray(target_quat, dtype=np.float64).reshape(self.B, 4)
+        q = np.ascontiguousarray(init_q, dtype=np.float64).reshape(self.B, -1).copy()
+        err = np.zeros((self.B, 2))
+        self.lib.orc_ik.restype = C.c_int
+        for e in range(self.B):
+            self.lib.orc_ik(self.model, C.c_int(link), tp[e].ctypes.data_as(C.c_void_p), tq[e].ctypes.data_as(C.c_void_p) if tq is not None else None,
+                            q[e].ctypes.data_as(C.c_void_p), C.c_int(max_iters), C.c_double(damping), C.c_double(pos_tol), C.c_double(rot_tol),
+                            C.c_double(max_step), C.c_int(1 if respect_limits else 0), err[e].ctypes.data_as(C.c_void_p))
+        return q, err
+
     def state(self):
         q = np.stack([self.read(F_QPOS, e) for e in range(self.B)])
         v = np.stack([self.read(F_QVEL, e) for e in range(self.B)])

@@ -22,6 +22,7 @@
 #include "orc_rigid.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -982,6 +983,106 @@ void orc_get_obs(const OrcModel* m, const OrcData* d, double* agent_pos, double*
     *reward = z > (float)m->task.reward_z ? 1.0 : 0.0;
   }
   *terminated = *reward == 1.0;
+}
+
+/* ------------------------------------------------------------------ inverse kinematics (checker of mir_inverse_kinematics)
+ * Restates the algorithm DEFINED in include/mirigid.h (the reference's IK is inside the external Genesis package:
+ * examples/franka/pick_cube_state.py:46-51): damped least squares on the geometric Jacobian of the chain world -> link,
+ * step clamp, joint-range clamp.  Written against the oracle's own dense kinematics (orc_fk on a scratch copy), no
+ * chain compaction, Gaussian elimination with partial pivoting for the 6x6 system.
+ * q_io (n_arm): scalar joints in body order, seed in / solution out.  err2: |e_pos|, |e_rot| at exit. */
+int orc_ik(const OrcModel* m, int link, const double* target_pos, const double* target_quat /* nullable */, double* q_io,
+           int max_iters, double damping, double pos_tol, double rot_tol, double max_step, int respect_limits, double* err2) {
+  OrcData* d = (OrcData*)malloc(sizeof(OrcData));
+  if (!d) return -1;
+  orc_init_data(m, d);
+  /* scalar joints in body order <-> bodies */
+  int jb[ORC_NB], nj = 0;
+  for (int b = 1; b < m->nbody; b++)
+    if (m->jtype[b] != MIR_JNT_FREE && m->ndof[b] == 1) jb[nj++] = b;
+  int onchain[ORC_NB] = {0};
+  for (int b = link; b > 0; b = m->parent[b]) onchain[b] = 1;
+  double tq[4] = {1, 0, 0, 0};
+  if (target_quat) {
+    double nn = sqrt(target_quat[0] * target_quat[0] + target_quat[1] * target_quat[1] + target_quat[2] * target_quat[2] + target_quat[3] * target_quat[3]);
+    for (int k = 0; k < 4; k++) tq[k] = target_quat[k] / nn;
+  }
+  double epn = 0, ern = 0;
+  for (int it = 0; it <= max_iters; it++) {
+    for (int j = 0; j < nj; j++) d->qpos[m->qadr[jb[j]]] = (real)q_io[j];
+    orc_fk(m, d);
+    double ep[3], er[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++) ep[k] = target_pos[k] - (double)d->xpos[link][k];
+    if (target_quat) {
+      /* dq = tq * conj(q_link) */
+      double qc[4] = {(double)d->xquat[link][0], -(double)d->xquat[link][1], -(double)d->xquat[link][2], -(double)d->xquat[link][3]};
+      double dq[4] = {tq[0] * qc[0] - tq[1] * qc[1] - tq[2] * qc[2] - tq[3] * qc[3], tq[0] * qc[1] + tq[1] * qc[0] + tq[2] * qc[3] - tq[3] * qc[2],
+                      tq[0] * qc[2] - tq[1] * qc[3] + tq[2] * qc[0] + tq[3] * qc[1], tq[0] * qc[3] + tq[1] * qc[2] - tq[2] * qc[1] + tq[3] * qc[0]};
+      if (dq[0] < 0) for (int k = 0; k < 4; k++) dq[k] = -dq[k];
+      double sn = sqrt(dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+      double kk = sn > 1e-9 ? 2.0 * atan2(sn, dq[0]) / sn : 2.0;
+      for (int k = 0; k < 3; k++) er[k] = kk * dq[1 + k];
+    }
+    epn = sqrt(ep[0] * ep[0] + ep[1] * ep[1] + ep[2] * ep[2]);
+    ern = sqrt(er[0] * er[0] + er[1] * er[1] + er[2] * er[2]);
+    if ((epn < pos_tol && ern < rot_tol) || it == max_iters) break;
+    /* Jacobian columns of the chain joints */
+    double J[6][ORC_NB];
+    for (int j = 0; j < nj; j++) {
+      int b = jb[j];
+      for (int r = 0; r < 6; r++) J[r][j] = 0;
+      if (!onchain[b]) continue;
+      double ax[3];
+      for (int r = 0; r < 3; r++) ax[r] = (double)d->xmat[b][3 * r] * (double)m->axis[b][0] + (double)d->xmat[b][3 * r + 1] * (double)m->axis[b][1] + (double)d->xmat[b][3 * r + 2] * (double)m->axis[b][2];
+      if (m->jtype[b] == MIR_JNT_REVOLUTE) {
+        double rr[3] = {(double)d->xpos[link][0] - (double)d->xpos[b][0], (double)d->xpos[link][1] - (double)d->xpos[b][1], (double)d->xpos[link][2] - (double)d->xpos[b][2]};
+        J[0][j] = ax[1] * rr[2] - ax[2] * rr[1]; J[1][j] = ax[2] * rr[0] - ax[0] * rr[2]; J[2][j] = ax[0] * rr[1] - ax[1] * rr[0];
+        if (target_quat) { J[3][j] = ax[0]; J[4][j] = ax[1]; J[5][j] = ax[2]; }
+      } else {
+        J[0][j] = ax[0]; J[1][j] = ax[1]; J[2][j] = ax[2];
+      }
+    }
+    double A[6][7];
+    for (int r = 0; r < 6; r++) {
+      for (int c = 0; c < 6; c++) {
+        double s = r == c ? damping * damping : 0.0;
+        for (int j = 0; j < nj; j++) s += J[r][j] * J[c][j];
+        A[r][c] = s;
+      }
+      A[r][6] = r < 3 ? ep[r] : er[r - 3];
+    }
+    for (int c = 0; c < 6; c++) { /* Gaussian elimination, partial pivoting */
+      int p = c;
+      for (int r = c + 1; r < 6; r++) if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+      if (p != c) for (int k = 0; k < 7; k++) { double t = A[c][k]; A[c][k] = A[p][k]; A[p][k] = t; }
+      for (int r = 0; r < 6; r++) {
+        if (r == c) continue;
+        double f = A[r][c] / A[c][c];
+        for (int k = c; k < 7; k++) A[r][k] -= f * A[c][k];
+      }
+    }
+    double y[6], dqv[ORC_NB], big = 0;
+    for (int r = 0; r < 6; r++) y[r] = A[r][6] / A[r][r];
+    for (int j = 0; j < nj; j++) {
+      dqv[j] = 0;
+      for (int r = 0; r < 6; r++) dqv[j] += J[r][j] * y[r];
+      if (fabs(dqv[j]) > big) big = fabs(dqv[j]);
+    }
+    double sc = big > max_step ? max_step / big : 1.0;
+    for (int j = 0; j < nj; j++) {
+      int b = jb[j];
+      if (!onchain[b]) continue;
+      q_io[j] += sc * dqv[j];
+      int dofi = m->dofadr[b];
+      if (respect_limits && m->dof_limited[dofi]) {
+        if (q_io[j] < (double)m->range[dofi][0]) q_io[j] = (double)m->range[dofi][0];
+        if (q_io[j] > (double)m->range[dofi][1]) q_io[j] = (double)m->range[dofi][1];
+      }
+    }
+  }
+  if (err2) { err2[0] = epn; err2[1] = ern; }
+  free(d);
+  return 0;
 }
 
 /* ------------------------------------------------------------------ accessors */
