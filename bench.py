@@ -319,6 +319,20 @@ def main():
     torch.cuda.synchronize(dev)
     loop_rate = api_steps * B * world / (time.perf_counter() - t2)
 
+    # K-step rollout launches (mir_rollout): the same fresh-action workload with the state kept on chip between steps
+    RK = 16
+    rows_ro = torch.zeros((RK, B, ROW_STRIDE), dtype=torch.float32, device=dev)
+    nro = max(1, min(200, n_act) // RK)
+    task.reset()
+    for i in range(2):
+        task._mir.rollout(actions[i * RK:(i + 1) * RK], rows_ro)
+    torch.cuda.synchronize(dev)
+    t3 = time.perf_counter()
+    for i in range(nro):
+        task._mir.rollout(actions[i * RK:(i + 1) * RK], rows_ro)
+    torch.cuda.synchronize(dev)
+    rollout_rate = nro * RK * B * world / (time.perf_counter() - t3)
+
     if rank == 0:
         value = K * B * world / wall_max
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/, measured offline on this kernel)
@@ -350,6 +364,7 @@ def main():
                          "note": "489 algorithmic B/env-step x 4096 envs per launch; the path is latency/occupancy-bound, not HBM-bound (SURVEY.md 8d)"},
             "env_step_api_rate": api_rate,
             "device_autoreset_loop_rate": loop_rate,
+            "device_rollout16_rate": rollout_rate,
         }
         if world == 1 and not args.no_pixels:
             out["pixels"] = pixels_bench(dev)

@@ -29,6 +29,8 @@ struct StepArgs {
   unsigned long long* prof; // debug: 16 phase timestamps (shader clock) from block 0, or null
   float* rows;          // (B, row_stride) packed [agent | env_state | reward | terminated] or null
   int row_stride;
+  long act_step;   // floats between the action blocks of consecutive steps (rollout mode), 0 = one action for all steps
+  long rows_step;  // floats between the row blocks of consecutive steps (rollout mode), 0 = only the final row
   int B;
   int mode;     // 0: full steps; 1: forward dynamics only (mir_forward); 2: kinematics + outputs only
   int n_steps;  // mode 0 only

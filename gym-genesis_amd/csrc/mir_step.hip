@@ -189,7 +189,6 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     float tg = a.target[(size_t)env * G + lane];
     if (a.action && isdof && d_uadr >= 0) tg = a.action[(size_t)env * m->nu + d_uadr];
     S.target[lane] = tg;
-    if (a.action && valid) a.target[(size_t)env * G + lane] = tg;
   }
   if (lane == 0) { S.ncon = 0; S.ncand = 0; }
   WSYNC();
@@ -210,7 +209,27 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   }
   STAMP(1);
   const int nsteps = a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0);
+  // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
+  const int eb = m->eef_body, ob = m->obj_body;
+  const int ad = 7 + m->n_grip;
+  auto column = [&](int c) -> float {
+    const V3 pe = ld3v(S.xpos[eb]), po = ld3v(S.xpos[ob]);
+    const V3 df = pe - po;
+    if (c < 3) return S.xpos[eb][c];
+    if (c < 7) return S.xquat[eb][c - 3];
+    if (c < ad) return S.qpos[m->grip_qadr[c - 7]];
+    const int k = c - ad;
+    if (k < 3) return S.xpos[ob][k];
+    if (k < 7) return S.xquat[ob][k - 3];
+    if (k < 10) return k == 7 ? df.x : (k == 8 ? df.y : df.z);
+    if (k == 10) return sqrtf(dot(df, df));
+    return po.z > m->reward_z ? 1.0f : 0.0f;  // k == 11 reward, k == 12 terminated
+  };
   for (int step = 0; step < nsteps; step++) {
+    // rollout mode (mir_rollout): a fresh action block per step
+    if (step > 0 && a.action && a.act_step) {
+      if (isdof && d_uadr >= 0) S.target[lane] = a.action[(size_t)step * a.act_step + (size_t)env * m->nu + d_uadr];
+    }
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
     if (isdof) {
       V3 ang = v3(0, 0, 0), lin = v3(0, 0, 0);
@@ -853,6 +872,10 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     STAMP(9);
     // kinematics of the new state: observations of this step, and the next step's starting poses
     group_fk(S, lane, nb, parents, bk);
+    if (a.rows && a.rows_step && step + 1 < nsteps && valid) {  // rollout mode: one packed row per env per step
+      float* row = a.rows + (size_t)step * a.rows_step + (size_t)env * a.row_stride;
+      for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
+    }
   }  // steps
   STAMP(10);
   if (!valid) return;
@@ -868,32 +891,17 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     a.qvel[(size_t)env * G + lane] = S.qvel[lane];
     a.qacc_ws[(size_t)env * G + lane] = S.qacc_ws[lane];
   }
+  if (a.action) a.target[(size_t)env * G + lane] = S.target[lane];
   // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
-  const int eb = m->eef_body, ob = m->obj_body;
-  const int ad = 7 + m->n_grip;
-  const V3 pe = ld3v(S.xpos[eb]), po = ld3v(S.xpos[ob]);
-  const V3 df = pe - po;
-  const float rew = po.z > m->reward_z ? 1.0f : 0.0f;
-  // column c of the packed row [agent_pos | env_state | reward | terminated]
-  auto column = [&](int c) -> float {
-    if (c < 3) return S.xpos[eb][c];
-    if (c < 7) return S.xquat[eb][c - 3];
-    if (c < ad) return S.qpos[m->grip_qadr[c - 7]];
-    const int k = c - ad;
-    if (k < 3) return S.xpos[ob][k];
-    if (k < 7) return S.xquat[ob][k - 3];
-    if (k < 10) return k == 7 ? df.x : (k == 8 ? df.y : df.z);
-    if (k == 10) return sqrtf(dot(df, df));
-    return rew;  // k == 11 reward, k == 12 terminated
-  };
+  const float rew = S.xpos[ob][2] > m->reward_z ? 1.0f : 0.0f;
   if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
   if (a.env_state && lane < 11) a.env_state[(size_t)env * 11 + lane] = column(ad + lane);
   if (lane == 0) {
     if (a.reward) a.reward[env] = rew;
     if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
   }
-  if (a.rows) {
-    float* row = a.rows + (size_t)env * a.row_stride;
+  if (a.rows) {  // (in rollout mode: the last step's row)
+    float* row = a.rows + (size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride;
     for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
   }
   if (a.out_xpos && lane < nb) {

@@ -271,7 +271,6 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     float tg = a.target[(size_t)env * NL + lane];
     if (a.action && isdof && d_uadr >= 0) tg = a.action[(size_t)env * m->nu + d_uadr];
     S.target[lane] = tg;
-    if (a.action) a.target[(size_t)env * NL + lane] = tg;
   }
   if (lane < NB) S.parent[lane] = lane < nb ? m->b_parent[lane] : 0;
   if (lane == 0) { S.ncon = 0; S.ncand = 0; }
@@ -293,7 +292,39 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   }
   STAMP(1);
   const int nsteps = a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0);
+  // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
+  const int eb = m->eef_body, ob = m->obj_body, ob2 = m->obj2_body;
+  const int ad = m->agent_dim, ed = m->env_dim;
+  auto reward_now = [&]() -> float {
+    const V3 po = ld3v(S.xpos[ob]);
+    if (m->reward_mode == MIR_REWARD_STACK) {
+      const V3 p2 = ld3v(S.xpos[ob2]);
+      const float dx = po.x - p2.x, dy = po.y - p2.y;
+      return (sqrtf(dx * dx + dy * dy) < m->reward_xy && po.z - p2.z > m->reward_dz) ? 1.0f : 0.0f;
+    }
+    return po.z > m->reward_z ? 1.0f : 0.0f;
+  };
+  auto column = [&](int c) -> float {
+    if (c < ad) {
+      if (m->agent_mode == MIR_AGENT_QPOS) return S.qpos[m->arm_qadr[c]];
+      if (c < 3) return S.xpos[eb][c];
+      if (c < 7) return S.xquat[eb][c - 3];
+      return S.qpos[m->grip_qadr[c - 7]];
+    }
+    const int k = c - ad;
+    if (k < 3) return S.xpos[ob][k];
+    if (k < 7) return S.xquat[ob][k - 3];
+    const V3 df = ld3v(S.xpos[eb]) - ld3v(S.xpos[ob]);
+    if (k < 10) return k == 7 ? df.x : (k == 8 ? df.y : df.z);
+    if (k == 10) return sqrtf(dot(df, df));
+    if (k < ed) return S.xpos[ob2][k - 11];
+    return reward_now();  // k == ed reward, k == ed + 1 terminated
+  };
   for (int step = 0; step < nsteps; step++) {
+    // rollout mode (mir_rollout): a fresh action block per step
+    if (step > 0 && a.action && a.act_step) {
+      if (isdof && d_uadr >= 0) S.target[lane] = a.action[(size_t)step * a.act_step + (size_t)env * m->nu + d_uadr];
+    }
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
     if (isdof) {
       V3 ang = v3(0, 0, 0), lin = v3(0, 0, 0);
@@ -1008,6 +1039,8 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     STAMP(17);
     // kinematics of the new state: observations of this step, and the next step's starting poses
     wave_fk(S, lane, nb, bk);
+    if (a.rows && a.rows_step && step + 1 < nsteps && lane < ad + ed + 2)  // rollout mode: one packed row per env per step
+      a.rows[(size_t)step * a.rows_step + (size_t)env * a.row_stride + lane] = column(lane);
   }  // steps
   STAMP(18);
   if (lane < nb) {
@@ -1022,43 +1055,18 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     a.qvel[(size_t)env * NL + lane] = S.qvel[lane];
     a.qacc_ws[(size_t)env * NL + lane] = S.qacc_ws[lane];
   }
+  if (a.action) a.target[(size_t)env * NL + lane] = S.target[lane];
   (void)nq;
   // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
-  const int eb = m->eef_body, ob = m->obj_body, ob2 = m->obj2_body;
-  const int ad = m->agent_dim, ed = m->env_dim;
-  const V3 pe = ld3v(S.xpos[eb]), po = ld3v(S.xpos[ob]);
-  const V3 df = pe - po;
-  float rew;
-  if (m->reward_mode == MIR_REWARD_STACK) {
-    const V3 p2 = ld3v(S.xpos[ob2]);
-    const float dx = po.x - p2.x, dy = po.y - p2.y;
-    rew = (sqrtf(dx * dx + dy * dy) < m->reward_xy && po.z - p2.z > m->reward_dz) ? 1.0f : 0.0f;
-  } else {
-    rew = po.z > m->reward_z ? 1.0f : 0.0f;
-  }
-  // column c of the packed row [agent_pos | env_state | reward | terminated]
-  auto column = [&](int c) -> float {
-    if (c < ad) {
-      if (m->agent_mode == MIR_AGENT_QPOS) return S.qpos[m->arm_qadr[c]];
-      if (c < 3) return S.xpos[eb][c];
-      if (c < 7) return S.xquat[eb][c - 3];
-      return S.qpos[m->grip_qadr[c - 7]];
-    }
-    const int k = c - ad;
-    if (k < 3) return S.xpos[ob][k];
-    if (k < 7) return S.xquat[ob][k - 3];
-    if (k < 10) return k == 7 ? df.x : (k == 8 ? df.y : df.z);
-    if (k == 10) return sqrtf(dot(df, df));
-    if (k < ed) return S.xpos[ob2][k - 11];
-    return rew;  // k == ed reward, k == ed + 1 terminated
-  };
+  const float rew = reward_now();
   if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
   if (a.env_state && lane < ed) a.env_state[(size_t)env * ed + lane] = column(ad + lane);
   if (lane == 0) {
     if (a.reward) a.reward[env] = rew;
     if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
   }
-  if (a.rows && lane < ad + ed + 2) a.rows[(size_t)env * a.row_stride + lane] = column(lane);
+  if (a.rows && lane < ad + ed + 2)  // (in rollout mode: the last step's row)
+    a.rows[(size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride + lane] = column(lane);
   if (a.out_xpos && lane < nb) {
     st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3v(S.xpos[lane]));
     st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));

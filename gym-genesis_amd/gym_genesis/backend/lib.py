@@ -49,6 +49,8 @@ def load_library() -> C.CDLL:
     lib.mir_step_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.mir_step_packed.argtypes = [vp, vp, vp, i32, vp]
     lib.mir_step_packed.restype = C.c_int
+    lib.mir_rollout.argtypes = [vp, vp, i32, vp, i32, vp]
+    lib.mir_rollout.restype = C.c_int
     lib.mir_get_obs.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.mir_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.mir_set_state.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -177,6 +179,14 @@ class MirScene:
     def step_packed(self, action, rows: torch.Tensor) -> None:
         """One step; all outputs in one (B, row_stride) float32 row tensor (see mir_step_packed)."""
         self._check(self.lib.mir_step_packed(self.h, _ptr(action), _ptr(rows), int(rows.stride(0)), self._stream()))
+
+    def rollout(self, actions: torch.Tensor, rows: torch.Tensor) -> None:
+        """K env steps in one launch (mir_rollout): actions (K,B,nu), rows (K,B,row_stride) float32 device tensors."""
+        K = actions.shape[0]
+        if tuple(actions.shape) != (K, self.num_envs, self.nu) or rows.shape[0] != K or rows.shape[1] != self.num_envs or not (
+                actions.is_contiguous() and rows.is_contiguous()):
+            raise ValueError("rollout: actions (K,B,nu) and rows (K,B,row_stride) must be contiguous device tensors")
+        self._check(self.lib.mir_rollout(self.h, _ptr(actions), int(K), _ptr(rows), int(rows.stride(1)), self._stream()))
 
     def get_obs(self):
         agent, env = self.empty(self.agent_dim), self.empty(self.env_dim)

@@ -224,6 +224,12 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  * (row_stride >= agent_dim + env_dim + 2, in floats). */
 int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream);
 
+/* K consecutive env.step() calls in ONE launch (the "multi-step variant for rollouts" of SURVEY.md 7-7; the loop shape of
+ * README.md:30-43 with the actions already on the device): for k < n_steps: targets <- actions[k] (B,nu); one physics step;
+ * rows[k] (B,row_stride) <- packed outputs as in mir_step_packed.  actions (n_steps,B,nu), rows (n_steps,B,row_stride).
+ * Bit-identical to n_steps calls of mir_step_packed; the state never leaves the chip between the steps. */
+int mir_rollout(MirHandle h, const float* actions, int32_t n_steps, float* rows, int32_t row_stride, void* stream);
+
 /* get_obs() without stepping */
 int mir_get_obs(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated,
                 void* stream);

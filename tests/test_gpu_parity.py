@@ -419,3 +419,33 @@ def test_device_autoreset_equals_host_driven_masked_reset():
         assert np.array_equal(dev_task._cursor.cpu().numpy(), host_cur)
     assert n_term >= 2 and n_trunc >= 3 * B
     print(f"autoreset: {n_term} terminations, {n_trunc} truncations, device == host-driven bit for bit")
+
+
+@pytest.mark.parametrize("scene", ["pick", "stack"])
+def test_rollout_launch_equals_step_by_step_bit_exact(scene, franka_spec):
+    """mir_rollout (K steps, fresh action per step, one launch) == K launches of mir_step_packed, bit for bit, on both
+    step kernels; the state left behind is identical too."""
+    B, K = 24, 12
+    if scene == "pick":
+        spec, home, nfree = franka_spec, HOME, 1
+    else:
+        spec, home, nfree = models.franka_cube_stack_scene().build(), HOME, 5
+    a, b = _scene(spec, B), _scene(spec, B)
+    rng = np.random.RandomState(4)
+    pos = np.zeros((B, nfree, 3), np.float32)
+    pos[:, :, 0] = rng.uniform(-0.3, 0.3, (B, nfree)) + (0.6 if scene == "pick" else 0.0)
+    pos[:, :, 1] = rng.uniform(-0.25, 0.25, (B, nfree))
+    pos[:, :, 2] = 0.02 if scene == "pick" else models.STACK_CUBE_Z
+    quat = np.tile(np.array([0, 0, 0, 1], np.float32), (B, nfree, 1))
+    for s in (a, b):
+        s.reset(pos, quat, np.tile(home, (B, 1)))
+    acts = torch.as_tensor((home + rng.uniform(-1, 1, (K, B, 9))).astype(np.float32), device=a.device)
+    stride = a.agent_dim + a.env_dim + 2
+    rows_a = torch.zeros((K, B, stride), device=a.device)
+    rows_b = torch.zeros((K, B, stride), device=a.device)
+    a.rollout(acts, rows_a)
+    for k in range(K):
+        b.step_packed(acts[k], rows_b[k])
+    assert torch.equal(rows_a, rows_b)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert torch.equal(x, y)
