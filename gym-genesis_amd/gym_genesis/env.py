@@ -27,6 +27,8 @@ _TASKS = {
     ("so101", "cube_pick", True): "gym_genesis.tasks.so101.cube_pick:CubePick",
     ("so101", "cube_stack", True): "gym_genesis.tasks.so101.cube_stack_batch:CubeStackBatch",
     ("franka", "cube_stack", True): "gym_genesis.tasks.franka.cube_stack_kitchen_batch:FrankaCubeStackKitchenBatch",
+    ("so101", "cube_stack", False): "gym_genesis.tasks.stack_one:CubeStackOne",            # num_envs = 0 (env.py:115)
+    ("franka", "cube_stack", False): "gym_genesis.tasks.stack_one:FrankaCubeStackOne",     # num_envs = 0 (env.py:117)
 }
 
 
@@ -49,7 +51,8 @@ class GenesisEnv(Env):
         self._shard = shard
         self.num_envs = num_envs
         self._env = self._make_env_task(task)
-        self.num_envs = self._env.num_envs  # local shard size when sharded
+        # local shard size when sharded; the unbatched tasks (num_envs = 0) keep 0 like the reference (env.py:56,65)
+        self.num_envs = 0 if getattr(self._env, "unbatched", False) else self._env.num_envs
         self.observation_space = self._env.observation_space
         self.action_space = self._env.action_space
         self.scene = None
@@ -65,7 +68,7 @@ class GenesisEnv(Env):
     def step(self, action):
         _, reward, _, observation = self._env.step(action)
         term_dev = getattr(self._env, "terminated_device", None)
-        if term_dev is not None:
+        if term_dev is not None and not getattr(self._env, "unbatched", False):
             is_success = term_dev.bool()                   # written by the same kernel as the reward
         elif isinstance(reward, torch.Tensor):
             is_success = reward == 1

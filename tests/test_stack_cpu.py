@@ -168,3 +168,24 @@ def test_stack_pixels_contract_on_the_test_double(monkeypatch, robot, mode):
     assert env.get_cams() == (task.cam_top, task.cam_side, task.cam_wrist)
     assert task.cam_top.fov == 40.0 and task.cam_wrist.fov == (90.0 if robot == "franka" else 70.0)
     assert len(np.unique(obs["pixels"]["top"].numpy().reshape(-1, 3), axis=0)) >= 3  # slab, floor, cubes in the top view
+
+
+@pytest.mark.parametrize("robot,n", [("franka", 9), ("so101", 6)])
+def test_unbatched_stack_tasks(monkeypatch, robot, n):
+    """num_envs = 0 routes to the unbatched classes (env.py:110-117): no batch axis, scalar reward, the batched class's
+    B = 1 spawn stream (the reference draws the same values as scalars: cube_stack_one.py:68-86, so101/cube_stack.py:66-93)."""
+    import fake_scene
+    from gym_genesis.env import GenesisEnv
+    from gym_genesis.tasks import stack_common
+
+    monkeypatch.setattr(stack_common, "MirScene", fake_scene.OracleScene)
+    env = GenesisEnv(task="cube_stack", robot=robot, num_envs=0, enable_pixels=False)
+    assert type(env._env).__name__ == ("FrankaCubeStackOne" if robot == "franka" else "CubeStackOne") and env.num_envs == 0
+    obs, info = env.reset(seed=2)
+    assert info == {"is_success": []} and obs["agent_pos"].shape == (n,) and obs["environment_state"].shape == (14,)
+    obs, reward, terminated, truncated, info = env.step(np.asarray(env._env._home_qpos(), np.float32))
+    assert reward.dim() == 0 and terminated.shape == () and truncated.shape == (0,) and obs["agent_pos"].shape == (n,)
+    ref = _task(monkeypatch, robot, 1)
+    ref.seed(2)
+    env._env.seed(2)
+    assert np.array_equal(env._env.sample_spawn(), ref.sample_spawn())
