@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pixels", action="store_true", help="skip the secondary pixels (configs[4]) measurement")
     ap.add_argument("--no-stack", action="store_true", help="skip the secondary CubeStack-v0 measurement")
+    ap.add_argument("--core-only", action="store_true",
+                    help="only the timed headline loop (no API / autoreset / rollout / pixels / stack / ik / CPU legs): the command "
+                         "profiled by tools/collect_profiles.sh, so that every mir_step_kernel launch in the trace is a headline step")
     ap.add_argument("--force-gather", action="store_true", help="exercise the RCCL gather path even with one rank (plumbing check)")
     args = ap.parse_args()
 
@@ -301,37 +304,41 @@ def main():
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall_max = float(wall_t.item())
 
+    if args.core_only:
+        args.no_pixels = args.no_stack = args.no_cpu_baseline = True
     # end-to-end env.step() (with the API's per-step D->H `terminated` copy), reported beside the hot path
-    api_steps = 200
+    api_steps = 0 if args.core_only else 200
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     for t in range(api_steps):
         env.step(actions[t % n_act])
     torch.cuda.synchronize(dev)
-    api_rate = api_steps * B * world / (time.perf_counter() - t1)
+    api_rate = api_steps * B * world / (time.perf_counter() - t1) if api_steps else None
 
     # device-resident episode loop: fused step + on-device truncation/termination/re-spawn, no host sync
-    task.enable_autoreset(max_episode_steps=EPISODE_STEPS)
+    if api_steps:
+        task.enable_autoreset(max_episode_steps=EPISODE_STEPS)
     torch.cuda.synchronize(dev)
     t2 = time.perf_counter()
     for t in range(api_steps):
         task.step_autoreset(actions[t % n_act])
     torch.cuda.synchronize(dev)
-    loop_rate = api_steps * B * world / (time.perf_counter() - t2)
+    loop_rate = api_steps * B * world / (time.perf_counter() - t2) if api_steps else None
 
     # K-step rollout launches (mir_rollout): the same fresh-action workload with the state kept on chip between steps
     RK = 16
     rows_ro = torch.zeros((RK, B, ROW_STRIDE), dtype=torch.float32, device=dev)
-    nro = max(1, min(200, n_act) // RK)
-    task.reset()
-    for i in range(2):
+    nro = 0 if args.core_only else max(1, min(200, n_act) // RK)
+    if nro:
+        task.reset()
+    for i in range(0 if args.core_only else 2):
         task._mir.rollout(actions[i * RK:(i + 1) * RK], rows_ro)
     torch.cuda.synchronize(dev)
     t3 = time.perf_counter()
     for i in range(nro):
         task._mir.rollout(actions[i * RK:(i + 1) * RK], rows_ro)
     torch.cuda.synchronize(dev)
-    rollout_rate = nro * RK * B * world / (time.perf_counter() - t3)
+    rollout_rate = nro * RK * B * world / (time.perf_counter() - t3) if nro else None
 
     if rank == 0:
         value = K * B * world / wall_max
