@@ -339,6 +339,19 @@ def main():
         task._mir.rollout(actions[i * RK:(i + 1) * RK], rows_ro)
     torch.cuda.synchronize(dev)
     rollout_rate = nro * RK * B * world / (time.perf_counter() - t3) if nro else None
+    # the same with the device-side episode loop (truncation at 200 steps, re-spawn from the pre-drawn pool) inside the launch
+    loop_rollout_rate = None
+    if nro:
+        rows_ar = torch.zeros((RK, B, ROW_STRIDE), dtype=torch.float32, device=dev)
+        task.reset()
+        task._episode_len.zero_()
+        task.rollout_autoreset(actions[:RK], rows_ar)
+        torch.cuda.synchronize(dev)
+        t4 = time.perf_counter()
+        for i in range(nro):
+            task.rollout_autoreset(actions[i * RK:(i + 1) * RK], rows_ar)
+        torch.cuda.synchronize(dev)
+        loop_rollout_rate = nro * RK * B * world / (time.perf_counter() - t4)
 
     if rank == 0:
         value = K * B * world / wall_max
@@ -372,6 +385,7 @@ def main():
             "env_step_api_rate": api_rate,
             "device_autoreset_loop_rate": loop_rate,
             "device_rollout16_rate": rollout_rate,
+            "device_autoreset_rollout16_rate": loop_rollout_rate,
         }
         if world == 1 and not args.no_pixels:
             out["pixels"] = pixels_bench(dev)

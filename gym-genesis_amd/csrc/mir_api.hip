@@ -166,6 +166,7 @@ struct Outs {
   float* rows = nullptr;
   int row_stride = 0, mode = 0, n_steps = 1;
   long act_step = 0, rows_step = 0;
+  AutoResetArgs ar = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
   bool diag = true;
   unsigned long long* prof = nullptr;  // 16-lane kernel only (debug)
 };
@@ -183,7 +184,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
-    a.act_step = o.act_step; a.rows_step = o.rows_step;
+    a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
     rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
   } else {
     StepArgs64 a;
@@ -196,7 +197,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
-    a.act_step = o.act_step; a.rows_step = o.rows_step;
+    a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
     rc = mir_launch_step64(&a, (hipStream_t)stream);
   }
   if (rc != 0) return hip_fail((hipError_t)rc, "step kernel launch");
@@ -433,6 +434,21 @@ int mir_rollout(MirHandle h, const float* actions, int32_t n_steps, float* rows,
   Outs o;
   o.action = actions; o.rows = rows; o.row_stride = row_stride; o.n_steps = n_steps;
   o.act_step = (long)h->B * h->nu; o.rows_step = (long)h->B * row_stride;
+  return launch(h, o, stream);
+}
+
+int mir_rollout_autoreset(MirHandle h, const float* actions, int32_t n_steps, float* rows, int32_t row_stride, int32_t* episode_len,
+                          int32_t max_len, const float* spawn_pool, int32_t pool_len, int32_t* cursor, const float* obj_quat,
+                          const float* arm_qpos, void* stream) {
+  if (check(h) || !actions || !rows) return set_err(MIR_E_INVALID, "mir_rollout_autoreset: null argument");
+  if (!episode_len || !spawn_pool || !cursor || !obj_quat || !arm_qpos || pool_len <= 0) return set_err(MIR_E_INVALID, "mir_rollout_autoreset: null argument");
+  if (n_steps <= 0) return MIR_OK;
+  if (row_stride < h->agent_dim + h->env_dim + 3) return set_err(MIR_E_INVALID, "mir_rollout_autoreset: row_stride too small (needs the truncated column)");
+  DeviceGuard guard(h->device);
+  Outs o;
+  o.action = actions; o.rows = rows; o.row_stride = row_stride; o.n_steps = n_steps;
+  o.act_step = (long)h->B * h->nu; o.rows_step = (long)h->B * row_stride;
+  o.ar = AutoResetArgs{episode_len, cursor, spawn_pool, obj_quat, arm_qpos, pool_len, max_len};
   return launch(h, o, stream);
 }
 

@@ -85,7 +85,8 @@ int mir_compile_model64(const MirSceneSpec* sp0, DevModel64* out, HostConsts* hc
     }
   }
   std::vector<int> lane_of_dof(nv, -1);
-  for (int l = 0; l < W64; l++) { m.d_dof[l] = -1; m.d_uadr[l] = -1; }
+  for (int l = 0; l < W64; l++) { m.d_dof[l] = -1; m.d_uadr[l] = -1; m.d_armidx[l] = -1; }
+  int nfree_seen = 0;
   for (int b = 1; b < nb; b++) {
     int r = m.b_root[b];
     m.b_block[b] = tree_lane[r] >= 0 ? tree_lane[r] / 16 : -1;
@@ -105,11 +106,13 @@ int mir_compile_model64(const MirSceneSpec* sp0, DevModel64* out, HostConsts* hc
       } else {
         m.d_kind[l] = m.b_jtype[b] == MIR_JNT_REVOLUTE ? 0 : 1;
         m.d_premask[l] = inherited;
+        m.d_armidx[l] = narm;
         m.arm_qadr[narm++] = m.b_qadr[b];
       }
       m.d_ancmask[l] = inherited | (((1ull << (k + 1)) - 1ull) << la);
       m.lanemask |= 1ull << l;
     }
+    if (m.b_jtype[b] == MIR_JNT_FREE) m.free_qadr[nfree_seen++] = m.b_qadr[b];
     m.b_dofmask[b] = inherited | (ndof[b] ? (((1ull << ndof[b]) - 1ull) << la) : 0ull);
     tree_next[r] += ndof[b];
   }

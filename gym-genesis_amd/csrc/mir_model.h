@@ -88,6 +88,17 @@ struct HostConsts {
 // Compile a scene spec for the 16-lane kernel.  Returns MIR_OK, MIR_E_CAPACITY if the scene does not fit this
 // kernel's limits (the caller then tries the wave-per-env model), or another MIR_E_* code; fills err (<=255 chars).
 int mir_compile_model(const MirSceneSpec* spec, DevModel* out, HostConsts* hc, char* err);
+// Device-side episode bookkeeping + re-spawn inside a rollout launch (mir_rollout_autoreset): same rules as k_autoreset
+// in mir_api.hip.  episode_len == nullptr switches it off.
+struct AutoResetArgs {
+  int32_t* episode_len;     // (B) in/out
+  int32_t* cursor;          // (B) in/out
+  const float* spawn_pool;  // (pool_len, B, nfree, 3)
+  const float* obj_quat;    // (B, nfree, 4)
+  const float* arm_qpos;    // (B, n_arm)
+  int32_t pool_len, max_len;
+};
+
 // shared host-side helpers (mir_compile.cpp)
 int mir_host_consts(const MirSceneSpec* spec, HostConsts* out, char* err);
 void mir_round_spec(MirSceneSpec* spec);

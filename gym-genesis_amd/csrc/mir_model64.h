@@ -29,6 +29,8 @@ struct DevModel64 {
   int32_t n_arm_q;
   int32_t arm_qadr[MIR_MAX_DOF]; /* qpos address of scalar joint k (MIR_AGENT_QPOS) */
   uint64_t lanemask;             /* lanes that carry a dof */
+  int32_t d_armidx[W64];         /* index into arm_qpos for scalar-joint lanes, else -1 */
+  int32_t free_qadr[MIR_MAX_FREE]; /* qpos address of free body k (body order) */
   // ---- per body (index = lane < 32) ----
   int32_t b_parent[K64_MAX_BODY], b_jtype[K64_MAX_BODY], b_dofadr[K64_MAX_BODY] /* first LANE */, b_qadr[K64_MAX_BODY];
   int32_t b_root[K64_MAX_BODY], b_static[K64_MAX_BODY], b_block[K64_MAX_BODY] /* block of the body's tree, -1 = static */;

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     if (k == 10) return sqrtf(dot(df, df));
     return po.z > m->reward_z ? 1.0f : 0.0f;  // k == 11 reward, k == 12 terminated
   };
+  int eplen = a.ar.episode_len ? a.ar.episode_len[env] : 0, epcur = a.ar.episode_len ? a.ar.cursor[env] : 0;
   for (int step = 0; step < nsteps; step++) {
     // rollout mode (mir_rollout): a fresh action block per step
     if (step > 0 && a.action && a.act_step) {
@@ -872,9 +873,41 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     STAMP(9);
     // kinematics of the new state: observations of this step, and the next step's starting poses
     group_fk(S, lane, nb, parents, bk);
-    if (a.rows && a.rows_step && step + 1 < nsteps && valid) {  // rollout mode: one packed row per env per step
+    if (a.rows && a.rows_step && (step + 1 < nsteps || a.ar.episode_len) && valid) {  // rollout mode: one packed row per env per step
       float* row = a.rows + (size_t)step * a.rows_step + (size_t)env * a.row_stride;
       for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
+    }
+    if (a.ar.episode_len) {
+      // episode bookkeeping and re-spawn on chip (the rules of k_autoreset): the row above is the terminal observation
+      const bool term = S.xpos[ob][2] > m->reward_z;
+      const int len = eplen + 1;
+      const bool trunc = !term && a.ar.max_len > 0 && len >= a.ar.max_len;
+      const bool done = term || trunc;
+      if (valid && lane == 0 && a.rows && a.row_stride > ad + 13)
+        a.rows[(size_t)step * a.rows_step + (size_t)env * a.row_stride + ad + 13] = trunc ? 1.0f : 0.0f;
+      eplen = done ? 0 : len;
+      WSYNC();
+      if (done) {
+        S.qvel[lane] = 0.0f;
+        S.qacc_ws[lane] = 0.0f;
+        if (isdof) {
+          const int ai = m->d_armidx[lane];
+          if (ai >= 0) {
+            const float v = a.ar.arm_qpos[(size_t)env * m->n_arm_q + ai];
+            S.qpos[d_qadr] = v;
+            S.target[lane] = v;
+          }
+        }
+        const int nfree = m->nfree;
+        const float* sp = a.ar.spawn_pool + ((size_t)(epcur % a.ar.pool_len) * a.B + env) * nfree * 3;
+        for (int c = lane; c < 7 * nfree; c += G) {
+          const int k = c / 7, j = c - 7 * k;
+          S.qpos[m->free_qadr[k] + j] = j < 3 ? sp[k * 3 + j] : a.ar.obj_quat[((size_t)env * nfree + k) * 4 + (j - 3)];
+        }
+        epcur += 1;
+      }
+      WSYNC();
+      if (__any(done)) group_fk(S, lane, nb, parents, bk);
     }
   }  // steps
   STAMP(10);
@@ -900,7 +933,8 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     if (a.reward) a.reward[env] = rew;
     if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
   }
-  if (a.rows) {  // (in rollout mode: the last step's row)
+  if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
+  if (a.rows && !(a.ar.episode_len && a.rows_step)) {  // (in rollout mode: the last step's row; with autoreset it was written in the loop)
     float* row = a.rows + (size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride;
     for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
   }

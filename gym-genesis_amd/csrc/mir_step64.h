@@ -31,6 +31,7 @@ struct StepArgs64 {
   int row_stride;
   long act_step;   // floats between the action blocks of consecutive steps (rollout mode), 0 = one action for all steps
   long rows_step;  // floats between the row blocks of consecutive steps (rollout mode), 0 = only the final row
+  AutoResetArgs ar;  // per-step episode bookkeeping + re-spawn inside the launch (rollout mode only)
   int B;
   int mode;     // 0: full steps; 1: forward dynamics only; 2: kinematics + outputs only
   int n_steps;  // mode 0 only

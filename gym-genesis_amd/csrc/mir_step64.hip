@@ -320,6 +320,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     if (k < ed) return S.xpos[ob2][k - 11];
     return reward_now();  // k == ed reward, k == ed + 1 terminated
   };
+  int eplen = a.ar.episode_len ? a.ar.episode_len[env] : 0, epcur = a.ar.episode_len ? a.ar.cursor[env] : 0;
   for (int step = 0; step < nsteps; step++) {
     // rollout mode (mir_rollout): a fresh action block per step
     if (step > 0 && a.action && a.act_step) {
@@ -1039,8 +1040,40 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     STAMP(17);
     // kinematics of the new state: observations of this step, and the next step's starting poses
     wave_fk(S, lane, nb, bk);
-    if (a.rows && a.rows_step && step + 1 < nsteps && lane < ad + ed + 2)  // rollout mode: one packed row per env per step
+    if (a.rows && a.rows_step && (step + 1 < nsteps || a.ar.episode_len) && lane < ad + ed + 2)  // rollout mode: one packed row per env per step
       a.rows[(size_t)step * a.rows_step + (size_t)env * a.row_stride + lane] = column(lane);
+    if (a.ar.episode_len) {
+      // episode bookkeeping and re-spawn on chip (the rules of k_autoreset): the row above is the terminal observation
+      const bool term = reward_now() == 1.0f;
+      const int len = eplen + 1;
+      const bool trunc = !term && a.ar.max_len > 0 && len >= a.ar.max_len;
+      const bool done = term || trunc;  // wave-uniform: one env per wave
+      if (lane == 0 && a.rows && a.row_stride > ad + ed + 2)
+        a.rows[(size_t)step * a.rows_step + (size_t)env * a.row_stride + ad + ed + 2] = trunc ? 1.0f : 0.0f;
+      eplen = done ? 0 : len;
+      WSYNC();
+      if (done) {
+        S.qvel[lane] = 0.0f;
+        S.qacc_ws[lane] = 0.0f;
+        if (isdof) {
+          const int ai = m->d_armidx[lane];
+          if (ai >= 0) {
+            const float v = a.ar.arm_qpos[(size_t)env * m->n_arm_q + ai];
+            S.qpos[d_qadr] = v;
+            S.target[lane] = v;
+          }
+        }
+        const int nfree = m->nfree;
+        const float* sp = a.ar.spawn_pool + ((size_t)(epcur % a.ar.pool_len) * a.B + env) * nfree * 3;
+        if (lane < 7 * nfree) {
+          const int k = lane / 7, j = lane - 7 * k;
+          S.qpos[m->free_qadr[k] + j] = j < 3 ? sp[k * 3 + j] : a.ar.obj_quat[((size_t)env * nfree + k) * 4 + (j - 3)];
+        }
+        epcur += 1;
+        WSYNC();
+        wave_fk(S, lane, nb, bk);
+      }
+    }
   }  // steps
   STAMP(18);
   if (lane < nb) {
@@ -1065,7 +1098,8 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     if (a.reward) a.reward[env] = rew;
     if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
   }
-  if (a.rows && lane < ad + ed + 2)  // (in rollout mode: the last step's row)
+  if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
+  if (a.rows && !(a.ar.episode_len && a.rows_step) && lane < ad + ed + 2)  // (in rollout mode: the last step's row; with autoreset: written in the loop)
     a.rows[(size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride + lane] = column(lane);
   if (a.out_xpos && lane < nb) {
     st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3v(S.xpos[lane]));

@@ -51,6 +51,8 @@ def load_library() -> C.CDLL:
     lib.mir_step_packed.restype = C.c_int
     lib.mir_rollout.argtypes = [vp, vp, i32, vp, i32, vp]
     lib.mir_rollout.restype = C.c_int
+    lib.mir_rollout_autoreset.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp]
+    lib.mir_rollout_autoreset.restype = C.c_int
     lib.mir_get_obs.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.mir_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.mir_set_state.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -187,6 +189,18 @@ class MirScene:
                 actions.is_contiguous() and rows.is_contiguous()):
             raise ValueError("rollout: actions (K,B,nu) and rows (K,B,row_stride) must be contiguous device tensors")
         self._check(self.lib.mir_rollout(self.h, _ptr(actions), int(K), _ptr(rows), int(rows.stride(1)), self._stream()))
+
+    def rollout_autoreset(self, actions: torch.Tensor, rows: torch.Tensor, episode_len, max_len: int, spawn_pool, cursor, obj_quat,
+                          arm_qpos) -> None:
+        """K env steps + the device-side episode loop in one launch (mir_rollout_autoreset); rows need one spare column
+        (truncated) after [agent | env_state | reward | terminated]."""
+        K = actions.shape[0]
+        if tuple(actions.shape) != (K, self.num_envs, self.nu) or rows.shape[0] != K or rows.shape[1] != self.num_envs or not (
+                actions.is_contiguous() and rows.is_contiguous()):
+            raise ValueError("rollout_autoreset: actions (K,B,nu) and rows (K,B,row_stride) must be contiguous device tensors")
+        self._check(self.lib.mir_rollout_autoreset(self.h, _ptr(actions), int(K), _ptr(rows), int(rows.stride(1)), _ptr(episode_len), int(max_len),
+                                                   _ptr(spawn_pool), int(spawn_pool.shape[0]), _ptr(cursor), _ptr(obj_quat), _ptr(arm_qpos),
+                                                   self._stream()))
 
     def get_obs(self):
         agent, env = self.empty(self.agent_dim), self.empty(self.env_dim)

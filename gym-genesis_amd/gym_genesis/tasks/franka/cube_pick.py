@@ -157,6 +157,13 @@ class FrankaCubePickBatch:
                       self._quat, self._home, self._truncated, self._done)
         return self._agent, self._envst, self._reward, self._term, self._truncated
 
+    def rollout_autoreset(self, actions_dev: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+        """K steps of the device-resident episode loop in ONE launch (after enable_autoreset()): actions (K,B,9), rows
+        (K,B,>=23) <- [agent_pos 9 | environment_state 11 | reward | terminated | truncated] per step and env."""
+        self._mir.rollout_autoreset(actions_dev, rows, self._episode_len, self._max_episode_steps, self._spawn_pool, self._cursor,
+                                    self._quat, self._home)
+        return rows
+
     def step(self, action):
         a = self._as_action(action)
         # fresh output tensors per call, like the reference (callers may keep old observations)

@@ -230,6 +230,14 @@ int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_s
  * Bit-identical to n_steps calls of mir_step_packed; the state never leaves the chip between the steps. */
 int mir_rollout(MirHandle h, const float* actions, int32_t n_steps, float* rows, int32_t row_stride, void* stream);
 
+/* mir_rollout with the episode loop of mir_autoreset inside the launch: after every step the packed row (the terminal
+ * observation of envs that just ended) is written, then episode_len / truncation / re-spawn are applied exactly as
+ * mir_autoreset does, on chip.  rows[k][e][agent_dim + env_dim + 2] = truncated (row_stride >= agent_dim + env_dim + 3).
+ * Bit-identical to n_steps x (mir_step_packed; mir_autoreset). */
+int mir_rollout_autoreset(MirHandle h, const float* actions, int32_t n_steps, float* rows, int32_t row_stride, int32_t* episode_len,
+                          int32_t max_len, const float* spawn_pool, int32_t pool_len, int32_t* cursor, const float* obj_quat,
+                          const float* arm_qpos, void* stream);
+
 /* get_obs() without stepping */
 int mir_get_obs(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated,
                 void* stream);

@@ -476,3 +476,48 @@ def test_against_captured_genesis_goldens():
             q = env.get_robot().get_dofs_position().cpu().numpy()[:, :nj]
             assert np.abs(q - g["qpos"][t]).max() < 1e-4, (f, t)
             assert np.array_equal(reward.cpu().numpy(), g["reward"][t]) and np.array_equal(terminated, g["terminated"][t]), (f, t)
+
+
+@pytest.mark.parametrize("scene", ["pick", "stack"])
+def test_rollout_autoreset_launch_equals_host_driven_loop_bit_exact(scene, franka_spec):
+    """mir_rollout_autoreset (K steps + episode bookkeeping + re-spawn on chip) == K x (mir_step_packed; mir_autoreset), bit
+    for bit: rows, truncated flags, counters and the final state; short episodes so that truncations and re-spawns happen."""
+    B, K, max_len, pool = 16, 25, 7, 5
+    spec, nfree = (franka_spec, 1) if scene == "pick" else (models.franka_cube_stack_scene().build(), 5)
+    a, b = _scene(spec, B), _scene(spec, B)
+    dev = a.device
+    rng = np.random.RandomState(9)
+
+    def spawn(n):
+        p = np.zeros((n, B, nfree, 3), np.float32)
+        p[..., 0] = rng.uniform(-0.3, 0.3, (n, B, nfree)) + (0.6 if scene == "pick" else 0.0)
+        p[..., 1] = rng.uniform(-0.25, 0.25, (n, B, nfree))
+        p[..., 2] = 0.02 if scene == "pick" else models.STACK_CUBE_Z
+        if scene == "pick":
+            p[1, :4, 0, 2] = 0.3  # some re-spawns start above the reward height: terminated episodes too
+        return p
+
+    pool_t = torch.as_tensor(spawn(pool), device=dev)
+    quat = torch.as_tensor(np.tile(np.array([0, 0, 0, 1], np.float32), (B, nfree, 1)), device=dev)
+    home = torch.as_tensor(np.tile(HOME, (B, 1)), device=dev)
+    for s in (a, b):
+        s.reset(pool_t[0], quat, home)
+    acts = torch.as_tensor((HOME + rng.uniform(-1, 1, (K, B, 9))).astype(np.float32), device=dev)
+    stride = a.agent_dim + a.env_dim + 3
+    rows_a, rows_b = torch.zeros((K, B, stride), device=dev), torch.zeros((K, B, stride), device=dev)
+    ep = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    cur = [torch.ones(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    a.rollout_autoreset(acts, rows_a, ep[0], max_len, pool_t, cur[0], quat, home)
+    trunc, done = torch.zeros(B, dtype=torch.uint8, device=dev), torch.zeros(B, dtype=torch.uint8, device=dev)
+    nd = 0
+    for k in range(K):
+        b.step_packed(acts[k], rows_b[k])
+        term = rows_b[k][:, a.agent_dim + a.env_dim + 1].to(torch.uint8).contiguous()
+        b.autoreset(term, ep[1], max_len, pool_t, cur[1], quat, home, trunc, done)
+        rows_b[k][:, a.agent_dim + a.env_dim + 2] = trunc.float()
+        nd += int(done.sum().item())
+    assert nd >= 3 * B  # episodes really ended (truncation every 7 steps, some terminations)
+    assert torch.equal(rows_a, rows_b)
+    assert torch.equal(ep[0], ep[1]) and torch.equal(cur[0], cur[1])
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert torch.equal(x, y)
