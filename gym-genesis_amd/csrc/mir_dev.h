@@ -166,7 +166,7 @@ __device__ __forceinline__ float bh(const BoxG& b, int k) { return k == 0 ? b.h.
 // Rare (only when bounding spheres overlap) and register-hungry: kept out of line.
 // Polygon workspace of the clipping stage (6 arrays x 9 floats, dynamically indexed).  PolyScratch keeps it in
 // private memory (the 16-lane kernel: the routine is rare there and its LDS is full); PolyLds places element k of this
-// lane at base[k * 64], a lane-interleaved, bank-conflict-free LDS area (the wave kernel runs the routine every step
+// lane at base[k * 32] (32 lanes at a time), a lane-interleaved, bank-conflict-free LDS area (the wave kernel runs the routine every step
 // for the cube-slab pairs, where scratch round trips dominated).
 struct PolyScratch {
   float a[6][9];
@@ -174,7 +174,7 @@ struct PolyScratch {
 };
 struct PolyLds {
   float* base;  // already offset by the lane index
-  __device__ __forceinline__ float& at(int arr, int i) { return base[(arr * 9 + i) * 64]; }
+  __device__ __forceinline__ float& at(int arr, int i) { return base[(arr * 9 + i) * 32]; }
 };
 template <class Poly>
 __device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4], V3& nout, Poly P) {

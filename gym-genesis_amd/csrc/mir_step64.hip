@@ -35,7 +35,7 @@
 #define MAXC MIR_MAX_CONTACT
 #define JSEG 52 /* floats per contact segment: 3 rows x 16 + 4 pad */
 #define MSTR 20 /* row stride of the block-diagonal M rows in LDS */
-#define HSTR 68 /* row stride of the dense Hessian in LDS */
+#define HSTR 68 /* row stride of the dense Hessian (HBM scratch rows, used only when a contact couples two blocks) */
 #define STAMP(k) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
 static_assert(MAXC <= NL, "lane c owns contact c");
 static_assert(MIR_MAX_GEOM <= NL && MIR_MAX_PAIR <= 4 * NL, "lane ownership of geoms / pairs");
@@ -155,15 +155,16 @@ struct Env64 {
   int parent[NB];
   int ncon, ncand, pad0, pad1;
   // three phase-local areas share storage: dynamics scratch + M (FK .. smooth solve), collision scratch, and the
-  // dense Newton Hessian (row i = lane i, stride HSTR: a 16-lane group's b128 accesses cover all 64 banks)
+  // contact Jacobian segments (written once the contacts are finished)
   union {
     DynM64 dm;
     Col64 col;
-    float H[NL][HSTR];
+    float Jb[MAXC][2][JSEG];
   };
-  Con64 con;
-  float Jb[MAXC][2][JSEG];
+  Con64 con;          // (before the contacts are finished: the box-box clipping workspace, 32 lanes at a time)
+  float Hb[NL][MSTR];  // Newton Hessian, block-diagonal part: row of lane i holds the 16 columns of its own block
 };
+static_assert(sizeof(Con64) >= 54 * 32 * sizeof(float), "box-box workspace lives in the contact arrays");
 
 struct BodyK64 {
   int jtype, qadr;
@@ -601,19 +602,21 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       WSYNC();
       mycount = S.col.ccount[lane];
       STAMP(7);
-      // narrowphase, box-box: one lane per candidate
-      if (lane < ncand) {
-        const int pr = m->pair[S.col.cand[lane]];
-        const int g1 = pr & 255, g2 = pr >> 8;
-        if (m->g_type[g1] != MIR_GEOM_PLANE) {
-          M3 R2 = q2m(ld4v(S.col.gquat[g2]));
-          BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(m->g_size[g2])};
-          M3 R1 = q2m(ld4v(S.col.gquat[g1]));
-          BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(m->g_size[g1])};
-          V3 n = v3(0, 0, 1);
-          // clipping workspace: the contact-Jacobian area is not written before the contacts are finished
-          mycount = box_box(B1, B2, S.col.stage[lane], n, PolyLds{&S.Jb[0][0][0] + lane});
-          st3v(S.col.snorm[lane], n);
+      // narrowphase, box-box: one lane per candidate, 32 candidates at a time (the clipping workspace of 32 lanes fits
+      // the contact arrays, which are not written before the contacts are finished)
+      for (int half = 0; half < ncand; half += 32) {
+        if (lane >= half && lane < half + 32 && lane < ncand) {
+          const int pr = m->pair[S.col.cand[lane]];
+          const int g1 = pr & 255, g2 = pr >> 8;
+          if (m->g_type[g1] != MIR_GEOM_PLANE) {
+            M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+            BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(m->g_size[g2])};
+            M3 R1 = q2m(ld4v(S.col.gquat[g1]));
+            BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(m->g_size[g1])};
+            V3 n = v3(0, 0, 1);
+            mycount = box_box(B1, B2, S.col.stage[lane], n, PolyLds{reinterpret_cast<float*>(&S.con) + (lane - half)});
+            st3v(S.col.snorm[lane], n);
+          }
         }
       }
     }
@@ -816,20 +819,28 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
           for (int q = 0; q < 4; q++)
             if ((comp >> (4 * p + q)) & 1u) comp |= ((comp >> (4 * q)) & 15u) << (4 * p);
     }
-    // Dense Hessian H = Mt + J^T D_active J in LDS, kept across iterations and updated incrementally (only rows whose
-    // active flag flipped contribute, as in the 16-lane kernel).  Initial rows: Mt in the lane's own block, identity on
-    // padding lanes.  (The collision scratch this overlays is dead: the barrier above separates its last read.)
-    {
-      float* hr = &S.H[lane][0];
+    // Newton Hessian H = Mt + J^T D_active J, kept across iterations and updated incrementally (only rows whose active
+    // flag flipped contribute, as in the 16-lane kernel).  When no contact couples two blocks this step (comp = identity:
+    // the arm is not touching a cube, no two cubes of different blocks touch) H is block-diagonal like M: 16-wide rows in
+    // LDS, solved by the DPP block solver.  Otherwise the dense 64-wide rows live in an HBM scratch row per lane
+    // (lane-private, L2-resident): that keeps the LDS footprint at 4 envs per CU for everybody.
+    const bool coupled = comp != 0x8421u;
+    float* const hg = a.hscratch + ((size_t)env * NL + lane) * HSTR;
+    if (coupled) {
 #pragma unroll
-      for (int q = 0; q < 16; q++) stv(hr + 4 * q, f4{0, 0, 0, 0});
+      for (int q = 0; q < 16; q++) *reinterpret_cast<f4*>(hg + 4 * q) = f4{0, 0, 0, 0};
       if (isdof) {
-        float* hb = hr + 16 * blk;
 #pragma unroll
-        for (int q = 0; q < 4; q++) stv(hb + 4 * q, f4{mrow[4 * q], mrow[4 * q + 1], mrow[4 * q + 2], mrow[4 * q + 3]});
+        for (int q = 0; q < 4; q++) *reinterpret_cast<f4*>(hg + 16 * blk + 4 * q) = f4{mrow[4 * q], mrow[4 * q + 1], mrow[4 * q + 2], mrow[4 * q + 3]};
       } else {
-        hr[lane] = 1.0f;
+        hg[lane] = 1.0f;
       }
+    } else {
+      float* hb = &S.Hb[lane][0];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        stv(hb + 4 * q, isdof ? f4{mrow[4 * q], mrow[4 * q + 1], mrow[4 * q + 2], mrow[4 * q + 3]}
+                              : f4{4 * q == l16 ? 1.0f : 0.0f, 4 * q + 1 == l16 ? 1.0f : 0.0f, 4 * q + 2 == l16 ? 1.0f : 0.0f, 4 * q + 3 == l16 ? 1.0f : 0.0f});
     }
     float oldlact = 0.0f;
     unsigned prevbits = 0u;
@@ -863,8 +874,11 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       const float gn = sqrtf(wsum(g * g));
       if (scale * gn < tol || gn < gfloor) { done = true; break; }
       if (it == 0) STAMP(12);
-      // ---- Hessian rows (lane = dof): incremental update of H = Mt + J^T D_active J in LDS
-      if (lact != oldlact) S.H[lane][lane] += lact - oldlact;
+      // ---- Hessian rows (lane = dof): incremental update of H = Mt + J^T D_active J
+      if (lact != oldlact) {
+        if (coupled) hg[lane] += lact - oldlact;
+        else S.Hb[lane][l16] += lact - oldlact;
+      }
       oldlact = lact;
       for (int kq = 0; kq < nmine; kq++) {  // only the rows of the (at most two) blocks a contact touches change
         const int eq = S.con.blist[blk][kq];
@@ -886,28 +900,40 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         for (int sgi = 0; sgi < 2; sgi++) {
           const int bs = sgi == 0 ? sg0 : sg1;
           if (bs < 0) continue;
-          float* hb = &S.H[lane][16 * bs];
           const float* seg = &S.Jb[c][sgi][0];
+          if (coupled) {
+            float* hb = hg + 16 * bs;
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const f4 xn = ldv(seg + 4 * q), x1 = ldv(seg + 16 + 4 * q), x2 = ldv(seg + 32 + 4 * q);
-            f4 hq = ldv(hb + 4 * q);
-            hq.x += tn * xn.x + t1 * x1.x + t2 * x2.x;
-            hq.y += tn * xn.y + t1 * x1.y + t2 * x2.y;
-            hq.z += tn * xn.z + t1 * x1.z + t2 * x2.z;
-            hq.w += tn * xn.w + t1 * x1.w + t2 * x2.w;
-            stv(hb + 4 * q, hq);
+            for (int q = 0; q < 4; q++) {
+              const f4 xn = ldv(seg + 4 * q), x1 = ldv(seg + 16 + 4 * q), x2 = ldv(seg + 32 + 4 * q);
+              f4 hq = *reinterpret_cast<const f4*>(hb + 4 * q);
+              hq.x += tn * xn.x + t1 * x1.x + t2 * x2.x;
+              hq.y += tn * xn.y + t1 * x1.y + t2 * x2.y;
+              hq.z += tn * xn.z + t1 * x1.z + t2 * x2.z;
+              hq.w += tn * xn.w + t1 * x1.w + t2 * x2.w;
+              *reinterpret_cast<f4*>(hb + 4 * q) = hq;
+            }
+          } else {  // single-block contact: bs == blk
+            float* hb = &S.Hb[lane][0];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const f4 xn = ldv(seg + 4 * q), x1 = ldv(seg + 16 + 4 * q), x2 = ldv(seg + 32 + 4 * q);
+              f4 hq = ldv(hb + 4 * q);
+              hq.x += tn * xn.x + t1 * x1.x + t2 * x2.x;
+              hq.y += tn * xn.y + t1 * x1.y + t2 * x2.y;
+              hq.z += tn * xn.z + t1 * x1.z + t2 * x2.z;
+              hq.w += tn * xn.w + t1 * x1.w + t2 * x2.w;
+              stv(hb + 4 * q, hq);
+            }
           }
         }
       }
       if (it == 0) STAMP(13);
-      // ---- Newton direction: H s = -g.  When no contact couples two blocks this step (comp = identity: the arm is
-      // not touching a cube and no two cubes of different blocks touch), H is block-diagonal like M and the four
-      // blocks are solved side by side by the 16-wide DPP Gauss-Jordan; otherwise dense over the wave.
+      // ---- Newton direction: H s = -g: four 16-wide DPP block solves side by side, or dense over the wave
       float sv = -g;
-      if (comp == 0x8421u) {
+      if (!coupled) {
         float hb[G];
-        const float* hr = &S.H[lane][16 * blk];
+        const float* hr = &S.Hb[lane][0];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const f4 v = ldv(hr + 4 * q);
@@ -916,10 +942,9 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         GJ<0>::run(hb, sv, l16);
       } else {
         float hrow[NL];
-        const float* hr = &S.H[lane][0];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-          const f4 v = ldv(hr + 4 * q);
+          const f4 v = *reinterpret_cast<const f4*>(hg + 4 * q);
           hrow[4 * q] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
         }
         gj_wave(hrow, sv, lane, lanemask, comp);

@@ -233,3 +233,40 @@ def test_env_api_and_sharded_equivalence():
             o_s, *_ = es.step(acts[t][lo:hi])
         parts.append(torch.cat([o_s["agent_pos"], o_s["environment_state"]], 1).cpu().numpy())
     assert np.array_equal(full, np.concatenate(parts))  # N shards == one batch, bit-exact
+
+
+def test_arm_cube_contact_takes_the_coupled_solver_path_and_matches_oracle():
+    """A cube wedged at the fingertips couples the arm's block with the cube's block: the Newton system is no longer
+    block-diagonal, the kernel switches to the dense solve over HBM scratch rows.  Constrained accelerations of that state
+    and a short free-running rollout against the oracle."""
+    B = 8
+    spec = _builder("franka").build()
+    sc, o = _scene(spec, B), orc.Oracle(spec, B)
+    pos = _reset_both(sc, o, B, "franka", seed=4)
+    xpos = sc.get_links()[0].cpu().numpy()
+    names = [b["name"] for b in _builder("franka").bodies]
+    lf, rf = names.index("left_finger"), names.index("right_finger")
+    q, v, tgt, ws = (t.cpu().numpy() for t in sc.get_state())
+    for e in range(B):  # cube_1 overlapping the left finger's box by a few millimetres (finger frame origin = box top)
+        q[e, 9:12] = xpos[e, lf] + np.array([0.0, 0.0, 0.016 - 0.001 * e])
+    sc.set_state(qpos=q, qvel=v)
+    for e in range(B):
+        o.write(orc.F_QPOS, q[e], e)
+        o.write(orc.F_QVEL, v[e], e)
+    M, bias, qas, qacc = (t.cpu().numpy().astype(np.float64) for t in sc.forward())
+    ncon = sc.get_diag()[0].cpu().numpy()
+    touching = 0
+    for e in range(B):
+        o.forward(e)
+        assert ncon[e] == o.counts(e)[0]
+        qo = o.read(orc.F_QACC, e)
+        assert np.abs(qacc[e] - qo).max() < 1e-3 * max(1.0, np.abs(qo).max()), e
+        touching += int(ncon[e] >= 4)
+    assert touching == B  # (the other cubes still float 1 mm above the slab right after reset: every contact here is arm-cube)
+    bufs = (sc.empty(sc.agent_dim), sc.empty(sc.env_dim), sc.empty(), sc.empty(dtype=torch.uint8))
+    for t in range(10):
+        sc.step_fused(None, *bufs)
+        o.step_batch(None)
+    qg = sc.get_state()[0].cpu().numpy()
+    assert np.abs(qg - o.state()[0]).max() < 1e-3  # a cube pushed off the finger: fast, contact-rich motion
+    _check_obs(sc, o, bufs, 2e-3)
