@@ -10,15 +10,18 @@
 //   * k_render_setup (one thread per (env, geom)): world pose of every primitive from the step kernel's
 //     FK cache, the camera expressed in the primitive's frame (origin o', and the images F', R', U' of
 //     the camera basis, so a pixel's ray in that frame is d' = F' + x R' + y U': 6 FMAs, no matrix
-//     product), the per-face light terms, and a conservative screen rectangle.  128 B per primitive.
-//   * mir_render_kernel: workgroup = 256 threads = one 128 x 32 pixel tile of one image; the tile's
-//     primitives are culled by rectangle into LDS (ordered ballot compaction) and read from there as
-//     wave-uniform broadcast ds_reads; a thread owns 4 consecutive pixels of a row (4 rows per thread),
-//     so a wave finishes two 384-byte row segments at a time and stores them as packed RGB8 with one
-//     global_store_dwordx3 per lane: every 128-byte line of the image is written exactly once, whole.
-//     Primitives are additionally culled per wave (2 rows) by a scalar branch.
+//     product), FINAL packed RGB8 colours per face (albedo x shade) or, for a plane, the two checker colours
+//     and the affine numerators of the perspective-correct checker coordinate, and a conservative screen
+//     rectangle.  128 B per primitive.  Per-env cameras (mir_render_cams) are resolved here too.
+//   * mir_render_kernel: workgroup = 256 threads = 4 waves side by side on a 128-pixel-wide strip, walked as
+//     128 x 32 sub-tiles; the strip's primitives are culled once by rectangle (ordered ballot compaction, id list
+//     in LDS); records are fetched with wave-uniform SCALAR loads (constant address space); a lane owns 4
+//     consecutive pixels of a row in each of four 32 x 8 regions, culled per region by scalar branches;
+//     arithmetic on packed fp32 pixel pairs; 4 pixels -> 3 dwords -> one global_store_dwordx3 per lane, not
+//     waited for (the next sub-tile's arithmetic runs under the stores).
 //   * ray/box in the box frame is a 3-slab test; depth order is resolved per pixel (strict <, list in
-//     ascending primitive order => deterministic); shading is deferred to one lookup per pixel.
+//     ascending primitive order => deterministic); the colour of a hit is selected at hit time from the
+//     record, so there is no shading pass and no per-pixel lookup.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,7 +36,6 @@
 #ifndef TH
 #define TH 96   /* rows per workgroup strip (multiple of 32): walked as 128 x 32 sub-tiles */
 #endif
-#define RCAP 64  /* primitive records resident in LDS per round */
 #define PREC 32  /* floats per primitive record */
 #ifndef MIR_RENDER_NT
 #define MIR_RENDER_NT 0 /* 1: nontemporal pixel stores */
