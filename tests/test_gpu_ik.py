@@ -76,3 +76,18 @@ def test_expert_pick_policy_end_to_end_on_device():
     frac = success.float().mean().item()
     assert frac > 0.8, f"only {frac:.2f} of the envs lifted the cube"
     print(f"expert pick with on-device IK: {frac * 100:.0f} % of {B} envs lifted the cube")
+
+
+def test_expert_pick_and_stack_end_to_end_on_device():
+    """The stack task's whole loop on the device: hover -> grasp -> lift -> place -> release (the stage list of
+    examples/franka/stack_cube_state.py:33-55), Cartesian targets through the batched IK every step, the wave-per-env kernel
+    carrying finger-cube and cube-cube contacts, the stack reward |dxy| < 0.05 and dz > 0.03 (cube_stack_kitchen_batch.py:138-146)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stack_expert
+
+    final, ever = stack_expert.run(B=32, seed=1, verbose=False, grasp_dz=0.058, place_dz=0.104)
+    assert final > 0.8, f"only {final:.2f} of the envs ended with cube_1 stacked on cube_2"
+    print(f"expert pick-and-stack with on-device IK: {final * 100:.0f} % stacked at the end ({ever * 100:.0f} % at some point)")
