@@ -115,6 +115,40 @@ class StackTaskBase:
         self._mir.step(1)                             # both references consume one physics step in reset()
         return self.get_obs()
 
+    def reset_masked(self, env_mask):
+        """Per-env reset without touching the other envs.  Draws one spawn per env from the task RandomState
+        exactly like reset() (the host stream advances identically whether or not an env is selected); no physics step."""
+        pos = torch.from_numpy(self.sample_spawn()[self.shard_lo:self.shard_hi]).to(self.device)
+        self._mir.reset(pos, self._quat, self._home, env_mask=env_mask)
+        return self.get_obs()
+
+    # ---- device-resident episode loop (SURVEY.md 8f-1), same contract as FrankaCubePickBatch ----------------
+    def enable_autoreset(self, max_episode_steps: int = 200, pool_len: int = 32):
+        B, dev = self.num_envs, self.device
+        pool = np.stack([self.sample_spawn()[self.shard_lo:self.shard_hi] for _ in range(pool_len)])  # (pool, B, 5, 3)
+        self._spawn_pool = torch.from_numpy(pool).to(dev).contiguous()
+        self._cursor = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self._episode_len = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self._truncated = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self._done = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self._max_episode_steps = int(max_episode_steps)
+
+    def step_autoreset(self, action_dev: torch.Tensor):
+        """One fused step, then device-side bookkeeping + re-spawn of finished envs (mir_autoreset); returns device tensors
+        (agent_pos, environment_state, reward, terminated u8, truncated u8) of THIS step."""
+        mir = self._mir
+        mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)
+        mir.autoreset(self._term, self._episode_len, self._max_episode_steps, self._spawn_pool, self._cursor, self._quat, self._home,
+                      self._truncated, self._done)
+        return self._agent, self._envst, self._reward, self._term, self._truncated
+
+    def rollout_autoreset(self, actions_dev: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+        """K steps of that loop in ONE launch: actions (K,B,n), rows (K,B,>= agent+14+3) <- [agent_pos | environment_state |
+        reward | terminated | truncated] per step and env."""
+        self._mir.rollout_autoreset(actions_dev, rows, self._episode_len, self._max_episode_steps, self._spawn_pool, self._cursor,
+                                    self._quat, self._home)
+        return rows
+
     def step(self, action):
         if not isinstance(action, torch.Tensor):
             action = torch.as_tensor(np.asarray(action))

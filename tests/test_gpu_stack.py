@@ -270,3 +270,31 @@ def test_arm_cube_contact_takes_the_coupled_solver_path_and_matches_oracle():
     qg = sc.get_state()[0].cpu().numpy()
     assert np.abs(qg - o.state()[0]).max() < 1e-3  # a cube pushed off the finger: fast, contact-rich motion
     _check_obs(sc, o, bufs, 2e-3)
+
+
+def test_stack_task_device_episode_loop_and_masked_reset():
+    from gym_genesis.env import GenesisEnv
+
+    B, K = 8, 12
+    env = GenesisEnv(task="cube_stack", robot="so101", num_envs=B)
+    env.reset(seed=0)
+    task = env._env
+    task.enable_autoreset(max_episode_steps=5, pool_len=4)
+    dev = task.device
+    acts = task._home[0] + torch.zeros((K, B, 6), device=dev)
+    rows = torch.zeros((K, B, task._mir.agent_dim + 14 + 3), device=dev)
+    task.rollout_autoreset(acts, rows)
+    trunc = rows[:, :, -1].cpu().numpy()
+    assert (trunc[4] == 1).all() and (trunc[9] == 1).all() and trunc.sum() == 2 * B  # every 5th step truncates
+    assert (task._episode_len.cpu().numpy() == 2).all() and (task._cursor.cpu().numpy() == 2).all()
+    # host-driven variant continues the same counters
+    out = task.step_autoreset(acts[0])
+    assert (task._episode_len.cpu().numpy() == 3).all() and out[0].shape == (B, 6)
+    # masked reset: untouched envs bit-identical
+    q0 = task._mir.get_state()[0].clone()
+    mask = torch.zeros(B, dtype=torch.uint8, device=dev)
+    mask[2] = 1
+    task.reset_masked(mask)
+    q1 = task._mir.get_state()[0]
+    keep = [e for e in range(B) if e != 2]
+    assert torch.equal(q0[keep], q1[keep]) and not torch.equal(q0[2], q1[2])
