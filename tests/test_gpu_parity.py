@@ -521,3 +521,55 @@ def test_rollout_autoreset_launch_equals_host_driven_loop_bit_exact(scene, frank
     assert torch.equal(ep[0], ep[1]) and torch.equal(cur[0], cur[1])
     for x, y in zip(a.get_state(), b.get_state()):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("scene", ["pick", "stack"])
+def test_checkpoint_resume_is_bit_exact(scene, franka_spec):
+    """mir_get_state / mir_set_state as checkpoint / resume: restoring (qpos, qvel, PD targets, solver warm
+    start) and replaying the same actions reproduces the trajectory bit for bit on both kernels."""
+    B = 16
+    spec, nfree = (franka_spec, 1) if scene == "pick" else (models.franka_cube_stack_scene().build(), 5)
+    sc = _scene(spec, B)
+    rng = np.random.RandomState(11)
+    pos = np.zeros((B, nfree, 3), np.float32)
+    pos[:, :, 0] = rng.uniform(-0.3, 0.3, (B, nfree)) + (0.6 if scene == "pick" else 0.0)
+    pos[:, :, 1] = rng.uniform(-0.25, 0.25, (B, nfree))
+    pos[:, :, 2] = 0.02 if scene == "pick" else models.STACK_CUBE_Z
+    sc.reset(pos, np.tile(np.array([0, 0, 0, 1], np.float32), (B, nfree, 1)), np.tile(HOME, (B, 1)))
+    acts = torch.as_tensor((HOME + rng.uniform(-1, 1, (40, B, 9))).astype(np.float32), device=sc.device)
+    stride = sc.agent_dim + sc.env_dim + 2
+    row = torch.zeros((B, stride), device=sc.device)
+    for t in range(20):
+        sc.step_packed(acts[t], row)
+    ckpt = [x.clone() for x in sc.get_state()]
+    first = []
+    for t in range(20, 40):
+        sc.step_packed(acts[t], row)
+        first.append(row.clone())
+    sc.set_state(*ckpt)
+    for t in range(20, 40):
+        sc.step_packed(acts[t], row)
+        assert torch.equal(row, first[t - 20]), t
+
+
+def test_c_abi_argument_errors_are_reported_not_crashed(franka_spec):
+    import ctypes as C
+
+    from gym_genesis.backend.lib import MirError
+    from gym_genesis.backend.spec import make_camera
+
+    sc = _scene(franka_spec, 4)
+    vis = models.franka_cube_pick_scene().visual()
+    with pytest.raises(MirError):
+        sc.render(make_camera(64, 48, (1, 1, 1), (1, 1, 1), 30), vis)            # pos == lookat
+    with pytest.raises(MirError):
+        sc.render(make_camera(64, 48, (1, 1, 1), (0, 0, 0), 190), vis)           # fov out of range
+    with pytest.raises(MirError):
+        sc.inverse_kinematics(99, np.zeros((4, 3), np.float32))                   # link out of range
+    with pytest.raises(MirError):
+        sc.inverse_kinematics(franka_spec.task.obj_body, np.zeros((4, 3), np.float32))  # the cube hangs off a free joint
+    with pytest.raises(MirError):
+        sc.step_packed(None, torch.zeros((4, 5), device=sc.device))                # row_stride too small
+    assert sc.lib.mir_step(None, 1, None) != 0 and b"null" in sc.lib.mir_last_error()
+    h2 = C.c_void_p()
+    assert sc.lib.mir_create(C.byref(franka_spec), 4, 99, C.byref(h2)) == -4     # MIR_E_NODEVICE: no such device
