@@ -162,8 +162,14 @@ struct Env64 {
     float Jb[MAXC][2][JSEG];
   };
   Con64 con;          // (before the contacts are finished: the box-box clipping workspace, 32 lanes at a time)
+  // the few model tables that are looked up with a DYNAMIC index inside the collision phases, staged once per launch:
+  // an LDS round trip (~64 cycles) instead of an L2 one per dependent hop (there is no room for the whole model)
+  float gts[MIR_MAX_GEOM][4];           // type | body << 8 (as int bits), half extents
+  float gfr[MIR_MAX_GEOM];              // friction
+  unsigned short pairs[MIR_MAX_PAIR];   // g1 | g2 << 8
   float Hb[NL][MSTR];  // Newton Hessian, block-diagonal part: row of lane i holds the 16 columns of its own block
 };
+static_assert(MIR_MAX_GEOM <= 256, "pair entries are 16 bits");
 static_assert(sizeof(Con64) >= 54 * 32 * sizeof(float), "box-box workspace lives in the contact arrays");
 
 struct BodyK64 {
@@ -262,6 +268,17 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   const float d_damping = m->d_damping[lane], d_kp = m->d_kp[lane], d_kv = m->d_kv[lane];
   const float d_frclo = m->d_frclo[lane], d_frchi = m->d_frchi[lane], d_mdiag = m->d_mdiag[lane];
   const int d_qbase = m->b_qadr[d_body], d_lbase = m->b_dofadr[d_body];
+  const float d_lo = m->d_lo[lane], d_hi = m->d_hi[lane];
+  // lane = geom: frame in its body, staged tables
+  const int gl = lane < ngeom ? lane : 0;
+  const int g_bodyl = m->g_body[gl];
+  const V3 g_posl = ld3(m->g_pos[gl]);
+  const Q4 g_quatl = ld4(m->g_quat[gl]);
+  if (lane < ngeom) {
+    stv(S.gts[lane], f4{__int_as_float(m->g_type[lane] | (g_bodyl << 8)), m->g_size[lane][0], m->g_size[lane][1], m->g_size[lane][2]});
+    S.gfr[lane] = m->g_pos[lane][3];
+  }
+  for (int p = lane; p < npair; p += NL) S.pairs[p] = (unsigned short)m->pair[p];
 
   STAMP(0);
   // ---- load state -----------------------------------------------------------------------------
@@ -520,10 +537,9 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     // ======================= collision detection ================================================
     if (lane == 0) { S.ncon = 0; S.ncand = 0; }
     if (lane < ngeom) {
-      const int gb = m->g_body[lane];
-      Q4 qb = ld4v(S.xquat[gb]);
-      st3v(S.col.gpos[lane], ld3v(S.xpos[gb]) + qrot(qb, ld3(m->g_pos[lane])));
-      st4v(S.col.gquat[lane], qmul(qb, ld4(m->g_quat[lane])));
+      Q4 qb = ld4v(S.xquat[g_bodyl]);
+      st3v(S.col.gpos[lane], ld3v(S.xpos[g_bodyl]) + qrot(qb, g_posl));
+      st4v(S.col.gquat[lane], qmul(qb, g_quatl));
     }
     S.col.ccount[lane] = 0;
     WSYNC();
@@ -536,17 +552,17 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         int p = p0 + lane;
         bool hit = false;
         if (p < npair) {
-          const int pr = m->pair[p];
+          const int pr = (int)S.pairs[p];
           const int g1 = pr & 255, g2 = pr >> 8;
-          V3 h2 = ld3(m->g_size[g2]);
+          V3 h2 = ld3(&S.gts[g2][1]);
           M3 R2 = q2m(ld4v(S.col.gquat[g2]));
           V3 c2 = ld3v(S.col.gpos[g2]);
-          if (m->g_type[g1] == MIR_GEOM_PLANE) {
+          if ((__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE) {
             V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
             float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
             hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
           } else {
-            V3 h1 = ld3(m->g_size[g1]);
+            V3 h1 = ld3(&S.gts[g1][1]);
             float rs = sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
             V3 dc = c2 - ld3v(S.col.gpos[g1]);
             hit = dot(dc, dc) <= rs * rs;
@@ -565,14 +581,14 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       for (int k0 = 0; k0 < ncand; k0 += 4) {
         const int k = k0 + blk;
         const bool act = k < ncand;
-        const int pr = act ? m->pair[S.col.cand[k]] : 0;
+        const int pr = act ? (int)S.pairs[S.col.cand[k]] : 0;
         const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isplane = act && m->g_type[g1] == MIR_GEOM_PLANE;
+        const bool isplane = act && (__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE;
         if (!__any(isplane)) continue;
         const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
         const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
         const M3 R2 = q2m(ld4v(S.col.gquat[g2]));
-        const V3 h = ld3(m->g_size[g2]);
+        const V3 h = ld3(&S.gts[g2][1]);
         const int c = lane & 7;
         const V3 w = ld3v(S.col.gpos[g2]) + ((c & 1) ? h.x : -h.x) * mcol(R2, 0) + ((c & 2) ? h.y : -h.y) * mcol(R2, 1) +
                      ((c & 4) ? h.z : -h.z) * mcol(R2, 2);
@@ -606,13 +622,13 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       // the contact arrays, which are not written before the contacts are finished)
       for (int half = 0; half < ncand; half += 32) {
         if (lane >= half && lane < half + 32 && lane < ncand) {
-          const int pr = m->pair[S.col.cand[lane]];
+          const int pr = (int)S.pairs[S.col.cand[lane]];
           const int g1 = pr & 255, g2 = pr >> 8;
-          if (m->g_type[g1] != MIR_GEOM_PLANE) {
+          if ((__float_as_int(S.gts[g1][0]) & 255) != MIR_GEOM_PLANE) {
             M3 R2 = q2m(ld4v(S.col.gquat[g2]));
-            BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(m->g_size[g2])};
+            BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(&S.gts[g2][1])};
             M3 R1 = q2m(ld4v(S.col.gquat[g1]));
-            BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(m->g_size[g1])};
+            BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(&S.gts[g1][1])};
             V3 n = v3(0, 0, 1);
             mycount = box_box(B1, B2, S.col.stage[lane], n, PolyLds{reinterpret_cast<float*>(&S.con) + (lane - half)});
             st3v(S.col.snorm[lane], n);
@@ -645,19 +661,19 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         const int k = lane;
         const int mp = S.col.cmap[k];
         const int cl = mp >> 3, ci = mp & 7;
-        const int pr = m->pair[S.col.cand[cl]];
+        const int pr = (int)S.pairs[S.col.cand[cl]];
         const int g1 = pr & 255, g2 = pr >> 8;
         const V3 n = ld3v(S.col.snorm[cl]);
         V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
         t1 = t1 - dot(n, t1) * n;
         t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
         const V3 t2 = cross(n, t1);
-        const float mu = fmaxf(m->g_pos[g1][3], m->g_pos[g2][3]);
+        const float mu = fmaxf(S.gfr[g1], S.gfr[g2]);
         const float* s1 = m->g_sol[g1];
         const float* s2 = m->g_sol[g2];
         const float sr0 = 0.5f * (s1[0] + s2[0]), sr1 = 0.5f * (s1[1] + s2[1]);
         const float si[5] = {0.5f * (s1[2] + s2[2]), 0.5f * (s1[3] + s2[3]), 0.5f * (s1[4] + s2[4]), 0.5f * (s1[5] + s2[5]), 0.5f * (s1[6] + s2[6])};
-        const int b1 = m->g_body[g1], b2 = m->g_body[g2];
+        const int b1 = __float_as_int(S.gts[g1][0]) >> 8, b2 = __float_as_int(S.gts[g2][0]) >> 8;
         const float wsumw = m->b_invweight0[b1] + m->b_invweight0[b2];
         const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
         const float tc = fmaxf(sr0, 2.0f * dt);
@@ -722,7 +738,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     float lsg = 0.0f, lD = 0.0f, laref = 0.0f;
     if (d_limited) {
       float q = S.qpos[d_qadr];
-      float dlo = q - m->d_lo[lane], dhi = m->d_hi[lane] - q;
+      float dlo = q - d_lo, dhi = d_hi - q;
       float pos = 0.0f;
       if (dlo < 0.0f) { pos = dlo; lsg = 1.0f; }
       else if (dhi < 0.0f) { pos = dhi; lsg = -1.0f; }
