@@ -5,8 +5,8 @@
 // in those loops, i.e. on the callers' side of the hot path.  The algorithm is defined in include/mirigid.h.
 //
 // Mapping: like the pick kernel, 16 lanes per env (4 envs per wave64, one DPP row each); lane j owns element j of the
-// kinematic chain world -> link (<= 16 bodies): its local joint transform, its world pose (each lane composes its own
-// prefix of the chain: no depth-serial barriers), its Jacobian column.  J J^T + lambda^2 I (6 x 6, symmetric: 21 DPP row
+// kinematic chain world -> link (<= 16 bodies): its local joint transform, its world pose (prefix of the chain by a log-step DPP
+// scan: no depth-serial barriers, no LDS round trips), its Jacobian column.  J J^T + lambda^2 I (6 x 6, symmetric: 21 DPP row
 // reductions) ends up in every lane's registers and each lane solves it redundantly (Cholesky, fully unrolled), so the
 // update dq_j = J_j . y needs no further communication.  The chain description travels in the kernel arguments
 // (built on the host per call: the link is a run-time argument).
@@ -45,7 +45,6 @@ struct IkArgs {
 };
 
 struct IkLds {
-  float lpos[G][4], lquat[G][4];
   float xpos[G][4], xquat[G][4];
 };
 
@@ -79,30 +78,41 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
   bool done = false;
   float epn = 0.0f, ern = 0.0f;
   for (int it = 0; it <= a.max_iters; it++) {
-    // ---- local transform of my chain element, then my own prefix of the chain
+    // ---- local transform of my chain element (identity off the chain) ...
+    V3 P = v3(0, 0, 0);
+    Q4 Qx = Q4{1, 0, 0, 0};
     if (onchain) {
-      Q4 ql = bquat;
-      V3 pl = bpos;
+      Qx = bquat;
+      P = bpos;
       if (jt == MIR_JNT_REVOLUTE) {
         float sn, cs;
         sincosf(0.5f * q, &sn, &cs);
-        ql = qmul(bquat, Q4{cs, baxis.x * sn, baxis.y * sn, baxis.z * sn});
+        Qx = qmul(bquat, Q4{cs, baxis.x * sn, baxis.y * sn, baxis.z * sn});
       } else if (jt == MIR_JNT_PRISMATIC) {
-        pl = bpos + qrot(bquat, q * baxis);
+        P = bpos + qrot(bquat, q * baxis);
       }
-      st3v(S.lpos[lane], pl);
-      st4v(S.lquat[lane], ql);
     }
-    WSYNC();
-    if (onchain) {
-      V3 P = ld3v(S.lpos[0]);
-      Q4 Qx = ld4v(S.lquat[0]);
-      for (int i = 1; i <= lane; i++) {
-        P = P + qrot(Qx, ld3v(S.lpos[i]));
-        Qx = qmul(Qx, ld4v(S.lquat[i]));
+    // ... then my own prefix of the chain by a log-step scan over the DPP row (composition (P,Q) o (p,q) = (P + Q p, Q q)
+    // is associative): 4 shifted exchanges instead of a walk of up to 15 links, no LDS round trips
+    {
+#define IK_SCAN_STEP(D)                                                                                          \
+      {                                                                                                          \
+        const V3 pp = v3(row_shr<D>(P.x), row_shr<D>(P.y), row_shr<D>(P.z));                                     \
+        const Q4 pq = Q4{row_shr<D>(Qx.w), row_shr<D>(Qx.x), row_shr<D>(Qx.y), row_shr<D>(Qx.z)};                \
+        if (lane >= D) {                                                                                         \
+          P = pp + qrot(pq, P);                                                                                  \
+          Qx = qmul(pq, Qx);                                                                                     \
+        }                                                                                                        \
       }
-      st3v(S.xpos[lane], P);
-      st4v(S.xquat[lane], Qx);
+      IK_SCAN_STEP(1)
+      IK_SCAN_STEP(2)
+      IK_SCAN_STEP(4)
+      IK_SCAN_STEP(8)
+#undef IK_SCAN_STEP
+      if (onchain) {
+        st3v(S.xpos[lane], P);
+        st4v(S.xquat[lane], Qx);
+      }
     }
     WSYNC();
     // ---- task-space error (every lane, redundantly)
