@@ -145,11 +145,22 @@ def stack_bench(dev, steps: int = 300):
     torch.cuda.synchronize(dev)
     us = ev0.elapsed_time(ev1) * 1e3 / steps
     ncon, _, niter = (x.float().mean().item() for x in task._mir.get_diag())
+    # the same workload in 16-step rollout launches (mir_rollout)
+    rows = torch.zeros((16, B, 9 + 14 + 2), dtype=torch.float32, device=dev)
+    task._mir.rollout(acts[:16], rows)
+    torch.cuda.synchronize(dev)
+    ev0.record()
+    for i in range(8):
+        task._mir.rollout(acts[16 * i:16 * i + 16], rows)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us_ro = ev0.elapsed_time(ev1) * 1e3 / (8 * 16)
     algo = 1109.0
     achieved = algo * B / (us * 1e-6) / 1e9
     del env
     return {"workload": "CubeStack-v0 robot=franka (39 dofs, 5 cubes) state-only obs, home + U(-1,1) joint targets, num_envs=4096",
-            "env_steps_per_s": B / (us * 1e-6), "us_per_step": us, "mean_contacts": ncon, "mean_newton_iterations": niter,
+            "env_steps_per_s": B / (us * 1e-6), "us_per_step": us, "rollout16_env_steps_per_s": B / (us_ro * 1e-6),
+            "mean_contacts": ncon, "mean_newton_iterations": niter,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "mir_step64_kernel",
                          "note": "1109 algorithmic B/env-step; one wave per env, 3 envs per CU: latency/occupancy-bound like the pick kernel"}}
