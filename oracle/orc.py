@@ -75,7 +75,7 @@ class Oracle:
 
     # ---- single-env accessors ------------------------------------------------------------
     def read(self, field: int, e: int = 0) -> np.ndarray:
-        out = np.zeros(4096, dtype=np.float64)
+        out = np.zeros(1 << 15, dtype=np.float64)  # the largest field: J, (4 x 48 + 48) rows x 48 dofs
         n = self.lib.orc_read(self.model, self.d(e), field, out.ctypes.data_as(C.c_void_p))
         if n < 0:
             raise KeyError(field)

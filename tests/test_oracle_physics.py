@@ -346,3 +346,149 @@ def test_scripted_grasp_lifts_cube_and_reward_flips_at_threshold():
     assert flipped.all() and (e[:, 2] > 0.2).all()             # every env picked its cube up
     assert np.abs(a[:, 7] - a[:, 8]).max() < 1e-3               # fingers closed symmetrically on the 4 cm cube
     assert np.abs(a[:, 7] - 0.0185).max() < 2e-3
+
+
+def test_constraint_solve_reaches_the_optimum_of_the_convex_problem():
+    """Independent check of the oracle's constraint solve: the constrained acceleration must minimise
+    1/2 (a - a0)^T Mt (a - a0) + sum_r 1/2 D_r min(0, J_r a - aref_r)^2 -- verified with SciPy on the exported M~, J, aref, D
+    in a contact-rich state of the stack scene (cubes resting, a cube pressed into the finger, joints pushed into limits)."""
+    from scipy.optimize import minimize
+
+    b = models.franka_cube_stack_scene()
+    spec = b.build()
+    o = orc.Oracle(spec, 1)
+    z = models.STACK_CUBE_Z
+    pos = [[(-0.3, -0.2, z), (-0.1, 0.2, z), (0.1, -0.2, z), (0.2, 0.2, z), (0.3, 0.0, z)]]
+    home = np.array([models.FRANKA_HOME])
+    o.reset(np.array(pos), np.tile([0, 0, 0, 1.0], (1, 5, 1)), home)
+    for _ in range(30):
+        o.step()
+    names = [x["name"] for x in b.bodies]
+    hand = names.index("hand")
+    q = o.read(orc.F_QPOS)
+    q[3] = -0.05                                                            # joint4 past its upper limit (-0.0698)
+    o.write(orc.F_QPOS, q)
+    o.fk()
+    q[9:12] = o.read(orc.F_XPOS).reshape(-1, 3)[hand] + [0.0, 0.0, 0.012]  # cube_1 overlapping the hand box
+    o.write(orc.F_QPOS, q)
+    v = o.read(orc.F_QVEL)
+    v[:9] = np.random.default_rng(0).uniform(-1, 1, 9)
+    o.write(orc.F_QVEL, v)
+    o.forward()
+    ncon, nefc, niter = o.counts()
+    assert ncon > 16 and nefc > 4 * ncon  # 16 resting contacts + arm-cube contacts + at least one limit row
+    nv = o.nv
+    Mt = o.read(orc.F_MT).reshape(-1, nv)[:nv]
+    J = o.read(orc.F_J).reshape(-1, nv)[:nefc]
+    aref, D = o.read(orc.F_AREF)[:nefc], o.read(orc.F_EFCD)[:nefc]
+    a0, a_orc = o.read(orc.F_QACC_SMOOTH), o.read(orc.F_QACC)
+
+    def cost(a):
+        r = np.minimum(0.0, J @ a - aref)
+        d = a - a0
+        return 0.5 * d @ Mt @ d + 0.5 * np.sum(D * r * r)
+
+    def grad(a):
+        r = np.minimum(0.0, J @ a - aref)
+        return Mt @ (a - a0) + J.T @ (D * r)
+
+    sol = minimize(cost, a0, jac=grad, method="BFGS", options=dict(gtol=1e-9, maxiter=5000))
+    scale = max(1.0, np.abs(a_orc).max())
+    assert cost(a_orc) <= cost(sol.x) * (1 + 1e-9) + 1e-12          # the oracle's point is at least as good as SciPy's
+    assert np.linalg.norm(grad(a_orc)) < 1e-6 * max(1.0, np.linalg.norm(Mt @ a0))  # stationarity (the problem is strictly convex)
+    assert np.abs(sol.x - a_orc).max() < 1e-4 * scale
+
+
+def test_contact_jacobian_matches_finite_differences_of_the_kinematics():
+    """Rows of the constraint Jacobian (pyramidal contact rows n +- mu t) against finite differences of the world position of
+    the contact point carried by each of the two bodies, dof by dof (scalar joints, free translations, free rotations in
+    world axes): pins frames, signs and the chain rule of the contact rows independently of the Jacobian code."""
+    b = models.franka_cube_stack_scene()
+    spec = b.build()
+    o = orc.Oracle(spec, 1)
+    z = models.STACK_CUBE_Z
+    pos = [[(-0.3, -0.2, z), (-0.1, 0.2, z), (0.1, -0.2, z), (0.2, 0.2, z), (0.3, 0.0, z)]]
+    o.reset(np.array(pos), np.tile([0, 0, 0, 1.0], (1, 5, 1)), np.array([models.FRANKA_HOME]))
+    for _ in range(20):
+        o.step()
+    names = [x["name"] for x in b.bodies]
+    q0 = o.read(orc.F_QPOS)
+    q0[9:12] = o.read(orc.F_XPOS).reshape(-1, 3)[names.index("left_finger")] + [0.0, 0.0, -0.012]
+    tilt = np.array([np.cos(0.15), np.sin(0.15) * 0.6, np.sin(0.15) * 0.8, 0.0])
+    q0[12:16] = tilt / np.linalg.norm(tilt)
+    o.write(orc.F_QPOS, q0)
+    o.forward()
+    ncon, nefc, _ = o.counts()
+    nv = o.nv
+    J = o.read(orc.F_J).reshape(-1, nv)[:nefc]
+    cpos = o.read(orc.F_CPOS).reshape(-1, 3)[:ncon]
+    cfrm = o.read(orc.F_CFRAME).reshape(-1, 3, 3)[:ncon]
+    xpos0, xquat0 = o.read(orc.F_XPOS).reshape(-1, 3), o.read(orc.F_XQUAT).reshape(-1, 4)
+
+    def rot(qw):
+        w, x, y, zz = np.asarray(qw) / np.linalg.norm(qw)  # (model quaternions are float32-rounded: unit only to 1e-8)
+        return np.array([[1 - 2 * (y * y + zz * zz), 2 * (x * y - w * zz), 2 * (x * zz + w * y)],
+                         [2 * (x * y + w * zz), 1 - 2 * (x * x + zz * zz), 2 * (y * zz - w * x)],
+                         [2 * (x * zz - w * y), 2 * (y * zz + w * x), 1 - 2 * (x * x + y * y)]])
+
+    def qmul(a, c):
+        return np.array([a[0] * c[0] - a[1:] @ c[1:], *(a[0] * c[1:] + c[0] * a[1:] + np.cross(a[1:], c[1:]))])
+
+    # which two bodies each contact joins: recover them as the bodies whose surface the point lies on is not needed -- the
+    # finite-difference relative motion is computed for EVERY ordered body pair and the pair that reproduces the row is found
+    eps = 1e-6
+    nb = spec.nbody
+    dP = np.zeros((nv, nb, ncon, 3))  # d(world position of contact c as carried by body b) / d(dof i)
+    qadr_free = {}
+    nq_scalar = 9
+    for k in range(5):
+        qadr_free[k] = (9 + 7 * k, 9 + 6 * k)
+    for i in range(nv):
+        q = q0.copy()
+        if i < nq_scalar:
+            q[i] += eps
+        else:
+            k, r = divmod(i - 9, 6)
+            qa = 9 + 7 * k
+            if r < 3:
+                q[qa + r] += eps
+            else:
+                ax = np.zeros(3)
+                ax[r - 3] = 1.0
+                dq = np.array([np.cos(eps / 2), *(np.sin(eps / 2) * ax)])
+                q[qa + 3:qa + 7] = qmul(dq, q[qa + 3:qa + 7])  # world-frame angular velocity (DESIGN.md 2.6)
+        o.write(orc.F_QPOS, q)
+        o.fk()
+        xp, xq = o.read(orc.F_XPOS).reshape(-1, 3), o.read(orc.F_XQUAT).reshape(-1, 4)
+        for bb in range(nb):
+            R0, R1 = rot(xquat0[bb]), rot(xq[bb])
+            local = (cpos - xpos0[bb]) @ R0          # (ncon,3): R0^T (p - x0)
+            dP[i, bb] = (xp[bb] + local @ R1.T - cpos) / eps
+    o.write(orc.F_QPOS, q0)
+    o.fk()
+    mu = 1.0
+    checked = 0
+    # locate the 4-row block of every contact by matching: each contact must have four rows r with
+    # J[r] = d/dq [(p_b2 - p_b1) . (n +- mu t)] for some body pair (b1, b2)
+    dirs = lambda c: [cfrm[c][0] + mu * cfrm[c][1], cfrm[c][0] - mu * cfrm[c][1], cfrm[c][0] + mu * cfrm[c][2], cfrm[c][0] - mu * cfrm[c][2]]  # noqa: E731
+    for c in range(ncon):
+        found = False
+        for b1 in range(nb):
+            for b2 in range(nb):
+                if b1 == b2:
+                    continue
+                rel = dP[:, b2, c, :] - dP[:, b1, c, :]            # (nv,3)
+                want = np.stack([rel @ d for d in dirs(c)])        # (4,nv)
+                if np.abs(want).max() < 1e-9:
+                    continue
+                for r0 in range(0, nefc - 3):
+                    if np.abs(J[r0:r0 + 4] - want).max() < 2e-4 * max(1.0, np.abs(want).max()):
+                        found = True
+                        break
+                if found:
+                    break
+            if found:
+                break
+        assert found, f"no four Jacobian rows reproduce the finite-difference relative motion at contact {c}"
+        checked += 1
+    assert checked == ncon and ncon > 16
