@@ -492,3 +492,69 @@ def test_contact_jacobian_matches_finite_differences_of_the_kinematics():
         assert found, f"no four Jacobian rows reproduce the finite-difference relative motion at contact {c}"
         checked += 1
     assert checked == ncon and ncon > 16
+
+
+def test_box_box_narrowphase_against_a_numpy_separating_axis_test():
+    """Random pairs of overlapping / separated cubes (the stack scene's cube_1 and cube_2 floating in the air): contacts are
+    reported iff a NumPy 15-axis separating-axis test finds no separating axis; the reported normal is the axis of least
+    penetration (up to the routine's edge-axis bias), pointing from the first box to the second; the deepest point's
+    distance equals minus that overlap; every contact point lies inside both boxes inflated by the penetration."""
+    b = models.franka_cube_stack_scene()
+    spec = b.build()
+    o = orc.Oracle(spec, 1)
+    rng = np.random.default_rng(5)
+    h = 0.02
+
+    def rot(q):
+        w, x, y, z = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+    def sat(pa, Ra, pb, Rb):
+        t = pb - pa
+        axes = [Ra[:, i] for i in range(3)] + [Rb[:, j] for j in range(3)]
+        for i in range(3):
+            for j in range(3):
+                c = np.cross(Ra[:, i], Rb[:, j])
+                if np.linalg.norm(c) > 1e-3:
+                    axes.append(c / np.linalg.norm(c))
+        best = -np.inf
+        for L in axes:
+            ra = h * np.abs(Ra.T @ L).sum()
+            rb = h * np.abs(Rb.T @ L).sum()
+            best = max(best, abs(t @ L) - (ra + rb))
+        return best  # > 0: separated by that much; < 0: minus the least overlap
+
+    hits = misses = 0
+    far = [(0.5, 0.3, 2.0), (0.5, -0.3, 2.0), (-0.6, 0.3, 2.0)]
+    for trial in range(60):
+        qa, qb = rng.normal(size=4), rng.normal(size=4)
+        qa, qb = qa / np.linalg.norm(qa), qb / np.linalg.norm(qb)
+        pa = np.array([0.3, 0.0, 1.5])
+        pb = pa + rng.normal(size=3) * 0.025
+        q = o.read(orc.F_QPOS)
+        q[9:12], q[12:16], q[16:19], q[19:23] = pa, qa, pb, qb
+        for k, f in enumerate(far):
+            q[23 + 7 * k:26 + 7 * k] = f
+        o.write(orc.F_QPOS, q)
+        o.forward()
+        ncon = o.counts()[0]
+        s = sat(pa, rot(qa), pb, rot(qb))
+        if s > 1e-9:
+            assert ncon == 0, (trial, s)
+            misses += 1
+            continue
+        if s > -1e-6:
+            continue  # grazing: either answer is fine
+        hits += 1
+        assert ncon >= 1, (trial, s)
+        cpos = o.read(orc.F_CPOS).reshape(-1, 3)[:ncon]
+        dist = o.read(orc.F_CDIST)[:ncon]
+        n = o.read(orc.F_CFRAME).reshape(-1, 3, 3)[0, 0]
+        assert n @ (pb - pa) > -1e-9                                  # from cube_1 towards cube_2
+        assert dist.min() >= s * 1.06 - 1e-6 and dist.min() <= s * 0.94 + 1e-6 or abs(dist.min() - s) < 2e-3 * h, (trial, dist.min(), s)
+        for p in cpos:                                                # inside both boxes (inflated by the overlap)
+            for pc, R in ((pa, rot(qa)), (pb, rot(qb))):
+                assert (np.abs(R.T @ (p - pc)) <= h - s + 1e-6).all(), trial
+    assert hits >= 15 and misses >= 10
