@@ -293,6 +293,26 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const float ez = fmaf(ysr[r], ru.z, rf.z), eu = fmaf(ysr[r], q5.z, q5.x), ev = fmaf(ysr[r], q6.z, q6.x);
+            if (rr.z == 0.0f) {
+              // the camera's right vector lies in the plane (no roll over a horizontal floor: every camera of the
+              // reference): the ray's normal component, hence 1/d'z and the depth, are constant along an image row --
+              // one reciprocal per lane instead of one per pixel (x * 0 + ez == ez: bit-identical to the general path)
+              const float iz1 = __builtin_amdgcn_rcpf(ez);
+              const float t1 = iz1 * (-ro.z);
+              const bool vld = t1 > 1e-6f;
+#pragma unroll
+              for (int h = 0; h < 2; h++) {
+                const f2 u = (xs[h] * q5.y + eu) * iz1, v = (xs[h] * q6.y + ev) * iz1;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                  const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
+                  const bool upd = vld && t1 < best[r][h][q];
+                  best[r][h][q] = upd ? t1 : best[r][h][q];
+                  col[r][2 * h + q] = upd ? (odd ? codd : ceven) : col[r][2 * h + q];
+                }
+              }
+              continue;
+            }
 #pragma unroll
             for (int h = 0; h < 2; h++) {
               const f2 iz = rcp2(xs[h] * rr.z + ez);
