@@ -325,6 +325,16 @@ def main():
         env.step(actions[t % n_act])
     torch.cuda.synchronize(dev)
     api_rate = api_steps * B * world / (time.perf_counter() - t1) if api_steps else None
+    # the README loop's variant: actions sampled on the HOST (README.md:34): + one 147 KB H->D copy per step
+    np_rate = None
+    if api_steps:
+        acts_np = np.random.default_rng(5).uniform(-1, 1, (8, B, 9)).astype(np.float32)
+        torch.cuda.synchronize(dev)
+        t1b = time.perf_counter()
+        for t in range(api_steps):
+            env.step(acts_np[t % 8])
+        torch.cuda.synchronize(dev)
+        np_rate = api_steps * B * world / (time.perf_counter() - t1b)
 
     # device-resident episode loop: fused step + on-device truncation/termination/re-spawn, no host sync
     if api_steps:
@@ -394,6 +404,7 @@ def main():
                          "traffic": traffic, "kernel": "mir_step_kernel", "kernel_us": launch_us,
                          "note": "489 algorithmic B/env-step x 4096 envs per launch; the path is latency/occupancy-bound, not HBM-bound (SURVEY.md 8d)"},
             "env_step_api_rate": api_rate,
+            "env_step_api_numpy_actions_rate": np_rate,
             "device_autoreset_loop_rate": loop_rate,
             "device_rollout16_rate": rollout_rate,
             "device_autoreset_rollout16_rate": loop_rollout_rate,
