@@ -119,15 +119,12 @@ struct GJ {
     const float pk = row_bcast<K>(a[K]);
     float inv = __builtin_amdgcn_rcpf(pk);
     inv = inv * (2.0f - pk * inv);  // one Newton step: full float accuracy
-    const bool isk = lane == K;
-    const float f = a[K] * inv;
+    // one fma per column for every row: with f = 1 - 1/p on the pivot row (whose broadcast entry is its own) and
+    // a_iK / p elsewhere, a[j] - f * pivotrow[j] scales the pivot row and eliminates the others
+    const float f = lane == K ? 1.0f - inv : a[K] * inv;
 #pragma unroll
-    for (int j = K + 1; j < G - 1; j++) {
-      const float rj = row_bcast<K>(a[j]);
-      a[j] = isk ? a[j] * inv : fmaf(-f, rj, a[j]);
-    }
-    const float rb = row_bcast<K>(b);
-    b = isk ? b * inv : fmaf(-f, rb, b);
+    for (int j = K + 1; j < G - 1; j++) a[j] = fmaf(-f, row_bcast<K>(a[j]), a[j]);
+    b = fmaf(-f, row_bcast<K>(b), b);
     GJ<K + 1>::run(a, b, lane);
   }
 };
