@@ -92,40 +92,46 @@ struct BodyK {
   Q4 quat;
 };
 
-// forward kinematics of one env group: local joint transforms, then every body composes its own
-// ancestor chain (leaf -> root) independently; two phases, no depth-serial barriers.  `parents`
-// packs the 16 parent indices, 4 bits each.
+// forward kinematics of one env group: local joint transforms, then POINTER JUMPING over the parent links -- in every
+// round a body composes the (partially composed) transform of its current ancestor pointer and inherits that body's
+// pointer, so after r rounds it holds the product over 2^r ancestors: 4 rounds for any tree of up to 16 bodies instead of
+// a dependent walk as long as the chain (10 links for a Panda finger).  `parents` packs the 16 parent indices, 4 bits each;
+// the pointer travels in the w slot of the position.
 __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t parents, const BodyK& k) {
+  V3 P = v3(0, 0, 0);
+  Q4 Qx = Q4{1, 0, 0, 0};
+  int anc = 0;
   if (lane > 0 && lane < nb) {
-    Q4 ql = k.quat;
-    V3 pl = k.pos;
+    Qx = k.quat;
+    P = k.pos;
     if (k.jtype == MIR_JNT_REVOLUTE) {
       float ang = S.qpos[k.qadr], sn, cs;
       sincosf(0.5f * ang, &sn, &cs);
-      ql = qmul(k.quat, Q4{cs, k.axis.x * sn, k.axis.y * sn, k.axis.z * sn});
+      Qx = qmul(k.quat, Q4{cs, k.axis.x * sn, k.axis.y * sn, k.axis.z * sn});
     } else if (k.jtype == MIR_JNT_PRISMATIC) {
-      pl = k.pos + qrot(k.quat, S.qpos[k.qadr] * k.axis);
+      P = k.pos + qrot(k.quat, S.qpos[k.qadr] * k.axis);
     } else if (k.jtype == MIR_JNT_FREE) {
-      pl = ld3(&S.qpos[k.qadr]);
-      ql = qnormalize(ld4(&S.qpos[k.qadr + 3]));
+      P = ld3(&S.qpos[k.qadr]);
+      Qx = qnormalize(ld4(&S.qpos[k.qadr + 3]));
     }
-    st3v(S.dyn.lpos[lane], pl);
-    st4v(S.dyn.lquat[lane], ql);
-  } else if (lane == 0) {
-    st3v(S.dyn.lpos[0], v3(0, 0, 0));
-    st4v(S.dyn.lquat[0], Q4{1, 0, 0, 0});
+    anc = (int)((parents >> (4 * lane)) & 15u);
   }
-  WSYNC();
-  if (lane < nb) {
-    V3 P = ld3v(S.dyn.lpos[lane]);
-    Q4 Qx = ld4v(S.dyn.lquat[lane]);
-    int anc = lane > 0 ? (int)((parents >> (4 * lane)) & 15u) : 0;
-    while (anc > 0) {
-      Q4 qa = ld4v(S.dyn.lquat[anc]);
-      P = ld3v(S.dyn.lpos[anc]) + qrot(qa, P);
+#pragma unroll 1
+  for (int round = 0; round < 4; round++) {
+    if (!__any(anc > 0)) break;
+    stv(S.dyn.lpos[lane], f4{P.x, P.y, P.z, __int_as_float(anc)});
+    st4v(S.dyn.lquat[lane], Qx);
+    WSYNC();
+    if (anc > 0) {
+      const f4 pa = ldv(S.dyn.lpos[anc]);
+      const Q4 qa = ld4v(S.dyn.lquat[anc]);
+      P = v3(pa.x, pa.y, pa.z) + qrot(qa, P);
       Qx = qmul(qa, Qx);
-      anc = (int)((parents >> (4 * anc)) & 15u);
+      anc = __float_as_int(pa.w);
     }
+    WSYNC();
+  }
+  if (lane < nb) {
     st3v(S.xpos[lane], P);
     st4v(S.xquat[lane], Qx);
   }
@@ -141,9 +147,16 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   STAMP(24);
   if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[26] = __builtin_amdgcn_s_memrealtime();
   {
+    // all table loads are issued before the first LDS store (one L2 round trip for the whole copy, not one per pass)
     const f4* src = reinterpret_cast<const f4*>(&m->tab);
     f4* dst = reinterpret_cast<f4*>(&T);
-    for (int i = tid; i < (int)(sizeof(ModelTab) / 16); i += 64) dst[i] = src[i];
+    constexpr int NQ = (int)(sizeof(ModelTab) / 16), NPASS = (NQ + 63) / 64;
+    f4 tmp[NPASS];
+#pragma unroll
+    for (int k = 0; k < NPASS; k++) tmp[k] = src[min(tid + 64 * k, NQ - 1)];
+#pragma unroll
+    for (int k = 0; k < NPASS; k++)
+      if (tid + 64 * k < NQ) dst[tid + 64 * k] = tmp[k];
   }
   const int lane = tid & (G - 1);
   const int grp = tid >> 4;
@@ -198,11 +211,14 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   // that produced its observations); reuse them unless reset / set_state invalidated this env.
   STAMP(0);
   {
+    // the cached poses are fetched together with their validity flag (no dependent second round trip); poses is a
+    // (B, 2, 16, 4) array, so the speculative read is always in bounds
+    const float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
+    const f4 cpos = *reinterpret_cast<const f4*>(p), cquat = *reinterpret_cast<const f4*>(p + 4 * G);
     const bool cached = a.fkvalid[env] != 0;
     if (cached && lane < nb) {
-      const float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
-      stv(S.xpos[lane], *reinterpret_cast<const f4*>(p));
-      stv(S.xquat[lane], *reinterpret_cast<const f4*>(p + 4 * G));
+      stv(S.xpos[lane], cpos);
+      stv(S.xquat[lane], cquat);
     }
     WSYNC();
     if (__any(!cached)) group_fk(S, lane, nb, parents, bk);  // recomputing a cached env is bit-identical

@@ -178,37 +178,45 @@ struct BodyK64 {
   Q4 quat;
 };
 
+// forward kinematics by pointer jumping over the parent links (see group_fk in mir_step.hip): 5 rounds cover any tree
+// of up to 32 bodies; the pointer travels in the w slot of the position
 __device__ __forceinline__ void wave_fk(Env64& S, int lane, int nb, const BodyK64& k) {
+  V3 P = v3(0, 0, 0);
+  Q4 Qx = Q4{1, 0, 0, 0};
+  int anc = 0;
   if (lane > 0 && lane < nb) {
-    Q4 ql = k.quat;
-    V3 pl = k.pos;
+    Qx = k.quat;
+    P = k.pos;
     if (k.jtype == MIR_JNT_REVOLUTE) {
       float ang = S.qpos[k.qadr], sn, cs;
       sincosf(0.5f * ang, &sn, &cs);
-      ql = qmul(k.quat, Q4{cs, k.axis.x * sn, k.axis.y * sn, k.axis.z * sn});
+      Qx = qmul(k.quat, Q4{cs, k.axis.x * sn, k.axis.y * sn, k.axis.z * sn});
     } else if (k.jtype == MIR_JNT_PRISMATIC) {
-      pl = k.pos + qrot(k.quat, S.qpos[k.qadr] * k.axis);
+      P = k.pos + qrot(k.quat, S.qpos[k.qadr] * k.axis);
     } else if (k.jtype == MIR_JNT_FREE) {
-      pl = ld3(&S.qpos[k.qadr]);
-      ql = qnormalize(ld4(&S.qpos[k.qadr + 3]));
+      P = ld3(&S.qpos[k.qadr]);
+      Qx = qnormalize(ld4(&S.qpos[k.qadr + 3]));
     }
-    st3v(S.dm.dyn.lpos[lane], pl);
-    st4v(S.dm.dyn.lquat[lane], ql);
-  } else if (lane == 0) {
-    st3v(S.dm.dyn.lpos[0], v3(0, 0, 0));
-    st4v(S.dm.dyn.lquat[0], Q4{1, 0, 0, 0});
+    anc = S.parent[lane];
   }
-  WSYNC();
-  if (lane < nb) {
-    V3 P = ld3v(S.dm.dyn.lpos[lane]);
-    Q4 Qx = ld4v(S.dm.dyn.lquat[lane]);
-    int anc = lane > 0 ? S.parent[lane] : 0;
-    while (anc > 0) {
-      Q4 qa = ld4v(S.dm.dyn.lquat[anc]);
-      P = ld3v(S.dm.dyn.lpos[anc]) + qrot(qa, P);
-      Qx = qmul(qa, Qx);
-      anc = S.parent[anc];
+#pragma unroll 1
+  for (int round = 0; round < 5; round++) {
+    if (!__any(anc > 0)) break;
+    if (lane < NB) {
+      stv(S.dm.dyn.lpos[lane], f4{P.x, P.y, P.z, __int_as_float(anc)});
+      st4v(S.dm.dyn.lquat[lane], Qx);
     }
+    WSYNC();
+    if (anc > 0) {
+      const f4 pa = ldv(S.dm.dyn.lpos[anc]);
+      const Q4 qa = ld4v(S.dm.dyn.lquat[anc]);
+      P = v3(pa.x, pa.y, pa.z) + qrot(qa, P);
+      Qx = qmul(qa, Qx);
+      anc = __float_as_int(pa.w);
+    }
+    WSYNC();
+  }
+  if (lane < nb) {
     st3v(S.xpos[lane], P);
     st4v(S.xquat[lane], Qx);
   }
