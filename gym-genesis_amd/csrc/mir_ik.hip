@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
       }
     // ---- y = A^-1 e (Cholesky, SPD by the damping)
     const float e[6] = {ep.x, ep.y, ep.z, er.x, er.y, er.z};
-    float L[6][6], y[6];
+    float L[6][6], y[6], il[6];  // il = 1 / L[c][c]: one reciprocal (+ a Newton step) per column instead of a division per use
 #pragma unroll
     for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -161,21 +161,29 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
         float sacc = A[r][c];
 #pragma unroll
         for (int k = 0; k < c; k++) sacc -= L[r][k] * L[c][k];
-        L[r][c] = r == c ? sqrtf(fmaxf(sacc, 1e-30f)) : sacc / L[c][c];
+        if (r == c) {
+          const float dd = sqrtf(fmaxf(sacc, 1e-30f));
+          float ir = __builtin_amdgcn_rcpf(dd);
+          ir = ir * (2.0f - dd * ir);
+          L[r][c] = dd;
+          il[r] = ir;
+        } else {
+          L[r][c] = sacc * il[c];
+        }
       }
 #pragma unroll
     for (int r = 0; r < 6; r++) {
       float sacc = e[r];
 #pragma unroll
       for (int k = 0; k < r; k++) sacc -= L[r][k] * y[k];
-      y[r] = sacc / L[r][r];
+      y[r] = sacc * il[r];
     }
 #pragma unroll
     for (int r = 5; r >= 0; r--) {
       float sacc = y[r];
 #pragma unroll
       for (int k = r + 1; k < 6; k++) sacc -= L[k][r] * y[k];
-      y[r] = sacc / L[r][r];
+      y[r] = sacc * il[r];
     }
     float dq = 0.0f;
 #pragma unroll
