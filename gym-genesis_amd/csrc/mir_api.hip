@@ -191,7 +191,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     memset(&a, 0, sizeof a);
     a.model = h->dm64;
     a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
-    a.poses = h->poses; a.fkvalid = h->fkvalid; a.hscratch = h->hscratch;
+    a.poses = h->poses; a.fkvalid = h->fkvalid;
     a.diag = o.diag ? h->diag : nullptr;
     a.B = h->B;
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
@@ -316,7 +316,6 @@ int mir_create(const MirSceneSpec* spec, int32_t num_envs, int32_t device_id, Mi
     mir_destroy(h);
     return hip_fail(e, "hipMalloc");
   }
-  if (h->kernel == 64) HIPCHK(hipMalloc((void**)&h->hscratch, B * W64 * 68 * sizeof(float)));
   HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(DevModel), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->dm64, &h->hm64, sizeof(DevModel64), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->dpt, &h->pt, sizeof(PlumbTab), hipMemcpyHostToDevice));
@@ -352,7 +351,6 @@ int mir_destroy(MirHandle h) {
   if (h->poses) (void)hipFree(h->poses);
   if (h->fkvalid) (void)hipFree(h->fkvalid);
   if (h->prims) (void)hipFree(h->prims);
-  if (h->hscratch) (void)hipFree(h->hscratch);
   delete h;
   return MIR_OK;
 }

@@ -20,7 +20,6 @@ struct MirScene {
   GeomTab* dgeom;
   float *qpos, *qvel, *target, *qacc_ws, *poses;
   int32_t *diag, *fkvalid;
-  float* hscratch;  // wave kernel: (B, 64, 68) dense Hessian scratch rows
   float* prims;     // render primitives (B, ngeom, 32) f32, allocated by the first mir_render
 };
 

@@ -13,7 +13,6 @@ struct StepArgs64 {
   float* qacc_ws;  // (B, 64) indexed by lane
   float* poses;    // (B, 2, 32, 4): link positions then quaternions of the current qpos (FK cache)
   int32_t* fkvalid;  // (B)
-  float* hscratch; // (B, 64, 68) dense Newton Hessian rows, touched only in steps where a contact couples two dof blocks
   const float* action;  // (B, nu) or null
   float* agent_pos;     // (B, agent_dim) or null
   float* env_state;     // (B, env_dim) or null

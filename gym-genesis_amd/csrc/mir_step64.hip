@@ -35,7 +35,6 @@
 #define MAXC MIR_MAX_CONTACT
 #define JSEG 52 /* floats per contact segment: 3 rows x 16 + 4 pad */
 #define MSTR 20 /* row stride of the block-diagonal M rows in LDS */
-#define HSTR 68 /* row stride of the dense Hessian (HBM scratch rows, used only when a contact couples two blocks) */
 #define STAMP(k) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
 static_assert(MAXC <= NL, "lane c owns contact c");
 static_assert(MIR_MAX_GEOM <= NL && MIR_MAX_PAIR <= 4 * NL, "lane ownership of geoms / pairs");
@@ -64,31 +63,14 @@ __device__ __forceinline__ float wmaxf(float v) {
 __device__ __forceinline__ float rlv(float v, int src) {  // src wave-uniform (SGPR lane select)
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
+typedef float v16f __attribute__((ext_vector_type(16)));
 template <int BLK>
-__device__ __forceinline__ void gj_block(float (&a)[NL], float& b, int lane, uint64_t act, unsigned comp) {
+__device__ __forceinline__ void gj_block(v16f (&a)[4], float& b, int lane, uint64_t act, unsigned comp) {
 #pragma nounroll
   for (int kk = 0; kk < 16; kk++) {
     const int K = __builtin_amdgcn_readfirstlane(16 * BLK + kk);
     if (!((act >> K) & 1ull)) continue;
-    float aK;
-    switch (kk) {  // wave-uniform
-      case 0: aK = a[16 * BLK + 0]; break;
-      case 1: aK = a[16 * BLK + 1]; break;
-      case 2: aK = a[16 * BLK + 2]; break;
-      case 3: aK = a[16 * BLK + 3]; break;
-      case 4: aK = a[16 * BLK + 4]; break;
-      case 5: aK = a[16 * BLK + 5]; break;
-      case 6: aK = a[16 * BLK + 6]; break;
-      case 7: aK = a[16 * BLK + 7]; break;
-      case 8: aK = a[16 * BLK + 8]; break;
-      case 9: aK = a[16 * BLK + 9]; break;
-      case 10: aK = a[16 * BLK + 10]; break;
-      case 11: aK = a[16 * BLK + 11]; break;
-      case 12: aK = a[16 * BLK + 12]; break;
-      case 13: aK = a[16 * BLK + 13]; break;
-      case 14: aK = a[16 * BLK + 14]; break;
-      default: aK = a[16 * BLK + 15]; break;
-    }
+    const float aK = a[BLK][__builtin_amdgcn_readfirstlane(kk)];  // column K of every row: wave-uniform register index (VGPR index mode)
     const float pk = rlv(aK, K);
     float inv = __builtin_amdgcn_rcpf(pk);
     inv = inv * (2.0f - pk * inv);
@@ -99,19 +81,19 @@ __device__ __forceinline__ void gj_block(float (&a)[NL], float& b, int lane, uin
     for (int bj = BLK; bj < 4; bj++) {
       if (!((comp >> (4 * BLK + bj)) & 1u)) continue;
 #pragma unroll
-      for (int j0 = 16 * bj; j0 < 16 * bj + 16; j0 += 8) {
+      for (int j0 = 0; j0 < 16; j0 += 8) {
         float r[8];
 #pragma unroll
-        for (int t = 0; t < 8; t++) r[t] = rlv(a[j0 + t], K);
+        for (int t = 0; t < 8; t++) r[t] = rlv(a[bj][j0 + t], K);
 #pragma unroll
-        for (int t = 0; t < 8; t++) a[j0 + t] = fmaf(-f, r[t], a[j0 + t]);
+        for (int t = 0; t < 8; t++) a[bj][j0 + t] = fmaf(-f, r[t], a[bj][j0 + t]);
       }
     }
     b = fmaf(-f, rlv(b, K), b);
   }
 }
 // comp: bit 4 b + b' set when blocks b and b' are in one connected component of the contact coupling graph
-__device__ __forceinline__ void gj_wave(float (&a)[NL], float& b, int lane, uint64_t act, unsigned comp) {
+__device__ __forceinline__ void gj_wave(v16f (&a)[4], float& b, int lane, uint64_t act, unsigned comp) {
   gj_block<0>(a, b, lane, act, comp);
   gj_block<1>(a, b, lane, act, comp);
   gj_block<2>(a, b, lane, act, comp);
@@ -167,7 +149,6 @@ struct Env64 {
   float gts[MIR_MAX_GEOM][4];           // type | body << 8 (as int bits), half extents
   float gfr[MIR_MAX_GEOM];              // friction
   unsigned short pairs[MIR_MAX_PAIR];   // g1 | g2 << 8
-  float Hb[NL][MSTR];  // Newton Hessian, block-diagonal part: row of lane i holds the 16 columns of its own block
 };
 static_assert(MIR_MAX_GEOM <= 256, "pair entries are 16 bits");
 static_assert(sizeof(Con64) >= 54 * 32 * sizeof(float), "box-box workspace lives in the contact arrays");
@@ -843,29 +824,19 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
           for (int q = 0; q < 4; q++)
             if ((comp >> (4 * p + q)) & 1u) comp |= ((comp >> (4 * q)) & 15u) << (4 * p);
     }
-    // Newton Hessian H = Mt + J^T D_active J, kept across iterations and updated incrementally (only rows whose active
-    // flag flipped contribute, as in the 16-lane kernel).  When no contact couples two blocks this step (comp = identity:
-    // the arm is not touching a cube, no two cubes of different blocks touch) H is block-diagonal like M: 16-wide rows in
-    // LDS, solved by the DPP block solver.  Otherwise the dense 64-wide rows live in an HBM scratch row per lane
-    // (lane-private, L2-resident): that keeps the LDS footprint at 4 envs per CU for everybody.
+    // Newton Hessian H = Mt + J^T D_active J, kept in REGISTERS across iterations and updated incrementally (only rows
+    // whose active flag flipped contribute, as in the 16-lane kernel): lane = dof row; hd = the 16 columns of the row's own
+    // block (M is block-diagonal), ho[b] = the columns of block b, non-zero only when a contact couples two blocks this
+    // step (comp != identity: the arm touches a cube, or two cubes of different blocks touch).  The wave runs alone on its
+    // SIMD (LDS bounds the occupancy), so the 80 registers are free and every update is FMA work without memory round trips.
     const bool coupled = comp != 0x8421u;
-    float* const hg = a.hscratch + ((size_t)env * NL + lane) * HSTR;
-    if (coupled) {
+    float hd[G], ho[4][G];
 #pragma unroll
-      for (int q = 0; q < 16; q++) *reinterpret_cast<f4*>(hg + 4 * q) = f4{0, 0, 0, 0};
-      if (isdof) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) *reinterpret_cast<f4*>(hg + 16 * blk + 4 * q) = f4{mrow[4 * q], mrow[4 * q + 1], mrow[4 * q + 2], mrow[4 * q + 3]};
-      } else {
-        hg[lane] = 1.0f;
-      }
-    } else {
-      float* hb = &S.Hb[lane][0];
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        stv(hb + 4 * q, isdof ? f4{mrow[4 * q], mrow[4 * q + 1], mrow[4 * q + 2], mrow[4 * q + 3]}
-                              : f4{4 * q == l16 ? 1.0f : 0.0f, 4 * q + 1 == l16 ? 1.0f : 0.0f, 4 * q + 2 == l16 ? 1.0f : 0.0f, 4 * q + 3 == l16 ? 1.0f : 0.0f});
+    for (int j = 0; j < G; j++) {
+      hd[j] = isdof ? mrow[j] : (j == l16 ? 1.0f : 0.0f);
+      ho[0][j] = 0.0f; ho[1][j] = 0.0f; ho[2][j] = 0.0f; ho[3][j] = 0.0f;
     }
+    const unsigned long long twoblk = __ballot(iscon && S.con.cblk[lane < MAXC ? lane : 0][1] >= 0);  // contacts with two segments
     float oldlact = 0.0f;
     unsigned prevbits = 0u;
     float gprev = 0.0f;
@@ -899,56 +870,78 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       if (scale * gn < tol || gn < gfloor) { done = true; break; }
       if (it == 0) STAMP(12);
       // ---- Hessian rows (lane = dof): incremental update of H = Mt + J^T D_active J
-      if (lact != oldlact) {
-        if (coupled) hg[lane] += lact - oldlact;
-        else S.Hb[lane][l16] += lact - oldlact;
+      if (__any(lact != oldlact)) {
+        const float dl = lact - oldlact;
+#pragma unroll
+        for (int j = 0; j < G; j++) hd[j] += j == l16 ? dl : 0.0f;
       }
       oldlact = lact;
-      for (int kq = 0; kq < nmine; kq++) {  // only the rows of the (at most two) blocks a contact touches change
+      // diagonal blocks: the four DPP rows walk their own contact lists side by side
+      for (int kq = 0; kq < nmine; kq++) {
         const int eq = S.con.blist[blk][kq];
         const int c = eq >> 1, myseg = eq & 1;
         const f4 fb = ldv(S.con.cfb[c]);
         const unsigned both = (unsigned)fb.w;
         const unsigned bits = both & 15u, old = both >> 4;
         if (bits == old) continue;
-        const int sg0 = S.con.cblk[c][0], sg1 = S.con.cblk[c][1];
-        const float* jb = &S.Jb[c][myseg][0];
-        const float jn = jb[l16], j1 = jb[16 + l16], j2 = jb[32 + l16];
+        const float* seg = &S.Jb[c][myseg][0];
+        const float jn = seg[l16], j1 = seg[16 + l16], j2 = seg[32 + l16];
         const f4 mt = ldv(S.con.cmeta[c]);
+        f4 xn[4], x1[4], x2[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { xn[q] = ldv(seg + 4 * q); x1[q] = ldv(seg + 16 + 4 * q); x2[q] = ldv(seg + 32 + 4 * q); }
         const float mu = mt.x, D = mt.y;
         const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
         const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
         const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
         const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
 #pragma unroll
-        for (int sgi = 0; sgi < 2; sgi++) {
-          const int bs = sgi == 0 ? sg0 : sg1;
-          if (bs < 0) continue;
-          const float* seg = &S.Jb[c][sgi][0];
-          if (coupled) {
-            float* hb = hg + 16 * bs;
+        for (int q = 0; q < 4; q++) {
+          hd[4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
+          hd[4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
+          hd[4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
+          hd[4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
+        }
+      }
+      // off-diagonal blocks: wave-uniform walk over the two-block contacts; the rows of either block take the other
+      // block's segment as columns
+      if (coupled) {
+        for (unsigned long long tw = twoblk; tw; tw &= tw - 1ull) {
+          const int c = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tw));
+          const f4 fb = ldv(S.con.cfb[c]);
+          const unsigned both = (unsigned)fb.w;
+          const unsigned bits = both & 15u, old = both >> 4;
+          if (bits == old) continue;
+          const int sg0 = S.con.cblk[c][0], sg1 = S.con.cblk[c][1];
+          const bool in0 = blk == sg0, in1 = blk == sg1;
+          if (in0 || in1) {
+            const float* seg = &S.Jb[c][in1 ? 1 : 0][0];
+            const float* oseg = &S.Jb[c][in1 ? 0 : 1][0];
+            const int ob = in1 ? sg0 : sg1;
+            const float jn = seg[l16], j1 = seg[16 + l16], j2 = seg[32 + l16];
+            const f4 mt = ldv(S.con.cmeta[c]);
+            f4 xn[4], x1[4], x2[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { xn[q] = ldv(oseg + 4 * q); x1[q] = ldv(oseg + 16 + 4 * q); x2[q] = ldv(oseg + 32 + 4 * q); }
+            const float mu = mt.x, D = mt.y;
+            const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
+            const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
+            const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
+            const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
+            float d[G];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-              const f4 xn = ldv(seg + 4 * q), x1 = ldv(seg + 16 + 4 * q), x2 = ldv(seg + 32 + 4 * q);
-              f4 hq = *reinterpret_cast<const f4*>(hb + 4 * q);
-              hq.x += tn * xn.x + t1 * x1.x + t2 * x2.x;
-              hq.y += tn * xn.y + t1 * x1.y + t2 * x2.y;
-              hq.z += tn * xn.z + t1 * x1.z + t2 * x2.z;
-              hq.w += tn * xn.w + t1 * x1.w + t2 * x2.w;
-              *reinterpret_cast<f4*>(hb + 4 * q) = hq;
+              d[4 * q + 0] = tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
+              d[4 * q + 1] = tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
+              d[4 * q + 2] = tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
+              d[4 * q + 3] = tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
             }
-          } else {  // single-block contact: bs == blk
-            float* hb = &S.Hb[lane][0];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const f4 xn = ldv(seg + 4 * q), x1 = ldv(seg + 16 + 4 * q), x2 = ldv(seg + 32 + 4 * q);
-              f4 hq = ldv(hb + 4 * q);
-              hq.x += tn * xn.x + t1 * x1.x + t2 * x2.x;
-              hq.y += tn * xn.y + t1 * x1.y + t2 * x2.y;
-              hq.z += tn * xn.z + t1 * x1.z + t2 * x2.z;
-              hq.w += tn * xn.w + t1 * x1.w + t2 * x2.w;
-              stv(hb + 4 * q, hq);
-            }
+            for (int bq = 0; bq < 4; bq++)
+              if (ob == bq) {
+#pragma unroll
+                for (int j = 0; j < G; j++) ho[bq][j] += d[j];
+              }
           }
         }
       }
@@ -957,20 +950,15 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       float sv = -g;
       if (!coupled) {
         float hb[G];
-        const float* hr = &S.Hb[lane][0];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const f4 v = ldv(hr + 4 * q);
-          hb[4 * q] = v.x; hb[4 * q + 1] = v.y; hb[4 * q + 2] = v.z; hb[4 * q + 3] = v.w;
-        }
+        for (int j = 0; j < G; j++) hb[j] = hd[j];
         GJ<0>::run(hb, sv, l16);
       } else {
-        float hrow[NL];
+        v16f hrow[4];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const f4 v = *reinterpret_cast<const f4*>(hg + 4 * q);
-          hrow[4 * q] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
-        }
+        for (int bq = 0; bq < 4; bq++)
+#pragma unroll
+          for (int j = 0; j < G; j++) hrow[bq][j] = blk == bq ? hd[j] : ho[bq][j];
         gj_wave(hrow, sv, lane, lanemask, comp);
       }
       if (!isdof) sv = 0.0f;

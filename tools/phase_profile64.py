@@ -11,7 +11,14 @@ task = env._env; sc = task._mir
 sc.lib.mir_debug_profile_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 sc.lib.mir_debug_profile_step.restype = C.c_int
 home = task._home
-for t in range(10): task.step_raw(home)
+if len(sys.argv) > 2:  # canonical layout for env 0: five cubes resting apart on the slab, arm at home (no coupling)
+    from gym_genesis.backend import models
+    pos = torch.from_numpy(task.sample_spawn()).to(sc.device).float()
+    pos[0] = torch.tensor([[0.1 + 0.12 * i - 0.3, (-1) ** i * 0.15, models.STACK_CUBE_Z] for i in range(5)], device=sc.device)
+    sc.reset(pos, task._quat, home)
+for t in range(30): task.step_raw(home)
+dg = sc.get_diag()
+print("ncon hist", np.bincount(dg[0].cpu().numpy())[15:40], "niter hist", np.bincount(dg[2].cpu().numpy()))
 names = ["load", "fk/cache", "cdof+cinert", "vel+crb", "rne+M", "smooth solve", "geom+broad", "plane-box", "box-box", "compact+finish", "J + limit rows",
          "warm start", "grad(it0)", "hessian(it0)", "GJ64(it0)", "linesearch(it0)", "rest of newton", "integrate", "fk", "store+obs"]
 acc = np.zeros(19)
