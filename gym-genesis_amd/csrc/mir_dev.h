@@ -156,8 +156,17 @@ struct BoxG {
   V3 a0, a1, a2;  // world axes
   V3 h;
 };
-__device__ __forceinline__ V3 bax(const BoxG& b, int k) { return k == 0 ? b.a0 : (k == 1 ? b.a1 : b.a2); }
-__device__ __forceinline__ float bh(const BoxG& b, int k) { return k == 0 ? b.h.x : (k == 1 ? b.h.y : b.h.z); }
+// (every field is read into a value first and the selects work on those: a conditional whose arms read the fields is
+// turned into a select between ADDRESSES, which forces the box into private memory)
+__device__ __forceinline__ V3 bax(const BoxG& b, int k) {
+  const float x0 = b.a0.x, y0 = b.a0.y, z0 = b.a0.z, x1 = b.a1.x, y1 = b.a1.y, z1 = b.a1.z, x2 = b.a2.x, y2 = b.a2.y, z2 = b.a2.z;
+  const bool k0 = k == 0, k1 = k == 1;
+  return v3(k0 ? x0 : (k1 ? x1 : x2), k0 ? y0 : (k1 ? y1 : y2), k0 ? z0 : (k1 ? z1 : z2));
+}
+__device__ __forceinline__ float bh(const BoxG& b, int k) {
+  const float hx = b.h.x, hy = b.h.y, hz = b.h.z;
+  return k == 0 ? hx : (k == 1 ? hy : hz);
+}
 
 // box-box by separating axes + reference-face clipping; normal from A to B; up to 8 points.
 // Rare (only when bounding spheres overlap) and register-hungry: kept out of line.
@@ -173,6 +182,41 @@ struct PolyLds {
   float* base;  // already offset by the lane index
   __device__ __forceinline__ float& at(int arr, int i) { return base[(arr * 9 + i) * 32]; }
 };
+// Sutherland-Hodgman clipping of the incident-face polygon (4 vertices in P arrays 0..2, reference-face coordinates)
+// against the four edges of the reference face, then the penetrating vertices (up to 8) in world coordinates
+template <class Poly>
+__device__ __forceinline__ int clip_ref_face(Poly P, float h1, float h2, V3 fc, V3 e1, V3 e2, V3 nr, float (*out)[4]) {
+  int np = 4;
+  for (int e = 0; e < 4; e++) {
+    const int ax = e >> 1;
+    const float sg = (e & 1) ? -1.0f : 1.0f;
+    const float lim = ax == 0 ? h1 : h2;
+    int nn = 0;
+    for (int v = 0; v < np; v++) {
+      int w = v + 1 == np ? 0 : v + 1;
+      float pc = ax == 0 ? P.at(0, v) : P.at(1, v), qc = ax == 0 ? P.at(0, w) : P.at(1, w);
+      float dp = sg * pc - lim, dq = sg * qc - lim;
+      if (dp <= 0.0f && nn < 9) { P.at(3, nn) = P.at(0, v); P.at(4, nn) = P.at(1, v); P.at(5, nn) = P.at(2, v); nn++; }
+      if ((dp <= 0.0f) != (dq <= 0.0f) && nn < 9) {
+        float u = dp / (dp - dq);
+        P.at(3, nn) = P.at(0, v) + u * (P.at(0, w) - P.at(0, v)); P.at(4, nn) = P.at(1, v) + u * (P.at(1, w) - P.at(1, v)); P.at(5, nn) = P.at(2, v) + u * (P.at(2, w) - P.at(2, v));
+        nn++;
+      }
+    }
+    np = nn;
+    for (int v = 0; v < np; v++) { P.at(0, v) = P.at(3, v); P.at(1, v) = P.at(4, v); P.at(2, v) = P.at(5, v); }
+    if (np == 0) return 0;
+  }
+  int cnt = 0;
+  for (int v = 0; v < np && cnt < 8; v++) {
+    if (P.at(2, v) < 0.0f) {
+      V3 w = fc + P.at(0, v) * e1 + P.at(1, v) * e2 + (0.5f * P.at(2, v)) * nr;
+      out[cnt][0] = w.x; out[cnt][1] = w.y; out[cnt][2] = w.z; out[cnt][3] = P.at(2, v);
+      cnt++;
+    }
+  }
+  return cnt;
+}
 template <class Poly>
 __device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4], V3& nout, Poly P) {
   V3 t = B.p - A.p;
@@ -239,7 +283,6 @@ __device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4
   V3 ic = I.p + (sj * bh(I, jb)) * bax(I, jb);
   V3 e1 = bax(R, k1), e2 = bax(R, k2);
   float h1 = bh(R, k1), h2 = bh(R, k2);
-  int np = 4;
   {
     const float sx[4] = {1, -1, -1, 1}, sy[4] = {1, 1, -1, -1};
     float vx[4], vy[4], vz[4];
@@ -267,35 +310,7 @@ __device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4
 #pragma unroll
     for (int v = 0; v < 4; v++) { P.at(0, v) = vx[v]; P.at(1, v) = vy[v]; P.at(2, v) = vz[v]; }
   }
-  for (int e = 0; e < 4; e++) {
-    const int ax = e >> 1;
-    const float sg = (e & 1) ? -1.0f : 1.0f;
-    const float lim = ax == 0 ? h1 : h2;
-    int nn = 0;
-    for (int v = 0; v < np; v++) {
-      int w = v + 1 == np ? 0 : v + 1;
-      float pc = ax == 0 ? P.at(0, v) : P.at(1, v), qc = ax == 0 ? P.at(0, w) : P.at(1, w);
-      float dp = sg * pc - lim, dq = sg * qc - lim;
-      if (dp <= 0.0f && nn < 9) { P.at(3, nn) = P.at(0, v); P.at(4, nn) = P.at(1, v); P.at(5, nn) = P.at(2, v); nn++; }
-      if ((dp <= 0.0f) != (dq <= 0.0f) && nn < 9) {
-        float u = dp / (dp - dq);
-        P.at(3, nn) = P.at(0, v) + u * (P.at(0, w) - P.at(0, v)); P.at(4, nn) = P.at(1, v) + u * (P.at(1, w) - P.at(1, v)); P.at(5, nn) = P.at(2, v) + u * (P.at(2, w) - P.at(2, v));
-        nn++;
-      }
-    }
-    np = nn;
-    for (int v = 0; v < np; v++) { P.at(0, v) = P.at(3, v); P.at(1, v) = P.at(4, v); P.at(2, v) = P.at(5, v); }
-    if (np == 0) return 0;
-  }
-  int cnt = 0;
-  for (int v = 0; v < np && cnt < 8; v++) {
-    if (P.at(2, v) < 0.0f) {
-      V3 w = fc + P.at(0, v) * e1 + P.at(1, v) * e2 + (0.5f * P.at(2, v)) * nr;
-      out[cnt][0] = w.x; out[cnt][1] = w.y; out[cnt][2] = w.z; out[cnt][3] = P.at(2, v);
-      cnt++;
-    }
-  }
-  return cnt;
+  return clip_ref_face(P, h1, h2, fc, e1, e2, nr, out);
 }
 
 // MuJoCo-style impedance from solimp at |pos|
