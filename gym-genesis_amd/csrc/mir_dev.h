@@ -313,6 +313,117 @@ __device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4
   return clip_ref_face(P, h1, h2, fc, e1, e2, nr, out);
 }
 
+// Box-box on a whole DPP row: every lane of the row calls this with the same pair.  The 15 separating axes sit on
+// lanes 0..14; the axis choice replays the sequential rule of box_box on row broadcasts, so both routines pick the same
+// feature; the four incident-face vertices sit on lanes 0..3, and only a partially overlapping face pair falls back to
+// lane 0 walking the clipping loops on the polygon workspace P.  Returns the contact count in every lane of the row;
+// points go to out[0..cnt), the normal (A to B) to snorm.  l16 = lane in the row, wlane = lane in the wave,
+// rowshift = bit position of the row in a wave ballot.
+__device__ __forceinline__ V3 selv(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+template <class Poly>
+__device__ __forceinline__ int box_box_row(const BoxG& A, const BoxG& B, int l16, int wlane, int rowshift, float (*out)[4], float* snorm, Poly P) {
+  const V3 t = B.p - A.p;
+  // ---- lane = axis: faces of A (0..2), faces of B (3..5), edge pairs i x j (6 + 3 i + j)
+  const int ax = l16;
+  const int ei = ax < 9 ? 0 : (ax < 12 ? 1 : 2), ej = ax - 6 - 3 * ei;
+  const V3 Lf = selv(ax < 3, bax(A, ax), bax(B, ax - 3));
+  V3 Le = cross(bax(A, ei), bax(B, ej));
+  const float len = sqrtf(dot(Le, Le));
+  Le = (1.0f / len) * Le;
+  const bool isedge = ax >= 6;
+  const bool deg = ax >= 15 || (isedge && len < 1e-3f);
+  const V3 L = selv(isedge, Le, Lf);
+  const float ra = A.h.x * fabsf(dot(A.a0, L)) + A.h.y * fabsf(dot(A.a1, L)) + A.h.z * fabsf(dot(A.a2, L));
+  const float rb = B.h.x * fabsf(dot(B.a0, L)) + B.h.y * fabsf(dot(B.a1, L)) + B.h.z * fabsf(dot(B.a2, L));
+  const float s = deg ? -3e38f : fabsf(dot(t, L)) - (ra + rb);
+  const unsigned sepm = (unsigned)(__ballot(s > 0.0f) >> rowshift) & 0xffffu;
+  int cnt = 0;
+  if (sepm == 0u) {  // row-uniform
+    float best = -1e30f;
+    int code = -1;
+#define MIR_FACE(c) { const float sc = row_bcast<c>(s); if (sc > best) { best = sc; code = c; } }
+    MIR_FACE(0) MIR_FACE(1) MIR_FACE(2) MIR_FACE(3) MIR_FACE(4) MIR_FACE(5)
+#undef MIR_FACE
+#define MIR_EDGE(c) { const float sc = row_bcast<c>(s); if (sc > -1e38f && sc * 1.05f > best && sc > best + 1e-6f) { best = sc; code = c; } }
+    MIR_EDGE(6) MIR_EDGE(7) MIR_EDGE(8) MIR_EDGE(9) MIR_EDGE(10) MIR_EDGE(11) MIR_EDGE(12) MIR_EDGE(13) MIR_EDGE(14)
+#undef MIR_EDGE
+    const int src = (wlane & ~15) + code;
+    const V3 bestL = v3(__shfl(L.x, src), __shfl(L.y, src), __shfl(L.z, src));
+    const V3 n = selv(dot(t, bestL) < 0.0f, -1.0f * bestL, bestL);
+    if (l16 == 0) st3v(snorm, n);
+    if (code >= 6) {
+      // edge-edge: closest points of the two supporting edges (every lane of the row computes, lane 0 writes)
+      const int i = (code - 6) / 3, j = (code - 6) % 3;
+      V3 PA = A.p, PB = B.p;
+  #pragma unroll
+      for (int q = 0; q < 3; q++) {
+        if (q != i) PA = PA + (dot(n, bax(A, q)) > 0.0f ? bh(A, q) : -bh(A, q)) * bax(A, q);
+        if (q != j) PB = PB + (dot(n, bax(B, q)) > 0.0f ? -bh(B, q) : bh(B, q)) * bax(B, q);
+      }
+      const V3 ua = bax(A, i), ub = bax(B, j), dd = PB - PA;
+      const float uaub = dot(ua, ub), q1 = dot(ua, dd), q2 = -dot(ub, dd), den = 1.0f - uaub * uaub;
+      float alpha = 0.0f, beta = 0.0f;
+      if (den > 1e-6f) { alpha = (q1 + uaub * q2) / den; beta = (uaub * q1 + q2) / den; }
+      PA = PA + alpha * ua;
+      PB = PB + beta * ub;
+      const V3 pos = 0.5f * (PA + PB);
+      if (l16 == 0) stv(out[0], f4{pos.x, pos.y, pos.z, best});
+      cnt = 1;
+    } else {
+      // face contact: reference face = the chosen axis, incident face = the most anti-parallel face of the other box
+      const bool refA = code < 3;
+      const BoxG R = {selv(refA, A.p, B.p), selv(refA, A.a0, B.a0), selv(refA, A.a1, B.a1), selv(refA, A.a2, B.a2), selv(refA, A.h, B.h)};
+      const BoxG I = {selv(refA, B.p, A.p), selv(refA, B.a0, A.a0), selv(refA, B.a1, A.a1), selv(refA, B.a2, A.a2), selv(refA, B.h, A.h)};
+      const int kf = refA ? code : code - 3;
+      const V3 nr = selv(refA, n, -1.0f * n);
+      const int k1 = (kf + 1) % 3, k2 = (kf + 2) % 3;
+      const V3 fc = R.p + bh(R, kf) * nr;
+      const float a0 = fabsf(dot(nr, I.a0)), a1 = fabsf(dot(nr, I.a1)), a2 = fabsf(dot(nr, I.a2));
+      int jb = 0;
+      float mx = a0;
+      if (a1 > mx) { mx = a1; jb = 1; }
+      if (a2 > mx) { mx = a2; jb = 2; }
+      const float sj = dot(nr, bax(I, jb)) > 0.0f ? -1.0f : 1.0f;
+      const int j1 = (jb + 1) % 3, j2 = (jb + 2) % 3;
+      const V3 ic = I.p + (sj * bh(I, jb)) * bax(I, jb);
+      const V3 e1 = bax(R, k1), e2 = bax(R, k2);
+      const float h1 = bh(R, k1), h2 = bh(R, k2);
+      // lane = incident-face vertex (0..3, same order as box_box: (+,+), (-,+), (-,-), (+,-))
+      const int v = l16 & 3;
+      const float sxv = (v == 0 || v == 3) ? 1.0f : -1.0f, syv = v < 2 ? 1.0f : -1.0f;
+      const V3 w = ic + (sxv * bh(I, j1)) * bax(I, j1) + (syv * bh(I, j2)) * bax(I, j2);
+      const V3 rel = w - fc;
+      const float vx = dot(rel, e1), vy = dot(rel, e2), vz = dot(rel, nr);
+      const bool in_v = fabsf(vx) <= h1 && fabsf(vy) <= h2;
+      const unsigned insm = (unsigned)(__ballot(in_v) >> rowshift) & 0xfu;
+      if (insm == 0xfu) {
+        // the whole incident face lies over the reference face (a cube resting on the slab): the clipped polygon
+        // is the face itself, so its penetrating vertices are emitted in order
+        const bool pen = l16 < 4 && vz < 0.0f;
+        const unsigned penm = (unsigned)(__ballot(pen) >> rowshift) & 0xfu;
+        cnt = __popc(penm);
+        if (pen) {
+          const V3 wp = fc + vx * e1 + vy * e2 + (0.5f * vz) * nr;
+          stv(out[__popc(penm & ((1u << l16) - 1u))], f4{wp.x, wp.y, wp.z, vz});
+        }
+      } else {
+        // partial overlap: lane 0 gathers the four vertices and walks the clipping loops on its polygon workspace
+        const float gx0 = row_bcast<0>(vx), gx1 = row_bcast<1>(vx), gx2 = row_bcast<2>(vx), gx3 = row_bcast<3>(vx);
+        const float gy0 = row_bcast<0>(vy), gy1 = row_bcast<1>(vy), gy2 = row_bcast<2>(vy), gy3 = row_bcast<3>(vy);
+        const float gz0 = row_bcast<0>(vz), gz1 = row_bcast<1>(vz), gz2 = row_bcast<2>(vz), gz3 = row_bcast<3>(vz);
+        if (l16 == 0) {
+          P.at(0, 0) = gx0; P.at(0, 1) = gx1; P.at(0, 2) = gx2; P.at(0, 3) = gx3;
+          P.at(1, 0) = gy0; P.at(1, 1) = gy1; P.at(1, 2) = gy2; P.at(1, 3) = gy3;
+          P.at(2, 0) = gz0; P.at(2, 1) = gz1; P.at(2, 2) = gz2; P.at(2, 3) = gz3;
+          cnt = clip_ref_face(P, h1, h2, fc, e1, e2, nr, out);
+        }
+        cnt = (int)row_bcast<0>((float)cnt);
+      }
+    }
+  }
+  return cnt;
+}
+
 // MuJoCo-style impedance from solimp at |pos|
 __device__ __forceinline__ float impedance(float dmin, float dmax, float width, float mid, float power, float pos) {
   dmin = fminf(fmaxf(dmin, 1e-4f), 0.9999f);

@@ -506,19 +506,21 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
           st3v(S.col.snorm[k], n);
         }
       }
-      // narrowphase, box-box: one lane per candidate (rare: only when bounding spheres overlap)
-      if (lane < ncand) {
-        const int p = S.col.cand[lane];
-        const int pr = T.pair[p];
+      // narrowphase, box-box: one candidate at a time on the whole row (box_box_row, mir_dev.h): the 15 separating axes
+      // on lanes 0..14, the incident-face vertices on lanes 0..3
+      for (int k = 0; k < G; k++) {
+        const bool act = k < ncand;
+        if (!__any(act)) break;
+        const int pr = act ? T.pair[S.col.cand[k]] : 0;
         const int g1 = pr & 255, g2 = pr >> 8;
-        if (T.g_info[g1][1] != MIR_GEOM_PLANE) {
-          M3 R2 = q2m(ld4v(S.col.gquat[g2]));
-          BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
-          M3 R1 = q2m(ld4v(S.col.gquat[g1]));
-          BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
-          V3 n = v3(0, 0, 1);
-          mycount = box_box(B1, B2, S.col.stage[lane], n, PolyScratch());
-          st3v(S.col.snorm[lane], n);
+        const bool isbox = act && T.g_info[g1][1] != MIR_GEOM_PLANE;
+        if (!__any(isbox)) continue;
+        if (isbox) {  // whole rows
+          const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
+          const BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
+          const BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
+          const int cnt = box_box_row(B1, B2, lane, tid, grp * G, S.col.stage[k], S.col.snorm[k], PolyScratch());
+          if (lane == k) mycount = cnt;
         }
       }
     }

@@ -63,7 +63,6 @@ __device__ __forceinline__ float wmaxf(float v) {
 __device__ __forceinline__ float rlv(float v, int src) {  // src wave-uniform (SGPR lane select)
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
-__device__ __forceinline__ V3 selv(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 typedef float v16f __attribute__((ext_vector_type(16)));
 template <int BLK>
 __device__ __forceinline__ void gj_block(v16f (&a)[4], float& b, int lane, uint64_t act, unsigned comp) {
@@ -637,98 +636,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
           const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
           const BoxG A = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(&S.gts[g1][1])};
           const BoxG B = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(&S.gts[g2][1])};
-          const V3 t = B.p - A.p;
-          // ---- lane = axis: faces of A (0..2), faces of B (3..5), edge pairs i x j (6 + 3 i + j)
-          const int ax = l16;
-          const int ei = ax < 9 ? 0 : (ax < 12 ? 1 : 2), ej = ax - 6 - 3 * ei;
-          const V3 Lf = selv(ax < 3, bax(A, ax), bax(B, ax - 3));
-          V3 Le = cross(bax(A, ei), bax(B, ej));
-          const float len = sqrtf(dot(Le, Le));
-          Le = (1.0f / len) * Le;
-          const bool isedge = ax >= 6;
-          const bool deg = ax >= 15 || (isedge && len < 1e-3f);
-          const V3 L = selv(isedge, Le, Lf);
-          const float ra = A.h.x * fabsf(dot(A.a0, L)) + A.h.y * fabsf(dot(A.a1, L)) + A.h.z * fabsf(dot(A.a2, L));
-          const float rb = B.h.x * fabsf(dot(B.a0, L)) + B.h.y * fabsf(dot(B.a1, L)) + B.h.z * fabsf(dot(B.a2, L));
-          const float s = deg ? -3e38f : fabsf(dot(t, L)) - (ra + rb);
-          const unsigned sepm = (unsigned)(__ballot(s > 0.0f) >> (blk * G)) & 0xffffu;
-          int cnt = 0;
-          if (sepm == 0u) {  // row-uniform
-            float best = -1e30f;
-            int code = -1;
-#define MIR_FACE(c) { const float sc = row_bcast<c>(s); if (sc > best) { best = sc; code = c; } }
-            MIR_FACE(0) MIR_FACE(1) MIR_FACE(2) MIR_FACE(3) MIR_FACE(4) MIR_FACE(5)
-#undef MIR_FACE
-#define MIR_EDGE(c) { const float sc = row_bcast<c>(s); if (sc > -1e38f && sc * 1.05f > best && sc > best + 1e-6f) { best = sc; code = c; } }
-            MIR_EDGE(6) MIR_EDGE(7) MIR_EDGE(8) MIR_EDGE(9) MIR_EDGE(10) MIR_EDGE(11) MIR_EDGE(12) MIR_EDGE(13) MIR_EDGE(14)
-#undef MIR_EDGE
-            const int src = (lane & ~15) + code;
-            const V3 bestL = v3(__shfl(L.x, src), __shfl(L.y, src), __shfl(L.z, src));
-            const V3 n = selv(dot(t, bestL) < 0.0f, -1.0f * bestL, bestL);
-            if (l16 == 0) st3v(S.col.snorm[k], n);
-            if (code >= 6) {
-              // edge-edge: closest points of the two supporting edges (every lane of the row computes, lane 0 writes)
-              const int i = (code - 6) / 3, j = (code - 6) % 3;
-              V3 PA = A.p, PB = B.p;
-#pragma unroll
-              for (int q = 0; q < 3; q++) {
-                if (q != i) PA = PA + (dot(n, bax(A, q)) > 0.0f ? bh(A, q) : -bh(A, q)) * bax(A, q);
-                if (q != j) PB = PB + (dot(n, bax(B, q)) > 0.0f ? -bh(B, q) : bh(B, q)) * bax(B, q);
-              }
-              const V3 ua = bax(A, i), ub = bax(B, j), dd = PB - PA;
-              const float uaub = dot(ua, ub), q1 = dot(ua, dd), q2 = -dot(ub, dd), den = 1.0f - uaub * uaub;
-              float alpha = 0.0f, beta = 0.0f;
-              if (den > 1e-6f) { alpha = (q1 + uaub * q2) / den; beta = (uaub * q1 + q2) / den; }
-              PA = PA + alpha * ua;
-              PB = PB + beta * ub;
-              const V3 pos = 0.5f * (PA + PB);
-              if (l16 == 0) stv(S.col.stage[k][0], f4{pos.x, pos.y, pos.z, best});
-              cnt = 1;
-            } else {
-              // face contact: reference face = the chosen axis, incident face = the most anti-parallel face of the other box
-              const bool refA = code < 3;
-              const BoxG R = {selv(refA, A.p, B.p), selv(refA, A.a0, B.a0), selv(refA, A.a1, B.a1), selv(refA, A.a2, B.a2), selv(refA, A.h, B.h)};
-              const BoxG I = {selv(refA, B.p, A.p), selv(refA, B.a0, A.a0), selv(refA, B.a1, A.a1), selv(refA, B.a2, A.a2), selv(refA, B.h, A.h)};
-              const int kf = refA ? code : code - 3;
-              const V3 nr = selv(refA, n, -1.0f * n);
-              const int k1 = (kf + 1) % 3, k2 = (kf + 2) % 3;
-              const V3 fc = R.p + bh(R, kf) * nr;
-              const float a0 = fabsf(dot(nr, I.a0)), a1 = fabsf(dot(nr, I.a1)), a2 = fabsf(dot(nr, I.a2));
-              int jb = 0;
-              float mx = a0;
-              if (a1 > mx) { mx = a1; jb = 1; }
-              if (a2 > mx) { mx = a2; jb = 2; }
-              const float sj = dot(nr, bax(I, jb)) > 0.0f ? -1.0f : 1.0f;
-              const int j1 = (jb + 1) % 3, j2 = (jb + 2) % 3;
-              const V3 ic = I.p + (sj * bh(I, jb)) * bax(I, jb);
-              const V3 e1 = bax(R, k1), e2 = bax(R, k2);
-              const float h1 = bh(R, k1), h2 = bh(R, k2);
-              // lane = incident-face vertex (0..3, same order as box_box: (+,+), (-,+), (-,-), (+,-))
-              const int v = l16 & 3;
-              const float sxv = (v == 0 || v == 3) ? 1.0f : -1.0f, syv = v < 2 ? 1.0f : -1.0f;
-              const V3 w = ic + (sxv * bh(I, j1)) * bax(I, j1) + (syv * bh(I, j2)) * bax(I, j2);
-              const V3 rel = w - fc;
-              const float vx = dot(rel, e1), vy = dot(rel, e2), vz = dot(rel, nr);
-              const bool in_v = fabsf(vx) <= h1 && fabsf(vy) <= h2;
-              const unsigned insm = (unsigned)(__ballot(in_v) >> (blk * G)) & 0xfu;
-              if (insm == 0xfu) {
-                // the whole incident face lies over the reference face (a cube resting on the slab): the clipped polygon
-                // is the face itself, so its penetrating vertices are emitted in order
-                const bool pen = l16 < 4 && vz < 0.0f;
-                const unsigned penm = (unsigned)(__ballot(pen) >> (blk * G)) & 0xfu;
-                cnt = __popc(penm);
-                if (pen) {
-                  const V3 wp = fc + vx * e1 + vy * e2 + (0.5f * vz) * nr;
-                  stv(S.col.stage[k][__popc(penm & ((1u << l16) - 1u))], f4{wp.x, wp.y, wp.z, vz});
-                }
-              } else {
-                PolyLds P{reinterpret_cast<float*>(&S.con) + blk};
-                if (l16 < 4) { P.at(0, l16) = vx; P.at(1, l16) = vy; P.at(2, l16) = vz; }
-                WSYNC();
-                if (l16 == 0) cnt = clip_ref_face(P, h1, h2, fc, e1, e2, nr, S.col.stage[k]);
-              }
-            }
-          }
+          const int cnt = box_box_row(A, B, l16, lane, blk * G, S.col.stage[k], S.col.snorm[k], PolyLds{reinterpret_cast<float*>(&S.con) + blk});
           if (l16 == 0) S.col.ccount[k] = cnt;
         }
       }
