@@ -403,5 +403,26 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     t.d_lim[i][0] = m.d_lo[i]; t.d_lim[i][1] = m.d_hi[i]; t.d_lim[i][2] = m.d_invweight0[i]; t.d_lim[i][3] = m.d_k[i]; t.d_lim[i][4] = m.d_b[i];
     for (int k = 0; k < 5; k++) t.d_lim[i][5 + k] = m.d_solimp[i][k];
   }
+  // ---- per-lane register constants (LaneK16) and the packed parent links ---------------------
+  m.parents = 0;
+  for (int b = 1; b < nb; b++) m.parents |= (uint64_t)(m.b_parent[b] & 15) << (4 * b);
+  for (int l = 0; l < MIR_G; l++) {
+    LaneK16& k = m.lanek[l];
+    memset(&k, 0, sizeof k);
+    k.b_jtype = m.b_jtype[l]; k.b_qadr = m.b_qadr[l]; k.b_root = m.b_root[l];
+    k.b_dofmask = m.b_dofmask[l]; k.b_submask = m.b_submask[l]; k.b_mass = m.b_mass[l];
+    for (int c = 0; c < 3; c++) { k.b_pos[c] = m.b_pos[l][c]; k.b_axis[c] = m.b_axis[l][c]; k.b_ipos[c] = m.b_ipos[l][c]; }
+    for (int c = 0; c < 4; c++) k.b_quat[c] = m.b_quat[l][c];
+    for (int c = 0; c < 6; c++) k.b_inertia[c] = m.b_inertia[l][c];
+    const int db = l < nv ? m.d_body[l] : 0;
+    k.d_body = db; k.d_kind = m.d_kind[l]; k.d_qadr = m.d_qadr[l]; k.d_axis_k = m.d_axis_k[l]; k.d_root = m.b_root[db];
+    k.d_ctrl = m.d_ctrl[l]; k.d_uadr = m.d_uadr[l]; k.d_submask = m.b_submask[db];
+    for (int c = 0; c < 3; c++) k.d_axis[c] = m.b_axis[db][c];
+    k.d_premask = m.d_premask[l]; k.d_ancmask = m.d_ancmask[l];
+    k.d_limited = (l < nv && m.d_limited[l] && m.enable_joint_limit) ? 1 : 0;
+    k.d_damping = m.d_damping[l]; k.d_kp = m.d_kp[l]; k.d_kv = m.d_kv[l]; k.d_frclo = m.d_frclo[l]; k.d_frchi = m.d_frchi[l];
+    k.d_mdiag = m.d_mdiag[l];
+    k.obs_qadr = (l >= 7 && l < 7 + m.n_grip) ? m.grip_qadr[l - 7] : 0;
+  }
   return MIR_OK;
 }

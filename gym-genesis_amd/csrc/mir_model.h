@@ -41,8 +41,29 @@ struct ModelTab {
 };
 static_assert(sizeof(ModelTab) % 16 == 0, "ModelTab is copied with 16-byte accesses");
 
+// Everything one lane (= body index = dof index) needs in registers for the whole launch, packed so the prologue fetches it
+// with twelve independent 16-byte loads (no load depends on another load's result, e.g. the joint axis of the dof's body
+// is resolved here, not by a second trip through b_axis[d_body]).  Filled at the end of mir_compile_model.
+struct LaneK16 {
+  int32_t b_jtype, b_qadr, b_root, d_body;
+  float b_pos[3]; uint32_t b_dofmask;
+  float b_quat[4];
+  float b_axis[3]; uint32_t b_submask;
+  float b_ipos[3], b_mass;
+  float b_inertia[6]; int32_t d_kind, d_qadr;
+  int32_t d_axis_k, d_root, d_ctrl, d_uadr;
+  float d_axis[3]; uint32_t d_submask;
+  uint32_t d_premask, d_ancmask; int32_t d_limited /* limited && enable_joint_limit && dof exists */; float d_damping;
+  float d_kp, d_kv, d_frclo, d_frchi;
+  float d_mdiag; int32_t obs_qadr /* qpos address behind agent_pos column `lane` (gripper columns), else 0 */, pad0, pad1;
+};
+static_assert(sizeof(LaneK16) == 12 * 16, "LaneK16 is read as twelve 16-byte quantities");
+
 struct DevModel {
   ModelTab tab;  // first member: 16-byte aligned with the allocation
+  LaneK16 lanek[MIR_G];  // (16-byte aligned: sizeof(ModelTab) is a multiple of 16)
+  uint64_t parents;      // the 16 parent indices, 4 bits each (pointer-jumping FK)
+  uint64_t pad_parents;
   // sizes / options
   int32_t nbody, nv, nq, ngeom, npair, nu, qstride, max_contacts;
   int32_t iterations, ls_iterations, enable_collision, enable_joint_limit;

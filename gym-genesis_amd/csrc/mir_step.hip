@@ -165,42 +165,52 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   const int env = valid ? env_raw : a.B - 1;
   EnvLds& S = s_env[grp];
 
-  const int nb = m->nbody, nv = m->nv, qst = m->qstride;
+  const int nb = m->nbody, nv = m->nv, qst = a.qst;
   const int ngeom = m->ngeom, npair = m->npair, max_contacts = m->max_contacts, enable_collision = m->enable_collision;
   const float dt = m->dt;
 
-  // ---- per-lane model constants (lane = body = dof) -------------------------------------------
+  // ---- per-lane model constants (lane = body = dof): twelve independent 16-byte loads (LaneK16) -------------
   const bool isbody = lane < nb && lane > 0;
   const bool isdof = lane < nv;
-  uint64_t parents = 0;
-  for (int b = 1; b < nb; b++) parents |= (uint64_t)(m->b_parent[b] & 15) << (4 * b);
-  BodyK bk;
-  bk.jtype = m->b_jtype[lane]; bk.qadr = m->b_qadr[lane];
-  bk.pos = ld3(m->b_pos[lane]); bk.axis = ld3(m->b_axis[lane]); bk.quat = ld4(m->b_quat[lane]);
-  const int b_root = m->b_root[lane];
-  const uint32_t b_dofmask = m->b_dofmask[lane], b_submask = m->b_submask[lane];
-  const V3 b_ipos = ld3(m->b_ipos[lane]);
-  const float b_mass = m->b_mass[lane];
-  float ib[6];
+  const uint64_t parents = m->parents;
+  f4 lk[12];
+  {
+    const f4* src = reinterpret_cast<const f4*>(&m->lanek[lane]);
 #pragma unroll
-  for (int k = 0; k < 6; k++) ib[k] = m->b_inertia[lane][k];
-  const int d_body = isdof ? m->d_body[lane] : 0;
-  const int d_kind = m->d_kind[lane], d_qadr = m->d_qadr[lane], d_axis_k = m->d_axis_k[lane];
-  const int d_root = m->b_root[d_body];
-  const V3 d_axis = ld3(m->b_axis[d_body]);
-  const uint32_t d_premask = m->d_premask[lane], d_ancmask = m->d_ancmask[lane], d_submask = m->b_submask[d_body];
-  const int d_ctrl = m->d_ctrl[lane], d_uadr = m->d_uadr[lane];
-  const bool d_limited = isdof && m->d_limited[lane] && m->enable_joint_limit;
-  const float d_damping = m->d_damping[lane], d_kp = m->d_kp[lane], d_kv = m->d_kv[lane];
-  const float d_frclo = m->d_frclo[lane], d_frchi = m->d_frchi[lane], d_mdiag = m->d_mdiag[lane];
+    for (int k = 0; k < 12; k++) lk[k] = src[k];
+  }
+  BodyK bk;
+  bk.jtype = __float_as_int(lk[0].x); bk.qadr = __float_as_int(lk[0].y);
+  const int b_root = __float_as_int(lk[0].z), d_body = __float_as_int(lk[0].w);
+  bk.pos = v3(lk[1].x, lk[1].y, lk[1].z);
+  const uint32_t b_dofmask = __float_as_uint(lk[1].w);
+  bk.quat = Q4{lk[2].x, lk[2].y, lk[2].z, lk[2].w};
+  bk.axis = v3(lk[3].x, lk[3].y, lk[3].z);
+  const uint32_t b_submask = __float_as_uint(lk[3].w);
+  const V3 b_ipos = v3(lk[4].x, lk[4].y, lk[4].z);
+  const float b_mass = lk[4].w;
+  const float ib[6] = {lk[5].x, lk[5].y, lk[5].z, lk[5].w, lk[6].x, lk[6].y};
+  const int d_kind = __float_as_int(lk[6].z), d_qadr = __float_as_int(lk[6].w);
+  const int d_axis_k = __float_as_int(lk[7].x), d_root = __float_as_int(lk[7].y), d_ctrl = __float_as_int(lk[7].z), d_uadr = __float_as_int(lk[7].w);
+  const V3 d_axis = v3(lk[8].x, lk[8].y, lk[8].z);
+  const uint32_t d_submask = __float_as_uint(lk[8].w);
+  const uint32_t d_premask = __float_as_uint(lk[9].x), d_ancmask = __float_as_uint(lk[9].y);
+  const bool d_limited = __float_as_int(lk[9].z) != 0;
+  const float d_damping = lk[9].w, d_kp = lk[10].x, d_kv = lk[10].y, d_frclo = lk[10].z, d_frchi = lk[10].w, d_mdiag = lk[11].x;
+  const int obs_qadr = __float_as_int(lk[11].y);
 
   // ---- load state -----------------------------------------------------------------------------
-  for (int i = lane; i < qst; i += G) S.qpos[i] = a.qpos[(size_t)env * qst + i];
+  // (addresses from the launch arguments only: these loads leave together with the model loads above)
+  for (int i = lane; i < a.qst; i += G) S.qpos[i] = a.qpos[(size_t)env * a.qst + i];
   S.qvel[lane] = a.qvel[(size_t)env * G + lane];
   S.qacc_ws[lane] = a.qacc_ws[(size_t)env * G + lane];
   {
     float tg = a.target[(size_t)env * G + lane];
-    if (a.action && isdof && d_uadr >= 0) tg = a.action[(size_t)env * m->nu + d_uadr];
+    if (a.action) {  // lane u fetches action component u; the dof that it drives picks it up across the row
+      const float au = lane < a.nu ? a.action[(size_t)env * a.nu + lane] : 0.0f;
+      const float mine = __shfl(au, (tid & ~(G - 1)) + (d_uadr >= 0 ? d_uadr : 0));
+      if (isdof && d_uadr >= 0) tg = mine;
+    }
     S.target[lane] = tg;
   }
   if (lane == 0) { S.ncon = 0; S.ncand = 0; }
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     const V3 df = pe - po;
     if (c < 3) return S.xpos[eb][c];
     if (c < 7) return S.xquat[eb][c - 3];
-    if (c < ad) return S.qpos[m->grip_qadr[c - 7]];
+    if (c < ad) return S.qpos[c == lane ? obs_qadr : m->grip_qadr[c - 7]];  // (every caller asks for its own lane: no model trip)
     const int k = c - ad;
     if (k < 3) return S.xpos[ob][k];
     if (k < 7) return S.xquat[ob][k - 3];
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   for (int step = 0; step < nsteps; step++) {
     // rollout mode (mir_rollout): a fresh action block per step
     if (step > 0 && a.action && a.act_step) {
-      if (isdof && d_uadr >= 0) S.target[lane] = a.action[(size_t)step * a.act_step + (size_t)env * m->nu + d_uadr];
+      if (isdof && d_uadr >= 0) S.target[lane] = a.action[(size_t)step * a.act_step + (size_t)env * a.nu + d_uadr];
     }
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
     if (isdof) {
