@@ -219,5 +219,29 @@ int mir_compile_model64(const MirSceneSpec* sp0, DevModel64* out, HostConsts* hc
   for (int b = 0; b < nb; b++) m.b_invweight0[b] = (float)H.body_invweight0[b];
   m.meaninertia = (float)H.meaninertia;
   m.solver_scale = (float)(1.0 / (H.meaninertia * (nv > 1 ? nv : 1)));
+
+  // ---- derived tables --------------------------------------------------------------------------------
+  auto bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+  for (int l = 0; l < W64; l++) {
+    const int db = ((m.lanemask >> l) & 1ull) ? m.d_body[l] : 0;
+    m.d_root[l] = m.b_root[db]; m.d_qbase[l] = m.b_qadr[db]; m.d_lbase[l] = m.b_dofadr[db]; m.d_bsubmask[l] = m.b_submask[db];
+    for (int c = 0; c < 3; c++) m.d_axis[l][c] = m.b_axis[db][c];
+    m.d_axis[l][3] = 0.0f;
+    int oq = 0;
+    if (l < m.agent_dim) {
+      if (m.agent_mode == MIR_AGENT_QPOS) oq = m.arm_qadr[l];
+      else if (l >= 7) oq = m.grip_qadr[l - 7];
+    }
+    m.obs_qadr[l] = oq;
+  }
+  for (int b = 0; b < K64_MAX_BODY; b++) {
+    const bool on = b < nb;
+    m.b_tab[b][0] = on ? m.b_invweight0[b] : 0.0f;
+    m.b_tab[b][1] = bits(on ? (uint32_t)m.b_dofmask[b] : 0u);
+    m.b_tab[b][2] = bits(on ? (uint32_t)(m.b_dofmask[b] >> 32) : 0u);
+    m.b_tab[b][3] = bits((uint32_t)(on ? m.b_block[b] : -1));
+    m.b_tab[b][4] = bits((uint32_t)(on ? m.b_root[b] : 0));
+    m.b_tab[b][5] = m.b_tab[b][6] = m.b_tab[b][7] = 0.0f;
+  }
   return MIR_OK;
 }

@@ -49,6 +49,12 @@ struct DevModel64 {
   float g_size[MIR_MAX_GEOM][4], g_pos[MIR_MAX_GEOM][4] /* w = friction */, g_quat[MIR_MAX_GEOM][4], g_sol[MIR_MAX_GEOM][8] /* solref2 solimp5 */;
   // ---- candidate pairs (static filter applied) ----
   int32_t pair[MIR_MAX_PAIR]; /* g1 | g2 << 8 */
+  // ---- derived tables (end of mir_compile_model64): no prologue load of the kernel depends on another load ----
+  int32_t d_root[W64], d_qbase[W64], d_lbase[W64] /* b_root / b_qadr / b_dofadr of the lane's body */;
+  int32_t obs_qadr[W64];   /* qpos address behind agent_pos column `lane` (joint / gripper columns), else 0 */
+  uint32_t d_bsubmask[W64];
+  float d_axis[W64][4];    /* joint axis of the lane's body */
+  float b_tab[K64_MAX_BODY][8]; /* contact finish, staged in LDS: invweight0, dofmask lo, dofmask hi, block, root (int bits) */
 };
 
 // Dof-order <-> storage maps used by the plumbing kernels of mir_api.hip for BOTH step kernels

@@ -33,6 +33,7 @@ struct StepArgs64 {
   long rows_step;  // floats between the row blocks of consecutive steps (rollout mode), 0 = only the final row
   AutoResetArgs ar;  // per-step episode bookkeeping + re-spawn inside the launch (rollout mode only)
   int B;
+  int nu;       // action width (copy of the model's: the action load does not wait for the model)
   int mode;     // 0: full steps; 1: forward dynamics only; 2: kinematics + outputs only
   int n_steps;  // mode 0 only
 };

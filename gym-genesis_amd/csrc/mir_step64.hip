@@ -149,6 +149,8 @@ struct Env64 {
   float gts[MIR_MAX_GEOM][4];           // type | body << 8 (as int bits), half extents
   float gfr[MIR_MAX_GEOM];              // friction
   unsigned short pairs[MIR_MAX_PAIR];   // g1 | g2 << 8
+  float gsol[MIR_MAX_GEOM][8];          // solref[2], solimp[5]
+  float btab[NB][8];                    // body_invweight0, dofmask lo, hi, block, root (contact finish)
 };
 static_assert(MIR_MAX_GEOM <= 256, "pair entries are 16 bits");
 static_assert(sizeof(Con64) >= 54 * 32 * sizeof(float), "box-box workspace lives in the contact arrays");
@@ -246,18 +248,22 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   float ib[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) ib[k] = m->b_inertia[bl][k];
-  const int d_body = isdof ? m->d_body[lane] : 0;
+  const int d_body = isdof ? m->d_body[lane] : 0;  // (lanemask is a scalar; the load itself is unconditional in effect)
   const int d_kind = m->d_kind[lane], d_qadr = m->d_qadr[lane], d_axis_k = m->d_axis_k[lane];
-  const int d_root = m->b_root[d_body];
-  const V3 d_axis = ld3(m->b_axis[d_body]);
+  const int d_root = m->d_root[lane];
+  const V3 d_axis = ld3(m->d_axis[lane]);
   const uint64_t d_premask = m->d_premask[lane], d_ancmask = m->d_ancmask[lane];
-  const uint32_t d_submask = m->b_submask[d_body];
+  const uint32_t d_submask = m->d_bsubmask[lane];
   const int d_ctrl = m->d_ctrl[lane], d_uadr = m->d_uadr[lane];
   const bool d_limited = isdof && m->d_limited[lane] && m->enable_joint_limit;
   const float d_damping = m->d_damping[lane], d_kp = m->d_kp[lane], d_kv = m->d_kv[lane];
   const float d_frclo = m->d_frclo[lane], d_frchi = m->d_frchi[lane], d_mdiag = m->d_mdiag[lane];
-  const int d_qbase = m->b_qadr[d_body], d_lbase = m->b_dofadr[d_body];
+  const int d_qbase = m->d_qbase[lane], d_lbase = m->d_lbase[lane];
   const float d_lo = m->d_lo[lane], d_hi = m->d_hi[lane];
+  // joint-limit row constants (used only while the limit is violated, but then inside the step's critical path)
+  const float d_iw0 = m->d_invweight0[lane], d_lk = m->d_k[lane], d_lb = m->d_b[lane];
+  const float d_si0 = m->d_solimp[lane][0], d_si1 = m->d_solimp[lane][1], d_si2 = m->d_solimp[lane][2], d_si3 = m->d_solimp[lane][3], d_si4 = m->d_solimp[lane][4];
+  const int obs_qadr = m->obs_qadr[lane];
   // lane = geom: frame in its body, staged tables
   const int gl = lane < ngeom ? lane : 0;
   const int g_bodyl = m->g_body[gl];
@@ -268,6 +274,14 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     S.gfr[lane] = m->g_pos[lane][3];
   }
   for (int p = lane; p < npair; p += NL) S.pairs[p] = (unsigned short)m->pair[p];
+  if (lane < ngeom) {
+    const f4* gs = reinterpret_cast<const f4*>(m->g_sol[lane]);
+    stv(&S.gsol[lane][0], gs[0]); stv(&S.gsol[lane][4], gs[1]);
+  }
+  if (lane < NB) {
+    const f4* bt = reinterpret_cast<const f4*>(m->b_tab[lane]);
+    stv(&S.btab[lane][0], bt[0]); stv(&S.btab[lane][4], bt[1]);
+  }
 
   STAMP(0);
   // ---- load state -----------------------------------------------------------------------------
@@ -276,7 +290,11 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   S.qacc_ws[lane] = a.qacc_ws[(size_t)env * NL + lane];
   {
     float tg = a.target[(size_t)env * NL + lane];
-    if (a.action && isdof && d_uadr >= 0) tg = a.action[(size_t)env * m->nu + d_uadr];
+    if (a.action) {  // lane u fetches action component u; the dof it drives picks it up across the wave
+      const float au = lane < a.nu ? a.action[(size_t)env * a.nu + lane] : 0.0f;
+      const float mine = __shfl(au, d_uadr >= 0 ? d_uadr : 0);
+      if (isdof && d_uadr >= 0) tg = mine;
+    }
     S.target[lane] = tg;
   }
   if (lane < NB) S.parent[lane] = lane < nb ? m->b_parent[lane] : 0;
@@ -285,12 +303,14 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
 
   // ======================= forward kinematics (FK cache as in the 16-lane kernel) ====================
   {
+    // the cached poses are fetched together with their validity flag ((B, 2, 32, 4): the speculative read is in bounds)
+    const float* p = a.poses + ((size_t)env * 2 * NB + (lane & (NB - 1))) * 4;
+    const f4 cpos = *reinterpret_cast<const f4*>(p), cquat = *reinterpret_cast<const f4*>(p + 4 * NB);
     const bool cached = a.fkvalid[env] != 0;  // wave-uniform
     if (cached) {
       if (lane < nb) {
-        const float* p = a.poses + ((size_t)env * 2 * NB + lane) * 4;
-        stv(S.xpos[lane], *reinterpret_cast<const f4*>(p));
-        stv(S.xquat[lane], *reinterpret_cast<const f4*>(p + 4 * NB));
+        stv(S.xpos[lane], cpos);
+        stv(S.xquat[lane], cquat);
       }
       WSYNC();
     } else {
@@ -313,10 +333,11 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   };
   auto column = [&](int c) -> float {
     if (c < ad) {
-      if (m->agent_mode == MIR_AGENT_QPOS) return S.qpos[m->arm_qadr[c]];
+      // (every caller asks for its own lane's column: the qpos address comes from the lane constants, no model trip)
+      if (m->agent_mode == MIR_AGENT_QPOS) return S.qpos[c == lane ? obs_qadr : m->arm_qadr[c]];
       if (c < 3) return S.xpos[eb][c];
       if (c < 7) return S.xquat[eb][c - 3];
-      return S.qpos[m->grip_qadr[c - 7]];
+      return S.qpos[c == lane ? obs_qadr : m->grip_qadr[c - 7]];
     }
     const int k = c - ad;
     if (k < 3) return S.xpos[ob][k];
@@ -331,7 +352,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   for (int step = 0; step < nsteps; step++) {
     // rollout mode (mir_rollout): a fresh action block per step
     if (step > 0 && a.action && a.act_step) {
-      if (isdof && d_uadr >= 0) S.target[lane] = a.action[(size_t)step * a.act_step + (size_t)env * m->nu + d_uadr];
+      if (isdof && d_uadr >= 0) S.target[lane] = a.action[(size_t)step * a.act_step + (size_t)env * a.nu + d_uadr];
     }
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
     if (isdof) {
@@ -676,19 +697,21 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
         const V3 t2 = cross(n, t1);
         const float mu = fmaxf(S.gfr[g1], S.gfr[g2]);
-        const float* s1 = m->g_sol[g1];
-        const float* s2 = m->g_sol[g2];
+        const float* s1 = S.gsol[g1];
+        const float* s2 = S.gsol[g2];
         const float sr0 = 0.5f * (s1[0] + s2[0]), sr1 = 0.5f * (s1[1] + s2[1]);
         const float si[5] = {0.5f * (s1[2] + s2[2]), 0.5f * (s1[3] + s2[3]), 0.5f * (s1[4] + s2[4]), 0.5f * (s1[5] + s2[5]), 0.5f * (s1[6] + s2[6])};
         const int b1 = __float_as_int(S.gts[g1][0]) >> 8, b2 = __float_as_int(S.gts[g2][0]) >> 8;
-        const float wsumw = m->b_invweight0[b1] + m->b_invweight0[b2];
+        const f4 bt1 = ldv(&S.btab[b1][0]), bt2 = ldv(&S.btab[b2][0]);
+        const float wsumw = bt1.x + bt2.x;
         const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
         const float tc = fmaxf(sr0, 2.0f * dt);
         const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
-        const uint64_t dm1 = m->b_dofmask[b1], dm2 = m->b_dofmask[b2];
-        const int k1 = m->b_block[b1], k2 = m->b_block[b2];
+        const uint64_t dm1 = (uint64_t)__float_as_uint(bt1.y) | ((uint64_t)__float_as_uint(bt1.z) << 32);
+        const uint64_t dm2 = (uint64_t)__float_as_uint(bt2.y) | ((uint64_t)__float_as_uint(bt2.z) << 32);
+        const int k1 = __float_as_int(bt1.w), k2 = __float_as_int(bt2.w);
         const int sg0 = k1 >= 0 ? k1 : k2, sg1 = (k1 >= 0 && k2 >= 0 && k2 != k1) ? k2 : -1;
-        const V3 ref1 = ld3v(S.xpos[m->b_root[b1]]), ref2 = ld3v(S.xpos[m->b_root[b2]]);
+        const V3 ref1 = ld3v(S.xpos[__float_as_int(S.btab[b1][4])]), ref2 = ld3v(S.xpos[__float_as_int(S.btab[b2][4])]);
         const f4 pd = ldv(S.col.stage[cl][ci]);
         const float dist = pd.w;
         stv(S.con.cpos[k], pd);
@@ -750,11 +773,10 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       if (dlo < 0.0f) { pos = dlo; lsg = 1.0f; }
       else if (dhi < 0.0f) { pos = dhi; lsg = -1.0f; }
       if (lsg != 0.0f) {
-        const float* si = m->d_solimp[lane];
-        float imp = impedance(si[0], si[1], si[2], si[3], si[4], pos);
-        float Rr = fmaxf((1.0f - imp) / imp * m->d_invweight0[lane], 1e-15f);
+        float imp = impedance(d_si0, d_si1, d_si2, d_si3, d_si4, pos);
+        float Rr = fmaxf((1.0f - imp) / imp * d_iw0, 1e-15f);
         lD = 1.0f / Rr;
-        laref = -m->d_b[lane] * (lsg * S.qvel[lane]) - m->d_k[lane] * imp * pos;
+        laref = -d_lb * (lsg * S.qvel[lane]) - d_lk * imp * pos;
       }
     }
     WSYNC();
