@@ -150,7 +150,7 @@ __device__ __forceinline__ void imul(const Inert& I, V3 w, V3 v, V3& t, V3& f) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// narrowphase primitives (one lane per candidate pair)
+// narrowphase primitives (one DPP row per candidate pair)
 struct BoxG {
   V3 p;
   V3 a0, a1, a2;  // world axes
@@ -168,160 +168,55 @@ __device__ __forceinline__ float bh(const BoxG& b, int k) {
   return k == 0 ? hx : (k == 1 ? hy : hz);
 }
 
-// box-box by separating axes + reference-face clipping; normal from A to B; up to 8 points.
-// Rare (only when bounding spheres overlap) and register-hungry: kept out of line.
-// Polygon workspace of the clipping stage (6 arrays x 9 floats, dynamically indexed).  PolyScratch keeps it in
-// private memory (the 16-lane kernel: the routine is rare there and its LDS is full); PolyLds places element k of this
-// lane at base[k * 32] (32 lanes at a time), a lane-interleaved, bank-conflict-free LDS area (the wave kernel runs the routine every step
-// for the cube-slab pairs, where scratch round trips dominated).
-struct PolyScratch {
-  float a[6][9];
-  __device__ __forceinline__ float& at(int arr, int i) { return a[arr][i]; }
-};
-struct PolyLds {
-  float* base;  // already offset by the lane index
-  __device__ __forceinline__ float& at(int arr, int i) { return base[(arr * 9 + i) * 32]; }
-};
-// Sutherland-Hodgman clipping of the incident-face polygon (4 vertices in P arrays 0..2, reference-face coordinates)
-// against the four edges of the reference face, then the penetrating vertices (up to 8) in world coordinates
-template <class Poly>
-__device__ __forceinline__ int clip_ref_face(Poly P, float h1, float h2, V3 fc, V3 e1, V3 e2, V3 nr, float (*out)[4]) {
+// Sutherland-Hodgman clipping of the incident face against the four edges of the reference face, on a DPP row: lane v
+// holds vertex v of the polygon (reference-face coordinates x, y and height z; 4 vertices on entry, at most 8 later).
+// Per edge every lane emits its vertex if it is inside and the edge crossing towards its successor, at the slots an
+// exclusive prefix sum over the row assigns (the order of the sequential algorithm); the new polygon travels through
+// ex (3 x 16 floats of LDS owned by this row).  Returns the vertex count (row-uniform); vertices in x, y, z again.
+__device__ __forceinline__ int clip_row(float& x, float& y, float& z, float h1, float h2, int l16, int wlane, float* ex) {
   int np = 4;
+  const int rowbase = wlane & ~15;
+#pragma unroll 1
   for (int e = 0; e < 4; e++) {
     const int ax = e >> 1;
     const float sg = (e & 1) ? -1.0f : 1.0f;
     const float lim = ax == 0 ? h1 : h2;
-    int nn = 0;
-    for (int v = 0; v < np; v++) {
-      int w = v + 1 == np ? 0 : v + 1;
-      float pc = ax == 0 ? P.at(0, v) : P.at(1, v), qc = ax == 0 ? P.at(0, w) : P.at(1, w);
-      float dp = sg * pc - lim, dq = sg * qc - lim;
-      if (dp <= 0.0f && nn < 9) { P.at(3, nn) = P.at(0, v); P.at(4, nn) = P.at(1, v); P.at(5, nn) = P.at(2, v); nn++; }
-      if ((dp <= 0.0f) != (dq <= 0.0f) && nn < 9) {
-        float u = dp / (dp - dq);
-        P.at(3, nn) = P.at(0, v) + u * (P.at(0, w) - P.at(0, v)); P.at(4, nn) = P.at(1, v) + u * (P.at(1, w) - P.at(1, v)); P.at(5, nn) = P.at(2, v) + u * (P.at(2, w) - P.at(2, v));
-        nn++;
-      }
+    const int succ = rowbase + (l16 + 1 >= np ? 0 : l16 + 1);
+    const float xs = __shfl(x, succ), ys = __shfl(y, succ), zs = __shfl(z, succ);
+    const float pc = ax == 0 ? x : y, qc = ax == 0 ? xs : ys;
+    const float dp = sg * pc - lim, dq = sg * qc - lim;
+    const bool act = l16 < np;
+    const bool keep = act && dp <= 0.0f, crs = act && ((dp <= 0.0f) != (dq <= 0.0f));
+    const float mine = (keep ? 1.0f : 0.0f) + (crs ? 1.0f : 0.0f);
+    float incl = mine;
+    incl += row_shr<1>(incl);
+    incl += row_shr<2>(incl);
+    incl += row_shr<4>(incl);
+    incl += row_shr<8>(incl);
+    const int off = (int)(incl - mine);
+    np = (int)row_bcast<15>(incl);
+    if (np == 0) return 0;  // row-uniform
+    if (keep) { ex[off] = x; ex[16 + off] = y; ex[32 + off] = z; }
+    if (crs) {
+      const float u = dp / (dp - dq);
+      const int o2 = off + (keep ? 1 : 0);
+      ex[o2] = x + u * (xs - x); ex[16 + o2] = y + u * (ys - y); ex[32 + o2] = z + u * (zs - z);
     }
-    np = nn;
-    for (int v = 0; v < np; v++) { P.at(0, v) = P.at(3, v); P.at(1, v) = P.at(4, v); P.at(2, v) = P.at(5, v); }
-    if (np == 0) return 0;
+    WSYNC();
+    x = ex[l16]; y = ex[16 + l16]; z = ex[32 + l16];
+    WSYNC();
   }
-  int cnt = 0;
-  for (int v = 0; v < np && cnt < 8; v++) {
-    if (P.at(2, v) < 0.0f) {
-      V3 w = fc + P.at(0, v) * e1 + P.at(1, v) * e2 + (0.5f * P.at(2, v)) * nr;
-      out[cnt][0] = w.x; out[cnt][1] = w.y; out[cnt][2] = w.z; out[cnt][3] = P.at(2, v);
-      cnt++;
-    }
-  }
-  return cnt;
-}
-template <class Poly>
-__device__ __noinline__ int box_box(const BoxG& A, const BoxG& B, float (*out)[4], V3& nout, Poly P) {
-  V3 t = B.p - A.p;
-  float best = -1e30f;
-  int code = -1;
-  V3 bestL = v3(0, 0, 1);
-#pragma unroll
-  for (int c = 0; c < 6; c++) {
-    V3 L = c < 3 ? bax(A, c) : bax(B, c - 3);
-    float ra = A.h.x * fabsf(dot(A.a0, L)) + A.h.y * fabsf(dot(A.a1, L)) + A.h.z * fabsf(dot(A.a2, L));
-    float rb = B.h.x * fabsf(dot(B.a0, L)) + B.h.y * fabsf(dot(B.a1, L)) + B.h.z * fabsf(dot(B.a2, L));
-    float s = fabsf(dot(t, L)) - (ra + rb);
-    if (s > 0.0f) return 0;
-    if (s > best) { best = s; code = c; bestL = L; }
-  }
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      V3 L = cross(bax(A, i), bax(B, j));
-      float len = sqrtf(dot(L, L));
-      if (len < 1e-3f) continue;
-      L = (1.0f / len) * L;
-      float ra = A.h.x * fabsf(dot(A.a0, L)) + A.h.y * fabsf(dot(A.a1, L)) + A.h.z * fabsf(dot(A.a2, L));
-      float rb = B.h.x * fabsf(dot(B.a0, L)) + B.h.y * fabsf(dot(B.a1, L)) + B.h.z * fabsf(dot(B.a2, L));
-      float s = fabsf(dot(t, L)) - (ra + rb);
-      if (s > 0.0f) return 0;
-      if (s * 1.05f > best && s > best + 1e-6f) { best = s; code = 6 + i * 3 + j; bestL = L; }
-    }
-  V3 n = dot(t, bestL) < 0.0f ? -1.0f * bestL : bestL;
-  nout = n;
-  if (code >= 6) {
-    int i = (code - 6) / 3, j = (code - 6) % 3;
-    V3 PA = A.p, PB = B.p;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      if (k != i) PA = PA + (dot(n, bax(A, k)) > 0.0f ? bh(A, k) : -bh(A, k)) * bax(A, k);
-      if (k != j) PB = PB + (dot(n, bax(B, k)) > 0.0f ? -bh(B, k) : bh(B, k)) * bax(B, k);
-    }
-    V3 ua = bax(A, i), ub = bax(B, j), dd = PB - PA;
-    float uaub = dot(ua, ub), q1 = dot(ua, dd), q2 = -dot(ub, dd), den = 1.0f - uaub * uaub;
-    float alpha = 0.0f, beta = 0.0f;
-    if (den > 1e-6f) { alpha = (q1 + uaub * q2) / den; beta = (uaub * q1 + q2) / den; }
-    PA = PA + alpha * ua;
-    PB = PB + beta * ub;
-    V3 pos = 0.5f * (PA + PB);
-    out[0][0] = pos.x; out[0][1] = pos.y; out[0][2] = pos.z; out[0][3] = best;
-    return 1;
-  }
-  const bool refA = code < 3;
-  const BoxG& R = refA ? A : B;
-  const BoxG& I = refA ? B : A;
-  int k = refA ? code : code - 3;
-  V3 nr = refA ? n : -1.0f * n;
-  int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-  V3 fc = R.p + bh(R, k) * nr;
-  float a0 = fabsf(dot(nr, I.a0)), a1 = fabsf(dot(nr, I.a1)), a2 = fabsf(dot(nr, I.a2));
-  int jb = 0;
-  float mx = a0;
-  if (a1 > mx) { mx = a1; jb = 1; }
-  if (a2 > mx) { mx = a2; jb = 2; }
-  float sj = dot(nr, bax(I, jb)) > 0.0f ? -1.0f : 1.0f;
-  int j1 = (jb + 1) % 3, j2 = (jb + 2) % 3;
-  V3 ic = I.p + (sj * bh(I, jb)) * bax(I, jb);
-  V3 e1 = bax(R, k1), e2 = bax(R, k2);
-  float h1 = bh(R, k1), h2 = bh(R, k2);
-  {
-    const float sx[4] = {1, -1, -1, 1}, sy[4] = {1, 1, -1, -1};
-    float vx[4], vy[4], vz[4];
-    bool inside = true;
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-      V3 w = ic + (sx[v] * bh(I, j1)) * bax(I, j1) + (sy[v] * bh(I, j2)) * bax(I, j2);
-      V3 rel = w - fc;
-      vx[v] = dot(rel, e1); vy[v] = dot(rel, e2); vz[v] = dot(rel, nr);
-      inside = inside && fabsf(vx[v]) <= h1 && fabsf(vy[v]) <= h2;
-    }
-    if (inside) {
-      // the whole incident face lies over the reference face (a cube resting on the slab): clipping against the four
-      // edges would hand back the same four vertices in the same order, so emit them from registers
-      int cnt = 0;
-#pragma unroll
-      for (int v = 0; v < 4; v++)
-        if (vz[v] < 0.0f) {
-          V3 w = fc + vx[v] * e1 + vy[v] * e2 + (0.5f * vz[v]) * nr;
-          out[cnt][0] = w.x; out[cnt][1] = w.y; out[cnt][2] = w.z; out[cnt][3] = vz[v];
-          cnt++;
-        }
-      return cnt;
-    }
-#pragma unroll
-    for (int v = 0; v < 4; v++) { P.at(0, v) = vx[v]; P.at(1, v) = vy[v]; P.at(2, v) = vz[v]; }
-  }
-  return clip_ref_face(P, h1, h2, fc, e1, e2, nr, out);
+  return np;
 }
 
 // Box-box on a whole DPP row: every lane of the row calls this with the same pair.  The 15 separating axes sit on
 // lanes 0..14; the axis choice replays the sequential rule of box_box on row broadcasts, so both routines pick the same
-// feature; the four incident-face vertices sit on lanes 0..3, and only a partially overlapping face pair falls back to
-// lane 0 walking the clipping loops on the polygon workspace P.  Returns the contact count in every lane of the row;
+// feature; the four incident-face vertices sit on lanes 0..3, and a partially overlapping face pair is clipped on the
+// row as well (clip_row; ex = 48 floats of LDS owned by this row).  Returns the contact count in every lane of the row;
 // points go to out[0..cnt), the normal (A to B) to snorm.  l16 = lane in the row, wlane = lane in the wave,
-// rowshift = bit position of the row in a wave ballot.
+// rowshift = bit position of the row in a wave ballot.  Same algorithm as oracle/orc_rigid.c (sequential there).
 __device__ __forceinline__ V3 selv(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
-template <class Poly>
-__device__ __forceinline__ int box_box_row(const BoxG& A, const BoxG& B, int l16, int wlane, int rowshift, float (*out)[4], float* snorm, Poly P) {
+__device__ __forceinline__ int box_box_row(const BoxG& A, const BoxG& B, int l16, int wlane, int rowshift, float (*out)[4], float* snorm, float* ex) {
   const V3 t = B.p - A.p;
   // ---- lane = axis: faces of A (0..2), faces of B (3..5), edge pairs i x j (6 + 3 i + j)
   const int ax = l16;
@@ -407,17 +302,17 @@ __device__ __forceinline__ int box_box_row(const BoxG& A, const BoxG& B, int l16
           stv(out[__popc(penm & ((1u << l16) - 1u))], f4{wp.x, wp.y, wp.z, vz});
         }
       } else {
-        // partial overlap: lane 0 gathers the four vertices and walks the clipping loops on its polygon workspace
-        const float gx0 = row_bcast<0>(vx), gx1 = row_bcast<1>(vx), gx2 = row_bcast<2>(vx), gx3 = row_bcast<3>(vx);
-        const float gy0 = row_bcast<0>(vy), gy1 = row_bcast<1>(vy), gy2 = row_bcast<2>(vy), gy3 = row_bcast<3>(vy);
-        const float gz0 = row_bcast<0>(vz), gz1 = row_bcast<1>(vz), gz2 = row_bcast<2>(vz), gz3 = row_bcast<3>(vz);
-        if (l16 == 0) {
-          P.at(0, 0) = gx0; P.at(0, 1) = gx1; P.at(0, 2) = gx2; P.at(0, 3) = gx3;
-          P.at(1, 0) = gy0; P.at(1, 1) = gy1; P.at(1, 2) = gy2; P.at(1, 3) = gy3;
-          P.at(2, 0) = gz0; P.at(2, 1) = gz1; P.at(2, 2) = gz2; P.at(2, 3) = gz3;
-          cnt = clip_ref_face(P, h1, h2, fc, e1, e2, nr, out);
+        // partial overlap: clip the incident face on the row, then emit the penetrating vertices (at most 8) in order
+        float px = vx, py = vy, pz = vz;
+        const int np = clip_row(px, py, pz, h1, h2, l16, wlane, ex);
+        const bool pen = l16 < np && pz < 0.0f;
+        const unsigned penm = (unsigned)(__ballot(pen) >> rowshift) & 0xffffu;
+        const int slot = __popc(penm & ((1u << l16) - 1u));
+        cnt = min(__popc(penm), 8);
+        if (pen && slot < 8) {
+          const V3 wp = fc + px * e1 + py * e2 + (0.5f * pz) * nr;
+          stv(out[slot], f4{wp.x, wp.y, wp.z, pz});
         }
-        cnt = (int)row_bcast<0>((float)cnt);
       }
     }
   }

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
           const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
           const BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
           const BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
-          const int cnt = box_box_row(B1, B2, lane, tid, grp * G, S.col.stage[k], S.col.snorm[k], PolyScratch());
+          const int cnt = box_box_row(B1, B2, lane, tid, grp * G, S.col.stage[k], S.col.snorm[k], reinterpret_cast<float*>(&S.con));  // (contact arrays: not written yet)
           if (lane == k) mycount = cnt;
         }
       }

@@ -143,7 +143,7 @@ struct Env64 {
     Col64 col;
     float Jb[MAXC][2][JSEG];
   };
-  Con64 con;          // (before the contacts are finished: the box-box clipping workspace, 32 lanes at a time)
+  Con64 con;          // (before the contacts are finished: the box-box clipping exchange, 48 floats per DPP row)
   // the few model tables that are looked up with a DYNAMIC index inside the collision phases, staged once per launch:
   // an LDS round trip (~64 cycles) instead of an L2 one per dependent hop (there is no room for the whole model)
   float gts[MIR_MAX_GEOM][4];           // type | body << 8 (as int bits), half extents
@@ -153,7 +153,7 @@ struct Env64 {
   float btab[NB][8];                    // body_invweight0, dofmask lo, hi, block, root (contact finish)
 };
 static_assert(MIR_MAX_GEOM <= 256, "pair entries are 16 bits");
-static_assert(sizeof(Con64) >= 54 * 32 * sizeof(float), "box-box workspace lives in the contact arrays");
+static_assert(sizeof(Con64) >= 4 * 48 * sizeof(float), "the box-box clipping exchange lives in the contact arrays");
 
 struct BodyK64 {
   int jtype, qadr;
@@ -643,9 +643,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       mycount = S.col.ccount[lane];
       STAMP(7);
       // narrowphase, box-box: DPP row r takes candidates r, r + 4, ... (like plane-box).  The 15 separating axes sit on
-      // lanes 0..14 of the row; the axis choice replays the sequential rule of box_box (mir_dev.h) on row broadcasts, so
-      // the two kernels pick the same feature; the four incident-face vertices sit on lanes 0..3.  Only a partially
-      // overlapping face pair falls back to one lane walking the clipping loops (LDS polygon workspace per row).
+      // lanes 0..14 of the row, the incident-face vertices on lanes 0..3 (box_box_row, mir_dev.h)
       for (int k0 = 0; k0 < ncand; k0 += 4) {
         const int k = k0 + blk;
         const bool actk = k < ncand;
@@ -657,7 +655,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
           const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
           const BoxG A = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(&S.gts[g1][1])};
           const BoxG B = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(&S.gts[g2][1])};
-          const int cnt = box_box_row(A, B, l16, lane, blk * G, S.col.stage[k], S.col.snorm[k], PolyLds{reinterpret_cast<float*>(&S.con) + blk});
+          const int cnt = box_box_row(A, B, l16, lane, blk * G, S.col.stage[k], S.col.snorm[k], reinterpret_cast<float*>(&S.con) + 48 * blk);  // (contact arrays: not written yet)
           if (l16 == 0) S.col.ccount[k] = cnt;
         }
       }
