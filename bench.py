@@ -163,7 +163,7 @@ def stack_bench(dev, steps: int = 300):
             "mean_contacts": ncon, "mean_newton_iterations": niter,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "mir_step64_kernel",
-                         "note": "1109 algorithmic B/env-step; one wave per env, 3 envs per CU: latency/occupancy-bound like the pick kernel"}}
+                         "note": "1109 algorithmic B/env-step; one wave per env, 4 envs per CU: latency/occupancy-bound like the pick kernel"}}
 
 
 def ik_bench(dev, calls: int = 200):
