@@ -112,12 +112,95 @@ def pixels_bench(dev, renders: int = 30):
         pass
     del out, env
     torch.cuda.empty_cache()
+    # reduced-resolution variant reported alongside: 96x128 images for 4096 envs
+    Bs, Hs, Ws = ENVS_PER_GPU, 96, 128
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=Bs, enable_pixels=True, observation_height=Hs, observation_width=Ws,
+                     camera_capture_mode="per_env")
+    env.reset(seed=0)
+    small = torch.empty((Bs, Hs, Ws, 3), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        env._env.cam.render_envs(out=small)
+    torch.cuda.synchronize(dev)
+    ev0.record()
+    for _ in range(renders):
+        env._env.cam.render_envs(out=small)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us_small = ev0.elapsed_time(ev1) * 1e3 / renders
+    del small, env
+    torch.cuda.empty_cache()
     return {"workload": "CubePick-v0 robot=franka enable_pixels=True per_env 480x640 RGB8, num_envs=1024 (BASELINE configs[4])",
             "env_frames_per_s": B / (us * 1e-6), "us_per_render": us, "dtype": "u8 out / f32 rays",
+            "reduced_96x128_num_envs_4096": {"env_frames_per_s": Bs / (us_small * 1e-6), "us_per_render": us_small,
+                                             "GBps": Bs * Hs * Ws * 3 / (us_small * 1e-6) / 1e9},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "mir_render_kernel",
                          "note": "algorithmic bytes = 1024x480x640x3 written once per render; time = whole mir_render call "
                                  "(FK refresh + primitive setup + pixel kernel), HIP events"}}
+
+
+def grasp_bench(dev):
+    """Secondary (SURVEY.md 8d, config 2's scripted-grasp scenario): the reference's expert pick -- five stages of 40 steps
+    (examples/franka/pick_cube_state.py:86-88), joint-space targets precomputed by this repo's batched IK from the reset
+    state -- on 4096 envs, so finger-pad/cube box-box contacts, friction, the arm-cube coupling in the Newton system and
+    terminated=True are all exercised.  One fused launch per step, HIP events on the launching stream."""
+    from gym_genesis.env import GenesisEnv
+
+    B = ENVS_PER_GPU
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
+    obs, _ = env.reset(seed=0)
+    task = env._env
+    robot, cube = env.get_robot(), obs["environment_state"][:, :3].clone()
+    eef = robot.get_link("hand")
+    quat = torch.tensor([0.0, 1.0, 0.0, 0.0], device=dev).repeat(B, 1)
+    stages = [(0.25, 0.04), (0.104, 0.04), (0.104, 0.0), (0.104, 0.0), (0.40, 0.0)]
+    targets, q_prev = [], None
+    for dz, grip in stages:
+        q = robot.inverse_kinematics(link=eef, pos=cube + torch.tensor([0.0, 0.0, dz], device=dev), quat=quat, init_qpos=q_prev)
+        q_prev = q
+        targets.append(torch.cat([q[:, :7], torch.full((B, 2), grip, device=dev)], 1).contiguous())
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ncon_max = 0
+    ev0.record()
+    for tg in targets:
+        for _ in range(40):
+            task.step_raw(tg)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us = ev0.elapsed_time(ev1) * 1e3 / 200
+    success = float((task._reward == 1).float().mean().item())
+    ncon_max = int(task._mir.get_diag()[0].max().item())
+    del env
+    return {"workload": "CubePick-v0 robot=franka scripted pick (hover, stabilize, grasp, grasp, lift; 5 x 40 steps; IK-precomputed joint "
+                        "targets), num_envs=4096", "env_steps_per_s": B / (us * 1e-6), "us_per_step": us, "lifted_frac": success,
+            "max_contacts_last_step": ncon_max}
+
+
+def so101_bench(dev, steps: int = 400):
+    """Secondary (BASELINE configs[3] / SURVEY.md 8d config 4): SO-101 cube-pick (6 arm dofs, cube on the kitchen slab: box-box
+    contact every step) at 4096 envs, U(-1,1) joint targets around the rest pose."""
+    from gym_genesis.env import GenesisEnv
+
+    B = ENVS_PER_GPU
+    env = GenesisEnv(task="cube_pick", robot="so101", num_envs=B, enable_pixels=False)
+    env.reset(seed=0)
+    task = env._env
+    gen = torch.Generator(device=dev).manual_seed(77)
+    acts = torch.empty((256, B, task._zero.shape[1]), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
+    for t in range(20):
+        task.step_raw(acts[t])
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for t in range(steps):
+        task.step_raw(acts[t % 256])
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us = ev0.elapsed_time(ev1) * 1e3 / steps
+    del env
+    return {"workload": "CubePick-v0 robot=so101 (12 dofs, cube on the slab) state-only obs, U(-1,1) joint targets, num_envs=4096",
+            "env_steps_per_s": B / (us * 1e-6), "us_per_step": us}
 
 
 def stack_bench(dev, steps: int = 300):
@@ -336,6 +419,16 @@ def main():
         torch.cuda.synchronize(dev)
         np_rate = api_steps * B * world / (time.perf_counter() - t1b)
 
+    # physics only: mir_step without the observation / reward outputs, PD targets unchanged
+    phys_rate = None
+    if api_steps:
+        torch.cuda.synchronize(dev)
+        t1c = time.perf_counter()
+        for t in range(api_steps):
+            task._mir.step(1)
+        torch.cuda.synchronize(dev)
+        phys_rate = api_steps * B * world / (time.perf_counter() - t1c)
+
     # device-resident episode loop: fused step + on-device truncation/termination/re-spawn, no host sync
     if api_steps:
         task.enable_autoreset(max_episode_steps=EPISODE_STEPS)
@@ -405,6 +498,7 @@ def main():
                          "note": "489 algorithmic B/env-step x 4096 envs per launch; the path is latency/occupancy-bound, not HBM-bound (SURVEY.md 8d)"},
             "env_step_api_rate": api_rate,
             "env_step_api_numpy_actions_rate": np_rate,
+            "physics_only_rate": phys_rate,
             "device_autoreset_loop_rate": loop_rate,
             "device_rollout16_rate": rollout_rate,
             "device_autoreset_rollout16_rate": loop_rollout_rate,
@@ -412,6 +506,8 @@ def main():
         if world == 1 and not args.no_pixels:
             out["pixels"] = pixels_bench(dev)
         if world == 1 and not args.no_stack:
+            out["scripted_grasp"] = grasp_bench(dev)
+            out["so101_pick"] = so101_bench(dev)
             out["stack"] = stack_bench(dev)
             out["ik"] = ik_bench(dev)
         if world == 1 and not args.no_cpu_baseline:
