@@ -48,10 +48,6 @@ inline int nblk(long n) { return (int)((n + TPB - 1) / TPB); }
 // ---- plumbing kernels: 64 threads per env, thread c = compact dof / qpos column c.  Both step kernels are
 // served through the PlumbTab maps (16-lane kernel: lane == dof, rows of 16; wave kernel: lane map, rows of 64).
 constexpr int PW = 64;
-__global__ void k_iota(int32_t* out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = i;
-}
 __global__ void k_fill_rows(float* dst, const float* row, int stride, int B) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (long)B * stride) dst[i] = row[i % stride];
@@ -202,14 +198,6 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
     a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
-    if (o.mode == 0 && !o.prof && h->B > 1024) {  // more envs than one round of waves: dispatch last step's long envs first
-      const int p = h->order_parity;
-      a.order_in = h->order + (size_t)p * h->B;
-      a.order_out = h->order + (size_t)(1 - p) * h->B;
-      a.cnt_out = h->order + 2 * (size_t)h->B + 2 * (1 - p);
-      a.cnt_zero = h->order + 2 * (size_t)h->B + 2 * p;
-      h->order_parity = 1 - p;
-    }
     rc = mir_launch_step64(&a, (hipStream_t)stream);
   }
   if (rc != 0) return hip_fail((hipError_t)rc, "step kernel launch");
@@ -342,11 +330,6 @@ int mir_create(const MirSceneSpec* spec, int32_t num_envs, int32_t device_id, Mi
   HIPCHK(hipMemset(h->diag, 0, B * 4 * sizeof(int32_t)));
   HIPCHK(hipMemset(h->poses, 0, B * 2 * pst * 4 * sizeof(float)));
   HIPCHK(hipMemset(h->fkvalid, 0, B * sizeof(int32_t)));
-  if (h->kernel == 64) {
-    HIPCHK(hipMalloc((void**)&h->order, (2 * B + 4) * sizeof(int32_t)));
-    HIPCHK(hipMemset(h->order, 0, (2 * B + 4) * sizeof(int32_t)));
-    hipLaunchKernelGGL(k_iota, dim3(nblk((long)B)), dim3(TPB), 0, 0, h->order, num_envs);
-  }
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipFree(drow));
   *out = h;
@@ -367,7 +350,6 @@ int mir_destroy(MirHandle h) {
   if (h->diag) (void)hipFree(h->diag);
   if (h->poses) (void)hipFree(h->poses);
   if (h->fkvalid) (void)hipFree(h->fkvalid);
-  if (h->order) (void)hipFree(h->order);
   if (h->prims) (void)hipFree(h->prims);
   delete h;
   return MIR_OK;

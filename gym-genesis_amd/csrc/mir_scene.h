@@ -20,8 +20,6 @@ struct MirScene {
   GeomTab* dgeom;
   float *qpos, *qvel, *target, *qacc_ws, *poses;
   int32_t *diag, *fkvalid;
-  int32_t* order;   // wave kernel: launch order of the envs, (2, B) double-buffered + 4 counters (heavy envs first, see mir_step64.hip)
-  int order_parity; // which half the next stepping launch reads
   float* prims;     // render primitives (B, ngeom, 32) f32, allocated by the first mir_render
 };
 

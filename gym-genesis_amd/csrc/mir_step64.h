@@ -32,12 +32,6 @@ struct StepArgs64 {
   long act_step;   // floats between the action blocks of consecutive steps (rollout mode), 0 = one action for all steps
   long rows_step;  // floats between the row blocks of consecutive steps (rollout mode), 0 = only the final row
   AutoResetArgs ar;  // per-step episode bookkeeping + re-spawn inside the launch (rollout mode only)
-  // launch order (mode 0 only, all null otherwise): workgroup i serves env order_in[i]; every wave files its env for the NEXT
-  // launch -- envs whose Newton system was coupled (the long ones) from the front of order_out, the others from the back
-  const int32_t* order_in;
-  int32_t* order_out;
-  int32_t* cnt_out;   // [2]: heavy count, light count (zero at launch)
-  int32_t* cnt_zero;  // [2]: the counters of the launch after this one (zeroed here)
   int B;
   int nu;       // action width (copy of the model's: the action load does not wait for the model)
   int mode;     // 0: full steps; 1: forward dynamics only; 2: kinematics + outputs only

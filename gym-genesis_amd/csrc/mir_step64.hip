@@ -226,9 +226,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   const DevModel64* __restrict__ m = a.model;
   const int lane = threadIdx.x;
   const int blk = lane >> 4, l16 = lane & 15;
-  const int env = a.order_in ? a.order_in[blockIdx.x] : (int)blockIdx.x;  // grid = B exactly; order_in is a permutation
-  if (a.cnt_zero && blockIdx.x == 0 && lane < 2) a.cnt_zero[lane] = 0;
-  bool heavy = false;
+  const int env = blockIdx.x;  // grid = B exactly
 
   const int nb = m->nbody, nv = m->nv, nq = m->nq;
   const int ngeom = m->ngeom, npair = m->npair, max_contacts = m->max_contacts, enable_collision = m->enable_collision;
@@ -870,7 +868,6 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     // step (comp != identity: the arm touches a cube, or two cubes of different blocks touch).  The wave runs alone on its
     // SIMD (LDS bounds the occupancy), so the 80 registers are free and every update is FMA work without memory round trips.
     const bool coupled = comp != 0x8421u;
-    heavy = heavy || coupled;
     float hd[G], ho[4][G];
 #pragma unroll
     for (int j = 0; j < G; j++) {
@@ -1177,10 +1174,6 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
   }
   if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
-  if (a.order_out && lane == 0) {  // next launch: the long (coupled) envs leave first, so the launch does not end on one of them
-    const int pos = heavy ? atomicAdd(&a.cnt_out[0], 1) : a.B - 1 - atomicAdd(&a.cnt_out[1], 1);
-    a.order_out[pos] = env;
-  }
   if (a.rows && !(a.ar.episode_len && a.rows_step) && lane < ad + ed + 2)  // (in rollout mode: the last step's row; with autoreset: written in the loop)
     a.rows[(size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride + lane] = column(lane);
   if (a.out_xpos && lane < nb) {
