@@ -793,7 +793,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       float alpha = 0.0f, lo = 0.0f, hi = -1.0f, g0 = 0.0f;
       bool lsdone = done;
       for (int ls = 0; ls < m->ls_iterations; ls++) {
-        float pg = 0.0f, ph = 0.0f;
+        float pg = 0.0f, ph = 0.0f, pa = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const float x = jar[r] + alpha * jv[r];
@@ -804,15 +804,26 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
           if (x < 0.0f) { pg += lD * ljv * x; ph += lD * ljv * ljv; }
         }
         const float gg = gsum(pg) + alpha * A + Bq, hh = gsum(ph) + A;
+        // From the fifth evaluation on (rare) also the magnitude of the
+        // terms phi' is summed from: at the root they cancel and what is left is rounding noise of about an epsilon of
+        // that magnitude, which no evaluation can resolve (same rule as the oracle)
+        float floorg = 0.0f;
+        if (ls >= 4) {  // wave-uniform
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (jar[r] + alpha * jv[r] < 0.0f) pa += cD * fabsf(jv[r]) * (fabsf(jar[r]) + fabsf(alpha * jv[r]));
+          if (ljar + alpha * ljv < 0.0f) pa += lD * fabsf(ljv) * (fabsf(ljar) + fabsf(alpha * ljv));
+          floorg = 4.0f * 1.1920929e-7f * (gsum(pa) + fabsf(alpha * A) + fabsf(Bq));
+        }
         if (!lsdone) {
           if (ls == 0) { g0 = gg; if (g0 >= 0.0f) lsdone = true; }
-          if (!lsdone && fabsf(gg) <= 1e-6f * fabsf(g0)) lsdone = true;
+          if (!lsdone && fabsf(gg) <= fmaxf(1e-6f * fabsf(g0), floorg)) lsdone = true;
           if (!lsdone) {
             if (gg < 0.0f) lo = alpha; else hi = alpha;
             float an = alpha - gg / hh;
             if (hi >= 0.0f && (an <= lo || an >= hi)) an = 0.5f * (lo + hi);
             if (an == alpha) lsdone = true;
-            alpha = an;
+            if (!lsdone) alpha = an;
           }
         }
         if (!__any(!lsdone)) break;

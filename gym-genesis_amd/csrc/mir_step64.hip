@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       float alpha = 0.0f, lo = 0.0f, hi = -1.0f, g0 = 0.0f;
       bool lsdone = false;
       for (int ls = 0; ls < m->ls_iterations; ls++) {
-        float pg = 0.0f, ph = 0.0f;
+        float pg = 0.0f, ph = 0.0f, pa = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const float x = jar[r] + alpha * jv[r];
@@ -1027,14 +1027,23 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
           if (x < 0.0f) { pg += lD * ljv * x; ph += lD * ljv * ljv; }
         }
         const float gg = wsum(pg) + alpha * A + Bq, hh = wsum(ph) + A;
+        // (from the fifth evaluation on: termination at the resolution of the evaluation itself, see the 16-lane kernel)
+        float floorg = 0.0f;
+        if (ls >= 4) {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (jar[r] + alpha * jv[r] < 0.0f) pa += cD * fabsf(jv[r]) * (fabsf(jar[r]) + fabsf(alpha * jv[r]));
+          if (ljar + alpha * ljv < 0.0f) pa += lD * fabsf(ljv) * (fabsf(ljar) + fabsf(alpha * ljv));
+          floorg = 4.0f * 1.1920929e-7f * (wsum(pa) + fabsf(alpha * A) + fabsf(Bq));
+        }
         if (ls == 0) { g0 = gg; if (g0 >= 0.0f) lsdone = true; }
-        if (!lsdone && fabsf(gg) <= 1e-6f * fabsf(g0)) lsdone = true;
+        if (!lsdone && fabsf(gg) <= fmaxf(1e-6f * fabsf(g0), floorg)) lsdone = true;
         if (!lsdone) {
           if (gg < 0.0f) lo = alpha; else hi = alpha;
           float an = alpha - gg / hh;
           if (hi >= 0.0f && (an <= lo || an >= hi)) an = 0.5f * (lo + hi);
           if (an == alpha) lsdone = true;
-          alpha = an;
+          if (!lsdone) alpha = an;
         }
         if (lsdone) break;  // wave-uniform
       }

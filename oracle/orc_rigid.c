@@ -29,6 +29,13 @@
 #endif
 
 #define MINVAL ((real)1e-15)
+#ifdef ORC_F32
+#define REAL_EPS ((real)1.1920929e-7)
+#define LS_RELTOL ((real)1e-4) /* x ls_tolerance 0.01 = 1e-6 |phi'(0)|: the float32 kernels' rule */
+#else
+#define REAL_EPS ((real)2.220446049250313e-16)
+#define LS_RELTOL ((real)1e-6)
+#endif
 #define MINIMP ((real)0.0001)
 #define MAXIMP ((real)0.9999)
 #define F32(x) ((real)(float)(x)) /* the product stores model constants, dt and gravity in float32: same inputs */
@@ -701,13 +708,21 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
     real alpha = 0, lo = 0, hi = -1;
     real g0 = 0;
     for (int ls = 0; ls < m->opt.ls_iterations; ls++) {
-      real g = alpha * A + Bq, h = A;
+      /* phi'(alpha), phi''(alpha), and the magnitude of the terms phi' is summed from: at the root they cancel, and
+       * what is left is rounding noise of about an epsilon of that magnitude -- no evaluation can resolve phi' below it */
+      real g = alpha * A + Bq, h = A, gabs = (real)fabs((double)(alpha * A)) + (real)fabs((double)Bq);
       for (int r = 0; r < n; r++) {
         real x = jar[r] + alpha * jv[r];
-        if (x < 0) { g += d->efcD[r] * jv[r] * x; h += d->efcD[r] * jv[r] * jv[r]; }
+        if (x < 0) {
+          g += d->efcD[r] * jv[r] * x; h += d->efcD[r] * jv[r] * jv[r];
+          gabs += d->efcD[r] * (real)fabs((double)jv[r]) * ((real)fabs((double)jar[r]) + (real)fabs((double)(alpha * jv[r])));
+        }
       }
       if (ls == 0) { g0 = g; if (g0 >= 0) break; }
-      if ((real)fabs((double)g) <= (real)m->opt.ls_tolerance * (real)fabs((double)g0) * (real)1e-6 + MINVAL) break;
+      {
+        real tolg = (real)m->opt.ls_tolerance * (real)fabs((double)g0) * LS_RELTOL, floorg = ls >= 4 ? 4 * REAL_EPS * gabs : 0; /* (from the fifth evaluation on, as the kernels) */
+        if ((real)fabs((double)g) <= (tolg > floorg ? tolg : floorg) + MINVAL) break;
+      }
       if (g < 0) lo = alpha; else hi = alpha;
       real an = alpha - g / h;
       if (hi >= 0 && (an <= lo || an >= hi)) an = (real)0.5 * (lo + hi);

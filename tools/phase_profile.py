@@ -32,9 +32,31 @@ def setup(B, warm=30):
     return sc, acts, bufs
 
 
+def setup_grasp(B):
+    """State in the middle of the scripted pick (fingers closed on the cube: ~12 contacts per env, arm-cube coupling)."""
+    from gym_genesis.env import GenesisEnv
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
+    obs, _ = env.reset(seed=0)
+    task = env._env
+    dev = task.device
+    robot, cube = env.get_robot(), obs["environment_state"][:, :3].clone()
+    quat = torch.tensor([0.0, 1.0, 0.0, 0.0], device=dev).repeat(B, 1)
+    q_prev = None
+    for dz, grip, n in ((0.25, 0.04, 40), (0.104, 0.04, 40), (0.104, 0.0, 60)):
+        q = robot.inverse_kinematics(link=robot.get_link("hand"), pos=cube + torch.tensor([0.0, 0.0, dz], device=dev), quat=quat, init_qpos=q_prev)
+        q_prev = q
+        tg = torch.cat([q[:, :7], torch.full((B, 2), grip, device=dev)], 1).contiguous()
+        for _ in range(n):
+            task.step_raw(tg)
+    torch.cuda.synchronize()
+    sc = task._mir
+    setup_grasp.keep = env
+    return sc, tg[None].repeat(64, 1, 1), None
+
+
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    sc, acts, bufs = setup(B)
+    sc, acts, bufs = setup_grasp(B) if len(sys.argv) > 2 and sys.argv[2] == "grasp" else setup(B)
     sc.lib.mir_debug_profile_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     sc.lib.mir_debug_profile_step.restype = C.c_int
     acc = np.zeros(10)
@@ -70,7 +92,7 @@ def main():
     print("  newton it0 fine: forces/cfb %.0f | gradient loop %.0f | gsum+check %.0f | H build %.0f | GJ %.0f | mv+jv %.0f | line search %.0f | improvement+update %.0f" % tuple(nw))
     nc, ne, ni = (x.cpu().numpy() for x in sc.get_diag())
     print(f"  ncon mean {nc.mean():.2f} nefc mean {ne.mean():.2f} niter mean {ni.mean():.2f} max {ni.max()}")
-    for Bx in (256, 4096, 65536):
+    for Bx in (() if len(sys.argv) > 2 else (256, 4096, 65536)):
         s2, a2, b2 = setup(Bx, warm=20)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
