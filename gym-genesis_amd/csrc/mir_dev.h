@@ -181,6 +181,8 @@ __device__ __forceinline__ int clip_row(float& x, float& y, float& z, float h1, 
     const int ax = e >> 1;
     const float sg = (e & 1) ? -1.0f : 1.0f;
     const float lim = ax == 0 ? h1 : h2;
+    // an edge that cuts nothing leaves the polygon as it is (same vertices, same order): skipped without the exchange
+    if ((((unsigned)(__ballot(l16 < np && sg * (ax == 0 ? x : y) - lim > 0.0f) >> (rowbase & 63)) & 0xffffu)) == 0u) continue;
     const int succ = rowbase + (l16 + 1 >= np ? 0 : l16 + 1);
     const float xs = __shfl(x, succ), ys = __shfl(y, succ), zs = __shfl(z, succ);
     const float pc = ax == 0 ? x : y, qc = ax == 0 ? xs : ys;

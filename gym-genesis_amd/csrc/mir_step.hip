@@ -465,6 +465,20 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
             float rs = sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
             V3 dc = c2 - ld3v(S.col.gpos[g1]);
             hit = dot(dc, dc) <= rs * rs;
+            if (hit) {
+              // the six face axes of the narrowphase's separating-axis test (same expressions): a pair they separate would
+              // come back with zero contacts, and the narrowphase takes the candidates of an env one after the other
+              const M3 R1 = q2m(ld4v(S.col.gquat[g1]));
+              const V3 A0 = mcol(R1, 0), A1 = mcol(R1, 1), A2 = mcol(R1, 2), B0 = mcol(R2, 0), B1 = mcol(R2, 1), B2 = mcol(R2, 2);
+              const V3 Ls[6] = {A0, A1, A2, B0, B1, B2};
+#pragma unroll
+              for (int c = 0; c < 6; c++) {
+                const V3 L = Ls[c];
+                const float ra = h1.x * fabsf(dot(A0, L)) + h1.y * fabsf(dot(A1, L)) + h1.z * fabsf(dot(A2, L));
+                const float rb = h2.x * fabsf(dot(B0, L)) + h2.y * fabsf(dot(B1, L)) + h2.z * fabsf(dot(B2, L));
+                if (fabsf(dot(dc, L)) - (ra + rb) > 0.0f) hit = false;
+              }
+            }
           }
         }
         unsigned long long bal = __ballot(hit);
