@@ -80,7 +80,42 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-class MirScene:
+class StepHelpers:
+    """Host-side helpers of the API path, shared by MirScene and the CPU test double (tests/fake_scene.py); they need
+    `num_envs`, `device` and `step_fused` of the scene."""
+
+    # ---- API-path helpers (GenesisEnv.step): the GPU idles while Python prepares a launch, so nothing that can wait is done
+    # before it -- the output tensors of the NEXT call are allocated while this call's kernel runs
+    def as_action(self, action, dim: int) -> torch.Tensor:
+        """(B, dim) float32 contiguous device tensor from a torch tensor (device or CPU) or anything NumPy understands."""
+        if not (isinstance(action, torch.Tensor) and action.dtype is torch.float32 and action.device == self.device and action.is_contiguous()):
+            if not isinstance(action, torch.Tensor):
+                action = torch.as_tensor(np.asarray(action))
+            action = action.to(device=self.device, dtype=torch.float32).contiguous()
+        if action.shape != (self.num_envs, dim):
+            raise ValueError(f"action must have shape {(self.num_envs, dim)}, got {tuple(action.shape)}")
+        return action
+
+    def _alloc_outputs(self, agent_dim: int, env_dim: int):
+        B = self.num_envs
+        buf = torch.empty(B * (agent_dim + env_dim + 1), dtype=torch.float32, device=self.device)
+        return (buf[:agent_dim * B].view(B, agent_dim), buf[agent_dim * B:(agent_dim + env_dim) * B].view(B, env_dim),
+                buf[(agent_dim + env_dim) * B:], torch.empty(B, dtype=torch.uint8, device=self.device))
+
+    def step_fresh(self, action, agent_dim: int, env_dim: int):
+        """One fused step into FRESH output tensors (callers may keep old observations, as with the reference):
+        returns (agent_pos, environment_state, reward, terminated u8)."""
+        key = (agent_dim, env_dim)
+        out = self._fresh.pop(key, None) if hasattr(self, "_fresh") else None
+        if out is None:
+            self._fresh = {}
+            out = self._alloc_outputs(agent_dim, env_dim)
+        self.step_fused(action, *out)
+        self._fresh[key] = self._alloc_outputs(agent_dim, env_dim)
+        return out
+
+
+class MirScene(StepHelpers):
     """A compiled, batched scene living on one GPU (``scene.build(n_envs=B)``)."""
 
     def __init__(self, spec: MirSceneSpec, num_envs: int, device: Optional[torch.device] = None):

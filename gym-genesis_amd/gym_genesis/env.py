@@ -69,12 +69,12 @@ class GenesisEnv(Env):
         _, reward, _, observation = self._env.step(action)
         term_dev = getattr(self._env, "terminated_device", None)
         if term_dev is not None and not getattr(self._env, "unbatched", False):
-            is_success = term_dev.bool()                   # written by the same kernel as the reward
+            is_success = term_dev.view(torch.bool)         # 0/1 bytes written by the same kernel as the reward (no extra launch)
         elif isinstance(reward, torch.Tensor):
             is_success = reward == 1
         else:
             is_success = torch.as_tensor(np.asarray(reward) == 1)
-        terminated = is_success.detach().cpu().numpy().astype(bool)  # the one D->H sync the API mandates
+        terminated = is_success.detach().cpu().numpy()     # the one D->H sync the API mandates (a fresh bool array)
         truncated = np.zeros(self.num_envs, dtype=bool)
         return observation, reward, terminated, truncated, {"is_success": is_success}
 

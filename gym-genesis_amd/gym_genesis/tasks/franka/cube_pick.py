@@ -165,12 +165,9 @@ class FrankaCubePickBatch:
         return rows
 
     def step(self, action):
-        a = self._as_action(action)
         # fresh output tensors per call, like the reference (callers may keep old observations)
         mir = self._mir
-        self._agent, self._envst = mir.empty(AGENT_DIM), mir.empty(ENV_DIM)
-        self._reward, self._term = mir.empty(), mir.empty(dtype=torch.uint8)
-        mir.step_fused(a, self._agent, self._envst, self._reward, self._term)
+        self._agent, self._envst, self._reward, self._term = mir.step_fresh(mir.as_action(action, AGENT_DIM), AGENT_DIM, ENV_DIM)
         return None, self._reward, None, self._pack_obs()
 
     def step_raw(self, action_dev: torch.Tensor) -> None:
@@ -187,12 +184,7 @@ class FrankaCubePickBatch:
 
     # ---- helpers ----------------------------------------------------------------------------
     def _as_action(self, action) -> torch.Tensor:
-        if not isinstance(action, torch.Tensor):
-            action = torch.as_tensor(np.asarray(action))
-        a = action.to(device=self.device, dtype=torch.float32).contiguous()
-        if a.shape != (self.num_envs, AGENT_DIM):
-            raise ValueError(f"action must have shape {(self.num_envs, AGENT_DIM)}, got {tuple(a.shape)}")
-        return a
+        return self._mir.as_action(action, AGENT_DIM)
 
     def _refresh(self):
         agent, env, rew, term = self._mir.get_obs()

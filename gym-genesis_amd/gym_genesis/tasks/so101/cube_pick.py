@@ -108,13 +108,11 @@ class CubePick:
         return self.get_obs()
 
     def step(self, action):
+        mir = self._mir
         if not isinstance(action, torch.Tensor):
             action = torch.as_tensor(np.asarray(action))
-        a = action.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, AGENT_DIM).contiguous()
-        mir = self._mir
-        self._agent, self._envst = mir.empty(AGENT_OBS), mir.empty(ENV_OBS)
-        self._reward, self._term = mir.empty(), mir.empty(dtype=torch.uint8)
-        mir.step_fused(a, self._agent, self._envst, self._reward, self._term)
+        a = mir.as_action(action.reshape(self.num_envs, AGENT_DIM), AGENT_DIM)
+        self._agent, self._envst, self._reward, self._term = mir.step_fresh(a, AGENT_OBS, ENV_OBS)
         return None, self._reward, None, self._pack_obs()
 
     def step_raw(self, action_dev: torch.Tensor) -> None:

@@ -150,15 +150,8 @@ class StackTaskBase:
         return rows
 
     def step(self, action):
-        if not isinstance(action, torch.Tensor):
-            action = torch.as_tensor(np.asarray(action))
-        a = action.to(device=self.device, dtype=torch.float32).contiguous()
-        if a.shape != (self.num_envs, self.AGENT_DIM):
-            raise ValueError(f"action must have shape {(self.num_envs, self.AGENT_DIM)}, got {tuple(a.shape)}")
         mir = self._mir
-        self._agent, self._envst = mir.empty(mir.agent_dim), mir.empty(ENV_OBS)
-        self._reward, self._term = mir.empty(), mir.empty(dtype=torch.uint8)
-        mir.step_fused(a, self._agent, self._envst, self._reward, self._term)
+        self._agent, self._envst, self._reward, self._term = mir.step_fresh(mir.as_action(action, self.AGENT_DIM), mir.agent_dim, ENV_OBS)
         return None, self._reward, None, self._pack_obs()
 
     def step_raw(self, action_dev: torch.Tensor) -> None:

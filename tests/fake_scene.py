@@ -10,9 +10,10 @@ import numpy as np
 import torch
 
 import orc
+from gym_genesis.backend.lib import StepHelpers
 
 
-class OracleScene:
+class OracleScene(StepHelpers):
     def __init__(self, spec, num_envs, device=None):
         self.spec = spec
         self.o = orc.Oracle(spec, int(num_envs))
