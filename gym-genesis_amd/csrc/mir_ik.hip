@@ -41,6 +41,7 @@ struct IkArgs {
   float* qpos_out;           // (B,n_arm)
   float* err_out;            // (B,2) or null
   int B, max_iters, respect_limits;
+  float inv_pos_tol, inv_rot_tol;
   float damping2, pos_tol, rot_tol, max_step;
 };
 
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
   const bool userot = a.target_quat != nullptr;
   const Q4 tq = userot ? qnormalize(ld4(a.target_quat + (size_t)env * 4)) : Q4{1, 0, 0, 0};
   bool done = false;
-  float epn = 0.0f, ern = 0.0f;
+  int stall = 0;
+  float epn = 0.0f, ern = 0.0f, mprev = 0.0f;
   for (int it = 0; it <= a.max_iters; it++) {
     // ---- local transform of my chain element (identity off the chain) ...
     V3 P = v3(0, 0, 0);
@@ -132,6 +134,15 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
     ern = sqrtf(dot(er, er));
     if (!done && epn < a.pos_tol && ern < a.rot_tol) done = true;
     if (it == a.max_iters) break;
+    // stagnation (a target beyond the joint limits or the reach): the scaled error did not drop by 1 % in three consecutive
+    // iterations (mirigid.h; the oracle applies the same rule).  Without it the few unreachable targets of a batch ran all
+    // max_iters iterations and set the time of the whole launch.
+    if (!done) {
+      const float metric = epn * a.inv_pos_tol + ern * a.inv_rot_tol;
+      stall = (it > 0 && metric > 0.99f * mprev) ? stall + 1 : 0;
+      mprev = metric;
+      if (stall >= 3) done = true;
+    }
     if (!__any(!done)) break;
     // ---- my Jacobian column (joint frame = my world pose)
     V3 jv = v3(0, 0, 0), jw = v3(0, 0, 0);
@@ -255,7 +266,7 @@ extern "C" int mir_inverse_kinematics(MirHandle h, int32_t link_body, const floa
   a.target_pos = target_pos; a.target_quat = target_quat; a.init_qpos = init_qpos; a.scene_qpos = h->qpos;
   a.qst = h->pt.qst; a.n_arm = narm; a.qpos_out = qpos_out; a.err_out = err_out; a.B = h->B;
   a.max_iters = o.max_iters; a.respect_limits = o.respect_joint_limit;
-  a.damping2 = (float)(o.damping * o.damping); a.pos_tol = (float)o.pos_tol; a.rot_tol = (float)o.rot_tol; a.max_step = (float)o.max_step;
+  a.damping2 = (float)(o.damping * o.damping); a.pos_tol = (float)o.pos_tol; a.rot_tol = (float)o.rot_tol; a.inv_pos_tol = (float)(1.0 / o.pos_tol); a.inv_rot_tol = (float)(1.0 / o.rot_tol); a.max_step = (float)o.max_step;
   int prev = -1;
   (void)hipGetDevice(&prev);
   if (prev != h->device) (void)hipSetDevice(h->device);

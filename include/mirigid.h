@@ -309,7 +309,8 @@ int mir_render_cams(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* 
  * Genesis's IK lives in the external package; this is a damped-least-squares solver on the scene's own kinematics,
  * defined here and restated independently by the oracle (oracle/orc_rigid.c: orc_ik):
  *   repeat up to max_iters:  e = [p* - p ; rotvec(q* q^-1)]   (rotation part dropped when target_quat == NULL);
- *     stop the env when |e_pos| < pos_tol and |e_rot| < rot_tol;  J = 6 x n geometric Jacobian of the link's chain;
+ *     stop the env when |e_pos| < pos_tol and |e_rot| < rot_tol, or when |e_pos|/pos_tol + |e_rot|/rot_tol has not dropped by
+ *     1 % in three consecutive iterations (a target beyond the joint limits or the reach);  J = 6 x n geometric Jacobian of the chain;
  *     dq = J^T (J J^T + damping^2 I)^-1 e, scaled down so that max |dq_i| <= max_step;  q += dq;
  *     q clamped to the joint ranges (respect_joint_limit).
  * Only the scalar joints on the chain world -> link move; every other entry of the result is the seed. */

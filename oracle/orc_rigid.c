@@ -1022,7 +1022,8 @@ int orc_ik(const OrcModel* m, int link, const double* target_pos, const double* 
     double nn = sqrt(target_quat[0] * target_quat[0] + target_quat[1] * target_quat[1] + target_quat[2] * target_quat[2] + target_quat[3] * target_quat[3]);
     for (int k = 0; k < 4; k++) tq[k] = target_quat[k] / nn;
   }
-  double epn = 0, ern = 0;
+  double epn = 0, ern = 0, mprev = 0;
+  int stall = 0;
   for (int it = 0; it <= max_iters; it++) {
     for (int j = 0; j < nj; j++) d->qpos[m->qadr[jb[j]]] = (real)q_io[j];
     orc_fk(m, d);
@@ -1041,6 +1042,14 @@ int orc_ik(const OrcModel* m, int link, const double* target_pos, const double* 
     epn = sqrt(ep[0] * ep[0] + ep[1] * ep[1] + ep[2] * ep[2]);
     ern = sqrt(er[0] * er[0] + er[1] * er[1] + er[2] * er[2]);
     if ((epn < pos_tol && ern < rot_tol) || it == max_iters) break;
+    /* stagnation (a target beyond the joint limits or the reach): the scaled error did not drop by 1 % in three
+     * consecutive iterations -- mirigid.h states the rule, mir_ik.hip applies the same */
+    {
+      double metric = epn / pos_tol + ern / rot_tol;
+      stall = (it > 0 && metric > 0.99 * mprev) ? stall + 1 : 0;
+      mprev = metric;
+      if (stall >= 3) break;
+    }
     /* Jacobian columns of the chain joints */
     double J[6][ORC_NB];
     for (int j = 0; j < nj; j++) {
