@@ -16,7 +16,7 @@ ORACLE_DIR = os.path.dirname(os.path.abspath(__file__))
 
 (F_QPOS, F_QVEL, F_TARGET, F_QACC_WS, F_XPOS, F_XQUAT, F_XIPOS, F_M, F_MT, F_QFRC_BIAS, F_QFRC_SMOOTH,
  F_QACC_SMOOTH, F_QACC, F_CPOS, F_CDIST, F_CFRAME, F_J, F_AREF, F_EFCD, F_EFCFORCE, F_DOF_INVWEIGHT0,
- F_BODY_INVWEIGHT0, F_MEANINERTIA, F_QFRC_ACT, F_QFRC_PASSIVE, F_EFCPOS, F_DBG_IMP, F_DBG_GN, F_DBG_ALPHA) = range(29)
+ F_BODY_INVWEIGHT0, F_MEANINERTIA, F_QFRC_ACT, F_QFRC_PASSIVE, F_EFCPOS, F_DBG_IMP, F_DBG_GN, F_DBG_ALPHA, F_DBG_LS) = range(30)
 
 
 def build_oracle() -> None:

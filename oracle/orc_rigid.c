@@ -707,7 +707,9 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
     for (int i = 0; i < nv; i++) { A += s[i] * Mv[i]; Bq += s[i] * (Ma[i] - d->qfrc_smooth[i]); }
     real alpha = 0, lo = 0, hi = -1;
     real g0 = 0;
+    int nls = 0;
     for (int ls = 0; ls < m->opt.ls_iterations; ls++) {
+      nls = ls + 1;
       /* phi'(alpha), phi''(alpha), and the magnitude of the terms phi' is summed from: at the root they cancel, and
        * what is left is rounding noise of about an epsilon of that magnitude -- no evaluation can resolve phi' below it */
       real g = alpha * A + Bq, h = A, gabs = (real)fabs((double)(alpha * A)) + (real)fabs((double)Bq);
@@ -749,7 +751,7 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
     for (int i = 0; i < nv; i++) { d->qacc[i] += alpha * s[i]; Ma[i] += alpha * Mv[i]; }
     for (int r = 0; r < n; r++) jar[r] += alpha * jv[r];
     d->niter = it + 1;
-    if (it < 64) { d->dbg_imp[it] = scale * imp; d->dbg_alpha[it] = alpha; }
+    if (it < 64) { d->dbg_imp[it] = scale * imp; d->dbg_alpha[it] = alpha; d->dbg_ls[it] = (real)nls; }
     if (scale * imp < tol) break;
   }
   for (int r = 0; r < n; r++) d->efcforce[r] = jar[r] < 0 ? -d->efcD[r] * jar[r] : 0;
@@ -1144,6 +1146,7 @@ int orc_read(const OrcModel* m, const OrcData* d, int field, double* out) {
     case ORC_F_DBG_IMP: return cp(out, d->dbg_imp, d->niter < 64 ? d->niter : 64);
     case ORC_F_DBG_GN: return cp(out, d->dbg_gn, d->niter < 64 ? d->niter : 64);
     case ORC_F_DBG_ALPHA: return cp(out, d->dbg_alpha, d->niter < 64 ? d->niter : 64);
+    case ORC_F_DBG_LS: return cp(out, d->dbg_ls, d->niter < 64 ? d->niter : 64);
   }
   return -1;
 }

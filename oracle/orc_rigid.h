@@ -90,7 +90,7 @@ typedef struct OrcData {
   int nefc;
   real J[ORC_NEFC][ORC_NV], aref[ORC_NEFC], efcD[ORC_NEFC], efcpos[ORC_NEFC], efcforce[ORC_NEFC];
   int niter;
-  real dbg_imp[64], dbg_gn[64], dbg_alpha[64]; /* per-iteration solver trace */
+  real dbg_imp[64], dbg_gn[64], dbg_alpha[64], dbg_ls[64]; /* per-iteration solver trace (dbg_ls: phi' evaluations of the line search) */
 } OrcData;
 
 /* field ids for orc_read */
@@ -98,7 +98,7 @@ enum {
   ORC_F_QPOS = 0, ORC_F_QVEL, ORC_F_TARGET, ORC_F_QACC_WS, ORC_F_XPOS, ORC_F_XQUAT, ORC_F_XIPOS, ORC_F_M,
   ORC_F_MT, ORC_F_QFRC_BIAS, ORC_F_QFRC_SMOOTH, ORC_F_QACC_SMOOTH, ORC_F_QACC, ORC_F_CPOS, ORC_F_CDIST,
   ORC_F_CFRAME, ORC_F_J, ORC_F_AREF, ORC_F_EFCD, ORC_F_EFCFORCE, ORC_F_DOF_INVWEIGHT0, ORC_F_BODY_INVWEIGHT0,
-  ORC_F_MEANINERTIA, ORC_F_QFRC_ACT, ORC_F_QFRC_PASSIVE, ORC_F_EFCPOS, ORC_F_DBG_IMP, ORC_F_DBG_GN, ORC_F_DBG_ALPHA
+  ORC_F_MEANINERTIA, ORC_F_QFRC_ACT, ORC_F_QFRC_PASSIVE, ORC_F_EFCPOS, ORC_F_DBG_IMP, ORC_F_DBG_GN, ORC_F_DBG_ALPHA, ORC_F_DBG_LS
 };
 
 #ifdef __cplusplus

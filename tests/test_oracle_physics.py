@@ -340,6 +340,9 @@ def test_scripted_grasp_lifts_cube_and_reward_flips_at_threshold():
             a, e, r, term = o.get_obs()
             assert np.array_equal(r == 1, np.float32(e[:, 2]) > np.float32(0.1)) and np.array_equal(term.astype(bool), r == 1)
             flipped |= r == 1
+            # line search: phi' is resolved to the evaluation's own rounding floor, not bisected beyond it:
+            # a handful of evaluations per Newton iteration even with a dozen stiff contact rows
+            assert max(o.read(orc.F_DBG_LS, i).max(initial=0) for i in range(B)) <= 16
         if name == "close":
             assert np.abs(e[:, :2] - pos[:, :2]).max() < 2e-3  # squeezed symmetrically: the cube stays put
             assert all(o.counts(i)[0] >= 8 for i in range(B))  # plane + two finger pads
