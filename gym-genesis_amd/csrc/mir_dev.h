@@ -118,7 +118,7 @@ struct GJ {
   static __device__ __forceinline__ void run(float (&a)[G], float& b, int lane) {
     const float pk = row_bcast<K>(a[K]);
     float inv = __builtin_amdgcn_rcpf(pk);
-    inv = inv * (2.0f - pk * inv);  // one Newton step: full float accuracy
+    // (v_rcp_f32 is good to 1 ulp; a Newton step here sat in the dependent chain of every pivot)
     // one fma per column for every row: with f = 1 - 1/p on the pivot row (whose broadcast entry is its own) and
     // a_iK / p elsewhere, a[j] - f * pivotrow[j] scales the pivot row and eliminates the others
     const float f = lane == K ? 1.0f - inv : a[K] * inv;

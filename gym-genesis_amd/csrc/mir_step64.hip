@@ -73,7 +73,7 @@ __device__ __forceinline__ void gj_block(v16f (&a)[4], float& b, int lane, uint6
     const float aK = a[BLK][__builtin_amdgcn_readfirstlane(kk)];  // column K of every row: wave-uniform register index (VGPR index mode)
     const float pk = rlv(aK, K);
     float inv = __builtin_amdgcn_rcpf(pk);
-    inv = inv * (2.0f - pk * inv);
+
     const float f = lane == K ? 1.0f - inv : aK * inv;
     // column blocks outside this block's connected component hold zeros in the pivot row: skipped (wave-uniform);
     // pivot-row entries are fetched eight at a time so the readlane -> fma SGPR dependencies overlap
