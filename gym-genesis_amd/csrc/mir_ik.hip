@@ -175,7 +175,6 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
         if (r == c) {
           const float dd = sqrtf(fmaxf(sacc, 1e-30f));
           float ir = __builtin_amdgcn_rcpf(dd);
-          ir = ir * (2.0f - dd * ir);
           L[r][c] = dd;
           il[r] = ir;
         } else {
