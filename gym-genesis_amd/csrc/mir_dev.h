@@ -42,6 +42,23 @@ __device__ __forceinline__ void stv(float* p, f4 v) { *reinterpret_cast<f4*>(p) 
 __device__ __forceinline__ V3 ld3v(const float* p) { f4 v = ldv(p); return {v.x, v.y, v.z}; }
 __device__ __forceinline__ void st3v(float* p, V3 a, float w = 0.0f) { stv(p, f4{a.x, a.y, a.z, w}); }
 
+// sin and cos of one argument without the library routine's large-argument path: Cody-Waite reduction by pi/2 (exact for the
+// |x| < 1e3 rad that joint angles and one-step rotation angles can reach), Cephes single-precision kernels on
+// [-pi/4, pi/4] (< 1 ulp there), quadrant fix-up by selects.  ~25 straight-line instructions in the FK chain of every step.
+__device__ __forceinline__ void sincos_pi2(float x, float* sn, float* cs) {
+  const float k = rintf(x * 0.63661977236758134308f);
+  float r = fmaf(-k, 1.57079625129699707031f, x);
+  r = fmaf(-k, 7.54978941586159635335e-08f, r);
+  r = fmaf(-k, 5.39030252995776476554e-15f, r);
+  const float z = r * r;
+  const float s = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float c = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)k & 3;
+  const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+  *sn = (q & 2) ? -ss : ss;
+  *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 struct Q4 {
   float w, x, y, z;
 };

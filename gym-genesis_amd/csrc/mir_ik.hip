@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
       P = bpos;
       if (jt == MIR_JNT_REVOLUTE) {
         float sn, cs;
-        sincosf(0.5f * q, &sn, &cs);
+        sincos_pi2(0.5f * q, &sn, &cs);
         Qx = qmul(bquat, Q4{cs, baxis.x * sn, baxis.y * sn, baxis.z * sn});
       } else if (jt == MIR_JNT_PRISMATIC) {
         P = bpos + qrot(bquat, q * baxis);

@@ -172,7 +172,7 @@ __device__ __forceinline__ void wave_fk(Env64& S, int lane, int nb, const BodyK6
     P = k.pos;
     if (k.jtype == MIR_JNT_REVOLUTE) {
       float ang = S.qpos[k.qadr], sn, cs;
-      sincosf(0.5f * ang, &sn, &cs);
+      sincos_pi2(0.5f * ang, &sn, &cs);
       Qx = qmul(k.quat, Q4{cs, k.axis.x * sn, k.axis.y * sn, k.axis.z * sn});
     } else if (k.jtype == MIR_JNT_PRISMATIC) {
       P = k.pos + qrot(k.quat, S.qpos[k.qadr] * k.axis);
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         float ang = wn * dt;
         if (ang > 1e-15f) {
           float sn, cs;
-          sincosf(0.5f * ang, &sn, &cs);
+          sincos_pi2(0.5f * ang, &sn, &cs);
           V3 ax = (1.0f / wn) * w;
           Q4 dq = {cs, ax.x * sn, ax.y * sn, ax.z * sn};
           st4(&S.qpos[d_qbase + 3], qnormalize(qmul(dq, ld4(&S.qpos[d_qbase + 3]))));
