@@ -76,9 +76,9 @@ __device__ __forceinline__ Q4 ld4v(const float* p) { f4 v = ldv(p); return {v.x,
 __device__ __forceinline__ void st4(float* p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
 __device__ __forceinline__ void st4v(float* p, Q4 q) { stv(p, f4{q.w, q.x, q.y, q.z}); }
 __device__ __forceinline__ Q4 qnormalize(Q4 q) {
-  float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  if (n < 1e-15f) return {1, 0, 0, 0};
-  float s = 1.0f / n;
+  const float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  if (n2 < 1e-30f) return {1, 0, 0, 0};
+  const float s = __builtin_amdgcn_rsqf(n2);  // one v_rsq_f32 (1 ulp) instead of sqrt + reciprocal
   return {q.w * s, q.x * s, q.y * s, q.z * s};
 }
 struct M3 {

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         const V3 n = ld3v(S.col.snorm[cl]);
         V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
         t1 = t1 - dot(n, t1) * n;
-        t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
+        t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
         const V3 t2 = cross(n, t1);
         const float mu = fmaxf(T.g_pos[g1][3], T.g_pos[g2][3]);
         const f4 s1a = ldv(&T.g_sol[g1][0]), s1b = ldv(&T.g_sol[g1][4]), s2a = ldv(&T.g_sol[g2][0]), s2b = ldv(&T.g_sol[g2][4]);

@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         const V3 n = ld3v(S.col.snorm[cl]);
         V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
         t1 = t1 - dot(n, t1) * n;
-        t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
+        t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
         const V3 t2 = cross(n, t1);
         const float mu = fmaxf(S.gfr[g1], S.gfr[g2]);
         const float* s1 = S.gsol[g1];
