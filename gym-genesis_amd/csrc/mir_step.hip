@@ -763,17 +763,18 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         const unsigned both = (unsigned)fb.w;
         const unsigned bits = both & 15u, old = both >> 4;
         if (bits == old) continue;  // group-uniform
+        // every read of this contact in one batch, before any arithmetic (one LDS round trip after the flag word)
         const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
         const f4 mt = ldv(S.con.cmeta[c]);
+        f4 xn[4], x1[4], x2[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { xn[q] = ldv(jb + 4 * q); x1[q] = ldv(jb + 16 + 4 * q); x2[q] = ldv(jb + 32 + 4 * q); }
+        __builtin_amdgcn_sched_barrier(0);
         const float mu = mt.x, D = mt.y;
         const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
         const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
         const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
         const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
-        // all twelve 16-byte row reads are issued back to back (one wait), no per-chunk branches
-        f4 xn[4], x1[4], x2[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) { xn[q] = ldv(jb + 4 * q); x1[q] = ldv(jb + 16 + 4 * q); x2[q] = ldv(jb + 32 + 4 * q); }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           hkeep[4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
