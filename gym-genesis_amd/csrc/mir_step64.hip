@@ -928,6 +928,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         f4 xn[4], x1[4], x2[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) { xn[q] = ldv(seg + 4 * q); x1[q] = ldv(seg + 16 + 4 * q); x2[q] = ldv(seg + 32 + 4 * q); }
+        __builtin_amdgcn_sched_barrier(0);  // (keep the whole batch of reads ahead of the arithmetic: one LDS round trip)
         const float mu = mt.x, D = mt.y;
         const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
         const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
