@@ -744,21 +744,25 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     // ======================= constraint rows ======================================================
     // contact base Jacobians: lane = dof writes its entry of the segment its block owns (zeros included, so a
     // segment is always fully defined)
+    // (cdof of the lane is loop-invariant; every read of a contact is issued in one batch ahead of the arithmetic, and a
+    // dof that moves neither body simply ends with sgn = 0: no divergent branch around the reads)
+    const V3 cd_ang = ld3v(&S.cdof[lane][0]), cd_lin = ld3v(&S.cdof[lane][4]);
     for (int kq = 0; kq < nmine; kq++) {
       const int eq = S.con.blist[blk][kq];
       const int c = eq >> 1, myseg = eq & 1;
-      float jn = 0.0f, j1 = 0.0f, j2 = 0.0f;
-      const uint64_t dm1 = (uint64_t)S.con.cmask[c][0] | ((uint64_t)S.con.cmask[c][1] << 32);
-      const uint64_t dm2 = (uint64_t)S.con.cmask[c][2] | ((uint64_t)S.con.cmask[c][3] << 32);
+      const f4 mk = ldv(reinterpret_cast<const float*>(S.con.cmask[c]));
+      const f4 cp = ldv(S.con.cpos[c]), r1 = ldv(&S.con.cref[c][0]), r2 = ldv(&S.con.cref[c][4]);
+      const f4 fn = ldv(&S.con.cfrm[c][0]), f1 = ldv(&S.con.cfrm[c][4]), f2 = ldv(&S.con.cfrm[c][8]);
+      __builtin_amdgcn_sched_barrier(0);
+      const uint64_t dm1 = (uint64_t)__float_as_uint(mk.x) | ((uint64_t)__float_as_uint(mk.y) << 32);
+      const uint64_t dm2 = (uint64_t)__float_as_uint(mk.z) | ((uint64_t)__float_as_uint(mk.w) << 32);
       const bool in2 = dm2 >> lane & 1ull, in1 = dm1 >> lane & 1ull;
       const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f);  // a dof moving both bodies cancels
-      if (sgn != 0.0f) {
-        V3 r = ld3v(S.con.cpos[c]) - ld3v(&S.con.cref[c][in2 ? 4 : 0]);
-        V3 vel = cross(ld3v(&S.cdof[lane][0]), r) + ld3v(&S.cdof[lane][4]);
-        jn = sgn * dot(vel, ld3v(&S.con.cfrm[c][0]));
-        j1 = sgn * dot(vel, ld3v(&S.con.cfrm[c][4]));
-        j2 = sgn * dot(vel, ld3v(&S.con.cfrm[c][8]));
-      }
+      const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));
+      const V3 vel = cross(cd_ang, r) + cd_lin;
+      const float jn = sgn * dot(vel, v3(fn.x, fn.y, fn.z));
+      const float j1 = sgn * dot(vel, v3(f1.x, f1.y, f1.z));
+      const float j2 = sgn * dot(vel, v3(f2.x, f2.y, f2.z));
       float* jb = &S.Jb[c][myseg][0];
       jb[l16] = jn; jb[16 + l16] = j1; jb[32 + l16] = j2;
     }
