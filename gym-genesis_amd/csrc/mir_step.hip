@@ -612,20 +612,34 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
 
     // ======================= constraint rows ======================================================
     // contact base Jacobians: lane = dof; Jb[c][r*16 + i], r = normal, t1, t2
-    for (int c = 0; c < ncon; c++) {
-      float jn = 0.0f, j1 = 0.0f, j2 = 0.0f;
-      const uint32_t dm1 = S.con.cmask[c][0], dm2 = S.con.cmask[c][1];
-      const bool in2 = dm2 >> lane & 1u, in1 = dm1 >> lane & 1u;
-      const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f);  // a dof moving both bodies cancels
-      if (sgn != 0.0f) {
-        V3 r = ld3v(S.con.cpos[c]) - ld3v(&S.con.cref[c][in2 ? 4 : 0]);
-        V3 vel = cross(ld3v(&S.cdof[lane][0]), r) + ld3v(&S.cdof[lane][4]);
-        jn = sgn * dot(vel, ld3v(&S.con.cfrm[c][0]));
-        j1 = sgn * dot(vel, ld3v(&S.con.cfrm[c][4]));
-        j2 = sgn * dot(vel, ld3v(&S.con.cfrm[c][8]));
+    // (two contacts per trip, every read of both issued in one batch ahead of the arithmetic; a dof that moves neither
+    // body ends with sgn = 0, so there is no divergent branch around the reads)
+    {
+      const V3 cd_ang = ld3v(&S.cdof[lane][0]), cd_lin = ld3v(&S.cdof[lane][4]);
+      for (int c0 = 0; c0 < ncon; c0 += 2) {
+        const int cA = c0, cB = c0 + 1 < ncon ? c0 + 1 : c0;
+        const f4 mkA = ldv(reinterpret_cast<const float*>(S.con.cmask[cA])), mkB = ldv(reinterpret_cast<const float*>(S.con.cmask[cB]));
+        const f4 cpA = ldv(S.con.cpos[cA]), r1A = ldv(&S.con.cref[cA][0]), r2A = ldv(&S.con.cref[cA][4]);
+        const f4 cpB = ldv(S.con.cpos[cB]), r1B = ldv(&S.con.cref[cB][0]), r2B = ldv(&S.con.cref[cB][4]);
+        const f4 fnA = ldv(&S.con.cfrm[cA][0]), f1A = ldv(&S.con.cfrm[cA][4]), f2A = ldv(&S.con.cfrm[cA][8]);
+        const f4 fnB = ldv(&S.con.cfrm[cB][0]), f1B = ldv(&S.con.cfrm[cB][4]), f2B = ldv(&S.con.cfrm[cB][8]);
+        __builtin_amdgcn_sched_barrier(0);
+#define MIR_JCOL(mk, cp, r1, r2, fn, f1, f2, cc)                                                              \
+        {                                                                                                     \
+          const uint32_t dm1 = __float_as_uint(mk.x), dm2 = __float_as_uint(mk.y);                            \
+          const bool in2 = dm2 >> lane & 1u, in1 = dm1 >> lane & 1u;                                          \
+          const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f); /* a dof moving both bodies cancels */ \
+          const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));            \
+          const V3 vel = cross(cd_ang, r) + cd_lin;                                                           \
+          float* jb = &S.Jb[cc][0];                                                                           \
+          jb[lane] = sgn * dot(vel, v3(fn.x, fn.y, fn.z));                                                    \
+          jb[16 + lane] = sgn * dot(vel, v3(f1.x, f1.y, f1.z));                                               \
+          jb[32 + lane] = sgn * dot(vel, v3(f2.x, f2.y, f2.z));                                               \
+        }
+        MIR_JCOL(mkA, cpA, r1A, r2A, fnA, f1A, f2A, cA)
+        if (c0 + 1 < ncon) MIR_JCOL(mkB, cpB, r1B, r2B, fnB, f1B, f2B, cB)
+#undef MIR_JCOL
       }
-      float* jb = &S.Jb[c][0];
-      jb[lane] = jn; jb[16 + lane] = j1; jb[32 + lane] = j2;
     }
     // joint-limit rows: lane = dof, lane-private
     float lsg = 0.0f, lD = 0.0f, laref = 0.0f;
@@ -740,10 +754,20 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       if (it == 0) STAMP(16);
       // ---- gradient first (cheap): convergence is decided before any Hessian work
       float g = isdof ? Ma - qfs - lsg * lf : 0.0f;
-      for (int c = 0; c < ncon; c++) {
-        const float* jb = &S.Jb[c][0];
-        const f4 fb = ldv(S.con.cfb[c]);
-        g -= jb[lane] * fb.x + jb[16 + lane] * fb.y + jb[32 + lane] * fb.z;
+      for (int c0 = 0; c0 < ncon; c0 += 4) {  // four contacts per trip: one batch of reads, then the sums in contact order
+        float jn[4], j1[4], j2[4];
+        f4 fb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int c = c0 + u < ncon ? c0 + u : c0;
+          const float* jb = &S.Jb[c][0];
+          jn[u] = jb[lane]; j1[u] = jb[16 + lane]; j2[u] = jb[32 + lane];
+          fb[u] = ldv(S.con.cfb[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (c0 + u < ncon) g -= jn[u] * fb[u].x + j1[u] * fb[u].y + j2[u] * fb[u].z;
       }
       if (!isdof) g = 0.0f;
       if (it == 0) STAMP(17);
