@@ -359,6 +359,30 @@ __device__ __forceinline__ float rowdot(const float (&r)[G], const float* x) {
   return r[0] * x0.x + r[1] * x0.y + r[2] * x0.z + r[3] * x0.w + r[4] * x1.x + r[5] * x1.y + r[6] * x1.z + r[7] * x1.w +
          r[8] * x2.x + r[9] * x2.y + r[10] * x2.z + r[11] * x2.w + r[12] * x3.x + r[13] * x3.y + r[14] * x3.z + r[15] * x3.w;
 }
+// The same two products with the vector spread over the lanes of the DPP row (lane j holds x_j) instead of in LDS: every
+// term takes its x_j by row broadcast inside the fma (v_fmac_f32_dpp), so the vector needs no LDS round trip.  Four
+// independent partial sums keep the dependent chain at four fmas.  Convergent code only (all lanes of the row active).
+__device__ __forceinline__ float rowdot_bc(const float (&r)[G], float x) {
+  float a0 = r[0] * row_bcast<0>(x), a1 = r[1] * row_bcast<1>(x), a2 = r[2] * row_bcast<2>(x), a3 = r[3] * row_bcast<3>(x);
+  a0 = fmaf(r[4], row_bcast<4>(x), a0); a1 = fmaf(r[5], row_bcast<5>(x), a1); a2 = fmaf(r[6], row_bcast<6>(x), a2); a3 = fmaf(r[7], row_bcast<7>(x), a3);
+  a0 = fmaf(r[8], row_bcast<8>(x), a0); a1 = fmaf(r[9], row_bcast<9>(x), a1); a2 = fmaf(r[10], row_bcast<10>(x), a2); a3 = fmaf(r[11], row_bcast<11>(x), a3);
+  a0 = fmaf(r[12], row_bcast<12>(x), a0); a1 = fmaf(r[13], row_bcast<13>(x), a1); a2 = fmaf(r[14], row_bcast<14>(x), a2); a3 = fmaf(r[15], row_bcast<15>(x), a3);
+  return (a0 + a1) + (a2 + a3);
+}
+__device__ __forceinline__ void jdot3_bc(const float* jb, float x, float& dn, float& d1, float& d2) {
+  f4 a[4], b[4], c[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { a[q] = ldv(jb + 4 * q); b[q] = ldv(jb + 16 + 4 * q); c[q] = ldv(jb + 32 + 4 * q); }
+  const float x0 = row_bcast<0>(x), x1 = row_bcast<1>(x), x2 = row_bcast<2>(x), x3 = row_bcast<3>(x), x4 = row_bcast<4>(x), x5 = row_bcast<5>(x),
+              x6 = row_bcast<6>(x), x7 = row_bcast<7>(x), x8 = row_bcast<8>(x), x9 = row_bcast<9>(x), x10 = row_bcast<10>(x), x11 = row_bcast<11>(x),
+              x12 = row_bcast<12>(x), x13 = row_bcast<13>(x), x14 = row_bcast<14>(x), x15 = row_bcast<15>(x);
+  dn = ((a[0].x * x0 + a[0].y * x1) + (a[0].z * x2 + a[0].w * x3)) + ((a[1].x * x4 + a[1].y * x5) + (a[1].z * x6 + a[1].w * x7)) +
+       (((a[2].x * x8 + a[2].y * x9) + (a[2].z * x10 + a[2].w * x11)) + ((a[3].x * x12 + a[3].y * x13) + (a[3].z * x14 + a[3].w * x15)));
+  d1 = ((b[0].x * x0 + b[0].y * x1) + (b[0].z * x2 + b[0].w * x3)) + ((b[1].x * x4 + b[1].y * x5) + (b[1].z * x6 + b[1].w * x7)) +
+       (((b[2].x * x8 + b[2].y * x9) + (b[2].z * x10 + b[2].w * x11)) + ((b[3].x * x12 + b[3].y * x13) + (b[3].z * x14 + b[3].w * x15)));
+  d2 = ((c[0].x * x0 + c[0].y * x1) + (c[0].z * x2 + c[0].w * x3)) + ((c[1].x * x4 + c[1].y * x5) + (c[1].z * x6 + c[1].w * x7)) +
+       (((c[2].x * x8 + c[2].y * x9) + (c[2].z * x10 + c[2].w * x11)) + ((c[3].x * x12 + c[3].y * x13) + (c[3].z * x14 + c[3].w * x15)));
+}
 // the three base-row dots (normal, t1, t2) of contact Jacobian block `jb` with a 16-float LDS vector
 __device__ __forceinline__ void jdot3(const float* jb, const float* x, float& dn, float& d1, float& d2) {
   dn = d1 = d2 = 0.0f;

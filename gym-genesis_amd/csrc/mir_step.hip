@@ -816,15 +816,15 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       GJ<0>::run(hrow, sv, lane);
       if (!isdof) sv = 0.0f;
       if (it == 0) STAMP(15);
-      S.srch[lane] = sv;
-      WSYNC();
-      const float mv = isdof ? rowdot(mrow, S.srch) : 0.0f;
+      // (the direction stays in the lanes: M s and J s take s_j by row broadcast, no LDS round trip)
+      const float mvb = rowdot_bc(mrow, sv);
+      const float mv = isdof ? mvb : 0.0f;
       const float ljv = lsg * sv;
       float jv[4] = {0, 0, 0, 0};
-      if (iscon) {
+      {
         float xn, x1, x2;
-        jdot3(&S.Jb[lane][0], S.srch, xn, x1, x2);
-        jv[0] = xn + cmu * x1; jv[1] = xn - cmu * x1; jv[2] = xn + cmu * x2; jv[3] = xn - cmu * x2;
+        jdot3_bc(&S.Jb[iscon ? lane : 0][0], sv, xn, x1, x2);  // (every lane of the row takes part in the broadcasts)
+        if (iscon) { jv[0] = xn + cmu * x1; jv[1] = xn - cmu * x1; jv[2] = xn + cmu * x2; jv[3] = xn - cmu * x2; }
       }
       if (it == 0) STAMP(19);
       // ---- exact line search on the piecewise-quadratic phi(alpha): safeguarded Newton on phi'
