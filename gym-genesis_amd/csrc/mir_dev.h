@@ -369,10 +369,19 @@ __device__ __forceinline__ float rowdot_bc(const float (&r)[G], float x) {
   a0 = fmaf(r[12], row_bcast<12>(x), a0); a1 = fmaf(r[13], row_bcast<13>(x), a1); a2 = fmaf(r[14], row_bcast<14>(x), a2); a3 = fmaf(r[15], row_bcast<15>(x), a3);
   return (a0 + a1) + (a2 + a3);
 }
-__device__ __forceinline__ void jdot3_bc(const float* jb, float x, float& dn, float& d1, float& d2) {
+struct JRow {  // the three base rows (normal, t1, t2) of one contact, kept in registers by the contact's lane
   f4 a[4], b[4], c[4];
+};
+__device__ __forceinline__ JRow jrow_load(const float* jb) {
+  JRow r;
 #pragma unroll
-  for (int q = 0; q < 4; q++) { a[q] = ldv(jb + 4 * q); b[q] = ldv(jb + 16 + 4 * q); c[q] = ldv(jb + 32 + 4 * q); }
+  for (int q = 0; q < 4; q++) { r.a[q] = ldv(jb + 4 * q); r.b[q] = ldv(jb + 16 + 4 * q); r.c[q] = ldv(jb + 32 + 4 * q); }
+  return r;
+}
+__device__ __forceinline__ void jdot3_bc(const JRow& jr, float x, float& dn, float& d1, float& d2) {
+  const f4 (&a)[4] = jr.a;
+  const f4 (&b)[4] = jr.b;
+  const f4 (&c)[4] = jr.c;
   const float x0 = row_bcast<0>(x), x1 = row_bcast<1>(x), x2 = row_bcast<2>(x), x3 = row_bcast<3>(x), x4 = row_bcast<4>(x), x5 = row_bcast<5>(x),
               x6 = row_bcast<6>(x), x7 = row_bcast<7>(x), x8 = row_bcast<8>(x), x9 = row_bcast<9>(x), x10 = row_bcast<10>(x), x11 = row_bcast<11>(x),
               x12 = row_bcast<12>(x), x13 = row_bcast<13>(x), x14 = row_bcast<14>(x), x15 = row_bcast<15>(x);

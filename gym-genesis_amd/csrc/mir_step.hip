@@ -67,8 +67,7 @@ struct ContactArrays {
   float cfb[MAXCON][4];           // per-iteration base forces (n, t1, t2), active-row flags (as int bits)
 };
 struct EnvLds {
-  float qpos[20], qvel[G], target[G], qacc_ws[G], qacc[G];
-  float qas[G], srch[G];
+  float qpos[20], qvel[G], target[G], qacc_ws[G];
   float xpos[G][4], xquat[G][4];
   float cdof[G][8];               // ang(3) pad lin(3) pad
   float M[G][MSTR];
@@ -427,8 +426,6 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       qas = isdof ? qfs : 0.0f;
       GJ<0>::run(arow, qas, lane);
     }
-    S.qas[lane] = qas;
-    S.qacc[lane] = qas;
     if (a.out_qas && valid && isdof && step == 0) a.out_qas[(size_t)env * nv + lane] = qas;
     WSYNC();  // dyn scratch is dead from here on
     STAMP(4);
@@ -663,9 +660,12 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     const bool iscon = lane < ncon;
     float cmu = 0.0f, cD = 0.0f;
     float aref[4] = {0, 0, 0, 0}, jar[4] = {0, 0, 0, 0};
+    // the contact's Jacobian rows stay in the registers of its lane for the whole solve; J x products take x_j from the dof
+    // lanes by DPP row broadcast (every lane of the row takes part)
+    const JRow jrow = jrow_load(&S.Jb[iscon ? lane : 0][0]);
+    float vn, v1, v2;
+    jdot3_bc(jrow, S.qvel[lane], vn, v1, v2);
     if (iscon) {
-      float vn, v1, v2;
-      jdot3(&S.Jb[lane][0], S.qvel, vn, v1, v2);
       f4 mt = ldv(S.con.cmeta[lane]);
       cmu = mt.x; cD = mt.y;
       const float base = mt.z, bb = mt.w;
@@ -685,19 +685,17 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       // warm start: cost(ws) vs cost(qacc_smooth); Gauss part 1/2 dq^T Mt dq
       const float ws = S.qacc_ws[lane];
       const float dq = isdof ? ws - qas : 0.0f;
-      S.srch[lane] = dq;
-      WSYNC();
-      float c_ws = 0.5f * rowdot(mrow, S.srch) * dq, c_sm = 0.0f;
+      float c_ws = 0.5f * rowdot_bc(mrow, dq) * dq, c_sm = 0.0f;
       const float ljs = lsg * qas - laref, ljw = lsg * ws - laref;
       if (lsg != 0.0f) {
         if (ljs < 0.0f) c_sm += 0.5f * lD * ljs * ljs;
         if (ljw < 0.0f) c_ws += 0.5f * lD * ljw * ljw;
       }
       float js[4] = {0, 0, 0, 0}, jw[4] = {0, 0, 0, 0};
+      float sn, s1, s2, wn, w1, w2;
+      jdot3_bc(jrow, qas, sn, s1, s2);
+      jdot3_bc(jrow, ws, wn, w1, w2);
       if (iscon) {
-        float sn, s1, s2, wn, w1, w2;
-        jdot3(&S.Jb[lane][0], S.qas, sn, s1, s2);
-        jdot3(&S.Jb[lane][0], S.qacc_ws, wn, w1, w2);
         js[0] = sn + cmu * s1 - aref[0]; js[1] = sn - cmu * s1 - aref[1]; js[2] = sn + cmu * s2 - aref[2]; js[3] = sn - cmu * s2 - aref[3];
         jw[0] = wn + cmu * w1 - aref[0]; jw[1] = wn - cmu * w1 - aref[1]; jw[2] = wn + cmu * w2 - aref[2]; jw[3] = wn - cmu * w2 - aref[3];
 #pragma unroll
@@ -713,10 +711,8 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       ljar = usews ? ljw : ljs;
 #pragma unroll
       for (int r = 0; r < 4; r++) jar[r] = usews ? jw[r] : js[r];
-      WSYNC();
-      S.qacc[lane] = qacc;
-      WSYNC();
-      Ma = isdof ? rowdot(mrow, S.qacc) : 0.0f;
+      const float Mab = rowdot_bc(mrow, qacc);
+      Ma = isdof ? Mab : 0.0f;
     }
     STAMP(7);
     int niter = 0;
@@ -823,7 +819,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       float jv[4] = {0, 0, 0, 0};
       {
         float xn, x1, x2;
-        jdot3_bc(&S.Jb[iscon ? lane : 0][0], sv, xn, x1, x2);  // (every lane of the row takes part in the broadcasts)
+        jdot3_bc(jrow, sv, xn, x1, x2);  // (every lane of the row takes part in the broadcasts)
         if (iscon) { jv[0] = xn + cmu * x1; jv[1] = xn - cmu * x1; jv[2] = xn + cmu * x2; jv[3] = xn - cmu * x2; }
       }
       if (it == 0) STAMP(19);
