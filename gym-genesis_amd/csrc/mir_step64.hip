@@ -901,11 +901,21 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       WSYNC();
       // ---- gradient first (cheap): convergence is decided before any Hessian work
       float g = isdof ? Ma - qfs - lsg * lf : 0.0f;
-      for (int kq = 0; kq < nmine; kq++) {
-        const int eq = S.con.blist[blk][kq];
-        const float* jb = &S.Jb[eq >> 1][eq & 1][0];
-        const f4 fb = ldv(S.con.cfb[eq >> 1]);
-        g -= jb[l16] * fb.x + jb[16 + l16] * fb.y + jb[32 + l16] * fb.z;
+      for (int k0 = 0; k0 < nmine; k0 += 4) {  // four list entries per trip: the entries, then every read in one batch
+        const int4 e4 = *reinterpret_cast<const int4*>(&S.con.blist[blk][k0]);  // (MAXC is a multiple of 4; k0 is one too)
+        const int eqs[4] = {e4.x, k0 + 1 < nmine ? e4.y : e4.x, k0 + 2 < nmine ? e4.z : e4.x, k0 + 3 < nmine ? e4.w : e4.x};
+        float jn[4], j1[4], j2[4];
+        f4 fb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float* jb = &S.Jb[eqs[u] >> 1][eqs[u] & 1][0];
+          jn[u] = jb[l16]; j1[u] = jb[16 + l16]; j2[u] = jb[32 + l16];
+          fb[u] = ldv(S.con.cfb[eqs[u] >> 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (k0 + u < nmine) g -= jn[u] * fb[u].x + j1[u] * fb[u].y + j2[u] * fb[u].z;
       }
       if (!isdof) g = 0.0f;
       const float gn = sqrtf(wsum(g * g));
