@@ -747,24 +747,32 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     // (cdof of the lane is loop-invariant; every read of a contact is issued in one batch ahead of the arithmetic, and a
     // dof that moves neither body simply ends with sgn = 0: no divergent branch around the reads)
     const V3 cd_ang = ld3v(&S.cdof[lane][0]), cd_lin = ld3v(&S.cdof[lane][4]);
-    for (int kq = 0; kq < nmine; kq++) {
-      const int eq = S.con.blist[blk][kq];
-      const int c = eq >> 1, myseg = eq & 1;
-      const f4 mk = ldv(reinterpret_cast<const float*>(S.con.cmask[c]));
-      const f4 cp = ldv(S.con.cpos[c]), r1 = ldv(&S.con.cref[c][0]), r2 = ldv(&S.con.cref[c][4]);
-      const f4 fn = ldv(&S.con.cfrm[c][0]), f1 = ldv(&S.con.cfrm[c][4]), f2 = ldv(&S.con.cfrm[c][8]);
+    for (int k0 = 0; k0 < nmine; k0 += 2) {  // two list entries per trip
+      const int2 e2 = *reinterpret_cast<const int2*>(&S.con.blist[blk][k0]);
+      const int eqA = e2.x, eqB = k0 + 1 < nmine ? e2.y : e2.x;
+      const int cA = eqA >> 1, cB = eqB >> 1;
+      const f4 mkA = ldv(reinterpret_cast<const float*>(S.con.cmask[cA])), mkB = ldv(reinterpret_cast<const float*>(S.con.cmask[cB]));
+      const f4 cpA = ldv(S.con.cpos[cA]), r1A = ldv(&S.con.cref[cA][0]), r2A = ldv(&S.con.cref[cA][4]);
+      const f4 cpB = ldv(S.con.cpos[cB]), r1B = ldv(&S.con.cref[cB][0]), r2B = ldv(&S.con.cref[cB][4]);
+      const f4 fnA = ldv(&S.con.cfrm[cA][0]), f1A = ldv(&S.con.cfrm[cA][4]), f2A = ldv(&S.con.cfrm[cA][8]);
+      const f4 fnB = ldv(&S.con.cfrm[cB][0]), f1B = ldv(&S.con.cfrm[cB][4]), f2B = ldv(&S.con.cfrm[cB][8]);
       __builtin_amdgcn_sched_barrier(0);
-      const uint64_t dm1 = (uint64_t)__float_as_uint(mk.x) | ((uint64_t)__float_as_uint(mk.y) << 32);
-      const uint64_t dm2 = (uint64_t)__float_as_uint(mk.z) | ((uint64_t)__float_as_uint(mk.w) << 32);
-      const bool in2 = dm2 >> lane & 1ull, in1 = dm1 >> lane & 1ull;
-      const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f);  // a dof moving both bodies cancels
-      const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));
-      const V3 vel = cross(cd_ang, r) + cd_lin;
-      const float jn = sgn * dot(vel, v3(fn.x, fn.y, fn.z));
-      const float j1 = sgn * dot(vel, v3(f1.x, f1.y, f1.z));
-      const float j2 = sgn * dot(vel, v3(f2.x, f2.y, f2.z));
-      float* jb = &S.Jb[c][myseg][0];
-      jb[l16] = jn; jb[16 + l16] = j1; jb[32 + l16] = j2;
+#define MIR_JCOL64(mk, cp, r1, r2, fn, f1, f2, eq)                                                                  \
+      {                                                                                                             \
+        const uint64_t dm1 = (uint64_t)__float_as_uint(mk.x) | ((uint64_t)__float_as_uint(mk.y) << 32);             \
+        const uint64_t dm2 = (uint64_t)__float_as_uint(mk.z) | ((uint64_t)__float_as_uint(mk.w) << 32);             \
+        const bool in2 = dm2 >> lane & 1ull, in1 = dm1 >> lane & 1ull;                                              \
+        const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f); /* a dof moving both bodies cancels */         \
+        const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));                    \
+        const V3 vel = cross(cd_ang, r) + cd_lin;                                                                   \
+        float* jb = &S.Jb[(eq) >> 1][(eq) & 1][0];                                                                  \
+        jb[l16] = sgn * dot(vel, v3(fn.x, fn.y, fn.z));                                                             \
+        jb[16 + l16] = sgn * dot(vel, v3(f1.x, f1.y, f1.z));                                                        \
+        jb[32 + l16] = sgn * dot(vel, v3(f2.x, f2.y, f2.z));                                                        \
+      }
+      MIR_JCOL64(mkA, cpA, r1A, r2A, fnA, f1A, f2A, eqA)
+      if (k0 + 1 < nmine) MIR_JCOL64(mkB, cpB, r1B, r2B, fnB, f1B, f2B, eqB)
+#undef MIR_JCOL64
     }
     // joint-limit rows: lane = dof, lane-private
     float lsg = 0.0f, lD = 0.0f, laref = 0.0f;
