@@ -300,16 +300,30 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
 
     // ======================= velocities, composite inertias =====================================
     {
+      // sum of qvel_j * cdof_j over the dofs of a mask, four per trip with the reads of the trip issued together (the masks
+      // differ per lane, so the compiler cannot batch them itself; one LDS round trip per four dofs instead of per dof)
+      auto gather_vel = [&](uint32_t mk, V3& W, V3& Vl) {
+        while (mk) {
+          int j[4];
+          bool ok[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { ok[u] = mk != 0u; j[u] = ok[u] ? __ffs(mk) - 1 : 0; mk &= mk - 1u; }
+          float qd[4];
+          f4 ca[4], cl[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { qd[u] = S.qvel[j[u]]; ca[u] = ldv(&S.cdof[j[u]][0]); cl[u] = ldv(&S.cdof[j[u]][4]); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (ok[u]) {
+              W = W + qd[u] * v3(ca[u].x, ca[u].y, ca[u].z);
+              Vl = Vl + qd[u] * v3(cl[u].x, cl[u].y, cl[u].z);
+            }
+        }
+      };
       if (isdof) {  // lane = dof: cdof_dot * qvel, "velocity before this dof" from the pre-mask
         V3 pw = v3(0, 0, 0), pv = v3(0, 0, 0);
-        uint32_t mk = d_premask;
-        while (mk) {
-          int j = __ffs(mk) - 1;
-          mk &= mk - 1;
-          float qd = S.qvel[j];
-          pw = pw + qd * ld3v(&S.cdof[j][0]);
-          pv = pv + qd * ld3v(&S.cdof[j][4]);
-        }
+        gather_vel(d_premask, pw, pv);
         V3 cw = ld3v(&S.cdof[lane][0]), cv = ld3v(&S.cdof[lane][4]);
         float qd = S.qvel[lane];
         st3v(&S.dyn.cddq[lane][0], qd * cross(pw, cw));
@@ -318,20 +332,20 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       V3 w = v3(0, 0, 0), v = v3(0, 0, 0);
       f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0;
       if (isbody) {  // lane = body: cvel, composite inertia over the subtree
-        uint32_t mk = b_dofmask;
-        while (mk) {
-          int j = __ffs(mk) - 1;
-          mk &= mk - 1;
-          float qd = S.qvel[j];
-          w = w + qd * ld3v(&S.cdof[j][0]);
-          v = v + qd * ld3v(&S.cdof[j][4]);
-        }
+        gather_vel(b_dofmask, w, v);
         uint32_t sm = b_submask;
-        while (sm) {
-          int c = __ffs(sm) - 1;
-          sm &= sm - 1;
-          const float* p = S.dyn.cinert[c];
-          c0 += ldv(p); c1 += ldv(p + 4); c2 += ldv(p + 8);
+        while (sm) {  // four subtree bodies per trip, reads batched
+          int cb[4];
+          bool ok[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { ok[u] = sm != 0u; cb[u] = ok[u] ? __ffs(sm) - 1 : 0; sm &= sm - 1u; }
+          f4 x0[4], x1[4], x2[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const float* p = S.dyn.cinert[cb[u]]; x0[u] = ldv(p); x1[u] = ldv(p + 4); x2[u] = ldv(p + 8); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (ok[u]) { c0 += x0[u]; c1 += x1[u]; c2 += x2[u]; }
         }
       }
       st3v(&S.dyn.cvel[lane][0], w);
