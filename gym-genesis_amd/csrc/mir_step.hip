@@ -138,6 +138,10 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 }
 
 // ---------------------------------------------------------------------------------------------
+// SINGLE = one full step per launch without the rollout / autoreset / per-stage-output options (the headline launch): the
+// step loop disappears at compile time, and with it the block of scalar-register spills that the loop structure forces in
+// front of it (every launch-invariant value is otherwise saved before the loop and restored inside it).
+template <bool SINGLE>
 __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
   __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     if (__any(!cached)) group_fk(S, lane, nb, parents, bk);  // recomputing a cached env is bit-identical
   }
   STAMP(1);
-  const int nsteps = a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0);
+  const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
+  if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; }
   // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
   const int eb = m->eef_body, ob = m->obj_body;
   const int ad = 7 + m->n_grip;
@@ -1048,6 +1053,9 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   StepArgs a = *args;
   int blocks = (a.B + EPB - 1) / EPB;
   (void)max_contacts_lds;
-  hipLaunchKernelGGL(mir_step_kernel, dim3(blocks), dim3(64), 0, stream, a);
+  const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !a.prof && !a.out_M && !a.out_bias &&
+                      !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat;
+  if (single) hipLaunchKernelGGL(mir_step_kernel<true>, dim3(blocks), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(mir_step_kernel<false>, dim3(blocks), dim3(64), 0, stream, a);
   return (int)hipGetLastError();
 }
