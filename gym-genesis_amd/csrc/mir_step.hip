@@ -362,17 +362,27 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     STAMP(2);
 
     // ======================= body forces (RNE, qacc=0) and mass matrix rows =======================
+    // sum of the (angular, linear) pairs of an 8-float-per-entry LDS table over the entries of a mask, four per trip
+    auto gather_pair = [&](uint32_t mk, const float* tab, V3& A, V3& Bv) {
+      while (mk) {
+        int j[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { ok[u] = mk != 0u; j[u] = ok[u] ? __ffs(mk) - 1 : 0; mk &= mk - 1u; }
+        f4 xa[4], xl[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { xa[u] = ldv(tab + 8 * j[u]); xl[u] = ldv(tab + 8 * j[u] + 4); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (ok[u]) { A = A + v3(xa[u].x, xa[u].y, xa[u].z); Bv = Bv + v3(xl[u].x, xl[u].y, xl[u].z); }
+      }
+    };
     {
       V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
       if (isbody) {
         V3 aw = v3(0, 0, 0), av = v3(-m->gx, -m->gy, -m->gz);
-        uint32_t mk = b_dofmask;
-        while (mk) {
-          int j = __ffs(mk) - 1;
-          mk &= mk - 1;
-          aw = aw + ld3v(&S.dyn.cddq[j][0]);
-          av = av + ld3v(&S.dyn.cddq[j][4]);
-        }
+        gather_pair(b_dofmask, &S.dyn.cddq[0][0], aw, av);
         Inert I = ldI(S.dyn.cinert[lane]);
         V3 w = ld3v(&S.dyn.cvel[lane][0]), v = ld3v(&S.dyn.cvel[lane][4]);
         V3 ta, fa, tv, fv;
@@ -393,26 +403,30 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       V3 bt, bf;
       imul(I, ld3v(&S.cdof[lane][0]), ld3v(&S.cdof[lane][4]), bt, bf);
       uint32_t mk = d_ancmask;
-      while (mk) {
-        int j = __ffs(mk) - 1;
-        mk &= mk - 1;
-        float val = dot(ld3v(&S.cdof[j][0]), bt) + dot(ld3v(&S.cdof[j][4]), bf);
-        if (j == lane) val += d_mdiag;
-        S.M[lane][j] = val;
-        S.M[j][lane] = val;
+      while (mk) {  // four ancestors per trip, reads batched
+        int j[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { ok[u] = mk != 0u; j[u] = ok[u] ? __ffs(mk) - 1 : 0; mk &= mk - 1u; }
+        f4 ca[4], cl[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { ca[u] = ldv(&S.cdof[j[u]][0]); cl[u] = ldv(&S.cdof[j[u]][4]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (ok[u]) {
+            float val = dot(v3(ca[u].x, ca[u].y, ca[u].z), bt) + dot(v3(cl[u].x, cl[u].y, cl[u].z), bf);
+            if (j[u] == lane) val += d_mdiag;
+            S.M[lane][j[u]] = val;
+            S.M[j[u]][lane] = val;
+          }
       }
     }
     // bias + smooth force (lane = dof)
     float qfrc_bias = 0.0f, qfs = 0.0f;
     if (isdof) {
       V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
-      uint32_t sm = d_submask;
-      while (sm) {
-        int c = __ffs(sm) - 1;
-        sm &= sm - 1;
-        t = t + ld3v(&S.dyn.cfrc[c][0]);
-        f = f + ld3v(&S.dyn.cfrc[c][4]);
-      }
+      gather_pair(d_submask, &S.dyn.cfrc[0][0], t, f);
       qfrc_bias = dot(ld3v(&S.cdof[lane][0]), t) + dot(ld3v(&S.cdof[lane][4]), f);
       float qd = S.qvel[lane];
       float fa = 0.0f;
