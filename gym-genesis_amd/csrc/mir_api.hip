@@ -461,6 +461,29 @@ int mir_debug_profile_step(MirHandle h, unsigned long long* prof16, void* stream
   return launch(h, o, stream);
 }
 
+/* debug aid (not part of the drop-in surface): overwrite the LDS of every CU with signalling-NaN bit patterns.  LDS keeps
+ * what the previous kernel left in it, so a step kernel that reads a slot before writing it usually finds plausible stale
+ * values there; the GPU tests call this first, which turns such a read into a NaN in the results. */
+namespace {
+__global__ void k_poison_lds(int words) {
+  extern __shared__ unsigned int lds_words[];
+  for (int i = threadIdx.x; i < words; i += blockDim.x) lds_words[i] = 0x7fa00000u + (unsigned)i;
+  __syncthreads();
+  if (lds_words[(threadIdx.x * 97) % words] == 1u) lds_words[0] = 2u;  // (keeps the stores observable)
+}
+}  // namespace
+extern "C" int mir_debug_poison_lds(int device_id, void* stream) {
+  DeviceGuard guard(device_id);
+  const int bytes = 160 * 1024;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+  // one 160 KB workgroup owns a whole CU; several waves of workgroups so that every CU is visited
+  hipLaunchKernelGGL(k_poison_lds, dim3(4096), dim3(256), bytes, (hipStream_t)stream, bytes / 4);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "k_poison_lds");
+  return MIR_OK;
+}
+
 int mir_get_obs(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);

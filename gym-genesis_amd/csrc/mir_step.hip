@@ -141,8 +141,11 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 // SINGLE = one full step per launch without the rollout / autoreset / per-stage-output options (the headline launch): the
 // step loop disappears at compile time, and with it the block of scalar-register spills that the loop structure forces in
 // front of it (every launch-invariant value is otherwise saved before the loop and restored inside it).
-template <bool SINGLE>
+// VARIANT 0 = SINGLE (above); 1 = the step loop for rollouts (no per-stage / debug outputs and no separate observation
+// buffers: only packed rows), which keeps 11 pointers out of the scalar registers; 2 = everything.
+template <int VARIANT>
 __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
+  constexpr bool SINGLE = VARIANT == 0;
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
   __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
   const DevModel* __restrict__ m = a.model;
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   STAMP(1);
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; }
+  if (VARIANT == 1) { a.mode = 0; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; a.agent_pos = a.env_state = a.reward = nullptr; a.terminated = nullptr; }
   // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
   const int eb = m->eef_body, ob = m->obj_body;
   const int ad = 7 + m->n_grip;
@@ -276,6 +280,9 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       }
       st3v(&S.cdof[lane][0], ang);
       st3v(&S.cdof[lane][4], lin);
+    } else {  // (a lane without a dof still owns a row: zeros, not stale LDS)
+      st3v(&S.cdof[lane][0], v3(0, 0, 0));
+      st3v(&S.cdof[lane][4], v3(0, 0, 0));
     }
     if (isbody) {
       M3 R = q2m(ld4v(S.xquat[lane]));
@@ -662,9 +669,10 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
           const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));            \
           const V3 vel = cross(cd_ang, r) + cd_lin;                                                           \
           float* jb = &S.Jb[cc][0];                                                                           \
-          jb[lane] = sgn * dot(vel, v3(fn.x, fn.y, fn.z));                                                    \
-          jb[16 + lane] = sgn * dot(vel, v3(f1.x, f1.y, f1.z));                                               \
-          jb[32 + lane] = sgn * dot(vel, v3(f2.x, f2.y, f2.z));                                               \
+          /* (selects, not products: a lane that carries no dof holds stale LDS in cd_ang / cd_lin, and 0 x NaN is NaN) */ \
+          jb[lane] = sgn != 0.0f ? sgn * dot(vel, v3(fn.x, fn.y, fn.z)) : 0.0f;                               \
+          jb[16 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f1.x, f1.y, f1.z)) : 0.0f;                          \
+          jb[32 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f2.x, f2.y, f2.z)) : 0.0f;                          \
         }
         MIR_JCOL(mkA, cpA, r1A, r2A, fnA, f1A, f2A, cA)
         if (c0 + 1 < ncon) MIR_JCOL(mkB, cpB, r1B, r2B, fnB, f1B, f2B, cB)
@@ -1069,7 +1077,10 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   (void)max_contacts_lds;
   const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !a.prof && !a.out_M && !a.out_bias &&
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat;
-  if (single) hipLaunchKernelGGL(mir_step_kernel<true>, dim3(blocks), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL(mir_step_kernel<false>, dim3(blocks), dim3(64), 0, stream, a);
+  const bool plain_loop = a.mode == 0 && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
+                          !a.env_state && !a.reward && !a.terminated;
+  if (single) hipLaunchKernelGGL(mir_step_kernel<0>, dim3(blocks), dim3(64), 0, stream, a);
+  else if (plain_loop) hipLaunchKernelGGL(mir_step_kernel<1>, dim3(blocks), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(mir_step_kernel<2>, dim3(blocks), dim3(64), 0, stream, a);
   return (int)hipGetLastError();
 }

@@ -770,9 +770,10 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));                    \
         const V3 vel = cross(cd_ang, r) + cd_lin;                                                                   \
         float* jb = &S.Jb[(eq) >> 1][(eq) & 1][0];                                                                  \
-        jb[l16] = sgn * dot(vel, v3(fn.x, fn.y, fn.z));                                                             \
-        jb[16 + l16] = sgn * dot(vel, v3(f1.x, f1.y, f1.z));                                                        \
-        jb[32 + l16] = sgn * dot(vel, v3(f2.x, f2.y, f2.z));                                                        \
+        /* (selects, not products: a lane that carries no dof holds stale LDS in cd_ang / cd_lin, and 0 x NaN is NaN) */       \
+        jb[l16] = sgn != 0.0f ? sgn * dot(vel, v3(fn.x, fn.y, fn.z)) : 0.0f;                                        \
+        jb[16 + l16] = sgn != 0.0f ? sgn * dot(vel, v3(f1.x, f1.y, f1.z)) : 0.0f;                                   \
+        jb[32 + l16] = sgn != 0.0f ? sgn * dot(vel, v3(f2.x, f2.y, f2.z)) : 0.0f;                                   \
       }
       MIR_JCOL64(mkA, cpA, r1A, r2A, fnA, f1A, f2A, eqA)
       if (k0 + 1 < nmine) MIR_JCOL64(mkB, cpB, r1B, r2B, fnB, f1B, f2B, eqB)

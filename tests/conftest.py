@@ -37,3 +37,21 @@ def franka_spec():
     from gym_genesis.backend import models
 
     return models.franka_cube_pick_scene().build()
+
+
+@pytest.fixture(autouse=True)
+def _poison_lds(request):
+    """GPU tests start from LDS full of NaN patterns (mir_debug_poison_lds): a step kernel that reads a slot before writing
+    it would otherwise usually find the plausible leftovers of the previous launch there."""
+    if "gpu" in request.keywords and _has_gpu():
+        import ctypes as C
+
+        import torch
+        from gym_genesis.backend import lib
+
+        L = lib.load_library()
+        L.mir_debug_poison_lds.argtypes = [C.c_int, C.c_void_p]
+        L.mir_debug_poison_lds.restype = C.c_int
+        assert L.mir_debug_poison_lds(torch.cuda.current_device(), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        torch.cuda.synchronize()
+    yield
