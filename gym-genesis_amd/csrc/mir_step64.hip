@@ -223,8 +223,10 @@ __device__ __forceinline__ void condot3(const Env64& S, int c, const float* x, f
 // ---------------------------------------------------------------------------------------------
 // SINGLE = one full step per launch without the rollout / autoreset / per-stage-output options: no step loop, hence none of
 // the scalar-register spills the loop structure forces (see mir_step.hip).
-template <bool SINGLE>
+// VARIANT 0 = SINGLE; 1 = the step loop of rollouts (packed rows only, no per-stage / separate outputs); 2 = everything.
+template <int VARIANT>
 __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
+  constexpr bool SINGLE = VARIANT == 0;
   __shared__ __attribute__((aligned(16))) Env64 S;
   const DevModel64* __restrict__ m = a.model;
   const int lane = threadIdx.x;
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   STAMP(1);
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; }
+  if (VARIANT == 1) { a.mode = 0; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; a.agent_pos = a.env_state = a.reward = nullptr; a.terminated = nullptr; }
   // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
   const int eb = m->eef_body, ob = m->obj_body, ob2 = m->obj2_body;
   const int ad = m->agent_dim, ed = m->env_dim;
@@ -1226,7 +1229,10 @@ extern "C" int mir_launch_step64(const StepArgs64* args, hipStream_t stream) {
   StepArgs64 a = *args;
   const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !a.prof && !a.out_M && !a.out_bias &&
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat;
-  if (single) hipLaunchKernelGGL(mir_step64_kernel<true>, dim3(a.B), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL(mir_step64_kernel<false>, dim3(a.B), dim3(64), 0, stream, a);
+  const bool plain_loop = a.mode == 0 && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
+                          !a.env_state && !a.reward && !a.terminated;
+  if (single) hipLaunchKernelGGL(mir_step64_kernel<0>, dim3(a.B), dim3(64), 0, stream, a);
+  else if (plain_loop) hipLaunchKernelGGL(mir_step64_kernel<1>, dim3(a.B), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(mir_step64_kernel<2>, dim3(a.B), dim3(64), 0, stream, a);
   return (int)hipGetLastError();
 }
