@@ -31,3 +31,25 @@ def test_expert_collection(tmp_path, monkeypatch, script, env_dim, min_frac):
     assert n == kept * (200 if script.startswith("pick") else 470)
     assert d["observation.state"].shape == (n, 9) and d["observation.environment_state"].shape == (n, env_dim)
     assert d["episode_index"].max() == kept - 1 and np.isfinite(d["observation.state"]).all()
+
+
+def test_step_outputs_are_fresh_tensors_on_the_device():
+    """GenesisEnv.step() hands out new tensors every call (the next call's outputs are allocated while the kernel runs):
+    what the caller keeps from one step is not touched by later steps."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "gym-genesis_amd"))
+    from gym_genesis.env import GenesisEnv
+
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=16, enable_pixels=False)
+    env.reset(seed=0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    acts = torch.empty((6, 16, 9), device="cuda").uniform_(-1, 1, generator=g)
+    obs, rew, term, trunc, info = env.step(acts[0])
+    held = (obs["agent_pos"], obs["environment_state"], rew, info["is_success"])
+    kept = [t.clone() for t in held]
+    for k in range(1, 6):
+        o2, *_ = env.step(acts[k])
+        assert o2["agent_pos"].data_ptr() != held[0].data_ptr()
+    assert all(torch.equal(a, b) for a, b in zip(held, kept))
+    assert info["is_success"].dtype == torch.bool and term.dtype == bool

@@ -131,6 +131,14 @@ def test_env_reset_step_contract(env):
     assert reward.shape == (B,) and reward.dtype == torch.float32
     assert np.array_equal(terminated, reward.numpy() == 1) and np.array_equal(info["is_success"].numpy(), terminated)
     assert obs2["agent_pos"] is not obs["agent_pos"]  # fresh tensors per step
+    # ... and really fresh: the outputs of the NEXT call are allocated while this call's kernel runs (MirScene.step_fresh), so an
+    # observation the caller keeps must not be overwritten by later steps, and info["is_success"] stays the step's own mask
+    keep_obs, keep_rew, keep_succ = obs2["agent_pos"].clone(), reward.clone(), info["is_success"].clone()
+    held_obs, held_rew, held_succ = obs2["agent_pos"], reward, info["is_success"]
+    for _ in range(3):
+        env.step(np.stack([env.action_space.sample() for _ in range(B)]))
+    assert torch.equal(held_obs, keep_obs) and torch.equal(held_rew, keep_rew) and torch.equal(held_succ, keep_succ)
+    assert info["is_success"].dtype == torch.bool
     # torch actions are accepted too (pick_cube_state.py:53)
     env.step(torch.as_tensor(act))
     with pytest.raises(ValueError):
