@@ -628,12 +628,16 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
         const bool pen = isplane && l16 < 8 && d < 0.0f;
         const uint32_t penm = (uint32_t)(__ballot(pen) >> (blk * G)) & 0xffu;
         const int cnt = __popc(penm);
-        // support extremes (+u, -u, +v, -v; lowest corner index wins ties) when more than 4 corners penetrate
-        const float uM = gmaxf(pen ? u : -3e38f), um = -gmaxf(pen ? -u : -3e38f);
-        const float vM = gmaxf(pen ? v : -3e38f), vm = -gmaxf(pen ? -v : -3e38f);
-        const uint32_t e0 = (uint32_t)(__ballot(pen && u == uM) >> (blk * G)) & 0xffu, e1 = (uint32_t)(__ballot(pen && u == um) >> (blk * G)) & 0xffu;
-        const uint32_t e2 = (uint32_t)(__ballot(pen && v == vM) >> (blk * G)) & 0xffu, e3 = (uint32_t)(__ballot(pen && v == vm) >> (blk * G)) & 0xffu;
-        const uint32_t ext = (e0 & -e0) | (e1 & -e1) | (e2 & -e2) | (e3 & -e3);
+        // support extremes (+u, -u, +v, -v; lowest corner index wins ties), needed only when more than 4 corners penetrate
+        // somewhere in the wave (a box lying flat has exactly 4: the reductions are skipped)
+        uint32_t ext = 0u;
+        if (__any(cnt > 4)) {
+          const float uM = gmaxf(pen ? u : -3e38f), um = -gmaxf(pen ? -u : -3e38f);
+          const float vM = gmaxf(pen ? v : -3e38f), vm = -gmaxf(pen ? -v : -3e38f);
+          const uint32_t e0 = (uint32_t)(__ballot(pen && u == uM) >> (blk * G)) & 0xffu, e1 = (uint32_t)(__ballot(pen && u == um) >> (blk * G)) & 0xffu;
+          const uint32_t e2 = (uint32_t)(__ballot(pen && v == vM) >> (blk * G)) & 0xffu, e3 = (uint32_t)(__ballot(pen && v == vm) >> (blk * G)) & 0xffu;
+          ext = (e0 & -e0) | (e1 & -e1) | (e2 & -e2) | (e3 & -e3);
+        }
         const uint32_t keepm = cnt <= 4 ? penm : ext;
         const bool keep = (keepm >> l16 & 1u) && l16 < 8;
         const int slot = __popc(keepm & ((1u << l16) - 1u));
