@@ -23,6 +23,8 @@
 //   * ~47 KB of LDS per env (phase-aliased like the 16-lane kernel) -> 3 envs per CU.  First correct path for the
 //     stack tasks; DESIGN.md lists what is still slow.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 #include "mir_model64.h"
@@ -892,11 +894,16 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     // step (comp != identity: the arm touches a cube, or two cubes of different blocks touch).  The wave runs alone on its
     // SIMD (LDS bounds the occupancy), so the 80 registers are free and every update is FMA work without memory round trips.
     const bool coupled = comp != 0x8421u;
-    float hd[G], ho[4][G];
+    // The solve is compiled twice: the block-diagonal case (no contact couples two blocks: 73 % of the envs) carries no
+    // off-diagonal rows and no 64-wide working copy, i.e. ~130 registers less than the coupled case.
+    auto newton = [&](auto coupled_t) {
+    constexpr bool COUPLED = decltype(coupled_t)::value;
+    float hd[G], ho[COUPLED ? 4 : 1][G];
 #pragma unroll
     for (int j = 0; j < G; j++) {
       hd[j] = isdof ? mrow[j] : (j == l16 ? 1.0f : 0.0f);
-      ho[0][j] = 0.0f; ho[1][j] = 0.0f; ho[2][j] = 0.0f; ho[3][j] = 0.0f;
+#pragma unroll
+      for (int bq = 0; bq < (COUPLED ? 4 : 1); bq++) ho[bq][j] = 0.0f;
     }
     const unsigned long long twoblk = __ballot(iscon && S.con.cblk[lane < MAXC ? lane : 0][1] >= 0);  // contacts with two segments
     float oldlact = 0.0f;
@@ -978,7 +985,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       }
       // off-diagonal blocks: wave-uniform walk over the two-block contacts; the rows of either block take the other
       // block's segment as columns
-      if (coupled) {
+      if constexpr (COUPLED) {
         for (unsigned long long tw = twoblk; tw; tw &= tw - 1ull) {
           const int c = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tw));
           const f4 fb = ldv(S.con.cfb[c]);
@@ -1021,7 +1028,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       if (it == 0) STAMP(13);
       // ---- Newton direction: H s = -g: four 16-wide DPP block solves side by side, or dense over the wave
       float sv = -g;
-      if (!coupled) {
+      if constexpr (!COUPLED) {
         float hb[G];
 #pragma unroll
         for (int j = 0; j < G; j++) hb[j] = hd[j];
@@ -1121,6 +1128,8 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       }
       WSYNC();
     }
+    };
+    if (coupled) newton(std::true_type{}); else newton(std::false_type{});
     STAMP(16);
     if (a.out_qacc && isdof && step == 0) a.out_qacc[(size_t)env * nv + m->d_dof[lane]] = qacc;
     if (a.diag && lane == 0) {
