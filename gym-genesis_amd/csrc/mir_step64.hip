@@ -894,16 +894,18 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     // step (comp != identity: the arm touches a cube, or two cubes of different blocks touch).  The wave runs alone on its
     // SIMD (LDS bounds the occupancy), so the 80 registers are free and every update is FMA work without memory round trips.
     const bool coupled = comp != 0x8421u;
-    // The solve is compiled twice: the block-diagonal case (no contact couples two blocks: 73 % of the envs) carries no
-    // off-diagonal rows and no 64-wide working copy, i.e. ~130 registers less than the coupled case.
-    auto newton = [&](auto coupled_t) {
-    constexpr bool COUPLED = decltype(coupled_t)::value;
-    float hd[G], ho[COUPLED ? 4 : 1][G];
+    // In the single-step instantiation the solve is compiled twice: the block-diagonal case (no contact couples two blocks:
+    // 73 % of the envs) carries no off-diagonal rows and no 64-wide working copy, i.e. ~130 registers less than the coupled
+    // case.  (The loop instantiations keep one run-time-switched copy: there the duplication cost more than it saved.)
+    auto newton = [&](auto mode_t) {
+    constexpr int MODE = decltype(mode_t)::value;  // 0: block-diagonal, 1: coupled, 2: decided at run time (loop instantiations)
+    const bool cpl = MODE == 2 ? coupled : MODE == 1;
+    float hd[G], ho[MODE == 0 ? 1 : 4][G];
 #pragma unroll
     for (int j = 0; j < G; j++) {
       hd[j] = isdof ? mrow[j] : (j == l16 ? 1.0f : 0.0f);
 #pragma unroll
-      for (int bq = 0; bq < (COUPLED ? 4 : 1); bq++) ho[bq][j] = 0.0f;
+      for (int bq = 0; bq < (MODE == 0 ? 1 : 4); bq++) ho[bq][j] = 0.0f;
     }
     const unsigned long long twoblk = __ballot(iscon && S.con.cblk[lane < MAXC ? lane : 0][1] >= 0);  // contacts with two segments
     float oldlact = 0.0f;
@@ -985,7 +987,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       }
       // off-diagonal blocks: wave-uniform walk over the two-block contacts; the rows of either block take the other
       // block's segment as columns
-      if constexpr (COUPLED) {
+      if constexpr (MODE != 0) if (cpl) {
         for (unsigned long long tw = twoblk; tw; tw &= tw - 1ull) {
           const int c = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tw));
           const f4 fb = ldv(S.con.cfb[c]);
@@ -1028,18 +1030,23 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       if (it == 0) STAMP(13);
       // ---- Newton direction: H s = -g: four 16-wide DPP block solves side by side, or dense over the wave
       float sv = -g;
-      if constexpr (!COUPLED) {
+      bool dense = false;
+      if constexpr (MODE != 0) dense = cpl;
+      if (!dense) {
         float hb[G];
 #pragma unroll
         for (int j = 0; j < G; j++) hb[j] = hd[j];
         GJ<0>::run(hb, sv, l16);
-      } else {
-        v16f hrow[4];
+      }
+      if constexpr (MODE != 0) {
+        if (dense) {
+          v16f hrow[4];
 #pragma unroll
-        for (int bq = 0; bq < 4; bq++)
+          for (int bq = 0; bq < 4; bq++)
 #pragma unroll
-          for (int j = 0; j < G; j++) hrow[bq][j] = blk == bq ? hd[j] : ho[bq][j];
-        gj_wave(hrow, sv, lane, lanemask, comp);
+            for (int j = 0; j < G; j++) hrow[bq][j] = blk == bq ? hd[j] : ho[bq][j];
+          gj_wave(hrow, sv, lane, lanemask, comp);
+        }
       }
       if (!isdof) sv = 0.0f;
       if (it == 0) STAMP(14);
@@ -1129,7 +1136,9 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       WSYNC();
     }
     };
-    if (coupled) newton(std::true_type{}); else newton(std::false_type{});
+    if constexpr (!SINGLE) newton(std::integral_constant<int, 2>{});
+    else if (coupled) newton(std::integral_constant<int, 1>{});
+    else newton(std::integral_constant<int, 0>{});
     STAMP(16);
     if (a.out_qacc && isdof && step == 0) a.out_qacc[(size_t)env * nv + m->d_dof[lane]] = qacc;
     if (a.diag && lane == 0) {
