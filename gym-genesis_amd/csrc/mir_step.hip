@@ -152,17 +152,15 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   const int tid = threadIdx.x;
   STAMP(24);
   if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[26] = __builtin_amdgcn_s_memrealtime();
+  // Prologue: EVERY global read of the launch -- model table, per-lane constants, state rows, action, cached poses -- is
+  // issued before the first LDS store, so the launch starts with one L2 round trip (the compiler otherwise kept three: the
+  // stores of one group sat in front of the loads of the next).
+  constexpr int TAB_NQ = (int)(sizeof(ModelTab) / 16), TAB_NPASS = (TAB_NQ + 63) / 64;
+  f4 tabtmp[TAB_NPASS];
   {
-    // all table loads are issued before the first LDS store (one L2 round trip for the whole copy, not one per pass)
     const f4* src = reinterpret_cast<const f4*>(&m->tab);
-    f4* dst = reinterpret_cast<f4*>(&T);
-    constexpr int NQ = (int)(sizeof(ModelTab) / 16), NPASS = (NQ + 63) / 64;
-    f4 tmp[NPASS];
 #pragma unroll
-    for (int k = 0; k < NPASS; k++) tmp[k] = src[min(tid + 64 * k, NQ - 1)];
-#pragma unroll
-    for (int k = 0; k < NPASS; k++)
-      if (tid + 64 * k < NQ) dst[tid + 64 * k] = tmp[k];
+    for (int k = 0; k < TAB_NPASS; k++) tabtmp[k] = src[min(tid + 64 * k, TAB_NQ - 1)];
   }
   const int lane = tid & (G - 1);
   const int grp = tid >> 4;
@@ -207,18 +205,32 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
 
   // ---- load state -----------------------------------------------------------------------------
   // (addresses from the launch arguments only: these loads leave together with the model loads above)
-  for (int i = lane; i < a.qst; i += G) S.qpos[i] = a.qpos[(size_t)env * a.qst + i];
-  S.qvel[lane] = a.qvel[(size_t)env * G + lane];
-  S.qacc_ws[lane] = a.qacc_ws[(size_t)env * G + lane];
+  static_assert(sizeof(((EnvLds*)nullptr)->qpos) / sizeof(float) <= 2 * G, "qpos row: at most two entries per lane");
+  const float q_lo = lane < a.qst ? a.qpos[(size_t)env * a.qst + lane] : 0.0f;
+  const float q_hi = lane + G < a.qst ? a.qpos[(size_t)env * a.qst + lane + G] : 0.0f;
+  const float qv_in = a.qvel[(size_t)env * G + lane], ws_in = a.qacc_ws[(size_t)env * G + lane];
+  float tg = a.target[(size_t)env * G + lane];
+  const float au = (a.action && lane < a.nu) ? a.action[(size_t)env * a.nu + lane] : 0.0f;
+  // the cached link poses travel with their validity flag (poses is a (B, 2, 16, 4) array: the speculative read is in bounds)
+  const float* pose_p = a.poses + ((size_t)env * 2 * G + lane) * 4;
+  const f4 cpos = *reinterpret_cast<const f4*>(pose_p), cquat = *reinterpret_cast<const f4*>(pose_p + 4 * G);
+  const bool cached = a.fkvalid[env] != 0;
+  __builtin_amdgcn_sched_barrier(0);  // (nothing below may move in front of the loads above)
   {
-    float tg = a.target[(size_t)env * G + lane];
-    if (a.action) {  // lane u fetches action component u; the dof that it drives picks it up across the row
-      const float au = lane < a.nu ? a.action[(size_t)env * a.nu + lane] : 0.0f;
-      const float mine = __shfl(au, (tid & ~(G - 1)) + (d_uadr >= 0 ? d_uadr : 0));
-      if (isdof && d_uadr >= 0) tg = mine;
-    }
-    S.target[lane] = tg;
+    f4* dst = reinterpret_cast<f4*>(&T);
+#pragma unroll
+    for (int k = 0; k < TAB_NPASS; k++)
+      if (tid + 64 * k < TAB_NQ) dst[tid + 64 * k] = tabtmp[k];
   }
+  if (lane < a.qst) S.qpos[lane] = q_lo;
+  if (lane + G < a.qst) S.qpos[lane + G] = q_hi;
+  S.qvel[lane] = qv_in;
+  S.qacc_ws[lane] = ws_in;
+  if (a.action) {  // lane u fetched action component u; the dof that it drives picks it up across the row
+    const float mine = __shfl(au, (tid & ~(G - 1)) + (d_uadr >= 0 ? d_uadr : 0));
+    if (isdof && d_uadr >= 0) tg = mine;
+  }
+  S.target[lane] = tg;
   if (lane == 0) { S.ncon = 0; S.ncand = 0; }
   WSYNC();
 
@@ -227,11 +239,6 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   // that produced its observations); reuse them unless reset / set_state invalidated this env.
   STAMP(0);
   {
-    // the cached poses are fetched together with their validity flag (no dependent second round trip); poses is a
-    // (B, 2, 16, 4) array, so the speculative read is always in bounds
-    const float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
-    const f4 cpos = *reinterpret_cast<const f4*>(p), cquat = *reinterpret_cast<const f4*>(p + 4 * G);
-    const bool cached = a.fkvalid[env] != 0;
     if (cached && lane < nb) {
       stv(S.xpos[lane], cpos);
       stv(S.xquat[lane], cquat);
