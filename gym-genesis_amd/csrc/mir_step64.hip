@@ -276,44 +276,54 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   const int g_bodyl = m->g_body[gl];
   const V3 g_posl = ld3(m->g_pos[gl]);
   const Q4 g_quatl = ld4(m->g_quat[gl]);
+  // Every global read of the launch -- staged tables, state rows, action, cached poses -- is issued before the first LDS
+  // store: one L2 round trip at the start of the launch instead of one per group of stores (see mir_step.hip).
+  const int gi = lane < ngeom ? lane : 0, bi = lane < NB ? lane : 0;
+  const int gt_in = m->g_type[gi];
+  const float gsx = m->g_size[gi][0], gsy = m->g_size[gi][1], gsz = m->g_size[gi][2], gfr_in = m->g_pos[gi][3];
+  static_assert(MIR_MAX_PAIR <= 4 * NL, "pair list: at most four entries per lane");
+  int pr_in[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) pr_in[u] = m->pair[lane + NL * u < npair ? lane + NL * u : 0];
+  const f4 gs0 = reinterpret_cast<const f4*>(m->g_sol[gi])[0], gs1 = reinterpret_cast<const f4*>(m->g_sol[gi])[1];
+  const f4 bt0 = reinterpret_cast<const f4*>(m->b_tab[bi])[0], bt1 = reinterpret_cast<const f4*>(m->b_tab[bi])[1];
+  const int par_in = m->b_parent[bi];
+  const float q_in = a.qpos[(size_t)env * K64_QSTRIDE + lane], qv_in = a.qvel[(size_t)env * NL + lane], ws_in = a.qacc_ws[(size_t)env * NL + lane];
+  float tg = a.target[(size_t)env * NL + lane];
+  const float au = (a.action && lane < a.nu) ? a.action[(size_t)env * a.nu + lane] : 0.0f;
+  // (the cached poses travel with their validity flag; (B, 2, 32, 4): the speculative read is in bounds)
+  const float* pose_p = a.poses + ((size_t)env * 2 * NB + (lane & (NB - 1))) * 4;
+  const f4 cpos = *reinterpret_cast<const f4*>(pose_p), cquat = *reinterpret_cast<const f4*>(pose_p + 4 * NB);
+  const bool cached = a.fkvalid[env] != 0;  // wave-uniform
+  __builtin_amdgcn_sched_barrier(0);  // (nothing below may move in front of the loads above)
   if (lane < ngeom) {
-    stv(S.gts[lane], f4{__int_as_float(m->g_type[lane] | (g_bodyl << 8)), m->g_size[lane][0], m->g_size[lane][1], m->g_size[lane][2]});
-    S.gfr[lane] = m->g_pos[lane][3];
+    stv(S.gts[lane], f4{__int_as_float(gt_in | (g_bodyl << 8)), gsx, gsy, gsz});
+    S.gfr[lane] = gfr_in;
+    stv(&S.gsol[lane][0], gs0); stv(&S.gsol[lane][4], gs1);
   }
-  for (int p = lane; p < npair; p += NL) S.pairs[p] = (unsigned short)m->pair[p];
-  if (lane < ngeom) {
-    const f4* gs = reinterpret_cast<const f4*>(m->g_sol[lane]);
-    stv(&S.gsol[lane][0], gs[0]); stv(&S.gsol[lane][4], gs[1]);
-  }
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+    if (lane + NL * u < npair) S.pairs[lane + NL * u] = (unsigned short)pr_in[u];
   if (lane < NB) {
-    const f4* bt = reinterpret_cast<const f4*>(m->b_tab[lane]);
-    stv(&S.btab[lane][0], bt[0]); stv(&S.btab[lane][4], bt[1]);
+    stv(&S.btab[lane][0], bt0); stv(&S.btab[lane][4], bt1);
+    S.parent[lane] = lane < nb ? par_in : 0;
   }
 
   STAMP(0);
-  // ---- load state -----------------------------------------------------------------------------
-  S.qpos[lane] = a.qpos[(size_t)env * K64_QSTRIDE + lane];
-  S.qvel[lane] = a.qvel[(size_t)env * NL + lane];
-  S.qacc_ws[lane] = a.qacc_ws[(size_t)env * NL + lane];
-  {
-    float tg = a.target[(size_t)env * NL + lane];
-    if (a.action) {  // lane u fetches action component u; the dof it drives picks it up across the wave
-      const float au = lane < a.nu ? a.action[(size_t)env * a.nu + lane] : 0.0f;
-      const float mine = __shfl(au, d_uadr >= 0 ? d_uadr : 0);
-      if (isdof && d_uadr >= 0) tg = mine;
-    }
-    S.target[lane] = tg;
+  // ---- state -------------------------------------------------------------------------------------
+  S.qpos[lane] = q_in;
+  S.qvel[lane] = qv_in;
+  S.qacc_ws[lane] = ws_in;
+  if (a.action) {  // lane u fetched action component u; the dof it drives picks it up across the wave
+    const float mine = __shfl(au, d_uadr >= 0 ? d_uadr : 0);
+    if (isdof && d_uadr >= 0) tg = mine;
   }
-  if (lane < NB) S.parent[lane] = lane < nb ? m->b_parent[lane] : 0;
+  S.target[lane] = tg;
   if (lane == 0) { S.ncon = 0; S.ncand = 0; }
   WSYNC();
 
   // ======================= forward kinematics (FK cache as in the 16-lane kernel) ====================
   {
-    // the cached poses are fetched together with their validity flag ((B, 2, 32, 4): the speculative read is in bounds)
-    const float* p = a.poses + ((size_t)env * 2 * NB + (lane & (NB - 1))) * 4;
-    const f4 cpos = *reinterpret_cast<const f4*>(p), cquat = *reinterpret_cast<const f4*>(p + 4 * NB);
-    const bool cached = a.fkvalid[env] != 0;  // wave-uniform
     if (cached) {
       if (lane < nb) {
         stv(S.xpos[lane], cpos);
