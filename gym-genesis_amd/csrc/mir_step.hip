@@ -172,6 +172,13 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   const int nb = m->nbody, nv = m->nv, qst = a.qst;
   const int ngeom = m->ngeom, npair = m->npair, max_contacts = m->max_contacts, enable_collision = m->enable_collision;
   const float dt = m->dt;
+  // Every scalar of the model that the step reads is fetched HERE, with the first batch of loads.  A read through `m` further
+  // down cannot be hoisted by the compiler above the wave fences that separate the phases, so it would sit where it is used
+  // -- an L2 round trip in the middle of the serial chain (m->iterations was re-read in every Newton iteration).
+  const int mdl_iterations = m->iterations, mdl_ls_iterations = m->ls_iterations;
+  const float mdl_tolerance = m->tolerance, mdl_scale = m->solver_scale, mdl_reward_z = m->reward_z;
+  const float mdl_gx = m->gx, mdl_gy = m->gy, mdl_gz = m->gz;
+  const int mdl_eef = m->eef_body, mdl_obj = m->obj_body, mdl_ngrip = m->n_grip;
 
   // ---- per-lane model constants (lane = body = dof): twelve independent 16-byte loads (LaneK16) -------------
   const bool isbody = lane < nb && lane > 0;
@@ -251,8 +258,8 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; }
   if (VARIANT == 1) { a.mode = 0; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; a.agent_pos = a.env_state = a.reward = nullptr; a.terminated = nullptr; }
   // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
-  const int eb = m->eef_body, ob = m->obj_body;
-  const int ad = 7 + m->n_grip;
+  const int eb = mdl_eef, ob = mdl_obj;
+  const int ad = 7 + mdl_ngrip;
   auto column = [&](int c) -> float {
     const V3 pe = ld3v(S.xpos[eb]), po = ld3v(S.xpos[ob]);
     const V3 df = pe - po;
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     if (k < 7) return S.xquat[ob][k - 3];
     if (k < 10) return k == 7 ? df.x : (k == 8 ? df.y : df.z);
     if (k == 10) return sqrtf(dot(df, df));
-    return po.z > m->reward_z ? 1.0f : 0.0f;  // k == 11 reward, k == 12 terminated
+    return po.z > mdl_reward_z ? 1.0f : 0.0f;  // k == 11 reward, k == 12 terminated
   };
   int eplen = a.ar.episode_len ? a.ar.episode_len[env] : 0, epcur = a.ar.episode_len ? a.ar.cursor[env] : 0;
   for (int step = 0; step < nsteps; step++) {
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     {
       V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
       if (isbody) {
-        V3 aw = v3(0, 0, 0), av = v3(-m->gx, -m->gy, -m->gz);
+        V3 aw = v3(0, 0, 0), av = v3(-mdl_gx, -mdl_gy, -mdl_gz);
         gather_pair(b_dofmask, &S.dyn.cddq[0][0], aw, av);
         Inert I = ldI(S.dyn.cinert[lane]);
         V3 w = ld3v(&S.dyn.cvel[lane][0]), v = ld3v(&S.dyn.cvel[lane][4]);
@@ -768,7 +775,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     }
     STAMP(7);
     int niter = 0;
-    const float tol = m->tolerance, scale = m->solver_scale;
+    const float tol = mdl_tolerance, scale = mdl_scale;
     // float32 rounding floor of the gradient Ma - qfrc_smooth - J^T f: below it a Newton step no
     // longer changes qacc, so iterating further is noise (same rule as the oracle, with float eps)
     const float gfloor = 16.0f * 5.96e-8f * sqrtf(gsum(Ma * Ma + qfs * qfs));
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     float oldlact = 0.0f;
     unsigned prevbits = 0u;  // contact lane: flags written in the previous iteration
     float gprev = 0.0f;
-    for (int it = 0; it < m->iterations; it++) {
+    for (int it = 0; it < mdl_iterations; it++) {
       if (!__any(!done)) break;
       // ---- forces of the active rows; base-force triple and active flags to LDS for the dof lanes
       float lact = (lsg != 0.0f && ljar < 0.0f) ? lD : 0.0f;
@@ -879,7 +886,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       const float A = gsum(sv * mv), Bq = gsum(sv * (Ma - qfs));
       float alpha = 0.0f, lo = 0.0f, hi = -1.0f, g0 = 0.0f;
       bool lsdone = done;
-      for (int ls = 0; ls < m->ls_iterations; ls++) {
+      for (int ls = 0; ls < mdl_ls_iterations; ls++) {
         float pg = 0.0f, ph = 0.0f, pa = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -1005,7 +1012,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     }
     if (a.ar.episode_len) {
       // episode bookkeeping and re-spawn on chip (the rules of k_autoreset): the row above is the terminal observation
-      const bool term = S.xpos[ob][2] > m->reward_z;
+      const bool term = S.xpos[ob][2] > mdl_reward_z;
       const int len = eplen + 1;
       const bool trunc = !term && a.ar.max_len > 0 && len >= a.ar.max_len;
       const bool done = term || trunc;
@@ -1052,7 +1059,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   }
   if (a.action) a.target[(size_t)env * G + lane] = S.target[lane];
   // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
-  const float rew = S.xpos[ob][2] > m->reward_z ? 1.0f : 0.0f;
+  const float rew = S.xpos[ob][2] > mdl_reward_z ? 1.0f : 0.0f;
   if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
   if (a.env_state && lane < 11) a.env_state[(size_t)env * 11 + lane] = column(ad + lane);
   if (lane == 0) {
