@@ -22,6 +22,14 @@
 //     by a compiler-level fence only (WSYNC), never an s_barrier.
 //   * HBM state is env-major (B, D): with 16 lanes per env a wave touches 4 contiguous 64-byte
 //     rows, the coalesced pattern for this lane mapping.  ~0.25 KB read + ~0.3 KB written per env-step.
+//   * the wave runs alone on its SIMD at the headline batch (the batch bounds the occupancy), so the kernel is a serial chain
+//     of LDS round trips: loops over contacts / tree masks issue the reads of two or four entries in one batch ahead of
+//     the arithmetic, vectors that a whole row needs once travel by row broadcast instead of through LDS, and every global
+//     read of a launch (tables, per-lane record, model scalars, state, action, cached poses) leaves before the first LDS
+//     store -- one L2 round trip at the start.
+//   * three instantiations: <0> one step per launch (no step loop: 17 SGPR spills, no AGPRs), <1> K-step rollouts with
+//     packed rows, <2> everything (per-stage outputs, pose refresh, profiling stamps).  Built with -ffp-contract=on so that
+//     they agree bit for bit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

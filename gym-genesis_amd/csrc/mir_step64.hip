@@ -3,7 +3,7 @@
 // What it replaces: scene.step() + get_obs() + compute_reward() of the reference's five-cube stack tasks
 // (/root/reference/gym_genesis/tasks/franka/cube_stack_kitchen_batch.py:131-160,
 //  /root/reference/gym_genesis/tasks/so101/cube_stack_batch.py:135-181; scene at tasks/utils.py:239-426,593-794):
-// arm + five free cubes on the kitchen-island slab, 36-39 dofs, up to 64 contacts.  Same formulation as
+// arm + five free cubes on the kitchen-island slab, 36-39 dofs, up to 48 contacts.  Same formulation as
 // mir_step.hip: CRB mass matrix + RNE bias, PD torques, box/plane narrowphase, pyramidal soft
 // contacts, primal Newton with exact line search, semi-implicit Euler.
 //
@@ -13,15 +13,17 @@
 //     inertia is block-diagonal: M rows are 16 wide, and M^-1 f is FOUR independent register-row Gauss-Jordan
 //     solves running side by side on row_newbcast DPP (the 16-lane kernel's solver, unchanged).
 //   * a contact touches at most two trees => at most two blocks: its Jacobian is stored as two dense 16-wide
-//     segments (3 base rows n, t1, t2 each) tagged with their block ids.  J x / J^T f / J^T D J touch only those
-//     segments; the Hessian row of a lane lives in 64 registers and a wave-uniform switch on the block id keeps
-//     every register index static.
-//   * the Newton system H = M + J^T D J couples blocks, so H^-1 g is a dense Gauss-Jordan over the 64 register
-//     rows with the pivot row travelling by v_readlane (SGPR broadcast); padding lanes are skipped wave-uniformly.
-//   * lane i is also body i (< 32), geom i, candidate pair i (4 passes), contact i: per-row solver state stays
-//     lane-private; wave-wide reductions are a DPP row reduction + 4 v_readlane.
-//   * ~47 KB of LDS per env (phase-aliased like the 16-lane kernel) -> 3 envs per CU.  First correct path for the
-//     stack tasks; DESIGN.md lists what is still slow.
+//     segments (3 base rows n, t1, t2 each) tagged with their block ids, and every dof lane walks the contact list of
+//     ITS block only (the four DPP rows side by side).
+//   * the Newton Hessian H = M + J^T D J lives in registers: the 16 columns of the lane's own block always, the columns of
+//     the other blocks only in steps where a contact couples two blocks (wave-uniform test).  Uncoupled: four DPP block
+//     solves side by side.  Coupled: a rolled Gauss-Jordan over 64 register columns, pivot row by v_readlane, pivot column
+//     by wave-uniform VGPR indexing, column blocks outside the pivot's component skipped.  In the single-step instantiation
+//     the two cases are compiled separately, so the common one carries none of the coupled one's registers.
+//   * lane i is also body i (< 32), geom i, candidate pair i (4 passes), contact i; box-box runs on a DPP row per pair
+//     (mir_dev.h); wave-wide reductions are a DPP row reduction + 4 v_readlane.
+//   * 37 KB of LDS per env (phase-aliased like the 16-lane kernel) -> 4 envs per CU, one wave per SIMD; no scratch.
+//   * three instantiations (single step / rollout loop / everything), as in mir_step.hip.  DESIGN.md section 10.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
