@@ -573,3 +573,38 @@ def test_c_abi_argument_errors_are_reported_not_crashed(franka_spec):
     assert sc.lib.mir_step(None, 1, None) != 0 and b"null" in sc.lib.mir_last_error()
     h2 = C.c_void_p()
     assert sc.lib.mir_create(C.byref(franka_spec), 4, 99, C.byref(h2)) == -4     # MIR_E_NODEVICE: no such device
+
+
+def test_full_batch_size_independent_properties(franka_spec):
+    """BASELINE's full batch (4096 envs, every SIMD of the chip busy), through properties that need no oracle run:
+    (a) envs that start identical stay bit-identical -- no env sees another one's lanes, LDS or launch order;
+    (b) a cube released above the table falls by the closed form of semi-implicit Euler, z_n = z_0 - g dt^2 n (n + 1) / 2,
+        while it touches nothing;
+    (c) the same actions through one 4096-env scene and through two 2048-env scenes give the same bits (sharding)."""
+    B, n = 4096, 20
+    sc = _scene(franka_spec, B)
+    rng = np.random.RandomState(11)
+    pos = np.tile(np.array([[0.6, 0.1, 0.8]], np.float32), (B, 1))
+    quat = np.tile(np.array([0, 0, 0, 1], np.float32), (B, 1))
+    arm = np.tile(HOME, (B, 1))
+    sc.reset(pos, quat, arm)
+    acts = torch.as_tensor((HOME + 0.3 * rng.uniform(-1, 1, (n, 1, 9))).astype(np.float32).repeat(B, axis=1), device=sc.device)
+    bufs = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    for k in range(n):
+        sc.step_fused(acts[k], *bufs)
+    q, v, _, _ = sc.get_state()
+    assert bool((q == q[0]).all()) and bool((v == v[0]).all())                       # (a)
+    z = q[:, 9 + 2].cpu().numpy().astype(np.float64)
+    want = 0.8 - 9.81 * 0.01 ** 2 * n * (n + 1) / 2
+    assert np.abs(z - want).max() < 2e-6, (z[0], want)                               # (b)
+    # (c) distinct actions per env, one scene vs two halves
+    big, lo, hi = _scene(franka_spec, B), _scene(franka_spec, B // 2), _scene(franka_spec, B // 2)
+    pos = np.stack([rng.uniform(0.45, 0.8, B), rng.uniform(-0.25, 0.25, B), np.full(B, 0.02)], 1).astype(np.float32)
+    big.reset(pos, quat, arm); lo.reset(pos[:B // 2], quat[:B // 2], arm[:B // 2]); hi.reset(pos[B // 2:], quat[B // 2:], arm[B // 2:])
+    a = torch.as_tensor(rng.uniform(-1, 1, (10, B, 9)).astype(np.float32), device=sc.device)
+    for k in range(10):
+        big.set_pd_targets(a[k]); big.step(1)
+        lo.set_pd_targets(a[k, :B // 2].contiguous()); lo.step(1)
+        hi.set_pd_targets(a[k, B // 2:].contiguous()); hi.step(1)
+    qb = big.get_state()[0]
+    assert torch.equal(qb, torch.cat([lo.get_state()[0], hi.get_state()[0]]))
