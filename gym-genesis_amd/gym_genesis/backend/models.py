@@ -30,7 +30,11 @@ FRANKA_HOME = (0.0, -0.4, 0.0, -2.2, 0.0, 2.0, 0.8, 0.04, 0.04)
 # reference: cube_stack_kitchen_batch.py:101-106
 FRANKA_KP = (4500.0, 4500.0, 3500.0, 3500.0, 2000.0, 2000.0, 2000.0, 100.0, 100.0)
 FRANKA_KV = (450.0, 450.0, 350.0, 350.0, 200.0, 200.0, 200.0, 10.0, 10.0)
+# the stack task sets +-87 on all seven arm joints explicitly (cube_stack_kitchen_batch.py:103-106)
 FRANKA_FRC = (87.0, 87.0, 87.0, 87.0, 87.0, 87.0, 87.0, 100.0, 100.0)
+# FrankaCubePickBatch sets NO force range (cube_pick.py:99-105), so it inherits the <actuator> block of panda.xml:
+# +-87 N m on joints 1-4, +-12 N m on the wrist joints 5-7, +-100 N on the fingers (UPSTREAM-RECALL)
+FRANKA_FRC_MJCF = (87.0, 87.0, 87.0, 87.0, 12.0, 12.0, 12.0, 100.0, 100.0)
 
 _S = math.sqrt(0.5)
 
@@ -68,10 +72,11 @@ _FINGER_BODY_BOX = ((0.0105, 0.0085, 0.0268), (0.0, 0.0145, 0.0268))
 _FINGER_PAD_BOX = ((0.0085, 0.004, 0.0085), (0.0, 0.0055, 0.0445))
 
 
-def _add_franka(sb: SceneBuilder, pos=(0.0, 0.0, 0.0), scale=1.0) -> None:
+def _add_franka(sb: SceneBuilder, pos=(0.0, 0.0, 0.0), scale=1.0, frc=FRANKA_FRC_MJCF) -> None:
     """The Panda (bodies, joints, collision boxes) mounted at `pos`, uniformly scaled like gs.morphs.MJCF(scale=...):
     lengths x s, masses x s^3, inertias x s^5, prismatic ranges x s; joint-level constants (armature, damping,
-    PD gains, force ranges) and revolute ranges unchanged."""
+    PD gains, force ranges) and revolute ranges unchanged.  `frc`: per-joint force limits (the MJCF defaults unless the task
+    overrides them with set_dofs_force_range)."""
     s = float(scale)
     s3, s5 = s ** 3, s ** 5
     sc = lambda v: tuple(x * s for x in v)  # noqa: E731
@@ -82,14 +87,14 @@ def _add_franka(sb: SceneBuilder, pos=(0.0, 0.0, 0.0), scale=1.0) -> None:
         sb.add_body(name, parent, pos=sc(lpos), quat=quat, jtype=JNT_REVOLUTE, axis=(0, 0, 1), mass=mass * s3, ipos=sc(com),
                     inertia=tuple(v * s5 for v in inertia), joint_name=FRANKA_JOINTS[i], limited=1, range=rng, armature=0.1,
                     damping=1.0, ctrl_mode=CTRL_POSITION, kp=FRANKA_KP[i], kv=FRANKA_KV[i],
-                    frc_range=(-FRANKA_FRC[i], FRANKA_FRC[i]))
+                    frc_range=(-frc[i], frc[i]))
     sb.add_body("hand", "link7", pos=sc((0, 0, 0.107)), quat=(0.9238795, 0, 0, -0.3826834), mass=0.73 * s3,
                 ipos=sc((-0.01, 0, 0.03)), inertia=tuple(v * s5 for v in (0.001, 0.0025, 0.0017, 0, 0, 0)))
     for k, (name, quat) in enumerate((("left_finger", (1, 0, 0, 0)), ("right_finger", (0, 0, 0, 1)))):
         sb.add_body(name, "hand", pos=sc((0, 0, 0.0584)), quat=quat, jtype=JNT_PRISMATIC, axis=(0, 1, 0), mass=0.015 * s3,
                     inertia=tuple(v * s5 for v in (2.375e-6, 2.375e-6, 7.5e-7, 0, 0, 0)), joint_name=FRANKA_JOINTS[7 + k], limited=1,
                     range=(0.0, 0.04 * s), armature=0.1, damping=1.0, ctrl_mode=CTRL_POSITION, kp=FRANKA_KP[7 + k],
-                    kv=FRANKA_KV[7 + k], frc_range=(-FRANKA_FRC[7 + k], FRANKA_FRC[7 + k]))
+                    kv=FRANKA_KV[7 + k], frc_range=(-frc[7 + k], frc[7 + k]))
     for body, half, centre in _PANDA_BOXES:
         sb.add_geom(body, GEOM_BOX, size=sc(half), pos=sc(centre), rgb=dark if body == "hand" else white)
     for finger in ("left_finger", "right_finger"):
@@ -206,7 +211,7 @@ def franka_cube_stack_scene() -> SceneBuilder:
     sb = SceneBuilder()
     sb.add_geom(0, GEOM_PLANE)                                                        # kitchen floor, z = 0
     sb.add_geom(0, GEOM_BOX, size=(0.915, 0.401, 0.05), pos=(0.0, 0.0, ISLAND_TOP_Z - 0.05), rgb=(0.75, 0.72, 0.68))
-    _add_franka(sb, pos=(-0.5, 0.0, 0.7), scale=0.6)
+    _add_franka(sb, pos=(-0.5, 0.0, 0.7), scale=0.6, frc=FRANKA_FRC)  # set explicitly by the task
     _stack_common(sb)
     sb.task = dict(eef_body=sb.body_index("hand"), obj_body=sb.body_index("cube_1"), obj2_body=sb.body_index("cube_2"),
                    grip_dof=(sb.dof_index("finger_joint1"), sb.dof_index("finger_joint2")), reward_z=0.1,

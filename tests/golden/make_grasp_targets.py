@@ -55,11 +55,11 @@ def ik(target_pos, seed):
 
 
 cubes = [(0.55, 0.0), (0.50, 0.15), (0.62, -0.12), (0.47, -0.05)]
-out = {"steps_per_stage": 40, "stages": ["hover", "descend", "close", "close", "lift"], "cube_xy": cubes, "targets": []}
+out = {"steps_per_stage": 40, "stages": ["hover", "stabilize", "descend", "close", "lift"], "cube_xy": cubes, "targets": []}
 for (x, y) in cubes:
     seed = HOME[:7].copy()
     per_env = []
-    for stage, (dz, grip) in (("hover", (0.25, 0.04)), ("descend", (0.104, 0.04)), ("close", (0.104, 0.0)), ("close", (0.104, 0.0)),
+    for stage, (dz, grip) in (("hover", (0.25, 0.04)), ("stabilize", (0.25, 0.04)), ("descend", (0.104, 0.04)), ("close", (0.104, 0.0)),
                                ("lift", (0.40, 0.0))):
         q7 = ik(np.array([x, y, 0.02 + dz]), seed)
         seed = q7
