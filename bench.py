@@ -1,46 +1,129 @@
 #!/usr/bin/env python3
-"""bench.py — env-steps/sec of the CubePick-v0 hot path on MI355X (BASELINE.json metric).
+"""bench.py — env-steps/sec of the CubePick-v0 `env.step()` hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: spawns N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1] / BASELINE.md §3): GenesisEnv(task="cube_pick", robot="franka",
-num_envs=4096 per GPU, enable_pixels=False); reset(seed=0); a fresh a_t ~ U(-1,1)^(B x 9) float32
-per step (generated on the device BEFORE the timed region: inputs are resident in HBM); one
-fused hot-path launch per step (control + scene.step + reward + observations); reset-all every
-200 steps (TimeLimit parity).  Env axis sharded across ranks (weak scaling: 4096 envs per GPU);
-with N > 1 the packed observation/reward rows are all-gathered over RCCL in rollout chunks of
---gather-every steps (default 8; 1 = every step), double-buffered so a chunk's gather overlaps the
-next chunk's physics.
+Workload (BASELINE.json configs[1]): GenesisEnv(task="cube_pick", robot="franka", num_envs=4096 per
+GPU, enable_pixels=False); reset(seed=0); a fresh a_t ~ U(-1,1)^(B x 9) float32 per step, generated on the device BEFORE the
+timed region (inputs resident in HBM).  The timed loop is the reference's own loop shape (README.md:32-43, test.py:11-22):
 
-One JSON line on rank 0: value = total env-steps / wall time (max over ranks) of exactly K steps.
-Extra objects: "roofline" (HBM; algorithmic 489 B per env-step), "cpu_baseline" (the float32 CPU port
-of the oracle, OpenMP over all host cores; rank 0, N=1 only) and "pixels" (secondary: BASELINE configs[4], the tiled
-rasteriser at 1024 x 480 x 640, HBM-write roofline; rank 0, N=1 only).
+    obs, reward, terminated, truncated, info = env.step(a_t)      # GenesisEnv.step, terminated = NumPy bool (B,)
+    if terminated.any() or truncated.any() or t % 200 == 199:      # TimeLimit(200) parity (gym_genesis/__init__.py:6)
+        env.reset()
+
+`value` = num_envs x env.step() calls per wall-second THROUGH GenesisEnv.step, max over ranks.  Exactly K steps
+are timed per repetition, bracketed by barrier + synchronize; when K steps are too short to time (K = 20 is ~1 ms) the bracketed
+K-step region is REPEATED until >= --min-time seconds have been measured, and `value` is total steps / total bracketed time
+(`repeats` in the line).  `hot_path_rate` is the bare fused launch (task.step_raw: no per-step host hand-over of `terminated`)
+over the same number of steps; its HIP-event time per launch is the kernel duration used by `roofline`.
+
+Env axis sharded across ranks (weak scaling: 4096 envs per GPU); with N > 1 the observation/reward outputs of --gather-every
+consecutive steps are all-gathered over RCCL in one collective, overlapped with the following steps.
+
+The headline line is assembled first; every secondary leg (raw launch, rollout, autoreset, pixels, grasp, SO-101, stack, IK,
+CPU baseline) runs in its own try/except and can only add an {"error": ...} object, and the line is printed in a `finally`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+import traceback
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, "gym-genesis_amd")]
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 ENVS_PER_GPU = 4096
 EPISODE_STEPS = 200
 ALGO_BYTES_PER_ENV_STEP = 489.0  # 55 f32 read + 67 f32 + 1 B written
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ROW_STRIDE = 24
+N_ACT = 256                      # pre-drawn action batches (device resident), cycled
+RK = 16                          # steps per rollout launch in the secondary rollout legs
+assert N_ACT % RK == 0
+METRIC = "env-steps/sec (num_envs x sim-steps/sec), CubePick-v0 @ num_envs=4096"
 
 
+# ---- pure helpers (covered by tests/test_bench_cpu.py) ---------------------------------------------------------------
+def action_index(t: int, n_act: int = N_ACT) -> int:
+    """Index of the action batch of global step t."""
+    return t % n_act
+
+
+def rollout_slice(i: int, rk: int = RK, n_act: int = N_ACT):
+    """[lo, hi) of the i-th rk-step rollout in the action pool: always rk rows, always inside the pool."""
+    lo = (i * rk) % n_act
+    if lo + rk > n_act:
+        lo = 0
+    return lo, lo + rk
+
+
+def repeats_for(seconds_per_rep: float, min_time: float, max_reps: int = 2000) -> int:
+    """How many K-step repetitions reach min_time seconds of measured time (at least 1)."""
+    if seconds_per_rep <= 0.0:
+        return max_reps
+    return int(max(1, min(max_reps, -(-min_time // seconds_per_rep))))
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--min-time", type=float, default=0.5, help="repeat the timed K-step region until this many seconds are measured")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL observation gather")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N>1: all-gather the outputs of this many consecutive steps in one collective (1 = every step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pixels", action="store_true", help="skip the secondary pixels (configs[4]) measurement")
+    ap.add_argument("--no-stack", action="store_true", help="skip the secondary grasp / SO-101 / CubeStack-v0 / IK measurements")
+    ap.add_argument("--core-only", action="store_true",
+                    help="only the headline loop and the raw-launch loop (the command profiled by tools/collect_profiles.sh)")
+    ap.add_argument("--raw-only", action="store_true",
+                    help="with --core-only: skip the API loop too, so that every mir_step_kernel launch in a trace is a raw launch")
+    ap.add_argument("--force-gather", action="store_true", help="exercise the gather path even with one rank (plumbing check)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for plumbing checks)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="plumbing check: let several ranks share a GPU (device = LOCAL_RANK %% device_count; use with --dist-backend gloo)")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="only spawn the ranks, rendezvous over gloo on CPU and print a line (no GPU, no physics)")
+    return ap.parse_args(argv)
+
+
+# ---- self-launch -----------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(gpus: int, argv, port: int):
+    """The driver's own launch line (one rank per GPU over torch.distributed.run)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (this parent never touches the GPU,
+    and nothing is exec'ed), pass their output through, exit with their code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launch_command(args.gpus, argv, _free_port())
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+# ---- secondary legs --------------------------------------------------------------------------------------------------
 def cpu_baseline(budget_s: float = 12.0):
-    """Time the float32 CPU port of the oracle (oracle/liborc32.so) on all host cores, same workload."""
+    """Time the float32 CPU port of the oracle (oracle/liborc32.so) on the host cores, same workload (kind "port")."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     from gym_genesis.backend import models
@@ -76,11 +159,14 @@ def cpu_baseline(budget_s: float = 12.0):
             "sample": f"{steps} steps x {B} envs, same random-action workload, float32 C port of the oracle, OpenMP over envs"}
 
 
-def pixels_bench(dev, renders: int = 30):
+def _events(torch):
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def pixels_bench(torch, dev, renders: int = 30):
     """BASELINE.json configs[4]: CubePick-v0, 1024 envs, enable_pixels=True, per-env 480x640 RGB8 images rendered by
-    the tiled HIP rasteriser (mir_render) from the state resident in HBM; one step + one render per iteration is NOT
-    what is timed here -- only the render launches (setup + pixel kernels), with HIP events on the launching stream.
-    Algorithmic bytes = B*H*W*3 written once (cfg 5: 943 MB/step, HBM-write-bound)."""
+    the tiled HIP rasteriser (mir_render) from the state resident in HBM; only the render launches are timed (setup +
+    pixel kernels), HIP events on the launching stream.  Algorithmic bytes = B*H*W*3 written once (cfg 5)."""
     from gym_genesis.env import GenesisEnv
 
     B, H, W = 1024, 480, 640
@@ -95,7 +181,7 @@ def pixels_bench(dev, renders: int = 30):
     for _ in range(3):
         task.cam.render_envs(out=out)
     torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = _events(torch)
     ev0.record()
     for _ in range(renders):
         task.cam.render_envs(out=out)
@@ -104,12 +190,7 @@ def pixels_bench(dev, renders: int = 30):
     us = ev0.elapsed_time(ev1) * 1e3 / renders
     nbytes = float(B * H * W * 3)
     achieved = nbytes / (us * 1e-6) / 1e9
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1", "render_pmc.json")) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
+    traffic = _profile_number("render_pmc.json", "hbm_bytes_per_launch")
     del out, env
     torch.cuda.empty_cache()
     # reduced-resolution variant reported alongside: 96x128 images for 4096 envs
@@ -139,11 +220,11 @@ def pixels_bench(dev, renders: int = 30):
                                  "(FK refresh + primitive setup + pixel kernel), HIP events"}}
 
 
-def grasp_bench(dev):
-    """Secondary (SURVEY.md 8d, config 2's scripted-grasp scenario): the reference's expert pick -- five stages of 40 steps
-    (examples/franka/pick_cube_state.py:86-88), joint-space targets precomputed by this repo's batched IK from the reset
-    state -- on 4096 envs, so finger-pad/cube box-box contacts, friction, the arm-cube coupling in the Newton system and
-    terminated=True are all exercised.  One fused launch per step, HIP events on the launching stream."""
+def grasp_bench(torch, dev):
+    """Secondary (SURVEY.md 8d, config 2's scripted-grasp scenario): five stages of 40 steps like the reference's expert
+    (examples/franka/pick_cube_state.py:86-88: hover, stabilize, grasp, grasp, lift), joint-space targets precomputed by this
+    repo's batched IK from the reset state, on 4096 envs: finger-pad/cube contacts, friction, the arm-cube coupling in the
+    Newton system and terminated=True are all exercised.  One fused launch per step, HIP events on the launching stream."""
     from gym_genesis.env import GenesisEnv
 
     B = ENVS_PER_GPU
@@ -153,15 +234,14 @@ def grasp_bench(dev):
     robot, cube = env.get_robot(), obs["environment_state"][:, :3].clone()
     eef = robot.get_link("hand")
     quat = torch.tensor([0.0, 1.0, 0.0, 0.0], device=dev).repeat(B, 1)
-    stages = [(0.25, 0.04), (0.104, 0.04), (0.104, 0.0), (0.104, 0.0), (0.40, 0.0)]
+    stages = [(0.25, 0.04), (0.25, 0.04), (0.104, 0.04), (0.104, 0.0), (0.40, 0.0)]
     targets, q_prev = [], None
     for dz, grip in stages:
         q = robot.inverse_kinematics(link=eef, pos=cube + torch.tensor([0.0, 0.0, dz], device=dev), quat=quat, init_qpos=q_prev)
         q_prev = q
         targets.append(torch.cat([q[:, :7], torch.full((B, 2), grip, device=dev)], 1).contiguous())
     torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ncon_max = 0
+    ev0, ev1 = _events(torch)
     ev0.record()
     for tg in targets:
         for _ in range(40):
@@ -172,12 +252,12 @@ def grasp_bench(dev):
     success = float((task._reward == 1).float().mean().item())
     ncon_max = int(task._mir.get_diag()[0].max().item())
     del env
-    return {"workload": "CubePick-v0 robot=franka scripted pick (hover, stabilize, grasp, grasp, lift; 5 x 40 steps; IK-precomputed joint "
-                        "targets), num_envs=4096", "env_steps_per_s": B / (us * 1e-6), "us_per_step": us, "lifted_frac": success,
+    return {"workload": "CubePick-v0 robot=franka scripted pick (hover, stabilize, descend, close, lift; 5 x 40 steps; IK-precomputed "
+                        "joint targets), num_envs=4096", "env_steps_per_s": B / (us * 1e-6), "us_per_step": us, "lifted_frac": success,
             "max_contacts_last_step": ncon_max}
 
 
-def so101_bench(dev, steps: int = 400):
+def so101_bench(torch, dev, steps: int = 400):
     """Secondary (BASELINE configs[3] / SURVEY.md 8d config 4): SO-101 cube-pick (6 arm dofs, cube on the kitchen slab: box-box
     contact every step) at 4096 envs, U(-1,1) joint targets around the rest pose."""
     from gym_genesis.env import GenesisEnv
@@ -191,19 +271,25 @@ def so101_bench(dev, steps: int = 400):
     for t in range(20):
         task.step_raw(acts[t])
     torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = _events(torch)
     ev0.record()
     for t in range(steps):
         task.step_raw(acts[t % 256])
     ev1.record()
     torch.cuda.synchronize(dev)
     us = ev0.elapsed_time(ev1) * 1e3 / steps
+    # the same through GenesisEnv.step
+    t0 = time.perf_counter()
+    for t in range(200):
+        env.step(acts[t % 256])
+    torch.cuda.synchronize(dev)
+    api = 200 * B / (time.perf_counter() - t0)
     del env
     return {"workload": "CubePick-v0 robot=so101 (12 dofs, cube on the slab) state-only obs, U(-1,1) joint targets, num_envs=4096",
-            "env_steps_per_s": B / (us * 1e-6), "us_per_step": us}
+            "env_steps_per_s": B / (us * 1e-6), "us_per_step": us, "env_step_api_rate": api}
 
 
-def stack_bench(dev, steps: int = 300):
+def stack_bench(torch, dev, steps: int = 300):
     """Secondary: gym_genesis/CubeStack-v0 (robot=franka: Panda x0.6 + five free cubes on the island slab, 39 dofs) at 4096
     envs on the wave-per-env kernel (mir_step64).  Fresh PD targets = home + U(-1,1) per step, resident in HBM; one fused
     launch per step; HIP events on the launching stream.  Algorithmic bytes per env-step, same accounting as SURVEY.md 8d:
@@ -220,7 +306,7 @@ def stack_bench(dev, steps: int = 300):
     for t in range(30):
         task.step_raw(acts[t])
     torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = _events(torch)
     ev0.record()
     for t in range(steps):
         task.step_raw(acts[t % 256])
@@ -234,7 +320,8 @@ def stack_bench(dev, steps: int = 300):
     torch.cuda.synchronize(dev)
     ev0.record()
     for i in range(8):
-        task._mir.rollout(acts[16 * i:16 * i + 16], rows)
+        lo, hi = rollout_slice(i, 16, 256)
+        task._mir.rollout(acts[lo:hi], rows)
     ev1.record()
     torch.cuda.synchronize(dev)
     us_ro = ev0.elapsed_time(ev1) * 1e3 / (8 * 16)
@@ -249,7 +336,7 @@ def stack_bench(dev, steps: int = 300):
                          "note": "1109 algorithmic B/env-step; one wave per env, 4 envs per CU: latency/occupancy-bound like the pick kernel"}}
 
 
-def ik_bench(dev, calls: int = 200):
+def ik_bench(torch, dev, calls: int = 200):
     """Secondary: the batched IK the reference's expert policies call once per env.step()
     (examples/franka/pick_cube_state.py:46-51): hand pose targets above the cube, 4096 envs, seed = current state."""
     from gym_genesis.env import GenesisEnv
@@ -264,7 +351,7 @@ def ik_bench(dev, calls: int = 200):
     for _ in range(5):
         q, err = task._mir.inverse_kinematics(hand, target, quat, return_error=True)
     torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = _events(torch)
     ev0.record()
     for _ in range(calls):
         task._mir.inverse_kinematics(hand, target, quat)
@@ -275,256 +362,335 @@ def ik_bench(dev, calls: int = 200):
             "env_solves_per_s": B / (us * 1e-6), "us_per_call": us, "converged_frac": float(((err[:, 0] < 5e-4) & (err[:, 1] < 5e-3)).float().mean().item())}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL observation gather")
-    ap.add_argument("--gather-every", type=int, default=8,
-                    help="N>1: all-gather the packed rows of this many consecutive steps in one collective (1 = every step)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pixels", action="store_true", help="skip the secondary pixels (configs[4]) measurement")
-    ap.add_argument("--no-stack", action="store_true", help="skip the secondary CubeStack-v0 measurement")
-    ap.add_argument("--core-only", action="store_true",
-                    help="only the timed headline loop (no API / autoreset / rollout / pixels / stack / ik / CPU legs): the command "
-                         "profiled by tools/collect_profiles.sh, so that every mir_step_kernel launch in the trace is a headline step")
-    ap.add_argument("--force-gather", action="store_true", help="exercise the RCCL gather path even with one rank (plumbing check)")
-    args = ap.parse_args()
+def _profile_number(name: str, key: str):
+    """A number measured offline with rocprofv3 PMC passes and committed under profiles/ (latest round first)."""
+    for rnd in ("r2", "r1"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, name)) as f:
+                v = json.load(f).get(key)
+            if v is not None:
+                return v
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def _guard(out: dict, key: str, fn, *a, **kw):
+    """Run one secondary leg; a failure becomes {"error": ...} under its key and never touches the headline."""
+    try:
+        out[key] = fn(*a, **kw)
+    except BaseException as e:  # noqa: BLE001 (KeyboardInterrupt included: the line must still be printed)
+        out[key] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc(limit=3)}
+        if isinstance(e, KeyboardInterrupt):
+            raise
+
+
+# ---- worker ----------------------------------------------------------------------------------------------------------
+def selftest_worker(args) -> int:
+    """--selftest-launch: the ranks rendezvous over gloo on CPU, agree on a sum, rank 0 prints a line.  No GPU, no physics."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "requested_gpus": args.gpus, "rank_sum": float(t.item())}), flush=True)
+    return 0 if world == args.gpus else 1
+
+
+def worker(args) -> int:
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and not args.oversubscribe:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {ndev} GPU(s) visible (one rank per GPU)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     use_pg = world > 1 or args.force_gather
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    pg_world = dist.get_world_size() if use_pg else 1
 
     from gym_genesis.env import GenesisEnv
-    from gym_genesis.sharding import gather_rows  # noqa: F401  (collective lives there)
 
     B = args.envs_per_gpu
-    K, W = args.steps, args.warmup
+    K, W = max(1, args.steps), max(0, args.warmup)
     env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B * world, enable_pixels=False, shard=(rank, world))
     task = env._env
     env.reset(seed=0)
 
-    # inputs resident in HBM before the timed region: one fresh action batch per step
+    # inputs resident in HBM before the timed region: N_ACT pre-drawn action batches, one per step, cycled
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    n_act = min(W + K, 4096)
-    actions = torch.empty((n_act, B, 9), dtype=torch.float32, device=dev)
-    for i in range(0, n_act, 256):
-        actions[i:i + 256].uniform_(-1.0, 1.0, generator=gen)
+    actions = torch.empty((N_ACT, B, 9), dtype=torch.float32, device=dev)
+    actions.uniform_(-1.0, 1.0, generator=gen)
 
     gather = use_pg and not args.no_gather
-    # One collective per step costs ~60 us of host time in torch.distributed (measured at world_size 1), more than the
-    # 41 us step itself, so rows are gathered in chunks of S steps: the host then stays ahead of the GPU.
     S = max(1, args.gather_every)
-    rows = [torch.zeros((S, B, ROW_STRIDE), dtype=torch.float32, device=dev) for _ in range(2)]
-    gathered = [torch.empty((world * S, B, ROW_STRIDE), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
+    flat = B * 21  # agent_pos 9 + environment_state 11 + reward 1 per env (terminated == (reward == 1), env.py:63)
+    gathered = [torch.empty((pg_world * S * flat,), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
     pending = [None, None]
-    launches = 0
-    filled = 0  # steps written into the current chunk
-
-    chunk = 0
+    chunk_parts: list = []
+    state = {"chunk": 0, "t": 0, "resets": 0}
 
     def flush():
-        """All-gather the rows written so far in the current chunk (async: overlaps the next chunk's physics)."""
-        nonlocal filled, chunk
-        if gather and filled:
-            s = chunk & 1
-            if filled == S:
-                pending[s] = dist.all_gather_into_tensor(gathered[s], rows[s], async_op=True)
-            else:  # partial chunk at the end of a run
-                pending[s] = dist.all_gather_into_tensor(gathered[s][:world * filled], rows[s][:filled], async_op=True)
-            chunk += 1
-            filled = 0
+        """All-gather the outputs of the steps collected so far (async: overlaps the following steps)."""
+        if gather and chunk_parts:
+            s = state["chunk"] & 1
+            if pending[s] is not None:
+                pending[s].wait()
+            send = torch.cat(chunk_parts)
+            pending[s] = dist.all_gather_into_tensor(gathered[s][:pg_world * send.numel()], send, async_op=True)
+            state["chunk"] += 1
+            chunk_parts.clear()
 
-    def one_step(t: int):
-        nonlocal launches, filled, chunk
-        a = actions[t % n_act]
+    def api_step():
+        """One iteration of the README loop through GenesisEnv.step."""
+        t = state["t"]
+        obs, reward, terminated, truncated, info = env.step(actions[action_index(t)])
         if gather:
-            s = chunk & 1
-            if filled == 0 and pending[s] is not None:
-                pending[s].wait()      # stream-level: the buffer's previous gather has drained
-                pending[s] = None
-            task._mir.step_packed(a, rows[s][filled])
-            filled += 1
-            if filled == S:
+            chunk_parts.extend((obs["agent_pos"].reshape(-1), obs["environment_state"].reshape(-1), reward))
+            if len(chunk_parts) == 3 * S:
                 flush()
-        else:
-            task.step_raw(a)
-        launches += 1
-        if (t + 1) % EPISODE_STEPS == 0:  # reset-all, as gymnasium's TimeLimit(200) makes the README loop do
-            task.reset()
-            launches += 1
+        state["t"] = t + 1
+        if terminated.any() or truncated.any() or (t + 1) % EPISODE_STEPS == 0:
+            env.reset()
+            state["resets"] += 1
+
+    def raw_step():
+        """The bare fused launch into persistent buffers (no host hand-over, no reset: every launch in the bracket is one
+        mir_step_kernel<0>, so HIP-event time / launches is that kernel's average duration including the launch gap)."""
+        t = state["t"]
+        task.step_raw(actions[action_index(t)])
+        state["t"] = t + 1
 
     def sync_all():
         flush()
-        for p in pending:
+        for i, p in enumerate(pending):
             if p is not None:
                 p.wait()
+                pending[i] = None
         torch.cuda.synchronize(dev)
         if use_pg:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for t in range(W):
-        one_step(t)
-    sync_all()
-    launches = 0
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for t in range(W, W + K):
-        one_step(t)
-    ev1.record()
-    sync_all()
-    wall = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
+    def max_over_ranks(x: float) -> float:
+        if not use_pg:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if use_pg:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall_max = float(wall_t.item())
+    def timed(step_fn, k: int):
+        """Exactly k steps bracketed by barrier + synchronize on both sides; (wall seconds max over ranks, HIP-event ms)."""
+        sync_all()
+        ev0, ev1 = _events(torch)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(k):
+            step_fn()
+        ev1.record()
+        sync_all()
+        wall = time.perf_counter() - t0
+        return max_over_ranks(wall), ev0.elapsed_time(ev1)
 
-    if args.core_only:
-        args.no_pixels = args.no_stack = args.no_cpu_baseline = True
-    # end-to-end env.step() (with the API's per-step D->H `terminated` copy), reported beside the hot path
-    api_steps = 0 if args.core_only else 200
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    for t in range(api_steps):
-        env.step(actions[t % n_act])
-    torch.cuda.synchronize(dev)
-    api_rate = api_steps * B * world / (time.perf_counter() - t1) if api_steps else None
-    # the README loop's variant: actions sampled on the HOST (README.md:34, SURVEY.md 8d): + one 147 KB H->D copy per step
-    np_rate = None
-    if api_steps:
-        acts_np = np.random.default_rng(5).uniform(-1, 1, (8, B, 9)).astype(np.float32)
-        torch.cuda.synchronize(dev)
-        t1b = time.perf_counter()
-        for t in range(api_steps):
-            env.step(acts_np[t % 8])
-        torch.cuda.synchronize(dev)
-        np_rate = api_steps * B * world / (time.perf_counter() - t1b)
+    def measure(step_fn):
+        """W warm-up steps, then the K-step timed region, repeated until --min-time seconds are measured."""
+        for _ in range(W):
+            step_fn()
+        first, ev_ms = timed(step_fn, K)
+        reps = repeats_for(first, args.min_time) if first < args.min_time else 1  # (`first` is already the max over ranks)
+        walls, evs = [first], [ev_ms]
+        for _ in range(reps - 1):
+            w, e = timed(step_fn, K)
+            walls.append(w)
+            evs.append(e)
+        return walls, evs
 
-    # physics only (SURVEY.md 8d): mir_step without the observation / reward outputs, PD targets unchanged
-    phys_rate = None
-    if api_steps:
-        torch.cuda.synchronize(dev)
-        t1c = time.perf_counter()
-        for t in range(api_steps):
-            task._mir.step(1)
-        torch.cuda.synchronize(dev)
-        phys_rate = api_steps * B * world / (time.perf_counter() - t1c)
-
-    # device-resident episode loop (SURVEY.md 8f-1): fused step + on-device truncation/termination/re-spawn, no host sync
-    if api_steps:
-        task.enable_autoreset(max_episode_steps=EPISODE_STEPS)
-    torch.cuda.synchronize(dev)
-    t2 = time.perf_counter()
-    for t in range(api_steps):
-        task.step_autoreset(actions[t % n_act])
-    torch.cuda.synchronize(dev)
-    loop_rate = api_steps * B * world / (time.perf_counter() - t2) if api_steps else None
-
-    # K-step rollout launches (mir_rollout): the same fresh-action workload with the state kept on chip between steps
-    RK = 16
-    rows_ro = torch.zeros((RK, B, ROW_STRIDE), dtype=torch.float32, device=dev)
-    nro = 0 if args.core_only else max(1, min(200, n_act) // RK)
-    if nro:
-        task.reset()
-    for i in range(0 if args.core_only else 2):
-        task._mir.rollout(actions[i * RK:(i + 1) * RK], rows_ro)
-    torch.cuda.synchronize(dev)
-    t3 = time.perf_counter()
-    for i in range(nro):
-        task._mir.rollout(actions[i * RK:(i + 1) * RK], rows_ro)
-    torch.cuda.synchronize(dev)
-    rollout_rate = nro * RK * B * world / (time.perf_counter() - t3) if nro else None
-    # the same with the device-side episode loop (truncation at 200 steps, re-spawn from the pre-drawn pool) inside the launch
-    loop_rollout_rate = None
-    if nro:
-        rows_ar = torch.zeros((RK, B, ROW_STRIDE), dtype=torch.float32, device=dev)
-        task.reset()
-        task._episode_len.zero_()
-        task.rollout_autoreset(actions[:RK], rows_ar)
-        torch.cuda.synchronize(dev)
-        t4 = time.perf_counter()
-        for i in range(nro):
-            task.rollout_autoreset(actions[i * RK:(i + 1) * RK], rows_ar)
-        torch.cuda.synchronize(dev)
-        loop_rollout_rate = nro * RK * B * world / (time.perf_counter() - t4)
-
-    if rank == 0:
-        value = K * B * world / wall_max
-        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/, measured offline on this kernel)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1", "pmc_hbm_traffic.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch_uncorrected"] if B == ENVS_PER_GPU else None
-        except (OSError, KeyError, ValueError):
-            pass
-        launch_us = gpu_ms * 1e3 / max(launches, 1)  # HIP events on the launching stream, per step-kernel launch
-        achieved = ALGO_BYTES_PER_ENV_STEP * B / (launch_us * 1e-6) / 1e9
+    out = None
+    rc = 0
+    try:
+        # ---- headline: the loop through GenesisEnv.step ---------------------------------------------------------------
+        if args.core_only and args.raw_only:
+            walls, evs = measure(raw_step)
+            api_walls = None
+        else:
+            api_walls, _ = measure(api_step)
+            walls = api_walls
+        total_wall = sum(walls)
+        value = len(walls) * K * B * world / total_wall
         out = {
-            "metric": "env-steps/sec (num_envs x sim-steps/sec), CubePick-v0 @ num_envs=4096",
+            "metric": METRIC,
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": wall_max * 1e3 / K,
+            "ms_per_step": total_wall * 1e3 / (len(walls) * K),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "CubePick-v0 robot=franka state-only obs, U(-1,1) joint-target actions, reset-all every 200 steps",
+            "config": {"workload": "CubePick-v0 robot=franka num_envs=4096 per GPU, state-only obs, U(-1,1) joint-target actions resident in HBM, "
+                                   "README loop through GenesisEnv.step (NumPy bool terminated per step), reset-all every 200 steps",
                        "num_envs_per_gpu": B, "global_num_envs": B * world, "parallelism": f"env-axis shard x{world}",
-                       "obs_gather": f"rccl all_gather of {S}-step row chunks, overlapped with the next chunk" if gather else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "mir_step_kernel", "kernel_us": launch_us,
-                         "note": "489 algorithmic B/env-step x 4096 envs per launch; the path is latency/occupancy-bound, not HBM-bound (SURVEY.md 8d)"},
-            "env_step_api_rate": api_rate,
-            "env_step_api_numpy_actions_rate": np_rate,
-            "physics_only_rate": phys_rate,
-            "device_autoreset_loop_rate": loop_rate,
-            "device_rollout16_rate": rollout_rate,
-            "device_autoreset_rollout16_rate": loop_rollout_rate,
+                       "world_size_observed": pg_world, "dist_backend": args.dist_backend if use_pg else None,
+                       "obs_gather": (f"{args.dist_backend} all_gather of [agent_pos|environment_state|reward] of {S} steps per collective, "
+                                      "overlapped with the following steps") if gather else "none",
+                       "terminated_sync_mode": task._mir.sync_mode},
+            "repeats": len(walls),
+            "timed_steps_total": len(walls) * K,
+            "timed_seconds_total": total_wall,
+            "best_repeat_value": K * B * world / min(walls),
+            "resets_in_loop": state["resets"],
+            "path": "GenesisEnv.step" if api_walls is not None else "task.step_raw (--raw-only)",
         }
-        if world == 1 and not args.no_pixels:
-            out["pixels"] = pixels_bench(dev)
-        if world == 1 and not args.no_stack:
-            out["scripted_grasp"] = grasp_bench(dev)
-            out["so101_pick"] = so101_bench(dev)
-            out["stack"] = stack_bench(dev)
-            out["ik"] = ik_bench(dev)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-    if use_pg:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        # RCCL writes a version banner through C stdio; flush it first so that the JSON line is the LAST line of stdout
+        # ---- the bare fused launch over the same number of steps: hot_path_rate + kernel duration for the roofline ----
         try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
+            state["t"] = 0
+            task.reset()
+            raw_walls, raw_evs = (walls, evs) if api_walls is None else measure(raw_step)
+            n_launch = len(raw_walls) * K
+            kernel_us = sum(raw_evs) * 1e3 / n_launch  # HIP events on the launching stream, per launch
+            achieved = ALGO_BYTES_PER_ENV_STEP * B / (kernel_us * 1e-6) / 1e9
+            out["hot_path_rate"] = n_launch * B * world / sum(raw_walls)
+            out["api_over_hot_path"] = out["value"] / out["hot_path_rate"]
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": _profile_number("pmc_hbm_traffic.json", "hbm_bytes_per_launch") if B == ENVS_PER_GPU else None,
+                               "kernel": "mir_step_kernel<0>", "kernel_us": kernel_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
+                               "note": "489 algorithmic B/env-step x 4096 envs per launch (SURVEY.md 8d); kernel_us = HIP events over the "
+                                       "back-to-back raw launches of the same K-step region; the path is latency/occupancy-bound, not HBM-bound"}
+        except Exception as e:  # noqa: BLE001
+            out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+            rc = 1
+
+        if rank == 0 and world == 1 and not args.core_only:
+            _guard(out, "secondary", lambda: secondary_rates(torch, dev, env, task, actions, B))
+            if not args.no_pixels:
+                _guard(out, "pixels", pixels_bench, torch, dev)
+            if not args.no_stack:
+                _guard(out, "scripted_grasp", grasp_bench, torch, dev)
+                _guard(out, "so101_pick", so101_bench, torch, dev)
+                _guard(out, "stack", stack_bench, torch, dev)
+                _guard(out, "ik", ik_bench, torch, dev)
+        if rank == 0 and world == 1 and not (args.no_cpu_baseline or args.core_only):
+            _guard(out, "cpu_baseline", cpu_baseline)
+    except BaseException as e:  # noqa: BLE001
+        rc = 1
+        if out is None:
+            out = {"metric": METRIC, "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+                   "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc(limit=6)}
+        else:
+            out["error_after_headline"] = f"{type(e).__name__}: {e}"
+    finally:
+        try:
+            if use_pg:
+                dist.barrier()
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
             pass
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        if rank == 0:
+            # RCCL writes a version banner through C stdio; flush it first so that the JSON line is the LAST line of stdout
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
+            sys.stdout.flush()
+            print(json.dumps(out), flush=True)
+    return rc
+
+
+def secondary_rates(torch, dev, env, task, actions, B):
+    """Other ways through the same kernel, N = 1 only: host-NumPy actions (README.md:34), physics only (mir_step), the
+    device-resident episode loop and K-step rollout launches (mir_rollout)."""
+    import numpy as np
+    res = {}
+    n = 200
+    env.reset(seed=0)
+    acts_np = np.random.default_rng(5).uniform(-1, 1, (8, B, 9)).astype(np.float32)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for t in range(n):
+        env.step(acts_np[t % 8])
+    torch.cuda.synchronize(dev)
+    res["env_step_api_numpy_actions_rate"] = n * B / (time.perf_counter() - t0)
+
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for t in range(n):
+        task._mir.step(1)
+    torch.cuda.synchronize(dev)
+    res["physics_only_rate"] = n * B / (time.perf_counter() - t0)
+
+    task.enable_autoreset(max_episode_steps=EPISODE_STEPS)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for t in range(n):
+        task.step_autoreset(actions[action_index(t)])
+    torch.cuda.synchronize(dev)
+    res["device_autoreset_loop_rate"] = n * B / (time.perf_counter() - t0)
+
+    rows = torch.zeros((RK, B, ROW_STRIDE), dtype=torch.float32, device=dev)
+    nro = 12
+    task.reset()
+    for i in range(2):
+        lo, hi = rollout_slice(i)
+        task._mir.rollout(actions[lo:hi], rows)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(nro):
+        lo, hi = rollout_slice(i)
+        task._mir.rollout(actions[lo:hi], rows)
+    torch.cuda.synchronize(dev)
+    res["device_rollout16_rate"] = nro * RK * B / (time.perf_counter() - t0)
+
+    task.reset()
+    task._episode_len.zero_()
+    lo, hi = rollout_slice(0)
+    task.rollout_autoreset(actions[lo:hi], rows)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(nro):
+        lo, hi = rollout_slice(i)
+        task.rollout_autoreset(actions[lo:hi], rows)
+    torch.cuda.synchronize(dev)
+    res["device_autoreset_rollout16_rate"] = nro * RK * B / (time.perf_counter() - t0)
+    return res
+
+
+def main(argv=None) -> int:
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args, argv)
+    if args.selftest_launch:
+        return selftest_worker(args)
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -162,6 +163,9 @@ struct Outs {
   const float* action = nullptr;
   float *agent_pos = nullptr, *env_state = nullptr, *reward = nullptr;
   uint8_t* terminated = nullptr;
+  uint8_t* term_host = nullptr;
+  uint32_t *done_ticket = nullptr, *done_flag = nullptr;
+  uint32_t done_seq = 0;
   float *out_M = nullptr, *out_bias = nullptr, *out_qas = nullptr, *out_qacc = nullptr, *out_xpos = nullptr, *out_xquat = nullptr;
   float* rows = nullptr;
   int row_stride = 0, mode = 0, n_steps = 1;
@@ -185,6 +189,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
     a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
+    a.term_host = o.term_host; a.done_ticket = o.done_ticket; a.done_flag = o.done_flag; a.done_seq = o.done_seq;
     rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
   } else {
     StepArgs64 a;
@@ -198,6 +203,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
     a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
+    a.term_host = o.term_host;
     rc = mir_launch_step64(&a, (hipStream_t)stream);
   }
   if (rc != 0) return hip_fail((hipError_t)rc, "step kernel launch");
@@ -206,6 +212,53 @@ int launch(MirScene* h, const Outs& o, void* stream) {
 
 int check(MirHandle h) {
   if (!h) return set_err(MIR_E_INVALID, "null MirHandle");
+  return MIR_OK;
+}
+
+// device half of mir_create: every allocation lands in the handle at once, so the caller can release a partially built
+// scene with mir_destroy whichever call failed
+int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t row_bytes) {
+  DeviceGuard guard(h->device);
+  const PlumbTab& t = h->pt;
+  const size_t B = (size_t)h->B;
+  const size_t qst = t.qst, vst = t.vst, pst = t.pst;
+  HIPCHK(hipMalloc((void**)&h->dm, sizeof(DevModel)));
+  HIPCHK(hipMalloc((void**)&h->dm64, sizeof(DevModel64)));
+  HIPCHK(hipMalloc((void**)&h->dpt, sizeof(PlumbTab)));
+  HIPCHK(hipMalloc((void**)&h->dgeom, sizeof(GeomTab)));
+  HIPCHK(hipMalloc((void**)&h->qpos, B * qst * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&h->qvel, B * vst * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&h->target, B * vst * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&h->qacc_ws, B * vst * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&h->diag, B * 4 * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&h->poses, B * 2 * pst * 4 * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&h->fkvalid, B * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&h->done_ticket, 64));
+  HIPCHK(hipMalloc((void**)&h->scratch_row, row_bytes));
+  // pinned, device-mapped, coherent host memory for the API's host-visible outputs: terminated bytes + completion word
+  const size_t pin_bytes = ((B + 63) / 64) * 64 + 64;
+  HIPCHK(hipHostMalloc((void**)&h->pin_host, pin_bytes, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(h->pin_host, 0, pin_bytes);
+  HIPCHK(hipHostGetDevicePointer((void**)&h->pin_dev, h->pin_host, 0));
+  HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(DevModel), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->dm64, &h->hm64, sizeof(DevModel64), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->dpt, &h->pt, sizeof(PlumbTab), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->dgeom, &gt, sizeof(GeomTab), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->scratch_row, row, row_bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_fill_rows, dim3(nblk((long)B * qst)), dim3(TPB), 0, 0, h->qpos, h->scratch_row, (int)qst, h->B);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemset(h->qvel, 0, B * vst * sizeof(float)));
+  HIPCHK(hipMemset(h->target, 0, B * vst * sizeof(float)));
+  HIPCHK(hipMemset(h->qacc_ws, 0, B * vst * sizeof(float)));
+  HIPCHK(hipMemset(h->diag, 0, B * 4 * sizeof(int32_t)));
+  HIPCHK(hipMemset(h->poses, 0, B * 2 * pst * 4 * sizeof(float)));
+  HIPCHK(hipMemset(h->fkvalid, 0, B * sizeof(int32_t)));
+  HIPCHK(hipMemset(h->done_ticket, 0, 64));
+  HIPCHK(hipDeviceSynchronize());
+  // how mir_step_end learns that a step has finished (MIR_SYNC_MODE overrides; see include/mirigid.h)
+  h->sync_mode = h->kernel == 16 ? 2 : 1;
+  if (const char* e = getenv("MIR_SYNC_MODE")) h->sync_mode = atoi(e);
+  if (h->sync_mode < 0 || h->sync_mode > 2 || (h->sync_mode == 2 && h->kernel != 16)) h->sync_mode = 1;
   return MIR_OK;
 }
 
@@ -303,35 +356,11 @@ int mir_create(const MirSceneSpec* spec, int32_t num_envs, int32_t device_id, Mi
   }
   h->device = device_id;
   h->B = num_envs;
-  DeviceGuard guard(device_id);
-  const size_t B = (size_t)num_envs;
-  const size_t qst = t.qst, vst = t.vst, pst = t.pst;
-  hipError_t e;
-  if ((e = hipMalloc((void**)&h->dm, sizeof(DevModel))) != hipSuccess || (e = hipMalloc((void**)&h->dm64, sizeof(DevModel64))) != hipSuccess ||
-      (e = hipMalloc((void**)&h->dpt, sizeof(PlumbTab))) != hipSuccess || (e = hipMalloc((void**)&h->dgeom, sizeof(GeomTab))) != hipSuccess ||
-      (e = hipMalloc((void**)&h->qpos, B * qst * sizeof(float))) != hipSuccess ||
-      (e = hipMalloc((void**)&h->qvel, B * vst * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->target, B * vst * sizeof(float))) != hipSuccess ||
-      (e = hipMalloc((void**)&h->qacc_ws, B * vst * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->diag, B * 4 * sizeof(int32_t))) != hipSuccess ||
-      (e = hipMalloc((void**)&h->poses, B * 2 * pst * 4 * sizeof(float))) != hipSuccess || (e = hipMalloc((void**)&h->fkvalid, B * sizeof(int32_t))) != hipSuccess) {
-    mir_destroy(h);
-    return hip_fail(e, "hipMalloc");
+  rc = create_device_state(h, gt, row, sizeof row);
+  if (rc != MIR_OK) {
+    mir_destroy(h);  // frees whatever was allocated before the failure (the error text is already set)
+    return rc;
   }
-  HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(DevModel), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->dm64, &h->hm64, sizeof(DevModel64), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->dpt, &h->pt, sizeof(PlumbTab), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->dgeom, &gt, sizeof(GeomTab), hipMemcpyHostToDevice));
-  float* drow = nullptr;
-  HIPCHK(hipMalloc((void**)&drow, sizeof row));
-  HIPCHK(hipMemcpy(drow, row, sizeof row, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_fill_rows, dim3(nblk((long)B * qst)), dim3(TPB), 0, 0, h->qpos, drow, (int)qst, num_envs);
-  HIPCHK(hipMemset(h->qvel, 0, B * vst * sizeof(float)));
-  HIPCHK(hipMemset(h->target, 0, B * vst * sizeof(float)));
-  HIPCHK(hipMemset(h->qacc_ws, 0, B * vst * sizeof(float)));
-  HIPCHK(hipMemset(h->diag, 0, B * 4 * sizeof(int32_t)));
-  HIPCHK(hipMemset(h->poses, 0, B * 2 * pst * 4 * sizeof(float)));
-  HIPCHK(hipMemset(h->fkvalid, 0, B * sizeof(int32_t)));
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipFree(drow));
   *out = h;
   return MIR_OK;
 }
@@ -351,6 +380,9 @@ int mir_destroy(MirHandle h) {
   if (h->poses) (void)hipFree(h->poses);
   if (h->fkvalid) (void)hipFree(h->fkvalid);
   if (h->prims) (void)hipFree(h->prims);
+  if (h->done_ticket) (void)hipFree(h->done_ticket);
+  if (h->scratch_row) (void)hipFree(h->scratch_row);
+  if (h->pin_host) (void)hipHostFree(h->pin_host);
   delete h;
   return MIR_OK;
 }
@@ -416,6 +448,60 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
   o.action = action; o.agent_pos = agent_pos; o.env_state = env_state; o.reward = reward; o.terminated = terminated;
   return launch(h, o, stream);
 }
+
+/* GenesisEnv.step in two halves (reference env.py:61-69).  mir_step_begin = mir_step_fused that ALSO stores the terminated bytes
+ * into the handle's pinned host buffer and arranges for a completion word; mir_step_end blocks until that launch has finished and
+ * copies the B bytes to the caller's plain host array -- `terminated = is_success.detach().cpu().numpy()` (env.py:64) without a
+ * separate copy command.  The host is free between the two calls (the Python side allocates the next outputs there). */
+int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
+  if (check(h)) return MIR_E_INVALID;
+  if (h->pending) return set_err(MIR_E_INVALID, "mir_step_begin: the previous mir_step_begin has not been closed by mir_step_end");
+  DeviceGuard guard(h->device);
+  uint32_t* flag_dev = reinterpret_cast<uint32_t*>(h->pin_dev + ((size_t)(h->B + 63) / 64) * 64);
+  Outs o;
+  o.action = action; o.agent_pos = agent_pos; o.env_state = env_state; o.reward = reward; o.terminated = terminated;
+  o.term_host = h->pin_dev;
+  const uint32_t seq = h->seq + 1u;
+  if (h->sync_mode == 2) { o.done_ticket = h->done_ticket; o.done_flag = flag_dev; o.done_seq = seq; }
+  int rc = launch(h, o, stream);
+  if (rc != MIR_OK) return rc;
+  if (h->sync_mode == 1) {
+    hipError_t e = hipStreamWriteValue32((hipStream_t)stream, flag_dev, seq, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); h->sync_mode = 0; }  // not supported on this stack: wait on the stream instead
+  }
+  h->seq = seq;
+  h->pending = 1;
+  h->pending_stream = stream;
+  return MIR_OK;
+}
+
+int mir_step_end(MirHandle h, uint8_t* terminated_host) {
+  if (check(h)) return MIR_E_INVALID;
+  if (!h->pending) return set_err(MIR_E_INVALID, "mir_step_end without mir_step_begin");
+  h->pending = 0;
+  volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->pin_host + ((size_t)(h->B + 63) / 64) * 64);
+  if (h->sync_mode == 0) {
+    DeviceGuard guard(h->device);
+    HIPCHK(hipStreamSynchronize((hipStream_t)h->pending_stream));
+  } else {
+    // spin on the pinned completion word; every 2^20 polls make sure the stream has not died under us
+    unsigned long polls = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != h->seq) {
+      __builtin_ia32_pause();
+      if ((++polls & 0xfffffu) == 0) {
+        DeviceGuard guard(h->device);
+        hipError_t e = hipStreamQuery((hipStream_t)h->pending_stream);
+        if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "mir_step_end: stream");
+        if (e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != h->seq)
+          return set_err(MIR_E_HIP, "mir_step_end: the launch finished without publishing its completion word");
+      }
+    }
+  }
+  if (terminated_host) memcpy(terminated_host, h->pin_host, (size_t)h->B);
+  return MIR_OK;
+}
+
+int mir_get_sync_mode(MirHandle h) { return check(h) ? MIR_E_INVALID : h->sync_mode; }
 
 int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream) {
   if (check(h) || !rows) return set_err(MIR_E_INVALID, "mir_step_packed: null argument");

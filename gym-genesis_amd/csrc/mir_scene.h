@@ -21,6 +21,16 @@ struct MirScene {
   float *qpos, *qvel, *target, *qacc_ws, *poses;
   int32_t *diag, *fkvalid;
   float* prims;     // render primitives (B, ngeom, 32) f32, allocated by the first mir_render
+  // host-visible tail of env.step() (mir_step_begin / mir_step_end): one pinned, device-mapped allocation
+  //   [terminated bytes (B, padded to 64) | completion word]
+  float* scratch_row;       // one qpos row (device), used while the scene is created
+  uint8_t* pin_host;        // host address
+  uint8_t* pin_dev;         // the same memory as the device sees it
+  uint32_t* done_ticket;    // device counter for the kernel-side completion (sync mode 2)
+  uint32_t seq;             // sequence number of the last mir_step_begin
+  int sync_mode;            // 0 hipStreamSynchronize, 1 stream write-value + host spin, 2 kernel-side ticket + host spin
+  int pending;              // a mir_step_begin is waiting for its mir_step_end
+  void* pending_stream;
 };
 
 // library-internal helpers implemented in mir_api.hip

@@ -18,6 +18,12 @@ struct StepArgs {
   float* env_state;     // (B, 11) or null
   float* reward;        // (B) or null
   uint8_t* terminated;  // (B) or null
+  // host-visible tail of GenesisEnv.step (mir_step_begin / mir_step_end): the same bytes as `terminated`, stored straight into
+  // pinned host memory (system-scope stores), and the launch's completion published by its LAST workgroup
+  uint8_t* term_host;     // (B) device address of pinned host memory, or null
+  uint32_t* done_ticket;  // device counter, 0 between launches; or null (completion is then signalled by the stream)
+  uint32_t* done_flag;    // device address of a pinned host word <- done_seq once every workgroup has stored its bytes
+  uint32_t done_seq;
   int32_t* diag;        // (B, 4): ncon, nefc, niter, flags; or null
   // debug / per-stage parity outputs (mir_forward), all nullable
   float* out_M;         // (B, nv, nv)

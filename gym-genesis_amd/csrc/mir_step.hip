@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   STAMP(1);
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; }
-  if (VARIANT == 1) { a.mode = 0; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; a.agent_pos = a.env_state = a.reward = nullptr; a.terminated = nullptr; }
+  if (VARIANT == 1) { a.mode = 0; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; a.agent_pos = a.env_state = a.reward = nullptr; a.terminated = a.term_host = nullptr; a.done_ticket = nullptr; }
   // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
   const int eb = mdl_eef, ob = mdl_obj;
   const int ad = 7 + mdl_ngrip;
@@ -1052,36 +1052,53 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     }
   }  // steps
   STAMP(10);
-  if (!valid) return;
-  if (lane < nb) {
-    float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
-    *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
-    *reinterpret_cast<f4*>(p + 4 * G) = ldv(S.xquat[lane]);
-  }
-  if (lane == 0) a.fkvalid[env] = 1;
-  // ---- store state ---------------------------------------------------------------------------------
-  if (a.mode == 0) {
-    for (int i = lane; i < qst; i += G) a.qpos[(size_t)env * qst + i] = S.qpos[i];
-    a.qvel[(size_t)env * G + lane] = S.qvel[lane];
-    a.qacc_ws[(size_t)env * G + lane] = S.qacc_ws[lane];
-  }
-  if (a.action) a.target[(size_t)env * G + lane] = S.target[lane];
-  // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
-  const float rew = S.xpos[ob][2] > mdl_reward_z ? 1.0f : 0.0f;
-  if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
-  if (a.env_state && lane < 11) a.env_state[(size_t)env * 11 + lane] = column(ad + lane);
-  if (lane == 0) {
-    if (a.reward) a.reward[env] = rew;
-    if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
-  }
-  if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
-  if (a.rows && !(a.ar.episode_len && a.rows_step)) {  // (in rollout mode: the last step's row; with autoreset it was written in the loop)
-    float* row = a.rows + (size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride;
-    for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
-  }
-  if (a.out_xpos && lane < nb) {
-    st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3v(S.xpos[lane]));
-    st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));
+  if (valid) {
+    if (lane < nb) {
+      float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
+      *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
+      *reinterpret_cast<f4*>(p + 4 * G) = ldv(S.xquat[lane]);
+    }
+    if (lane == 0) a.fkvalid[env] = 1;
+    // ---- store state ---------------------------------------------------------------------------------
+    if (a.mode == 0) {
+      for (int i = lane; i < qst; i += G) a.qpos[(size_t)env * qst + i] = S.qpos[i];
+      a.qvel[(size_t)env * G + lane] = S.qvel[lane];
+      a.qacc_ws[(size_t)env * G + lane] = S.qacc_ws[lane];
+    }
+    if (a.action) a.target[(size_t)env * G + lane] = S.target[lane];
+    // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
+    const float rew = S.xpos[ob][2] > mdl_reward_z ? 1.0f : 0.0f;
+    if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
+    if (a.env_state && lane < 11) a.env_state[(size_t)env * 11 + lane] = column(ad + lane);
+    if (lane == 0) {
+      if (a.reward) a.reward[env] = rew;
+      if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
+      // the same byte straight into pinned host memory (write-through, system scope): GenesisEnv.step's D->H copy
+      if (a.term_host) __hip_atomic_store(&a.term_host[env], (uint8_t)(rew == 1.0f ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
+    if (a.rows && !(a.ar.episode_len && a.rows_step)) {  // (in rollout mode: the last step's row; with autoreset it was written in the loop)
+      float* row = a.rows + (size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride;
+      for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
+    }
+    if (a.out_xpos && lane < nb) {
+      st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3v(S.xpos[lane]));
+      st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));
+    }
+  }  // valid
+  if (VARIANT != 1 && a.done_ticket) {
+    // Completion published by the kernel itself (mir_step_begin, sync mode 2): every wave waits for its host stores to be
+    // acknowledged, then takes a ticket; the wave that takes the last one knows that every terminated byte of the launch is in
+    // host memory and writes the sequence number the host is spinning on.  (The host-side stores above are system-scope
+    // write-through atomics, so no cache write-back is needed to order them: s_waitcnt is the release.)
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned old = 0;
+    if (tid == 0) old = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old == gridDim.x - 1 && tid == 0) {
+      __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next launch starts from zero
+      __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   STAMP(25);
   if (a.prof && threadIdx.x == 0) {  // debug: wall-clock (100 MHz) exit time of block 0 and of the last block
@@ -1104,7 +1121,7 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !a.prof && !a.out_M && !a.out_bias &&
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat;
   const bool plain_loop = a.mode == 0 && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
-                          !a.env_state && !a.reward && !a.terminated;
+                          !a.env_state && !a.reward && !a.terminated && !a.term_host && !a.done_ticket;
   if (single) hipLaunchKernelGGL(mir_step_kernel<0>, dim3(blocks), dim3(64), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL(mir_step_kernel<1>, dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL(mir_step_kernel<2>, dim3(blocks), dim3(64), 0, stream, a);

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   STAMP(1);
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; }
-  if (VARIANT == 1) { a.mode = 0; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; a.agent_pos = a.env_state = a.reward = nullptr; a.terminated = nullptr; }
+  if (VARIANT == 1) { a.mode = 0; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; a.agent_pos = a.env_state = a.reward = nullptr; a.terminated = a.term_host = nullptr; }
   // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
   const int eb = m->eef_body, ob = m->obj_body, ob2 = m->obj2_body;
   const int ad = m->agent_dim, ed = m->env_dim;
@@ -1246,6 +1246,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   if (lane == 0) {
     if (a.reward) a.reward[env] = rew;
     if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
+    if (a.term_host) __hip_atomic_store(&a.term_host[env], (uint8_t)(rew == 1.0f ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
   if (a.rows && !(a.ar.episode_len && a.rows_step) && lane < ad + ed + 2)  // (in rollout mode: the last step's row; with autoreset: written in the loop)
@@ -1264,7 +1265,7 @@ extern "C" int mir_launch_step64(const StepArgs64* args, hipStream_t stream) {
   const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !a.prof && !a.out_M && !a.out_bias &&
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat;
   const bool plain_loop = a.mode == 0 && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
-                          !a.env_state && !a.reward && !a.terminated;
+                          !a.env_state && !a.reward && !a.terminated && !a.term_host;
   if (single) hipLaunchKernelGGL(mir_step64_kernel<0>, dim3(a.B), dim3(64), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL(mir_step64_kernel<1>, dim3(a.B), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL(mir_step64_kernel<2>, dim3(a.B), dim3(64), 0, stream, a);

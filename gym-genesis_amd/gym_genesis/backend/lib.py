@@ -47,6 +47,12 @@ def load_library() -> C.CDLL:
     lib.mir_set_pd_targets.argtypes = [vp, vp, vp]
     lib.mir_step.argtypes = [vp, i32, vp]
     lib.mir_step_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.mir_step_begin.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.mir_step_begin.restype = C.c_int
+    lib.mir_step_end.argtypes = [vp, vp]
+    lib.mir_step_end.restype = C.c_int
+    lib.mir_get_sync_mode.argtypes = [vp]
+    lib.mir_get_sync_mode.restype = C.c_int
     lib.mir_step_packed.argtypes = [vp, vp, vp, i32, vp]
     lib.mir_step_packed.restype = C.c_int
     lib.mir_rollout.argtypes = [vp, vp, i32, vp, i32, vp]
@@ -102,16 +108,20 @@ class StepHelpers:
         return (buf[:agent_dim * B].view(B, agent_dim), buf[agent_dim * B:(agent_dim + env_dim) * B].view(B, env_dim),
                 buf[(agent_dim + env_dim) * B:], torch.empty(B, dtype=torch.uint8, device=self.device))
 
-    def step_fresh(self, action, agent_dim: int, env_dim: int):
+    def step_fresh(self, action, agent_dim: int, env_dim: int, host_terminated: bool = False):
         """One fused step into FRESH output tensors (callers may keep old observations, as with the reference):
-        returns (agent_pos, environment_state, reward, terminated u8)."""
+        returns (agent_pos, environment_state, reward, terminated u8).  With host_terminated the launch also delivers the
+        terminated bytes to the host (step_begin); the caller must then close the step with step_end()."""
         key = (agent_dim, env_dim)
         out = self._fresh.pop(key, None) if hasattr(self, "_fresh") else None
         if out is None:
             self._fresh = {}
             out = self._alloc_outputs(agent_dim, env_dim)
-        self.step_fused(action, *out)
-        self._fresh[key] = self._alloc_outputs(agent_dim, env_dim)
+        if host_terminated:
+            self.step_begin(action, *out)
+        else:
+            self.step_fused(action, *out)
+        self._fresh[key] = self._alloc_outputs(agent_dim, env_dim)  # (while the kernel runs)
         return out
 
 
@@ -125,7 +135,9 @@ class MirScene(StepHelpers):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.spec = spec
         h = C.c_void_p()
-        rc = self.lib.mir_create(C.byref(spec), int(num_envs), self.device.index or 0, C.byref(h))
+        if self.device.index is None:  # "cuda" without an index means the CURRENT device, not device 0
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        rc = self.lib.mir_create(C.byref(spec), int(num_envs), self.device.index, C.byref(h))
         self._check(rc)
         self.h = h
         d = MirDims()
@@ -212,6 +224,21 @@ class MirScene(StepHelpers):
         """Raw launch: all arguments are preallocated device tensors (action may be None)."""
         self._check(self.lib.mir_step_fused(self.h, _ptr(action), _ptr(agent_pos), _ptr(env_state), _ptr(reward),
                                             _ptr(terminated), self._stream()))
+
+    def step_begin(self, action, agent_pos, env_state, reward, terminated) -> None:
+        """mir_step_begin: step_fused whose terminated bytes also go to the host; close with step_end()."""
+        self._check(self.lib.mir_step_begin(self.h, _ptr(action), _ptr(agent_pos), _ptr(env_state), _ptr(reward),
+                                            _ptr(terminated), self._stream()))
+
+    def step_end(self) -> np.ndarray:
+        """mir_step_end: wait for the launch of step_begin; a FRESH NumPy bool (B,) = terminated (env.py:64)."""
+        out = np.empty(self.num_envs, dtype=np.bool_)
+        self._check(self.lib.mir_step_end(self.h, C.c_void_p(out.ctypes.data)))
+        return out
+
+    @property
+    def sync_mode(self) -> int:
+        return int(self.lib.mir_get_sync_mode(self.h))
 
     def step_packed(self, action, rows: torch.Tensor) -> None:
         """One step; all outputs in one (B, row_stride) float32 row tensor (see mir_step_packed)."""

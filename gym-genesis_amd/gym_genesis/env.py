@@ -66,6 +66,17 @@ class GenesisEnv(Env):
         return observation, {"is_success": [False] * self.num_envs}
 
     def step(self, action):
+        begin = getattr(self._env, "step_begin", None)
+        if begin is not None and not self.enable_pixels and not getattr(self._env, "unbatched", False):
+            # Fast path: the launch stores `terminated` into pinned host memory itself.  Everything the API returns besides
+            # that mask is built while the kernel runs; step_end() then waits for the launch and hands over a fresh NumPy
+            # bool array -- the reference's `is_success.detach().cpu().numpy().astype(bool)` (env.py:64).
+            _, reward, _, observation = begin(action)
+            is_success = self._env.terminated_device.view(torch.bool)
+            truncated = np.zeros(self.num_envs, dtype=bool)
+            info = {"is_success": is_success}
+            terminated = self._env.step_end()
+            return observation, reward, terminated, truncated, info
         _, reward, _, observation = self._env.step(action)
         term_dev = getattr(self._env, "terminated_device", None)
         if term_dev is not None and not getattr(self._env, "unbatched", False):

@@ -33,11 +33,33 @@ def unpack_rows(rows: torch.Tensor, agent_dim: int = 9, env_dim: int = 11):
     return obs, reward, terminated
 
 
-def gather_rows(rows: torch.Tensor, group=None) -> torch.Tensor:
-    """All-gather equally sized row blocks into the global (B, D) tensor (rank order = env order)."""
+def gather_rows(rows: torch.Tensor, group=None, num_envs: int | None = None) -> torch.Tensor:
+    """All-gather the row blocks of all ranks into the global (B, D) tensor (rank order = env order).
+
+    shard_bounds gives ranks blocks that differ by one row when num_envs % world != 0, and all_gather_into_tensor needs
+    equal blocks: every rank pads its block to the largest one (ceil(num_envs / world)) and the padding is dropped after
+    the collective.  `num_envs` = the global batch; without it the blocks must be equal (checked with a second, tiny
+    collective only when a rank could otherwise hang)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return rows
     world = dist.get_world_size(group)
-    out = torch.empty((world * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
-    dist.all_gather_into_tensor(out, rows, group=group)
-    return out
+    n = rows.shape[0]
+    if num_envs is None:
+        sizes = torch.tensor([n], dtype=torch.int64, device=rows.device)
+        all_sizes = torch.empty((world,), dtype=torch.int64, device=rows.device)
+        dist.all_gather_into_tensor(all_sizes, sizes, group=group)
+        counts = [int(c) for c in all_sizes.tolist()]
+    else:
+        counts = [shard_bounds(num_envs, r, world)[1] - shard_bounds(num_envs, r, world)[0] for r in range(world)]
+        if counts[dist.get_rank(group)] != n:
+            raise ValueError(f"gather_rows: this rank holds {n} rows, shard_bounds({num_envs}) gives it {counts[dist.get_rank(group)]}")
+    width = max(counts)
+    if min(counts) == width:  # equal shards: one collective, no padding
+        out = torch.empty((world * n, *rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(out, rows.contiguous(), group=group)
+        return out
+    send = rows.new_zeros((width, *rows.shape[1:]))
+    send[:n] = rows
+    out = torch.empty((world * width, *rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(out, send, group=group)
+    return torch.cat([out[r * width:r * width + counts[r]] for r in range(world)], dim=0)

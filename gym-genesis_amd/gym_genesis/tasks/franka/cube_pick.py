@@ -170,6 +170,17 @@ class FrankaCubePickBatch:
         self._agent, self._envst, self._reward, self._term = mir.step_fresh(mir.as_action(action, AGENT_DIM), AGENT_DIM, ENV_DIM)
         return None, self._reward, None, self._pack_obs()
 
+    def step_begin(self, action):
+        """step() for GenesisEnv.step: the same launch also delivers `terminated` to the host; GenesisEnv prepares its other
+        return values while the kernel runs and then collects the mask with step_end()."""
+        mir = self._mir
+        self._agent, self._envst, self._reward, self._term = mir.step_fresh(mir.as_action(action, AGENT_DIM), AGENT_DIM, ENV_DIM,
+                                                                            host_terminated=True)
+        return None, self._reward, None, self._pack_obs()
+
+    def step_end(self) -> np.ndarray:
+        return self._mir.step_end()
+
     def step_raw(self, action_dev: torch.Tensor) -> None:
         """Hot path without any Python-side packing: `action_dev` is a contiguous float32 (B,9) device tensor."""
         self._mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)

@@ -107,13 +107,20 @@ class CubePick:
         self._mir.reset(pos, self._quat, self._zero)  # no scene.step() here (so101/cube_pick.py:81)
         return self.get_obs()
 
-    def step(self, action):
+    def step(self, action, host_terminated: bool = False):
         mir = self._mir
         if not isinstance(action, torch.Tensor):
             action = torch.as_tensor(np.asarray(action))
         a = mir.as_action(action.reshape(self.num_envs, AGENT_DIM), AGENT_DIM)
-        self._agent, self._envst, self._reward, self._term = mir.step_fresh(a, AGENT_OBS, ENV_OBS)
+        self._agent, self._envst, self._reward, self._term = mir.step_fresh(a, AGENT_OBS, ENV_OBS, host_terminated=host_terminated)
         return None, self._reward, None, self._pack_obs()
+
+    def step_begin(self, action):
+        """step() whose launch also delivers `terminated` to the host (GenesisEnv.step collects it with step_end())."""
+        return self.step(action, host_terminated=True)
+
+    def step_end(self) -> np.ndarray:
+        return self._mir.step_end()
 
     def step_raw(self, action_dev: torch.Tensor) -> None:
         self._mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)

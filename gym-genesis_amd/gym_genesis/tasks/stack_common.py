@@ -149,10 +149,18 @@ class StackTaskBase:
                                     self._quat, self._home)
         return rows
 
-    def step(self, action):
+    def step(self, action, host_terminated: bool = False):
         mir = self._mir
-        self._agent, self._envst, self._reward, self._term = mir.step_fresh(mir.as_action(action, self.AGENT_DIM), mir.agent_dim, ENV_OBS)
+        self._agent, self._envst, self._reward, self._term = mir.step_fresh(mir.as_action(action, self.AGENT_DIM), mir.agent_dim, ENV_OBS,
+                                                                            host_terminated=host_terminated)
         return None, self._reward, None, self._pack_obs()
+
+    def step_begin(self, action):
+        """step() whose launch also delivers `terminated` to the host (GenesisEnv.step collects it with step_end())."""
+        return self.step(action, host_terminated=True)
+
+    def step_end(self):
+        return self._mir.step_end()
 
     def step_raw(self, action_dev: torch.Tensor) -> None:
         self._mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)

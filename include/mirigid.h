@@ -218,6 +218,22 @@ int mir_step(MirHandle h, int32_t n_steps, void* stream);
 int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward,
                    uint8_t* terminated, void* stream);
 
+/* GenesisEnv.step's host-visible tail, in two halves (gym_genesis/env.py:61-69):
+ *     is_success = (reward == 1); terminated = is_success.detach().cpu().numpy().astype(bool)        (env.py:63-64)
+ * mir_step_begin = mir_step_fused (same arguments, `terminated` = the device copy, nullable) that also stores the
+ * terminated bytes into a pinned host buffer owned by the handle, straight from the kernel (no copy command);
+ * mir_step_end blocks until THAT launch has finished and copies the B bytes into terminated_host (plain host memory,
+ * nullable).  Between the two calls the host is free (the Python side prepares its return values there).  Exactly one
+ * mir_step_end per mir_step_begin; the only entry point of the library that waits for the device.
+ * How the wait is done (mir_get_sync_mode; environment variable MIR_SYNC_MODE overrides at mir_create):
+ *   2  the kernel's last workgroup writes a sequence word into pinned host memory, the host spins on it (16-lane kernel)
+ *   1  hipStreamWriteValue32 behind the launch writes that word, the host spins on it (wave-per-env kernel; fallback)
+ *   0  hipStreamSynchronize */
+int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward,
+                   uint8_t* terminated, void* stream);
+int mir_step_end(MirHandle h, uint8_t* terminated_host);
+int mir_get_sync_mode(MirHandle h);
+
 /* Same step, but every output of an env lands in ONE packed float32 row
  * rows[e*row_stride + ...] = [agent_pos (agent_dim) | env_state (env_dim) | reward | terminated(0/1)]
  * so a sharded run gathers all per-step outputs with a single collective
@@ -327,6 +343,13 @@ typedef struct MirIkOptions {
  * final |e_pos|, |e_rot|.  The scene state is not modified. */
 int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_pos, const float* target_quat, const float* init_qpos,
                            const MirIkOptions* opt, float* qpos_out, float* err_out, void* stream);
+
+/* ---- debug aids (exported for the tests and tools/; not part of the drop-in surface) ---------------------------
+ * mir_debug_profile_step: one step with phase timestamps (shader clock) of workgroup 0 into prof (32 x u64, device).
+ * mir_debug_poison_lds: overwrite the LDS of every CU with signalling-NaN patterns, so that a kernel reading an LDS slot
+ * before writing it yields NaNs instead of plausible stale values (the GPU tests call it before every scene). */
+int mir_debug_profile_step(MirHandle h, unsigned long long* prof, void* stream);
+int mir_debug_poison_lds(int device_id, void* stream);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,15 @@ class OracleScene(StepHelpers):
         self.o.step_batch(None if action is None else self._np(action).astype(np.float32))
         self._fill(agent_pos, env_state, reward, terminated)
 
+    def step_begin(self, action, agent_pos, env_state, reward, terminated):
+        assert getattr(self, "_pending", None) is None, "step_begin twice without step_end"
+        self.step_fused(action, agent_pos, env_state, reward, terminated)
+        self._pending = terminated.numpy().astype(np.bool_)
+
+    def step_end(self):
+        out, self._pending = self._pending.copy(), None
+        return out
+
     def step_packed(self, action, rows):
         bufs = (self.empty(self.agent_dim), self.empty(self.env_dim), self.empty(), self.empty(dtype=torch.uint8))
         self.step_fused(action, *bufs)

@@ -1,0 +1,67 @@
+"""CPU-tier checks of bench.py: the index arithmetic that crashed the round-1 driver run (`--steps 20 --warmup 5` sliced past
+the action pool), the self-launch line, and a 2-rank gloo dry run of the launcher (no GPU, no physics)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+@pytest.mark.parametrize("steps,warmup", [(20, 5), (1, 0), (2000, 50), (7, 300)])
+def test_every_index_stays_inside_the_action_pool(steps, warmup):
+    n = bench.N_ACT
+    for t in range(warmup + 3 * steps + 5):
+        assert 0 <= bench.action_index(t) < n
+    for rk in (bench.RK, 1, 7, n):
+        for i in range(3 * n // rk + 5):
+            lo, hi = bench.rollout_slice(i, rk, n)
+            assert 0 <= lo < hi <= n and hi - lo == rk
+    # the pools of the secondary legs (256 batches, 16-step rollouts)
+    for i in range(40):
+        lo, hi = bench.rollout_slice(i, 16, 256)
+        assert hi - lo == 16 and hi <= 256
+
+
+def test_repeats_reach_the_minimum_time():
+    assert bench.repeats_for(0.001, 0.5) == 500
+    assert bench.repeats_for(0.6, 0.5) == 1
+    assert bench.repeats_for(0.0, 0.5) == 2000
+    assert bench.repeats_for(1e-9, 0.5) == 2000  # capped
+    assert bench.repeats_for(0.3, 0.5) == 2
+
+
+def test_launch_command_is_the_drivers_line():
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29555)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+
+
+def test_defaults_are_one_gpu_and_bounded():
+    a = bench.parse_args([])
+    assert a.gpus == 1 and a.steps == 2000 and a.warmup == 50
+
+
+def test_gpus_2_without_a_launcher_spawns_two_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start two ranks itself (round 1 silently ran one)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rank_sum"] == 3.0
+
+
+def test_without_a_gpu_the_bench_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)

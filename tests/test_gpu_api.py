@@ -1,0 +1,81 @@
+"""GPU tests of the env.step() host hand-over (mir_step_begin / mir_step_end): in every sync mode the NumPy `terminated` that
+GenesisEnv.step returns equals the device mask of the same launch bit for bit, the physics is untouched (bit-identical to
+mir_step_fused), and each call hands out a fresh array (gym_genesis/env.py:61-69 of the reference)."""
+import numpy as np
+import pytest
+import torch
+
+from gym_genesis.backend import models
+
+pytestmark = pytest.mark.gpu
+HOME = np.array(models.FRANKA_HOME, dtype=np.float32)
+
+
+def _reset(sc, B, seed=0):
+    rng = np.random.RandomState(seed)
+    pos = np.stack([rng.uniform(0.45, 0.80, B), rng.uniform(-0.25, 0.25, B), np.full(B, 0.02)], 1).astype(np.float32)
+    pos[::2, 2] = rng.uniform(0.12, 0.16, size=pos[::2].shape[0])  # every other cube starts above the reward threshold and falls
+    quat = np.tile(np.array([0, 0, 0, 1], np.float32), (B, 1))
+    sc.reset(pos, quat, np.tile(HOME, (B, 1)))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("B", [1, 5, 4096])
+def test_step_begin_end_equals_step_fused(franka_spec, monkeypatch, mode, B):
+    from gym_genesis.backend.lib import MirScene
+
+    monkeypatch.setenv("MIR_SYNC_MODE", str(mode))
+    sc = MirScene(franka_spec, B)
+    monkeypatch.delenv("MIR_SYNC_MODE")
+    ref = MirScene(franka_spec, B)
+    assert sc.sync_mode == mode and ref.sync_mode == 2
+    _reset(sc, B)
+    _reset(ref, B)
+    acts = torch.as_tensor(np.random.default_rng(3).uniform(-1, 1, (25, B, 9)).astype(np.float32), device=sc.device)
+    b1 = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    b2 = (ref.empty(9), ref.empty(11), ref.empty(), ref.empty(dtype=torch.uint8))
+    seen_true = seen_false = False
+    for t in range(25):
+        sc.step_begin(acts[t], *b1)
+        host = sc.step_end()
+        ref.step_fused(acts[t], *b2)
+        assert host.dtype == np.bool_ and host.shape == (B,)
+        assert np.array_equal(host, b1[3].cpu().numpy().astype(bool)), f"step {t}: host mask differs from the device mask"
+        for x, y in zip(b1, b2):
+            assert torch.equal(x, y)
+        seen_true |= bool(host.any())
+        seen_false |= bool((~host).any())
+    assert seen_false and (seen_true or B == 1)
+    for x, y in zip(sc.get_state(), ref.get_state()):
+        assert torch.equal(x, y)
+
+
+def test_step_end_without_begin_and_double_begin_are_errors(franka_spec):
+    from gym_genesis.backend.lib import MirError, MirScene
+
+    sc = MirScene(franka_spec, 8)
+    _reset(sc, 8)
+    with pytest.raises(MirError):
+        sc.step_end()
+    bufs = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    sc.step_begin(None, *bufs)
+    with pytest.raises(MirError):
+        sc.step_begin(None, *bufs)
+    assert sc.step_end().shape == (8,)
+
+
+def test_env_step_returns_fresh_host_masks_every_call():
+    from gym_genesis.env import GenesisEnv
+
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=64, enable_pixels=False)
+    env.reset(seed=0)
+    a = torch.zeros((64, 9), device=env._env.device)
+    kept = []
+    for t in range(5):
+        obs, reward, terminated, truncated, info = env.step(a)
+        assert isinstance(terminated, np.ndarray) and terminated.dtype == np.bool_ and truncated.dtype == np.bool_
+        assert np.array_equal(terminated, (reward == 1).cpu().numpy()) and torch.equal(info["is_success"].cpu(), torch.as_tensor(terminated))
+        kept.append((terminated, terminated.copy(), obs["agent_pos"], obs["agent_pos"].clone()))
+    for arr, snap, ten, tsnap in kept:  # earlier results are not overwritten by later steps
+        assert np.array_equal(arr, snap) and torch.equal(ten, tsnap)
+    assert len({id(k[0]) for k in kept}) == 5

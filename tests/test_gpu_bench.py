@@ -1,0 +1,45 @@
+"""The driver's own bench command, run as a subprocess on the GPU box: it must exit 0 and its last stdout line must be the
+JSON contract line carrying `roofline` and `cpu_baseline` (round 1's driver run crashed before printing anything)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(*flags, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    last = r.stdout.strip().splitlines()[-1]
+    return json.loads(last)
+
+
+def test_driver_command_prints_the_contract_line():
+    out = _run("--gpus", "1", "--steps", "20", "--warmup", "5")
+    assert out["metric"].startswith("env-steps/sec") and out["unit"] == "env-steps/s" and out["n_gpus"] == 1
+    assert out["steps"] == 20 and out["warmup"] == 5 and out["higher_is_better"] is True and out["vs_baseline"] is None
+    assert out["value"] > 1e6 and out["path"] == "GenesisEnv.step"
+    assert abs(out["ms_per_step"] * 1e-3 * out["value"] - 4096) < 1.0          # value and ms_per_step describe the same time
+    assert out["timed_seconds_total"] >= 0.4 and out["repeats"] * 20 == out["timed_steps_total"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
+    assert abs(rf["achieved"] - 489.0 * 4096 / (rf["kernel_us"] * 1e-6) / 1e9) < 1e-6 * rf["achieved"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "env-steps/s"
+    for key in ("secondary", "pixels", "scripted_grasp", "so101_pick", "stack", "ik"):
+        assert key in out and "error" not in out[key], (key, out.get(key))
+    assert out["hot_path_rate"] >= out["value"] * 0.9
+
+
+def test_two_ranks_share_the_gpu_over_gloo():
+    """N > 1 plumbing on a 1-GPU box: bench.py spawns two ranks itself, both on cuda:0, process group over gloo, the env axis
+    sharded, outputs gathered; rank 0 prints n_gpus == 2 with the world size the process group reports."""
+    out = _run("--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo", "--oversubscribe", "--envs-per-gpu", "512",
+               "--min-time", "0.1", "--gather-every", "4")
+    assert out["n_gpus"] == 2 and out["config"]["world_size_observed"] == 2 and out["config"]["global_num_envs"] == 1024
+    assert out["value"] > 0 and "gloo all_gather" in out["config"]["obs_gather"]

@@ -20,7 +20,7 @@ def _paths():
             sys.path.insert(0, p)
 
 
-def _run(shard, actions):
+def _run(shard, actions, b_global=B_GLOBAL, pass_num_envs=True):
     """Rollout of this shard on the oracle-backed test double; returns packed rows per step."""
     _paths()
     import fake_scene
@@ -30,47 +30,52 @@ def _run(shard, actions):
     from gym_genesis.env import GenesisEnv
     from gym_genesis.sharding import gather_rows, pack_rows, shard_bounds
 
-    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B_GLOBAL, enable_pixels=False, shard=shard)
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=b_global, enable_pixels=False, shard=shard)
     rank, world = shard if shard else (0, 1)
-    lo, hi = shard_bounds(B_GLOBAL, rank, world)
+    lo, hi = shard_bounds(b_global, rank, world)
     assert env.num_envs == hi - lo
     env.reset(seed=3)
     out = []
     for t in range(STEPS):
         obs, reward, terminated, truncated, info = env.step(actions[t, lo:hi])
         rows = pack_rows(obs, reward, torch.as_tensor(terminated))
-        out.append(gather_rows(rows))
+        out.append(gather_rows(rows, num_envs=b_global if pass_num_envs else None))
     return torch.stack(out)
 
 
-def _worker(rank, world, port, actions, q):
+def _worker(rank, world, port, actions, q, b_global=B_GLOBAL, pass_num_envs=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rows = _run((rank, world), actions)
+        rows = _run((rank, world), actions, b_global, pass_num_envs)
         q.put((rank, rows.numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_shard_equals_single_process():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("b_global,pass_num_envs", [(6, True), (7, True), (7, False)])
+def test_two_rank_shard_equals_single_process(b_global, pass_num_envs):
+    """Equal (3 + 3) and unequal (3 + 4) shards: the gathered rows equal the unsharded run bit for bit."""
     _paths()
-    actions = np.random.default_rng(0).uniform(-1, 1, (STEPS, B_GLOBAL, 9)).astype(np.float32)
-    ref = _run(None, actions).numpy()
+    actions = np.random.default_rng(0).uniform(-1, 1, (STEPS, b_global, 9)).astype(np.float32)
+    ref = _run(None, actions, b_global).numpy()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, actions, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, actions, q, b_global, pass_num_envs)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert ref.shape == (STEPS, B_GLOBAL, 22)
+    assert ref.shape == (STEPS, b_global, 22)
     for r in range(2):
         assert np.array_equal(got[r], ref), f"rank {r}: gathered rows differ from the unsharded run"
 
