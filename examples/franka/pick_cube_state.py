@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "gym-genesis_amd"))
 
 from gym_genesis.env import GenesisEnv  # noqa: E402
 
-STAGES = ("hover", "stabilize", "grasp", "grasp", "lift")  # pick_cube_state.py:86
+STAGES = ("hover", "stabilize", "descend", "grasp", "lift")  # five stages of 40 steps (pick_cube_state.py:86)
 
 
 def expert_policy(robot, observation, stage, cube_ref):
@@ -30,7 +30,7 @@ def expert_policy(robot, observation, stage, cube_ref):
     B, device = observation["agent_pos"].shape[0], observation["agent_pos"].device
     quat = torch.tensor([0, 1, 0, 0], dtype=torch.float32, device=device).expand(B, -1)  # hand pointing down
     eef = robot.get_link("hand")
-    dz, grip = {"hover": (0.25, 0.04), "stabilize": (0.104, 0.04), "grasp": (0.104, 0.0), "lift": (0.40, 0.0)}[stage]
+    dz, grip = {"hover": (0.25, 0.04), "stabilize": (0.25, 0.04), "descend": (0.104, 0.04), "grasp": (0.104, 0.0), "lift": (0.40, 0.0)}[stage]
     target_pos = cube_ref + torch.tensor([0.0, 0.0, dz], device=device)
     qpos = robot.inverse_kinematics(link=eef, pos=target_pos, quat=quat, envs_idx=torch.arange(B, device=device))  # (B, 9)
     return torch.cat([qpos[:, :-2], torch.full((B, 2), grip, device=device)], dim=1)

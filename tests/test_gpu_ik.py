@@ -53,8 +53,9 @@ def test_ik_matches_oracle_and_forward_kinematics():
 
 
 def test_expert_pick_policy_end_to_end_on_device():
-    """hover -> stabilize -> grasp -> grasp -> lift, 40 steps each, targets from batched IK every step, as the reference's
-    data-collection loop does; heights adapted to this repo's box-pad fingers (tests/golden/make_grasp_targets.py)."""
+    """hover -> stabilize -> descend -> grasp -> lift, 40 steps each, targets from batched IK every step, as the reference's
+    data-collection loop does (pick_cube_state.py:86-88: the hover target is held for two stages, which the wrist joints --
+    +-12 N m -- need to settle); heights adapted to this repo's box-pad fingers (tests/golden/make_grasp_targets.py)."""
     from gym_genesis.env import GenesisEnv
 
     B = 64
@@ -66,7 +67,7 @@ def test_expert_pick_policy_end_to_end_on_device():
     quat = torch.tensor([0, 1, 0, 0], dtype=torch.float32, device=dev).expand(B, -1)
     cube0 = obs["environment_state"][:, :3].clone()
     success = torch.zeros(B, dtype=torch.bool, device=dev)
-    for stage, dz, grip in (("hover", 0.25, 0.04), ("stabilize", 0.104, 0.04), ("grasp", 0.104, 0.0), ("grasp", 0.104, 0.0), ("lift", 0.40, 0.0)):
+    for stage, dz, grip in (("hover", 0.25, 0.04), ("stabilize", 0.25, 0.04), ("descend", 0.104, 0.04), ("grasp", 0.104, 0.0), ("lift", 0.40, 0.0)):
         for _ in range(40):
             target = cube0 + torch.tensor([0.0, 0.0, dz], device=dev)
             qpos = robot.inverse_kinematics(link=eef, pos=target, quat=quat, envs_idx=torch.arange(B, device=dev))

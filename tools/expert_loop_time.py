@@ -12,7 +12,7 @@ task = env._env; dev = task.device
 robot, cube = env.get_robot(), obs["environment_state"][:, :3].clone()
 eef = robot.get_link("hand")
 quat = torch.tensor([0.0, 1.0, 0.0, 0.0], device=dev).repeat(B, 1)
-stages = [("hover", 0.25, 0.04), ("stabilize", 0.104, 0.04), ("grasp", 0.104, 0.0), ("grasp", 0.104, 0.0), ("lift", 0.40, 0.0)]
+stages = [("hover", 0.25, 0.04), ("stabilize", 0.25, 0.04), ("descend", 0.104, 0.04), ("grasp", 0.104, 0.0), ("lift", 0.40, 0.0)]
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 for name, dz, grip in stages:
     tgt = cube + torch.tensor([0.0, 0.0, dz], device=dev)

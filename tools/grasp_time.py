@@ -11,7 +11,7 @@ task = env._env; dev = task.device
 robot, cube = env.get_robot(), obs["environment_state"][:, :3].clone()
 eef = robot.get_link("hand")
 quat = torch.tensor([0.0, 1.0, 0.0, 0.0], device=dev).repeat(B, 1)
-stages = [("hover", 0.25, 0.04), ("stabilize", 0.104, 0.04), ("grasp", 0.104, 0.0), ("grasp2", 0.104, 0.0), ("lift", 0.40, 0.0)]
+stages = [("hover", 0.25, 0.04), ("stabilize", 0.25, 0.04), ("descend", 0.104, 0.04), ("grasp", 0.104, 0.0), ("lift", 0.40, 0.0)]
 q_prev = None
 for name, dz, grip in stages:
     q = robot.inverse_kinematics(link=eef, pos=cube + torch.tensor([0.0, 0.0, dz], device=dev), quat=quat, init_qpos=q_prev)
