@@ -445,6 +445,7 @@ def worker(args) -> int:
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     actions = torch.empty((N_ACT, B, 9), dtype=torch.float32, device=dev)
     actions.uniform_(-1.0, 1.0, generator=gen)
+    act_list = list(actions.unbind(0))  # one (B, 9) device tensor per pre-drawn step: no view is built inside the timed loop
 
     gather = use_pg and not args.no_gather
     S = max(1, args.gather_every)
@@ -468,7 +469,7 @@ def worker(args) -> int:
     def api_step():
         """One iteration of the README loop through GenesisEnv.step."""
         t = state["t"]
-        obs, reward, terminated, truncated, info = env.step(actions[action_index(t)])
+        obs, reward, terminated, truncated, info = env.step(act_list[action_index(t)])
         if gather:
             chunk_parts.extend((obs["agent_pos"].reshape(-1), obs["environment_state"].reshape(-1), reward))
             if len(chunk_parts) == 3 * S:
@@ -482,7 +483,7 @@ def worker(args) -> int:
         """The bare fused launch into persistent buffers (no host hand-over, no reset: every launch in the bracket is one
         mir_step_kernel<0>, so HIP-event time / launches is that kernel's average duration including the launch gap)."""
         t = state["t"]
-        task.step_raw(actions[action_index(t)])
+        task.step_raw(act_list[action_index(t)])
         state["t"] = t + 1
 
     def sync_all():
@@ -578,6 +579,15 @@ def worker(args) -> int:
             achieved = ALGO_BYTES_PER_ENV_STEP * B / (kernel_us * 1e-6) / 1e9
             out["hot_path_rate"] = n_launch * B * world / sum(raw_walls)
             out["api_over_hot_path"] = out["value"] / out["hot_path_rate"]
+            # what a synchronous step cannot go below on this machine: the kernel + one empty-kernel launch/completion round trip
+            try:
+                null_us = task._mir.null_roundtrip_us(2000)
+                out["sync_step_floor"] = {"null_launch_roundtrip_us": null_us, "kernel_us": kernel_us,
+                                          "floor_us_per_step": kernel_us + null_us, "measured_us_per_step": out["ms_per_step"] * 1e3,
+                                          "note": "env.step must hand a NumPy `terminated` to the host every step (env.py:64), so the next launch "
+                                                  "cannot be queued behind the running one: each step pays launch + dispatch + completion latency"}
+            except Exception as e:  # noqa: BLE001
+                out["sync_step_floor"] = {"error": f"{type(e).__name__}: {e}"}
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": _profile_number("pmc_hbm_traffic.json", "hbm_bytes_per_launch") if B == ENVS_PER_GPU else None,
                                "kernel": "mir_step_kernel<0>", "kernel_us": kernel_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,

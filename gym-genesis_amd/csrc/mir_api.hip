@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 
 #include "mir_model.h"
@@ -545,6 +546,39 @@ int mir_debug_profile_step(MirHandle h, unsigned long long* prof16, void* stream
   Outs o;
   o.prof = prof16;
   return launch(h, o, stream);
+}
+
+/* debug aid (not part of the drop-in surface): the floor under one synchronous env.step() on this machine -- launch an (almost)
+ * empty kernel that writes a sequence word into pinned host memory, spin on that word, repeat; *out_us = microseconds per round
+ * trip (launch call + dispatch latency + host-visible completion), nothing of the physics in it. */
+namespace {
+__global__ void k_null_flag(uint32_t* flag, uint32_t seq) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+extern "C" int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* out_us) {
+  if (check(h) || !out_us || iters <= 0) return set_err(MIR_E_INVALID, "mir_debug_null_roundtrip: bad argument");
+  if (h->pending) return set_err(MIR_E_INVALID, "mir_debug_null_roundtrip: a step is pending");
+  DeviceGuard guard(h->device);
+  const size_t off = ((size_t)(h->B + 63) / 64) * 64;
+  uint32_t* flag_dev = reinterpret_cast<uint32_t*>(h->pin_dev + off);
+  volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->pin_host + off);
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int i = 0; i < iters; i++) {
+    const uint32_t seq = ++h->seq;
+    hipLaunchKernelGGL(k_null_flag, dim3(1), dim3(64), 0, (hipStream_t)stream, flag_dev, seq);
+    unsigned long polls = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+      __builtin_ia32_pause();
+      if (++polls > (1ul << 28)) return set_err(MIR_E_HIP, "mir_debug_null_roundtrip: no completion word");
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  HIPCHK(hipGetLastError());
+  *out_us = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) * 1e-3 / iters;
+  return MIR_OK;
 }
 
 /* debug aid (not part of the drop-in surface): overwrite the LDS of every CU with signalling-NaN bit patterns.  LDS keeps

@@ -53,6 +53,8 @@ def load_library() -> C.CDLL:
     lib.mir_step_end.restype = C.c_int
     lib.mir_get_sync_mode.argtypes = [vp]
     lib.mir_get_sync_mode.restype = C.c_int
+    lib.mir_debug_null_roundtrip.argtypes = [vp, i32, vp, C.POINTER(C.c_double)]
+    lib.mir_debug_null_roundtrip.restype = C.c_int
     lib.mir_step_packed.argtypes = [vp, vp, vp, i32, vp]
     lib.mir_step_packed.restype = C.c_int
     lib.mir_rollout.argtypes = [vp, vp, i32, vp, i32, vp]
@@ -86,6 +88,11 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+# torch.cuda.current_stream(device).cuda_stream costs ~1.5 us per call (two Python objects); the raw getter is ~0.1 us.  It sits
+# in front of every launch of the API path, where the GPU is idle while the host prepares the call.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 class StepHelpers:
     """Host-side helpers of the API path, shared by MirScene and the CPU test double (tests/fake_scene.py); they need
     `num_envs`, `device` and `step_fused` of the scene."""
@@ -94,35 +101,57 @@ class StepHelpers:
     # before it -- the output tensors of the NEXT call are allocated while this call's kernel runs
     def as_action(self, action, dim: int) -> torch.Tensor:
         """(B, dim) float32 contiguous device tensor from a torch tensor (device or CPU) or anything NumPy understands."""
-        if not (isinstance(action, torch.Tensor) and action.dtype is torch.float32 and action.device == self.device and action.is_contiguous()):
-            if not isinstance(action, torch.Tensor):
-                action = torch.as_tensor(np.asarray(action))
-            action = action.to(device=self.device, dtype=torch.float32).contiguous()
+        if type(action) is torch.Tensor and action.dtype is torch.float32 and action.device == self.device and action.is_contiguous():
+            if action.shape[0] != self.num_envs or action.dim() != 2 or action.shape[1] != dim:
+                raise ValueError(f"action must have shape {(self.num_envs, dim)}, got {tuple(action.shape)}")
+            return action
+        if not isinstance(action, torch.Tensor):
+            action = torch.as_tensor(np.asarray(action))
+        action = action.to(device=self.device, dtype=torch.float32).contiguous()
         if action.shape != (self.num_envs, dim):
             raise ValueError(f"action must have shape {(self.num_envs, dim)}, got {tuple(action.shape)}")
         return action
 
     def _alloc_outputs(self, agent_dim: int, env_dim: int):
+        """Fresh output tensors of one step, with their device addresses (so the launch itself does no attribute lookups):
+        ((agent_pos, environment_state, reward, terminated u8), (ptr, ptr, ptr, ptr))."""
         B = self.num_envs
         buf = torch.empty(B * (agent_dim + env_dim + 1), dtype=torch.float32, device=self.device)
-        return (buf[:agent_dim * B].view(B, agent_dim), buf[agent_dim * B:(agent_dim + env_dim) * B].view(B, env_dim),
-                buf[(agent_dim + env_dim) * B:], torch.empty(B, dtype=torch.uint8, device=self.device))
+        term = torch.empty(B, dtype=torch.uint8, device=self.device)
+        base = buf.data_ptr()
+        outs = (buf[:agent_dim * B].view(B, agent_dim), buf[agent_dim * B:(agent_dim + env_dim) * B].view(B, env_dim),
+                buf[(agent_dim + env_dim) * B:], term)
+        return outs, (base, base + 4 * agent_dim * B, base + 4 * (agent_dim + env_dim) * B, term.data_ptr())
 
     def step_fresh(self, action, agent_dim: int, env_dim: int, host_terminated: bool = False):
         """One fused step into FRESH output tensors (callers may keep old observations, as with the reference):
         returns (agent_pos, environment_state, reward, terminated u8).  With host_terminated the launch also delivers the
-        terminated bytes to the host (step_begin); the caller must then close the step with step_end()."""
+        terminated bytes to the host (step_begin); the caller must then close the step with step_end().
+        The GPU idles while Python prepares a launch, so nothing that can wait is done before it: the output tensors of the
+        NEXT call and the host array of THIS call are allocated while the kernel runs."""
         key = (agent_dim, env_dim)
-        out = self._fresh.pop(key, None) if hasattr(self, "_fresh") else None
-        if out is None:
-            self._fresh = {}
-            out = self._alloc_outputs(agent_dim, env_dim)
+        fresh = self.__dict__.get("_fresh")
+        if fresh is None:
+            fresh = self._fresh = {}
+        slot = fresh.pop(key, None)
+        if slot is None:
+            slot = self._alloc_outputs(agent_dim, env_dim)
+        outs, ptrs = slot
         if host_terminated:
-            self.step_begin(action, *out)
+            self.step_begin_ptrs(action.data_ptr(), ptrs)
+            host = np.empty(self.num_envs, dtype=np.bool_)
+            self._host_pending = (host, host.ctypes.data)
         else:
-            self.step_fused(action, *out)
-        self._fresh[key] = self._alloc_outputs(agent_dim, env_dim)  # (while the kernel runs)
-        return out
+            self.step_fused_ptrs(action.data_ptr(), ptrs)
+        fresh[key] = self._alloc_outputs(agent_dim, env_dim)  # (while the kernel runs)
+        return outs
+
+    # pointer-level launches; the CPU test double (tests/fake_scene.py) overrides these two
+    def step_begin_ptrs(self, action_ptr, ptrs):
+        raise NotImplementedError
+
+    def step_fused_ptrs(self, action_ptr, ptrs):
+        raise NotImplementedError
 
 
 class MirScene(StepHelpers):
@@ -154,6 +183,8 @@ class MirScene(StepHelpers):
             raise MirError(f"libmirigid error {rc}: {self.lib.mir_last_error().decode()}")
 
     def _stream(self):
+        if _raw_stream is not None:
+            return _raw_stream(self.device.index)  # int; the c_void_p argtype converts it
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _f32(self, t, *cols: int) -> torch.Tensor:
@@ -229,12 +260,35 @@ class MirScene(StepHelpers):
         """mir_step_begin: step_fused whose terminated bytes also go to the host; close with step_end()."""
         self._check(self.lib.mir_step_begin(self.h, _ptr(action), _ptr(agent_pos), _ptr(env_state), _ptr(reward),
                                             _ptr(terminated), self._stream()))
+        self._host_pending = None
+
+    def step_begin_ptrs(self, action_ptr, ptrs) -> None:
+        rc = self.lib.mir_step_begin(self.h, action_ptr, ptrs[0], ptrs[1], ptrs[2], ptrs[3], self._stream())
+        if rc:
+            self._check(rc)
+
+    def step_fused_ptrs(self, action_ptr, ptrs) -> None:
+        rc = self.lib.mir_step_fused(self.h, action_ptr, ptrs[0], ptrs[1], ptrs[2], ptrs[3], self._stream())
+        if rc:
+            self._check(rc)
 
     def step_end(self) -> np.ndarray:
         """mir_step_end: wait for the launch of step_begin; a FRESH NumPy bool (B,) = terminated (env.py:64)."""
-        out = np.empty(self.num_envs, dtype=np.bool_)
-        self._check(self.lib.mir_step_end(self.h, C.c_void_p(out.ctypes.data)))
-        return out
+        pend = self.__dict__.get("_host_pending")
+        if pend is None:  # (step_begin called directly: nothing was prepared during the kernel)
+            host = np.empty(self.num_envs, dtype=np.bool_)
+            pend = (host, host.ctypes.data)
+        self._host_pending = None
+        rc = self.lib.mir_step_end(self.h, pend[1])
+        if rc:
+            self._check(rc)
+        return pend[0]
+
+    def null_roundtrip_us(self, iters: int = 2000) -> float:
+        """mir_debug_null_roundtrip: microseconds per empty-kernel launch + host-visible completion (the floor under env.step)."""
+        out = C.c_double()
+        self._check(self.lib.mir_debug_null_roundtrip(self.h, int(iters), self._stream(), C.byref(out)))
+        return out.value
 
     @property
     def sync_mode(self) -> int:

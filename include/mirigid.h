@@ -347,8 +347,11 @@ int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_p
 /* ---- debug aids (exported for the tests and tools/; not part of the drop-in surface) ---------------------------
  * mir_debug_profile_step: one step with phase timestamps (shader clock) of workgroup 0 into prof (32 x u64, device).
  * mir_debug_poison_lds: overwrite the LDS of every CU with signalling-NaN patterns, so that a kernel reading an LDS slot
- * before writing it yields NaNs instead of plausible stale values (the GPU tests call it before every scene). */
+ * before writing it yields NaNs instead of plausible stale values (the GPU tests call it before every scene).
+ * mir_debug_null_roundtrip: microseconds per (launch of an empty kernel + host-visible completion word), averaged over iters:
+ * the floor under one synchronous env.step() on this machine, with none of the physics in it. */
 int mir_debug_profile_step(MirHandle h, unsigned long long* prof, void* stream);
+int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* out_us);
 int mir_debug_poison_lds(int device_id, void* stream);
 
 #ifdef __cplusplus

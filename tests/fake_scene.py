@@ -54,6 +54,25 @@ class OracleScene(StepHelpers):
         self.o.step_batch(None if action is None else self._np(action).astype(np.float32))
         self._fill(agent_pos, env_state, reward, terminated)
 
+    # pointer-level launches of StepHelpers.step_fresh: the double looks its tensors up by address
+    def _alloc_outputs(self, agent_dim, env_dim):
+        outs, ptrs = super()._alloc_outputs(agent_dim, env_dim)
+        self.__dict__.setdefault("_by_ptr", {})[ptrs] = outs
+        return outs, ptrs
+
+    def as_action(self, action, dim):
+        a = super().as_action(action, dim)
+        self._last_action = a
+        return a
+
+    def step_begin_ptrs(self, action_ptr, ptrs):
+        assert action_ptr == self._last_action.data_ptr()
+        self.step_begin(self._last_action, *self._by_ptr.pop(ptrs))
+
+    def step_fused_ptrs(self, action_ptr, ptrs):
+        assert action_ptr == self._last_action.data_ptr()
+        self.step_fused(self._last_action, *self._by_ptr.pop(ptrs))
+
     def step_begin(self, action, agent_pos, env_state, reward, terminated):
         assert getattr(self, "_pending", None) is None, "step_begin twice without step_end"
         self.step_fused(action, agent_pos, env_state, reward, terminated)
@@ -61,6 +80,7 @@ class OracleScene(StepHelpers):
 
     def step_end(self):
         out, self._pending = self._pending.copy(), None
+        self._host_pending = None
         return out
 
     def step_packed(self, action, rows):

@@ -136,11 +136,13 @@ def test_rollout_home_pose_resting_contact_1000_steps(franka_spec):
 
 
 def test_rollout_smooth_targets_1000_steps(franka_spec):
-    """PD-tracked smooth joint-space motion inside the limits (contractive regime): 1000 free-running
-    steps, joint-state L-inf < 1e-4."""
+    """PD-tracked smooth joint-space motion inside the joint limits AND the actuator limits (contractive regime): 1000
+    free-running steps, joint-state L-inf < 1e-4.  The wrist amplitudes are small enough that joints 5-7 track without
+    riding their +-12 N m limit: with 0.6 / 0.5 / 0.8 rad they saturate and the motion stops being contractive -- the float32
+    CPU port of the oracle itself then ends 1.7e-3 from the float64 run (the yardstick test covers that regime)."""
     B, T = 16, 1000
     home = HOME.astype(np.float64)
-    amp = np.array([0.5, 0.3, 0.5, 0.4, 0.6, 0.5, 0.8, 0.015, 0.015])
+    amp = np.array([0.5, 0.3, 0.5, 0.4, 0.15, 0.15, 0.2, 0.015, 0.015])
     ph = np.random.default_rng(7).uniform(0, 2 * np.pi, (B, 9))
 
     def act(t):
