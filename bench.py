@@ -231,6 +231,7 @@ def grasp_bench(torch, dev):
     env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
     obs, _ = env.reset(seed=0)
     task = env._env
+    task._mir.set_diag(True)
     robot, cube = env.get_robot(), obs["environment_state"][:, :3].clone()
     eef = robot.get_link("hand")
     quat = torch.tensor([0.0, 1.0, 0.0, 0.0], device=dev).repeat(B, 1)
@@ -300,6 +301,7 @@ def stack_bench(torch, dev, steps: int = 300):
     B = ENVS_PER_GPU
     env = GenesisEnv(task="cube_stack", robot="franka", num_envs=B, enable_pixels=False)
     task = env._env
+    task._mir.set_diag(True)
     env.reset(seed=0)
     gen = torch.Generator(device=dev).manual_seed(4321)
     acts = task._home[0] + torch.empty((256, B, 9), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
@@ -466,25 +468,29 @@ def worker(args) -> int:
             state["chunk"] += 1
             chunk_parts.clear()
 
-    def api_step():
-        """One iteration of the README loop through GenesisEnv.step."""
-        t = state["t"]
-        obs, reward, terminated, truncated, info = env.step(act_list[action_index(t)])
-        if gather:
-            chunk_parts.extend((obs["agent_pos"].reshape(-1), obs["environment_state"].reshape(-1), reward))
-            if len(chunk_parts) == 3 * S:
-                flush()
-        state["t"] = t + 1
-        if terminated.any() or truncated.any() or (t + 1) % EPISODE_STEPS == 0:
-            env.reset()
-            state["resets"] += 1
+    def api_loop(k: int):
+        """k iterations of the README loop through GenesisEnv.step (README.md:32-43)."""
+        t, step, n = state["t"], env.step, N_ACT
+        for _ in range(k):
+            obs, reward, terminated, truncated, info = step(act_list[t % n])
+            if gather:
+                chunk_parts.extend((obs["agent_pos"].reshape(-1), obs["environment_state"].reshape(-1), reward))
+                if len(chunk_parts) == 3 * S:
+                    flush()
+            t += 1
+            if terminated.any() or truncated.any() or t % EPISODE_STEPS == 0:
+                env.reset()
+                state["resets"] += 1
+        state["t"] = t
 
-    def raw_step():
-        """The bare fused launch into persistent buffers (no host hand-over, no reset: every launch in the bracket is one
+    def raw_loop(k: int):
+        """k bare fused launches into persistent buffers (no host hand-over, no reset: every launch in the bracket is one
         mir_step_kernel<0>, so HIP-event time / launches is that kernel's average duration including the launch gap)."""
-        t = state["t"]
-        task.step_raw(act_list[action_index(t)])
-        state["t"] = t + 1
+        t, step, n = state["t"], task.step_raw, N_ACT
+        for _ in range(k):
+            step(act_list[t % n])
+            t += 1
+        state["t"] = t
 
     def sync_all():
         flush()
@@ -504,28 +510,26 @@ def worker(args) -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(step_fn, k: int):
+    def timed(loop_fn, k: int):
         """Exactly k steps bracketed by barrier + synchronize on both sides; (wall seconds max over ranks, HIP-event ms)."""
         sync_all()
         ev0, ev1 = _events(torch)
         t0 = time.perf_counter()
         ev0.record()
-        for _ in range(k):
-            step_fn()
+        loop_fn(k)
         ev1.record()
         sync_all()
         wall = time.perf_counter() - t0
         return max_over_ranks(wall), ev0.elapsed_time(ev1)
 
-    def measure(step_fn):
+    def measure(loop_fn):
         """W warm-up steps, then the K-step timed region, repeated until --min-time seconds are measured."""
-        for _ in range(W):
-            step_fn()
-        first, ev_ms = timed(step_fn, K)
+        loop_fn(W)
+        first, ev_ms = timed(loop_fn, K)
         reps = repeats_for(first, args.min_time) if first < args.min_time else 1  # (`first` is already the max over ranks)
         walls, evs = [first], [ev_ms]
         for _ in range(reps - 1):
-            w, e = timed(step_fn, K)
+            w, e = timed(loop_fn, K)
             walls.append(w)
             evs.append(e)
         return walls, evs
@@ -535,10 +539,10 @@ def worker(args) -> int:
     try:
         # ---- headline: the loop through GenesisEnv.step ---------------------------------------------------------------
         if args.core_only and args.raw_only:
-            walls, evs = measure(raw_step)
+            walls, evs = measure(raw_loop)
             api_walls = None
         else:
-            api_walls, _ = measure(api_step)
+            api_walls, _ = measure(api_loop)
             walls = api_walls
         total_wall = sum(walls)
         value = len(walls) * K * B * world / total_wall
@@ -573,7 +577,7 @@ def worker(args) -> int:
         try:
             state["t"] = 0
             task.reset()
-            raw_walls, raw_evs = (walls, evs) if api_walls is None else measure(raw_step)
+            raw_walls, raw_evs = (walls, evs) if api_walls is None else measure(raw_loop)
             n_launch = len(raw_walls) * K
             kernel_us = sum(raw_evs) * 1e3 / n_launch  # HIP events on the launching stream, per launch
             achieved = ALGO_BYTES_PER_ENV_STEP * B / (kernel_us * 1e-6) / 1e9

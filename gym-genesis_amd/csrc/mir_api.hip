@@ -166,13 +166,14 @@ struct Outs {
   uint8_t* terminated = nullptr;
   uint8_t* term_host = nullptr;
   uint32_t *done_ticket = nullptr, *done_flag = nullptr;
-  uint32_t done_seq = 0;
+  uint32_t done_seq = 0, term_tag = 0;
   float *out_M = nullptr, *out_bias = nullptr, *out_qas = nullptr, *out_qacc = nullptr, *out_xpos = nullptr, *out_xquat = nullptr;
   float* rows = nullptr;
   int row_stride = 0, mode = 0, n_steps = 1;
   long act_step = 0, rows_step = 0;
   AutoResetArgs ar = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
   bool diag = true;
+  bool poses = false;  // 16-lane kernel: also write the link poses into h->poses (the rasteriser reads them)
   unsigned long long* prof = nullptr;  // 16-lane kernel only (debug)
 };
 
@@ -183,14 +184,14 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     memset(&a, 0, sizeof a);
     a.model = h->dm;
     a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
-    a.poses = h->poses; a.fkvalid = h->fkvalid;
-    a.diag = o.diag ? h->diag : nullptr;
+    a.poses = o.poses ? h->poses : nullptr;
+    a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
     a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu;
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
     a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
-    a.term_host = o.term_host; a.done_ticket = o.done_ticket; a.done_flag = o.done_flag; a.done_seq = o.done_seq;
+    a.term_host = o.term_host; a.term_tag = o.term_tag; a.done_ticket = o.done_ticket; a.done_flag = o.done_flag; a.done_seq = o.done_seq;
     rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
   } else {
     StepArgs64 a;
@@ -198,13 +199,13 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.model = h->dm64;
     a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
     a.poses = h->poses; a.fkvalid = h->fkvalid;
-    a.diag = o.diag ? h->diag : nullptr;
+    a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
     a.B = h->B; a.nu = h->hm64.nu;
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
     a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
-    a.term_host = o.term_host;
+    a.term_host = o.term_host; a.term_tag = o.term_tag;
     rc = mir_launch_step64(&a, (hipStream_t)stream);
   }
   if (rc != 0) return hip_fail((hipError_t)rc, "step kernel launch");
@@ -237,7 +238,7 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   HIPCHK(hipMalloc((void**)&h->done_ticket, 64));
   HIPCHK(hipMalloc((void**)&h->scratch_row, row_bytes));
   // pinned, device-mapped, coherent host memory for the API's host-visible outputs: terminated bytes + completion word
-  const size_t pin_bytes = ((B + 63) / 64) * 64 + 64;
+  const size_t pin_bytes = ((B + 63) / 64) * 64 + 64;  // (whole 32-bit words for the packed stores of the 16-lane kernel)
   HIPCHK(hipHostMalloc((void**)&h->pin_host, pin_bytes, hipHostMallocMapped | hipHostMallocCoherent));
   memset(h->pin_host, 0, pin_bytes);
   HIPCHK(hipHostGetDevicePointer((void**)&h->pin_dev, h->pin_host, 0));
@@ -257,9 +258,10 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   HIPCHK(hipMemset(h->done_ticket, 0, 64));
   HIPCHK(hipDeviceSynchronize());
   // how mir_step_end learns that a step has finished (MIR_SYNC_MODE overrides; see include/mirigid.h)
-  h->sync_mode = h->kernel == 16 ? 2 : 1;
+  h->diag_on = 1;
+  h->sync_mode = 3;
   if (const char* e = getenv("MIR_SYNC_MODE")) h->sync_mode = atoi(e);
-  if (h->sync_mode < 0 || h->sync_mode > 2 || (h->sync_mode == 2 && h->kernel != 16)) h->sync_mode = 1;
+  if (h->sync_mode < 0 || h->sync_mode > 3 || (h->sync_mode == 2 && h->kernel != 16)) h->sync_mode = 3;
   return MIR_OK;
 }
 
@@ -269,7 +271,7 @@ int mir_set_error(int code, const char* msg) { return set_err(code, "%s", msg); 
 
 int mir_refresh_poses(MirScene* h, void* stream) {
   Outs o;
-  o.mode = 2; o.diag = false;
+  o.mode = 2; o.diag = false; o.poses = true;
   return launch(h, o, stream);
 }
 
@@ -463,6 +465,7 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   o.action = action; o.agent_pos = agent_pos; o.env_state = env_state; o.reward = reward; o.terminated = terminated;
   o.term_host = h->pin_dev;
   const uint32_t seq = h->seq + 1u;
+  o.term_tag = 1u + seq % 3u;  // 1, 2, 3, 1, ...: never 0 (fresh memory), never the tag of the previous launch
   if (h->sync_mode == 2) { o.done_ticket = h->done_ticket; o.done_flag = flag_dev; o.done_seq = seq; }
   int rc = launch(h, o, stream);
   if (rc != MIR_OK) return rc;
@@ -476,14 +479,50 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   return MIR_OK;
 }
 
+/* The same launch with its output pointers registered ahead of time: mir_step_prepare costs nothing on the device and is called
+ * while the PREVIOUS step's kernel is still running, so that the call in front of which the GPU idles -- mir_step_go -- carries
+ * three arguments instead of seven. */
+int mir_step_prepare(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated) {
+  if (check(h)) return MIR_E_INVALID;
+  h->prep[0] = agent_pos; h->prep[1] = env_state; h->prep[2] = reward; h->prep[3] = terminated;
+  h->prepared = 1;
+  return MIR_OK;
+}
+
+int mir_step_go(MirHandle h, const float* action, void* stream) {
+  if (check(h)) return MIR_E_INVALID;
+  if (!h->prepared) return set_err(MIR_E_INVALID, "mir_step_go without mir_step_prepare");
+  h->prepared = 0;
+  return mir_step_begin(h, action, (float*)h->prep[0], (float*)h->prep[1], (float*)h->prep[2], (uint8_t*)h->prep[3], stream);
+}
+
 int mir_step_end(MirHandle h, uint8_t* terminated_host) {
   if (check(h)) return MIR_E_INVALID;
   if (!h->pending) return set_err(MIR_E_INVALID, "mir_step_end without mir_step_begin");
   h->pending = 0;
   volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->pin_host + ((size_t)(h->B + 63) / 64) * 64);
+  const uint8_t* bytes = h->pin_host;
+  const size_t B = (size_t)h->B;
   if (h->sync_mode == 0) {
     DeviceGuard guard(h->device);
     HIPCHK(hipStreamSynchronize((hipStream_t)h->pending_stream));
+  } else if (h->sync_mode == 3) {
+    // the bytes announce themselves: wait until every one of them carries this launch's tag
+    const uint8_t want = (uint8_t)(1u + h->seq % 3u);
+    size_t i = 0;
+    unsigned long polls = 0;
+    while (i < B) {
+      if ((uint8_t)(__atomic_load_n(bytes + i, __ATOMIC_RELAXED) >> 1) == want) { i++; continue; }
+      __builtin_ia32_pause();
+      if ((++polls & 0xfffffu) == 0) {
+        DeviceGuard guard(h->device);
+        hipError_t e = hipStreamQuery((hipStream_t)h->pending_stream);
+        if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "mir_step_end: stream");
+        if (e == hipSuccess && (uint8_t)(__atomic_load_n(bytes + i, __ATOMIC_RELAXED) >> 1) != want && polls > 0x4000000u)
+          return set_err(MIR_E_HIP, "mir_step_end: the launch finished without delivering its terminated bytes");
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
   } else {
     // spin on the pinned completion word; every 2^20 polls make sure the stream has not died under us
     unsigned long polls = 0;
@@ -498,7 +537,8 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
       }
     }
   }
-  if (terminated_host) memcpy(terminated_host, h->pin_host, (size_t)h->B);
+  if (terminated_host)
+    for (size_t i = 0; i < B; i++) terminated_host[i] = bytes[i] & 1u;
   return MIR_OK;
 }
 
@@ -581,6 +621,24 @@ extern "C" int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream
   return MIR_OK;
 }
 
+/* debug aid (not part of the drop-in surface): a copy with the step kernel's own access shape -- 64-thread workgroups, 4 bytes per
+ * lane, a wave touching 256 contiguous bytes -- over a byte count the caller knows: the calibration of rocprofv3's FETCH_SIZE /
+ * WRITE_SIZE for this access width (MI355X_MICROARCH.md, HBM: only 16 B/lane streams are calibrated there). */
+namespace {
+__global__ __launch_bounds__(64) void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * 64 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+}  // namespace
+extern "C" int mir_debug_copy_rows(const float* src, float* dst, int64_t n_floats, int device_id, void* stream) {
+  if (!src || !dst || n_floats <= 0) return set_err(MIR_E_INVALID, "mir_debug_copy_rows: bad argument");
+  DeviceGuard guard(device_id);
+  hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n_floats + 63) / 64)), dim3(64), 0, (hipStream_t)stream, src, dst, (long)n_floats);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "k_copy_rows");
+  return MIR_OK;
+}
+
 /* debug aid (not part of the drop-in surface): overwrite the LDS of every CU with signalling-NaN bit patterns.  LDS keeps
  * what the previous kernel left in it, so a step kernel that reads a slot before writing it usually finds plausible stale
  * values there; the GPU tests call this first, which turns such a read into a NaN in the results. */
@@ -640,8 +698,15 @@ int mir_get_links(MirHandle h, float* pos, float* quat, void* stream) {
   return launch(h, o, stream);
 }
 
+int mir_set_diag(MirHandle h, int32_t on) {
+  if (check(h)) return MIR_E_INVALID;
+  h->diag_on = on ? 1 : 0;
+  return MIR_OK;
+}
+
 int mir_get_diag(MirHandle h, int32_t* ncon, int32_t* nefc, int32_t* niter, void* stream) {
   if (check(h)) return MIR_E_INVALID;
+  if (!h->diag_on) return set_err(MIR_E_INVALID, "mir_get_diag: per-env diagnostics are switched off (mir_set_diag)");
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_get_diag, dim3(nblk(h->B)), dim3(TPB), 0, (hipStream_t)stream, h->diag, ncon, nefc, niter, h->B);
   HIPCHK(hipGetLastError());

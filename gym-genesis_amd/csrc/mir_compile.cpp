@@ -292,7 +292,7 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
   if (nv != sp->ndof) return fail(err, MIR_E_INVALID, "ndof does not match the joints");
   if (nq > K16_MAX_Q) return fail(err, MIR_E_CAPACITY, "nq > K16_MAX_Q");
   m.nv = nv; m.nq = nq; m.n_arm_q = narm;
-  m.qstride = (K16_MAX_Q + 3) & ~3;
+  m.qstride = (m.nq + 3) & ~3;  // (the Franka pick scene: 16 floats = one 64-byte row)
   for (int b = 0; b < nb; b++) {
     uint32_t sub = 1u << b;
     for (int c = b + 1; c < nb; c++) {

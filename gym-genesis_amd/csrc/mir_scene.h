@@ -29,8 +29,11 @@ struct MirScene {
   uint32_t* done_ticket;    // device counter for the kernel-side completion (sync mode 2)
   uint32_t seq;             // sequence number of the last mir_step_begin
   int sync_mode;            // 0 hipStreamSynchronize, 1 stream write-value + host spin, 2 kernel-side ticket + host spin
+  int diag_on;              // step kernels write the per-env diagnostics (mir_set_diag)
   int pending;              // a mir_step_begin is waiting for its mir_step_end
   void* pending_stream;
+  void* prep[4];            // output pointers registered by mir_step_prepare for the next mir_step_go
+  int prepared;
 };
 
 // library-internal helpers implemented in mir_api.hip

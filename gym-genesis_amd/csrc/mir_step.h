@@ -11,8 +11,7 @@ struct StepArgs {
   float* qvel;    // (B, 16)
   float* target;  // (B, 16) indexed by dof
   float* qacc_ws; // (B, 16)
-  float* poses;   // (B, 2, 16, 4): link positions then quaternions of the current qpos (FK cache)
-  int32_t* fkvalid; // (B): poses[env] match qpos[env]
+  float* poses;   // (B, 2, 16, 4) or null: link positions then quaternions written for the rasteriser (mode 2 only)
   const float* action;  // (B, nu) or null
   float* agent_pos;     // (B, 7+n_grip) or null
   float* env_state;     // (B, 11) or null
@@ -20,7 +19,8 @@ struct StepArgs {
   uint8_t* terminated;  // (B) or null
   // host-visible tail of GenesisEnv.step (mir_step_begin / mir_step_end): the same bytes as `terminated`, stored straight into
   // pinned host memory (system-scope stores), and the launch's completion published by its LAST workgroup
-  uint8_t* term_host;     // (B) device address of pinned host memory, or null
+  uint8_t* term_host;     // (B padded to 4) device address of pinned host memory, or null; byte = terminated | term_tag << 1
+  uint32_t term_tag;      // 0..127: stamped into every byte so that the host can tell this launch's bytes from older ones
   uint32_t* done_ticket;  // device counter, 0 between launches; or null (completion is then signalled by the stream)
   uint32_t* done_flag;    // device address of a pinned host word <- done_seq once every workgroup has stored its bytes
   uint32_t done_seq;

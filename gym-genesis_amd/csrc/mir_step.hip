@@ -21,7 +21,8 @@
 //   * single-wave workgroups: LDS accesses of a wave execute in order, so phases are separated
 //     by a compiler-level fence only (WSYNC), never an s_barrier.
 //   * HBM state is env-major (B, D): with 16 lanes per env a wave touches 4 contiguous 64-byte
-//     rows, the coalesced pattern for this lane mapping.  ~0.25 KB read + ~0.3 KB written per env-step.
+//     rows, the coalesced pattern for this lane mapping.  228 B read + 341 B written per env-step (489 B algorithmic:
+//     qpos, qvel, warm start, action in; qpos, qvel, warm start, targets, observations, reward, mask out).
 //   * the wave runs alone on its SIMD at the headline batch (the batch bounds the occupancy), so the kernel is a serial chain
 //     of LDS round trips: loops over contacts / tree masks issue the reads of two or four entries in one batch ahead of
 //     the arithmetic, vectors that a whole row needs once travel by row broadcast instead of through LDS, and every global
@@ -224,12 +225,9 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   const float q_lo = lane < a.qst ? a.qpos[(size_t)env * a.qst + lane] : 0.0f;
   const float q_hi = lane + G < a.qst ? a.qpos[(size_t)env * a.qst + lane + G] : 0.0f;
   const float qv_in = a.qvel[(size_t)env * G + lane], ws_in = a.qacc_ws[(size_t)env * G + lane];
-  float tg = a.target[(size_t)env * G + lane];
+  // (with an action every controlled dof takes its target from it and nothing else reads a target: the stored row is not fetched)
+  float tg = a.action ? 0.0f : a.target[(size_t)env * G + lane];
   const float au = (a.action && lane < a.nu) ? a.action[(size_t)env * a.nu + lane] : 0.0f;
-  // the cached link poses travel with their validity flag (poses is a (B, 2, 16, 4) array: the speculative read is in bounds)
-  const float* pose_p = a.poses + ((size_t)env * 2 * G + lane) * 4;
-  const f4 cpos = *reinterpret_cast<const f4*>(pose_p), cquat = *reinterpret_cast<const f4*>(pose_p + 4 * G);
-  const bool cached = a.fkvalid[env] != 0;
   __builtin_amdgcn_sched_barrier(0);  // (nothing below may move in front of the loads above)
   {
     f4* dst = reinterpret_cast<f4*>(&T);
@@ -250,19 +248,14 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   WSYNC();
 
   // ======================= forward kinematics =================================================
-  // Link poses of the current qpos are persisted in HBM by the previous launch (the end-of-step FK
-  // that produced its observations); reuse them unless reset / set_state invalidated this env.
+  // Link poses are a function of qpos and are recomputed at the start of every launch: four pointer-jumping rounds (~1 us)
+  // instead of 16 x 32 B per env written by one launch and read back by the next (round 1 cached them in HBM: 2.8x the
+  // algorithmic traffic).
   STAMP(0);
-  {
-    if (cached && lane < nb) {
-      stv(S.xpos[lane], cpos);
-      stv(S.xquat[lane], cquat);
-    }
-    WSYNC();
-    if (__any(!cached)) group_fk(S, lane, nb, parents, bk);  // recomputing a cached env is bit-identical
-  }
+  group_fk(S, lane, nb, parents, bk);
   STAMP(1);
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
+  if (VARIANT != 2) a.poses = nullptr;
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; }
   if (VARIANT == 1) { a.mode = 0; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; a.agent_pos = a.env_state = a.reward = nullptr; a.terminated = a.term_host = nullptr; a.done_ticket = nullptr; }
   // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
@@ -1052,13 +1045,13 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     }
   }  // steps
   STAMP(10);
+  bool term_now = false;
   if (valid) {
-    if (lane < nb) {
+    if (a.poses && lane < nb) {  // (pose refresh for the rasteriser, mode 2 only)
       float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
       *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
       *reinterpret_cast<f4*>(p + 4 * G) = ldv(S.xquat[lane]);
     }
-    if (lane == 0) a.fkvalid[env] = 1;
     // ---- store state ---------------------------------------------------------------------------------
     if (a.mode == 0) {
       for (int i = lane; i < qst; i += G) a.qpos[(size_t)env * qst + i] = S.qpos[i];
@@ -1073,9 +1066,8 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     if (lane == 0) {
       if (a.reward) a.reward[env] = rew;
       if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
-      // the same byte straight into pinned host memory (write-through, system scope): GenesisEnv.step's D->H copy
-      if (a.term_host) __hip_atomic_store(&a.term_host[env], (uint8_t)(rew == 1.0f ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    term_now = rew == 1.0f;
     if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
     if (a.rows && !(a.ar.episode_len && a.rows_step)) {  // (in rollout mode: the last step's row; with autoreset it was written in the loop)
       float* row = a.rows + (size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride;
@@ -1086,9 +1078,20 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));
     }
   }  // valid
+  if (VARIANT != 1 && a.term_host) {
+    // GenesisEnv.step's D->H copy of `terminated`, done by the kernel: the four masks of the wave as ONE 32-bit store straight
+    // into pinned host memory (write-through, system scope), each byte = term | tag << 1.  The tag changes from launch to
+    // launch, so the host recognises the bytes of THIS launch by themselves (sync mode 3: no fence, no ticket, nothing waits).
+    const unsigned long long tb = __ballot(term_now && lane == 0);
+    if (tid == 0) {
+      const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (VARIANT != 1 && a.done_ticket) {
-    // Completion published by the kernel itself (mir_step_begin, sync mode 2): every wave waits for its host stores to be
-    // acknowledged, then takes a ticket; the wave that takes the last one knows that every terminated byte of the launch is in
+    // Completion published by the kernel itself (mir_step_begin, sync mode 2): every wave waits for its host store to be
+    // acknowledged (~3 us over PCIe), then takes a ticket; the wave that takes the last one knows that every terminated byte of the launch is in
     // host memory and writes the sequence number the host is spinning on.  (The host-side stores above are system-scope
     // write-through atomics, so no cache write-back is needed to order them: s_waitcnt is the release.)
     __builtin_amdgcn_s_waitcnt(0);
@@ -1119,8 +1122,8 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   int blocks = (a.B + EPB - 1) / EPB;
   (void)max_contacts_lds;
   const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !a.prof && !a.out_M && !a.out_bias &&
-                      !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat;
-  const bool plain_loop = a.mode == 0 && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
+                      !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.poses;
+  const bool plain_loop = a.mode == 0 && !a.poses && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
                           !a.env_state && !a.reward && !a.terminated && !a.term_host && !a.done_ticket;
   if (single) hipLaunchKernelGGL(mir_step_kernel<0>, dim3(blocks), dim3(64), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL(mir_step_kernel<1>, dim3(blocks), dim3(64), 0, stream, a);

@@ -18,7 +18,8 @@ struct StepArgs64 {
   float* env_state;     // (B, env_dim) or null
   float* reward;        // (B) or null
   uint8_t* terminated;  // (B) or null
-  uint8_t* term_host;   // (B) device address of pinned host memory (mir_step_begin), or null
+  uint8_t* term_host;   // (B) device address of pinned host memory (mir_step_begin), or null; byte = terminated | term_tag << 1
+  uint32_t term_tag;
   int32_t* diag;        // (B, 4): ncon, nefc, niter, ncand; or null
   // per-stage parity outputs (mir_forward), all nullable; compact dof order
   float* out_M;     // (B, nv, nv)

@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   if (lane == 0) {
     if (a.reward) a.reward[env] = rew;
     if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
-    if (a.term_host) __hip_atomic_store(&a.term_host[env], (uint8_t)(rew == 1.0f ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.term_host) __hip_atomic_store(&a.term_host[env], (uint8_t)((rew == 1.0f ? 1u : 0u) | a.term_tag << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
   if (a.rows && !(a.ar.episode_len && a.rows_step) && lane < ad + ed + 2)  // (in rollout mode: the last step's row; with autoreset: written in the loop)

@@ -51,6 +51,10 @@ def load_library() -> C.CDLL:
     lib.mir_step_begin.restype = C.c_int
     lib.mir_step_end.argtypes = [vp, vp]
     lib.mir_step_end.restype = C.c_int
+    lib.mir_step_prepare.argtypes = [vp, vp, vp, vp, vp]
+    lib.mir_step_prepare.restype = C.c_int
+    lib.mir_step_go.argtypes = [vp, vp, vp]
+    lib.mir_step_go.restype = C.c_int
     lib.mir_get_sync_mode.argtypes = [vp]
     lib.mir_get_sync_mode.restype = C.c_int
     lib.mir_debug_null_roundtrip.argtypes = [vp, i32, vp, C.POINTER(C.c_double)]
@@ -66,6 +70,8 @@ def load_library() -> C.CDLL:
     lib.mir_set_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.mir_get_links.argtypes = [vp, vp, vp, vp]
     lib.mir_get_diag.argtypes = [vp, vp, vp, vp, vp]
+    lib.mir_set_diag.argtypes = [vp, i32]
+    lib.mir_set_diag.restype = C.c_int
     lib.mir_forward.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.mir_render.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), i32, vp, vp, vp]
     lib.mir_render.restype = C.c_int
@@ -128,26 +134,35 @@ class StepHelpers:
         returns (agent_pos, environment_state, reward, terminated u8).  With host_terminated the launch also delivers the
         terminated bytes to the host (step_begin); the caller must then close the step with step_end().
         The GPU idles while Python prepares a launch, so nothing that can wait is done before it: the output tensors of the
-        NEXT call and the host array of THIS call are allocated while the kernel runs."""
-        key = (agent_dim, env_dim)
+        NEXT call (and, on the host path, their registration with the library) and the host array of THIS call are made
+        while the kernel runs."""
+        key = (agent_dim, env_dim, host_terminated)
         fresh = self.__dict__.get("_fresh")
         if fresh is None:
             fresh = self._fresh = {}
         slot = fresh.pop(key, None)
         if slot is None:
             slot = self._alloc_outputs(agent_dim, env_dim)
+            if host_terminated:
+                self.step_prepare_ptrs(slot[1])
         outs, ptrs = slot
         if host_terminated:
-            self.step_begin_ptrs(action.data_ptr(), ptrs)
+            self.step_go_ptr(action.data_ptr())
             host = np.empty(self.num_envs, dtype=np.bool_)
             self._host_pending = (host, host.ctypes.data)
         else:
             self.step_fused_ptrs(action.data_ptr(), ptrs)
-        fresh[key] = self._alloc_outputs(agent_dim, env_dim)  # (while the kernel runs)
+        nxt = self._alloc_outputs(agent_dim, env_dim)  # (while the kernel runs)
+        if host_terminated:
+            self.step_prepare_ptrs(nxt[1])
+        fresh[key] = nxt
         return outs
 
-    # pointer-level launches; the CPU test double (tests/fake_scene.py) overrides these two
-    def step_begin_ptrs(self, action_ptr, ptrs):
+    # pointer-level launches; the CPU test double (tests/fake_scene.py) overrides these
+    def step_prepare_ptrs(self, ptrs):
+        raise NotImplementedError
+
+    def step_go_ptr(self, action_ptr):
         raise NotImplementedError
 
     def step_fused_ptrs(self, action_ptr, ptrs):
@@ -174,6 +189,7 @@ class MirScene(StepHelpers):
         self.num_envs, self.nbody, self.nq, self.nv = d.num_envs, d.nbody, d.nq, d.nv
         self.ngeom, self.npair, self.agent_dim, self.env_dim = d.ngeom, d.npair, d.agent_dim, d.env_dim
         self.nfree, self.kernel = d.nfree, d.kernel
+        self._go, self._devidx = self.lib.mir_step_go, self.device.index  # (looked up once: they sit in front of every API launch)
         self.nu = sum(1 for i in range(spec.ndof) if spec.dof[i].ctrl_mode == 1)
         self.n_arm = sum(1 for b in range(1, spec.nbody) if spec.body[b].jtype in (1, 2))
 
@@ -262,8 +278,13 @@ class MirScene(StepHelpers):
                                             _ptr(terminated), self._stream()))
         self._host_pending = None
 
-    def step_begin_ptrs(self, action_ptr, ptrs) -> None:
-        rc = self.lib.mir_step_begin(self.h, action_ptr, ptrs[0], ptrs[1], ptrs[2], ptrs[3], self._stream())
+    def step_prepare_ptrs(self, ptrs) -> None:
+        rc = self.lib.mir_step_prepare(self.h, ptrs[0], ptrs[1], ptrs[2], ptrs[3])
+        if rc:
+            self._check(rc)
+
+    def step_go_ptr(self, action_ptr) -> None:
+        rc = self._go(self.h, action_ptr, _raw_stream(self._devidx) if _raw_stream is not None else self._stream())
         if rc:
             self._check(rc)
 
@@ -341,6 +362,10 @@ class MirScene(StepHelpers):
         pos, quat = self.empty(self.nbody, 3), self.empty(self.nbody, 4)
         self._check(self.lib.mir_get_links(self.h, _ptr(pos), _ptr(quat), self._stream()))
         return pos, quat
+
+    def set_diag(self, on: bool) -> None:
+        """Switch the per-env solver diagnostics (ncon / nefc / niter, 16 B per env-step) on or off (mir_set_diag)."""
+        self._check(self.lib.mir_set_diag(self.h, 1 if on else 0))
 
     def get_diag(self):
         a, b, c = (self.empty(dtype=torch.int32) for _ in range(3))

@@ -56,6 +56,10 @@ class GenesisEnv(Env):
         self.observation_space = self._env.observation_space
         self.action_space = self._env.action_space
         self.scene = None
+        # the two halves of the fast step path, looked up once (they sit in front of every launch, where the GPU idles)
+        fast = hasattr(self._env, "step_begin") and not self.enable_pixels and not getattr(self._env, "unbatched", False)
+        self._begin = self._env.step_begin if fast else None
+        self._end = self._env.step_end if fast else None
 
     # ---- gymnasium API ------------------------------------------------------------------------
     def reset(self, seed=None, options=None):
@@ -66,8 +70,8 @@ class GenesisEnv(Env):
         return observation, {"is_success": [False] * self.num_envs}
 
     def step(self, action):
-        begin = getattr(self._env, "step_begin", None)
-        if begin is not None and not self.enable_pixels and not getattr(self._env, "unbatched", False):
+        begin = self._begin
+        if begin is not None:
             # Fast path: the launch stores `terminated` into pinned host memory itself.  Everything the API returns besides
             # that mask is built while the kernel runs; step_end() then waits for the launch and hands over a fresh NumPy
             # bool array -- the reference's `is_success.detach().cpu().numpy().astype(bool)` (env.py:64).
@@ -75,7 +79,7 @@ class GenesisEnv(Env):
             is_success = self._env.terminated_device.view(torch.bool)
             truncated = np.zeros(self.num_envs, dtype=bool)
             info = {"is_success": is_success}
-            terminated = self._env.step_end()
+            terminated = self._end()
             return observation, reward, terminated, truncated, info
         _, reward, _, observation = self._env.step(action)
         term_dev = getattr(self._env, "terminated_device", None)

@@ -60,6 +60,7 @@ class FrankaCubePickBatch:
         builder = models.franka_cube_pick_scene()
         self._builder = builder
         self._mir = MirScene(builder.build(), self.num_envs)
+        self._mir.set_diag(False)  # solver diagnostics (16 B per env-step) are a debugging aid: _mir.set_diag(True) to read them
         B, dev = self.num_envs, self._mir.device
         self.device = dev
         self.scene = SceneView(self._mir, env_spacing=self.env_spacing, global_num_envs=self.global_num_envs,

@@ -49,6 +49,7 @@ class StackTaskBase:
         builder = self._scene_builder()
         self._builder = builder
         self._mir = MirScene(builder.build(), self.num_envs)
+        self._mir.set_diag(False)  # solver diagnostics (16 B per env-step) are a debugging aid: _mir.set_diag(True) to read them
         self.device = self._mir.device
         self.island_top_z = models.ISLAND_TOP_Z
         self.scene = SceneView(self._mir, env_spacing=env_spacing, global_num_envs=self.global_num_envs, offset=self.shard_lo)

@@ -226,13 +226,21 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  * nullable).  Between the two calls the host is free (the Python side prepares its return values there).  Exactly one
  * mir_step_end per mir_step_begin; the only entry point of the library that waits for the device.
  * How the wait is done (mir_get_sync_mode; environment variable MIR_SYNC_MODE overrides at mir_create):
- *   2  the kernel's last workgroup writes a sequence word into pinned host memory, the host spins on it (16-lane kernel)
- *   1  hipStreamWriteValue32 behind the launch writes that word, the host spins on it (wave-per-env kernel; fallback)
+ *   3  (default) every terminated byte carries a tag that changes from launch to launch; the host spins until all B bytes
+ *      show the tag of this launch -- no fence, no flag, nothing in the kernel waits for the PCIe acknowledgement
+ *   2  every wave waits for its host store, the kernel's last workgroup then writes a sequence word into pinned host memory
+ *      and the host spins on it (16-lane kernel only)
+ *   1  hipStreamWriteValue32 behind the launch writes that word, the host spins on it
  *   0  hipStreamSynchronize */
 int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward,
                    uint8_t* terminated, void* stream);
 int mir_step_end(MirHandle h, uint8_t* terminated_host);
 int mir_get_sync_mode(MirHandle h);
+/* mir_step_begin with the four output pointers registered ahead of time (mir_step_prepare touches no device state and is meant to
+ * be called while the previous step's kernel is still running): the GPU idles in front of mir_step_go, which then takes three
+ * arguments instead of seven.  One mir_step_prepare per mir_step_go. */
+int mir_step_prepare(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated);
+int mir_step_go(MirHandle h, const float* action, void* stream);
 
 /* Same step, but every output of an env lands in ONE packed float32 row
  * rows[e*row_stride + ...] = [agent_pos (agent_dim) | env_state (env_dim) | reward | terminated(0/1)]
@@ -267,7 +275,10 @@ int mir_set_state(MirHandle h, const float* qpos, const float* qvel, const float
 /* link.get_pos / get_quat for all bodies: pos (B,nbody,3) quat (B,nbody,4) */
 int mir_get_links(MirHandle h, float* pos, float* quat, void* stream);
 
-/* per-env diagnostics of the last step: ncon (B) i32, nefc (B) i32, niter (B) i32; nullable */
+/* per-env diagnostics of the last step: ncon (B) i32, nefc (B) i32, niter (B) i32; nullable.  The step kernels write them
+ * (16 B per env-step) while they are switched on: mir_set_diag(h, 0) drops that traffic (the task classes do), after which
+ * mir_get_diag is an error until they are switched on again.  On by default. */
+int mir_set_diag(MirHandle h, int32_t on);
 int mir_get_diag(MirHandle h, int32_t* ncon, int32_t* nefc, int32_t* niter, void* stream);
 
 /* stage outputs of one forward-dynamics evaluation at the current state (no
@@ -349,10 +360,13 @@ int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_p
  * mir_debug_poison_lds: overwrite the LDS of every CU with signalling-NaN patterns, so that a kernel reading an LDS slot
  * before writing it yields NaNs instead of plausible stale values (the GPU tests call it before every scene).
  * mir_debug_null_roundtrip: microseconds per (launch of an empty kernel + host-visible completion word), averaged over iters:
- * the floor under one synchronous env.step() on this machine, with none of the physics in it. */
+ * the floor under one synchronous env.step() on this machine, with none of the physics in it.
+ * mir_debug_copy_rows: dst[i] = src[i] for n_floats floats with the step kernel's access shape (64-thread workgroups, 4 B per
+ * lane): a known byte count against which rocprofv3's FETCH_SIZE / WRITE_SIZE are calibrated for this access width. */
 int mir_debug_profile_step(MirHandle h, unsigned long long* prof, void* stream);
 int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* out_us);
 int mir_debug_poison_lds(int device_id, void* stream);
+int mir_debug_copy_rows(const float* src, float* dst, int64_t n_floats, int device_id, void* stream);
 
 #ifdef __cplusplus
 }

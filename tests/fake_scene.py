@@ -25,6 +25,9 @@ class OracleScene(StepHelpers):
         self.nfree, self.kernel = self.o.nfree, 0
         self.n_arm = sum(1 for b in range(1, spec.nbody) if spec.body[b].jtype in (1, 2))
 
+    def set_diag(self, on):
+        pass
+
     def empty(self, *shape, dtype=torch.float32):
         return torch.empty((self.num_envs, *shape), dtype=dtype)
 
@@ -65,8 +68,12 @@ class OracleScene(StepHelpers):
         self._last_action = a
         return a
 
-    def step_begin_ptrs(self, action_ptr, ptrs):
+    def step_prepare_ptrs(self, ptrs):
+        self._prepared = ptrs
+
+    def step_go_ptr(self, action_ptr):
         assert action_ptr == self._last_action.data_ptr()
+        ptrs, self._prepared = self._prepared, None
         self.step_begin(self._last_action, *self._by_ptr.pop(ptrs))
 
     def step_fused_ptrs(self, action_ptr, ptrs):

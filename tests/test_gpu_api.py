@@ -19,7 +19,7 @@ def _reset(sc, B, seed=0):
     sc.reset(pos, quat, np.tile(HOME, (B, 1)))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("B", [1, 5, 4096])
 def test_step_begin_end_equals_step_fused(franka_spec, monkeypatch, mode, B):
     from gym_genesis.backend.lib import MirScene
@@ -28,7 +28,7 @@ def test_step_begin_end_equals_step_fused(franka_spec, monkeypatch, mode, B):
     sc = MirScene(franka_spec, B)
     monkeypatch.delenv("MIR_SYNC_MODE")
     ref = MirScene(franka_spec, B)
-    assert sc.sync_mode == mode and ref.sync_mode == 2
+    assert sc.sync_mode == mode and ref.sync_mode == 3
     _reset(sc, B)
     _reset(ref, B)
     acts = torch.as_tensor(np.random.default_rng(3).uniform(-1, 1, (25, B, 9)).astype(np.float32), device=sc.device)

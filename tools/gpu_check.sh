@@ -13,7 +13,7 @@ timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_d
 echo "bench rc=$?"
 tail -c 6000 gpurun_out/bench_driver.out
 tail -5 gpurun_out/bench_driver.err
-for m in 0 1 2; do
+for m in 0 1 2 3; do
   MIR_SYNC_MODE=$m timeout 300 python3 bench.py --gpus 1 --steps 2000 --warmup 50 --core-only > gpurun_out/bench_sync$m.out 2> gpurun_out/bench_sync$m.err
   echo "sync mode $m rc=$?"
   python3 - <<PY

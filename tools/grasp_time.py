@@ -8,6 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
 obs, _ = env.reset(seed=0)
 task = env._env; dev = task.device
+task._mir.set_diag(True)
 robot, cube = env.get_robot(), obs["environment_state"][:, :3].clone()
 eef = robot.get_link("hand")
 quat = torch.tensor([0.0, 1.0, 0.0, 0.0], device=dev).repeat(B, 1)

@@ -9,6 +9,7 @@ for robot in ("franka", "so101"):
     env = GenesisEnv(task="cube_pick", robot=robot, num_envs=B, enable_pixels=False)
     env.reset(seed=0)
     task = env._env
+    task._mir.set_diag(True)
     dev = task.device
     home = (task._home if hasattr(task, "_home") else task._zero)[0]
     gen = torch.Generator(device=dev).manual_seed(1)

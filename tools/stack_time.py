@@ -9,6 +9,7 @@ for robot in ("franka", "so101"):
     env = GenesisEnv(task="cube_stack", robot=robot, num_envs=B)
     env.reset(seed=0)
     task = env._env
+    task._mir.set_diag(True)
     dev = task.device
     home = task._home[0]
     gen = torch.Generator(device=dev).manual_seed(1)
