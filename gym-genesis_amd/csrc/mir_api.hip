@@ -186,7 +186,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
     a.poses = o.poses ? h->poses : nullptr;
     a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
-    a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu;
+    a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.convex = h->hm.has_convex;
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
@@ -618,6 +618,16 @@ extern "C" int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream
   clock_gettime(CLOCK_MONOTONIC, &t1);
   HIPCHK(hipGetLastError());
   *out_us = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) * 1e-3 / iters;
+  return MIR_OK;
+}
+
+/* debug aid (not part of the drop-in surface): the kernel's lane-private convex narrowphase (GJK on the cores, MPR when they
+ * overlap) on n pairs given directly; device arrays in (n,22) / out (n,8), layout in mir_step.hip: k_debug_convex */
+extern "C" int mir_debug_convex_pairs(const float* in, float* out, int32_t n, int device_id, void* stream) {
+  if (!in || !out || n <= 0) return set_err(MIR_E_INVALID, "mir_debug_convex_pairs: bad argument");
+  DeviceGuard guard(device_id);
+  int rc = mir_launch_debug_convex(in, out, n, (hipStream_t)stream);
+  if (rc != 0) return hip_fail((hipError_t)rc, "k_debug_convex");
   return MIR_OK;
 }
 

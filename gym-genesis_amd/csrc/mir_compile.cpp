@@ -341,7 +341,11 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
   for (int g = 0; g < sp->ngeom; g++) {
     const MirGeomSpec& s = sp->geom[g];
     if (s.body < 0 || s.body >= nb) return fail(err, MIR_E_INVALID, "geom body out of range");
-    if (s.type != MIR_GEOM_PLANE && s.type != MIR_GEOM_BOX) return fail(err, MIR_E_INVALID, "unsupported geom type");
+    if (s.type != MIR_GEOM_PLANE && s.type != MIR_GEOM_BOX && s.type != MIR_GEOM_SPHERE && s.type != MIR_GEOM_CAPSULE)
+      return fail(err, MIR_E_INVALID, "unsupported geom type");
+    if ((s.type == MIR_GEOM_SPHERE || s.type == MIR_GEOM_CAPSULE) && !(s.size[0] > 0)) return fail(err, MIR_E_INVALID, "sphere / capsule radius must be > 0");
+    if (s.type == MIR_GEOM_CAPSULE && !(s.size[1] >= 0)) return fail(err, MIR_E_INVALID, "capsule half length must be >= 0");
+    if (s.type == MIR_GEOM_SPHERE || s.type == MIR_GEOM_CAPSULE) m.has_convex = 1;
     m.g_body[g] = s.body; m.g_type[g] = s.type;
     for (int k = 0; k < 3; k++) { m.g_size[g][k] = (float)s.size[k]; m.g_pos[g][k] = (float)s.pos[k]; }
     for (int k = 0; k < 4; k++) m.g_quat[g][k] = (float)s.quat[k];
@@ -389,6 +393,10 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
   for (int g = 0; g < m.ngeom; g++) {
     for (int k = 0; k < 3; k++) { t.g_pos[g][k] = m.g_pos[g][k]; t.g_size[g][k] = m.g_size[g][k]; }
     t.g_pos[g][3] = m.g_friction[g];
+    {  // bounding radius about the geom centre
+      const float* z = m.g_size[g];
+      t.g_size[g][3] = m.g_type[g] == MIR_GEOM_SPHERE ? z[0] : (m.g_type[g] == MIR_GEOM_CAPSULE ? z[0] + z[1] : sqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]));
+    }
     for (int k = 0; k < 4; k++) t.g_quat[g][k] = m.g_quat[g][k];
     t.g_info[g][0] = m.g_body[g]; t.g_info[g][1] = m.g_type[g];
     t.g_sol[g][0] = m.g_solref[g][0]; t.g_sol[g][1] = m.g_solref[g][1];

@@ -31,7 +31,7 @@ static_assert(K16_MAX_PAIR <= 4 * MIR_G, "four pairs per lane");
 struct ModelTab {
   float g_pos[K16_MAX_GEOM][4];   // xyz in body frame, w = friction
   float g_quat[K16_MAX_GEOM][4];  // wxyz in body frame
-  float g_size[K16_MAX_GEOM][4];  // half extents, w unused
+  float g_size[K16_MAX_GEOM][4];  // box: half extents; sphere: radius, -, -; capsule: radius, half length, -; w = bounding radius
   int32_t g_info[K16_MAX_GEOM][4];  // body, type, 0, 0
   float g_sol[K16_MAX_GEOM][8];   // solref[2], solimp[5], 0
   int32_t pair[K16_MAX_PAIR];     // g1 | g2 << 8
@@ -98,6 +98,7 @@ struct DevModel {
   int32_t p_g1[K16_MAX_PAIR], p_g2[K16_MAX_PAIR];
   // ---- free bodies in body order (reset / re-spawn poses) ----
   int32_t nfree, free_qadr[MIR_MAX_FREE];
+  int32_t has_convex;  // any sphere / capsule geom
 };
 
 struct HostConsts {

@@ -42,8 +42,10 @@ struct StepArgs {
   int qst, nu;  // qpos row stride and action width (copies of the model's, so the state loads do not wait for the model)
   int mode;     // 0: full steps; 1: forward dynamics only (mir_forward); 2: kinematics + outputs only
   int n_steps;  // mode 0 only
+  int convex;   // the scene has sphere / capsule geoms: launch the instantiation with the GJK / MPR narrowphase
 };
 
 
 // enqueue the fused kernel on `stream`; returns a hipError_t as int
 extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipStream_t stream);
+extern "C" int mir_launch_debug_convex(const float* in, float* out, int n, hipStream_t stream);

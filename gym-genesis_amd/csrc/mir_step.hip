@@ -39,6 +39,7 @@
 
 #define G MIR_G
 #include "mir_dev.h"
+#include "mir_convex.h"
 #define EPB 4       /* envs per block */
 #define MAXCON K16_MAX_CONTACT
 #define JST 52      /* floats per contact in Jb: 3 rows x 16 + 4 pad -> conflict-free ds_read_b128 across contact lanes */
@@ -152,7 +153,10 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 // front of it (every launch-invariant value is otherwise saved before the loop and restored inside it).
 // VARIANT 0 = SINGLE (above); 1 = the step loop for rollouts (no per-stage / debug outputs and no separate observation
 // buffers: only packed rows), which keeps 11 pointers out of the scalar registers; 2 = everything.
-template <int VARIANT>
+// CONVEX = the scene has sphere / capsule geoms: the closed-form plane cases and the lane-private GJK / MPR narrowphase
+// (mir_convex.h) are compiled in.  Scenes of planes and boxes only (the registered tasks) run the instantiations without
+// them, whose register allocation and schedule are therefore untouched by that code.
+template <int VARIANT, bool CONVEX>
 __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   constexpr bool SINGLE = VARIANT == 0;
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
@@ -508,16 +512,20 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
           V3 h2 = ld3v(T.g_size[g2]);
           M3 R2 = q2m(ld4v(S.col.gquat[g2]));
           V3 c2 = ld3v(S.col.gpos[g2]);
-          if (T.g_info[g1][1] == MIR_GEOM_PLANE) {
+          const int t1 = T.g_info[g1][1], t2 = T.g_info[g2][1];
+          if (t1 == MIR_GEOM_PLANE) {
             V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
             float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
+            if (CONVEX && t2 == MIR_GEOM_SPHERE) ext = h2.x;
+            if (CONVEX && t2 == MIR_GEOM_CAPSULE) ext = h2.y * fabsf(dot(n, mcol(R2, 2))) + h2.x;
             hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
           } else {
             V3 h1 = ld3v(T.g_size[g1]);
-            float rs = sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
+            // bounding spheres (box: half diagonal; sphere: radius; capsule: half length + radius -- T.g_size[.][3])
+            float rs = CONVEX ? T.g_size[g1][3] + T.g_size[g2][3] : sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
             V3 dc = c2 - ld3v(S.col.gpos[g1]);
             hit = dot(dc, dc) <= rs * rs;
-            if (hit) {
+            if (hit && (!CONVEX || (t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX))) {
               // the six face axes of the narrowphase's separating-axis test (same expressions): a pair they separate would
               // come back with zero contacts, and the narrowphase takes the candidates of an env one after the other
               const M3 R1 = q2m(ld4v(S.col.gquat[g1]));
@@ -550,7 +558,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         if (!__any(act)) break;
         const int pr = act ? T.pair[S.col.cand[k]] : 0;
         const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isplane = act && T.g_info[g1][1] == MIR_GEOM_PLANE;
+        const bool isplane = act && T.g_info[g1][1] == MIR_GEOM_PLANE && (!CONVEX || T.g_info[g2][1] == MIR_GEOM_BOX);
         if (!__any(isplane)) continue;
         const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
         const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         if (!__any(act)) break;
         const int pr = act ? T.pair[S.col.cand[k]] : 0;
         const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isbox = act && T.g_info[g1][1] != MIR_GEOM_PLANE;
+        const bool isbox = act && T.g_info[g1][1] != MIR_GEOM_PLANE && (!CONVEX || (T.g_info[g1][1] == MIR_GEOM_BOX && T.g_info[g2][1] == MIR_GEOM_BOX));
         if (!__any(isbox)) continue;
         if (isbox) {  // whole rows
           const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
@@ -601,6 +609,47 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
           const BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
           const int cnt = box_box_row(B1, B2, lane, tid, grp * G, S.col.stage[k], S.col.snorm[k], reinterpret_cast<float*>(&S.con));  // (contact arrays: not written yet)
           if (lane == k) mycount = cnt;
+        }
+      }
+      if constexpr (CONVEX) {
+        // narrowphase of the round shapes, LANE-PRIVATE: lane c takes candidate c.  Plane - sphere / capsule in closed form
+        // (one / two points at half depth), every other pair that is not box - box through GJK on the cores, MPR when the
+        // cores overlap (mir_convex.h).  Lanes diverge here and reconverge at the end of the block.
+        if (lane < ncand) {
+          const int pr = T.pair[S.col.cand[lane]];
+          const int g1 = pr & 255, g2 = pr >> 8;
+          const int t1 = T.g_info[g1][1], t2 = T.g_info[g2][1];
+          if (t1 == MIR_GEOM_PLANE && (t2 == MIR_GEOM_SPHERE || t2 == MIR_GEOM_CAPSULE)) {
+            const V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2), pp = ld3v(S.col.gpos[g1]), pc = ld3v(S.col.gpos[g2]);
+            const V3 sz = ld3v(T.g_size[g2]);
+            const float r = sz.x;
+            int cnt = 0;
+            if (t2 == MIR_GEOM_SPHERE) {
+              const float dist = dot(pc - pp, n) - r;
+              if (dist < 0.0f) { const V3 c = pc - (r + 0.5f * dist) * n; stv(S.col.stage[lane][0], f4{c.x, c.y, c.z, dist}); cnt = 1; }
+            } else {  // the two end spheres, axis - then axis +
+              const V3 ax = mcol(q2m(ld4v(S.col.gquat[g2])), 2);
+#pragma unroll
+              for (int sgn = -1; sgn <= 1; sgn += 2) {
+                const V3 e = pc + ((float)sgn * sz.y) * ax;
+                const float dist = dot(e - pp, n) - r;
+                if (dist < 0.0f) { const V3 c = e - (r + 0.5f * dist) * n; stv(S.col.stage[lane][cnt], f4{c.x, c.y, c.z, dist}); cnt++; }
+              }
+            }
+            if (cnt) st3v(S.col.snorm[lane], n);
+            mycount = cnt;
+          } else if (t1 != MIR_GEOM_PLANE && !(t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX)) {
+            const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
+            const ShapeD A = {t1, ld3v(T.g_size[g1]), ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2)};
+            const ShapeD B = {t2, ld3v(T.g_size[g2]), ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2)};
+            f4 pt;
+            V3 n;
+            if (convex_pair(A, B, pt, n)) {
+              stv(S.col.stage[lane][0], pt);
+              st3v(S.col.snorm[lane], n);
+              mycount = 1;
+            }
+          }
         }
       }
     }
@@ -1116,7 +1165,47 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
 
 }  // namespace
 
-// launcher used by the C ABI (mir_api.hip)
+#ifdef MIR_STEP_CONVEX_TU
+// debug aid: the lane-private convex narrowphase on n pairs given directly, one thread per pair.
+//   in  (n, 22): type1, size1[3], pos1[3], quat1[4] (wxyz), type2, size2[3], pos2[3], quat2[4]
+//   out (n, 8):  hit (0/1), pos[3], dist, normal[3]
+namespace {
+__global__ void k_debug_convex(const float* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = in + (size_t)i * 22;
+  const M3 R1 = q2m(qnormalize(Q4{r[7], r[8], r[9], r[10]})), R2 = q2m(qnormalize(Q4{r[18], r[19], r[20], r[21]}));
+  const ShapeD A = {(int)r[0], v3(r[1], r[2], r[3]), v3(r[4], r[5], r[6]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2)};
+  const ShapeD B = {(int)r[11], v3(r[12], r[13], r[14]), v3(r[15], r[16], r[17]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2)};
+  f4 pt = {0, 0, 0, 0};
+  V3 nrm = v3(0, 0, 0);
+  const bool hit = convex_pair(A, B, pt, nrm);
+  float* o = out + (size_t)i * 8;
+  o[0] = hit ? 1.0f : 0.0f; o[1] = pt.x; o[2] = pt.y; o[3] = pt.z; o[4] = pt.w; o[5] = nrm.x; o[6] = nrm.y; o[7] = nrm.z;
+}
+}  // namespace
+extern "C" int mir_launch_debug_convex(const float* in, float* out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(k_debug_convex, dim3((n + 63) / 64), dim3(64), 0, stream, in, out, n);
+  return (int)hipGetLastError();
+}
+
+#endif
+
+// launcher used by the C ABI (mir_api.hip).  The instantiations with the convex narrowphase live in their own translation unit
+// (mir_step_convex.hip = this file compiled with MIR_STEP_CONVEX_TU and WITHOUT -fno-signed-zeros: together with
+// -ffp-contract=on that flag miscompiles the support-mapping selects of mir_convex.h -- box pairs lose contacts -- while the
+// planes-and-boxes kernels gain 1 % from it).
+#ifdef MIR_STEP_CONVEX_TU
+extern "C" int mir_launch_step_convex(const StepArgs* args, int single, int plain_loop, hipStream_t stream) {
+  StepArgs a = *args;
+  const int blocks = (a.B + EPB - 1) / EPB;
+  if (single) hipLaunchKernelGGL((mir_step_kernel<0, true>), dim3(blocks), dim3(64), 0, stream, a);
+  else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, true>), dim3(blocks), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((mir_step_kernel<2, true>), dim3(blocks), dim3(64), 0, stream, a);
+  return (int)hipGetLastError();
+}
+#else
+extern "C" int mir_launch_step_convex(const StepArgs* args, int single, int plain_loop, hipStream_t stream);
 extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipStream_t stream) {
   StepArgs a = *args;
   int blocks = (a.B + EPB - 1) / EPB;
@@ -1125,8 +1214,10 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.poses;
   const bool plain_loop = a.mode == 0 && !a.poses && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
                           !a.env_state && !a.reward && !a.terminated && !a.term_host && !a.done_ticket;
-  if (single) hipLaunchKernelGGL(mir_step_kernel<0>, dim3(blocks), dim3(64), 0, stream, a);
-  else if (plain_loop) hipLaunchKernelGGL(mir_step_kernel<1>, dim3(blocks), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL(mir_step_kernel<2>, dim3(blocks), dim3(64), 0, stream, a);
+  if (a.convex) return mir_launch_step_convex(&a, single, plain_loop, stream);
+  if (single) hipLaunchKernelGGL((mir_step_kernel<0, false>), dim3(blocks), dim3(64), 0, stream, a);
+  else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, false>), dim3(blocks), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((mir_step_kernel<2, false>), dim3(blocks), dim3(64), 0, stream, a);
   return (int)hipGetLastError();
 }
+#endif

@@ -25,7 +25,7 @@ REWARD_LIFT, REWARD_STACK = 0, 1
 AGENT_EEF, AGENT_QPOS = 0, 1
 
 JNT_FIXED, JNT_REVOLUTE, JNT_PRISMATIC, JNT_FREE = 0, 1, 2, 3
-GEOM_PLANE, GEOM_BOX = 0, 1
+GEOM_PLANE, GEOM_BOX, GEOM_SPHERE, GEOM_CAPSULE = 0, 1, 2, 3  # sphere: size = (radius,); capsule: (radius, half length), axis z
 CTRL_NONE, CTRL_POSITION = 0, 1
 
 DEFAULT_SOLREF = (0.02, 1.0)
@@ -197,6 +197,21 @@ def box_inertia(mass: float, half: Sequence[float]) -> tuple:
     """Solid-box inertia about its centre, (xx, yy, zz, xy, xz, yz)."""
     x, y, z = (2 * h for h in half)
     return (mass * (y * y + z * z) / 12, mass * (x * x + z * z) / 12, mass * (x * x + y * y) / 12, 0.0, 0.0, 0.0)
+
+
+def sphere_inertia(mass: float, radius: float) -> tuple:
+    i = 0.4 * mass * radius * radius
+    return (i, i, i, 0.0, 0.0, 0.0)
+
+
+def capsule_inertia(mass: float, radius: float, half: float) -> tuple:
+    """Solid capsule (cylinder of length 2 half + two hemispherical caps) of total mass `mass`, axis z, about its centre."""
+    r, h = radius, 2.0 * half
+    vc, vs = math.pi * r * r * h, 4.0 / 3.0 * math.pi * r ** 3
+    mc, ms = mass * vc / (vc + vs), mass * vs / (vc + vs)
+    izz = 0.5 * mc * r * r + 0.4 * ms * r * r
+    ixx = mc * (h * h / 12 + r * r / 4) + ms * (0.4 * r * r + h * h / 4 + 3.0 / 8.0 * h * r)
+    return (ixx, ixx, izz, 0.0, 0.0, 0.0)
 
 
 class SceneBuilder:

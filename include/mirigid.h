@@ -72,6 +72,13 @@ extern "C" {
 /* geom types */
 #define MIR_GEOM_PLANE 0 /* z = 0 plane of its body frame, normal +z */
 #define MIR_GEOM_BOX 1   /* size = half extents */
+#define MIR_GEOM_SPHERE 2  /* size[0] = radius */
+#define MIR_GEOM_CAPSULE 3 /* size[0] = radius, size[1] = half length of the axis segment, axis = z of the geom frame */
+/* Narrowphase by pair type: plane-box / plane-sphere / plane-capsule in closed form (<= 4 / 1 / 2 points), box-box by
+ * separating axes and face clipping (<= 8 points), every other convex pair by Minkowski Portal Refinement on the shapes'
+ * support mappings (one point: deepest penetration) -- the default convex-convex path of Genesis.
+ * Sphere and capsule geoms are supported by the 16-lanes-per-env kernel (the pick scenes); the wave-per-env kernel
+ * (five-cube stack scenes) takes planes and boxes only. */
 
 /* dof control modes */
 #define MIR_CTRL_NONE 0
@@ -367,6 +374,9 @@ int mir_debug_profile_step(MirHandle h, unsigned long long* prof, void* stream);
 int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* out_us);
 int mir_debug_poison_lds(int device_id, void* stream);
 int mir_debug_copy_rows(const float* src, float* dst, int64_t n_floats, int device_id, void* stream);
+/* the kernels' convex narrowphase on n pairs given directly (device arrays): in (n,22) = type1, size1[3], pos1[3], quat1[4] wxyz,
+ * type2, size2[3], pos2[3], quat2[4]; out (n,8) = hit, pos[3], dist, normal[3] (from geom 1 to geom 2) */
+int mir_debug_convex_pairs(const float* in, float* out, int32_t n, int device_id, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@
  *   crb           composite-rigid-body mass matrix            (App. A.3 1.i)
  *   rne           Coriolis/centrifugal/gravity bias forces     (App. A.3 1.iv)
  *   smooth        PD actuation + passive damping, qacc_smooth  (App. A.3 1.iii,v)
- *   collide       plane-box, box-box narrowphase               (App. A.3 2)
+ *   collide       plane-box/sphere/capsule, box-box, convex-convex (MPR) narrowphase   (App. A.3 2)
  *   make_rows     joint-limit + pyramidal contact rows, R, aref (App. A.3 2)
  *   newton        primal Newton with exact line search          (App. A.3 2)
  *   integrate     semi-implicit Euler, quaternion integration   (App. A.3 3)
@@ -492,6 +492,371 @@ static int box_box(const real* pa, const real* Ra, const real* ha, const real* p
   return cnt;
 }
 
+/* ------------------------------------------------------------------ plane vs sphere / capsule (closed form) */
+/* plane (point pp, normal = plane z axis) vs sphere (centre ps, radius r): one point at half depth */
+static int plane_sphere(const real* pp, const real* Rp, const real* ps, real r, CPoint* pts, real* n) {
+  n[0] = Rp[2]; n[1] = Rp[5]; n[2] = Rp[8];
+  real rel[3];
+  v3sub(rel, ps, pp);
+  real dist = v3dot(rel, n) - r;
+  if (!(dist < 0)) return 0;
+  v3addscl(pts[0].pos, ps, n, -(r + dist * (real)0.5));
+  pts[0].dist = dist; pts[0].u = pts[0].v = 0;
+  return 1;
+}
+
+/* plane vs capsule (centre pc, axis = z of Rc, radius r, half length h): the two end spheres, axis - then axis + */
+static int plane_capsule(const real* pp, const real* Rp, const real* pc, const real* Rc, real r, real h, CPoint* pts, real* n) {
+  real ax[3] = {Rc[2], Rc[5], Rc[8]};
+  int cnt = 0;
+  for (int s = -1; s <= 1; s += 2) {
+    real end[3], nn[3];
+    v3addscl(end, pc, ax, (real)s * h);
+    cnt += plane_sphere(pp, Rp, end, r, pts + cnt, nn);
+  }
+  n[0] = Rp[2]; n[1] = Rp[5]; n[2] = Rp[8];
+  return cnt;
+}
+
+/* ------------------------------------------------------------------ convex-convex: Minkowski Portal Refinement
+ * Restated from the published XenoCollide / libccd formulation (ccd/mpr.c: discover portal, refine portal, find
+ * penetration, barycentric contact position), which is the algorithm behind Genesis's default convex-convex path
+ * (UPSTREAM-RECALL).  Shapes enter only through their support mappings, so any convex geom type can
+ * be added by giving it one.  Result: ONE contact (deepest penetration): normal from shape A to shape B, depth > 0,
+ * position between the two witness points.  Same decisions, in the same order, as the kernel's lane-private version
+ * (mir_dev.h: mpr_pair). */
+#define MPR_TOL ((real)1e-6)
+#define MPR_MAXIT 64
+typedef struct { int type; real size[3], pos[3], R[9]; } Shape;
+
+/* farthest point of the shape along the UNIT direction d (world frame) */
+static void shape_support(const Shape* s, const real* d, real* out) {
+  v3copy(out, s->pos);
+  if (s->type == MIR_GEOM_SPHERE) {
+    v3addscl(out, out, d, s->size[0]);
+  } else if (s->type == MIR_GEOM_CAPSULE) {
+    real ax[3] = {s->R[2], s->R[5], s->R[8]};
+    v3addscl(out, out, ax, v3dot(d, ax) >= 0 ? s->size[1] : -s->size[1]);
+    v3addscl(out, out, d, s->size[0]);
+  } else { /* box */
+    for (int k = 0; k < 3; k++) {
+      real ax[3] = {s->R[k], s->R[3 + k], s->R[6 + k]};
+      v3addscl(out, out, ax, v3dot(d, ax) >= 0 ? s->size[k] : -s->size[k]);
+    }
+  }
+}
+
+typedef struct { real v[3], a[3], b[3]; } MprPt; /* point of A - B with its witnesses on A and on B */
+
+static void mpr_support(const Shape* A, const Shape* B, const real* d, MprPt* o) {
+  real nd[3] = {-d[0], -d[1], -d[2]};
+  shape_support(A, d, o->a);
+  shape_support(B, nd, o->b);
+  v3sub(o->v, o->a, o->b);
+}
+
+static int v3unit(real* d) { /* normalise in place; 0 if (numerically) zero */
+  real l2 = v3dot(d, d);
+  if (!(l2 > (real)1e-30)) return 0;
+  real il = (real)1 / (real)sqrt((double)l2);
+  d[0] *= il; d[1] *= il; d[2] *= il;
+  return 1;
+}
+
+static void portal_dir(const MprPt* p, real* d) { /* normal of the triangle (v1, v2, v3) */
+  real e1[3], e2[3];
+  v3sub(e1, p[2].v, p[1].v);
+  v3sub(e2, p[3].v, p[1].v);
+  v3cross(d, e1, e2);
+  v3unit(d);
+}
+
+static int portal_reach_tolerance(const MprPt* p, const MprPt* v4, const real* d) {
+  real dv4 = v3dot(v4->v, d);
+  real m = dv4 - v3dot(p[1].v, d), t = dv4 - v3dot(p[2].v, d), u = dv4 - v3dot(p[3].v, d);
+  if (t < m) m = t;
+  if (u < m) m = u;
+  return m < MPR_TOL;
+}
+
+static void portal_expand(MprPt* p, const MprPt* v4) {
+  real c[3];
+  v3cross(c, v4->v, p[0].v);
+  if (v3dot(p[1].v, c) > 0) {
+    if (v3dot(p[2].v, c) > 0) p[1] = *v4; else p[3] = *v4;
+  } else {
+    if (v3dot(p[3].v, c) > 0) p[2] = *v4; else p[1] = *v4;
+  }
+}
+
+/* closest point of the triangle (a, b, c) to the origin (Ericson, Real-Time Collision Detection 5.1.5) */
+static void tri_closest_to_origin(const real* a, const real* b, const real* c, real* out) {
+  real ab[3], ac[3];
+  v3sub(ab, b, a); v3sub(ac, c, a);
+  real d1 = -v3dot(ab, a), d2 = -v3dot(ac, a);
+  if (d1 <= 0 && d2 <= 0) { v3copy(out, a); return; }
+  real d3 = -v3dot(ab, b), d4 = -v3dot(ac, b);
+  if (d3 >= 0 && d4 <= d3) { v3copy(out, b); return; }
+  real vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { v3addscl(out, a, ab, d1 / (d1 - d3)); return; }
+  real d5 = -v3dot(ab, c), d6 = -v3dot(ac, c);
+  if (d6 >= 0 && d5 <= d6) { v3copy(out, c); return; }
+  real vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { v3addscl(out, a, ac, d2 / (d2 - d6)); return; }
+  real va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    real bc[3];
+    v3sub(bc, c, b);
+    v3addscl(out, b, bc, (d4 - d3) / ((d4 - d3) + (d5 - d6)));
+    return;
+  }
+  real den = (real)1 / (va + vb + vc);
+  v3addscl(out, a, ab, vb * den);
+  v3addscl(out, out, ac, vc * den);
+}
+
+static void mpr_find_pos(const MprPt* p, real* pos) {
+  real d[3], c[3], b[4];
+  portal_dir(p, d);
+  v3cross(c, p[1].v, p[2].v); b[0] = v3dot(c, p[3].v);
+  v3cross(c, p[3].v, p[2].v); b[1] = v3dot(c, p[0].v);
+  v3cross(c, p[0].v, p[1].v); b[2] = v3dot(c, p[3].v);
+  v3cross(c, p[2].v, p[1].v); b[3] = v3dot(c, p[0].v);
+  real sum = b[0] + b[1] + b[2] + b[3];
+  if (!(sum > 0)) {
+    b[0] = 0;
+    v3cross(c, p[2].v, p[3].v); b[1] = v3dot(c, d);
+    v3cross(c, p[3].v, p[1].v); b[2] = v3dot(c, d);
+    v3cross(c, p[1].v, p[2].v); b[3] = v3dot(c, d);
+    sum = b[1] + b[2] + b[3];
+  }
+  real inv = (real)1 / sum, pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    v3addscl(pa, pa, p[i].a, b[i]);
+    v3addscl(pb, pb, p[i].b, b[i]);
+  }
+  for (int k = 0; k < 3; k++) pos[k] = (real)0.5 * inv * (pa[k] + pb[k]);
+}
+
+/* 1 = penetrating (depth, normal A->B, pos filled), 0 = separated */
+static int mpr_pair(const Shape* A, const Shape* B, real* depth, real* normal, real* pos) {
+  MprPt p[4], v4;
+  real d[3], c[3];
+  /* interior point of A - B: difference of the centres */
+  v3copy(p[0].a, A->pos); v3copy(p[0].b, B->pos);
+  v3sub(p[0].v, p[0].a, p[0].b);
+  if (!(v3dot(p[0].v, p[0].v) > (real)1e-20)) { p[0].v[0] = (real)1e-5; p[0].v[1] = p[0].v[2] = 0; }
+  v3set(d, -p[0].v[0], -p[0].v[1], -p[0].v[2]);
+  v3unit(d);
+  mpr_support(A, B, d, &p[1]);
+  if (!(v3dot(p[1].v, d) > 0)) return 0;
+  v3cross(d, p[0].v, p[1].v);
+  if (!v3unit(d)) {
+    /* the origin lies on the ray v0 -> v1: v1 itself is the penetration */
+    real l = v3norm(p[1].v);
+    *depth = l;
+    if (l > (real)1e-15) { for (int k = 0; k < 3; k++) normal[k] = p[1].v[k] / l; }
+    else { real l0 = v3norm(p[0].v); for (int k = 0; k < 3; k++) normal[k] = -p[0].v[k] / l0; }
+    for (int k = 0; k < 3; k++) pos[k] = (real)0.5 * (p[1].a[k] + p[1].b[k]);
+    return 1;
+  }
+  mpr_support(A, B, d, &p[2]);
+  if (!(v3dot(p[2].v, d) > 0)) return 0;
+  {
+    real e1[3], e2[3];
+    v3sub(e1, p[1].v, p[0].v); v3sub(e2, p[2].v, p[0].v);
+    v3cross(d, e1, e2);
+    v3unit(d);
+    if (v3dot(d, p[0].v) > 0) { MprPt t = p[1]; p[1] = p[2]; p[2] = t; d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+  }
+  for (int it = 0;; it++) { /* discover the portal */
+    if (it > MPR_MAXIT) return 0;
+    mpr_support(A, B, d, &p[3]);
+    if (!(v3dot(p[3].v, d) > 0)) return 0;
+    int again = 0;
+    v3cross(c, p[1].v, p[3].v);
+    if (v3dot(c, p[0].v) < 0) { p[2] = p[3]; again = 1; }
+    if (!again) {
+      v3cross(c, p[3].v, p[2].v);
+      if (v3dot(c, p[0].v) < 0) { p[1] = p[3]; again = 1; }
+    }
+    if (!again) break;
+    real e1[3], e2[3];
+    v3sub(e1, p[1].v, p[0].v); v3sub(e2, p[2].v, p[0].v);
+    v3cross(d, e1, e2);
+    v3unit(d);
+  }
+  for (int it = 0;; it++) { /* refine until the portal is beyond the origin */
+    portal_dir(p, d);
+    if (v3dot(d, p[1].v) >= 0) break;
+    mpr_support(A, B, d, &v4);
+    if (!(v3dot(v4.v, d) >= 0) || portal_reach_tolerance(p, &v4, d) || it > MPR_MAXIT) return 0;
+    portal_expand(p, &v4);
+  }
+  for (int it = 0;; it++) { /* push the portal to the surface of A - B */
+    portal_dir(p, d);
+    mpr_support(A, B, d, &v4);
+    if (portal_reach_tolerance(p, &v4, d) || it > MPR_MAXIT) {
+      real w[3];
+      tri_closest_to_origin(p[1].v, p[2].v, p[3].v, w);
+      real l = v3norm(w);
+      *depth = l;
+      if (l > (real)1e-15) { for (int k = 0; k < 3; k++) normal[k] = w[k] / l; }
+      else v3copy(normal, d);
+      mpr_find_pos(p, pos);
+      return 1;
+    }
+    portal_expand(p, &v4);
+  }
+}
+
+/* ------------------------------------------------------------------ convex-convex: GJK distance between the CORE shapes
+ * Spheres and capsules are a point / a segment swept by a radius, so their contact follows from the DISTANCE between the cores
+ * (point, segment, box: polytopes, for which GJK terminates on an exact feature pair): depth = r1 + r2 - distance, normal along
+ * the connecting line, position midway between the two surfaces.  That is exact to rounding -- a support-mapping method run on
+ * the round surfaces themselves resolves the normal only to sqrt(2 tol / R) -- and is the usual treatment of rounded convexes
+ * (a collision margin around a core).  When the cores themselves overlap (penetration deeper than the radii) the pair goes to
+ * MPR on the full shapes, above.  GJK as in Gilbert-Johnson-Keerthi 1988 / van den Bergen 1999: the simplex is reduced to the
+ * smallest face that contains the closest point (Ericson, Real-Time Collision Detection 5.1), duplicates and lack of progress
+ * end the iteration. */
+#define GJK_MAXIT 32
+static void core_support(const Shape* s, const real* d, real* out) { /* farthest point of the CORE along d (any length) */
+  v3copy(out, s->pos);
+  if (s->type == MIR_GEOM_CAPSULE) {
+    real ax[3] = {s->R[2], s->R[5], s->R[8]};
+    v3addscl(out, out, ax, v3dot(d, ax) >= 0 ? s->size[1] : -s->size[1]);
+  } else if (s->type == MIR_GEOM_BOX) {
+    for (int k = 0; k < 3; k++) {
+      real ax[3] = {s->R[k], s->R[3 + k], s->R[6 + k]};
+      v3addscl(out, out, ax, v3dot(d, ax) >= 0 ? s->size[k] : -s->size[k]);
+    }
+  }
+}
+static real core_radius(const Shape* s) { return s->type == MIR_GEOM_BOX ? (real)0 : s->size[0]; }
+
+/* closest point of the segment / triangle to the origin as barycentric weights; vertices with weight 0 are dropped by the caller */
+static void seg_bary(const real* a, const real* b, real* l) {
+  real ab[3];
+  v3sub(ab, b, a);
+  real t = -v3dot(a, ab), den = v3dot(ab, ab);
+  if (t <= 0 || !(den > 0)) { l[0] = 1; l[1] = 0; }
+  else if (t >= den) { l[0] = 0; l[1] = 1; }
+  else { l[1] = t / den; l[0] = 1 - l[1]; }
+}
+static void tri_bary(const real* a, const real* b, const real* c, real* l) {
+  real ab[3], ac[3];
+  v3sub(ab, b, a); v3sub(ac, c, a);
+  real d1 = -v3dot(ab, a), d2 = -v3dot(ac, a);
+  l[0] = l[1] = l[2] = 0;
+  if (d1 <= 0 && d2 <= 0) { l[0] = 1; return; }
+  real d3 = -v3dot(ab, b), d4 = -v3dot(ac, b);
+  if (d3 >= 0 && d4 <= d3) { l[1] = 1; return; }
+  real vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { l[1] = d1 / (d1 - d3); l[0] = 1 - l[1]; return; }
+  real d5 = -v3dot(ab, c), d6 = -v3dot(ac, c);
+  if (d6 >= 0 && d5 <= d6) { l[2] = 1; return; }
+  real vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { l[2] = d2 / (d2 - d6); l[0] = 1 - l[2]; return; }
+  real va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { l[2] = (d4 - d3) / ((d4 - d3) + (d5 - d6)); l[1] = 1 - l[2]; return; }
+  real den = (real)1 / (va + vb + vc);
+  l[1] = vb * den; l[2] = vc * den; l[0] = 1 - l[1] - l[2];
+}
+static real bary_norm2(int n, real P[4][3], const int* idx, const real* l) {
+  real v[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++) v3addscl(v, v, P[idx[i]], l[i]);
+  return v3dot(v, v);
+}
+
+/* 0: cores apart, *dist > 0, pa / pb = closest points on core A / core B;  1: cores touch or overlap */
+static int gjk_core_distance(const Shape* A, const Shape* B, real* dist, real* pa, real* pb) {
+  real P[4][3], PA[4][3], PB[4][3], lam[4] = {1, 0, 0, 0}, v[3];
+  int n = 0;
+  v3sub(v, A->pos, B->pos);
+  if (!(v3dot(v, v) > (real)1e-24)) v3set(v, 1, 0, 0);
+  for (int it = 0; it < GJK_MAXIT; it++) {
+    real d[3] = {-v[0], -v[1], -v[2]}, wa[3], wb[3], w[3];
+    core_support(A, d, wa);
+    core_support(B, v, wb);
+    v3sub(w, wa, wb);
+    real vv = v3dot(v, v);
+    if (n > 0 && vv - v3dot(v, w) <= (real)1e-12 * vv) break; /* no point of A - B is closer along v: v is the closest point */
+    int dup = 0;
+    for (int i = 0; i < n; i++) { real e[3]; v3sub(e, w, P[i]); if (!(v3dot(e, e) > (real)1e-24)) dup = 1; }
+    if (dup) break;
+    v3copy(P[n], w); v3copy(PA[n], wa); v3copy(PB[n], wb); n++;
+    /* closest point of the simplex to the origin; keep the smallest face that carries it */
+    real l[4] = {1, 0, 0, 0};
+    if (n == 2) seg_bary(P[0], P[1], l);
+    else if (n == 3) tri_bary(P[0], P[1], P[2], l);
+    else if (n == 4) {
+      /* the origin is inside the tetrahedron iff it is on the inner side of all four faces; otherwise the closest of the
+       * faces it is outside of (faces in the fixed order 012, 013, 023, 123) */
+      static const int F[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
+      real best = -1, bl[4] = {0, 0, 0, 0};
+      int inside = 1;
+      for (int f = 0; f < 4; f++) {
+        real e1[3], e2[3], nn[3], eo[3];
+        v3sub(e1, P[F[f][1]], P[F[f][0]]); v3sub(e2, P[F[f][2]], P[F[f][0]]);
+        v3cross(nn, e1, e2);
+        v3sub(eo, P[F[f][3]], P[F[f][0]]);
+        real so = v3dot(nn, eo), s0 = -v3dot(nn, P[F[f][0]]); /* sides of the opposite vertex and of the origin */
+        /* origin outside this face, or the tetrahedron is flatter than 1e-5 rad (four vertices of one box face): no inside */
+        if (so * s0 < 0 || so * so <= (real)1e-10 * v3dot(nn, nn) * v3dot(eo, eo)) {
+          inside = 0;
+          real tl[3];
+          tri_bary(P[F[f][0]], P[F[f][1]], P[F[f][2]], tl);
+          real d2 = bary_norm2(3, P, F[f], tl);
+          if (best < 0 || d2 < best) {
+            best = d2;
+            bl[0] = bl[1] = bl[2] = bl[3] = 0;
+            for (int i = 0; i < 3; i++) bl[F[f][i]] = tl[i];
+          }
+        }
+      }
+      if (inside) return 1;
+      for (int i = 0; i < 4; i++) l[i] = bl[i];
+    }
+    /* compact: drop the vertices with zero weight, recompute v */
+    int m = 0;
+    v3set(v, 0, 0, 0);
+    for (int i = 0; i < n; i++)
+      if (l[i] > 0) {
+        if (m != i) { v3copy(P[m], P[i]); v3copy(PA[m], PA[i]); v3copy(PB[m], PB[i]); }
+        lam[m] = l[i];
+        v3addscl(v, v, P[m], l[i]);
+        m++;
+      }
+    n = m;
+    if (!(v3dot(v, v) > (real)1e-20)) return 1; /* the cores touch */
+  }
+  v3set(pa, 0, 0, 0); v3set(pb, 0, 0, 0);
+  for (int i = 0; i < n; i++) { v3addscl(pa, pa, PA[i], lam[i]); v3addscl(pb, pb, PB[i], lam[i]); }
+  *dist = v3norm(v);
+  return 0;
+}
+
+static int convex_pair(int t1, const real* s1, const real* p1, const real* R1, int t2, const real* s2, const real* p2, const real* R2,
+                       CPoint* pts, real* n) {
+  Shape A, B;
+  A.type = t1; B.type = t2;
+  for (int k = 0; k < 3; k++) { A.size[k] = s1[k]; B.size[k] = s2[k]; A.pos[k] = p1[k]; B.pos[k] = p2[k]; }
+  memcpy(A.R, R1, sizeof A.R); memcpy(B.R, R2, sizeof B.R);
+  real dist, pa[3], pb[3], ra = core_radius(&A), rb = core_radius(&B);
+  if (!gjk_core_distance(&A, &B, &dist, pa, pb)) {
+    if (!(dist < ra + rb)) return 0;
+    for (int k = 0; k < 3; k++) n[k] = (pb[k] - pa[k]) / dist;
+    /* midway between the surface points pa + ra n and pb - rb n */
+    for (int k = 0; k < 3; k++) pts[0].pos[k] = (real)0.5 * (pa[k] + pb[k] + (ra - rb) * n[k]);
+    pts[0].dist = dist - ra - rb; pts[0].u = pts[0].v = 0;
+    return 1;
+  }
+  real depth; /* cores overlap: deep penetration, portal refinement on the full shapes */
+  if (!mpr_pair(&A, &B, &depth, n, pts[0].pos)) return 0;
+  pts[0].dist = -depth; pts[0].u = pts[0].v = 0;
+  return 1;
+}
+
 static void make_frame(real* F, const real* n) { /* rows: normal, t1, t2 */
   real t1[3] = {0, 0, 0};
   if (fabs((double)n[1]) < 0.5) t1[1] = 1; else t1[2] = 1;
@@ -518,7 +883,10 @@ static void orc_collide(const OrcModel* m, OrcData* d) {
     qmul(q, d->xquat[b2], m->gquat[g2]); q2mat(R2, q);
     CPoint pts[16]; real n[3]; int cnt = 0;
     if (m->gtype[g1] == MIR_GEOM_PLANE && m->gtype[g2] == MIR_GEOM_BOX) cnt = plane_box(p1, R1, p2, R2, m->gsize[g2], pts, n);
+    else if (m->gtype[g1] == MIR_GEOM_PLANE && m->gtype[g2] == MIR_GEOM_SPHERE) cnt = plane_sphere(p1, R1, p2, m->gsize[g2][0], pts, n);
+    else if (m->gtype[g1] == MIR_GEOM_PLANE && m->gtype[g2] == MIR_GEOM_CAPSULE) cnt = plane_capsule(p1, R1, p2, R2, m->gsize[g2][0], m->gsize[g2][1], pts, n);
     else if (m->gtype[g1] == MIR_GEOM_BOX && m->gtype[g2] == MIR_GEOM_BOX) cnt = box_box(p1, R1, m->gsize[g1], p2, R2, m->gsize[g2], pts, n);
+    else if (m->gtype[g1] != MIR_GEOM_PLANE) cnt = convex_pair(m->gtype[g1], m->gsize[g1], p1, R1, m->gtype[g2], m->gsize[g2], p2, R2, pts, n);
     for (int c = 0; c < cnt && d->ncon < maxc; c++) {
       int k = d->ncon++;
       v3copy(d->cpos[k], pts[c].pos);
@@ -530,6 +898,30 @@ static void orc_collide(const OrcModel* m, OrcData* d) {
       d->cb1[k] = b1; d->cb2[k] = b2; d->cg1[k] = g1; d->cg2[k] = g2;
     }
   }
+}
+
+/* test hook: narrowphase of ONE pair of geoms given directly (types, sizes, world poses as pos3 + quat4 wxyz);
+ * out = up to 8 x (pos3, dist), normal3; returns the number of points */
+int orc_narrowphase(int t1, const double* size1, const double* pos1, const double* quat1, int t2, const double* size2, const double* pos2,
+                    const double* quat2, double* out_pts, double* out_normal) {
+  real s1[3], s2[3], p1[3], p2[3], q1[4], q2[4], R1[9], R2[9], n[3] = {0, 0, 0};
+  for (int k = 0; k < 3; k++) { s1[k] = (real)size1[k]; s2[k] = (real)size2[k]; p1[k] = (real)pos1[k]; p2[k] = (real)pos2[k]; }
+  for (int k = 0; k < 4; k++) { q1[k] = (real)quat1[k]; q2[k] = (real)quat2[k]; }
+  qnormalize(q1); qnormalize(q2);
+  q2mat(R1, q1); q2mat(R2, q2);
+  CPoint pts[16];
+  int cnt = 0;
+  if (t1 == MIR_GEOM_PLANE && t2 == MIR_GEOM_BOX) cnt = plane_box(p1, R1, p2, R2, s2, pts, n);
+  else if (t1 == MIR_GEOM_PLANE && t2 == MIR_GEOM_SPHERE) cnt = plane_sphere(p1, R1, p2, s2[0], pts, n);
+  else if (t1 == MIR_GEOM_PLANE && t2 == MIR_GEOM_CAPSULE) cnt = plane_capsule(p1, R1, p2, R2, s2[0], s2[1], pts, n);
+  else if (t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX) cnt = box_box(p1, R1, s1, p2, R2, s2, pts, n);
+  else if (t1 != MIR_GEOM_PLANE && t2 != MIR_GEOM_PLANE) cnt = convex_pair(t1, s1, p1, R1, t2, s2, p2, R2, pts, n);
+  for (int c = 0; c < cnt; c++) {
+    for (int k = 0; k < 3; k++) out_pts[4 * c + k] = (double)pts[c].pos[k];
+    out_pts[4 * c + 3] = (double)pts[c].dist;
+  }
+  for (int k = 0; k < 3; k++) out_normal[k] = (double)n[k];
+  return cnt;
 }
 
 /* ------------------------------------------------------------------ constraint rows */

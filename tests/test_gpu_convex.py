@@ -1,0 +1,189 @@
+"""GPU parity of the convex narrowphase (sphere / capsule geoms: GJK on the cores, MPR when the cores overlap, closed-form plane
+cases) against the float64 oracle, through the C ABI.
+
+A batch IS a set of poses: two free bodies per env, every env in its own random relative pose, one forward-dynamics evaluation
+(mir_forward): contact counts must agree and the constrained accelerations -- which see every contact's position, normal and
+depth -- must match.  Then free-running rollouts of bodies dropped on the plane and on a static box.
+"""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from gym_genesis.backend import spec as S
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "sphere": (S.GEOM_SPHERE, (0.04,)),
+    "capsule": (S.GEOM_CAPSULE, (0.03, 0.07)),
+    "box": (S.GEOM_BOX, (0.04, 0.03, 0.05)),
+}
+
+
+def _inertia(kind, mass):
+    t, size = SHAPES[kind]
+    if t == S.GEOM_SPHERE:
+        return S.sphere_inertia(mass, size[0])
+    if t == S.GEOM_CAPSULE:
+        return S.capsule_inertia(mass, size[0], size[1])
+    return S.box_inertia(mass, size)
+
+
+def _scene(kind_a, kind_b):
+    """plane + a static box + two free bodies."""
+    sb = S.SceneBuilder()
+    sb.add_geom(0, S.GEOM_PLANE)
+    sb.add_geom(0, S.GEOM_BOX, size=(0.15, 0.15, 0.05), pos=(0.0, 0.0, 0.05))
+    for name, kind, x in (("a", kind_a, -0.3), ("b", kind_b, 0.3)):
+        t, size = SHAPES[kind]
+        sb.add_body(name, 0, pos=(x, 0.0, 0.5), jtype=S.JNT_FREE, mass=0.3, inertia=_inertia(kind, 0.3))
+        sb.add_geom(name, t, size=tuple(size) + (0.0,) * (3 - len(size)))
+    sb.task = dict(eef_body=1, obj_body=2, grip_dof=(), reward_z=0.1)
+    return sb.build()
+
+
+def _mir(spec, B):
+    from gym_genesis.backend.lib import MirScene
+
+    return MirScene(spec, B)
+
+
+def _rand_quat(rng, n):
+    q = rng.normal(size=(n, 4))
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("pair", [("sphere", "sphere"), ("sphere", "capsule"), ("capsule", "capsule"), ("capsule", "box"), ("sphere", "box")])
+def test_pose_batch_contacts_match_oracle(pair):
+    """512 random relative poses of the two bodies in mid-air (only their mutual contact is possible), from grazing to
+    overlapping cores: contact count identical; for contacts that go through GJK on the cores (shallower than the radii) the
+    constrained acceleration is within 1e-3 relative of the oracle's."""
+    spec = _scene(*pair)
+    B = 512
+    rng = np.random.default_rng(11)
+    q = np.zeros((B, 14), np.float32)
+    q[:, 0:3] = rng.uniform(-0.02, 0.02, (B, 3)) + [0, 0, 1.0]
+    d = rng.normal(size=(B, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    q[:, 7:10] = q[:, 0:3] + d * rng.uniform(0.01, 0.16, (B, 1))
+    q[:, 3:7], q[:, 10:14] = _rand_quat(rng, B), _rand_quat(rng, B)
+    v = rng.uniform(-0.2, 0.2, (B, 12)).astype(np.float32)
+    sc, o = _mir(spec, B), orc.Oracle(spec, B)
+    assert sc.kernel == 16
+    sc.set_state(qpos=q, qvel=v, warmstart=np.zeros((B, 12), np.float32))
+    _, _, _, qacc = (t.cpu().numpy() for t in sc.forward())
+    ncon = sc.get_diag()[0].cpu().numpy()
+    nco = np.zeros(B, int)
+    worst = 0.0
+    deep = shallow = 0
+    for e in range(B):
+        o.write(orc.F_QPOS, q[e], e)
+        o.write(orc.F_QVEL, v[e], e)
+        o.forward(e)
+        nco[e] = o.counts(e)[0]
+        if nco[e] != ncon[e]:
+            continue
+        qo = o.read(orc.F_QACC, e)
+        dist = o.read(orc.F_CDIST, e)
+        if nco[e] and dist[0] > -1e-4:
+            continue  # grazing: the force is discontinuous at zero depth
+        radii = sum(SHAPES[k][1][0] for k in pair if k != "box")
+        err = np.abs(qacc[e] - qo).max() / max(1.0, np.abs(qo).max())
+        if nco[e] and -dist[0] > 0.9 * radii:
+            # cores overlapping (or about to): MPR, whose depth and normal depend on where the portal refinement stops -- the two
+            # precisions may stop one refinement apart, so only the contact itself is required to agree (count, above)
+            deep += 1
+        else:
+            shallow += int(nco[e] > 0)
+            worst = max(worst, err)
+    mism = int((nco != ncon).sum())
+    print(f"{pair}: {int((nco > 0).sum())} contacts in {B} poses ({shallow} through GJK, {deep} through MPR), {mism} count mismatches, qacc rel err {worst:.2e}")
+    assert mism <= 2                      # a pose exactly at touching distance may flip between the precisions
+    assert (nco > 0).sum() > 100 and shallow > 50
+    assert worst < 1e-3
+
+
+@pytest.mark.parametrize("pair", [("sphere", "capsule"), ("capsule", "box")])
+def test_dropped_bodies_settle_like_the_oracle(pair):
+    """The two bodies fall on the plane / on the static box from random poses: plane-sphere, plane-capsule (two end points),
+    capsule-box and sphere-box through GJK, free-running for 120 steps; the final resting heights agree and every env's position
+    error stays below 2e-3 (tumbling contacts amplify float32 rounding; medians are ~1e-5)."""
+    spec = _scene(*pair)
+    B = 64
+    rng = np.random.default_rng(5)
+    pos = np.zeros((B, 2, 3), np.float32)
+    pos[:, 0] = rng.uniform(-0.05, 0.05, (B, 3)) + [0.0, 0.0, 0.22]    # above the static box
+    pos[:, 1] = rng.uniform(-0.05, 0.05, (B, 3)) + [0.5, 0.0, 0.12]    # above the bare plane
+    quat = np.stack([_rand_quat(rng, B), _rand_quat(rng, B)], 1).astype(np.float32)
+    sc, o = _mir(spec, B), orc.Oracle(spec, B)
+    arm = np.zeros((B, 0), np.float32)
+    sc.reset(pos, quat, arm)
+    o.reset(pos, quat, arm)
+    bufs = (sc.empty(sc.agent_dim), sc.empty(sc.env_dim), sc.empty(), sc.empty(dtype=torch.uint8))
+    for t in range(120):
+        sc.step_fused(None, *bufs)
+        o.step_batch(None)
+        if t == 20:
+            qh = sc.get_state()[0].cpu().numpy()
+            early = np.abs(qh - o.state()[0]).max()
+    qh = sc.get_state()[0].cpu().numpy()
+    qo = o.state()[0]
+    err = np.abs(qh - qo)[:, [0, 1, 2, 7, 8, 9]].max(1)
+    ncon = sc.get_diag()[0].cpu().numpy()
+    print(f"{pair}: after 21 steps L-inf {early:.2e}; after 120 steps position err median {np.median(err):.2e}, max {err.max():.2e}; contacts {ncon.min()}..{ncon.max()}")
+    assert early < 1e-5
+    assert np.median(err) < 1e-4 and err.max() < 5e-3
+    assert (ncon >= 1).all()
+    assert np.abs(qh[:, 2] - qo[:, 2]).max() < 2e-3 and np.abs(qh[:, 9] - qo[:, 9]).max() < 2e-3   # resting heights
+
+
+def test_round_geoms_need_the_16_lane_kernel():
+    """The wave-per-env kernel (five-cube stack scenes) takes planes and boxes only: a scene too large for the 16-lane kernel
+    that contains a capsule is refused with a clear message instead of being simulated with the wrong shape."""
+    from gym_genesis.backend.lib import MirError
+
+    sb = S.SceneBuilder()
+    sb.add_geom(0, S.GEOM_PLANE)
+    for i in range(3):  # 18 dofs > 15
+        sb.add_body(f"c{i}", 0, pos=(0.2 * i, 0, 0.1), jtype=S.JNT_FREE, mass=0.1, inertia=S.capsule_inertia(0.1, 0.02, 0.05))
+        sb.add_geom(f"c{i}", S.GEOM_CAPSULE, size=(0.02, 0.05, 0.0))
+    sb.task = dict(eef_body=1, obj_body=2, grip_dof=(), reward_z=0.1)
+    with pytest.raises(MirError, match="unsupported geom type"):
+        _mir(sb.build(), 4)
+
+
+def _device_pairs(rows):
+    """Run the kernel-side convex_pair on (n, 22) float32 rows; returns (n, 8)."""
+    import ctypes as C
+
+    from gym_genesis.backend import lib
+
+    L = lib.load_library()
+    L.mir_debug_convex_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p]
+    L.mir_debug_convex_pairs.restype = C.c_int
+    t_in = torch.as_tensor(np.ascontiguousarray(rows, np.float32), device="cuda")
+    t_out = torch.zeros((rows.shape[0], 8), dtype=torch.float32, device="cuda")
+    assert L.mir_debug_convex_pairs(t_in.data_ptr(), t_out.data_ptr(), rows.shape[0], torch.cuda.current_device(),
+                                    torch.cuda.current_stream().cuda_stream) == 0
+    return t_out.cpu().numpy()
+
+
+def test_kernel_narrowphase_equals_oracle_pair_by_pair():
+    """4000 random pairs of {box, sphere, capsule} (not box-box): the kernel's convex_pair against the oracle's, pair by pair, and
+    against the host build of the same source (tests/test_convex_host.py), with which it must agree to float32 rounding."""
+    import ctypes as C
+
+    import test_convex_host as H
+
+    rows = H.random_pairs(4000, 21)
+    got = _device_pairs(rows)
+    shallow, deep = H.compare(rows, got, H.oracle_pairs(rows))
+    print(f"pair by pair vs oracle: {shallow} shallow (GJK), {deep} deep (MPR) contacts agree")
+    assert shallow > 300 and deep > 100
+    host = np.zeros_like(got)
+    H.host_lib().convex_host_pairs(rows.ctypes.data_as(C.c_void_p), host.ctypes.data_as(C.c_void_p), rows.shape[0])
+    same = (got[:, 0] == host[:, 0])
+    assert same.mean() > 0.995
+    both = same & (got[:, 0] == 1)
+    assert np.median(np.abs(got[both, 4] - host[both, 4])) < 1e-7
