@@ -258,6 +258,32 @@ def grasp_bench(torch, dev):
             "max_contacts_last_step": ncon_max}
 
 
+def capsule_links_bench(torch, dev, steps: int = 400):
+    """Secondary: the headline workload with links 1-7 of the Panda as capsules (GenesisEnv(..., link_shape="capsule")): the
+    instantiation of the step kernel that carries the convex narrowphase (GJK on the cores / MPR, mir_convex.h)."""
+    from gym_genesis.env import GenesisEnv
+
+    B = ENVS_PER_GPU
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False, link_shape="capsule")
+    env.reset(seed=0)
+    task = env._env
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    acts = torch.empty((256, B, 9), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
+    for t in range(20):
+        task.step_raw(acts[t])
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = _events(torch)
+    ev0.record()
+    for t in range(steps):
+        task.step_raw(acts[t % 256])
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us = ev0.elapsed_time(ev1) * 1e3 / steps
+    del env
+    return {"workload": "CubePick-v0 robot=franka, links 1-7 as capsules (convex narrowphase instantiation), U(-1,1) joint targets, num_envs=4096",
+            "env_steps_per_s": B / (us * 1e-6), "us_per_step": us}
+
+
 def so101_bench(torch, dev, steps: int = 400):
     """Secondary (BASELINE configs[3] / SURVEY.md 8d config 4): SO-101 cube-pick (6 arm dofs, cube on the kitchen slab: box-box
     contact every step) at 4096 envs, U(-1,1) joint targets around the rest pose."""
@@ -607,6 +633,7 @@ def worker(args) -> int:
                 _guard(out, "pixels", pixels_bench, torch, dev)
             if not args.no_stack:
                 _guard(out, "scripted_grasp", grasp_bench, torch, dev)
+                _guard(out, "capsule_links", capsule_links_bench, torch, dev)
                 _guard(out, "so101_pick", so101_bench, torch, dev)
                 _guard(out, "stack", stack_bench, torch, dev)
                 _guard(out, "ik", ik_bench, torch, dev)

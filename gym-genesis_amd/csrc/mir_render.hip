@@ -108,7 +108,9 @@ __global__ void k_render_setup(SetupArgs a) {
   if (i >= a.B * a.ngeom) return;
   const int e = i / a.ngeom, g = i % a.ngeom;
   const GeomTab* __restrict__ m = a.geom;
-  const int b = m->g_body[g], type = m->g_type[g];
+  const int b = m->g_body[g], gtype = m->g_type[g];
+  // round geoms are drawn as their bounding boxes (sphere: r r r; capsule: r r half+r): the rasteriser knows boxes and planes
+  const int type = (gtype == MIR_GEOM_SPHERE || gtype == MIR_GEOM_CAPSULE) ? MIR_GEOM_BOX : gtype;
   const float* pp = a.poses + ((size_t)e * 2 * a.pst + b) * 4;
   const V3 xp = {pp[0], pp[1], pp[2]};
   const float* qq = pp + 4 * a.pst;
@@ -140,7 +142,8 @@ __global__ void k_render_setup(SetupArgs a) {
   }
   const V3 L = {a.light[0], a.light[1], a.light[2]};
   const V3 rel = cp - c;
-  const V3 h = {m->g_size[g][0], m->g_size[g][1], m->g_size[g][2]};
+  const float* gs = m->g_size[g];
+  const V3 h = gtype == MIR_GEOM_SPHERE ? V3{gs[0], gs[0], gs[0]} : (gtype == MIR_GEOM_CAPSULE ? V3{gs[0], gs[0], gs[0] + gs[1]} : V3{gs[0], gs[1], gs[2]});
   const V3 o = {dot(ax[0], rel), dot(ax[1], rel), dot(ax[2], rel)};
   const V3 F = {dot(ax[0], cf), dot(ax[1], cf), dot(ax[2], cf)}, R = {dot(ax[0], cr), dot(ax[1], cr), dot(ax[2], cr)};
   const V3 U = {dot(ax[0], cu), dot(ax[1], cu), dot(ax[2], cu)};

@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import math
 
-from .spec import (AGENT_QPOS, CTRL_POSITION, GEOM_BOX, GEOM_PLANE, JNT_FREE, JNT_PRISMATIC, JNT_REVOLUTE, MIR_MAX_CONTACT,
+from .spec import (AGENT_QPOS, CTRL_POSITION, GEOM_BOX, GEOM_CAPSULE, GEOM_PLANE, JNT_FREE, JNT_PRISMATIC, JNT_REVOLUTE, MIR_MAX_CONTACT,
                    REWARD_STACK, SceneBuilder, box_inertia)
 
 # reference: cube_pick.py:7-17
@@ -72,11 +72,22 @@ _FINGER_BODY_BOX = ((0.0105, 0.0085, 0.0268), (0.0, 0.0145, 0.0268))
 _FINGER_PAD_BOX = ((0.0085, 0.004, 0.0085), (0.0, 0.0055, 0.0445))
 
 
-def _add_franka(sb: SceneBuilder, pos=(0.0, 0.0, 0.0), scale=1.0, frc=FRANKA_FRC_MJCF) -> None:
+def _capsule_of_box(half):
+    """The capsule inscribed along the longest edge of a link box: (radius, half length of the axis segment), quaternion that
+    turns the capsule's z axis onto that edge."""
+    k = max(range(3), key=lambda i: half[i])
+    r = min(half[(k + 1) % 3], half[(k + 2) % 3])
+    quat = ((_S, 0.0, _S, 0.0), (_S, -_S, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0))[k]  # z -> x, z -> y, z -> z
+    return (r, max(half[k] - r, 0.0)), quat
+
+
+def _add_franka(sb: SceneBuilder, pos=(0.0, 0.0, 0.0), scale=1.0, frc=FRANKA_FRC_MJCF, link_shape="box") -> None:
     """The Panda (bodies, joints, collision boxes) mounted at `pos`, uniformly scaled like gs.morphs.MJCF(scale=...):
     lengths x s, masses x s^3, inertias x s^5, prismatic ranges x s; joint-level constants (armature, damping,
     PD gains, force ranges) and revolute ranges unchanged.  `frc`: per-joint force limits (the MJCF defaults unless the task
-    overrides them with set_dofs_force_range)."""
+    overrides them with set_dofs_force_range).  `link_shape`: "box" (the stand-ins of round 1) or "capsule" -- links 1-7 as
+    capsules along the longest edge of those boxes (closer to the rounded link meshes; convex narrowphase: GJK / MPR).  Hand and
+    fingers stay boxes (the finger pads ARE boxes in the MJCF)."""
     s = float(scale)
     s3, s5 = s ** 3, s ** 5
     sc = lambda v: tuple(x * s for x in v)  # noqa: E731
@@ -96,7 +107,11 @@ def _add_franka(sb: SceneBuilder, pos=(0.0, 0.0, 0.0), scale=1.0, frc=FRANKA_FRC
                     range=(0.0, 0.04 * s), armature=0.1, damping=1.0, ctrl_mode=CTRL_POSITION, kp=FRANKA_KP[7 + k],
                     kv=FRANKA_KV[7 + k], frc_range=(-frc[7 + k], frc[7 + k]))
     for body, half, centre in _PANDA_BOXES:
-        sb.add_geom(body, GEOM_BOX, size=sc(half), pos=sc(centre), rgb=dark if body == "hand" else white)
+        if link_shape == "capsule" and body != "hand":
+            (r, hl), quat = _capsule_of_box(half)
+            sb.add_geom(body, GEOM_CAPSULE, size=(r * s, hl * s, 0.0), pos=sc(centre), quat=quat, rgb=white)
+        else:
+            sb.add_geom(body, GEOM_BOX, size=sc(half), pos=sc(centre), rgb=dark if body == "hand" else white)
     for finger in ("left_finger", "right_finger"):
         sb.add_geom(finger, GEOM_BOX, size=sc(_FINGER_BODY_BOX[0]), pos=sc(_FINGER_BODY_BOX[1]), rgb=dark)
         sb.add_geom(finger, GEOM_BOX, size=sc(_FINGER_PAD_BOX[0]), pos=sc(_FINGER_PAD_BOX[1]), rgb=dark)
@@ -110,12 +125,12 @@ def _add_cube(sb: SceneBuilder, name: str, pos, size=0.04, rho=200.0, friction=1
     sb.add_geom(name, GEOM_BOX, size=(h, h, h), friction=friction, rgb=rgb)
 
 
-def franka_cube_pick_scene(cube_size=0.04, cube_pos=(0.65, 0.0, 0.02), cube_rho=200.0) -> SceneBuilder:
+def franka_cube_pick_scene(cube_size=0.04, cube_pos=(0.65, 0.0, 0.02), cube_rho=200.0, link_shape="box") -> SceneBuilder:
     sb = SceneBuilder()
     # ground plane (gs.morphs.Plane, cube_pick.py:50)
     sb.add_geom(0, GEOM_PLANE)
     # Panda (cube_pick.py:51)
-    _add_franka(sb)
+    _add_franka(sb, link_shape=link_shape)
     # cube (gs.morphs.Box, cube_pick.py:52-54)
     _add_cube(sb, "cube", cube_pos, size=cube_size, rho=cube_rho)
     # visual-only pedestal of the fixed base link (never collides: contype = conaffinity = 0); appended last so

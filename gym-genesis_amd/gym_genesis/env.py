@@ -37,7 +37,9 @@ class GenesisEnv(Env):
 
     def __init__(self, task, robot="so101", enable_pixels=False, observation_height=480, observation_width=640,
                  num_envs=1, env_spacing=(1.0, 1.0), render_mode=None, camera_capture_mode="per_env",
-                 strip_environment_state=True, shard: Optional[Tuple[int, int]] = None):
+                 strip_environment_state=True, shard: Optional[Tuple[int, int]] = None, **task_kwargs):
+        # (shard and task_kwargs are additions to the reference signature: the env-axis shard of this process, and options of
+        # this backend's scene restatement, e.g. link_shape="capsule" for the Franka pick task)
         super().__init__()
         self.task = task
         self.robot = robot
@@ -49,6 +51,7 @@ class GenesisEnv(Env):
         self.camera_capture_mode = camera_capture_mode
         self.strip_environment_state = strip_environment_state
         self._shard = shard
+        self._task_kwargs = task_kwargs
         self.num_envs = num_envs
         self._env = self._make_env_task(task)
         # local shard size when sharded; the unbatched tasks (num_envs = 0) keep 0 like the reference (env.py:56,65)
@@ -145,4 +148,5 @@ class GenesisEnv(Env):
         )
         if self._shard is not None:
             kwargs["shard"] = self._shard
+        kwargs.update(self._task_kwargs)
         return ctor(**kwargs)

@@ -35,13 +35,15 @@ ENV_DIM = 11
 
 class FrankaCubePickBatch:
     def __init__(self, enable_pixels, observation_height, observation_width, num_envs, env_spacing,
-                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None):
+                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None, link_shape: str = "box"):
+        # link_shape: collision stand-ins of links 1-7, "box" or "capsule" (models._add_franka); not a reference kwarg
         self.enable_pixels = enable_pixels
         self.observation_height = observation_height
         self.observation_width = observation_width
         self.camera_capture_mode = camera_capture_mode
         self.strip_environment_state = strip_environment_state
         self.env_spacing = env_spacing
+        self.link_shape = link_shape
         # env-axis shard: this process owns envs [lo, hi) of the global batch
         self.global_num_envs = int(num_envs)
         rank, world = shard if shard is not None else (0, 1)
@@ -57,7 +59,7 @@ class FrankaCubePickBatch:
     def _build_scene(self):
         if self.enable_pixels and self.camera_capture_mode not in ("per_env", "global"):
             raise ValueError(f"Unknown camera_capture_mode: {self.camera_capture_mode}")  # cube_pick.py:177-178
-        builder = models.franka_cube_pick_scene()
+        builder = models.franka_cube_pick_scene(link_shape=self.link_shape)
         self._builder = builder
         self._mir = MirScene(builder.build(), self.num_envs)
         self._mir.set_diag(False)  # solver diagnostics (16 B per env-step) are a debugging aid: _mir.set_diag(True) to read them

@@ -72,6 +72,9 @@ int orc_render_image(const MirSceneSpec* spec, const MirCameraSpec* cam, const M
       q2m(q, p->R);
       for (int i = 0; i < 3; i++) p->h[i] = gs->size[i];
       p->type = gs->type;
+      /* round geoms are drawn as their bounding boxes, as the kernel does (mir_render.hip: k_render_setup) */
+      if (gs->type == MIR_GEOM_SPHERE) { p->h[1] = p->h[2] = gs->size[0]; p->type = MIR_GEOM_BOX; }
+      if (gs->type == MIR_GEOM_CAPSULE) { p->h[1] = gs->size[0]; p->h[2] = gs->size[0] + gs->size[1]; p->type = MIR_GEOM_BOX; }
       p->geom = g;
     }
   double f[3] = {cam->lookat[0] - cam->pos[0], cam->lookat[1] - cam->pos[1], cam->lookat[2] - cam->pos[2]}, r[3], u[3];
