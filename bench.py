@@ -258,13 +258,14 @@ def grasp_bench(torch, dev):
             "max_contacts_last_step": ncon_max}
 
 
-def capsule_links_bench(torch, dev, steps: int = 400):
-    """Secondary: the headline workload with links 1-7 of the Panda as capsules (GenesisEnv(..., link_shape="capsule")): the
-    instantiation of the step kernel that carries the convex narrowphase (GJK on the cores / MPR, mir_convex.h)."""
+def box_links_bench(torch, dev, steps: int = 400):
+    """Secondary: the headline workload with links 1-7 of the Panda as round 1's boxes (GenesisEnv(..., link_shape="box")): the
+    instantiation of the step kernel WITHOUT the convex narrowphase (the default scene has capsule links and runs the
+    instantiation with GJK on the cores / MPR, mir_convex.h)."""
     from gym_genesis.env import GenesisEnv
 
     B = ENVS_PER_GPU
-    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False, link_shape="capsule")
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False, link_shape="box")
     env.reset(seed=0)
     task = env._env
     gen = torch.Generator(device=dev).manual_seed(1234)
@@ -280,7 +281,7 @@ def capsule_links_bench(torch, dev, steps: int = 400):
     torch.cuda.synchronize(dev)
     us = ev0.elapsed_time(ev1) * 1e3 / steps
     del env
-    return {"workload": "CubePick-v0 robot=franka, links 1-7 as capsules (convex narrowphase instantiation), U(-1,1) joint targets, num_envs=4096",
+    return {"workload": "CubePick-v0 robot=franka, links 1-7 as boxes (planes-and-boxes instantiation of the kernel), U(-1,1) joint targets, num_envs=4096",
             "env_steps_per_s": B / (us * 1e-6), "us_per_step": us}
 
 
@@ -633,7 +634,7 @@ def worker(args) -> int:
                 _guard(out, "pixels", pixels_bench, torch, dev)
             if not args.no_stack:
                 _guard(out, "scripted_grasp", grasp_bench, torch, dev)
-                _guard(out, "capsule_links", capsule_links_bench, torch, dev)
+                _guard(out, "box_links", box_links_bench, torch, dev)
                 _guard(out, "so101_pick", so101_bench, torch, dev)
                 _guard(out, "stack", stack_bench, torch, dev)
                 _guard(out, "ik", ik_bench, torch, dev)

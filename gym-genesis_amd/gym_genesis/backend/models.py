@@ -125,7 +125,7 @@ def _add_cube(sb: SceneBuilder, name: str, pos, size=0.04, rho=200.0, friction=1
     sb.add_geom(name, GEOM_BOX, size=(h, h, h), friction=friction, rgb=rgb)
 
 
-def franka_cube_pick_scene(cube_size=0.04, cube_pos=(0.65, 0.0, 0.02), cube_rho=200.0, link_shape="box") -> SceneBuilder:
+def franka_cube_pick_scene(cube_size=0.04, cube_pos=(0.65, 0.0, 0.02), cube_rho=200.0, link_shape="capsule") -> SceneBuilder:
     sb = SceneBuilder()
     # ground plane (gs.morphs.Plane, cube_pick.py:50)
     sb.add_geom(0, GEOM_PLANE)

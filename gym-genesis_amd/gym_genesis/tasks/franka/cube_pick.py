@@ -35,7 +35,7 @@ ENV_DIM = 11
 
 class FrankaCubePickBatch:
     def __init__(self, enable_pixels, observation_height, observation_width, num_envs, env_spacing,
-                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None, link_shape: str = "box"):
+                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None, link_shape: str = "capsule"):
         # link_shape: collision stand-ins of links 1-7, "box" or "capsule" (models._add_franka); not a reference kwarg
         self.enable_pixels = enable_pixels
         self.observation_height = observation_height

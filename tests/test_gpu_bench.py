@@ -31,7 +31,7 @@ def test_driver_command_prints_the_contract_line():
     assert abs(rf["achieved"] - 489.0 * 4096 / (rf["kernel_us"] * 1e-6) / 1e9) < 1e-6 * rf["achieved"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "env-steps/s"
-    for key in ("secondary", "pixels", "scripted_grasp", "so101_pick", "stack", "ik"):
+    for key in ("secondary", "pixels", "scripted_grasp", "box_links", "so101_pick", "stack", "ik"):
         assert key in out and "error" not in out[key], (key, out.get(key))
     assert out["hot_path_rate"] >= out["value"] * 0.9
 

@@ -190,7 +190,8 @@ def test_kernel_narrowphase_equals_oracle_pair_by_pair():
 
 
 def test_franka_pick_with_capsule_links_matches_oracle():
-    """CubePick-v0 with links 1-7 as capsules (GenesisEnv(..., link_shape="capsule")): the benchmark's random-action workload at
+    """CubePick-v0 with links 1-7 as capsules (the default; GenesisEnv(..., link_shape="box") gives round 1's boxes): the
+    benchmark's random-action workload at
     256 envs, 60 free-running steps against the oracle (link-cube and link-plane pairs go through GJK / the closed-form plane
     cases when they come close), then the scripted grasp still lifts the cube."""
     import json
