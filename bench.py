@@ -621,7 +621,7 @@ def worker(args) -> int:
                 out["sync_step_floor"] = {"error": f"{type(e).__name__}: {e}"}
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": _profile_number("pmc_hbm_traffic.json", "hbm_bytes_per_launch") if B == ENVS_PER_GPU else None,
-                               "kernel": "mir_step_kernel<0>", "kernel_us": kernel_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
+                               "kernel": "mir_step_kernel<0, true>", "kernel_us": kernel_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
                                "note": "489 algorithmic B/env-step x 4096 envs per launch (SURVEY.md 8d); kernel_us = HIP events over the "
                                        "back-to-back raw launches of the same K-step region; the path is latency/occupancy-bound, not HBM-bound"}
         except Exception as e:  # noqa: BLE001
