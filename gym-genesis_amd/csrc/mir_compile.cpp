@@ -10,6 +10,7 @@
 // (M = sum_b m Jv^T Jv + Jw^T I Jw), not by the CRB recursion the kernels use.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -354,6 +355,7 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     for (int k = 0; k < 5; k++) m.g_solimp[g][k] = (float)s.solimp[k];
   }
   int np = 0;
+  uint32_t allow[K16_MAX_GEOM] = {0};
   for (int ga = 0; ga < sp->ngeom; ga++)
     for (int gb = ga + 1; gb < sp->ngeom; gb++) {
       int a = ga, b = gb;
@@ -371,9 +373,17 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
         if ((pa == lb && lb > 0) || (pb == la && la > 0)) continue;
       }
       if (!sp->opt.enable_self_collision && ba > 0 && bb > 0 && m.b_root[ba] == m.b_root[bb]) continue;
-      if (np >= K16_MAX_PAIR) return fail(err, MIR_E_CAPACITY, "too many candidate collision pairs");
-      m.p_g1[np] = a; m.p_g2[np] = b; np++;
+      allow[ga] |= 1u << gb; allow[gb] |= 1u << ga;
+      if (np < K16_MAX_PAIR) { m.p_g1[np] = a; m.p_g2[np] = b; }
+      np++;
     }
+  // Broadphase: a short static list is tested pair by pair; a list longer than K16_MAX_PAIR (self-collision enabled, many
+  // geoms) is replaced by the sweep-and-prune over world AABBs, which needs only the symmetric "may collide" masks.
+  // MIR_BROADPHASE=sap / static forces one or the other (static fails with MIR_E_CAPACITY when the list does not fit).
+  const char* bp = getenv("MIR_BROADPHASE");
+  m.use_sap = (np > K16_MAX_PAIR || (bp && !strcmp(bp, "sap"))) ? 1 : 0;
+  if (bp && !strcmp(bp, "static")) m.use_sap = 0;
+  if (!m.use_sap && np > K16_MAX_PAIR) return fail(err, MIR_E_CAPACITY, "too many candidate collision pairs");
   m.npair = np;
 
   // ---- constants at qpos0: M from body Jacobians, inverse weights ----------------------------
@@ -402,7 +412,8 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     t.g_sol[g][0] = m.g_solref[g][0]; t.g_sol[g][1] = m.g_solref[g][1];
     for (int k = 0; k < 5; k++) t.g_sol[g][2 + k] = m.g_solimp[g][k];
   }
-  for (int p = 0; p < m.npair; p++) t.pair[p] = m.p_g1[p] | (m.p_g2[p] << 8);
+  for (int p = 0; p < m.npair && p < K16_MAX_PAIR; p++) t.pair[p] = m.p_g1[p] | (m.p_g2[p] << 8);
+  for (int g = 0; g < m.ngeom; g++) t.g_allow[g] = allow[g];
   for (int b = 0; b < nb; b++) {
     t.b_info[b][0] = (int32_t)m.b_dofmask[b]; t.b_info[b][1] = m.b_root[b]; t.b_info[b][2] = m.b_qadr[b]; t.b_info[b][3] = m.b_dofadr[b];
     t.b_invw[b] = m.b_invweight0[b];

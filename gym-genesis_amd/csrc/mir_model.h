@@ -35,6 +35,7 @@ struct ModelTab {
   int32_t g_info[K16_MAX_GEOM][4];  // body, type, 0, 0
   float g_sol[K16_MAX_GEOM][8];   // solref[2], solimp[5], 0
   int32_t pair[K16_MAX_PAIR];     // g1 | g2 << 8
+  uint32_t g_allow[K16_MAX_GEOM]; // bit h: geoms g and h pass the static pair filter (sweep-and-prune broadphase)
   int32_t b_info[MIR_G][4];       // dofmask, root, qadr, dofadr
   float b_invw[MIR_G];            // body_invweight0
   float d_lim[MIR_G][12];         // lo, hi, invweight0, k, b, solimp[5], 0, 0
@@ -99,6 +100,7 @@ struct DevModel {
   // ---- free bodies in body order (reset / re-spawn poses) ----
   int32_t nfree, free_qadr[MIR_MAX_FREE];
   int32_t has_convex;  // any sphere / capsule geom
+  int32_t use_sap;     // candidate pairs from the sweep-and-prune over AABBs (static list too long, or MIR_BROADPHASE=sap)
 };
 
 struct HostConsts {

@@ -42,7 +42,7 @@ struct StepArgs {
   int qst, nu;  // qpos row stride and action width (copies of the model's, so the state loads do not wait for the model)
   int mode;     // 0: full steps; 1: forward dynamics only (mir_forward); 2: kinematics + outputs only
   int n_steps;  // mode 0 only
-  int convex;   // the scene has sphere / capsule geoms: launch the instantiation with the GJK / MPR narrowphase
+  int features; // bit 0: sphere / capsule geoms (GJK / MPR narrowphase); bit 1: sweep-and-prune broadphase
 };
 
 

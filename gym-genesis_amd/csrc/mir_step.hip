@@ -65,9 +65,19 @@ struct ColScratch {
   float gpos[K16_MAX_GEOM][4], gquat[K16_MAX_GEOM][4];
   int cand[G];
   int cmap[G];                    // contact slot -> candidate lane * 8 + point index
-  float stage[G][8][4];           // narrowphase output per candidate pair: pos, dist
+  union {
+    float stage[G][8][4];         // narrowphase output per candidate pair: pos, dist
+    struct {                      // sweep-and-prune scratch (dead before the narrowphase writes `stage`)
+      float lo[K16_MAX_GEOM][4], hi[K16_MAX_GEOM][4];  // world AABB; lo.w = geom type as int bits
+      int order[K16_MAX_GEOM];    // non-plane geoms sorted by lo.x
+      unsigned hitrow[K16_MAX_GEOM];  // bit b of row a: geoms a < b overlap (AABB) and may collide
+      int plist[K16_MAX_PAIR];    // overlapping pairs g1 | g2 << 8 (plane first), in the order of the static list
+      int npl, nnp, pad0, pad1;
+    } sap;
+  };
   float snorm[G][4];
 };
+static_assert(sizeof(((ColScratch*)nullptr)->sap) <= sizeof(((ColScratch*)nullptr)->stage), "SAP scratch must fit under the staging area");
 struct ContactArrays {
   float cpos[MAXCON][4];          // pos, dist
   float cfrm[MAXCON][12];         // normal, t1, t2 (4-padded)
@@ -153,12 +163,15 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 // front of it (every launch-invariant value is otherwise saved before the loop and restored inside it).
 // VARIANT 0 = SINGLE (above); 1 = the step loop for rollouts (no per-stage / debug outputs and no separate observation
 // buffers: only packed rows), which keeps 11 pointers out of the scalar registers; 2 = everything.
-// CONVEX = the scene has sphere / capsule geoms: the closed-form plane cases and the lane-private GJK / MPR narrowphase
-// (mir_convex.h) are compiled in.  Scenes of planes and boxes only (the registered tasks) run the instantiations without
-// them, whose register allocation and schedule are therefore untouched by that code.
-template <int VARIANT, bool CONVEX>
+// FEAT bit 0 (CONVEX) = the scene has sphere / capsule geoms: the closed-form plane cases and the lane-private GJK / MPR
+// narrowphase (mir_convex.h) are compiled in.  FEAT bit 1 (SAP) = the candidate pairs come from a sweep-and-prune over the
+// geoms' world AABBs instead of the static pair list (scenes whose static list would exceed K16_MAX_PAIR, e.g. with
+// self-collision enabled).  Scenes of planes and boxes with a short static list run the instantiation without either, whose
+// register allocation and schedule are therefore untouched by that code.
+template <int VARIANT, int FEAT>
 __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   constexpr bool SINGLE = VARIANT == 0;
+  constexpr bool CONVEX = (FEAT & 1) != 0, SAP = (FEAT & 2) != 0;
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
   __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
   const DevModel* __restrict__ m = a.model;
@@ -501,13 +514,89 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     STAMP(11);
     int mycount = 0;
     if (enable_collision) {
-      // broadphase: bounding test per static candidate pair, ordered compaction of survivors
+      int npl = npair;  // pairs that reach the bounding test below
+      if constexpr (SAP) {
+        // ---- sweep and prune over world AABBs (two geoms per lane: g = lane, lane + 16) ----
+        // (a) AABB of every geom; planes are unbounded and are tested against every geom's AABB directly in (c)
+        for (int g = lane; g < ngeom; g += G) {
+          const int tg = T.g_info[g][1];
+          const V3 c = ld3v(S.col.gpos[g]), hz = ld3v(T.g_size[g]);
+          const M3 R = q2m(ld4v(S.col.gquat[g]));
+          V3 e = v3(hz.x, hz.x, hz.x);  // sphere
+          if (tg == MIR_GEOM_BOX) e = v3(fabsf(R.r0.x) * hz.x + fabsf(R.r0.y) * hz.y + fabsf(R.r0.z) * hz.z, fabsf(R.r1.x) * hz.x + fabsf(R.r1.y) * hz.y + fabsf(R.r1.z) * hz.z,
+                                         fabsf(R.r2.x) * hz.x + fabsf(R.r2.y) * hz.y + fabsf(R.r2.z) * hz.z);
+          else if (tg == MIR_GEOM_CAPSULE) e = v3(fabsf(R.r0.z) * hz.y + hz.x, fabsf(R.r1.z) * hz.y + hz.x, fabsf(R.r2.z) * hz.y + hz.x);
+          stv(S.col.sap.lo[g], f4{c.x - e.x, c.y - e.y, c.z - e.z, __int_as_float(tg)});
+          stv(S.col.sap.hi[g], f4{c.x + e.x, c.y + e.y, c.z + e.z, 0.0f});
+          S.col.sap.hitrow[g] = 0u;
+        }
+        WSYNC();
+        // (b) sort the bounded geoms by lo.x: the rank of a geom is the number of geoms in front of it (ties by index)
+        int nnp = 0;
+        for (int g = lane; g < ngeom; g += G) {
+          const f4 me = ldv(S.col.sap.lo[g]);
+          int rank = 0;
+          for (int h = 0; h < ngeom; h++) {
+            const f4 ot = ldv(S.col.sap.lo[h]);
+            if (__float_as_int(ot.w) != MIR_GEOM_PLANE && (ot.x < me.x || (ot.x == me.x && h < g))) rank++;
+          }
+          if (__float_as_int(me.w) != MIR_GEOM_PLANE) S.col.sap.order[rank] = g;
+        }
+        for (int h = 0; h < ngeom; h++) nnp += __float_as_int(S.col.sap.lo[h][3]) != MIR_GEOM_PLANE ? 1 : 0;
+        WSYNC();
+        // (c) sweep: the geom at sorted position p meets those behind it until one starts beyond its end
+        for (int p = lane; p < nnp; p += G) {
+          const int g = S.col.sap.order[p];
+          const f4 lg = ldv(S.col.sap.lo[g]), hg = ldv(S.col.sap.hi[g]);
+          const unsigned allow = T.g_allow[g];
+          for (int q = p + 1; q < nnp; q++) {
+            const int h = S.col.sap.order[q];
+            const f4 lh = ldv(S.col.sap.lo[h]);
+            if (lh.x > hg.x) break;
+            const f4 hh = ldv(S.col.sap.hi[h]);
+            if ((allow >> h & 1u) && lh.y <= hg.y && lg.y <= hh.y && lh.z <= hg.z && lg.z <= hh.z)
+              atomicOr(&S.col.sap.hitrow[g < h ? g : h], 1u << (g < h ? h : g));
+          }
+          // unbounded geoms (planes): the AABB's lowest corner along the plane normal
+          for (int pl = 0; pl < ngeom; pl++)
+            if (T.g_info[pl][1] == MIR_GEOM_PLANE && (allow >> pl & 1u)) {
+              const V3 n = mcol(q2m(ld4v(S.col.gquat[pl])), 2), pp = ld3v(S.col.gpos[pl]);
+              const V3 low = v3(n.x >= 0.0f ? lg.x : hg.x, n.y >= 0.0f ? lg.y : hg.y, n.z >= 0.0f ? lg.z : hg.z);
+              if (dot(low - pp, n) < 0.0f) atomicOr(&S.col.sap.hitrow[g < pl ? g : pl], 1u << (g < pl ? pl : g));
+            }
+        }
+        WSYNC();
+        // (d) the overlapping pairs in the order of the static list (lower geom index, then higher), plane first in a pair
+        int off = 0;
+        for (int r0 = 0; r0 < ngeom; r0 += G) {
+          const int r = r0 + lane;
+          unsigned bits = r < ngeom ? S.col.sap.hitrow[r] : 0u;
+          float inc = (float)__popc(bits);
+          const float cnt = inc;
+          inc += row_shr<1>(inc);
+          inc += row_shr<2>(inc);
+          inc += row_shr<4>(inc);
+          inc += row_shr<8>(inc);
+          int k = off + (int)(inc - cnt);
+          off += (int)row_bcast<15>(inc);
+          while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1u;
+            if (k < K16_MAX_PAIR) S.col.sap.plist[k] = T.g_info[b][1] == MIR_GEOM_PLANE ? (b | r << 8) : (r | b << 8);
+            k++;
+          }
+        }
+        npl = off < K16_MAX_PAIR ? off : K16_MAX_PAIR;
+        WSYNC();
+      }
+      // broadphase: bounding test per candidate pair (static list, or the sweep's survivors), ordered compaction
       int base = 0;
-      for (int p0 = 0; p0 < npair; p0 += G) {
+      for (int p0 = 0; p0 < npl; p0 += G) {
         int p = p0 + lane;
         bool hit = false;
-        if (p < npair) {
-          const int pr = T.pair[p];
+        int pr = 0;
+        if (p < npl) {
+          pr = SAP ? S.col.sap.plist[p] : T.pair[p];
           const int g1 = pr & 255, g2 = pr >> 8;
           V3 h2 = ld3v(T.g_size[g2]);
           M3 R2 = q2m(ld4v(S.col.gquat[g2]));
@@ -544,7 +633,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         unsigned long long bal = __ballot(hit);
         uint32_t gm = (uint32_t)(bal >> (grp * G)) & 0xffffu;
         int pos = base + __popc(gm & ((1u << lane) - 1u));
-        if (hit && pos < G) S.col.cand[pos] = p;
+        if (hit && pos < G) S.col.cand[pos] = pr;  // (the pair itself, g1 | g2 << 8)
         base += __popc(gm);
       }
       const int ncand = base < G ? base : G;
@@ -556,7 +645,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       for (int k = 0; k < G; k++) {
         const bool act = k < ncand;
         if (!__any(act)) break;
-        const int pr = act ? T.pair[S.col.cand[k]] : 0;
+        const int pr = act ? S.col.cand[k] : 0;
         const int g1 = pr & 255, g2 = pr >> 8;
         const bool isplane = act && T.g_info[g1][1] == MIR_GEOM_PLANE && (!CONVEX || T.g_info[g2][1] == MIR_GEOM_BOX);
         if (!__any(isplane)) continue;
@@ -599,7 +688,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       for (int k = 0; k < G; k++) {
         const bool act = k < ncand;
         if (!__any(act)) break;
-        const int pr = act ? T.pair[S.col.cand[k]] : 0;
+        const int pr = act ? S.col.cand[k] : 0;
         const int g1 = pr & 255, g2 = pr >> 8;
         const bool isbox = act && T.g_info[g1][1] != MIR_GEOM_PLANE && (!CONVEX || (T.g_info[g1][1] == MIR_GEOM_BOX && T.g_info[g2][1] == MIR_GEOM_BOX));
         if (!__any(isbox)) continue;
@@ -616,7 +705,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         // (one / two points at half depth), every other pair that is not box - box through GJK on the cores, MPR when the
         // cores overlap (mir_convex.h).  Lanes diverge here and reconverge at the end of the block.
         if (lane < ncand) {
-          const int pr = T.pair[S.col.cand[lane]];
+          const int pr = S.col.cand[lane];
           const int g1 = pr & 255, g2 = pr >> 8;
           const int t1 = T.g_info[g1][1], t2 = T.g_info[g2][1];
           if (t1 == MIR_GEOM_PLANE && (t2 == MIR_GEOM_SPHERE || t2 == MIR_GEOM_CAPSULE)) {
@@ -680,7 +769,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         const int k = lane;
         const int mp = S.col.cmap[k];
         const int cl = mp >> 3, ci = mp & 7;
-        const int pr = T.pair[S.col.cand[cl]];
+        const int pr = S.col.cand[cl];
         const int g1 = pr & 255, g2 = pr >> 8;
         const V3 n = ld3v(S.col.snorm[cl]);
         V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
@@ -1196,12 +1285,17 @@ extern "C" int mir_launch_debug_convex(const float* in, float* out, int n, hipSt
 // -ffp-contract=on that flag miscompiles the support-mapping selects of mir_convex.h -- box pairs lose contacts -- while the
 // planes-and-boxes kernels gain 1 % from it).
 #ifdef MIR_STEP_CONVEX_TU
+template <int FEAT>
+static void launch_feat(const StepArgs& a, int blocks, int single, int plain_loop, hipStream_t stream) {
+  if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
+  else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
+}
 extern "C" int mir_launch_step_convex(const StepArgs* args, int single, int plain_loop, hipStream_t stream) {
   StepArgs a = *args;
   const int blocks = (a.B + EPB - 1) / EPB;
-  if (single) hipLaunchKernelGGL((mir_step_kernel<0, true>), dim3(blocks), dim3(64), 0, stream, a);
-  else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, true>), dim3(blocks), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL((mir_step_kernel<2, true>), dim3(blocks), dim3(64), 0, stream, a);
+  if (a.features & 2) launch_feat<3>(a, blocks, single, plain_loop, stream);  // sweep-and-prune scenes carry the convex code too
+  else launch_feat<1>(a, blocks, single, plain_loop, stream);
   return (int)hipGetLastError();
 }
 #else
@@ -1214,10 +1308,10 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.poses;
   const bool plain_loop = a.mode == 0 && !a.poses && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
                           !a.env_state && !a.reward && !a.terminated && !a.term_host && !a.done_ticket;
-  if (a.convex) return mir_launch_step_convex(&a, single, plain_loop, stream);
-  if (single) hipLaunchKernelGGL((mir_step_kernel<0, false>), dim3(blocks), dim3(64), 0, stream, a);
-  else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, false>), dim3(blocks), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL((mir_step_kernel<2, false>), dim3(blocks), dim3(64), 0, stream, a);
+  if (a.features) return mir_launch_step_convex(&a, single, plain_loop, stream);
+  if (single) hipLaunchKernelGGL((mir_step_kernel<0, 0>), dim3(blocks), dim3(64), 0, stream, a);
+  else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, 0>), dim3(blocks), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((mir_step_kernel<2, 0>), dim3(blocks), dim3(64), 0, stream, a);
   return (int)hipGetLastError();
 }
 #endif
