@@ -304,6 +304,16 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     m.b_submask[b] = sub;
   }
 
+  // The tree scans of the step kernel need (a) bodies numbered in depth-first preorder: the subtree of body b is the lane
+  // range [b, b + size), and (b) every ancestor set to be a prefix of a dof chain (true by construction above).  A scene
+  // whose bodies are not in preorder goes to the wave-per-env kernel, which makes no such assumption.
+  for (int b = 1; b < nb; b++) {
+    int size = 0;
+    for (int c = 0; c < nb; c++) size += (m.b_submask[b] >> c & 1u) ? 1 : 0;
+    const uint32_t range = (size >= 32 ? 0xffffffffu : ((1u << size) - 1u)) << b;
+    if (m.b_submask[b] != range) return fail(err, MIR_E_CAPACITY, "bodies are not numbered in depth-first preorder");
+  }
+
   // ---- dof parameters -------------------------------------------------------------------
   int nu = 0;
   for (int i = 0; i < nv; i++) {
@@ -442,6 +452,22 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     k.d_damping = m.d_damping[l]; k.d_kp = m.d_kp[l]; k.d_kv = m.d_kv[l]; k.d_frclo = m.d_frclo[l]; k.d_frchi = m.d_frchi[l];
     k.d_mdiag = m.d_mdiag[l];
     k.obs_qadr = (l >= 7 && l < 7 + m.n_grip) ? m.grip_qadr[l - 7] : 0;
+    {  // links of the tree scans (mir_step.hip): all derived from the masks above
+      auto top = [](uint32_t mk) { int t = -1; for (int i = 0; i < 32; i++) if (mk >> i & 1u) t = i; return t; };
+      int d_par = -1, d_bef = -1, b_last = -1, b_next = MIR_G;
+      if (l < nv) {
+        d_par = top(m.d_ancmask[l] & ~(1u << l));   // the dof in front of this one on its chain
+        d_bef = top(m.d_premask[l]);                 // whose inclusive sum is the velocity "before" this dof
+        // (both are prefixes of the chain: premask / ancmask are the chain up to that dof -- checked below)
+      }
+      if (l > 0 && l < nb) {
+        b_last = top(m.b_dofmask[l]);
+        int size = 0;
+        for (int c = 0; c < nb; c++) size += (m.b_submask[l] >> c & 1u) ? 1 : 0;
+        b_next = l + size;
+      }
+      k.scan = (d_par & 255) | ((d_bef & 255) << 8) | ((b_last & 255) << 16) | ((b_next & 255) << 24);
+    }
   }
   return MIR_OK;
 }

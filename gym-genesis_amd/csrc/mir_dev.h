@@ -111,6 +111,10 @@ template <int N>
 __device__ __forceinline__ float row_shr(float v) {  // lane i reads lane i-N of its row, 0 shifted in
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
 }
+template <int N>
+__device__ __forceinline__ float row_shl(float v) {  // lane i reads lane i+N of its row, 0 shifted in
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float gsum(float v) {  // all-reduce sum over the row
   v += row_ror<1>(v);
   v += row_ror<2>(v);

@@ -56,7 +56,8 @@ struct LaneK16 {
   float d_axis[3]; uint32_t d_submask;
   uint32_t d_premask, d_ancmask; int32_t d_limited /* limited && enable_joint_limit && dof exists */; float d_damping;
   float d_kp, d_kv, d_frclo, d_frchi;
-  float d_mdiag; int32_t obs_qadr /* qpos address behind agent_pos column `lane` (gripper columns), else 0 */, pad0, pad1;
+  float d_mdiag; int32_t obs_qadr /* qpos address behind agent_pos column `lane` (gripper columns), else 0 */;
+  int32_t scan /* bytes: d_par, d_bef, b_last (signed, -1 = none), b_next (lane behind the body's subtree, 16 = none) */, pad1;
 };
 static_assert(sizeof(LaneK16) == 12 * 16, "LaneK16 is read as twelve 16-byte quantities");
 

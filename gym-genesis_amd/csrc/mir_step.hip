@@ -41,6 +41,9 @@
 #include "mir_dev.h"
 #include "mir_convex.h"
 #define EPB 4       /* envs per block */
+#ifndef MIR_TREE_SCAN
+#define MIR_TREE_SCAN 1 /* tree recursions of the dynamics as scans (pointer jumping + DPP suffix sums); 0 = masked gathers */
+#endif
 #define MAXCON K16_MAX_CONTACT
 #define JST 52      /* floats per contact in Jb: 3 rows x 16 + 4 pad -> conflict-free ds_read_b128 across contact lanes */
 #define MSTR 20     /* row stride of M in LDS (floats): 16-byte aligned rows, conflict-free b128 row reads */
@@ -235,6 +238,11 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   const bool d_limited = __float_as_int(lk[9].z) != 0;
   const float d_damping = lk[9].w, d_kp = lk[10].x, d_kv = lk[10].y, d_frclo = lk[10].z, d_frchi = lk[10].w, d_mdiag = lk[11].x;
   const int obs_qadr = __float_as_int(lk[11].y);
+  // tree-scan links (mir_compile.cpp): scan parent of the dof, the dof whose inclusive sum is the velocity in front of this
+  // dof, the last dof that moves this body, the lane behind this body's subtree (bytes of one word; 255 = none)
+  const int scanw = __float_as_int(lk[11].z);
+  const int d_par = (int)(signed char)(scanw & 255), d_bef = (int)(signed char)(scanw >> 8 & 255);
+  const int b_last = (int)(signed char)(scanw >> 16 & 255), b_next = scanw >> 24 & 255;
 
   // ---- load state -----------------------------------------------------------------------------
   // (addresses from the launch arguments only: these loads leave together with the model loads above)
@@ -270,10 +278,17 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   // algorithmic traffic).
   STAMP(0);
   group_fk(S, lane, nb, parents, bk);
+#ifdef MIR_EXP_FK2
+  group_fk(S, lane, nb, parents, bk);
+#endif
   STAMP(1);
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
   if (VARIANT != 2) a.poses = nullptr;
-  if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; }
+  if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr;
+#ifndef MIR_PROFILE_SINGLE  /* (a profiling build keeps the phase stamps in the single-step instantiation: tools/phase_profile.py) */
+    a.prof = nullptr;
+#endif
+  }
   if (VARIANT == 1) { a.mode = 0; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; a.agent_pos = a.env_state = a.reward = nullptr; a.terminated = a.term_host = nullptr; a.done_ticket = nullptr; }
   // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
   const int eb = mdl_eef, ob = mdl_obj;
@@ -341,7 +356,148 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       stv(c, f4{0, 0, 0, 0}); stv(c + 4, f4{0, 0, 0, 0}); stv(c + 8, f4{0, 0, 0, 0});
     }
     WSYNC();
-
+    STAMP(32);
+#if MIR_TREE_SCAN
+    // ======================= velocities, composite inertias, body forces: tree SCANS =============
+    // Sums over the ancestors of a dof are inclusive prefix sums along its dof chain: POINTER JUMPING over the chain's parent
+    // links (<= 4 rounds of one LDS exchange each, as in the FK) instead of a masked gather per lane and per quantity.  Sums over
+    // the subtree of a body are suffix sums over the body lanes -- bodies are numbered in depth-first preorder, so a subtree is
+    // the lane range [b, b_next) -- formed by four DPP row shifts per component and one subtraction (distal bodies sit at the
+    // end of the row, so the subtraction never takes a small subtree out of a large total).
+    float qfrc_bias = 0.0f, qfs = 0.0f;
+    {
+      // ancestor scan of a 6-vector held by the dof lanes; the result table (inclusive sums, by dof lane) is left in `tab`
+      auto ancestor_scan = [&](V3& A, V3& Bv, float* tab) {
+        int p = isdof ? d_par : -1;
+#pragma unroll 1
+        for (int round = 0; round < 4; round++) {
+          if (!__any(p >= 0)) break;
+          stv(tab + 8 * lane, f4{A.x, A.y, A.z, __int_as_float(p)});
+          st3v(tab + 8 * lane + 4, Bv);
+          WSYNC();
+          if (p >= 0) {
+            const f4 xa = ldv(tab + 8 * p), xb = ldv(tab + 8 * p + 4);
+            A = A + v3(xa.x, xa.y, xa.z);
+            Bv = Bv + v3(xb.x, xb.y, xb.z);
+            p = __float_as_int(xa.w);
+          }
+          WSYNC();
+        }
+        st3v(tab + 8 * lane, A);
+        st3v(tab + 8 * lane + 4, Bv);
+        WSYNC();
+      };
+      const V3 cw = ld3v(&S.cdof[lane][0]), cv = ld3v(&S.cdof[lane][4]);
+      const float qd = isdof ? S.qvel[lane] : 0.0f;
+      // (1) V_i = sum over the dof chain up to and including i of qvel_j cdof_j
+      V3 Vw = isdof ? qd * cw : v3(0, 0, 0), Vv = isdof ? qd * cv : v3(0, 0, 0);
+      ancestor_scan(Vw, Vv, &S.dyn.cvel[0][0]);
+      STAMP(33);
+      // cdof_dot * qvel from the velocity in front of the dof; body velocity = V at the last dof that moves the body
+      V3 Yw = v3(0, 0, 0), Yv = v3(0, 0, 0);
+      if (isdof) {
+        V3 pw = v3(0, 0, 0), pv = v3(0, 0, 0);
+        if (d_bef >= 0) { pw = ld3v(&S.dyn.cvel[d_bef][0]); pv = ld3v(&S.dyn.cvel[d_bef][4]); }
+        Yw = qd * cross(pw, cw);
+        Yv = qd * (cross(pw, cv) + cross(pv, cw));
+      }
+      V3 w = v3(0, 0, 0), v = v3(0, 0, 0);
+      if (isbody && b_last >= 0) { w = ld3v(&S.dyn.cvel[b_last][0]); v = ld3v(&S.dyn.cvel[b_last][4]); }
+      // (2) composite inertia: suffix sums of the body inertias over the row, minus the suffix behind the subtree
+      {
+        float* ci = S.dyn.cinert[lane];
+        f4 c0 = ldv(ci), c1 = ldv(ci + 4), c2 = ldv(ci + 8);
+        float comp[10] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y};
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+          float t = comp[k];
+          t += row_shl<1>(t); t += row_shl<2>(t); t += row_shl<4>(t); t += row_shl<8>(t);
+          comp[k] = t;
+        }
+        float* cs = S.dyn.crb[lane];
+        stv(cs, f4{comp[0], comp[1], comp[2], comp[3]}); stv(cs + 4, f4{comp[4], comp[5], comp[6], comp[7]}); stv(cs + 8, f4{comp[8], comp[9], 0.0f, 0.0f});
+        WSYNC();
+        f4 e0 = {0, 0, 0, 0}, e1 = e0, e2 = e0;
+        if (b_next < G) { const float* ce = S.dyn.crb[b_next]; e0 = ldv(ce); e1 = ldv(ce + 4); e2 = ldv(ce + 8); }
+        WSYNC();
+        const bool own = isbody;
+        stv(cs, own ? f4{comp[0] - e0.x, comp[1] - e0.y, comp[2] - e0.z, comp[3] - e0.w} : f4{0, 0, 0, 0});
+        stv(cs + 4, own ? f4{comp[4] - e1.x, comp[5] - e1.y, comp[6] - e1.z, comp[7] - e1.w} : f4{0, 0, 0, 0});
+        stv(cs + 8, own ? f4{comp[8] - e2.x, comp[9] - e2.y, 0.0f, 0.0f} : f4{0, 0, 0, 0});
+      }
+      STAMP(2);
+      // (3) A_i = sum over the dof chain of cdof_dot_j qvel_j; body forces at zero acceleration (RNE)
+      ancestor_scan(Yw, Yv, &S.dyn.cddq[0][0]);
+      STAMP(34);
+      V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
+      if (isbody) {
+        V3 aw = v3(0, 0, 0), av = v3(-mdl_gx, -mdl_gy, -mdl_gz);
+        if (b_last >= 0) { aw = aw + ld3v(&S.dyn.cddq[b_last][0]); av = av + ld3v(&S.dyn.cddq[b_last][4]); }
+        Inert I = ldI(S.dyn.cinert[lane]);
+        V3 ta, fa, tv, fv;
+        imul(I, aw, av, ta, fa);
+        imul(I, w, v, tv, fv);
+        t = ta + cross(w, tv) + cross(v, fv);
+        f = fa + cross(w, fv);
+      }
+      // zero this lane's row of M, then (after the fence) fill the tree-sparse entries
+#pragma unroll
+      for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{0, 0, 0, 0});
+      // (4) subtree forces: suffix sums again
+      {
+        float comp[6] = {t.x, t.y, t.z, f.x, f.y, f.z};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          float u = comp[k];
+          u += row_shl<1>(u); u += row_shl<2>(u); u += row_shl<4>(u); u += row_shl<8>(u);
+          comp[k] = u;
+        }
+        float* fs = S.dyn.cfrc[lane];
+        st3v(fs, v3(comp[0], comp[1], comp[2])); st3v(fs + 4, v3(comp[3], comp[4], comp[5]));
+        WSYNC();
+        V3 et = v3(0, 0, 0), ef = v3(0, 0, 0);
+        if (b_next < G) { et = ld3v(&S.dyn.cfrc[b_next][0]); ef = ld3v(&S.dyn.cfrc[b_next][4]); }
+        WSYNC();
+        st3v(fs, v3(comp[0], comp[1], comp[2]) - et);
+        st3v(fs + 4, v3(comp[3], comp[4], comp[5]) - ef);
+      }
+      WSYNC();
+      STAMP(35);
+      if (isdof) {  // M[i][j] = cdof_j . (crb_body(i) cdof_i), j over ancestors-or-self
+        Inert I = ldI(S.dyn.crb[d_body]);
+        V3 bt, bf;
+        imul(I, cw, cv, bt, bf);
+        uint32_t mk = d_ancmask;
+        while (mk) {  // four ancestors per trip, reads batched
+          int j[4];
+          bool ok[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { ok[u] = mk != 0u; j[u] = ok[u] ? __ffs(mk) - 1 : 0; mk &= mk - 1u; }
+          f4 ca[4], cl[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { ca[u] = ldv(&S.cdof[j[u]][0]); cl[u] = ldv(&S.cdof[j[u]][4]); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (ok[u]) {
+              float val = dot(v3(ca[u].x, ca[u].y, ca[u].z), bt) + dot(v3(cl[u].x, cl[u].y, cl[u].z), bf);
+              if (j[u] == lane) val += d_mdiag;
+              S.M[lane][j[u]] = val;
+              S.M[j[u]][lane] = val;
+            }
+        }
+        // bias = cdof . (forces of the subtree of the dof's body); smooth force
+        const V3 ft = ld3v(&S.dyn.cfrc[d_body][0]), ff = ld3v(&S.dyn.cfrc[d_body][4]);
+        qfrc_bias = dot(cw, ft) + dot(cv, ff);
+        float fa = 0.0f;
+        if (d_ctrl == MIR_CTRL_POSITION) {
+          fa = d_kp * (S.target[lane] - S.qpos[d_qadr]) - d_kv * qd;
+          fa = fminf(fmaxf(fa, d_frclo), d_frchi);
+        }
+        qfs = -d_damping * qd + fa - qfrc_bias;
+      }
+    }
+#else
     // ======================= velocities, composite inertias =====================================
     {
       // sum of qvel_j * cdof_j over the dofs of a mask, four per trip with the reads of the trip issued together (the masks
@@ -475,6 +631,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       }
       qfs = -d_damping * qd + fa - qfrc_bias;
     }
+#endif
     WSYNC();
     STAMP(3);
     // qacc_smooth = Mt^-1 qfrc_smooth: Gauss-Jordan on register rows
@@ -1304,7 +1461,12 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   StepArgs a = *args;
   int blocks = (a.B + EPB - 1) / EPB;
   (void)max_contacts_lds;
-  const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !a.prof && !a.out_M && !a.out_bias &&
+#ifdef MIR_PROFILE_SINGLE
+  const bool prof_blocks_single = false;
+#else
+  const bool prof_blocks_single = a.prof != nullptr;
+#endif
+  const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !prof_blocks_single && !a.out_M && !a.out_bias &&
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.poses;
   const bool plain_loop = a.mode == 0 && !a.poses && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
                           !a.env_state && !a.reward && !a.terminated && !a.term_host && !a.done_ticket;

@@ -61,13 +61,14 @@ def main():
     sc.lib.mir_debug_profile_step.restype = C.c_int
     acc = np.zeros(10)
     sub = np.zeros(7)
+    dyn = np.zeros(6)
     nw = np.zeros(8)
     ex = np.zeros(6)
     n = 20
     wall = []
     for k in range(n):
         sc.set_pd_targets(acts[k % 64])
-        prof = torch.zeros(32, dtype=torch.int64, device=sc.device)
+        prof = torch.zeros(64, dtype=torch.int64, device=sc.device)
         prof[29] = 2**62
         sc._check(sc.lib.mir_debug_profile_step(sc.h, C.c_void_p(prof.data_ptr()), sc._stream()))
         p = prof.cpu().numpy().astype(np.float64)
@@ -75,17 +76,20 @@ def main():
         wall.append(((p[27]-p[26])/100.0, (p[28]-p[26])/100.0, (p[29]-p[26])/100.0, (p[25]-p[24])))
         nw += np.array([p[16]-p[7], p[17]-p[16], p[14]-p[17], p[18]-p[14], p[15]-p[18], p[19]-p[15], p[20]-p[19], p[21]-p[20]])
         ex += np.array([p[22]-p[13], p[23]-p[22], p[5]-p[23], p[0]-p[24], p[25]-p[10], p[25]-p[24]])
+        dyn += np.array([p[32]-p[1], p[33]-p[32], p[2]-p[33], p[34]-p[2], p[35]-p[34], p[3]-p[35]])
         sub += np.array([p[11]-p[4], p[12]-p[11], p[13]-p[12], p[5]-p[13], p[14]-p[7], p[15]-p[14], p[8]-p[15]])
     acc /= n
     nw /= n
     ex /= n
     sub /= n
+    dyn /= n
     print(f"B={B}: phase cycles (block 0, shader clock; avg of {n} steps)")
     for name, c in zip(PHASES, acc):
         print(f"  {name:14s} {c:9.0f} cyc  {100 * c / acc.sum():5.1f}%")
     print(f"  total          {acc.sum():9.0f} cyc")
     w = np.array(wall)
     print("  wall clock (us from block-0 entry): block-0 exit %.1f | first block exit %.1f | LAST block exit %.1f (per-step max %.1f) ; block-0 cycles/us = %.0f MHz" % (w[:,0].mean(), w[:,2].mean(), w[:,1].mean(), w[:,1].max(), (w[:,3]/w[:,0]).mean()))
+    print("  dynamics split: cdof+cinert %.0f | velocity scan %.0f | cddq+cvel+crb suffix %.0f | acc scan %.0f | RNE+force suffix %.0f | M fill+bias %.0f" % tuple(dyn))
     print("  collide split: geoms %.0f | broadphase %.0f | narrowphase %.0f | compaction+contacts %.0f" % (sub[0], sub[1], sub[2], sub[3]))
     print("  newton it0 split: forces+H build %.0f | gsum+GJ %.0f | rest of iteration(s) %.0f" % (sub[4], sub[5], sub[6]))
     print("  compaction split: scan %.0f | per-candidate consts %.0f | contact writes %.0f ; prologue (entry->stamp0) %.0f | epilogue (stamp10->exit) %.0f | whole kernel %.0f" % (ex[0], ex[1], ex[2], ex[3], ex[4], ex[5]))
