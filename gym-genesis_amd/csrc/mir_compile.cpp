@@ -433,15 +433,41 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     for (int k = 0; k < 5; k++) t.d_lim[i][5 + k] = m.d_solimp[i][k];
   }
   // ---- per-lane register constants (LaneK16) and the packed parent links ---------------------
+  // FK links: the static transforms of FIXED bodies are folded into their children (double precision, once), so the pointer
+  // jumping of the kernel's FK walks only over jointed ancestors -- the Panda's finger is 8 links from the world instead of 10,
+  // three rounds instead of four.  (A fixed body itself keeps its parent: its pose is still needed.)
+  int fk_parent[MIR_G];
+  double fk_pos[MIR_G][3], fk_quat[MIR_G][4];
   m.parents = 0;
-  for (int b = 1; b < nb; b++) m.parents |= (uint64_t)(m.b_parent[b] & 15) << (4 * b);
+  for (int b = 1; b < nb; b++) {
+    const MirBodySpec& sb0 = sp->body[b];
+    int par = sb0.parent;
+    double pos[3] = {sb0.pos[0], sb0.pos[1], sb0.pos[2]}, q[4] = {sb0.quat[0], sb0.quat[1], sb0.quat[2], sb0.quat[3]};
+    while (par > 0 && sp->body[par].jtype == MIR_JNT_FIXED) {
+      const MirBodySpec& sp_ = sp->body[par];
+      const double w = sp_.quat[0], x = sp_.quat[1], y = sp_.quat[2], z = sp_.quat[3];
+      // pos <- p.pos + R(p.quat) pos
+      const double tx = 2 * (y * pos[2] - z * pos[1]), ty = 2 * (z * pos[0] - x * pos[2]), tz = 2 * (x * pos[1] - y * pos[0]);
+      const double rx = pos[0] + w * tx + (y * tz - z * ty), ry = pos[1] + w * ty + (z * tx - x * tz), rz = pos[2] + w * tz + (x * ty - y * tx);
+      pos[0] = sp_.pos[0] + rx; pos[1] = sp_.pos[1] + ry; pos[2] = sp_.pos[2] + rz;
+      // quat <- p.quat * quat
+      const double a = q[0], bq = q[1], c = q[2], d = q[3];
+      q[0] = w * a - x * bq - y * c - z * d; q[1] = w * bq + x * a + y * d - z * c;
+      q[2] = w * c - x * d + y * a + z * bq; q[3] = w * d + x * c - y * bq + z * a;
+      par = sp_.parent;
+    }
+    fk_parent[b] = par;
+    for (int k = 0; k < 3; k++) fk_pos[b][k] = pos[k];
+    for (int k = 0; k < 4; k++) fk_quat[b][k] = q[k];
+    m.parents |= (uint64_t)(par & 15) << (4 * b);
+  }
   for (int l = 0; l < MIR_G; l++) {
     LaneK16& k = m.lanek[l];
     memset(&k, 0, sizeof k);
     k.b_jtype = m.b_jtype[l]; k.b_qadr = m.b_qadr[l]; k.b_root = m.b_root[l];
     k.b_dofmask = m.b_dofmask[l]; k.b_submask = m.b_submask[l]; k.b_mass = m.b_mass[l];
-    for (int c = 0; c < 3; c++) { k.b_pos[c] = m.b_pos[l][c]; k.b_axis[c] = m.b_axis[l][c]; k.b_ipos[c] = m.b_ipos[l][c]; }
-    for (int c = 0; c < 4; c++) k.b_quat[c] = m.b_quat[l][c];
+    for (int c = 0; c < 3; c++) { k.b_pos[c] = (l > 0 && l < nb) ? (float)fk_pos[l][c] : m.b_pos[l][c]; k.b_axis[c] = m.b_axis[l][c]; k.b_ipos[c] = m.b_ipos[l][c]; }
+    for (int c = 0; c < 4; c++) k.b_quat[c] = (l > 0 && l < nb) ? (float)fk_quat[l][c] : m.b_quat[l][c];
     for (int c = 0; c < 6; c++) k.b_inertia[c] = m.b_inertia[l][c];
     const int db = l < nv ? m.d_body[l] : 0;
     k.d_body = db; k.d_kind = m.d_kind[l]; k.d_qadr = m.d_qadr[l]; k.d_axis_k = m.d_axis_k[l]; k.d_root = m.b_root[db];
