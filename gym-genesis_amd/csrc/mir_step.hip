@@ -751,7 +751,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
       for (int p0 = 0; p0 < npl; p0 += G) {
         int p = p0 + lane;
         bool hit = false;
-        int pr = 0;
+        int pr = 0, ptypes = 0;
         if (p < npl) {
           pr = SAP ? S.col.sap.plist[p] : T.pair[p];
           const int g1 = pr & 255, g2 = pr >> 8;
@@ -759,6 +759,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
           M3 R2 = q2m(ld4v(S.col.gquat[g2]));
           V3 c2 = ld3v(S.col.gpos[g2]);
           const int t1 = T.g_info[g1][1], t2 = T.g_info[g2][1];
+          ptypes = t1 | t2 << 8;
           if (t1 == MIR_GEOM_PLANE) {
             V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
             float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         unsigned long long bal = __ballot(hit);
         uint32_t gm = (uint32_t)(bal >> (grp * G)) & 0xffffu;
         int pos = base + __popc(gm & ((1u << lane) - 1u));
-        if (hit && pos < G) S.col.cand[pos] = pr;  // (the pair itself, g1 | g2 << 8)
+        if (hit && pos < G) S.col.cand[pos] = pr | ptypes << 16;  // (the pair itself with its geom types: g1 | g2 << 8 | t1 << 16 | t2 << 24)
         base += __popc(gm);
       }
       const int ncand = base < G ? base : G;
@@ -803,8 +804,8 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         const bool act = k < ncand;
         if (!__any(act)) break;
         const int pr = act ? S.col.cand[k] : 0;
-        const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isplane = act && T.g_info[g1][1] == MIR_GEOM_PLANE && (!CONVEX || T.g_info[g2][1] == MIR_GEOM_BOX);
+        const int g1 = pr & 255, g2 = pr >> 8 & 255;
+        const bool isplane = act && (pr >> 16 & 255) == MIR_GEOM_PLANE && (!CONVEX || (pr >> 24) == MIR_GEOM_BOX);
         if (!__any(isplane)) continue;
         const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
         const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
@@ -846,8 +847,8 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         const bool act = k < ncand;
         if (!__any(act)) break;
         const int pr = act ? S.col.cand[k] : 0;
-        const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isbox = act && T.g_info[g1][1] != MIR_GEOM_PLANE && (!CONVEX || (T.g_info[g1][1] == MIR_GEOM_BOX && T.g_info[g2][1] == MIR_GEOM_BOX));
+        const int g1 = pr & 255, g2 = pr >> 8 & 255;
+        const bool isbox = act && (pr >> 16 & 255) != MIR_GEOM_PLANE && (!CONVEX || ((pr >> 16 & 255) == MIR_GEOM_BOX && (pr >> 24) == MIR_GEOM_BOX));
         if (!__any(isbox)) continue;
         if (isbox) {  // whole rows
           const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
@@ -863,8 +864,8 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         // cores overlap (mir_convex.h).  Lanes diverge here and reconverge at the end of the block.
         if (lane < ncand) {
           const int pr = S.col.cand[lane];
-          const int g1 = pr & 255, g2 = pr >> 8;
-          const int t1 = T.g_info[g1][1], t2 = T.g_info[g2][1];
+          const int g1 = pr & 255, g2 = pr >> 8 & 255;
+          const int t1 = pr >> 16 & 255, t2 = pr >> 24;
           if (t1 == MIR_GEOM_PLANE && (t2 == MIR_GEOM_SPHERE || t2 == MIR_GEOM_CAPSULE)) {
             const V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2), pp = ld3v(S.col.gpos[g1]), pc = ld3v(S.col.gpos[g2]);
             const V3 sz = ld3v(T.g_size[g2]);
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
         const int mp = S.col.cmap[k];
         const int cl = mp >> 3, ci = mp & 7;
         const int pr = S.col.cand[cl];
-        const int g1 = pr & 255, g2 = pr >> 8;
+        const int g1 = pr & 255, g2 = pr >> 8 & 255;
         const V3 n = ld3v(S.col.snorm[cl]);
         V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
         t1 = t1 - dot(n, t1) * n;
