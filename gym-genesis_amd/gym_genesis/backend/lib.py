@@ -305,6 +305,12 @@ class MirScene(StepHelpers):
             self._check(rc)
         return pend[0]
 
+    def step_end_ptr(self, host_ptr: int) -> None:
+        """mir_step_end into a caller-provided host array (address): the flat fast path of GenesisEnv.step."""
+        rc = self.lib.mir_step_end(self.h, host_ptr)
+        if rc:
+            self._check(rc)
+
     def null_roundtrip_us(self, iters: int = 2000) -> float:
         """mir_debug_null_roundtrip: microseconds per empty-kernel launch + host-visible completion (the floor under env.step)."""
         out = C.c_double()

@@ -72,9 +72,12 @@ class OracleScene(StepHelpers):
         self._prepared = ptrs
 
     def step_go_ptr(self, action_ptr):
-        assert action_ptr == self._last_action.data_ptr()
+        import ctypes
+
+        # (the product passes addresses only; on the CPU double the action is read back from its address)
+        a = np.ctypeslib.as_array((ctypes.c_float * (self.num_envs * self.nu)).from_address(action_ptr)).reshape(self.num_envs, self.nu).copy()
         ptrs, self._prepared = self._prepared, None
-        self.step_begin(self._last_action, *self._by_ptr.pop(ptrs))
+        self.step_begin(torch.from_numpy(a), *self._by_ptr.pop(ptrs))
 
     def step_fused_ptrs(self, action_ptr, ptrs):
         assert action_ptr == self._last_action.data_ptr()
@@ -89,6 +92,12 @@ class OracleScene(StepHelpers):
         out, self._pending = self._pending.copy(), None
         self._host_pending = None
         return out
+
+    def step_end_ptr(self, host_ptr):
+        import ctypes
+
+        out = self.step_end()
+        ctypes.memmove(host_ptr, out.ctypes.data, out.nbytes)
 
     def step_packed(self, action, rows):
         bufs = (self.empty(self.agent_dim), self.empty(self.env_dim), self.empty(), self.empty(dtype=torch.uint8))
