@@ -3,6 +3,7 @@
 //
 // Everything is enqueued on the caller's HIP stream and nothing synchronises the device.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -597,7 +598,12 @@ __global__ void k_null_flag(uint32_t* flag, uint32_t seq) {
 }
 }  // namespace
 extern "C" int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* out_us) {
-  if (check(h) || !out_us || iters <= 0) return set_err(MIR_E_INVALID, "mir_debug_null_roundtrip: bad argument");
+  if (check(h) || !out_us) return set_err(MIR_E_INVALID, "mir_debug_null_roundtrip: bad argument");
+  // (experiment, iters < 0: the same round trip with other launch mechanisms -- -1: hipExtLaunchKernelGGL any-order, -2: a
+  // one-node graph relaunched with updated kernel parameters; |iters| is then 2000)
+  const int variant = iters < 0 ? -iters : 0;
+  if (iters < 0) iters = 2000;
+  if (iters <= 0) return set_err(MIR_E_INVALID, "mir_debug_null_roundtrip: bad argument");
   if (h->pending) return set_err(MIR_E_INVALID, "mir_debug_null_roundtrip: a step is pending");
   DeviceGuard guard(h->device);
   const size_t off = ((size_t)(h->B + 63) / 64) * 64;
@@ -606,9 +612,24 @@ extern "C" int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  hipGraphNode_t node = nullptr;
+  hipKernelNodeParams kp;
+  uint32_t gseq = 0;
+  void* kargs[2] = {&flag_dev, &gseq};
+  if (variant == 2) {
+    memset(&kp, 0, sizeof kp);
+    kp.func = (void*)k_null_flag; kp.gridDim = dim3(1); kp.blockDim = dim3(64); kp.kernelParams = kargs;
+    HIPCHK(hipGraphCreate(&graph, 0));
+    HIPCHK(hipGraphAddKernelNode(&node, graph, nullptr, 0, &kp));
+    HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+  }
   for (int i = 0; i < iters; i++) {
     const uint32_t seq = ++h->seq;
-    hipLaunchKernelGGL(k_null_flag, dim3(1), dim3(64), 0, (hipStream_t)stream, flag_dev, seq);
+    if (variant == 1) hipExtLaunchKernelGGL(k_null_flag, dim3(1), dim3(64), 0, (hipStream_t)stream, nullptr, nullptr, 1 /* hipExtAnyOrderLaunch */, flag_dev, seq);
+    else if (variant == 2) { gseq = seq; (void)hipGraphExecKernelNodeSetParams(gexec, node, &kp); (void)hipGraphLaunch(gexec, (hipStream_t)stream); }
+    else hipLaunchKernelGGL(k_null_flag, dim3(1), dim3(64), 0, (hipStream_t)stream, flag_dev, seq);
     unsigned long polls = 0;
     while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
       __builtin_ia32_pause();
@@ -616,6 +637,8 @@ extern "C" int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream
     }
   }
   clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (gexec) (void)hipGraphExecDestroy(gexec);
+  if (graph) (void)hipGraphDestroy(graph);
   HIPCHK(hipGetLastError());
   *out_us = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) * 1e-3 / iters;
   return MIR_OK;
