@@ -58,8 +58,10 @@ namespace {
 // per-env LDS working set (~8 KB).  Three phase-local scratch areas share storage:
 //   dyn  (FK .. smooth dynamics)   overlays   contact arrays + Jb
 //   col  (collision detection)     overlays   Jb
+struct FkScratch {
+  float lpos[G][4], lquat[G][4];  // pointer-jumping exchange of the forward kinematics (start and end of a step)
+};
 struct DynScratch {
-  float lpos[G][4], lquat[G][4];
   float cddq[G][8];               // cdof_dot * qvel: ang(3) pad lin(3) pad
   float cinert[G][12], crb[G][12];
   float cvel[G][8], cfrc[G][8];
@@ -79,6 +81,8 @@ struct ColScratch {
     } sap;
   };
   float snorm[G][4];
+  int count[G];                   // contact points found per candidate (handed from the collision wave to the main wave)
+  float clip[48];                 // polygon clipping scratch of the box-box routine (one row)
 };
 static_assert(sizeof(((ColScratch*)nullptr)->sap) <= sizeof(((ColScratch*)nullptr)->stage), "SAP scratch must fit under the staging area");
 struct ContactArrays {
@@ -95,17 +99,24 @@ struct EnvLds {
   float cdof[G][8];               // ang(3) pad lin(3) pad
   float M[G][MSTR];
   int ncon, ncand, pad0, pad1;
+  // Phase-aliased working set.  `dyn` (smooth dynamics) and `col` (collision detection) are live AT THE SAME TIME in the
+  // single-step instantiation, where a second wave of the workgroup detects collisions while the first one does the dynamics;
+  // the contact arrays and the contact Jacobians take the place of both afterwards (con never overlaps col: the contact
+  // finishing reads the staging area while it writes con; Jb does, and is written after col is dead).
   union {
-    DynScratch dyn;
+    FkScratch fk;
+    struct {
+      DynScratch dyn;
+      ColScratch col;
+    };
     struct {
       ContactArrays con;
-      union {
-        float Jb[MAXCON][JST];
-        ColScratch col;
-      };
+      float Jb[MAXCON][JST];
     };
   };
 };
+static_assert(sizeof(ContactArrays) <= sizeof(DynScratch), "the contact arrays must not reach the collision staging area");
+static_assert(EPB * sizeof(EnvLds) + sizeof(ModelTab) <= 40960, "four workgroups per CU: 160 KB of LDS / 4");
 
 // body-lane constants needed by forward kinematics
 struct BodyK {
@@ -141,12 +152,12 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 #pragma unroll 1
   for (int round = 0; round < 4; round++) {
     if (!__any(anc > 0)) break;
-    stv(S.dyn.lpos[lane], f4{P.x, P.y, P.z, __int_as_float(anc)});
-    st4v(S.dyn.lquat[lane], Qx);
+    stv(S.fk.lpos[lane], f4{P.x, P.y, P.z, __int_as_float(anc)});
+    st4v(S.fk.lquat[lane], Qx);
     WSYNC();
     if (anc > 0) {
-      const f4 pa = ldv(S.dyn.lpos[anc]);
-      const Q4 qa = ld4v(S.dyn.lquat[anc]);
+      const f4 pa = ldv(S.fk.lpos[anc]);
+      const Q4 qa = ld4v(S.fk.lquat[anc]);
       P = v3(pa.x, pa.y, pa.z) + qrot(qa, P);
       Qx = qmul(qa, Qx);
       anc = __float_as_int(pa.w);
@@ -171,14 +182,23 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 // geoms' world AABBs instead of the static pair list (scenes whose static list would exceed K16_MAX_PAIR, e.g. with
 // self-collision enabled).  Scenes of planes and boxes with a short static list run the instantiation without either, whose
 // register allocation and schedule are therefore untouched by that code.
+//
+// DUAL (the single-step instantiation): the workgroup has TWO waves.  Collision detection (geom poses, broadphase, narrowphase)
+// needs only the link poses, and so do the smooth dynamics (subspaces, CRB, RNE, mass matrix, smooth solve): wave 1 does the
+// former while wave 0 does the latter, in disjoint LDS areas, between two workgroup barriers.  At 4096 envs there is otherwise
+// ONE wave per SIMD that spends 60 % of its life waiting on LDS round trips; the second wave fills those slots and takes
+// ~5 k cycles out of the ~50 k of a step.  The step-loop instantiations keep one wave (they need the AGPRs a second wave
+// per SIMD would have to give up); both run the same detection code, so they agree bit for bit.
 template <int VARIANT, int FEAT>
-__global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
+__global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepArgs a) {
   constexpr bool SINGLE = VARIANT == 0;
+  constexpr bool DUAL = SINGLE;
   constexpr bool CONVEX = (FEAT & 1) != 0, SAP = (FEAT & 2) != 0;
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
   __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
   const DevModel* __restrict__ m = a.model;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 63;   // lane within the wave
+  const int wave = threadIdx.x >> 6;  // 0 = main wave; 1 = collision wave (DUAL only)
   STAMP(24);
   if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[26] = __builtin_amdgcn_s_memrealtime();
   // Prologue: EVERY global read of the launch -- model table, per-lane constants, state rows, action, cached poses -- is
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   // stores of one group sat in front of the loads of the next).
   constexpr int TAB_NQ = (int)(sizeof(ModelTab) / 16), TAB_NPASS = (TAB_NQ + 63) / 64;
   f4 tabtmp[TAB_NPASS];
-  {
+  if (!DUAL || wave == 1) {  // (DUAL: the collision wave brings the model table in while the main wave fetches the state)
     const f4* src = reinterpret_cast<const f4*>(&m->tab);
 #pragma unroll
     for (int k = 0; k < TAB_NPASS; k++) tabtmp[k] = src[min(tid + 64 * k, TAB_NQ - 1)];
@@ -208,6 +228,266 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   const float mdl_tolerance = m->tolerance, mdl_scale = m->solver_scale, mdl_reward_z = m->reward_z;
   const float mdl_gx = m->gx, mdl_gy = m->gy, mdl_gz = m->gz;
   const int mdl_eef = m->eef_body, mdl_obj = m->obj_body, mdl_ngrip = m->n_grip;
+
+  // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
+  // (lane = candidate).  Needs the link poses and the model table in LDS, nothing else: in the DUAL instantiation the second
+  // wave of the workgroup runs it while the first one does the smooth dynamics.
+  auto collide_detect = [&]() -> int {
+  if (lane == 0) { S.ncon = 0; S.ncand = 0; }
+  for (int g = lane; g < ngeom; g += G) {
+    int gb = T.g_info[g][0];
+    Q4 qb = ld4v(S.xquat[gb]);
+    st3v(S.col.gpos[g], ld3v(S.xpos[gb]) + qrot(qb, ld3v(T.g_pos[g])));
+    st4v(S.col.gquat[g], qmul(qb, ld4v(T.g_quat[g])));
+  }
+  WSYNC();
+  STAMP(11);
+  int mycount = 0;
+  if (enable_collision) {
+    int npl = npair;  // pairs that reach the bounding test below
+    if constexpr (SAP) {
+      // ---- sweep and prune over world AABBs (two geoms per lane: g = lane, lane + 16) ----
+      // (a) AABB of every geom; planes are unbounded and are tested against every geom's AABB directly in (c)
+      for (int g = lane; g < ngeom; g += G) {
+        const int tg = T.g_info[g][1];
+        const V3 c = ld3v(S.col.gpos[g]), hz = ld3v(T.g_size[g]);
+        const M3 R = q2m(ld4v(S.col.gquat[g]));
+        V3 e = v3(hz.x, hz.x, hz.x);  // sphere
+        if (tg == MIR_GEOM_BOX) e = v3(fabsf(R.r0.x) * hz.x + fabsf(R.r0.y) * hz.y + fabsf(R.r0.z) * hz.z, fabsf(R.r1.x) * hz.x + fabsf(R.r1.y) * hz.y + fabsf(R.r1.z) * hz.z,
+                                       fabsf(R.r2.x) * hz.x + fabsf(R.r2.y) * hz.y + fabsf(R.r2.z) * hz.z);
+        else if (tg == MIR_GEOM_CAPSULE) e = v3(fabsf(R.r0.z) * hz.y + hz.x, fabsf(R.r1.z) * hz.y + hz.x, fabsf(R.r2.z) * hz.y + hz.x);
+        stv(S.col.sap.lo[g], f4{c.x - e.x, c.y - e.y, c.z - e.z, __int_as_float(tg)});
+        stv(S.col.sap.hi[g], f4{c.x + e.x, c.y + e.y, c.z + e.z, 0.0f});
+        S.col.sap.hitrow[g] = 0u;
+      }
+      WSYNC();
+      // (b) sort the bounded geoms by lo.x: the rank of a geom is the number of geoms in front of it (ties by index)
+      int nnp = 0;
+      for (int g = lane; g < ngeom; g += G) {
+        const f4 me = ldv(S.col.sap.lo[g]);
+        int rank = 0;
+        for (int h = 0; h < ngeom; h++) {
+          const f4 ot = ldv(S.col.sap.lo[h]);
+          if (__float_as_int(ot.w) != MIR_GEOM_PLANE && (ot.x < me.x || (ot.x == me.x && h < g))) rank++;
+        }
+        if (__float_as_int(me.w) != MIR_GEOM_PLANE) S.col.sap.order[rank] = g;
+      }
+      for (int h = 0; h < ngeom; h++) nnp += __float_as_int(S.col.sap.lo[h][3]) != MIR_GEOM_PLANE ? 1 : 0;
+      WSYNC();
+      // (c) sweep: the geom at sorted position p meets those behind it until one starts beyond its end
+      for (int p = lane; p < nnp; p += G) {
+        const int g = S.col.sap.order[p];
+        const f4 lg = ldv(S.col.sap.lo[g]), hg = ldv(S.col.sap.hi[g]);
+        const unsigned allow = T.g_allow[g];
+        for (int q = p + 1; q < nnp; q++) {
+          const int h = S.col.sap.order[q];
+          const f4 lh = ldv(S.col.sap.lo[h]);
+          if (lh.x > hg.x) break;
+          const f4 hh = ldv(S.col.sap.hi[h]);
+          if ((allow >> h & 1u) && lh.y <= hg.y && lg.y <= hh.y && lh.z <= hg.z && lg.z <= hh.z)
+            atomicOr(&S.col.sap.hitrow[g < h ? g : h], 1u << (g < h ? h : g));
+        }
+        // unbounded geoms (planes): the AABB's lowest corner along the plane normal
+        for (int pl = 0; pl < ngeom; pl++)
+          if (T.g_info[pl][1] == MIR_GEOM_PLANE && (allow >> pl & 1u)) {
+            const V3 n = mcol(q2m(ld4v(S.col.gquat[pl])), 2), pp = ld3v(S.col.gpos[pl]);
+            const V3 low = v3(n.x >= 0.0f ? lg.x : hg.x, n.y >= 0.0f ? lg.y : hg.y, n.z >= 0.0f ? lg.z : hg.z);
+            if (dot(low - pp, n) < 0.0f) atomicOr(&S.col.sap.hitrow[g < pl ? g : pl], 1u << (g < pl ? pl : g));
+          }
+      }
+      WSYNC();
+      // (d) the overlapping pairs in the order of the static list (lower geom index, then higher), plane first in a pair
+      int off = 0;
+      for (int r0 = 0; r0 < ngeom; r0 += G) {
+        const int r = r0 + lane;
+        unsigned bits = r < ngeom ? S.col.sap.hitrow[r] : 0u;
+        float inc = (float)__popc(bits);
+        const float cnt = inc;
+        inc += row_shr<1>(inc);
+        inc += row_shr<2>(inc);
+        inc += row_shr<4>(inc);
+        inc += row_shr<8>(inc);
+        int k = off + (int)(inc - cnt);
+        off += (int)row_bcast<15>(inc);
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1u;
+          if (k < K16_MAX_PAIR) S.col.sap.plist[k] = T.g_info[b][1] == MIR_GEOM_PLANE ? (b | r << 8) : (r | b << 8);
+          k++;
+        }
+      }
+      npl = off < K16_MAX_PAIR ? off : K16_MAX_PAIR;
+      WSYNC();
+    }
+    // broadphase: bounding test per candidate pair (static list, or the sweep's survivors), ordered compaction
+    int base = 0;
+    for (int p0 = 0; p0 < npl; p0 += G) {
+      int p = p0 + lane;
+      bool hit = false;
+      int pr = 0, ptypes = 0;
+      if (p < npl) {
+        pr = SAP ? S.col.sap.plist[p] : T.pair[p];
+        const int g1 = pr & 255, g2 = pr >> 8;
+        V3 h2 = ld3v(T.g_size[g2]);
+        M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+        V3 c2 = ld3v(S.col.gpos[g2]);
+        const int t1 = T.g_info[g1][1], t2 = T.g_info[g2][1];
+        ptypes = t1 | t2 << 8;
+        if (t1 == MIR_GEOM_PLANE) {
+          V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
+          float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
+          if (CONVEX && t2 == MIR_GEOM_SPHERE) ext = h2.x;
+          if (CONVEX && t2 == MIR_GEOM_CAPSULE) ext = h2.y * fabsf(dot(n, mcol(R2, 2))) + h2.x;
+          hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
+        } else {
+          V3 h1 = ld3v(T.g_size[g1]);
+          // bounding spheres (box: half diagonal; sphere: radius; capsule: half length + radius -- T.g_size[.][3])
+          float rs = CONVEX ? T.g_size[g1][3] + T.g_size[g2][3] : sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
+          V3 dc = c2 - ld3v(S.col.gpos[g1]);
+          hit = dot(dc, dc) <= rs * rs;
+          if (hit && (!CONVEX || (t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX))) {
+            // the six face axes of the narrowphase's separating-axis test (same expressions): a pair they separate would
+            // come back with zero contacts, and the narrowphase takes the candidates of an env one after the other
+            const M3 R1 = q2m(ld4v(S.col.gquat[g1]));
+            const V3 A0 = mcol(R1, 0), A1 = mcol(R1, 1), A2 = mcol(R1, 2), B0 = mcol(R2, 0), B1 = mcol(R2, 1), B2 = mcol(R2, 2);
+            const V3 Ls[6] = {A0, A1, A2, B0, B1, B2};
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+              const V3 L = Ls[c];
+              const float ra = h1.x * fabsf(dot(A0, L)) + h1.y * fabsf(dot(A1, L)) + h1.z * fabsf(dot(A2, L));
+              const float rb = h2.x * fabsf(dot(B0, L)) + h2.y * fabsf(dot(B1, L)) + h2.z * fabsf(dot(B2, L));
+              if (fabsf(dot(dc, L)) - (ra + rb) > 0.0f) hit = false;
+            }
+          }
+        }
+      }
+      unsigned long long bal = __ballot(hit);
+      uint32_t gm = (uint32_t)(bal >> (grp * G)) & 0xffffu;
+      int pos = base + __popc(gm & ((1u << lane) - 1u));
+      if (hit && pos < G) S.col.cand[pos] = pr | ptypes << 16;  // (the pair itself with its geom types: g1 | g2 << 8 | t1 << 16 | t2 << 24)
+      base += __popc(gm);
+    }
+    const int ncand = base < G ? base : G;
+    if (lane == 0) S.ncand = ncand;
+    WSYNC();
+    STAMP(12);
+    // narrowphase, plane-box: one candidate at a time, its 8 box corners on lanes 0..7 of the group
+    // (wave-uniform loop: the DPP/ballot selection below needs all lanes present)
+    for (int k = 0; k < G; k++) {
+      const bool act = k < ncand;
+      if (!__any(act)) break;
+      const int pr = act ? S.col.cand[k] : 0;
+      const int g1 = pr & 255, g2 = pr >> 8 & 255;
+      const bool isplane = act && (pr >> 16 & 255) == MIR_GEOM_PLANE && (!CONVEX || (pr >> 24) == MIR_GEOM_BOX);
+      if (!__any(isplane)) continue;
+      const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
+      const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
+      const M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+      const V3 h = ld3v(T.g_size[g2]);
+      const int c = lane & 7;
+      const V3 w = ld3v(S.col.gpos[g2]) + ((c & 1) ? h.x : -h.x) * mcol(R2, 0) + ((c & 2) ? h.y : -h.y) * mcol(R2, 1) +
+                   ((c & 4) ? h.z : -h.z) * mcol(R2, 2);
+      const V3 rel = w - ld3v(S.col.gpos[g1]);
+      const float d = dot(rel, n), u = dot(rel, eu), v = dot(rel, ev);
+      const bool pen = isplane && lane < 8 && d < 0.0f;
+      const uint32_t penm = (uint32_t)(__ballot(pen) >> (grp * G)) & 0xffu;
+      const int cnt = __popc(penm);
+      // support extremes (+u, -u, +v, -v; lowest corner index wins ties), needed only when more than 4 corners penetrate
+      // somewhere in the wave (a box lying flat has exactly 4: the reductions are skipped)
+      uint32_t ext = 0u;
+      if (__any(cnt > 4)) {
+        const float uM = gmaxf(pen ? u : -3e38f), um = -gmaxf(pen ? -u : -3e38f);
+        const float vM = gmaxf(pen ? v : -3e38f), vm = -gmaxf(pen ? -v : -3e38f);
+        const uint32_t e0 = (uint32_t)(__ballot(pen && u == uM) >> (grp * G)) & 0xffu, e1 = (uint32_t)(__ballot(pen && u == um) >> (grp * G)) & 0xffu;
+        const uint32_t e2 = (uint32_t)(__ballot(pen && v == vM) >> (grp * G)) & 0xffu, e3 = (uint32_t)(__ballot(pen && v == vm) >> (grp * G)) & 0xffu;
+        ext = (e0 & -e0) | (e1 & -e1) | (e2 & -e2) | (e3 & -e3);
+      }
+      const uint32_t keepm = cnt <= 4 ? penm : ext;
+      const bool keep = (keepm >> lane & 1u) && lane < 8;
+      const int slot = __popc(keepm & ((1u << lane) - 1u));
+      if (keep && slot < 4) {
+        const V3 pos = w - (0.5f * d) * n;
+        stv(S.col.stage[k][slot], f4{pos.x, pos.y, pos.z, d});
+      }
+      if (lane == k && isplane) {
+        mycount = min(__popc(keepm), 4);
+        st3v(S.col.snorm[k], n);
+      }
+    }
+    // narrowphase, box-box: one candidate at a time on the whole row (box_box_row, mir_dev.h): the 15 separating axes
+    // on lanes 0..14, the incident-face vertices on lanes 0..3
+    for (int k = 0; k < G; k++) {
+      const bool act = k < ncand;
+      if (!__any(act)) break;
+      const int pr = act ? S.col.cand[k] : 0;
+      const int g1 = pr & 255, g2 = pr >> 8 & 255;
+      const bool isbox = act && (pr >> 16 & 255) != MIR_GEOM_PLANE && (!CONVEX || ((pr >> 16 & 255) == MIR_GEOM_BOX && (pr >> 24) == MIR_GEOM_BOX));
+      if (!__any(isbox)) continue;
+      if (isbox) {  // whole rows
+        const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
+        const BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
+        const BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
+        const int cnt = box_box_row(B1, B2, lane, tid, grp * G, S.col.stage[k], S.col.snorm[k], S.col.clip);
+        if (lane == k) mycount = cnt;
+      }
+    }
+    if constexpr (CONVEX) {
+      // narrowphase of the round shapes, LANE-PRIVATE: lane c takes candidate c.  Plane - sphere / capsule in closed form
+      // (one / two points at half depth), every other pair that is not box - box through GJK on the cores, MPR when the
+      // cores overlap (mir_convex.h).  Lanes diverge here and reconverge at the end of the block.
+      if (lane < ncand) {
+        const int pr = S.col.cand[lane];
+        const int g1 = pr & 255, g2 = pr >> 8 & 255;
+        const int t1 = pr >> 16 & 255, t2 = pr >> 24;
+        if (t1 == MIR_GEOM_PLANE && (t2 == MIR_GEOM_SPHERE || t2 == MIR_GEOM_CAPSULE)) {
+          const V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2), pp = ld3v(S.col.gpos[g1]), pc = ld3v(S.col.gpos[g2]);
+          const V3 sz = ld3v(T.g_size[g2]);
+          const float r = sz.x;
+          int cnt = 0;
+          if (t2 == MIR_GEOM_SPHERE) {
+            const float dist = dot(pc - pp, n) - r;
+            if (dist < 0.0f) { const V3 c = pc - (r + 0.5f * dist) * n; stv(S.col.stage[lane][0], f4{c.x, c.y, c.z, dist}); cnt = 1; }
+          } else {  // the two end spheres, axis - then axis +
+            const V3 ax = mcol(q2m(ld4v(S.col.gquat[g2])), 2);
+#pragma unroll
+            for (int sgn = -1; sgn <= 1; sgn += 2) {
+              const V3 e = pc + ((float)sgn * sz.y) * ax;
+              const float dist = dot(e - pp, n) - r;
+              if (dist < 0.0f) { const V3 c = e - (r + 0.5f * dist) * n; stv(S.col.stage[lane][cnt], f4{c.x, c.y, c.z, dist}); cnt++; }
+            }
+          }
+          if (cnt) st3v(S.col.snorm[lane], n);
+          mycount = cnt;
+        } else if (t1 != MIR_GEOM_PLANE && !(t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX)) {
+          const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
+          const ShapeD A = {t1, ld3v(T.g_size[g1]), ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2)};
+          const ShapeD B = {t2, ld3v(T.g_size[g2]), ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2)};
+          f4 pt;
+          V3 n;
+          if (convex_pair(A, B, pt, n)) {
+            stv(S.col.stage[lane][0], pt);
+            st3v(S.col.snorm[lane], n);
+            mycount = 1;
+          }
+        }
+      }
+    }
+  }
+    return mycount;
+  };
+  if (DUAL && wave == 1) {
+    {
+      f4* dst = reinterpret_cast<f4*>(&T);
+#pragma unroll
+      for (int k = 0; k < TAB_NPASS; k++)
+        if (tid + 64 * k < TAB_NQ) dst[tid + 64 * k] = tabtmp[k];
+    }
+    __syncthreads();  // (1) the model table is in LDS; the main wave has finished the FK of the launch's state
+    const int cnt = collide_detect();
+    S.col.count[lane] = cnt;
+    __syncthreads();  // (2) staging area and counts handed to the main wave
+    return;
+  }
 
   // ---- per-lane model constants (lane = body = dof): twelve independent 16-byte loads (LaneK16) -------------
   const bool isbody = lane < nb && lane > 0;
@@ -254,7 +534,7 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   float tg = a.action ? 0.0f : a.target[(size_t)env * G + lane];
   const float au = (a.action && lane < a.nu) ? a.action[(size_t)env * a.nu + lane] : 0.0f;
   __builtin_amdgcn_sched_barrier(0);  // (nothing below may move in front of the loads above)
-  {
+  if (!DUAL) {
     f4* dst = reinterpret_cast<f4*>(&T);
 #pragma unroll
     for (int k = 0; k < TAB_NPASS; k++)
@@ -278,10 +558,8 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
   // algorithmic traffic).
   STAMP(0);
   group_fk(S, lane, nb, parents, bk);
-#ifdef MIR_EXP_FK2
-  group_fk(S, lane, nb, parents, bk);
-#endif
   STAMP(1);
+  if (DUAL) __syncthreads();  // (1) link poses ready for the collision wave, model table ready for this one
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
   if (VARIANT != 2) a.poses = nullptr;
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr;
@@ -660,245 +938,13 @@ __global__ __launch_bounds__(64) void mir_step_kernel(StepArgs a) {
     STAMP(4);
 
     // ======================= collision detection ================================================
-    if (lane == 0) { S.ncon = 0; S.ncand = 0; }
-    for (int g = lane; g < ngeom; g += G) {
-      int gb = T.g_info[g][0];
-      Q4 qb = ld4v(S.xquat[gb]);
-      st3v(S.col.gpos[g], ld3v(S.xpos[gb]) + qrot(qb, ld3v(T.g_pos[g])));
-      st4v(S.col.gquat[g], qmul(qb, ld4v(T.g_quat[g])));
-    }
-    WSYNC();
-    STAMP(11);
-    int mycount = 0;
-    if (enable_collision) {
-      int npl = npair;  // pairs that reach the bounding test below
-      if constexpr (SAP) {
-        // ---- sweep and prune over world AABBs (two geoms per lane: g = lane, lane + 16) ----
-        // (a) AABB of every geom; planes are unbounded and are tested against every geom's AABB directly in (c)
-        for (int g = lane; g < ngeom; g += G) {
-          const int tg = T.g_info[g][1];
-          const V3 c = ld3v(S.col.gpos[g]), hz = ld3v(T.g_size[g]);
-          const M3 R = q2m(ld4v(S.col.gquat[g]));
-          V3 e = v3(hz.x, hz.x, hz.x);  // sphere
-          if (tg == MIR_GEOM_BOX) e = v3(fabsf(R.r0.x) * hz.x + fabsf(R.r0.y) * hz.y + fabsf(R.r0.z) * hz.z, fabsf(R.r1.x) * hz.x + fabsf(R.r1.y) * hz.y + fabsf(R.r1.z) * hz.z,
-                                         fabsf(R.r2.x) * hz.x + fabsf(R.r2.y) * hz.y + fabsf(R.r2.z) * hz.z);
-          else if (tg == MIR_GEOM_CAPSULE) e = v3(fabsf(R.r0.z) * hz.y + hz.x, fabsf(R.r1.z) * hz.y + hz.x, fabsf(R.r2.z) * hz.y + hz.x);
-          stv(S.col.sap.lo[g], f4{c.x - e.x, c.y - e.y, c.z - e.z, __int_as_float(tg)});
-          stv(S.col.sap.hi[g], f4{c.x + e.x, c.y + e.y, c.z + e.z, 0.0f});
-          S.col.sap.hitrow[g] = 0u;
-        }
-        WSYNC();
-        // (b) sort the bounded geoms by lo.x: the rank of a geom is the number of geoms in front of it (ties by index)
-        int nnp = 0;
-        for (int g = lane; g < ngeom; g += G) {
-          const f4 me = ldv(S.col.sap.lo[g]);
-          int rank = 0;
-          for (int h = 0; h < ngeom; h++) {
-            const f4 ot = ldv(S.col.sap.lo[h]);
-            if (__float_as_int(ot.w) != MIR_GEOM_PLANE && (ot.x < me.x || (ot.x == me.x && h < g))) rank++;
-          }
-          if (__float_as_int(me.w) != MIR_GEOM_PLANE) S.col.sap.order[rank] = g;
-        }
-        for (int h = 0; h < ngeom; h++) nnp += __float_as_int(S.col.sap.lo[h][3]) != MIR_GEOM_PLANE ? 1 : 0;
-        WSYNC();
-        // (c) sweep: the geom at sorted position p meets those behind it until one starts beyond its end
-        for (int p = lane; p < nnp; p += G) {
-          const int g = S.col.sap.order[p];
-          const f4 lg = ldv(S.col.sap.lo[g]), hg = ldv(S.col.sap.hi[g]);
-          const unsigned allow = T.g_allow[g];
-          for (int q = p + 1; q < nnp; q++) {
-            const int h = S.col.sap.order[q];
-            const f4 lh = ldv(S.col.sap.lo[h]);
-            if (lh.x > hg.x) break;
-            const f4 hh = ldv(S.col.sap.hi[h]);
-            if ((allow >> h & 1u) && lh.y <= hg.y && lg.y <= hh.y && lh.z <= hg.z && lg.z <= hh.z)
-              atomicOr(&S.col.sap.hitrow[g < h ? g : h], 1u << (g < h ? h : g));
-          }
-          // unbounded geoms (planes): the AABB's lowest corner along the plane normal
-          for (int pl = 0; pl < ngeom; pl++)
-            if (T.g_info[pl][1] == MIR_GEOM_PLANE && (allow >> pl & 1u)) {
-              const V3 n = mcol(q2m(ld4v(S.col.gquat[pl])), 2), pp = ld3v(S.col.gpos[pl]);
-              const V3 low = v3(n.x >= 0.0f ? lg.x : hg.x, n.y >= 0.0f ? lg.y : hg.y, n.z >= 0.0f ? lg.z : hg.z);
-              if (dot(low - pp, n) < 0.0f) atomicOr(&S.col.sap.hitrow[g < pl ? g : pl], 1u << (g < pl ? pl : g));
-            }
-        }
-        WSYNC();
-        // (d) the overlapping pairs in the order of the static list (lower geom index, then higher), plane first in a pair
-        int off = 0;
-        for (int r0 = 0; r0 < ngeom; r0 += G) {
-          const int r = r0 + lane;
-          unsigned bits = r < ngeom ? S.col.sap.hitrow[r] : 0u;
-          float inc = (float)__popc(bits);
-          const float cnt = inc;
-          inc += row_shr<1>(inc);
-          inc += row_shr<2>(inc);
-          inc += row_shr<4>(inc);
-          inc += row_shr<8>(inc);
-          int k = off + (int)(inc - cnt);
-          off += (int)row_bcast<15>(inc);
-          while (bits) {
-            const int b = __ffs(bits) - 1;
-            bits &= bits - 1u;
-            if (k < K16_MAX_PAIR) S.col.sap.plist[k] = T.g_info[b][1] == MIR_GEOM_PLANE ? (b | r << 8) : (r | b << 8);
-            k++;
-          }
-        }
-        npl = off < K16_MAX_PAIR ? off : K16_MAX_PAIR;
-        WSYNC();
-      }
-      // broadphase: bounding test per candidate pair (static list, or the sweep's survivors), ordered compaction
-      int base = 0;
-      for (int p0 = 0; p0 < npl; p0 += G) {
-        int p = p0 + lane;
-        bool hit = false;
-        int pr = 0, ptypes = 0;
-        if (p < npl) {
-          pr = SAP ? S.col.sap.plist[p] : T.pair[p];
-          const int g1 = pr & 255, g2 = pr >> 8;
-          V3 h2 = ld3v(T.g_size[g2]);
-          M3 R2 = q2m(ld4v(S.col.gquat[g2]));
-          V3 c2 = ld3v(S.col.gpos[g2]);
-          const int t1 = T.g_info[g1][1], t2 = T.g_info[g2][1];
-          ptypes = t1 | t2 << 8;
-          if (t1 == MIR_GEOM_PLANE) {
-            V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
-            float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
-            if (CONVEX && t2 == MIR_GEOM_SPHERE) ext = h2.x;
-            if (CONVEX && t2 == MIR_GEOM_CAPSULE) ext = h2.y * fabsf(dot(n, mcol(R2, 2))) + h2.x;
-            hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
-          } else {
-            V3 h1 = ld3v(T.g_size[g1]);
-            // bounding spheres (box: half diagonal; sphere: radius; capsule: half length + radius -- T.g_size[.][3])
-            float rs = CONVEX ? T.g_size[g1][3] + T.g_size[g2][3] : sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
-            V3 dc = c2 - ld3v(S.col.gpos[g1]);
-            hit = dot(dc, dc) <= rs * rs;
-            if (hit && (!CONVEX || (t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX))) {
-              // the six face axes of the narrowphase's separating-axis test (same expressions): a pair they separate would
-              // come back with zero contacts, and the narrowphase takes the candidates of an env one after the other
-              const M3 R1 = q2m(ld4v(S.col.gquat[g1]));
-              const V3 A0 = mcol(R1, 0), A1 = mcol(R1, 1), A2 = mcol(R1, 2), B0 = mcol(R2, 0), B1 = mcol(R2, 1), B2 = mcol(R2, 2);
-              const V3 Ls[6] = {A0, A1, A2, B0, B1, B2};
-#pragma unroll
-              for (int c = 0; c < 6; c++) {
-                const V3 L = Ls[c];
-                const float ra = h1.x * fabsf(dot(A0, L)) + h1.y * fabsf(dot(A1, L)) + h1.z * fabsf(dot(A2, L));
-                const float rb = h2.x * fabsf(dot(B0, L)) + h2.y * fabsf(dot(B1, L)) + h2.z * fabsf(dot(B2, L));
-                if (fabsf(dot(dc, L)) - (ra + rb) > 0.0f) hit = false;
-              }
-            }
-          }
-        }
-        unsigned long long bal = __ballot(hit);
-        uint32_t gm = (uint32_t)(bal >> (grp * G)) & 0xffffu;
-        int pos = base + __popc(gm & ((1u << lane) - 1u));
-        if (hit && pos < G) S.col.cand[pos] = pr | ptypes << 16;  // (the pair itself with its geom types: g1 | g2 << 8 | t1 << 16 | t2 << 24)
-        base += __popc(gm);
-      }
-      const int ncand = base < G ? base : G;
-      if (lane == 0) S.ncand = ncand;
-      WSYNC();
-      STAMP(12);
-      // narrowphase, plane-box: one candidate at a time, its 8 box corners on lanes 0..7 of the group
-      // (wave-uniform loop: the DPP/ballot selection below needs all lanes present)
-      for (int k = 0; k < G; k++) {
-        const bool act = k < ncand;
-        if (!__any(act)) break;
-        const int pr = act ? S.col.cand[k] : 0;
-        const int g1 = pr & 255, g2 = pr >> 8 & 255;
-        const bool isplane = act && (pr >> 16 & 255) == MIR_GEOM_PLANE && (!CONVEX || (pr >> 24) == MIR_GEOM_BOX);
-        if (!__any(isplane)) continue;
-        const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
-        const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
-        const M3 R2 = q2m(ld4v(S.col.gquat[g2]));
-        const V3 h = ld3v(T.g_size[g2]);
-        const int c = lane & 7;
-        const V3 w = ld3v(S.col.gpos[g2]) + ((c & 1) ? h.x : -h.x) * mcol(R2, 0) + ((c & 2) ? h.y : -h.y) * mcol(R2, 1) +
-                     ((c & 4) ? h.z : -h.z) * mcol(R2, 2);
-        const V3 rel = w - ld3v(S.col.gpos[g1]);
-        const float d = dot(rel, n), u = dot(rel, eu), v = dot(rel, ev);
-        const bool pen = isplane && lane < 8 && d < 0.0f;
-        const uint32_t penm = (uint32_t)(__ballot(pen) >> (grp * G)) & 0xffu;
-        const int cnt = __popc(penm);
-        // support extremes (+u, -u, +v, -v; lowest corner index wins ties), needed only when more than 4 corners penetrate
-        // somewhere in the wave (a box lying flat has exactly 4: the reductions are skipped)
-        uint32_t ext = 0u;
-        if (__any(cnt > 4)) {
-          const float uM = gmaxf(pen ? u : -3e38f), um = -gmaxf(pen ? -u : -3e38f);
-          const float vM = gmaxf(pen ? v : -3e38f), vm = -gmaxf(pen ? -v : -3e38f);
-          const uint32_t e0 = (uint32_t)(__ballot(pen && u == uM) >> (grp * G)) & 0xffu, e1 = (uint32_t)(__ballot(pen && u == um) >> (grp * G)) & 0xffu;
-          const uint32_t e2 = (uint32_t)(__ballot(pen && v == vM) >> (grp * G)) & 0xffu, e3 = (uint32_t)(__ballot(pen && v == vm) >> (grp * G)) & 0xffu;
-          ext = (e0 & -e0) | (e1 & -e1) | (e2 & -e2) | (e3 & -e3);
-        }
-        const uint32_t keepm = cnt <= 4 ? penm : ext;
-        const bool keep = (keepm >> lane & 1u) && lane < 8;
-        const int slot = __popc(keepm & ((1u << lane) - 1u));
-        if (keep && slot < 4) {
-          const V3 pos = w - (0.5f * d) * n;
-          stv(S.col.stage[k][slot], f4{pos.x, pos.y, pos.z, d});
-        }
-        if (lane == k && isplane) {
-          mycount = min(__popc(keepm), 4);
-          st3v(S.col.snorm[k], n);
-        }
-      }
-      // narrowphase, box-box: one candidate at a time on the whole row (box_box_row, mir_dev.h): the 15 separating axes
-      // on lanes 0..14, the incident-face vertices on lanes 0..3
-      for (int k = 0; k < G; k++) {
-        const bool act = k < ncand;
-        if (!__any(act)) break;
-        const int pr = act ? S.col.cand[k] : 0;
-        const int g1 = pr & 255, g2 = pr >> 8 & 255;
-        const bool isbox = act && (pr >> 16 & 255) != MIR_GEOM_PLANE && (!CONVEX || ((pr >> 16 & 255) == MIR_GEOM_BOX && (pr >> 24) == MIR_GEOM_BOX));
-        if (!__any(isbox)) continue;
-        if (isbox) {  // whole rows
-          const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
-          const BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
-          const BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
-          const int cnt = box_box_row(B1, B2, lane, tid, grp * G, S.col.stage[k], S.col.snorm[k], reinterpret_cast<float*>(&S.con));  // (contact arrays: not written yet)
-          if (lane == k) mycount = cnt;
-        }
-      }
-      if constexpr (CONVEX) {
-        // narrowphase of the round shapes, LANE-PRIVATE: lane c takes candidate c.  Plane - sphere / capsule in closed form
-        // (one / two points at half depth), every other pair that is not box - box through GJK on the cores, MPR when the
-        // cores overlap (mir_convex.h).  Lanes diverge here and reconverge at the end of the block.
-        if (lane < ncand) {
-          const int pr = S.col.cand[lane];
-          const int g1 = pr & 255, g2 = pr >> 8 & 255;
-          const int t1 = pr >> 16 & 255, t2 = pr >> 24;
-          if (t1 == MIR_GEOM_PLANE && (t2 == MIR_GEOM_SPHERE || t2 == MIR_GEOM_CAPSULE)) {
-            const V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2), pp = ld3v(S.col.gpos[g1]), pc = ld3v(S.col.gpos[g2]);
-            const V3 sz = ld3v(T.g_size[g2]);
-            const float r = sz.x;
-            int cnt = 0;
-            if (t2 == MIR_GEOM_SPHERE) {
-              const float dist = dot(pc - pp, n) - r;
-              if (dist < 0.0f) { const V3 c = pc - (r + 0.5f * dist) * n; stv(S.col.stage[lane][0], f4{c.x, c.y, c.z, dist}); cnt = 1; }
-            } else {  // the two end spheres, axis - then axis +
-              const V3 ax = mcol(q2m(ld4v(S.col.gquat[g2])), 2);
-#pragma unroll
-              for (int sgn = -1; sgn <= 1; sgn += 2) {
-                const V3 e = pc + ((float)sgn * sz.y) * ax;
-                const float dist = dot(e - pp, n) - r;
-                if (dist < 0.0f) { const V3 c = e - (r + 0.5f * dist) * n; stv(S.col.stage[lane][cnt], f4{c.x, c.y, c.z, dist}); cnt++; }
-              }
-            }
-            if (cnt) st3v(S.col.snorm[lane], n);
-            mycount = cnt;
-          } else if (t1 != MIR_GEOM_PLANE && !(t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX)) {
-            const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
-            const ShapeD A = {t1, ld3v(T.g_size[g1]), ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2)};
-            const ShapeD B = {t2, ld3v(T.g_size[g2]), ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2)};
-            f4 pt;
-            V3 n;
-            if (convex_pair(A, B, pt, n)) {
-              stv(S.col.stage[lane][0], pt);
-              st3v(S.col.snorm[lane], n);
-              mycount = 1;
-            }
-          }
-        }
-      }
+    // (DUAL: done by the collision wave since the first barrier; its per-candidate point counts arrive through LDS)
+    int mycount;
+    if (DUAL) {
+      __syncthreads();
+      mycount = S.col.count[lane];
+    } else {
+      mycount = collide_detect();
     }
     STAMP(13);
     // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
@@ -1445,7 +1491,7 @@ extern "C" int mir_launch_debug_convex(const float* in, float* out, int n, hipSt
 #ifdef MIR_STEP_CONVEX_TU
 template <int FEAT>
 static void launch_feat(const StepArgs& a, int blocks, int single, int plain_loop, hipStream_t stream) {
-  if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
+  if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
 }
@@ -1472,7 +1518,7 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   const bool plain_loop = a.mode == 0 && !a.poses && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
                           !a.env_state && !a.reward && !a.terminated && !a.term_host && !a.done_ticket;
   if (a.features) return mir_launch_step_convex(&a, single, plain_loop, stream);
-  if (single) hipLaunchKernelGGL((mir_step_kernel<0, 0>), dim3(blocks), dim3(64), 0, stream, a);
+  if (single) hipLaunchKernelGGL((mir_step_kernel<0, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, 0>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, 0>), dim3(blocks), dim3(64), 0, stream, a);
   return (int)hipGetLastError();
