@@ -475,6 +475,105 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   }
     return mycount;
   };
+  // ---- contact arrays and base Jacobians from the staging area (`mycount` = this lane's point count, lane = candidate): ordered
+  // compaction, per-contact frames / impedance / references, then the contact Jacobian columns (lane = dof).  Needs the staging
+  // area, the link poses, the motion subspaces and the model table; writes `con` (over the dead dynamics scratch) and `Jb`.
+  auto contacts_build = [&](int mycount) {
+  STAMP(13);
+  // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
+  const int maxc = max_contacts < MAXCON ? max_contacts : MAXCON;
+  {
+    // inclusive prefix sum over the row by DPP shifts (zeros shifted in), total from lane 15
+    float inclf = (float)mycount;
+    inclf += row_shr<1>(inclf);
+    inclf += row_shr<2>(inclf);
+    inclf += row_shr<4>(inclf);
+    inclf += row_shr<8>(inclf);
+    const int incl = (int)inclf;
+    const int off = incl - mycount;
+    const int total = (int)row_bcast<15>(inclf);
+    if (lane == 0) S.ncon = total < maxc ? total : maxc;
+    const int ncon_new = total < maxc ? total : maxc;
+    STAMP(22);
+    // candidate lanes publish which (candidate, point) fills each contact slot ...
+    for (int c = 0; c < mycount; c++)
+      if (off + c < maxc) S.col.cmap[off + c] = lane * 8 + c;
+    WSYNC();
+    STAMP(23);
+    // ... and every contact is then finished by its own lane, in parallel (staging lives in col
+    // scratch, which does not overlap the contact arrays)
+    if (lane < ncon_new) {
+      const int k = lane;
+      const int mp = S.col.cmap[k];
+      const int cl = mp >> 3, ci = mp & 7;
+      const int pr = S.col.cand[cl];
+      const int g1 = pr & 255, g2 = pr >> 8 & 255;
+      const V3 n = ld3v(S.col.snorm[cl]);
+      V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
+      t1 = t1 - dot(n, t1) * n;
+      t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
+      const V3 t2 = cross(n, t1);
+      const float mu = fmaxf(T.g_pos[g1][3], T.g_pos[g2][3]);
+      const f4 s1a = ldv(&T.g_sol[g1][0]), s1b = ldv(&T.g_sol[g1][4]), s2a = ldv(&T.g_sol[g2][0]), s2b = ldv(&T.g_sol[g2][4]);
+      const float sr0 = 0.5f * (s1a.x + s2a.x), sr1 = 0.5f * (s1a.y + s2a.y);
+      const float si[5] = {0.5f * (s1a.z + s2a.z), 0.5f * (s1a.w + s2a.w), 0.5f * (s1b.x + s2b.x), 0.5f * (s1b.y + s2b.y), 0.5f * (s1b.z + s2b.z)};
+      const int b1 = T.g_info[g1][0], b2 = T.g_info[g2][0];
+      const float wsum = T.b_invw[b1] + T.b_invw[b2];
+      const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
+      const float tc = fmaxf(sr0, 2.0f * dt);
+      const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
+      const uint32_t dm1 = (uint32_t)T.b_info[b1][0], dm2 = (uint32_t)T.b_info[b2][0];
+      const uint32_t inv = dm1 | dm2;
+      const uint32_t chunks = ((inv & 0xfu) ? 1u : 0u) | ((inv & 0xf0u) ? 2u : 0u) | ((inv & 0xf00u) ? 4u : 0u) | ((inv & 0xf000u) ? 8u : 0u);
+      const V3 ref1 = ld3v(S.xpos[T.b_info[b1][1]]), ref2 = ld3v(S.xpos[T.b_info[b2][1]]);
+      const f4 pd = ldv(S.col.stage[cl][ci]);
+      const float dist = pd.w;
+      stv(S.con.cpos[k], pd);
+      st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
+      const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
+      const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
+      stv(S.con.cmeta[k], f4{mu, 1.0f / Rr, -kk * imp * dist, bb});
+      st3v(&S.con.cref[k][0], ref1); st3v(&S.con.cref[k][4], ref2);
+      S.con.cmask[k][0] = dm1; S.con.cmask[k][1] = dm2; S.con.cmask[k][2] = chunks; S.con.cmask[k][3] = 0u;
+    }
+  }
+  WSYNC();  // col scratch is dead from here on (Jb may overwrite it)
+  const int ncon = S.ncon;
+  STAMP(5);
+
+  // ======================= constraint rows ======================================================
+  // contact base Jacobians: lane = dof; Jb[c][r*16 + i], r = normal, t1, t2
+  // (two contacts per trip, every read of both issued in one batch ahead of the arithmetic; a dof that moves neither
+  // body ends with sgn = 0, so there is no divergent branch around the reads)
+  {
+    const V3 cd_ang = ld3v(&S.cdof[lane][0]), cd_lin = ld3v(&S.cdof[lane][4]);
+    for (int c0 = 0; c0 < ncon; c0 += 2) {
+      const int cA = c0, cB = c0 + 1 < ncon ? c0 + 1 : c0;
+      const f4 mkA = ldv(reinterpret_cast<const float*>(S.con.cmask[cA])), mkB = ldv(reinterpret_cast<const float*>(S.con.cmask[cB]));
+      const f4 cpA = ldv(S.con.cpos[cA]), r1A = ldv(&S.con.cref[cA][0]), r2A = ldv(&S.con.cref[cA][4]);
+      const f4 cpB = ldv(S.con.cpos[cB]), r1B = ldv(&S.con.cref[cB][0]), r2B = ldv(&S.con.cref[cB][4]);
+      const f4 fnA = ldv(&S.con.cfrm[cA][0]), f1A = ldv(&S.con.cfrm[cA][4]), f2A = ldv(&S.con.cfrm[cA][8]);
+      const f4 fnB = ldv(&S.con.cfrm[cB][0]), f1B = ldv(&S.con.cfrm[cB][4]), f2B = ldv(&S.con.cfrm[cB][8]);
+      __builtin_amdgcn_sched_barrier(0);
+#define MIR_JCOL(mk, cp, r1, r2, fn, f1, f2, cc)                                                              \
+      {                                                                                                     \
+        const uint32_t dm1 = __float_as_uint(mk.x), dm2 = __float_as_uint(mk.y);                            \
+        const bool in2 = dm2 >> lane & 1u, in1 = dm1 >> lane & 1u;                                          \
+        const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f); /* a dof moving both bodies cancels */ \
+        const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));            \
+        const V3 vel = cross(cd_ang, r) + cd_lin;                                                           \
+        float* jb = &S.Jb[cc][0];                                                                           \
+        /* (selects, not products: a lane that carries no dof holds stale LDS in cd_ang / cd_lin, and 0 x NaN is NaN) */ \
+        jb[lane] = sgn != 0.0f ? sgn * dot(vel, v3(fn.x, fn.y, fn.z)) : 0.0f;                               \
+        jb[16 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f1.x, f1.y, f1.z)) : 0.0f;                          \
+        jb[32 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f2.x, f2.y, f2.z)) : 0.0f;                          \
+      }
+      MIR_JCOL(mkA, cpA, r1A, r2A, fnA, f1A, f2A, cA)
+      if (c0 + 1 < ncon) MIR_JCOL(mkB, cpB, r1B, r2B, fnB, f1B, f2B, cB)
+#undef MIR_JCOL
+    }
+  }
+  };
   if (DUAL && wave == 1) {
     {
       f4* dst = reinterpret_cast<f4*>(&T);
@@ -484,8 +583,9 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     }
     __syncthreads();  // (1) the model table is in LDS; the main wave has finished the FK of the launch's state
     const int cnt = collide_detect();
-    S.col.count[lane] = cnt;
-    __syncthreads();  // (2) staging area and counts handed to the main wave
+    __syncthreads();  // (2) the main wave has left the dynamics scratch: the contact arrays may be built over it
+    contacts_build(cnt);
+    __syncthreads();  // (3) contact arrays and base Jacobians handed to the main wave
     return;
   }
 
@@ -912,6 +1012,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
 #endif
     WSYNC();
     STAMP(3);
+    if (DUAL) __syncthreads();  // (2) this wave is done with the dynamics scratch (M is in its own area, the rest in registers)
     // qacc_smooth = Mt^-1 qfrc_smooth: Gauss-Jordan on register rows
     float mrow[G];
     {
@@ -937,108 +1038,11 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     WSYNC();  // dyn scratch is dead from here on
     STAMP(4);
 
-    // ======================= collision detection ================================================
-    // (DUAL: done by the collision wave since the first barrier; its per-candidate point counts arrive through LDS)
-    int mycount;
-    if (DUAL) {
-      __syncthreads();
-      mycount = S.col.count[lane];
-    } else {
-      mycount = collide_detect();
-    }
-    STAMP(13);
-    // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
-    const int maxc = max_contacts < MAXCON ? max_contacts : MAXCON;
-    {
-      // inclusive prefix sum over the row by DPP shifts (zeros shifted in), total from lane 15
-      float inclf = (float)mycount;
-      inclf += row_shr<1>(inclf);
-      inclf += row_shr<2>(inclf);
-      inclf += row_shr<4>(inclf);
-      inclf += row_shr<8>(inclf);
-      const int incl = (int)inclf;
-      const int off = incl - mycount;
-      const int total = (int)row_bcast<15>(inclf);
-      if (lane == 0) S.ncon = total < maxc ? total : maxc;
-      const int ncon_new = total < maxc ? total : maxc;
-      STAMP(22);
-      // candidate lanes publish which (candidate, point) fills each contact slot ...
-      for (int c = 0; c < mycount; c++)
-        if (off + c < maxc) S.col.cmap[off + c] = lane * 8 + c;
-      WSYNC();
-      STAMP(23);
-      // ... and every contact is then finished by its own lane, in parallel (staging lives in col
-      // scratch, which does not overlap the contact arrays)
-      if (lane < ncon_new) {
-        const int k = lane;
-        const int mp = S.col.cmap[k];
-        const int cl = mp >> 3, ci = mp & 7;
-        const int pr = S.col.cand[cl];
-        const int g1 = pr & 255, g2 = pr >> 8 & 255;
-        const V3 n = ld3v(S.col.snorm[cl]);
-        V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
-        t1 = t1 - dot(n, t1) * n;
-        t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
-        const V3 t2 = cross(n, t1);
-        const float mu = fmaxf(T.g_pos[g1][3], T.g_pos[g2][3]);
-        const f4 s1a = ldv(&T.g_sol[g1][0]), s1b = ldv(&T.g_sol[g1][4]), s2a = ldv(&T.g_sol[g2][0]), s2b = ldv(&T.g_sol[g2][4]);
-        const float sr0 = 0.5f * (s1a.x + s2a.x), sr1 = 0.5f * (s1a.y + s2a.y);
-        const float si[5] = {0.5f * (s1a.z + s2a.z), 0.5f * (s1a.w + s2a.w), 0.5f * (s1b.x + s2b.x), 0.5f * (s1b.y + s2b.y), 0.5f * (s1b.z + s2b.z)};
-        const int b1 = T.g_info[g1][0], b2 = T.g_info[g2][0];
-        const float wsum = T.b_invw[b1] + T.b_invw[b2];
-        const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
-        const float tc = fmaxf(sr0, 2.0f * dt);
-        const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
-        const uint32_t dm1 = (uint32_t)T.b_info[b1][0], dm2 = (uint32_t)T.b_info[b2][0];
-        const uint32_t inv = dm1 | dm2;
-        const uint32_t chunks = ((inv & 0xfu) ? 1u : 0u) | ((inv & 0xf0u) ? 2u : 0u) | ((inv & 0xf00u) ? 4u : 0u) | ((inv & 0xf000u) ? 8u : 0u);
-        const V3 ref1 = ld3v(S.xpos[T.b_info[b1][1]]), ref2 = ld3v(S.xpos[T.b_info[b2][1]]);
-        const f4 pd = ldv(S.col.stage[cl][ci]);
-        const float dist = pd.w;
-        stv(S.con.cpos[k], pd);
-        st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
-        const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
-        const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
-        stv(S.con.cmeta[k], f4{mu, 1.0f / Rr, -kk * imp * dist, bb});
-        st3v(&S.con.cref[k][0], ref1); st3v(&S.con.cref[k][4], ref2);
-        S.con.cmask[k][0] = dm1; S.con.cmask[k][1] = dm2; S.con.cmask[k][2] = chunks; S.con.cmask[k][3] = 0u;
-      }
-    }
-    WSYNC();  // col scratch is dead from here on (Jb may overwrite it)
-    const int ncon = S.ncon;
-    STAMP(5);
-
-    // ======================= constraint rows ======================================================
-    // contact base Jacobians: lane = dof; Jb[c][r*16 + i], r = normal, t1, t2
-    // (two contacts per trip, every read of both issued in one batch ahead of the arithmetic; a dof that moves neither
-    // body ends with sgn = 0, so there is no divergent branch around the reads)
-    {
-      const V3 cd_ang = ld3v(&S.cdof[lane][0]), cd_lin = ld3v(&S.cdof[lane][4]);
-      for (int c0 = 0; c0 < ncon; c0 += 2) {
-        const int cA = c0, cB = c0 + 1 < ncon ? c0 + 1 : c0;
-        const f4 mkA = ldv(reinterpret_cast<const float*>(S.con.cmask[cA])), mkB = ldv(reinterpret_cast<const float*>(S.con.cmask[cB]));
-        const f4 cpA = ldv(S.con.cpos[cA]), r1A = ldv(&S.con.cref[cA][0]), r2A = ldv(&S.con.cref[cA][4]);
-        const f4 cpB = ldv(S.con.cpos[cB]), r1B = ldv(&S.con.cref[cB][0]), r2B = ldv(&S.con.cref[cB][4]);
-        const f4 fnA = ldv(&S.con.cfrm[cA][0]), f1A = ldv(&S.con.cfrm[cA][4]), f2A = ldv(&S.con.cfrm[cA][8]);
-        const f4 fnB = ldv(&S.con.cfrm[cB][0]), f1B = ldv(&S.con.cfrm[cB][4]), f2B = ldv(&S.con.cfrm[cB][8]);
-        __builtin_amdgcn_sched_barrier(0);
-#define MIR_JCOL(mk, cp, r1, r2, fn, f1, f2, cc)                                                              \
-        {                                                                                                     \
-          const uint32_t dm1 = __float_as_uint(mk.x), dm2 = __float_as_uint(mk.y);                            \
-          const bool in2 = dm2 >> lane & 1u, in1 = dm1 >> lane & 1u;                                          \
-          const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f); /* a dof moving both bodies cancels */ \
-          const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));            \
-          const V3 vel = cross(cd_ang, r) + cd_lin;                                                           \
-          float* jb = &S.Jb[cc][0];                                                                           \
-          /* (selects, not products: a lane that carries no dof holds stale LDS in cd_ang / cd_lin, and 0 x NaN is NaN) */ \
-          jb[lane] = sgn != 0.0f ? sgn * dot(vel, v3(fn.x, fn.y, fn.z)) : 0.0f;                               \
-          jb[16 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f1.x, f1.y, f1.z)) : 0.0f;                          \
-          jb[32 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f2.x, f2.y, f2.z)) : 0.0f;                          \
-        }
-        MIR_JCOL(mkA, cpA, r1A, r2A, fnA, f1A, f2A, cA)
-        if (c0 + 1 < ncon) MIR_JCOL(mkB, cpB, r1B, r2B, fnB, f1B, f2B, cB)
-#undef MIR_JCOL
-      }
+    // ======================= collision detection, contact arrays, contact Jacobians ==============
+    // (DUAL: the collision wave does all of it, detection since the first barrier, the rest since the second)
+    if (!DUAL) {
+      const int mc = collide_detect();
+      contacts_build(mc);
     }
     // joint-limit rows: lane = dof, lane-private
     float lsg = 0.0f, lD = 0.0f, laref = 0.0f;
@@ -1058,6 +1062,8 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       }
     }
     WSYNC();
+    if (DUAL) __syncthreads();  // (3) contact arrays and base Jacobians are in LDS
+    const int ncon = S.ncon;
     // contact rows, lane = contact, lane-private: aref_r = -b (J_r qvel) - k imp dist
     const bool iscon = lane < ncon;
     float cmu = 0.0f, cD = 0.0f;
