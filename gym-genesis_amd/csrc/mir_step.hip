@@ -502,17 +502,23 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     STAMP(23);
     // ... and every contact is then finished by its own lane, in parallel (staging lives in col
     // scratch, which does not overlap the contact arrays)
-    if (lane < ncon_new) {
-      const int k = lane;
+    // (computed first, stored second: in the DUAL instantiation the contact arrays overlay the dynamics scratch of the main
+    // wave, so the collision wave does the arithmetic while that wave is still busy and stores after the barrier)
+    const bool mine = lane < ncon_new;
+    const int k = lane;
+    f4 pd = {0, 0, 0, 0}, meta = {0, 0, 0, 0};
+    V3 n = v3(0, 0, 0), t1 = n, t2 = n, ref1 = n, ref2 = n;
+    uint32_t dm1 = 0u, dm2 = 0u, chunks = 0u;
+    if (mine) {
       const int mp = S.col.cmap[k];
       const int cl = mp >> 3, ci = mp & 7;
       const int pr = S.col.cand[cl];
       const int g1 = pr & 255, g2 = pr >> 8 & 255;
-      const V3 n = ld3v(S.col.snorm[cl]);
-      V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
+      n = ld3v(S.col.snorm[cl]);
+      t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
       t1 = t1 - dot(n, t1) * n;
       t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
-      const V3 t2 = cross(n, t1);
+      t2 = cross(n, t1);
       const float mu = fmaxf(T.g_pos[g1][3], T.g_pos[g2][3]);
       const f4 s1a = ldv(&T.g_sol[g1][0]), s1b = ldv(&T.g_sol[g1][4]), s2a = ldv(&T.g_sol[g2][0]), s2b = ldv(&T.g_sol[g2][4]);
       const float sr0 = 0.5f * (s1a.x + s2a.x), sr1 = 0.5f * (s1a.y + s2a.y);
@@ -522,17 +528,21 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
       const float tc = fmaxf(sr0, 2.0f * dt);
       const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
-      const uint32_t dm1 = (uint32_t)T.b_info[b1][0], dm2 = (uint32_t)T.b_info[b2][0];
+      dm1 = (uint32_t)T.b_info[b1][0]; dm2 = (uint32_t)T.b_info[b2][0];
       const uint32_t inv = dm1 | dm2;
-      const uint32_t chunks = ((inv & 0xfu) ? 1u : 0u) | ((inv & 0xf0u) ? 2u : 0u) | ((inv & 0xf00u) ? 4u : 0u) | ((inv & 0xf000u) ? 8u : 0u);
-      const V3 ref1 = ld3v(S.xpos[T.b_info[b1][1]]), ref2 = ld3v(S.xpos[T.b_info[b2][1]]);
-      const f4 pd = ldv(S.col.stage[cl][ci]);
+      chunks = ((inv & 0xfu) ? 1u : 0u) | ((inv & 0xf0u) ? 2u : 0u) | ((inv & 0xf00u) ? 4u : 0u) | ((inv & 0xf000u) ? 8u : 0u);
+      ref1 = ld3v(S.xpos[T.b_info[b1][1]]); ref2 = ld3v(S.xpos[T.b_info[b2][1]]);
+      pd = ldv(S.col.stage[cl][ci]);
       const float dist = pd.w;
-      stv(S.con.cpos[k], pd);
-      st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
       const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
       const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
-      stv(S.con.cmeta[k], f4{mu, 1.0f / Rr, -kk * imp * dist, bb});
+      meta = f4{mu, 1.0f / Rr, -kk * imp * dist, bb};
+    }
+    if (DUAL) __syncthreads();  // (2) the main wave has left the dynamics scratch: the contact arrays may be stored over it
+    if (mine) {
+      stv(S.con.cpos[k], pd);
+      st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
+      stv(S.con.cmeta[k], meta);
       st3v(&S.con.cref[k][0], ref1); st3v(&S.con.cref[k][4], ref2);
       S.con.cmask[k][0] = dm1; S.con.cmask[k][1] = dm2; S.con.cmask[k][2] = chunks; S.con.cmask[k][3] = 0u;
     }
@@ -583,8 +593,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     }
     __syncthreads();  // (1) the model table is in LDS; the main wave has finished the FK of the launch's state
     const int cnt = collide_detect();
-    __syncthreads();  // (2) the main wave has left the dynamics scratch: the contact arrays may be built over it
-    contacts_build(cnt);
+    contacts_build(cnt);  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
     __syncthreads();  // (3) contact arrays and base Jacobians handed to the main wave
     return;
   }
