@@ -314,6 +314,15 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     if (m.b_submask[b] != range) return fail(err, MIR_E_CAPACITY, "bodies are not numbered in depth-first preorder");
   }
 
+  {  // block split of the mass matrix: trees own contiguous dof ranges (bodies are in preorder)
+    int ntree = 0, second = 0, last_root = -1;
+    for (int i = 0; i < nv; i++) {
+      const int r = m.b_root[m.d_body[i]];
+      if (r != last_root) { ntree++; if (ntree == 2) second = i; last_root = r; }
+    }
+    m.gj_split = (ntree == 2 && (second == 6 || second == 9)) ? second : 0;
+  }
+
   // ---- dof parameters -------------------------------------------------------------------
   int nu = 0;
   for (int i = 0; i < nv; i++) {

@@ -154,6 +154,34 @@ struct GJ<G - 1> {
   static __device__ __forceinline__ void run(float (&)[G], float&, int) {}
 };
 
+// The same elimination for a matrix that is block diagonal with blocks [0, S) and [S, 15): a pivot of the first block only
+// touches the columns of the first block (the rest of its row is zero), so those fmas are left out -- for every row, since
+// f * 0 changes nothing.  Bit-identical to GJ<0> on such a matrix.  (The mass matrix is block diagonal by kinematic tree --
+// arm and cube -- and so is the Newton Hessian as long as no contact joins the two trees.)
+template <int S, int K>
+struct GJ2 {
+  static __device__ __forceinline__ void run(float (&a)[G], float& b, int lane) {
+    const float pk = row_bcast<K>(a[K]);
+    const float inv = __builtin_amdgcn_rcpf(pk);
+    const float f = lane == K ? 1.0f - inv : a[K] * inv;
+    constexpr int END = K < S ? S : G - 1;
+#pragma unroll
+    for (int j = K + 1; j < END; j++) a[j] = fmaf(-f, row_bcast<K>(a[j]), a[j]);
+    b = fmaf(-f, row_bcast<K>(b), b);
+    GJ2<S, K + 1>::run(a, b, lane);
+  }
+};
+template <int S>
+struct GJ2<S, G - 1> {
+  static __device__ __forceinline__ void run(float (&)[G], float&, int) {}
+};
+// dispatch on the model's block split (0 = dense); `split` must be wave-uniform
+__device__ __forceinline__ void gj_solve(float (&a)[G], float& b, int lane, int split) {
+  if (split == 9) GJ2<9, 0>::run(a, b, lane);
+  else if (split == 6) GJ2<6, 0>::run(a, b, lane);
+  else GJ<0>::run(a, b, lane);
+}
+
 // spatial inertia {m, h, I(xx yy zz xy xz yz)} applied to motion {w, v} -> force {t, f}
 struct Inert {
   float m;

@@ -101,6 +101,8 @@ struct DevModel {
   // ---- free bodies in body order (reset / re-spawn poses) ----
   int32_t nfree, free_qadr[MIR_MAX_FREE];
   int32_t has_convex;  // any sphere / capsule geom
+  int32_t gj_split;    // first dof of the second kinematic tree when the model has exactly two trees with dofs and that dof is 6 or 9
+                       // (the block-diagonal eliminations instantiated in mir_dev.h), else 0 = dense
   int32_t use_sap;     // candidate pairs from the sweep-and-prune over AABBs (static list too long, or MIR_BROADPHASE=sap)
 };
 

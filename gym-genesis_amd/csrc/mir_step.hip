@@ -98,7 +98,7 @@ struct EnvLds {
   float xpos[G][4], xquat[G][4];
   float cdof[G][8];               // ang(3) pad lin(3) pad
   float M[G][MSTR];
-  int ncon, ncand, pad0, pad1;
+  int ncon, ncand, coupled /* some contact joins the two kinematic trees: the Newton Hessian is not block diagonal */, pad1;
   // Phase-aliased working set.  `dyn` (smooth dynamics) and `col` (collision detection) are live AT THE SAME TIME in the
   // single-step instantiation, where a second wave of the workgroup detects collisions while the first one does the dynamics;
   // the contact arrays and the contact Jacobians take the place of both afterwards (con never overlaps col: the contact
@@ -228,6 +228,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   const float mdl_tolerance = m->tolerance, mdl_scale = m->solver_scale, mdl_reward_z = m->reward_z;
   const float mdl_gx = m->gx, mdl_gy = m->gy, mdl_gz = m->gz;
   const int mdl_eef = m->eef_body, mdl_obj = m->obj_body, mdl_ngrip = m->n_grip;
+  const int mdl_split = m->gj_split;
 
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
   // (lane = candidate).  Needs the link poses and the model table in LDS, nothing else: in the DUAL instantiation the second
@@ -537,6 +538,11 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
       const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
       meta = f4{mu, 1.0f / Rr, -kk * imp * dist, bb};
+    }
+    {  // does any contact of the env move dofs of both trees?
+      const uint32_t low = (1u << mdl_split) - 1u, both = dm1 | dm2;
+      const unsigned long long cb = __ballot(mine && (both & low) != 0u && (both & ~low) != 0u);
+      if (lane == 0) S.coupled = (uint32_t)(cb >> (grp * G)) & 0xffffu ? 1 : 0;
     }
     if (DUAL) __syncthreads();  // (2) the main wave has left the dynamics scratch: the contact arrays may be stored over it
     if (mine) {
@@ -1041,7 +1047,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
 #pragma unroll
       for (int j = 0; j < G; j++) arow[j] = isdof ? mrow[j] : (j == lane ? 1.0f : 0.0f);
       qas = isdof ? qfs : 0.0f;
-      GJ<0>::run(arow, qas, lane);
+      gj_solve(arow, qas, lane, mdl_split);  // (the mass matrix is block diagonal by tree)
     }
     if (a.out_qas && valid && isdof && step == 0) a.out_qas[(size_t)env * nv + lane] = qas;
     WSYNC();  // dyn scratch is dead from here on
@@ -1134,6 +1140,8 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     STAMP(7);
     int niter = 0;
     const float tol = mdl_tolerance, scale = mdl_scale;
+    // the Hessian is block diagonal by tree unless a contact joins the arm and the cube somewhere in this wave
+    const int hsplit = __any(S.coupled != 0) ? 0 : mdl_split;
     // float32 rounding floor of the gradient Ma - qfrc_smooth - J^T f: below it a Newton step no
     // longer changes qacc, so iterating further is noise (same rule as the oracle, with float eps)
     const float gfloor = 16.0f * 5.96e-8f * sqrtf(gsum(Ma * Ma + qfs * qfs));
@@ -1226,7 +1234,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       if (it == 0) STAMP(18);
       // ---- Newton direction: H s = -g
       float sv = -g;
-      GJ<0>::run(hrow, sv, lane);
+      gj_solve(hrow, sv, lane, hsplit);
       if (!isdof) sv = 0.0f;
       if (it == 0) STAMP(15);
       // (the direction stays in the lanes: M s and J s take s_j by row broadcast, no LDS round trip)
