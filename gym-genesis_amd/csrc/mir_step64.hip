@@ -105,10 +105,12 @@ __device__ __forceinline__ void gj_wave(v16f (&a)[4], float& b, int lane, uint64
 }
 
 struct Dyn64 {
-  float lpos[NB][4], lquat[NB][4];
   float cddq[NL][8];
   float cinert[NB][12], crb[NB][12];
-  float cvel[NB][8], cfrc[NB][8];
+  union {
+    struct { float cvel[NB][8], cfrc[NB][8]; };
+    struct { float lpos[NB][4], lquat[NB][4]; };  // forward-kinematics exchange: dead before the dynamics start
+  };
 };
 struct Col64 {
   float gpos[MIR_MAX_GEOM][4], gquat[MIR_MAX_GEOM][4];
@@ -140,11 +142,14 @@ struct Env64 {
   float cdof[NL][8];
   int parent[NB];
   int ncon, ncand, pad0, pad1;
-  // three phase-local areas share storage: dynamics scratch + M (FK .. smooth solve), collision scratch, and the
-  // contact Jacobian segments (written once the contacts are finished)
+  // two phase-local areas share storage: dynamics scratch + M (FK .. smooth solve) next to the collision scratch -- both
+  // live at once in the single-step instantiation, where a second wave detects the contacts while this one runs the
+  // dynamics -- and the contact Jacobian segments (written once both are dead)
   union {
-    DynM64 dm;
-    Col64 col;
+    struct {
+      DynM64 dm;
+      Col64 col;
+    };
     float Jb[MAXC][2][JSEG];
   };
   Con64 con;          // (before the contacts are finished: the box-box clipping exchange, 48 floats per DPP row)
@@ -228,12 +233,19 @@ __device__ __forceinline__ void condot3(const Env64& S, int c, const float* x, f
 // SINGLE = one full step per launch without the rollout / autoreset / per-stage-output options: no step loop, hence none of
 // the scalar-register spills the loop structure forces (see mir_step.hip).
 // VARIANT 0 = SINGLE; 1 = the step loop of rollouts (packed rows only, no per-stage / separate outputs); 2 = everything.
+// DUAL (the single-step instantiation): the workgroup is TWO waves on one env.  Wave 1 stages the model tables, then -- once
+// wave 0 has the body poses -- runs the whole collision phase (geom poses, broadphase, plane-box, box-box, contact finish, per-block
+// lists) in its own scratch while wave 0 runs the dynamics up to the smooth solve; they meet before the Jacobian segments are
+// written, and wave 1 retires.  The register budget is held at 256 so that the four workgroups of a CU (LDS) are two waves per SIMD.
 template <int VARIANT>
-__global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
+__global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(VARIANT == 0 ? 2 : 1, VARIANT == 0 ? 2 : 1)))
+void mir_step64_kernel(StepArgs64 a) {
   constexpr bool SINGLE = VARIANT == 0;
+  constexpr bool DUAL = SINGLE;
   __shared__ __attribute__((aligned(16))) Env64 S;
   const DevModel64* __restrict__ m = a.model;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool helper = DUAL && threadIdx.x >= 64;  // wave-uniform
   const int blk = lane >> 4, l16 = lane & 15;
   const int env = blockIdx.x;  // grid = B exactly
 
@@ -290,25 +302,240 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
   const f4 gs0 = reinterpret_cast<const f4*>(m->g_sol[gi])[0], gs1 = reinterpret_cast<const f4*>(m->g_sol[gi])[1];
   const f4 bt0 = reinterpret_cast<const f4*>(m->b_tab[bi])[0], bt1 = reinterpret_cast<const f4*>(m->b_tab[bi])[1];
   const int par_in = m->b_parent[bi];
-  const float q_in = a.qpos[(size_t)env * K64_QSTRIDE + lane], qv_in = a.qvel[(size_t)env * NL + lane], ws_in = a.qacc_ws[(size_t)env * NL + lane];
-  float tg = a.target[(size_t)env * NL + lane];
-  const float au = (a.action && lane < a.nu) ? a.action[(size_t)env * a.nu + lane] : 0.0f;
-  // (the cached poses travel with their validity flag; (B, 2, 32, 4): the speculative read is in bounds)
-  const float* pose_p = a.poses + ((size_t)env * 2 * NB + (lane & (NB - 1))) * 4;
-  const f4 cpos = *reinterpret_cast<const f4*>(pose_p), cquat = *reinterpret_cast<const f4*>(pose_p + 4 * NB);
-  const bool cached = a.fkvalid[env] != 0;  // wave-uniform
-  __builtin_amdgcn_sched_barrier(0);  // (nothing below may move in front of the loads above)
-  if (lane < ngeom) {
-    stv(S.gts[lane], f4{__int_as_float(gt_in | (g_bodyl << 8)), gsx, gsy, gsz});
-    S.gfr[lane] = gfr_in;
-    stv(&S.gsol[lane][0], gs0); stv(&S.gsol[lane][4], gs1);
+  float q_in = 0.0f, qv_in = 0.0f, ws_in = 0.0f, tg = 0.0f, au = 0.0f;
+  f4 cpos = {0, 0, 0, 0}, cquat = {0, 0, 0, 0};
+  bool cached = false;
+  if (!helper) {
+    q_in = a.qpos[(size_t)env * K64_QSTRIDE + lane]; qv_in = a.qvel[(size_t)env * NL + lane]; ws_in = a.qacc_ws[(size_t)env * NL + lane];
+    tg = a.target[(size_t)env * NL + lane];
+    au = (a.action && lane < a.nu) ? a.action[(size_t)env * a.nu + lane] : 0.0f;
+    // (the cached poses travel with their validity flag; (B, 2, 32, 4): the speculative read is in bounds)
+    const float* pose_p = a.poses + ((size_t)env * 2 * NB + (lane & (NB - 1))) * 4;
+    cpos = *reinterpret_cast<const f4*>(pose_p); cquat = *reinterpret_cast<const f4*>(pose_p + 4 * NB);
+    cached = a.fkvalid[env] != 0;  // wave-uniform
   }
+  __builtin_amdgcn_sched_barrier(0);  // (nothing below may move in front of the loads above)
+  if (!DUAL || helper) {
+    if (lane < ngeom) {
+      stv(S.gts[lane], f4{__int_as_float(gt_in | (g_bodyl << 8)), gsx, gsy, gsz});
+      S.gfr[lane] = gfr_in;
+      stv(&S.gsol[lane][0], gs0); stv(&S.gsol[lane][4], gs1);
+    }
 #pragma unroll
-  for (int u = 0; u < 4; u++)
-    if (lane + NL * u < npair) S.pairs[lane + NL * u] = (unsigned short)pr_in[u];
-  if (lane < NB) {
-    stv(&S.btab[lane][0], bt0); stv(&S.btab[lane][4], bt1);
-    S.parent[lane] = lane < nb ? par_in : 0;
+    for (int u = 0; u < 4; u++)
+      if (lane + NL * u < npair) S.pairs[lane + NL * u] = (unsigned short)pr_in[u];
+    if (lane < NB) { stv(&S.btab[lane][0], bt0); stv(&S.btab[lane][4], bt1); }
+  }
+  if (!helper && lane < NB) S.parent[lane] = lane < nb ? par_in : 0;
+
+  // ======================= collision detection ================================================
+  // From the body poses to the finished contact arrays and the per-block contact lists; leaves S.ncon / S.ncand.  Touches only
+  // its own scratch (S.col), the contact arrays (S.con) and read-only state, so in the single-step instantiation it runs on
+  // wave 1 next to the dynamics.
+  auto collide = [&]() {
+    if (lane == 0) { S.ncon = 0; S.ncand = 0; }
+    if (lane < ngeom) {
+      Q4 qb = ld4v(S.xquat[g_bodyl]);
+      st3v(S.col.gpos[lane], ld3v(S.xpos[g_bodyl]) + qrot(qb, g_posl));
+      st4v(S.col.gquat[lane], qmul(qb, g_quatl));
+    }
+    S.col.ccount[lane] = 0;
+    WSYNC();
+    int mycount = 0;
+    int ncand = 0;
+    if (enable_collision) {
+      // broadphase: bounding test per static candidate pair, ordered compaction of survivors (lane = pair)
+      int base = 0;
+      for (int p0 = 0; p0 < npair; p0 += NL) {
+        int p = p0 + lane;
+        bool hit = false;
+        if (p < npair) {
+          const int pr = (int)S.pairs[p];
+          const int g1 = pr & 255, g2 = pr >> 8;
+          V3 h2 = ld3(&S.gts[g2][1]);
+          M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+          V3 c2 = ld3v(S.col.gpos[g2]);
+          if ((__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE) {
+            V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
+            float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
+            hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
+          } else {
+            V3 h1 = ld3(&S.gts[g1][1]);
+            float rs = sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
+            V3 dc = c2 - ld3v(S.col.gpos[g1]);
+            hit = dot(dc, dc) <= rs * rs;
+            if (hit) {
+              // the six face axes of the narrowphase's separating-axis test (same expressions): a pair they separate
+              // would come back with zero contacts, and the narrowphase walks its candidates four at a time
+              const M3 R1 = q2m(ld4v(S.col.gquat[g1]));
+              const V3 A0 = mcol(R1, 0), A1 = mcol(R1, 1), A2 = mcol(R1, 2), B0 = mcol(R2, 0), B1 = mcol(R2, 1), B2 = mcol(R2, 2);
+              const V3 Ls[6] = {A0, A1, A2, B0, B1, B2};
+#pragma unroll
+              for (int c = 0; c < 6; c++) {
+                const V3 L = Ls[c];
+                const float ra = h1.x * fabsf(dot(A0, L)) + h1.y * fabsf(dot(A1, L)) + h1.z * fabsf(dot(A2, L));
+                const float rb = h2.x * fabsf(dot(B0, L)) + h2.y * fabsf(dot(B1, L)) + h2.z * fabsf(dot(B2, L));
+                if (fabsf(dot(dc, L)) - (ra + rb) > 0.0f) hit = false;
+              }
+            }
+          }
+        }
+        const unsigned long long bal = __ballot(hit);
+        int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && pos < NL) S.col.cand[pos] = p;
+        base += __popcll(bal);
+      }
+      ncand = base < NL ? base : NL;
+      if (lane == 0) S.ncand = ncand;
+      WSYNC();
+      STAMP(6);
+      // narrowphase, plane-box: DPP row r takes candidates r, r + 4, ...; the 8 box corners on lanes 0..7 of the row
+      for (int k0 = 0; k0 < ncand; k0 += 4) {
+        const int k = k0 + blk;
+        const bool act = k < ncand;
+        const int pr = act ? (int)S.pairs[S.col.cand[k]] : 0;
+        const int g1 = pr & 255, g2 = pr >> 8;
+        const bool isplane = act && (__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE;
+        if (!__any(isplane)) continue;
+        const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
+        const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
+        const M3 R2 = q2m(ld4v(S.col.gquat[g2]));
+        const V3 h = ld3(&S.gts[g2][1]);
+        const int c = lane & 7;
+        const V3 w = ld3v(S.col.gpos[g2]) + ((c & 1) ? h.x : -h.x) * mcol(R2, 0) + ((c & 2) ? h.y : -h.y) * mcol(R2, 1) +
+                     ((c & 4) ? h.z : -h.z) * mcol(R2, 2);
+        const V3 rel = w - ld3v(S.col.gpos[g1]);
+        const float d = dot(rel, n), u = dot(rel, eu), v = dot(rel, ev);
+        const bool pen = isplane && l16 < 8 && d < 0.0f;
+        const uint32_t penm = (uint32_t)(__ballot(pen) >> (blk * G)) & 0xffu;
+        const int cnt = __popc(penm);
+        // support extremes (+u, -u, +v, -v; lowest corner index wins ties), needed only when more than 4 corners penetrate
+        // somewhere in the wave (a box lying flat has exactly 4: the reductions are skipped)
+        uint32_t ext = 0u;
+        if (__any(cnt > 4)) {
+          const float uM = gmaxf(pen ? u : -3e38f), um = -gmaxf(pen ? -u : -3e38f);
+          const float vM = gmaxf(pen ? v : -3e38f), vm = -gmaxf(pen ? -v : -3e38f);
+          const uint32_t e0 = (uint32_t)(__ballot(pen && u == uM) >> (blk * G)) & 0xffu, e1 = (uint32_t)(__ballot(pen && u == um) >> (blk * G)) & 0xffu;
+          const uint32_t e2 = (uint32_t)(__ballot(pen && v == vM) >> (blk * G)) & 0xffu, e3 = (uint32_t)(__ballot(pen && v == vm) >> (blk * G)) & 0xffu;
+          ext = (e0 & -e0) | (e1 & -e1) | (e2 & -e2) | (e3 & -e3);
+        }
+        const uint32_t keepm = cnt <= 4 ? penm : ext;
+        const bool keep = (keepm >> l16 & 1u) && l16 < 8;
+        const int slot = __popc(keepm & ((1u << l16) - 1u));
+        if (isplane && keep && slot < 4) {
+          const V3 pos = w - (0.5f * d) * n;
+          stv(S.col.stage[k][slot], f4{pos.x, pos.y, pos.z, d});
+        }
+        if (isplane && l16 == 0) {
+          S.col.ccount[k] = min(__popc(keepm), 4);
+          st3v(S.col.snorm[k], n);
+        }
+      }
+      WSYNC();
+      mycount = S.col.ccount[lane];
+      STAMP(7);
+      // narrowphase, box-box: DPP row r takes candidates r, r + 4, ... (like plane-box).  The 15 separating axes sit on
+      // lanes 0..14 of the row, the incident-face vertices on lanes 0..3 (box_box_row, mir_dev.h)
+      for (int k0 = 0; k0 < ncand; k0 += 4) {
+        const int k = k0 + blk;
+        const bool actk = k < ncand;
+        const int pr = actk ? (int)S.pairs[S.col.cand[k]] : 0;
+        const int g1 = pr & 255, g2 = pr >> 8;
+        const bool isbox = actk && (__float_as_int(S.gts[g1][0]) & 255) != MIR_GEOM_PLANE;
+        if (!__any(isbox)) continue;
+        if (isbox) {  // whole rows
+          const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
+          const BoxG A = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(&S.gts[g1][1])};
+          const BoxG B = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(&S.gts[g2][1])};
+          const int cnt = box_box_row(A, B, l16, lane, blk * G, S.col.stage[k], S.col.snorm[k], reinterpret_cast<float*>(&S.con) + 48 * blk);  // (contact arrays: not written yet)
+          if (l16 == 0) S.col.ccount[k] = cnt;
+        }
+      }
+      WSYNC();
+      mycount = S.col.ccount[lane];
+    }
+    STAMP(8);
+    // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
+    const int maxc = max_contacts < MAXC ? max_contacts : MAXC;
+    int ncon;
+    {
+      float inclf = (float)mycount;
+      inclf += row_shr<1>(inclf);
+      inclf += row_shr<2>(inclf);
+      inclf += row_shr<4>(inclf);
+      inclf += row_shr<8>(inclf);
+      const float r0 = rl(inclf, 15), r1 = rl(inclf, 31), r2 = rl(inclf, 47), r3 = rl(inclf, 63);
+      const float rowbase = blk == 0 ? 0.0f : (blk == 1 ? r0 : (blk == 2 ? r0 + r1 : r0 + r1 + r2));
+      const int incl = (int)(inclf + rowbase);
+      const int off = incl - mycount;
+      const int total = (int)(r0 + r1 + r2 + r3);
+      ncon = total < maxc ? total : maxc;
+      if (lane == 0) S.ncon = ncon;
+      for (int c = 0; c < mycount; c++)
+        if (off + c < maxc) S.col.cmap[off + c] = lane * 8 + c;
+      WSYNC();
+      // every contact is finished by its own lane (staging lives in col scratch, disjoint from the contact arrays)
+      if (lane < ncon) {
+        const int k = lane;
+        const int mp = S.col.cmap[k];
+        const int cl = mp >> 3, ci = mp & 7;
+        const int pr = (int)S.pairs[S.col.cand[cl]];
+        const int g1 = pr & 255, g2 = pr >> 8;
+        const V3 n = ld3v(S.col.snorm[cl]);
+        V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
+        t1 = t1 - dot(n, t1) * n;
+        t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
+        const V3 t2 = cross(n, t1);
+        const float mu = fmaxf(S.gfr[g1], S.gfr[g2]);
+        const float* s1 = S.gsol[g1];
+        const float* s2 = S.gsol[g2];
+        const float sr0 = 0.5f * (s1[0] + s2[0]), sr1 = 0.5f * (s1[1] + s2[1]);
+        const float si[5] = {0.5f * (s1[2] + s2[2]), 0.5f * (s1[3] + s2[3]), 0.5f * (s1[4] + s2[4]), 0.5f * (s1[5] + s2[5]), 0.5f * (s1[6] + s2[6])};
+        const int b1 = __float_as_int(S.gts[g1][0]) >> 8, b2 = __float_as_int(S.gts[g2][0]) >> 8;
+        const f4 bt1 = ldv(&S.btab[b1][0]), bt2 = ldv(&S.btab[b2][0]);
+        const float wsumw = bt1.x + bt2.x;
+        const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
+        const float tc = fmaxf(sr0, 2.0f * dt);
+        const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
+        const uint64_t dm1 = (uint64_t)__float_as_uint(bt1.y) | ((uint64_t)__float_as_uint(bt1.z) << 32);
+        const uint64_t dm2 = (uint64_t)__float_as_uint(bt2.y) | ((uint64_t)__float_as_uint(bt2.z) << 32);
+        const int k1 = __float_as_int(bt1.w), k2 = __float_as_int(bt2.w);
+        const int sg0 = k1 >= 0 ? k1 : k2, sg1 = (k1 >= 0 && k2 >= 0 && k2 != k1) ? k2 : -1;
+        const V3 ref1 = ld3v(S.xpos[__float_as_int(S.btab[b1][4])]), ref2 = ld3v(S.xpos[__float_as_int(S.btab[b2][4])]);
+        const f4 pd = ldv(S.col.stage[cl][ci]);
+        const float dist = pd.w;
+        stv(S.con.cpos[k], pd);
+        st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
+        const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
+        const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsumw * (1.0f + mu * mu), 1e-15f);
+        stv(S.con.cmeta[k], f4{mu, 1.0f / Rr, -kk * imp * dist, bb});
+        st3v(&S.con.cref[k][0], ref1); st3v(&S.con.cref[k][4], ref2);
+        S.con.cmask[k][0] = (unsigned)dm1; S.con.cmask[k][1] = (unsigned)(dm1 >> 32);
+        S.con.cmask[k][2] = (unsigned)dm2; S.con.cmask[k][3] = (unsigned)(dm2 >> 32);
+        S.con.cblk[k][0] = sg0; S.con.cblk[k][1] = sg1; S.con.cblk[k][2] = 0; S.con.cblk[k][3] = 0;
+      }
+    }
+    WSYNC();  // col scratch is dead from here on
+    // per-block contact lists (lane = contact; ordered ballot compaction): every later loop of a dof lane runs over
+    // the contacts that touch ITS block only, and the four blocks (DPP rows) walk their lists side by side
+    {
+      const bool isc = lane < ncon;
+      const int s0 = isc ? S.con.cblk[lane][0] : -1, s1 = isc ? S.con.cblk[lane][1] : -1;
+#pragma unroll
+      for (int bq = 0; bq < 4; bq++) {
+        const bool touch = isc && (s0 == bq || s1 == bq);
+        const unsigned long long bal = __ballot(touch);
+        if (touch) S.con.blist[bq][__popcll(bal & ((1ull << lane) - 1ull))] = lane * 2 + (s0 == bq ? 0 : 1);
+        if (lane == 0) S.con.bcount[bq] = __popcll(bal);
+      }
+    }
+    WSYNC();
+  };
+  if (helper) {
+    __syncthreads();  // (1) staged tables (this wave), body poses (wave 0)
+    collide();
+    __syncthreads();  // (2)
+    return;
   }
 
   STAMP(0);
@@ -321,7 +548,6 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     if (isdof && d_uadr >= 0) tg = mine;
   }
   S.target[lane] = tg;
-  if (lane == 0) { S.ncon = 0; S.ncand = 0; }
   WSYNC();
 
   // ======================= forward kinematics (FK cache as in the 16-lane kernel) ====================
@@ -336,6 +562,7 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
       wave_fk(S, lane, nb, bk);
     }
   }
+  if (DUAL) __syncthreads();  // (1)
   STAMP(1);
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; }
@@ -565,204 +792,10 @@ __global__ __launch_bounds__(64) void mir_step64_kernel(StepArgs64 a) {
     WSYNC();  // dyn scratch is dead from here on
 
     STAMP(5);
-    // ======================= collision detection ================================================
-    if (lane == 0) { S.ncon = 0; S.ncand = 0; }
-    if (lane < ngeom) {
-      Q4 qb = ld4v(S.xquat[g_bodyl]);
-      st3v(S.col.gpos[lane], ld3v(S.xpos[g_bodyl]) + qrot(qb, g_posl));
-      st4v(S.col.gquat[lane], qmul(qb, g_quatl));
-    }
-    S.col.ccount[lane] = 0;
-    WSYNC();
-    int mycount = 0;
-    int ncand = 0;
-    if (enable_collision) {
-      // broadphase: bounding test per static candidate pair, ordered compaction of survivors (lane = pair)
-      int base = 0;
-      for (int p0 = 0; p0 < npair; p0 += NL) {
-        int p = p0 + lane;
-        bool hit = false;
-        if (p < npair) {
-          const int pr = (int)S.pairs[p];
-          const int g1 = pr & 255, g2 = pr >> 8;
-          V3 h2 = ld3(&S.gts[g2][1]);
-          M3 R2 = q2m(ld4v(S.col.gquat[g2]));
-          V3 c2 = ld3v(S.col.gpos[g2]);
-          if ((__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE) {
-            V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
-            float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
-            hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
-          } else {
-            V3 h1 = ld3(&S.gts[g1][1]);
-            float rs = sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
-            V3 dc = c2 - ld3v(S.col.gpos[g1]);
-            hit = dot(dc, dc) <= rs * rs;
-            if (hit) {
-              // the six face axes of the narrowphase's separating-axis test (same expressions): a pair they separate
-              // would come back with zero contacts, and the narrowphase walks its candidates four at a time
-              const M3 R1 = q2m(ld4v(S.col.gquat[g1]));
-              const V3 A0 = mcol(R1, 0), A1 = mcol(R1, 1), A2 = mcol(R1, 2), B0 = mcol(R2, 0), B1 = mcol(R2, 1), B2 = mcol(R2, 2);
-              const V3 Ls[6] = {A0, A1, A2, B0, B1, B2};
-#pragma unroll
-              for (int c = 0; c < 6; c++) {
-                const V3 L = Ls[c];
-                const float ra = h1.x * fabsf(dot(A0, L)) + h1.y * fabsf(dot(A1, L)) + h1.z * fabsf(dot(A2, L));
-                const float rb = h2.x * fabsf(dot(B0, L)) + h2.y * fabsf(dot(B1, L)) + h2.z * fabsf(dot(B2, L));
-                if (fabsf(dot(dc, L)) - (ra + rb) > 0.0f) hit = false;
-              }
-            }
-          }
-        }
-        const unsigned long long bal = __ballot(hit);
-        int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (hit && pos < NL) S.col.cand[pos] = p;
-        base += __popcll(bal);
-      }
-      ncand = base < NL ? base : NL;
-      if (lane == 0) S.ncand = ncand;
-      WSYNC();
-      STAMP(6);
-      // narrowphase, plane-box: DPP row r takes candidates r, r + 4, ...; the 8 box corners on lanes 0..7 of the row
-      for (int k0 = 0; k0 < ncand; k0 += 4) {
-        const int k = k0 + blk;
-        const bool act = k < ncand;
-        const int pr = act ? (int)S.pairs[S.col.cand[k]] : 0;
-        const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isplane = act && (__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE;
-        if (!__any(isplane)) continue;
-        const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
-        const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
-        const M3 R2 = q2m(ld4v(S.col.gquat[g2]));
-        const V3 h = ld3(&S.gts[g2][1]);
-        const int c = lane & 7;
-        const V3 w = ld3v(S.col.gpos[g2]) + ((c & 1) ? h.x : -h.x) * mcol(R2, 0) + ((c & 2) ? h.y : -h.y) * mcol(R2, 1) +
-                     ((c & 4) ? h.z : -h.z) * mcol(R2, 2);
-        const V3 rel = w - ld3v(S.col.gpos[g1]);
-        const float d = dot(rel, n), u = dot(rel, eu), v = dot(rel, ev);
-        const bool pen = isplane && l16 < 8 && d < 0.0f;
-        const uint32_t penm = (uint32_t)(__ballot(pen) >> (blk * G)) & 0xffu;
-        const int cnt = __popc(penm);
-        // support extremes (+u, -u, +v, -v; lowest corner index wins ties), needed only when more than 4 corners penetrate
-        // somewhere in the wave (a box lying flat has exactly 4: the reductions are skipped)
-        uint32_t ext = 0u;
-        if (__any(cnt > 4)) {
-          const float uM = gmaxf(pen ? u : -3e38f), um = -gmaxf(pen ? -u : -3e38f);
-          const float vM = gmaxf(pen ? v : -3e38f), vm = -gmaxf(pen ? -v : -3e38f);
-          const uint32_t e0 = (uint32_t)(__ballot(pen && u == uM) >> (blk * G)) & 0xffu, e1 = (uint32_t)(__ballot(pen && u == um) >> (blk * G)) & 0xffu;
-          const uint32_t e2 = (uint32_t)(__ballot(pen && v == vM) >> (blk * G)) & 0xffu, e3 = (uint32_t)(__ballot(pen && v == vm) >> (blk * G)) & 0xffu;
-          ext = (e0 & -e0) | (e1 & -e1) | (e2 & -e2) | (e3 & -e3);
-        }
-        const uint32_t keepm = cnt <= 4 ? penm : ext;
-        const bool keep = (keepm >> l16 & 1u) && l16 < 8;
-        const int slot = __popc(keepm & ((1u << l16) - 1u));
-        if (isplane && keep && slot < 4) {
-          const V3 pos = w - (0.5f * d) * n;
-          stv(S.col.stage[k][slot], f4{pos.x, pos.y, pos.z, d});
-        }
-        if (isplane && l16 == 0) {
-          S.col.ccount[k] = min(__popc(keepm), 4);
-          st3v(S.col.snorm[k], n);
-        }
-      }
-      WSYNC();
-      mycount = S.col.ccount[lane];
-      STAMP(7);
-      // narrowphase, box-box: DPP row r takes candidates r, r + 4, ... (like plane-box).  The 15 separating axes sit on
-      // lanes 0..14 of the row, the incident-face vertices on lanes 0..3 (box_box_row, mir_dev.h)
-      for (int k0 = 0; k0 < ncand; k0 += 4) {
-        const int k = k0 + blk;
-        const bool actk = k < ncand;
-        const int pr = actk ? (int)S.pairs[S.col.cand[k]] : 0;
-        const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isbox = actk && (__float_as_int(S.gts[g1][0]) & 255) != MIR_GEOM_PLANE;
-        if (!__any(isbox)) continue;
-        if (isbox) {  // whole rows
-          const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
-          const BoxG A = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(&S.gts[g1][1])};
-          const BoxG B = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3(&S.gts[g2][1])};
-          const int cnt = box_box_row(A, B, l16, lane, blk * G, S.col.stage[k], S.col.snorm[k], reinterpret_cast<float*>(&S.con) + 48 * blk);  // (contact arrays: not written yet)
-          if (l16 == 0) S.col.ccount[k] = cnt;
-        }
-      }
-      WSYNC();
-      mycount = S.col.ccount[lane];
-    }
-    STAMP(8);
-    // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
-    const int maxc = max_contacts < MAXC ? max_contacts : MAXC;
-    int ncon;
-    {
-      float inclf = (float)mycount;
-      inclf += row_shr<1>(inclf);
-      inclf += row_shr<2>(inclf);
-      inclf += row_shr<4>(inclf);
-      inclf += row_shr<8>(inclf);
-      const float r0 = rl(inclf, 15), r1 = rl(inclf, 31), r2 = rl(inclf, 47), r3 = rl(inclf, 63);
-      const float rowbase = blk == 0 ? 0.0f : (blk == 1 ? r0 : (blk == 2 ? r0 + r1 : r0 + r1 + r2));
-      const int incl = (int)(inclf + rowbase);
-      const int off = incl - mycount;
-      const int total = (int)(r0 + r1 + r2 + r3);
-      ncon = total < maxc ? total : maxc;
-      if (lane == 0) S.ncon = ncon;
-      for (int c = 0; c < mycount; c++)
-        if (off + c < maxc) S.col.cmap[off + c] = lane * 8 + c;
-      WSYNC();
-      // every contact is finished by its own lane (staging lives in col scratch, disjoint from the contact arrays)
-      if (lane < ncon) {
-        const int k = lane;
-        const int mp = S.col.cmap[k];
-        const int cl = mp >> 3, ci = mp & 7;
-        const int pr = (int)S.pairs[S.col.cand[cl]];
-        const int g1 = pr & 255, g2 = pr >> 8;
-        const V3 n = ld3v(S.col.snorm[cl]);
-        V3 t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
-        t1 = t1 - dot(n, t1) * n;
-        t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
-        const V3 t2 = cross(n, t1);
-        const float mu = fmaxf(S.gfr[g1], S.gfr[g2]);
-        const float* s1 = S.gsol[g1];
-        const float* s2 = S.gsol[g2];
-        const float sr0 = 0.5f * (s1[0] + s2[0]), sr1 = 0.5f * (s1[1] + s2[1]);
-        const float si[5] = {0.5f * (s1[2] + s2[2]), 0.5f * (s1[3] + s2[3]), 0.5f * (s1[4] + s2[4]), 0.5f * (s1[5] + s2[5]), 0.5f * (s1[6] + s2[6])};
-        const int b1 = __float_as_int(S.gts[g1][0]) >> 8, b2 = __float_as_int(S.gts[g2][0]) >> 8;
-        const f4 bt1 = ldv(&S.btab[b1][0]), bt2 = ldv(&S.btab[b2][0]);
-        const float wsumw = bt1.x + bt2.x;
-        const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
-        const float tc = fmaxf(sr0, 2.0f * dt);
-        const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
-        const uint64_t dm1 = (uint64_t)__float_as_uint(bt1.y) | ((uint64_t)__float_as_uint(bt1.z) << 32);
-        const uint64_t dm2 = (uint64_t)__float_as_uint(bt2.y) | ((uint64_t)__float_as_uint(bt2.z) << 32);
-        const int k1 = __float_as_int(bt1.w), k2 = __float_as_int(bt2.w);
-        const int sg0 = k1 >= 0 ? k1 : k2, sg1 = (k1 >= 0 && k2 >= 0 && k2 != k1) ? k2 : -1;
-        const V3 ref1 = ld3v(S.xpos[__float_as_int(S.btab[b1][4])]), ref2 = ld3v(S.xpos[__float_as_int(S.btab[b2][4])]);
-        const f4 pd = ldv(S.col.stage[cl][ci]);
-        const float dist = pd.w;
-        stv(S.con.cpos[k], pd);
-        st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
-        const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
-        const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsumw * (1.0f + mu * mu), 1e-15f);
-        stv(S.con.cmeta[k], f4{mu, 1.0f / Rr, -kk * imp * dist, bb});
-        st3v(&S.con.cref[k][0], ref1); st3v(&S.con.cref[k][4], ref2);
-        S.con.cmask[k][0] = (unsigned)dm1; S.con.cmask[k][1] = (unsigned)(dm1 >> 32);
-        S.con.cmask[k][2] = (unsigned)dm2; S.con.cmask[k][3] = (unsigned)(dm2 >> 32);
-        S.con.cblk[k][0] = sg0; S.con.cblk[k][1] = sg1; S.con.cblk[k][2] = 0; S.con.cblk[k][3] = 0;
-      }
-    }
-    WSYNC();  // col scratch is dead from here on
-    // per-block contact lists (lane = contact; ordered ballot compaction): every later loop of a dof lane runs over
-    // the contacts that touch ITS block only, and the four blocks (DPP rows) walk their lists side by side
-    {
-      const bool isc = lane < ncon;
-      const int s0 = isc ? S.con.cblk[lane][0] : -1, s1 = isc ? S.con.cblk[lane][1] : -1;
-#pragma unroll
-      for (int bq = 0; bq < 4; bq++) {
-        const bool touch = isc && (s0 == bq || s1 == bq);
-        const unsigned long long bal = __ballot(touch);
-        if (touch) S.con.blist[bq][__popcll(bal & ((1ull << lane) - 1ull))] = lane * 2 + (s0 == bq ? 0 : 1);
-        if (lane == 0) S.con.bcount[bq] = __popcll(bal);
-      }
-    }
-    WSYNC();
+    // ======================= collision detection (wave 1's work in the single-step instantiation) ==
+    if (!DUAL) collide();
+    else __syncthreads();  // (2) contacts finished by wave 1; this wave is done with the dynamics scratch
+    const int ncon = __builtin_amdgcn_readfirstlane(S.ncon), ncand = __builtin_amdgcn_readfirstlane(S.ncand);
     const int nmine = S.con.bcount[blk];  // contacts touching this lane's block
 
     STAMP(9);
@@ -1266,7 +1299,7 @@ extern "C" int mir_launch_step64(const StepArgs64* args, hipStream_t stream) {
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat;
   const bool plain_loop = a.mode == 0 && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
                           !a.env_state && !a.reward && !a.terminated && !a.term_host;
-  if (single) hipLaunchKernelGGL(mir_step64_kernel<0>, dim3(a.B), dim3(64), 0, stream, a);
+  if (single) hipLaunchKernelGGL(mir_step64_kernel<0>, dim3(a.B), dim3(128), 0, stream, a);  // two waves per env
   else if (plain_loop) hipLaunchKernelGGL(mir_step64_kernel<1>, dim3(a.B), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL(mir_step64_kernel<2>, dim3(a.B), dim3(64), 0, stream, a);
   return (int)hipGetLastError();

@@ -49,7 +49,7 @@ def setup_grasp(B):
         for _ in range(n):
             task.step_raw(tg)
     torch.cuda.synchronize()
-    sc = task._mir
+    sc = task._mir; sc.set_diag(True)
     setup_grasp.keep = env
     return sc, tg[None].repeat(64, 1, 1), None
 

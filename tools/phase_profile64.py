@@ -7,7 +7,7 @@ from gym_genesis.env import GenesisEnv
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 env = GenesisEnv(task="cube_stack", robot="franka", num_envs=B)
 env.reset(seed=0)
-task = env._env; sc = task._mir
+task = env._env; sc = task._mir; sc.set_diag(True)
 sc.lib.mir_debug_profile_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 sc.lib.mir_debug_profile_step.restype = C.c_int
 home = task._home

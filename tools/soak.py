@@ -11,7 +11,7 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 for task, robot in (("cube_pick", "franka"), ("cube_pick", "so101"), ("cube_stack", "franka"), ("cube_stack", "so101")):
     env = GenesisEnv(task=task, robot=robot, num_envs=B)
     env.reset(seed=0)
-    t = env._env; sc = t._mir; dev = sc.device
+    t = env._env; sc = t._mir; sc.set_diag(True); dev = sc.device
     nu = sc.nu
     home = getattr(t, "_home", torch.zeros((B, nu), device=dev))[:, :nu]
     gen = torch.Generator(device=dev).manual_seed(7)
