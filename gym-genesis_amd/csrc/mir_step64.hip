@@ -39,7 +39,7 @@
 #define MAXC MIR_MAX_CONTACT
 #define JSEG 52 /* floats per contact segment: 3 rows x 16 + 4 pad */
 #define MSTR 20 /* row stride of the block-diagonal M rows in LDS */
-#define STAMP(k) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(k) do { if (a.prof && blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
 static_assert(MAXC <= NL, "lane c owns contact c");
 static_assert(MIR_MAX_GEOM <= NL && MIR_MAX_PAIR <= 4 * NL, "lane ownership of geoms / pairs");
 
@@ -150,17 +150,29 @@ struct Env64 {
       DynM64 dm;
       Col64 col;
     };
-    float Jb[MAXC][2][JSEG];
+    struct {
+      float Jb[MAXC][2][JSEG];
+      float hx3[NL - 48][G];  // (second piece of the Hessian hand-over, see hx)
+    };
   };
   Con64 con;          // (before the contacts are finished: the box-box clipping exchange, 48 floats per DPP row)
   // the few model tables that are looked up with a DYNAMIC index inside the collision phases, staged once per launch:
   // an LDS round trip (~64 cycles) instead of an L2 one per dependent hop (there is no room for the whole model)
-  float gts[MIR_MAX_GEOM][4];           // type | body << 8 (as int bits), half extents
-  float gfr[MIR_MAX_GEOM];              // friction
-  unsigned short pairs[MIR_MAX_PAIR];   // g1 | g2 << 8
-  float gsol[MIR_MAX_GEOM][8];          // solref[2], solimp[5]
-  float btab[NB][8];                    // body_invweight0, dofmask lo, hi, block, root (contact finish)
+  union {
+    struct {
+      float gts[MIR_MAX_GEOM][4];           // type | body << 8 (as int bits), half extents
+      float gfr[MIR_MAX_GEOM];              // friction
+      unsigned short pairs[MIR_MAX_PAIR];   // g1 | g2 << 8
+      float gsol[MIR_MAX_GEOM][8];          // solref[2], solimp[5]
+      float btab[NB][8];                    // body_invweight0, dofmask lo, hi, block, root (contact finish)
+    };
+    // two-wave single-step instantiation only (one launch = one step, the tables are dead once the contacts are finished): the
+    // Hessian rows wave 1 accumulates for wave 0, lanes 0..47 here and the rest in hx3
+    float hx[48][G];
+  };
 };
+static_assert(sizeof(float[48][G]) <= sizeof(float[MIR_MAX_GEOM][4]) + sizeof(float[MIR_MAX_GEOM]) + sizeof(unsigned short[MIR_MAX_PAIR]) +
+                                          sizeof(float[MIR_MAX_GEOM][8]) + sizeof(float[NB][8]), "Hessian hand-over fits the staged tables");
 static_assert(MIR_MAX_GEOM <= 256, "pair entries are 16 bits");
 static_assert(sizeof(Con64) >= 4 * 48 * sizeof(float), "the box-box clipping exchange lives in the contact arrays");
 
@@ -531,10 +543,91 @@ void mir_step64_kernel(StepArgs64 a) {
     }
     WSYNC();
   };
+  auto jacobians = [&](int nmine, int first, int stride) {
+    // contact base Jacobians: lane = dof writes its entry of the segment its block owns (zeros included, so a
+    // segment is always fully defined)
+    // (cdof of the lane is loop-invariant; every read of a contact is issued in one batch ahead of the arithmetic, and a
+    // dof that moves neither body simply ends with sgn = 0: no divergent branch around the reads)
+    const V3 cd_ang = ld3v(&S.cdof[lane][0]), cd_lin = ld3v(&S.cdof[lane][4]);
+    for (int k0 = first; k0 < nmine; k0 += stride) {  // two list entries per trip
+      const int2 e2 = *reinterpret_cast<const int2*>(&S.con.blist[blk][k0]);
+      const int eqA = e2.x, eqB = k0 + 1 < nmine ? e2.y : e2.x;
+      const int cA = eqA >> 1, cB = eqB >> 1;
+      const f4 mkA = ldv(reinterpret_cast<const float*>(S.con.cmask[cA])), mkB = ldv(reinterpret_cast<const float*>(S.con.cmask[cB]));
+      const f4 cpA = ldv(S.con.cpos[cA]), r1A = ldv(&S.con.cref[cA][0]), r2A = ldv(&S.con.cref[cA][4]);
+      const f4 cpB = ldv(S.con.cpos[cB]), r1B = ldv(&S.con.cref[cB][0]), r2B = ldv(&S.con.cref[cB][4]);
+      const f4 fnA = ldv(&S.con.cfrm[cA][0]), f1A = ldv(&S.con.cfrm[cA][4]), f2A = ldv(&S.con.cfrm[cA][8]);
+      const f4 fnB = ldv(&S.con.cfrm[cB][0]), f1B = ldv(&S.con.cfrm[cB][4]), f2B = ldv(&S.con.cfrm[cB][8]);
+      __builtin_amdgcn_sched_barrier(0);
+#define MIR_JCOL64(mk, cp, r1, r2, fn, f1, f2, eq)                                                                  \
+      {                                                                                                             \
+        const uint64_t dm1 = (uint64_t)__float_as_uint(mk.x) | ((uint64_t)__float_as_uint(mk.y) << 32);             \
+        const uint64_t dm2 = (uint64_t)__float_as_uint(mk.z) | ((uint64_t)__float_as_uint(mk.w) << 32);             \
+        const bool in2 = dm2 >> lane & 1ull, in1 = dm1 >> lane & 1ull;                                              \
+        const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f); /* a dof moving both bodies cancels */         \
+        const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));                    \
+        const V3 vel = cross(cd_ang, r) + cd_lin;                                                                   \
+        float* jb = &S.Jb[(eq) >> 1][(eq) & 1][0];                                                                  \
+        /* (selects, not products: a lane that carries no dof holds stale LDS in cd_ang / cd_lin, and 0 x NaN is NaN) */       \
+        jb[l16] = sgn != 0.0f ? sgn * dot(vel, v3(fn.x, fn.y, fn.z)) : 0.0f;                                        \
+        jb[16 + l16] = sgn != 0.0f ? sgn * dot(vel, v3(f1.x, f1.y, f1.z)) : 0.0f;                                   \
+        jb[32 + l16] = sgn != 0.0f ? sgn * dot(vel, v3(f2.x, f2.y, f2.z)) : 0.0f;                                   \
+      }
+      MIR_JCOL64(mkA, cpA, r1A, r2A, fnA, f1A, f2A, eqA)
+      if (k0 + 1 < nmine) MIR_JCOL64(mkB, cpB, r1B, r2B, fnB, f1B, f2B, eqB)
+#undef MIR_JCOL64
+    }
+  };
+  // J^T D J of the lane's own block with EVERY pyramid row of every contact active (lane = dof row, 16 columns), from zero in list
+  // order.  The Newton loop starts its incremental Hessian from M + this (resting contacts have all four rows active; the rows
+  // that are not come off in the first incremental update), so with two waves it is accumulated by wave 1 while wave 0 evaluates
+  // the constraint rows, the warm start and the first gradient.
+  auto hess_full = [&](float (&hp)[G], int nmine) {
+#pragma unroll
+    for (int j = 0; j < G; j++) hp[j] = 0.0f;
+    for (int kq = 0; kq < nmine; kq++) {
+      const int eq = S.con.blist[blk][kq];
+      const int c = eq >> 1;
+      const float* seg = &S.Jb[c][eq & 1][0];
+      const float jn = seg[l16], j1 = seg[16 + l16], j2 = seg[32 + l16];
+      const f4 mt = ldv(S.con.cmeta[c]);
+      f4 xn[4], x1[4], x2[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { xn[q] = ldv(seg + 4 * q); x1[q] = ldv(seg + 16 + 4 * q); x2[q] = ldv(seg + 32 + 4 * q); }
+      __builtin_amdgcn_sched_barrier(0);  // (the whole batch of reads ahead of the arithmetic: one LDS round trip)
+      const float mu = mt.x, D = mt.y;
+      const float tn = jn * (4.0f * D), t1 = j1 * (mu * mu * (2.0f * D)), t2 = j2 * (mu * mu * (2.0f * D));
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        hp[4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
+        hp[4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
+        hp[4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
+        hp[4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
+      }
+    }
+  };
+  float* const hxrow = lane < 48 ? &S.hx[lane][0] : &S.hx3[lane - 48][0];
   if (helper) {
+#ifndef MIR_PROFILE_SINGLE
+    a.prof = nullptr;
+#endif
+    STAMP(24);
     __syncthreads();  // (1) staged tables (this wave), body poses (wave 0)
+    STAMP(25);
     collide();
-    __syncthreads();  // (2)
+    STAMP(26);
+    __syncthreads();  // (2) wave 0 is done with the dynamics scratch: the Jacobian segments may overwrite it
+    STAMP(27);
+    const int nmine = S.con.bcount[blk];
+    jacobians(nmine, 2, 4);
+    STAMP(28);
+    __syncthreads();  // (3)
+    float hp[G];
+    hess_full(hp, nmine);
+#pragma unroll
+    for (int q = 0; q < 4; q++) stv(hxrow + 4 * q, f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]});
+    STAMP(29);
+    __syncthreads();  // (4)
     return;
   }
 
@@ -565,7 +658,11 @@ void mir_step64_kernel(StepArgs64 a) {
   if (DUAL) __syncthreads();  // (1)
   STAMP(1);
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
-  if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; }
+  if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr;
+#ifndef MIR_PROFILE_SINGLE  /* (a profiling build keeps the phase stamps in the single-step instantiation: tools/phase_profile64.py) */
+    a.prof = nullptr;
+#endif
+  }
   if (VARIANT == 1) { a.mode = 0; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr; a.prof = nullptr; a.agent_pos = a.env_state = a.reward = nullptr; a.terminated = a.term_host = nullptr; }
   // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
   const int eb = m->eef_body, ob = m->obj_body, ob2 = m->obj2_body;
@@ -800,39 +897,8 @@ void mir_step64_kernel(StepArgs64 a) {
 
     STAMP(9);
     // ======================= constraint rows ======================================================
-    // contact base Jacobians: lane = dof writes its entry of the segment its block owns (zeros included, so a
-    // segment is always fully defined)
-    // (cdof of the lane is loop-invariant; every read of a contact is issued in one batch ahead of the arithmetic, and a
-    // dof that moves neither body simply ends with sgn = 0: no divergent branch around the reads)
-    const V3 cd_ang = ld3v(&S.cdof[lane][0]), cd_lin = ld3v(&S.cdof[lane][4]);
-    for (int k0 = 0; k0 < nmine; k0 += 2) {  // two list entries per trip
-      const int2 e2 = *reinterpret_cast<const int2*>(&S.con.blist[blk][k0]);
-      const int eqA = e2.x, eqB = k0 + 1 < nmine ? e2.y : e2.x;
-      const int cA = eqA >> 1, cB = eqB >> 1;
-      const f4 mkA = ldv(reinterpret_cast<const float*>(S.con.cmask[cA])), mkB = ldv(reinterpret_cast<const float*>(S.con.cmask[cB]));
-      const f4 cpA = ldv(S.con.cpos[cA]), r1A = ldv(&S.con.cref[cA][0]), r2A = ldv(&S.con.cref[cA][4]);
-      const f4 cpB = ldv(S.con.cpos[cB]), r1B = ldv(&S.con.cref[cB][0]), r2B = ldv(&S.con.cref[cB][4]);
-      const f4 fnA = ldv(&S.con.cfrm[cA][0]), f1A = ldv(&S.con.cfrm[cA][4]), f2A = ldv(&S.con.cfrm[cA][8]);
-      const f4 fnB = ldv(&S.con.cfrm[cB][0]), f1B = ldv(&S.con.cfrm[cB][4]), f2B = ldv(&S.con.cfrm[cB][8]);
-      __builtin_amdgcn_sched_barrier(0);
-#define MIR_JCOL64(mk, cp, r1, r2, fn, f1, f2, eq)                                                                  \
-      {                                                                                                             \
-        const uint64_t dm1 = (uint64_t)__float_as_uint(mk.x) | ((uint64_t)__float_as_uint(mk.y) << 32);             \
-        const uint64_t dm2 = (uint64_t)__float_as_uint(mk.z) | ((uint64_t)__float_as_uint(mk.w) << 32);             \
-        const bool in2 = dm2 >> lane & 1ull, in1 = dm1 >> lane & 1ull;                                              \
-        const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f); /* a dof moving both bodies cancels */         \
-        const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));                    \
-        const V3 vel = cross(cd_ang, r) + cd_lin;                                                                   \
-        float* jb = &S.Jb[(eq) >> 1][(eq) & 1][0];                                                                  \
-        /* (selects, not products: a lane that carries no dof holds stale LDS in cd_ang / cd_lin, and 0 x NaN is NaN) */       \
-        jb[l16] = sgn != 0.0f ? sgn * dot(vel, v3(fn.x, fn.y, fn.z)) : 0.0f;                                        \
-        jb[16 + l16] = sgn != 0.0f ? sgn * dot(vel, v3(f1.x, f1.y, f1.z)) : 0.0f;                                   \
-        jb[32 + l16] = sgn != 0.0f ? sgn * dot(vel, v3(f2.x, f2.y, f2.z)) : 0.0f;                                   \
-      }
-      MIR_JCOL64(mkA, cpA, r1A, r2A, fnA, f1A, f2A, eqA)
-      if (k0 + 1 < nmine) MIR_JCOL64(mkB, cpB, r1B, r2B, fnB, f1B, f2B, eqB)
-#undef MIR_JCOL64
-    }
+    // contact base Jacobians (with two waves: wave 1 takes every other pair of list entries)
+    jacobians(nmine, 0, DUAL ? 4 : 2);
     // joint-limit rows: lane = dof, lane-private
     float lsg = 0.0f, lD = 0.0f, laref = 0.0f;
     if (d_limited) {
@@ -849,6 +915,7 @@ void mir_step64_kernel(StepArgs64 a) {
       }
     }
     WSYNC();
+    if (DUAL) __syncthreads();  // (3) both halves of the Jacobian segments
     // contact rows, lane = contact, lane-private: aref_r = -b (J_r qvel) - k imp dist
     const bool iscon = lane < ncon;
     float cmu = 0.0f, cD = 0.0f;
@@ -942,6 +1009,7 @@ void mir_step64_kernel(StepArgs64 a) {
     // In the single-step instantiation the solve is compiled twice: the block-diagonal case (no contact couples two blocks:
     // 73 % of the envs) carries no off-diagonal rows and no 64-wide working copy, i.e. ~130 registers less than the coupled
     // case.  (The loop instantiations keep one run-time-switched copy: there the duplication cost more than it saved.)
+    bool met4 = false;
     auto newton = [&](auto mode_t) {
     constexpr int MODE = decltype(mode_t)::value;  // 0: block-diagonal, 1: coupled, 2: decided at run time (loop instantiations)
     const bool cpl = MODE == 2 ? coupled : MODE == 1;
@@ -1002,13 +1070,29 @@ void mir_step64_kernel(StepArgs64 a) {
         for (int j = 0; j < G; j++) hd[j] += j == l16 ? dl : 0.0f;
       }
       oldlact = lact;
-      // diagonal blocks: the four DPP rows walk their own contact lists side by side
+      if (it == 0) {  // the all-rows-active Hessian: from wave 1 where there is one
+        float hp[G];
+        if (DUAL) {
+          __syncthreads();  // (4)
+          met4 = true;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const f4 v = ldv(hxrow + 4 * q);
+            hp[4 * q] = v.x; hp[4 * q + 1] = v.y; hp[4 * q + 2] = v.z; hp[4 * q + 3] = v.w;
+          }
+        } else {
+          hess_full(hp, nmine);
+        }
+#pragma unroll
+        for (int j = 0; j < G; j++) hd[j] += hp[j];
+      }
+      // diagonal blocks: the four DPP rows walk their own contact lists side by side (first iteration: relative to all-active)
       for (int kq = 0; kq < nmine; kq++) {
         const int eq = S.con.blist[blk][kq];
         const int c = eq >> 1, myseg = eq & 1;
         const f4 fb = ldv(S.con.cfb[c]);
         const unsigned both = (unsigned)fb.w;
-        const unsigned bits = both & 15u, old = both >> 4;
+        const unsigned bits = both & 15u, old = it == 0 ? 15u : both >> 4;
         if (bits == old) continue;
         const float* seg = &S.Jb[c][myseg][0];
         const float jn = seg[l16], j1 = seg[16 + l16], j2 = seg[32 + l16];
@@ -1184,6 +1268,7 @@ void mir_step64_kernel(StepArgs64 a) {
     if constexpr (!SINGLE) newton(std::integral_constant<int, 2>{});
     else if (coupled) newton(std::integral_constant<int, 1>{});
     else newton(std::integral_constant<int, 0>{});
+    if (DUAL && !met4) __syncthreads();  // (4) (no Hessian was needed: wave 1 is let go)
     STAMP(16);
     if (a.out_qacc && isdof && step == 0) a.out_qacc[(size_t)env * nv + m->d_dof[lane]] = qacc;
     if (a.diag && lane == 0) {
@@ -1295,7 +1380,12 @@ void mir_step64_kernel(StepArgs64 a) {
 
 extern "C" int mir_launch_step64(const StepArgs64* args, hipStream_t stream) {
   StepArgs64 a = *args;
-  const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !a.prof && !a.out_M && !a.out_bias &&
+#ifdef MIR_PROFILE_SINGLE
+  const bool prof_blocks_single = false;
+#else
+  const bool prof_blocks_single = a.prof != nullptr;
+#endif
+  const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !prof_blocks_single && !a.out_M && !a.out_bias &&
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat;
   const bool plain_loop = a.mode == 0 && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
                           !a.env_state && !a.reward && !a.terminated && !a.term_host;

@@ -23,13 +23,24 @@ names = ["load", "fk/cache", "cdof+cinert", "vel+crb", "rne+M", "smooth solve", 
          "warm start", "grad(it0)", "hessian(it0)", "GJ64(it0)", "linesearch(it0)", "rest of newton", "integrate", "fk", "store+obs"]
 acc = np.zeros(19)
 n = 20
+dual = np.zeros(12)
 for r in range(n):
     prof = torch.zeros(32, dtype=torch.int64, device=sc.device)
     sc._check(sc.lib.mir_debug_profile_step(sc.h, C.c_void_p(prof.data_ptr()), sc._stream()))
     torch.cuda.synchronize()
     p = prof.cpu().numpy().astype(np.float64)
+    if p[24] > 0:  # a -DMIR_PROFILE_SINGLE build: the two-wave single-step instantiation; stamps 6..8 and 24..28 are wave 1's
+        t0 = p[0]
+        dual += np.array([p[1] - t0, p[5] - p[1], p[9] - p[5], p[10] - p[9], p[25] - t0, p[6] - p[25], p[7] - p[6], p[8] - p[7], p[26] - p[8],
+                          p[27] - p[26], p[28] - p[27], p[19] - t0])
+        p[6] = p[7] = p[8] = p[5]
     acc += np.diff(p[:20])
 acc /= n
+if dual.any():
+    dual /= n
+    for nm, c in zip(["w0 load+fk -> (1)", "w0 dynamics", "w0 wait (2)", "w0 J + rows (3)", "w1 tables -> (1)", "w1 geom+broad", "w1 plane-box", "w1 box-box",
+                      "w1 compact+finish", "w1 wait (2)", "w1 J half", "whole step"], dual):
+        print(f"{nm:18s} {c:9.0f} cycles")
 for nm, c in zip(names[1:], acc):
     print(f"{nm:18s} {c:9.0f} cycles")
 print(f"{'total':18s} {acc.sum():9.0f} cycles; diag: ncon {sc.get_diag()[0][0].item()} niter {sc.get_diag()[2][0].item()}")
