@@ -207,7 +207,23 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
     a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
     a.term_host = o.term_host; a.term_tag = o.term_tag;
-    rc = mir_launch_step64(&a, (hipStream_t)stream);
+    if (a.mode == 0 && a.n_steps > 1 && a.act_step && a.rows_step && !a.ar.episode_len && !a.prof) {
+      // a plain K-step rollout of the wave kernel is K launches of its two-wave single-step instantiation: at ~140 us a step the
+      // launch gap is nothing, and the single-step code is faster than the step loop (which carries the loop's register spills)
+      const int K = a.n_steps;
+      const float* act0 = a.action;
+      float* rows0 = a.rows;
+      const long as = a.act_step, rs = a.rows_step;
+      a.n_steps = 1; a.act_step = 0; a.rows_step = 0;
+      rc = 0;
+      for (int k = 0; k < K && rc == 0; k++) {
+        a.action = act0 + (size_t)k * as;
+        a.rows = rows0 + (size_t)k * rs;
+        rc = mir_launch_step64(&a, (hipStream_t)stream);
+      }
+    } else {
+      rc = mir_launch_step64(&a, (hipStream_t)stream);
+    }
   }
   if (rc != 0) return hip_fail((hipError_t)rc, "step kernel launch");
   return MIR_OK;

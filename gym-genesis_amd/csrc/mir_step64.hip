@@ -1006,6 +1006,7 @@ void mir_step64_kernel(StepArgs64 a) {
     // step (comp != identity: the arm touches a cube, or two cubes of different blocks touch).  The wave runs alone on its
     // SIMD (LDS bounds the occupancy), so the 80 registers are free and every update is FMA work without memory round trips.
     const bool coupled = comp != 0x8421u;
+    STAMP(20);
     // In the single-step instantiation the solve is compiled twice: the block-diagonal case (no contact couples two blocks:
     // 73 % of the envs) carries no off-diagonal rows and no 64-wide working copy, i.e. ~130 registers less than the coupled
     // case.  (The loop instantiations keep one run-time-switched copy: there the duplication cost more than it saved.)
@@ -1041,6 +1042,7 @@ void mir_step64_kernel(StepArgs64 a) {
         prevbits = bits;
       }
       WSYNC();
+      if (it == 0) STAMP(21);
       // ---- gradient first (cheap): convergence is decided before any Hessian work
       float g = isdof ? Ma - qfs - lsg * lf : 0.0f;
       for (int k0 = 0; k0 < nmine; k0 += 4) {  // four list entries per trip: the entries, then every read in one batch
@@ -1060,6 +1062,7 @@ void mir_step64_kernel(StepArgs64 a) {
           if (k0 + u < nmine) g -= jn[u] * fb[u].x + j1[u] * fb[u].y + j2[u] * fb[u].z;
       }
       if (!isdof) g = 0.0f;
+      if (it == 0) STAMP(22);
       const float gn = sqrtf(wsum(g * g));
       if (scale * gn < tol || gn < gfloor) { done = true; break; }
       if (it == 0) STAMP(12);
@@ -1074,6 +1077,7 @@ void mir_step64_kernel(StepArgs64 a) {
         float hp[G];
         if (DUAL) {
           __syncthreads();  // (4)
+          STAMP(23);
           met4 = true;
 #pragma unroll
           for (int q = 0; q < 4; q++) {

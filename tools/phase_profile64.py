@@ -24,6 +24,7 @@ names = ["load", "fk/cache", "cdof+cinert", "vel+crb", "rne+M", "smooth solve", 
 acc = np.zeros(19)
 n = 20
 dual = np.zeros(12)
+fine = np.zeros(6)
 for r in range(n):
     prof = torch.zeros(32, dtype=torch.int64, device=sc.device)
     sc._check(sc.lib.mir_debug_profile_step(sc.h, C.c_void_p(prof.data_ptr()), sc._stream()))
@@ -34,12 +35,15 @@ for r in range(n):
         dual += np.array([p[1] - t0, p[5] - p[1], p[9] - p[5], p[10] - p[9], p[25] - t0, p[6] - p[25], p[7] - p[6], p[8] - p[7], p[26] - p[8],
                           p[27] - p[26], p[28] - p[27], p[19] - t0])
         p[6] = p[7] = p[8] = p[5]
+        fine += np.array([p[20] - p[11], p[21] - p[20], p[22] - p[21], p[12] - p[22], p[23] - p[12], p[29] - p[28]])
     acc += np.diff(p[:20])
 acc /= n
 if dual.any():
     dual /= n
     for nm, c in zip(["w0 load+fk -> (1)", "w0 dynamics", "w0 wait (2)", "w0 J + rows (3)", "w1 tables -> (1)", "w1 geom+broad", "w1 plane-box", "w1 box-box",
                       "w1 compact+finish", "w1 wait (2)", "w1 J half", "whole step"], dual):
+        print(f"{nm:18s} {c:9.0f} cycles")
+    for nm, c in zip(["w0 coupling graph", "w0 row forces", "w0 gradient loop", "w0 |g| + test", "w0 wait (4)", "w1 hessian"], fine / n):
         print(f"{nm:18s} {c:9.0f} cycles")
 for nm, c in zip(names[1:], acc):
     print(f"{nm:18s} {c:9.0f} cycles")
