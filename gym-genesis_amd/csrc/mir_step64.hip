@@ -22,8 +22,10 @@
 //     the two cases are compiled separately, so the common one carries none of the coupled one's registers.
 //   * lane i is also body i (< 32), geom i, candidate pair i (4 passes), contact i; box-box runs on a DPP row per pair
 //     (mir_dev.h); wave-wide reductions are a DPP row reduction + 4 v_readlane.
-//   * 37 KB of LDS per env (phase-aliased like the 16-lane kernel) -> 4 envs per CU, one wave per SIMD; no scratch.
-//   * three instantiations (single step / rollout loop / everything), as in mir_step.hip.  DESIGN.md section 10.
+//   * 40 KB of LDS per env (phase-aliased like the 16-lane kernel) -> 4 envs per CU; no scratch.
+//   * three instantiations (single step / rollout loop / everything), as in mir_step.hip.  The single-step one runs TWO waves
+//     per env (256-register budget: two waves per SIMD): wave 1 does the collision phase beside wave 0's dynamics, half of the
+//     Jacobian segments, and the all-rows-active Newton Hessian beside wave 0's warm start and first gradient.  DESIGN.md section 10.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
