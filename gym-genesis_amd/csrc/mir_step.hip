@@ -590,6 +590,33 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     }
   }
   };
+  // J^T D J with EVERY pyramid row of every contact active (lane = dof row, 16 columns), summed from zero in contact order.  The
+  // Newton loop starts its incremental Hessian from Mt + this: resting and gripping contacts have all four rows active, and the
+  // rows that are not come off in the first incremental update.  In the DUAL instantiation the collision wave accumulates it
+  // while the main wave evaluates the constraint rows, the warm start and the first gradient (hand-over through S.M, which is
+  // dead once the mass-matrix rows are in registers).
+  auto hess_full = [&](float (&hp)[G], int ncon) {
+#pragma unroll
+    for (int j = 0; j < G; j++) hp[j] = 0.0f;
+    for (int c = 0; c < ncon; c++) {
+      const float* jb = &S.Jb[c][0];
+      const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
+      const f4 mt = ldv(S.con.cmeta[c]);
+      f4 xn[4], x1[4], x2[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { xn[q] = ldv(jb + 4 * q); x1[q] = ldv(jb + 16 + 4 * q); x2[q] = ldv(jb + 32 + 4 * q); }
+      __builtin_amdgcn_sched_barrier(0);
+      const float mu = mt.x, D = mt.y;
+      const float tn = jn * (4.0f * D), t1 = j1 * (mu * mu * (2.0f * D)), t2 = j2 * (mu * mu * (2.0f * D));
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        hp[4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
+        hp[4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
+        hp[4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
+        hp[4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
+      }
+    }
+  };
   if (DUAL && wave == 1) {
     {
       f4* dst = reinterpret_cast<f4*>(&T);
@@ -601,6 +628,13 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     const int cnt = collide_detect();
     contacts_build(cnt);  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
     __syncthreads();  // (3) contact arrays and base Jacobians handed to the main wave
+    {
+      float hp[G];
+      hess_full(hp, S.ncon);
+#pragma unroll
+      for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]});
+    }
+    __syncthreads();  // (4) all-rows-active Hessian handed to the main wave
     return;
   }
 
@@ -1153,6 +1187,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     float oldlact = 0.0f;
     unsigned prevbits = 0u;  // contact lane: flags written in the previous iteration
     float gprev = 0.0f;
+    bool met4 = false;
     for (int it = 0; it < mdl_iterations; it++) {
       if (!__any(!done)) break;
       // ---- forces of the active rows; base-force triple and active flags to LDS for the dof lanes
@@ -1196,6 +1231,22 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       if (!done && (scale * gn < tol || gn < gfloor)) done = true;
       if (it == 0) STAMP(14);
       if (!__any(!done)) break;
+      if (it == 0) {  // start from Mt + the all-rows-active J^T D J (from the collision wave where there is one)
+        float hp[G];
+        if (DUAL) {
+          __syncthreads();  // (4)
+          met4 = true;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const f4 v = ldv(&S.M[lane][4 * q]);
+            hp[4 * q] = v.x; hp[4 * q + 1] = v.y; hp[4 * q + 2] = v.z; hp[4 * q + 3] = v.w;
+          }
+        } else {
+          hess_full(hp, ncon);
+        }
+#pragma unroll
+        for (int j = 0; j < G; j++) hkeep[j] += hp[j];
+      }
       // ---- Hessian row (lane = dof): incremental update of H = Mt + J^T D_active J; per contact the
       // change enters through the 3x3 weight of its pyramid in (n, t1, t2) coordinates, which is
       // linear in the per-row activity, so flipped rows contribute +-D and unchanged contacts nothing
@@ -1206,7 +1257,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
         const float* jb = &S.Jb[c][0];
         const f4 fb = ldv(S.con.cfb[c]);
         const unsigned both = (unsigned)fb.w;
-        const unsigned bits = both & 15u, old = both >> 4;
+        const unsigned bits = both & 15u, old = it == 0 ? 15u : both >> 4;  // (first iteration: relative to all rows active)
         if (bits == old) continue;  // group-uniform
         // every read of this contact in one batch, before any arithmetic (one LDS round trip after the flag word)
         const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
@@ -1333,6 +1384,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       WSYNC();
       if (it == 0) STAMP(21);
     }
+    if (DUAL && !met4) __syncthreads();  // (4) (no Hessian was needed: the collision wave is let go)
     if (a.out_qacc && valid && isdof && step == 0) a.out_qacc[(size_t)env * nv + lane] = qacc;
     if (a.diag && valid && lane == 0) {
       a.diag[(size_t)env * 4 + 0] = ncon;
