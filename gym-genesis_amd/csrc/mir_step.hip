@@ -50,7 +50,15 @@
 static_assert(MAXCON == G, "lane c owns contact c");
 
 // optional phase timestamps (debug): block 0, thread 0 records the shader clock at phase boundaries
+#ifdef MIR_PROFILE_SINGLE
+/* profiling build: the block to stamp is chosen by the host (slot 63 of the buffer), and every Newton iteration gets its own
+ * eight slots from 64 on (tools/phase_profile.py) */
+#define STAMP(k) do { if (a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
+#define ITSTAMP(it, k) do { if ((it) < 8) STAMP(64 + 8 * (it) + (k)); } while (0)
+#else
 #define STAMP(k) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
+#define ITSTAMP(it, k) do { } while (0)
+#endif
 
 namespace {
 
@@ -199,8 +207,13 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   const DevModel* __restrict__ m = a.model;
   const int tid = threadIdx.x & 63;   // lane within the wave
   const int wave = threadIdx.x >> 6;  // 0 = main wave; 1 = collision wave (DUAL only)
+#ifdef MIR_PROFILE_SINGLE
+  const int prof_blk = a.prof ? (int)a.prof[63] : -1;
+#else
+  const int prof_blk = 0;
+#endif
   STAMP(24);
-  if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[26] = __builtin_amdgcn_s_memrealtime();
+  if (a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 0) a.prof[26] = __builtin_amdgcn_s_memrealtime();
   // Prologue: EVERY global read of the launch -- model table, per-lane constants, state rows, action, cached poses -- is
   // issued before the first LDS store, so the launch starts with one L2 round trip (the compiler otherwise kept three: the
   // stores of one group sat in front of the loads of the next).
@@ -1193,6 +1206,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       // ---- forces of the active rows; base-force triple and active flags to LDS for the dof lanes
       float lact = (lsg != 0.0f && ljar < 0.0f) ? lD : 0.0f;
       const float lf = -lact * ljar;
+      bool flipped = false;  // contact lane: some pyramid row changed sides since the Hessian last saw this contact
       if (iscon) {
         float f[4];
         unsigned bits = 0;
@@ -1204,10 +1218,14 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
         }
         // w = new flags | previous flags << 4, as an exactly representable small float
         stv(S.con.cfb[lane], f4{f[0] + f[1] + f[2] + f[3], cmu * (f[0] - f[1]), cmu * (f[2] - f[3]), (float)(bits | (prevbits << 4))});
+        flipped = bits != (it == 0 ? 15u : prevbits);  // (the Hessian starts from all rows active)
         prevbits = bits;
       }
+      // the env's flipped contacts as a bit mask in every one of its lanes: the Hessian update walks those only
+      const unsigned flipmask = (unsigned)(__ballot(flipped) >> (tid & 48)) & 0xffffu;
       WSYNC();
       if (it == 0) STAMP(16);
+      ITSTAMP(it, 0);
       // ---- gradient first (cheap): convergence is decided before any Hessian work
       float g = isdof ? Ma - qfs - lsg * lf : 0.0f;
       for (int c0 = 0; c0 < ncon; c0 += 4) {  // four contacts per trip: one batch of reads, then the sums in contact order
@@ -1227,9 +1245,11 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       }
       if (!isdof) g = 0.0f;
       if (it == 0) STAMP(17);
+      ITSTAMP(it, 1);
       const float gn = sqrtf(gsum(g * g));
       if (!done && (scale * gn < tol || gn < gfloor)) done = true;
       if (it == 0) STAMP(14);
+      ITSTAMP(it, 2);
       if (!__any(!done)) break;
       if (it == 0) {  // start from Mt + the all-rows-active J^T D J (from the collision wave where there is one)
         float hp[G];
@@ -1253,19 +1273,19 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
 #pragma unroll
       for (int j = 0; j < G; j++) hkeep[j] += j == lane ? lact - oldlact : 0.0f;
       oldlact = lact;
-      for (int c = 0; c < ncon; c++) {
+      for (unsigned fm = flipmask; fm; fm &= fm - 1u) {  // (group-uniform trip count)
+        const int c = __ffs(fm) - 1;
         const float* jb = &S.Jb[c][0];
+        // every read of this contact in one batch, before any arithmetic (one LDS round trip)
         const f4 fb = ldv(S.con.cfb[c]);
-        const unsigned both = (unsigned)fb.w;
-        const unsigned bits = both & 15u, old = it == 0 ? 15u : both >> 4;  // (first iteration: relative to all rows active)
-        if (bits == old) continue;  // group-uniform
-        // every read of this contact in one batch, before any arithmetic (one LDS round trip after the flag word)
         const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
         const f4 mt = ldv(S.con.cmeta[c]);
         f4 xn[4], x1[4], x2[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) { xn[q] = ldv(jb + 4 * q); x1[q] = ldv(jb + 16 + 4 * q); x2[q] = ldv(jb + 32 + 4 * q); }
         __builtin_amdgcn_sched_barrier(0);
+        const unsigned both = (unsigned)fb.w;
+        const unsigned bits = both & 15u, old = it == 0 ? 15u : both >> 4;  // (first iteration: relative to all rows active)
         const float mu = mt.x, D = mt.y;
         const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
         const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
@@ -1283,11 +1303,13 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
 #pragma unroll
       for (int j = 0; j < G; j++) hrow[j] = hkeep[j];
       if (it == 0) STAMP(18);
+      ITSTAMP(it, 3);
       // ---- Newton direction: H s = -g
       float sv = -g;
       gj_solve(hrow, sv, lane, hsplit);
       if (!isdof) sv = 0.0f;
       if (it == 0) STAMP(15);
+      ITSTAMP(it, 4);
       // (the direction stays in the lanes: M s and J s take s_j by row broadcast, no LDS round trip)
       const float mvb = rowdot_bc(mrow, sv);
       const float mv = isdof ? mvb : 0.0f;
@@ -1299,11 +1321,15 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
         if (iscon) { jv[0] = xn + cmu * x1; jv[1] = xn - cmu * x1; jv[2] = xn + cmu * x2; jv[3] = xn - cmu * x2; }
       }
       if (it == 0) STAMP(19);
+      ITSTAMP(it, 5);
       // ---- exact line search on the piecewise-quadratic phi(alpha): safeguarded Newton on phi'
-      const float A = gsum(sv * mv), Bq = gsum(sv * (Ma - qfs));
-      float alpha = 0.0f, lo = 0.0f, hi = -1.0f, g0 = 0.0f;
-      bool lsdone = done;
-      for (int ls = 0; ls < mdl_ls_iterations; ls++) {
+      // phi'(0) is the gradient along the direction, g . s, and with the exact Hessian the first Newton iterate on phi' is
+      // alpha = 1: the evaluation at alpha = 0 (a full pass over the rows and two reductions) is not spent; the search starts
+      // at 1 with the bracket [0, ?) and phi'(0) = g . s as the scale of its stopping rule
+      const float A = gsum(sv * mv), Bq = gsum(sv * (Ma - qfs)), g0 = gsum(sv * g);
+      bool lsdone = done || g0 >= 0.0f;
+      float alpha = lsdone ? 0.0f : 1.0f, lo = 0.0f, hi = -1.0f;
+      for (int ls = 1; ls < mdl_ls_iterations && __any(!lsdone); ls++) {  // (ls counts evaluations of phi', the one at 0 included)
         float pg = 0.0f, ph = 0.0f, pa = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -1327,8 +1353,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
           floorg = 4.0f * 1.1920929e-7f * (gsum(pa) + fabsf(alpha * A) + fabsf(Bq));
         }
         if (!lsdone) {
-          if (ls == 0) { g0 = gg; if (g0 >= 0.0f) lsdone = true; }
-          if (!lsdone && fabsf(gg) <= fmaxf(1e-6f * fabsf(g0), floorg)) lsdone = true;
+          if (fabsf(gg) <= fmaxf(1e-6f * fabsf(g0), floorg)) lsdone = true;
           if (!lsdone) {
             if (gg < 0.0f) lo = alpha; else hi = alpha;
             float an = alpha - gg / hh;
@@ -1337,9 +1362,9 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
             if (!lsdone) alpha = an;
           }
         }
-        if (!__any(!lsdone)) break;
       }
       if (it == 0) STAMP(20);
+      ITSTAMP(it, 6);
       // ---- improvement from the 1-D model, then the update.  Row-cost differences are formed as
       // 1/2 D d (2 x0 + d) with d = alpha jv, never as a difference of squares: a step below the
       // resolution of jar must yield a (correctly) tiny improvement, not an absorbed one
@@ -1355,10 +1380,15 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
         pim -= (x0 < 0.0f && x1 < 0.0f) ? 0.5f * lD * d * (2.0f * x0 + d)
                : ((x1 < 0.0f ? 0.5f * lD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * lD * x0 * x0 : 0.0f));
       }
+      // (rows whose sign the step changes, from the same x0 / x1: the three reductions of this block are independent and overlap)
+      float crossed = ((ljar < 0.0f) != (ljar + alpha * ljv < 0.0f)) && lsg != 0.0f ? 1.0f : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) crossed += ((jar[r] < 0.0f) != (jar[r] + alpha * jv[r] < 0.0f)) ? 1.0f : 0.0f;
       const float improvement = gsum(pim) - (0.5f * alpha * alpha * A + alpha * Bq);
       // float32 resolution: if no dof's acceleration changes, or the gradient has stopped shrinking
       // within a few floors of its rounding level, further iterations are noise
       const float moved = gsum((isdof && qacc + alpha * sv != qacc) ? 1.0f : 0.0f);
+      const float ncross = gsum(crossed);
       const bool stagnant = it > 0 && gn > 0.5f * gprev && gn < 4.0f * gfloor;
       gprev = gn;
       if (!done && (moved == 0.0f || stagnant)) { done = true; niter = it + 1; }
@@ -1374,15 +1404,12 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       {
         // if the step crossed no row boundary, phi is one quadratic along it and the new gradient is
         // exactly (1 - alpha) g: decide convergence now instead of paying another gradient pass
-        float crossed = (ljar - alpha * ljv < 0.0f) != (ljar < 0.0f) && lsg != 0.0f ? 1.0f : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; r++) crossed += ((jar[r] - alpha * jv[r] < 0.0f) != (jar[r] < 0.0f)) ? 1.0f : 0.0f;
-        const float ncross = gsum(done ? 0.0f : crossed);
         const float gnew = fabsf(1.0f - alpha) * gn;
         if (!done && ncross == 0.0f && (scale * gnew < tol || gnew < gfloor)) done = true;
       }
       WSYNC();
       if (it == 0) STAMP(21);
+      ITSTAMP(it, 7);
     }
     if (DUAL && !met4) __syncthreads();  // (4) (no Hessian was needed: the collision wave is let go)
     if (a.out_qacc && valid && isdof && step == 0) a.out_qacc[(size_t)env * nv + lane] = qacc;
@@ -1523,8 +1550,8 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   STAMP(25);
   if (a.prof && threadIdx.x == 0) {  // debug: wall-clock (100 MHz) exit time of block 0 and of the last block
     const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
-    if (blockIdx.x == 0) a.prof[27] = tnow;
-    if ((blockIdx.x & 7) == 0) {  // same XCD as block 0: the realtime counters of different XCDs are not aligned
+    if ((int)blockIdx.x == prof_blk) a.prof[27] = tnow;
+    if ((blockIdx.x & 7) == (unsigned)(prof_blk & 7)) {  // same XCD as block 0: the realtime counters of different XCDs are not aligned
       atomicMax(&a.prof[28], tnow);
       atomicMin(&a.prof[29], tnow);
     }

@@ -1097,10 +1097,13 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
     /* exact line search on the piecewise-quadratic phi(alpha): safeguarded Newton on phi' */
     real A = 0, Bq = 0;
     for (int i = 0; i < nv; i++) { A += s[i] * Mv[i]; Bq += s[i] * (Ma[i] - d->qfrc_smooth[i]); }
-    real alpha = 0, lo = 0, hi = -1;
+    /* phi'(0) = grad . s, and with the exact Hessian the first Newton iterate on phi' is alpha = 1: the search starts there,
+     * bracket [0, ?), with phi'(0) as the scale of its stopping rule (ls counts evaluations of phi', the one at 0 included) */
     real g0 = 0;
-    int nls = 0;
-    for (int ls = 0; ls < m->opt.ls_iterations; ls++) {
+    for (int i = 0; i < nv; i++) g0 += s[i] * grad[i];
+    real alpha = g0 >= 0 ? 0 : 1, lo = 0, hi = -1;
+    int nls = 1;
+    for (int ls = 1; ls < m->opt.ls_iterations && g0 < 0; ls++) {
       nls = ls + 1;
       /* phi'(alpha), phi''(alpha), and the magnitude of the terms phi' is summed from: at the root they cancel, and
        * what is left is rounding noise of about an epsilon of that magnitude -- no evaluation can resolve phi' below it */
@@ -1112,7 +1115,6 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
           gabs += d->efcD[r] * (real)fabs((double)jv[r]) * ((real)fabs((double)jar[r]) + (real)fabs((double)(alpha * jv[r])));
         }
       }
-      if (ls == 0) { g0 = g; if (g0 >= 0) break; }
       {
         real tolg = (real)m->opt.ls_tolerance * (real)fabs((double)g0) * LS_RELTOL, floorg = ls >= 4 ? 4 * REAL_EPS * gabs : 0; /* (from the fifth evaluation on, as the kernels) */
         if ((real)fabs((double)g) <= (tolg > floorg ? tolg : floorg) + MINVAL) break;
