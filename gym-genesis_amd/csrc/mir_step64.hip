@@ -1031,6 +1031,7 @@ void mir_step64_kernel(StepArgs64 a) {
       if (done) break;  // wave-uniform: one env per wave
       float lact = (lsg != 0.0f && ljar < 0.0f) ? lD : 0.0f;
       const float lf = -lact * ljar;
+      bool flip_d = false, flip_o = false;
       if (iscon) {
         float f[4];
         unsigned bits = 0;
@@ -1041,8 +1042,12 @@ void mir_step64_kernel(StepArgs64 a) {
           bits |= on ? (1u << r) : 0u;
         }
         stv(S.con.cfb[lane], f4{f[0] + f[1] + f[2] + f[3], cmu * (f[0] - f[1]), cmu * (f[2] - f[3]), (float)(bits | (prevbits << 4))});
+        flip_d = bits != (it == 0 ? 15u : prevbits);  // (the diagonal blocks start from all rows active,
+        flip_o = bits != prevbits;                    //  the off-diagonal ones from zero)
         prevbits = bits;
       }
+      // contacts whose active rows changed since the Hessian last saw them (bit = contact): the updates walk those only
+      const unsigned long long flipd = __ballot(flip_d), flipo = __ballot(flip_o);
       WSYNC();
       if (it == 0) STAMP(21);
       // ---- gradient first (cheap): convergence is decided before any Hessian work
@@ -1093,13 +1098,11 @@ void mir_step64_kernel(StepArgs64 a) {
         for (int j = 0; j < G; j++) hd[j] += hp[j];
       }
       // diagonal blocks: the four DPP rows walk their own contact lists side by side (first iteration: relative to all-active)
-      for (int kq = 0; kq < nmine; kq++) {
+      if (flipd) for (int kq = 0; kq < nmine; kq++) {
         const int eq = S.con.blist[blk][kq];
         const int c = eq >> 1, myseg = eq & 1;
+        if (!((flipd >> c) & 1ull)) continue;
         const f4 fb = ldv(S.con.cfb[c]);
-        const unsigned both = (unsigned)fb.w;
-        const unsigned bits = both & 15u, old = it == 0 ? 15u : both >> 4;
-        if (bits == old) continue;
         const float* seg = &S.Jb[c][myseg][0];
         const float jn = seg[l16], j1 = seg[16 + l16], j2 = seg[32 + l16];
         const f4 mt = ldv(S.con.cmeta[c]);
@@ -1107,6 +1110,8 @@ void mir_step64_kernel(StepArgs64 a) {
 #pragma unroll
         for (int q = 0; q < 4; q++) { xn[q] = ldv(seg + 4 * q); x1[q] = ldv(seg + 16 + 4 * q); x2[q] = ldv(seg + 32 + 4 * q); }
         __builtin_amdgcn_sched_barrier(0);  // (keep the whole batch of reads ahead of the arithmetic: one LDS round trip)
+        const unsigned both = (unsigned)fb.w;
+        const unsigned bits = both & 15u, old = it == 0 ? 15u : both >> 4;
         const float mu = mt.x, D = mt.y;
         const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
         const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
@@ -1123,7 +1128,7 @@ void mir_step64_kernel(StepArgs64 a) {
       // off-diagonal blocks: wave-uniform walk over the two-block contacts; the rows of either block take the other
       // block's segment as columns
       if constexpr (MODE != 0) if (cpl) {
-        for (unsigned long long tw = twoblk; tw; tw &= tw - 1ull) {
+        for (unsigned long long tw = twoblk & flipo; tw; tw &= tw - 1ull) {
           const int c = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tw));
           const f4 fb = ldv(S.con.cfb[c]);
           const unsigned both = (unsigned)fb.w;
@@ -1196,10 +1201,11 @@ void mir_step64_kernel(StepArgs64 a) {
         jv[0] = xn + cmu * x1; jv[1] = xn - cmu * x1; jv[2] = xn + cmu * x2; jv[3] = xn - cmu * x2;
       }
       // ---- exact line search on the piecewise-quadratic phi(alpha): safeguarded Newton on phi'
-      const float A = wsum(sv * mv), Bq = wsum(sv * (Ma - qfs));
-      float alpha = 0.0f, lo = 0.0f, hi = -1.0f, g0 = 0.0f;
-      bool lsdone = false;
-      for (int ls = 0; ls < m->ls_iterations; ls++) {
+      // (the search starts at alpha = 1 with phi'(0) = g . s, see the 16-lane kernel; ls counts evaluations, the one at 0 included)
+      const float A = wsum(sv * mv), Bq = wsum(sv * (Ma - qfs)), g0 = wsum(sv * g);
+      bool lsdone = g0 >= 0.0f;
+      float alpha = lsdone ? 0.0f : 1.0f, lo = 0.0f, hi = -1.0f;
+      for (int ls = 1; ls < m->ls_iterations && !lsdone; ls++) {
         float pg = 0.0f, ph = 0.0f, pa = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -1220,8 +1226,7 @@ void mir_step64_kernel(StepArgs64 a) {
           if (ljar + alpha * ljv < 0.0f) pa += lD * fabsf(ljv) * (fabsf(ljar) + fabsf(alpha * ljv));
           floorg = 4.0f * 1.1920929e-7f * (wsum(pa) + fabsf(alpha * A) + fabsf(Bq));
         }
-        if (ls == 0) { g0 = gg; if (g0 >= 0.0f) lsdone = true; }
-        if (!lsdone && fabsf(gg) <= fmaxf(1e-6f * fabsf(g0), floorg)) lsdone = true;
+        if (fabsf(gg) <= fmaxf(1e-6f * fabsf(g0), floorg)) lsdone = true;
         if (!lsdone) {
           if (gg < 0.0f) lo = alpha; else hi = alpha;
           float an = alpha - gg / hh;
@@ -1229,7 +1234,6 @@ void mir_step64_kernel(StepArgs64 a) {
           if (an == alpha) lsdone = true;
           if (!lsdone) alpha = an;
         }
-        if (lsdone) break;  // wave-uniform
       }
       if (it == 0) STAMP(15);
       // ---- improvement from the 1-D model, then the update (row-cost differences as 1/2 D d (2 x0 + d))
@@ -1245,8 +1249,13 @@ void mir_step64_kernel(StepArgs64 a) {
         pim -= (x0 < 0.0f && x1 < 0.0f) ? 0.5f * lD * d * (2.0f * x0 + d)
                : ((x1 < 0.0f ? 0.5f * lD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * lD * x0 * x0 : 0.0f));
       }
+      // (rows whose sign the step changes, from the same x0 / x1: the three reductions of this block are independent and overlap)
+      float crossed = ((ljar < 0.0f) != (ljar + alpha * ljv < 0.0f)) && lsg != 0.0f ? 1.0f : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) crossed += ((jar[r] < 0.0f) != (jar[r] + alpha * jv[r] < 0.0f)) ? 1.0f : 0.0f;
       const float improvement = wsum(pim) - (0.5f * alpha * alpha * A + alpha * Bq);
       const float moved = wsum((isdof && qacc + alpha * sv != qacc) ? 1.0f : 0.0f);
+      const float ncross = wsum(crossed);
       const bool stagnant = it > 0 && gn > 0.5f * gprev && gn < 4.0f * gfloor;
       gprev = gn;
       niter = it + 1;
@@ -1261,10 +1270,6 @@ void mir_step64_kernel(StepArgs64 a) {
       }
       if (!done) {
         // if the step crossed no row boundary the new gradient is exactly (1 - alpha) g
-        float crossed = (ljar - alpha * ljv < 0.0f) != (ljar < 0.0f) && lsg != 0.0f ? 1.0f : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; r++) crossed += ((jar[r] - alpha * jv[r] < 0.0f) != (jar[r] < 0.0f)) ? 1.0f : 0.0f;
-        const float ncross = wsum(crossed);
         const float gnew = fabsf(1.0f - alpha) * gn;
         if (ncross == 0.0f && (scale * gnew < tol || gnew < gfloor)) done = true;
       }
