@@ -1370,15 +1370,17 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       // resolution of jar must yield a (correctly) tiny improvement, not an absorbed one
       float pim = 0.0f;
 #pragma unroll
+      // (with a = min(x, 0) the cost of a row is 1/2 D a^2, and its change 1/2 D (a1 - a0)(a1 + a0); a1 - a0 is the step d
+      //  itself while the row stays active)
       for (int r = 0; r < 4; r++) {
         const float x0 = jar[r], d = alpha * jv[r], x1 = x0 + d;
-        pim -= (x0 < 0.0f && x1 < 0.0f) ? 0.5f * cD * d * (2.0f * x0 + d)
-               : ((x1 < 0.0f ? 0.5f * cD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * cD * x0 * x0 : 0.0f));
+        const float a0 = fminf(x0, 0.0f), a1 = fminf(x1, 0.0f);
+        pim -= 0.5f * cD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0);
       }
       {
         const float x0 = ljar, d = alpha * ljv, x1 = x0 + d;
-        pim -= (x0 < 0.0f && x1 < 0.0f) ? 0.5f * lD * d * (2.0f * x0 + d)
-               : ((x1 < 0.0f ? 0.5f * lD * x1 * x1 : 0.0f) - (x0 < 0.0f ? 0.5f * lD * x0 * x0 : 0.0f));
+        const float a0 = fminf(x0, 0.0f), a1 = fminf(x1, 0.0f);
+        pim -= 0.5f * lD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0);
       }
       // (rows whose sign the step changes, from the same x0 / x1: the three reductions of this block are independent and overlap)
       float crossed = ((ljar < 0.0f) != (ljar + alpha * ljv < 0.0f)) && lsg != 0.0f ? 1.0f : 0.0f;

@@ -1129,9 +1129,10 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
      * difference of squares (a step below the resolution of jar must give a tiny improvement) */
     real imp = -((real)0.5 * alpha * alpha * A + alpha * Bq);
     for (int r = 0; r < n; r++) {
+      /* with a = min(x, 0) the cost of a row is 1/2 D a^2 and its change 1/2 D (a1 - a0)(a1 + a0); a1 - a0 = dx while it stays active */
       real x0 = jar[r], dx = alpha * jv[r], x1 = x0 + dx;
-      if (x0 < 0 && x1 < 0) imp -= (real)0.5 * d->efcD[r] * dx * (2 * x0 + dx);
-      else imp -= (x1 < 0 ? (real)0.5 * d->efcD[r] * x1 * x1 : 0) - (x0 < 0 ? (real)0.5 * d->efcD[r] * x0 * x0 : 0);
+      real a0 = x0 < 0 ? x0 : 0, a1 = x1 < 0 ? x1 : 0;
+      imp -= (real)0.5 * d->efcD[r] * ((x0 < 0 && x1 < 0) ? dx : a1 - a0) * (a1 + a0);
     }
     /* resolution of this precision: no dof moves, or the gradient stopped shrinking near its floor */
     {
