@@ -175,9 +175,42 @@ template <int S>
 struct GJ2<S, G - 1> {
   static __device__ __forceinline__ void run(float (&)[G], float&, int) {}
 };
-// dispatch on the model's block split (0 = dense); `split` must be wave-uniform
-__device__ __forceinline__ void gj_solve(float (&a)[G], float& b, int lane, int split) {
-  if (split == 9) GJ2<9, 0>::run(a, b, lane);
+// The same two blocks eliminated SIDE BY SIDE: step K pivots on row K of the first block (columns < S) and on row S + K of the
+// second (columns S .. E-1) at once.  A row of one block holds zeros in the other block's columns, so its factor for the other
+// block's pivot is zero and every entry sees exactly the operations GJ2 applies to it, in the same order: bit-identical to
+// GJ2<S> (and to GJ<0>) on such a matrix, in max(S, E - S) dependent steps instead of E.  Rows >= E are identity rows.
+template <int S, int E, int K>
+struct GJP {
+  static __device__ __forceinline__ void run(float (&a)[G], float& b, int lane) {
+    constexpr bool HA = K < S, HB = S + K < E;
+    constexpr int KA = HA ? K : 0, KB = HB ? S + K : 0;
+    float fA = 0.0f, fB = 0.0f;
+    if (HA) {
+      const float inv = __builtin_amdgcn_rcpf(row_bcast<KA>(a[KA]));
+      fA = lane == KA ? 1.0f - inv : a[KA] * inv;
+    }
+    if (HB) {
+      const float inv = __builtin_amdgcn_rcpf(row_bcast<KB>(a[KB]));
+      fB = lane == KB ? 1.0f - inv : a[KB] * inv;
+    }
+    if (HA) {
+#pragma unroll
+      for (int j = KA + 1; j < S; j++) a[j] = fmaf(-fA, row_bcast<KA>(a[j]), a[j]);
+    }
+    if (HB) {
+#pragma unroll
+      for (int j = KB + 1; j < E; j++) a[j] = fmaf(-fB, row_bcast<KB>(a[j]), a[j]);
+    }
+    if (HA) b = fmaf(-fA, row_bcast<KA>(b), b);
+    if (HB) b = fmaf(-fB, row_bcast<KB>(b), b);
+    if constexpr (K + 1 < (S > E - S ? S : E - S)) GJP<S, E, K + 1>::run(a, b, lane);
+  }
+};
+// dispatch on the model's block split (0 = dense) and dof count; both must be wave-uniform
+__device__ __forceinline__ void gj_solve(float (&a)[G], float& b, int lane, int split, int nv) {
+  if (split == 9 && nv == 15) GJP<9, 15, 0>::run(a, b, lane);
+  else if (split == 6 && nv == 12) GJP<6, 12, 0>::run(a, b, lane);
+  else if (split == 9) GJ2<9, 0>::run(a, b, lane);
   else if (split == 6) GJ2<6, 0>::run(a, b, lane);
   else GJ<0>::run(a, b, lane);
 }

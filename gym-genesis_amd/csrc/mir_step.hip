@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
 #pragma unroll
       for (int j = 0; j < G; j++) arow[j] = isdof ? mrow[j] : (j == lane ? 1.0f : 0.0f);
       qas = isdof ? qfs : 0.0f;
-      gj_solve(arow, qas, lane, mdl_split);  // (the mass matrix is block diagonal by tree)
+      gj_solve(arow, qas, lane, mdl_split, nv);  // (the mass matrix is block diagonal by tree)
     }
     if (a.out_qas && valid && isdof && step == 0) a.out_qas[(size_t)env * nv + lane] = qas;
     WSYNC();  // dyn scratch is dead from here on
@@ -1270,8 +1270,10 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       // ---- Hessian row (lane = dof): incremental update of H = Mt + J^T D_active J; per contact the
       // change enters through the 3x3 weight of its pyramid in (n, t1, t2) coordinates, which is
       // linear in the per-row activity, so flipped rows contribute +-D and unchanged contacts nothing
+      if (__any(lact != oldlact)) {  // (a joint-limit row switched somewhere in the wave: rare)
 #pragma unroll
-      for (int j = 0; j < G; j++) hkeep[j] += j == lane ? lact - oldlact : 0.0f;
+        for (int j = 0; j < G; j++) hkeep[j] += j == lane ? lact - oldlact : 0.0f;
+      }
       oldlact = lact;
       for (unsigned fm = flipmask; fm; fm &= fm - 1u) {  // (group-uniform trip count)
         const int c = __ffs(fm) - 1;
@@ -1306,7 +1308,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       ITSTAMP(it, 3);
       // ---- Newton direction: H s = -g
       float sv = -g;
-      gj_solve(hrow, sv, lane, hsplit);
+      gj_solve(hrow, sv, lane, hsplit, nv);
       if (!isdof) sv = 0.0f;
       if (it == 0) STAMP(15);
       ITSTAMP(it, 4);
