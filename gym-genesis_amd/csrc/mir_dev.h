@@ -115,6 +115,12 @@ template <int N>
 __device__ __forceinline__ float row_shl(float v) {  // lane i reads lane i+N of its row, 0 shifted in
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
 }
+// lane gather through the LDS crossbar (ds_bpermute_b32: no LDS memory, no write-then-read fence): every lane names the wave
+// lane it reads from as a BYTE offset (4 x lane)
+__device__ __forceinline__ float lane_gather(int src4, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src4, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ int lane_gather(int src4, int v) { return __builtin_amdgcn_ds_bpermute(src4, v); }
 __device__ __forceinline__ float gsum(float v) {  // all-reduce sum over the row
   v += row_ror<1>(v);
   v += row_ror<2>(v);

@@ -137,8 +137,9 @@ struct BodyK {
 // round a body composes the (partially composed) transform of its current ancestor pointer and inherits that body's
 // pointer, so after r rounds it holds the product over 2^r ancestors: 4 rounds for any tree of up to 16 bodies instead of
 // a dependent walk as long as the chain (10 links for a Panda finger).  `parents` packs the 16 parent indices, 4 bits each;
-// the pointer travels in the w slot of the position.
-__device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t parents, const BodyK& k) {
+// the ancestor's transform and pointer are gathered lane to lane (ds_bpermute), so a round is one crossbar trip and no LDS fence.
+// `row4` = byte offset of the group's first lane in the wave (64 x group).
+__device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t parents, const BodyK& k, int row4) {
   V3 P = v3(0, 0, 0);
   Q4 Qx = Q4{1, 0, 0, 0};
   int anc = 0;
@@ -160,17 +161,15 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 #pragma unroll 1
   for (int round = 0; round < 4; round++) {
     if (!__any(anc > 0)) break;
-    stv(S.fk.lpos[lane], f4{P.x, P.y, P.z, __int_as_float(anc)});
-    st4v(S.fk.lquat[lane], Qx);
-    WSYNC();
+    const int src = row4 + ((anc > 0 ? anc : lane) << 2);
+    const V3 pa = v3(lane_gather(src, P.x), lane_gather(src, P.y), lane_gather(src, P.z));
+    const Q4 qa = Q4{lane_gather(src, Qx.w), lane_gather(src, Qx.x), lane_gather(src, Qx.y), lane_gather(src, Qx.z)};
+    const int nxt = lane_gather(src, anc);
     if (anc > 0) {
-      const f4 pa = ldv(S.fk.lpos[anc]);
-      const Q4 qa = ld4v(S.fk.lquat[anc]);
-      P = v3(pa.x, pa.y, pa.z) + qrot(qa, P);
+      P = pa + qrot(qa, P);
       Qx = qmul(qa, Qx);
-      anc = __float_as_int(pa.w);
+      anc = nxt;
     }
-    WSYNC();
   }
   if (lane < nb) {
     st3v(S.xpos[lane], P);
@@ -225,6 +224,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     for (int k = 0; k < TAB_NPASS; k++) tabtmp[k] = src[min(tid + 64 * k, TAB_NQ - 1)];
   }
   const int lane = tid & (G - 1);
+  const int row4 = (tid & ~(G - 1)) << 2;  // byte offset of this env's first lane in the wave (lane_gather)
   const int grp = tid >> 4;
   const int env_raw = blockIdx.x * EPB + grp;
   const bool valid = env_raw < a.B;
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   // instead of 16 x 32 B per env written by one launch and read back by the next (round 1 cached them in HBM: 2.8x the
   // algorithmic traffic).
   STAMP(0);
-  group_fk(S, lane, nb, parents, bk);
+  group_fk(S, lane, nb, parents, bk, row4);
   STAMP(1);
   if (DUAL) __syncthreads();  // (1) link poses ready for the collision wave, model table ready for this one
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
 #if MIR_TREE_SCAN
     // ======================= velocities, composite inertias, body forces: tree SCANS =============
     // Sums over the ancestors of a dof are inclusive prefix sums along its dof chain: POINTER JUMPING over the chain's parent
-    // links (<= 4 rounds of one LDS exchange each, as in the FK) instead of a masked gather per lane and per quantity.  Sums over
+    // links (<= 4 rounds of one lane gather each, as in the FK) instead of a masked gather per lane and per quantity.  Sums over
     // the subtree of a body are suffix sums over the body lanes -- bodies are numbered in depth-first preorder, so a subtree is
     // the lane range [b, b_next) -- formed by four DPP row shifts per component and one subtraction (distal bodies sit at the
     // end of the row, so the subtraction never takes a small subtree out of a large total).
@@ -812,16 +812,15 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
 #pragma unroll 1
         for (int round = 0; round < 4; round++) {
           if (!__any(p >= 0)) break;
-          stv(tab + 8 * lane, f4{A.x, A.y, A.z, __int_as_float(p)});
-          st3v(tab + 8 * lane + 4, Bv);
-          WSYNC();
+          const int src = row4 + ((p >= 0 ? p : lane) << 2);
+          const V3 xa = v3(lane_gather(src, A.x), lane_gather(src, A.y), lane_gather(src, A.z));
+          const V3 xb = v3(lane_gather(src, Bv.x), lane_gather(src, Bv.y), lane_gather(src, Bv.z));
+          const int nxt = lane_gather(src, p);
           if (p >= 0) {
-            const f4 xa = ldv(tab + 8 * p), xb = ldv(tab + 8 * p + 4);
-            A = A + v3(xa.x, xa.y, xa.z);
-            Bv = Bv + v3(xb.x, xb.y, xb.z);
-            p = __float_as_int(xa.w);
+            A = A + xa;
+            Bv = Bv + xb;
+            p = nxt;
           }
-          WSYNC();
         }
         st3v(tab + 8 * lane, A);
         st3v(tab + 8 * lane + 4, Bv);
@@ -855,15 +854,18 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
           comp[k] = t;
         }
         float* cs = S.dyn.crb[lane];
-        stv(cs, f4{comp[0], comp[1], comp[2], comp[3]}); stv(cs + 4, f4{comp[4], comp[5], comp[6], comp[7]}); stv(cs + 8, f4{comp[8], comp[9], 0.0f, 0.0f});
-        WSYNC();
-        f4 e0 = {0, 0, 0, 0}, e1 = e0, e2 = e0;
-        if (b_next < G) { const float* ce = S.dyn.crb[b_next]; e0 = ldv(ce); e1 = ldv(ce + 4); e2 = ldv(ce + 8); }
-        WSYNC();
+        // (the suffix behind the subtree is the suffix sum of lane b_next: a lane gather, no LDS round trip)
+        const int src = row4 + ((b_next < G ? b_next : lane) << 2);
+        float e[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+          const float gk = lane_gather(src, comp[k]);
+          e[k] = b_next < G ? gk : 0.0f;
+        }
         const bool own = isbody;
-        stv(cs, own ? f4{comp[0] - e0.x, comp[1] - e0.y, comp[2] - e0.z, comp[3] - e0.w} : f4{0, 0, 0, 0});
-        stv(cs + 4, own ? f4{comp[4] - e1.x, comp[5] - e1.y, comp[6] - e1.z, comp[7] - e1.w} : f4{0, 0, 0, 0});
-        stv(cs + 8, own ? f4{comp[8] - e2.x, comp[9] - e2.y, 0.0f, 0.0f} : f4{0, 0, 0, 0});
+        stv(cs, own ? f4{comp[0] - e[0], comp[1] - e[1], comp[2] - e[2], comp[3] - e[3]} : f4{0, 0, 0, 0});
+        stv(cs + 4, own ? f4{comp[4] - e[4], comp[5] - e[5], comp[6] - e[6], comp[7] - e[7]} : f4{0, 0, 0, 0});
+        stv(cs + 8, own ? f4{comp[8] - e[8], comp[9] - e[9], 0.0f, 0.0f} : f4{0, 0, 0, 0});
       }
       STAMP(2);
       // (3) A_i = sum over the dof chain of cdof_dot_j qvel_j; body forces at zero acceleration (RNE)
@@ -893,13 +895,15 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
           comp[k] = u;
         }
         float* fs = S.dyn.cfrc[lane];
-        st3v(fs, v3(comp[0], comp[1], comp[2])); st3v(fs + 4, v3(comp[3], comp[4], comp[5]));
-        WSYNC();
-        V3 et = v3(0, 0, 0), ef = v3(0, 0, 0);
-        if (b_next < G) { et = ld3v(&S.dyn.cfrc[b_next][0]); ef = ld3v(&S.dyn.cfrc[b_next][4]); }
-        WSYNC();
-        st3v(fs, v3(comp[0], comp[1], comp[2]) - et);
-        st3v(fs + 4, v3(comp[3], comp[4], comp[5]) - ef);
+        const int src = row4 + ((b_next < G ? b_next : lane) << 2);
+        float e[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const float gk = lane_gather(src, comp[k]);
+          e[k] = b_next < G ? gk : 0.0f;
+        }
+        st3v(fs, v3(comp[0], comp[1], comp[2]) - v3(e[0], e[1], e[2]));
+        st3v(fs + 4, v3(comp[3], comp[4], comp[5]) - v3(e[3], e[4], e[5]));
       }
       WSYNC();
       STAMP(35);
@@ -1454,7 +1458,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     WSYNC();
     STAMP(9);
     // kinematics of the new state: observations of this step, and the next step's starting poses
-    group_fk(S, lane, nb, parents, bk);
+    group_fk(S, lane, nb, parents, bk, row4);
     if (a.rows && a.rows_step && (step + 1 < nsteps || a.ar.episode_len) && valid) {  // rollout mode: one packed row per env per step
       float* row = a.rows + (size_t)step * a.rows_step + (size_t)env * a.row_stride;
       for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
@@ -1489,7 +1493,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
         epcur += 1;
       }
       WSYNC();
-      if (__any(done)) group_fk(S, lane, nb, parents, bk);
+      if (__any(done)) group_fk(S, lane, nb, parents, bk, row4);
     }
   }  // steps
   STAMP(10);
