@@ -66,9 +66,6 @@ namespace {
 // per-env LDS working set (~8 KB).  Three phase-local scratch areas share storage:
 //   dyn  (FK .. smooth dynamics)   overlays   contact arrays + Jb
 //   col  (collision detection)     overlays   Jb
-struct FkScratch {
-  float lpos[G][4], lquat[G][4];  // pointer-jumping exchange of the forward kinematics (start and end of a step)
-};
 struct DynScratch {
   float cddq[G][8];               // cdof_dot * qvel: ang(3) pad lin(3) pad
   float cinert[G][12], crb[G][12];
@@ -112,7 +109,6 @@ struct EnvLds {
   // the contact arrays and the contact Jacobians take the place of both afterwards (con never overlaps col: the contact
   // finishing reads the staging area while it writes con; Jb does, and is written after col is dead).
   union {
-    FkScratch fk;
     struct {
       DynScratch dyn;
       ColScratch col;
@@ -665,18 +661,19 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   bk.jtype = __float_as_int(lk[0].x); bk.qadr = __float_as_int(lk[0].y);
   const int b_root = __float_as_int(lk[0].z), d_body = __float_as_int(lk[0].w);
   bk.pos = v3(lk[1].x, lk[1].y, lk[1].z);
-  const uint32_t b_dofmask = __float_as_uint(lk[1].w);
+  [[maybe_unused]] const uint32_t b_dofmask = __float_as_uint(lk[1].w);  // (masks: the gather formulation, MIR_TREE_SCAN 0)
   bk.quat = Q4{lk[2].x, lk[2].y, lk[2].z, lk[2].w};
   bk.axis = v3(lk[3].x, lk[3].y, lk[3].z);
-  const uint32_t b_submask = __float_as_uint(lk[3].w);
+  [[maybe_unused]] const uint32_t b_submask = __float_as_uint(lk[3].w);
   const V3 b_ipos = v3(lk[4].x, lk[4].y, lk[4].z);
   const float b_mass = lk[4].w;
   const float ib[6] = {lk[5].x, lk[5].y, lk[5].z, lk[5].w, lk[6].x, lk[6].y};
   const int d_kind = __float_as_int(lk[6].z), d_qadr = __float_as_int(lk[6].w);
   const int d_axis_k = __float_as_int(lk[7].x), d_root = __float_as_int(lk[7].y), d_ctrl = __float_as_int(lk[7].z), d_uadr = __float_as_int(lk[7].w);
   const V3 d_axis = v3(lk[8].x, lk[8].y, lk[8].z);
-  const uint32_t d_submask = __float_as_uint(lk[8].w);
-  const uint32_t d_premask = __float_as_uint(lk[9].x), d_ancmask = __float_as_uint(lk[9].y);
+  [[maybe_unused]] const uint32_t d_submask = __float_as_uint(lk[8].w);
+  [[maybe_unused]] const uint32_t d_premask = __float_as_uint(lk[9].x);
+  const uint32_t d_ancmask = __float_as_uint(lk[9].y);
   const bool d_limited = __float_as_int(lk[9].z) != 0;
   const float d_damping = lk[9].w, d_kp = lk[10].x, d_kv = lk[10].y, d_frclo = lk[10].z, d_frchi = lk[10].w, d_mdiag = lk[11].x;
   const int obs_qadr = __float_as_int(lk[11].y);

@@ -79,3 +79,44 @@ def test_env_step_returns_fresh_host_masks_every_call():
     for arr, snap, ten, tsnap in kept:  # earlier results are not overwritten by later steps
         assert np.array_equal(arr, snap) and torch.equal(ten, tsnap)
     assert len({id(k[0]) for k in kept}) == 5
+
+
+@pytest.mark.parametrize("which", ["pick", "stack"])
+@pytest.mark.parametrize("iterations", [0, 1])
+def test_two_wave_kernels_with_a_solver_that_never_or_once_iterates(which, iterations):
+    """The single-step instantiations run two waves per workgroup that meet at four barriers; the last one sits inside the first
+    Newton iteration, or behind the loop when no iteration needs the Hessian.  A solver capped at 0 or 1 iterations (and envs
+    without any constraint) must take the second route without hanging, and the K-step rollout (one wave, no barriers) must
+    still agree bit for bit."""
+    from gym_genesis.backend.lib import MirScene
+
+    sb = models.franka_cube_pick_scene() if which == "pick" else models.franka_cube_stack_scene()
+    sb.opt["iterations"] = iterations
+    spec = sb.build()
+    B = 64
+    sc, sr = MirScene(spec, B), MirScene(spec, B)
+    nfree = 1 if which == "pick" else 5
+    rng = np.random.RandomState(3)
+    pos = np.zeros((B, nfree, 3), np.float32)
+    pos[..., 0] = rng.uniform(0.45, 0.8, (B, nfree)) if which == "pick" else rng.uniform(-0.3, 0.3, (B, nfree))
+    pos[..., 1] = rng.uniform(-0.25, 0.25, (B, nfree))
+    pos[..., 2] = 0.5 if which == "pick" else 1.5  # in the air: the first steps have no contact at all
+    quat = np.tile(np.array([1, 0, 0, 0], np.float32), (B, nfree, 1))
+    home = np.tile(np.array(models.FRANKA_HOME, np.float32), (B, 1))
+    for s in (sc, sr):
+        s.reset(pos.reshape(B, -1) if nfree == 1 else pos, quat.reshape(B, -1) if nfree == 1 else quat, home)
+    K = 12
+    g = torch.Generator(device=sc.device).manual_seed(0)
+    acts = torch.from_numpy(home).to(sc.device) + torch.empty((K, B, 9), device=sc.device).uniform_(-0.5, 0.5, generator=g)
+    stride = sc.agent_dim + sc.env_dim + 2
+    rows1 = torch.zeros((K, B, stride), device=sc.device)
+    for k in range(K):
+        sc.step_packed(acts[k], rows1[k])
+    rowsK = torch.zeros((K, B, stride), device=sc.device)
+    sr.rollout(acts, rowsK)
+    torch.cuda.synchronize()
+    assert torch.isfinite(rows1).all()
+    if which == "pick":  # (the wave kernel's plain rollout IS K single-step launches)
+        assert torch.equal(rows1, rowsK)
+    assert all(torch.equal(a, b) for a, b in zip(sc.get_state(), sr.get_state()))
+    assert int(sc.get_diag()[2].max()) <= iterations
