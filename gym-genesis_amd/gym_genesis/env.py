@@ -64,7 +64,7 @@ class GenesisEnv(Env):
         self._begin = self._env.step_begin if fast else None
         self._end = self._env.step_end if fast else None
         if fast and hasattr(self._env, "make_fast_step"):
-            # the state-only Franka pick task supplies the whole of step() as one flat function; bound on the instance, so
+            # the state-only batched tasks supply the whole of step() as one flat function; bound on the instance, so
             # `env.step(a)` calls it without passing through this class's method
             self.step = self._env.make_fast_step()
 

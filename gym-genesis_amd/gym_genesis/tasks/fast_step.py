@@ -1,0 +1,47 @@
+"""GenesisEnv.step as ONE flat function for the state-only batched tasks (gym_genesis/env.py:61-69 of the reference).
+
+Every Python frame and attribute lookup between two launches is time the GPU idles, so the whole step is a closure over
+pre-bound callables.  Order: validate the action, launch (mir_step_go: the outputs were registered while the previous kernel
+ran), then -- while this kernel runs -- make everything the API returns besides `terminated` and prepare the next call, then
+wait for the launch's terminated bytes (mir_step_end) and return.
+"""
+import numpy as np
+import torch
+
+
+def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coerce=None):
+    """-> step(action) returning (observation, reward, terminated, truncated, info) like GenesisEnv.step.
+
+    `task` keeps `_agent / _envst / _reward / _term` pointing at the tensors of the latest step (get_obs(), views);
+    `coerce(action)` (optional) is the task's own pre-processing of an action that is not already a (B, action_dim) float32
+    device tensor (e.g. the SO-101 tasks' reshape)."""
+    go, prepare, alloc, end, as_action = mir.step_go_ptr, mir.step_prepare_ptrs, mir._alloc_outputs, mir.step_end_ptr, mir.as_action
+    B, dev, tensor, f32, tbool = task.num_envs, task.device, torch.Tensor, torch.float32, torch.bool
+    np_empty, np_zeros, np_bool = np.empty, np.zeros, np.bool_
+    nxt = [None]
+
+    def fast_step(action):
+        if not (type(action) is tensor and action.dtype is f32 and action.device == dev and action.is_contiguous()
+                and action.dim() == 2 and action.shape[0] == B and action.shape[1] == action_dim):
+            if coerce is not None:
+                action = coerce(action)
+            action = as_action(action, action_dim)
+        slot = nxt[0]
+        if slot is None:
+            slot = alloc(agent_obs, env_obs)
+            prepare(slot[1])
+        go(action.data_ptr())
+        # ---- the kernel is running: nothing below is on the critical path until end()
+        outs = slot[0]
+        host = np_empty(B, np_bool)
+        n = alloc(agent_obs, env_obs)
+        prepare(n[1])
+        nxt[0] = n
+        task._agent, task._envst, task._reward, task._term = outs
+        observation = {"agent_pos": outs[0], "environment_state": outs[1]}
+        info = {"is_success": outs[3].view(tbool)}
+        truncated = np_zeros(B, np_bool)
+        end(host.ctypes.data)
+        return observation, outs[2], host, truncated, info
+
+    return fast_step

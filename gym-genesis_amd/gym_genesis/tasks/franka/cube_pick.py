@@ -185,40 +185,9 @@ class FrankaCubePickBatch:
         return self._mir.step_end()
 
     def make_fast_step(self):
-        """GenesisEnv.step as ONE flat function for the state-only case (gym_genesis/env.py:61-69 of the reference): every
-        Python frame and attribute lookup between two launches is time the GPU idles, so the whole step is a closure over
-        pre-bound callables.  Order: validate the action, launch (mir_step_go: the outputs were registered while the previous
-        kernel ran), then -- while this kernel runs -- make everything the API returns besides `terminated` and prepare the
-        next call, then wait for the launch's terminated bytes (mir_step_end) and return."""
-        mir, task = self._mir, self
-        go, prepare, alloc, end, as_action = mir.step_go_ptr, mir.step_prepare_ptrs, mir._alloc_outputs, mir.step_end_ptr, mir.as_action
-        B, dev, tensor, f32, tbool = self.num_envs, self.device, torch.Tensor, torch.float32, torch.bool
-        np_empty, np_zeros, np_bool = np.empty, np.zeros, np.bool_
-        nxt = [None]
-
-        def fast_step(action):
-            if not (type(action) is tensor and action.dtype is f32 and action.device == dev and action.is_contiguous()
-                    and action.dim() == 2 and action.shape[0] == B and action.shape[1] == AGENT_DIM):
-                action = as_action(action, AGENT_DIM)
-            slot = nxt[0]
-            if slot is None:
-                slot = alloc(AGENT_DIM, ENV_DIM)
-                prepare(slot[1])
-            go(action.data_ptr())
-            # ---- the kernel is running: nothing below is on the critical path until end()
-            outs = slot[0]
-            host = np_empty(B, np_bool)
-            n = alloc(AGENT_DIM, ENV_DIM)
-            prepare(n[1])
-            nxt[0] = n
-            task._agent, task._envst, task._reward, task._term = outs
-            observation = {"agent_pos": outs[0], "environment_state": outs[1]}
-            info = {"is_success": outs[3].view(tbool)}
-            truncated = np_zeros(B, np_bool)
-            end(host.ctypes.data)
-            return observation, outs[2], host, truncated, info
-
-        return fast_step
+        """The whole of GenesisEnv.step as one flat closure (tasks/fast_step.py)."""
+        from ..fast_step import make_fast_step
+        return make_fast_step(self, self._mir, AGENT_DIM, AGENT_DIM, ENV_DIM)
 
     def step_raw(self, action_dev: torch.Tensor) -> None:
         """Hot path without any Python-side packing: `action_dev` is a contiguous float32 (B,9) device tensor."""

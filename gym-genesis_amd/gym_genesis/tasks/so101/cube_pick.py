@@ -123,6 +123,17 @@ class CubePick:
     def step_end(self) -> np.ndarray:
         return self._mir.step_end()
 
+    def make_fast_step(self):
+        """The whole of GenesisEnv.step as one flat closure (tasks/fast_step.py)."""
+        from ..fast_step import make_fast_step
+
+        def coerce(action):
+            if not isinstance(action, torch.Tensor):
+                action = torch.as_tensor(np.asarray(action))
+            return action.reshape(self.num_envs, AGENT_DIM)
+
+        return make_fast_step(self, self._mir, AGENT_DIM, AGENT_OBS, ENV_OBS, coerce)
+
     def step_raw(self, action_dev: torch.Tensor) -> None:
         self._mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)
 

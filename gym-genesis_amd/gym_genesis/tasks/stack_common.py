@@ -163,6 +163,11 @@ class StackTaskBase:
     def step_end(self):
         return self._mir.step_end()
 
+    def make_fast_step(self):
+        """The whole of GenesisEnv.step as one flat closure (tasks/fast_step.py)."""
+        from .fast_step import make_fast_step
+        return make_fast_step(self, self._mir, self.AGENT_DIM, self._mir.agent_dim, ENV_OBS)
+
     def step_raw(self, action_dev: torch.Tensor) -> None:
         self._mir.step_fused(action_dev, self._agent, self._envst, self._reward, self._term)
 
