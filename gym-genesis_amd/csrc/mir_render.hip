@@ -13,10 +13,11 @@
 //     product), FINAL packed RGB8 colours per face (albedo x shade) or, for a plane, the two checker colours
 //     and the affine numerators of the perspective-correct checker coordinate, and a conservative screen
 //     rectangle.  128 B per primitive.  Per-env cameras (mir_render_cams) are resolved here too.
-//   * mir_render_kernel: workgroup = 256 threads = 4 waves side by side on a 128-pixel-wide strip, walked as
+//   * mir_render_kernel: workgroup = 256 threads = 4 waves stacked on a 128-pixel-wide strip, walked as
 //     128 x 32 sub-tiles; the strip's primitives are culled once by rectangle (ordered ballot compaction, id list
 //     in LDS); records are fetched with wave-uniform SCALAR loads (constant address space); a lane owns 4
-//     consecutive pixels of a row in each of four 32 x 8 regions, culled per region by scalar branches;
+//     consecutive pixels of a row in each of four 128 x 2 regions of its wave's 8-row band, culled per band and
+//     region by scalar branches;
 //     arithmetic on packed fp32 pixel pairs; 4 pixels -> 3 dwords -> one global_store_dwordx3 per lane, not
 //     waited for (the next sub-tile's arithmetic runs under the stores).
 //   * ray/box in the box frame is a 3-slab test; depth order is resolved per pixel (strict <, list in
@@ -192,11 +193,12 @@ __global__ void k_render_setup(SetupArgs a) {
 }
 
 // ---- pixels --------------------------------------------------------------------------------------
-// 256 threads = 4 waves side by side; a workgroup walks a 128-pixel-wide strip of `th` rows in 128 x 32 sub-tiles.
+// 256 threads = 4 waves stacked; a workgroup walks a 128-pixel-wide strip of `th` rows in 128 x 32 sub-tiles.
 // Per sub-tile: the image's primitives are culled against it (ordered ballot compaction into an LDS id list), then
-// every listed primitive is tested on the wave's 32 x 32 column (4 regions of 32 x 8; lane = 4 consecutive pixels of
-// one row; wave-uniform region cull), then the 4 regions are stored as packed RGB8, one global_store_dwordx3 per
-// lane and region.  The wave does NOT wait for those stores: it goes on to the next sub-tile, so the write traffic
+// every listed primitive is tested on the wave's 128 x 8 band (4 regions of 128 x 2; lane = 4 consecutive pixels of
+// one row; wave-uniform band and region cull), then the 4 regions are stored as packed RGB8, one global_store_dwordx3 per
+// lane and region: a store instruction writes two whole rows of 384 B, i.e. six full 128-byte lines (round 1 gave each wave a
+// 32-pixel column, 96-byte pieces that straddle lines shared with the neighbouring wave: 348 -> 335 us per 1024 x 480 x 640).  The wave does NOT wait for those stores: it goes on to the next sub-tile, so the write traffic
 // of one sub-tile drains under the arithmetic of the next (a workgroup per sub-tile serialises the two: measured
 // 240 us of arithmetic + 150 us of stores = 390 us).  Primitive records are read with wave-uniform addresses
 // straight from global memory (scalar loads, amortised over 16 pixels per lane); LDS holds only the id list.
@@ -205,8 +207,11 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
   __shared__ int s_wcnt[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tx0 = blockIdx.x * TW, sy0 = blockIdx.y * a.th, img = blockIdx.z;
-  const int wx0 = tx0 + 32 * wv;              // this wave's column
-  const int px = wx0 + 4 * (lane & 7);
+  // lane -> pixels: a wave covers the full 128-pixel width of the strip, 2 rows per region (lane & 31 = 4 consecutive pixels,
+  // lane >> 5 = row), four regions = 8 rows; the four waves are stacked.  One store instruction of a wave thus writes whole
+  // rows of 384 B = three full 128-byte lines (32-pixel columns per wave wrote 96-byte pieces that straddle lines shared with
+  // the neighbouring wave).
+  const int px = tx0 + 4 * (lane & 31);
   const float* __restrict__ prims = a.prims + (size_t)img * a.nprim * PREC;
   const int txmax = min(tx0 + TW, a.W) - 1, symax = min(sy0 + a.th, a.H) - 1;
   const bool fast = (a.W & 3) == 0;
@@ -218,14 +223,15 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
 
   for (int ty0 = sy0; ty0 <= symax; ty0 += 32) {
     const int tymax = min(ty0 + 31, symax);
-    const int prow = ty0 + (lane >> 3);  // rows prow, prow + 8, prow + 16, prow + 24
+    const int wy0 = ty0 + 8 * wv;            // this wave's band of 8 rows
+    const int prow = wy0 + (lane >> 5);      // rows prow, prow + 2, prow + 4, prow + 6
     f2 best[4][2];
     unsigned col[4][4];
     float ysr[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       best[r][0] = best[r][1] = f2{3e38f, 3e38f};
-      ysr[r] = a.y0 + (float)(prow + 8 * r) * a.dy;
+      ysr[r] = a.y0 + (float)(prow + 2 * r) * a.dy;
 #pragma unroll
       for (int p = 0; p < 4; p++) col[r][p] = a.sky;
     }
@@ -264,13 +270,13 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
         const cf4* rec = (const cf4*)(uintptr_t)(prims + (size_t)id * PREC);
         const f4 ro = rec[0], rf = rec[1], rr = rec[2], ru = rec[3], rh = rec[4], q5 = rec[5], q6 = rec[6];
         const int xmin = __float_as_int(rf.w), xmax = __float_as_int(rr.w), ymin = __float_as_int(ru.w), ymax = __float_as_int(rh.w);
-        if (xmax < wx0 || xmin > wx0 + 31 || ymax < ty0 || ymin > tymax) continue;  // wave-uniform column / sub-tile cull
+        if (ymax < wy0 || ymin > wy0 + 7) continue;  // wave-uniform band cull (the strip cull covered x)
         if (__float_as_int(ro.w) == MIR_GEOM_BOX) {
           const float ax = -rh.x - ro.x, bx = rh.x - ro.x, ay = -rh.y - ro.y, by = rh.y - ro.y, az = -rh.z - ro.z, bz = rh.z - ro.z;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const int wy = ty0 + 8 * r;  // wave-uniform region cull: rows wy .. wy + 7
-            if (ymax < wy || ymin > wy + 7) continue;
+            const int wy = wy0 + 2 * r;  // wave-uniform region cull: rows wy, wy + 1
+            if (ymax < wy || ymin > wy + 1) continue;
             const float ex = fmaf(ysr[r], ru.x, rf.x), ey = fmaf(ysr[r], ru.y, rf.y), ez = fmaf(ysr[r], ru.z, rf.z);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -293,6 +299,10 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
           }
         } else {
           const unsigned ceven = __float_as_uint(q5.w), codd = __float_as_uint(q6.w);
+          // (the floor is the first primitive of every scene: nothing has been drawn into the sub-tile when it comes up first, so
+          //  its depth test is the validity test alone and the pixel is ASSIGNED: one select per pixel instead of a compare and
+          //  two selects.  Wave-uniform.)
+          const bool first = k == 0 && base == 0;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const float ez = fmaf(ysr[r], ru.z, rf.z), eu = fmaf(ysr[r], q5.z, q5.x), ev = fmaf(ysr[r], q6.z, q6.x);
@@ -303,6 +313,21 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
               const float iz1 = __builtin_amdgcn_rcpf(ez);
               const float t1 = iz1 * (-ro.z);
               const bool vld = t1 > 1e-6f;
+              if (first) {
+                const float tb = vld ? t1 : 3e38f;
+                const unsigned ca = vld ? ceven : a.sky, cb = vld ? codd : a.sky;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                  const f2 u = (xs[h] * q5.y + eu) * iz1, v = (xs[h] * q6.y + ev) * iz1;
+#pragma unroll
+                  for (int q = 0; q < 2; q++) {
+                    const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
+                    best[r][h][q] = tb;
+                    col[r][2 * h + q] = odd ? cb : ca;
+                  }
+                }
+                continue;
+              }
 #pragma unroll
               for (int h = 0; h < 2; h++) {
                 const f2 u = (xs[h] * q5.y + eu) * iz1, v = (xs[h] * q6.y + ev) * iz1;
@@ -338,8 +363,8 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
     uint8_t* __restrict__ ibase = a.pixels + (size_t)img * a.H * a.W * 3;
     unsigned boff = ((unsigned)prow * (unsigned)a.W + (unsigned)px) * 3u;
 #pragma unroll
-    for (int r = 0; r < 4; r++, boff += 24u * (unsigned)a.W) {
-      const int y = prow + 8 * r;
+    for (int r = 0; r < 4; r++, boff += 6u * (unsigned)a.W) {
+      const int y = prow + 2 * r;
       if (y > symax || px >= a.W) continue;
       uint8_t* dst = ibase + boff;
       const unsigned c0 = col[r][0], c1 = col[r][1], c2 = col[r][2], c3 = col[r][3];
