@@ -471,7 +471,7 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     m.parents |= (uint64_t)(par & 15) << (4 * b);
   }
   for (int l = 0; l < MIR_G; l++) {
-    LaneK16& k = m.lanek[l];
+    LaneK16 k;
     memset(&k, 0, sizeof k);
     k.b_jtype = m.b_jtype[l]; k.b_qadr = m.b_qadr[l]; k.b_root = m.b_root[l];
     k.b_dofmask = m.b_dofmask[l]; k.b_submask = m.b_submask[l]; k.b_mass = m.b_mass[l];
@@ -503,6 +503,7 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
       }
       k.scan = (d_par & 255) | ((d_bef & 255) << 8) | ((b_last & 255) << 16) | ((b_next & 255) << 24);
     }
+    for (int q = 0; q < 12; q++) memcpy(m.lanek_t[q][l], reinterpret_cast<const char*>(&k) + 16 * q, 16);
   }
   return MIR_OK;
 }

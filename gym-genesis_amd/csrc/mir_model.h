@@ -63,7 +63,9 @@ static_assert(sizeof(LaneK16) == 12 * 16, "LaneK16 is read as twelve 16-byte qua
 
 struct DevModel {
   ModelTab tab;  // first member: 16-byte aligned with the allocation
-  LaneK16 lanek[MIR_G];  // (16-byte aligned: sizeof(ModelTab) is a multiple of 16)
+  // the LaneK16 records TRANSPOSED, [quad][lane]: load k of the prologue then reads 16 lanes x 16 B = 256 contiguous bytes (the
+  // same for the four env groups of a wave) instead of 64 pieces at a stride of 192 B
+  float lanek_t[12][MIR_G][4];  // (16-byte aligned: sizeof(ModelTab) is a multiple of 16)
   uint64_t parents;      // the 16 parent indices, 4 bits each (pointer-jumping FK)
   uint64_t pad_parents;
   // sizes / options

@@ -653,9 +653,8 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   const uint64_t parents = m->parents;
   f4 lk[12];
   {
-    const f4* src = reinterpret_cast<const f4*>(&m->lanek[lane]);
 #pragma unroll
-    for (int k = 0; k < 12; k++) lk[k] = src[k];
+    for (int k = 0; k < 12; k++) lk[k] = *reinterpret_cast<const f4*>(m->lanek_t[k][lane]);
   }
   BodyK bk;
   bk.jtype = __float_as_int(lk[0].x); bk.qadr = __float_as_int(lk[0].y);
