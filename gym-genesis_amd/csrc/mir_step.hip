@@ -190,8 +190,11 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 // needs only the link poses, and so do the smooth dynamics (subspaces, CRB, RNE, mass matrix, smooth solve): wave 1 does the
 // former while wave 0 does the latter, in disjoint LDS areas, between two workgroup barriers.  At 4096 envs there is otherwise
 // ONE wave per SIMD that spends 60 % of its life waiting on LDS round trips; the second wave fills those slots and takes
-// ~5 k cycles out of the ~50 k of a step.  The step-loop instantiations keep one wave (they need the AGPRs a second wave
-// per SIMD would have to give up); both run the same detection code, so they agree bit for bit.
+// ~5 k cycles out of the ~50 k of a step.  Wave 1 also opens the launch with the forward kinematics of the stored state (its loads
+// -- one qpos row, four quads of lane constants -- are back before wave 0's, which brings in the model table and everything else),
+// and after the contacts it accumulates the all-rows-active Newton Hessian beside wave 0's warm start and first gradient: four
+// barriers in all.  The step-loop instantiations keep one wave (they need the AGPRs a second wave per SIMD would have to give up);
+// both run the same code in the same order of operations, so they agree bit for bit.
 template <int VARIANT, int FEAT>
 __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepArgs a) {
   constexpr bool SINGLE = VARIANT == 0;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   // stores of one group sat in front of the loads of the next).
   constexpr int TAB_NQ = (int)(sizeof(ModelTab) / 16), TAB_NPASS = (TAB_NQ + 63) / 64;
   f4 tabtmp[TAB_NPASS];
-  if (!DUAL || wave == 1) {  // (DUAL: the collision wave brings the model table in while the main wave fetches the state)
+  if (wave == 0) {  // (DUAL: the collision wave fetches the qpos row and runs the forward kinematics meanwhile)
     const f4* src = reinterpret_cast<const f4*>(&m->tab);
 #pragma unroll
     for (int k = 0; k < TAB_NPASS; k++) tabtmp[k] = src[min(tid + 64 * k, TAB_NQ - 1)];
@@ -628,12 +631,27 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   };
   if (DUAL && wave == 1) {
     {
-      f4* dst = reinterpret_cast<f4*>(&T);
+      // The collision wave opens the launch with the FORWARD KINEMATICS of the stored state: it needs one row of qpos and four of
+      // the twelve quads of lane constants, so its loads are back sooner than the main wave's (which also brings in the model
+      // table, the other rows and the action), and the main wave finds the link poses ready when it reaches the first barrier.
+      f4 hq[4];
 #pragma unroll
-      for (int k = 0; k < TAB_NPASS; k++)
-        if (tid + 64 * k < TAB_NQ) dst[tid + 64 * k] = tabtmp[k];
+      for (int k = 0; k < 4; k++) hq[k] = *reinterpret_cast<const f4*>(m->lanek_t[k][lane]);
+      const float hq_lo = lane < a.qst ? a.qpos[(size_t)env * a.qst + lane] : 0.0f;
+      const float hq_hi = lane + G < a.qst ? a.qpos[(size_t)env * a.qst + lane + G] : 0.0f;
+      const uint64_t hparents = m->parents;
+      __builtin_amdgcn_sched_barrier(0);
+      BodyK hk;
+      hk.jtype = __float_as_int(hq[0].x); hk.qadr = __float_as_int(hq[0].y);
+      hk.pos = v3(hq[1].x, hq[1].y, hq[1].z);
+      hk.quat = Q4{hq[2].x, hq[2].y, hq[2].z, hq[2].w};
+      hk.axis = v3(hq[3].x, hq[3].y, hq[3].z);
+      if (lane < a.qst) S.qpos[lane] = hq_lo;
+      if (lane + G < a.qst) S.qpos[lane + G] = hq_hi;
+      WSYNC();
+      group_fk(S, lane, nb, hparents, hk, row4);
     }
-    __syncthreads();  // (1) the model table is in LDS; the main wave has finished the FK of the launch's state
+    __syncthreads();  // (1) link poses (this wave) and model table, velocities, targets (main wave) are in LDS
     const int cnt = collide_detect();
     contacts_build(cnt);  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
     __syncthreads();  // (3) contact arrays and base Jacobians handed to the main wave
@@ -685,21 +703,24 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   // ---- load state -----------------------------------------------------------------------------
   // (addresses from the launch arguments only: these loads leave together with the model loads above)
   static_assert(sizeof(((EnvLds*)nullptr)->qpos) / sizeof(float) <= 2 * G, "qpos row: at most two entries per lane");
-  const float q_lo = lane < a.qst ? a.qpos[(size_t)env * a.qst + lane] : 0.0f;
-  const float q_hi = lane + G < a.qst ? a.qpos[(size_t)env * a.qst + lane + G] : 0.0f;
+  // (DUAL: the qpos row is fetched and stored by the collision wave, with the forward kinematics)
+  const float q_lo = (!DUAL && lane < a.qst) ? a.qpos[(size_t)env * a.qst + lane] : 0.0f;
+  const float q_hi = (!DUAL && lane + G < a.qst) ? a.qpos[(size_t)env * a.qst + lane + G] : 0.0f;
   const float qv_in = a.qvel[(size_t)env * G + lane], ws_in = a.qacc_ws[(size_t)env * G + lane];
   // (with an action every controlled dof takes its target from it and nothing else reads a target: the stored row is not fetched)
   float tg = a.action ? 0.0f : a.target[(size_t)env * G + lane];
   const float au = (a.action && lane < a.nu) ? a.action[(size_t)env * a.nu + lane] : 0.0f;
   __builtin_amdgcn_sched_barrier(0);  // (nothing below may move in front of the loads above)
-  if (!DUAL) {
+  {
     f4* dst = reinterpret_cast<f4*>(&T);
 #pragma unroll
     for (int k = 0; k < TAB_NPASS; k++)
       if (tid + 64 * k < TAB_NQ) dst[tid + 64 * k] = tabtmp[k];
   }
-  if (lane < a.qst) S.qpos[lane] = q_lo;
-  if (lane + G < a.qst) S.qpos[lane + G] = q_hi;
+  if (!DUAL) {
+    if (lane < a.qst) S.qpos[lane] = q_lo;
+    if (lane + G < a.qst) S.qpos[lane + G] = q_hi;
+  }
   S.qvel[lane] = qv_in;
   S.qacc_ws[lane] = ws_in;
   if (a.action) {  // lane u fetched action component u; the dof that it drives picks it up across the row
@@ -715,7 +736,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   // instead of 16 x 32 B per env written by one launch and read back by the next (round 1 cached them in HBM: 2.8x the
   // algorithmic traffic).
   STAMP(0);
-  group_fk(S, lane, nb, parents, bk, row4);
+  if (!DUAL) group_fk(S, lane, nb, parents, bk, row4);
   STAMP(1);
   if (DUAL) __syncthreads();  // (1) link poses ready for the collision wave, model table ready for this one
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
