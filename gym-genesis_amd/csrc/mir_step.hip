@@ -55,7 +55,9 @@ static_assert(MAXCON == G, "lane c owns contact c");
  * eight slots from 64 on (tools/phase_profile.py) */
 #define STAMP(k) do { if (a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
 #define ITSTAMP(it, k) do { if ((it) < 8) STAMP(64 + 8 * (it) + (k)); } while (0)
+#define HSTAMP(k) do { if (a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 64) a.prof[k] = __builtin_readcyclecounter(); } while (0)
 #else
+#define HSTAMP(k) do { } while (0)
 #define STAMP(k) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
 #define ITSTAMP(it, k) do { } while (0)
 #endif
@@ -556,7 +558,9 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       const unsigned long long cb = __ballot(mine && (both & low) != 0u && (both & ~low) != 0u);
       if (lane == 0) S.coupled = (uint32_t)(cb >> (grp * G)) & 0xffffu ? 1 : 0;
     }
+    HSTAMP(43);
     if (DUAL) __syncthreads();  // (2) the main wave has left the dynamics scratch: the contact arrays may be stored over it
+    HSTAMP(44);
     if (mine) {
       stv(S.con.cpos[k], pd);
       st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
@@ -651,16 +655,22 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       WSYNC();
       group_fk(S, lane, nb, hparents, hk, row4);
     }
+    HSTAMP(40);
     __syncthreads();  // (1) link poses (this wave) and model table, velocities, targets (main wave) are in LDS
+    HSTAMP(41);
     const int cnt = collide_detect();
+    HSTAMP(42);
     contacts_build(cnt);  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
+    HSTAMP(45);
     __syncthreads();  // (3) contact arrays and base Jacobians handed to the main wave
+    HSTAMP(46);
     {
       float hp[G];
       hess_full(hp, S.ncon);
 #pragma unroll
       for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]});
     }
+    HSTAMP(47);
     __syncthreads();  // (4) all-rows-active Hessian handed to the main wave
     return;
   }
@@ -738,7 +748,8 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   STAMP(0);
   if (!DUAL) group_fk(S, lane, nb, parents, bk, row4);
   STAMP(1);
-  if (DUAL) __syncthreads();  // (1) link poses ready for the collision wave, model table ready for this one
+  STAMP(48);
+  if (DUAL) __syncthreads();  // (1) link poses from the collision wave; model table, velocities and targets from this one
   const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
   if (VARIANT != 2) a.poses = nullptr;
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr;
@@ -1095,6 +1106,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
 #endif
     WSYNC();
     STAMP(3);
+    STAMP(49);
     if (DUAL) __syncthreads();  // (2) this wave is done with the dynamics scratch (M is in its own area, the rest in registers)
     // qacc_smooth = Mt^-1 qfrc_smooth: Gauss-Jordan on register rows
     float mrow[G];
@@ -1145,7 +1157,9 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       }
     }
     WSYNC();
+    STAMP(50);
     if (DUAL) __syncthreads();  // (3) contact arrays and base Jacobians are in LDS
+    STAMP(52);
     const int ncon = S.ncon;
     // contact rows, lane = contact, lane-private: aref_r = -b (J_r qvel) - k imp dist
     const bool iscon = lane < ncon;
@@ -1275,7 +1289,9 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       if (it == 0) {  // start from Mt + the all-rows-active J^T D J (from the collision wave where there is one)
         float hp[G];
         if (DUAL) {
+          STAMP(51);
           __syncthreads();  // (4)
+          STAMP(53);
           met4 = true;
 #pragma unroll
           for (int q = 0; q < 4; q++) {
