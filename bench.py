@@ -537,26 +537,33 @@ def worker(args) -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(loop_fn, k: int):
-        """Exactly k steps bracketed by barrier + synchronize on both sides; (wall seconds max over ranks, HIP-event ms)."""
+    def timed(loop_fn, k: int, events: bool):
+        """Exactly k steps bracketed by barrier + synchronize on both sides; (wall seconds max over ranks, HIP-event ms or 0).
+        HIP events are recorded only around the raw launch loop (they give the kernel's duration there); the API loop is
+        timed by the wall clock alone, so nothing of this harness sits inside its bracket."""
         sync_all()
-        ev0, ev1 = _events(torch)
-        t0 = time.perf_counter()
-        ev0.record()
-        loop_fn(k)
-        ev1.record()
+        if events:
+            ev0, ev1 = _events(torch)
+            t0 = time.perf_counter()
+            ev0.record()
+            loop_fn(k)
+            ev1.record()
+        else:
+            t0 = time.perf_counter()
+            loop_fn(k)
         sync_all()
         wall = time.perf_counter() - t0
-        return max_over_ranks(wall), ev0.elapsed_time(ev1)
+        return max_over_ranks(wall), (ev0.elapsed_time(ev1) if events else 0.0)
 
     def measure(loop_fn):
         """W warm-up steps, then the K-step timed region, repeated until --min-time seconds are measured."""
+        events = loop_fn is raw_loop
         loop_fn(W)
-        first, ev_ms = timed(loop_fn, K)
+        first, ev_ms = timed(loop_fn, K, events)
         reps = repeats_for(first, args.min_time) if first < args.min_time else 1  # (`first` is already the max over ranks)
         walls, evs = [first], [ev_ms]
         for _ in range(reps - 1):
-            w, e = timed(loop_fn, K)
+            w, e = timed(loop_fn, K, events)
             walls.append(w)
             evs.append(e)
         return walls, evs
