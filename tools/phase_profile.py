@@ -72,6 +72,8 @@ def main():
         prof[29] = 2**62
         sc._check(sc.lib.mir_debug_profile_step(sc.h, C.c_void_p(prof.data_ptr()), sc._stream()))
         p = prof.cpu().numpy().astype(np.float64)
+        if p[48] > 0:  # two-wave single-step instantiation (-DMIR_PROFILE_SINGLE): stamp 5 (end of the collision phase) belongs to
+            p[5] = p[4]   # the other wave; tools/probes/dual_timeline.py prints both waves' barrier times instead
         acc += np.diff(p[:11])
         wall.append(((p[27]-p[26])/100.0, (p[28]-p[26])/100.0, (p[29]-p[26])/100.0, (p[25]-p[24])))
         nw += np.array([p[16]-p[7], p[17]-p[16], p[14]-p[17], p[18]-p[14], p[15]-p[18], p[19]-p[15], p[20]-p[19], p[21]-p[20]])
@@ -90,7 +92,8 @@ def main():
     w = np.array(wall)
     print("  wall clock (us from block-0 entry): block-0 exit %.1f | first block exit %.1f | LAST block exit %.1f (per-step max %.1f) ; block-0 cycles/us = %.0f MHz" % (w[:,0].mean(), w[:,2].mean(), w[:,1].mean(), w[:,1].max(), (w[:,3]/w[:,0]).mean()))
     print("  dynamics split: cdof+cinert %.0f | velocity scan %.0f | cddq+cvel+crb suffix %.0f | acc scan %.0f | RNE+force suffix %.0f | M fill+bias %.0f" % tuple(dyn))
-    print("  collide split: geoms %.0f | broadphase %.0f | narrowphase %.0f | compaction+contacts %.0f" % (sub[0], sub[1], sub[2], sub[3]))
+    if sub[0] >= 0:
+        print("  collide split: geoms %.0f | broadphase %.0f | narrowphase %.0f | compaction+contacts %.0f" % (sub[0], sub[1], sub[2], sub[3]))
     print("  newton it0 split: forces+H build %.0f | gsum+GJ %.0f | rest of iteration(s) %.0f" % (sub[4], sub[5], sub[6]))
     print("  compaction split: scan %.0f | per-candidate consts %.0f | contact writes %.0f ; prologue (entry->stamp0) %.0f | epilogue (stamp10->exit) %.0f | whole kernel %.0f" % (ex[0], ex[1], ex[2], ex[3], ex[4], ex[5]))
     print("  newton it0 fine: forces/cfb %.0f | gradient loop %.0f | gsum+check %.0f | H build %.0f | GJ %.0f | mv+jv %.0f | line search %.0f | improvement+update %.0f" % tuple(nw))
