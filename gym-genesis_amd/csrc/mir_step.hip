@@ -1530,7 +1530,19 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     }
   }  // steps
   STAMP(10);
-  bool term_now = false;
+  // GenesisEnv.step's D->H copy of `terminated`, done by the kernel and issued FIRST: the four masks of the wave as ONE 32-bit store
+  // straight into pinned host memory (write-through, system scope), each byte = term | tag << 1; its trip over PCIe runs under the
+  // state and observation stores below.  The tag changes from launch to launch, so the host recognises the bytes of THIS launch by
+  // themselves (sync mode 3: no fence, no ticket, nothing waits).
+  const bool term_now = valid && S.xpos[ob][2] > mdl_reward_z;
+  if (VARIANT != 1 && a.term_host) {
+    const unsigned long long tb = __ballot(term_now && lane == 0);
+    if (tid == 0) {
+      const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (valid) {
     if (a.poses && lane < nb) {  // (pose refresh for the rasteriser, mode 2 only)
       float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
@@ -1545,14 +1557,13 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     }
     if (a.action) a.target[(size_t)env * G + lane] = S.target[lane];
     // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
-    const float rew = S.xpos[ob][2] > mdl_reward_z ? 1.0f : 0.0f;
+    const float rew = term_now ? 1.0f : 0.0f;
     if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
     if (a.env_state && lane < 11) a.env_state[(size_t)env * 11 + lane] = column(ad + lane);
     if (lane == 0) {
       if (a.reward) a.reward[env] = rew;
       if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
     }
-    term_now = rew == 1.0f;
     if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
     if (a.rows && !(a.ar.episode_len && a.rows_step)) {  // (in rollout mode: the last step's row; with autoreset it was written in the loop)
       float* row = a.rows + (size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride;
@@ -1563,17 +1574,6 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));
     }
   }  // valid
-  if (VARIANT != 1 && a.term_host) {
-    // GenesisEnv.step's D->H copy of `terminated`, done by the kernel: the four masks of the wave as ONE 32-bit store straight
-    // into pinned host memory (write-through, system scope), each byte = term | tag << 1.  The tag changes from launch to
-    // launch, so the host recognises the bytes of THIS launch by themselves (sync mode 3: no fence, no ticket, nothing waits).
-    const unsigned long long tb = __ballot(term_now && lane == 0);
-    if (tid == 0) {
-      const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
-      __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
   if (VARIANT != 1 && a.done_ticket) {
     // Completion published by the kernel itself (mir_step_begin, sync mode 2): every wave waits for its host store to be
     // acknowledged (~3 us over PCIe), then takes a ticket; the wave that takes the last one knows that every terminated byte of the launch is in

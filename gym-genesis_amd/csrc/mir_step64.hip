@@ -1356,6 +1356,10 @@ void mir_step64_kernel(StepArgs64 a) {
     }
   }  // steps
   STAMP(18);
+  // (the host-visible terminated byte goes out first: its trip over PCIe runs under the stores below)
+  const float rew = reward_now();
+  if (lane == 0 && a.term_host)
+    __hip_atomic_store(&a.term_host[env], (uint8_t)((rew == 1.0f ? 1u : 0u) | a.term_tag << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (lane < nb) {
     float* p = a.poses + ((size_t)env * 2 * NB + lane) * 4;
     *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
@@ -1371,13 +1375,11 @@ void mir_step64_kernel(StepArgs64 a) {
   if (a.action) a.target[(size_t)env * NL + lane] = S.target[lane];
   (void)nq;
   // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
-  const float rew = reward_now();
   if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
   if (a.env_state && lane < ed) a.env_state[(size_t)env * ed + lane] = column(ad + lane);
   if (lane == 0) {
     if (a.reward) a.reward[env] = rew;
     if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
-    if (a.term_host) __hip_atomic_store(&a.term_host[env], (uint8_t)((rew == 1.0f ? 1u : 0u) | a.term_tag << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
   if (a.rows && !(a.ar.episode_len && a.rows_step) && lane < ad + ed + 2)  // (in rollout mode: the last step's row; with autoreset: written in the loop)
