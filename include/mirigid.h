@@ -229,8 +229,9 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  *     is_success = (reward == 1); terminated = is_success.detach().cpu().numpy().astype(bool)        (env.py:63-64)
  * mir_step_begin = mir_step_fused (same arguments, `terminated` = the device copy, nullable) that also stores the
  * terminated bytes into a pinned host buffer owned by the handle, straight from the kernel (no copy command);
- * mir_step_end blocks until THAT launch has finished and copies the B bytes into terminated_host (plain host memory,
- * nullable).  Between the two calls the host is free (the Python side prepares its return values there).  Exactly one
+ * mir_step_end blocks until THAT launch has delivered its terminated bytes and copies the B bytes into terminated_host (plain
+ * host memory, nullable).  In mode 3 the kernel stores those bytes before its device-side outputs, so the other outputs of the
+ * launch are ordered by the stream as after any launch (a later launch, copy or synchronize on it sees them), not by this call.  Between the two calls the host is free (the Python side prepares its return values there).  Exactly one
  * mir_step_end per mir_step_begin; the only entry point of the library that waits for the device.
  * How the wait is done (mir_get_sync_mode; environment variable MIR_SYNC_MODE overrides at mir_create):
  *   3  (default) every terminated byte carries a tag that changes from launch to launch; the host spins until all B bytes
