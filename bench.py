@@ -604,6 +604,9 @@ def worker(args) -> int:
             "timed_steps_total": len(walls) * K,
             "timed_seconds_total": total_wall,
             "best_repeat_value": K * B * world / min(walls),
+            # spread of the repeated K-step regions (us per step): the headline is their mean, resets included
+            "repeat_us_per_step": {"min": min(walls) * 1e6 / K, "median": sorted(walls)[len(walls) // 2] * 1e6 / K,
+                                   "p95": sorted(walls)[min(len(walls) - 1, (95 * len(walls)) // 100)] * 1e6 / K, "max": max(walls) * 1e6 / K},
             "resets_in_loop": state["resets"],
             "path": "GenesisEnv.step" if api_walls is not None else "task.step_raw (--raw-only)",
         }
