@@ -470,6 +470,11 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     for (int k = 0; k < 4; k++) fk_quat[b][k] = q[k];
     m.parents |= (uint64_t)(par & 15) << (4 * b);
   }
+  m.fk_free_leaf = 1;
+  for (int b = 1; b < nb; b++) {
+    if (sp->body[b].jtype == MIR_JNT_FREE && fk_parent[b] != 0) m.fk_free_leaf = 0;
+    if (fk_parent[b] > 0 && sp->body[fk_parent[b]].jtype == MIR_JNT_FREE) m.fk_free_leaf = 0;
+  }
   for (int l = 0; l < MIR_G; l++) {
     LaneK16 k;
     memset(&k, 0, sizeof k);

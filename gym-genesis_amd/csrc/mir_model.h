@@ -67,7 +67,7 @@ struct DevModel {
   // same for the four env groups of a wave) instead of 64 pieces at a stride of 192 B
   float lanek_t[12][MIR_G][4];  // (16-byte aligned: sizeof(ModelTab) is a multiple of 16)
   uint64_t parents;      // the 16 parent indices, 4 bits each (pointer-jumping FK)
-  uint64_t pad_parents;
+  uint64_t fk_free_leaf;  // 1: every free-joint body hangs off the world and carries no children (its pose is its qpos row)
   // sizes / options
   int32_t nbody, nv, nq, ngeom, npair, nu, qstride, max_contacts;
   int32_t iterations, ls_iterations, enable_collision, enable_joint_limit;

@@ -137,11 +137,15 @@ struct BodyK {
 // a dependent walk as long as the chain (10 links for a Panda finger).  `parents` packs the 16 parent indices, 4 bits each;
 // the ancestor's transform and pointer are gathered lane to lane (ds_bpermute), so a round is one crossbar trip and no LDS fence.
 // `row4` = byte offset of the group's first lane in the wave (64 x group).
+// SKIPFREE: free-joint bodies are left out (neither read nor written): in the two-wave instantiation the closing FK runs on the
+// collision wave while the main wave is still integrating the free bodies' quaternions, and writes their poses itself.
+template <bool SKIPFREE = false>
 __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t parents, const BodyK& k, int row4) {
   V3 P = v3(0, 0, 0);
   Q4 Qx = Q4{1, 0, 0, 0};
   int anc = 0;
-  if (lane > 0 && lane < nb) {
+  const bool mine = lane < nb && !(SKIPFREE && k.jtype == MIR_JNT_FREE);
+  if (lane > 0 && lane < nb && mine) {
     Qx = k.quat;
     P = k.pos;
     if (k.jtype == MIR_JNT_REVOLUTE) {
@@ -169,7 +173,7 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
       anc = nxt;
     }
   }
-  if (lane < nb) {
+  if (mine) {
     st3v(S.xpos[lane], P);
     st4v(S.xquat[lane], Qx);
   }
@@ -243,6 +247,8 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   const float mdl_gx = m->gx, mdl_gy = m->gy, mdl_gz = m->gz;
   const int mdl_eef = m->eef_body, mdl_obj = m->obj_body, mdl_ngrip = m->n_grip;
   const int mdl_split = m->gj_split;
+  // DUAL: the closing FK is split between the waves when every free-joint body is a childless child of the world (wave-uniform)
+  const bool fksplit = DUAL && m->fk_free_leaf != 0;
 
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
   // (lane = candidate).  Needs the link poses and the model table in LDS, nothing else: in the DUAL instantiation the second
@@ -634,22 +640,25 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     }
   };
   if (DUAL && wave == 1) {
+    // the four quads of lane constants the forward kinematics needs (fetched again for the closing FK: nothing is kept live
+    // through the collision phase)
+    auto fk_consts = [&](BodyK& hk) {
+      const f4 h0 = *reinterpret_cast<const f4*>(m->lanek_t[0][lane]), h1 = *reinterpret_cast<const f4*>(m->lanek_t[1][lane]);
+      const f4 h2 = *reinterpret_cast<const f4*>(m->lanek_t[2][lane]), h3 = *reinterpret_cast<const f4*>(m->lanek_t[3][lane]);
+      hk.jtype = __float_as_int(h0.x); hk.qadr = __float_as_int(h0.y);
+      hk.pos = v3(h1.x, h1.y, h1.z);
+      hk.quat = Q4{h2.x, h2.y, h2.z, h2.w};
+      hk.axis = v3(h3.x, h3.y, h3.z);
+    };
+    const uint64_t hparents = m->parents;
     {
       // The collision wave opens the launch with the FORWARD KINEMATICS of the stored state: it needs one row of qpos and four of
       // the twelve quads of lane constants, so its loads are back sooner than the main wave's (which also brings in the model
       // table, the other rows and the action), and the main wave finds the link poses ready when it reaches the first barrier.
-      f4 hq[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) hq[k] = *reinterpret_cast<const f4*>(m->lanek_t[k][lane]);
       const float hq_lo = lane < a.qst ? a.qpos[(size_t)env * a.qst + lane] : 0.0f;
       const float hq_hi = lane + G < a.qst ? a.qpos[(size_t)env * a.qst + lane + G] : 0.0f;
-      const uint64_t hparents = m->parents;
-      __builtin_amdgcn_sched_barrier(0);
       BodyK hk;
-      hk.jtype = __float_as_int(hq[0].x); hk.qadr = __float_as_int(hq[0].y);
-      hk.pos = v3(hq[1].x, hq[1].y, hq[1].z);
-      hk.quat = Q4{hq[2].x, hq[2].y, hq[2].z, hq[2].w};
-      hk.axis = v3(hq[3].x, hq[3].y, hq[3].z);
+      fk_consts(hk);
       if (lane < a.qst) S.qpos[lane] = hq_lo;
       if (lane + G < a.qst) S.qpos[lane + G] = hq_hi;
       WSYNC();
@@ -672,6 +681,15 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     }
     HSTAMP(47);
     __syncthreads();  // (4) all-rows-active Hessian handed to the main wave
+    if (fksplit) {
+      // the closing forward kinematics of the jointed bodies, beside the main wave's quaternion integration of the free bodies
+      // and its state stores (the four quads of lane constants are fetched again: nothing of the opening FK was kept in registers)
+      BodyK hk;
+      fk_consts(hk);
+      __syncthreads();  // (5) the main wave has integrated the jointed dofs
+      group_fk<true>(S, lane, nb, hparents, hk, row4);
+      __syncthreads();  // (6) link poses of the new state handed to the main wave
+    }
     return;
   }
 
@@ -1474,7 +1492,13 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       const float qd = S.qvel[lane];
       if (d_kind < 2) S.qpos[d_qadr] += dt * qd;
       else if (d_kind == 2) S.qpos[T.b_info[d_body][2] + d_axis_k] += dt * qd;
-      else if (d_axis_k == 0) {
+    }
+    if (fksplit) {
+      WSYNC();
+      __syncthreads();  // (5) jointed dofs integrated: the collision wave starts the closing FK of the jointed bodies
+    }
+    if (isdof) {
+      if (d_kind == 3 && d_axis_k == 0) {
         const int da = T.b_info[d_body][3], qa = T.b_info[d_body][2];
         V3 w = v3(S.qvel[da + 3], S.qvel[da + 4], S.qvel[da + 5]);
         float wn = sqrtf(dot(w, w));
@@ -1491,7 +1515,17 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     WSYNC();
     STAMP(9);
     // kinematics of the new state: observations of this step, and the next step's starting poses
-    group_fk(S, lane, nb, parents, bk, row4);
+    if (fksplit) {
+      // (the free bodies' poses are their qpos rows -- the expressions of group_fk for a childless child of the world)
+      if (isbody && bk.jtype == MIR_JNT_FREE) {
+        st3v(S.xpos[lane], ld3(&S.qpos[bk.qadr]));
+        st4v(S.xquat[lane], qnormalize(ld4(&S.qpos[bk.qadr + 3])));
+      }
+      WSYNC();
+      __syncthreads();  // (6) the jointed bodies' poses from the collision wave
+    } else {
+      group_fk(S, lane, nb, parents, bk, row4);
+    }
     if (a.rows && a.rows_step && (step + 1 < nsteps || a.ar.episode_len) && valid) {  // rollout mode: one packed row per env per step
       float* row = a.rows + (size_t)step * a.rows_step + (size_t)env * a.row_stride;
       for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
