@@ -249,6 +249,10 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   const int mdl_split = m->gj_split;
   // DUAL: the closing FK is split between the waves when every free-joint body is a childless child of the world (wave-uniform)
   const bool fksplit = DUAL && m->fk_free_leaf != 0;
+  // the task's object is a free body hanging off the world: its height -- all that `terminated` needs -- is a qpos entry, final as
+  // soon as the translations are integrated, so the host-visible bytes can leave before the closing FK (wave-uniform)
+  const int mdl_obj_qadr = m->obj_qadr;
+  const bool term_early = VARIANT != 1 && m->fk_free_leaf != 0 && mdl_obj_qadr >= 0;
 
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
   // (lane = candidate).  Needs the link poses and the model table in LDS, nothing else: in the DUAL instantiation the second
@@ -1493,6 +1497,18 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
       if (d_kind < 2) S.qpos[d_qadr] += dt * qd;
       else if (d_kind == 2) S.qpos[T.b_info[d_body][2] + d_axis_k] += dt * qd;
     }
+    if (VARIANT != 1 && a.term_host && term_early) {
+      // GenesisEnv.step's D->H copy of `terminated`, done by the kernel: see the epilogue; here ~1 us earlier, so that the trip
+      // over PCIe is over when the launch ends
+      WSYNC();
+      const bool tn = valid && S.qpos[mdl_obj_qadr + 2] > mdl_reward_z;
+      const unsigned long long tb = __ballot(tn && lane == 0);
+      if (tid == 0) {
+        const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     if (fksplit) {
       WSYNC();
       __syncthreads();  // (5) jointed dofs integrated: the collision wave starts the closing FK of the jointed bodies
@@ -1569,7 +1585,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   // state and observation stores below.  The tag changes from launch to launch, so the host recognises the bytes of THIS launch by
   // themselves (sync mode 3: no fence, no ticket, nothing waits).
   const bool term_now = valid && S.xpos[ob][2] > mdl_reward_z;
-  if (VARIANT != 1 && a.term_host) {
+  if (VARIANT != 1 && a.term_host && !term_early) {
     const unsigned long long tb = __ballot(term_now && lane == 0);
     if (tid == 0) {
       const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
