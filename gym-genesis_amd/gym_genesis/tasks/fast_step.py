@@ -17,12 +17,13 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
     device tensor (e.g. the SO-101 tasks' reshape)."""
     go, prepare, alloc, end, as_action = mir.step_go_ptr, mir.step_prepare_ptrs, mir._alloc_outputs, mir.step_end_ptr, mir.as_action
     B, dev, tensor, f32, tbool = task.num_envs, task.device, torch.Tensor, torch.float32, torch.bool
+    shape = torch.Size((B, action_dim))
     np_empty, np_zeros, np_bool = np.empty, np.zeros, np.bool_
     nxt = [None]
 
     def fast_step(action):
-        if not (type(action) is tensor and action.dtype is f32 and action.device == dev and action.is_contiguous()
-                and action.dim() == 2 and action.shape[0] == B and action.shape[1] == action_dim):
+        if not (type(action) is tensor and action.dtype is f32 and action.shape == shape and action.is_contiguous()
+                and action.device == dev):
             if coerce is not None:
                 action = coerce(action)
             action = as_action(action, action_dim)
