@@ -626,7 +626,7 @@ def worker(args) -> int:
                 out["sync_step_floor"] = {"null_launch_roundtrip_us": null_us, "kernel_us": kernel_us,
                                           "floor_us_per_step": kernel_us + null_us, "measured_us_per_step": out["ms_per_step"] * 1e3,
                                           "note": "env.step must hand a NumPy `terminated` to the host every step (env.py:64), so the next launch "
-                                                  "cannot be queued behind the running one: each step pays launch + dispatch + completion latency"}
+                                                  "cannot be queued behind the running one: each step pays launch + dispatch + completion latency (the kernel stores the terminated bytes as soon as the object's height is integrated, ~1.5 us before it ends, so the measured step can come in slightly under kernel + round trip)"}
             except Exception as e:  # noqa: BLE001
                 out["sync_step_floor"] = {"error": f"{type(e).__name__}: {e}"}
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
