@@ -168,6 +168,13 @@ int mir_compile_model64(const MirSceneSpec* sp0, DevModel64* out, HostConsts* hc
   m.reward_z = (float)t.reward_z; m.reward_xy = (float)t.reward_xy; m.reward_dz = (float)t.reward_dz;
   m.agent_dim = t.agent_mode == MIR_AGENT_QPOS ? narm : 7 + m.n_grip;
   m.env_dim = t.obj2_body >= 0 ? 14 : 11;
+  {
+    auto free_root = [&](int b) { return b > 0 && m.b_jtype[b] == MIR_JNT_FREE && m.b_parent[b] == 0; };
+    m.obj_qadr = free_root(m.obj_body) ? m.b_qadr[m.obj_body] : -1;
+    m.obj2_qadr = (m.obj2_body >= 0 && free_root(m.obj2_body)) ? m.b_qadr[m.obj2_body] : -1;
+    m.term_early = (m.obj_qadr >= 0 && (t.reward_mode != MIR_REWARD_STACK || m.obj2_qadr >= 0)) ? 1 : 0;
+    m.pad_te = 0;
+  }
 
   // ---- geoms + static pair filter (same rules as mir_compile.cpp) -----------------------------------
   for (int g = 0; g < sp->ngeom; g++) {

@@ -31,6 +31,9 @@ struct DevModel64 {
   uint64_t lanemask;             /* lanes that carry a dof */
   int32_t d_armidx[W64];         /* index into arm_qpos for scalar-joint lanes, else -1 */
   int32_t free_qadr[MIR_MAX_FREE]; /* qpos address of free body k (body order) */
+  /* qpos address of the task's object(s) when they are free bodies hanging off the world -- their world positions ARE those qpos
+   * entries, so the reward is known as soon as the step is integrated -- else -1 (obj2: -1 also when the task has none) */
+  int32_t obj_qadr, obj2_qadr, term_early, pad_te;
   // ---- per body (index = lane < 32) ----
   int32_t b_parent[K64_MAX_BODY], b_jtype[K64_MAX_BODY], b_dofadr[K64_MAX_BODY] /* first LANE */, b_qadr[K64_MAX_BODY];
   int32_t b_root[K64_MAX_BODY], b_static[K64_MAX_BODY], b_block[K64_MAX_BODY] /* block of the body's tree, -1 = static */;

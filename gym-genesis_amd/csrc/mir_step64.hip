@@ -669,15 +669,17 @@ void mir_step64_kernel(StepArgs64 a) {
   // packed output row [agent_pos | env_state | reward | terminated] of the current kinematic state
   const int eb = m->eef_body, ob = m->obj_body, ob2 = m->obj2_body;
   const int ad = m->agent_dim, ed = m->env_dim;
-  auto reward_now = [&]() -> float {
-    const V3 po = ld3v(S.xpos[ob]);
+  auto reward_of = [&](const V3 po, const V3 p2) -> float {
     if (m->reward_mode == MIR_REWARD_STACK) {
-      const V3 p2 = ld3v(S.xpos[ob2]);
       const float dx = po.x - p2.x, dy = po.y - p2.y;
       return (sqrtf(dx * dx + dy * dy) < m->reward_xy && po.z - p2.z > m->reward_dz) ? 1.0f : 0.0f;
     }
     return po.z > m->reward_z ? 1.0f : 0.0f;
   };
+  auto reward_now = [&]() -> float { return reward_of(ld3v(S.xpos[ob]), ld3v(S.xpos[ob2 >= 0 ? ob2 : ob])); };
+  // (free objects hanging off the world: the same positions straight from qpos, before any forward kinematics)
+  const bool term_early = m->term_early != 0;
+  const int obj_qadr = m->obj_qadr, obj2_qadr = m->obj2_qadr;
   auto column = [&](int c) -> float {
     if (c < ad) {
       // (every caller asks for its own lane's column: the qpos address comes from the lane constants, no model trip)
@@ -1318,6 +1320,13 @@ void mir_step64_kernel(StepArgs64 a) {
     }
     WSYNC();
     STAMP(17);
+    if (a.term_host && term_early && lane == 0) {
+      // the host-visible terminated byte leaves here, before the closing FK, the observation and the state stores: its trip over
+      // PCIe runs under them (see the 16-lane kernel)
+      const V3 po = ld3(&S.qpos[obj_qadr]);
+      const float r0 = reward_of(po, obj2_qadr >= 0 ? ld3(&S.qpos[obj2_qadr]) : po);
+      __hip_atomic_store(&a.term_host[env], (uint8_t)((r0 == 1.0f ? 1u : 0u) | a.term_tag << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // kinematics of the new state: observations of this step, and the next step's starting poses
     wave_fk(S, lane, nb, bk);
     if (a.rows && a.rows_step && (step + 1 < nsteps || a.ar.episode_len) && lane < ad + ed + 2)  // rollout mode: one packed row per env per step
@@ -1358,7 +1367,7 @@ void mir_step64_kernel(StepArgs64 a) {
   STAMP(18);
   // (the host-visible terminated byte goes out first: its trip over PCIe runs under the stores below)
   const float rew = reward_now();
-  if (lane == 0 && a.term_host)
+  if (lane == 0 && a.term_host && !term_early)
     __hip_atomic_store(&a.term_host[env], (uint8_t)((rew == 1.0f ? 1u : 0u) | a.term_tag << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (lane < nb) {
     float* p = a.poses + ((size_t)env * 2 * NB + lane) * 4;
