@@ -41,9 +41,6 @@
 #include "mir_dev.h"
 #include "mir_convex.h"
 #define EPB 4       /* envs per block */
-#ifndef MIR_TREE_SCAN
-#define MIR_TREE_SCAN 1 /* tree recursions of the dynamics as scans (pointer jumping + DPP suffix sums); 0 = masked gathers */
-#endif
 #define MAXCON K16_MAX_CONTACT
 #define JST 52      /* floats per contact in Jb: 3 rows x 16 + 4 pad -> conflict-free ds_read_b128 across contact lanes */
 #define MSTR 20     /* row stride of M in LDS (floats): 16-byte aligned rows, conflict-free b128 row reads */
@@ -710,18 +707,14 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   bk.jtype = __float_as_int(lk[0].x); bk.qadr = __float_as_int(lk[0].y);
   const int b_root = __float_as_int(lk[0].z), d_body = __float_as_int(lk[0].w);
   bk.pos = v3(lk[1].x, lk[1].y, lk[1].z);
-  [[maybe_unused]] const uint32_t b_dofmask = __float_as_uint(lk[1].w);  // (masks: the gather formulation, MIR_TREE_SCAN 0)
   bk.quat = Q4{lk[2].x, lk[2].y, lk[2].z, lk[2].w};
   bk.axis = v3(lk[3].x, lk[3].y, lk[3].z);
-  [[maybe_unused]] const uint32_t b_submask = __float_as_uint(lk[3].w);
   const V3 b_ipos = v3(lk[4].x, lk[4].y, lk[4].z);
   const float b_mass = lk[4].w;
   const float ib[6] = {lk[5].x, lk[5].y, lk[5].z, lk[5].w, lk[6].x, lk[6].y};
   const int d_kind = __float_as_int(lk[6].z), d_qadr = __float_as_int(lk[6].w);
   const int d_axis_k = __float_as_int(lk[7].x), d_root = __float_as_int(lk[7].y), d_ctrl = __float_as_int(lk[7].z), d_uadr = __float_as_int(lk[7].w);
   const V3 d_axis = v3(lk[8].x, lk[8].y, lk[8].z);
-  [[maybe_unused]] const uint32_t d_submask = __float_as_uint(lk[8].w);
-  [[maybe_unused]] const uint32_t d_premask = __float_as_uint(lk[9].x);
   const uint32_t d_ancmask = __float_as_uint(lk[9].y);
   const bool d_limited = __float_as_int(lk[9].z) != 0;
   const float d_damping = lk[9].w, d_kp = lk[10].x, d_kv = lk[10].y, d_frclo = lk[10].z, d_frchi = lk[10].w, d_mdiag = lk[11].x;
@@ -847,7 +840,6 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     }
     WSYNC();
     STAMP(32);
-#if MIR_TREE_SCAN
     // ======================= velocities, composite inertias, body forces: tree SCANS =============
     // Sums over the ancestors of a dof are inclusive prefix sums along its dof chain: POINTER JUMPING over the chain's parent
     // links (<= 4 rounds of one lane gather each, as in the FK) instead of a masked gather per lane and per quantity.  Sums over
@@ -991,141 +983,6 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
         qfs = -d_damping * qd + fa - qfrc_bias;
       }
     }
-#else
-    // ======================= velocities, composite inertias =====================================
-    {
-      // sum of qvel_j * cdof_j over the dofs of a mask, four per trip with the reads of the trip issued together (the masks
-      // differ per lane, so the compiler cannot batch them itself; one LDS round trip per four dofs instead of per dof)
-      auto gather_vel = [&](uint32_t mk, V3& W, V3& Vl) {
-        while (mk) {
-          int j[4];
-          bool ok[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) { ok[u] = mk != 0u; j[u] = ok[u] ? __ffs(mk) - 1 : 0; mk &= mk - 1u; }
-          float qd[4];
-          f4 ca[4], cl[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) { qd[u] = S.qvel[j[u]]; ca[u] = ldv(&S.cdof[j[u]][0]); cl[u] = ldv(&S.cdof[j[u]][4]); }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (ok[u]) {
-              W = W + qd[u] * v3(ca[u].x, ca[u].y, ca[u].z);
-              Vl = Vl + qd[u] * v3(cl[u].x, cl[u].y, cl[u].z);
-            }
-        }
-      };
-      if (isdof) {  // lane = dof: cdof_dot * qvel, "velocity before this dof" from the pre-mask
-        V3 pw = v3(0, 0, 0), pv = v3(0, 0, 0);
-        gather_vel(d_premask, pw, pv);
-        V3 cw = ld3v(&S.cdof[lane][0]), cv = ld3v(&S.cdof[lane][4]);
-        float qd = S.qvel[lane];
-        st3v(&S.dyn.cddq[lane][0], qd * cross(pw, cw));
-        st3v(&S.dyn.cddq[lane][4], qd * (cross(pw, cv) + cross(pv, cw)));
-      }
-      V3 w = v3(0, 0, 0), v = v3(0, 0, 0);
-      f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0;
-      if (isbody) {  // lane = body: cvel, composite inertia over the subtree
-        gather_vel(b_dofmask, w, v);
-        uint32_t sm = b_submask;
-        while (sm) {  // four subtree bodies per trip, reads batched
-          int cb[4];
-          bool ok[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) { ok[u] = sm != 0u; cb[u] = ok[u] ? __ffs(sm) - 1 : 0; sm &= sm - 1u; }
-          f4 x0[4], x1[4], x2[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) { const float* p = S.dyn.cinert[cb[u]]; x0[u] = ldv(p); x1[u] = ldv(p + 4); x2[u] = ldv(p + 8); }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (ok[u]) { c0 += x0[u]; c1 += x1[u]; c2 += x2[u]; }
-        }
-      }
-      st3v(&S.dyn.cvel[lane][0], w);
-      st3v(&S.dyn.cvel[lane][4], v);
-      float* p = S.dyn.crb[lane];
-      stv(p, c0); stv(p + 4, c1); stv(p + 8, c2);
-    }
-    WSYNC();
-    STAMP(2);
-
-    // ======================= body forces (RNE, qacc=0) and mass matrix rows =======================
-    // sum of the (angular, linear) pairs of an 8-float-per-entry LDS table over the entries of a mask, four per trip
-    auto gather_pair = [&](uint32_t mk, const float* tab, V3& A, V3& Bv) {
-      while (mk) {
-        int j[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { ok[u] = mk != 0u; j[u] = ok[u] ? __ffs(mk) - 1 : 0; mk &= mk - 1u; }
-        f4 xa[4], xl[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { xa[u] = ldv(tab + 8 * j[u]); xl[u] = ldv(tab + 8 * j[u] + 4); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (ok[u]) { A = A + v3(xa[u].x, xa[u].y, xa[u].z); Bv = Bv + v3(xl[u].x, xl[u].y, xl[u].z); }
-      }
-    };
-    {
-      V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
-      if (isbody) {
-        V3 aw = v3(0, 0, 0), av = v3(-mdl_gx, -mdl_gy, -mdl_gz);
-        gather_pair(b_dofmask, &S.dyn.cddq[0][0], aw, av);
-        Inert I = ldI(S.dyn.cinert[lane]);
-        V3 w = ld3v(&S.dyn.cvel[lane][0]), v = ld3v(&S.dyn.cvel[lane][4]);
-        V3 ta, fa, tv, fv;
-        imul(I, aw, av, ta, fa);
-        imul(I, w, v, tv, fv);
-        t = ta + cross(w, tv) + cross(v, fv);
-        f = fa + cross(w, fv);
-      }
-      st3v(&S.dyn.cfrc[lane][0], t);
-      st3v(&S.dyn.cfrc[lane][4], f);
-      // zero this lane's row of M, then (after the fence) fill the tree-sparse entries
-#pragma unroll
-      for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{0, 0, 0, 0});
-    }
-    WSYNC();
-    if (isdof) {  // M[i][j] = cdof_j . (crb_body(i) cdof_i), j over ancestors-or-self
-      Inert I = ldI(S.dyn.crb[d_body]);
-      V3 bt, bf;
-      imul(I, ld3v(&S.cdof[lane][0]), ld3v(&S.cdof[lane][4]), bt, bf);
-      uint32_t mk = d_ancmask;
-      while (mk) {  // four ancestors per trip, reads batched
-        int j[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { ok[u] = mk != 0u; j[u] = ok[u] ? __ffs(mk) - 1 : 0; mk &= mk - 1u; }
-        f4 ca[4], cl[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { ca[u] = ldv(&S.cdof[j[u]][0]); cl[u] = ldv(&S.cdof[j[u]][4]); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (ok[u]) {
-            float val = dot(v3(ca[u].x, ca[u].y, ca[u].z), bt) + dot(v3(cl[u].x, cl[u].y, cl[u].z), bf);
-            if (j[u] == lane) val += d_mdiag;
-            S.M[lane][j[u]] = val;
-            S.M[j[u]][lane] = val;
-          }
-      }
-    }
-    // bias + smooth force (lane = dof)
-    float qfrc_bias = 0.0f, qfs = 0.0f;
-    if (isdof) {
-      V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
-      gather_pair(d_submask, &S.dyn.cfrc[0][0], t, f);
-      qfrc_bias = dot(ld3v(&S.cdof[lane][0]), t) + dot(ld3v(&S.cdof[lane][4]), f);
-      float qd = S.qvel[lane];
-      float fa = 0.0f;
-      if (d_ctrl == MIR_CTRL_POSITION) {
-        fa = d_kp * (S.target[lane] - S.qpos[d_qadr]) - d_kv * qd;
-        fa = fminf(fmaxf(fa, d_frclo), d_frchi);
-      }
-      qfs = -d_damping * qd + fa - qfrc_bias;
-    }
-#endif
     WSYNC();
     STAMP(3);
     STAMP(49);
