@@ -175,11 +175,13 @@ struct Outs {
   AutoResetArgs ar = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
   bool diag = true;
   bool poses = false;  // 16-lane kernel: also write the link poses into h->poses (the rasteriser reads them)
+  int phase = 0;       // 16-lane kernel: 0 whole step, 1 / 2 the two halves of a split step (mir_step.h)
   unsigned long long* prof = nullptr;  // 16-lane kernel only (debug)
 };
 
 int launch(MirScene* h, const Outs& o, void* stream) {
   int rc;
+  if (o.phase != 1 && o.mode != 2) h->pre_valid = 0;  // (whatever this launch is, the state it leaves is not the one `pre` was made from)
   if (h->kernel == 16) {
     StepArgs a;
     memset(&a, 0, sizeof a);
@@ -193,6 +195,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
     a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
     a.term_host = o.term_host; a.term_tag = o.term_tag; a.done_ticket = o.done_ticket; a.done_flag = o.done_flag; a.done_seq = o.done_seq;
+    a.phase = o.phase; a.pre = h->pre;
     rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
   } else {
     StepArgs64 a;
@@ -254,6 +257,7 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   HIPCHK(hipMalloc((void**)&h->fkvalid, B * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&h->done_ticket, 64));
   HIPCHK(hipMalloc((void**)&h->scratch_row, row_bytes));
+  if (h->kernel == 16) HIPCHK(hipMalloc((void**)&h->pre, B * K16_PRE_STRIDE * sizeof(float)));
   // pinned, device-mapped, coherent host memory for the API's host-visible outputs: terminated bytes + completion word
   const size_t pin_bytes = ((B + 63) / 64) * 64 + 64;  // (whole 32-bit words for the packed stores of the 16-lane kernel)
   HIPCHK(hipHostMalloc((void**)&h->pin_host, pin_bytes, hipHostMallocMapped | hipHostMallocCoherent));
@@ -279,6 +283,9 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   h->sync_mode = 3;
   if (const char* e = getenv("MIR_SYNC_MODE")) h->sync_mode = atoi(e);
   if (h->sync_mode < 0 || h->sync_mode > 3 || (h->sync_mode == 2 && h->kernel != 16)) h->sync_mode = 3;
+  h->split_step = h->kernel == 16 ? 1 : 0;
+  if (const char* e = getenv("MIR_SPLIT_STEP")) h->split_step = (atoi(e) != 0 && h->kernel == 16) ? 1 : 0;
+  h->pre_valid = 0;
   return MIR_OK;
 }
 
@@ -402,6 +409,7 @@ int mir_destroy(MirHandle h) {
   if (h->prims) (void)hipFree(h->prims);
   if (h->done_ticket) (void)hipFree(h->done_ticket);
   if (h->scratch_row) (void)hipFree(h->scratch_row);
+  if (h->pre) (void)hipFree(h->pre);
   if (h->pin_host) (void)hipHostFree(h->pin_host);
   delete h;
   return MIR_OK;
@@ -425,6 +433,7 @@ int mir_get_model_consts(MirHandle h, double* dof_invweight0, double* body_invwe
 
 int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const float* arm_qpos, const uint8_t* env_mask, void* stream) {
   if (check(h)) return MIR_E_INVALID;
+  h->pre_valid = 0;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_reset, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, obj_pos, obj_quat, arm_qpos, env_mask, h->fkvalid, h->B);
@@ -436,6 +445,7 @@ int mir_autoreset(MirHandle h, const uint8_t* terminated, int32_t* episode_len, 
                   int32_t* cursor, const float* obj_quat, const float* arm_qpos, uint8_t* truncated_out, uint8_t* done_out, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   if (!episode_len || !spawn_pool || !cursor || !obj_quat || !arm_qpos || pool_len <= 0) return set_err(MIR_E_INVALID, "mir_autoreset: null argument");
+  h->pre_valid = 0;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_autoreset, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, terminated, episode_len, max_len, spawn_pool, pool_len, cursor, obj_quat, arm_qpos, truncated_out, done_out,
@@ -484,11 +494,24 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   const uint32_t seq = h->seq + 1u;
   o.term_tag = 1u + seq % 3u;  // 1, 2, 3, 1, ...: never 0 (fresh memory), never the tag of the previous launch
   if (h->sync_mode == 2) { o.done_ticket = h->done_ticket; o.done_flag = flag_dev; o.done_seq = seq; }
+  // split step: if the previous mir_step_begin left the action-independent half of THIS step in `pre` (same stream, nothing
+  // touched the state since), only the other half is launched now
+  const bool split = h->split_step && h->sync_mode != 2;
+  o.phase = (split && h->pre_valid && h->pre_stream == stream) ? 2 : 0;
   int rc = launch(h, o, stream);
   if (rc != MIR_OK) return rc;
   if (h->sync_mode == 1) {
     hipError_t e = hipStreamWriteValue32((hipStream_t)stream, flag_dev, seq, 0);
     if (e != hipSuccess) { (void)hipGetLastError(); h->sync_mode = 0; }  // not supported on this stack: wait on the stream instead
+  }
+  if (split) {
+    // ... and the action-independent half of the NEXT step goes out right behind it: it runs while the host is between two calls
+    Outs p;
+    p.phase = 1; p.diag = false;
+    rc = launch(h, p, stream);
+    if (rc != MIR_OK) return rc;
+    h->pre_valid = 1;
+    h->pre_stream = stream;
   }
   h->seq = seq;
   h->pending = 1;
@@ -747,6 +770,7 @@ int mir_get_state(MirHandle h, float* qpos, float* qvel, float* target, float* w
 
 int mir_set_state(MirHandle h, const float* qpos, const float* qvel, const float* target, const float* warmstart, void* stream) {
   if (check(h)) return MIR_E_INVALID;
+  h->pre_valid = 0;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_copy_state, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, (float*)qpos, (float*)qvel, (float*)target, (float*)warmstart, h->fkvalid, h->B, 1);

@@ -198,10 +198,16 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 // and after the contacts it accumulates the all-rows-active Newton Hessian beside wave 0's warm start and first gradient: four
 // barriers in all.  The step-loop instantiations keep one wave (they need the AGPRs a second wave per SIMD would have to give up);
 // both run the same code in the same order of operations, so they agree bit for bit.
+// VARIANT 3 / 4 = the two halves of a single step for GenesisEnv.step (StepArgs.phase 1 / 2): 3 is the action-independent
+// half -- everything the two waves do up to the contact Jacobians and the all-rows-active Hessian -- whose results go to the
+// `pre` buffer instead of staying in LDS; 4 picks them up and runs the rest on one wave.  The host launches 3 for the NEXT step
+// right behind the current step, so that it runs while the host is between two env.step() calls.
 template <int VARIANT, int FEAT>
-__global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepArgs a) {
-  constexpr bool SINGLE = VARIANT == 0;
-  constexpr bool DUAL = SINGLE;
+__global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir_step_kernel(StepArgs a) {
+  constexpr bool PRE = VARIANT == 3, POST = VARIANT == 4;
+  constexpr bool SINGLE = VARIANT == 0 || PRE || POST;
+  constexpr bool DUAL = VARIANT == 0 || PRE;
+  static_assert(JST == 52 && K16_PRE_STRIDE >= K16_PRE_JB + JST * MAXCON, "pre-buffer layout");
   constexpr bool CONVEX = (FEAT & 1) != 0, SAP = (FEAT & 2) != 0;
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
   __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
@@ -677,6 +683,20 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     {
       float hp[G];
       hess_full(hp, S.ncon);
+      if (PRE) {
+        // the action-independent half ends here: contact data, Jacobian rows and the all-active Hessian go to the pre buffer
+        if (valid) {
+          float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
+          const int nc = S.ncon;
+#pragma unroll
+          for (int q = 0; q < 4; q++) *reinterpret_cast<f4*>(pre + K16_PRE_HP + 16 * lane + 4 * q) = f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]};
+          if (lane == 0) *reinterpret_cast<f4*>(pre + K16_PRE_HEAD) = f4{__int_as_float(nc), __int_as_float(S.coupled), 0.0f, 0.0f};
+          if (lane < nc) *reinterpret_cast<f4*>(pre + K16_PRE_CMETA + 4 * lane) = ldv(S.con.cmeta[lane]);
+          const f4* jsrc = reinterpret_cast<const f4*>(&S.Jb[0][0]);
+          for (int i = lane; i < nc * (JST / 4); i += G) *reinterpret_cast<f4*>(pre + K16_PRE_JB + 4 * i) = jsrc[i];
+        }
+        return;
+      }
 #pragma unroll
       for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]});
     }
@@ -761,7 +781,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
   // instead of 16 x 32 B per env written by one launch and read back by the next (round 1 cached them in HBM: 2.8x the
   // algorithmic traffic).
   STAMP(0);
-  if (!DUAL) group_fk(S, lane, nb, parents, bk, row4);
+  if (!DUAL && !POST) group_fk(S, lane, nb, parents, bk, row4);
   STAMP(1);
   STAMP(48);
   if (DUAL) __syncthreads();  // (1) link poses from the collision wave; model table, velocities and targets from this one
@@ -790,11 +810,34 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     return po.z > mdl_reward_z ? 1.0f : 0.0f;  // k == 11 reward, k == 12 terminated
   };
   int eplen = a.ar.episode_len ? a.ar.episode_len[env] : 0, epcur = a.ar.episode_len ? a.ar.cursor[env] : 0;
+  // POST (the second half of a split step): everything the previous launch left in the pre buffer is fetched here, in one batch --
+  // the mass-matrix row, the bias force and the all-rows-active Hessian into registers, contact count, coupling flag, row constants
+  // and Jacobian rows into the LDS arrays the rest of the step reads
+  f4 pre_m[4] = {}, pre_h[4] = {};
+  float pre_bias = 0.0f;
+  if (POST) {
+    const float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      pre_m[q] = *reinterpret_cast<const f4*>(pre + K16_PRE_MROW + 16 * lane + 4 * q);
+      pre_h[q] = *reinterpret_cast<const f4*>(pre + K16_PRE_HP + 16 * lane + 4 * q);
+    }
+    pre_bias = pre[K16_PRE_BIAS + lane];
+    const f4 head = *reinterpret_cast<const f4*>(pre + K16_PRE_HEAD);
+    const int nc = __float_as_int(head.x);
+    if (lane == 0) { S.ncon = nc; S.coupled = __float_as_int(head.y); S.ncand = 0; }
+    if (lane < nc) stv(S.con.cmeta[lane], *reinterpret_cast<const f4*>(pre + K16_PRE_CMETA + 4 * lane));
+    f4* jdst = reinterpret_cast<f4*>(&S.Jb[0][0]);
+    for (int i = lane; i < nc * (JST / 4); i += G) jdst[i] = *reinterpret_cast<const f4*>(pre + K16_PRE_JB + 4 * i);
+    WSYNC();
+  }
   for (int step = 0; step < nsteps; step++) {
     // rollout mode (mir_rollout): a fresh action block per step
     if (step > 0 && a.action && a.act_step) {
       if (isdof && d_uadr >= 0) S.target[lane] = a.action[(size_t)step * a.act_step + (size_t)env * a.nu + d_uadr];
     }
+    float qfrc_bias = 0.0f, qfs = 0.0f;
+    if (!POST) {
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
     if (isdof) {
       V3 ang = v3(0, 0, 0), lin = v3(0, 0, 0);
@@ -846,7 +889,6 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     // the subtree of a body are suffix sums over the body lanes -- bodies are numbered in depth-first preorder, so a subtree is
     // the lane range [b, b_next) -- formed by four DPP row shifts per component and one subtraction (distal bodies sit at the
     // end of the row, so the subtraction never takes a small subtree out of a large total).
-    float qfrc_bias = 0.0f, qfs = 0.0f;
     {
       // ancestor scan of a 6-vector held by the dof lanes; the result table (inclusive sums, by dof lane) is left in `tab`
       auto ancestor_scan = [&](V3& A, V3& Bv, float* tab) {
@@ -983,6 +1025,7 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
         qfs = -d_damping * qd + fa - qfrc_bias;
       }
     }
+    }  // !POST
     WSYNC();
     STAMP(3);
     STAMP(49);
@@ -990,7 +1033,35 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
     // qacc_smooth = Mt^-1 qfrc_smooth: Gauss-Jordan on register rows
     float mrow[G];
     {
-      f4 r0 = ldv(&S.M[lane][0]), r1 = ldv(&S.M[lane][4]), r2 = ldv(&S.M[lane][8]), r3 = ldv(&S.M[lane][12]);
+      f4 r0, r1, r2, r3;
+      if (POST) {
+        // the action-independent half of this step was computed by the previous launch (VARIANT 3): mass-matrix row and bias force
+        // from the pre buffer, then the smooth force with THIS launch's targets (the expressions of the fused kernel)
+        r0 = pre_m[0]; r1 = pre_m[1]; r2 = pre_m[2]; r3 = pre_m[3];
+        qfrc_bias = pre_bias;
+        if (isdof) {
+          const float qd = S.qvel[lane];
+          float fa = 0.0f;
+          if (d_ctrl == MIR_CTRL_POSITION) {
+            fa = d_kp * (S.target[lane] - S.qpos[d_qadr]) - d_kv * qd;
+            fa = fminf(fmaxf(fa, d_frclo), d_frchi);
+          }
+          qfs = -d_damping * qd + fa - qfrc_bias;
+        } else {
+          qfrc_bias = 0.0f;
+        }
+      } else {
+        r0 = ldv(&S.M[lane][0]); r1 = ldv(&S.M[lane][4]); r2 = ldv(&S.M[lane][8]); r3 = ldv(&S.M[lane][12]);
+      }
+      if (PRE) {
+        if (valid) {
+          float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
+          *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane) = r0; *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 4) = r1;
+          *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 8) = r2; *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 12) = r3;
+          pre[K16_PRE_BIAS + lane] = qfrc_bias;
+        }
+        return;
+      }
       mrow[0] = r0.x; mrow[1] = r0.y; mrow[2] = r0.z; mrow[3] = r0.w; mrow[4] = r1.x; mrow[5] = r1.y; mrow[6] = r1.z; mrow[7] = r1.w;
       mrow[8] = r2.x; mrow[9] = r2.y; mrow[10] = r2.z; mrow[11] = r2.w; mrow[12] = r3.x; mrow[13] = r3.y; mrow[14] = r3.z; mrow[15] = r3.w;
     }
@@ -1014,10 +1085,11 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
 
     // ======================= collision detection, contact arrays, contact Jacobians ==============
     // (DUAL: the collision wave does all of it, detection since the first barrier, the rest since the second)
-    if (!DUAL) {
+    if (!DUAL && !POST) {
       const int mc = collide_detect();
       contacts_build(mc);
     }
+
     // joint-limit rows: lane = dof, lane-private
     float lsg = 0.0f, lD = 0.0f, laref = 0.0f;
     if (d_limited) {
@@ -1177,6 +1249,9 @@ __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) void mir_step_kernel(StepA
             const f4 v = ldv(&S.M[lane][4 * q]);
             hp[4 * q] = v.x; hp[4 * q + 1] = v.y; hp[4 * q + 2] = v.z; hp[4 * q + 3] = v.w;
           }
+        } else if (POST) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) { hp[4 * q] = pre_h[q].x; hp[4 * q + 1] = pre_h[q].y; hp[4 * q + 2] = pre_h[q].z; hp[4 * q + 3] = pre_h[q].w; }
         } else {
           hess_full(hp, ncon);
         }
@@ -1541,7 +1616,8 @@ extern "C" int mir_launch_debug_convex(const float* in, float* out, int n, hipSt
 #ifdef MIR_STEP_CONVEX_TU
 template <int FEAT>
 static void launch_feat(const StepArgs& a, int blocks, int single, int plain_loop, hipStream_t stream) {
-  if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
+  if (a.phase == 1) hipLaunchKernelGGL((mir_step_kernel<3, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
 }
@@ -1567,8 +1643,13 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.poses;
   const bool plain_loop = a.mode == 0 && !a.poses && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
                           !a.env_state && !a.reward && !a.terminated && !a.term_host && !a.done_ticket;
+  if (a.phase == 2) {  // (the second half of a split step has no collision code in it: one instantiation serves every scene)
+    hipLaunchKernelGGL((mir_step_kernel<4, 0>), dim3(blocks), dim3(64), 0, stream, a);
+    return (int)hipGetLastError();
+  }
   if (a.features) return mir_launch_step_convex(&a, single, plain_loop, stream);
-  if (single) hipLaunchKernelGGL((mir_step_kernel<0, 0>), dim3(blocks), dim3(128), 0, stream, a);
+  if (a.phase == 1) hipLaunchKernelGGL((mir_step_kernel<3, 0>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (single) hipLaunchKernelGGL((mir_step_kernel<0, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, 0>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, 0>), dim3(blocks), dim3(64), 0, stream, a);
   return (int)hipGetLastError();
