@@ -497,14 +497,19 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   // split step: if the previous mir_step_begin left the action-independent half of THIS step in `pre` (same stream, nothing
   // touched the state since), only the other half is launched now
   const bool split = h->split_step && h->sync_mode != 2;
-  o.phase = (split && h->pre_valid && h->pre_stream == stream) ? 2 : 0;
+  const bool have_pre = split && h->pre_valid && h->pre_stream == stream;
+  // (one rotated launch -- this step's second half, then the next step's first half -- where the closing FK can be shared between
+  //  the waves; otherwise two launches)
+  const bool rotated = have_pre && h->hm.fk_free_leaf != 0 && h->split_step != 2;
+  o.phase = rotated ? 3 : (have_pre ? 2 : 0);
   int rc = launch(h, o, stream);
   if (rc != MIR_OK) return rc;
+  if (rotated) h->pre_valid = 1;  // (launch() cleared it; the same launch has refilled `pre` for the state it leaves)
   if (h->sync_mode == 1) {
     hipError_t e = hipStreamWriteValue32((hipStream_t)stream, flag_dev, seq, 0);
     if (e != hipSuccess) { (void)hipGetLastError(); h->sync_mode = 0; }  // not supported on this stack: wait on the stream instead
   }
-  if (split) {
+  if (split && !rotated) {
     // ... and the action-independent half of the NEXT step goes out right behind it: it runs while the host is between two calls
     Outs p;
     p.phase = 1; p.diag = false;

@@ -45,7 +45,7 @@ struct StepArgs {
   int features; // bit 0: sphere / capsule geoms (GJK / MPR narrowphase); bit 1: sweep-and-prune broadphase
   // split step (GenesisEnv.step path): `phase` 0 = whole step; 1 = the ACTION-INDEPENDENT half of the coming step only (poses,
   // dynamics, collision, contact arrays, Jacobians, all-rows-active Hessian) written to `pre`; 2 = the rest of the step, read from
-  // `pre`.  `pre`: K16_PRE_STRIDE floats per env.
+  // `pre`.  3 = 2 followed by 1 (of the next step) in one launch.  `pre`: K16_PRE_STRIDE floats per env.
   int phase;
   float* pre;
 };

@@ -32,6 +32,8 @@
 //     packed rows, <2> everything (per-stage outputs, pose refresh, profiling stamps).  Built with -ffp-contract=on so that
 //     they agree bit for bit.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 #include "mir_model.h"
@@ -203,10 +205,16 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 // `pre` buffer instead of staying in LDS; 4 picks them up and runs the rest on one wave.  The host launches 3 for the NEXT step
 // right behind the current step, so that it runs while the host is between two env.step() calls.
 template <int VARIANT, int FEAT>
-__global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir_step_kernel(StepArgs a) {
+__global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3 || VARIANT == 5) ? 128 : 64)
+__attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))) void mir_step_kernel(StepArgs a) {
+  // VARIANT 5 = both halves in one launch, ROTATED: first the action-dependent half of THIS step (from the pre buffer), then the
+  // action-independent half of the NEXT one (into the pre buffer).  The host sees `terminated` after the first half; the second
+  // runs while it is between two env.step() calls, without a second launch, a second prologue or a second forward kinematics
+  // (the closing FK of this step is the opening FK of the next).  Needs the split closing FK (fk_free_leaf scenes).
+  constexpr bool ROT = VARIANT == 5;
   constexpr bool PRE = VARIANT == 3, POST = VARIANT == 4;
-  constexpr bool SINGLE = VARIANT == 0 || PRE || POST;
-  constexpr bool DUAL = VARIANT == 0 || PRE;
+  constexpr bool SINGLE = VARIANT == 0 || PRE || POST || ROT;
+  constexpr bool DUAL = VARIANT == 0 || PRE || ROT;
   static_assert(JST == 52 && K16_PRE_STRIDE >= K16_PRE_JB + JST * MAXCON, "pre-buffer layout");
   constexpr bool CONVEX = (FEAT & 1) != 0, SAP = (FEAT & 2) != 0;
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
@@ -658,7 +666,15 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
       hk.axis = v3(h3.x, h3.y, h3.z);
     };
     const uint64_t hparents = m->parents;
-    {
+    if (ROT) {
+      // rotated launch: this wave's first job is the closing FK of the step the main wave is finishing -- which is the opening
+      // FK of the step whose action-independent half follows
+      BodyK hk;
+      fk_consts(hk);
+      __syncthreads();  // (5) the main wave has integrated the jointed dofs
+      group_fk<true>(S, lane, nb, hparents, hk, row4);
+      __syncthreads();  // (6) link poses of the new state handed to the main wave
+    } else {
       // The collision wave opens the launch with the FORWARD KINEMATICS of the stored state: it needs one row of qpos and four of
       // the twelve quads of lane constants, so its loads are back sooner than the main wave's (which also brings in the model
       // table, the other rows and the action), and the main wave finds the link poses ready when it reaches the first barrier.
@@ -672,7 +688,7 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
       group_fk(S, lane, nb, hparents, hk, row4);
     }
     HSTAMP(40);
-    __syncthreads();  // (1) link poses (this wave) and model table, velocities, targets (main wave) are in LDS
+    if (!ROT) __syncthreads();  // (1) link poses (this wave) and model table, velocities, targets (main wave) are in LDS
     HSTAMP(41);
     const int cnt = collide_detect();
     HSTAMP(42);
@@ -683,7 +699,7 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
     {
       float hp[G];
       hess_full(hp, S.ncon);
-      if (PRE) {
+      if (PRE || ROT) {
         // the action-independent half ends here: contact data, Jacobian rows and the all-active Hessian go to the pre buffer
         if (valid) {
           float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
@@ -749,8 +765,8 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
   // (addresses from the launch arguments only: these loads leave together with the model loads above)
   static_assert(sizeof(((EnvLds*)nullptr)->qpos) / sizeof(float) <= 2 * G, "qpos row: at most two entries per lane");
   // (DUAL: the qpos row is fetched and stored by the collision wave, with the forward kinematics)
-  const float q_lo = (!DUAL && lane < a.qst) ? a.qpos[(size_t)env * a.qst + lane] : 0.0f;
-  const float q_hi = (!DUAL && lane + G < a.qst) ? a.qpos[(size_t)env * a.qst + lane + G] : 0.0f;
+  const float q_lo = ((!DUAL || ROT) && lane < a.qst) ? a.qpos[(size_t)env * a.qst + lane] : 0.0f;
+  const float q_hi = ((!DUAL || ROT) && lane + G < a.qst) ? a.qpos[(size_t)env * a.qst + lane + G] : 0.0f;
   const float qv_in = a.qvel[(size_t)env * G + lane], ws_in = a.qacc_ws[(size_t)env * G + lane];
   // (with an action every controlled dof takes its target from it and nothing else reads a target: the stored row is not fetched)
   float tg = a.action ? 0.0f : a.target[(size_t)env * G + lane];
@@ -762,7 +778,7 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
     for (int k = 0; k < TAB_NPASS; k++)
       if (tid + 64 * k < TAB_NQ) dst[tid + 64 * k] = tabtmp[k];
   }
-  if (!DUAL) {
+  if (!DUAL || ROT) {
     if (lane < a.qst) S.qpos[lane] = q_lo;
     if (lane + G < a.qst) S.qpos[lane + G] = q_hi;
   }
@@ -784,8 +800,9 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
   if (!DUAL && !POST) group_fk(S, lane, nb, parents, bk, row4);
   STAMP(1);
   STAMP(48);
-  if (DUAL) __syncthreads();  // (1) link poses from the collision wave; model table, velocities and targets from this one
-  const int nsteps = SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0));
+  if (DUAL && !ROT) __syncthreads();  // (1) link poses from the collision wave; model table, velocities and targets from this one
+  // (ROT: the loop below runs twice -- pass 0 is the second half of this step, pass 1 the first half of the next one)
+  const int nsteps = ROT ? 2 : (SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0)));
   if (VARIANT != 2) a.poses = nullptr;
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr;
 #ifndef MIR_PROFILE_SINGLE  /* (a profiling build keeps the phase stamps in the single-step instantiation: tools/phase_profile.py) */
@@ -813,15 +830,18 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
   // POST (the second half of a split step): everything the previous launch left in the pre buffer is fetched here, in one batch --
   // the mass-matrix row, the bias force and the all-rows-active Hessian into registers, contact count, coupling flag, row constants
   // and Jacobian rows into the LDS arrays the rest of the step reads
-  f4 pre_m[4] = {}, pre_h[4] = {};
+  f4 pre_m[4] = {};
   float pre_bias = 0.0f;
-  if (POST) {
+  if (POST || ROT) {
     const float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
+    f4 pre_h[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       pre_m[q] = *reinterpret_cast<const f4*>(pre + K16_PRE_MROW + 16 * lane + 4 * q);
       pre_h[q] = *reinterpret_cast<const f4*>(pre + K16_PRE_HP + 16 * lane + 4 * q);
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], pre_h[q]);  // (parked in the M area, idle in this half, until the first Newton iteration)
     pre_bias = pre[K16_PRE_BIAS + lane];
     const f4 head = *reinterpret_cast<const f4*>(pre + K16_PRE_HEAD);
     const int nc = __float_as_int(head.x);
@@ -831,13 +851,90 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
     for (int i = lane; i < nc * (JST / 4); i += G) jdst[i] = *reinterpret_cast<const f4*>(pre + K16_PRE_JB + 4 * i);
     WSYNC();
   }
-  for (int step = 0; step < nsteps; step++) {
+  // ---- what a step hands back: host-visible terminated bytes, state rows, observations (after the step loop; in the rotated
+  // launch after its first pass) -------------------------------------------------------------------------------------------
+  auto emit_outputs = [&]() {
+    STAMP(10);
+    // GenesisEnv.step's D->H copy of `terminated`, done by the kernel and issued FIRST: the four masks of the wave as ONE 32-bit store
+    // straight into pinned host memory (write-through, system scope), each byte = term | tag << 1; its trip over PCIe runs under the
+    // state and observation stores below.  The tag changes from launch to launch, so the host recognises the bytes of THIS launch by
+    // themselves (sync mode 3: no fence, no ticket, nothing waits).
+    const bool term_now = valid && S.xpos[ob][2] > mdl_reward_z;
+    if (VARIANT != 1 && a.term_host && !term_early) {
+      const unsigned long long tb = __ballot(term_now && lane == 0);
+      if (tid == 0) {
+        const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    if (valid) {
+      if (a.poses && lane < nb) {  // (pose refresh for the rasteriser, mode 2 only)
+        float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
+        *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
+        *reinterpret_cast<f4*>(p + 4 * G) = ldv(S.xquat[lane]);
+      }
+      // ---- store state ---------------------------------------------------------------------------------
+      if (a.mode == 0) {
+        for (int i = lane; i < qst; i += G) a.qpos[(size_t)env * qst + i] = S.qpos[i];
+        a.qvel[(size_t)env * G + lane] = S.qvel[lane];
+        a.qacc_ws[(size_t)env * G + lane] = S.qacc_ws[lane];
+      }
+      if (a.action) a.target[(size_t)env * G + lane] = S.target[lane];
+      // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
+      const float rew = term_now ? 1.0f : 0.0f;
+      if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
+      if (a.env_state && lane < 11) a.env_state[(size_t)env * 11 + lane] = column(ad + lane);
+      if (lane == 0) {
+        if (a.reward) a.reward[env] = rew;
+        if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
+      }
+      if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
+      if (a.rows && !(a.ar.episode_len && a.rows_step)) {  // (in rollout mode: the last step's row; with autoreset it was written in the loop)
+        float* row = a.rows + (size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride;
+        for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
+      }
+      if (a.out_xpos && lane < nb) {
+        st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3v(S.xpos[lane]));
+        st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));
+      }
+    }  // valid
+    if (VARIANT != 1 && a.done_ticket) {
+      // Completion published by the kernel itself (mir_step_begin, sync mode 2): every wave waits for its host store to be
+      // acknowledged (~3 us over PCIe), then takes a ticket; the wave that takes the last one knows that every terminated byte of the launch is in
+      // host memory and writes the sequence number the host is spinning on.  (The host-side stores above are system-scope
+      // write-through atomics, so no cache write-back is needed to order them: s_waitcnt is the release.)
+      __builtin_amdgcn_s_waitcnt(0);
+      unsigned old = 0;
+      if (tid == 0) old = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old == gridDim.x - 1 && tid == 0) {
+        __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next launch starts from zero
+        __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    STAMP(25);
+    if (a.prof && threadIdx.x == 0) {  // debug: wall-clock (100 MHz) exit time of block 0 and of the last block
+      const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
+      if ((int)blockIdx.x == prof_blk) a.prof[27] = tnow;
+      if ((blockIdx.x & 7) == (unsigned)(prof_blk & 7)) {  // same XCD as block 0: the realtime counters of different XCDs are not aligned
+        atomicMax(&a.prof[28], tnow);
+        atomicMin(&a.prof[29], tnow);
+      }
+    }
+  };
+  // One step of the loop as a function of the step index: an int in the step-loop instantiations, a compile-time constant in the
+  // rotated launch (pass 0 = second half of this step, pass 1 = first half of the next), whose two calls therefore compile to
+  // straight-line code like the single-step kernel.  Returns 0 to go on, 1 to leave the loop, 2 to leave the kernel.
+  auto step_body = [&](auto stepv) __attribute__((always_inline)) -> int {
+    const int step = stepv;
     // rollout mode (mir_rollout): a fresh action block per step
     if (step > 0 && a.action && a.act_step) {
       if (isdof && d_uadr >= 0) S.target[lane] = a.action[(size_t)step * a.act_step + (size_t)env * a.nu + d_uadr];
     }
+    const bool post_now = POST || (ROT && step == 0), pre_now = PRE || (ROT && step == 1);
     float qfrc_bias = 0.0f, qfs = 0.0f;
-    if (!POST) {
+    if (!post_now) {
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
     if (isdof) {
       V3 ang = v3(0, 0, 0), lin = v3(0, 0, 0);
@@ -1025,16 +1122,16 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
         qfs = -d_damping * qd + fa - qfrc_bias;
       }
     }
-    }  // !POST
+    }  // !post_now
     WSYNC();
     STAMP(3);
     STAMP(49);
-    if (DUAL) __syncthreads();  // (2) this wave is done with the dynamics scratch (M is in its own area, the rest in registers)
+    if (DUAL && !post_now) __syncthreads();  // (2) this wave is done with the dynamics scratch (M is in its own area, the rest in registers)
     // qacc_smooth = Mt^-1 qfrc_smooth: Gauss-Jordan on register rows
     float mrow[G];
     {
       f4 r0, r1, r2, r3;
-      if (POST) {
+      if (post_now) {
         // the action-independent half of this step was computed by the previous launch (VARIANT 3): mass-matrix row and bias force
         // from the pre buffer, then the smooth force with THIS launch's targets (the expressions of the fused kernel)
         r0 = pre_m[0]; r1 = pre_m[1]; r2 = pre_m[2]; r3 = pre_m[3];
@@ -1053,14 +1150,14 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
       } else {
         r0 = ldv(&S.M[lane][0]); r1 = ldv(&S.M[lane][4]); r2 = ldv(&S.M[lane][8]); r3 = ldv(&S.M[lane][12]);
       }
-      if (PRE) {
+      if (pre_now) {
         if (valid) {
           float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
           *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane) = r0; *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 4) = r1;
           *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 8) = r2; *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 12) = r3;
           pre[K16_PRE_BIAS + lane] = qfrc_bias;
         }
-        return;
+        return 2;
       }
       mrow[0] = r0.x; mrow[1] = r0.y; mrow[2] = r0.z; mrow[3] = r0.w; mrow[4] = r1.x; mrow[5] = r1.y; mrow[6] = r1.z; mrow[7] = r1.w;
       mrow[8] = r2.x; mrow[9] = r2.y; mrow[10] = r2.z; mrow[11] = r2.w; mrow[12] = r3.x; mrow[13] = r3.y; mrow[14] = r3.z; mrow[15] = r3.w;
@@ -1109,7 +1206,7 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
     }
     WSYNC();
     STAMP(50);
-    if (DUAL) __syncthreads();  // (3) contact arrays and base Jacobians are in LDS
+    if (DUAL && !post_now) __syncthreads();  // (3) contact arrays and base Jacobians are in LDS
     STAMP(52);
     const int ncon = S.ncon;
     // contact rows, lane = contact, lane-private: aref_r = -b (J_r qvel) - k imp dist
@@ -1239,7 +1336,7 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
       if (!__any(!done)) break;
       if (it == 0) {  // start from Mt + the all-rows-active J^T D J (from the collision wave where there is one)
         float hp[G];
-        if (DUAL) {
+        if (DUAL && !post_now) {
           STAMP(51);
           __syncthreads();  // (4)
           STAMP(53);
@@ -1249,9 +1346,12 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
             const f4 v = ldv(&S.M[lane][4 * q]);
             hp[4 * q] = v.x; hp[4 * q + 1] = v.y; hp[4 * q + 2] = v.z; hp[4 * q + 3] = v.w;
           }
-        } else if (POST) {
+        } else if (post_now) {
 #pragma unroll
-          for (int q = 0; q < 4; q++) { hp[4 * q] = pre_h[q].x; hp[4 * q + 1] = pre_h[q].y; hp[4 * q + 2] = pre_h[q].z; hp[4 * q + 3] = pre_h[q].w; }
+          for (int q = 0; q < 4; q++) {
+            const f4 v = ldv(&S.M[lane][4 * q]);
+            hp[4 * q] = v.x; hp[4 * q + 1] = v.y; hp[4 * q + 2] = v.z; hp[4 * q + 3] = v.w;
+          }
         } else {
           hess_full(hp, ncon);
         }
@@ -1406,7 +1506,7 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
       if (it == 0) STAMP(21);
       ITSTAMP(it, 7);
     }
-    if (DUAL && !met4) __syncthreads();  // (4) (no Hessian was needed: the collision wave is let go)
+    if (DUAL && !post_now && !met4) __syncthreads();  // (4) (no Hessian was needed: the collision wave is let go)
     if (a.out_qacc && valid && isdof && step == 0) a.out_qacc[(size_t)env * nv + lane] = qacc;
     if (a.diag && valid && lane == 0) {
       a.diag[(size_t)env * 4 + 0] = ncon;
@@ -1415,7 +1515,7 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
       a.diag[(size_t)env * 4 + 3] = S.ncand;
     }
     STAMP(8);
-    if (a.mode != 0) break;
+    if (a.mode != 0) return 1;
 
     // ======================= integrate ==============================================================
     WSYNC();
@@ -1510,74 +1610,18 @@ __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3) ? 128 : 64) void mir
       WSYNC();
       if (__any(done)) group_fk(S, lane, nb, parents, bk, row4);
     }
-  }  // steps
-  STAMP(10);
-  // GenesisEnv.step's D->H copy of `terminated`, done by the kernel and issued FIRST: the four masks of the wave as ONE 32-bit store
-  // straight into pinned host memory (write-through, system scope), each byte = term | tag << 1; its trip over PCIe runs under the
-  // state and observation stores below.  The tag changes from launch to launch, so the host recognises the bytes of THIS launch by
-  // themselves (sync mode 3: no fence, no ticket, nothing waits).
-  const bool term_now = valid && S.xpos[ob][2] > mdl_reward_z;
-  if (VARIANT != 1 && a.term_host && !term_early) {
-    const unsigned long long tb = __ballot(term_now && lane == 0);
-    if (tid == 0) {
-      const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
-      __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
+    if (ROT && step == 0) emit_outputs();
+    return 0;
+  };  // step_body
+  if constexpr (ROT) {
+    if (step_body(std::integral_constant<int, 0>{}) == 0) step_body(std::integral_constant<int, 1>{});
+  } else {
+    for (int step = 0; step < nsteps; step++) {
+      const int r = step_body(step);
+      if (r == 2) return;
+      if (r == 1) break;
     }
-  }
-  if (valid) {
-    if (a.poses && lane < nb) {  // (pose refresh for the rasteriser, mode 2 only)
-      float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
-      *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
-      *reinterpret_cast<f4*>(p + 4 * G) = ldv(S.xquat[lane]);
-    }
-    // ---- store state ---------------------------------------------------------------------------------
-    if (a.mode == 0) {
-      for (int i = lane; i < qst; i += G) a.qpos[(size_t)env * qst + i] = S.qpos[i];
-      a.qvel[(size_t)env * G + lane] = S.qvel[lane];
-      a.qacc_ws[(size_t)env * G + lane] = S.qacc_ws[lane];
-    }
-    if (a.action) a.target[(size_t)env * G + lane] = S.target[lane];
-    // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
-    const float rew = term_now ? 1.0f : 0.0f;
-    if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
-    if (a.env_state && lane < 11) a.env_state[(size_t)env * 11 + lane] = column(ad + lane);
-    if (lane == 0) {
-      if (a.reward) a.reward[env] = rew;
-      if (a.terminated) a.terminated[env] = rew == 1.0f ? 1 : 0;
-    }
-    if (a.ar.episode_len && lane == 0) { a.ar.episode_len[env] = eplen; a.ar.cursor[env] = epcur; }
-    if (a.rows && !(a.ar.episode_len && a.rows_step)) {  // (in rollout mode: the last step's row; with autoreset it was written in the loop)
-      float* row = a.rows + (size_t)(a.rows_step ? (nsteps > 0 ? nsteps - 1 : 0) : 0) * a.rows_step + (size_t)env * a.row_stride;
-      for (int c = lane; c < ad + 13; c += G) row[c] = column(c);
-    }
-    if (a.out_xpos && lane < nb) {
-      st3(&a.out_xpos[((size_t)env * nb + lane) * 3], ld3v(S.xpos[lane]));
-      st4(&a.out_xquat[((size_t)env * nb + lane) * 4], ld4v(S.xquat[lane]));
-    }
-  }  // valid
-  if (VARIANT != 1 && a.done_ticket) {
-    // Completion published by the kernel itself (mir_step_begin, sync mode 2): every wave waits for its host store to be
-    // acknowledged (~3 us over PCIe), then takes a ticket; the wave that takes the last one knows that every terminated byte of the launch is in
-    // host memory and writes the sequence number the host is spinning on.  (The host-side stores above are system-scope
-    // write-through atomics, so no cache write-back is needed to order them: s_waitcnt is the release.)
-    __builtin_amdgcn_s_waitcnt(0);
-    unsigned old = 0;
-    if (tid == 0) old = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old == gridDim.x - 1 && tid == 0) {
-      __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next launch starts from zero
-      __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  STAMP(25);
-  if (a.prof && threadIdx.x == 0) {  // debug: wall-clock (100 MHz) exit time of block 0 and of the last block
-    const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
-    if ((int)blockIdx.x == prof_blk) a.prof[27] = tnow;
-    if ((blockIdx.x & 7) == (unsigned)(prof_blk & 7)) {  // same XCD as block 0: the realtime counters of different XCDs are not aligned
-      atomicMax(&a.prof[28], tnow);
-      atomicMin(&a.prof[29], tnow);
-    }
+    emit_outputs();
   }
 }
 
@@ -1617,6 +1661,7 @@ extern "C" int mir_launch_debug_convex(const float* in, float* out, int n, hipSt
 template <int FEAT>
 static void launch_feat(const StepArgs& a, int blocks, int single, int plain_loop, hipStream_t stream) {
   if (a.phase == 1) hipLaunchKernelGGL((mir_step_kernel<3, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 3) hipLaunchKernelGGL((mir_step_kernel<5, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
@@ -1649,6 +1694,7 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   }
   if (a.features) return mir_launch_step_convex(&a, single, plain_loop, stream);
   if (a.phase == 1) hipLaunchKernelGGL((mir_step_kernel<3, 0>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 3) hipLaunchKernelGGL((mir_step_kernel<5, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, 0>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, 0>), dim3(blocks), dim3(64), 0, stream, a);

@@ -120,3 +120,63 @@ def test_two_wave_kernels_with_a_solver_that_never_or_once_iterates(which, itera
         assert torch.equal(rows1, rowsK)
     assert all(torch.equal(a, b) for a, b in zip(sc.get_state(), sr.get_state()))
     assert int(sc.get_diag()[2].max()) <= iterations
+
+
+@pytest.mark.parametrize("split", ["0", "1", "2"])
+def test_split_step_survives_everything_that_touches_the_state_between_two_steps(franka_spec, monkeypatch, split):
+    """GenesisEnv.step's launch leaves the action-independent half of the NEXT step behind (MIR_SPLIT_STEP: 1 = one rotated launch,
+    2 = two launches, 0 = off).  That half is only valid for the state the launch left: a reset (whole batch or masked), a state
+    write, a plain step, a K-step rollout, a render or a kinematics query in between must either keep it valid or make the next
+    step fall back to the fused launch.  300 steps with all of those mixed in, against a twin scene that only ever runs fused
+    launches: every output and the final state bit-identical."""
+    from gym_genesis.backend.lib import MirScene
+    from gym_genesis.backend.spec import make_camera
+
+    B = 64
+    monkeypatch.setenv("MIR_SPLIT_STEP", split)
+    sc = MirScene(franka_spec, B)
+    monkeypatch.setenv("MIR_SPLIT_STEP", "0")
+    ref = MirScene(franka_spec, B)
+    _reset(sc, B)
+    _reset(ref, B)
+    g = np.random.default_rng(11)
+    acts = torch.as_tensor(g.uniform(-1, 1, (300, B, 9)).astype(np.float32), device=sc.device)
+    b1 = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    b2 = (ref.empty(9), ref.empty(11), ref.empty(), ref.empty(dtype=torch.uint8))
+    rows = torch.zeros((4, B, 22), device=sc.device)
+    cam = make_camera(32, 24, (3.5, 0, 2.5), (0, 0, 0.5), 30)
+    vis = models.franka_cube_pick_scene().visual()
+    for t in range(300):
+        k = t % 37
+        if k == 5:      # reset of the whole batch
+            _reset(sc, B, seed=t); _reset(ref, B, seed=t)
+        elif k == 11:   # masked reset
+            mask = torch.as_tensor(g.integers(0, 2, B).astype(np.uint8), device=sc.device)
+            pos = np.stack([g.uniform(.45, .8, B), g.uniform(-.25, .25, B), np.full(B, .02)], 1).astype(np.float32)
+            quat = np.tile(np.array([1, 0, 0, 0], np.float32), (B, 1)); home = np.tile(np.array(models.FRANKA_HOME, np.float32), (B, 1))
+            for s in (sc, ref):
+                s.reset(pos, quat, home, env_mask=mask)
+        elif k == 17:   # state written back (qvel perturbed)
+            q, v, tg, ws = sc.get_state()
+            for s in (sc, ref):
+                s.set_state(qpos=q, qvel=v * 0.5, target=tg, warmstart=ws)
+        elif k == 21:   # a plain fused step and a rollout in between
+            for s, b in ((sc, b1), (ref, b2)):
+                s.step_fused(acts[t], *b)
+                s.rollout(acts[t:t + 4].contiguous() if t + 4 <= 300 else acts[:4].contiguous(), rows)
+        elif k == 27:   # read-only visitors: image, link poses, observation
+            sc.render(cam, vis); sc.get_links(); sc.get_obs()
+        elif k == 31:   # PD targets set from outside, then a step without an action
+            for s in (sc, ref):
+                s.set_pd_targets(acts[t] * 0.3)
+            sc.step_begin(None, *b1); h = sc.step_end()
+            ref.step_fused(None, *b2)
+            assert np.array_equal(h, b2[3].cpu().numpy().astype(bool))
+        sc.step_begin(acts[t], *b1)
+        host = sc.step_end()
+        ref.step_fused(acts[t], *b2)
+        assert np.array_equal(host, b2[3].cpu().numpy().astype(bool)), f"step {t}"
+        for x, y in zip(b1, b2):
+            assert torch.equal(x, y), f"step {t}"
+    for x, y in zip(sc.get_state(), ref.get_state()):
+        assert torch.equal(x, y)
