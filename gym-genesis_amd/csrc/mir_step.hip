@@ -1615,6 +1615,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   };  // step_body
   if constexpr (ROT) {
     if (step_body(std::integral_constant<int, 0>{}) == 0) step_body(std::integral_constant<int, 1>{});
+  } else if constexpr (SINGLE) {
+    if (step_body(std::integral_constant<int, 0>{}) == 2) return;
+    emit_outputs();
   } else {
     for (int step = 0; step < nsteps; step++) {
       const int r = step_body(step);
