@@ -599,7 +599,7 @@ def worker(args) -> int:
                        "world_size_observed": pg_world, "dist_backend": args.dist_backend if use_pg else None,
                        "obs_gather": (f"{args.dist_backend} all_gather of [agent_pos|environment_state|reward] of {S} steps per collective, "
                                       "overlapped with the following steps") if gather else "none",
-                       "terminated_sync_mode": task._mir.sync_mode},
+                       "terminated_sync_mode": task._mir.sync_mode, "split_step": int(getattr(task._mir, "split_step", 0))},
             "repeats": len(walls),
             "timed_steps_total": len(walls) * K,
             "timed_seconds_total": total_wall,
@@ -629,11 +629,41 @@ def worker(args) -> int:
                                                   "cannot be queued behind the running one: each step pays launch + dispatch + completion latency (the kernel stores the terminated bytes as soon as the object's height is integrated, ~1.5 us before it ends, so the measured step can come in slightly under kernel + round trip)"}
             except Exception as e:  # noqa: BLE001
                 out["sync_step_floor"] = {"error": f"{type(e).__name__}: {e}"}
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": _profile_number("pmc_hbm_traffic.json", "hbm_bytes_per_launch") if B == ENVS_PER_GPU else None,
-                               "kernel": "mir_step_kernel<0, true>", "kernel_us": kernel_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
-                               "note": "489 algorithmic B/env-step x 4096 envs per launch (SURVEY.md 8d); kernel_us = HIP events over the "
-                                       "back-to-back raw launches of the same K-step region; the path is latency/occupancy-bound, not HBM-bound"}
+            fused = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": _profile_number("pmc_hbm_traffic.json", "hbm_bytes_per_launch") if B == ENVS_PER_GPU else None,
+                     "kernel": "mir_step_kernel<0, true>", "kernel_us": kernel_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
+                     "note": "489 algorithmic B/env-step x 4096 envs per launch (SURVEY.md 8d); kernel_us = HIP events over the "
+                             "back-to-back raw launches of the same K-step region; the path is latency/occupancy-bound, not HBM-bound"}
+            out["roofline"] = fused
+            # The launches of the HEADLINE loop are a different instantiation when the split step is on (mir_get_split_step): the
+            # rotated kernel, second half of this step + first half of the next.  Its duration: HIP events on the launching stream
+            # around every launch of a begin / end loop of its own (the timed loop itself carries no events).
+            split = int(getattr(task._mir, "split_step", 0))
+            if split == 1 and api_walls is not None:
+                try:
+                    mir = task._mir
+                    task.reset()
+                    mir.rotated_launches(actions, 50)
+                    torch.cuda.synchronize(dev)
+                    n_ev = 1000
+                    e0, e1 = _events(torch)
+                    e0.record()
+                    mir.rotated_launches(actions, n_ev)
+                    e1.record()
+                    torch.cuda.synchronize(dev)
+                    rot_us = e0.elapsed_time(e1) * 1e3 / n_ev
+                    ach = ALGO_BYTES_PER_ENV_STEP * B / (rot_us * 1e-6) / 1e9
+                    out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                       "traffic": _profile_number("pmc_hbm_traffic_api.json", "hbm_bytes_per_launch") if B == ENVS_PER_GPU else None,
+                                       "kernel": "mir_step_kernel<5, true>", "kernel_us": rot_us,
+                                       "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
+                                       "note": "the kernel of the headline loop: the rotated launch of GenesisEnv.step (this step's action-dependent "
+                                               "half, then the next step's action-independent half through a 5.8 KB/env scratch row, which is why its "
+                                               "traffic is several times the 489 algorithmic B/env-step: bytes spent to take ~8 us of work out of the "
+                                               "host-visible latency); kernel_us = HIP events around 1000 back-to-back launches (mir_debug_rotated_launches), launch gap included"}
+                    out["roofline_fused_launch"] = fused
+                except Exception as e:  # noqa: BLE001
+                    out["roofline_api_kernel_error"] = f"{type(e).__name__}: {e}"
         except Exception as e:  # noqa: BLE001
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
             rc = 1

@@ -284,7 +284,7 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   if (const char* e = getenv("MIR_SYNC_MODE")) h->sync_mode = atoi(e);
   if (h->sync_mode < 0 || h->sync_mode > 3 || (h->sync_mode == 2 && h->kernel != 16)) h->sync_mode = 3;
   h->split_step = h->kernel == 16 ? 1 : 0;
-  if (const char* e = getenv("MIR_SPLIT_STEP")) h->split_step = (atoi(e) != 0 && h->kernel == 16) ? 1 : 0;
+  if (const char* e = getenv("MIR_SPLIT_STEP")) h->split_step = h->kernel == 16 ? (atoi(e) == 2 ? 2 : (atoi(e) != 0 ? 1 : 0)) : 0;
   h->pre_valid = 0;
   return MIR_OK;
 }
@@ -604,6 +604,32 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
 }
 
 int mir_get_sync_mode(MirHandle h) { return check(h) ? MIR_E_INVALID : h->sync_mode; }
+/* debug aid (bench.py's roofline): n back-to-back launches of the rotated step kernel (what mir_step_begin launches in split mode 1)
+ * cycling through n_actions action blocks of (B, nu) and without observation outputs, so that two events around the call time that kernel the way the fused one is
+ * timed.  Advances the state by n steps. */
+extern "C" int mir_debug_rotated_launches(MirHandle h, const float* actions, int32_t n_actions, int32_t n, void* stream) {
+  if (check(h)) return MIR_E_INVALID;
+  if (h->kernel != 16 || h->split_step != 1 || !h->hm.fk_free_leaf) return set_err(MIR_E_INVALID, "mir_debug_rotated_launches: the scene does not use rotated launches");
+  DeviceGuard guard(h->device);
+  if (!(h->pre_valid && h->pre_stream == stream)) {
+    Outs f; f.action = actions; f.diag = false;
+    int rc = launch(h, f, stream);
+    if (rc != MIR_OK) return rc;
+    Outs p; p.phase = 1; p.diag = false;
+    rc = launch(h, p, stream);
+    if (rc != MIR_OK) return rc;
+  }
+  for (int i = 0; i < n; i++) {
+    Outs o; o.action = actions + (size_t)(i % (n_actions > 0 ? n_actions : 1)) * h->B * h->nu; o.diag = false; o.phase = 3;
+    int rc = launch(h, o, stream);
+    if (rc != MIR_OK) return rc;
+  }
+  h->pre_valid = 1;
+  h->pre_stream = stream;
+  return MIR_OK;
+}
+
+int mir_get_split_step(MirHandle h) { return check(h) ? MIR_E_INVALID : (h->sync_mode == 2 ? 0 : h->split_step); }
 
 int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream) {
   if (check(h) || !rows) return set_err(MIR_E_INVALID, "mir_step_packed: null argument");

@@ -57,6 +57,10 @@ def load_library() -> C.CDLL:
     lib.mir_step_go.restype = C.c_int
     lib.mir_get_sync_mode.argtypes = [vp]
     lib.mir_get_sync_mode.restype = C.c_int
+    lib.mir_debug_rotated_launches.argtypes = [vp, vp, i32, i32, vp]
+    lib.mir_debug_rotated_launches.restype = C.c_int
+    lib.mir_get_split_step.argtypes = [vp]
+    lib.mir_get_split_step.restype = C.c_int
     lib.mir_debug_null_roundtrip.argtypes = [vp, i32, vp, C.POINTER(C.c_double)]
     lib.mir_debug_null_roundtrip.restype = C.c_int
     lib.mir_step_packed.argtypes = [vp, vp, vp, i32, vp]
@@ -320,6 +324,15 @@ class MirScene(StepHelpers):
     @property
     def sync_mode(self) -> int:
         return int(self.lib.mir_get_sync_mode(self.h))
+
+    def rotated_launches(self, actions: torch.Tensor, n: int) -> None:
+        """mir_debug_rotated_launches: n back-to-back rotated launches cycling through actions (K,B,nu) (bench.py times them)."""
+        self._check(self.lib.mir_debug_rotated_launches(self.h, _ptr(actions), int(actions.shape[0]), int(n), self._stream()))
+
+    @property
+    def split_step(self) -> int:
+        """How step_begin launches (mir_get_split_step): 1 rotated, 2 two launches, 0 fused."""
+        return int(self.lib.mir_get_split_step(self.h))
 
     def step_packed(self, action, rows: torch.Tensor) -> None:
         """One step; all outputs in one (B, row_stride) float32 row tensor (see mir_step_packed)."""

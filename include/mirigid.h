@@ -244,6 +244,15 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
                    uint8_t* terminated, void* stream);
 int mir_step_end(MirHandle h, uint8_t* terminated_host);
 int mir_get_sync_mode(MirHandle h);
+/* How mir_step_begin launches (16-lane kernel; environment variable MIR_SPLIT_STEP overrides at mir_create):
+ *   1  (default) ROTATED: a step's launch runs the action-dependent half of THIS step (smooth force with the new targets, solves,
+ *      integration, terminated bytes, observations) and then the action-independent half of the NEXT step (poses, dynamics, collision
+ *      detection, contact Jacobians) into a scratch buffer of the handle -- work that so runs while the host is between two calls.
+ *      Bit-identical to the fused launch.  Whatever touches the state in between (reset, state write, any other step entry point)
+ *      makes the next mir_step_begin start over with a fused launch.
+ *   2  the same split as two launches (also the fallback where a scene's closing forward kinematics cannot be shared by the waves)
+ *   0  one fused launch per step (the wave kernel always) */
+int mir_get_split_step(MirHandle h);
 /* mir_step_begin with the four output pointers registered ahead of time (mir_step_prepare touches no device state and is meant to
  * be called while the previous step's kernel is still running): the GPU idles in front of mir_step_go, which then takes three
  * arguments instead of seven.  One mir_step_prepare per mir_step_go. */
@@ -373,6 +382,10 @@ int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_p
  * lane): a known byte count against which rocprofv3's FETCH_SIZE / WRITE_SIZE are calibrated for this access width. */
 int mir_debug_profile_step(MirHandle h, unsigned long long* prof, void* stream);
 int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* out_us);
+/* n back-to-back launches of the rotated step kernel (split mode 1), cycling through n_actions (B, nu) action blocks, without
+ * observation outputs: lets two events time that kernel the way the fused one is timed (bench.py's roofline).  Advances the state by
+ * n steps. */
+int mir_debug_rotated_launches(MirHandle h, const float* actions, int32_t n_actions, int32_t n, void* stream);
 int mir_debug_poison_lds(int device_id, void* stream);
 int mir_debug_copy_rows(const float* src, float* dst, int64_t n_floats, int device_id, void* stream);
 /* the kernels' convex narrowphase on n pairs given directly (device arrays): in (n,22) = type1, size1[3], pos1[3], quat1[4] wxyz,

@@ -17,12 +17,16 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- py
 # (4) the same two counters on a copy of known size with the same access width
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_cfetch -- python3 $R/tools/traffic_calib.py > $R/gpurun_out/pmc_cfetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_cwrite -- python3 $R/tools/traffic_calib.py > $R/gpurun_out/pmc_cwrite.log 2>&1
+# (5) the same two counters over the API loop: its launches are the rotated kernel (second half of this step + first half of the next)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_afetch -- python3 $R/bench.py --steps 200 --warmup 10 --min-time 0 --core-only > $R/gpurun_out/pmc_afetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_awrite -- python3 $R/bench.py --steps 200 --warmup 10 --min-time 0 --core-only > $R/gpurun_out/pmc_awrite.log 2>&1
 cd $R
 python3 tools/summarise_pmc.py gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_cfetch gpurun_out/prof_cwrite > gpurun_out/pmc_hbm_traffic.json 2> gpurun_out/pmc_summary.err
+MIR_PMC_KERNEL="mir_step_kernel<5" python3 tools/summarise_pmc.py gpurun_out/prof_afetch gpurun_out/prof_awrite gpurun_out/prof_cfetch gpurun_out/prof_cwrite > gpurun_out/pmc_hbm_traffic_api.json 2>> gpurun_out/pmc_summary.err
 find gpurun_out/prof_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/bench_kernel_stats.csv \;
 find gpurun_out/prof_trace_raw -name "*kernel_stats.csv" -exec cp {} gpurun_out/bench_raw_kernel_stats.csv \;
 # raw counter dumps are large: keep only the summaries
-rm -rf gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_cfetch gpurun_out/prof_cwrite
+rm -rf gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_cfetch gpurun_out/prof_cwrite gpurun_out/prof_afetch gpurun_out/prof_awrite
 find gpurun_out/prof_trace gpurun_out/prof_trace_raw -name "*kernel_trace.csv" -delete
 cat gpurun_out/pmc_hbm_traffic.json
 head -5 gpurun_out/bench_kernel_stats.csv gpurun_out/bench_raw_kernel_stats.csv

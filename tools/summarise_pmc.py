@@ -31,9 +31,10 @@ def per_launch(d, counter, kernel):
 
 
 def main():
-    fetch = per_launch(sys.argv[1], "FETCH_SIZE", "mir_step_kernel")
-    write = per_launch(sys.argv[2], "WRITE_SIZE", "mir_step_kernel")
-    out = {"FETCH_SIZE": fetch, "WRITE_SIZE": write, "kernel": "mir_step_kernel<0>", "grid": "1024 workgroups x 64 threads (B=4096)",
+    kname = os.environ.get("MIR_PMC_KERNEL", "mir_step_kernel<0")  # e.g. "mir_step_kernel<5" = the rotated launch of the API path
+    fetch = per_launch(sys.argv[1], "FETCH_SIZE", kname)
+    write = per_launch(sys.argv[2], "WRITE_SIZE", kname)
+    out = {"FETCH_SIZE": fetch, "WRITE_SIZE": write, "kernel": kname, "grid": "1024 workgroups x 64 threads (B=4096)",
            "algorithmic_bytes_per_launch": ALGO_BYTES}
     raw = 1024.0 * (fetch["median_KB_per_launch"] + write["median_KB_per_launch"])
     out["hbm_bytes_per_launch_uncorrected"] = raw

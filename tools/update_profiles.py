@@ -11,8 +11,9 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
 dst = os.path.join(R, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 src = os.path.join(R, "gpurun_out")
-for name in ("pmc_hbm_traffic.json",):
-    shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+for name in ("pmc_hbm_traffic.json", "pmc_hbm_traffic_api.json"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 for name in ("bench_kernel_stats.csv", "bench_raw_kernel_stats.csv"):
     rows = list(csv.reader(open(os.path.join(src, name))))
     for r in rows:
