@@ -697,15 +697,12 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     __syncthreads();  // (3) contact arrays and base Jacobians handed to the main wave
     HSTAMP(46);
     {
-      float hp[G];
-      hess_full(hp, S.ncon);
       if (PRE || ROT) {
-        // the action-independent half ends here: contact data, Jacobian rows and the all-active Hessian go to the pre buffer
+        // the action-independent half ends here: contact data and Jacobian rows go to the pre buffer (the all-active Hessian is
+        // accumulated and stored by the main wave meanwhile: it has nothing else left to do)
         if (valid) {
           float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
           const int nc = S.ncon;
-#pragma unroll
-          for (int q = 0; q < 4; q++) *reinterpret_cast<f4*>(pre + K16_PRE_HP + 16 * lane + 4 * q) = f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]};
           if (lane == 0) *reinterpret_cast<f4*>(pre + K16_PRE_HEAD) = f4{__int_as_float(nc), __int_as_float(S.coupled), 0.0f, 0.0f};
           if (lane < nc) *reinterpret_cast<f4*>(pre + K16_PRE_CMETA + 4 * lane) = ldv(S.con.cmeta[lane]);
           const f4* jsrc = reinterpret_cast<const f4*>(&S.Jb[0][0]);
@@ -713,6 +710,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         }
         return;
       }
+      float hp[G];
+      hess_full(hp, S.ncon);
 #pragma unroll
       for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]});
     }
@@ -1156,6 +1155,16 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
           *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane) = r0; *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 4) = r1;
           *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 8) = r2; *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 12) = r3;
           pre[K16_PRE_BIAS + lane] = qfrc_bias;
+        }
+        __syncthreads();  // (3) contact arrays and Jacobian rows of the coming step are in LDS
+        {
+          float hp[G];
+          hess_full(hp, S.ncon);
+          if (valid) {
+            float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
+#pragma unroll
+            for (int q = 0; q < 4; q++) *reinterpret_cast<f4*>(pre + K16_PRE_HP + 16 * lane + 4 * q) = f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]};
+          }
         }
         return 2;
       }
