@@ -514,6 +514,39 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   // ---- contact arrays and base Jacobians from the staging area (`mycount` = this lane's point count, lane = candidate): ordered
   // compaction, per-contact frames / impedance / references, then the contact Jacobian columns (lane = dof).  Needs the staging
   // area, the link poses, the motion subspaces and the model table; writes `con` (over the dead dynamics scratch) and `Jb`.
+  // ======================= constraint rows ======================================================
+  // contact base Jacobians: lane = dof; Jb[c][r*16 + i], r = normal, t1, t2
+  // (two contacts per trip, every read of both issued in one batch ahead of the arithmetic; a dof that moves neither
+  // body ends with sgn = 0, so there is no divergent branch around the reads)
+  auto jac_build = [&](int first, int stride) {
+    const int ncon = S.ncon;
+    const V3 cd_ang = ld3v(&S.cdof[lane][0]), cd_lin = ld3v(&S.cdof[lane][4]);
+    for (int c0 = first; c0 < ncon; c0 += stride) {
+      const int cA = c0, cB = c0 + 1 < ncon ? c0 + 1 : c0;
+      const f4 mkA = ldv(reinterpret_cast<const float*>(S.con.cmask[cA])), mkB = ldv(reinterpret_cast<const float*>(S.con.cmask[cB]));
+      const f4 cpA = ldv(S.con.cpos[cA]), r1A = ldv(&S.con.cref[cA][0]), r2A = ldv(&S.con.cref[cA][4]);
+      const f4 cpB = ldv(S.con.cpos[cB]), r1B = ldv(&S.con.cref[cB][0]), r2B = ldv(&S.con.cref[cB][4]);
+      const f4 fnA = ldv(&S.con.cfrm[cA][0]), f1A = ldv(&S.con.cfrm[cA][4]), f2A = ldv(&S.con.cfrm[cA][8]);
+      const f4 fnB = ldv(&S.con.cfrm[cB][0]), f1B = ldv(&S.con.cfrm[cB][4]), f2B = ldv(&S.con.cfrm[cB][8]);
+      __builtin_amdgcn_sched_barrier(0);
+#define MIR_JCOL(mk, cp, r1, r2, fn, f1, f2, cc)                                                              \
+      {                                                                                                     \
+        const uint32_t dm1 = __float_as_uint(mk.x), dm2 = __float_as_uint(mk.y);                            \
+        const bool in2 = dm2 >> lane & 1u, in1 = dm1 >> lane & 1u;                                          \
+        const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f); /* a dof moving both bodies cancels */ \
+        const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));            \
+        const V3 vel = cross(cd_ang, r) + cd_lin;                                                           \
+        float* jb = &S.Jb[cc][0];                                                                           \
+        /* (selects, not products: a lane that carries no dof holds stale LDS in cd_ang / cd_lin, and 0 x NaN is NaN) */ \
+        jb[lane] = sgn != 0.0f ? sgn * dot(vel, v3(fn.x, fn.y, fn.z)) : 0.0f;                               \
+        jb[16 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f1.x, f1.y, f1.z)) : 0.0f;                          \
+        jb[32 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f2.x, f2.y, f2.z)) : 0.0f;                          \
+      }
+      MIR_JCOL(mkA, cpA, r1A, r2A, fnA, f1A, f2A, cA)
+      if (c0 + 1 < ncon) MIR_JCOL(mkB, cpB, r1B, r2B, fnB, f1B, f2B, cB)
+#undef MIR_JCOL
+    }
+  };
   auto contacts_build = [&](int mycount) {
   STAMP(13);
   // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
@@ -591,41 +624,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     }
   }
   WSYNC();  // col scratch is dead from here on (Jb may overwrite it)
-  const int ncon = S.ncon;
   STAMP(5);
-
-  // ======================= constraint rows ======================================================
-  // contact base Jacobians: lane = dof; Jb[c][r*16 + i], r = normal, t1, t2
-  // (two contacts per trip, every read of both issued in one batch ahead of the arithmetic; a dof that moves neither
-  // body ends with sgn = 0, so there is no divergent branch around the reads)
-  {
-    const V3 cd_ang = ld3v(&S.cdof[lane][0]), cd_lin = ld3v(&S.cdof[lane][4]);
-    for (int c0 = 0; c0 < ncon; c0 += 2) {
-      const int cA = c0, cB = c0 + 1 < ncon ? c0 + 1 : c0;
-      const f4 mkA = ldv(reinterpret_cast<const float*>(S.con.cmask[cA])), mkB = ldv(reinterpret_cast<const float*>(S.con.cmask[cB]));
-      const f4 cpA = ldv(S.con.cpos[cA]), r1A = ldv(&S.con.cref[cA][0]), r2A = ldv(&S.con.cref[cA][4]);
-      const f4 cpB = ldv(S.con.cpos[cB]), r1B = ldv(&S.con.cref[cB][0]), r2B = ldv(&S.con.cref[cB][4]);
-      const f4 fnA = ldv(&S.con.cfrm[cA][0]), f1A = ldv(&S.con.cfrm[cA][4]), f2A = ldv(&S.con.cfrm[cA][8]);
-      const f4 fnB = ldv(&S.con.cfrm[cB][0]), f1B = ldv(&S.con.cfrm[cB][4]), f2B = ldv(&S.con.cfrm[cB][8]);
-      __builtin_amdgcn_sched_barrier(0);
-#define MIR_JCOL(mk, cp, r1, r2, fn, f1, f2, cc)                                                              \
-      {                                                                                                     \
-        const uint32_t dm1 = __float_as_uint(mk.x), dm2 = __float_as_uint(mk.y);                            \
-        const bool in2 = dm2 >> lane & 1u, in1 = dm1 >> lane & 1u;                                          \
-        const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f); /* a dof moving both bodies cancels */ \
-        const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));            \
-        const V3 vel = cross(cd_ang, r) + cd_lin;                                                           \
-        float* jb = &S.Jb[cc][0];                                                                           \
-        /* (selects, not products: a lane that carries no dof holds stale LDS in cd_ang / cd_lin, and 0 x NaN is NaN) */ \
-        jb[lane] = sgn != 0.0f ? sgn * dot(vel, v3(fn.x, fn.y, fn.z)) : 0.0f;                               \
-        jb[16 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f1.x, f1.y, f1.z)) : 0.0f;                          \
-        jb[32 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f2.x, f2.y, f2.z)) : 0.0f;                          \
-      }
-      MIR_JCOL(mkA, cpA, r1A, r2A, fnA, f1A, f2A, cA)
-      if (c0 + 1 < ncon) MIR_JCOL(mkB, cpB, r1B, r2B, fnB, f1B, f2B, cB)
-#undef MIR_JCOL
-    }
-  }
+  // (where this half is all the launch has left to do -- the pre half of a split step -- the main wave takes every other pair
+  //  of contacts of the Jacobian build: barrier (2b) hands it the contact arrays stored just above)
+  if (PRE || ROT) { __syncthreads(); jac_build(0, 4); }
+  else jac_build(0, 2);
   };
   // J^T D J with EVERY pyramid row of every contact active (lane = dof row, 16 columns), summed from zero in contact order.  The
   // Newton loop starts its incremental Hessian from Mt + this: resting and gripping contacts have all four rows active, and the
@@ -1156,6 +1159,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
           *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 8) = r2; *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 12) = r3;
           pre[K16_PRE_BIAS + lane] = qfrc_bias;
         }
+        __syncthreads();  // (2b) the collision wave has stored the contact arrays: this wave builds every other pair of Jacobian rows
+        jac_build(2, 4);
         __syncthreads();  // (3) contact arrays and Jacobian rows of the coming step are in LDS
         {
           float hp[G];
