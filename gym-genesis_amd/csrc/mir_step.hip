@@ -104,7 +104,8 @@ struct EnvLds {
   float xpos[G][4], xquat[G][4];
   float cdof[G][8];               // ang(3) pad lin(3) pad
   float M[G][MSTR];
-  int ncon, ncand, coupled /* some contact joins the two kinematic trees: the Newton Hessian is not block diagonal */, pad1;
+  int ncon, ncand, coupled /* some contact joins the two kinematic trees: the Newton Hessian is not block diagonal */;
+  int cin_ready;  // two-wave instantiations: the collision wave has stored the body inertias of this step (main wave spins on it)
   // Phase-aliased working set.  `dyn` (smooth dynamics) and `col` (collision detection) are live AT THE SAME TIME in the
   // single-step instantiation, where a second wave of the workgroup detects collisions while the first one does the dynamics;
   // the contact arrays and the contact Jacobians take the place of both afterwards (con never overlaps col: the contact
@@ -657,7 +658,44 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       }
     }
   };
+  // body inertia about the tree reference point, in the world frame (lane = body): needs the link poses only.  In the two-wave
+  // instantiations the collision wave computes it in front of its detection (it has ~1.8 k cycles of slack before the second
+  // barrier, the main wave none) and raises S.cin_ready; the main wave picks it up where the composite inertias start.
+  auto cinert_store = [&](bool isb, const float (&ibv)[6], V3 ipos, float mass, int root) {
+    float* c = S.dyn.cinert[lane];
+    if (isb) {
+      M3 R = q2m(ld4v(S.xquat[lane]));
+      float Ib[3][3] = {{ibv[0], ibv[3], ibv[4]}, {ibv[3], ibv[1], ibv[5]}, {ibv[4], ibv[5], ibv[2]}};
+      float Rm[3][3] = {{R.r0.x, R.r0.y, R.r0.z}, {R.r1.x, R.r1.y, R.r1.z}, {R.r2.x, R.r2.y, R.r2.z}};
+      float T[3][3], W[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T[i][j] = Rm[i][0] * Ib[0][j] + Rm[i][1] * Ib[1][j] + Rm[i][2] * Ib[2][j];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) W[i][j] = T[i][0] * Rm[j][0] + T[i][1] * Rm[j][1] + T[i][2] * Rm[j][2];
+      V3 r = ld3v(S.xpos[lane]) + mmul(R, ipos) - ld3v(S.xpos[root]);
+      float rr = dot(r, r);
+      stv(c, f4{mass, mass * r.x, mass * r.y, mass * r.z});
+      stv(c + 4, f4{W[0][0] + mass * (rr - r.x * r.x), W[1][1] + mass * (rr - r.y * r.y), W[2][2] + mass * (rr - r.z * r.z),
+                    W[0][1] - mass * r.x * r.y});
+      stv(c + 8, f4{W[0][2] - mass * r.x * r.z, W[1][2] - mass * r.y * r.z, 0.0f, 0.0f});
+    } else {
+      stv(c, f4{0, 0, 0, 0}); stv(c + 4, f4{0, 0, 0, 0}); stv(c + 8, f4{0, 0, 0, 0});
+    }
+  };
   if (DUAL && wave == 1) {
+    // (lane constants of the body inertia: quads 0, 4, 5, 6 of LaneK16)
+    auto helper_cinert = [&]() {
+      const f4 h0 = *reinterpret_cast<const f4*>(m->lanek_t[0][lane]), h4 = *reinterpret_cast<const f4*>(m->lanek_t[4][lane]);
+      const f4 h5 = *reinterpret_cast<const f4*>(m->lanek_t[5][lane]), h6 = *reinterpret_cast<const f4*>(m->lanek_t[6][lane]);
+      const float hib[6] = {h5.x, h5.y, h5.z, h5.w, h6.x, h6.y};
+      cinert_store(lane < nb && lane > 0, hib, v3(h4.x, h4.y, h4.z), h4.w, __float_as_int(h0.z));
+      WSYNC();
+      if (lane == 0) __hip_atomic_store(&S.cin_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     // the four quads of lane constants the forward kinematics needs (fetched again for the closing FK: nothing is kept live
     // through the collision phase)
     auto fk_consts = [&](BodyK& hk) {
@@ -693,6 +731,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     HSTAMP(40);
     if (!ROT) __syncthreads();  // (1) link poses (this wave) and model table, velocities, targets (main wave) are in LDS
     HSTAMP(41);
+    helper_cinert();
     const int cnt = collide_detect();
     HSTAMP(42);
     contacts_build(cnt);  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
@@ -791,7 +830,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     if (isdof && d_uadr >= 0) tg = mine;
   }
   S.target[lane] = tg;
-  if (lane == 0) { S.ncon = 0; S.ncand = 0; }
+  if (lane == 0) { S.ncon = 0; S.ncand = 0; S.cin_ready = 0; }
   WSYNC();
 
   // ======================= forward kinematics =================================================
@@ -956,30 +995,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       st3v(&S.cdof[lane][0], v3(0, 0, 0));
       st3v(&S.cdof[lane][4], v3(0, 0, 0));
     }
-    if (isbody) {
-      M3 R = q2m(ld4v(S.xquat[lane]));
-      float Ib[3][3] = {{ib[0], ib[3], ib[4]}, {ib[3], ib[1], ib[5]}, {ib[4], ib[5], ib[2]}};
-      float Rm[3][3] = {{R.r0.x, R.r0.y, R.r0.z}, {R.r1.x, R.r1.y, R.r1.z}, {R.r2.x, R.r2.y, R.r2.z}};
-      float T[3][3], W[3][3];
-#pragma unroll
-      for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) T[i][j] = Rm[i][0] * Ib[0][j] + Rm[i][1] * Ib[1][j] + Rm[i][2] * Ib[2][j];
-#pragma unroll
-      for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) W[i][j] = T[i][0] * Rm[j][0] + T[i][1] * Rm[j][1] + T[i][2] * Rm[j][2];
-      V3 r = ld3v(S.xpos[lane]) + mmul(R, b_ipos) - ld3v(S.xpos[b_root]);
-      float rr = dot(r, r);
-      float* c = S.dyn.cinert[lane];
-      stv(c, f4{b_mass, b_mass * r.x, b_mass * r.y, b_mass * r.z});
-      stv(c + 4, f4{W[0][0] + b_mass * (rr - r.x * r.x), W[1][1] + b_mass * (rr - r.y * r.y), W[2][2] + b_mass * (rr - r.z * r.z),
-                    W[0][1] - b_mass * r.x * r.y});
-      stv(c + 8, f4{W[0][2] - b_mass * r.x * r.z, W[1][2] - b_mass * r.y * r.z, 0.0f, 0.0f});
-    } else {
-      float* c = S.dyn.cinert[lane];
-      stv(c, f4{0, 0, 0, 0}); stv(c + 4, f4{0, 0, 0, 0}); stv(c + 8, f4{0, 0, 0, 0});
-    }
+    if (!DUAL) cinert_store(isbody, ib, b_ipos, b_mass, b_root);
     WSYNC();
     STAMP(32);
     // ======================= velocities, composite inertias, body forces: tree SCANS =============
@@ -1027,6 +1043,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       if (isbody && b_last >= 0) { w = ld3v(&S.dyn.cvel[b_last][0]); v = ld3v(&S.dyn.cvel[b_last][4]); }
       // (2) composite inertia: suffix sums of the body inertias over the row, minus the suffix behind the subtree
       {
+        if (DUAL) {  // (the body inertias come from the collision wave: long since there, as a rule)
+          while (__hip_atomic_load(&S.cin_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+        }
         float* ci = S.dyn.cinert[lane];
         f4 c0 = ldv(ci), c1 = ldv(ci + 4), c2 = ldv(ci + 8);
         float comp[10] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y};
