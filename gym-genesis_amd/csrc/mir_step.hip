@@ -13,13 +13,15 @@
 //   * the two dense solves per Newton iteration (M^-1 f, H^-1 g) are Gauss-Jordan eliminations
 //     on register-resident matrix rows (lane i = row i), the pivot row travelling by
 //     row_newbcast: no LDS, no sqrt, no forward/back substitution chains.
-//   * kinematic-tree recursions are mask-driven sums over ancestors / descendants: single
-//     phases, no depth-serial chain of barriers; the parent table is a 64-bit register.
+//   * kinematic-tree recursions are scans: pointer jumping over the parent links for sums over ancestors (forward
+//     kinematics, velocities, bias accelerations), DPP suffix sums over the depth-first body lanes for sums over
+//     subtrees -- no depth-serial chain; the parent table is a 64-bit register.
 //   * per-env working data that other lanes must see (poses, motion subspaces, M, contact
 //     Jacobians) lives in ~8 KB of LDS per env, phase-aliased, so 4 workgroups (16 envs) fit a CU
 //     and all 4096 envs of the headline batch are co-resident on the 256 CUs.
-//   * single-wave workgroups: LDS accesses of a wave execute in order, so phases are separated
-//     by a compiler-level fence only (WSYNC), never an s_barrier.
+//   * LDS accesses of a wave execute in order, so the phases of a wave are separated by a compiler-level fence only (WSYNC).
+//     The single-step instantiations put a SECOND wave on the same four envs (collision detection, contact arrays, opening and
+//     closing forward kinematics, body inertias beside the first wave's dynamics and solves); the two meet at s_barriers.
 //   * HBM state is env-major (B, D): with 16 lanes per env a wave touches 4 contiguous 64-byte
 //     rows, the coalesced pattern for this lane mapping.  228 B read + 341 B written per env-step (489 B algorithmic:
 //     qpos, qvel, warm start, action in; qpos, qvel, warm start, targets, observations, reward, mask out).
@@ -28,9 +30,11 @@
 //     the arithmetic, vectors that a whole row needs once travel by row broadcast instead of through LDS, and every global
 //     read of a launch (tables, per-lane record, model scalars, state, action, cached poses) leaves before the first LDS
 //     store -- one L2 round trip at the start.
-//   * three instantiations: <0> one step per launch (no step loop: 17 SGPR spills, no AGPRs), <1> K-step rollouts with
-//     packed rows, <2> everything (per-stage outputs, pose refresh, profiling stamps).  Built with -ffp-contract=on so that
-//     they agree bit for bit.
+//   * instantiations: <0> one step per launch (two waves, no step loop, no AGPRs), <1> K-step rollouts with packed rows, <2>
+//     everything (per-stage outputs, pose refresh, profiling stamps); <3> / <4> the action-independent / action-dependent half
+//     of a step through a scratch row in HBM, <5> the ROTATED launch of GenesisEnv.step -- <4> of this step followed by <3> of
+//     the next in one kernel, so that the host has its `terminated` after half a step and the rest runs while it is between two
+//     calls.  One step body serves all of them; built with -ffp-contract=on so that they agree bit for bit.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
