@@ -137,6 +137,7 @@ def test_split_step_survives_everything_that_touches_the_state_between_two_steps
     sc = MirScene(franka_spec, B)
     monkeypatch.setenv("MIR_SPLIT_STEP", "0")
     ref = MirScene(franka_spec, B)
+    assert sc.split_step == int(split) and ref.split_step == 0
     _reset(sc, B)
     _reset(ref, B)
     g = np.random.default_rng(11)
