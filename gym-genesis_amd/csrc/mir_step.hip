@@ -712,8 +712,26 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     };
     const uint64_t hparents = m->parents;
     if (ROT) {
-      // rotated launch: this wave's first job is the closing FK of the step the main wave is finishing -- which is the opening
-      // FK of the step whose action-independent half follows
+      // rotated launch.  First, as in the fused launch, this wave hands the main wave the contact rows of the step it is solving
+      // (here they come from the scratch row the previous launch left) and the all-rows-active Hessian accumulated from them
+      {
+        const float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
+        const f4 head = *reinterpret_cast<const f4*>(pre + K16_PRE_HEAD);
+        const int nc = __float_as_int(head.x);
+        if (lane == 0) { S.ncon = nc; S.coupled = __float_as_int(head.y); S.ncand = 0; }
+        if (lane < nc) stv(S.con.cmeta[lane], *reinterpret_cast<const f4*>(pre + K16_PRE_CMETA + 4 * lane));
+        f4* jdst = reinterpret_cast<f4*>(&S.Jb[0][0]);
+        for (int i = lane; i < nc * (JST / 4); i += G) jdst[i] = *reinterpret_cast<const f4*>(pre + K16_PRE_JB + 4 * i);
+        WSYNC();
+        __syncthreads();  // (3) contact rows of this step are in LDS
+        float hp[G];
+        hess_full(hp, nc);
+#pragma unroll
+        for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]});
+        __syncthreads();  // (4) all-rows-active Hessian handed to the main wave
+      }
+      // then the closing FK of the step the main wave is finishing -- which is the opening FK of the step whose
+      // action-independent half follows
       BodyK hk;
       fk_consts(hk);
       __syncthreads();  // (5) the main wave has integrated the jointed dofs
@@ -745,7 +763,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     {
       if (PRE || ROT) {
         // the action-independent half ends here: contact data and Jacobian rows go to the pre buffer (the all-active Hessian is
-        // accumulated and stored by the main wave meanwhile: it has nothing else left to do)
+        // accumulated from them by this wave at the start of the launch that consumes them, while the main wave starts on the action)
         if (valid) {
           float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
           const int nc = S.ncon;
@@ -834,7 +852,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     if (isdof && d_uadr >= 0) tg = mine;
   }
   S.target[lane] = tg;
-  if (lane == 0) { S.ncon = 0; S.ncand = 0; S.cin_ready = 0; }
+  if (lane == 0) {
+    if (!ROT) { S.ncon = 0; S.ncand = 0; }  // (rotated launch: the collision wave is writing this step's contact count meanwhile)
+    S.cin_ready = 0;
+  }
   WSYNC();
 
   // ======================= forward kinematics =================================================
@@ -879,22 +900,18 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   float pre_bias = 0.0f;
   if (POST || ROT) {
     const float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
-    f4 pre_h[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      pre_m[q] = *reinterpret_cast<const f4*>(pre + K16_PRE_MROW + 16 * lane + 4 * q);
-      pre_h[q] = *reinterpret_cast<const f4*>(pre + K16_PRE_HP + 16 * lane + 4 * q);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], pre_h[q]);  // (parked in the M area, idle in this half, until the first Newton iteration)
+    for (int q = 0; q < 4; q++) pre_m[q] = *reinterpret_cast<const f4*>(pre + K16_PRE_MROW + 16 * lane + 4 * q);
     pre_bias = pre[K16_PRE_BIAS + lane];
-    const f4 head = *reinterpret_cast<const f4*>(pre + K16_PRE_HEAD);
-    const int nc = __float_as_int(head.x);
-    if (lane == 0) { S.ncon = nc; S.coupled = __float_as_int(head.y); S.ncand = 0; }
-    if (lane < nc) stv(S.con.cmeta[lane], *reinterpret_cast<const f4*>(pre + K16_PRE_CMETA + 4 * lane));
-    f4* jdst = reinterpret_cast<f4*>(&S.Jb[0][0]);
-    for (int i = lane; i < nc * (JST / 4); i += G) jdst[i] = *reinterpret_cast<const f4*>(pre + K16_PRE_JB + 4 * i);
-    WSYNC();
+    if (POST) {  // (one wave: it fetches the contact rows itself; in the rotated launch the collision wave does)
+      const f4 head = *reinterpret_cast<const f4*>(pre + K16_PRE_HEAD);
+      const int nc = __float_as_int(head.x);
+      if (lane == 0) { S.ncon = nc; S.coupled = __float_as_int(head.y); S.ncand = 0; }
+      if (lane < nc) stv(S.con.cmeta[lane], *reinterpret_cast<const f4*>(pre + K16_PRE_CMETA + 4 * lane));
+      f4* jdst = reinterpret_cast<f4*>(&S.Jb[0][0]);
+      for (int i = lane; i < nc * (JST / 4); i += G) jdst[i] = *reinterpret_cast<const f4*>(pre + K16_PRE_JB + 4 * i);
+      WSYNC();
+    }
   }
   // ---- what a step hands back: host-visible terminated bytes, state rows, observations (after the step loop; in the rotated
   // launch after its first pass) -------------------------------------------------------------------------------------------
@@ -1184,16 +1201,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         }
         __syncthreads();  // (2b) the collision wave has stored the contact arrays: this wave builds every other pair of Jacobian rows
         jac_build(2, 4);
-        __syncthreads();  // (3) contact arrays and Jacobian rows of the coming step are in LDS
-        {
-          float hp[G];
-          hess_full(hp, S.ncon);
-          if (valid) {
-            float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
-#pragma unroll
-            for (int q = 0; q < 4; q++) *reinterpret_cast<f4*>(pre + K16_PRE_HP + 16 * lane + 4 * q) = f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]};
-          }
-        }
+        __syncthreads();  // (3) every Jacobian row of the coming step is in LDS: the collision wave stores them
         return 2;
       }
       mrow[0] = r0.x; mrow[1] = r0.y; mrow[2] = r0.z; mrow[3] = r0.w; mrow[4] = r1.x; mrow[5] = r1.y; mrow[6] = r1.z; mrow[7] = r1.w;
@@ -1243,7 +1251,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     }
     WSYNC();
     STAMP(50);
-    if (DUAL && !post_now) __syncthreads();  // (3) contact arrays and base Jacobians are in LDS
+    if (DUAL && (!post_now || ROT)) __syncthreads();  // (3) contact arrays and base Jacobians are in LDS
     STAMP(52);
     const int ncon = S.ncon;
     // contact rows, lane = contact, lane-private: aref_r = -b (J_r qvel) - k imp dist
@@ -1373,17 +1381,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       if (!__any(!done)) break;
       if (it == 0) {  // start from Mt + the all-rows-active J^T D J (from the collision wave where there is one)
         float hp[G];
-        if (DUAL && !post_now) {
+        if (DUAL && (!post_now || ROT)) {
           STAMP(51);
           __syncthreads();  // (4)
           STAMP(53);
           met4 = true;
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const f4 v = ldv(&S.M[lane][4 * q]);
-            hp[4 * q] = v.x; hp[4 * q + 1] = v.y; hp[4 * q + 2] = v.z; hp[4 * q + 3] = v.w;
-          }
-        } else if (post_now) {
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const f4 v = ldv(&S.M[lane][4 * q]);
@@ -1543,7 +1545,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       if (it == 0) STAMP(21);
       ITSTAMP(it, 7);
     }
-    if (DUAL && !post_now && !met4) __syncthreads();  // (4) (no Hessian was needed: the collision wave is let go)
+    if (DUAL && (!post_now || ROT) && !met4) __syncthreads();  // (4) (no Hessian was needed: the collision wave is let go)
     if (a.out_qacc && valid && isdof && step == 0) a.out_qacc[(size_t)env * nv + lane] = qacc;
     if (a.diag && valid && lane == 0) {
       a.diag[(size_t)env * 4 + 0] = ncon;
