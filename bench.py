@@ -643,24 +643,32 @@ def worker(args) -> int:
                 try:
                     mir = task._mir
                     task.reset()
-                    mir.rotated_launches(actions, 50)
+                    # (the launches write what GenesisEnv.step's write: the four outputs and the host-visible terminated bytes)
+                    outs_api = (mir.empty(9), mir.empty(11), mir.empty(), mir.empty(dtype=torch.uint8))
+                    mir.rotated_launches(actions, 50, outputs=outs_api)
                     torch.cuda.synchronize(dev)
                     n_ev = 1000
                     e0, e1 = _events(torch)
                     e0.record()
-                    mir.rotated_launches(actions, n_ev)
+                    mir.rotated_launches(actions, n_ev, outputs=outs_api)
                     e1.record()
                     torch.cuda.synchronize(dev)
                     rot_us = e0.elapsed_time(e1) * 1e3 / n_ev
+                    e0.record()
+                    mir.rotated_launches(actions, n_ev)
+                    e1.record()
+                    torch.cuda.synchronize(dev)
+                    rot_us_bare = e0.elapsed_time(e1) * 1e3 / n_ev
                     ach = ALGO_BYTES_PER_ENV_STEP * B / (rot_us * 1e-6) / 1e9
                     out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                        "traffic": _profile_number("pmc_hbm_traffic_api.json", "hbm_bytes_per_launch") if B == ENVS_PER_GPU else None,
-                                       "kernel": "mir_step_kernel<5, true>", "kernel_us": rot_us,
+                                       "kernel": "mir_step_kernel<5, true>", "kernel_us": rot_us, "kernel_us_without_outputs": rot_us_bare,
                                        "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
                                        "note": "the kernel of the headline loop: the rotated launch of GenesisEnv.step (this step's action-dependent "
                                                "half, then the next step's action-independent half through a 5.8 KB/env scratch row, which is why its "
                                                "traffic is several times the 489 algorithmic B/env-step: bytes spent to take ~8 us of work out of the "
-                                               "host-visible latency); kernel_us = HIP events around 1000 back-to-back launches (mir_debug_rotated_launches), launch gap included"}
+                                               "host-visible latency); kernel_us = HIP events around 1000 back-to-back launches (mir_debug_rotated_launches) that write the "
+                                               "same outputs as GenesisEnv.step's, launch gap included"}
                     out["roofline_fused_launch"] = fused
                 except Exception as e:  # noqa: BLE001
                     out["roofline_api_kernel_error"] = f"{type(e).__name__}: {e}"

@@ -502,6 +502,8 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   //  the waves; otherwise two launches)
   const bool rotated = have_pre && h->hm.fk_free_leaf != 0 && h->split_step != 2;
   o.phase = rotated ? 3 : (have_pre ? 2 : 0);
+  o.prof = h->dbg_prof;
+  h->dbg_prof = nullptr;
   int rc = launch(h, o, stream);
   if (rc != MIR_OK) return rc;
   if (rotated) h->pre_valid = 1;  // (launch() cleared it; the same launch has refilled `pre` for the state it leaves)
@@ -607,7 +609,7 @@ int mir_get_sync_mode(MirHandle h) { return check(h) ? MIR_E_INVALID : h->sync_m
 /* debug aid (bench.py's roofline): n back-to-back launches of the rotated step kernel (what mir_step_begin launches in split mode 1)
  * cycling through n_actions action blocks of (B, nu) and without observation outputs, so that two events around the call time that kernel the way the fused one is
  * timed.  Advances the state by n steps. */
-extern "C" int mir_debug_rotated_launches(MirHandle h, const float* actions, int32_t n_actions, int32_t n, void* stream) {
+extern "C" int mir_debug_rotated_launches(MirHandle h, const float* actions, int32_t n_actions, int32_t n, void* const* outputs, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   if (h->kernel != 16 || h->split_step != 1 || !h->hm.fk_free_leaf) return set_err(MIR_E_INVALID, "mir_debug_rotated_launches: the scene does not use rotated launches");
   DeviceGuard guard(h->device);
@@ -619,8 +621,15 @@ extern "C" int mir_debug_rotated_launches(MirHandle h, const float* actions, int
     rc = launch(h, p, stream);
     if (rc != MIR_OK) return rc;
   }
+  // (with `outputs` the launches write what mir_step_go's would: the four outputs and the tagged terminated bytes)
+  const bool outs = outputs != nullptr;
   for (int i = 0; i < n; i++) {
     Outs o; o.action = actions + (size_t)(i % (n_actions > 0 ? n_actions : 1)) * h->B * h->nu; o.diag = false; o.phase = 3;
+    if (outs) {
+      o.agent_pos = (float*)outputs[0]; o.env_state = (float*)outputs[1]; o.reward = (float*)outputs[2]; o.terminated = (uint8_t*)outputs[3];
+      o.term_host = h->pin_dev;
+      o.term_tag = 1u + ++h->seq % 3u;
+    }
     int rc = launch(h, o, stream);
     if (rc != MIR_OK) return rc;
   }
@@ -673,6 +682,14 @@ int mir_debug_profile_step(MirHandle h, unsigned long long* prof16, void* stream
   Outs o;
   o.prof = prof16;
   return launch(h, o, stream);
+}
+
+/* debug aid for -DMIR_PROFILE_SINGLE builds (tools/probes/rot_timeline.py): the next mir_step_begin launch -- whichever kernel the
+ * split-step protocol picks for it -- leaves its shader-clock stamps in prof (device memory, 160 x u64, slot 29 = workgroup). */
+extern "C" int mir_debug_profile_next_step(MirHandle h, unsigned long long* prof) {
+  if (check(h)) return MIR_E_INVALID;
+  h->dbg_prof = prof;
+  return MIR_OK;
 }
 
 /* debug aid (not part of the drop-in surface): the floor under one synchronous env.step() on this machine -- launch an (almost)

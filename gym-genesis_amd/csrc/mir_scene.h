@@ -34,6 +34,7 @@ struct MirScene {
   void* pending_stream;
   void* prep[4];            // output pointers registered by mir_step_prepare for the next mir_step_go
   int prepared;
+  unsigned long long* dbg_prof = nullptr;  // (mir_debug_profile_next_step: shader-clock stamps of the next mir_step_begin launch)
   // split step of the GenesisEnv.step path (16-lane kernel; MIR_SPLIT_STEP=0 switches it off): mir_step_begin launches the
   // action-independent half of the NEXT step right behind the current one; `pre_valid` says that `pre` holds that half for the
   // state as it is now (any other launch or state write clears it), `pre_stream` the stream it was launched on

@@ -723,11 +723,13 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         f4* jdst = reinterpret_cast<f4*>(&S.Jb[0][0]);
         for (int i = lane; i < nc * (JST / 4); i += G) jdst[i] = *reinterpret_cast<const f4*>(pre + K16_PRE_JB + 4 * i);
         WSYNC();
+        HSTAMP(54);
         __syncthreads();  // (3) contact rows of this step are in LDS
         float hp[G];
         hess_full(hp, nc);
 #pragma unroll
         for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]});
+        HSTAMP(55);
         __syncthreads();  // (4) all-rows-active Hessian handed to the main wave
       }
       // then the closing FK of the step the main wave is finishing -- which is the opening FK of the step whose
@@ -735,7 +737,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       BodyK hk;
       fk_consts(hk);
       __syncthreads();  // (5) the main wave has integrated the jointed dofs
+      HSTAMP(56);
       group_fk<true>(S, lane, nb, hparents, hk, row4);
+      HSTAMP(57);
       __syncthreads();  // (6) link poses of the new state handed to the main wave
     } else {
       // The collision wave opens the launch with the FORWARD KINEMATICS of the stored state: it needs one row of qpos and four of
@@ -772,6 +776,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
           const f4* jsrc = reinterpret_cast<const f4*>(&S.Jb[0][0]);
           for (int i = lane; i < nc * (JST / 4); i += G) *reinterpret_cast<f4*>(pre + K16_PRE_JB + 4 * i) = jsrc[i];
         }
+#ifdef MIR_PROFILE_SINGLE
+        // (debug: wall clock of the last exit among the workgroups on the watched one's XCD = the end of the launch)
+        if (a.prof && threadIdx.x == 64 && (blockIdx.x & 7) == (unsigned)(prof_blk & 7)) atomicMax(&a.prof[31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
         return;
       }
       float hp[G];
@@ -1579,6 +1587,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
       }
+      STAMP(30);
     }
     if (fksplit) {
       WSYNC();

@@ -57,7 +57,7 @@ def load_library() -> C.CDLL:
     lib.mir_step_go.restype = C.c_int
     lib.mir_get_sync_mode.argtypes = [vp]
     lib.mir_get_sync_mode.restype = C.c_int
-    lib.mir_debug_rotated_launches.argtypes = [vp, vp, i32, i32, vp]
+    lib.mir_debug_rotated_launches.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.mir_debug_rotated_launches.restype = C.c_int
     lib.mir_get_split_step.argtypes = [vp]
     lib.mir_get_split_step.restype = C.c_int
@@ -91,7 +91,28 @@ def load_library() -> C.CDLL:
     if lib.mir_spec_sizeof() != C.sizeof(MirSceneSpec) or lib.mir_version() != 2 or lib.mir_visual_sizeof() != C.sizeof(MirVisualSpec):
         raise MirError("libmirigid.so ABI mismatch with gym_genesis.backend.spec (rebuild the library)")
     _lib = lib
+    _bind_fast(lib)
     return lib
+
+
+_fast = None  # the _mirfast built-ins (csrc/mir_pyfast.c), bound to the loaded library; None = ctypes is used for those calls too
+
+
+def _bind_fast(lib) -> None:
+    """The three calls between two env.step launches as CPython built-ins (~0.06 us per call instead of ctypes' ~0.39 us: that
+    difference is GPU idle time).  They are the SAME library functions, bound by address; without the module the ctypes route is
+    taken, and a warning says so."""
+    global _fast
+    try:
+        from . import _mirfast
+    except ImportError as e:
+        import warnings
+
+        warnings.warn(f"gym_genesis.backend._mirfast is not built ({e}); env.step uses ctypes calls (run `make -C gym-genesis_amd/csrc`)", RuntimeWarning)
+        return
+    addr = lambda f: C.cast(f, C.c_void_p).value  # noqa: E731
+    _mirfast.bind(addr(lib.mir_step_prepare), addr(lib.mir_step_go), addr(lib.mir_step_end))
+    _fast = _mirfast
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -188,6 +209,7 @@ class MirScene(StepHelpers):
         rc = self.lib.mir_create(C.byref(spec), int(num_envs), self.device.index, C.byref(h))
         self._check(rc)
         self.h = h
+        self._hbox = [h.value]
         d = MirDims()
         self._check(self.lib.mir_get_dims(self.h, C.byref(d)))
         self.num_envs, self.nbody, self.nq, self.nv = d.num_envs, d.nbody, d.nq, d.nv
@@ -231,6 +253,7 @@ class MirScene(StepHelpers):
         if getattr(self, "h", None):
             self.lib.mir_destroy(self.h)
             self.h = None
+            self._hbox[0] = 0
 
     def __del__(self):
         try:
@@ -292,6 +315,14 @@ class MirScene(StepHelpers):
         if rc:
             self._check(rc)
 
+    def fast_calls(self):
+        """-> (prepare, go, end, handle_box, raw_stream, device_index) for the flat env.step closure (tasks/fast_step.py): the
+        _mirfast built-ins with everything they need as plain ints (handle_box[0] = the handle's address, 0 once the scene is
+        closed: the library then answers "null MirHandle"), or None where ctypes has to do (no module, no raw stream getter)."""
+        if _fast is None or _raw_stream is None:
+            return None
+        return _fast.prepare, _fast.go, _fast.end, self._hbox, _raw_stream, self._devidx
+
     def step_fused_ptrs(self, action_ptr, ptrs) -> None:
         rc = self.lib.mir_step_fused(self.h, action_ptr, ptrs[0], ptrs[1], ptrs[2], ptrs[3], self._stream())
         if rc:
@@ -325,9 +356,12 @@ class MirScene(StepHelpers):
     def sync_mode(self) -> int:
         return int(self.lib.mir_get_sync_mode(self.h))
 
-    def rotated_launches(self, actions: torch.Tensor, n: int) -> None:
-        """mir_debug_rotated_launches: n back-to-back rotated launches cycling through actions (K,B,nu) (bench.py times them)."""
-        self._check(self.lib.mir_debug_rotated_launches(self.h, _ptr(actions), int(actions.shape[0]), int(n), self._stream()))
+    def rotated_launches(self, actions: torch.Tensor, n: int, outputs=None) -> None:
+        """mir_debug_rotated_launches: n back-to-back rotated launches cycling through actions (K,B,nu) (bench.py times them);
+        `outputs` = (agent_pos, env_state, reward, terminated) tensors: every launch also writes them and the host-visible
+        terminated bytes, like the launches of GenesisEnv.step."""
+        outs = None if outputs is None else (C.c_void_p * 4)(*[t.data_ptr() for t in outputs])
+        self._check(self.lib.mir_debug_rotated_launches(self.h, _ptr(actions), int(actions.shape[0]), int(n), outs, self._stream()))
 
     @property
     def split_step(self) -> int:

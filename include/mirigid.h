@@ -381,11 +381,15 @@ int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_p
  * mir_debug_copy_rows: dst[i] = src[i] for n_floats floats with the step kernel's access shape (64-thread workgroups, 4 B per
  * lane): a known byte count against which rocprofv3's FETCH_SIZE / WRITE_SIZE are calibrated for this access width. */
 int mir_debug_profile_step(MirHandle h, unsigned long long* prof, void* stream);
+/* profiling builds (-DMIR_PROFILE_SINGLE): the next mir_step_begin / mir_step_go launch -- whichever kernel the split-step protocol
+ * picks -- leaves its stamps in prof (160 x u64, device; slot 63 = workgroup to watch) */
+int mir_debug_profile_next_step(MirHandle h, unsigned long long* prof);
 int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* out_us);
 /* n back-to-back launches of the rotated step kernel (split mode 1), cycling through n_actions (B, nu) action blocks, without
- * observation outputs: lets two events time that kernel the way the fused one is timed (bench.py's roofline).  Advances the state by
- * n steps. */
-int mir_debug_rotated_launches(MirHandle h, const float* actions, int32_t n_actions, int32_t n, void* stream);
+ * observation outputs -- or, with outputs = {agent_pos, env_state, reward, terminated} (device pointers, shapes as in
+ * mir_step_fused), with the outputs and host-visible terminated bytes of a mir_step_go launch: lets two events time that kernel the way the fused one is timed (bench.py's roofline).  Advances the state
+ * by n steps. */
+int mir_debug_rotated_launches(MirHandle h, const float* actions, int32_t n_actions, int32_t n, void* const* outputs, void* stream);
 int mir_debug_poison_lds(int device_id, void* stream);
 int mir_debug_copy_rows(const float* src, float* dst, int64_t n_floats, int device_id, void* stream);
 /* the kernels' convex narrowphase on n pairs given directly (device arrays): in (n,22) = type1, size1[3], pos1[3], quat1[4] wxyz,

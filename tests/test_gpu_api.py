@@ -181,3 +181,63 @@ def test_split_step_survives_everything_that_touches_the_state_between_two_steps
             assert torch.equal(x, y), f"step {t}"
     for x, y in zip(sc.get_state(), ref.get_state()):
         assert torch.equal(x, y)
+
+
+def test_env_step_over_builtins_equals_env_step_over_ctypes_and_a_closed_scene_is_an_error(monkeypatch):
+    """GenesisEnv.step's flat closure exists twice (tasks/fast_step.py): over the _mirfast built-ins and over ctypes (taken when the
+    module is missing).  Same launches, same results bit for bit; after MirScene.close() both raise instead of touching freed memory."""
+    from gym_genesis.backend import lib as mirlib
+    from gym_genesis.env import GenesisEnv
+
+    assert mirlib._fast is not None, "_mirfast.so did not travel / is not built"
+    e1 = GenesisEnv(task="cube_pick", robot="franka", num_envs=64, enable_pixels=False)
+    monkeypatch.setattr(mirlib, "_fast", None)
+    e2 = GenesisEnv(task="cube_pick", robot="franka", num_envs=64, enable_pixels=False)
+    monkeypatch.undo()
+    assert e1.step.__name__ == "fast_step_builtin" and e2.step.__name__ == "fast_step"
+    e1.reset(seed=3); e2.reset(seed=3)
+    g = torch.Generator(device=e1._env.device).manual_seed(0)
+    for t in range(40):
+        a = torch.empty((64, 9), device=e1._env.device).uniform_(-1, 1, generator=g)
+        r1, r2 = e1.step(a), e2.step(a)
+        assert all(torch.equal(r1[0][k], r2[0][k]) for k in r1[0]) and torch.equal(r1[1], r2[1])
+        assert np.array_equal(r1[2], r2[2]) and np.array_equal(r1[3], r2[3]) and torch.equal(r1[4]["is_success"], r2[4]["is_success"])
+    for e in (e1, e2):
+        e._env._mir.close()
+        with pytest.raises(mirlib.MirError):
+            e.step(a)
+
+
+def test_back_to_back_rotated_launches_with_outputs_equal_fused_steps(franka_spec):
+    """bench.py times the rotated kernel through mir_debug_rotated_launches with the outputs of a GenesisEnv.step launch: those
+    launches must BE steps -- same state, same four outputs as fused launches fed the same actions -- and must not disturb the
+    output registration (mir_step_prepare) a step closure made ahead of its next call."""
+    from gym_genesis.backend.lib import MirScene
+
+    B, K, n = 64, 5, 12
+    sc, ref = MirScene(franka_spec, B), MirScene(franka_spec, B)
+    assert sc.split_step == 1
+    _reset(sc, B); _reset(ref, B)
+    acts = torch.as_tensor(np.random.default_rng(5).uniform(-1, 1, (K, B, 9)).astype(np.float32), device=sc.device)
+    b1 = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    b2 = (ref.empty(9), ref.empty(11), ref.empty(), ref.empty(dtype=torch.uint8))
+    ahead = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    sc.step_prepare_ptrs([t.data_ptr() for t in ahead])
+    sc.rotated_launches(acts, n, outputs=b1)   # (no first half is waiting after a reset: one fused step on acts[0] goes first)
+    ref.step_fused(acts[0], *b2)
+    for i in range(n):
+        ref.step_fused(acts[i % K], *b2)
+    for x, y in zip(b1, b2):
+        assert torch.equal(x, y)
+    for x, y in zip(sc.get_state(), ref.get_state()):
+        assert torch.equal(x, y)
+    sc.rotated_launches(acts, 3)              # without outputs; the first half left by the launches above is used
+    for i in range(3):
+        ref.step_fused(acts[i % K], *b2)
+    sc.step_go_ptr(acts[3].data_ptr())         # the registration made before the debug launches is still there
+    host = np.empty(B, np.bool_)
+    sc.step_end_ptr(host.ctypes.data)
+    ref.step_fused(acts[3], *b2)
+    for x, y in zip(ahead, b2):
+        assert torch.equal(x, y)
+    assert np.array_equal(host, b2[3].cpu().numpy().astype(bool))

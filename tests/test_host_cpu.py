@@ -41,6 +41,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.mir_visual_sizeof() == C.sizeof(S.MirVisualSpec)
 
 
+def test_builtin_step_calls_are_the_library_functions_bound_by_address():
+    """gym_genesis.backend._mirfast (csrc/mir_pyfast.c) carries mir_step_prepare / mir_step_go / mir_step_end as CPython built-ins:
+    it must be built, be bound to the loaded library by load_library(), and pass handles through untouched -- a null handle comes
+    back as the library's own MIR_E_INVALID with its message, no GPU involved."""
+    lib = mirlib.load_library()
+    assert mirlib._fast is not None, "_mirfast.so is not built (make -C gym-genesis_amd/csrc)"
+    f = mirlib._fast
+    assert f.go(0, 0, 0) == -1 and b"null MirHandle" in lib.mir_last_error()
+    assert f.end(None, 0) == -1 and f.prepare(0, 0, 0, 0, 0) == -1
+    with pytest.raises(TypeError):
+        f.go(0, 0)
+    with pytest.raises(TypeError):
+        f.go("handle", 0, 0)
+
+
 def test_no_cpu_fallback_create_fails_loudly_without_gpu(franka_spec):
     if torch.cuda.is_available():
         pytest.skip("GPU present")
