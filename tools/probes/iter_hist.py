@@ -1,33 +1,28 @@
-import sys, os
-R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path[:0]=[R+'/oracle',R+'/gym-genesis_amd']
-import numpy as np, torch, time
-from gym_genesis.backend import models
-from gym_genesis.backend.lib import MirScene
-B=4096
-def run(iters):
-    sb=models.franka_cube_pick_scene(); sb.opt["iterations"]=iters
-    sc=MirScene(sb.build(),B)
-    rng=np.random.RandomState(0)
-    pos=np.stack([rng.uniform(.45,.8,B),rng.uniform(-.25,.25,B),np.full(B,.02)],1).astype(np.float32)
-    sc.reset(pos,np.tile(np.array([0,0,0,1],np.float32),(B,1)),np.tile(np.array(models.FRANKA_HOME,np.float32),(B,1)))
-    g=torch.Generator(device=sc.device).manual_seed(1234)
-    acts=torch.empty((256,B,9),device=sc.device).uniform_(-1,1,generator=g)
-    bufs=(sc.empty(9),sc.empty(11),sc.empty(),sc.empty(dtype=torch.uint8))
-    hist=np.zeros(8); blockmax=np.zeros(8)
-    for t in range(100):
-        sc.step_fused(acts[t],*bufs)
-        if t>=20:
-            ni=sc.get_diag()[2].cpu().numpy()
-            hist+=np.bincount(np.minimum(ni,7),minlength=8)
-            blockmax+=np.bincount(np.minimum(ni.reshape(-1,4).max(1),7),minlength=8)
-    sc.set_diag(False)
-    torch.cuda.synchronize(); t0=time.perf_counter()
-    for t in range(500): sc.step_fused(acts[t%256],*bufs)
-    torch.cuda.synchronize(); us=(time.perf_counter()-t0)/500*1e6
-    return hist/hist.sum(), blockmax/blockmax.sum(), us, sc.get_state()[0].cpu().numpy()
-h50,b50,us50,q50=run(50)
-print('iterations=50: niter hist',h50.round(4),'block-max hist',b50.round(4),'us/step',round(us50,2))
-for it in (1,2,3):
-    h,b,us,q=run(it)
-    print(f'iterations={it}: us/step {us:.2f}; state diff vs 50 after 600 steps: median {np.median(np.abs(q-q50).max(1)):.2e}')
+"""Newton iterations per env and step on the headline workload (solver diagnostics on): histogram over all envs, and the
+histogram of the per-launch maximum -- the number the launch time follows."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "gym-genesis_amd")]
+import numpy as np, torch
+from gym_genesis.env import GenesisEnv
+B = 4096
+env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
+env.reset(seed=0)
+task = env._env; mir = task._mir
+mir.set_diag(True)
+g = torch.Generator(device=task.device).manual_seed(0)
+allh = np.zeros(12, np.int64); maxh = np.zeros(12, np.int64); wgh = np.zeros(12, np.int64)
+N = 400
+for t in range(N):
+    a = torch.empty((B, 9), device=task.device).uniform_(-1, 1, generator=g)
+    env.step(a)
+    if t % 200 == 199:
+        env.reset()
+    it = mir.get_diag()[2].cpu().numpy()
+    allh += np.bincount(np.minimum(it, 11), minlength=12)
+    maxh[min(int(it.max()), 11)] += 1
+    wgh += np.bincount(np.minimum(it.reshape(-1, 4).max(1), 11), minlength=12)
+print("iterations          :", list(range(8)))
+print("envs (fraction)     :", np.round(allh[:8] / allh.sum(), 4))
+print("workgroups (max of 4):", np.round(wgh[:8] / wgh.sum(), 4))
+print("launches (max of all):", np.round(maxh[:8] / maxh.sum(), 3), " mean of max", round(float((maxh * np.arange(12)).sum() / maxh.sum()), 2))
