@@ -44,16 +44,15 @@ struct StepArgs {
   int n_steps;  // mode 0 only
   int features; // bit 0: sphere / capsule geoms (GJK / MPR narrowphase); bit 1: sweep-and-prune broadphase
   // split step (GenesisEnv.step path): `phase` 0 = whole step; 1 = the ACTION-INDEPENDENT half of the coming step only (poses,
-  // dynamics, collision, contact arrays, Jacobians, all-rows-active Hessian) written to `pre`; 2 = the rest of the step, read from
+  // dynamics, collision, contact arrays, Jacobians) written to `pre`; 2 = the rest of the step, read from
   // `pre`.  3 = 2 followed by 1 (of the next step) in one launch.  `pre`: K16_PRE_STRIDE floats per env.
   int phase;
   float* pre;
 };
 #define K16_PRE_MROW 0     /* 16 lanes x 16: rows of the regularised mass matrix */
-#define K16_PRE_HP 256     /* 16 x 16: J^T D J with every pyramid row active */
-#define K16_PRE_BIAS 512   /* 16: qfrc_bias */
-#define K16_PRE_HEAD 528   /* ncon, coupled (int bits), 2 pad */
-#define K16_PRE_CMETA 532  /* K16_MAX_CONTACT x 4 */
+#define K16_PRE_BIAS 256   /* 16: qfrc_bias */
+#define K16_PRE_HEAD 272   /* ncon, coupled (int bits), 2 pad */
+#define K16_PRE_CMETA 276  /* K16_MAX_CONTACT x 4 */
 #define K16_PRE_JB (K16_PRE_CMETA + 4 * K16_MAX_CONTACT) /* K16_MAX_CONTACT rows of 52 floats */
 #define K16_PRE_STRIDE (((K16_PRE_JB + 52 * K16_MAX_CONTACT) + 15) / 16 * 16)
 

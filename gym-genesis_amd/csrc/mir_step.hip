@@ -206,8 +206,8 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 // barriers in all.  The step-loop instantiations keep one wave (they need the AGPRs a second wave per SIMD would have to give up);
 // both run the same code in the same order of operations, so they agree bit for bit.
 // VARIANT 3 / 4 = the two halves of a single step for GenesisEnv.step (StepArgs.phase 1 / 2): 3 is the action-independent
-// half -- everything the two waves do up to the contact Jacobians and the all-rows-active Hessian -- whose results go to the
-// `pre` buffer instead of staying in LDS; 4 picks them up and runs the rest on one wave.  The host launches 3 for the NEXT step
+// half -- everything the two waves do up to the contact Jacobians -- whose results go to the `pre` buffer instead of staying in
+// LDS; 4 picks them up and runs the rest on one wave (all-rows-active Hessian included).  The host launches 3 for the NEXT step
 // right behind the current step, so that it runs while the host is between two env.step() calls.
 template <int VARIANT, int FEAT>
 __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3 || VARIANT == 5) ? 128 : 64)
@@ -902,8 +902,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   };
   int eplen = a.ar.episode_len ? a.ar.episode_len[env] : 0, epcur = a.ar.episode_len ? a.ar.cursor[env] : 0;
   // POST (the second half of a split step): everything the previous launch left in the pre buffer is fetched here, in one batch --
-  // the mass-matrix row, the bias force and the all-rows-active Hessian into registers, contact count, coupling flag, row constants
-  // and Jacobian rows into the LDS arrays the rest of the step reads
+  // the mass-matrix row and the bias force into registers; contact count, coupling flag, row constants and Jacobian rows into the
+  // LDS arrays the rest of the step reads (by the collision wave in the rotated launch, which then accumulates the all-rows-active
+  // Hessian from them while this wave starts on the action)
   f4 pre_m[4] = {};
   float pre_bias = 0.0f;
   if (POST || ROT) {

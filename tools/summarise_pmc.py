@@ -52,7 +52,8 @@ def main():
     if kf is not None:
         corrected = 1024.0 * (kf * fetch["median_KB_per_launch"] + kw * write["median_KB_per_launch"])
         out["hbm_bytes_per_launch"] = corrected
-        out["note"] = ("separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over `bench.py --core-only --raw-only`; per-launch medians in the "
+        loop = "`bench.py --core-only` (the GenesisEnv.step loop)" if os.environ.get("MIR_PMC_KERNEL") else "`bench.py --core-only --raw-only`"
+        out["note"] = (f"separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over {loop}; per-launch medians in the "
                        "KB units rocprofv3 reports, each multiplied by the factor that makes the same counter read 64 MiB on the "
                        "calibration copy, which has this kernel's access width (4 B per lane)")
     else:
