@@ -668,8 +668,8 @@ def worker(args) -> int:
                                        "kernel": "mir_step_kernel<5, true>", "kernel_us": rot_us, "kernel_us_regions": rot_all, "kernel_us_without_outputs": rot_us_bare,
                                        "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
                                        "note": "the kernel of the headline loop: the rotated launch of GenesisEnv.step (this step's action-dependent "
-                                               "half, then the next step's action-independent half through a 5.8 KB/env scratch row, which is why its "
-                                               "traffic is several times the 489 algorithmic B/env-step: bytes spent to take ~8 us of work out of the "
+                                               "half, then the next step's action-independent half through a 4.7 KB/env scratch row (~2.4 KB used), which is why its "
+                                               "traffic is several times the 489 algorithmic B/env-step: bytes spent to take ~7 us of work out of the "
                                                "host-visible latency); kernel_us = HIP events around 1000 back-to-back launches (mir_debug_rotated_launches) that write the "
                                                "same outputs as GenesisEnv.step's, launch gap included; median of three such regions"}
                     out["roofline_fused_launch"] = fused
