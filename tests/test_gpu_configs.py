@@ -172,6 +172,45 @@ def test_cfg1_num_envs_1_through_genesis_env(franka_spec):
     assert worst < 1e-4
 
 
+# ---------------------------------------------------------------- cfg 3: 32768 envs as 8 shards of 4096
+def test_cfg3_32768_envs_as_eight_shards_equal_the_unsharded_batch():
+    """configs[2]: the global batch of 32768 envs split 8 ways along the env axis.  The eight shards (GenesisEnv(shard=(r, 8)), one
+    after the other on this GPU -- the shards never exchange anything, so running them in turn is the same computation as running
+    them on eight GPUs) against the unsharded 32768-env batch: same reset stream, 40 steps of shared random actions plus a
+    reset-all in the middle, every observation, reward and mask bit for bit."""
+    from gym_genesis.env import GenesisEnv
+
+    Bg, W, T = 32768, 8, 40
+    full = GenesisEnv(task="cube_pick", robot="franka", num_envs=Bg, enable_pixels=False)
+    dev = full._env.device
+    g = torch.Generator(device=dev).manual_seed(7)
+    acts = torch.empty((T, Bg, 9), device=dev).uniform_(-1, 1, generator=g)
+
+    def run(env, lo, hi):
+        out = []
+        obs, _ = env.reset(seed=5)
+        out.append(torch.cat([obs["agent_pos"], obs["environment_state"]], 1).clone())
+        for t in range(T):
+            if t == T // 2:
+                obs, _ = env.reset()
+                out.append(torch.cat([obs["agent_pos"], obs["environment_state"]], 1).clone())
+            obs, reward, terminated, truncated, info = env.step(acts[t, lo:hi].contiguous())
+            out.append(torch.cat([obs["agent_pos"], obs["environment_state"], reward[:, None],
+                                  torch.as_tensor(terminated, device=dev)[:, None].float()], 1).clone())
+        return out
+
+    ref = run(full, 0, Bg)
+    del full
+    for r in range(W):
+        env = GenesisEnv(task="cube_pick", robot="franka", num_envs=Bg, enable_pixels=False, shard=(r, W))
+        lo, hi = env._env.shard_lo, env._env.shard_hi
+        assert (lo, hi) == (r * 4096, (r + 1) * 4096) and env.num_envs == 4096
+        got = run(env, lo, hi)
+        for k, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b[lo:hi]), f"shard {r}, record {k}"
+        del env
+
+
 # ---------------------------------------------------------------- the chaos yardstick
 def test_yardstick_kernel_is_as_close_to_float64_as_a_float32_cpu_port(franka_spec):
     """Random joint targets every step make the arm chaotic: ANY float32 implementation drifts from the float64 trajectory.
