@@ -184,6 +184,30 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
   WSYNC();
 }
 
+// One env's rows along a Newton direction: this lane's share of the cost decrease of the step al * s in the 1-D model, and the
+// number of its rows whose sign the step changes.  With a = min(x, 0) the cost of a row is 1/2 D a^2 and its change
+// 1/2 D (a1 - a0)(a1 + a0), where a1 - a0 is the step d itself while the row stays active: never a difference of squares (a step
+// below the resolution of jar must yield a correctly tiny improvement, not an absorbed one).
+__device__ __forceinline__ void step_rows(float al, float j0, float j1, float j2, float j3, float v0, float v1, float v2, float v3, float cD, float ljar, float ljv,
+                                          float lD, float lsg, float& pim, float& crossed) {
+  const float jr[4] = {j0, j1, j2, j3}, vr[4] = {v0, v1, v2, v3};
+  pim = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const float x0 = jr[r], d = al * vr[r], x1 = x0 + d;
+    const float a0 = fminf(x0, 0.0f), a1 = fminf(x1, 0.0f);
+    pim -= 0.5f * cD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0);
+  }
+  {
+    const float x0 = ljar, d = al * ljv, x1 = x0 + d;
+    const float a0 = fminf(x0, 0.0f), a1 = fminf(x1, 0.0f);
+    pim -= 0.5f * lD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0);
+  }
+  crossed = ((ljar < 0.0f) != (ljar + al * ljv < 0.0f)) && lsg != 0.0f ? 1.0f : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; r++) crossed += ((jr[r] < 0.0f) != (jr[r] + al * vr[r] < 0.0f)) ? 1.0f : 0.0f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // SINGLE = one full step per launch without the rollout / autoreset / per-stage-output options (the headline launch): the
 // step loop disappears at compile time, and with it the block of scalar-register spills that the loop structure forces in
@@ -1470,6 +1494,25 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       const float A = gsum(sv * mv), Bq = gsum(sv * (Ma - qfs)), g0 = gsum(sv * g);
       bool lsdone = done || g0 >= 0.0f;
       float alpha = lsdone ? 0.0f : 1.0f, lo = 0.0f, hi = -1.0f;
+      // improvement of a step alpha s from the 1-D model (exact: phi is piecewise quadratic) and the number of rows whose sign it
+      // changes.  Row-cost differences are formed as 1/2 D d (2 x0 + d) with d = alpha jv, never as a difference of squares: a
+      // step below the resolution of jar must yield a (correctly) tiny improvement, not an absorbed one
+      // (with a = min(x, 0) the cost of a row is 1/2 D a^2, and its change 1/2 D (a1 - a0)(a1 + a0); a1 - a0 is the step d
+      //  itself while the row stays active)
+      auto step_gain = [&](float al, float& gain, float& ncr) __attribute__((always_inline)) {
+        float pim, crossed;
+        step_rows(al, jar[0], jar[1], jar[2], jar[3], jv[0], jv[1], jv[2], jv[3], cD, ljar, ljv, lD, lsg, pim, crossed);
+        gain = gsum(pim) - (0.5f * al * al * A + al * Bq);
+        ncr = gsum(crossed);  // (the two reductions are independent and overlap)
+      };
+      // The full Newton step first.  Where it crosses no row boundary it IS the minimiser along s; where it does, it is taken as it
+      // is when it realises at least a quarter of the decrease the quadratic piece at alpha = 0 predicts for it (-g0 / 2): the
+      // search below then has nothing to do for that env, and a wave whose envs all accept skips it.  (The fixed point is the
+      // same minimiser; the oracle keeps the exact search, and the parity tests hold the two together.)
+      float improvement, ncross;
+      step_gain(alpha, improvement, ncross);
+      const float alpha0 = alpha;
+      lsdone = lsdone || improvement > -0.125f * g0;
       for (int ls = 1; ls < mdl_ls_iterations && __any(!lsdone); ls++) {  // (ls counts evaluations of phi', the one at 0 included)
         float pg = 0.0f, ph = 0.0f, pa = 0.0f;
 #pragma unroll
@@ -1506,32 +1549,15 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       }
       if (it == 0) STAMP(20);
       ITSTAMP(it, 6);
-      // ---- improvement from the 1-D model, then the update.  Row-cost differences are formed as
-      // 1/2 D d (2 x0 + d) with d = alpha jv, never as a difference of squares: a step below the
-      // resolution of jar must yield a (correctly) tiny improvement, not an absorbed one
-      float pim = 0.0f;
-#pragma unroll
-      // (with a = min(x, 0) the cost of a row is 1/2 D a^2, and its change 1/2 D (a1 - a0)(a1 + a0); a1 - a0 is the step d
-      //  itself while the row stays active)
-      for (int r = 0; r < 4; r++) {
-        const float x0 = jar[r], d = alpha * jv[r], x1 = x0 + d;
-        const float a0 = fminf(x0, 0.0f), a1 = fminf(x1, 0.0f);
-        pim -= 0.5f * cD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0);
+      // ---- improvement of the step the search settled on (envs that took the full step have theirs already), then the update
+      if (__any(alpha != alpha0)) {
+        float gi, gc;
+        step_gain(alpha, gi, gc);
+        if (alpha != alpha0) { improvement = gi; ncross = gc; }
       }
-      {
-        const float x0 = ljar, d = alpha * ljv, x1 = x0 + d;
-        const float a0 = fminf(x0, 0.0f), a1 = fminf(x1, 0.0f);
-        pim -= 0.5f * lD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0);
-      }
-      // (rows whose sign the step changes, from the same x0 / x1: the three reductions of this block are independent and overlap)
-      float crossed = ((ljar < 0.0f) != (ljar + alpha * ljv < 0.0f)) && lsg != 0.0f ? 1.0f : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 4; r++) crossed += ((jar[r] < 0.0f) != (jar[r] + alpha * jv[r] < 0.0f)) ? 1.0f : 0.0f;
-      const float improvement = gsum(pim) - (0.5f * alpha * alpha * A + alpha * Bq);
       // float32 resolution: if no dof's acceleration changes, or the gradient has stopped shrinking
       // within a few floors of its rounding level, further iterations are noise
       const float moved = gsum((isdof && qacc + alpha * sv != qacc) ? 1.0f : 0.0f);
-      const float ncross = gsum(crossed);
       const bool stagnant = it > 0 && gn > 0.5f * gprev && gn < 4.0f * gfloor;
       gprev = gn;
       if (!done && (moved == 0.0f || stagnant)) { done = true; niter = it + 1; }
