@@ -643,7 +643,8 @@ def worker(args) -> int:
                 try:
                     mir = task._mir
                     task.reset()
-                    # (the launches write what GenesisEnv.step's write: the four outputs and the host-visible terminated bytes)
+                    # (the launches write the four outputs of a GenesisEnv.step launch; not its host-visible terminated bytes, which
+                    # back to back and with nobody reading them time the PCIe write path instead of the kernel)
                     outs_api = (mir.empty(9), mir.empty(11), mir.empty(), mir.empty(dtype=torch.uint8))
                     mir.rotated_launches(actions, 50, outputs=outs_api)
                     torch.cuda.synchronize(dev)
@@ -671,7 +672,7 @@ def worker(args) -> int:
                                                "half, then the next step's action-independent half through a 4.7 KB/env scratch row (~2.4 KB used), which is why its "
                                                "traffic is several times the 489 algorithmic B/env-step: bytes spent to take ~7 us of work out of the "
                                                "host-visible latency); kernel_us = HIP events around 1000 back-to-back launches (mir_debug_rotated_launches) that write the "
-                                               "same outputs as GenesisEnv.step's, launch gap included; median of three such regions"}
+                                               "same device outputs as GenesisEnv.step's, launch gap included; median of three such regions"}
                     out["roofline_fused_launch"] = fused
                 except Exception as e:  # noqa: BLE001
                     out["roofline_api_kernel_error"] = f"{type(e).__name__}: {e}"

@@ -358,8 +358,8 @@ class MirScene(StepHelpers):
 
     def rotated_launches(self, actions: torch.Tensor, n: int, outputs=None) -> None:
         """mir_debug_rotated_launches: n back-to-back rotated launches cycling through actions (K,B,nu) (bench.py times them);
-        `outputs` = (agent_pos, env_state, reward, terminated) tensors: every launch also writes them and the host-visible
-        terminated bytes, like the launches of GenesisEnv.step."""
+        `outputs` = (agent_pos, env_state, reward, terminated) tensors: every launch also writes them, like the launches of
+        GenesisEnv.step (whose host-visible terminated bytes are left out: see mir_api.hip)."""
         outs = None if outputs is None else (C.c_void_p * 4)(*[t.data_ptr() for t in outputs])
         self._check(self.lib.mir_debug_rotated_launches(self.h, _ptr(actions), int(actions.shape[0]), int(n), outs, self._stream()))
 

@@ -387,7 +387,7 @@ int mir_debug_profile_next_step(MirHandle h, unsigned long long* prof);
 int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* out_us);
 /* n back-to-back launches of the rotated step kernel (split mode 1), cycling through n_actions (B, nu) action blocks, without
  * observation outputs -- or, with outputs = {agent_pos, env_state, reward, terminated} (device pointers, shapes as in
- * mir_step_fused), with the outputs and host-visible terminated bytes of a mir_step_go launch: lets two events time that kernel the way the fused one is timed (bench.py's roofline).  Advances the state
+ * mir_step_fused), with the four device outputs of a mir_step_go launch (not its host-visible bytes): lets two events time that kernel the way the fused one is timed (bench.py's roofline).  Advances the state
  * by n steps. */
 int mir_debug_rotated_launches(MirHandle h, const float* actions, int32_t n_actions, int32_t n, void* const* outputs, void* stream);
 int mir_debug_poison_lds(int device_id, void* stream);

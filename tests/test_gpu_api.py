@@ -209,7 +209,7 @@ def test_env_step_over_builtins_equals_env_step_over_ctypes_and_a_closed_scene_i
 
 
 def test_back_to_back_rotated_launches_with_outputs_equal_fused_steps(franka_spec):
-    """bench.py times the rotated kernel through mir_debug_rotated_launches with the outputs of a GenesisEnv.step launch: those
+    """bench.py times the rotated kernel through mir_debug_rotated_launches with the device outputs of a GenesisEnv.step launch: those
     launches must BE steps -- same state, same four outputs as fused launches fed the same actions -- and must not disturb the
     output registration (mir_step_prepare) a step closure made ahead of its next call."""
     from gym_genesis.backend.lib import MirScene
