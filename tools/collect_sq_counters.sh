@@ -15,7 +15,9 @@ done
 cd $R
 python3 - <<'PY'
 import csv, glob, collections, json
-for pat, kern, dst in (("gpurun_out/pmc_sq[0-9]*/*/*counter_collection.csv", "mir_step_kernel", "gpurun_out/sq_counters.json"),
+# (bench.py --core-only launches two instantiations: <0, .> in the raw loop, <5, .> -- the rotated kernel -- in the GenesisEnv.step loop)
+for pat, kern, dst in (("gpurun_out/pmc_sq[0-9]*/*/*counter_collection.csv", "mir_step_kernel<0", "gpurun_out/sq_counters.json"),
+                       ("gpurun_out/pmc_sq[0-9]*/*/*counter_collection.csv", "mir_step_kernel<5", "gpurun_out/sq_counters_rotated.json"),
                        ("gpurun_out/pmc_sqw*/*/*counter_collection.csv", "mir_step64_kernel", "gpurun_out/sq_counters_step64.json")):
     out = {}
     for f in glob.glob(pat):
