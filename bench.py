@@ -560,12 +560,17 @@ def worker(args) -> int:
         events = loop_fn is raw_loop
         loop_fn(W)
         first, ev_ms = timed(loop_fn, K, events)
-        reps = repeats_for(first, args.min_time) if first < args.min_time else 1  # (`first` is already the max over ranks)
         walls, evs = [first], [ev_ms]
-        for _ in range(reps - 1):
+        # (the regions are repeated until --min-time seconds are MEASURED, not a number of times derived from the first region: one
+        #  slow first region -- a stall of the shared host -- would otherwise cut the whole measurement short.  Every wall value is
+        #  already the maximum over the ranks, so all ranks take the same decisions.)
+        max_reps = repeats_for(0.0, args.min_time)
+        total = first
+        while total < args.min_time and len(walls) < max_reps:
             w, e = timed(loop_fn, K, events)
             walls.append(w)
             evs.append(e)
+            total += w
         return walls, evs
 
     out = None

@@ -208,13 +208,14 @@ def test_env_step_over_builtins_equals_env_step_over_ctypes_and_a_closed_scene_i
             e.step(a)
 
 
-def test_back_to_back_rotated_launches_with_outputs_equal_fused_steps(franka_spec):
+def test_back_to_back_rotated_launches_with_outputs_equal_fused_steps(franka_spec, monkeypatch):
     """bench.py times the rotated kernel through mir_debug_rotated_launches with the device outputs of a GenesisEnv.step launch: those
     launches must BE steps -- same state, same four outputs as fused launches fed the same actions -- and must not disturb the
     output registration (mir_step_prepare) a step closure made ahead of its next call."""
     from gym_genesis.backend.lib import MirScene
 
     B, K, n = 64, 5, 12
+    monkeypatch.setenv("MIR_SPLIT_STEP", "1")  # (rotated launches exist in this mode only, whatever the environment asks for)
     sc, ref = MirScene(franka_spec, B), MirScene(franka_spec, B)
     assert sc.split_step == 1
     _reset(sc, B); _reset(ref, B)
