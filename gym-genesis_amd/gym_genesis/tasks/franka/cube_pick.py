@@ -112,13 +112,14 @@ class FrankaCubePickBatch:
         """Cube spawn positions for the GLOBAL batch (so a sharded run draws the same stream as an
         unsharded one), float32 (B_global, 3)."""
         Bg = self.global_num_envs
-        x = self._random.uniform(0.45, 0.80, size=(Bg,))
-        y = self._random.uniform(-0.25, 0.25, size=(Bg,))
-        z = np.full((Bg,), 0.02)
-        return np.stack([x, y, z], axis=1).astype(np.float32)
+        out = np.empty((Bg, 3), dtype=np.float32)  # (x block, then y block, as the reference draws them; rounded to float32 once)
+        out[:, 0] = self._random.uniform(0.45, 0.80, size=(Bg,))
+        out[:, 1] = self._random.uniform(-0.25, 0.25, size=(Bg,))
+        out[:, 2] = 0.02
+        return out
 
     def reset(self):
-        pos = torch.from_numpy(self.sample_spawn()[self.shard_lo:self.shard_hi]).to(self.device)
+        pos = self._mir.staged(self.sample_spawn()[self.shard_lo:self.shard_hi])  # (pinned: the reset kernel reads it in place)
         self._mir.reset(pos, self._quat, self._home)  # set_pos/set_quat/set_qpos(zero_velocity) + PD targets = home
         self._mir.step(1)                             # the reference consumes one physics step in reset()
         return self.get_obs()
@@ -129,7 +130,7 @@ class FrankaCubePickBatch:
         Draws one spawn per env from the task RandomState exactly like reset() (so the host stream
         advances identically whether or not an env is selected); masked envs get the home pose, zero
         velocity and PD targets = home.  No physics step is consumed: the other envs must not advance."""
-        pos = torch.from_numpy(self.sample_spawn()[self.shard_lo:self.shard_hi]).to(self.device)
+        pos = self._mir.staged(self.sample_spawn()[self.shard_lo:self.shard_hi])  # (pinned: the reset kernel reads it in place)
         self._mir.reset(pos, self._quat, self._home, env_mask=env_mask)
         return self.get_obs()
 

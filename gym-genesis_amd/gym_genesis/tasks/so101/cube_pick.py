@@ -104,7 +104,7 @@ class CubePick:
         return np.stack([x, y, z], axis=1).astype(np.float32)
 
     def reset(self):
-        pos = torch.from_numpy(self.sample_spawn()[self.shard_lo:self.shard_hi]).to(self.device)
+        pos = self._mir.staged(self.sample_spawn()[self.shard_lo:self.shard_hi])  # (pinned: the reset kernel reads it in place)
         self._mir.reset(pos, self._quat, self._zero)  # no scene.step() here (so101/cube_pick.py:81)
         return self.get_obs()
 

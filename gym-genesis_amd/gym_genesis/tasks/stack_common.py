@@ -111,7 +111,7 @@ class StackTaskBase:
         self.action_space.seed(seed)
 
     def reset(self):
-        pos = torch.from_numpy(self.sample_spawn()[self.shard_lo:self.shard_hi]).to(self.device)
+        pos = self._mir.staged(self.sample_spawn()[self.shard_lo:self.shard_hi])  # (pinned: the reset kernel reads it in place)
         self._mir.reset(pos, self._quat, self._home)  # set_pos/set_quat x5 + set_qpos(zero_velocity) + PD targets = home
         self._mir.step(1)                             # both references consume one physics step in reset()
         return self.get_obs()
@@ -119,7 +119,7 @@ class StackTaskBase:
     def reset_masked(self, env_mask):
         """Per-env reset without touching the other envs.  Draws one spawn per env from the task RandomState
         exactly like reset() (the host stream advances identically whether or not an env is selected); no physics step."""
-        pos = torch.from_numpy(self.sample_spawn()[self.shard_lo:self.shard_hi]).to(self.device)
+        pos = self._mir.staged(self.sample_spawn()[self.shard_lo:self.shard_hi])  # (pinned: the reset kernel reads it in place)
         self._mir.reset(pos, self._quat, self._home, env_mask=env_mask)
         return self.get_obs()
 

@@ -35,6 +35,9 @@ class OracleScene(StepHelpers):
     def _np(t):
         return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
+    def staged(self, rows):
+        return torch.from_numpy(np.ascontiguousarray(rows))
+
     def reset(self, obj_pos, obj_quat, arm_qpos, env_mask=None):
         assert env_mask is None
         self.o.reset(self._np(obj_pos), self._np(obj_quat), self._np(arm_qpos))
