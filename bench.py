@@ -451,6 +451,29 @@ def worker(args) -> int:
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # The stepping thread stays on the core it is on (single-rank runs; MIR_BENCH_PIN=0 switches it off): env.step is a host /
+    # device ping-pong of ~25 us, and every migration of the host thread costs it a cold cache in the middle of one.  Same box,
+    # five runs each, driver command: 159.5 M free, 162.1 M pinned (tools/probes/ab_pin.sh).  Ranks of a multi-GPU run are left to
+    # the scheduler: two of them could be sharing a core at this moment.
+    pinned_cpu, free_cpus = None, None
+    if world == 1 and os.environ.get("MIR_BENCH_PIN", "1") == "1":
+        try:
+            import ctypes
+            free_cpus = os.sched_getaffinity(0)
+            cpu = ctypes.CDLL(None).sched_getcpu()
+            if cpu >= 0:
+                os.sched_setaffinity(0, {cpu})
+                pinned_cpu = cpu
+        except Exception:  # noqa: BLE001
+            pinned_cpu = None
+
+    def unpin():
+        """Back to the affinity the process started with (the CPU baseline spreads over every core it may use)."""
+        if pinned_cpu is not None and free_cpus:
+            try:
+                os.sched_setaffinity(0, free_cpus)
+            except Exception:  # noqa: BLE001
+                pass
 
     use_pg = world > 1 or args.force_gather
     if use_pg:
@@ -604,7 +627,8 @@ def worker(args) -> int:
                        "world_size_observed": pg_world, "dist_backend": args.dist_backend if use_pg else None,
                        "obs_gather": (f"{args.dist_backend} all_gather of [agent_pos|environment_state|reward] of {S} steps per collective, "
                                       "overlapped with the following steps") if gather else "none",
-                       "terminated_sync_mode": task._mir.sync_mode, "split_step": int(getattr(task._mir, "split_step", 0))},
+                       "terminated_sync_mode": task._mir.sync_mode, "split_step": int(getattr(task._mir, "split_step", 0)),
+                       "host_thread": ("pinned to cpu %d for the headline and raw loops" % pinned_cpu) if pinned_cpu is not None else "not pinned"},
             "repeats": len(walls),
             "timed_steps_total": len(walls) * K,
             "timed_seconds_total": total_wall,
@@ -685,6 +709,7 @@ def worker(args) -> int:
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
             rc = 1
 
+        unpin()
         if rank == 0 and world == 1 and not args.core_only:
             _guard(out, "secondary", lambda: secondary_rates(torch, dev, env, task, actions, B))
             if not args.no_pixels:
