@@ -433,6 +433,10 @@ int mir_get_model_consts(MirHandle h, double* dof_invweight0, double* body_invwe
 
 int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const float* arm_qpos, const uint8_t* env_mask, void* stream) {
   if (check(h)) return MIR_E_INVALID;
+  if (h->pending) {  // (a step left open by an exception on the caller's side: see mir_step_begin)
+    int rc = mir_step_end(h, nullptr);
+    if (rc != MIR_OK) return rc;
+  }
   h->pre_valid = 0;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_reset, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
@@ -485,14 +489,21 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  * separate copy command.  The host is free between the two calls (the Python side allocates the next outputs there). */
 int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
   if (check(h)) return MIR_E_INVALID;
-  if (h->pending) return set_err(MIR_E_INVALID, "mir_step_begin: the previous mir_step_begin has not been closed by mir_step_end");
+  // a step left open (an exception between the two calls on the Python side) is closed here: its bytes are waited for and dropped
+  if (h->pending) {
+    int rc = mir_step_end(h, nullptr);
+    if (rc != MIR_OK) return rc;
+  }
   DeviceGuard guard(h->device);
   uint32_t* flag_dev = reinterpret_cast<uint32_t*>(h->pin_dev + ((size_t)(h->B + 63) / 64) * 64);
   Outs o;
   o.action = action; o.agent_pos = agent_pos; o.env_state = env_state; o.reward = reward; o.terminated = terminated;
   o.term_host = h->pin_dev;
   const uint32_t seq = h->seq + 1u;
-  o.term_tag = 1u + seq % 3u;  // 1, 2, 3, 1, ...: never 0 (fresh memory), never the tag of the previous launch
+  // The tag has a counter of its own that nothing else advances (h->seq is shared with mir_debug_null_roundtrip and wraps): 1 .. 127,
+  // never 0 (fresh memory), and a launch's tag differs from those of the 126 launches before it -- each of which overwrote every byte.
+  const uint32_t tag = h->tag % 127u + 1u;
+  o.term_tag = tag;
   if (h->sync_mode == 2) { o.done_ticket = h->done_ticket; o.done_flag = flag_dev; o.done_seq = seq; }
   // split step: if the previous mir_step_begin left the action-independent half of THIS step in `pre` (same stream, nothing
   // touched the state since), only the other half is launched now
@@ -506,6 +517,11 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   h->dbg_prof = nullptr;
   int rc = launch(h, o, stream);
   if (rc != MIR_OK) return rc;
+  // the launch that carries the tag is queued: from here on the step is pending whatever happens to the calls behind it
+  h->seq = seq;
+  h->tag = tag;
+  h->pending = 1;
+  h->pending_stream = stream;
   if (rotated) h->pre_valid = 1;  // (launch() cleared it; the same launch has refilled `pre` for the state it leaves)
   if (h->sync_mode == 1) {
     hipError_t e = hipStreamWriteValue32((hipStream_t)stream, flag_dev, seq, 0);
@@ -516,13 +532,10 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
     Outs p;
     p.phase = 1; p.diag = false;
     rc = launch(h, p, stream);
-    if (rc != MIR_OK) return rc;
+    if (rc != MIR_OK) return rc;  // (the step itself is queued and pending: the caller may still close it, or the next begin does)
     h->pre_valid = 1;
     h->pre_stream = stream;
   }
-  h->seq = seq;
-  h->pending = 1;
-  h->pending_stream = stream;
   return MIR_OK;
 }
 
@@ -539,8 +552,9 @@ int mir_step_prepare(MirHandle h, float* agent_pos, float* env_state, float* rew
 int mir_step_go(MirHandle h, const float* action, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   if (!h->prepared) return set_err(MIR_E_INVALID, "mir_step_go without mir_step_prepare");
-  h->prepared = 0;
-  return mir_step_begin(h, action, (float*)h->prep[0], (float*)h->prep[1], (float*)h->prep[2], (uint8_t*)h->prep[3], stream);
+  const int rc = mir_step_begin(h, action, (float*)h->prep[0], (float*)h->prep[1], (float*)h->prep[2], (uint8_t*)h->prep[3], stream);
+  if (rc == MIR_OK || h->pending) h->prepared = 0;  // (consumed once a launch is queued; a call that failed before that may be repeated)
+  return rc;
 }
 
 int mir_step_end(MirHandle h, uint8_t* terminated_host) {
@@ -558,7 +572,7 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
     // (a pointer that walks the buffer once, eight bytes at a time: it stands still at the first workgroup that has not delivered
     // yet and touches every cache line once after the device's last write to it; polling the whole buffer instead was measured
     // slower -- the host keeps pulling lines the device is still writing)
-    const uint8_t want = (uint8_t)(1u + h->seq % 3u);
+    const uint8_t want = (uint8_t)h->tag;
     const uint64_t want8 = 0x0101010101010101ull * want, tagm = 0x7f7f7f7f7f7f7f7full;
     const volatile uint64_t* w8 = reinterpret_cast<const volatile uint64_t*>(bytes);
     const size_t nw = B / 8;

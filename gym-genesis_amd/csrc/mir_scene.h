@@ -27,7 +27,8 @@ struct MirScene {
   uint8_t* pin_host;        // host address
   uint8_t* pin_dev;         // the same memory as the device sees it
   uint32_t* done_ticket;    // device counter for the kernel-side completion (sync mode 2)
-  uint32_t seq;             // sequence number of the last mir_step_begin
+  uint32_t seq;             // sequence number of the completion word (sync modes 1 / 2, mir_debug_null_roundtrip)
+  uint32_t tag;             // tag of the last mir_step_begin's terminated bytes, 1..127; advances in mir_step_begin ONLY
   int sync_mode;            // 0 hipStreamSynchronize, 1 stream write-value + host spin, 2 kernel-side ticket + host spin
   int diag_on;              // step kernels write the per-env diagnostics (mir_set_diag)
   int pending;              // a mir_step_begin is waiting for its mir_step_end

@@ -58,5 +58,5 @@ struct StepArgs {
 
 
 // enqueue the fused kernel on `stream`; returns a hipError_t as int
-extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipStream_t stream);
-extern "C" int mir_launch_debug_convex(const float* in, float* out, int n, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) int mir_launch_debug_convex(const float* in, float* out, int n, hipStream_t stream);

@@ -1744,7 +1744,7 @@ static void launch_feat(const StepArgs& a, int blocks, int single, int plain_loo
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
 }
-extern "C" int mir_launch_step_convex(const StepArgs* args, int single, int plain_loop, hipStream_t stream) {
+extern "C" __attribute__((visibility("hidden"))) int mir_launch_step_convex(const StepArgs* args, int single, int plain_loop, hipStream_t stream) {
   StepArgs a = *args;
   const int blocks = (a.B + EPB - 1) / EPB;
   if (a.features & 2) launch_feat<3>(a, blocks, single, plain_loop, stream);  // sweep-and-prune scenes carry the convex code too
@@ -1752,7 +1752,7 @@ extern "C" int mir_launch_step_convex(const StepArgs* args, int single, int plai
   return (int)hipGetLastError();
 }
 #else
-extern "C" int mir_launch_step_convex(const StepArgs* args, int single, int plain_loop, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) int mir_launch_step_convex(const StepArgs* args, int single, int plain_loop, hipStream_t stream);
 extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipStream_t stream) {
   StepArgs a = *args;
   int blocks = (a.B + EPB - 1) / EPB;

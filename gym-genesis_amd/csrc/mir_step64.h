@@ -40,4 +40,4 @@ struct StepArgs64 {
   int n_steps;  // mode 0 only
 };
 
-extern "C" int mir_launch_step64(const StepArgs64* args, hipStream_t stream);
+extern "C" __attribute__((visibility("hidden"))) int mir_launch_step64(const StepArgs64* args, hipStream_t stream);

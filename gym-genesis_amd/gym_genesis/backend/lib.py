@@ -233,7 +233,9 @@ class MirScene(StepHelpers):
         """Accept torch (any device) or NumPy, return a contiguous f32 device tensor (B, *cols)."""
         if not isinstance(t, torch.Tensor):
             t = torch.as_tensor(np.asarray(t))
-        if not (t.device.type == "cpu" and t.dtype is torch.float32 and t.is_contiguous() and t.is_pinned()):  # (staged(): read in place)
+        # (a buffer handed out by staged() is read in place by the kernel -- its reuse is guarded by an event; any other host
+        #  tensor, pinned or not, is copied: the caller may overwrite it as soon as this call returns)
+        if not (t.device.type == "cpu" and t.data_ptr() in self.__dict__.get("_staged_ptrs", ())):
             t = t.to(device=self.device, dtype=torch.float32).contiguous()
         if t.shape != (self.num_envs, *cols):
             raise ValueError(f"expected shape {(self.num_envs, *cols)}, got {tuple(t.shape)}")
@@ -257,6 +259,7 @@ class MirScene(StepHelpers):
         if slot is None:
             slot = ring[rows.shape] = {"buf": [torch.empty(rows.shape, dtype=torch.float32).pin_memory() for _ in range(2)],
                                        "ev": [torch.cuda.Event(), torch.cuda.Event()], "used": [False, False], "k": 0}
+            self.__dict__.setdefault("_staged_ptrs", set()).update(b.data_ptr() for b in slot["buf"])
         k = slot["k"]
         slot["k"] = k ^ 1
         if slot["used"][k]:

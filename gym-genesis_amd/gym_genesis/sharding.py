@@ -33,22 +33,30 @@ def unpack_rows(rows: torch.Tensor, agent_dim: int = 9, env_dim: int = 11):
     return obs, reward, terminated
 
 
+_COUNTS: dict = {}  # (group, world, local rows) -> rows per rank, for gather_rows(num_envs=None)
+
+
 def gather_rows(rows: torch.Tensor, group=None, num_envs: int | None = None) -> torch.Tensor:
     """All-gather the row blocks of all ranks into the global (B, D) tensor (rank order = env order).
 
     shard_bounds gives ranks blocks that differ by one row when num_envs % world != 0, and all_gather_into_tensor needs
     equal blocks: every rank pads its block to the largest one (ceil(num_envs / world)) and the padding is dropped after
-    the collective.  `num_envs` = the global batch; without it the blocks must be equal (checked with a second, tiny
-    collective only when a rank could otherwise hang)."""
+    the collective.  `num_envs` = the global batch (what the callers on the data path pass: the block sizes then follow from
+    shard_bounds, no communication).  Without it the ranks exchange their block sizes ONCE per (group, local size) -- one small
+    collective and one host read -- and the answer is cached (so the block sizes of a group must not change between calls;
+    pass `num_envs` where they can)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return rows
     world = dist.get_world_size(group)
     n = rows.shape[0]
     if num_envs is None:
-        sizes = torch.tensor([n], dtype=torch.int64, device=rows.device)
-        all_sizes = torch.empty((world,), dtype=torch.int64, device=rows.device)
-        dist.all_gather_into_tensor(all_sizes, sizes, group=group)
-        counts = [int(c) for c in all_sizes.tolist()]
+        ck = (id(group) if group is not None else None, world, n)
+        counts = _COUNTS.get(ck)
+        if counts is None:
+            sizes = torch.tensor([n], dtype=torch.int64, device=rows.device)
+            all_sizes = torch.empty((world,), dtype=torch.int64, device=rows.device)
+            dist.all_gather_into_tensor(all_sizes, sizes, group=group)
+            counts = _COUNTS[ck] = [int(c) for c in all_sizes.tolist()]
     else:
         counts = [shard_bounds(num_envs, r, world)[1] - shard_bounds(num_envs, r, world)[0] for r in range(world)]
         if counts[dist.get_rank(group)] != n:

@@ -4,6 +4,9 @@ Every Python frame and attribute lookup between two launches is time the GPU idl
 pre-bound callables.  Order: validate the action, launch (mir_step_go: the outputs were registered while the previous kernel
 ran), then -- while this kernel runs -- make everything the API returns besides `terminated` and prepare the next call, then
 wait for the launch's terminated bytes (mir_step_end) and return.
+
+The outputs registered for the NEXT launch live in the scene's one slot cache (`mir._fresh`, shared with StepHelpers.step_fresh:
+whoever registered last is what the library holds), and an exception between launch and wait closes the step before it propagates.
 """
 import numpy as np
 import torch
@@ -19,7 +22,8 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
     B, dev, tensor, f32, tbool = task.num_envs, task.device, torch.Tensor, torch.float32, torch.bool
     shape = torch.Size((B, action_dim))
     np_empty, np_zeros, np_bool = np.empty, np.zeros, np.bool_
-    nxt = [None]
+    fresh = mir.__dict__.setdefault("_fresh", {})   # the scene's slot cache: the outputs registered with the library for the next launch
+    key = (agent_obs, env_obs, True)
 
     def fast_step(action):
         if not (type(action) is tensor and action.dtype is f32 and action.shape == shape and action.is_contiguous()
@@ -27,21 +31,26 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
             if coerce is not None:
                 action = coerce(action)
             action = as_action(action, action_dim)
-        slot = nxt[0]
+        slot = fresh.pop(key, None)
         if slot is None:
             slot = alloc(agent_obs, env_obs)
             prepare(slot[1])
         go(action.data_ptr())
         # ---- the kernel is running: nothing below is on the critical path until end()
-        outs = slot[0]
-        host = np_empty(B, np_bool)
-        n = alloc(agent_obs, env_obs)
-        prepare(n[1])
-        nxt[0] = n
-        task._agent, task._envst, task._reward, task._term = outs
-        observation = {"agent_pos": outs[0], "environment_state": outs[1]}
-        info = {"is_success": outs[3].view(tbool)}
-        truncated = np_zeros(B, np_bool)
+        try:
+            outs = slot[0]
+            host = np_empty(B, np_bool)
+            n = alloc(agent_obs, env_obs)
+            prepare(n[1])
+            fresh[key] = n
+            task._agent, task._envst, task._reward, task._term = outs
+            observation = {"agent_pos": outs[0], "environment_state": outs[1]}
+            info = {"is_success": outs[3].view(tbool)}
+            truncated = np_zeros(B, np_bool)
+        except BaseException:
+            fresh.pop(key, None)
+            end(0)  # (close the step: the env stays usable)
+            raise
         end(host.ctypes.data)
         return observation, outs[2], host, truncated, info
 
@@ -62,7 +71,7 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
                 action = coerce(action)
             action = as_action(action, action_dim)
         h = hbox[0]
-        slot = nxt[0]
+        slot = fresh.pop(key, None)
         if slot is None:
             slot = alloc(agent_obs, env_obs)
             p = slot[1]
@@ -73,17 +82,22 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
         if rc:
             check(rc)
         # ---- the kernel is running
-        outs = slot[0]
-        host = np_empty(B, np_bool)
-        host_ptr = host.ctypes.data
-        n = alloc(agent_obs, env_obs)
-        p = n[1]
-        rc = fprepare(h, p[0], p[1], p[2], p[3])
-        if rc:
-            check(rc)
-        nxt[0] = n
-        task._agent, task._envst, task._reward, task._term = outs
-        result = ({"agent_pos": outs[0], "environment_state": outs[1]}, outs[2], host, np_zeros(B, np_bool), {"is_success": outs[3].view(tbool)})
+        try:
+            outs = slot[0]
+            host = np_empty(B, np_bool)
+            host_ptr = host.ctypes.data
+            n = alloc(agent_obs, env_obs)
+            p = n[1]
+            rc = fprepare(h, p[0], p[1], p[2], p[3])
+            if rc:
+                check(rc)
+            fresh[key] = n
+            task._agent, task._envst, task._reward, task._term = outs
+            result = ({"agent_pos": outs[0], "environment_state": outs[1]}, outs[2], host, np_zeros(B, np_bool), {"is_success": outs[3].view(tbool)})
+        except BaseException:
+            fresh.pop(key, None)
+            fend(h, 0)  # (close the step: the env stays usable)
+            raise
         rc = fend(h, host_ptr)
         if rc:
             check(rc)

@@ -231,11 +231,14 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  * terminated bytes into a pinned host buffer owned by the handle, straight from the kernel (no copy command);
  * mir_step_end blocks until THAT launch has delivered its terminated bytes and copies the B bytes into terminated_host (plain
  * host memory, nullable).  In mode 3 the kernel stores those bytes before its device-side outputs, so the other outputs of the
- * launch are ordered by the stream as after any launch (a later launch, copy or synchronize on it sees them), not by this call.  Between the two calls the host is free (the Python side prepares its return values there).  Exactly one
- * mir_step_end per mir_step_begin; the only entry point of the library that waits for the device.
+ * launch are ordered by the stream as after any launch (a later launch, copy or synchronize on it sees them), not by this call.  Between the two calls the host is free (the Python side prepares its return values there).
+ * One mir_step_end per mir_step_begin; a step left open (the caller raised between the two calls) is closed by the next
+ * mir_step_begin / mir_step_go / mir_reset, which wait for its bytes and drop them.  mir_step_end is otherwise the only entry point
+ * of the library that waits for the device.
  * How the wait is done (mir_get_sync_mode; environment variable MIR_SYNC_MODE overrides at mir_create):
- *   3  (default) every terminated byte carries a tag that changes from launch to launch; the host spins until all B bytes
- *      show the tag of this launch -- no fence, no flag, nothing in the kernel waits for the PCIe acknowledgement
+ *   3  (default) every terminated byte carries a 7-bit tag (1..127, a counter only mir_step_begin advances) that changes from
+ *      launch to launch; the host spins until all B bytes show the tag of this launch -- no fence, no flag, nothing in the kernel
+ *      waits for the PCIe acknowledgement
  *   2  every wave waits for its host store, the kernel's last workgroup then writes a sequence word into pinned host memory
  *      and the host spins on it (16-lane kernel only)
  *   1  hipStreamWriteValue32 behind the launch writes that word, the host spins on it
@@ -255,7 +258,8 @@ int mir_get_sync_mode(MirHandle h);
 int mir_get_split_step(MirHandle h);
 /* mir_step_begin with the four output pointers registered ahead of time (mir_step_prepare touches no device state and is meant to
  * be called while the previous step's kernel is still running): the GPU idles in front of mir_step_go, which then takes three
- * arguments instead of seven.  One mir_step_prepare per mir_step_go. */
+ * arguments instead of seven.  One mir_step_prepare per mir_step_go (the registration is consumed when a launch is queued; the
+ * latest registration wins). */
 int mir_step_prepare(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated);
 int mir_step_go(MirHandle h, const float* action, void* stream);
 

@@ -50,18 +50,60 @@ def test_step_begin_end_equals_step_fused(franka_spec, monkeypatch, mode, B):
         assert torch.equal(x, y)
 
 
-def test_step_end_without_begin_and_double_begin_are_errors(franka_spec):
+def test_step_end_without_begin_is_an_error_and_an_open_step_is_closed_by_the_next_begin_or_reset(franka_spec):
+    """A step left open (the caller raised between begin and end) must not brick the scene: the next mir_step_begin / mir_reset
+    waits for its bytes and drops them.  The physics is that of two ordinary steps."""
     from gym_genesis.backend.lib import MirError, MirScene
 
-    sc = MirScene(franka_spec, 8)
+    sc, ref = MirScene(franka_spec, 8), MirScene(franka_spec, 8)
     _reset(sc, 8)
+    _reset(ref, 8)
     with pytest.raises(MirError):
         sc.step_end()
     bufs = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    rb = (ref.empty(9), ref.empty(11), ref.empty(), ref.empty(dtype=torch.uint8))
     sc.step_begin(None, *bufs)
+    sc.step_begin(None, *bufs)      # closes the open one first
+    host = sc.step_end()
+    ref.step_fused(None, *rb)
+    ref.step_fused(None, *rb)
+    assert host.shape == (8,) and np.array_equal(host, bufs[3].cpu().numpy().astype(bool))
+    for x, y in zip(sc.get_state(), ref.get_state()):
+        assert torch.equal(x, y)
+    sc.step_begin(None, *bufs)
+    _reset(sc, 8)                   # ... and so does a reset
     with pytest.raises(MirError):
-        sc.step_begin(None, *bufs)
+        sc.step_end()
+    sc.step_begin(None, *bufs)
     assert sc.step_end().shape == (8,)
+
+
+def test_terminated_tag_survives_every_other_user_of_the_sequence_counter(franka_spec):
+    """The tag of the host-visible terminated bytes has its own counter: 2001 null round trips between two steps (bench.py does
+    exactly that) used to leave the next launch with the tag already in the buffer, and mir_step_end returned the PREVIOUS step's
+    mask before the kernel had written anything.  Step 1 leaves all-False bytes, step 2 must deliver all-True."""
+    from gym_genesis.backend.lib import MirScene
+
+    B = 4096
+    sc = MirScene(franka_spec, B)
+    bufs = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    for n_null in (2001, 3, 126, 127, 1):
+        _reset(sc, B, seed=1)
+        q = sc.get_state()[0]
+        q[:, 11] = 0.02                                   # every cube on the floor: terminated all False
+        sc.set_state(qpos=q)
+        sc.step_begin(None, *bufs)
+        assert not sc.step_end().any()
+        sc.null_roundtrip_us(n_null)
+        q[:, 11] = 0.5                                    # every cube released well above the threshold: all True
+        sc.set_state(qpos=q)
+        sc.step_begin(None, *bufs)
+        host = sc.step_end()
+        assert host.all(), f"{n_null} null round trips: stale terminated bytes were accepted ({int(host.sum())} of {B} True)"
+    for _ in range(300):                                  # more steps than there are tags
+        sc.step_begin(None, *bufs)
+        host = sc.step_end()
+        assert np.array_equal(host, bufs[3].cpu().numpy().astype(bool))
 
 
 def test_env_step_returns_fresh_host_masks_every_call():
@@ -242,3 +284,80 @@ def test_back_to_back_rotated_launches_with_outputs_equal_fused_steps(franka_spe
     for x, y in zip(ahead, b2):
         assert torch.equal(x, y)
     assert np.array_equal(host, b2[3].cpu().numpy().astype(bool))
+
+
+def test_task_step_begin_between_two_env_steps_does_not_leave_the_closure_with_unwritten_outputs():
+    """The library holds ONE registration of output pointers (mir_step_prepare) and two Python callers make them: the env.step
+    closure and task.step_begin.  They share the scene's slot cache, so whichever registered last is what the next launch uses
+    and returns."""
+    from gym_genesis.env import GenesisEnv
+
+    B = 32
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
+    env.reset(seed=0)
+    task = env._env
+    a = torch.as_tensor(np.random.default_rng(0).uniform(-1, 1, (6, B, 9)).astype(np.float32), device=task.device)
+    env.step(a[0])
+    task.step_begin(a[1])
+    task.step_end()
+    obs, reward, terminated, _, _ = env.step(a[2])
+    agent, envst, rew, term = task._mir.get_obs()
+    assert torch.equal(obs["agent_pos"], agent) and torch.equal(obs["environment_state"], envst) and torch.equal(reward, rew)
+    assert np.array_equal(terminated, term.cpu().numpy().astype(bool))
+    task.step(a[3])
+    obs, reward, terminated, _, _ = env.step(a[4])
+    agent, envst, rew, term = task._mir.get_obs()
+    assert torch.equal(obs["agent_pos"], agent) and torch.equal(obs["environment_state"], envst)
+
+
+def test_exception_inside_env_step_leaves_the_env_usable(monkeypatch):
+    """An exception between launch and wait (out of memory in the allocation of the next outputs, KeyboardInterrupt) closes the
+    step before it propagates; the next env.step works and the physics has advanced by exactly the launched step."""
+    from gym_genesis.env import GenesisEnv
+
+    B = 16
+    env, ref = (GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False) for _ in range(2))
+    env.reset(seed=0)
+    ref.reset(seed=0)
+    a = torch.zeros((B, 9), device=env._env.device)
+    env.step(a)
+    ref.step(a)
+    real = np.zeros
+    calls = {"n": 0}
+
+    def boom(*args, **kw):
+        calls["n"] += 1
+        raise MemoryError("injected")
+
+    monkeypatch.setattr("gym_genesis.tasks.fast_step.np.zeros", boom, raising=True)
+    # (the closure bound np.zeros at creation: rebuild it so that the injected failure is the one it calls)
+    env.step = env._env.make_fast_step()
+    with pytest.raises(MemoryError):
+        env.step(a)
+    monkeypatch.setattr("gym_genesis.tasks.fast_step.np.zeros", real, raising=True)
+    env.step = env._env.make_fast_step()
+    ref.step(a)
+    obs, _, terminated, _, _ = env.step(a)
+    robs, _, rterm, _, _ = ref.step(a)
+    assert calls["n"] == 1
+    assert torch.equal(obs["agent_pos"], robs["agent_pos"]) and np.array_equal(terminated, rterm)
+    env.reset()
+
+
+def test_pinned_host_inputs_are_copied_unless_they_come_from_staged(franka_spec):
+    """A caller's pinned tensor may be overwritten as soon as the call returns (the kernel must not read it in place); only
+    MirScene.staged() buffers, whose reuse an event guards, are read over PCIe by the reset kernel."""
+    from gym_genesis.backend.lib import MirScene
+
+    B = 2048
+    sc = MirScene(franka_spec, B)
+    _reset(sc, B)
+    q0 = sc.get_state()[0].cpu()
+    pinned = q0.clone().pin_memory()
+    for _ in range(20):
+        sc.set_state(qpos=pinned)
+        pinned.fill_(float("nan"))      # the caller reuses its buffer at once
+        assert torch.equal(sc.get_state()[0].cpu(), q0)
+        pinned.copy_(q0)
+    st = sc.staged(np.zeros((B, 3), np.float32))
+    assert st.is_pinned() and st.data_ptr() in sc._staged_ptrs
