@@ -70,6 +70,105 @@ def repeats_for(seconds_per_rep: float, min_time: float, max_reps: int = 2000) -
     return int(max(1, min(max_reps, -(-min_time // seconds_per_rep))))
 
 
+def parse_cpulist(text: str):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def rank_cpu_plan(local_rank: int, world: int, allowed, gpu_numa=None, numa_cpus=None):
+    """Which host cores rank `local_rank` of `world` takes: (sorted cores of its slice, the core of its stepping thread).
+
+    env.step is a ~25 us host / device ping-pong in which the host SPINS on the launch's terminated bytes (mir_step_end): every
+    rank needs a core of its own for that thread, close to its GPU, and its helper threads (HIP runtime, RCCL proxy, allocator)
+    must not share it.  The cores the process may use that belong to the NUMA node of the rank's GPU are split evenly among the
+    ranks whose GPUs sit on that node; without topology information (or with fewer than two such cores per rank) the allowed
+    cores are split evenly among all ranks.  Returns ([], None) when there are fewer allowed cores than ranks."""
+    allowed = sorted(allowed)
+    if len(allowed) < world or not (0 <= local_rank < world):
+        return [], None
+    group, pool = list(range(world)), allowed
+    if gpu_numa and numa_cpus and local_rank < len(gpu_numa) and gpu_numa[local_rank] is not None:
+        node = gpu_numa[local_rank]
+        peers = [r for r in range(world) if r < len(gpu_numa) and gpu_numa[r] == node]
+        near = sorted(set(numa_cpus.get(node, ())) & set(allowed))
+        if len(near) >= 2 * len(peers):
+            group, pool = peers, near
+    i, n = group.index(local_rank), len(group)
+    mine = pool[len(pool) * i // n:len(pool) * (i + 1) // n]
+    return mine, (mine[0] if mine else None)
+
+
+def gpu_numa_nodes():
+    """NUMA node of every GPU in HIP device order, from sysfs (no GPU call): the KFD topology lists the GPU nodes (simd_count > 0)
+    in the order the runtime enumerates them; *_VISIBLE_DEVICES given as integer lists re-map it.  None where unknown."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    nodes = []
+    try:
+        for n in sorted(os.listdir(base), key=int):
+            props = {}
+            with open(os.path.join(base, n, "properties")) as f:
+                for ln in f:
+                    k, _, v = ln.strip().partition(" ")
+                    props[k] = v
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            numa = None
+            try:
+                with open(f"/sys/class/drm/renderD{int(props['drm_render_minor'])}/device/numa_node") as f:
+                    numa = int(f.read())
+                if numa < 0:
+                    numa = None
+            except (OSError, KeyError, ValueError):
+                numa = None
+            nodes.append(numa)
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            try:
+                nodes = [nodes[int(x)] for x in v.split(",") if x.strip() != ""]
+            except (ValueError, IndexError):
+                return None
+    return nodes or None
+
+
+def numa_cpu_lists():
+    """{NUMA node: [cores]} from sysfs."""
+    out, base = {}, "/sys/devices/system/node"
+    try:
+        for d in os.listdir(base):
+            if d.startswith("node") and d[4:].isdigit():
+                with open(os.path.join(base, d, "cpulist")) as f:
+                    out[int(d[4:])] = parse_cpulist(f.read())
+    except OSError:
+        return {}
+    return out
+
+
+def move_other_threads(cpus, keep_tid: int) -> int:
+    """Affinity of every thread of this process except `keep_tid` <- cpus; returns how many were moved."""
+    moved = 0
+    try:
+        for t in os.listdir("/proc/self/task"):
+            tid = int(t)
+            if tid != keep_tid:
+                try:
+                    os.sched_setaffinity(tid, cpus)
+                    moved += 1
+                except OSError:
+                    pass
+    except OSError:
+        pass
+    return moved
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +187,8 @@ def parse_args(argv=None):
     ap.add_argument("--raw-only", action="store_true",
                     help="with --core-only: skip the API loop too, so that every mir_step_kernel launch in a trace is a raw launch")
     ap.add_argument("--force-gather", action="store_true", help="exercise the gather path even with one rank (plumbing check)")
+    ap.add_argument("--no-gather-ab", action="store_true",
+                    help="skip the second headline measurement WITHOUT the gather that gives `gather_overhead_us` (runs whenever a gather is on)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for plumbing checks)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="plumbing check: let several ranks share a GPU (device = LOCAL_RANK %% device_count; use with --dist-backend gloo)")
@@ -443,6 +544,23 @@ def worker(args) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # ---- host placement, part 1 (N > 1; BEFORE the first GPU call, so that every thread the HIP runtime, RCCL and torch create
+    # starts inside the rank's own cores): the cores this process may use that sit on the NUMA node of the rank's GPU, split among
+    # the ranks on that node (rank_cpu_plan).  MIR_BENCH_PIN=0 leaves everything to the scheduler.
+    pin_on = os.environ.get("MIR_BENCH_PIN", "1") == "1"
+    try:
+        free_cpus = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        free_cpus, pin_on = None, False
+    my_cpus, spin_cpu, gpu_numa = [], None, None
+    if world > 1 and pin_on:
+        try:
+            gpu_numa = gpu_numa_nodes()
+            my_cpus, spin_cpu = rank_cpu_plan(local_rank, world, free_cpus, gpu_numa, numa_cpu_lists())
+            if my_cpus:
+                os.sched_setaffinity(0, my_cpus)
+        except Exception:  # noqa: BLE001
+            my_cpus, spin_cpu = [], None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
     ndev = torch.cuda.device_count()
@@ -451,29 +569,51 @@ def worker(args) -> int:
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    # The stepping thread stays on the core it is on (single-rank runs; MIR_BENCH_PIN=0 switches it off): env.step is a host /
-    # device ping-pong of ~25 us, and every migration of the host thread costs it a cold cache in the middle of one.  Same box,
-    # five runs each, driver command: 159.5 M free, 162.1 M pinned (tools/probes/ab_pin.sh).  Ranks of a multi-GPU run are left to
-    # the scheduler: two of them could be sharing a core at this moment.
-    pinned_cpu, free_cpus = None, None
-    if world == 1 and os.environ.get("MIR_BENCH_PIN", "1") == "1":
+    placement = {"pinned_cpu": None, "helpers_moved": 0}
+
+    def pin_stepping_thread():
+        """Host placement, part 2 (called once everything that creates threads has run: process group, scene, first steps): the
+        stepping thread gets a core to itself.  env.step is a host / device ping-pong of ~25 us, and every migration of the host
+        thread costs it a cold cache in the middle of one (single rank, same box, five runs each, driver command: 159.5 M free,
+        162.1 M pinned; tools/probes/ab_pin.sh).  One rank: the core it is on.  N ranks: the first core of the rank's slice, and
+        every other thread of the process (HIP runtime, RCCL proxy) is moved to the rest of the slice -- the stepping thread
+        busy-waits in mir_step_end, and a helper thread scheduled behind it would wait for a time slice."""
+        if not pin_on:
+            return
         try:
-            import ctypes
-            free_cpus = os.sched_getaffinity(0)
-            cpu = ctypes.CDLL(None).sched_getcpu()
-            if cpu >= 0:
-                os.sched_setaffinity(0, {cpu})
-                pinned_cpu = cpu
+            if world == 1:
+                import ctypes
+                cpu = ctypes.CDLL(None).sched_getcpu()
+                if cpu >= 0:
+                    os.sched_setaffinity(0, {cpu})
+                    placement["pinned_cpu"] = cpu
+            elif spin_cpu is not None:
+                import threading
+                rest = set(my_cpus) - {spin_cpu}
+                if rest:
+                    placement["helpers_moved"] = move_other_threads(rest, threading.get_native_id())
+                os.sched_setaffinity(0, {spin_cpu})
+                placement["pinned_cpu"] = spin_cpu
         except Exception:  # noqa: BLE001
-            pinned_cpu = None
+            placement["pinned_cpu"] = None
 
     def unpin():
         """Back to the affinity the process started with (the CPU baseline spreads over every core it may use)."""
-        if pinned_cpu is not None and free_cpus:
+        if free_cpus:
             try:
                 os.sched_setaffinity(0, free_cpus)
             except Exception:  # noqa: BLE001
                 pass
+
+    def host_thread_note() -> str:
+        if placement["pinned_cpu"] is None:
+            return "not pinned"
+        if world == 1:
+            return "pinned to cpu %d for the headline and raw loops" % placement["pinned_cpu"]
+        numa = gpu_numa[local_rank] if gpu_numa and local_rank < len(gpu_numa) else None
+        return ("rank 0 of %d: stepping thread on cpu %d, %d helper threads on the other %d cores of its slice %s (NUMA node of its GPU: %s)"
+                % (world, placement["pinned_cpu"], placement["helpers_moved"], max(0, len(my_cpus) - 1),
+                   "%d-%d" % (my_cpus[0], my_cpus[-1]) if my_cpus else "-", "unknown" if numa is None else numa))
 
     use_pg = world > 1 or args.force_gather
     if use_pg:
@@ -499,7 +639,14 @@ def worker(args) -> int:
     actions.uniform_(-1.0, 1.0, generator=gen)
     act_list = list(actions.unbind(0))  # one (B, 9) device tensor per pre-drawn step: no view is built inside the timed loop
 
+    for t in range(4):  # (first launches: lazily created runtime threads exist before the stepping thread is pinned)
+        env.step(act_list[t])
+    env.reset(seed=0)
+    torch.cuda.synchronize(dev)
+    pin_stepping_thread()
+
     gather = use_pg and not args.no_gather
+    gather_on = [gather]  # (switched off for the A/B region that gives gather_overhead_us)
     S = max(1, args.gather_every)
     flat = B * 21  # agent_pos 9 + environment_state 11 + reward 1 per env (terminated == (reward == 1), env.py:63)
     gathered = [torch.empty((pg_world * S * flat,), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
@@ -509,7 +656,7 @@ def worker(args) -> int:
 
     def flush():
         """All-gather the outputs of the steps collected so far (async: overlaps the following steps)."""
-        if gather and chunk_parts:
+        if gather_on[0] and chunk_parts:
             s = state["chunk"] & 1
             if pending[s] is not None:
                 pending[s].wait()
@@ -523,7 +670,7 @@ def worker(args) -> int:
         t, step, n = state["t"], env.step, N_ACT
         for _ in range(k):
             obs, reward, terminated, truncated, info = step(act_list[t % n])
-            if gather:
+            if gather_on[0]:
                 chunk_parts.extend((obs["agent_pos"].reshape(-1), obs["environment_state"].reshape(-1), reward))
                 if len(chunk_parts) == 3 * S:
                     flush()
@@ -628,17 +775,39 @@ def worker(args) -> int:
                        "obs_gather": (f"{args.dist_backend} all_gather of [agent_pos|environment_state|reward] of {S} steps per collective, "
                                       "overlapped with the following steps") if gather else "none",
                        "terminated_sync_mode": task._mir.sync_mode, "split_step": int(getattr(task._mir, "split_step", 0)),
-                       "host_thread": ("pinned to cpu %d for the headline and raw loops" % pinned_cpu) if pinned_cpu is not None else "not pinned"},
+                       "host_thread": host_thread_note()},
             "repeats": len(walls),
             "timed_steps_total": len(walls) * K,
             "timed_seconds_total": total_wall,
             "best_repeat_value": K * B * world / min(walls),
+            # `value` is the MEAN over the repeated K-step regions (resets and whatever else the shared host does included); the
+            # median region is the figure that reproduces from run to run
+            "value_median_region": K * B * world / sorted(walls)[len(walls) // 2],
             # spread of the repeated K-step regions (us per step): the headline is their mean, resets included
             "repeat_us_per_step": {"min": min(walls) * 1e6 / K, "median": sorted(walls)[len(walls) // 2] * 1e6 / K,
                                    "p95": sorted(walls)[min(len(walls) - 1, (95 * len(walls)) // 100)] * 1e6 / K, "max": max(walls) * 1e6 / K},
             "resets_in_loop": state["resets"],
             "path": "GenesisEnv.step" if api_walls is not None else "task.step_raw (--raw-only)",
         }
+        # ---- what the observation gather costs: the same loop once more with the gather switched off (all ranks take this branch
+        # together: `gather` and the flag are the same everywhere) ---------------------------------------------------------
+        if gather and api_walls is not None and not args.no_gather_ab:
+            try:
+                sync_all()
+                gather_on[0] = False
+                ng_walls, _ = measure(api_loop)
+                gather_on[0] = True
+                us_g = sorted(walls)[len(walls) // 2] * 1e6 / K
+                us_ng = sorted(ng_walls)[len(ng_walls) // 2] * 1e6 / K
+                out["gather_overhead_us"] = us_g - us_ng
+                out["no_gather"] = {"value": len(ng_walls) * K * B * world / sum(ng_walls), "value_median_region": K * B * world / sorted(ng_walls)[len(ng_walls) // 2],
+                                    "median_us_per_step": us_ng, "median_us_per_step_with_gather": us_g, "repeats": len(ng_walls),
+                                    "note": "the headline loop with the observation gather switched off, measured right after the headline; "
+                                            "gather_overhead_us = difference of the median regions"}
+            except Exception as e:  # noqa: BLE001
+                gather_on[0] = True
+                out["gather_overhead_us"] = None
+                out["no_gather"] = {"error": f"{type(e).__name__}: {e}"}
         # ---- the bare fused launch over the same number of steps: hot_path_rate + kernel duration for the roofline ----
         try:
             state["t"] = 0
@@ -720,7 +889,8 @@ def worker(args) -> int:
                 _guard(out, "so101_pick", so101_bench, torch, dev)
                 _guard(out, "stack", stack_bench, torch, dev)
                 _guard(out, "ik", ik_bench, torch, dev)
-        if rank == 0 and world == 1 and not (args.no_cpu_baseline or args.core_only):
+        # (rank 0 of any world size: the other ranks wait at the final barrier, their host cores idle)
+        if rank == 0 and not (args.no_cpu_baseline or args.core_only):
             _guard(out, "cpu_baseline", cpu_baseline)
     except BaseException as e:  # noqa: BLE001
         rc = 1

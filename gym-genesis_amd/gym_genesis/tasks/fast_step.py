@@ -24,6 +24,9 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
     np_empty, np_zeros, np_bool = np.empty, np.zeros, np.bool_
     fresh = mir.__dict__.setdefault("_fresh", {})   # the scene's slot cache: the outputs registered with the library for the next launch
     key = (agent_obs, env_obs, True)
+    # the next reset's spawn draws, a chunk per step while the kernel runs (tasks/spawn_ahead.py); complete within ~128 steps
+    ahead = getattr(task, "_ahead", None)
+    chunk = max(1024, -(-ahead.total // 128)) if ahead is not None else 0
 
     def fast_step(action):
         if not (type(action) is tensor and action.dtype is f32 and action.shape == shape and action.is_contiguous()
@@ -43,6 +46,8 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
             n = alloc(agent_obs, env_obs)
             prepare(n[1])
             fresh[key] = n
+            if ahead is not None and ahead.left:
+                ahead.advance(chunk)
             task._agent, task._envst, task._reward, task._term = outs
             observation = {"agent_pos": outs[0], "environment_state": outs[1]}
             info = {"is_success": outs[3].view(tbool)}
@@ -93,6 +98,8 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
                 check(rc)
             fresh[key] = n
             task._agent, task._envst, task._reward, task._term = outs
+            if chunk and ahead.left:
+                ahead.advance(chunk)
             result = ({"agent_pos": outs[0], "environment_state": outs[1]}, outs[2], host, np_zeros(B, np_bool), {"is_success": outs[3].view(tbool)})
         except BaseException:
             fresh.pop(key, None)

@@ -27,6 +27,7 @@ import torch
 from ..._gym import spaces
 from ...backend import models
 from ...backend.lib import MirScene
+from ..spawn_ahead import UniformBlocksAhead
 from ..views import CameraView, EntityView, SceneView
 
 AGENT_DIM = len(models.FRANKA_JOINTS)
@@ -51,6 +52,8 @@ class FrankaCubePickBatch:
         self.shard_hi = self.global_num_envs * (rank + 1) // world
         self.num_envs = self.shard_hi - self.shard_lo
         self._random = np.random.RandomState()
+        # the next reset's draws (x block, then y block: cube_pick.py:90-91), made a chunk per env.step() while its kernel runs
+        self._ahead = UniformBlocksAhead([(0.45, 0.80, self.global_num_envs), (-0.25, 0.25, self.global_num_envs)])
         self._build_scene()
         self.observation_space = self._make_obs_space()
         self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(AGENT_DIM,), dtype=np.float32)
@@ -103,6 +106,7 @@ class FrankaCubePickBatch:
         np.random.seed(seed)
         random.seed(seed)
         self._random = np.random.RandomState(seed)
+        self._ahead.invalidate()  # (draws made ahead came from the old stream)
         torch.manual_seed(seed)
         if torch.cuda.is_available():
             torch.cuda.manual_seed_all(seed)
@@ -110,12 +114,15 @@ class FrankaCubePickBatch:
 
     def sample_spawn(self) -> np.ndarray:
         """Cube spawn positions for the GLOBAL batch (so a sharded run draws the same stream as an
-        unsharded one), float32 (B_global, 3)."""
+        unsharded one), float32 (B_global, 3).  The draws may have been made ahead of time (tasks/spawn_ahead.py): same
+        stream, same values; the next block is then started."""
         Bg = self.global_num_envs
+        x, y = self._ahead.take(self._random)
         out = np.empty((Bg, 3), dtype=np.float32)  # (x block, then y block, as the reference draws them; rounded to float32 once)
-        out[:, 0] = self._random.uniform(0.45, 0.80, size=(Bg,))
-        out[:, 1] = self._random.uniform(-0.25, 0.25, size=(Bg,))
+        out[:, 0] = x
+        out[:, 1] = y
         out[:, 2] = 0.02
+        self._ahead.start(self._random)
         return out
 
     def reset(self):

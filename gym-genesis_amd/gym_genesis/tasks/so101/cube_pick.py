@@ -27,6 +27,7 @@ import torch
 from ..._gym import spaces
 from ...backend import models
 from ...backend.lib import MirScene
+from ..spawn_ahead import UniformBlocksAhead
 from ..views import CameraView, EntityView, SceneView
 
 AGENT_DIM = len(models.SO101_JOINTS)  # declared space shape, as in the reference (cube_pick.py:15)
@@ -48,6 +49,7 @@ class CubePick:
         self.shard_hi = self.global_num_envs * (rank + 1) // world
         self.num_envs = self.shard_hi - self.shard_lo
         self._random = np.random.RandomState()
+        self._ahead = UniformBlocksAhead([(-0.32, -0.28, self.global_num_envs), (-0.05, 0.05, self.global_num_envs)])  # so101/cube_pick.py:61-62
         if enable_pixels and camera_capture_mode not in ("per_env", "global"):
             raise ValueError(f"Unknown camera_capture_mode: {camera_capture_mode}")  # so101/cube_pick.py:154-155
         builder = models.so101_cube_pick_scene()
@@ -91,6 +93,7 @@ class CubePick:
         np.random.seed(seed)
         random.seed(seed)
         self._random = np.random.RandomState(seed)
+        self._ahead.invalidate()
         torch.manual_seed(seed)
         if torch.cuda.is_available():
             torch.cuda.manual_seed_all(seed)
@@ -98,10 +101,11 @@ class CubePick:
 
     def sample_spawn(self) -> np.ndarray:
         Bg = self.global_num_envs
-        x = self._random.uniform(-0.32, -0.28, size=(Bg,))
-        y = self._random.uniform(-0.05, 0.05, size=(Bg,))
+        x, y = self._ahead.take(self._random)  # (x block, then y block; possibly drawn ahead, tasks/spawn_ahead.py)
         z = np.full((Bg,), self.island_top_z + 0.02 + 0.001)
-        return np.stack([x, y, z], axis=1).astype(np.float32)
+        out = np.stack([x, y, z], axis=1).astype(np.float32)
+        self._ahead.start(self._random)
+        return out
 
     def reset(self):
         pos = self._mir.staged(self.sample_spawn()[self.shard_lo:self.shard_hi])  # (pinned: the reset kernel reads it in place)

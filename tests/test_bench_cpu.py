@@ -65,3 +65,31 @@ def test_without_a_gpu_the_bench_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0"], capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
+
+
+def test_rank_cpu_plan_gives_every_rank_its_own_cores_next_to_its_gpu():
+    """N > 1 host placement (bench.rank_cpu_plan): disjoint slices, each inside the NUMA node of the rank's GPU when the topology
+    is known, the stepping thread's core inside the slice; even split of the allowed cores otherwise."""
+    numa = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    gpus = [0, 0, 0, 0, 1, 1, 1, 1]
+    seen = set()
+    for r in range(8):
+        mine, spin = bench.rank_cpu_plan(r, 8, range(128), gpus, numa)
+        assert len(mine) == 16 and spin == mine[0] and set(mine) <= set(numa[gpus[r]]) and not (set(mine) & seen)
+        seen |= set(mine)
+    assert seen == set(range(128))
+    # a cpuset that leaves one node almost empty: that node's ranks fall back to the even split of what is allowed
+    allowed = list(range(0, 64)) + [64, 65]
+    slices = [bench.rank_cpu_plan(r, 8, allowed, gpus, numa)[0] for r in range(8)]
+    assert all(slices) and all(set(s) <= set(allowed) for s in slices)
+    assert len(slices[0]) == 16 and set(slices[0]) <= set(numa[0])          # node 0 ranks keep their NUMA-local cores
+    # no topology: even split; fewer cores than ranks: no plan (the scheduler places the ranks)
+    assert bench.rank_cpu_plan(1, 2, range(8)) == ([4, 5, 6, 7], 4)
+    assert bench.rank_cpu_plan(0, 8, range(4)) == ([], None)
+    assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_sysfs_probes_never_raise():
+    nodes, cpus = bench.gpu_numa_nodes(), bench.numa_cpu_lists()
+    assert nodes is None or isinstance(nodes, list)
+    assert isinstance(cpus, dict)

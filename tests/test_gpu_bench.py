@@ -34,6 +34,7 @@ def test_driver_command_prints_the_contract_line():
     for key in ("secondary", "pixels", "scripted_grasp", "box_links", "so101_pick", "stack", "ik"):
         assert key in out and "error" not in out[key], (key, out.get(key))
     assert out["hot_path_rate"] >= out["value"] * 0.9
+    assert out["value_median_region"] >= out["value"] * 0.8 and out["config"]["host_thread"].startswith("pinned to cpu")
 
 
 def test_two_ranks_share_the_gpu_over_gloo():
@@ -43,3 +44,22 @@ def test_two_ranks_share_the_gpu_over_gloo():
                "--min-time", "0.1", "--gather-every", "4")
     assert out["n_gpus"] == 2 and out["config"]["world_size_observed"] == 2 and out["config"]["global_num_envs"] == 1024
     assert out["value"] > 0 and "gloo all_gather" in out["config"]["obs_gather"]
+    # every N > 1 line carries the CPU baseline (rank 0 times it while the others wait at the final barrier), the cost of the
+    # gather as a number, and where the rank's threads were put
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert isinstance(out["gather_overhead_us"], float) and out["no_gather"]["value"] > 0
+    if len(os.sched_getaffinity(0)) >= 4:
+        assert "stepping thread on cpu" in out["config"]["host_thread"], out["config"]["host_thread"]
+
+
+def test_first_rccl_run_one_rank_force_gather():
+    """The RCCL path on the MI355X with the one rank a 1-GPU box has: `nccl` process group bound to the device, the observation
+    gather (all_gather_into_tensor of 8 steps' outputs), barriers and the max-over-ranks all-reduce all execute through RCCL;
+    the line reports the world size the group observed and what the gather costs per step against the same loop without it."""
+    out = _run("--gpus", "1", "--force-gather", "--dist-backend", "nccl", "--steps", "20", "--warmup", "5", "--no-pixels", "--no-stack",
+               "--no-cpu-baseline")
+    cfg = out["config"]
+    assert out["n_gpus"] == 1 and cfg["world_size_observed"] == 1 and cfg["dist_backend"] == "nccl"
+    assert "all_gather" in cfg["obs_gather"] and out["value"] > 1e6
+    assert isinstance(out["gather_overhead_us"], float) and abs(out["gather_overhead_us"]) < 50.0
+    assert out["no_gather"]["median_us_per_step"] > 0

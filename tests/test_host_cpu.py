@@ -100,6 +100,42 @@ def test_reset_rng_stream_matches_golden_fixture(monkeypatch):
     assert np.allclose(rs.uniform(0.45, 0.80, size=(4,)), [0.64208473, 0.70031628, 0.66096718, 0.64070911])
 
 
+def test_spawn_draws_made_ahead_in_chunks_are_the_reference_stream(env):
+    """tasks/spawn_ahead.py: the next reset's x / y blocks drawn a few values per env.step() (complete, partial, or not at all)
+    are the values the reference's two uniform() calls draw (cube_pick.py:90-91); seed() drops what was drawn ahead."""
+    from gym_genesis.tasks.spawn_ahead import UniformBlocksAhead
+
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reset_rng.json")))["seed0_B4"]
+    for chunk, n_adv in ((1, 100), (3, 2), (5, 1), (1000, 1), (3, 0)):
+        rs, ref = np.random.RandomState(11), np.random.RandomState(11)
+        ah = UniformBlocksAhead([(0.45, 0.80, 7), (-0.25, 0.25, 7)])
+        for rep in range(3):
+            ah.start(rs)
+            for _ in range(n_adv):
+                if ah.left:
+                    ah.advance(chunk)
+            x, y = ah.take(rs)
+            assert np.array_equal(x, ref.uniform(0.45, 0.80, size=(7,))) and np.array_equal(y, ref.uniform(-0.25, 0.25, size=(7,)))
+        assert rs.uniform() == ref.uniform()      # both streams stand at the same place
+    # through the task and the env.step closure: 3 envs -> 6 draws, one value per step would do; the closure draws >= 1024 at once
+    task = env._env
+    env.reset(seed=gold["seed"])
+    ref = np.random.RandomState(gold["seed"])
+    ref.uniform(size=6)                            # the reset above
+    a = np.zeros((3, 9), np.float32)
+    assert task._ahead.left == 6
+    env.step(a)
+    assert task._ahead.left == 0                  # drawn while the "kernel" ran
+    want = np.stack([ref.uniform(0.45, 0.80, size=(3,)), ref.uniform(-0.25, 0.25, size=(3,)), np.full(3, 0.02)], 1).astype(np.float32)
+    assert np.array_equal(task.sample_spawn(), want)
+    env.step(a)                                    # the next block is drawn ahead again ...
+    assert task._ahead.left == 0
+    task.seed(gold["seed"])                        # ... and dropped by seed(): the stream starts over
+    r2 = np.random.RandomState(gold["seed"])
+    want = np.stack([r2.uniform(0.45, 0.80, size=(3,)), r2.uniform(-0.25, 0.25, size=(3,)), np.full(3, 0.02)], 1).astype(np.float32)
+    assert np.array_equal(task.sample_spawn(), want)
+
+
 def test_reference_constants():
     """Constants the reference spells out (file:line in models.py / cube_pick.py docstrings)."""
     assert models.FRANKA_HOME == (0.0, -0.4, 0.0, -2.2, 0.0, 2.0, 0.8, 0.04, 0.04)  # cube_pick.py:100
