@@ -581,6 +581,42 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
   const int maxc = max_contacts < MAXCON ? max_contacts : MAXCON;
   {
+    // ---- more candidate points than the capacity: the largest manifolds are thinned before any pair loses all of its points
+    // (the rule is defined at oracle/orc_rigid.c: thin_manifolds -- per round, the pairs holding the most points merge their last
+    // two points into the mean, in pair order, until the total fits).  Rare path: both fingers AND the cube on the floor while
+    // the pads hold the cube (20+ points), which is exactly where the reference's expert puts the hand
+    // (examples/franka/pick_cube_state.py:38-39 of the reference: hand target 3 cm above the cube centre).
+    float totf = (float)mycount;
+    totf += row_shr<1>(totf);
+    totf += row_shr<2>(totf);
+    totf += row_shr<4>(totf);
+    totf += row_shr<8>(totf);
+    int total0 = (int)row_bcast<15>(totf);
+    if (__any(total0 > maxc)) {
+      WSYNC();  // (the staging area was written by other lanes of the row)
+      for (int round = 0; round < 8; round++) {  // (a manifold holds at most 8 points)
+        const int mx = (int)gmaxf((float)mycount);
+        const bool live = total0 > maxc && mx > 1;
+        if (!__any(live)) break;
+        const bool is = live && mycount == mx;
+        float r = is ? 1.0f : 0.0f;
+        const float self = r;
+        r += row_shr<1>(r);
+        r += row_shr<2>(r);
+        r += row_shr<4>(r);
+        r += row_shr<8>(r);
+        const int rank = (int)(r - self), nis = (int)row_bcast<15>(r), need = total0 - maxc;
+        if (is && rank < need) {
+          const f4 pa = ldv(S.col.stage[lane][mx - 2]), pb = ldv(S.col.stage[lane][mx - 1]);
+          stv(S.col.stage[lane][mx - 2], f4{0.5f * (pa.x + pb.x), 0.5f * (pa.y + pb.y), 0.5f * (pa.z + pb.z), 0.5f * (pa.w + pb.w)});
+          mycount--;
+        }
+        if (live) total0 -= need < nis ? need : nis;
+      }
+      WSYNC();
+    }
+  }
+  {
     // inclusive prefix sum over the row by DPP shifts (zeros shifted in), total from lane 15
     float inclf = (float)mycount;
     inclf += row_shr<1>(inclf);

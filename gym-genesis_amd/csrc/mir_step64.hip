@@ -473,6 +473,27 @@ void mir_step64_kernel(StepArgs64 a) {
     const int maxc = max_contacts < MAXC ? max_contacts : MAXC;
     int ncon;
     {
+      // more candidate points than the capacity: the largest manifolds are thinned before any pair loses all of its points (the
+      // rule is defined at oracle/orc_rigid.c: thin_manifolds; same code path as in the 16-lane kernel, one env per wave here)
+      int total0 = (int)wsum((float)mycount);
+      if (total0 > maxc) {
+        for (int round = 0; round < 8; round++) {  // (a manifold holds at most 8 points)
+          const int mx = (int)wmaxf((float)mycount);
+          if (!(total0 > maxc && mx > 1)) break;
+          const bool is = mycount == mx;
+          const unsigned long long bm = __ballot(is);
+          const int rank = __popcll(bm & ((1ull << lane) - 1ull)), nis = __popcll(bm), need = total0 - maxc;
+          if (is && rank < need) {
+            const f4 pa = ldv(S.col.stage[lane][mx - 2]), pb = ldv(S.col.stage[lane][mx - 1]);
+            stv(S.col.stage[lane][mx - 2], f4{0.5f * (pa.x + pb.x), 0.5f * (pa.y + pb.y), 0.5f * (pa.z + pb.z), 0.5f * (pa.w + pb.w)});
+            mycount--;
+          }
+          total0 -= need < nis ? need : nis;
+        }
+        WSYNC();
+      }
+    }
+    {
       float inclf = (float)mycount;
       inclf += row_shr<1>(inclf);
       inclf += row_shr<2>(inclf);

@@ -125,12 +125,12 @@ def _add_cube(sb: SceneBuilder, name: str, pos, size=0.04, rho=200.0, friction=1
     sb.add_geom(name, GEOM_BOX, size=(h, h, h), friction=friction, rgb=rgb)
 
 
-def franka_cube_pick_scene(cube_size=0.04, cube_pos=(0.65, 0.0, 0.02), cube_rho=200.0, link_shape="capsule") -> SceneBuilder:
+def franka_cube_pick_scene(cube_size=0.04, cube_pos=(0.65, 0.0, 0.02), cube_rho=200.0, link_shape="capsule", frc=FRANKA_FRC_MJCF) -> SceneBuilder:
     sb = SceneBuilder()
     # ground plane (gs.morphs.Plane, cube_pick.py:50)
     sb.add_geom(0, GEOM_PLANE)
     # Panda (cube_pick.py:51)
-    _add_franka(sb, link_shape=link_shape)
+    _add_franka(sb, link_shape=link_shape, frc=frc)
     # cube (gs.morphs.Box, cube_pick.py:52-54)
     _add_cube(sb, "cube", cube_pos, size=cube_size, rho=cube_rho)
     # visual-only pedestal of the fixed base link (never collides: contype = conaffinity = 0); appended last so

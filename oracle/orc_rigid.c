@@ -869,10 +869,40 @@ static void make_frame(real* F, const real* n) { /* rows: normal, t1, t2 */
   v3copy(F, n); v3copy(F + 3, t1); v3copy(F + 6, t2);
 }
 
+/* More candidate points than the scene's contact capacity: manifolds are THINNED before any pair loses all of its points
+ * (the capacity is the 16 lanes of the pick kernel; Genesis itself keeps 100+ pairs, SURVEY.md App. A.1, so whatever is done
+ * here is this backend's own definition).  While the total exceeds the capacity: among the pairs that hold the most points
+ * (at least two), in pair order, the LAST TWO points of a pair are merged into their mean (position and depth) -- neighbours
+ * on the contact polygon, so a four-corner face patch becomes a triangle that still surrounds the patch centre, then an edge --
+ * one merge per pair and round, until the total fits.  No depth comparison is involved (a box lying flat has four equal
+ * depths up to rounding).  Only when every pair is down to one point does the capacity cut the list, in pair order. */
+static void thin_manifolds(int* cnt, CPoint (*pts)[16], int npairs, int maxc) {
+  int total = 0;
+  for (int i = 0; i < npairs; i++) total += cnt[i];
+  while (total > maxc) {
+    int mx = 0;
+    for (int i = 0; i < npairs; i++) mx = cnt[i] > mx ? cnt[i] : mx;
+    if (mx <= 1) break;
+    int need = total - maxc;
+    for (int i = 0; i < npairs && need > 0; i++) {
+      if (cnt[i] != mx) continue;
+      CPoint *a = &pts[i][mx - 2], *b = &pts[i][mx - 1];
+      for (int k = 0; k < 3; k++) a->pos[k] = (real)0.5 * (a->pos[k] + b->pos[k]);
+      a->dist = (real)0.5 * (a->dist + b->dist);
+      cnt[i]--; total--; need--;
+    }
+  }
+}
+
 static void orc_collide(const OrcModel* m, OrcData* d) {
   d->ncon = 0;
   if (!m->opt.enable_collision) return;
   int maxc = m->opt.max_contacts < ORC_NC ? m->opt.max_contacts : ORC_NC;
+  /* pass 1: the narrowphase of every pair, in pair order */
+  static _Thread_local CPoint ppts[ORC_NP][16];
+  static _Thread_local real pn[ORC_NP][3];
+  static _Thread_local int pcnt[ORC_NP], ppair[ORC_NP];
+  int np = 0;
   for (int pidx = 0; pidx < m->npair; pidx++) {
     int g1 = m->pair_g1[pidx], g2 = m->pair_g2[pidx];
     int b1 = m->gbody[g1], b2 = m->gbody[g2];
@@ -881,17 +911,24 @@ static void orc_collide(const OrcModel* m, OrcData* d) {
     qmul(q, d->xquat[b1], m->gquat[g1]); q2mat(R1, q);
     matvec3(off, d->xmat[b2], m->gpos[g2]); v3addscl(p2, d->xpos[b2], off, 1);
     qmul(q, d->xquat[b2], m->gquat[g2]); q2mat(R2, q);
-    CPoint pts[16]; real n[3]; int cnt = 0;
+    CPoint* pts = ppts[np]; real* n = pn[np]; int cnt = 0;
     if (m->gtype[g1] == MIR_GEOM_PLANE && m->gtype[g2] == MIR_GEOM_BOX) cnt = plane_box(p1, R1, p2, R2, m->gsize[g2], pts, n);
     else if (m->gtype[g1] == MIR_GEOM_PLANE && m->gtype[g2] == MIR_GEOM_SPHERE) cnt = plane_sphere(p1, R1, p2, m->gsize[g2][0], pts, n);
     else if (m->gtype[g1] == MIR_GEOM_PLANE && m->gtype[g2] == MIR_GEOM_CAPSULE) cnt = plane_capsule(p1, R1, p2, R2, m->gsize[g2][0], m->gsize[g2][1], pts, n);
     else if (m->gtype[g1] == MIR_GEOM_BOX && m->gtype[g2] == MIR_GEOM_BOX) cnt = box_box(p1, R1, m->gsize[g1], p2, R2, m->gsize[g2], pts, n);
     else if (m->gtype[g1] != MIR_GEOM_PLANE) cnt = convex_pair(m->gtype[g1], m->gsize[g1], p1, R1, m->gtype[g2], m->gsize[g2], p2, R2, pts, n);
-    for (int c = 0; c < cnt && d->ncon < maxc; c++) {
+    if (cnt > 0) { pcnt[np] = cnt; ppair[np] = pidx; np++; }
+  }
+  /* pass 2: fit the capacity, then the contact arrays in pair order */
+  thin_manifolds(pcnt, ppts, np, maxc);
+  for (int i = 0; i < np; i++) {
+    int g1 = m->pair_g1[ppair[i]], g2 = m->pair_g2[ppair[i]];
+    int b1 = m->gbody[g1], b2 = m->gbody[g2];
+    for (int c = 0; c < pcnt[i] && d->ncon < maxc; c++) {
       int k = d->ncon++;
-      v3copy(d->cpos[k], pts[c].pos);
-      d->cdist[k] = pts[c].dist;
-      make_frame(d->cframe[k], n);
+      v3copy(d->cpos[k], ppts[i][c].pos);
+      d->cdist[k] = ppts[i][c].dist;
+      make_frame(d->cframe[k], pn[i]);
       d->cmu[k] = m->gfriction[g1] > m->gfriction[g2] ? m->gfriction[g1] : m->gfriction[g2];
       for (int s = 0; s < 2; s++) d->csolref[k][s] = (real)0.5 * (m->gsolref[g1][s] + m->gsolref[g2][s]);
       for (int s = 0; s < 5; s++) d->csolimp[k][s] = (real)0.5 * (m->gsolimp[g1][s] + m->gsolimp[g2][s]);
