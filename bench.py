@@ -42,6 +42,7 @@ ENVS_PER_GPU = 4096
 EPISODE_STEPS = 200
 ALGO_BYTES_PER_ENV_STEP = 489.0  # 55 f32 read + 67 f32 + 1 B written
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: peak FP32 (vector), spec
 ROW_STRIDE = 24
 N_ACT = 256                      # pre-drawn action batches (device resident), cycled
 RK = 16                          # steps per rollout launch in the secondary rollout legs
@@ -260,6 +261,94 @@ def cpu_baseline(budget_s: float = 12.0):
             "sample": f"{steps} steps x {B} envs, same random-action workload, float32 C port of the oracle, OpenMP over envs"}
 
 
+def stack_flops_per_env_step(envs: int = 32, steps: int = 40):
+    """F_step of the CubeStack-v0 workload of stack_bench (Franka, five cubes, home + U(-1,1) joint targets), counted like
+    flops_per_env_step by the instrumented oracle at the full capacities (oracle/liborc_flops_big.so)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    from gym_genesis.backend import models
+
+    spec = models.franka_cube_stack_scene().build()
+    o = orc.Oracle(spec, envs, f32=True, flops="big")
+    rng = np.random.RandomState(0)
+    pos = np.zeros((envs, 5, 3), np.float32)
+    pos[:, :, 0] = np.array([-0.3, -0.15, 0.0, 0.15, 0.3]) + rng.uniform(-0.03, 0.03, (envs, 5))
+    pos[:, :, 1] = rng.uniform(-0.2, 0.2, (envs, 5))
+    pos[:, :, 2] = models.STACK_CUBE_Z
+    home = np.tile(np.array(models.FRANKA_HOME, np.float32), (envs, 1))
+    o.reset(pos, np.tile(np.array([0, 0, 0, 1], np.float32), (envs, 5, 1)), home)
+    acts = (home + np.random.default_rng(4321).uniform(-1, 1, (steps, envs, 9))).astype(np.float32)
+    for t in range(10):
+        o.step_batch(acts[t], 1)
+    o.flops_reset()
+    for t in range(steps):
+        o.step_batch(acts[t], 1)
+    f = o.flops()
+    n = float(steps * envs)
+    kinds = {k: v / n for k, v in f.items()}
+    return {"F_step": sum(v for k, v in kinds.items() if k != "cmp"), "per_kind": kinds,
+            "sample": f"{steps} steps x {envs} envs of the stack workload, float32 port of the oracle with counted arithmetic (one thread)"}
+
+
+def flops_per_env_step(envs: int = 256, steps: int = 200):
+    """F_step: floating-point operations per env-step of the headline workload, counted by the oracle's instrumented build
+    (oracle/liborc_flops.so: the float32 port compiled with an arithmetic type that counts its own +, -, *, /, sqrt, sin / cos / atan2 /
+    pow; SURVEY.md 8d "Figures for roofline.achieved").  Same scene, same reset stream, same U(-1,1) joint targets, one episode of
+    `steps` steps on a sample of `envs` envs.  An ALGORITHMIC count of a dense scalar restatement: fma counts as two (mul + add)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    from gym_genesis.backend import models
+
+    spec = models.franka_cube_pick_scene().build()
+    o = orc.Oracle(spec, envs, f32=True, flops=True)
+    rng = np.random.RandomState(0)
+    pos = np.stack([rng.uniform(0.45, 0.80, envs), rng.uniform(-0.25, 0.25, envs), np.full(envs, 0.02)], 1).astype(np.float32)
+    o.reset(pos, np.tile(np.array([0, 0, 0, 1.0], np.float32), (envs, 1)), np.tile(np.array(models.FRANKA_HOME, np.float32), (envs, 1)))
+    o.step_batch(None, 1)
+    acts = np.random.default_rng(1234).uniform(-1, 1, (steps, envs, 9)).astype(np.float32)
+    o.flops_reset()
+    for t in range(steps):
+        o.step_batch(acts[t], 1)  # (one thread: the counters are per thread)
+    f = o.flops()
+    n = float(steps * envs)
+    kinds = {k: v / n for k, v in f.items()}
+    return {"F_step": sum(v for k, v in kinds.items() if k != "cmp"), "per_kind": kinds,
+            "sample": f"{steps} steps x {envs} envs of the headline workload, float32 port of the oracle with counted arithmetic (one thread)"}
+
+
+def valu_roofline(fl: dict, kernel_us: float, kernel: str, B: int, sq_profile: str):
+    """The roofline that is nearer to binding than HBM: fp32 vector throughput.  achieved = F_step x envs per launch /
+    the kernel's duration; beside it the kernel's own instruction-level count from the committed SQ counter pass
+    (SQ_INSTS_VALU_FLOPS_FP32 wave-instructions x 64 lanes per launch: every lane slot counted, fma = 2) for the same kernel."""
+    ach = fl["F_step"] * B / (kernel_us * 1e-6) / 1e12
+    out = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / VALU_PEAK_TFLOPS, "kernel": kernel,
+           "kernel_us": kernel_us, "F_step": fl["F_step"], "F_step_per_kind": fl["per_kind"], "F_step_source": fl["sample"],
+           "note": "algorithmic flops of the float32 CPU restatement per env-step x 4096 envs per launch / measured kernel time, against the fp32 "
+                   "vector peak; the path is a dependent chain on one or two waves per SIMD (latency/occupancy-bound), so neither this nor the "
+                   "HBM figure is near 1"}
+    try:
+        sq = None
+        for rnd in ("r3", "r2"):  # (the latest committed counter pass of this kernel)
+            path = os.path.join(ROOT, "profiles", rnd, sq_profile)
+            if os.path.exists(path):
+                with open(path) as f:
+                    sq = json.load(f)
+                sq_profile = f"{rnd}/{sq_profile}"
+                break
+        wi = float(sq["SQ_INSTS_VALU_FLOPS_FP32"]["median_per_launch"])
+        lane_flops = wi * 64.0
+        out["instruction_level"] = {"source": f"profiles/{sq_profile}: SQ_INSTS_VALU_FLOPS_FP32 (median per launch, 4096 envs) x 64 lanes",
+                                    "flops_per_launch": lane_flops, "flops_per_env_step": lane_flops / ENVS_PER_GPU,
+                                    "achieved": lane_flops / (kernel_us * 1e-6) / 1e12, "frac": lane_flops / (kernel_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS,
+                                    "over_algorithmic": lane_flops / ENVS_PER_GPU / fl["F_step"],
+                                    "valu_wave_instructions_per_launch": float(sq.get("SQ_INSTS_VALU", {}).get("median_per_launch", 0.0))}
+    except (OSError, KeyError, ValueError, TypeError):
+        out["instruction_level"] = None
+    return out
+
+
 def _events(torch):
     return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -458,12 +547,17 @@ def stack_bench(torch, dev, steps: int = 300):
     algo = 1109.0
     achieved = algo * B / (us * 1e-6) / 1e9
     del env
+    try:
+        valu = valu_roofline(stack_flops_per_env_step(), us, "mir_step64_kernel", B, "sq_counters_step64.json")
+    except Exception as e:  # noqa: BLE001
+        valu = {"error": f"{type(e).__name__}: {e}"}
     return {"workload": "CubeStack-v0 robot=franka (39 dofs, 5 cubes) state-only obs, home + U(-1,1) joint targets, num_envs=4096",
             "env_steps_per_s": B / (us * 1e-6), "us_per_step": us, "rollout16_env_steps_per_s": B / (us_ro * 1e-6),
             "mean_contacts": ncon, "mean_newton_iterations": niter,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "mir_step64_kernel",
-                         "note": "1109 algorithmic B/env-step; one wave per env, 4 envs per CU: latency/occupancy-bound like the pick kernel"}}
+                         "traffic": _profile_number("pmc_hbm_traffic_step64.json", "hbm_bytes_per_launch"), "kernel": "mir_step64_kernel",
+                         "note": "1109 algorithmic B/env-step; one wave per env, 4 envs per CU: latency/occupancy-bound like the pick kernel"},
+            "roofline_valu": valu}
 
 
 def ik_bench(torch, dev, calls: int = 200):
@@ -494,7 +588,7 @@ def ik_bench(torch, dev, calls: int = 200):
 
 def _profile_number(name: str, key: str):
     """A number measured offline with rocprofv3 PMC passes and committed under profiles/ (latest round first)."""
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, name)) as f:
                 v = json.load(f).get(key)
@@ -879,6 +973,18 @@ def worker(args) -> int:
             rc = 1
 
         unpin()
+        if rank == 0 and not args.core_only and isinstance(out.get("roofline"), dict) and "kernel_us" in out["roofline"]:
+            def _valu():
+                fl = flops_per_env_step()
+                rf = out["roofline"]
+                rot = rf["kernel"].startswith("mir_step_kernel<5")
+                res = valu_roofline(fl, rf["kernel_us"], rf["kernel"], B, "sq_counters_rotated.json" if rot else "sq_counters.json")
+                if "roofline_fused_launch" in out:
+                    ff = out["roofline_fused_launch"]
+                    res["fused_launch"] = {k: v for k, v in valu_roofline(fl, ff["kernel_us"], ff["kernel"], B, "sq_counters.json").items()
+                                           if k in ("achieved", "frac", "kernel", "kernel_us", "instruction_level")}
+                return res
+            _guard(out, "roofline_valu", _valu)
         if rank == 0 and world == 1 and not args.core_only:
             _guard(out, "secondary", lambda: secondary_rates(torch, dev, env, task, actions, B))
             if not args.no_pixels:

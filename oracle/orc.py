@@ -27,12 +27,14 @@ def build_oracle() -> None:
 _libs = {}
 
 
-def load(f32: bool = False):
-    key = "32" if f32 else "64"
+def load(f32: bool = False, flops=False):
+    """liborc64.so (float64 oracle), liborc32.so (float32 port) or liborc_flops.so / liborc_flops_big.so (the float32 port with
+    counted arithmetic at the pick-task / full capacities; flops = True / "big")."""
+    key = ("_flops_big" if flops == "big" else "_flops") if flops else ("32" if f32 else "64")
     if key not in _libs:
         path = os.path.join(ORACLE_DIR, f"liborc{key}.so")
         srcs = [os.path.join(ORACLE_DIR, "orc_rigid.c"), os.path.join(ORACLE_DIR, "orc_render.c"), os.path.join(ORACLE_DIR, "orc_rigid.h"),
-                os.path.join(ORACLE_DIR, "..", "include", "mirigid.h")]
+                os.path.join(ORACLE_DIR, "orc_flops.h"), os.path.join(ORACLE_DIR, "..", "include", "mirigid.h")]
         if not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(s) for s in srcs):
             build_oracle()
         lib = C.CDLL(path)
@@ -45,8 +47,8 @@ def load(f32: bool = False):
 class Oracle:
     """One compiled model + a batch of per-env data blocks."""
 
-    def __init__(self, spec, num_envs: int = 1, f32: bool = False):
-        self.lib = load(f32)
+    def __init__(self, spec, num_envs: int = 1, f32: bool = False, flops=False):
+        self.lib = load(f32, flops)
         self.spec = spec
         self.B = num_envs
         self.model = C.create_string_buffer(self.lib.orc_sizeof_model())
@@ -69,6 +71,17 @@ class Oracle:
         self.env_dim = 14 if spec.task.obj2_body >= 0 else 11
         self.nu = sum(1 for i in range(spec.ndof) if spec.dof[i].ctrl_mode == 1)
         self.u_dofs = [i for i in range(spec.ndof) if spec.dof[i].ctrl_mode == 1]
+
+    FLOP_KINDS = ("add", "mul", "div", "sqrt", "trans", "cmp")
+
+    def flops_reset(self) -> None:
+        self.lib.orc_flops_reset()
+
+    def flops(self) -> dict:
+        """Operations the CALLING thread has executed in this library since flops_reset() (liborc_flops.so; zeros otherwise)."""
+        out = (C.c_ulonglong * 6)()
+        self.lib.orc_flops_read(out)
+        return dict(zip(self.FLOP_KINDS, (int(x) for x in out)))
 
     def d(self, e: int = 0):
         return C.c_void_p(self._dptr + e * self.dsize)

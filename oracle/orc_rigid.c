@@ -40,6 +40,25 @@
 #define MAXIMP ((real)0.9999)
 #define F32(x) ((real)(float)(x)) /* the product stores model constants, dt and gravity in float32: same inputs */
 
+#ifdef ORC_COUNT_FLOPS
+thread_local OrcFlops orc_flops_tl;
+#endif
+int orc_flops_read(unsigned long long* out) {
+#ifdef ORC_COUNT_FLOPS
+  out[0] = orc_flops_tl.add; out[1] = orc_flops_tl.mul; out[2] = orc_flops_tl.div;
+  out[3] = orc_flops_tl.sqrt_; out[4] = orc_flops_tl.trans; out[5] = orc_flops_tl.cmp;
+  return 1;
+#else
+  for (int i = 0; i < 6; i++) out[i] = 0;
+  return 0;
+#endif
+}
+void orc_flops_reset(void) {
+#ifdef ORC_COUNT_FLOPS
+  orc_flops_tl = OrcFlops();
+#endif
+}
+
 /* ------------------------------------------------------------------ small math */
 static void v3set(real* o, real a, real b, real c) { o[0] = a; o[1] = b; o[2] = c; }
 static void v3copy(real* o, const real* a) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
@@ -899,9 +918,9 @@ static void orc_collide(const OrcModel* m, OrcData* d) {
   if (!m->opt.enable_collision) return;
   int maxc = m->opt.max_contacts < ORC_NC ? m->opt.max_contacts : ORC_NC;
   /* pass 1: the narrowphase of every pair, in pair order */
-  static _Thread_local CPoint ppts[ORC_NP][16];
-  static _Thread_local real pn[ORC_NP][3];
-  static _Thread_local int pcnt[ORC_NP], ppair[ORC_NP];
+  static ORC_TLS CPoint ppts[ORC_NP][16];
+  static ORC_TLS real pn[ORC_NP][3];
+  static ORC_TLS int pcnt[ORC_NP], ppair[ORC_NP];
   int np = 0;
   for (int pidx = 0; pidx < m->npair; pidx++) {
     int g1 = m->pair_g1[pidx], g2 = m->pair_g2[pidx];

@@ -27,10 +27,17 @@
 
 #include "../include/mirigid.h"
 
-#ifdef ORC_F32
+#ifdef ORC_COUNT_FLOPS
+#include "orc_flops.h" /* C++ build: `real` counts its own arithmetic (liborc_flops.so, bench.py's F_step) */
+#elif defined(ORC_F32)
 typedef float real;
 #else
 typedef double real;
+#endif
+#ifdef __cplusplus
+#define ORC_TLS thread_local
+#else
+#define ORC_TLS _Thread_local
 #endif
 
 #ifdef ORC_SMALL /* pick-task capacities: keeps the per-env block of the timed float32 port small and cache-resident */
@@ -123,6 +130,10 @@ int orc_counts(const OrcData* d, int* ncon, int* nefc, int* niter);
 void orc_aba(const OrcModel* m, OrcData* d, double* qacc_out);
 /* batch driver (OpenMP over envs) for the timed CPU baseline: action (T?) — random targets supplied by caller */
 void orc_step_batch(const OrcModel* m, OrcData* d, int B, const float* action /* (B,nu) or NULL */, int nthreads);
+/* -DORC_COUNT_FLOPS builds only (0 / no-op otherwise): floating-point operations executed by THIS thread since the last reset,
+ * out[6] = add+sub, mul, div, sqrt, sin/cos/atan2/pow, comparisons */
+int orc_flops_read(unsigned long long* out);
+void orc_flops_reset(void);
 
 #ifdef __cplusplus
 }

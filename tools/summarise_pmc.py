@@ -9,7 +9,7 @@ import json
 import os
 import sys
 
-ALGO_BYTES = 489.0 * 4096
+ALGO_BYTES = float(os.environ.get("MIR_PMC_ALGO_BYTES", 489.0 * 4096))  # (1109 x 4096 for the stack kernel)
 CALIB_BYTES = 16 * 1024 * 1024 * 4  # tools/traffic_calib.py: 64 MiB read and 64 MiB written per launch
 
 
