@@ -151,8 +151,12 @@ __device__ __forceinline__ bool gjk_core_distance(const ShapeD& A, const ShapeD&
       }
     n = m;
     v = nv;
-    if (!(dot(v, v) > 1e-20f)) return true;  // the cores touch
+    if (!(dot(v, v) > 1e-12f)) return true;  // the cores touch (closer than 1e-6 m: the connecting line carries no direction in float32)
   }
+  // (left through the no-progress / repeated-vertex exits with the origin numerically ON the simplex -- a core centre on a symmetry
+  //  plane of the other core, e.g. a sphere sunk into the middle of a box face past its radius: an overlap too.  Without this the pair
+  //  came back as a "shallow" contact of depth r with an unnormalised normal: tests/test_convex_host.py, analytic cases)
+  if (!(dot(v, v) > 1e-12f)) return true;
   pa = v3(0.0f, 0.0f, 0.0f); pb = pa;
 #pragma unroll
   for (int i = 0; i < 4; i++)

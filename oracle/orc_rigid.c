@@ -847,8 +847,12 @@ static int gjk_core_distance(const Shape* A, const Shape* B, real* dist, real* p
         m++;
       }
     n = m;
-    if (!(v3dot(v, v) > (real)1e-20)) return 1; /* the cores touch */
+    if (!(v3dot(v, v) > (real)1e-12)) return 1; /* the cores touch (closer than 1e-6 m: the connecting line carries no direction
+                                                     * in float32, portal refinement on the full shapes takes over) */
   }
+  /* (left through the no-progress / repeated-vertex exits with the origin numerically ON the simplex -- a core centre on a symmetry
+   *  plane of the other core, e.g. a sphere dropped onto the middle of a box and sunk past its radius: that is an overlap too) */
+  if (!(v3dot(v, v) > (real)1e-12)) return 1;
   v3set(pa, 0, 0, 0); v3set(pb, 0, 0, 0);
   for (int i = 0; i < n; i++) { v3addscl(pa, pa, PA[i], lam[i]); v3addscl(pb, pb, PB[i], lam[i]); }
   *dist = v3norm(v);

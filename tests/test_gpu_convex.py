@@ -189,6 +189,21 @@ def test_kernel_narrowphase_equals_oracle_pair_by_pair():
     assert np.median(np.abs(got[both, 4] - host[both, 4])) < 1e-7
 
 
+def test_kernel_mpr_on_analytic_cases():
+    """The deep pairs with a closed-form answer (tests/test_convex_host.py: analytic_deep_pairs -- a sphere / capsule whose core lies
+    inside a box on one of its symmetry planes): the device build gives the analytic depth within 5 % and the normal within 2e-2 rad
+    (before round 3 these came back as a depth-r contact with an unnormalised normal: GJK left through its repeated-vertex exit
+    with the origin ON the simplex and reported the cores as apart)."""
+    import test_convex_host as H
+
+    rows, want = H.analytic_deep_pairs()
+    got = _device_pairs(rows)
+    for i, (depth, n) in enumerate(want):
+        assert got[i, 0] == 1, (i, rows[i], got[i])
+        assert abs(-got[i, 4] - depth) < 0.05 * depth, (i, -got[i, 4], depth)
+        assert np.arccos(np.clip(np.dot(got[i, 5:8], n), -1, 1)) < 2e-2, (i, got[i, 5:8], n)
+
+
 def test_franka_pick_with_capsule_links_matches_oracle():
     """CubePick-v0 with links 1-7 as capsules (the default; GenesisEnv(..., link_shape="box") gives round 1's boxes): the
     benchmark's random-action workload at

@@ -7,11 +7,12 @@ import shutil
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r3"
 dst = os.path.join(R, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 src = os.path.join(R, "gpurun_out")
-for name in ("pmc_hbm_traffic.json", "pmc_hbm_traffic_api.json"):
+for name in ("pmc_hbm_traffic.json", "pmc_hbm_traffic_api.json", "pmc_hbm_traffic_step64.json", "sq_counters.json", "sq_counters_rotated.json",
+             "sq_counters_step64.json", "stack_kernel_stats.csv", "stack_phase_profile.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 for name in ("bench_kernel_stats.csv", "bench_raw_kernel_stats.csv"):
@@ -22,6 +23,8 @@ for name in ("bench_kernel_stats.csv", "bench_raw_kernel_stats.csv"):
     csv.writer(open(os.path.join(dst, name), "w", newline="")).writerows(rows)
 for log, out in (("bench_under_rocprof.log", "bench_under_rocprof.log"), ("bench_raw_under_rocprof.log", "bench_raw_under_rocprof.log"),
                  ("bench_driver.out", "bench_driver_command.log")):
+    if not os.path.exists(os.path.join(src, log)):
+        continue
     text = open(os.path.join(src, log)).read()
     m = re.findall(r'^\{"metric".*$', text, flags=re.M)
     open(os.path.join(dst, out), "w").write((m[-1] if m else text[-4000:]) + "\n")
