@@ -188,6 +188,10 @@ def parse_args(argv=None):
     ap.add_argument("--raw-only", action="store_true",
                     help="with --core-only: skip the API loop too, so that every mir_step_kernel launch in a trace is a raw launch")
     ap.add_argument("--force-gather", action="store_true", help="exercise the gather path even with one rank (plumbing check)")
+    ap.add_argument("--gather-path", choices=("copy", "rccl"), default="copy",
+                    help="N>1: how the observation gather travels -- copy: peer-to-peer device copies on the SDMA engines + sequence words "
+                         "(sharding.CopyPathGather; no kernel takes CUs / LDS from the step kernel), verified at start-up against the RCCL "
+                         "collective and replaced by it where peer access does not work; rccl: all_gather_into_tensor")
     ap.add_argument("--no-gather-ab", action="store_true",
                     help="skip the second headline measurement WITHOUT the gather that gives `gather_overhead_us` (runs whenever a gather is on)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for plumbing checks)")
@@ -745,17 +749,25 @@ def worker(args) -> int:
     flat = B * 21  # agent_pos 9 + environment_state 11 + reward 1 per env (terminated == (reward == 1), env.py:63)
     gathered = [torch.empty((pg_world * S * flat,), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
     pending = [None, None]
+    copy_gather, gather_note = None, ""
+    if gather and args.gather_path == "copy":
+        from gym_genesis.sharding import make_copy_gather
+        copy_gather, gather_note = make_copy_gather(S * flat, dev)
+    last_seq = [0]
     chunk_parts: list = []
     state = {"chunk": 0, "t": 0, "resets": 0}
 
     def flush():
         """All-gather the outputs of the steps collected so far (async: overlaps the following steps)."""
         if gather_on[0] and chunk_parts:
-            s = state["chunk"] & 1
-            if pending[s] is not None:
-                pending[s].wait()
             send = torch.cat(chunk_parts)
-            pending[s] = dist.all_gather_into_tensor(gathered[s][:pg_world * send.numel()], send, async_op=True)
+            if copy_gather is not None:
+                last_seq[0] = copy_gather.push(send)   # device-to-device copies on the side stream: nothing to wait for here
+            else:
+                s = state["chunk"] & 1
+                if pending[s] is not None:
+                    pending[s].wait()
+                pending[s] = dist.all_gather_into_tensor(gathered[s][:pg_world * send.numel()], send, async_op=True)
             state["chunk"] += 1
             chunk_parts.clear()
 
@@ -789,6 +801,8 @@ def worker(args) -> int:
             if p is not None:
                 p.wait()
                 pending[i] = None
+        if copy_gather is not None and last_seq[0]:
+            copy_gather.wait(last_seq[0])   # every rank's last block has landed HERE (the words of the earlier ones came first)
         torch.cuda.synchronize(dev)
         if use_pg:
             dist.barrier()
@@ -866,8 +880,12 @@ def worker(args) -> int:
                                    "README loop through GenesisEnv.step (NumPy bool terminated per step), reset-all every 200 steps",
                        "num_envs_per_gpu": B, "global_num_envs": B * world, "parallelism": f"env-axis shard x{world}",
                        "world_size_observed": pg_world, "dist_backend": args.dist_backend if use_pg else None,
-                       "obs_gather": (f"{args.dist_backend} all_gather of [agent_pos|environment_state|reward] of {S} steps per collective, "
-                                      "overlapped with the following steps") if gather else "none",
+                       "obs_gather": ("none" if not gather else
+                                      (f"copy path: [agent_pos|environment_state|reward] of {S} steps pushed to every rank by peer-to-peer device "
+                                       f"copies + sequence words (no collective kernel), process group {args.dist_backend}") if copy_gather is not None else
+                                      (f"{args.dist_backend} all_gather of [agent_pos|environment_state|reward] of {S} steps per collective, "
+                                       "overlapped with the following steps" + (f" (copy path not used: {gather_note})" if gather_note else ""))),
+                       "gather_path": None if not gather else ("copy" if copy_gather is not None else "rccl"),
                        "terminated_sync_mode": task._mir.sync_mode, "split_step": int(getattr(task._mir, "split_step", 0)),
                        "host_thread": host_thread_note()},
             "repeats": len(walls),

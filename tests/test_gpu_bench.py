@@ -43,7 +43,7 @@ def test_two_ranks_share_the_gpu_over_gloo():
     out = _run("--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo", "--oversubscribe", "--envs-per-gpu", "512",
                "--min-time", "0.1", "--gather-every", "4")
     assert out["n_gpus"] == 2 and out["config"]["world_size_observed"] == 2 and out["config"]["global_num_envs"] == 1024
-    assert out["value"] > 0 and "gloo all_gather" in out["config"]["obs_gather"]
+    assert out["value"] > 0 and out["config"]["gather_path"] == "copy", out["config"]["obs_gather"]
     # every N > 1 line carries the CPU baseline (rank 0 times it while the others wait at the final barrier), the cost of the
     # gather as a number, and where the rank's threads were put
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
@@ -60,6 +60,18 @@ def test_first_rccl_run_one_rank_force_gather():
                "--no-cpu-baseline")
     cfg = out["config"]
     assert out["n_gpus"] == 1 and cfg["world_size_observed"] == 1 and cfg["dist_backend"] == "nccl"
-    assert "all_gather" in cfg["obs_gather"] and out["value"] > 1e6
+    assert cfg["gather_path"] == "copy" and out["value"] > 1e6
     assert isinstance(out["gather_overhead_us"], float) and abs(out["gather_overhead_us"]) < 50.0
     assert out["no_gather"]["median_us_per_step"] > 0
+
+
+
+def test_rccl_collective_path_still_runs():
+    """`--gather-path rccl`: the all_gather_into_tensor variant (the fallback of the copy path), one rank over nccl and two ranks
+    sharing the GPU over gloo."""
+    out = _run("--gpus", "1", "--force-gather", "--dist-backend", "nccl", "--gather-path", "rccl", "--steps", "20", "--warmup", "5", "--no-pixels",
+               "--no-stack", "--no-cpu-baseline", "--min-time", "0.2")
+    assert out["config"]["gather_path"] == "rccl" and "nccl all_gather" in out["config"]["obs_gather"]
+    out = _run("--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo", "--oversubscribe", "--envs-per-gpu", "512", "--min-time", "0.1",
+               "--gather-every", "4", "--gather-path", "rccl", "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["config"]["gather_path"] == "rccl" and "gloo all_gather" in out["config"]["obs_gather"]

@@ -1,0 +1,27 @@
+"""The copy-path observation gather (gym_genesis/sharding.py: CopyPathGather) between PROCESSES: two and three ranks of a
+torch.distributed.run job share the one GPU of the test box; their receive buffers are mapped into each other through HIP IPC
+handles, blocks travel as device-to-device copies on a side stream with a sequence word behind each, and every rank checks every
+other rank's blocks over twelve rounds (both slots, full and partial blocks).  On a multi-GPU node the same code addresses peer
+devices; what cannot be exercised here is the xGMI transport itself."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_copy_path_gather_between_processes(world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(ROOT, "tests", "copy_gather_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and f"COPY_GATHER_OK {world}" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
