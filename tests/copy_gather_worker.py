@@ -19,11 +19,13 @@ def main() -> int:
     numel = 5000
     cg, why = make_copy_gather(numel, dev)
     assert cg is not None, why
+    base = cg.pushes                          # (make_copy_gather's verification was push number 1)
+    assert base == 1
     for k in range(12):
         n = numel if k % 3 else 1234          # full and partial blocks, both slots
         block = torch.arange(n, dtype=torch.float32, device=dev) * (k + 1) + 1e6 * (rank + 1)
         seq = cg.push(block)
-        assert seq == k + 1
+        assert seq == base + k + 1
         cg.wait(seq, timeout_s=20.0)
         got = cg.gathered(seq, n)
         for r in range(world):
