@@ -178,7 +178,7 @@ def parse_args(argv=None):
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--min-time", type=float, default=0.5, help="repeat the timed K-step region until this many seconds are measured")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL observation gather")
-    ap.add_argument("--gather-every", type=int, default=8,
+    ap.add_argument("--gather-every", type=int, default=32,
                     help="N>1: all-gather the outputs of this many consecutive steps in one collective (1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pixels", action="store_true", help="skip the secondary pixels (configs[4]) measurement")
@@ -192,6 +192,9 @@ def parse_args(argv=None):
                     help="N>1: how the observation gather travels -- copy: peer-to-peer device copies on the SDMA engines + sequence words "
                          "(sharding.CopyPathGather; no kernel takes CUs / LDS from the step kernel), verified at start-up against the RCCL "
                          "collective and replaced by it where peer access does not work; rccl: all_gather_into_tensor")
+    ap.add_argument("--output-ring", type=int, default=0,
+                    help="experiment: step outputs as rows of a ring of this many steps even without a gather (not the headline's semantics: "
+                         "GenesisEnv.step hands out fresh tensors by default)")
     ap.add_argument("--no-gather-ab", action="store_true",
                     help="skip the second headline measurement WITHOUT the gather that gives `gather_overhead_us` (runs whenever a gather is on)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for plumbing checks)")
@@ -754,13 +757,18 @@ def worker(args) -> int:
         from gym_genesis.sharding import make_copy_gather
         copy_gather, gather_note = make_copy_gather(S * flat, dev)
     last_seq = [0]
+    # the step kernels write straight into the gather's send buffer: the outputs of consecutive steps are consecutive rows of one
+    # ring (4 chunks of S steps: two in flight, one being filled, one spare), a chunk = S contiguous rows, no concatenation
+    ring = task._mir.use_output_ring(4 * S, 9, 11) if gather else None
+    if not gather and args.output_ring > 0:
+        task._mir.use_output_ring(args.output_ring, 9, 11)
     chunk_parts: list = []
     state = {"chunk": 0, "t": 0, "resets": 0}
 
     def flush():
         """All-gather the outputs of the steps collected so far (async: overlaps the following steps)."""
         if gather_on[0] and chunk_parts:
-            send = torch.cat(chunk_parts)
+            send = chunk_parts[0] if len(chunk_parts) == 1 else torch.cat(chunk_parts)
             if copy_gather is not None:
                 last_seq[0] = copy_gather.push(send)   # device-to-device copies on the side stream: nothing to wait for here
             else:
@@ -777,8 +785,9 @@ def worker(args) -> int:
         for _ in range(k):
             obs, reward, terminated, truncated, info = step(act_list[t % n])
             if gather_on[0]:
-                chunk_parts.extend((obs["agent_pos"].reshape(-1), obs["environment_state"].reshape(-1), reward))
-                if len(chunk_parts) == 3 * S:
+                row = obs["agent_pos"].storage_offset() // flat   # the ring row this step's kernel wrote
+                if row % S == S - 1:                              # a chunk is complete: its S rows are one contiguous block
+                    chunk_parts.append(ring[row - S + 1:row + 1].reshape(-1))
                     flush()
             t += 1
             if terminated.any() or truncated.any() or t % EPISODE_STEPS == 0:

@@ -813,6 +813,26 @@ extern "C" int mir_debug_poison_lds(int device_id, void* stream) {
   return MIR_OK;
 }
 
+int mir_p2p_enable(int32_t device, int32_t peer) {
+  if (device == peer) return MIR_OK;
+  DeviceGuard guard(device);
+  int can = 0;
+  HIPCHK(hipDeviceCanAccessPeer(&can, device, peer));
+  if (!can) return set_err(MIR_E_HIP, "mir_p2p_enable: the device cannot access the peer's memory");
+  hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+  if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return hip_fail(e, "hipDeviceEnablePeerAccess");
+  (void)hipGetLastError();
+  return MIR_OK;
+}
+
+int mir_p2p_push(void* const* dst, int32_t n, const void* src, uint64_t nbytes, void* const* flag_dst, const void* flag_src, void* stream) {
+  if (!dst || !src || n <= 0 || (flag_dst && !flag_src)) return set_err(MIR_E_INVALID, "mir_p2p_push: bad argument");
+  for (int i = 0; i < n; i++) HIPCHK(hipMemcpyAsync(dst[i], src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (flag_dst)
+    for (int i = 0; i < n; i++) HIPCHK(hipMemcpyAsync(flag_dst[i], flag_src, 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MIR_OK;
+}
+
 int mir_get_obs(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   DeviceGuard guard(h->device);

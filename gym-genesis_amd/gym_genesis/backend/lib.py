@@ -143,9 +143,33 @@ class StepHelpers:
             raise ValueError(f"action must have shape {(self.num_envs, dim)}, got {tuple(action.shape)}")
         return action
 
+    def use_output_ring(self, steps: int, agent_dim: int, env_dim: int) -> torch.Tensor:
+        """From now on the outputs of consecutive steps are consecutive ROWS of one preallocated (steps, B * (agent + env + 1)) float32
+        buffer (row = [agent_pos (B, a) | environment_state (B, e) | reward (B)] of one step) instead of fresh allocations: the
+        send buffer of a sharded run's observation gather IS the place the kernels write to (bench.py, sharding.CopyPathGather), no
+        concatenation, no per-step allocation.  A row is overwritten `steps` steps later: what the caller keeps from a step is
+        valid for that long (the default -- fresh tensors every step, like the reference -- is unchanged).  Returns the buffer."""
+        B, w = self.num_envs, agent_dim + env_dim + 1
+        buf = torch.empty((steps, B * w), dtype=torch.float32, device=self.device)
+        term = torch.empty((steps, B), dtype=torch.uint8, device=self.device)
+        slots = []
+        for i in range(steps):
+            row, base = buf[i], buf[i].data_ptr()
+            outs = (row[:agent_dim * B].view(B, agent_dim), row[agent_dim * B:(agent_dim + env_dim) * B].view(B, env_dim),
+                    row[(agent_dim + env_dim) * B:], term[i])
+            slots.append((outs, (base, base + 4 * agent_dim * B, base + 4 * (agent_dim + env_dim) * B, term[i].data_ptr())))
+        self.__dict__.get("_fresh", {}).clear()   # (outputs registered ahead came from the allocator)
+        self._ring = {"dims": (agent_dim, env_dim), "slots": slots, "pos": 0, "n": steps, "buf": buf, "term": term}
+        return buf
+
     def _alloc_outputs(self, agent_dim: int, env_dim: int):
         """Fresh output tensors of one step, with their device addresses (so the launch itself does no attribute lookups):
         ((agent_pos, environment_state, reward, terminated u8), (ptr, ptr, ptr, ptr))."""
+        ring = self.__dict__.get("_ring")
+        if ring is not None and ring["dims"] == (agent_dim, env_dim):
+            i = ring["pos"]
+            ring["pos"] = i + 1 if i + 1 < ring["n"] else 0
+            return ring["slots"][i]
         B = self.num_envs
         buf = torch.empty(B * (agent_dim + env_dim + 1), dtype=torch.float32, device=self.device)
         term = torch.empty(B, dtype=torch.uint8, device=self.device)

@@ -376,6 +376,17 @@ typedef struct MirIkOptions {
 int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_pos, const float* target_quat, const float* init_qpos,
                            const MirIkOptions* opt, float* qpos_out, float* err_out, void* stream);
 
+/* ---- multi-GPU observation gather on the copy path (no reference counterpart: README.md:41-48 is single-device) ----
+ * One process per GPU; every rank owns a receive buffer that the other ranks have mapped through HIP IPC (the host side does the
+ * handle exchange: gym_genesis/sharding.py: CopyPathGather).  mir_p2p_push enqueues, on `stream` of the CURRENT device, one
+ * device-to-device copy of `nbytes` from src to each of the n destinations (addresses inside the peers' buffers; a local address
+ * is a plain device copy) and THEN one 4-byte copy of *flag_src to each flag_dst[i]: copies of one stream complete in order, so a
+ * receiver that sees the sequence word has the whole block.  No kernel is launched (the copies run on the SDMA engines), which
+ * is the point: a collective kernel cannot share a CU with the step kernel's four resident workgroups.
+ * mir_p2p_enable makes `peer`'s memory addressable from `device` (idempotent). */
+int mir_p2p_enable(int32_t device, int32_t peer);
+int mir_p2p_push(void* const* dst, int32_t n, const void* src, uint64_t nbytes, void* const* flag_dst, const void* flag_src, void* stream);
+
 /* ---- debug aids (exported for the tests and tools/; not part of the drop-in surface) ---------------------------
  * mir_debug_profile_step: one step with phase timestamps (shader clock) of workgroup 0 into prof (32 x u64, device).
  * mir_debug_poison_lds: overwrite the LDS of every CU with signalling-NaN patterns, so that a kernel reading an LDS slot
