@@ -411,6 +411,12 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
     return mir_set_error(MIR_E_INVALID, "mir_render: bad camera (res / fov)");
   if (mode != MIR_RENDER_PER_ENV && mode != MIR_RENDER_GLOBAL) return mir_set_error(MIR_E_INVALID, "mir_render: unknown mode");
   if (!(vis->checker_size > 0.0)) return mir_set_error(MIR_E_INVALID, "mir_render: checker_size must be > 0");
+  // Addressing limits of the pixel kernel: the image index is the grid's z coordinate (<= 65535 images per call), a pixel's byte
+  // offset INSIDE its image is 32 bits (the image base is 64 bits: B x H x W x 3 may exceed 2^31 and 2^32; tests/test_gpu_render.py
+  // renders 2400 x 480 x 640 x 3 = 3.3 GB)
+  if ((unsigned long long)cam->width * (unsigned long long)cam->height * 3ull >= (1ull << 32))
+    return mir_set_error(MIR_E_CAPACITY, "mir_render: one image must stay below 2^32 bytes (width x height x 3)");
+  if (mode == MIR_RENDER_PER_ENV && h->B > 65535) return mir_set_error(MIR_E_CAPACITY, "mir_render: at most 65535 per-env images per call");
   double f[3] = {1, 0, 0}, r[3] = {0, 1, 0}, u[3] = {0, 0, 1};
   if (!cam_pos) {
     double d[3] = {cam->lookat[0] - cam->pos[0], cam->lookat[1] - cam->pos[1], cam->lookat[2] - cam->pos[2]};

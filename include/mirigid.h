@@ -340,7 +340,8 @@ int mir_visual_sizeof(void);
 /* Render RGB8 images of the current state.  mode PER_ENV: pixels (B,H,W,3) u8, env e drawn alone
  * as seen from `cam` in its own frame (env_offset ignored).  mode GLOBAL: pixels (H,W,3) u8, every env
  * drawn displaced by env_offset[e] (B,3 f32 device, NULL = all zero); plane geoms are drawn once.
- * cam / vis are host structs (copied into the launch).  pixels is a device pointer. */
+ * cam / vis are host structs (copied into the launch).  pixels is a device pointer.  B x H x W x 3 may exceed 2^32 bytes (64-bit
+ * image bases); MIR_E_CAPACITY when a single image reaches 2^32 bytes or a per-env call has more than 65535 images. */
 int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, int32_t mode, const float* env_offset,
                uint8_t* pixels, void* stream);
 

@@ -93,6 +93,59 @@ def test_global_image_matches_oracle():
     _compare(img, ref, max_bad_frac=3e-3)  # hundreds of small silhouettes: more edge pixels per image
 
 
+def _single_env_image(builder, qpos_row, cam, vis):
+    """The image of ONE env holding `qpos_row`, rendered by a scene of its own."""
+    from gym_genesis.backend.lib import MirScene
+
+    one = MirScene(builder.build(), 1)
+    one.set_state(qpos=qpos_row[None])
+    return one.render(cam, vis, mode=0)[0]
+
+
+def test_cfg5_real_size_1024_envs_480x640():
+    """BASELINE configs[4] at its real size -- 1024 per-env images of 480 x 640 x 3 (943.7 MB per render): the first, a middle and
+    the last image equal the render of a single-env scene holding that env's state bit for bit (no image sees another env's
+    primitives, tiles or store offsets), and the middle one is within 1 LSB of the float64 ray caster."""
+    B = 1024
+    builder = models.franka_cube_pick_scene()
+    sc = _stepped_scene(builder, B, steps=12)
+    cam = make_camera(640, 480, (3.5, 0.0, 2.5), (0, 0, 0.5), 30)   # cube_pick.py:56-63
+    vis = builder.visual()
+    img = sc.render(cam, vis, mode=0)
+    assert img.shape == (B, 480, 640, 3) and img.dtype == torch.uint8 and img.numel() == 943718400
+    q = sc.get_state()[0]
+    for e in (0, 511, 1023):
+        assert torch.equal(img[e], _single_env_image(builder, q[e], cam, vis)), f"env {e}"
+    xpos, xquat = (t.cpu().numpy() for t in sc.get_links())
+    ref = orc.render_image(builder.build(), cam, vis, xpos[511:512], xquat[511:512])
+    _compare(img[511].cpu().numpy(), ref)
+    assert not torch.equal(img[0], img[1023])
+
+
+def test_more_than_2_31_bytes_of_pixels_and_the_addressing_limits():
+    """2400 x 480 x 640 x 3 = 3.3 GB in one call: the images on either side of the 2^31- and 2^32-byte marks (envs 2330 and -- past
+    the end here -- none for 2^32, so also 2399, the last) equal their single-env renders; an image of 2^32 bytes or more is
+    refused with MIR_E_CAPACITY before anything is launched."""
+    import ctypes as C
+
+    B = 2400
+    builder = models.franka_cube_pick_scene()
+    sc = _stepped_scene(builder, B, steps=3)
+    cam = make_camera(640, 480, (3.5, 0.0, 2.5), (0, 0, 0.5), 30)
+    vis = builder.visual()
+    img = sc.render(cam, vis, mode=0)
+    assert img.numel() > 2 ** 31
+    q = sc.get_state()[0]
+    for e in (2329, 2330, 2331, 2399):
+        assert torch.equal(img[e], _single_env_image(builder, q[e], cam, vis)), f"env {e}"
+    del img
+    torch.cuda.empty_cache()
+    big = make_camera(40000, 36000, (3.5, 0.0, 2.5), (0, 0, 0.5), 30)   # 4.3e9 bytes per image
+    dummy = torch.empty(16, dtype=torch.uint8, device=sc.device)
+    rc = sc.lib.mir_render(sc.h, C.byref(big), C.byref(vis), 0, None, C.c_void_p(dummy.data_ptr()), sc._stream())
+    assert rc == -2 and b"2^32" in sc.lib.mir_last_error()   # MIR_E_CAPACITY
+
+
 def test_render_is_deterministic_and_does_not_disturb_physics():
     B = 8
     builder = models.franka_cube_pick_scene()
