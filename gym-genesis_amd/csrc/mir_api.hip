@@ -407,6 +407,7 @@ int mir_destroy(MirHandle h) {
   if (h->poses) (void)hipFree(h->poses);
   if (h->fkvalid) (void)hipFree(h->fkvalid);
   if (h->prims) (void)hipFree(h->prims);
+  if (h->bins) (void)hipFree(h->bins);
   if (h->done_ticket) (void)hipFree(h->done_ticket);
   if (h->scratch_row) (void)hipFree(h->scratch_row);
   if (h->pre) (void)hipFree(h->pre);

@@ -7,19 +7,21 @@
 //
 // MI355X mapping.  At B=1024, 480x640 the output is 943 MB per step, so the kernel is HBM-WRITE-bound
 // by construction; everything else is arranged to stay below that:
-//   * k_render_setup (one thread per (env, geom)): world pose of every primitive from the step kernel's
-//     FK cache, the camera expressed in the primitive's frame (origin o', and the images F', R', U' of
-//     the camera basis, so a pixel's ray in that frame is d' = F' + x R' + y U': 6 FMAs, no matrix
-//     product), FINAL packed RGB8 colours per face (albedo x shade) or, for a plane, the two checker colours
-//     and the affine numerators of the perspective-correct checker coordinate, and a conservative screen
-//     rectangle.  128 B per primitive.  Per-env cameras (mir_render_cams) are resolved here too.
-//   * mir_render_kernel: workgroup = 256 threads = 4 waves stacked on a 128-pixel-wide strip, walked as
-//     128 x 32 sub-tiles; the strip's primitives are culled once by rectangle (ordered ballot compaction, id list
-//     in LDS); records are fetched with wave-uniform SCALAR loads (constant address space); a lane owns 4
-//     consecutive pixels of a row in each of four 128 x 2 regions of its wave's 8-row band, culled per band and
-//     region by scalar branches;
-//     arithmetic on packed fp32 pixel pairs; 4 pixels -> 3 dwords -> one global_store_dwordx3 per lane, not
-//     waited for (the next sub-tile's arithmetic runs under the stores).
+//   * k_render_setup: world pose of every primitive from the step kernel's FK cache, the camera expressed in the
+//     primitive's frame (origin o', and the images F', R', U' of the camera basis, so a pixel's ray in that frame is
+//     d' = F' + x R' + y U': 6 FMAs, no matrix product), FINAL packed RGB8 colours per face (albedo x shade) or, for a
+//     plane, the two checker colours and the affine numerators of the perspective-correct checker coordinate, and a
+//     conservative screen rectangle.  128 B per primitive.  Per-env cameras (mir_render_cams) are resolved here too.
+//     For per-env images one WAVE handles an env (lane = geom) and also writes the per-strip primitive lists.
+//   * mir_render_binned (per-env images, the pixels observation): workgroup = 4 waves stacked on a 128-pixel-wide strip
+//     of 160 rows, walked as 128 x 32 sub-tiles, wave = a band of 128 x 8 pixels.  The strip's list arrives with one
+//     vector load (lane k = entry k); depth-tested primitives are drawn on 32 x 8-pixel regions (lane = 4 pixels of one
+//     row), only where the entry's row range and column mask say so, records by wave-uniform SCALAR loads; their colours
+//     move through a wave-private LDS tile into the store layout (regions of 128 x 2: lane = 4 consecutive pixels, one
+//     global_store_dwordx3 per lane and region = whole 128-byte lines, not waited for); the floor is drawn last, in
+//     the store layout, without a depth buffer.  1024 x 480 x 640: 227 us = 4.15 TB/s written (round 2: 335 us).
+//   * mir_render_kernel (the global view of all envs, odd widths): the same tiling with the list culled per workgroup
+//     (ordered ballot compaction into LDS) and everything drawn in the store layout.
 //   * ray/box in the box frame is a 3-slab test; depth order is resolved per pixel (strict <, list in
 //     ascending primitive order => deterministic); the colour of a hit is selected at hit time from the
 //     record, so there is no shading pass and no per-pixel lookup.
@@ -36,6 +38,9 @@
 #define TW 128   /* tile width, pixels  */
 #ifndef TH
 #define TH 96   /* rows per workgroup strip (multiple of 32): walked as 128 x 32 sub-tiles */
+#endif
+#ifndef TH_BINNED
+#define TH_BINNED 160 /* strip height of the binned kernel (swept on MI355X at 1024 x 480 x 640: 96 -> 253, 160 / 256 -> 234, 480 -> 242 us) */
 #endif
 #define PREC 32  /* floats per primitive record */
 #ifndef MIR_RENDER_NT
@@ -89,6 +94,14 @@ struct PixArgs {
   float x0, dx, y0, dy;  // image-plane coordinates of pixel (i, j): x0 + i dx, y0 + j dy
   unsigned sky;          // packed RGB8
   int th;                // rows per workgroup strip (multiple of 32)
+  const int* bins;       // binned kernel: (image, strip row, strip column, BINW) lists written by k_render_bin
+};
+
+#define BINW 64  /* ints per strip list: header (count | floor flag << 8), then one packed entry per listed primitive */
+struct BinArgs {
+  const float* prims;
+  int* bins;
+  int W, H, nprim, th, nsx, nsy, nimg;
 };
 
 __device__ __forceinline__ f2 rcp2(f2 v) { return f2{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; }
@@ -104,10 +117,16 @@ __device__ __forceinline__ float pack_rgb(const float* alb, float shade) {
 //  box  : q5 = colours of the faces +x +y +z -x, q6 = -y -z
 //  plane: q5 = Nu0 NuX NuY colour(even cell), q6 = Nv0 NvX NvY colour(odd cell), with the hit point's checker
 //         coordinate u/2 = (Nu0 + x NuX + y NuY) / d'z  (perspective-correct ratio of two affine functions)
-__global__ void k_render_setup(SetupArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.B * a.ngeom) return;
-  const int e = i / a.ngeom, g = i % a.ngeom;
+// BIN: one WAVE per env (lane = geom, ngeom <= 63) and the per-strip lists of the binned pixel kernel are written here as well
+// (see below); otherwise one thread per (env, geom).
+template <bool BIN>
+__global__ void k_render_setup(SetupArgs a, BinArgs bn) {
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = BIN ? gi >> 6 : gi / a.ngeom;
+  const bool valid = BIN ? (e < a.B && (gi & 63) < a.ngeom) : gi < a.B * a.ngeom;
+  if (BIN ? e >= a.B : !valid) return;  // (BIN: whole waves leave together)
+  const int g = valid ? (BIN ? gi & 63 : gi % a.ngeom) : 0;
+  const int i = e * a.ngeom + g;
   const GeomTab* __restrict__ m = a.geom;
   const int b = m->g_body[g], gtype = m->g_type[g];
   // round geoms are drawn as their bounding boxes (sphere: r r r; capsule: r r half+r): the rasteriser knows boxes and planes
@@ -181,15 +200,89 @@ __global__ void k_render_setup(SetupArgs a) {
     q5 = f4{s * (o.x * F.z - o.z * F.x), s * (o.x * R.z - o.z * R.x), s * (o.x * U.z - o.z * U.x), pack_rgb(a.chk[0], sh)};
     q6 = f4{s * (o.y * F.z - o.z * F.y), s * (o.y * R.z - o.z * R.y), s * (o.y * U.z - o.z * U.y), pack_rgb(a.chk[1], sh)};
   }
-  f4* o4 = reinterpret_cast<f4*>(a.prims + (size_t)i * PREC);
-  o4[0] = f4{o.x, o.y, o.z, __int_as_float(type)};
-  o4[1] = f4{F.x, F.y, F.z, __int_as_float(xmin)};
-  o4[2] = f4{R.x, R.y, R.z, __int_as_float(xmax)};
-  o4[3] = f4{U.x, U.y, U.z, __int_as_float(ymin)};
-  o4[4] = f4{h.x, h.y, h.z, __int_as_float(ymax)};
-  o4[5] = q5;
-  o4[6] = q6;
-  o4[7] = f4{0, 0, 0, 0};
+  if (valid) {
+    f4* o4 = reinterpret_cast<f4*>(a.prims + (size_t)i * PREC);
+    o4[0] = f4{o.x, o.y, o.z, __int_as_float(type)};
+    o4[1] = f4{F.x, F.y, F.z, __int_as_float(xmin)};
+    o4[2] = f4{R.x, R.y, R.z, __int_as_float(xmax)};
+    o4[3] = f4{U.x, U.y, U.z, __int_as_float(ymin)};
+    o4[4] = f4{h.x, h.y, h.z, __int_as_float(ymax)};
+    o4[5] = q5;
+    o4[6] = q6;
+    o4[7] = f4{0, 0, 0, 0};
+  }
+  if (!BIN) return;
+  // ---- per-strip primitive lists of the binned pixel kernel (per-env images with <= 63 primitives), built while the rectangles
+  // are still in registers.  For every strip of the image the primitives whose rectangle meets it are listed in ascending order
+  // (ballot + prefix count), each as  id | ymin << 6 | ymax << 17 | columns << 28  (rows clamped to 11 bits; `columns` = which of
+  // the strip's four 32-pixel columns the rectangle meets), so that the pixel kernel can cull a primitive against a wave's 8-row
+  // band and its 32 x 8 regions WITHOUT fetching its record.  Header = count | floor << 8: `floor` says that primitive 0 is a
+  // plane seen by a roll-free camera (the floor of every scene of the reference); it is then left out of the list and drawn by
+  // the pixel kernel's floor pass.  This replaces the per-workgroup culling prologue of the generic kernel (one global load per
+  // thread, two ballots and three barriers per strip: 40 us of the 335 us a 1024 x 480 x 640 render took).
+  const int lane = gi & 63;
+  const bool is_floor = valid && g == 0 && type != MIR_GEOM_BOX && R.z == 0.0f && xmin <= 0 && xmax >= bn.W - 1 && ymin <= 0 && ymax >= bn.H - 1;
+  const int floor = __builtin_amdgcn_readfirstlane(is_floor ? 1 : 0);  // lane 0 = geom 0
+  for (int st = 0; st < bn.nsx * bn.nsy; st++) {
+    const int sx = st % bn.nsx, sy = st / bn.nsx;
+    const int tx0 = sx * TW, txmax = min(tx0 + TW, bn.W) - 1, sy0 = sy * bn.th, symax = min(sy0 + bn.th, bn.H) - 1;
+    const bool hit = valid && !is_floor && xmin <= txmax && xmax >= tx0 && ymin <= symax && ymax >= sy0;
+    const unsigned long long bal = __ballot(hit);
+    int* out = bn.bins + ((size_t)e * bn.nsx * bn.nsy + st) * BINW;
+    if (hit) {
+      int rmask = 0;
+#pragma unroll
+      for (int r = 0; r < 4; r++) rmask |= (xmax < tx0 + 32 * r || xmin > tx0 + 32 * r + 31) ? 0 : 1 << r;
+      out[1 + __popcll(bal & ((1ull << lane) - 1ull))] = g | max(ymin, 0) << 6 | min(ymax, 2047) << 17 | rmask << 28;
+    }
+    if (lane == 0) out[0] = __popcll(bal) | floor << 8;
+  }
+}
+
+// ray / box in the box frame on ONE region of a wave: the lane's 4 consecutive pixels (two packed pairs, image-plane x in xs)
+// of the row with image-plane y `ys`.  Shared by both pixel kernels, which therefore agree bit for bit.
+__device__ __forceinline__ void box_region(const f4 ro, const f4 rf, const f4 rr, const f4 ru, const f4 rh, const f4 q5, const f4 q6, float ys,
+                                           const f2 (&xs)[2], f2 (&best)[2], unsigned (&col)[4]) {
+  const float ax = -rh.x - ro.x, bx = rh.x - ro.x, ay = -rh.y - ro.y, by = rh.y - ro.y, az = -rh.z - ro.z, bz = rh.z - ro.z;
+  const float ex = fmaf(ys, ru.x, rf.x), ey = fmaf(ys, ru.y, rf.y), ez = fmaf(ys, ru.z, rf.z);
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const f2 dxp = xs[h] * rr.x + ex, dyp = xs[h] * rr.y + ey, dzp = xs[h] * rr.z + ez;
+    const f2 ix = rcp2(dxp), iy = rcp2(dyp), iz = rcp2(dzp);
+    const f2 x1 = ix * ax, x2 = ix * bx, y1 = iy * ay, y2 = iy * by, z1 = iz * az, z2 = iz * bz;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const float nx = fminf(x1[q], x2[q]), ny = fminf(y1[q], y2[q]), nz = fminf(z1[q], z2[q]);
+      const float tn = fmaxf(fmaxf(nx, ny), nz);
+      const float tf = fminf(fminf(fmaxf(x1[q], x2[q]), fmaxf(y1[q], y2[q])), fmaxf(z1[q], z2[q]));
+      const bool upd = tn <= tf && tn > 1e-6f && tn < best[h][q];
+      // the face whose slab entry is the latest; the ray enters through the face opposing its direction
+      const float cx = dxp[q] > 0.0f ? q5.w : q5.x, cy = dyp[q] > 0.0f ? q6.x : q5.y, cz = dzp[q] > 0.0f ? q6.y : q5.z;
+      const unsigned c = __float_as_uint(tn == nx ? cx : (tn == ny ? cy : cz));
+      best[h][q] = upd ? tn : best[h][q];
+      col[2 * h + q] = upd ? c : col[2 * h + q];
+    }
+  }
+}
+
+// a plane in the general position (depth-tested, any camera) on one region
+__device__ __forceinline__ void plane_region(const f4 ro, const f4 rf, const f4 rr, const f4 ru, const f4 q5, const f4 q6, float ys,
+                                             const f2 (&xs)[2], f2 (&best)[2], unsigned (&col)[4]) {
+  const unsigned ceven = __float_as_uint(q5.w), codd = __float_as_uint(q6.w);
+  const float ez = fmaf(ys, ru.z, rf.z), eu = fmaf(ys, q5.z, q5.x), ev = fmaf(ys, q6.z, q6.x);
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const f2 iz = rcp2(xs[h] * rr.z + ez);
+    const f2 t = iz * (-ro.z);
+    const f2 u = (xs[h] * q5.y + eu) * iz, v = (xs[h] * q6.y + ev) * iz;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
+      const bool upd = t[q] > 1e-6f && t[q] < best[h][q];
+      best[h][q] = upd ? t[q] : best[h][q];
+      col[2 * h + q] = upd ? (odd ? codd : ceven) : col[2 * h + q];
+    }
+  }
 }
 
 // ---- pixels --------------------------------------------------------------------------------------
@@ -269,33 +362,14 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
         // plain global_load here would also tie the record fetch to the outstanding pixel stores through vmcnt
         const cf4* rec = (const cf4*)(uintptr_t)(prims + (size_t)id * PREC);
         const f4 ro = rec[0], rf = rec[1], rr = rec[2], ru = rec[3], rh = rec[4], q5 = rec[5], q6 = rec[6];
-        const int xmin = __float_as_int(rf.w), xmax = __float_as_int(rr.w), ymin = __float_as_int(ru.w), ymax = __float_as_int(rh.w);
+        const int ymin = __float_as_int(ru.w), ymax = __float_as_int(rh.w);
         if (ymax < wy0 || ymin > wy0 + 7) continue;  // wave-uniform band cull (the strip cull covered x)
         if (__float_as_int(ro.w) == MIR_GEOM_BOX) {
-          const float ax = -rh.x - ro.x, bx = rh.x - ro.x, ay = -rh.y - ro.y, by = rh.y - ro.y, az = -rh.z - ro.z, bz = rh.z - ro.z;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int wy = wy0 + 2 * r;  // wave-uniform region cull: rows wy, wy + 1
             if (ymax < wy || ymin > wy + 1) continue;
-            const float ex = fmaf(ysr[r], ru.x, rf.x), ey = fmaf(ysr[r], ru.y, rf.y), ez = fmaf(ysr[r], ru.z, rf.z);
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-              const f2 dxp = xs[h] * rr.x + ex, dyp = xs[h] * rr.y + ey, dzp = xs[h] * rr.z + ez;
-              const f2 ix = rcp2(dxp), iy = rcp2(dyp), iz = rcp2(dzp);
-              const f2 x1 = ix * ax, x2 = ix * bx, y1 = iy * ay, y2 = iy * by, z1 = iz * az, z2 = iz * bz;
-#pragma unroll
-              for (int q = 0; q < 2; q++) {
-                const float nx = fminf(x1[q], x2[q]), ny = fminf(y1[q], y2[q]), nz = fminf(z1[q], z2[q]);
-                const float tn = fmaxf(fmaxf(nx, ny), nz);
-                const float tf = fminf(fminf(fmaxf(x1[q], x2[q]), fmaxf(y1[q], y2[q])), fmaxf(z1[q], z2[q]));
-                const bool upd = tn <= tf && tn > 1e-6f && tn < best[r][h][q];
-                // the face whose slab entry is the latest; the ray enters through the face opposing its direction
-                const float cx = dxp[q] > 0.0f ? q5.w : q5.x, cy = dyp[q] > 0.0f ? q6.x : q5.y, cz = dzp[q] > 0.0f ? q6.y : q5.z;
-                const unsigned c = __float_as_uint(tn == nx ? cx : (tn == ny ? cy : cz));
-                best[r][h][q] = upd ? tn : best[r][h][q];
-                col[r][2 * h + q] = upd ? c : col[r][2 * h + q];
-              }
-            }
+            box_region(ro, rf, rr, ru, rh, q5, q6, ysr[r], xs, best[r], col[r]);
           }
         } else {
           const unsigned ceven = __float_as_uint(q5.w), codd = __float_as_uint(q6.w);
@@ -388,6 +462,138 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
   }
 }
 
+
+// The binned pixel kernel.  Same tiling (workgroup = 4 waves stacked on a 128-pixel-wide strip, walked in 128 x 32 sub-tiles, a
+// wave = a band of 128 x 8 pixels), same per-pixel arithmetic and the same stores as mir_render_kernel -- the two agree bit for
+// bit -- but
+//   * nothing in it waits for memory once the strip has started: the strip's list arrives with ONE vector load per wave (lane k
+//     holds entry k, the loop reads it with v_readlane), the floor's scalars are fetched once per workgroup, a record is fetched
+//     only for the bands its rectangle meets, and there is no workgroup barrier;
+//   * depth-tested primitives are drawn in a second lane layout, four regions of 32 x 8 pixels SIDE BY SIDE (lane = 4 pixels of
+//     row lane / 8), so a primitive costs arithmetic only in the 32-pixel columns its rectangle meets -- the robot's boxes are
+//     20 to 60 pixels wide, and in the store layout (regions of 128 x 2 stacked) each of them ran on all 128 columns.  Their
+//     colours go through a wave-private 4 KB LDS tile into the store layout (NOHIT where nothing was hit);
+//   * the floor is drawn last, in the store layout, without a depth buffer: its depth and colours are row constants (one
+//     reciprocal per lane and row), it fills the pixels the boxes left (all of them in the bands no rectangle meets), and the
+//     boxes were depth-tested against its row depth.
+#define NOHIT 0xffffffffu
+__global__ __launch_bounds__(256) void mir_render_binned(PixArgs a) {
+  __shared__ unsigned s_tile[4][8 * 128];  // per wave: 8 rows x 128 pixels of packed colours
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tx0 = blockIdx.x * TW, sy0 = blockIdx.y * a.th, img = blockIdx.z;
+  const int* bin = a.bins + (((size_t)img * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * BINW;
+  const int ent = bin[lane];
+  const int px = tx0 + 4 * (lane & 31);         // store layout: 4 pixels of rows prow + 2r
+  const int pxa = tx0 + 4 * (lane & 7);         // box layout: 4 pixels of row wy0 + lane / 8, in the columns pxa + 32r
+  const float* __restrict__ prims = a.prims + (size_t)img * a.nprim * PREC;
+  const int symax = min(sy0 + a.th, a.H) - 1;
+  f2 xs[2];
+  xs[0] = f2{a.x0 + (float)px * a.dx, a.x0 + (float)(px + 1) * a.dx};
+  xs[1] = f2{a.x0 + (float)(px + 2) * a.dx, a.x0 + (float)(px + 3) * a.dx};
+  const int hdr = __builtin_amdgcn_readfirstlane(ent);
+  const int cnt = hdr & 255;
+  const bool floor = (hdr >> 8) & 1;
+  // the floor record (primitive 0), read once per workgroup: o'z, F'z, U'z, the checker numerators and the two colours
+  const cf4* frec = (const cf4*)(uintptr_t)prims;
+  float f_oz = 0.0f, f_fz = 0.0f, f_uz = 0.0f;
+  f4 fq5 = f4{0, 0, 0, 0}, fq6 = f4{0, 0, 0, 0};
+  if (floor) {
+    f_oz = frec[0].z; f_fz = frec[1].z; f_uz = frec[3].z;
+    fq5 = frec[5]; fq6 = frec[6];
+  }
+  const unsigned ceven = __float_as_uint(fq5.w), codd = __float_as_uint(fq6.w);
+  uint8_t* __restrict__ ibase = a.pixels + (size_t)img * a.H * a.W * 3;
+  unsigned* tile = s_tile[wv];
+
+  for (int ty0 = sy0; ty0 <= symax; ty0 += 32) {
+    const int wy0 = ty0 + 8 * wv;            // this wave's band of 8 rows
+    if (wy0 > symax) break;
+    const int prow = wy0 + (lane >> 5);      // store layout: rows prow, prow + 2, prow + 4, prow + 6
+    unsigned col[4][4];
+    // ---- depth-tested primitives, box layout.  Lane k tests entry k against the band; one ballot per 32-pixel column gives
+    // the entries to draw there (ascending = list order), so untouched bands and columns cost a handful of instructions
+    unsigned long long cm[4];
+    {
+      const int ymin = (ent >> 6) & 0x7ff, ymax = (ent >> 17) & 0x7ff;
+      const bool on = lane >= 1 && lane <= cnt && !(ymax < wy0 || ymin > wy0 + 7);
+#pragma unroll
+      for (int r = 0; r < 4; r++) cm[r] = __ballot(on && ((ent >> (28 + r)) & 1));
+    }
+    const bool touched = (cm[0] | cm[1] | cm[2] | cm[3]) != 0ull;
+    if (touched) {
+      const float ya = a.y0 + (float)(wy0 + (lane >> 3)) * a.dy;
+      float tb = 3e38f;
+      if (floor) {  // the floor's depth on this lane's row: the same expressions as in the floor pass below
+        const float t1 = __builtin_amdgcn_rcpf(fmaf(ya, f_uz, f_fz)) * (-f_oz);
+        tb = t1 > 1e-6f ? t1 : 3e38f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        unsigned ca[4] = {NOHIT, NOHIT, NOHIT, NOHIT};
+        if (cm[r]) {
+          const int x = pxa + 32 * r;
+          const f2 xsa[2] = {f2{a.x0 + (float)x * a.dx, a.x0 + (float)(x + 1) * a.dx}, f2{a.x0 + (float)(x + 2) * a.dx, a.x0 + (float)(x + 3) * a.dx}};
+          f2 best[2] = {f2{tb, tb}, f2{tb, tb}};
+          for (unsigned long long m = cm[r]; m; m &= m - 1) {
+            const int e = __builtin_amdgcn_readlane(ent, __builtin_ctzll(m));
+            const cf4* rec = (const cf4*)(uintptr_t)(prims + (size_t)(e & 63) * PREC);
+            const f4 ro = rec[0], rf = rec[1], rr = rec[2], ru = rec[3], q5 = rec[5], q6 = rec[6];
+            if (__float_as_int(ro.w) == MIR_GEOM_BOX) box_region(ro, rf, rr, ru, rec[4], q5, q6, ya, xsa, best, ca);
+            else plane_region(ro, rf, rr, ru, q5, q6, ya, xsa, best, ca);
+          }
+        }
+        // box layout -> store layout through the wave's LDS tile (rows of 128 pixels)
+        *reinterpret_cast<uint4*>(tile + (lane >> 3) * 128 + 32 * r + 4 * (lane & 7)) = make_uint4(ca[0], ca[1], ca[2], ca[3]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (no barrier: a wave's LDS operations complete in order)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + (2 * r + (lane >> 5)) * 128 + 4 * (lane & 31));
+        col[r][0] = v.x; col[r][1] = v.y; col[r][2] = v.z; col[r][3] = v.w;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // ---- floor pass, store layout
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      unsigned fc[4];
+      if (floor) {
+        const float y = a.y0 + (float)(prow + 2 * r) * a.dy;
+        const float ez = fmaf(y, f_uz, f_fz), eu = fmaf(y, fq5.z, fq5.x), ev = fmaf(y, fq6.z, fq6.x);
+        const float iz1 = __builtin_amdgcn_rcpf(ez);
+        const bool vld = iz1 * (-f_oz) > 1e-6f;
+        const unsigned c0 = vld ? ceven : a.sky, c1 = vld ? codd : a.sky;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const f2 u = (xs[h] * fq5.y + eu) * iz1, v = (xs[h] * fq6.y + ev) * iz1;
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
+            fc[2 * h + q] = odd ? c1 : c0;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; p++) fc[p] = a.sky;
+      }
+#pragma unroll
+      for (int p = 0; p < 4; p++) col[r][p] = touched ? (col[r][p] == NOHIT ? fc[p] : col[r][p]) : fc[p];
+    }
+    // ---- packed RGB8 store: 4 pixels = 3 dwords per lane and region; not waited for
+    unsigned boff = ((unsigned)prow * (unsigned)a.W + (unsigned)px) * 3u;
+#pragma unroll
+    for (int r = 0; r < 4; r++, boff += 6u * (unsigned)a.W) {
+      if (prow + 2 * r > symax || px >= a.W) continue;
+      const unsigned c0 = col[r][0], c1 = col[r][1], c2 = col[r][2], c3 = col[r][3];
+      u3 v;
+      v.x = c0 | c1 << 24;
+      v.y = c1 >> 8 | c2 << 16;
+      v.z = c2 >> 16 | c3 << 8;
+      *reinterpret_cast<u3*>(ibase + boff) = v;
+    }
+  }
+}
+
 void norm3(const double* v, double* o) {
   const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   for (int k = 0; k < 3; k++) o[k] = n > 0 ? v[k] / n : 0.0;
@@ -460,7 +666,6 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
     sa.amb = (float)vis->ambient; sa.dif = (float)vis->diffuse; sa.inv_chk = (float)(1.0 / vis->checker_size);
     for (int k = 0; k < 3; k++) { sa.chk[0][k] = (float)vis->checker_rgb[0][k]; sa.chk[1][k] = (float)vis->checker_rgb[1][k]; }
     sa.B = B; sa.ngeom = ng; sa.global_mode = mode == MIR_RENDER_GLOBAL;
-    hipLaunchKernelGGL(k_render_setup, dim3((B * ng + 255) / 256), dim3(256), 0, st, sa);
     PixArgs pa;
     memset(&pa, 0, sizeof pa);
     pa.prims = h->prims; pa.pixels = pixels; pa.W = cam->width; pa.H = cam->height;
@@ -471,9 +676,32 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
       auto u8 = [](double c) { return (unsigned)(std::fmin(std::fmax(c, 0.0), 1.0) * 255.0 + 0.5); };
       pa.sky = u8(vis->sky_rgb[0]) | u8(vis->sky_rgb[1]) << 8 | u8(vis->sky_rgb[2]) << 16;
     }
-    pa.th = TH;
+    pa.th = h->render_th > 0 ? h->render_th : TH;
     const int nimg = mode == MIR_RENDER_GLOBAL ? 1 : B;
-    hipLaunchKernelGGL(mir_render_kernel, dim3((cam->width + TW - 1) / TW, (cam->height + pa.th - 1) / pa.th, nimg), dim3(256), 0, st, pa);
+    // Per-env images (short primitive lists) take the binned kernel; the global view of all envs (one long list), widths
+    // that are not a multiple of 4 pixels and images taller than the 11-bit row fields keep the generic kernel.
+    const bool binned = mode == MIR_RENDER_PER_ENV && ng < BINW && (cam->width & 3) == 0 && cam->height <= 2048 && !h->render_generic;
+    if (binned) {
+      pa.th = h->render_th > 0 ? h->render_th : TH_BINNED;
+      const int nsx = (cam->width + TW - 1) / TW, nsy = (cam->height + pa.th - 1) / pa.th;
+      const size_t need = (size_t)nimg * nsx * nsy * BINW;
+      if (need > h->bins_cap) {
+        if (h->bins) (void)hipFree(h->bins);
+        h->bins = nullptr; h->bins_cap = 0;
+        hipError_t e = hipMalloc((void**)&h->bins, need * sizeof(int));
+        if (e != hipSuccess) { rc = mir_set_error(MIR_E_HIP, hipGetErrorString(e)); break; }
+        h->bins_cap = need;
+      }
+      BinArgs ba;
+      ba.prims = h->prims; ba.bins = h->bins; ba.W = cam->width; ba.H = cam->height; ba.nprim = pa.nprim; ba.th = pa.th;
+      ba.nsx = nsx; ba.nsy = nsy; ba.nimg = nimg;
+      hipLaunchKernelGGL(k_render_setup<true>, dim3((B * 64 + 255) / 256), dim3(256), 0, st, sa, ba);
+      pa.bins = h->bins;
+      hipLaunchKernelGGL(mir_render_binned, dim3(nsx, nsy, nimg), dim3(256), 0, st, pa);
+    } else {
+      hipLaunchKernelGGL(k_render_setup<false>, dim3((B * ng + 255) / 256), dim3(256), 0, st, sa, BinArgs{});
+      hipLaunchKernelGGL(mir_render_kernel, dim3((cam->width + TW - 1) / TW, (cam->height + pa.th - 1) / pa.th, nimg), dim3(256), 0, st, pa);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) rc = mir_set_error(MIR_E_HIP, hipGetErrorString(e));
   } while (0);
@@ -484,6 +712,13 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
 extern "C" int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, int32_t mode, const float* env_offset,
                           uint8_t* pixels, void* stream) {
   return render_impl(h, cam, vis, mode, env_offset, nullptr, nullptr, nullptr, pixels, stream);
+}
+
+extern "C" int mir_debug_render_path(MirHandle h, int32_t generic, int32_t strip_rows) {
+  if (!h || strip_rows < 0 || (strip_rows & 31)) return mir_set_error(MIR_E_INVALID, "mir_debug_render_path: strip_rows must be a multiple of 32");
+  h->render_generic = generic != 0;
+  h->render_th = strip_rows;
+  return MIR_OK;
 }
 
 extern "C" int mir_render_cams(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, const float* cam_pos, const float* cam_lookat,

@@ -21,6 +21,10 @@ struct MirScene {
   float *qpos, *qvel, *target, *qacc_ws, *poses;
   int32_t *diag, *fkvalid;
   float* prims;     // render primitives (B, ngeom, 32) f32, allocated by the first mir_render
+  int* bins = nullptr;      // per-strip primitive lists of the binned pixel kernel (grown on demand)
+  size_t bins_cap = 0;      // ints
+  int render_th = 0;        // strip height override (mir_debug_render_path; 0 = default)
+  int render_generic = 0;   // force the generic pixel kernel (mir_debug_render_path)
   // host-visible tail of env.step() (mir_step_begin / mir_step_end): one pinned, device-mapped allocation
   //   [terminated bytes (B, padded to 64) | completion word]
   float* scratch_row;       // one qpos row (device), used while the scene is created

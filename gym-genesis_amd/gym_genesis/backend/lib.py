@@ -77,6 +77,8 @@ def load_library() -> C.CDLL:
     lib.mir_set_diag.argtypes = [vp, i32]
     lib.mir_set_diag.restype = C.c_int
     lib.mir_forward.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mir_debug_render_path.argtypes = [vp, i32, i32]
+    lib.mir_debug_render_path.restype = C.c_int
     lib.mir_render.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), i32, vp, vp, vp]
     lib.mir_render.restype = C.c_int
     lib.mir_visual_sizeof.restype = C.c_int
@@ -495,6 +497,10 @@ class MirScene(StepHelpers):
             off = self._f32(env_offset, 3)
         self._check(self.lib.mir_render(self.h, C.byref(cam), C.byref(vis), int(mode), _ptr(off), _ptr(out), self._stream()))
         return out
+
+    def debug_render_path(self, generic: bool = False, strip_rows: int = 0) -> None:
+        """mir_debug_render_path: force the generic pixel kernel / override the strip height for the following renders."""
+        self._check(self.lib.mir_debug_render_path(self.h, 1 if generic else 0, int(strip_rows)))
 
     def render_cams(self, cam: MirCameraSpec, vis: MirVisualSpec, cam_pos, cam_lookat, cam_up=None,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:

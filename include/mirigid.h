@@ -411,6 +411,11 @@ int mir_debug_copy_rows(const float* src, float* dst, int64_t n_floats, int devi
 /* the kernels' convex narrowphase on n pairs given directly (device arrays): in (n,22) = type1, size1[3], pos1[3], quat1[4] wxyz,
  * type2, size2[3], pos2[3], quat2[4]; out (n,8) = hit, pos[3], dist, normal[3] (from geom 1 to geom 2) */
 int mir_debug_convex_pairs(const float* in, float* out, int32_t n, int device_id, void* stream);
+/* which pixel kernel the following mir_render / mir_render_cams calls of this handle use: generic != 0 forces the kernel that
+ * culls per workgroup (the one long primitive lists and odd widths always take), 0 restores the default (per-strip lists built
+ * once per render whenever an image has fewer than 64 primitives); strip_rows > 0 (a multiple of 32) overrides the height of a
+ * workgroup's strip, 0 restores the default.  The two kernels must agree bit for bit (tests/test_gpu_render.py). */
+int mir_debug_render_path(MirHandle h, int32_t generic, int32_t strip_rows);
 
 #ifdef __cplusplus
 }

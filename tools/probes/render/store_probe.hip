@@ -1,0 +1,178 @@
+// store_probe.hip — what bounds the rasteriser's floor-only path: the store pattern or the arithmetic?
+// Writes a 1024 x 480 x 640 x 3 image set with the rasteriser's walk (workgroup = 4 waves on a 128-px strip of 96 rows) and
+// different lane -> byte mappings, with and without the floor's per-pixel arithmetic.  hipcc --offload-arch=gfx950 -O3.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+typedef unsigned u3 __attribute__((ext_vector_type(3)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define W 640
+#define H 480
+
+struct A { uint8_t* px; float x0, dx, y0, dy, nu0, nux, nuy, nv0, nvx, nvy, fz, uz, oz; unsigned ce, co, sky; };
+
+// floor colour of pixel (x, y) image-plane coords: row-constant reciprocal
+__device__ __forceinline__ unsigned floor_col(const A& a, float xs, float eu, float ev, float iz1, unsigned ca, unsigned cb) {
+  const float u = fmaf(xs, a.nux, eu) * iz1, v = fmaf(xs, a.nvx, ev) * iz1;
+  const bool odd = (__builtin_amdgcn_fractf(u) >= 0.5f) != (__builtin_amdgcn_fractf(v) >= 0.5f);
+  return odd ? cb : ca;
+}
+
+// MODE 0: current pattern, dwordx3 per lane, 2 rows x 384 B per wave store.  ARITH 0: constant colour, 1: floor arithmetic
+template <int MODE, int ARITH>
+__global__ __launch_bounds__(256) void k(A a) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tx0 = blockIdx.x * 128, sy0 = blockIdx.y * 96, img = blockIdx.z;
+  uint8_t* ibase = a.px + (size_t)img * H * W * 3;
+  if (MODE == 0) {
+    const int px = tx0 + 4 * (lane & 31);
+    for (int ty0 = sy0; ty0 < sy0 + 96; ty0 += 32) {
+      const int prow = ty0 + 8 * wv + (lane >> 5);
+      unsigned boff = ((unsigned)prow * W + px) * 3u;
+#pragma unroll
+      for (int r = 0; r < 4; r++, boff += 6u * W) {
+        unsigned c[4];
+        if (ARITH) {
+          const float ys = a.y0 + (float)(prow + 2 * r) * a.dy;
+          const float ez = fmaf(ys, a.uz, a.fz), eu = fmaf(ys, a.nuy, a.nu0), ev = fmaf(ys, a.nvy, a.nv0);
+          const float iz1 = __builtin_amdgcn_rcpf(ez);
+          const bool vld = iz1 * (-a.oz) > 1e-6f;
+          const unsigned ca = vld ? a.ce : a.sky, cb = vld ? a.co : a.sky;
+#pragma unroll
+          for (int p = 0; p < 4; p++) c[p] = floor_col(a, a.x0 + (float)(px + p) * a.dx, eu, ev, iz1, ca, cb);
+        } else {
+#pragma unroll
+          for (int p = 0; p < 4; p++) c[p] = a.sky + lane;
+        }
+        u3 v;
+        v.x = c[0] | c[1] << 24; v.y = c[1] >> 8 | c[2] << 16; v.z = c[2] >> 16 | c[3] << 8;
+        *reinterpret_cast<u3*>(ibase + boff) = v;
+      }
+    }
+  } else if (MODE == 1) {
+    // dwordx4, 48 lanes: lane l < 48 owns 16 B of a 384-B row segment (24 lanes per row, 2 rows per store); pixels straddle
+    // lanes: a lane evaluates the 6 pixels its 16 bytes touch
+    if (lane >= 48) return;
+    const int lr = lane % 24, rw = lane / 24;
+    const int b0 = 16 * lr;            // byte offset in the 384-B segment
+    const int p0 = b0 / 3, sh = b0 % 3;  // first pixel touched, bytes of it already behind
+    const int px = tx0 + p0;
+    for (int ty0 = sy0; ty0 < sy0 + 96; ty0 += 32) {
+      const int prow = ty0 + 8 * wv + rw;
+      unsigned boff = ((unsigned)prow * W + tx0) * 3u + b0;
+#pragma unroll
+      for (int r = 0; r < 4; r++, boff += 6u * W) {
+        unsigned c[6];
+        if (ARITH) {
+          const float ys = a.y0 + (float)(prow + 2 * r) * a.dy;
+          const float ez = fmaf(ys, a.uz, a.fz), eu = fmaf(ys, a.nuy, a.nu0), ev = fmaf(ys, a.nvy, a.nv0);
+          const float iz1 = __builtin_amdgcn_rcpf(ez);
+          const bool vld = iz1 * (-a.oz) > 1e-6f;
+          const unsigned ca = vld ? a.ce : a.sky, cb = vld ? a.co : a.sky;
+#pragma unroll
+          for (int p = 0; p < 6; p++) c[p] = floor_col(a, a.x0 + (float)(px + p) * a.dx, eu, ev, iz1, ca, cb);
+        } else {
+#pragma unroll
+          for (int p = 0; p < 6; p++) c[p] = a.sky + lane;
+        }
+        // 18 bytes of 6 pixels -> the 16 starting at byte `sh`
+        const unsigned long long q0 = (unsigned long long)c[0] | (unsigned long long)c[1] << 24 | (unsigned long long)c[2] << 48;
+        const unsigned d0 = (unsigned)q0, d1 = (unsigned)(q0 >> 32);                 // bytes 0..7 (c2's first 2 bytes at 6,7)
+        const unsigned d2 = c[2] >> 16 | c[3] << 8;                                  // bytes 8..11
+        const unsigned d3 = c[4] | c[5] << 24, d4 = c[5] >> 8;                       // bytes 12..15, 16..17
+        u4 v;
+        const unsigned s8 = 8u * sh;
+        v.x = __builtin_amdgcn_alignbit(d1, d0, s8); v.y = __builtin_amdgcn_alignbit(d2, d1, s8);
+        v.z = __builtin_amdgcn_alignbit(d3, d2, s8); v.w = __builtin_amdgcn_alignbit(d4, d3, s8);
+        *reinterpret_cast<u4*>(ibase + boff) = v;
+      }
+    }
+  } else if (MODE == 2) {
+    // linear: the image as a byte stream, a wave store = 1024 contiguous bytes; workgroup = 4 KB chunks walked like the strip
+    // (same bytes per workgroup as modes 0/1: 128 x 96 x 3 = 36864 B = 9 trips of 4 KB)
+    const size_t wg = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 36864;
+    for (int t = 0; t < 9; t++) {
+      const size_t off = wg + (size_t)t * 4096 + tid * 16;
+      const unsigned bo = (unsigned)off;
+      const int row = bo / (W * 3), b0 = bo % (W * 3);
+      const int p0 = b0 / 3, sh = b0 % 3;
+      unsigned c[6];
+      if (ARITH) {
+        const float ys = a.y0 + (float)row * a.dy;
+        const float ez = fmaf(ys, a.uz, a.fz), eu = fmaf(ys, a.nuy, a.nu0), ev = fmaf(ys, a.nvy, a.nv0);
+        const float iz1 = __builtin_amdgcn_rcpf(ez);
+        const bool vld = iz1 * (-a.oz) > 1e-6f;
+        const unsigned ca = vld ? a.ce : a.sky, cb = vld ? a.co : a.sky;
+#pragma unroll
+        for (int p = 0; p < 6; p++) c[p] = floor_col(a, a.x0 + (float)(p0 + p) * a.dx, eu, ev, iz1, ca, cb);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 6; p++) c[p] = a.sky + lane;
+      }
+      const unsigned long long q0 = (unsigned long long)c[0] | (unsigned long long)c[1] << 24 | (unsigned long long)c[2] << 48;
+      const unsigned d0 = (unsigned)q0, d1 = (unsigned)(q0 >> 32);
+      const unsigned d2 = c[2] >> 16 | c[3] << 8;
+      const unsigned d3 = c[4] | c[5] << 24, d4 = c[5] >> 8;
+      u4 v;
+      const unsigned s8 = 8u * sh;
+      v.x = __builtin_amdgcn_alignbit(d1, d0, s8); v.y = __builtin_amdgcn_alignbit(d2, d1, s8);
+      v.z = __builtin_amdgcn_alignbit(d3, d2, s8); v.w = __builtin_amdgcn_alignbit(d4, d3, s8);
+      *reinterpret_cast<u4*>(ibase + off) = v;
+    }
+  } else if (MODE == 3) {
+    // dwordx3 on a 256-px-wide strip: wave store = ONE row segment of 768 B (lane = 4 px), strip 256 x 48 rows
+    const int sx0 = (blockIdx.x & 1) * 256 + (blockIdx.x >> 1) * 512;  // 5 x 128 -> not a multiple of 256: probe only the pattern
+    const int px = (sx0 + 4 * lane) % W;
+    for (int ty0 = sy0; ty0 < sy0 + 96; ty0 += 32) {
+      const int prow = ty0 + 8 * wv;
+      unsigned boff = ((unsigned)prow * W + px) * 3u;
+#pragma unroll
+      for (int r = 0; r < 4; r++, boff += 3u * W) {   // 4 of the 8 rows (same store count per wave as mode 0)
+        unsigned c[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) c[p] = a.sky + lane;
+        u3 v;
+        v.x = c[0] | c[1] << 24; v.y = c[1] >> 8 | c[2] << 16; v.z = c[2] >> 16 | c[3] << 8;
+        *reinterpret_cast<u3*>(ibase + boff) = v;
+      }
+    }
+  }
+}
+
+template <int MODE, int ARITH>
+float run(A a, int B, int n) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  dim3 g(5, 5, B);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<MODE, ARITH>), g, dim3(256), 0, 0, a);
+  hipEventRecord(e0);
+  for (int i = 0; i < n; i++) hipLaunchKernelGGL((k<MODE, ARITH>), g, dim3(256), 0, 0, a);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms / n * 1e3f;
+}
+
+int main() {
+  const int B = 1024;
+  const size_t bytes = (size_t)B * H * W * 3;
+  A a{};
+  hipMalloc((void**)&a.px, bytes);
+  // camera (3.5, 0, 2.5) -> (0, 0, 0.5), fov 30: numbers of the plane record in the right ballpark
+  a.dx = 2.0f * 0.357f / W; a.x0 = -0.357f + 0.5f * a.dx; a.dy = -2.0f * 0.268f / H; a.y0 = 0.268f + 0.5f * a.dy;
+  a.fz = -0.496f; a.uz = 0.868f; a.oz = 2.5f; a.nu0 = 1.2f; a.nux = 0.0f; a.nuy = 3.1f; a.nv0 = 0.0f; a.nvx = 2.5f; a.nvy = 0.0f;
+  a.ce = 0x00c8c8c8; a.co = 0x00505050; a.sky = 0x00e6b48c;
+  const double gb = bytes / 1e9;
+#define R(M, AR) { float us = run<M, AR>(a, B, 20); printf("mode %d arith %d: %7.1f us  %6.0f GB/s\n", M, AR, us, gb / us * 1e6); }
+  R(0, 0) R(1, 0) R(2, 0) R(3, 0) R(0, 1) R(1, 1) R(2, 1)
+  // plain fill
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; i++) hipMemsetAsync(a.px, 7, bytes, 0);
+  hipEventRecord(e0);
+  for (int i = 0; i < 20; i++) hipMemsetAsync(a.px, 7, bytes, 0);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("hipMemset: %7.1f us  %6.0f GB/s\n", ms / 20 * 1e3, gb / (ms / 20) * 1e3);
+  return 0;
+}

@@ -21,9 +21,9 @@ for d in ("prof_render_write", "prof_render_fetch", "prof_render_sq", "prof_rend
         acc = {}
         for r in csv.DictReader(open(f)):
             kn = r.get("Kernel_Name", "")
-            if "mir_render_kernel" not in kn and "fill" not in kn.lower():
+            if "mir_render_" not in kn and "fill" not in kn.lower():
                 continue
-            grid = ("render " if "mir_render_kernel" in kn else "fill ") + r.get("Grid_Size", "")
+            grid = ("render " if "mir_render_" in kn else "fill ") + r.get("Grid_Size", "")
             key = (r["Counter_Name"], grid)
             acc.setdefault(key, {}).setdefault(int(r.get("Dispatch_Id", 0)), 0.0)
             acc[key][int(r.get("Dispatch_Id", 0))] += float(r["Counter_Value"])
