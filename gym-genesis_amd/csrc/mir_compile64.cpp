@@ -241,6 +241,30 @@ int mir_compile_model64(const MirSceneSpec* sp0, DevModel64* out, HostConsts* hc
     }
     m.obs_qadr[l] = oq;
   }
+  // tree-scan links (the kernel's dynamics run prefix sums along dof chains and suffix sums over body lanes)
+  {
+    auto top = [](uint64_t mk) { int t = -1; for (int l = 0; l < 64; l++) if ((mk >> l) & 1ull) t = l; return t; };
+    for (int l = 0; l < W64; l++) {
+      int par = -1, bef = -1, last = -1, next = -1;
+      if ((m.lanemask >> l) & 1ull) {
+        par = top(m.d_ancmask[l] & ~(1ull << l));
+        bef = top(m.d_premask[l]);
+        if (par >= 0 && m.d_ancmask[par] != (m.d_ancmask[l] & ~(1ull << l))) return fail(err, MIR_E_INVALID, "dof chains must be laid out ancestor-first");
+        if (bef >= 0 && m.d_ancmask[bef] != m.d_premask[l]) return fail(err, MIR_E_INVALID, "the dofs in front of a dof must form a chain prefix");
+      }
+      if (l > 0 && l < nb) {
+        last = top(m.b_dofmask[l]);
+        if (last >= 0 && m.d_ancmask[last] != m.b_dofmask[l]) return fail(err, MIR_E_INVALID, "the dofs that move a body must form a chain prefix");
+        int e = l + 1;
+        while (e < nb && ((m.b_submask[l] >> e) & 1u)) e++;
+        if (m.b_submask[l] != (uint32_t)(((1ull << e) - 1ull) & ~((1ull << l) - 1ull)))
+          return fail(err, MIR_E_INVALID, "bodies must be numbered depth-first (a subtree is a contiguous index range)");
+        if (((e - 1) >> 4) != (l >> 4)) return fail(err, MIR_E_CAPACITY, "the bodies of a subtree must share a 16-lane row");
+        next = (e >> 4) == (l >> 4) ? e : -1;
+      }
+      m.scanw[l] = (par & 255) | (bef & 255) << 8 | (last & 255) << 16 | (int32_t)((uint32_t)(next & 255) << 24);
+    }
+  }
   for (int b = 0; b < K64_MAX_BODY; b++) {
     const bool on = b < nb;
     m.b_tab[b][0] = on ? m.b_invweight0[b] : 0.0f;

@@ -58,6 +58,10 @@ struct DevModel64 {
   uint32_t d_bsubmask[W64];
   float d_axis[W64][4];    /* joint axis of the lane's body */
   float b_tab[K64_MAX_BODY][8]; /* contact finish, staged in LDS: invweight0, dofmask lo, dofmask hi, block, root (int bits) */
+  /* tree-scan links of the dynamics (bytes, -1 = none): [0] scan parent of dof lane l (the dof before it in its chain), [1] the dof
+   * whose inclusive chain sum is the velocity in front of dof l, [2] (lane = body) the body's last moving dof, [3] (lane = body)
+   * the lane behind the body's subtree, -1 when the subtree ends with its 16-lane row */
+  int32_t scanw[W64];
 };
 
 // Dof-order <-> storage maps used by the plumbing kernels of mir_api.hip for BOTH step kernels

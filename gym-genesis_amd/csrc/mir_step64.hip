@@ -36,6 +36,7 @@
 
 #define G 16
 #include "mir_dev.h"
+#include "mir_gj_dpp.h"
 #define NL W64
 #define NB K64_MAX_BODY
 #define MAXC MIR_MAX_CONTACT
@@ -59,51 +60,184 @@ __device__ __forceinline__ float wmaxf(float v) {
   return fmaxf(fmaxf(rl(v, 0), rl(v, 16)), fmaxf(rl(v, 32), rl(v, 48)));
 }
 
-// Dense Gauss-Jordan over the 64 register rows (lane i = row i of the SPD matrix, b_i the right-hand side; on
-// return b = x_i).  The pivot loop is ROLLED per block (a fully unrolled 64-pivot elimination is ~10 k instructions,
-// more than the instruction cache, and with one wave per SIMD nothing hides the fetch misses): pivot K of block BLK
-// only touches columns >= 16 BLK (row K is already zero to the left), so each block has a static column range; the
-// own-row entry a[K] is picked by a wave-uniform switch.  One readlane + one fma per column: with
-// f = (1 - 1/p) on the pivot row and a_iK / p elsewhere, a[j] -= f * pivotrow[j] both scales the pivot row and
-// eliminates the others.  Padding lanes (identity rows) are skipped through the wave-uniform `act` mask.
-__device__ __forceinline__ float rlv(float v, int src) {  // src wave-uniform (SGPR lane select)
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
-}
-typedef float v16f __attribute__((ext_vector_type(16)));
-template <int BLK>
-__device__ __forceinline__ void gj_block(v16f (&a)[4], float& b, int lane, uint64_t act, unsigned comp) {
-#pragma nounroll
-  for (int kk = 0; kk < 16; kk++) {
-    const int K = __builtin_amdgcn_readfirstlane(16 * BLK + kk);
-    if (!((act >> K) & 1ull)) continue;
-    const float aK = a[BLK][__builtin_amdgcn_readfirstlane(kk)];  // column K of every row: wave-uniform register index (VGPR index mode)
-    const float pk = rlv(aK, K);
-    float inv = __builtin_amdgcn_rcpf(pk);
+// ---- the Newton direction when contacts couple blocks: block elimination on the DPP rows --------------------------------------
+// Lane (block r, row i) holds row i of H as four column blocks h[0..3] (h[r] = its own diagonal block; h[q] is zero unless a
+// contact couples r and q this step).  `comp` (wave-uniform) has bit 4 p + q set when blocks p and q lie in one connected
+// component of the coupling graph.  Blocks are eliminated in index order; later(p) = the blocks q > p of p's component:
+//   * forward, p = 0, 1, 2 with later(p) not empty: the rows of p run the 16-wide register Gauss-Jordan of the uncoupled case on
+//     [H_pp | H_pq, q in later(p) | g_p] (one DPP row_newbcast fma per column and pivot, the other rows idle), which leaves
+//     X_pq = H_pp^-1 H_pq in h[q] and y_p in b; X_pq goes through a 1 KB LDS tile (one column block at a time) to the rows of
+//     every r in later(p), which take the Schur update H_rq -= H_rp X_pq, g_r -= H_rp y_p with their own H_rp = h[p] as
+//     multipliers (broadcast reads: every lane of the wave reads the same 16 bytes);
+//   * then every block that was not eliminated solves its (updated) diagonal block: the four-rows-side-by-side solve of the
+//     uncoupled case;
+//   * backward, p = 2, 1, 0: s_p = y_p - sum_q X_pq s_q with X_pq still in the rows' registers and s_q read from LDS.
+// Work is proportional to what is coupled: one coupled pair of blocks costs one augmented 15-pivot elimination (31 columns), one
+// 15 x 15 x 15 update and the common final solve -- ~1 k instructions; the rolled 64-column Gauss-Jordan this replaces (pivot row by
+// v_readlane, pivot column by VGPR indexing) took 25-35 k cycles per Newton iteration (per-env timing, tools/probes/env_time_hist64.py).
+// (four separately named arrays and compile-time block indices: with a float[4][16] walked by unrolled loops the matrix stayed in
+//  private memory -- the unrolling comes too late for the scalar-replacement pass)
+struct H4 {
+  float (&c0)[G], (&c1)[G], (&c2)[G], (&c3)[G];  // (four separate 64-byte objects: one 256-byte object was left in private memory too)
+  template <int Q>
+  __device__ __forceinline__ float (&col())[G] {
+    if constexpr (Q == 0) return c0;
+    else if constexpr (Q == 1) return c1;
+    else if constexpr (Q == 2) return c2;
+    else return c3;
+  }
+};
+__device__ __forceinline__ unsigned later_of(unsigned comp, int p) { return (comp >> (4 * p)) & (0xfu << (p + 1)) & 0xfu; }
 
-    const float f = lane == K ? 1.0f - inv : aK * inv;
-    // column blocks outside this block's connected component hold zeros in the pivot row: skipped (wave-uniform);
-    // pivot-row entries are fetched eight at a time so the readlane -> fma SGPR dependencies overlap
+// The 16-wide solve of the uncoupled case with its column updates as v_fmac_f32_dpp (mir_gj_dpp.h): bit-identical to GJ<0>::run.
+template <int K>
+__device__ __forceinline__ void gj16_dpp(float (&a)[G], float& b, int l16) {
+  const float inv = __builtin_amdgcn_rcpf(row_bcast<K>(a[K]));
+  const float nf = l16 == K ? inv - 1.0f : -(a[K] * inv);
+  gj_dpp_step<K, K + 1>(a, b, nf);
+  if constexpr (K + 1 < G - 1) gj16_dpp<K + 1>(a, b, l16);
+}
+template <int P, int K>
+struct GJA {
+  // (all lanes run it -- the DPP broadcasts want convergent code; the rows of the other blocks carry f = 0 and keep their values.
+  //  Column updates: one v_fmac_f32_dpp per entry, mir_gj_dpp.h)
+  static __device__ __forceinline__ void run(H4& h, float& b, int l16, bool mine, unsigned later) {
+    float (&own)[G] = h.col<P>();
+    const float pk = row_bcast<K>(own[K]);
+    const float inv = __builtin_amdgcn_rcpf(pk);
+    const float nf = mine ? (l16 == K ? inv - 1.0f : -(own[K] * inv)) : 0.0f;  // -f of GJ in mir_dev.h
+    gj_dpp_step<K, K + 1>(own, b, nf);
+    if constexpr (P < 1) { if (later & 2u) gj_dpp_cols<K>(h.col<1>(), nf); }
+    if constexpr (P < 2) { if (later & 4u) gj_dpp_cols<K>(h.col<2>(), nf); }
+    if constexpr (P < 3) { if (later & 8u) gj_dpp_cols<K>(h.col<3>(), nf); }
+    if constexpr (K + 1 < G - 1) GJA<P, K + 1>::run(h, b, l16, mine, later);
+  }
+};
+
+// dst[j] -= sum_k mul[k] * X[k][j] over the 15 x 15 tile in LDS (rows of 16 floats; broadcast reads, two rows per batch)
+__device__ __forceinline__ void schur_update(float (&dst)[G], const float (&mul)[G], const float* xs) {
 #pragma unroll
-    for (int bj = BLK; bj < 4; bj++) {
-      if (!((comp >> (4 * BLK + bj)) & 1u)) continue;
+  for (int k0 = 0; k0 < 16; k0 += 2) {
+    f4 x[2][4];
 #pragma unroll
-      for (int j0 = 0; j0 < 16; j0 += 8) {
-        float r[8];
+    for (int u = 0; u < 2; u++)
 #pragma unroll
-        for (int t = 0; t < 8; t++) r[t] = rlv(a[bj][j0 + t], K);
+      for (int c = 0; c < 4; c++) x[u][c] = ldv(xs + 16 * (k0 + u) + 4 * c);
 #pragma unroll
-        for (int t = 0; t < 8; t++) a[bj][j0 + t] = fmaf(-f, r[t], a[bj][j0 + t]);
+    for (int u = 0; u < 2; u++) {
+      if (k0 + u >= G - 1) continue;  // (slot 15 of a block never carries a dof)
+      const float mk = -mul[k0 + u];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        dst[4 * c + 0] = fmaf(mk, x[u][c].x, dst[4 * c + 0]);
+        dst[4 * c + 1] = fmaf(mk, x[u][c].y, dst[4 * c + 1]);
+        dst[4 * c + 2] = fmaf(mk, x[u][c].z, dst[4 * c + 2]);
+        dst[4 * c + 3] = fmaf(mk, x[u][c].w, dst[4 * c + 3]);
       }
     }
-    b = fmaf(-f, rlv(b, K), b);
+    __builtin_amdgcn_sched_barrier(0);  // (the batches stay apart: registers)
   }
 }
-// comp: bit 4 b + b' set when blocks b and b' are in one connected component of the contact coupling graph
-__device__ __forceinline__ void gj_wave(v16f (&a)[4], float& b, int lane, uint64_t act, unsigned comp) {
-  gj_block<0>(a, b, lane, act, comp);
-  gj_block<1>(a, b, lane, act, comp);
-  gj_block<2>(a, b, lane, act, comp);
-  gj_block<3>(a, b, lane, act, comp);
+__device__ __forceinline__ float dot16(const float (&a)[G], const float* x) {  // sum_j a[j] x[j], x in LDS
+  const f4 x0 = ldv(x), x1 = ldv(x + 4), x2 = ldv(x + 8), x3 = ldv(x + 12);
+  return ((a[0] * x0.x + a[1] * x0.y + a[2] * x0.z + a[3] * x0.w) + (a[4] * x1.x + a[5] * x1.y + a[6] * x1.z + a[7] * x1.w)) +
+         ((a[8] * x2.x + a[9] * x2.y + a[10] * x2.z + a[11] * x2.w) + (a[12] * x3.x + a[13] * x3.y + a[14] * x3.z + a[15] * x3.w));
+}
+
+// X_pq through the LDS tile to the rows of later(p): H_rq -= H_rp X_pq
+template <int P, int Q>
+__device__ __forceinline__ void schur_block(H4& h, bool mine, bool target, int l16, float* xs) {
+  float (&xq)[G] = h.col<Q>();
+  if (mine) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) stv(xs + 16 * l16 + 4 * c, f4{xq[4 * c], xq[4 * c + 1], xq[4 * c + 2], xq[4 * c + 3]});
+  }
+  WSYNC();
+  if (target) schur_update(xq, h.col<P>(), xs);
+  WSYNC();
+}
+// forward step for pivot block P (wave-uniform early-out when nothing later is coupled to it); xs = 1 KB tile, ys = 64 floats
+template <int P>
+__device__ __forceinline__ void coupled_forward(H4& h, float& b, int blk, int l16, unsigned comp, float* xs, float* ys) {
+  const unsigned later = later_of(comp, P);
+  if (!later) return;
+  const bool mine = blk == P, target = (later >> blk) & 1u;
+  GJA<P, 0>::run(h, b, l16, mine, later);
+  if (mine) ys[16 * P + l16] = b;
+  if constexpr (P < 1) { if (later & 2u) schur_block<P, 1>(h, mine, target, l16, xs); }
+  if constexpr (P < 2) { if (later & 4u) schur_block<P, 2>(h, mine, target, l16, xs); }
+  if constexpr (P < 3) { if (later & 8u) schur_block<P, 3>(h, mine, target, l16, xs); }
+  if (target) b -= dot16(h.col<P>(), ys + 16 * P);
+}
+template <int P>
+__device__ __forceinline__ void coupled_backward(H4& h, float& b, int blk, unsigned comp, float* ys, int lane) {
+  const unsigned later = later_of(comp, P);
+  if (!later) return;
+  if (blk == P) {
+    float acc = 0.0f;
+    if constexpr (P < 1) { if (later & 2u) acc += dot16(h.col<1>(), ys + 16); }
+    if constexpr (P < 2) { if (later & 4u) acc += dot16(h.col<2>(), ys + 32); }
+    if constexpr (P < 3) { if (later & 8u) acc += dot16(h.col<3>(), ys + 48); }
+    b -= acc;
+  }
+  WSYNC();
+  if (blk == P) ys[lane] = b;
+  WSYNC();
+}
+// H s = b for the whole wave; on return b = s_i.  h is consumed.
+__device__ __forceinline__ void coupled_solve(H4& h, float& b, int lane, unsigned comp, float* xs, float* ys) {
+  const int blk = lane >> 4, l16 = lane & 15;
+  coupled_forward<0>(h, b, blk, l16, comp, xs, ys);
+  coupled_forward<1>(h, b, blk, l16, comp, xs, ys);
+  coupled_forward<2>(h, b, blk, l16, comp, xs, ys);
+  {
+    float hb[G], sf = b;
+#pragma unroll
+    for (int j = 0; j < G; j++) hb[j] = blk == 0 ? h.c0[j] : (blk == 1 ? h.c1[j] : (blk == 2 ? h.c2[j] : h.c3[j]));
+    gj16_dpp<0>(hb, sf, l16);
+    if (!later_of(comp, blk)) b = sf;  // (the eliminated blocks keep their y)
+  }
+  WSYNC();
+  ys[lane] = b;
+  WSYNC();
+  coupled_backward<2>(h, b, blk, comp, ys, lane);
+  coupled_backward<1>(h, b, blk, comp, ys, lane);
+  coupled_backward<0>(h, b, blk, comp, ys, lane);
+}
+
+// [own | aug | b] of the rows of ONE block (`mine`); the other rows run along with nf = 0 and keep their values
+template <int K>
+__device__ __forceinline__ void gj16_aug(float (&own)[G], float (&aug)[G], float& b, int l16, bool mine) {
+  const float inv = __builtin_amdgcn_rcpf(row_bcast<K>(own[K]));
+  const float nf = mine ? (l16 == K ? inv - 1.0f : -(own[K] * inv)) : 0.0f;
+  gj_dpp_step<K, K + 1>(own, b, nf);
+  gj_dpp_cols<K>(aug, nf);
+  if constexpr (K + 1 < G - 1) gj16_aug<K + 1>(own, aug, b, l16, mine);
+}
+// ONE coupled pair of blocks p < q (92 % of the coupled envs of the stack tasks: two cubes of different blocks touching, the arm
+// on a cube): the block elimination above with everything static but the two row masks -- a lane needs one off-diagonal block
+// only, hx = H_pq for the rows of p and H_qp for the rows of q.  ~1.1 k instructions (the general routine runs ~4 k for a
+// component of three blocks, and instructions, not flops, are what a wave alone on its SIMD pays for).  hb / hx are consumed.
+__device__ __forceinline__ void pair_solve(float (&hb)[G], float (&hx)[G], float& b, int blk, int l16, int lane, int p, int q, float* xs, float* ys) {
+  const bool mine = blk == p, target = blk == q;
+  gj16_aug<0>(hb, hx, b, l16, mine);  // rows of p: hx = X = H_pp^-1 H_pq, b = y_p
+  if (mine) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) stv(xs + 16 * l16 + 4 * c, f4{hx[4 * c], hx[4 * c + 1], hx[4 * c + 2], hx[4 * c + 3]});
+    ys[lane] = b;
+  }
+  WSYNC();
+  if (target) {  // Schur complement of the rows of q
+    schur_update(hb, hx, xs);
+    b -= dot16(hx, ys + 16 * p);
+  }
+  float sf = b;
+  gj16_dpp<0>(hb, sf, l16);  // every block's own solve, side by side (the rows of p have theirs already)
+  if (!mine) b = sf;
+  WSYNC();
+  if (target) ys[lane] = b;
+  WSYNC();
+  if (mine) b -= dot16(hx, ys + 16 * q);
 }
 
 struct Dyn64 {
@@ -260,6 +394,9 @@ void mir_step64_kernel(StepArgs64 a) {
   const DevModel64* __restrict__ m = a.model;
   const int lane = threadIdx.x & 63;
   const bool helper = DUAL && threadIdx.x >= 64;  // wave-uniform
+#ifdef MIR_PROFILE_SINGLE
+  const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
   const int blk = lane >> 4, l16 = lane & 15;
   const int env = blockIdx.x;  // grid = B exactly
 
@@ -276,8 +413,6 @@ void mir_step64_kernel(StepArgs64 a) {
   bk.jtype = m->b_jtype[bl]; bk.qadr = m->b_qadr[bl];
   bk.pos = ld3(m->b_pos[bl]); bk.axis = ld3(m->b_axis[bl]); bk.quat = ld4(m->b_quat[bl]);
   const int b_root = m->b_root[bl];
-  const uint64_t b_dofmask = m->b_dofmask[bl];
-  const uint32_t b_submask = m->b_submask[bl];
   const V3 b_ipos = ld3(m->b_ipos[bl]);
   const float b_mass = m->b_mass[bl];
   float ib[6];
@@ -287,8 +422,12 @@ void mir_step64_kernel(StepArgs64 a) {
   const int d_kind = m->d_kind[lane], d_qadr = m->d_qadr[lane], d_axis_k = m->d_axis_k[lane];
   const int d_root = m->d_root[lane];
   const V3 d_axis = ld3(m->d_axis[lane]);
-  const uint64_t d_premask = m->d_premask[lane], d_ancmask = m->d_ancmask[lane];
-  const uint32_t d_submask = m->d_bsubmask[lane];
+  const uint64_t d_ancmask = m->d_ancmask[lane];
+  // tree-scan links (mir_compile64.cpp): scan parent of the dof, the dof whose inclusive sum is the velocity in front of this dof,
+  // the body's last moving dof, the lane behind the body's subtree (-1: none / the subtree ends with its row)
+  const int scanw = m->scanw[lane];
+  const int d_par = (int)(signed char)(scanw & 255), d_bef = (int)(signed char)(scanw >> 8 & 255);
+  const int b_last = (int)(signed char)(scanw >> 16 & 255), b_next = (int)(signed char)(scanw >> 24 & 255);
   const int d_ctrl = m->d_ctrl[lane], d_uadr = m->d_uadr[lane];
   const bool d_limited = isdof && m->d_limited[lane] && m->enable_joint_limit;
   const float d_damping = m->d_damping[lane], d_kp = m->d_kp[lane], d_kv = m->d_kv[lane];
@@ -771,115 +910,147 @@ void mir_step64_kernel(StepArgs64 a) {
     WSYNC();
 
     STAMP(2);
-    // ======================= velocities, composite inertias =====================================
+    // ======================= velocities, composite inertias, body forces: tree SCANS (as in the 16-lane kernel) =========
+    // Sums over the ancestors of a dof are inclusive prefix sums along its dof chain: POINTER JUMPING over the chain's parent
+    // links (<= 4 rounds of one lane gather each) instead of a masked gather per lane and per quantity (those loops were a
+    // dependent LDS round trip per ancestor: 11 k of this wave's 39 k cycles).  Sums over the subtree of a body are suffix sums
+    // over the body lanes -- bodies are numbered in depth-first preorder and a tree's bodies share a DPP row (checked by
+    // mir_compile64.cpp), so a subtree is the lane range [b, b_next) -- four DPP row shifts per component and one subtraction.
+    float qfrc_bias = 0.0f, qfs = 0.0f;
     {
-      if (isdof) {  // lane = dof: cdof_dot * qvel, "velocity before this dof" from the pre-mask
+      auto ancestor_scan = [&](V3& A, V3& Bv, float* tab) {  // tab: NL rows of 8 floats, inclusive sums by dof lane
+        int pj = isdof ? d_par : -1;
+#pragma unroll 1
+        for (int round = 0; round < 4; round++) {
+          if (!__any(pj >= 0)) break;
+          const int src = (pj >= 0 ? pj : lane) << 2;
+          const V3 xa = v3(lane_gather(src, A.x), lane_gather(src, A.y), lane_gather(src, A.z));
+          const V3 xb = v3(lane_gather(src, Bv.x), lane_gather(src, Bv.y), lane_gather(src, Bv.z));
+          const int nxt = lane_gather(src, pj);
+          if (pj >= 0) {
+            A = A + xa;
+            Bv = Bv + xb;
+            pj = nxt;
+          }
+        }
+        st3v(tab + 8 * lane, A);
+        st3v(tab + 8 * lane + 4, Bv);
+        WSYNC();
+      };
+      float* const tab = &S.dm.dyn.cddq[0][0];
+      const V3 cw = ld3v(&S.cdof[lane][0]), cv = ld3v(&S.cdof[lane][4]);
+      const float qd = isdof ? S.qvel[lane] : 0.0f;
+      // (1) V_i = sum over the dof chain up to and including i of qvel_j cdof_j
+      V3 Vw = isdof ? qd * cw : v3(0, 0, 0), Vv = isdof ? qd * cv : v3(0, 0, 0);
+      ancestor_scan(Vw, Vv, tab);
+      // cdof_dot * qvel from the velocity in front of the dof; body velocity = V at the last dof that moves the body
+      V3 Yw = v3(0, 0, 0), Yv = v3(0, 0, 0);
+      if (isdof) {
         V3 pw = v3(0, 0, 0), pv = v3(0, 0, 0);
-        uint64_t mk = d_premask;
-        while (mk) {
-          int j = __ffsll((unsigned long long)mk) - 1;
-          mk &= mk - 1;
-          float qd = S.qvel[j];
-          pw = pw + qd * ld3v(&S.cdof[j][0]);
-          pv = pv + qd * ld3v(&S.cdof[j][4]);
-        }
-        V3 cw = ld3v(&S.cdof[lane][0]), cv = ld3v(&S.cdof[lane][4]);
-        float qd = S.qvel[lane];
-        st3v(&S.dm.dyn.cddq[lane][0], qd * cross(pw, cw));
-        st3v(&S.dm.dyn.cddq[lane][4], qd * (cross(pw, cv) + cross(pv, cw)));
-      } else {
-        st3v(&S.dm.dyn.cddq[lane][0], v3(0, 0, 0));
-        st3v(&S.dm.dyn.cddq[lane][4], v3(0, 0, 0));
+        if (d_bef >= 0) { pw = ld3v(tab + 8 * d_bef); pv = ld3v(tab + 8 * d_bef + 4); }
+        Yw = qd * cross(pw, cw);
+        Yv = qd * (cross(pw, cv) + cross(pv, cw));
       }
-      if (lane < NB) {
-        V3 w = v3(0, 0, 0), v = v3(0, 0, 0);
-        f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0;
-        if (isbody) {  // lane = body: cvel, composite inertia over the subtree
-          uint64_t mk = b_dofmask;
-          while (mk) {
-            int j = __ffsll((unsigned long long)mk) - 1;
-            mk &= mk - 1;
-            float qd = S.qvel[j];
-            w = w + qd * ld3v(&S.cdof[j][0]);
-            v = v + qd * ld3v(&S.cdof[j][4]);
-          }
-          uint32_t sm = b_submask;
-          while (sm) {
-            int c = __ffs(sm) - 1;
-            sm &= sm - 1;
-            const float* p = S.dm.dyn.cinert[c];
-            c0 += ldv(p); c1 += ldv(p + 4); c2 += ldv(p + 8);
-          }
+      V3 w = v3(0, 0, 0), v = v3(0, 0, 0);
+      if (isbody && b_last >= 0) { w = ld3v(tab + 8 * b_last); v = ld3v(tab + 8 * b_last + 4); }
+      // (2) composite inertia: suffix sums of the body inertias over the row, minus the suffix behind the subtree
+      const bool has_next = b_next >= 0;  // (the subtree ends inside the row)
+      const int nsrc = (has_next ? b_next : lane) << 2;
+      {
+        const float* ci = S.dm.dyn.cinert[bl];
+        const f4 c0 = ldv(ci), c1 = ldv(ci + 4), c2 = ldv(ci + 8);
+        float comp[10] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y};
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+          float t = lane < NB ? comp[k] : 0.0f;
+          t += row_shl<1>(t); t += row_shl<2>(t); t += row_shl<4>(t); t += row_shl<8>(t);
+          comp[k] = t;
         }
-        st3v(&S.dm.dyn.cvel[lane][0], w);
-        st3v(&S.dm.dyn.cvel[lane][4], v);
-        float* p = S.dm.dyn.crb[lane];
-        stv(p, c0); stv(p + 4, c1); stv(p + 8, c2);
+        float e[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+          const float gk = lane_gather(nsrc, comp[k]);
+          e[k] = has_next ? gk : 0.0f;
+        }
+        if (lane < NB) {
+          float* cs = S.dm.dyn.crb[lane];
+          stv(cs, isbody ? f4{comp[0] - e[0], comp[1] - e[1], comp[2] - e[2], comp[3] - e[3]} : f4{0, 0, 0, 0});
+          stv(cs + 4, isbody ? f4{comp[4] - e[4], comp[5] - e[5], comp[6] - e[6], comp[7] - e[7]} : f4{0, 0, 0, 0});
+          stv(cs + 8, isbody ? f4{comp[8] - e[8], comp[9] - e[9], 0.0f, 0.0f} : f4{0, 0, 0, 0});
+        }
       }
-    }
-    WSYNC();
-
-    STAMP(3);
-    // ======================= body forces (RNE, qacc=0) and mass matrix rows =======================
-    {
-      if (lane < NB) {
-        V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
-        if (isbody) {
-          V3 aw = v3(0, 0, 0), av = v3(-m->gx, -m->gy, -m->gz);
-          uint64_t mk = b_dofmask;
-          while (mk) {
-            int j = __ffsll((unsigned long long)mk) - 1;
-            mk &= mk - 1;
-            aw = aw + ld3v(&S.dm.dyn.cddq[j][0]);
-            av = av + ld3v(&S.dm.dyn.cddq[j][4]);
-          }
-          Inert I = ldI(S.dm.dyn.cinert[lane]);
-          V3 w = ld3v(&S.dm.dyn.cvel[lane][0]), v = ld3v(&S.dm.dyn.cvel[lane][4]);
-          V3 ta, fa, tv, fv;
-          imul(I, aw, av, ta, fa);
-          imul(I, w, v, tv, fv);
-          t = ta + cross(w, tv) + cross(v, fv);
-          f = fa + cross(w, fv);
-        }
-        st3v(&S.dm.dyn.cfrc[lane][0], t);
-        st3v(&S.dm.dyn.cfrc[lane][4], f);
+      WSYNC();  // (every read of the V table is done before the next scan overwrites it)
+      STAMP(3);
+      // (3) A_i = sum over the dof chain of cdof_dot_j qvel_j; body forces at zero acceleration (RNE)
+      ancestor_scan(Yw, Yv, tab);
+      V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
+      if (isbody) {
+        V3 aw = v3(0, 0, 0), av = v3(-m->gx, -m->gy, -m->gz);
+        if (b_last >= 0) { aw = aw + ld3v(tab + 8 * b_last); av = av + ld3v(tab + 8 * b_last + 4); }
+        Inert I = ldI(S.dm.dyn.cinert[lane]);
+        V3 ta, fa, tv, fv;
+        imul(I, aw, av, ta, fa);
+        imul(I, w, v, tv, fv);
+        t = ta + cross(w, tv) + cross(v, fv);
+        f = fa + cross(w, fv);
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) stv(&S.dm.M[lane][4 * q], f4{0, 0, 0, 0});
-    }
-    WSYNC();
-    if (isdof) {  // M[i][j] = cdof_j . (crb_body(i) cdof_i), j over ancestors-or-self (same tree => same block)
-      Inert I = ldI(S.dm.dyn.crb[d_body]);
-      V3 bt, bf;
-      imul(I, ld3v(&S.cdof[lane][0]), ld3v(&S.cdof[lane][4]), bt, bf);
-      uint64_t mk = d_ancmask;
-      while (mk) {
-        int j = __ffsll((unsigned long long)mk) - 1;
-        mk &= mk - 1;
-        float val = dot(ld3v(&S.cdof[j][0]), bt) + dot(ld3v(&S.cdof[j][4]), bf);
-        if (j == lane) val += d_mdiag;
-        S.dm.M[lane][j & 15] = val;
-        S.dm.M[j][l16] = val;
+      // (4) subtree forces: suffix sums again
+      {
+        float comp[6] = {t.x, t.y, t.z, f.x, f.y, f.z};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          float u = comp[k];
+          u += row_shl<1>(u); u += row_shl<2>(u); u += row_shl<4>(u); u += row_shl<8>(u);
+          comp[k] = u;
+        }
+        float e[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const float gk = lane_gather(nsrc, comp[k]);
+          e[k] = has_next ? gk : 0.0f;
+        }
+        if (lane < NB) {
+          float* fs = S.dm.dyn.cfrc[lane];
+          st3v(fs, v3(comp[0], comp[1], comp[2]) - v3(e[0], e[1], e[2]));
+          st3v(fs + 4, v3(comp[3], comp[4], comp[5]) - v3(e[3], e[4], e[5]));
+        }
       }
-    }
-    float qfrc_bias = 0.0f, qfs = 0.0f;
-    if (isdof) {
-      V3 t = v3(0, 0, 0), f = v3(0, 0, 0);
-      uint32_t sm = d_submask;
-      while (sm) {
-        int c = __ffs(sm) - 1;
-        sm &= sm - 1;
-        t = t + ld3v(&S.dm.dyn.cfrc[c][0]);
-        f = f + ld3v(&S.dm.dyn.cfrc[c][4]);
+      WSYNC();
+      if (isdof) {  // M[i][j] = cdof_j . (crb_body(i) cdof_i), j over ancestors-or-self (same tree => same block)
+        Inert I = ldI(S.dm.dyn.crb[d_body]);
+        V3 bt, bf;
+        imul(I, cw, cv, bt, bf);
+        uint64_t mk = d_ancmask;
+        while (mk) {  // four ancestors per trip, reads batched
+          int j[4];
+          bool ok[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { ok[u] = mk != 0ull; j[u] = ok[u] ? __ffsll((unsigned long long)mk) - 1 : 0; mk &= mk - 1ull; }
+          f4 ca[4], cl[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { ca[u] = ldv(&S.cdof[j[u]][0]); cl[u] = ldv(&S.cdof[j[u]][4]); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (ok[u]) {
+              float val = dot(v3(ca[u].x, ca[u].y, ca[u].z), bt) + dot(v3(cl[u].x, cl[u].y, cl[u].z), bf);
+              if (j[u] == lane) val += d_mdiag;
+              S.dm.M[lane][j[u] & 15] = val;
+              S.dm.M[j[u]][l16] = val;
+            }
+        }
+        // bias = cdof . (forces of the subtree of the dof's body); smooth force
+        const V3 ft = ld3v(&S.dm.dyn.cfrc[d_body][0]), ff = ld3v(&S.dm.dyn.cfrc[d_body][4]);
+        qfrc_bias = dot(cw, ft) + dot(cv, ff);
+        float fa = 0.0f;
+        if (d_ctrl == MIR_CTRL_POSITION) {
+          fa = d_kp * (S.target[lane] - S.qpos[d_qadr]) - d_kv * qd;
+          fa = fminf(fmaxf(fa, d_frclo), d_frchi);
+        }
+        qfs = -d_damping * qd + fa - qfrc_bias;
       }
-      qfrc_bias = dot(ld3v(&S.cdof[lane][0]), t) + dot(ld3v(&S.cdof[lane][4]), f);
-      float qd = S.qvel[lane];
-      float fa = 0.0f;
-      if (d_ctrl == MIR_CTRL_POSITION) {
-        fa = d_kp * (S.target[lane] - S.qpos[d_qadr]) - d_kv * qd;
-        fa = fminf(fmaxf(fa, d_frclo), d_frchi);
-      }
-      qfs = -d_damping * qd + fa - qfrc_bias;
     }
     WSYNC();
     STAMP(4);
@@ -906,7 +1077,7 @@ void mir_step64_kernel(StepArgs64 a) {
 #pragma unroll
       for (int j = 0; j < G; j++) arow[j] = isdof ? mrow[j] : (j == l16 ? 1.0f : 0.0f);
       qas = isdof ? qfs : 0.0f;
-      GJ<0>::run(arow, qas, l16);
+      gj16_dpp<0>(arow, qas, l16);
     }
     S.qas[lane] = qas;
     S.qacc[lane] = qas;
@@ -1025,27 +1196,30 @@ void mir_step64_kernel(StepArgs64 a) {
           for (int q = 0; q < 4; q++)
             if ((comp >> (4 * p + q)) & 1u) comp |= ((comp >> (4 * q)) & 15u) << (4 * p);
     }
-    // Newton Hessian H = Mt + J^T D_active J, kept in REGISTERS across iterations and updated incrementally (only rows
-    // whose active flag flipped contribute, as in the 16-lane kernel): lane = dof row; hd = the 16 columns of the row's own
-    // block (M is block-diagonal), ho[b] = the columns of block b, non-zero only when a contact couples two blocks this
-    // step (comp != identity: the arm touches a cube, or two cubes of different blocks touch).  The wave runs alone on its
-    // SIMD (LDS bounds the occupancy), so the 80 registers are free and every update is FMA work without memory round trips.
+    // Newton Hessian H = Mt + J^T D_active J.  Its diagonal blocks are kept in REGISTERS across iterations and updated incrementally
+    // (only rows whose active flag flipped contribute, as in the 16-lane kernel): lane = dof row, hd = the 16 columns of the row's
+    // own block (M is block-diagonal).  The off-diagonal blocks are non-zero only when a contact couples two blocks this step
+    // (comp != identity: the arm touches a cube, or two cubes of different blocks touch); they are formed inside the coupled solve.
     const bool coupled = comp != 0x8421u;
+    // exactly one coupled pair of blocks (p < q)?  (wave-uniform; -1 otherwise)
+    int pair_p = -1, pair_q = -1;
+    {
+      const unsigned off = comp & ~0x8421u;
+      if (__popc(off) == 2) {
+        const int bit = __ffs(off) - 1;  // lowest set bit = 4 p + q with p < q
+        pair_p = bit >> 2; pair_q = bit & 3;
+      }
+    }
     STAMP(20);
     // In the single-step instantiation the solve is compiled twice: the block-diagonal case (no contact couples two blocks:
-    // 73 % of the envs) carries no off-diagonal rows and no 64-wide working copy, i.e. ~130 registers less than the coupled
-    // case.  (The loop instantiations keep one run-time-switched copy: there the duplication cost more than it saved.)
+    // 73 % of the envs) carries no 64-wide working copy, i.e. ~65 registers less than the coupled case.  (The loop instantiations keep one run-time-switched copy: there the duplication cost more than it saved.)
     bool met4 = false;
     auto newton = [&](auto mode_t) {
     constexpr int MODE = decltype(mode_t)::value;  // 0: block-diagonal, 1: coupled, 2: decided at run time (loop instantiations)
     const bool cpl = MODE == 2 ? coupled : MODE == 1;
-    float hd[G], ho[MODE == 0 ? 1 : 4][G];
+    float hd[G];
 #pragma unroll
-    for (int j = 0; j < G; j++) {
-      hd[j] = isdof ? mrow[j] : (j == l16 ? 1.0f : 0.0f);
-#pragma unroll
-      for (int bq = 0; bq < (MODE == 0 ? 1 : 4); bq++) ho[bq][j] = 0.0f;
-    }
+    for (int j = 0; j < G; j++) hd[j] = isdof ? mrow[j] : (j == l16 ? 1.0f : 0.0f);
     const unsigned long long twoblk = __ballot(iscon && S.con.cblk[lane < MAXC ? lane : 0][1] >= 0);  // contacts with two segments
     float oldlact = 0.0f;
     unsigned prevbits = 0u;
@@ -1054,7 +1228,7 @@ void mir_step64_kernel(StepArgs64 a) {
       if (done) break;  // wave-uniform: one env per wave
       float lact = (lsg != 0.0f && ljar < 0.0f) ? lD : 0.0f;
       const float lf = -lact * ljar;
-      bool flip_d = false, flip_o = false;
+      bool flip_d = false, act_any = false;
       if (iscon) {
         float f[4];
         unsigned bits = 0;
@@ -1065,12 +1239,12 @@ void mir_step64_kernel(StepArgs64 a) {
           bits |= on ? (1u << r) : 0u;
         }
         stv(S.con.cfb[lane], f4{f[0] + f[1] + f[2] + f[3], cmu * (f[0] - f[1]), cmu * (f[2] - f[3]), (float)(bits | (prevbits << 4))});
-        flip_d = bits != (it == 0 ? 15u : prevbits);  // (the diagonal blocks start from all rows active,
-        flip_o = bits != prevbits;                    //  the off-diagonal ones from zero)
+        flip_d = bits != (it == 0 ? 15u : prevbits);  // (the diagonal blocks start from all rows active)
+        act_any = bits != 0u;
         prevbits = bits;
       }
       // contacts whose active rows changed since the Hessian last saw them (bit = contact): the updates walk those only
-      const unsigned long long flipd = __ballot(flip_d), flipo = __ballot(flip_o);
+      const unsigned long long flipd = __ballot(flip_d), actc = __ballot(act_any);
       WSYNC();
       if (it == 0) STAMP(21);
       // ---- gradient first (cheap): convergence is decided before any Hessian work
@@ -1148,48 +1322,6 @@ void mir_step64_kernel(StepArgs64 a) {
           hd[4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
         }
       }
-      // off-diagonal blocks: wave-uniform walk over the two-block contacts; the rows of either block take the other
-      // block's segment as columns
-      if constexpr (MODE != 0) if (cpl) {
-        for (unsigned long long tw = twoblk & flipo; tw; tw &= tw - 1ull) {
-          const int c = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tw));
-          const f4 fb = ldv(S.con.cfb[c]);
-          const unsigned both = (unsigned)fb.w;
-          const unsigned bits = both & 15u, old = both >> 4;
-          if (bits == old) continue;
-          const int sg0 = S.con.cblk[c][0], sg1 = S.con.cblk[c][1];
-          const bool in0 = blk == sg0, in1 = blk == sg1;
-          if (in0 || in1) {
-            const float* seg = &S.Jb[c][in1 ? 1 : 0][0];
-            const float* oseg = &S.Jb[c][in1 ? 0 : 1][0];
-            const int ob = in1 ? sg0 : sg1;
-            const float jn = seg[l16], j1 = seg[16 + l16], j2 = seg[32 + l16];
-            const f4 mt = ldv(S.con.cmeta[c]);
-            f4 xn[4], x1[4], x2[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { xn[q] = ldv(oseg + 4 * q); x1[q] = ldv(oseg + 16 + 4 * q); x2[q] = ldv(oseg + 32 + 4 * q); }
-            const float mu = mt.x, D = mt.y;
-            const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
-            const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
-            const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
-            const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
-            float d[G];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              d[4 * q + 0] = tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
-              d[4 * q + 1] = tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
-              d[4 * q + 2] = tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
-              d[4 * q + 3] = tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
-            }
-#pragma unroll
-            for (int bq = 0; bq < 4; bq++)
-              if (ob == bq) {
-#pragma unroll
-                for (int j = 0; j < G; j++) ho[bq][j] += d[j];
-              }
-          }
-        }
-      }
       if (it == 0) STAMP(13);
       // ---- Newton direction: H s = -g: four 16-wide DPP block solves side by side, or dense over the wave
       float sv = -g;
@@ -1199,16 +1331,108 @@ void mir_step64_kernel(StepArgs64 a) {
         float hb[G];
 #pragma unroll
         for (int j = 0; j < G; j++) hb[j] = hd[j];
-        GJ<0>::run(hb, sv, l16);
+        gj16_dpp<0>(hb, sv, l16);
       }
       if constexpr (MODE != 0) {
         if (dense) {
-          v16f hrow[4];
+          // The solve consumes its matrix: a working copy of the diagonal block, and the off-diagonal blocks built HERE, from zero, in
+          // every iteration: J_r^T D_active J_q over the two-block contacts with an active row (wave-uniform walk; the rows of either
+          // block take the other block's segment as columns).  They are nowhere else: persistent off-diagonal rows cost 64 registers
+          // for blocks that are zero in most envs, and the walk is a few contacts long.
+          if (pair_p >= 0) {
+            // one coupled pair: the rows of either block carry ONE off-diagonal block, the other block's columns
+            float hb[G], hx[G];
 #pragma unroll
-          for (int bq = 0; bq < 4; bq++)
+            for (int j = 0; j < G; j++) { hb[j] = hd[j]; hx[j] = 0.0f; }
+            const bool inpair = blk == pair_p || blk == pair_q;
+            // (segment 0 of contact c belongs to block p?  one ballot instead of a dependent LDS read per contact)
+            const unsigned long long seg0p = __ballot(iscon && S.con.cblk[lane < MAXC ? lane : 0][0] == pair_p);
+            for (unsigned long long tw = twoblk & actc; tw;) {  // two contacts per trip, every read of both in one batch
+              const int cA = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tw));
+              tw &= tw - 1ull;
+              const bool two = tw != 0ull;
+              const int cB = two ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(tw)) : cA;
+              if (two) tw &= tw - 1ull;
+              // my segment: segment 0 when (segment 0 is p's) == (I am in p)
+              const int mA = (((seg0p >> cA) & 1ull) != 0ull) == (blk == pair_p) ? 0 : 1, mB = (((seg0p >> cB) & 1ull) != 0ull) == (blk == pair_p) ? 0 : 1;
+              const float* segA = &S.Jb[cA][mA][0]; const float* osegA = &S.Jb[cA][mA ^ 1][0];
+              const float* segB = &S.Jb[cB][mB][0]; const float* osegB = &S.Jb[cB][mB ^ 1][0];
+              const f4 fbA = ldv(S.con.cfb[cA]), fbB = ldv(S.con.cfb[cB]);
+              const f4 mtA = ldv(S.con.cmeta[cA]), mtB = ldv(S.con.cmeta[cB]);
+              const float jnA = segA[l16], j1A = segA[16 + l16], j2A = segA[32 + l16];
+              const float jnB = segB[l16], j1B = segB[16 + l16], j2B = segB[32 + l16];
+              f4 xnA[4], x1A[4], x2A[4], xnB[4], x1B[4], x2B[4];
 #pragma unroll
-            for (int j = 0; j < G; j++) hrow[bq][j] = blk == bq ? hd[j] : ho[bq][j];
-          gj_wave(hrow, sv, lane, lanemask, comp);
+              for (int q = 0; q < 4; q++) {
+                xnA[q] = ldv(osegA + 4 * q); x1A[q] = ldv(osegA + 16 + 4 * q); x2A[q] = ldv(osegA + 32 + 4 * q);
+                xnB[q] = ldv(osegB + 4 * q); x1B[q] = ldv(osegB + 16 + 4 * q); x2B[q] = ldv(osegB + 32 + 4 * q);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#define MIR_OFFDIAG(fb, mt, jn, j1, j2, xn, x1, x2, on)                                                                                   \
+              {                                                                                                                             \
+                const unsigned bits = (unsigned)fb.w & 15u;                                                                                 \
+                const float mu = mt.x, D = (on) ? mt.y : 0.0f;                                                                              \
+                const float a0 = (bits & 1u) ? D : 0.0f, a1 = (bits & 2u) ? D : 0.0f, a2 = (bits & 4u) ? D : 0.0f, a3 = (bits & 8u) ? D : 0.0f; \
+                const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3); \
+                const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;                               \
+                _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                                             \
+                  hx[4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;                                                              \
+                  hx[4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;                                                              \
+                  hx[4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;                                                              \
+                  hx[4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;                                                              \
+                }                                                                                                                           \
+              }
+              MIR_OFFDIAG(fbA, mtA, jnA, j1A, j2A, xnA, x1A, x2A, inpair)
+              MIR_OFFDIAG(fbB, mtB, jnB, j1B, j2B, xnB, x1B, x2B, inpair && two)
+#undef MIR_OFFDIAG
+            }
+            if (it == 0) STAMP(30);
+            pair_solve(hb, hx, sv, blk, l16, lane, pair_p, pair_q, &S.hx3[0][0], S.srch);
+          } else {
+          float hw0[G], hw1[G], hw2[G], hw3[G];
+          H4 hw{hw0, hw1, hw2, hw3};
+#pragma unroll
+          for (int j = 0; j < G; j++) {
+            hw.c0[j] = blk == 0 ? hd[j] : 0.0f; hw.c1[j] = blk == 1 ? hd[j] : 0.0f;
+            hw.c2[j] = blk == 2 ? hd[j] : 0.0f; hw.c3[j] = blk == 3 ? hd[j] : 0.0f;
+          }
+          for (unsigned long long tw = twoblk & actc; tw; tw &= tw - 1ull) {
+            const int c = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tw));
+            const f4 fb = ldv(S.con.cfb[c]);
+            const unsigned bits = (unsigned)fb.w & 15u;
+            const int sg0 = S.con.cblk[c][0], sg1 = S.con.cblk[c][1];
+            const bool in0 = blk == sg0, in1 = blk == sg1;
+            if (in0 || in1) {
+              const float* seg = &S.Jb[c][in1 ? 1 : 0][0];
+              const float* oseg = &S.Jb[c][in1 ? 0 : 1][0];
+              const int ob = in1 ? sg0 : sg1;
+              const float jn = seg[l16], j1 = seg[16 + l16], j2 = seg[32 + l16];
+              const f4 mt = ldv(S.con.cmeta[c]);
+              f4 xn[4], x1[4], x2[4];
+#pragma unroll
+              for (int q = 0; q < 4; q++) { xn[q] = ldv(oseg + 4 * q); x1[q] = ldv(oseg + 16 + 4 * q); x2[q] = ldv(oseg + 32 + 4 * q); }
+              const float mu = mt.x, D = mt.y;
+              const float a0 = (bits & 1u) ? D : 0.0f, a1 = (bits & 2u) ? D : 0.0f, a2 = (bits & 4u) ? D : 0.0f, a3 = (bits & 8u) ? D : 0.0f;
+              const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
+              const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
+              float d[G];
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                d[4 * q + 0] = tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
+                d[4 * q + 1] = tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
+                d[4 * q + 2] = tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
+                d[4 * q + 3] = tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
+              }
+#pragma unroll
+              for (int j = 0; j < G; j++) {  // (selects, not a branch per block: `ob` differs between the two blocks of the contact)
+                hw.c0[j] += ob == 0 ? d[j] : 0.0f; hw.c1[j] += ob == 1 ? d[j] : 0.0f;
+                hw.c2[j] += ob == 2 ? d[j] : 0.0f; hw.c3[j] += ob == 3 ? d[j] : 0.0f;
+              }
+            }
+          }
+          coupled_solve(hw, sv, lane, comp, &S.hx3[0][0], S.srch);
+          }
+          if (it == 0) STAMP(31);
         }
       }
       if (!isdof) sv = 0.0f;
@@ -1309,8 +1533,17 @@ void mir_step64_kernel(StepArgs64 a) {
     if (a.out_qacc && isdof && step == 0) a.out_qacc[(size_t)env * nv + m->d_dof[lane]] = qacc;
     if (a.diag && lane == 0) {
       a.diag[(size_t)env * 4 + 0] = ncon;
+#ifndef MIR_PROFILE_SINGLE
       a.diag[(size_t)env * 4 + 1] = nefc;
+#endif
       a.diag[(size_t)env * 4 + 2] = niter;
+#ifdef MIR_PROFILE_SINGLE  /* (profiling build: cycles from this wave's entry to the end of its solve, and whether blocks coupled) */
+#ifdef MIR_PROFILE_COMP
+      a.diag[(size_t)env * 4 + 1] = (int)comp;
+#else
+      a.diag[(size_t)env * 4 + 1] = (int)(__builtin_readcyclecounter() - t_entry) | (coupled ? 1 << 30 : 0);
+#endif
+#endif
       a.diag[(size_t)env * 4 + 3] = ncand;
     }
     if (a.mode != 0) break;

@@ -15,8 +15,18 @@ if len(sys.argv) > 2:  # canonical layout for env 0: five cubes resting apart on
     from gym_genesis.backend import models
     pos = torch.from_numpy(task.sample_spawn()).to(sc.device).float()
     pos[0] = torch.tensor([[0.1 + 0.12 * i - 0.3, (-1) ** i * 0.15, models.STACK_CUBE_Z] for i in range(5)], device=sc.device)
+    if sys.argv[2] == "coupled":  # cube 2 (block 1) and cube 3 (block 2) touching side by side: one coupled pair of blocks
+        pos[0, 2, 0] = pos[0, 1, 0] + 0.0399; pos[0, 2, 1] = pos[0, 1, 1]
     sc.reset(pos, task._quat, home)
 for t in range(30): task.step_raw(home)
+if len(sys.argv) > 2 and sys.argv[2] == "real":  # (-DMIR_PROFILE_SINGLE build) env 0 := a copy of an env whose blocks couple (bit 30 of the nefc slot)
+    raw = sc.get_diag()[1].cpu().numpy()
+    e = int(np.nonzero((raw >> 30) & 1)[0][int(sys.argv[3]) if len(sys.argv) > 3 else 0])
+    st = [x.clone() for x in sc.get_state()]
+    for x in st: x[0] = x[e]
+    sc.set_state(*st)
+    print("env 0 := env", e)
+    for t in range(3): task.step_raw(home)
 dg = sc.get_diag()
 print("ncon hist", np.bincount(dg[0].cpu().numpy())[15:40], "niter hist", np.bincount(dg[2].cpu().numpy()))
 names = ["load", "fk/cache", "cdof+cinert", "vel+crb", "rne+M", "smooth solve", "geom+broad", "plane-box", "box-box", "compact+finish", "J + limit rows",
@@ -37,6 +47,7 @@ for r in range(n):
         p[6] = p[7] = p[8] = p[5]
         fine += np.array([p[20] - p[11], p[21] - p[20], p[22] - p[21], p[12] - p[22], p[23] - p[12], p[29] - p[28]])
     acc += np.diff(p[:20])
+    if p[30] > 0: print(f'   it0: H walk {p[30]-p[13]:.0f}, coupled_solve {p[31]-p[30]:.0f} cycles') if r == 0 else None
 acc /= n
 if dual.any():
     dual /= n
