@@ -412,7 +412,7 @@ def pixels_bench(torch, dev, renders: int = 30):
             "reduced_96x128_num_envs_4096": {"env_frames_per_s": Bs / (us_small * 1e-6), "us_per_render": us_small,
                                              "GBps": Bs * Hs * Ws * 3 / (us_small * 1e-6) / 1e9},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "mir_render_kernel",
+                         "traffic": traffic, "kernel": "mir_render_binned",
                          "note": "algorithmic bytes = 1024x480x640x3 written once per render; time = whole mir_render call "
                                  "(FK refresh + primitive setup + pixel kernel), HIP events"}}
 

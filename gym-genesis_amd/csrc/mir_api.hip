@@ -210,6 +210,12 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
     a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
     a.term_host = o.term_host; a.term_tag = o.term_tag;
+    auto order = [&]() {  // the single-step launches read one cost buffer and write the other
+      if (!h->cost) return;
+      a.cost_in = h->cost + (size_t)h->cost_par * h->cost_stride;
+      a.cost_out = h->cost + (size_t)(h->cost_par ^ 1) * h->cost_stride;
+      h->cost_par ^= 1;
+    };
     if (a.mode == 0 && a.n_steps > 1 && a.act_step && a.rows_step && !a.ar.episode_len && !a.prof) {
       // a plain K-step rollout of the wave kernel is K launches of its two-wave single-step instantiation: at ~140 us a step the
       // launch gap is nothing, and the single-step code is faster than the step loop (which carries the loop's register spills)
@@ -222,9 +228,11 @@ int launch(MirScene* h, const Outs& o, void* stream) {
       for (int k = 0; k < K && rc == 0; k++) {
         a.action = act0 + (size_t)k * as;
         a.rows = rows0 + (size_t)k * rs;
+        order();
         rc = mir_launch_step64(&a, (hipStream_t)stream);
       }
     } else {
+      if (a.mode == 0 && a.n_steps == 1) order();
       rc = mir_launch_step64(&a, (hipStream_t)stream);
     }
   }
@@ -258,6 +266,11 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   HIPCHK(hipMalloc((void**)&h->done_ticket, 64));
   HIPCHK(hipMalloc((void**)&h->scratch_row, row_bytes));
   if (h->kernel == 16) HIPCHK(hipMalloc((void**)&h->pre, B * K16_PRE_STRIDE * sizeof(float)));
+  if (h->kernel == 64 && !getenv("MIR_NO_ORDER")) {  // dispatch-order flags of the wave kernel (mir_step64.h): two buffers, padded to whole 64-byte reads
+    h->cost_stride = (int)(((B + 63) / 64) * 64);
+    HIPCHK(hipMalloc((void**)&h->cost, 2 * (size_t)h->cost_stride));
+    HIPCHK(hipMemset(h->cost, 0, 2 * (size_t)h->cost_stride));
+  }
   // pinned, device-mapped, coherent host memory for the API's host-visible outputs: terminated bytes + completion word
   const size_t pin_bytes = ((B + 63) / 64) * 64 + 64;  // (whole 32-bit words for the packed stores of the 16-lane kernel)
   HIPCHK(hipHostMalloc((void**)&h->pin_host, pin_bytes, hipHostMallocMapped | hipHostMallocCoherent));
@@ -407,6 +420,7 @@ int mir_destroy(MirHandle h) {
   if (h->poses) (void)hipFree(h->poses);
   if (h->fkvalid) (void)hipFree(h->fkvalid);
   if (h->prims) (void)hipFree(h->prims);
+  if (h->cost) (void)hipFree(h->cost);
   if (h->bins) (void)hipFree(h->bins);
   if (h->done_ticket) (void)hipFree(h->done_ticket);
   if (h->scratch_row) (void)hipFree(h->scratch_row);

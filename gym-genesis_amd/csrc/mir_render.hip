@@ -495,12 +495,10 @@ __global__ __launch_bounds__(256) void mir_render_binned(PixArgs a) {
   const bool floor = (hdr >> 8) & 1;
   // the floor record (primitive 0), read once per workgroup: o'z, F'z, U'z, the checker numerators and the two colours
   const cf4* frec = (const cf4*)(uintptr_t)prims;
-  float f_oz = 0.0f, f_fz = 0.0f, f_uz = 0.0f;
-  f4 fq5 = f4{0, 0, 0, 0}, fq6 = f4{0, 0, 0, 0};
-  if (floor) {
-    f_oz = frec[0].z; f_fz = frec[1].z; f_uz = frec[3].z;
-    fq5 = frec[5]; fq6 = frec[6];
-  }
+  // (fetched whether or not the header says `floor`: record 0 always exists, and waiting for the header first would put a second
+  //  memory round trip in front of every strip)
+  const float f_oz = frec[0].z, f_fz = frec[1].z, f_uz = frec[3].z;
+  const f4 fq5 = frec[5], fq6 = frec[6];
   const unsigned ceven = __float_as_uint(fq5.w), codd = __float_as_uint(fq6.w);
   uint8_t* __restrict__ ibase = a.pixels + (size_t)img * a.H * a.W * 3;
   unsigned* tile = s_tile[wv];

@@ -20,6 +20,9 @@ struct MirScene {
   GeomTab* dgeom;
   float *qpos, *qvel, *target, *qacc_ws, *poses;
   int32_t *diag, *fkvalid;
+  uint8_t* cost = nullptr;  // wave kernel: two buffers of per-env cost flags (B padded to 64 each) for the dispatch order, see mir_step64.h
+  int cost_par = 0;         // which of the two the next single-step launch reads
+  int cost_stride = 0;
   float* prims;     // render primitives (B, ngeom, 32) f32, allocated by the first mir_render
   int* bins = nullptr;      // per-strip primitive lists of the binned pixel kernel (grown on demand)
   size_t bins_cap = 0;      // ints

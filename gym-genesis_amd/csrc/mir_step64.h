@@ -38,6 +38,13 @@ struct StepArgs64 {
   int nu;       // action width (copy of the model's: the action load does not wait for the model)
   int mode;     // 0: full steps; 1: forward dynamics only; 2: kinematics + outputs only
   int n_steps;  // mode 0 only
+  // Dispatch order of the single-step launch (nullable): cost_in[e] != 0 says env e was expensive in the previous step (blocks
+  // coupled by a contact, or three and more Newton iterations); workgroup r then serves the r-th env of "expensive first" within
+  // its chunk of 4096 envs instead of env r -- a launch ends with its slowest workgroup, and an expensive env that starts in the
+  // last round of workgroups is what it then waits for.  cost_out[e]: this step's verdict, read by the NEXT launch (two buffers,
+  // swapped by the host: every workgroup of a launch sees the same snapshot, so the order is a permutation).
+  const uint8_t* cost_in;
+  uint8_t* cost_out;
 };
 
 extern "C" __attribute__((visibility("hidden"))) int mir_launch_step64(const StepArgs64* args, hipStream_t stream);

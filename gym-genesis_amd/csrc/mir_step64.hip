@@ -398,7 +398,62 @@ void mir_step64_kernel(StepArgs64 a) {
   const unsigned long long t_entry = __builtin_readcyclecounter();
 #endif
   const int blk = lane >> 4, l16 = lane & 15;
-  const int env = blockIdx.x;  // grid = B exactly
+  int env = blockIdx.x;  // grid = B exactly
+  if (SINGLE && a.cost_in) {
+    // expensive-first order inside this workgroup's chunk of 4096 envs (see mir_step64.h): lane i counts the flags of envs
+    // 64 i .. 64 i + 63 (one 64-byte read, four bytes per v_sad_u8), a wave scan of the counts finds the lane that holds the
+    // wanted env, and the flag bytes of that lane alone are walked on the scalar unit.  Every workgroup of the launch reads the
+    // same bytes, so the map is a permutation of the chunk.
+    const int base = (int)blockIdx.x & ~4095, r = (int)blockIdx.x - base;
+    const int n = min(4096, a.B - base);
+    const int first = 64 * lane, have = min(max(n - first, 0), 64);  // envs of this lane that exist
+    const uint4* fp = reinterpret_cast<const uint4*>(a.cost_in + base + first);
+    uint4 fw[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    if (have > 0) {  // (the buffers are padded to a multiple of 64 bytes; flags are 0 / 1)
+#pragma unroll
+      for (int k = 0; k < 4; k++) fw[k] = fp[k];
+    }
+    unsigned cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      cnt = __builtin_amdgcn_sad_u8(fw[k].x, 0u, cnt); cnt = __builtin_amdgcn_sad_u8(fw[k].y, 0u, cnt);
+      cnt = __builtin_amdgcn_sad_u8(fw[k].z, 0u, cnt); cnt = __builtin_amdgcn_sad_u8(fw[k].w, 0u, cnt);
+    }
+    // inclusive scans over the wave of (expensive, cheap) counts, packed in one float pair via two DPP row scans + row totals
+    float sh = (float)cnt, sl = (float)(have - (int)cnt);
+    sh += row_shr<1>(sh); sl += row_shr<1>(sl);
+    sh += row_shr<2>(sh); sl += row_shr<2>(sl);
+    sh += row_shr<4>(sh); sl += row_shr<4>(sl);
+    sh += row_shr<8>(sh); sl += row_shr<8>(sl);
+    const float h0 = rl(sh, 15), h1 = rl(sh, 31), h2 = rl(sh, 47), h3 = rl(sh, 63);
+    const float l0 = rl(sl, 15), l1 = rl(sl, 31), l2 = rl(sl, 47);
+    const int rowq = lane >> 4;
+    const int inch = (int)(sh + (rowq == 0 ? 0.0f : (rowq == 1 ? h0 : (rowq == 2 ? h0 + h1 : h0 + h1 + h2))));
+    const int incl = (int)(sl + (rowq == 0 ? 0.0f : (rowq == 1 ? l0 : (rowq == 2 ? l0 + l1 : l0 + l1 + l2))));
+    const int H = (int)(h0 + h1 + h2 + h3);
+    const bool wantexp = r < H;
+    const int want = wantexp ? r : r - H;  // rank inside its class
+    const unsigned long long reach = __ballot((wantexp ? inch : incl) > want);
+    const int L = __builtin_amdgcn_readfirstlane(__builtin_ctzll(reach));  // (r < n, so some lane reaches it)
+    const int before = L == 0 ? 0 : __builtin_amdgcn_readlane(wantexp ? inch : incl, L - 1);
+    int k = want - before;  // the (k + 1)-th env of the class among lane L's
+    int pos = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const unsigned wq[4] = {(unsigned)__builtin_amdgcn_readlane((int)fw[q].x, L), (unsigned)__builtin_amdgcn_readlane((int)fw[q].y, L),
+                              (unsigned)__builtin_amdgcn_readlane((int)fw[q].z, L), (unsigned)__builtin_amdgcn_readlane((int)fw[q].w, L)};
+#pragma unroll
+      for (int d = 0; d < 4; d++)
+#pragma unroll
+        for (int b8 = 0; b8 < 4; b8++) {
+          const bool isexp = ((wq[d] >> (8 * b8)) & 0xffu) != 0u;
+          const bool hit = k >= 0 && isexp == wantexp;
+          if (hit && k == 0) pos = 16 * q + 4 * d + b8;
+          k -= hit ? 1 : 0;
+        }
+    }
+    env = base + 64 * L + pos;
+  }
 
   const int nb = m->nbody, nv = m->nv, nq = m->nq;
   const int ngeom = m->ngeom, npair = m->npair, max_contacts = m->max_contacts, enable_collision = m->enable_collision;
@@ -1084,17 +1139,6 @@ void mir_step64_kernel(StepArgs64 a) {
     if (a.out_qas && isdof && step == 0) a.out_qas[(size_t)env * nv + m->d_dof[lane]] = qas;
     WSYNC();  // dyn scratch is dead from here on
 
-    STAMP(5);
-    // ======================= collision detection (wave 1's work in the single-step instantiation) ==
-    if (!DUAL) collide();
-    else __syncthreads();  // (2) contacts finished by wave 1; this wave is done with the dynamics scratch
-    const int ncon = __builtin_amdgcn_readfirstlane(S.ncon), ncand = __builtin_amdgcn_readfirstlane(S.ncand);
-    const int nmine = S.con.bcount[blk];  // contacts touching this lane's block
-
-    STAMP(9);
-    // ======================= constraint rows ======================================================
-    // contact base Jacobians (with two waves: wave 1 takes every other pair of list entries)
-    jacobians(nmine, 0, DUAL ? 4 : 2);
     // joint-limit rows: lane = dof, lane-private
     float lsg = 0.0f, lD = 0.0f, laref = 0.0f;
     if (d_limited) {
@@ -1110,6 +1154,27 @@ void mir_step64_kernel(StepArgs64 a) {
         laref = -d_lb * (lsg * S.qvel[lane]) - d_lk * imp * pos;
       }
     }
+    // Everything of the warm start that does not need the contacts, ahead of the meeting with the collision wave (this wave
+    // arrives there first): the Gauss term of the warm-start candidate and Mt times either candidate.
+    const float* xblk_srch = &S.srch[16 * blk];
+    const float* xblk_qacc = &S.qacc[16 * blk];
+    const float ws = S.qacc_ws[lane];
+    const float dq = isdof ? ws - qas : 0.0f;
+    S.srch[lane] = dq;
+    WSYNC();
+    const float gauss_ws = isdof ? 0.5f * rowdot(mrow, xblk_srch) * dq : 0.0f;
+    const float Ma_qas = isdof ? rowdot(mrow, &S.qas[16 * blk]) : 0.0f, Ma_ws = isdof ? rowdot(mrow, &S.qacc_ws[16 * blk]) : 0.0f;
+    STAMP(5);
+    // ======================= collision detection (wave 1's work in the single-step instantiation) ==
+    if (!DUAL) collide();
+    else __syncthreads();  // (2) contacts finished by wave 1; this wave is done with the dynamics scratch
+    const int ncon = __builtin_amdgcn_readfirstlane(S.ncon), ncand = __builtin_amdgcn_readfirstlane(S.ncand);
+    const int nmine = S.con.bcount[blk];  // contacts touching this lane's block
+
+    STAMP(9);
+    // ======================= constraint rows ======================================================
+    // contact base Jacobians (with two waves: wave 1 takes every other pair of list entries)
+    jacobians(nmine, 0, DUAL ? 4 : 2);
     WSYNC();
     if (DUAL) __syncthreads();  // (3) both halves of the Jacobian segments
     // contact rows, lane = contact, lane-private: aref_r = -b (J_r qvel) - k imp dist
@@ -1134,15 +1199,9 @@ void mir_step64_kernel(StepArgs64 a) {
     const int nefc = 4 * ncon + __popcll(limmask);
     bool done = nefc == 0;
     float qacc = qas, Ma = 0.0f, ljar = 0.0f;
-    const float* xblk_srch = &S.srch[16 * blk];
-    const float* xblk_qacc = &S.qacc[16 * blk];
     {
       // warm start: cost(ws) vs cost(qacc_smooth); Gauss part 1/2 dq^T Mt dq
-      const float ws = S.qacc_ws[lane];
-      const float dq = isdof ? ws - qas : 0.0f;
-      S.srch[lane] = dq;
-      WSYNC();
-      float c_ws = isdof ? 0.5f * rowdot(mrow, xblk_srch) * dq : 0.0f, c_sm = 0.0f;
+      float c_ws = gauss_ws, c_sm = 0.0f;
       const float ljs = lsg * qas - laref, ljw = lsg * ws - laref;
       if (lsg != 0.0f) {
         if (ljs < 0.0f) c_sm += 0.5f * lD * ljs * ljs;
@@ -1171,7 +1230,7 @@ void mir_step64_kernel(StepArgs64 a) {
       WSYNC();
       S.qacc[lane] = qacc;
       WSYNC();
-      Ma = isdof ? rowdot(mrow, xblk_qacc) : 0.0f;
+      Ma = usews ? Ma_ws : Ma_qas;  // = rowdot(mrow, the chosen candidate)
     }
     STAMP(11);
     int niter = 0;
@@ -1531,6 +1590,7 @@ void mir_step64_kernel(StepArgs64 a) {
     if (DUAL && !met4) __syncthreads();  // (4) (no Hessian was needed: wave 1 is let go)
     STAMP(16);
     if (a.out_qacc && isdof && step == 0) a.out_qacc[(size_t)env * nv + m->d_dof[lane]] = qacc;
+    if (SINGLE && a.cost_out && lane == 0) a.cost_out[env] = (coupled || niter >= 3) ? 1 : 0;
     if (a.diag && lane == 0) {
       a.diag[(size_t)env * 4 + 0] = ncon;
 #ifndef MIR_PROFILE_SINGLE

@@ -33,3 +33,11 @@ sc.debug_render_path(generic=False, strip_rows=0)
 print(f"binned, robot out of view (floor only): {t():.1f} us")
 sc.debug_render_path(generic=True)
 print(f"generic, robot out of view (floor only): {t():.1f} us")
+# the bench's state: arms apart after 20 random-action steps
+import torch as _t
+g = _t.Generator(device=sc.device).manual_seed(99)
+for _ in range(20):
+    sc.set_pd_targets(_t.empty((B, 9), dtype=_t.float32, device=sc.device).uniform_(-1.0, 1.0, generator=g)); sc.step(1)
+cam = make_camera(640, 480, (3.5, 0, 2.5), (0, 0, 0.5), 30)
+sc.debug_render_path(generic=False, strip_rows=0)
+print(f"binned, arms apart (the bench's state): {t():.1f} us")
