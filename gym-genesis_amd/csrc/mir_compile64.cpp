@@ -180,9 +180,15 @@ int mir_compile_model64(const MirSceneSpec* sp0, DevModel64* out, HostConsts* hc
   for (int g = 0; g < sp->ngeom; g++) {
     const MirGeomSpec& s = sp->geom[g];
     if (s.body < 0 || s.body >= nb) return fail(err, MIR_E_INVALID, "geom body out of range");
-    if (s.type != MIR_GEOM_PLANE && s.type != MIR_GEOM_BOX) return fail(err, MIR_E_INVALID, "unsupported geom type");
+    if (s.type != MIR_GEOM_PLANE && s.type != MIR_GEOM_BOX && s.type != MIR_GEOM_SPHERE && s.type != MIR_GEOM_CAPSULE)
+      return fail(err, MIR_E_INVALID, "unsupported geom type");
+    if (s.type == MIR_GEOM_SPHERE || s.type == MIR_GEOM_CAPSULE) m.has_convex = 1;
     m.g_body[g] = s.body; m.g_type[g] = s.type;
     for (int k = 0; k < 3; k++) { m.g_size[g][k] = (float)s.size[k]; m.g_pos[g][k] = (float)s.pos[k]; }
+    // bounding-sphere radius of the broadphase (box: half diagonal; sphere: radius; capsule: half length + radius), as in mir_compile.cpp
+    m.g_size[g][3] = s.type == MIR_GEOM_SPHERE ? (float)s.size[0]
+                     : (s.type == MIR_GEOM_CAPSULE ? (float)(s.size[0] + s.size[1])
+                                                    : (float)std::sqrt(s.size[0] * s.size[0] + s.size[1] * s.size[1] + s.size[2] * s.size[2]));
     m.g_pos[g][3] = (float)s.friction;
     for (int k = 0; k < 4; k++) m.g_quat[g][k] = (float)s.quat[k];
     m.g_sol[g][0] = (float)s.solref[0]; m.g_sol[g][1] = (float)s.solref[1];

@@ -137,6 +137,8 @@ __device__ __forceinline__ float gmaxf(float v) {  // all-reduce max over the ro
 }
 __device__ __forceinline__ int gsumi(int v) { return (int)(gsum((float)v) + 0.5f); }
 
+#include "mir_gj_dpp.h"
+
 // ---- Gauss-Jordan solve A x = b on register rows: lane i holds row i of the SPD matrix A in
 // a[0..15] and b_i in b; on return b = x_i.  Rows >= nv must be identity rows.  15 pivots, each:
 // one reciprocal, (16-k) row_newbcast + fma pairs.  No pivoting needed (SPD).
@@ -212,8 +214,34 @@ struct GJP {
     if constexpr (K + 1 < (S > E - S ? S : E - S)) GJP<S, E, K + 1>::run(a, b, lane);
   }
 };
+// GJP<9, 15> / GJP<6, 12> with the column updates as v_fmac_f32_dpp blocks (mir_gj_dpp.h): the same operations on every entry in
+// the same order, one instruction per entry instead of a v_mov_b32_dpp + v_fma_f32 pair -- bit-identical results.
+#define MIR_GJPD(S, E)                                                                                              \
+  template <int K>                                                                                                  \
+  __device__ __forceinline__ void gjpd_##S##_##E(float (&a)[G], float& b, int lane) {                               \
+    constexpr bool HA = K < S, HB = S + K < E;                                                                      \
+    constexpr int KA = HA ? K : 0, KB = HB ? S + K : 0;                                                             \
+    float nfa = 0.0f, nfb = 0.0f;                                                                                   \
+    if (HA) {                                                                                                       \
+      const float inv = __builtin_amdgcn_rcpf(row_bcast<KA>(a[KA]));                                                \
+      nfa = lane == KA ? inv - 1.0f : -(a[KA] * inv);                                                               \
+    }                                                                                                               \
+    if (HB) {                                                                                                       \
+      const float inv = __builtin_amdgcn_rcpf(row_bcast<KB>(a[KB]));                                                \
+      nfb = lane == KB ? inv - 1.0f : -(a[KB] * inv);                                                               \
+    }                                                                                                               \
+    gjp_dpp_step_##S##_##E<K>(a, b, nfa, nfb);                                                                      \
+    if constexpr (K + 1 < (S > E - S ? S : E - S)) gjpd_##S##_##E<K + 1>(a, b, lane);                               \
+  }
+MIR_GJPD(9, 15)
+MIR_GJPD(6, 12)
+#undef MIR_GJPD
 // dispatch on the model's block split (0 = dense) and dof count; both must be wave-uniform
 __device__ __forceinline__ void gj_solve(float (&a)[G], float& b, int lane, int split, int nv) {
+#ifndef MIR_GJ_NO_DPP_ASM
+  if (split == 9 && nv == 15) { gjpd_9_15<0>(a, b, lane); return; }
+  if (split == 6 && nv == 12) { gjpd_6_12<0>(a, b, lane); return; }
+#endif
   if (split == 9 && nv == 15) GJP<9, 15, 0>::run(a, b, lane);
   else if (split == 6 && nv == 12) GJP<6, 12, 0>::run(a, b, lane);
   else if (split == 9) GJ2<9, 0>::run(a, b, lane);

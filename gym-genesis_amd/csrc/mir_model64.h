@@ -62,6 +62,8 @@ struct DevModel64 {
    * whose inclusive chain sum is the velocity in front of dof l, [2] (lane = body) the body's last moving dof, [3] (lane = body)
    * the lane behind the body's subtree, -1 when the subtree ends with its 16-lane row */
   int32_t scanw[W64];
+  int32_t has_convex; /* the scene has sphere / capsule geoms: the launcher picks the instantiation with the convex narrowphase */
+  int32_t pad_hc;
 };
 
 // Dof-order <-> storage maps used by the plumbing kernels of mir_api.hip for BOTH step kernels

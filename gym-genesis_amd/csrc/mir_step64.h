@@ -38,6 +38,7 @@ struct StepArgs64 {
   int nu;       // action width (copy of the model's: the action load does not wait for the model)
   int mode;     // 0: full steps; 1: forward dynamics only; 2: kinematics + outputs only
   int n_steps;  // mode 0 only
+  int convex;   // the scene has sphere / capsule geoms (DevModel64.has_convex): instantiation with the convex narrowphase
   // Dispatch order of the single-step launch (nullable): cost_in[e] != 0 says env e was expensive in the previous step (blocks
   // coupled by a contact, or three and more Newton iterations); workgroup r then serves the r-th env of "expensive first" within
   // its chunk of 4096 envs instead of env r -- a launch ends with its slowest workgroup, and an expensive env that starts in the

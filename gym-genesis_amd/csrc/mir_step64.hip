@@ -36,7 +36,7 @@
 
 #define G 16
 #include "mir_dev.h"
-#include "mir_gj_dpp.h"
+#include "mir_convex.h"
 #define NL W64
 #define NB K64_MAX_BODY
 #define MAXC MIR_MAX_CONTACT
@@ -385,7 +385,10 @@ __device__ __forceinline__ void condot3(const Env64& S, int c, const float* x, f
 // wave 0 has the body poses -- runs the whole collision phase (geom poses, broadphase, plane-box, box-box, contact finish, per-block
 // lists) in its own scratch while wave 0 runs the dynamics up to the smooth solve; they meet before the Jacobian segments are
 // written, and wave 1 retires.  The register budget is held at 256 so that the four workgroups of a CU (LDS) are two waves per SIMD.
-template <int VARIANT>
+// CONVEX: the scene has sphere / capsule geoms (the Panda's links 1-7 in the reference's scenes are rounded link meshes: capsules
+// here, as in the 16-lane kernel): plane - sphere / capsule in closed form, every other pair that is not box - box through GJK on
+// the cores and MPR (mir_convex.h), lane = candidate pair.
+template <int VARIANT, bool CONVEX>
 __global__ __launch_bounds__(VARIANT == 0 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(VARIANT == 0 ? 2 : 1, VARIANT == 0 ? 2 : 1)))
 void mir_step64_kernel(StepArgs64 a) {
   constexpr bool SINGLE = VARIANT == 0;
@@ -563,16 +566,25 @@ void mir_step64_kernel(StepArgs64 a) {
           V3 h2 = ld3(&S.gts[g2][1]);
           M3 R2 = q2m(ld4v(S.col.gquat[g2]));
           V3 c2 = ld3v(S.col.gpos[g2]);
-          if ((__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE) {
+          const int t1 = __float_as_int(S.gts[g1][0]) & 255, t2 = __float_as_int(S.gts[g2][0]) & 255;
+          if (t1 == MIR_GEOM_PLANE) {
             V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
             float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
+            if (CONVEX && t2 == MIR_GEOM_SPHERE) ext = h2.x;
+            if (CONVEX && t2 == MIR_GEOM_CAPSULE) ext = h2.y * fabsf(dot(n, mcol(R2, 2))) + h2.x;
             hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
           } else {
             V3 h1 = ld3(&S.gts[g1][1]);
-            float rs = sqrtf(dot(h1, h1)) + sqrtf(dot(h2, h2));
+            // bounding spheres (box: half diagonal; sphere: radius; capsule: half length + radius)
+            float b1 = sqrtf(dot(h1, h1)), b2 = sqrtf(dot(h2, h2));
+            if (CONVEX) {
+              b1 = t1 == MIR_GEOM_SPHERE ? h1.x : (t1 == MIR_GEOM_CAPSULE ? h1.x + h1.y : b1);
+              b2 = t2 == MIR_GEOM_SPHERE ? h2.x : (t2 == MIR_GEOM_CAPSULE ? h2.x + h2.y : b2);
+            }
+            float rs = b1 + b2;
             V3 dc = c2 - ld3v(S.col.gpos[g1]);
             hit = dot(dc, dc) <= rs * rs;
-            if (hit) {
+            if (hit && (!CONVEX || (t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX))) {
               // the six face axes of the narrowphase's separating-axis test (same expressions): a pair they separate
               // would come back with zero contacts, and the narrowphase walks its candidates four at a time
               const M3 R1 = q2m(ld4v(S.col.gquat[g1]));
@@ -603,7 +615,8 @@ void mir_step64_kernel(StepArgs64 a) {
         const bool act = k < ncand;
         const int pr = act ? (int)S.pairs[S.col.cand[k]] : 0;
         const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isplane = act && (__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE;
+        const bool isplane = act && (__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE &&
+                             (!CONVEX || (__float_as_int(S.gts[g2][0]) & 255) == MIR_GEOM_BOX);
         if (!__any(isplane)) continue;
         const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
         const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
@@ -649,7 +662,8 @@ void mir_step64_kernel(StepArgs64 a) {
         const bool actk = k < ncand;
         const int pr = actk ? (int)S.pairs[S.col.cand[k]] : 0;
         const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isbox = actk && (__float_as_int(S.gts[g1][0]) & 255) != MIR_GEOM_PLANE;
+        const bool isbox = actk && (__float_as_int(S.gts[g1][0]) & 255) != MIR_GEOM_PLANE &&
+                           (!CONVEX || ((__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_BOX && (__float_as_int(S.gts[g2][0]) & 255) == MIR_GEOM_BOX));
         if (!__any(isbox)) continue;
         if (isbox) {  // whole rows
           const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
@@ -660,6 +674,47 @@ void mir_step64_kernel(StepArgs64 a) {
         }
       }
       WSYNC();
+      if constexpr (CONVEX) {
+        // narrowphase of the round shapes, LANE-PRIVATE: lane c takes candidate c (see mir_step.hip).  Lanes diverge here and
+        // reconverge at the end of the block.
+        if (lane < ncand) {
+          const int pr = (int)S.pairs[S.col.cand[lane]];
+          const int g1 = pr & 255, g2 = pr >> 8;
+          const int t1 = __float_as_int(S.gts[g1][0]) & 255, t2 = __float_as_int(S.gts[g2][0]) & 255;
+          if (t1 == MIR_GEOM_PLANE && (t2 == MIR_GEOM_SPHERE || t2 == MIR_GEOM_CAPSULE)) {
+            const V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2), pp = ld3v(S.col.gpos[g1]), pc = ld3v(S.col.gpos[g2]);
+            const V3 sz = ld3(&S.gts[g2][1]);
+            const float r = sz.x;
+            int cnt = 0;
+            if (t2 == MIR_GEOM_SPHERE) {
+              const float dist = dot(pc - pp, n) - r;
+              if (dist < 0.0f) { const V3 c = pc - (r + 0.5f * dist) * n; stv(S.col.stage[lane][0], f4{c.x, c.y, c.z, dist}); cnt = 1; }
+            } else {  // the two end spheres, axis - then axis +
+              const V3 ax = mcol(q2m(ld4v(S.col.gquat[g2])), 2);
+#pragma unroll
+              for (int sgn = -1; sgn <= 1; sgn += 2) {
+                const V3 e = pc + ((float)sgn * sz.y) * ax;
+                const float dist = dot(e - pp, n) - r;
+                if (dist < 0.0f) { const V3 c = e - (r + 0.5f * dist) * n; stv(S.col.stage[lane][cnt], f4{c.x, c.y, c.z, dist}); cnt++; }
+              }
+            }
+            if (cnt) st3v(S.col.snorm[lane], n);
+            S.col.ccount[lane] = cnt;
+          } else if (t1 != MIR_GEOM_PLANE && !(t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX)) {
+            const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
+            const ShapeD A = {t1, ld3(&S.gts[g1][1]), ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2)};
+            const ShapeD B = {t2, ld3(&S.gts[g2][1]), ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2)};
+            f4 pt;
+            V3 n;
+            if (convex_pair(A, B, pt, n)) {
+              stv(S.col.stage[lane][0], pt);
+              st3v(S.col.snorm[lane], n);
+              S.col.ccount[lane] = 1;
+            }
+          }
+        }
+        WSYNC();
+      }
       mycount = S.col.ccount[lane];
     }
     STAMP(8);
@@ -1727,8 +1782,14 @@ extern "C" int mir_launch_step64(const StepArgs64* args, hipStream_t stream) {
                       !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat;
   const bool plain_loop = a.mode == 0 && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
                           !a.env_state && !a.reward && !a.terminated && !a.term_host;
-  if (single) hipLaunchKernelGGL(mir_step64_kernel<0>, dim3(a.B), dim3(128), 0, stream, a);  // two waves per env
-  else if (plain_loop) hipLaunchKernelGGL(mir_step64_kernel<1>, dim3(a.B), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL(mir_step64_kernel<2>, dim3(a.B), dim3(64), 0, stream, a);
+  if (a.convex) {
+    if (single) hipLaunchKernelGGL((mir_step64_kernel<0, true>), dim3(a.B), dim3(128), 0, stream, a);  // two waves per env
+    else if (plain_loop) hipLaunchKernelGGL((mir_step64_kernel<1, true>), dim3(a.B), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((mir_step64_kernel<2, true>), dim3(a.B), dim3(64), 0, stream, a);
+  } else {
+    if (single) hipLaunchKernelGGL((mir_step64_kernel<0, false>), dim3(a.B), dim3(128), 0, stream, a);  // two waves per env
+    else if (plain_loop) hipLaunchKernelGGL((mir_step64_kernel<1, false>), dim3(a.B), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((mir_step64_kernel<2, false>), dim3(a.B), dim3(64), 0, stream, a);
+  }
   return (int)hipGetLastError();
 }

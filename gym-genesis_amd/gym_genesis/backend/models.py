@@ -81,7 +81,7 @@ def _capsule_of_box(half):
     return (r, max(half[k] - r, 0.0)), quat
 
 
-def _add_franka(sb: SceneBuilder, pos=(0.0, 0.0, 0.0), scale=1.0, frc=FRANKA_FRC_MJCF, link_shape="box") -> None:
+def _add_franka(sb: SceneBuilder, pos=(0.0, 0.0, 0.0), scale=1.0, frc=FRANKA_FRC_MJCF, link_shape="capsule") -> None:
     """The Panda (bodies, joints, collision boxes) mounted at `pos`, uniformly scaled like gs.morphs.MJCF(scale=...):
     lengths x s, masses x s^3, inertias x s^5, prismatic ranges x s; joint-level constants (armature, damping,
     PD gains, force ranges) and revolute ranges unchanged.  `frc`: per-joint force limits (the MJCF defaults unless the task
@@ -220,13 +220,15 @@ def _stack_common(sb: SceneBuilder, friction=1.0) -> None:
     sb.opt["max_contacts"] = MIR_MAX_CONTACT  # five resting cubes alone are 20 contact points
 
 
-def franka_cube_stack_scene() -> SceneBuilder:
+def franka_cube_stack_scene(link_shape="capsule") -> SceneBuilder:
     """build_house (utils.py:239-426): Panda MJCF at (-0.5, 0, 0.7), scale 0.6 (:370-377); PD gains / force ranges as
-    reset() sets them (cube_stack_kitchen_batch.py:101-106) -- the same arrays the pick scene uses."""
+    reset() sets them (cube_stack_kitchen_batch.py:101-106) -- the same arrays the pick scene uses.  The SAME Panda as in the pick
+    scene: links 1-7 are capsules (`link_shape="box"` restores the box links the stack scenes had before the wave kernel learnt
+    the round geoms)."""
     sb = SceneBuilder()
     sb.add_geom(0, GEOM_PLANE)                                                        # kitchen floor, z = 0
     sb.add_geom(0, GEOM_BOX, size=(0.915, 0.401, 0.05), pos=(0.0, 0.0, ISLAND_TOP_Z - 0.05), rgb=(0.75, 0.72, 0.68))
-    _add_franka(sb, pos=(-0.5, 0.0, 0.7), scale=0.6, frc=FRANKA_FRC)  # set explicitly by the task
+    _add_franka(sb, pos=(-0.5, 0.0, 0.7), scale=0.6, frc=FRANKA_FRC, link_shape=link_shape)  # set explicitly by the task
     _stack_common(sb)
     sb.task = dict(eef_body=sb.body_index("hand"), obj_body=sb.body_index("cube_1"), obj2_body=sb.body_index("cube_2"),
                    grip_dof=(sb.dof_index("finger_joint1"), sb.dof_index("finger_joint2")), reward_z=0.1,

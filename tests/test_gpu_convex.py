@@ -138,19 +138,49 @@ def test_dropped_bodies_settle_like_the_oracle(pair):
     assert np.abs(qh[:, 2] - qo[:, 2]).max() < 2e-3 and np.abs(qh[:, 9] - qo[:, 9]).max() < 2e-3   # resting heights
 
 
-def test_round_geoms_need_the_16_lane_kernel():
-    """The wave-per-env kernel (five-cube stack scenes) takes planes and boxes only: a scene too large for the 16-lane kernel
-    that contains a capsule is refused with a clear message instead of being simulated with the wrong shape."""
-    from gym_genesis.backend.lib import MirError
-
+def test_round_geoms_on_the_wave_kernel_settle_like_the_oracle():
+    """The wave-per-env kernel (scenes beyond 15 dofs: the five-cube stack tasks) carries the same convex narrowphase since round 3:
+    four free bodies (24 dofs) -- sphere, capsule, box, capsule -- dropped from random poses on the plane and on a static box, free
+    running for 120 steps against the oracle.  Plane - sphere / capsule in closed form, capsule - box and sphere - box through GJK
+    on the cores, MPR when a core dips into the box."""
     sb = S.SceneBuilder()
     sb.add_geom(0, S.GEOM_PLANE)
-    for i in range(3):  # 18 dofs > 15
-        sb.add_body(f"c{i}", 0, pos=(0.2 * i, 0, 0.1), jtype=S.JNT_FREE, mass=0.1, inertia=S.capsule_inertia(0.1, 0.02, 0.05))
-        sb.add_geom(f"c{i}", S.GEOM_CAPSULE, size=(0.02, 0.05, 0.0))
+    sb.add_geom(0, S.GEOM_BOX, size=(0.4, 0.15, 0.05), pos=(0.0, 0.0, 0.05))
+    kinds = ("sphere", "capsule", "box", "capsule")
+    for i, kind in enumerate(kinds):
+        t, size = SHAPES[kind]
+        sb.add_body(f"b{i}", 0, pos=(0.0, 0.0, 0.5), jtype=S.JNT_FREE, mass=0.3, inertia=_inertia(kind, 0.3))
+        sb.add_geom(f"b{i}", t, size=tuple(size) + (0.0,) * (3 - len(size)))
     sb.task = dict(eef_body=1, obj_body=2, grip_dof=(), reward_z=0.1)
-    with pytest.raises(MirError, match="unsupported geom type"):
-        _mir(sb.build(), 4)
+    spec = sb.build()
+    B = 64
+    sc, o = _mir(spec, B), orc.Oracle(spec, B)
+    assert sc.kernel == 64
+    rng = np.random.default_rng(11)
+    pos = np.zeros((B, 4, 3), np.float32)
+    pos[:, 0] = rng.uniform(-0.04, 0.04, (B, 3)) + [-0.25, 0.0, 0.22]   # sphere above the static box
+    pos[:, 1] = rng.uniform(-0.04, 0.04, (B, 3)) + [0.0, 0.0, 0.24]     # capsule above the static box
+    pos[:, 2] = rng.uniform(-0.04, 0.04, (B, 3)) + [0.25, 0.0, 0.22]    # box above the static box
+    pos[:, 3] = rng.uniform(-0.04, 0.04, (B, 3)) + [0.0, 0.6, 0.12]     # capsule above the bare plane
+    quat = np.stack([_rand_quat(rng, B) for _ in range(4)], 1).astype(np.float32)
+    arm = np.zeros((B, 0), np.float32)
+    sc.reset(pos, quat, arm)
+    o.reset(pos, quat, arm)
+    bufs = (sc.empty(sc.agent_dim), sc.empty(sc.env_dim), sc.empty(), sc.empty(dtype=torch.uint8))
+    for t in range(120):
+        sc.step_fused(None, *bufs)
+        o.step_batch(None)
+        if t == 20:
+            early = np.abs(sc.get_state()[0].cpu().numpy() - o.state()[0]).max()
+    qh, qo = sc.get_state()[0].cpu().numpy(), o.state()[0]
+    cols = [7 * k + c for k in range(4) for c in range(3)]
+    err = np.abs(qh - qo)[:, cols].max(1)
+    ncon = sc.get_diag()[0].cpu().numpy()
+    print(f"wave kernel, round geoms: after 21 steps L-inf {early:.2e}; after 120 steps position err median {np.median(err):.2e}, max {err.max():.2e}; contacts {ncon.min()}..{ncon.max()}")
+    assert early < 1e-5
+    assert np.median(err) < 1e-4 and err.max() < 5e-3
+    assert (ncon >= 3).all()
+    assert np.abs(qh[:, [2, 9, 16, 23]] - qo[:, [2, 9, 16, 23]]).max() < 2e-3   # resting heights
 
 
 def _device_pairs(rows):

@@ -340,7 +340,7 @@ def test_scripted_grasp_lifts_cube_and_reward_flips_at_threshold():
             a, e, r, term = o.get_obs()
             assert np.array_equal(r == 1, np.float32(e[:, 2]) > np.float32(0.1)) and np.array_equal(term.astype(bool), r == 1)
             flipped |= r == 1
-            # line search: phi' is resolved to the evaluation's own rounding floor, not bisected beyond it:
+            # line search: phi' is resolved to the evaluation's own rounding floor, not bisected beyond it (NOTEBOOK.md section 2, item 5):
             # a handful of evaluations per Newton iteration even with a dozen stiff contact rows
             assert max(o.read(orc.F_DBG_LS, i).max(initial=0) for i in range(B)) <= 16
         if name == "close":
@@ -461,7 +461,7 @@ def test_contact_jacobian_matches_finite_differences_of_the_kinematics():
                 ax = np.zeros(3)
                 ax[r - 3] = 1.0
                 dq = np.array([np.cos(eps / 2), *(np.sin(eps / 2) * ax)])
-                q[qa + 3:qa + 7] = qmul(dq, q[qa + 3:qa + 7])  # world-frame angular velocity (DESIGN.md 2.6)
+                q[qa + 3:qa + 7] = qmul(dq, q[qa + 3:qa + 7])  # world-frame angular velocity (DESIGN.md section 2, item 6)
         o.write(orc.F_QPOS, q)
         o.fk()
         xp, xq = o.read(orc.F_XPOS).reshape(-1, 3), o.read(orc.F_XQUAT).reshape(-1, 4)
