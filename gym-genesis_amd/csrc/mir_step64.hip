@@ -584,6 +584,18 @@ void mir_step64_kernel(StepArgs64 a) {
             float rs = b1 + b2;
             V3 dc = c2 - ld3v(S.col.gpos[g1]);
             hit = dot(dc, dc) <= rs * rs;
+            if (CONVEX && hit && (t1 == MIR_GEOM_BOX) != (t2 == MIR_GEOM_BOX)) {
+              // one box, one round geom: the round geom's bounding sphere against the BOX itself (clamped distance in the box frame),
+              // not against the box's bounding sphere -- the kitchen slab's is a metre wide and every link near it would run GJK
+              const bool box1 = t1 == MIR_GEOM_BOX;
+              const M3 Rb = box1 ? q2m(ld4v(S.col.gquat[g1])) : R2;
+              const V3 hb = box1 ? h1 : h2;
+              const V3 dd = box1 ? dc : v3(-dc.x, -dc.y, -dc.z);  // round centre - box centre
+              const float br = box1 ? b2 : b1;
+              const float ex = fmaxf(fabsf(dot(dd, mcol(Rb, 0))) - hb.x, 0.0f), ey = fmaxf(fabsf(dot(dd, mcol(Rb, 1))) - hb.y, 0.0f),
+                          ez = fmaxf(fabsf(dot(dd, mcol(Rb, 2))) - hb.z, 0.0f);
+              hit = ex * ex + ey * ey + ez * ez <= br * br;
+            }
             if (hit && (!CONVEX || (t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX))) {
               // the six face axes of the narrowphase's separating-axis test (same expressions): a pair they separate
               // would come back with zero contacts, and the narrowphase walks its candidates four at a time
