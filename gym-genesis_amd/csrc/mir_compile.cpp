@@ -361,8 +361,15 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
   for (int g = 0; g < sp->ngeom; g++) {
     const MirGeomSpec& s = sp->geom[g];
     if (s.body < 0 || s.body >= nb) return fail(err, MIR_E_INVALID, "geom body out of range");
-    if (s.type != MIR_GEOM_PLANE && s.type != MIR_GEOM_BOX && s.type != MIR_GEOM_SPHERE && s.type != MIR_GEOM_CAPSULE)
+    if (s.type != MIR_GEOM_PLANE && s.type != MIR_GEOM_BOX && s.type != MIR_GEOM_SPHERE && s.type != MIR_GEOM_CAPSULE && s.type != MIR_GEOM_HULL)
       return fail(err, MIR_E_INVALID, "unsupported geom type");
+    if (s.type == MIR_GEOM_HULL) {
+      const int v0 = (int)s.size[0], nvg = (int)s.size[1];
+      if (v0 < 0 || nvg < 4 || nvg > MIR_MAX_HULL_VERT || v0 + nvg > sp->nvert || sp->nvert > MIR_MAX_VERT)
+        return fail(err, MIR_E_INVALID, "hull geom: vertex range outside the scene's vertex pool (4 .. MIR_MAX_HULL_VERT vertices)");
+      if (sp->nvert > K16_MAX_VERT) return fail(err, MIR_E_CAPACITY, "more hull vertices than the 16-lane kernel keeps in LDS (K16_MAX_VERT)");
+      m.has_convex = 1;
+    }
     if ((s.type == MIR_GEOM_SPHERE || s.type == MIR_GEOM_CAPSULE) && !(s.size[0] > 0)) return fail(err, MIR_E_INVALID, "sphere / capsule radius must be > 0");
     if (s.type == MIR_GEOM_CAPSULE && !(s.size[1] >= 0)) return fail(err, MIR_E_INVALID, "capsule half length must be >= 0");
     if (s.type == MIR_GEOM_SPHERE || s.type == MIR_GEOM_CAPSULE) m.has_convex = 1;
@@ -372,6 +379,11 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     m.g_friction[g] = (float)s.friction;
     for (int k = 0; k < 2; k++) m.g_solref[g][k] = (float)s.solref[k];
     for (int k = 0; k < 5; k++) m.g_solimp[g][k] = (float)s.solimp[k];
+  }
+  m.nvert = sp->nvert > 0 && sp->nvert <= K16_MAX_VERT ? sp->nvert : 0;
+  for (int i = 0; i < m.nvert; i++) {
+    for (int k = 0; k < 3; k++) m.hverts[i][k] = (float)sp->vert[i][k];
+    m.hverts[i][3] = 0.0f;
   }
   int np = 0;
   uint32_t allow[K16_MAX_GEOM] = {0};
@@ -425,6 +437,15 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     {  // bounding radius about the geom centre
       const float* z = m.g_size[g];
       t.g_size[g][3] = m.g_type[g] == MIR_GEOM_SPHERE ? z[0] : (m.g_type[g] == MIR_GEOM_CAPSULE ? z[0] + z[1] : sqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]));
+      if (m.g_type[g] == MIR_GEOM_HULL) {  // farthest vertex from the geom frame's origin; bounding box for the rasteriser
+        float r2 = 0.0f;
+        for (int i = (int)z[0]; i < (int)z[0] + (int)z[1]; i++) {
+          const float* v = m.hverts[i];
+          r2 = fmaxf(r2, v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+          for (int k = 0; k < 3; k++) m.g_bbox[g][k] = fmaxf(m.g_bbox[g][k], fabsf(v[k]));
+        }
+        t.g_size[g][3] = sqrtf(r2);
+      }
     }
     for (int k = 0; k < 4; k++) t.g_quat[g][k] = m.g_quat[g][k];
     t.g_info[g][0] = m.g_body[g]; t.g_info[g][1] = m.g_type[g];

@@ -21,9 +21,25 @@ namespace {
 struct ShapeD {
   int type;
   V3 size, pos, a0, a1, a2;  // a* = columns of the rotation (the geom's axes in the world)
+  const float* verts;        // MIR_GEOM_HULL: the hull's vertices (rows of 4 floats, geom frame; LDS in the kernel), else unused
+  int nvert;
 };
 
+// hull: the vertex of largest projection on d, lowest index on ties (the oracle's hull_support), in world coordinates
+__device__ __forceinline__ V3 hull_support(const ShapeD& s, V3 d) {
+  const V3 dl = v3(dot(d, s.a0), dot(d, s.a1), dot(d, s.a2));
+  V3 best = v3(s.verts[0], s.verts[1], s.verts[2]);
+  float bv = dot(best, dl);
+  for (int i = 1; i < s.nvert; i++) {
+    const V3 v = v3(s.verts[4 * i], s.verts[4 * i + 1], s.verts[4 * i + 2]);
+    const float pv = dot(v, dl);
+    if (pv > bv) { bv = pv; best = v; }
+  }
+  return s.pos + best.x * s.a0 + best.y * s.a1 + best.z * s.a2;
+}
+
 __device__ __forceinline__ V3 core_support(const ShapeD& s, V3 d) {  // farthest point of the CORE along d (any length)
+  if (s.type == MIR_GEOM_HULL) return hull_support(s, d);  // (a hull is its own core, radius 0)
   V3 o = s.pos;
   if (s.type == MIR_GEOM_CAPSULE) {
     o = o + (dot(d, s.a2) >= 0.0f ? s.size.y : -s.size.y) * s.a2;
@@ -35,6 +51,7 @@ __device__ __forceinline__ V3 core_support(const ShapeD& s, V3 d) {  // farthest
   return o;
 }
 __device__ __forceinline__ V3 shape_support(const ShapeD& s, V3 d) {  // farthest point of the shape along the UNIT direction d
+  if (s.type == MIR_GEOM_HULL) return hull_support(s, d);
   V3 o = s.pos;
   if (s.type == MIR_GEOM_SPHERE) {
     o = o + s.size.x * d;
@@ -48,7 +65,7 @@ __device__ __forceinline__ V3 shape_support(const ShapeD& s, V3 d) {  // farthes
   }
   return o;
 }
-__device__ __forceinline__ float core_radius(const ShapeD& s) { return s.type == MIR_GEOM_BOX ? 0.0f : s.size.x; }
+__device__ __forceinline__ float core_radius(const ShapeD& s) { return (s.type == MIR_GEOM_BOX || s.type == MIR_GEOM_HULL) ? 0.0f : s.size.x; }
 __device__ __forceinline__ V3 neg(V3 a) { return {-a.x, -a.y, -a.z}; }
 __device__ __forceinline__ bool unit(V3& d) {  // normalise in place; false if (numerically) zero
   const float l2 = dot(d, d);

@@ -20,6 +20,7 @@
 #define K16_MAX_GEOM 24
 #define K16_MAX_PAIR 64
 #define K16_MAX_CONTACT 16
+#define K16_MAX_VERT 40 /* hull vertices the 16-lane kernel keeps in LDS beside the model table (what is left of its 40 KB per workgroup) */
 
 static_assert(K16_MAX_BODY <= MIR_G && K16_MAX_DOF <= MIR_G, "lane ownership needs nbody, nv <= group width");
 static_assert(K16_MAX_GEOM <= 2 * MIR_G, "two geoms per lane");
@@ -106,6 +107,9 @@ struct DevModel {
   int32_t gj_split;    // first dof of the second kinematic tree when the model has exactly two trees with dofs and that dof is 6 or 9
                        // (the block-diagonal eliminations instantiated in mir_dev.h), else 0 = dense
   int32_t use_sap;     // candidate pairs from the sweep-and-prune over AABBs (static list too long, or MIR_BROADPHASE=sap)
+  int32_t nvert;       // hull vertices in use (MIR_GEOM_HULL geoms: g_size = first vertex, count, -)
+  float hverts[K16_MAX_VERT][4];  // the scene's hull vertex pool, geom frames (16-byte rows: copied into LDS by the convex instantiations)
+  float g_bbox[K16_MAX_GEOM][3];  // hull geoms: half extents of the vertices' bounding box (what the rasteriser draws)
 };
 
 struct HostConsts {

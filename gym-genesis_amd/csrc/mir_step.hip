@@ -126,7 +126,7 @@ struct EnvLds {
   };
 };
 static_assert(sizeof(ContactArrays) <= sizeof(DynScratch), "the contact arrays must not reach the collision staging area");
-static_assert(EPB * sizeof(EnvLds) + sizeof(ModelTab) <= 40960, "four workgroups per CU: 160 KB of LDS / 4");
+static_assert(EPB * sizeof(EnvLds) + sizeof(ModelTab) + K16_MAX_VERT * 16 <= 40960, "four workgroups per CU: 160 KB of LDS / 4 (hull vertices included)");
 
 // body-lane constants needed by forward kinematics
 struct BodyK {
@@ -248,6 +248,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   constexpr bool CONVEX = (FEAT & 1) != 0, SAP = (FEAT & 2) != 0;
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
   __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
+  // hull vertices (MIR_GEOM_HULL), convex instantiations only: what is left of the workgroup's 40 KB
+  __shared__ __attribute__((aligned(16))) float s_hull[(FEAT & 1) ? K16_MAX_VERT : 1][4];
   const DevModel* __restrict__ m = a.model;
   const int tid = threadIdx.x & 63;   // lane within the wave
   const int wave = threadIdx.x >> 6;  // 0 = main wave; 1 = collision wave (DUAL only)
@@ -268,6 +270,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
 #pragma unroll
     for (int k = 0; k < TAB_NPASS; k++) tabtmp[k] = src[min(tid + 64 * k, TAB_NQ - 1)];
   }
+  f4 hulltmp = {0, 0, 0, 0};
+  if ((FEAT & 1) && wave == 0) hulltmp = reinterpret_cast<const f4*>(&m->hverts[0][0])[min(tid, K16_MAX_VERT - 1)];
   const int lane = tid & (G - 1);
   const int row4 = (tid & ~(G - 1)) << 2;  // byte offset of this env's first lane in the wave (lane_gather)
   const int grp = tid >> 4;
@@ -321,6 +325,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         if (tg == MIR_GEOM_BOX) e = v3(fabsf(R.r0.x) * hz.x + fabsf(R.r0.y) * hz.y + fabsf(R.r0.z) * hz.z, fabsf(R.r1.x) * hz.x + fabsf(R.r1.y) * hz.y + fabsf(R.r1.z) * hz.z,
                                        fabsf(R.r2.x) * hz.x + fabsf(R.r2.y) * hz.y + fabsf(R.r2.z) * hz.z);
         else if (tg == MIR_GEOM_CAPSULE) e = v3(fabsf(R.r0.z) * hz.y + hz.x, fabsf(R.r1.z) * hz.y + hz.x, fabsf(R.r2.z) * hz.y + hz.x);
+        else if (tg == MIR_GEOM_HULL) e = v3(T.g_size[g][3], T.g_size[g][3], T.g_size[g][3]);  // (bounding sphere)
         stv(S.col.sap.lo[g], f4{c.x - e.x, c.y - e.y, c.z - e.z, __int_as_float(tg)});
         stv(S.col.sap.hi[g], f4{c.x + e.x, c.y + e.y, c.z + e.z, 0.0f});
         S.col.sap.hitrow[g] = 0u;
@@ -403,6 +408,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
           float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
           if (CONVEX && t2 == MIR_GEOM_SPHERE) ext = h2.x;
           if (CONVEX && t2 == MIR_GEOM_CAPSULE) ext = h2.y * fabsf(dot(n, mcol(R2, 2))) + h2.x;
+          if (CONVEX && t2 == MIR_GEOM_HULL) ext = T.g_size[g2][3];  // (bounding sphere)
           hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
         } else {
           V3 h1 = ld3v(T.g_size[g1]);
@@ -523,10 +529,44 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
           }
           if (cnt) st3v(S.col.snorm[lane], n);
           mycount = cnt;
+        } else if (t1 == MIR_GEOM_PLANE && t2 == MIR_GEOM_HULL) {
+          // plane - hull: the penetrating vertices in index order, reduced to four like plane - box (support extremes, first
+          // index wins ties; oracle: plane_hull / reduce4).  Two passes over the vertices, lane-private.
+          const M3 Rp = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
+          const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1), pp = ld3v(S.col.gpos[g1]), pc = ld3v(S.col.gpos[g2]);
+          const int v0 = (int)T.g_size[g2][0], nvg = (int)T.g_size[g2][1];
+          int npen = 0, pk0 = -1, pk1 = -1, pk2 = -1, pk3 = -1;
+          float uM = 0.0f, um = 0.0f, vM = 0.0f, vm = 0.0f;
+          for (int i = 0; i < nvg; i++) {
+            const V3 l = ld3v(s_hull[v0 + i]);
+            const V3 rel = pc + l.x * mcol(R2, 0) + l.y * mcol(R2, 1) + l.z * mcol(R2, 2) - pp;
+            if (dot(rel, n) < 0.0f) {
+              const float u = dot(rel, eu), v = dot(rel, ev);
+              if (npen == 0 || u > uM) { uM = u; pk0 = i; }
+              if (npen == 0 || u < um) { um = u; pk1 = i; }
+              if (npen == 0 || v > vM) { vM = v; pk2 = i; }
+              if (npen == 0 || v < vm) { vm = v; pk3 = i; }
+              npen++;
+            }
+          }
+          int cnt = 0;
+          for (int i = 0; i < nvg && cnt < 4; i++) {
+            const V3 l = ld3v(s_hull[v0 + i]);
+            const V3 w = pc + l.x * mcol(R2, 0) + l.y * mcol(R2, 1) + l.z * mcol(R2, 2);
+            const float d = dot(w - pp, n);
+            if (d < 0.0f && (npen <= 4 || i == pk0 || i == pk1 || i == pk2 || i == pk3)) {
+              const V3 c = w - (0.5f * d) * n;
+              stv(S.col.stage[lane][cnt], f4{c.x, c.y, c.z, d});
+              cnt++;
+            }
+          }
+          if (cnt) st3v(S.col.snorm[lane], n);
+          mycount = cnt;
         } else if (t1 != MIR_GEOM_PLANE && !(t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX)) {
           const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
-          const ShapeD A = {t1, ld3v(T.g_size[g1]), ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2)};
-          const ShapeD B = {t2, ld3v(T.g_size[g2]), ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2)};
+          const V3 z1 = ld3v(T.g_size[g1]), z2 = ld3v(T.g_size[g2]);
+          const ShapeD A = {t1, z1, ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), &s_hull[t1 == MIR_GEOM_HULL ? (int)z1.x : 0][0], (int)z1.y};
+          const ShapeD B = {t2, z2, ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), &s_hull[t2 == MIR_GEOM_HULL ? (int)z2.x : 0][0], (int)z2.y};
           f4 pt;
           V3 n;
           if (convex_pair(A, B, pt, n)) {
@@ -908,6 +948,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
 #pragma unroll
     for (int k = 0; k < TAB_NPASS; k++)
       if (tid + 64 * k < TAB_NQ) dst[tid + 64 * k] = tabtmp[k];
+    if ((FEAT & 1) && tid < K16_MAX_VERT) stv(s_hull[tid], hulltmp);
   }
   if (!DUAL || ROT) {
     if (lane < a.qst) S.qpos[lane] = q_lo;
@@ -1751,8 +1792,8 @@ __global__ void k_debug_convex(const float* __restrict__ in, float* __restrict__
   if (i >= n) return;
   const float* r = in + (size_t)i * 22;
   const M3 R1 = q2m(qnormalize(Q4{r[7], r[8], r[9], r[10]})), R2 = q2m(qnormalize(Q4{r[18], r[19], r[20], r[21]}));
-  const ShapeD A = {(int)r[0], v3(r[1], r[2], r[3]), v3(r[4], r[5], r[6]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2)};
-  const ShapeD B = {(int)r[11], v3(r[12], r[13], r[14]), v3(r[15], r[16], r[17]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2)};
+  const ShapeD A = {(int)r[0], v3(r[1], r[2], r[3]), v3(r[4], r[5], r[6]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), nullptr, 0};
+  const ShapeD B = {(int)r[11], v3(r[12], r[13], r[14]), v3(r[15], r[16], r[17]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), nullptr, 0};
   f4 pt = {0, 0, 0, 0};
   V3 nrm = v3(0, 0, 0);
   const bool hit = convex_pair(A, B, pt, nrm);

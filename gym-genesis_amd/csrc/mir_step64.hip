@@ -714,8 +714,8 @@ void mir_step64_kernel(StepArgs64 a) {
             S.col.ccount[lane] = cnt;
           } else if (t1 != MIR_GEOM_PLANE && !(t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX)) {
             const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
-            const ShapeD A = {t1, ld3(&S.gts[g1][1]), ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2)};
-            const ShapeD B = {t2, ld3(&S.gts[g2][1]), ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2)};
+            const ShapeD A = {t1, ld3(&S.gts[g1][1]), ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), nullptr, 0};
+            const ShapeD B = {t2, ld3(&S.gts[g2][1]), ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), nullptr, 0};
             f4 pt;
             V3 n;
             if (convex_pair(A, B, pt, n)) {
@@ -1224,7 +1224,6 @@ void mir_step64_kernel(StepArgs64 a) {
     // Everything of the warm start that does not need the contacts, ahead of the meeting with the collision wave (this wave
     // arrives there first): the Gauss term of the warm-start candidate and Mt times either candidate.
     const float* xblk_srch = &S.srch[16 * blk];
-    const float* xblk_qacc = &S.qacc[16 * blk];
     const float ws = S.qacc_ws[lane];
     const float dq = isdof ? ws - qas : 0.0f;
     S.srch[lane] = dq;

@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .spec import IK_DEFAULTS, MirCameraSpec, MirDims, MirIkOptions, MirSceneSpec, MirVisualSpec
+from .spec import IK_DEFAULTS, MIR_VERSION, MirCameraSpec, MirDims, MirIkOptions, MirSceneSpec, MirVisualSpec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libmirigid.so"))
@@ -90,7 +90,7 @@ def load_library() -> C.CDLL:
                  "mir_step", "mir_step_fused", "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links",
                  "mir_get_diag", "mir_forward"):
         getattr(lib, name).restype = C.c_int
-    if lib.mir_spec_sizeof() != C.sizeof(MirSceneSpec) or lib.mir_version() != 2 or lib.mir_visual_sizeof() != C.sizeof(MirVisualSpec):
+    if lib.mir_spec_sizeof() != C.sizeof(MirSceneSpec) or lib.mir_version() != MIR_VERSION or lib.mir_visual_sizeof() != C.sizeof(MirVisualSpec):
         raise MirError("libmirigid.so ABI mismatch with gym_genesis.backend.spec (rebuild the library)")
     _lib = lib
     _bind_fast(lib)

@@ -10,7 +10,7 @@ import ctypes as C
 import math
 from typing import List, Optional, Sequence
 
-MIR_VERSION = 2
+MIR_VERSION = 3
 MIR_MAX_BODY = 32
 MIR_MAX_DOF = 48
 MIR_MAX_Q = 56
@@ -26,6 +26,8 @@ AGENT_EEF, AGENT_QPOS = 0, 1
 
 JNT_FIXED, JNT_REVOLUTE, JNT_PRISMATIC, JNT_FREE = 0, 1, 2, 3
 GEOM_PLANE, GEOM_BOX, GEOM_SPHERE, GEOM_CAPSULE = 0, 1, 2, 3  # sphere: size = (radius,); capsule: (radius, half length), axis z
+GEOM_HULL = 4  # convex hull of the vertices given to add_geom(vertices=...), geom frame, origin inside the hull
+MIR_MAX_HULL_VERT, MIR_MAX_VERT = 32, 96
 CTRL_NONE, CTRL_POSITION = 0, 1
 
 DEFAULT_SOLREF = (0.02, 1.0)
@@ -121,6 +123,9 @@ class MirSceneSpec(C.Structure):
         ("body", MirBodySpec * MIR_MAX_BODY),
         ("dof", MirDofSpec * MIR_MAX_DOF),
         ("geom", MirGeomSpec * MIR_MAX_GEOM),
+        ("nvert", C.c_int32),
+        ("_pad2", C.c_int32),
+        ("vert", (C.c_double * 3) * MIR_MAX_VERT),
     ]
 
 
@@ -193,6 +198,26 @@ def quat_normalize(q: Sequence[float]) -> tuple:
     return tuple(x / n for x in q)
 
 
+def box_hull_vertices(half: Sequence[float]) -> list:
+    """The 8 corners of a box as hull vertices, in the corner order of the plane - box narrowphase (bit 0 = +x, bit 1 = +y,
+    bit 2 = +z): a GEOM_HULL of these reproduces the GEOM_BOX contact points."""
+    return [((1 if c & 1 else -1) * half[0], (1 if c & 2 else -1) * half[1], (1 if c & 4 else -1) * half[2]) for c in range(8)]
+
+
+def icosphere_vertices(radius: float, level: int = 0) -> list:
+    """Vertices on the sphere of `radius`: the icosahedron's 12 (level 0), or those plus its 20 face centres pushed out to the
+    sphere (level 1: 32 vertices = MIR_MAX_HULL_VERT, the pentakis dodecahedron)."""
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    norm = lambda p: tuple(radius * c / (p[0] ** 2 + p[1] ** 2 + p[2] ** 2) ** 0.5 for c in p)  # noqa: E731
+    out = [norm(p) for p in v]
+    if level >= 1:
+        out += [norm(tuple(v[a][i] + v[b][i] + v[c][i] for i in range(3))) for a, b, c in f]
+    return out
+
+
 def box_inertia(mass: float, half: Sequence[float]) -> tuple:
     """Solid-box inertia about its centre, (xx, yy, zz, xy, xz, yz)."""
     x, y, z = (2 * h for h in half)
@@ -225,6 +250,7 @@ class SceneBuilder:
                                         axis=(0, 0, 1), mass=0.0, ipos=(0, 0, 0), inertia=(0,) * 6)]
         self.dofs: List[dict] = []
         self.geoms: List[dict] = []
+        self.verts: List[tuple] = []   # vertex pool of the GEOM_HULL geoms
         self.dof_names: List[str] = []
         self.opt = dict(dt=0.01, gravity=(0.0, 0.0, -9.81), tolerance=1e-8, ls_tolerance=0.01, iterations=50,
                         ls_iterations=50, enable_collision=1, enable_joint_limit=1, enable_self_collision=0,
@@ -261,8 +287,16 @@ class SceneBuilder:
     # -- geoms ------------------------------------------------------------------------------
     def add_geom(self, body: str | int, gtype: int, size=(0, 0, 0), pos=(0, 0, 0), quat=(1, 0, 0, 0),
                  friction=1.0, contype=1, conaffinity=1, solref=DEFAULT_SOLREF, solimp=DEFAULT_SOLIMP,
-                 rgb=(0.8, 0.8, 0.8)) -> int:
+                 rgb=(0.8, 0.8, 0.8), vertices=None) -> int:
         bidx = body if isinstance(body, int) else self.body_index(body)
+        if gtype == GEOM_HULL:
+            verts = [tuple(float(c) for c in v) for v in vertices]
+            if not 4 <= len(verts) <= MIR_MAX_HULL_VERT:
+                raise ValueError("a hull geom takes 4 .. MIR_MAX_HULL_VERT vertices")
+            if len(self.verts) + len(verts) > MIR_MAX_VERT:
+                raise ValueError("scene exceeds MIR_MAX_VERT hull vertices")
+            size = (float(len(self.verts)), float(len(verts)), 0.0)
+            self.verts.extend(verts)
         self.geoms.append(dict(body=bidx, type=gtype, size=tuple(size), pos=tuple(pos), quat=quat_normalize(quat),
                                friction=float(friction), contype=contype, conaffinity=conaffinity,
                                solref=tuple(solref), solimp=tuple(solimp), rgb=tuple(rgb)))
@@ -323,4 +357,7 @@ class SceneBuilder:
             sg.size[:], sg.pos[:], sg.quat[:] = g["size"], g["pos"], g["quat"]
             sg.friction = g["friction"]
             sg.solref[:], sg.solimp[:] = g["solref"], g["solimp"]
+        s.nvert = len(self.verts)
+        for i, v in enumerate(self.verts):
+            s.vert[i][:] = v
         return s

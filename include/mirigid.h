@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MIR_VERSION 2
+#define MIR_VERSION 3
 
 /* capacity limits of the spec.  Two step kernels sit behind the ABI: scenes with nv <= 15, nbody <= 16,
  * ngeom <= 24, <= 64 candidate pairs and max_contacts <= 16 (the pick tasks) run on the 16-lanes-per-env kernel
@@ -55,6 +55,8 @@ extern "C" {
 #define MIR_MAX_CONTACT 48 /* contacts kept per env per step (plane-box <= 4, box-box <= 8 per pair) */
 #define MIR_MAX_GRIP 4
 #define MIR_MAX_FREE 8     /* free bodies (cubes) */
+#define MIR_MAX_HULL_VERT 32 /* vertices of one MIR_GEOM_HULL geom */
+#define MIR_MAX_VERT 96      /* the scene's vertex pool */
 
 /* error codes */
 #define MIR_OK 0
@@ -74,6 +76,12 @@ extern "C" {
 #define MIR_GEOM_BOX 1   /* size = half extents */
 #define MIR_GEOM_SPHERE 2  /* size[0] = radius */
 #define MIR_GEOM_CAPSULE 3 /* size[0] = radius, size[1] = half length of the axis segment, axis = z of the geom frame */
+#define MIR_GEOM_HULL 4    /* convex hull of size[1] vertices of the scene's pool starting at vertex size[0] (MirSceneSpec.vert, geom
+                            * frame; the frame's origin must lie inside the hull: MPR starts from it); size[2] is ignored.  The
+                            * stand-in for the reference's mesh collision geometry (convex hulls of link meshes).  Support mapping
+                            * = the vertex of largest projection, lowest index on ties.  Plane - hull: the penetrating vertices,
+                            * reduced to four like plane - box; every other pair through GJK on the cores (the hull is its own core,
+                            * radius 0) and MPR.  16-lane kernel only. */
 /* Narrowphase by pair type: plane-box / plane-sphere / plane-capsule in closed form (<= 4 / 1 / 2 points), box-box by
  * separating axes and face clipping (<= 8 points), every other convex pair by Minkowski Portal Refinement on the shapes'
  * support mappings (one point: deepest penetration) -- the default convex-convex path of Genesis.
@@ -166,6 +174,8 @@ typedef struct MirSceneSpec {
   MirBodySpec body[MIR_MAX_BODY];
   MirDofSpec dof[MIR_MAX_DOF]; /* in body order: 1 per REVOLUTE/PRISMATIC, 6 per FREE */
   MirGeomSpec geom[MIR_MAX_GEOM];
+  int32_t nvert, _pad2;
+  double vert[MIR_MAX_VERT][3]; /* vertex pool of the MIR_GEOM_HULL geoms, geom frame */
 } MirSceneSpec;
 
 typedef struct MirScene* MirHandle;

@@ -75,6 +75,12 @@ int orc_render_image(const MirSceneSpec* spec, const MirCameraSpec* cam, const M
       /* round geoms are drawn as their bounding boxes, as the kernel does (mir_render.hip: k_render_setup) */
       if (gs->type == MIR_GEOM_SPHERE) { p->h[1] = p->h[2] = gs->size[0]; p->type = MIR_GEOM_BOX; }
       if (gs->type == MIR_GEOM_CAPSULE) { p->h[1] = gs->size[0]; p->h[2] = gs->size[0] + gs->size[1]; p->type = MIR_GEOM_BOX; }
+      if (gs->type == MIR_GEOM_HULL) { /* the bounding box of the vertices (float32, as the kernel's model holds them) */
+        p->h[0] = p->h[1] = p->h[2] = 0.0;
+        for (int i = (int)gs->size[0]; i < (int)gs->size[0] + (int)gs->size[1]; i++)
+          for (int k = 0; k < 3; k++) { double a = fabs((double)(float)spec->vert[i][k]); if (a > p->h[k]) p->h[k] = a; }
+        p->type = MIR_GEOM_BOX;
+      }
       p->geom = g;
     }
   double f[3] = {cam->lookat[0] - cam->pos[0], cam->lookat[1] - cam->pos[1], cam->lookat[2] - cam->pos[2]}, r[3], u[3];

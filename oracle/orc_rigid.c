@@ -390,6 +390,30 @@ static int plane_box(const real* pp, const real* Rp, const real* pb, const real*
   return cnt;
 }
 
+/* plane - hull: the penetrating vertices in index order, reduced to four like plane - box (support extremes) */
+static int plane_hull(const real* pp, const real* Rp, const real* pb, const real* Rb, const real (*verts)[3], int nvert, CPoint* pts, real* n) {
+  n[0] = Rp[2]; n[1] = Rp[5]; n[2] = Rp[8];
+  int cnt = 0;
+  CPoint all[MIR_MAX_HULL_VERT];
+  for (int c = 0; c < nvert; c++) {
+    real w[3], rel[3];
+    matvec3(w, Rb, verts[c]);
+    v3addscl(w, w, pb, 1);
+    v3sub(rel, w, pp);
+    real dist = v3dot(rel, n);
+    if (dist < 0) {
+      v3addscl(all[cnt].pos, w, n, -dist * (real)0.5);
+      all[cnt].dist = dist;
+      all[cnt].u = rel[0] * Rp[0] + rel[1] * Rp[3] + rel[2] * Rp[6];
+      all[cnt].v = rel[0] * Rp[1] + rel[1] * Rp[4] + rel[2] * Rp[7];
+      cnt++;
+    }
+  }
+  cnt = reduce4(all, cnt);
+  memcpy(pts, all, cnt * sizeof(CPoint));
+  return cnt;
+}
+
 static void col(real* o, const real* R, int k) { o[0] = R[k]; o[1] = R[3 + k]; o[2] = R[6 + k]; }
 
 /* box-box by separating axes + reference-face clipping; normal from A to B */
@@ -546,10 +570,29 @@ static int plane_capsule(const real* pp, const real* Rp, const real* pc, const r
  * (mir_dev.h: mpr_pair). */
 #define MPR_TOL ((real)1e-6)
 #define MPR_MAXIT 64
-typedef struct { int type; real size[3], pos[3], R[9]; } Shape;
+typedef struct { int type; real size[3], pos[3], R[9]; const real (*verts)[3]; int nvert; } Shape;
+/* vertex pool the MIR_GEOM_HULL shapes of the current call index into (set by orc_collide from the model, by orc_set_hull_pool for
+ * the narrowphase test hook) */
+static ORC_TLS const real (*cur_verts)[3] = 0;
+
+/* hull: the vertex of largest projection on d (geom frame: d_l = R^T d), lowest index on ties; out in world coordinates */
+static void hull_support(const Shape* s, const real* d, real* out) {
+  real dl[3] = {s->R[0] * d[0] + s->R[3] * d[1] + s->R[6] * d[2], s->R[1] * d[0] + s->R[4] * d[1] + s->R[7] * d[2],
+                s->R[2] * d[0] + s->R[5] * d[1] + s->R[8] * d[2]};
+  int best = 0;
+  real bv = v3dot(s->verts[0], dl);
+  for (int i = 1; i < s->nvert; i++) {
+    real v = v3dot(s->verts[i], dl);
+    if (v > bv) { bv = v; best = i; }
+  }
+  real w[3];
+  matvec3(w, s->R, s->verts[best]);
+  v3addscl(out, s->pos, w, 1);
+}
 
 /* farthest point of the shape along the UNIT direction d (world frame) */
 static void shape_support(const Shape* s, const real* d, real* out) {
+  if (s->type == MIR_GEOM_HULL) { hull_support(s, d, out); return; }
   v3copy(out, s->pos);
   if (s->type == MIR_GEOM_SPHERE) {
     v3addscl(out, out, d, s->size[0]);
@@ -740,6 +783,7 @@ static int mpr_pair(const Shape* A, const Shape* B, real* depth, real* normal, r
  * end the iteration. */
 #define GJK_MAXIT 32
 static void core_support(const Shape* s, const real* d, real* out) { /* farthest point of the CORE along d (any length) */
+  if (s->type == MIR_GEOM_HULL) { hull_support(s, d, out); return; } /* (a hull is its own core, radius 0) */
   v3copy(out, s->pos);
   if (s->type == MIR_GEOM_CAPSULE) {
     real ax[3] = {s->R[2], s->R[5], s->R[8]};
@@ -751,7 +795,7 @@ static void core_support(const Shape* s, const real* d, real* out) { /* farthest
     }
   }
 }
-static real core_radius(const Shape* s) { return s->type == MIR_GEOM_BOX ? (real)0 : s->size[0]; }
+static real core_radius(const Shape* s) { return (s->type == MIR_GEOM_BOX || s->type == MIR_GEOM_HULL) ? (real)0 : s->size[0]; }
 
 /* closest point of the segment / triangle to the origin as barycentric weights; vertices with weight 0 are dropped by the caller */
 static void seg_bary(const real* a, const real* b, real* l) {
@@ -865,6 +909,9 @@ static int convex_pair(int t1, const real* s1, const real* p1, const real* R1, i
   A.type = t1; B.type = t2;
   for (int k = 0; k < 3; k++) { A.size[k] = s1[k]; B.size[k] = s2[k]; A.pos[k] = p1[k]; B.pos[k] = p2[k]; }
   memcpy(A.R, R1, sizeof A.R); memcpy(B.R, R2, sizeof B.R);
+  A.verts = B.verts = 0; A.nvert = B.nvert = 0;
+  if (t1 == MIR_GEOM_HULL) { A.verts = cur_verts + (int)s1[0]; A.nvert = (int)s1[1]; }
+  if (t2 == MIR_GEOM_HULL) { B.verts = cur_verts + (int)s2[0]; B.nvert = (int)s2[1]; }
   real dist, pa[3], pb[3], ra = core_radius(&A), rb = core_radius(&B);
   if (!gjk_core_distance(&A, &B, &dist, pa, pb)) {
     if (!(dist < ra + rb)) return 0;
@@ -926,6 +973,7 @@ static void orc_collide(const OrcModel* m, OrcData* d) {
   static ORC_TLS real pn[ORC_NP][3];
   static ORC_TLS int pcnt[ORC_NP], ppair[ORC_NP];
   int np = 0;
+  cur_verts = m->vert;
   for (int pidx = 0; pidx < m->npair; pidx++) {
     int g1 = m->pair_g1[pidx], g2 = m->pair_g2[pidx];
     int b1 = m->gbody[g1], b2 = m->gbody[g2];
@@ -938,6 +986,7 @@ static void orc_collide(const OrcModel* m, OrcData* d) {
     if (m->gtype[g1] == MIR_GEOM_PLANE && m->gtype[g2] == MIR_GEOM_BOX) cnt = plane_box(p1, R1, p2, R2, m->gsize[g2], pts, n);
     else if (m->gtype[g1] == MIR_GEOM_PLANE && m->gtype[g2] == MIR_GEOM_SPHERE) cnt = plane_sphere(p1, R1, p2, m->gsize[g2][0], pts, n);
     else if (m->gtype[g1] == MIR_GEOM_PLANE && m->gtype[g2] == MIR_GEOM_CAPSULE) cnt = plane_capsule(p1, R1, p2, R2, m->gsize[g2][0], m->gsize[g2][1], pts, n);
+    else if (m->gtype[g1] == MIR_GEOM_PLANE && m->gtype[g2] == MIR_GEOM_HULL) cnt = plane_hull(p1, R1, p2, R2, m->vert + (int)m->gsize[g2][0], (int)m->gsize[g2][1], pts, n);
     else if (m->gtype[g1] == MIR_GEOM_BOX && m->gtype[g2] == MIR_GEOM_BOX) cnt = box_box(p1, R1, m->gsize[g1], p2, R2, m->gsize[g2], pts, n);
     else if (m->gtype[g1] != MIR_GEOM_PLANE) cnt = convex_pair(m->gtype[g1], m->gsize[g1], p1, R1, m->gtype[g2], m->gsize[g2], p2, R2, pts, n);
     if (cnt > 0) { pcnt[np] = cnt; ppair[np] = pidx; np++; }
@@ -960,6 +1009,15 @@ static void orc_collide(const OrcModel* m, OrcData* d) {
   }
 }
 
+/* test hook: the vertex pool that MIR_GEOM_HULL geoms handed to orc_narrowphase index into (size = first vertex, count) */
+static ORC_TLS real hook_pool[MIR_MAX_VERT][3];
+void orc_set_hull_pool(const double* verts, int n) {
+  if (n > MIR_MAX_VERT) n = MIR_MAX_VERT;
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) hook_pool[i][k] = (real)(float)verts[3 * i + k];
+  cur_verts = hook_pool;
+}
+
 /* test hook: narrowphase of ONE pair of geoms given directly (types, sizes, world poses as pos3 + quat4 wxyz);
  * out = up to 8 x (pos3, dist), normal3; returns the number of points */
 int orc_narrowphase(int t1, const double* size1, const double* pos1, const double* quat1, int t2, const double* size2, const double* pos2,
@@ -974,6 +1032,7 @@ int orc_narrowphase(int t1, const double* size1, const double* pos1, const doubl
   if (t1 == MIR_GEOM_PLANE && t2 == MIR_GEOM_BOX) cnt = plane_box(p1, R1, p2, R2, s2, pts, n);
   else if (t1 == MIR_GEOM_PLANE && t2 == MIR_GEOM_SPHERE) cnt = plane_sphere(p1, R1, p2, s2[0], pts, n);
   else if (t1 == MIR_GEOM_PLANE && t2 == MIR_GEOM_CAPSULE) cnt = plane_capsule(p1, R1, p2, R2, s2[0], s2[1], pts, n);
+  else if (t1 == MIR_GEOM_PLANE && t2 == MIR_GEOM_HULL) cnt = plane_hull(p1, R1, p2, R2, cur_verts + (int)s2[0], (int)s2[1], pts, n);
   else if (t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX) cnt = box_box(p1, R1, s1, p2, R2, s2, pts, n);
   else if (t1 != MIR_GEOM_PLANE && t2 != MIR_GEOM_PLANE) cnt = convex_pair(t1, s1, p1, R1, t2, s2, p2, R2, pts, n);
   for (int c = 0; c < cnt; c++) {
@@ -1308,10 +1367,15 @@ int orc_compile(const MirSceneSpec* sp, OrcModel* m) {
     for (int k = 0; k < 5; k++) m->dsolimp[i][k] = F32(s->solimp[k]);
   }
   m->nu = nu;
+  m->nvert = sp->nvert < 0 ? 0 : (sp->nvert > MIR_MAX_VERT ? MIR_MAX_VERT : sp->nvert);
+  for (int i = 0; i < m->nvert; i++)
+    for (int k = 0; k < 3; k++) m->vert[i][k] = F32(sp->vert[i][k]);
   for (int g = 0; g < sp->ngeom; g++) {
     const MirGeomSpec* s = &sp->geom[g];
     m->gbody[g] = s->body; m->gtype[g] = s->type;
     for (int k = 0; k < 3; k++) { m->gsize[g][k] = F32(s->size[k]); m->gpos[g][k] = F32(s->pos[k]); }
+    if (s->type == MIR_GEOM_HULL && ((int)s->size[0] < 0 || (int)s->size[1] < 4 || (int)s->size[1] > MIR_MAX_HULL_VERT || (int)s->size[0] + (int)s->size[1] > sp->nvert))
+      return -1;
     for (int k = 0; k < 4; k++) m->gquat[g][k] = F32(s->quat[k]);
     m->gfriction[g] = F32(s->friction);
     for (int k = 0; k < 2; k++) m->gsolref[g][k] = F32(s->solref[k]);

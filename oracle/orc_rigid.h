@@ -72,6 +72,8 @@ typedef struct OrcModel {
   int gbody[ORC_NG], gtype[ORC_NG];
   real gsize[ORC_NG][3], gpos[ORC_NG][3], gquat[ORC_NG][4], gfriction[ORC_NG], gsolref[ORC_NG][2], gsolimp[ORC_NG][5];
   int pair_g1[ORC_NP], pair_g2[ORC_NP];
+  int nvert;
+  real vert[MIR_MAX_VERT][3]; /* vertex pool of the MIR_GEOM_HULL geoms (gsize = first vertex, count) */
   real body_invweight0[ORC_NB];
   real meaninertia;
   real qpos0[ORC_NQ];

@@ -15,6 +15,7 @@
 #define MIR_GEOM_BOX 1
 #define MIR_GEOM_SPHERE 2
 #define MIR_GEOM_CAPSULE 3
+#define MIR_GEOM_HULL 4
 namespace {
 struct f4 { float x, y, z, w; };
 struct V3 { float x, y, z; };
@@ -26,6 +27,15 @@ inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 }  // namespace
 #include "../gym-genesis_amd/csrc/mir_convex.h"
+
+// vertex pool the MIR_GEOM_HULL shapes index into (size = first vertex, count): rows of 4 floats like the kernel's LDS copy
+static float g_pool[96][4];
+extern "C" void convex_host_set_pool(const double* verts, int n) {
+  for (int i = 0; i < n && i < 96; i++) {
+    for (int k = 0; k < 3; k++) g_pool[i][k] = (float)verts[3 * i + k];
+    g_pool[i][3] = 0;
+  }
+}
 
 // in: type1, size1[3], pos1[3], quat1[4] wxyz, type2, ...; out: hit, pos[3], dist, normal[3]
 extern "C" void convex_host_pairs(const float* in, float* out, int n) {
@@ -43,6 +53,8 @@ extern "C" void convex_host_pairs(const float* in, float* out, int n) {
       S[k].a0 = v3(1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y));
       S[k].a1 = v3(2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x));
       S[k].a2 = v3(2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y));
+      S[k].verts = &g_pool[S[k].type == MIR_GEOM_HULL ? (int)p[1] : 0][0];
+      S[k].nvert = (int)p[2];
     }
     f4 pt = {0, 0, 0, 0};
     V3 nrm = v3(0, 0, 0);

@@ -183,6 +183,126 @@ def test_round_geoms_on_the_wave_kernel_settle_like_the_oracle():
     assert np.abs(qh[:, [2, 9, 16, 23]] - qo[:, [2, 9, 16, 23]]).max() < 2e-3   # resting heights
 
 
+def test_hull_contacts_match_the_oracle_pose_by_pose():
+    """Vertex-hull geoms (MIR_GEOM_HULL, 40 vertices in LDS: an 8-vertex cube and a 32-vertex ball) in the 16-lane kernel, one
+    forward evaluation at 512 random relative poses of a hull and a round body in mid-air (hull - sphere through GJK on the
+    polytope and the point, MPR when the centre dips into the hull): contact counts as the oracle's, constrained accelerations of the
+    shallow contacts within 1e-3.  (Against a ROUND partner the closest feature pair is unique; two polytopes resting face to face
+    have a whole polygon of closest points, and which of them a single-point narrowphase reports is decided by rounding.)"""
+    for kind_a, verts in (("cube", S.box_hull_vertices((0.04, 0.03, 0.05))), ("ball", S.icosphere_vertices(0.05, 1))):
+        sb = S.SceneBuilder()
+        sb.add_geom(0, S.GEOM_PLANE)
+        sb.add_body("a", 0, pos=(-0.3, 0.0, 0.5), jtype=S.JNT_FREE, mass=0.3, inertia=S.box_inertia(0.3, (0.04, 0.03, 0.05)))
+        sb.add_geom("a", S.GEOM_HULL, vertices=verts)
+        sb.add_body("b", 0, pos=(0.3, 0.0, 0.5), jtype=S.JNT_FREE, mass=0.3, inertia=S.sphere_inertia(0.3, 0.04))
+        sb.add_geom("b", S.GEOM_SPHERE, size=(0.04, 0.0, 0.0))
+        sb.task = dict(eef_body=1, obj_body=2, grip_dof=(), reward_z=0.1)
+        spec = sb.build()
+        B = 512
+        rng = np.random.default_rng(11)
+        q = np.zeros((B, 14), np.float32)
+        q[:, 0:3] = rng.uniform(-0.02, 0.02, (B, 3)) + [0, 0, 1.0]
+        d = rng.normal(size=(B, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        q[:, 7:10] = q[:, 0:3] + d * rng.uniform(0.02, 0.13, (B, 1))
+        q[:, 3:7], q[:, 10:14] = _rand_quat(rng, B), _rand_quat(rng, B)
+        v = rng.uniform(-0.2, 0.2, (B, 12)).astype(np.float32)
+        sc, o = _mir(spec, B), orc.Oracle(spec, B)
+        assert sc.kernel == 16
+        sc.set_state(qpos=q, qvel=v, warmstart=np.zeros((B, 12), np.float32))
+        _, _, _, qacc = (t.cpu().numpy() for t in sc.forward())
+        ncon = sc.get_diag()[0].cpu().numpy()
+        nco = np.zeros(B, int)
+        worst, shallow, deep = 0.0, 0, 0
+        for e in range(B):
+            o.write(orc.F_QPOS, q[e], e)
+            o.write(orc.F_QVEL, v[e], e)
+            o.forward(e)
+            nco[e] = o.counts(e)[0]
+            if nco[e] != ncon[e] or not nco[e]:
+                continue
+            dist = o.read(orc.F_CDIST, e)
+            if dist[0] > -1e-4:
+                continue
+            if -dist[0] > 0.9 * 0.04:
+                deep += 1
+                continue
+            qo = o.read(orc.F_QACC, e)
+            worst = max(worst, np.abs(qacc[e] - qo).max() / max(1.0, np.abs(qo).max()))
+            shallow += 1
+        mism = int((nco != ncon).sum())
+        print(f"hull {kind_a} vs sphere: {int((nco > 0).sum())} contacts in {B} poses ({shallow} through GJK, {deep} through MPR), {mism} count mismatches, qacc rel err {worst:.2e}")
+        assert mism <= 2 and (nco > 0).sum() > 100 and shallow > 50
+        assert worst < 1e-3
+
+
+def _hull_scene(kind_a, kind_b):
+    """plane + two free bodies: an 8-vertex cube (or the same cube as GEOM_BOX) and a 32-vertex ball."""
+    sb = S.SceneBuilder()
+    sb.add_geom(0, S.GEOM_PLANE)
+    h = (0.03, 0.03, 0.03)
+    sb.add_body("a", 0, pos=(-0.3, 0.0, 0.5), jtype=S.JNT_FREE, mass=0.3, inertia=S.box_inertia(0.3, h))
+    if kind_a == "hull":
+        sb.add_geom("a", S.GEOM_HULL, vertices=S.box_hull_vertices(h))
+    else:
+        sb.add_geom("a", S.GEOM_BOX, size=h)
+    sb.add_body("b", 0, pos=(0.3, 0.0, 0.5), jtype=S.JNT_FREE, mass=0.3, inertia=S.sphere_inertia(0.3, 0.04))
+    sb.add_geom("b", S.GEOM_HULL, vertices=S.icosphere_vertices(0.04, 1))
+    sb.task = dict(eef_body=1, obj_body=2, grip_dof=(), reward_z=0.1)
+    return sb.build()
+
+
+def test_hull_bodies_settle_on_the_plane_like_the_oracle():
+    """The cube given as its 8 corners and a 32-vertex ball dropped from random poses on the plane (plane - hull: the penetrating
+    vertices, reduced to four like plane - box), 150 free-running steps against the oracle; and the cube given as its corners follows
+    the GEOM_BOX cube of the same kernel bit for bit (the lane-private hull path and the 8-lane plane - box path do the same
+    arithmetic)."""
+    B = 64
+    rng = np.random.default_rng(9)
+    pos = np.zeros((B, 2, 3), np.float32)
+    pos[:, 0] = rng.uniform(-0.05, 0.05, (B, 3)) + [0.5, 0.0, 0.12]
+    pos[:, 1] = rng.uniform(-0.05, 0.05, (B, 3)) + [0.0, 0.0, 0.12]
+    quat = np.stack([_rand_quat(rng, B), _rand_quat(rng, B)], 1).astype(np.float32)
+    arm = np.zeros((B, 0), np.float32)
+    spec = _hull_scene("hull", "hull")
+    sc, o = _mir(spec, B), orc.Oracle(spec, B)
+    assert sc.kernel == 16
+    ref = _mir(_hull_scene("box", "hull"), B)
+    for x in (sc, o, ref):
+        x.reset(pos, quat, arm)
+    bufs = (sc.empty(sc.agent_dim), sc.empty(sc.env_dim), sc.empty(), sc.empty(dtype=torch.uint8))
+    for t in range(150):
+        sc.step_fused(None, *bufs)
+        ref.step_fused(None, *bufs)
+        o.step_batch(None)
+        if t == 20:
+            early = np.abs(sc.get_state()[0].cpu().numpy() - o.state()[0]).max()
+    qh, qo, qr = sc.get_state()[0].cpu().numpy(), o.state()[0], ref.get_state()[0].cpu().numpy()
+    err = np.abs(qh - qo)[:, [0, 1, 2, 7, 8, 9]].max(1)
+    ncon = sc.get_diag()[0].cpu().numpy()
+    print(f"hull bodies on the plane: after 21 steps L-inf {early:.2e}; after 150 steps position err median {np.median(err):.2e}, max {err.max():.2e}; contacts {ncon.min()}..{ncon.max()}; "
+          f"hull cube vs box cube {np.abs(qh[:, :7] - qr[:, :7]).max():.2e}")
+    assert early < 1e-5
+    assert np.median(err) < 1e-4 and err.max() < 5e-3
+    assert (ncon >= 4).all()
+    assert np.abs(qh[:, 2] - qo[:, 2]).max() < 2e-3 and np.abs(qh[:, 9] - qo[:, 9]).max() < 2e-3   # resting heights
+    assert np.array_equal(qh[:, :7], qr[:, :7])                                                      # cube as corners == cube as box
+
+
+def test_hull_vertex_pool_beyond_the_kernel_capacity_is_refused():
+    """More hull vertices than the 16-lane kernel keeps in LDS (K16_MAX_VERT = 40): not simulated with anything else."""
+    from gym_genesis.backend.lib import MirError
+
+    sb = S.SceneBuilder()
+    sb.add_geom(0, S.GEOM_PLANE)
+    for i in range(2):
+        sb.add_body(f"b{i}", 0, pos=(0.2 * i, 0, 0.1), jtype=S.JNT_FREE, mass=0.1, inertia=S.sphere_inertia(0.1, 0.04))
+        sb.add_geom(f"b{i}", S.GEOM_HULL, vertices=S.icosphere_vertices(0.04, 1))
+    sb.task = dict(eef_body=1, obj_body=2, grip_dof=(), reward_z=0.1)
+    with pytest.raises(MirError):
+        _mir(sb.build(), 4)
+
+
 def _device_pairs(rows):
     """Run the kernel-side convex_pair on (n, 22) float32 rows; returns (n, 8)."""
     import ctypes as C
