@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
 //     reciprocal per lane and row), it fills the pixels the boxes left (all of them in the bands no rectangle meets), and the
 //     boxes were depth-tested against its row depth.
 #define NOHIT 0xffffffffu
-__global__ __launch_bounds__(256) void mir_render_binned(PixArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void mir_render_binned(PixArgs a) {
   __shared__ unsigned s_tile[4][8 * 128];  // per wave: 8 rows x 128 pixels of packed colours
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tx0 = blockIdx.x * TW, sy0 = blockIdx.y * a.th, img = blockIdx.z;
@@ -502,6 +503,11 @@ __global__ __launch_bounds__(256) void mir_render_binned(PixArgs a) {
   const unsigned ceven = __float_as_uint(fq5.w), codd = __float_as_uint(fq6.w);
   uint8_t* __restrict__ ibase = a.pixels + (size_t)img * a.H * a.W * 3;
   unsigned* tile = s_tile[wv];
+  // (a VALU instruction takes ONE scalar operand: the addends of the row expressions below live in vector registers for the whole
+  //  strip instead of being moved there in every region -- the kernel is VALU-bound: 23 instructions per pixel x 4 cycles)
+  float v_y0 = a.y0, v_fz = f_fz, v_5x = fq5.x, v_6x = fq6.x;
+  unsigned v_sky = a.sky;
+  asm volatile("" : "+v"(v_y0), "+v"(v_fz), "+v"(v_5x), "+v"(v_6x), "+v"(v_sky));
 
   for (int ty0 = sy0; ty0 <= symax; ty0 += 32) {
     const int wy0 = ty0 + 8 * wv;            // this wave's band of 8 rows
@@ -551,44 +557,46 @@ __global__ __launch_bounds__(256) void mir_render_binned(PixArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // ---- floor pass, store layout
+    // ---- floor pass and packed RGB8 store (4 pixels = 3 dwords per lane and region; not waited for), store layout.  Two copies:
+    // bands no primitive touched (most) assign the floor colour, the others fill the pixels the boxes left.
+    auto finish = [&](auto touched_c) {
+      constexpr bool TOUCHED = decltype(touched_c)::value;
+      unsigned boff = ((unsigned)prow * (unsigned)a.W + (unsigned)px) * 3u;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      unsigned fc[4];
-      if (floor) {
-        const float y = a.y0 + (float)(prow + 2 * r) * a.dy;
-        const float ez = fmaf(y, f_uz, f_fz), eu = fmaf(y, fq5.z, fq5.x), ev = fmaf(y, fq6.z, fq6.x);
-        const float iz1 = __builtin_amdgcn_rcpf(ez);
-        const bool vld = iz1 * (-f_oz) > 1e-6f;
-        const unsigned c0 = vld ? ceven : a.sky, c1 = vld ? codd : a.sky;
+      for (int r = 0; r < 4; r++, boff += 6u * (unsigned)a.W) {
+        unsigned fc[4];
+        if (floor) {
+          const float y = fmaf((float)(prow + 2 * r), a.dy, v_y0);
+          const float ez = fmaf(y, f_uz, v_fz), eu = fmaf(y, fq5.z, v_5x), ev = fmaf(y, fq6.z, v_6x);
+          const float iz1 = __builtin_amdgcn_rcpf(ez);
+          const bool vld = iz1 * (-f_oz) > 1e-6f;
+          const unsigned c0 = vld ? ceven : v_sky, c1 = vld ? codd : v_sky;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const f2 u = (xs[h] * fq5.y + eu) * iz1, v = (xs[h] * fq6.y + ev) * iz1;
+          for (int h = 0; h < 2; h++) {
+            const f2 u = (xs[h] * fq5.y + eu) * iz1, v = (xs[h] * fq6.y + ev) * iz1;
 #pragma unroll
-          for (int q = 0; q < 2; q++) {
-            const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
-            fc[2 * h + q] = odd ? c1 : c0;
+            for (int q = 0; q < 2; q++) {
+              const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
+              fc[2 * h + q] = odd ? c1 : c0;
+            }
           }
+        } else {
+#pragma unroll
+          for (int p = 0; p < 4; p++) fc[p] = v_sky;
         }
-      } else {
+        if (prow + 2 * r > symax || px >= a.W) continue;
+        unsigned c[4];
 #pragma unroll
-        for (int p = 0; p < 4; p++) fc[p] = a.sky;
+        for (int p = 0; p < 4; p++) c[p] = TOUCHED ? (col[r][p] == NOHIT ? fc[p] : col[r][p]) : fc[p];
+        u3 v;
+        v.x = c[0] | c[1] << 24;
+        v.y = c[1] >> 8 | c[2] << 16;
+        v.z = c[2] >> 16 | c[3] << 8;
+        *reinterpret_cast<u3*>(ibase + boff) = v;
       }
-#pragma unroll
-      for (int p = 0; p < 4; p++) col[r][p] = touched ? (col[r][p] == NOHIT ? fc[p] : col[r][p]) : fc[p];
-    }
-    // ---- packed RGB8 store: 4 pixels = 3 dwords per lane and region; not waited for
-    unsigned boff = ((unsigned)prow * (unsigned)a.W + (unsigned)px) * 3u;
-#pragma unroll
-    for (int r = 0; r < 4; r++, boff += 6u * (unsigned)a.W) {
-      if (prow + 2 * r > symax || px >= a.W) continue;
-      const unsigned c0 = col[r][0], c1 = col[r][1], c2 = col[r][2], c3 = col[r][3];
-      u3 v;
-      v.x = c0 | c1 << 24;
-      v.y = c1 >> 8 | c2 << 16;
-      v.z = c2 >> 16 | c3 << 8;
-      *reinterpret_cast<u3*>(ibase + boff) = v;
-    }
+    };
+    if (touched) finish(std::true_type{});
+    else finish(std::false_type{});
   }
 }
 

@@ -12,10 +12,12 @@ dst = os.path.join(R, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 src = os.path.join(R, "gpurun_out")
 for name in ("pmc_hbm_traffic.json", "pmc_hbm_traffic_api.json", "pmc_hbm_traffic_step64.json", "sq_counters.json", "sq_counters_rotated.json",
-             "sq_counters_step64.json", "stack_kernel_stats.csv", "stack_phase_profile.txt"):
+             "sq_counters_step64.json", "stack_kernel_stats.csv", "stack_phase_profile.txt", "render_pmc.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
-for name in ("bench_kernel_stats.csv", "bench_raw_kernel_stats.csv"):
+for name in ("bench_kernel_stats.csv", "bench_raw_kernel_stats.csv", "render_kernel_stats.csv"):
+    if not os.path.exists(os.path.join(src, name)):
+        continue
     rows = list(csv.reader(open(os.path.join(src, name))))
     for r in rows:
         if len(r[0]) > 200:
