@@ -291,6 +291,60 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   const float mdl_gx = m->gx, mdl_gy = m->gy, mdl_gz = m->gz;
   const int mdl_eef = m->eef_body, mdl_obj = m->obj_body, mdl_ngrip = m->n_grip;
   const int mdl_split = m->gj_split;
+  // ---- the scratch row of the split step, PACKED (it travels through HBM twice per env.step): a mass-matrix row keeps the
+  // 16-byte quads of its own tree block only (9 + 6 dofs: 3 quads for the arm's rows, 2 for the cube's, 624 B instead of 1 KB), a
+  // contact's three Jacobian rows keep the quads in which one of its two bodies has a dof (a cube on the floor: 2 of 4) and no
+  // bank-conflict pad.  Which quads a contact keeps is 4 bits in the row's head word.
+  const int pk_split = mdl_split, pk_nvq = (nv + 3) >> 2;
+  const bool pk_rowA = pk_split > 0 && lane < pk_split, pk_rowB = pk_split > 0 && lane >= pk_split;
+  const int pk_qlo = pk_rowB ? pk_split >> 2 : 0, pk_qhi = pk_rowA ? (pk_split + 3) >> 2 : pk_nvq;  // quads [qlo, qhi) of this lane's row
+  const int pk_moff = 4 * (pk_rowB ? pk_split * ((pk_split + 3) >> 2) + (lane - pk_split) * (pk_nvq - (pk_split >> 2)) : lane * (pk_qhi - pk_qlo));
+  // Jacobian rows of nc contacts from LDS to the scratch row; returns the quad masks (4 bits per contact).  Four contacts per trip:
+  // every LDS read of the trip is issued before the first global store (one round trip per trip, not per contact).
+  auto jrows_store = [&](float* pre, int nc, auto& Sx) -> uint64_t {
+    uint64_t qm = 0ull;
+    int off = 0;
+    const int r = lane >> 2, q = lane & 3;
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+      uint32_t mk[4];
+      f4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u < nc ? c0 + u : c0;
+        mk[u] = c0 + u < nc ? Sx.con.cmask[c][2] : 0u;  // (the contact's 4-dof chunks: the quads in which one of its bodies has a dof)
+        v[u] = ldv(&Sx.Jb[c][lane < 12 ? 16 * r + 4 * q : 0]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int nq = __popc(mk[u]);
+        if (lane < 12 && ((mk[u] >> q) & 1u)) *reinterpret_cast<f4*>(pre + K16_PRE_JB + 4 * (off + r * nq + __popc(mk[u] & ((1u << q) - 1u)))) = v[u];
+        off += 3 * nq;
+        qm |= (uint64_t)mk[u] << (4 * (c0 + u));
+      }
+    }
+    return qm;
+  };
+  // ... and back: the loads of four contacts in flight together (addresses follow from the head word alone), then their LDS stores;
+  // a quad the contact did not keep reads the row's first quad and is zeroed by a select (no divergent branch around a load)
+  auto jrows_load = [&](const float* pre, int nc, uint64_t qm, auto& Sx) {
+    int off = 0;
+    const int r = lane >> 2, q = lane & 3;
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+      f4 v[4];
+      bool on[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t mk = c0 + u < nc ? (uint32_t)(qm >> (4 * (c0 + u))) & 15u : 0u;
+        const int nq = __popc(mk);
+        on[u] = lane < 12 && ((mk >> q) & 1u);
+        v[u] = *reinterpret_cast<const f4*>(pre + K16_PRE_JB + 4 * (on[u] ? off + r * nq + __popc(mk & ((1u << q) - 1u)) : 0));
+        off += 3 * nq;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (lane < 12 && c0 + u < nc) stv(&Sx.Jb[c0 + u][16 * r + 4 * q], on[u] ? v[u] : f4{0, 0, 0, 0});
+    }
+  };
   // DUAL: the closing FK is split between the waves when every free-joint body is a childless child of the world (wave-uniform)
   const bool fksplit = DUAL && m->fk_free_leaf != 0;
   // the task's object is a free body hanging off the world: its height -- all that `terminated` needs -- is a qpos entry, final as
@@ -820,8 +874,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         const int nc = __float_as_int(head.x);
         if (lane == 0) { S.ncon = nc; S.coupled = __float_as_int(head.y); S.ncand = 0; }
         if (lane < nc) stv(S.con.cmeta[lane], *reinterpret_cast<const f4*>(pre + K16_PRE_CMETA + 4 * lane));
-        f4* jdst = reinterpret_cast<f4*>(&S.Jb[0][0]);
-        for (int i = lane; i < nc * (JST / 4); i += G) jdst[i] = *reinterpret_cast<const f4*>(pre + K16_PRE_JB + 4 * i);
+        jrows_load(pre, nc, (uint64_t)__float_as_uint(head.z) | ((uint64_t)__float_as_uint(head.w) << 32), S);
         WSYNC();
         HSTAMP(54);
         __syncthreads();  // (3) contact rows of this step are in LDS
@@ -871,10 +924,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         if (valid) {
           float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
           const int nc = S.ncon;
-          if (lane == 0) *reinterpret_cast<f4*>(pre + K16_PRE_HEAD) = f4{__int_as_float(nc), __int_as_float(S.coupled), 0.0f, 0.0f};
+          const uint64_t qm = jrows_store(pre, nc, S);
+          if (lane == 0) *reinterpret_cast<f4*>(pre + K16_PRE_HEAD) = f4{__int_as_float(nc), __int_as_float(S.coupled), __uint_as_float((uint32_t)qm), __uint_as_float((uint32_t)(qm >> 32))};
           if (lane < nc) *reinterpret_cast<f4*>(pre + K16_PRE_CMETA + 4 * lane) = ldv(S.con.cmeta[lane]);
-          const f4* jsrc = reinterpret_cast<const f4*>(&S.Jb[0][0]);
-          for (int i = lane; i < nc * (JST / 4); i += G) *reinterpret_cast<f4*>(pre + K16_PRE_JB + 4 * i) = jsrc[i];
         }
 #ifdef MIR_PROFILE_SINGLE
         // (debug: wall clock of the last exit among the workgroups on the watched one's XCD = the end of the launch)
@@ -1011,15 +1063,18 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   if (POST || ROT) {
     const float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
 #pragma unroll
-    for (int q = 0; q < 4; q++) pre_m[q] = *reinterpret_cast<const f4*>(pre + K16_PRE_MROW + 16 * lane + 4 * q);
+    for (int q = 0; q < 4; q++) {  // (a quad outside the row's block reads the row's first quad and is zeroed: no branch around a load)
+      const bool in = lane < nv && q >= pk_qlo && q < pk_qhi;
+      const f4 v = *reinterpret_cast<const f4*>(pre + K16_PRE_MROW + (lane < nv ? pk_moff : 0) + (in ? 4 * (q - pk_qlo) : 0));
+      pre_m[q] = in ? v : f4{0, 0, 0, 0};
+    }
     pre_bias = pre[K16_PRE_BIAS + lane];
     if (POST) {  // (one wave: it fetches the contact rows itself; in the rotated launch the collision wave does)
       const f4 head = *reinterpret_cast<const f4*>(pre + K16_PRE_HEAD);
       const int nc = __float_as_int(head.x);
       if (lane == 0) { S.ncon = nc; S.coupled = __float_as_int(head.y); S.ncand = 0; }
       if (lane < nc) stv(S.con.cmeta[lane], *reinterpret_cast<const f4*>(pre + K16_PRE_CMETA + 4 * lane));
-      f4* jdst = reinterpret_cast<f4*>(&S.Jb[0][0]);
-      for (int i = lane; i < nc * (JST / 4); i += G) jdst[i] = *reinterpret_cast<const f4*>(pre + K16_PRE_JB + 4 * i);
+      jrows_load(pre, nc, (uint64_t)__float_as_uint(head.z) | ((uint64_t)__float_as_uint(head.w) << 32), S);
       WSYNC();
     }
   }
@@ -1305,8 +1360,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       if (pre_now) {
         if (valid) {
           float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
-          *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane) = r0; *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 4) = r1;
-          *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 8) = r2; *reinterpret_cast<f4*>(pre + K16_PRE_MROW + 16 * lane + 12) = r3;
+          const f4 rq[4] = {r0, r1, r2, r3};
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (lane < nv && q >= pk_qlo && q < pk_qhi) *reinterpret_cast<f4*>(pre + K16_PRE_MROW + pk_moff + 4 * (q - pk_qlo)) = rq[q];
           pre[K16_PRE_BIAS + lane] = qfrc_bias;
         }
         __syncthreads();  // (2b) the collision wave has stored the contact arrays: this wave builds every other pair of Jacobian rows
