@@ -585,16 +585,21 @@ void mir_step64_kernel(StepArgs64 a) {
             V3 dc = c2 - ld3v(S.col.gpos[g1]);
             hit = dot(dc, dc) <= rs * rs;
             if (CONVEX && hit && (t1 == MIR_GEOM_BOX) != (t2 == MIR_GEOM_BOX)) {
-              // one box, one round geom: the round geom's bounding sphere against the BOX itself (clamped distance in the box frame),
-              // not against the box's bounding sphere -- the kitchen slab's is a metre wide and every link near it would run GJK
+              // one box, one round geom: the round geom's CORE (centre, or the axis segment's bounding box in the box frame) against
+              // the box itself (clamped distance <= radius), not bounding spheres -- the kitchen slab's is a metre wide, and link 1
+              // stands a few centimetres above it for the whole episode: every such pair would run GJK every step
               const bool box1 = t1 == MIR_GEOM_BOX;
               const M3 Rb = box1 ? q2m(ld4v(S.col.gquat[g1])) : R2;
-              const V3 hb = box1 ? h1 : h2;
+              const M3 Rr = box1 ? R2 : q2m(ld4v(S.col.gquat[g1]));
+              const V3 hb = box1 ? h1 : h2, hr = box1 ? h2 : h1;
               const V3 dd = box1 ? dc : v3(-dc.x, -dc.y, -dc.z);  // round centre - box centre
-              const float br = box1 ? b2 : b1;
-              const float ex = fmaxf(fabsf(dot(dd, mcol(Rb, 0))) - hb.x, 0.0f), ey = fmaxf(fabsf(dot(dd, mcol(Rb, 1))) - hb.y, 0.0f),
-                          ez = fmaxf(fabsf(dot(dd, mcol(Rb, 2))) - hb.z, 0.0f);
-              hit = ex * ex + ey * ey + ez * ez <= br * br;
+              const bool cap = (box1 ? t2 : t1) == MIR_GEOM_CAPSULE;
+              const V3 axr = mcol(Rr, 2);
+              const float hl = cap ? hr.y : 0.0f;  // half length of the core segment
+              const float ex = fmaxf(fabsf(dot(dd, mcol(Rb, 0))) - hb.x - hl * fabsf(dot(axr, mcol(Rb, 0))), 0.0f);
+              const float ey = fmaxf(fabsf(dot(dd, mcol(Rb, 1))) - hb.y - hl * fabsf(dot(axr, mcol(Rb, 1))), 0.0f);
+              const float ez = fmaxf(fabsf(dot(dd, mcol(Rb, 2))) - hb.z - hl * fabsf(dot(axr, mcol(Rb, 2))), 0.0f);
+              hit = ex * ex + ey * ey + ez * ez <= hr.x * hr.x;
             }
             if (hit && (!CONVEX || (t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX))) {
               // the six face axes of the narrowphase's separating-axis test (same expressions): a pair they separate
