@@ -406,3 +406,27 @@ def test_full_batch_identical_envs_and_shards_bit_exact():
         lo.set_pd_targets(a[k, :B // 2].contiguous()); lo.step(1)
         hi.set_pd_targets(a[k, B // 2:].contiguous()); hi.step(1)
     assert torch.equal(big.get_state()[0], torch.cat([lo.get_state()[0], hi.get_state()[0]]))
+
+
+def test_dispatch_order_is_a_permutation_at_odd_batch_sizes():
+    """The single-step launch serves the envs that were expensive in the previous step first (per-env cost flags, chunks of 4096
+    workgroups): at batch sizes that end in a partial 64-env lane block and in a partial chunk, with envs that couple (cube_2 spawned
+    on cube_1 in every third env) mixed among envs that do not, every env is stepped exactly once per launch -- the batch equals
+    the same envs run as smaller scenes (whose order is a different permutation), bit for bit, over steps in which the flags change."""
+    spec = _builder("franka").build()
+    rng = np.random.RandomState(5)
+    for B in (37, 4096 + 133):
+        pos = _spawn(B, 21)
+        pos[::3, 1, :2] = pos[::3, 0, :2] + 0.03
+        quat = np.tile(np.array([0, 0, 0, 1], np.float32), (B, 5, 1))
+        arm = np.tile(_home("franka"), (B, 1))
+        cut = B // 3 + 5
+        big, lo, hi = _scene(spec, B), _scene(spec, cut), _scene(spec, B - cut)
+        big.reset(pos, quat, arm); lo.reset(pos[:cut], quat[:cut], arm[:cut]); hi.reset(pos[cut:], quat[cut:], arm[cut:])
+        a = torch.as_tensor((_home("franka") + rng.uniform(-1, 1, (8, B, 9))).astype(np.float32), device=big.device)
+        for k in range(8):
+            big.set_pd_targets(a[k]); big.step(1)
+            lo.set_pd_targets(a[k, :cut].contiguous()); lo.step(1)
+            hi.set_pd_targets(a[k, cut:].contiguous()); hi.step(1)
+        assert torch.equal(big.get_state()[0], torch.cat([lo.get_state()[0], hi.get_state()[0]])), B
+        assert torch.equal(big.get_state()[1], torch.cat([lo.get_state()[1], hi.get_state()[1]])), B
