@@ -247,6 +247,11 @@ int mir_compile_model64(const MirSceneSpec* sp0, DevModel64* out, HostConsts* hc
     }
     m.obs_qadr[l] = oq;
   }
+  m.fk_free_leaf = 1;
+  for (int b = 1; b < nb; b++) {
+    if (m.b_jtype[b] == MIR_JNT_FREE && m.b_parent[b] != 0) m.fk_free_leaf = 0;
+    if (m.b_parent[b] > 0 && m.b_jtype[m.b_parent[b]] == MIR_JNT_FREE) m.fk_free_leaf = 0;
+  }
   // tree-scan links (the kernel's dynamics run prefix sums along dof chains and suffix sums over body lanes)
   {
     auto top = [](uint64_t mk) { int t = -1; for (int l = 0; l < 64; l++) if ((mk >> l) & 1ull) t = l; return t; };

@@ -63,7 +63,7 @@ struct DevModel64 {
    * the lane behind the body's subtree, -1 when the subtree ends with its 16-lane row */
   int32_t scanw[W64];
   int32_t has_convex; /* the scene has sphere / capsule geoms: the launcher picks the instantiation with the convex narrowphase */
-  int32_t pad_hc;
+  int32_t fk_free_leaf; /* every free-joint body hangs off the world and carries no children: its pose is its qpos row (split closing FK) */
 };
 
 // Dof-order <-> storage maps used by the plumbing kernels of mir_api.hip for BOTH step kernels

@@ -320,11 +320,15 @@ struct BodyK64 {
 
 // forward kinematics by pointer jumping over the parent links (see group_fk in mir_step.hip): 5 rounds cover any tree
 // of up to 32 bodies; the pointer travels in the w slot of the position
+// JOINTED_ONLY: the free bodies are left out (their poses are their qpos rows; the caller writes them) -- requires that no jointed
+// body hangs off a free body (DevModel64.fk_free_leaf).
+template <bool JOINTED_ONLY = false>
 __device__ __forceinline__ void wave_fk(Env64& S, int lane, int nb, const BodyK64& k) {
   V3 P = v3(0, 0, 0);
   Q4 Qx = Q4{1, 0, 0, 0};
   int anc = 0;
-  if (lane > 0 && lane < nb) {
+  const bool mine = lane < nb && !(JOINTED_ONLY && k.jtype == MIR_JNT_FREE);
+  if (lane > 0 && mine) {
     Qx = k.quat;
     P = k.pos;
     if (k.jtype == MIR_JNT_REVOLUTE) {
@@ -356,7 +360,7 @@ __device__ __forceinline__ void wave_fk(Env64& S, int lane, int nb, const BodyK6
     }
     WSYNC();
   }
-  if (lane < nb) {
+  if (mine) {
     st3v(S.xpos[lane], P);
     st4v(S.xquat[lane], Qx);
   }
@@ -397,6 +401,7 @@ void mir_step64_kernel(StepArgs64 a) {
   const DevModel64* __restrict__ m = a.model;
   const int lane = threadIdx.x & 63;
   const bool helper = DUAL && threadIdx.x >= 64;  // wave-uniform
+  const bool fk_split = DUAL && m->fk_free_leaf != 0;  // the closing FK of the jointed bodies runs on wave 1 (wave-uniform)
 #ifdef MIR_PROFILE_SINGLE
   const unsigned long long t_entry = __builtin_readcyclecounter();
 #endif
@@ -917,6 +922,13 @@ void mir_step64_kernel(StepArgs64 a) {
     for (int q = 0; q < 4; q++) stv(hxrow + 4 * q, f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]});
     STAMP(29);
     __syncthreads();  // (4)
+    if (fk_split) {
+      // the closing forward kinematics of the jointed bodies, while wave 0 integrates the free bodies' quaternions, writes their
+      // poses and stores the state rows
+      __syncthreads();  // (5) scalar joints integrated
+      wave_fk<true>(S, lane, nb, bk);
+      __syncthreads();  // (6) link poses of the new state
+    }
     return;
   }
 
@@ -1690,17 +1702,21 @@ void mir_step64_kernel(StepArgs64 a) {
       const float qd = S.qvel[lane];
       if (d_kind < 2) S.qpos[d_qadr] += dt * qd;
       else if (d_kind == 2) S.qpos[d_qbase + d_axis_k] += dt * qd;
-      else if (d_axis_k == 0) {
-        V3 w = v3(S.qvel[d_lbase + 3], S.qvel[d_lbase + 4], S.qvel[d_lbase + 5]);
-        float wn = sqrtf(dot(w, w));
-        float ang = wn * dt;
-        if (ang > 1e-15f) {
-          float sn, cs;
-          sincos_pi2(0.5f * ang, &sn, &cs);
-          V3 ax = (1.0f / wn) * w;
-          Q4 dq = {cs, ax.x * sn, ax.y * sn, ax.z * sn};
-          st4(&S.qpos[d_qbase + 3], qnormalize(qmul(dq, ld4(&S.qpos[d_qbase + 3]))));
-        }
+    }
+    if (fk_split) {
+      WSYNC();
+      __syncthreads();  // (5) the scalar joints are integrated: wave 1 starts on the jointed bodies' kinematics
+    }
+    if (isdof && d_kind == 3 && d_axis_k == 0) {
+      V3 w = v3(S.qvel[d_lbase + 3], S.qvel[d_lbase + 4], S.qvel[d_lbase + 5]);
+      float wn = sqrtf(dot(w, w));
+      float ang = wn * dt;
+      if (ang > 1e-15f) {
+        float sn, cs;
+        sincos_pi2(0.5f * ang, &sn, &cs);
+        V3 ax = (1.0f / wn) * w;
+        Q4 dq = {cs, ax.x * sn, ax.y * sn, ax.z * sn};
+        st4(&S.qpos[d_qbase + 3], qnormalize(qmul(dq, ld4(&S.qpos[d_qbase + 3]))));
       }
     }
     WSYNC();
@@ -1713,7 +1729,24 @@ void mir_step64_kernel(StepArgs64 a) {
       __hip_atomic_store(&a.term_host[env], (uint8_t)((r0 == 1.0f ? 1u : 0u) | a.term_tag << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // kinematics of the new state: observations of this step, and the next step's starting poses
-    wave_fk(S, lane, nb, bk);
+    if (fk_split) {
+      // (wave 1 has the jointed bodies; the free bodies' poses are their qpos rows -- the expressions of wave_fk -- and the state rows
+      //  leave meanwhile: nothing in them depends on the kinematics)
+      if (lane > 0 && lane < nb && bk.jtype == MIR_JNT_FREE) {
+        st3v(S.xpos[lane], ld3(&S.qpos[bk.qadr]));
+        st4v(S.xquat[lane], qnormalize(ld4(&S.qpos[bk.qadr + 3])));
+      }
+      if (a.mode == 0) {
+        a.qpos[(size_t)env * K64_QSTRIDE + lane] = S.qpos[lane];
+        a.qvel[(size_t)env * NL + lane] = S.qvel[lane];
+        a.qacc_ws[(size_t)env * NL + lane] = S.qacc_ws[lane];
+      }
+      if (a.action) a.target[(size_t)env * NL + lane] = S.target[lane];
+      WSYNC();
+      __syncthreads();  // (6)
+    } else {
+      wave_fk(S, lane, nb, bk);
+    }
     if (a.rows && a.rows_step && (step + 1 < nsteps || a.ar.episode_len) && lane < ad + ed + 2)  // rollout mode: one packed row per env per step
       a.rows[(size_t)step * a.rows_step + (size_t)env * a.row_stride + lane] = column(lane);
     if (a.ar.episode_len) {
@@ -1761,12 +1794,14 @@ void mir_step64_kernel(StepArgs64 a) {
   }
   if (lane == 0) a.fkvalid[env] = 1;
   // ---- store state ---------------------------------------------------------------------------------
-  if (a.mode == 0) {
-    a.qpos[(size_t)env * K64_QSTRIDE + lane] = S.qpos[lane];
-    a.qvel[(size_t)env * NL + lane] = S.qvel[lane];
-    a.qacc_ws[(size_t)env * NL + lane] = S.qacc_ws[lane];
+  if (!fk_split) {  // (with the split closing FK the state rows left while wave 1 ran the kinematics)
+    if (a.mode == 0) {
+      a.qpos[(size_t)env * K64_QSTRIDE + lane] = S.qpos[lane];
+      a.qvel[(size_t)env * NL + lane] = S.qvel[lane];
+      a.qacc_ws[(size_t)env * NL + lane] = S.qacc_ws[lane];
+    }
+    if (a.action) a.target[(size_t)env * NL + lane] = S.target[lane];
   }
-  if (a.action) a.target[(size_t)env * NL + lane] = S.target[lane];
   (void)nq;
   // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
   if (a.agent_pos && lane < ad) a.agent_pos[(size_t)env * ad + lane] = column(lane);
