@@ -562,12 +562,14 @@ void mir_step64_kernel(StepArgs64 a) {
     if (enable_collision) {
       // broadphase: bounding test per static candidate pair, ordered compaction of survivors (lane = pair)
       int base = 0;
+      bool any_plane = false, any_solid = false;  // wave-uniform: which narrowphase loops have anything to do
       for (int p0 = 0; p0 < npair; p0 += NL) {
         int p = p0 + lane;
-        bool hit = false;
+        bool hit = false, planepair = false;
         if (p < npair) {
           const int pr = (int)S.pairs[p];
           const int g1 = pr & 255, g2 = pr >> 8;
+          planepair = (__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE;
           V3 h2 = ld3(&S.gts[g2][1]);
           M3 R2 = q2m(ld4v(S.col.gquat[g2]));
           V3 c2 = ld3v(S.col.gpos[g2]);
@@ -626,13 +628,16 @@ void mir_step64_kernel(StepArgs64 a) {
         int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
         if (hit && pos < NL) S.col.cand[pos] = p;
         base += __popcll(bal);
+        any_plane = any_plane || __ballot(hit && planepair) != 0ull;
+        any_solid = any_solid || __ballot(hit && !planepair) != 0ull;
       }
       ncand = base < NL ? base : NL;
       if (lane == 0) S.ncand = ncand;
       WSYNC();
       STAMP(6);
       // narrowphase, plane-box: DPP row r takes candidates r, r + 4, ...; the 8 box corners on lanes 0..7 of the row
-      for (int k0 = 0; k0 < ncand; k0 += 4) {
+      // (skipped as a whole when no candidate has a plane: on the kitchen slab nothing reaches the floor)
+      if (any_plane) for (int k0 = 0; k0 < ncand; k0 += 4) {
         const int k = k0 + blk;
         const bool act = k < ncand;
         const int pr = act ? (int)S.pairs[S.col.cand[k]] : 0;
@@ -679,7 +684,7 @@ void mir_step64_kernel(StepArgs64 a) {
       STAMP(7);
       // narrowphase, box-box: DPP row r takes candidates r, r + 4, ... (like plane-box).  The 15 separating axes sit on
       // lanes 0..14 of the row, the incident-face vertices on lanes 0..3 (box_box_row, mir_dev.h)
-      for (int k0 = 0; k0 < ncand; k0 += 4) {
+      if (any_solid) for (int k0 = 0; k0 < ncand; k0 += 4) {
         const int k = k0 + blk;
         const bool actk = k < ncand;
         const int pr = actk ? (int)S.pairs[S.col.cand[k]] : 0;
