@@ -13,6 +13,7 @@
 
 #include "mir_model.h"
 #include "mir_scene.h"
+#include "mir_spec_pick.h"
 #include "mir_step.h"
 #include "mir_step64.h"
 
@@ -189,7 +190,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
     a.poses = o.poses ? h->poses : nullptr;
     a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
-    a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0);
+    a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0) | (h->spec_pick ? 4 : 0);
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
@@ -266,6 +267,7 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   HIPCHK(hipMalloc((void**)&h->done_ticket, 64));
   HIPCHK(hipMalloc((void**)&h->scratch_row, row_bytes));
   if (h->kernel == 16) HIPCHK(hipMalloc((void**)&h->pre, B * K16_PRE_STRIDE * sizeof(float)));
+  h->spec_pick = h->kernel == 16 && SpecPick::matches(h->hm) && !getenv("MIR_NO_SPEC");
   if (h->kernel == 64 && !getenv("MIR_NO_ORDER")) {  // dispatch-order flags of the wave kernel (mir_step64.h): two buffers, padded to whole 64-byte reads
     h->cost_stride = (int)(((B + 63) / 64) * 64);
     HIPCHK(hipMalloc((void**)&h->cost, 2 * (size_t)h->cost_stride));
@@ -673,6 +675,7 @@ extern "C" int mir_debug_rotated_launches(MirHandle h, const float* actions, int
 }
 
 int mir_get_split_step(MirHandle h) { return check(h) ? MIR_E_INVALID : (h->sync_mode == 2 ? 0 : h->split_step); }
+int mir_debug_spec_active(MirHandle h) { return check(h) ? MIR_E_INVALID : h->spec_pick; }
 
 int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream) {
   if (check(h) || !rows) return set_err(MIR_E_INVALID, "mir_step_packed: null argument");

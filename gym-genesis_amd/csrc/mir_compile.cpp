@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <cstring>
 #include <vector>
 
@@ -532,4 +533,33 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     for (int q = 0; q < 12; q++) memcpy(m.lanek_t[q][l], reinterpret_cast<const char*>(&k) + 16 * q, 16);
   }
   return MIR_OK;
+}
+
+// ---- scene constants for a specialised instantiation of the 16-lane kernel ------------------------------------------
+// The sizes and options of a compiled scene as a C++ struct of literals (`struct <name>`), plus `matches(const DevModel&)`:
+// mir_create runs the specialised instantiation only for a scene whose compiled model carries exactly these values, every other
+// scene runs the generic one.  tools/gen_scene_spec.py writes the headline scene's struct into mir_spec_pick.h (committed; a CPU
+// test regenerates and compares it).
+#define MIR_SPEC_FIELDS(X) \
+  X(nbody) X(nv) X(nq) X(ngeom) X(npair) X(max_contacts) X(enable_collision) X(iterations) X(ls_iterations) X(eef_body) X(obj_body) X(n_grip) \
+  X(gj_split) X(obj_qadr) X(use_sap) X(has_convex)
+extern "C" int mir_debug_emit_spec(const MirSceneSpec* spec, const char* name, char* out, int32_t cap) {
+  static DevModel m;  // (large: not on the stack)
+  HostConsts hc;
+  char err[256] = {0};
+  const int rc = mir_compile_model(spec, &m, &hc, err);
+  if (rc != MIR_OK) return rc;
+  std::string t = std::string("struct ") + name + " {\n";
+#define X(f) t += "  static constexpr int " #f " = " + std::to_string((int)m.f) + ";\n";
+  MIR_SPEC_FIELDS(X)
+#undef X
+  t += "  static constexpr int fk_free_leaf = " + std::to_string((int)m.fk_free_leaf) + ";\n";
+  t += "  static bool matches(const DevModel& m) {\n    return m.fk_free_leaf == (uint64_t)fk_free_leaf";
+#define X(f) t += " && m." #f " == " #f;
+  MIR_SPEC_FIELDS(X)
+#undef X
+  t += ";\n  }\n};\n";
+  if ((int)t.size() + 1 > cap) return MIR_E_CAPACITY;
+  memcpy(out, t.c_str(), t.size() + 1);
+  return (int)t.size();
 }

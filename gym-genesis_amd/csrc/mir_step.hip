@@ -42,6 +42,7 @@
 
 #include "mir_model.h"
 #include "mir_step.h"
+#include "mir_spec_pick.h"
 
 #define G MIR_G
 #include "mir_dev.h"
@@ -219,6 +220,7 @@ __device__ __forceinline__ void step_rows(float al, float j0, float j1, float j2
 // geoms' world AABBs instead of the static pair list (scenes whose static list would exceed K16_MAX_PAIR, e.g. with
 // self-collision enabled).  Scenes of planes and boxes with a short static list run the instantiation without either, whose
 // register allocation and schedule are therefore untouched by that code.
+// FEAT bit 2 (SPEC) = the headline scene: its sizes and options (SpecPick, mir_spec_pick.h) are literals instead of model reads.
 //
 // DUAL (the single-step instantiation): the workgroup has TWO waves.  Collision detection (geom poses, broadphase, narrowphase)
 // needs only the link poses, and so do the smooth dynamics (subspaces, CRB, RNE, mass matrix, smooth solve): wave 1 does the
@@ -245,7 +247,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   constexpr bool SINGLE = VARIANT == 0 || PRE || POST || ROT;
   constexpr bool DUAL = VARIANT == 0 || PRE || ROT;
   static_assert(JST == 52 && K16_PRE_STRIDE >= K16_PRE_JB + JST * MAXCON, "pre-buffer layout");
-  constexpr bool CONVEX = (FEAT & 1) != 0, SAP = (FEAT & 2) != 0;
+  constexpr bool CONVEX = (FEAT & 1) != 0, SAP = (FEAT & 2) != 0, SPEC = (FEAT & 4) != 0;
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
   __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
   // hull vertices (MIR_GEOM_HULL), convex instantiations only: what is left of the workgroup's 40 KB
@@ -280,17 +282,20 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   const int env = valid ? env_raw : a.B - 1;
   EnvLds& S = s_env[grp];
 
-  const int nb = m->nbody, nv = m->nv, qst = a.qst;
-  const int ngeom = m->ngeom, npair = m->npair, max_contacts = m->max_contacts, enable_collision = m->enable_collision;
+  // (SPEC: the headline scene's sizes and options are literals -- SpecPick, emitted by mir_compile into mir_spec_pick.h -- so
+  // `lane < nv`, the one-trip geom / pair loops and the solver dispatch fold at compile time)
+  const int nb = SPEC ? SpecPick::nbody : m->nbody, nv = SPEC ? SpecPick::nv : m->nv, qst = a.qst;
+  const int ngeom = SPEC ? SpecPick::ngeom : m->ngeom, npair = SPEC ? SpecPick::npair : m->npair;
+  const int max_contacts = SPEC ? SpecPick::max_contacts : m->max_contacts, enable_collision = SPEC ? SpecPick::enable_collision : m->enable_collision;
   const float dt = m->dt;
   // Every scalar of the model that the step reads is fetched HERE, with the first batch of loads.  A read through `m` further
   // down cannot be hoisted by the compiler above the wave fences that separate the phases, so it would sit where it is used
   // -- an L2 round trip in the middle of the serial chain (m->iterations was re-read in every Newton iteration).
-  const int mdl_iterations = m->iterations, mdl_ls_iterations = m->ls_iterations;
+  const int mdl_iterations = SPEC ? SpecPick::iterations : m->iterations, mdl_ls_iterations = SPEC ? SpecPick::ls_iterations : m->ls_iterations;
+  const int mdl_eef = SPEC ? SpecPick::eef_body : m->eef_body, mdl_obj = SPEC ? SpecPick::obj_body : m->obj_body, mdl_ngrip = SPEC ? SpecPick::n_grip : m->n_grip;
+  const int mdl_split = SPEC ? SpecPick::gj_split : m->gj_split;
   const float mdl_tolerance = m->tolerance, mdl_scale = m->solver_scale, mdl_reward_z = m->reward_z;
   const float mdl_gx = m->gx, mdl_gy = m->gy, mdl_gz = m->gz;
-  const int mdl_eef = m->eef_body, mdl_obj = m->obj_body, mdl_ngrip = m->n_grip;
-  const int mdl_split = m->gj_split;
   // ---- the scratch row of the split step, PACKED (it travels through HBM twice per env.step): a mass-matrix row keeps the
   // 16-byte quads of its own tree block only (9 + 6 dofs: 3 quads for the arm's rows, 2 for the cube's, 624 B instead of 1 KB), a
   // contact's three Jacobian rows keep the quads in which one of its two bodies has a dof (a cube on the floor: 2 of 4) and no
@@ -346,11 +351,12 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     }
   };
   // DUAL: the closing FK is split between the waves when every free-joint body is a childless child of the world (wave-uniform)
-  const bool fksplit = DUAL && m->fk_free_leaf != 0;
+  const bool fk_free_leaf = SPEC ? SpecPick::fk_free_leaf != 0 : m->fk_free_leaf != 0;
+  const bool fksplit = DUAL && fk_free_leaf;
   // the task's object is a free body hanging off the world: its height -- all that `terminated` needs -- is a qpos entry, final as
   // soon as the translations are integrated, so the host-visible bytes can leave before the closing FK (wave-uniform)
-  const int mdl_obj_qadr = m->obj_qadr;
-  const bool term_early = VARIANT != 1 && m->fk_free_leaf != 0 && mdl_obj_qadr >= 0;
+  const int mdl_obj_qadr = SPEC ? SpecPick::obj_qadr : m->obj_qadr;
+  const bool term_early = VARIANT != 1 && fk_free_leaf && mdl_obj_qadr >= 0;
 
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
   // (lane = candidate).  Needs the link poses and the model table in LDS, nothing else: in the DUAL instantiation the second
@@ -1876,12 +1882,14 @@ static void launch_feat(const StepArgs& a, int blocks, int single, int plain_loo
   else if (a.phase == 3) hipLaunchKernelGGL((mir_step_kernel<5, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
+  else if constexpr ((FEAT & 4) == 0) hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
 }
 extern "C" __attribute__((visibility("hidden"))) int mir_launch_step_convex(const StepArgs* args, int single, int plain_loop, hipStream_t stream) {
   StepArgs a = *args;
   const int blocks = (a.B + EPB - 1) / EPB;
-  if (a.features & 2) launch_feat<3>(a, blocks, single, plain_loop, stream);  // sweep-and-prune scenes carry the convex code too
+  // the headline scene's instantiation (features bit 2: mir_create found SpecPick::matches); the everything-variant stays generic
+  if ((a.features & 4) && (a.phase == 1 || a.phase == 3 || single || plain_loop)) launch_feat<5>(a, blocks, single, plain_loop, stream);
+  else if (a.features & 2) launch_feat<3>(a, blocks, single, plain_loop, stream);  // sweep-and-prune scenes carry the convex code too
   else launch_feat<1>(a, blocks, single, plain_loop, stream);
   return (int)hipGetLastError();
 }

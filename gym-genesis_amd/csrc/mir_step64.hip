@@ -467,6 +467,11 @@ void mir_step64_kernel(StepArgs64 a) {
   const int ngeom = m->ngeom, npair = m->npair, max_contacts = m->max_contacts, enable_collision = m->enable_collision;
   const float dt = m->dt;
   const uint64_t lanemask = m->lanemask;
+  // every scalar of the model that the step reads is fetched here, with the first batch of loads: a read through `m` further down
+  // cannot move above the barriers and sits where it is used -- a scalar-cache round trip in the middle of the serial chain
+  // (m->iterations was re-read in every Newton iteration, m->ls_iterations in every line-search evaluation)
+  const int mdl_iterations = m->iterations, mdl_ls_iterations = m->ls_iterations;
+  const float mdl_tolerance = m->tolerance, mdl_scale = m->solver_scale;
 
   // ---- per-lane model constants (lane = body = dof slot) ------------------------------------------
   const bool isbody = lane < nb && lane > 0;
@@ -1322,7 +1327,7 @@ void mir_step64_kernel(StepArgs64 a) {
     }
     STAMP(11);
     int niter = 0;
-    const float tol = m->tolerance, scale = m->solver_scale;
+    const float tol = mdl_tolerance, scale = mdl_scale;
     const float gfloor = 16.0f * 5.96e-8f * sqrtf(wsum(Ma * Ma + qfs * qfs));
     // which blocks can ever be coupled this step: contacts spanning two blocks, closed transitively (wave-uniform)
     unsigned comp = 0x8421u;  // every block with itself
@@ -1371,7 +1376,7 @@ void mir_step64_kernel(StepArgs64 a) {
     float oldlact = 0.0f;
     unsigned prevbits = 0u;
     float gprev = 0.0f;
-    for (int it = 0; it < m->iterations; it++) {
+    for (int it = 0; it < mdl_iterations; it++) {
       if (done) break;  // wave-uniform: one env per wave
       float lact = (lsg != 0.0f && ljar < 0.0f) ? lD : 0.0f;
       const float lf = -lact * ljar;
@@ -1599,7 +1604,7 @@ void mir_step64_kernel(StepArgs64 a) {
       const float A = wsum(sv * mv), Bq = wsum(sv * (Ma - qfs)), g0 = wsum(sv * g);
       bool lsdone = g0 >= 0.0f;
       float alpha = lsdone ? 0.0f : 1.0f, lo = 0.0f, hi = -1.0f;
-      for (int ls = 1; ls < m->ls_iterations && !lsdone; ls++) {
+      for (int ls = 1; ls < mdl_ls_iterations && !lsdone; ls++) {
         float pg = 0.0f, ph = 0.0f, pa = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {

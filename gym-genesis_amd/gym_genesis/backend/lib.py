@@ -79,6 +79,8 @@ def load_library() -> C.CDLL:
     lib.mir_forward.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.mir_debug_render_path.argtypes = [vp, i32, i32]
     lib.mir_debug_render_path.restype = C.c_int
+    lib.mir_debug_spec_active.argtypes = [vp]
+    lib.mir_debug_spec_active.restype = C.c_int
     lib.mir_render.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), i32, vp, vp, vp]
     lib.mir_render.restype = C.c_int
     lib.mir_visual_sizeof.restype = C.c_int
@@ -497,6 +499,11 @@ class MirScene(StepHelpers):
             off = self._f32(env_offset, 3)
         self._check(self.lib.mir_render(self.h, C.byref(cam), C.byref(vis), int(mode), _ptr(off), _ptr(out), self._stream()))
         return out
+
+    @property
+    def spec_active(self) -> bool:
+        """True when this scene runs the scene-specialised instantiation of the 16-lane kernel (mir_debug_spec_active)."""
+        return bool(self.lib.mir_debug_spec_active(self.h))
 
     def debug_render_path(self, generic: bool = False, strip_rows: int = 0) -> None:
         """mir_debug_render_path: force the generic pixel kernel / override the strip height for the following renders."""
