@@ -948,9 +948,11 @@ def worker(args) -> int:
                                                   "cannot be queued behind the running one: each step pays launch + dispatch + completion latency (the kernel stores the terminated bytes as soon as the object's height is integrated, ~1.5 us before it ends, so the measured step can come in slightly under kernel + round trip)"}
             except Exception as e:  # noqa: BLE001
                 out["sync_step_floor"] = {"error": f"{type(e).__name__}: {e}"}
+            # (the instantiation rocprofv3 lists: FEAT = 1 round geoms | 4 the headline scene's sizes as literals, csrc/mir_spec_pick.h)
+            feat = 5 if getattr(task._mir, "spec_active", False) else 1
             fused = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": _profile_number("pmc_hbm_traffic.json", "hbm_bytes_per_launch") if B == ENVS_PER_GPU else None,
-                     "kernel": "mir_step_kernel<0, true>", "kernel_us": kernel_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
+                     "kernel": f"mir_step_kernel<0, {feat}>", "kernel_us": kernel_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
                      "note": "489 algorithmic B/env-step x 4096 envs per launch (SURVEY.md 8d); kernel_us = HIP events over the "
                              "back-to-back raw launches of the same K-step region; the path is latency/occupancy-bound, not HBM-bound"}
             out["roofline"] = fused
@@ -985,7 +987,7 @@ def worker(args) -> int:
                     ach = ALGO_BYTES_PER_ENV_STEP * B / (rot_us * 1e-6) / 1e9
                     out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                        "traffic": _profile_number("pmc_hbm_traffic_api.json", "hbm_bytes_per_launch") if B == ENVS_PER_GPU else None,
-                                       "kernel": "mir_step_kernel<5, true>", "kernel_us": rot_us, "kernel_us_regions": rot_all, "kernel_us_without_outputs": rot_us_bare,
+                                       "kernel": f"mir_step_kernel<5, {feat}>", "kernel_us": rot_us, "kernel_us_regions": rot_all, "kernel_us_without_outputs": rot_us_bare,
                                        "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * B,
                                        "note": "the kernel of the headline loop: the rotated launch of GenesisEnv.step (this step's action-dependent "
                                                "half, then the next step's action-independent half through a 4.7 KB/env scratch row (~2.4 KB used), which is why its "
