@@ -189,6 +189,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.model = h->dm;
     a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
     a.poses = o.poses ? h->poses : nullptr;
+    a.pose_cache = h->poses; a.fkvalid = h->pose_cache_on ? h->fkvalid : nullptr;
     a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
     a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0) | (h->spec_pick ? 4 : 0);
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
@@ -268,6 +269,7 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   HIPCHK(hipMalloc((void**)&h->scratch_row, row_bytes));
   if (h->kernel == 16) HIPCHK(hipMalloc((void**)&h->pre, B * K16_PRE_STRIDE * sizeof(float)));
   h->spec_pick = h->kernel == 16 && SpecPick::matches(h->hm) && !getenv("MIR_NO_SPEC");
+  h->pose_cache_on = !getenv("MIR_NO_POSE_CACHE");
   if (h->kernel == 64 && !getenv("MIR_NO_ORDER")) {  // dispatch-order flags of the wave kernel (mir_step64.h): two buffers, padded to whole 64-byte reads
     h->cost_stride = (int)(((B + 63) / 64) * 64);
     HIPCHK(hipMalloc((void**)&h->cost, 2 * (size_t)h->cost_stride));

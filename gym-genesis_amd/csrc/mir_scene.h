@@ -23,6 +23,7 @@ struct MirScene {
   uint8_t* cost = nullptr;  // wave kernel: two buffers of per-env cost flags (B padded to 64 each) for the dispatch order, see mir_step64.h
   int cost_par = 0;         // which of the two the next single-step launch reads
   int cost_stride = 0;
+  int pose_cache_on = 1;    // 16-lane kernel: fused single-step launches open with the poses the previous one closed with (MIR_NO_POSE_CACHE=1: always FK)
   int spec_pick = 0;        // 16-lane kernel: the compiled model matches SpecPick (mir_spec_pick.h) and MIR_NO_SPEC is unset: specialised instantiation
   float* prims;     // render primitives (B, ngeom, 32) f32, allocated by the first mir_render
   int* bins = nullptr;      // per-strip primitive lists of the binned pixel kernel (grown on demand)

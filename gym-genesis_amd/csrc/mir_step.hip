@@ -906,12 +906,27 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // table, the other rows and the action), and the main wave finds the link poses ready when it reaches the first barrier.
       const float hq_lo = lane < a.qst ? a.qpos[(size_t)env * a.qst + lane] : 0.0f;
       const float hq_hi = lane + G < a.qst ? a.qpos[(size_t)env * a.qst + lane + G] : 0.0f;
+      // ... unless the previous launch was a fused step of the same env and nothing has touched its state since: then the poses it
+      // closed with are in the pose cache (fetched with the same batch of loads; group-uniform branch)
+      const bool use_cache = VARIANT == 0 && a.fkvalid != nullptr;
+      const int cvalid = use_cache ? a.fkvalid[env] : 0;
+      f4 cpos = {0, 0, 0, 0}, cquat = {0, 0, 0, 0};
+      if (use_cache) {
+        const float* p = a.pose_cache + ((size_t)env * 2 * G + lane) * 4;
+        cpos = *reinterpret_cast<const f4*>(p);
+        cquat = *reinterpret_cast<const f4*>(p + 4 * G);
+      }
       BodyK hk;
       fk_consts(hk);
       if (lane < a.qst) S.qpos[lane] = hq_lo;
       if (lane + G < a.qst) S.qpos[lane + G] = hq_hi;
-      WSYNC();
-      group_fk(S, lane, nb, hparents, hk, row4);
+      if (cvalid != 0) {
+        if (lane < nb) { stv(S.xpos[lane], cpos); stv(S.xquat[lane], cquat); }
+        WSYNC();
+      } else {
+        WSYNC();
+        group_fk(S, lane, nb, hparents, hk, row4);
+      }
     }
     HSTAMP(40);
     if (!ROT) __syncthreads();  // (1) link poses (this wave) and model table, velocities, targets (main wave) are in LDS
@@ -1112,6 +1127,21 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         for (int i = lane; i < qst; i += G) a.qpos[(size_t)env * qst + i] = S.qpos[i];
         a.qvel[(size_t)env * G + lane] = S.qvel[lane];
         a.qacc_ws[(size_t)env * G + lane] = S.qacc_ws[lane];
+        // the link poses of the state just stored: the fused single-step launch leaves them in the pose cache and opens with them
+        // instead of a forward kinematics (the collision wave's FK was what the main wave waited for at the first barrier); every
+        // other launch that advances the state marks the env's cache stale, as resets and state writes do (mir_api.hip)
+        if (a.fkvalid) {
+          if (VARIANT == 0) {
+            if (lane < nb) {
+              float* p = a.pose_cache + ((size_t)env * 2 * G + lane) * 4;
+              *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
+              *reinterpret_cast<f4*>(p + 4 * G) = ldv(S.xquat[lane]);
+            }
+            if (lane == 0) a.fkvalid[env] = 1;
+          } else if (lane == 0) {
+            a.fkvalid[env] = 0;
+          }
+        }
       }
       if (a.action) a.target[(size_t)env * G + lane] = S.target[lane];
       // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------

@@ -361,3 +361,62 @@ def test_pinned_host_inputs_are_copied_unless_they_come_from_staged(franka_spec)
         pinned.copy_(q0)
     st = sc.staged(np.zeros((B, 3), np.float32))
     assert st.is_pinned() and st.data_ptr() in sc._staged_ptrs
+
+
+def test_pose_cache_of_the_fused_launch_survives_everything_that_touches_the_state(franka_spec, monkeypatch):
+    """A fused single-step launch opens with the link poses the previous one closed with (pose cache + per-env fkvalid) instead of a
+    forward kinematics.  The cache is only good for the state that launch stored: resets (whole batch or masked), state writes,
+    rollouts, rotated / split launches and renders in between must either refresh it or mark it stale.  300 steps with all of
+    those mixed in, against a twin scene that always runs the forward kinematics (MIR_NO_POSE_CACHE=1): every output and the
+    final state bit-identical."""
+    from gym_genesis.backend.lib import MirScene
+    from gym_genesis.backend.spec import make_camera
+
+    B = 64
+    monkeypatch.setenv("MIR_SPLIT_STEP", "1")
+    sc = MirScene(franka_spec, B)
+    monkeypatch.setenv("MIR_NO_POSE_CACHE", "1")
+    monkeypatch.setenv("MIR_SPLIT_STEP", "0")
+    ref = MirScene(franka_spec, B)
+    _reset(sc, B)
+    _reset(ref, B)
+    g = np.random.default_rng(12)
+    acts = torch.as_tensor(g.uniform(-1, 1, (300, B, 9)).astype(np.float32), device=sc.device)
+    b1 = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    b2 = (ref.empty(9), ref.empty(11), ref.empty(), ref.empty(dtype=torch.uint8))
+    rows1 = torch.zeros((4, B, 22), device=sc.device)
+    rows2 = torch.zeros((4, B, 22), device=sc.device)
+    cam = make_camera(32, 24, (3.5, 0, 2.5), (0, 0, 0.5), 30)
+    vis = models.franka_cube_pick_scene().visual()
+    for t in range(300):
+        k = t % 41
+        if k == 5:      # reset of the whole batch
+            _reset(sc, B, seed=t); _reset(ref, B, seed=t)
+        elif k == 9:    # masked reset: the other envs keep their cached poses
+            mask = torch.as_tensor(g.integers(0, 2, B).astype(np.uint8), device=sc.device)
+            pos = np.stack([g.uniform(.45, .8, B), g.uniform(-.25, .25, B), np.full(B, .02)], 1).astype(np.float32)
+            quat = np.tile(np.array([1, 0, 0, 0], np.float32), (B, 1)); home = np.tile(HOME, (B, 1))
+            for s in (sc, ref):
+                s.reset(pos, quat, home, env_mask=mask)
+        elif k == 14:   # state written back with another qpos: the cached poses are those of the old one
+            q, v, tg, ws = sc.get_state()
+            q2 = q.clone(); q2[:, :7] += 0.01
+            for s in (sc, ref):
+                s.set_state(qpos=q2, qvel=v, target=tg, warmstart=ws)
+        elif k == 19:   # a rollout launch in between
+            sc.rollout(acts[:4].contiguous(), rows1); ref.rollout(acts[:4].contiguous(), rows2)
+            assert torch.equal(rows1, rows2)
+        elif k in (23, 24, 25):   # rotated launches (GenesisEnv.step's) between fused ones
+            sc.step_begin(acts[t], *b1); h = sc.step_end()
+            ref.step_fused(acts[t], *b2)
+            assert np.array_equal(h, b2[3].cpu().numpy().astype(bool))
+        elif k == 30:   # read-only visitors (the render refreshes the pose buffer through another launch)
+            sc.render(cam, vis); sc.get_links(); sc.get_obs()
+        elif k == 35:   # plain physics steps
+            sc.step(3); ref.step(3)
+        sc.step_fused(acts[t], *b1)
+        ref.step_fused(acts[t], *b2)
+        for x, y in zip(b1, b2):
+            assert torch.equal(x, y), f"step {t}"
+    for x, y in zip(sc.get_state(), ref.get_state()):
+        assert torch.equal(x, y)
