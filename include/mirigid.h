@@ -429,7 +429,7 @@ int mir_debug_render_path(MirHandle h, int32_t generic, int32_t strip_rows);
 /* host only (no GPU): the sizes and options of the compiled scene as the text of a C++ struct of literals, `struct <name>` with
  * a `matches(const DevModel&)` member -- the constants of a scene-specialised instantiation of the 16-lane step kernel
  * (csrc/mir_spec_pick.h is this text for the CubePick scene, written by tools/gen_scene_spec.py).  Returns the text length, or
- * MIR_E_* (MIR_E_CAPACITY: the scene belongs to the wave kernel, or cap is too small). */
+ * MIR_E_* (MIR_E_CAPACITY: the scene belongs to the wave kernel, or cap is too small).  A build-time tool: not thread-safe. */
 int mir_debug_emit_spec(const MirSceneSpec* spec, const char* name, char* out, int32_t cap);
 /* 1 if this handle's launches use the scene-specialised instantiation (its compiled model matched SpecPick and the environment
  * variable MIR_NO_SPEC was unset at mir_create), else 0 */
