@@ -190,6 +190,8 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
     a.poses = o.poses ? h->poses : nullptr;
     a.pose_cache = h->poses; a.fkvalid = h->pose_cache_on ? h->fkvalid : nullptr;
+    a.early_stats = h->early_stats; a.no_early_mask = h->no_early_mask;
+    a.term_wstride = h->term_wstride;
     a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
     a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0) | (h->spec_pick ? 4 : 0);
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
@@ -270,13 +272,23 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   if (h->kernel == 16) HIPCHK(hipMalloc((void**)&h->pre, B * K16_PRE_STRIDE * sizeof(float)));
   h->spec_pick = h->kernel == 16 && SpecPick::matches(h->hm) && !getenv("MIR_NO_SPEC");
   h->pose_cache_on = !getenv("MIR_NO_POSE_CACHE");
+  h->no_early_mask = getenv("MIR_NO_EARLY_MASK") ? 1 : 0;
+  HIPCHK(hipMalloc((void**)&h->early_stats, 2 * sizeof(uint32_t)));
+  HIPCHK(hipMemset(h->early_stats, 0, 2 * sizeof(uint32_t)));
   if (h->kernel == 64 && !getenv("MIR_NO_ORDER")) {  // dispatch-order flags of the wave kernel (mir_step64.h): two buffers, padded to whole 64-byte reads
     h->cost_stride = (int)(((B + 63) / 64) * 64);
     HIPCHK(hipMalloc((void**)&h->cost, 2 * (size_t)h->cost_stride));
     HIPCHK(hipMemset(h->cost, 0, 2 * (size_t)h->cost_stride));
   }
   // pinned, device-mapped, coherent host memory for the API's host-visible outputs: terminated bytes + completion word
-  const size_t pin_bytes = ((B + 63) / 64) * 64 + 64;  // (whole 32-bit words for the packed stores of the 16-lane kernel)
+  // 16-lane kernel: every workgroup (4 envs) owns a whole 64-byte line of the area.  Sixteen workgroups storing their 4 bytes into one
+  // line -- sixteen partial writes over PCIe into a line the polling CPU holds -- cost the launch that follows 1.6 us and now and then
+  // several (tools/probes/launch/late_enqueue3.hip: idle gap between two kernels 4.7 us with 16, 8 or 4 writers per line, 3.9 with two,
+  // 3.05 with one = as with no host stores at all); MIR_TERM_DENSE=1 keeps the dense layout
+  h->term_wstride = h->kernel == 16 ? (getenv("MIR_TERM_DENSE") ? 1 : 16) : 0;
+  h->pin_flag_off = h->term_wstride ? ((B + 3) / 4) * 4 * (size_t)h->term_wstride : ((B + 63) / 64) * 64;
+  h->pin_flag_off = (h->pin_flag_off + 63) / 64 * 64;
+  const size_t pin_bytes = h->pin_flag_off + 64;
   HIPCHK(hipHostMalloc((void**)&h->pin_host, pin_bytes, hipHostMallocMapped | hipHostMallocCoherent));
   memset(h->pin_host, 0, pin_bytes);
   HIPCHK(hipHostGetDevicePointer((void**)&h->pin_dev, h->pin_host, 0));
@@ -427,6 +439,7 @@ int mir_destroy(MirHandle h) {
   if (h->diag) (void)hipFree(h->diag);
   if (h->poses) (void)hipFree(h->poses);
   if (h->fkvalid) (void)hipFree(h->fkvalid);
+  if (h->early_stats) (void)hipFree(h->early_stats);
   if (h->prims) (void)hipFree(h->prims);
   if (h->cost) (void)hipFree(h->cost);
   if (h->bins) (void)hipFree(h->bins);
@@ -518,7 +531,7 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
     if (rc != MIR_OK) return rc;
   }
   DeviceGuard guard(h->device);
-  uint32_t* flag_dev = reinterpret_cast<uint32_t*>(h->pin_dev + ((size_t)(h->B + 63) / 64) * 64);
+  uint32_t* flag_dev = reinterpret_cast<uint32_t*>(h->pin_dev + h->pin_flag_off);
   Outs o;
   o.action = action; o.agent_pos = agent_pos; o.env_state = env_state; o.reward = reward; o.terminated = terminated;
   o.term_host = h->pin_dev;
@@ -584,12 +597,40 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
   if (check(h)) return MIR_E_INVALID;
   if (!h->pending) return set_err(MIR_E_INVALID, "mir_step_end without mir_step_begin");
   h->pending = 0;
-  volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->pin_host + ((size_t)(h->B + 63) / 64) * 64);
+  volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->pin_host + h->pin_flag_off);
   const uint8_t* bytes = h->pin_host;
   const size_t B = (size_t)h->B;
   if (h->sync_mode == 0) {
     DeviceGuard guard(h->device);
     HIPCHK(hipStreamSynchronize((hipStream_t)h->pending_stream));
+  } else if (h->sync_mode == 3 && h->term_wstride) {
+    // 16-lane kernel: one 32-bit word (4 envs) per workgroup, `term_wstride` words apart; every byte carries this launch's tag.  One
+    // pass: wait for a word, take its bits, go on to the next (the pointer stands still at the first workgroup that has not delivered)
+    const uint32_t want4 = 0x01010101u * (uint8_t)h->tag, tagm4 = 0x7f7f7f7fu;
+    const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(bytes);
+    const size_t nwg = (B + 3) / 4, ws = (size_t)h->term_wstride;
+    unsigned long polls = 0;
+    for (size_t g = 0; g < nwg;) {
+      uint32_t v = w[g * ws];
+      if (((v >> 1) & tagm4) == want4) {
+        if (terminated_host) {
+          v &= 0x01010101u;
+          memcpy(terminated_host + 4 * g, &v, 4 * g + 4 <= B ? 4 : B - 4 * g);
+        }
+        g++;
+        continue;
+      }
+      __builtin_ia32_pause();
+      if ((++polls & 0xfffffu) == 0) {
+        DeviceGuard guard(h->device);
+        hipError_t e = hipStreamQuery((hipStream_t)h->pending_stream);
+        if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "mir_step_end: stream");
+        if (e == hipSuccess && polls > 0x4000000u)
+          return set_err(MIR_E_HIP, "mir_step_end: the launch finished without delivering its terminated bytes");
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return MIR_OK;
   } else if (h->sync_mode == 3) {
     // the bytes announce themselves: wait until every one of them carries this launch's tag
     // (a pointer that walks the buffer once, eight bytes at a time: it stands still at the first workgroup that has not delivered
@@ -629,7 +670,13 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
       }
     }
   }
-  if (terminated_host) {
+  if (terminated_host && h->term_wstride) {  // (sync modes 0 - 2 on the 16-lane kernel: one word per workgroup, term_wstride words apart)
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(bytes);
+    for (size_t g = 0; 4 * g < B; g++) {
+      const uint32_t v = w[g * (size_t)h->term_wstride] & 0x01010101u;
+      memcpy(terminated_host + 4 * g, &v, 4 * g + 4 <= B ? 4 : B - 4 * g);
+    }
+  } else if (terminated_host) {
     size_t i = 0;
     for (; i + 8 <= B; i += 8) {
       uint64_t v;
@@ -678,6 +725,14 @@ extern "C" int mir_debug_rotated_launches(MirHandle h, const float* actions, int
 
 int mir_get_split_step(MirHandle h) { return check(h) ? MIR_E_INVALID : (h->sync_mode == 2 ? 0 : h->split_step); }
 int mir_debug_spec_active(MirHandle h) { return check(h) ? MIR_E_INVALID : h->spec_pick; }
+int mir_debug_early_mask_stats(MirHandle h, uint32_t* out2, int32_t reset, void* stream) {
+  if (check(h) || !out2) return set_err(MIR_E_INVALID, "mir_debug_early_mask_stats: null argument");
+  DeviceGuard guard(h->device);
+  HIPCHK(hipMemcpyAsync(out2, h->early_stats, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  if (reset) HIPCHK(hipMemsetAsync(h->early_stats, 0, 2 * sizeof(uint32_t), (hipStream_t)stream));
+  return MIR_OK;
+}
 
 int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream) {
   if (check(h) || !rows) return set_err(MIR_E_INVALID, "mir_step_packed: null argument");
@@ -748,7 +803,7 @@ extern "C" int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream
   if (iters <= 0) return set_err(MIR_E_INVALID, "mir_debug_null_roundtrip: bad argument");
   if (h->pending) return set_err(MIR_E_INVALID, "mir_debug_null_roundtrip: a step is pending");
   DeviceGuard guard(h->device);
-  const size_t off = ((size_t)(h->B + 63) / 64) * 64;
+  const size_t off = h->pin_flag_off;
   uint32_t* flag_dev = reinterpret_cast<uint32_t*>(h->pin_dev + off);
   volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->pin_host + off);
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));

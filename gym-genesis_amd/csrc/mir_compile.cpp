@@ -497,6 +497,30 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
     if (sp->body[b].jtype == MIR_JNT_FREE && fk_parent[b] != 0) m.fk_free_leaf = 0;
     if (fk_parent[b] > 0 && sp->body[fk_parent[b]].jtype == MIR_JNT_FREE) m.fk_free_leaf = 0;
   }
+  // ---- weights of the early-mask bound (mir_model.h: term_bound_ok): Mt >= blockdiag(diag(d_mdiag) over jointed dofs, free bodies) ----
+  float gw[MIR_G];
+  {
+    bool ok = m.fk_free_leaf != 0 && m.obj_qadr >= 0;
+    for (int l = 0; l < MIR_G; l++) gw[l] = 0.0f;
+    for (int l = 0; l < nv && ok; l++) {
+      const int b = m.d_body[l];
+      if (m.d_kind[l] < 2) {
+        if (m.d_mdiag[l] > 0.0f) gw[l] = 1.0f / m.d_mdiag[l];
+        else ok = false;
+      } else {
+        // free body: translations and rotations decouple when the centre of mass is the body origin; lowest eigenvalue of the
+        // rotational inertia bounded from below by Gershgorin
+        const float* I = m.b_inertia[b];
+        const float lo = fminf(fminf(I[0] - fabsf(I[3]) - fabsf(I[4]), I[1] - fabsf(I[3]) - fabsf(I[5])), I[2] - fabsf(I[4]) - fabsf(I[5]));
+        if (m.b_ipos[b][0] != 0.0f || m.b_ipos[b][1] != 0.0f || m.b_ipos[b][2] != 0.0f || !(m.b_mass[b] > 0.0f) || !(lo > 0.0f)) ok = false;
+        else gw[l] = m.d_kind[l] == 2 ? 1.0f / m.b_mass[b] : 1.0f / lo;
+      }
+    }
+    m.term_bound_ok = ok ? 1 : 0;
+    m.term_zlane = ok ? m.b_dofadr[m.obj_body] + 2 : 0;
+    m.term_zscale = ok ? 1.0f / sqrtf(m.b_mass[m.obj_body]) : 0.0f;
+    m.pad_term = 0.0f;
+  }
   for (int l = 0; l < MIR_G; l++) {
     LaneK16 k;
     memset(&k, 0, sizeof k);
@@ -530,6 +554,7 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
       }
       k.scan = (d_par & 255) | ((d_bef & 255) << 8) | ((b_last & 255) << 16) | ((b_next & 255) << 24);
     }
+    k.d_gw = gw[l];
     for (int q = 0; q < 12; q++) memcpy(m.lanek_t[q][l], reinterpret_cast<const char*>(&k) + 16 * q, 16);
   }
   return MIR_OK;

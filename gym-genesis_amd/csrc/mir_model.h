@@ -58,7 +58,8 @@ struct LaneK16 {
   uint32_t d_premask, d_ancmask; int32_t d_limited /* limited && enable_joint_limit && dof exists */; float d_damping;
   float d_kp, d_kv, d_frclo, d_frchi;
   float d_mdiag; int32_t obs_qadr /* qpos address behind agent_pos column `lane` (gripper columns), else 0 */;
-  int32_t scan /* bytes: d_par, d_bef, b_last (signed, -1 = none), b_next (lane behind the body's subtree, 16 = none) */, pad1;
+  int32_t scan /* bytes: d_par, d_bef, b_last (signed, -1 = none), b_next (lane behind the body's subtree, 16 = none) */;
+  float d_gw /* 1 / (a lower bound of the regularised mass matrix along this dof): weight of g_i^2 in the early-mask bound, see DevModel::term_bound_ok */;
 };
 static_assert(sizeof(LaneK16) == 12 * 16, "LaneK16 is read as twelve 16-byte quantities");
 
@@ -110,6 +111,15 @@ struct DevModel {
   int32_t nvert;       // hull vertices in use (MIR_GEOM_HULL geoms: g_size = first vertex, count, -)
   float hverts[K16_MAX_VERT][4];  // the scene's hull vertex pool, geom frames (16-byte rows: copied into LDS by the convex instantiations)
   float g_bbox[K16_MAX_GEOM][3];  // hull geoms: half extents of the vertices' bounding box (what the rasteriser draws)
+  // ---- early `terminated` bytes (mir_step.hip: the mask leaves before the solver has converged when it provably cannot change) ----
+  // The solver minimises f(a) = 1/2 (a - a_s)^T Mt (a - a_s) + convex row penalties, 1-strongly convex in the Mt norm, so an iterate
+  // with gradient g is within |g|_{Mt^-1} of the minimiser, and Mt >= blockdiag(diag(d_mdiag) over the jointed dofs, the free bodies'
+  // own inertias): |g|^2_{Mt^-1} <= sum_i d_gw_i g_i^2.  The object's height after the step moves by dt^2 times its vertical
+  // acceleration, whose distance from the minimiser's is at most term_zscale = 1 / sqrt(mass) times that norm.
+  int32_t term_bound_ok;  // the bound exists: the object is a free body with its centre of mass at its origin, a childless child of the world, and every dof has a weight
+  int32_t term_zlane;     // dof (= lane) of the object's vertical translation
+  float term_zscale;      // 1 / sqrt(object mass)
+  float pad_term;
 };
 
 struct HostConsts {

@@ -50,6 +50,11 @@ struct StepArgs {
   // `pre`.  3 = 2 followed by 1 (of the next step) in one launch.  `pre`: K16_PRE_STRIDE floats per env.
   int phase;
   float* pre;
+  // early terminated bytes (mir_step.hip, mir_model.h: term_bound_ok): [0] workgroups that sent their bytes from inside the solver loop
+  // (counted while diagnostics are on), [1] workgroups whose early bytes differed from the integrated state (always counted; must be 0)
+  uint32_t* early_stats;
+  int no_early_mask;  // MIR_NO_EARLY_MASK=1: the bytes always wait for the integrator
+  int term_wstride;   // 32-bit words between the term_host words of consecutive workgroups (mir_scene.h)
 };
 #define K16_PRE_MROW 0     /* 16 lanes x 16: rows of the regularised mass matrix */
 #define K16_PRE_BIAS 256   /* 16: qfrc_bias */

@@ -66,6 +66,11 @@ static_assert(MAXCON == G, "lane c owns contact c");
 #define ITSTAMP(it, k) do { } while (0)
 #endif
 
+#ifdef MIR_PROFILE_SINGLE
+#define TERMSTAMP() do { if (a.prof && threadIdx.x == 0 && (blockIdx.x & 7) == (unsigned)(prof_blk & 7)) atomicMax(&a.prof[130], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#else
+#define TERMSTAMP() do { } while (0)
+#endif
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -357,6 +362,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   // soon as the translations are integrated, so the host-visible bytes can leave before the closing FK (wave-uniform)
   const int mdl_obj_qadr = SPEC ? SpecPick::obj_qadr : m->obj_qadr;
   const bool term_early = VARIANT != 1 && fk_free_leaf && mdl_obj_qadr >= 0;
+  // ... and before the solver has converged where the mask provably cannot change any more (see mir_model.h: term_bound_ok)
+  const bool term_bound = (VARIANT == 0 || VARIANT == 5) && term_early && m->term_bound_ok != 0 && a.term_host != nullptr && !a.no_early_mask;
+  const int term_zlane = m->term_zlane;
+  const float term_zscale = m->term_zscale;
 
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
   // (lane = candidate).  Needs the link poses and the model table in LDS, nothing else: in the DUAL instantiation the second
@@ -999,6 +1008,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   const bool d_limited = __float_as_int(lk[9].z) != 0;
   const float d_damping = lk[9].w, d_kp = lk[10].x, d_kv = lk[10].y, d_frclo = lk[10].z, d_frchi = lk[10].w, d_mdiag = lk[11].x;
   const int obs_qadr = __float_as_int(lk[11].y);
+  const float d_gw = lk[11].w;
   // tree-scan links (mir_compile.cpp): scan parent of the dof, the dof whose inclusive sum is the velocity in front of this
   // dof, the last dof that moves this body, the lane behind this body's subtree (bytes of one word; 255 = none)
   const int scanw = __float_as_int(lk[11].z);
@@ -1112,7 +1122,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       const unsigned long long tb = __ballot(term_now && lane == 0);
       if (tid == 0) {
         const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + (size_t)blockIdx.x * a.term_wstride, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
@@ -1529,6 +1539,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
 #pragma unroll
     for (int j = 0; j < G; j++) hkeep[j] = isdof ? mrow[j] : (j == lane ? 1.0f : 0.0f);
     float oldlact = 0.0f;
+    bool term_sent = false;    // (wave-uniform) the terminated bytes of this step have left, from inside the solver loop
+    uint32_t term_bits = 0u;
     unsigned prevbits = 0u;  // contact lane: flags written in the previous iteration
     float gprev = 0.0f;
     bool met4 = false;
@@ -1577,6 +1589,33 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       if (!isdof) g = 0.0f;
       if (it == 0) STAMP(17);
       ITSTAMP(it, 1);
+      if (term_bound && !term_sent) {
+        // ---- the host-visible terminated bytes, as soon as they cannot change: the iterate is within |g|_{Mt^-1} of the minimiser and
+        // the final iterate within sqrt(2) times that (the cost never increases), so the object's vertical acceleration is within
+        // (1 + sqrt 2) / sqrt(mass) |g|_{Mt^-1} of its final value, and |g|^2_{Mt^-1} <= sum_i d_gw_i g_i^2.  Where no contact joins
+        // the arm and the object the problem separates and the object's own dofs suffice.  The height the current iterate predicts
+        // (same two fused multiply-adds as the integrator below) must be farther from the threshold than dt^2 times that bound --
+        // doubled, plus 1 m/s^2 for the solver's own tolerance, plus 1e-5 m -- for all four envs of the wave; otherwise the bytes
+        // wait for the next iteration, or for the integrator.  A cube at rest on the floor qualifies at the first gradient.
+        const float wg = d_gw * g * g;
+        const float sall = gsum(wg), sobj = gsum(lane >= mdl_split ? wg : 0.0f);
+        const float gm = sqrtf((mdl_split > 0 && S.coupled == 0) ? sobj : sall);
+        const float az = lane_gather(row4 + (term_zlane << 2), qacc);
+        const float zp = S.qpos[mdl_obj_qadr + 2] + dt * (S.qvel[term_zlane] + dt * az);
+        const float slack = 2.0f * dt * dt * (2.4142137f * term_zscale * gm + 1.0f) + 1e-5f;
+        const bool decided = !valid || fabsf(zp - mdl_reward_z) > slack;
+        if (!__any(!decided)) {
+          const unsigned long long tb = __ballot(valid && zp > mdl_reward_z && lane == 0);
+          term_bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
+          if (tid == 0)
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + (size_t)blockIdx.x * a.term_wstride, term_bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+          term_sent = true;
+          TERMSTAMP();
+          if (a.early_stats && a.diag && tid == 0) atomicAdd(a.early_stats, 1u);  // (diagnostics on: how many workgroups sent early)
+          STAMP(30);
+        }
+      }
       const float gn = sqrtf(gsum(g * g));
       if (!done && (scale * gn < tol || gn < gfloor)) done = true;
       if (it == 0) STAMP(14);
@@ -1781,10 +1820,14 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       const unsigned long long tb = __ballot(tn && lane == 0);
       if (tid == 0) {
         const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
+        // (bytes that left from inside the solver loop are checked against the integrated state: a difference would mean the bound
+        //  was violated -- it is counted, mir_debug_early_mask_stats, and the right bytes are stored over the wrong ones)
+        if (!term_sent || bits != term_bits)
+          __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + (size_t)blockIdx.x * a.term_wstride, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+        if (term_sent && bits != term_bits && a.early_stats) atomicAdd(a.early_stats + 1, 1u);
       }
-      STAMP(30);
+      if (!term_sent) { STAMP(30); TERMSTAMP(); }
     }
     if (fksplit) {
       WSYNC();

@@ -81,6 +81,8 @@ def load_library() -> C.CDLL:
     lib.mir_debug_render_path.restype = C.c_int
     lib.mir_debug_spec_active.argtypes = [vp]
     lib.mir_debug_spec_active.restype = C.c_int
+    lib.mir_debug_early_mask_stats.argtypes = [vp, C.POINTER(C.c_uint32), i32, vp]
+    lib.mir_debug_early_mask_stats.restype = C.c_int
     lib.mir_render.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), i32, vp, vp, vp]
     lib.mir_render.restype = C.c_int
     lib.mir_visual_sizeof.restype = C.c_int
@@ -504,6 +506,13 @@ class MirScene(StepHelpers):
     def spec_active(self) -> bool:
         """True when this scene runs the scene-specialised instantiation of the 16-lane kernel (mir_debug_spec_active)."""
         return bool(self.lib.mir_debug_spec_active(self.h))
+
+    def early_mask_stats(self, reset: bool = False):
+        """(workgroups that sent their terminated bytes from inside the solver loop -- counted while diagnostics are on --,
+        workgroups whose early bytes differed from the integrated state: must be 0) -- mir_debug_early_mask_stats."""
+        out = (C.c_uint32 * 2)()
+        self._check(self.lib.mir_debug_early_mask_stats(self.h, out, 1 if reset else 0, self._stream()))
+        return int(out[0]), int(out[1])
 
     def debug_render_path(self, generic: bool = False, strip_rows: int = 0) -> None:
         """mir_debug_render_path: force the generic pixel kernel / override the strip height for the following renders."""

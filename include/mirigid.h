@@ -434,6 +434,12 @@ int mir_debug_emit_spec(const MirSceneSpec* spec, const char* name, char* out, i
 /* 1 if this handle's launches use the scene-specialised instantiation (its compiled model matched SpecPick and the environment
  * variable MIR_NO_SPEC was unset at mir_create), else 0 */
 int mir_debug_spec_active(MirHandle h);
+/* 16-lane kernel, mir_step_begin / mir_step_go launches: the terminated bytes leave from inside the solver loop as soon as a
+ * convexity bound says the object's height cannot reach the threshold whatever the remaining iterations do (csrc/mir_model.h:
+ * term_bound_ok; MIR_NO_EARLY_MASK=1 at mir_create switches it off).  out2[0] = workgroups that sent early (counted while
+ * diagnostics are on, mir_set_diag), out2[1] = workgroups whose early bytes differed from the integrated state (always counted;
+ * anything but 0 is a bug).  Synchronises the stream; reset != 0 clears the counters. */
+int mir_debug_early_mask_stats(MirHandle h, uint32_t* out2, int32_t reset, void* stream);
 
 #ifdef __cplusplus
 }

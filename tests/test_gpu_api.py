@@ -420,3 +420,48 @@ def test_pose_cache_of_the_fused_launch_survives_everything_that_touches_the_sta
             assert torch.equal(x, y), f"step {t}"
     for x, y in zip(sc.get_state(), ref.get_state()):
         assert torch.equal(x, y)
+
+
+def test_early_terminated_bytes_equal_the_integrated_mask(franka_spec, monkeypatch):
+    """The terminated bytes of a mir_step_begin launch leave from inside the solver loop once a convexity bound says the object's height
+    cannot reach the threshold any more (csrc/mir_model.h: term_bound_ok).  Against a twin scene that always waits for the integrator
+    (MIR_NO_EARLY_MASK=1) and stores them densely (MIR_TERM_DENSE=1): the host masks agree step for step -- random actions, cubes
+    falling through the threshold, cubes thrown up through it, hands pushing cubes -- the kernel's own check counts no workgroup
+    whose early bytes differed from the integrated state, and most workgroups did send early."""
+    from gym_genesis.backend.lib import MirScene
+
+    B = 1024
+    monkeypatch.setenv("MIR_SPLIT_STEP", "1")
+    sc = MirScene(franka_spec, B)
+    monkeypatch.setenv("MIR_NO_EARLY_MASK", "1")
+    monkeypatch.setenv("MIR_TERM_DENSE", "1")
+    ref = MirScene(franka_spec, B)
+    sc.set_diag(True)
+    g = np.random.default_rng(21)
+    acts = torch.as_tensor(g.uniform(-1, 1, (64, B, 9)).astype(np.float32), device=sc.device)
+    b1 = (sc.empty(9), sc.empty(11), sc.empty(), sc.empty(dtype=torch.uint8))
+    b2 = (ref.empty(9), ref.empty(11), ref.empty(), ref.empty(dtype=torch.uint8))
+    seen_true = seen_false = 0
+    sc.early_mask_stats(reset=True)
+    for phase in range(4):
+        _reset(sc, B, seed=phase); _reset(ref, B, seed=phase)          # (every other cube starts above the threshold and falls through it)
+        if phase >= 2:                                                  # cubes thrown upwards from the floor: they cross it on the way up
+            q, v, tg, ws = sc.get_state()
+            v2 = v.clone(); v2[1::4, 11] = 2.5 + 0.5 * phase
+            for s in (sc, ref):
+                s.set_state(qpos=q, qvel=v2, target=tg, warmstart=ws)
+        for t in range(60):
+            a = acts[(17 * phase + t) % 64]
+            sc.step_begin(a, *b1); h1 = sc.step_end()
+            ref.step_begin(a, *b2); h2 = ref.step_end()
+            assert np.array_equal(h1, h2), f"phase {phase} step {t}"
+            assert np.array_equal(h1, b1[3].cpu().numpy().astype(bool))
+            for x, y in zip(b1, b2):
+                assert torch.equal(x, y)
+            seen_true += int(h1.sum()); seen_false += int((~h1).sum())
+    early, bad = sc.early_mask_stats()
+    assert bad == 0
+    assert seen_true > 100 and seen_false > 100
+    assert early > 0.3 * 4 * 60 * (B // 4)   # (workgroup-launches that sent early; the rest converge at the first gradient and store after the integrator)
+    for x, y in zip(sc.get_state(), ref.get_state()):
+        assert torch.equal(x, y)

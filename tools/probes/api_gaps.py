@@ -22,7 +22,7 @@ else:
     import csv
     import numpy as np
     f = glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "mir_step_kernel<5" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "mir_step_kernel<" in r["Kernel_Name"]]
     s = np.array([int(r["Start_Timestamp"]) for r in rows], dtype=np.int64)
     e = np.array([int(r["End_Timestamp"]) for r in rows], dtype=np.int64)
     o = np.argsort(s); s, e = s[o], e[o]

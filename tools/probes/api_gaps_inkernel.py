@@ -39,9 +39,10 @@ for rep in range(60):
     start, end = P[:, 26], P[:, 31]
     if (start == 0).any():
         continue
-    res.append(np.concatenate([(end - start) / 100.0, (start[1:] - end[:-1]) / 100.0, (start[1:] - start[:-1]) / 100.0]))
+    res.append(np.concatenate([(end - start) / 100.0, (start[1:] - end[:-1]) / 100.0, (start[1:] - start[:-1]) / 100.0, (P[:, 130] - start) / 100.0]))
 R = np.array(res)
 print(f"split_step {mir.split_step}; {len(R)} samples of {NP} consecutive launches (us)")
 print("  duration       ", np.round(R[:, :NP].mean(0), 2), " mean", round(R[:, 1:NP - 1].mean(), 2))
 print("  gap to the next", np.round(R[:, NP:2 * NP - 1].mean(0), 2), " mean", round(R[:, NP + 1:2 * NP - 1].mean(), 2))
-print("  start to start ", np.round(R[:, 2 * NP - 1:].mean(0), 2))
+print("  start to start ", np.round(R[:, 2 * NP - 1:3 * NP - 2].mean(0), 2))
+print("  last terminated store of the XCD after the start", np.round(R[:, 3 * NP - 2:].mean(0), 2))
