@@ -516,6 +516,8 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
         else gw[l] = m.d_kind[l] == 2 ? 1.0f / m.b_mass[b] : 1.0f / lo;
       }
     }
+    // (1 / object mass folded into the weights: the kernel needs sqrt(sum_i gw_i g_i^2) = |g|_{Mt^-1} / sqrt(mass) only)
+    for (int l = 0; l < MIR_G; l++) gw[l] = ok ? gw[l] / m.b_mass[m.obj_body] : 0.0f;
     m.term_bound_ok = ok ? 1 : 0;
     m.term_zlane = ok ? m.b_dofadr[m.obj_body] + 2 : 0;
     m.term_zscale = ok ? 1.0f / sqrtf(m.b_mass[m.obj_body]) : 0.0f;
@@ -567,7 +569,7 @@ int mir_compile_model(const MirSceneSpec* sp, DevModel* out, HostConsts* hc, cha
 // test regenerates and compares it).
 #define MIR_SPEC_FIELDS(X) \
   X(nbody) X(nv) X(nq) X(ngeom) X(npair) X(max_contacts) X(enable_collision) X(iterations) X(ls_iterations) X(eef_body) X(obj_body) X(n_grip) \
-  X(gj_split) X(obj_qadr) X(use_sap) X(has_convex)
+  X(gj_split) X(obj_qadr) X(use_sap) X(has_convex) X(term_zlane)
 extern "C" int mir_debug_emit_spec(const MirSceneSpec* spec, const char* name, char* out, int32_t cap) {
   static DevModel m;  // (large: not on the stack)
   HostConsts hc;

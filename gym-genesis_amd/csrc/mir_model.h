@@ -59,7 +59,7 @@ struct LaneK16 {
   float d_kp, d_kv, d_frclo, d_frchi;
   float d_mdiag; int32_t obs_qadr /* qpos address behind agent_pos column `lane` (gripper columns), else 0 */;
   int32_t scan /* bytes: d_par, d_bef, b_last (signed, -1 = none), b_next (lane behind the body's subtree, 16 = none) */;
-  float d_gw /* 1 / (a lower bound of the regularised mass matrix along this dof): weight of g_i^2 in the early-mask bound, see DevModel::term_bound_ok */;
+  float d_gw /* 1 / (a lower bound of the regularised mass matrix along this dof x the object's mass): weight of g_i^2 in the early-mask bound, see DevModel::term_bound_ok */;
 };
 static_assert(sizeof(LaneK16) == 12 * 16, "LaneK16 is read as twelve 16-byte quantities");
 

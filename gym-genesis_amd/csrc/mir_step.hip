@@ -363,9 +363,12 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   const int mdl_obj_qadr = SPEC ? SpecPick::obj_qadr : m->obj_qadr;
   const bool term_early = VARIANT != 1 && fk_free_leaf && mdl_obj_qadr >= 0;
   // ... and before the solver has converged where the mask provably cannot change any more (see mir_model.h: term_bound_ok)
+#ifdef MIR_NO_EARLY_CODE  /* (A/B builds: the early-mask code compiled out) */
+  constexpr bool term_bound = false;
+#else
   const bool term_bound = (VARIANT == 0 || VARIANT == 5) && term_early && m->term_bound_ok != 0 && a.term_host != nullptr && !a.no_early_mask;
-  const int term_zlane = m->term_zlane;
-  const float term_zscale = m->term_zscale;
+#endif
+  const int term_zlane = SPEC ? SpecPick::term_zlane : m->term_zlane;
 
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
   // (lane = candidate).  Needs the link poses and the model table in LDS, nothing else: in the DUAL instantiation the second
@@ -1008,7 +1011,6 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   const bool d_limited = __float_as_int(lk[9].z) != 0;
   const float d_damping = lk[9].w, d_kp = lk[10].x, d_kv = lk[10].y, d_frclo = lk[10].z, d_frchi = lk[10].w, d_mdiag = lk[11].x;
   const int obs_qadr = __float_as_int(lk[11].y);
-  const float d_gw = lk[11].w;
   // tree-scan links (mir_compile.cpp): scan parent of the dof, the dof whose inclusive sum is the velocity in front of this
   // dof, the last dof that moves this body, the lane behind this body's subtree (bytes of one word; 255 = none)
   const int scanw = __float_as_int(lk[11].z);
@@ -1541,6 +1543,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     float oldlact = 0.0f;
     bool term_sent = false;    // (wave-uniform) the terminated bytes of this step have left, from inside the solver loop
     uint32_t term_bits = 0u;
+    // (the weight of this lane's gradient entry in the bound, object mass folded in: fetched here, used after the first gradient)
+    float d_gw = 0.0f;
+    if (term_bound) d_gw = m->lanek_t[11][lane][3];
     unsigned prevbits = 0u;  // contact lane: flags written in the previous iteration
     float gprev = 0.0f;
     bool met4 = false;
@@ -1592,7 +1597,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       if (term_bound && !term_sent) {
         // ---- the host-visible terminated bytes, as soon as they cannot change: the iterate is within |g|_{Mt^-1} of the minimiser and
         // the final iterate within sqrt(2) times that (the cost never increases), so the object's vertical acceleration is within
-        // (1 + sqrt 2) / sqrt(mass) |g|_{Mt^-1} of its final value, and |g|^2_{Mt^-1} <= sum_i d_gw_i g_i^2.  Where no contact joins
+        // (1 + sqrt 2) / sqrt(mass) |g|_{Mt^-1} of its final value, and |g|^2_{Mt^-1} / mass <= sum_i d_gw_i g_i^2.  Where no contact joins
         // the arm and the object the problem separates and the object's own dofs suffice.  The height the current iterate predicts
         // (same two fused multiply-adds as the integrator below) must be farther from the threshold than dt^2 times that bound --
         // doubled, plus 1 m/s^2 for the solver's own tolerance, plus 1e-5 m -- for all four envs of the wave; otherwise the bytes
@@ -1602,7 +1607,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         const float gm = sqrtf((mdl_split > 0 && S.coupled == 0) ? sobj : sall);
         const float az = lane_gather(row4 + (term_zlane << 2), qacc);
         const float zp = S.qpos[mdl_obj_qadr + 2] + dt * (S.qvel[term_zlane] + dt * az);
-        const float slack = 2.0f * dt * dt * (2.4142137f * term_zscale * gm + 1.0f) + 1e-5f;
+        const float slack = 2.0f * dt * dt * (2.4142137f * gm + 1.0f) + 1e-5f;
         const bool decided = !valid || fabsf(zp - mdl_reward_z) > slack;
         if (!__any(!decided)) {
           const unsigned long long tb = __ballot(valid && zp > mdl_reward_z && lane == 0);
