@@ -896,6 +896,7 @@ def worker(args) -> int:
                                        "overlapped with the following steps" + (f" (copy path not used: {gather_note})" if gather_note else ""))),
                        "gather_path": None if not gather else ("copy" if copy_gather is not None else "rccl"),
                        "terminated_sync_mode": task._mir.sync_mode, "split_step": int(getattr(task._mir, "split_step", 0)),
+                       "early_terminated_bytes": os.environ.get("MIR_NO_EARLY_MASK") is None,
                        "host_thread": host_thread_note()},
             "repeats": len(walls),
             "timed_steps_total": len(walls) * K,
@@ -945,7 +946,7 @@ def worker(args) -> int:
                 out["sync_step_floor"] = {"null_launch_roundtrip_us": null_us, "kernel_us": kernel_us,
                                           "floor_us_per_step": kernel_us + null_us, "measured_us_per_step": out["ms_per_step"] * 1e3,
                                           "note": "env.step must hand a NumPy `terminated` to the host every step (env.py:64), so the next launch "
-                                                  "cannot be queued behind the running one: each step pays launch + dispatch + completion latency (the kernel stores the terminated bytes as soon as the object's height is integrated, ~1.5 us before it ends, so the measured step can come in slightly under kernel + round trip)"}
+                                                  "cannot be queued before that mask exists.  The kernel sends the mask bytes from inside its solver loop, as soon as a convexity bound says the object's height cannot reach the threshold any more (same mask, checked against the integrated state; csrc/mir_model.h: term_bound_ok), each workgroup into its own 64-byte line of pinned host memory: the host is back with the next launch while this one is still running, and the measured step is the kernel plus the gap between two dependent launches -- under this floor, which prices a launch + completion round trip per step"}
             except Exception as e:  # noqa: BLE001
                 out["sync_step_floor"] = {"error": f"{type(e).__name__}: {e}"}
             # (the instantiation rocprofv3 lists: FEAT = 1 round geoms | 4 the headline scene's sizes as literals, csrc/mir_spec_pick.h)
