@@ -1598,7 +1598,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         // ---- the host-visible terminated bytes, as soon as they cannot change: the iterate is within |g|_{Mt^-1} of the minimiser and
         // the final iterate within sqrt(2) times that (the cost never increases), so the object's vertical acceleration is within
         // (1 + sqrt 2) / sqrt(mass) |g|_{Mt^-1} of its final value, and |g|^2_{Mt^-1} / mass <= sum_i d_gw_i g_i^2.  Where no contact joins
-        // the arm and the object the problem separates and the object's own dofs suffice.  The height the current iterate predicts
+        // the arm and the object the problem separates and the object's own dofs are used: its iterate is that close to ITS minimiser,
+        // and so is the final one once the solver stops on its gradient rule (the allowance below); exits at the rounding floor or
+        // the iteration cap carry no such guarantee -- that is what the re-check of the sent bytes against the integrated state
+        // further down is for (with the full gradient instead, 57 of 1024 workgroups qualify early, not 466: the arm's limit rows are
+        // what keeps a straggler iterating).  The height the current iterate predicts
         // (same two fused multiply-adds as the integrator below) must be farther from the threshold than dt^2 times that bound --
         // doubled, plus 1 m/s^2 for the solver's own tolerance, plus 1e-5 m -- for all four envs of the wave; otherwise the bytes
         // wait for the next iteration, or for the integrator.  A cube at rest on the floor qualifies at the first gradient.
