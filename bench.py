@@ -85,7 +85,7 @@ def parse_cpulist(text: str):
 def rank_cpu_plan(local_rank: int, world: int, allowed, gpu_numa=None, numa_cpus=None):
     """Which host cores rank `local_rank` of `world` takes: (sorted cores of its slice, the core of its stepping thread).
 
-    env.step is a ~25 us host / device ping-pong in which the host SPINS on the launch's terminated bytes (mir_step_end): every
+    env.step is a ~22 us host / device ping-pong in which the host SPINS on the launch's terminated bytes (mir_step_end): every
     rank needs a core of its own for that thread, close to its GPU, and its helper threads (HIP runtime, RCCL proxy, allocator)
     must not share it.  The cores the process may use that belong to the NUMA node of the rank's GPU are split evenly among the
     ranks whose GPUs sit on that node; without topology information (or with fewer than two such cores per rank) the allowed
