@@ -868,8 +868,13 @@ def worker(args) -> int:
             walls, evs = measure(raw_loop)
             api_walls = None
         else:
+            task._mir.early_mask_stats(reset=True)
             api_walls, _ = measure(api_loop)
             walls = api_walls
+        # the early `terminated` bytes of exactly these launches (warm-up included): workgroup-launches that sent their bytes from inside the
+        # solver loop, and how many of those the kernel's own check against the integrated state found wrong (a non-zero count would
+        # also have failed the loop with MIR_E_MASK, include/mirigid.h: mir_step_begin)
+        em_sent, em_bad = task._mir.early_mask_stats()
         total_wall = sum(walls)
         value = len(walls) * K * B * world / total_wall
         out = {
@@ -896,8 +901,12 @@ def worker(args) -> int:
                                        "overlapped with the following steps" + (f" (copy path not used: {gather_note})" if gather_note else ""))),
                        "gather_path": None if not gather else ("copy" if copy_gather is not None else "rccl"),
                        "terminated_sync_mode": task._mir.sync_mode, "split_step": int(getattr(task._mir, "split_step", 0)),
-                       "early_terminated_bytes": os.environ.get("MIR_NO_EARLY_MASK") is None,
+                       "early_terminated_bytes": bool(task._mir.early_mask),
+                       "value_is": "mean over the repeated K-step regions (value_median_region: their median)",
                        "host_thread": host_thread_note()},
+            "early_mask": {"sent": em_sent, "mismatches": em_bad, "workgroup_launches": (len(walls) * K + W) * ((B + 3) // 4) if api_walls is not None else 0,
+                           "note": "rank 0; counted by the kernel over the headline loop's launches (warm-up included; the launches of its resets are "
+                                   "plain steps and send nothing to the host)"},
             "repeats": len(walls),
             "timed_steps_total": len(walls) * K,
             "timed_seconds_total": total_wall,

@@ -191,6 +191,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.poses = o.poses ? h->poses : nullptr;
     a.pose_cache = h->poses; a.fkvalid = h->pose_cache_on ? h->fkvalid : nullptr;
     a.early_stats = h->early_stats; a.no_early_mask = h->no_early_mask;
+    a.term_bad = h->pin_dev ? reinterpret_cast<uint32_t*>(h->pin_dev + h->pin_flag_off + 16) : nullptr;
     a.term_wstride = h->term_wstride;
     a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
     a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0) | (h->spec_pick ? 4 : 0);
@@ -249,6 +250,21 @@ int check(MirHandle h) {
   return MIR_OK;
 }
 
+// words of the early-mask counters: mismatches + one `sent` counter per workgroup of the 16-lane kernel (mir_step.h)
+size_t early_words(const MirScene* h) { return 2 + ((size_t)h->B + 3) / 4; }
+
+// The sticky word a step kernel raises when terminated bytes it sent early differ from the integrated state (mir_step.hip).  Checked
+// by every entry point of the env.step path: fails ONCE with MIR_E_MASK and switches the handle to late bytes.
+int check_mask(MirScene* h) {
+  if (!h->pin_host) return MIR_OK;
+  volatile uint32_t* bad = reinterpret_cast<volatile uint32_t*>(h->pin_host + h->pin_flag_off + 16);
+  if (*bad == 0u) return MIR_OK;
+  *bad = 0u;
+  h->no_early_mask = 1;
+  return set_err(MIR_E_MASK, "terminated bytes sent before the solve had finished differ from the integrated state: a mask returned since the last "
+                             "successful call was wrong; early bytes are now off for this handle (MIR_NO_EARLY_MASK=1 avoids them from the start)");
+}
+
 // device half of mir_create: every allocation lands in the handle at once, so the caller can release a partially built
 // scene with mir_destroy whichever call failed
 int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t row_bytes) {
@@ -273,8 +289,8 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   h->spec_pick = h->kernel == 16 && SpecPick::matches(h->hm) && !getenv("MIR_NO_SPEC");
   h->pose_cache_on = !getenv("MIR_NO_POSE_CACHE");
   h->no_early_mask = getenv("MIR_NO_EARLY_MASK") ? 1 : 0;
-  HIPCHK(hipMalloc((void**)&h->early_stats, 2 * sizeof(uint32_t)));
-  HIPCHK(hipMemset(h->early_stats, 0, 2 * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&h->early_stats, early_words(h) * sizeof(uint32_t)));
+  HIPCHK(hipMemset(h->early_stats, 0, early_words(h) * sizeof(uint32_t)));
   if (h->kernel == 64 && !getenv("MIR_NO_ORDER")) {  // dispatch-order flags of the wave kernel (mir_step64.h): two buffers, padded to whole 64-byte reads
     h->cost_stride = (int)(((B + 63) / 64) * 64);
     HIPCHK(hipMalloc((void**)&h->cost, 2 * (size_t)h->cost_stride));
@@ -473,6 +489,7 @@ int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const fl
     int rc = mir_step_end(h, nullptr);
     if (rc != MIR_OK) return rc;
   }
+  if (int rc = check_mask(h)) return rc;
   h->pre_valid = 0;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_reset, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
@@ -530,6 +547,7 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
     int rc = mir_step_end(h, nullptr);
     if (rc != MIR_OK) return rc;
   }
+  if (int rc = check_mask(h)) return rc;
   DeviceGuard guard(h->device);
   uint32_t* flag_dev = reinterpret_cast<uint32_t*>(h->pin_dev + h->pin_flag_off);
   Outs o;
@@ -596,6 +614,9 @@ int mir_step_go(MirHandle h, const float* action, void* stream) {
 int mir_step_end(MirHandle h, uint8_t* terminated_host) {
   if (check(h)) return MIR_E_INVALID;
   if (!h->pending) return set_err(MIR_E_INVALID, "mir_step_end without mir_step_begin");
+  // (early bytes of an EARLIER launch that turned out wrong: reported here, before this step's bytes are handed over; the step stays
+  //  pending and is closed by the next call)
+  if (int rc = check_mask(h)) return rc;
   h->pending = 0;
   volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(h->pin_host + h->pin_flag_off);
   const uint8_t* bytes = h->pin_host;
@@ -728,11 +749,27 @@ int mir_debug_spec_active(MirHandle h) { return check(h) ? MIR_E_INVALID : h->sp
 int mir_debug_early_mask_stats(MirHandle h, uint32_t* out2, int32_t reset, void* stream) {
   if (check(h) || !out2) return set_err(MIR_E_INVALID, "mir_debug_early_mask_stats: null argument");
   DeviceGuard guard(h->device);
-  HIPCHK(hipMemcpyAsync(out2, h->early_stats, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
-  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  if (reset) HIPCHK(hipMemsetAsync(h->early_stats, 0, 2 * sizeof(uint32_t), (hipStream_t)stream));
+  const size_t n = early_words(h);
+  uint32_t* tmp = new (std::nothrow) uint32_t[n];
+  if (!tmp) return set_err(MIR_E_INVALID, "out of host memory");
+  hipError_t e = hipMemcpyAsync(tmp, h->early_stats, n * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e == hipSuccess && reset) e = hipMemsetAsync(h->early_stats, 0, n * sizeof(uint32_t), (hipStream_t)stream);
+  uint64_t sent = 0;
+  for (size_t i = 2; i < n; i++) sent += tmp[i];
+  out2[0] = sent > 0xffffffffull ? 0xffffffffu : (uint32_t)sent;
+  out2[1] = tmp[1];
+  delete[] tmp;
+  if (e != hipSuccess) return hip_fail(e, "mir_debug_early_mask_stats");
   return MIR_OK;
 }
+
+int mir_debug_raise_mask_flag(MirHandle h) {
+  if (check(h) || !h->pin_host) return set_err(MIR_E_INVALID, "mir_debug_raise_mask_flag: no pinned area");
+  *reinterpret_cast<volatile uint32_t*>(h->pin_host + h->pin_flag_off + 16) = 1u;
+  return MIR_OK;
+}
+int mir_get_early_mask(MirHandle h) { return check(h) ? MIR_E_INVALID : (h->no_early_mask ? 0 : 1); }
 
 int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream) {
   if (check(h) || !rows) return set_err(MIR_E_INVALID, "mir_step_packed: null argument");

@@ -24,8 +24,8 @@ struct MirScene {
   int cost_par = 0;         // which of the two the next single-step launch reads
   int cost_stride = 0;
   int pose_cache_on = 1;    // 16-lane kernel: fused single-step launches open with the poses the previous one closed with (MIR_NO_POSE_CACHE=1: always FK)
-  uint32_t* early_stats = nullptr;  // 16-lane kernel: {workgroups that sent their terminated bytes from inside the solver loop (diagnostics on), mismatches}
-  int no_early_mask = 0;    // MIR_NO_EARLY_MASK=1
+  uint32_t* early_stats = nullptr;  // 16-lane kernel: [1] mismatches of the early terminated bytes, [2 + w] launches in which workgroup w sent early (mir_step.h)
+  int no_early_mask = 0;    // MIR_NO_EARLY_MASK=1, or a mismatch was seen (MIR_E_MASK)
   int spec_pick = 0;        // 16-lane kernel: the compiled model matches SpecPick (mir_spec_pick.h) and MIR_NO_SPEC is unset: specialised instantiation
   float* prims;     // render primitives (B, ngeom, 32) f32, allocated by the first mir_render
   int* bins = nullptr;      // per-strip primitive lists of the binned pixel kernel (grown on demand)

@@ -50,9 +50,11 @@ struct StepArgs {
   // `pre`.  3 = 2 followed by 1 (of the next step) in one launch.  `pre`: K16_PRE_STRIDE floats per env.
   int phase;
   float* pre;
-  // early terminated bytes (mir_step.hip, mir_model.h: term_bound_ok): [0] workgroups that sent their bytes from inside the solver loop
-  // (counted while diagnostics are on), [1] workgroups whose early bytes differed from the integrated state (always counted; must be 0)
+  // early terminated bytes (mir_step.hip, mir_model.h: term_bound_ok): [1] workgroups whose early bytes differed from the integrated
+  // state (must be 0: a non-zero count also raises the sticky word `term_bad`), [2 + w] launches in which workgroup w sent its bytes
+  // from inside the solver loop (a contention-free counter per workgroup, always counted; summed by mir_debug_early_mask_stats)
   uint32_t* early_stats;
+  uint32_t* term_bad;  // device address of a pinned host word <- 1 when early bytes turned out wrong (checked by the next API call: MIR_E_MASK)
   int no_early_mask;  // MIR_NO_EARLY_MASK=1: the bytes always wait for the integrator
   int term_wstride;   // 32-bit words between the term_host words of consecutive workgroups (mir_scene.h)
 };

@@ -195,23 +195,26 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 // 1/2 D (a1 - a0)(a1 + a0), where a1 - a0 is the step d itself while the row stays active: never a difference of squares (a step
 // below the resolution of jar must yield a correctly tiny improvement, not an absorbed one).
 __device__ __forceinline__ void step_rows(float al, float j0, float j1, float j2, float j3, float v0, float v1, float v2, float v3, float cD, float ljar, float ljv,
-                                          float lD, float lsg, float& pim, float& crossed) {
+                                          float lD, float lsg, float& pimc, float& piml, float& crossc, float& crossl) {
+  // (the contact rows' share and the limit row's share are returned apart: where the problem separates by tree, the lane's contact
+  //  and its dof may belong to different trees)
   const float jr[4] = {j0, j1, j2, j3}, vr[4] = {v0, v1, v2, v3};
-  pim = 0.0f;
+  pimc = 0.0f;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const float x0 = jr[r], d = al * vr[r], x1 = x0 + d;
     const float a0 = fminf(x0, 0.0f), a1 = fminf(x1, 0.0f);
-    pim -= 0.5f * cD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0);
+    pimc -= 0.5f * cD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0);
   }
   {
     const float x0 = ljar, d = al * ljv, x1 = x0 + d;
     const float a0 = fminf(x0, 0.0f), a1 = fminf(x1, 0.0f);
-    pim -= 0.5f * lD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0);
+    piml = -(0.5f * lD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0));
   }
-  crossed = ((ljar < 0.0f) != (ljar + al * ljv < 0.0f)) && lsg != 0.0f ? 1.0f : 0.0f;
+  crossl = ((ljar < 0.0f) != (ljar + al * ljv < 0.0f)) && lsg != 0.0f ? 1.0f : 0.0f;
+  crossc = 0.0f;
 #pragma unroll
-  for (int r = 0; r < 4; r++) crossed += ((jr[r] < 0.0f) != (jr[r] + al * vr[r] < 0.0f)) ? 1.0f : 0.0f;
+  for (int r = 0; r < 4; r++) crossc += ((jr[r] < 0.0f) != (jr[r] + al * vr[r] < 0.0f)) ? 1.0f : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -784,10 +787,12 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
       meta = f4{mu, 1.0f / Rr, -kk * imp * dist, bb};
     }
-    {  // does any contact of the env move dofs of both trees?
+    {  // does any contact of the env move dofs of both trees?  (bit 0; bits 1 .. 16: contact c moves dofs of the second tree only --
+       // what the per-tree line searches of the solver need to know about a contact when the problem separates)
       const uint32_t low = (1u << mdl_split) - 1u, both = dm1 | dm2;
       const unsigned long long cb = __ballot(mine && (both & low) != 0u && (both & ~low) != 0u);
-      if (lane == 0) S.coupled = (uint32_t)(cb >> (grp * G)) & 0xffffu ? 1 : 0;
+      const unsigned long long tb = __ballot(mine && (both & low) == 0u);
+      if (lane == 0) S.coupled = (int)(((uint32_t)(cb >> (grp * G)) & 0xffffu ? 1u : 0u) | ((uint32_t)(tb >> (grp * G)) & 0xffffu) << 1);
     }
     HSTAMP(43);
     if (DUAL) __syncthreads();  // (2) the main wave has left the dynamics scratch: the contact arrays may be stored over it
@@ -1492,17 +1497,34 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     // ======================= primal Newton solve ====================================================
     const uint32_t limmask = (uint32_t)(__ballot(lsg != 0.0f) >> (grp * G)) & 0xffffu;
     const int nefc = 4 * ncon + __popc(limmask);
+    // the Hessian is block diagonal by tree unless a contact joins the arm and the cube somewhere in this wave
+    const int cpl = S.coupled;  // bit 0: some contact joins the trees; bits 1 .. 16: contact c belongs to the second tree
+    const int hsplit = __any((cpl & 1) != 0) ? 0 : mdl_split;
+    // Where no contact joins the two trees the problem SEPARATES -- f = f_A(a_A) + f_B(a_B), block-diagonal Hessian.  The line search
+    // stays one per env, but a step is ACCEPTED tree by tree (below), so that each tree's own cost decreases monotonically: what the
+    // early `terminated` bytes rely on.  `sep` is uniform over the env's row; an env that does not separate has every row in tree A.
+#ifdef MIR_AB_NOSEP  /* (A/B builds: the problem is never treated as separable) */
+    const bool sep = false;
+#else
+    const bool sep = mdl_split > 0 && (cpl & 1) == 0;
+#endif
+    const bool dofB = sep && lane >= mdl_split;               // this lane's dof, and its joint-limit row
+    const bool conB = sep && ((cpl >> (1 + lane)) & 1) != 0;  // this lane's contact
     bool done = nefc == 0;
     float qacc = qas, Ma = 0.0f, ljar = 0.0f;
     {
-      // warm start: cost(ws) vs cost(qacc_smooth); Gauss part 1/2 dq^T Mt dq
+      // warm start: cost(ws) vs cost(qacc_smooth); Gauss part 1/2 dq^T Mt dq.  Where the problem separates the choice is made TREE BY
+      // TREE (the cost is a sum over the trees, and so is every term below: Mt is block diagonal, a limit row belongs to its dof's
+      // tree, a contact's rows to the one tree it touches): the cube keeps yesterday's solution -- at rest, the minimiser itself --
+      // whatever a jump of the arm's targets does to the arm's, and the first gradient already bounds its height (the early bytes).
       const float ws = S.qacc_ws[lane];
       const float dq = isdof ? ws - qas : 0.0f;
-      float c_ws = 0.5f * rowdot_bc(mrow, dq) * dq, c_sm = 0.0f;
+      float d_ws = 0.5f * rowdot_bc(mrow, dq) * dq, d_sm = 0.0f;  // this lane's dof: Gauss term + limit row
+      float k_ws = 0.0f, k_sm = 0.0f;                              // this lane's contact: its four rows
       const float ljs = lsg * qas - laref, ljw = lsg * ws - laref;
       if (lsg != 0.0f) {
-        if (ljs < 0.0f) c_sm += 0.5f * lD * ljs * ljs;
-        if (ljw < 0.0f) c_ws += 0.5f * lD * ljw * ljw;
+        if (ljs < 0.0f) d_sm += 0.5f * lD * ljs * ljs;
+        if (ljw < 0.0f) d_ws += 0.5f * lD * ljw * ljw;
       }
       float js[4] = {0, 0, 0, 0}, jw[4] = {0, 0, 0, 0};
       float sn, s1, s2, wn, w1, w2;
@@ -1513,28 +1535,41 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         jw[0] = wn + cmu * w1 - aref[0]; jw[1] = wn - cmu * w1 - aref[1]; jw[2] = wn + cmu * w2 - aref[2]; jw[3] = wn - cmu * w2 - aref[3];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          if (js[r] < 0.0f) c_sm += 0.5f * cD * js[r] * js[r];
-          if (jw[r] < 0.0f) c_ws += 0.5f * cD * jw[r] * jw[r];
+          if (js[r] < 0.0f) k_sm += 0.5f * cD * js[r] * js[r];
+          if (jw[r] < 0.0f) k_ws += 0.5f * cD * jw[r] * jw[r];
         }
       }
-      c_ws = gsum(c_ws);
-      c_sm = gsum(c_sm);
-      const bool usews = c_ws < c_sm;
-      qacc = usews ? ws : qas;
-      ljar = usews ? ljw : ljs;
+      const float cA_ws = gsum((dofB ? 0.0f : d_ws) + (conB ? 0.0f : k_ws)), cA_sm = gsum((dofB ? 0.0f : d_sm) + (conB ? 0.0f : k_sm));
+      bool usewsA = cA_ws < cA_sm, usewsB = usewsA;
+      if (__any(sep)) {  // (wave-uniform)
+        const float cB_ws = gsum((dofB ? d_ws : 0.0f) + (conB ? k_ws : 0.0f)), cB_sm = gsum((dofB ? d_sm : 0.0f) + (conB ? k_sm : 0.0f));
+        usewsB = cB_ws < cB_sm;
+      }
+      const bool usewsd = dofB ? usewsB : usewsA, usewsc = conB ? usewsB : usewsA;
+      qacc = usewsd ? ws : qas;
+      ljar = usewsd ? ljw : ljs;
 #pragma unroll
-      for (int r = 0; r < 4; r++) jar[r] = usews ? jw[r] : js[r];
+      for (int r = 0; r < 4; r++) jar[r] = usewsc ? jw[r] : js[r];
       const float Mab = rowdot_bc(mrow, qacc);
       Ma = isdof ? Mab : 0.0f;
     }
     STAMP(7);
     int niter = 0;
     const float tol = mdl_tolerance, scale = mdl_scale;
-    // the Hessian is block diagonal by tree unless a contact joins the arm and the cube somewhere in this wave
-    const int hsplit = __any(S.coupled != 0) ? 0 : mdl_split;
     // float32 rounding floor of the gradient Ma - qfrc_smooth - J^T f: below it a Newton step no
-    // longer changes qacc, so iterating further is noise (same rule as the oracle, with float eps)
-    const float gfloor = 16.0f * 5.96e-8f * sqrtf(gsum(Ma * Ma + qfs * qfs));
+    // longer changes qacc, so iterating further is noise (same rule as the oracle, with float eps).  The floor is that of the
+    // forces the gradient is summed from, TREE BY TREE where the problem separates: a cube of 64 g is not converged because its
+    // gradient has sunk below the rounding noise of the ARM's torques (with the per-tree warm start it may never have been far
+    // above it).  One weighted norm does: each dof's gradient entry is measured in units of its own tree's force scale.
+    constexpr float gfl = 16.0f * 5.96e-8f;
+    float gfw;  // 1 / (force scale of this lane's tree)^2
+    {
+      const float f2 = Ma * Ma + qfs * qfs;
+      const float FA2 = gsum(dofB ? 0.0f : f2);
+      float FB2 = FA2;
+      if (__any(sep)) FB2 = gsum(dofB ? f2 : 0.0f);  // (wave-uniform)
+      gfw = 1.0f / fmaxf(dofB ? FB2 : FA2, 1e-30f);
+    }
     // Hessian row kept across iterations: H = Mt + J^T D_active J is updated incrementally, only rows
     // whose active flag flipped since the previous iteration contribute a (signed) delta
     float hkeep[G];
@@ -1595,20 +1630,22 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       if (it == 0) STAMP(17);
       ITSTAMP(it, 1);
       if (term_bound && !term_sent) {
-        // ---- the host-visible terminated bytes, as soon as they cannot change: the iterate is within |g|_{Mt^-1} of the minimiser and
-        // the final iterate within sqrt(2) times that (the cost never increases), so the object's vertical acceleration is within
-        // (1 + sqrt 2) / sqrt(mass) |g|_{Mt^-1} of its final value, and |g|^2_{Mt^-1} / mass <= sum_i d_gw_i g_i^2.  Where no contact joins
-        // the arm and the object the problem separates and the object's own dofs are used: its iterate is that close to ITS minimiser,
-        // and so is the final one once the solver stops on its gradient rule (the allowance below); exits at the rounding floor or
-        // the iteration cap carry no such guarantee -- that is what the re-check of the sent bytes against the integrated state
-        // further down is for (with the full gradient instead, 57 of 1024 workgroups qualify early, not 466: the arm's limit rows are
-        // what keeps a straggler iterating).  The height the current iterate predicts
-        // (same two fused multiply-adds as the integrator below) must be farther from the threshold than dt^2 times that bound --
-        // doubled, plus 1 m/s^2 for the solver's own tolerance, plus 1e-5 m -- for all four envs of the wave; otherwise the bytes
-        // wait for the next iteration, or for the integrator.  A cube at rest on the floor qualifies at the first gradient.
+        // ---- the host-visible terminated bytes, as soon as they cannot change.  The cost f is 1-strongly convex in the Mt norm, so the
+        // iterate is within |g|_{Mt^-1} of the minimiser, and so is the FINAL iterate, however the solver stops -- gradient rule,
+        // rounding floor or iteration cap -- because every accepted step lowers the cost (enforced above: a step whose exact 1-D
+        // model does not, is not taken): f(a_F) - f* <= f(a_k) - f* <= 1/2 |g_k|^2.  The object's vertical acceleration is therefore
+        // within 2 / sqrt(mass) |g|_{Mt^-1} of its final value, and |g|^2_{Mt^-1} / mass <= sum_i d_gw_i g_i^2.  Where no contact joins
+        // the arm and the object the problem separates, each tree runs its own line search and its own cost is monotone: the same
+        // argument holds for the object's block with the object's share of the gradient alone (the arm's limit rows are what keeps
+        // a straggler iterating: 466 of 1024 workgroups qualify at the first gradient this way, 57 with the full gradient).
+        // The height the current iterate predicts (same two fused multiply-adds as the integrator below) must be farther from the
+        // threshold than dt^2 times that bound -- with (1 + sqrt 2) for 2, doubled again, plus 1 m/s^2, plus 1e-5 m: the margin that
+        // float32 evaluation of g, of the 1-D model and of the integrator could consume -- for all four envs of the wave; otherwise the
+        // bytes wait for the next iteration, or for the integrator.  A cube at rest on the floor qualifies at the first gradient.
+        // The bytes are checked against the integrated state all the same (below): a difference raises the sticky word `term_bad`.
         const float wg = d_gw * g * g;
         const float sall = gsum(wg), sobj = gsum(lane >= mdl_split ? wg : 0.0f);
-        const float gm = sqrtf((mdl_split > 0 && S.coupled == 0) ? sobj : sall);
+        const float gm = sqrtf(sep ? sobj : sall);
         const float az = lane_gather(row4 + (term_zlane << 2), qacc);
         const float zp = S.qpos[mdl_obj_qadr + 2] + dt * (S.qvel[term_zlane] + dt * az);
         const float slack = 2.0f * dt * dt * (2.4142137f * gm + 1.0f) + 1e-5f;
@@ -1621,12 +1658,12 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
                                __HIP_MEMORY_SCOPE_SYSTEM);
           term_sent = true;
           TERMSTAMP();
-          if (a.early_stats && a.diag && tid == 0) atomicAdd(a.early_stats, 1u);  // (diagnostics on: how many workgroups sent early)
+          if (a.early_stats && tid == 0) atomicAdd(a.early_stats + 2 + blockIdx.x, 1u);  // (this workgroup's own counter: no contention, no return value)
           STAMP(30);
         }
       }
-      const float gn = sqrtf(gsum(g * g));
-      if (!done && (scale * gn < tol || gn < gfloor)) done = true;
+      const float gn = sqrtf(gsum(g * g)), gw = sqrtf(gsum(gfw * g * g));
+      if (!done && (scale * gn < tol || gw < gfl)) done = true;
       if (it == 0) STAMP(14);
       ITSTAMP(it, 2);
       if (!__any(!done)) break;
@@ -1709,7 +1746,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // phi'(0) is the gradient along the direction, g . s, and with the exact Hessian the first Newton iterate on phi' is
       // alpha = 1: the evaluation at alpha = 0 (a full pass over the rows and two reductions) is not spent; the search starts
       // at 1 with the bracket [0, ?) and phi'(0) = g . s as the scale of its stopping rule
-      const float A = gsum(sv * mv), Bq = gsum(sv * (Ma - qfs)), g0 = gsum(sv * g);
+      const float svmv = sv * mv, svb = sv * (Ma - qfs);
+      const float A = gsum(svmv), Bq = gsum(svb), g0 = gsum(sv * g);
       bool lsdone = done || g0 >= 0.0f;
       float alpha = lsdone ? 0.0f : 1.0f, lo = 0.0f, hi = -1.0f;
       // improvement of a step alpha s from the 1-D model (exact: phi is piecewise quadratic) and the number of rows whose sign it
@@ -1717,11 +1755,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // step below the resolution of jar must yield a (correctly) tiny improvement, not an absorbed one
       // (with a = min(x, 0) the cost of a row is 1/2 D a^2, and its change 1/2 D (a1 - a0)(a1 + a0); a1 - a0 is the step d
       //  itself while the row stays active)
+      float pimc = 0.0f, piml = 0.0f, crsc = 0.0f, crsl = 0.0f;  // this lane's share at the last evaluation: contact rows / limit row
       auto step_gain = [&](float al, float& gain, float& ncr) __attribute__((always_inline)) {
-        float pim, crossed;
-        step_rows(al, jar[0], jar[1], jar[2], jar[3], jv[0], jv[1], jv[2], jv[3], cD, ljar, ljv, lD, lsg, pim, crossed);
-        gain = gsum(pim) - (0.5f * al * al * A + al * Bq);
-        ncr = gsum(crossed);  // (the two reductions are independent and overlap)
+        step_rows(al, jar[0], jar[1], jar[2], jar[3], jv[0], jv[1], jv[2], jv[3], cD, ljar, ljv, lD, lsg, pimc, piml, crsc, crsl);
+        gain = gsum(pimc + piml) - (0.5f * al * al * A + al * Bq);
+        ncr = gsum(crsc + crsl);  // (the two reductions are independent and overlap)
       };
       // The full Newton step first.  Where it crosses no row boundary it IS the minimiser along s; where it does, it is taken as it
       // is when it realises at least a quarter of the decrease the quadratic piece at alpha = 0 predicts for it (-g0 / 2): the
@@ -1773,26 +1811,56 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         step_gain(alpha, gi, gc);
         if (alpha != alpha0) { improvement = gi; ncross = gc; }
       }
+      // ---- acceptance, TREE BY TREE.  A tree moves only if the step lowers ITS OWN cost: where no contact joins the two trees the
+      // cost is a sum f_A(a_A) + f_B(a_B), the common step length minimises the sum along s and may raise one of the terms; that tree
+      // then stays where it is for this iteration (the other one's gain is all the larger).  The cost of every tree -- of the whole
+      // problem where it does not separate -- is so non-increasing over the iterations BY CONSTRUCTION, whatever made the search
+      // stop: the property the early `terminated` bytes are derived from (above).
+      //   * no row changes sides along the step: every tree's cost is ONE quadratic along its own Newton direction, s_T . H_T s_T =
+      //     -g_T . s_T, and falls by -g_T . s_T (alpha - alpha^2 / 2) > 0 at the alpha = 1 the search then returns: nothing to check;
+      //   * some row does: tree B's share of the exact 1-D model -- three masked reductions over the lane shares of the last
+      //     evaluation, still in registers -- and tree A's = the rest, each accepted on its own sign.
+      float ald = alpha, alc = alpha;  // the step length this lane's dof / its contact takes
+      const bool need = sep && ncross != 0.0f && alpha != 0.0f;
+      bool partial = false;  // one tree moves, the other was held back: the env is not finished whatever the moving tree's gain says
+      if (__any(need)) {  // (wave-uniform; an env's result does not depend on its neighbours: only `need` envs use the sums)
+        const float AB = gsum(dofB ? svmv : 0.0f), BB = gsum(dofB ? svb : 0.0f);
+        const float gainB = gsum((conB ? pimc : 0.0f) + (dofB ? piml : 0.0f)) - (0.5f * alpha * alpha * AB + alpha * BB);
+        const float gainA = improvement - gainB;
+        const bool okA = gainA > 0.0f, okB = gainB > 0.0f;
+        if (need && !(okA && okB)) {  // (rare: an exact search on the sum usually lowers both terms)
+          ald = (dofB ? okB : okA) ? alpha : 0.0f;
+          alc = (conB ? okB : okA) ? alpha : 0.0f;
+          improvement = (okA ? gainA : 0.0f) + (okB ? gainB : 0.0f);
+          partial = okA != okB;
+        }
+      }
+      if (!need && !(improvement > 0.0f)) {  // (one tree, or a crossing-free step at the rounding floor of the model)
+        ald = alc = 0.0f;
+        improvement = 0.0f;
+      }
       // float32 resolution: if no dof's acceleration changes, or the gradient has stopped shrinking
       // within a few floors of its rounding level, further iterations are noise
-      const float moved = gsum((isdof && qacc + alpha * sv != qacc) ? 1.0f : 0.0f);
-      const bool stagnant = it > 0 && gn > 0.5f * gprev && gn < 4.0f * gfloor;
-      gprev = gn;
-      if (!done && (moved == 0.0f || stagnant)) { done = true; niter = it + 1; }
+      const float moved = gsum((isdof && qacc + ald * sv != qacc) ? 1.0f : 0.0f);
+      const bool stagnant = it > 0 && gw > 0.5f * gprev && gw < 4.0f * gfl;
+      gprev = gw;
+      // (an env with a tree held back goes on: with the other tree out of the way -- converged, or closer -- the common step length
+      //  becomes the held-back tree's own)
+      if (!done && !partial && (moved == 0.0f || stagnant)) { done = true; niter = it + 1; }
       if (!done) {
-        qacc += alpha * sv;
-        Ma += alpha * mv;
-        ljar += alpha * ljv;
+        qacc += ald * sv;
+        Ma += ald * mv;
+        ljar += ald * ljv;
 #pragma unroll
-        for (int r = 0; r < 4; r++) jar[r] += alpha * jv[r];
+        for (int r = 0; r < 4; r++) jar[r] += alc * jv[r];
         niter = it + 1;
-        if (scale * improvement < tol) done = true;
+        if (!partial && scale * improvement < tol) done = true;
       }
       {
         // if the step crossed no row boundary, phi is one quadratic along it and the new gradient is
         // exactly (1 - alpha) g: decide convergence now instead of paying another gradient pass
-        const float gnew = fabsf(1.0f - alpha) * gn;
-        if (!done && ncross == 0.0f && (scale * gnew < tol || gnew < gfloor)) done = true;
+        const float gnew = fabsf(1.0f - alpha) * gn, gwnew = fabsf(1.0f - alpha) * gw;
+        if (!done && ncross == 0.0f && (scale * gnew < tol || gwnew < gfl)) done = true;
       }
       WSYNC();
       if (it == 0) STAMP(21);
@@ -1834,7 +1902,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         if (!term_sent || bits != term_bits)
           __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + (size_t)blockIdx.x * a.term_wstride, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
-        if (term_sent && bits != term_bits && a.early_stats) atomicAdd(a.early_stats + 1, 1u);
+        if (term_sent && bits != term_bits) {
+          if (a.early_stats) atomicAdd(a.early_stats + 1, 1u);
+          if (a.term_bad) __hip_atomic_store(a.term_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // sticky: the next API call fails with MIR_E_MASK
+        }
       }
       if (!term_sent) { STAMP(30); TERMSTAMP(); }
     }

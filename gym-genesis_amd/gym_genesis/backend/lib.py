@@ -25,6 +25,11 @@ class MirError(RuntimeError):
     pass
 
 
+class MirMaskError(MirError):
+    """MIR_E_MASK: terminated bytes that a step kernel handed over before its solve had finished turned out wrong (include/mirigid.h,
+    mir_step_begin).  A mask returned since the last successful call cannot be trusted; the scene continues with late bytes."""
+
+
 def load_library() -> C.CDLL:
     """Load libmirigid.so (built in-tree by ``make -C gym-genesis_amd/csrc``)."""
     global _lib
@@ -83,6 +88,10 @@ def load_library() -> C.CDLL:
     lib.mir_debug_spec_active.restype = C.c_int
     lib.mir_debug_early_mask_stats.argtypes = [vp, C.POINTER(C.c_uint32), i32, vp]
     lib.mir_debug_early_mask_stats.restype = C.c_int
+    lib.mir_debug_raise_mask_flag.argtypes = [vp]
+    lib.mir_debug_raise_mask_flag.restype = C.c_int
+    lib.mir_get_early_mask.argtypes = [vp]
+    lib.mir_get_early_mask.restype = C.c_int
     lib.mir_render.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), i32, vp, vp, vp]
     lib.mir_render.restype = C.c_int
     lib.mir_visual_sizeof.restype = C.c_int
@@ -252,7 +261,7 @@ class MirScene(StepHelpers):
     # -- helpers -----------------------------------------------------------------------------
     def _check(self, rc: int) -> None:
         if rc != 0:
-            raise MirError(f"libmirigid error {rc}: {self.lib.mir_last_error().decode()}")
+            raise (MirMaskError if rc == -5 else MirError)(f"libmirigid error {rc}: {self.lib.mir_last_error().decode()}")
 
     def _stream(self):
         if _raw_stream is not None:
@@ -508,11 +517,16 @@ class MirScene(StepHelpers):
         return bool(self.lib.mir_debug_spec_active(self.h))
 
     def early_mask_stats(self, reset: bool = False):
-        """(workgroups that sent their terminated bytes from inside the solver loop -- counted while diagnostics are on --,
-        workgroups whose early bytes differed from the integrated state: must be 0) -- mir_debug_early_mask_stats."""
+        """(workgroup-launches that sent their terminated bytes from inside the solver loop, workgroup-launches whose early bytes
+        differed from the integrated state: must be 0 -- the library also fails the next call with MIR_E_MASK) -- mir_debug_early_mask_stats."""
         out = (C.c_uint32 * 2)()
         self._check(self.lib.mir_debug_early_mask_stats(self.h, out, 1 if reset else 0, self._stream()))
         return int(out[0]), int(out[1])
+
+    @property
+    def early_mask(self) -> bool:
+        """True while mir_step_begin launches may send their terminated bytes early (mir_get_early_mask)."""
+        return bool(self.lib.mir_get_early_mask(self.h))
 
     def debug_render_path(self, generic: bool = False, strip_rows: int = 0) -> None:
         """mir_debug_render_path: force the generic pixel kernel / override the strip height for the following renders."""

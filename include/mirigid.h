@@ -64,6 +64,7 @@ extern "C" {
 #define MIR_E_CAPACITY (-2) /* spec exceeds MIR_MAX_* */
 #define MIR_E_HIP (-3)      /* HIP runtime error */
 #define MIR_E_NODEVICE (-4) /* no gfx950 device visible */
+#define MIR_E_MASK (-5)     /* early terminated bytes (mir_step_begin) turned out wrong; see mir_step_begin */
 
 /* joint types (one joint per body, anchored at the body origin) */
 #define MIR_JNT_FIXED 0
@@ -252,7 +253,19 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  *   2  every wave waits for its host store, the kernel's last workgroup then writes a sequence word into pinned host memory
  *      and the host spins on it (16-lane kernel only)
  *   1  hipStreamWriteValue32 behind the launch writes that word, the host spins on it
- *   0  hipStreamSynchronize */
+ *   0  hipStreamSynchronize
+ * EARLY BYTES (mode 3, 16-lane kernel, scenes whose task object is a free body under the world: DevModel::term_bound_ok).  The
+ * bytes mir_step_end returns may PRECEDE the end of the solve they belong to: a workgroup stores them from inside its Newton loop
+ * once  |z_pred - reward_z| > 2 dt^2 ((1 + sqrt 2) |g|_w + 1 m/s^2) + 1e-5 m  holds for its four envs, where z_pred is the object's
+ * height integrated from the current iterate and |g|_w^2 = sum_i w_i g_i^2 >= |g|^2_{Mt^-1} / mass over the dofs of the object's
+ * block of the problem (all dofs while a contact joins it to the arm).  The solver's cost is 1-strongly convex in the Mt norm and
+ * no accepted step raises it -- per tree, with per-tree line searches, when the problem separates -- so the final iterate is within
+ * 2 |g|_{Mt^-1} of the current one whatever makes the solver stop; the bound is that with a 2.4 x margin for float32 evaluation.
+ * The kernel still compares the bytes it sent with the integrated state.  A difference (none in any test or soak run) is counted
+ * (mir_debug_early_mask_stats), raises a sticky word in pinned memory, and the NEXT mir_step_begin / mir_step_go / mir_step_end /
+ * mir_reset on the handle fails ONCE with MIR_E_MASK after switching the handle to late bytes for good (the step that failed the
+ * check has already returned its mask: the caller learns that one of the masks since the last successful call was wrong).
+ * MIR_NO_EARLY_MASK=1 at mir_create: the bytes always wait for the integrator. */
 int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward,
                    uint8_t* terminated, void* stream);
 int mir_step_end(MirHandle h, uint8_t* terminated_host);
@@ -434,12 +447,15 @@ int mir_debug_emit_spec(const MirSceneSpec* spec, const char* name, char* out, i
 /* 1 if this handle's launches use the scene-specialised instantiation (its compiled model matched SpecPick and the environment
  * variable MIR_NO_SPEC was unset at mir_create), else 0 */
 int mir_debug_spec_active(MirHandle h);
-/* 16-lane kernel, mir_step_begin / mir_step_go launches: the terminated bytes leave from inside the solver loop as soon as a
- * convexity bound says the object's height cannot reach the threshold whatever the remaining iterations do (csrc/mir_model.h:
- * term_bound_ok; MIR_NO_EARLY_MASK=1 at mir_create switches it off).  out2[0] = workgroups that sent early (counted while
- * diagnostics are on, mir_set_diag), out2[1] = workgroups whose early bytes differed from the integrated state (always counted;
- * anything but 0 is a bug).  Synchronises the stream; reset != 0 clears the counters. */
+/* counters of the early terminated bytes (see mir_step_begin): out2[0] = workgroup-launches that sent their bytes from inside the
+ * solver loop, out2[1] = workgroup-launches whose early bytes differed from the integrated state (anything but 0 also makes the next
+ * API call fail with MIR_E_MASK).  Both always counted (a private counter per workgroup, summed here).  Synchronises the stream;
+ * reset != 0 clears the counters. */
 int mir_debug_early_mask_stats(MirHandle h, uint32_t* out2, int32_t reset, void* stream);
+/* test aid: raises the sticky word by hand, as a kernel that found its early bytes wrong would (the next call fails with MIR_E_MASK) */
+int mir_debug_raise_mask_flag(MirHandle h);
+/* 1 while mir_step_begin launches may send early bytes on this handle, 0 after MIR_NO_EARLY_MASK=1 or a MIR_E_MASK */
+int mir_get_early_mask(MirHandle h);
 
 #ifdef __cplusplus
 }

@@ -166,10 +166,31 @@ class Oracle:
                             C.c_double(max_step), C.c_int(1 if respect_limits else 0), err[e].ctypes.data_as(C.c_void_p))
         return q, err
 
+    def read_all(self, field: int, n: int) -> np.ndarray:
+        """(B, n) float64: field `field` (of length <= n) of every env in one call (orc_read_batch)."""
+        out = np.zeros((self.B, n))
+        self.lib.orc_read_batch.restype = C.c_int
+        got = self.lib.orc_read_batch(self.model, self.data, C.c_int(self.B), C.c_int(field), out.ctypes.data_as(C.c_void_p), C.c_int(n))
+        if got < 0:
+            raise KeyError(field)
+        return out[:, :got]
+
+    def counts_all(self):
+        """(ncon, nefc, niter) int32 arrays over the envs (orc_counts_batch)."""
+        a, b, c = (np.zeros(self.B, np.int32) for _ in range(3))
+        self.lib.orc_counts_batch(self.data, C.c_int(self.B), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
+        return a, b, c
+
+    def get_obs_all(self):
+        """get_obs() in one call (orc_get_obs_batch)."""
+        agent, env = np.zeros((self.B, self.agent_dim)), np.zeros((self.B, self.env_dim))
+        rew, term = np.zeros(self.B), np.zeros(self.B, dtype=np.uint8)
+        self.lib.orc_get_obs_batch(self.model, self.data, C.c_int(self.B), agent.ctypes.data_as(C.c_void_p), C.c_int(self.agent_dim),
+                                   env.ctypes.data_as(C.c_void_p), C.c_int(self.env_dim), rew.ctypes.data_as(C.c_void_p), term.ctypes.data_as(C.c_void_p))
+        return agent, env, rew, term
+
     def state(self):
-        q = np.stack([self.read(F_QPOS, e) for e in range(self.B)])
-        v = np.stack([self.read(F_QVEL, e) for e in range(self.B)])
-        return q, v
+        return self.read_all(F_QPOS, self.nq), self.read_all(F_QVEL, self.nv)
 
 
 def render_image(spec, cam, vis, xpos, xquat, offsets=None, want_depth=False):

@@ -1690,6 +1690,36 @@ int orc_counts(const OrcData* d, int* ncon, int* nefc, int* niter) {
   return 0;
 }
 
+/* batched accessors (tests at 4096 envs): field `field` of B consecutive data blocks into out (B, stride) / from in (B, stride);
+ * contact counts into ncon (B); observations as orc_get_obs, rows of agent_dim / env_dim doubles */
+int orc_read_batch(const OrcModel* m, const OrcData* d, int B, int field, double* out, int stride) {
+  int n = 0;
+  for (int e = 0; e < B; e++) {
+    n = orc_read(m, d + e, field, out + (size_t)e * stride);
+    if (n < 0 || n > stride) return -1;
+  }
+  return n;
+}
+int orc_write_batch(const OrcModel* m, OrcData* d, int B, int field, const double* in, int stride) {
+  int n = 0;
+  for (int e = 0; e < B; e++) {
+    n = orc_write(m, d + e, field, in + (size_t)e * stride);
+    if (n < 0) return -1;
+  }
+  return n;
+}
+void orc_counts_batch(const OrcData* d, int B, int* ncon, int* nefc, int* niter) {
+  for (int e = 0; e < B; e++) {
+    if (ncon) ncon[e] = d[e].ncon;
+    if (nefc) nefc[e] = d[e].nefc;
+    if (niter) niter[e] = d[e].niter;
+  }
+}
+void orc_get_obs_batch(const OrcModel* m, const OrcData* d, int B, double* agent_pos, int agent_dim, double* env_state, int env_dim, double* reward,
+                       unsigned char* terminated) {
+  for (int e = 0; e < B; e++) orc_get_obs(m, d + e, agent_pos + (size_t)e * agent_dim, env_state + (size_t)e * env_dim, reward + e, terminated + e);
+}
+
 /* ------------------------------------------------------------------ independent ABA (unconstrained) */
 /* Featherstone articulated-body algorithm in the same c-frame, used only to
  * cross-check CRB + Cholesky: qacc_aba == M^-1 (tau - bias) with the plain

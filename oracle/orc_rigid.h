@@ -128,6 +128,11 @@ void orc_get_obs(const OrcModel* m, const OrcData* d, double* agent_pos, double*
 int orc_read(const OrcModel* m, const OrcData* d, int field, double* out);
 int orc_write(const OrcModel* m, OrcData* d, int field, const double* in);
 int orc_counts(const OrcData* d, int* ncon, int* nefc, int* niter);
+int orc_read_batch(const OrcModel* m, const OrcData* d, int B, int field, double* out, int stride);
+int orc_write_batch(const OrcModel* m, OrcData* d, int B, int field, const double* in, int stride);
+void orc_counts_batch(const OrcData* d, int B, int* ncon, int* nefc, int* niter);
+void orc_get_obs_batch(const OrcModel* m, const OrcData* d, int B, double* agent_pos, int agent_dim, double* env_state, int env_dim, double* reward,
+                       unsigned char* terminated);
 /* independent articulated-body (Featherstone ABA) unconstrained forward dynamics, for cross-checks */
 void orc_aba(const OrcModel* m, OrcData* d, double* qacc_out);
 /* batch driver (OpenMP over envs) for the timed CPU baseline: action (T?) — random targets supplied by caller */
