@@ -161,6 +161,11 @@ __global__ void k_get_diag(const int32_t* diag, int32_t* ncon, int32_t* nefc, in
   if (niter) niter[e] = diag[(long)e * 4 + 2];
 }
 
+__global__ void k_get_bad(const int32_t* diag, uint8_t* bad, int B) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < B) bad[e] = (uint8_t)((diag[(long)e * 4 + 3] >> 30) & 1);
+}
+
 // launch arguments common to both kernels
 struct Outs {
   const float* action = nullptr;
@@ -209,6 +214,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
     a.poses = h->poses; a.fkvalid = h->fkvalid;
     a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
+    a.bad_count = h->early_stats;  // (word 0)
     a.B = h->B; a.nu = h->hm64.nu; a.convex = h->hm64.has_convex;
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
@@ -754,13 +760,29 @@ int mir_debug_early_mask_stats(MirHandle h, uint32_t* out2, int32_t reset, void*
   if (!tmp) return set_err(MIR_E_INVALID, "out of host memory");
   hipError_t e = hipMemcpyAsync(tmp, h->early_stats, n * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-  if (e == hipSuccess && reset) e = hipMemsetAsync(h->early_stats, 0, n * sizeof(uint32_t), (hipStream_t)stream);
+  if (e == hipSuccess && reset) e = hipMemsetAsync(h->early_stats + 1, 0, (n - 1) * sizeof(uint32_t), (hipStream_t)stream);  // (word 0 is mir_get_bad's)
   uint64_t sent = 0;
   for (size_t i = 2; i < n; i++) sent += tmp[i];
   out2[0] = sent > 0xffffffffull ? 0xffffffffu : (uint32_t)sent;
   out2[1] = tmp[1];
   delete[] tmp;
   if (e != hipSuccess) return hip_fail(e, "mir_debug_early_mask_stats");
+  return MIR_OK;
+}
+
+int mir_get_bad(MirHandle h, uint8_t* bad, uint32_t* env_steps, int32_t reset, void* stream) {
+  if (check(h)) return MIR_E_INVALID;
+  if (!h->diag_on) return set_err(MIR_E_INVALID, "mir_get_bad: diagnostics are switched off (mir_set_diag)");
+  DeviceGuard guard(h->device);
+  if (bad) {
+    hipLaunchKernelGGL(k_get_bad, dim3(nblk(h->B)), dim3(TPB), 0, (hipStream_t)stream, h->diag, bad, h->B);
+    HIPCHK(hipGetLastError());
+  }
+  if (env_steps) {
+    HIPCHK(hipMemcpyAsync(env_steps, h->early_stats, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  }
+  if (reset) HIPCHK(hipMemsetAsync(h->early_stats, 0, sizeof(uint32_t), (hipStream_t)stream));
   return MIR_OK;
 }
 

@@ -115,6 +115,10 @@ template <int N>
 __device__ __forceinline__ float row_shl(float v) {  // lane i reads lane i+N of its row, 0 shifted in
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
 }
+// the task's threshold test on a height (reward / terminated): true for a FINITE z above the threshold.  A state that has gone
+// non-finite (a NaN target from the caller, a diverged env) never terminates an episode: NaN fails the first comparison, +Inf the second.
+__device__ __forceinline__ bool above(float z, float thr) { return z > thr && z <= 3.0e38f; }
+__device__ __forceinline__ bool nonfinite(float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u; }
 // lane gather through the LDS crossbar (ds_bpermute_b32: no LDS memory, no write-then-read fence): every lane names the wave
 // lane it reads from as a BYTE offset (4 x lane)
 __device__ __forceinline__ float lane_gather(int src4, float v) {

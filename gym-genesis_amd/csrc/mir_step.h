@@ -50,6 +50,7 @@ struct StepArgs {
   // `pre`.  3 = 2 followed by 1 (of the next step) in one launch.  `pre`: K16_PRE_STRIDE floats per env.
   int phase;
   float* pre;
+  // [0] env-steps that ended with a non-finite state (divergence guard, counted while diag is set; mir_get_bad);
   // early terminated bytes (mir_step.hip, mir_model.h: term_bound_ok): [1] workgroups whose early bytes differed from the integrated
   // state (must be 0: a non-zero count also raises the sticky word `term_bad`), [2 + w] launches in which workgroup w sent its bytes
   // from inside the solver loop (a contention-free counter per workgroup, always counted; summed by mir_debug_early_mask_stats)

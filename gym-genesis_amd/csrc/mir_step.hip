@@ -1089,7 +1089,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     if (k < 7) return S.xquat[ob][k - 3];
     if (k < 10) return k == 7 ? df.x : (k == 8 ? df.y : df.z);
     if (k == 10) return sqrtf(dot(df, df));
-    return po.z > mdl_reward_z ? 1.0f : 0.0f;  // k == 11 reward, k == 12 terminated
+    return above(po.z, mdl_reward_z) ? 1.0f : 0.0f;  // k == 11 reward, k == 12 terminated
   };
   int eplen = a.ar.episode_len ? a.ar.episode_len[env] : 0, epcur = a.ar.episode_len ? a.ar.cursor[env] : 0;
   // POST (the second half of a split step): everything the previous launch left in the pre buffer is fetched here, in one batch --
@@ -1124,7 +1124,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     // straight into pinned host memory (write-through, system scope), each byte = term | tag << 1; its trip over PCIe runs under the
     // state and observation stores below.  The tag changes from launch to launch, so the host recognises the bytes of THIS launch by
     // themselves (sync mode 3: no fence, no ticket, nothing waits).
-    const bool term_now = valid && S.xpos[ob][2] > mdl_reward_z;
+    const bool term_now = valid && above(S.xpos[ob][2], mdl_reward_z);
     if (VARIANT != 1 && a.term_host && !term_early) {
       const unsigned long long tb = __ballot(term_now && lane == 0);
       if (tid == 0) {
@@ -1203,6 +1203,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       }
     }
   };
+  bool bad_acc = false;  // (diagnostics on) the env's state went non-finite in some step of this launch
   // One step of the loop as a function of the step index: an int in the step-loop instantiations, a compile-time constant in the
   // rotated launch (pass 0 = second half of this step, pass 1 = first half of the next), whose two calls therefore compile to
   // straight-line code like the single-step kernel.  Returns 0 to go on, 1 to leave the loop, 2 to leave the kernel.
@@ -1539,12 +1540,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
           if (jw[r] < 0.0f) k_ws += 0.5f * cD * jw[r] * jw[r];
         }
       }
-      const float cA_ws = gsum((dofB ? 0.0f : d_ws) + (conB ? 0.0f : k_ws)), cA_sm = gsum((dofB ? 0.0f : d_sm) + (conB ? 0.0f : k_sm));
-      bool usewsA = cA_ws < cA_sm, usewsB = usewsA;
-      if (__any(sep)) {  // (wave-uniform)
-        const float cB_ws = gsum((dofB ? d_ws : 0.0f) + (conB ? k_ws : 0.0f)), cB_sm = gsum((dofB ? d_sm : 0.0f) + (conB ? k_sm : 0.0f));
-        usewsB = cB_ws < cB_sm;
-      }
+      // (one reduction per tree: the sign of the summed cost DIFFERENCES decides)
+      const float d_df = d_ws - d_sm, k_df = k_ws - k_sm;
+      bool usewsA = gsum((dofB ? 0.0f : d_df) + (conB ? 0.0f : k_df)) < 0.0f, usewsB = usewsA;
+      if (__any(sep)) usewsB = gsum((dofB ? d_df : 0.0f) + (conB ? k_df : 0.0f)) < 0.0f;  // (wave-uniform)
       const bool usewsd = dofB ? usewsB : usewsA, usewsc = conB ? usewsB : usewsA;
       qacc = usewsd ? ws : qas;
       ljar = usewsd ? ljw : ljs;
@@ -1651,7 +1650,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         const float slack = 2.0f * dt * dt * (2.4142137f * gm + 1.0f) + 1e-5f;
         const bool decided = !valid || fabsf(zp - mdl_reward_z) > slack;
         if (!__any(!decided)) {
-          const unsigned long long tb = __ballot(valid && zp > mdl_reward_z && lane == 0);
+          const unsigned long long tb = __ballot(valid && above(zp, mdl_reward_z) && lane == 0);
           term_bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
           if (tid == 0)
             __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + (size_t)blockIdx.x * a.term_wstride, term_bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
@@ -1893,7 +1892,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // GenesisEnv.step's D->H copy of `terminated`, done by the kernel: see the epilogue; here ~1 us earlier, so that the trip
       // over PCIe is over when the launch ends
       WSYNC();
-      const bool tn = valid && S.qpos[mdl_obj_qadr + 2] > mdl_reward_z;
+      const bool tn = valid && above(S.qpos[mdl_obj_qadr + 2], mdl_reward_z);
       const unsigned long long tb = __ballot(tn && lane == 0);
       if (tid == 0) {
         const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
@@ -1930,6 +1929,18 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     }
     WSYNC();
     STAMP(9);
+    if (a.diag) {
+      // divergence guard (diagnostics on): an env whose integrated state holds a NaN or an Inf is flagged in its
+      // diagnostics record -- bit 30 of word 3, sticky over the steps of a rollout launch -- and counted; its `terminated` is False
+      // (mir_dev.h: above()).  The other envs of the wave are not touched by it: every reduction and gather stays inside an env's row.
+      const bool nf = nonfinite(S.qpos[lane]) || (lane + G < qst && nonfinite(S.qpos[lane + G])) || nonfinite(S.qvel[lane]);
+      const bool bad = ((uint32_t)(__ballot(nf) >> (grp * G)) & 0xffffu) != 0u;
+      bad_acc = bad_acc || bad;
+      if (valid && lane == 0) {
+        a.diag[(size_t)env * 4 + 3] = S.ncand | (bad_acc ? 1 << 30 : 0);
+        if (bad && a.early_stats) atomicAdd(a.early_stats, 1u);  // (word 0: env-steps that ended non-finite, since the last reset of the counters)
+      }
+    }
     // kinematics of the new state: observations of this step, and the next step's starting poses
     if (fksplit) {
       // (the free bodies' poses are their qpos rows -- the expressions of group_fk for a childless child of the world)
@@ -1948,7 +1959,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     }
     if (a.ar.episode_len) {
       // episode bookkeeping and re-spawn on chip (the rules of k_autoreset): the row above is the terminal observation
-      const bool term = S.xpos[ob][2] > mdl_reward_z;
+      const bool term = above(S.xpos[ob][2], mdl_reward_z);
       const int len = eplen + 1;
       const bool trunc = !term && a.ar.max_len > 0 && len >= a.ar.max_len;
       const bool done = term || trunc;

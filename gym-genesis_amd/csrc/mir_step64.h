@@ -21,6 +21,7 @@ struct StepArgs64 {
   uint8_t* term_host;   // (B) device address of pinned host memory (mir_step_begin), or null; byte = terminated | term_tag << 1
   uint32_t term_tag;
   int32_t* diag;        // (B, 4): ncon, nefc, niter, ncand; or null
+  uint32_t* bad_count;  // device counter of env-steps that ended with a non-finite state (counted while diag is set), or null
   // per-stage parity outputs (mir_forward), all nullable; compact dof order
   float* out_M;     // (B, nv, nv)
   float* out_bias;  // (B, nv)

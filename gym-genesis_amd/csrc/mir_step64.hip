@@ -981,9 +981,9 @@ void mir_step64_kernel(StepArgs64 a) {
   auto reward_of = [&](const V3 po, const V3 p2) -> float {
     if (m->reward_mode == MIR_REWARD_STACK) {
       const float dx = po.x - p2.x, dy = po.y - p2.y;
-      return (sqrtf(dx * dx + dy * dy) < m->reward_xy && po.z - p2.z > m->reward_dz) ? 1.0f : 0.0f;
+      return (sqrtf(dx * dx + dy * dy) < m->reward_xy && above(po.z - p2.z, m->reward_dz)) ? 1.0f : 0.0f;
     }
-    return po.z > m->reward_z ? 1.0f : 0.0f;
+    return above(po.z, m->reward_z) ? 1.0f : 0.0f;
   };
   auto reward_now = [&]() -> float { return reward_of(ld3v(S.xpos[ob]), ld3v(S.xpos[ob2 >= 0 ? ob2 : ob])); };
   // (free objects hanging off the world: the same positions straight from qpos, before any forward kinematics)
@@ -1007,6 +1007,7 @@ void mir_step64_kernel(StepArgs64 a) {
     return reward_now();  // k == ed reward, k == ed + 1 terminated
   };
   int eplen = a.ar.episode_len ? a.ar.episode_len[env] : 0, epcur = a.ar.episode_len ? a.ar.cursor[env] : 0;
+  bool bad_acc = false;  // (diagnostics on) the env's state went non-finite in some step of this launch
   for (int step = 0; step < nsteps; step++) {
     // rollout mode (mir_rollout): a fresh action block per step
     if (step > 0 && a.action && a.act_step) {
@@ -1731,6 +1732,17 @@ void mir_step64_kernel(StepArgs64 a) {
     }
     WSYNC();
     STAMP(17);
+    if (a.diag) {
+      // divergence guard (diagnostics on; as in the 16-lane kernel): a NaN or an Inf in the integrated state -> bit 30 of word 3 of
+      // the env's diagnostics record, sticky over the steps of a launch, and the handle's counter; `terminated` is False for it
+      const bool nf = nonfinite(S.qpos[lane]) || nonfinite(S.qvel[lane]);
+      const bool bad = __any(nf);
+      bad_acc = bad_acc || bad;
+      if (lane == 0) {
+        a.diag[(size_t)env * 4 + 3] = ncand | (bad_acc ? 1 << 30 : 0);
+        if (bad && a.bad_count) atomicAdd(a.bad_count, 1u);
+      }
+    }
     if (a.term_host && term_early && lane == 0) {
       // the host-visible terminated byte leaves here, before the closing FK, the observation and the state stores: its trip over
       // PCIe runs under them (see the 16-lane kernel)

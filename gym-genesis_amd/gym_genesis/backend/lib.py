@@ -88,6 +88,8 @@ def load_library() -> C.CDLL:
     lib.mir_debug_spec_active.restype = C.c_int
     lib.mir_debug_early_mask_stats.argtypes = [vp, C.POINTER(C.c_uint32), i32, vp]
     lib.mir_debug_early_mask_stats.restype = C.c_int
+    lib.mir_get_bad.argtypes = [vp, vp, C.POINTER(C.c_uint32), i32, vp]
+    lib.mir_get_bad.restype = C.c_int
     lib.mir_debug_raise_mask_flag.argtypes = [vp]
     lib.mir_debug_raise_mask_flag.restype = C.c_int
     lib.mir_get_early_mask.argtypes = [vp]
@@ -490,6 +492,14 @@ class MirScene(StepHelpers):
         a, b, c = (self.empty(dtype=torch.int32) for _ in range(3))
         self._check(self.lib.mir_get_diag(self.h, _ptr(a), _ptr(b), _ptr(c), self._stream()))
         return a, b, c
+
+    def get_bad(self, reset: bool = False):
+        """Divergence guard (mir_get_bad; diagnostics must be on): (uint8 (B,) device tensor, 1 = the env's state was non-finite after
+        the last step launch; env-steps flagged since the counter was last reset)."""
+        bad = self.empty(dtype=torch.uint8)
+        n = C.c_uint32()
+        self._check(self.lib.mir_get_bad(self.h, _ptr(bad), C.byref(n), 1 if reset else 0, self._stream()))
+        return bad, int(n.value)
 
     def forward(self):
         M, bias = self.empty(self.nv, self.nv), self.empty(self.nv)

@@ -325,6 +325,15 @@ int mir_get_links(MirHandle h, float* pos, float* quat, void* stream);
 int mir_set_diag(MirHandle h, int32_t on);
 int mir_get_diag(MirHandle h, int32_t* ncon, int32_t* nefc, int32_t* niter, void* stream);
 
+/* Divergence guard (the reference's users get Genesis's own error on a NaN state, scene.step() at
+ * gym_genesis/tasks/franka/cube_pick.py:107,125).  While diagnostics are on, a step kernel flags every env whose integrated qpos / qvel
+ * holds a NaN or an Inf: bad (B) u8 device, nullable <- 1 for the envs flagged by the LAST step launch (sticky over the steps of a
+ * rollout launch); *env_steps (host, nullable) <- env-steps flagged since the counter was last reset (synchronises the stream);
+ * reset != 0 clears the counter.  Off the hot path: nothing is computed or stored while diagnostics are off (mir_set_diag(h, 0)).
+ * A flagged env keeps stepping (its state stays non-finite until it is reset); its reward is 0 and its `terminated` False -- the
+ * threshold tests hold for finite heights only -- and no other env is affected (bit-identical to a run without it). */
+int mir_get_bad(MirHandle h, uint8_t* bad, uint32_t* env_steps, int32_t reset, void* stream);
+
 /* stage outputs of one forward-dynamics evaluation at the current state (no
  * integration), for per-stage parity tests: M (B,nv,nv), qfrc_bias (B,nv),
  * qacc_smooth (B,nv), qacc (B,nv); nullable */
