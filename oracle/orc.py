@@ -31,12 +31,17 @@ def load(f32: bool = False, flops=False):
     """liborc64.so (float64 oracle), liborc32.so (float32 port) or liborc_flops.so / liborc_flops_big.so (the float32 port with
     counted arithmetic at the pick-task / full capacities; flops = True / "big")."""
     key = ("_flops_big" if flops == "big" else "_flops") if flops else ("32" if f32 else "64")
+    if key == "64" and os.environ.get("ORC_SANITIZE"):  # (tests/test_sanitizers_cpu.py: the ASan + UBSan build, `make -C oracle asan`)
+        key = "64_asan"
     if key not in _libs:
         path = os.path.join(ORACLE_DIR, f"liborc{key}.so")
         srcs = [os.path.join(ORACLE_DIR, "orc_rigid.c"), os.path.join(ORACLE_DIR, "orc_render.c"), os.path.join(ORACLE_DIR, "orc_rigid.h"),
                 os.path.join(ORACLE_DIR, "orc_flops.h"), os.path.join(ORACLE_DIR, "..", "include", "mirigid.h")]
         if not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(s) for s in srcs):
-            build_oracle()
+            if key == "64_asan":
+                subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "asan"], stdout=subprocess.DEVNULL)
+            else:
+                build_oracle()
         lib = C.CDLL(path)
         lib.orc_read.restype = C.c_int
         lib.orc_compile.restype = C.c_int
