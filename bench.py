@@ -449,10 +449,20 @@ def grasp_bench(torch, dev):
     us = ev0.elapsed_time(ev1) * 1e3 / 200
     success = float((task._reward == 1).float().mean().item())
     ncon_max = int(task._mir.get_diag()[0].max().item())
+    # how often the 16-point contact capacity of the pick kernel is reached: the same 200 steps once more, untimed, reading the
+    # candidate-point count of every env after every step (mir_get_diag4; more than 16 = the manifolds of that env-step were thinned)
+    env.reset(seed=0)
+    hits = pts_max = 0
+    for tg in targets:
+        for _ in range(40):
+            task.step_raw(tg)
+            pts = task._mir.get_diag(points=True)[3]
+            hits += int((pts > 16).sum().item())
+            pts_max = max(pts_max, int(pts.max().item()))
     del env
     return {"workload": "CubePick-v0 robot=franka scripted pick (hover, stabilize, descend, close, lift; 5 x 40 steps; IK-precomputed "
                         "joint targets), num_envs=4096", "env_steps_per_s": B / (us * 1e-6), "us_per_step": us, "lifted_frac": success,
-            "max_contacts_last_step": ncon_max}
+            "max_contacts_last_step": ncon_max, "cap_hit_frac": hits / (200.0 * B), "max_candidate_points": pts_max, "contact_capacity": 16}
 
 
 def box_links_bench(torch, dev, steps: int = 400):

@@ -161,6 +161,11 @@ __global__ void k_get_diag(const int32_t* diag, int32_t* ncon, int32_t* nefc, in
   if (niter) niter[e] = diag[(long)e * 4 + 2];
 }
 
+__global__ void k_get_diag_points(const int32_t* diag, int32_t* points, int B) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < B) points[e] = (diag[(long)e * 4 + 3] >> 8) & 255;
+}
+
 __global__ void k_get_bad(const int32_t* diag, uint8_t* bad, int B) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < B) bad[e] = (uint8_t)((diag[(long)e * 4 + 3] >> 30) & 1);
@@ -767,6 +772,15 @@ int mir_debug_early_mask_stats(MirHandle h, uint32_t* out2, int32_t reset, void*
   out2[1] = tmp[1];
   delete[] tmp;
   if (e != hipSuccess) return hip_fail(e, "mir_debug_early_mask_stats");
+  return MIR_OK;
+}
+
+int mir_get_diag4(MirHandle h, int32_t* ncon, int32_t* nefc, int32_t* niter, int32_t* ncand_points, void* stream) {
+  int rc = mir_get_diag(h, ncon, nefc, niter, stream);
+  if (rc != MIR_OK || !ncand_points) return rc;
+  DeviceGuard guard(h->device);
+  hipLaunchKernelGGL(k_get_diag_points, dim3(nblk(h->B)), dim3(TPB), 0, (hipStream_t)stream, h->diag, ncand_points, h->B);
+  HIPCHK(hipGetLastError());
   return MIR_OK;
 }
 

@@ -695,6 +695,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   STAMP(13);
   // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
   const int maxc = max_contacts < MAXCON ? max_contacts : MAXCON;
+  int ptotal = 0;
   {
     // ---- more candidate points than the capacity: the largest manifolds are thinned before any pair loses all of its points
     // (the rule is defined at oracle/orc_rigid.c: thin_manifolds -- per round, the pairs holding the most points merge their last
@@ -707,6 +708,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     totf += row_shr<4>(totf);
     totf += row_shr<8>(totf);
     int total0 = (int)row_bcast<15>(totf);
+    ptotal = total0;  // (candidate points before the capacity is applied: more than max_contacts says the manifolds were thinned)
     if (__any(total0 > maxc)) {
       WSYNC();  // (the staging area was written by other lanes of the row)
       for (int round = 0; round < 8; round++) {  // (a manifold holds at most 8 points)
@@ -788,11 +790,12 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       meta = f4{mu, 1.0f / Rr, -kk * imp * dist, bb};
     }
     {  // does any contact of the env move dofs of both trees?  (bit 0; bits 1 .. 16: contact c moves dofs of the second tree only --
-       // what the per-tree line searches of the solver need to know about a contact when the problem separates)
+       // what the tree-wise parts of the solver need to know about a contact when the problem separates; bits 20 .. 27: candidate
+       // points before the capacity was applied, for the diagnostics record -- the word travels with the scratch row of a split step)
       const uint32_t low = (1u << mdl_split) - 1u, both = dm1 | dm2;
       const unsigned long long cb = __ballot(mine && (both & low) != 0u && (both & ~low) != 0u);
       const unsigned long long tb = __ballot(mine && (both & low) == 0u);
-      if (lane == 0) S.coupled = (int)(((uint32_t)(cb >> (grp * G)) & 0xffffu ? 1u : 0u) | ((uint32_t)(tb >> (grp * G)) & 0xffffu) << 1);
+      if (lane == 0) S.coupled = (int)(((uint32_t)(cb >> (grp * G)) & 0xffffu ? 1u : 0u) | ((uint32_t)(tb >> (grp * G)) & 0xffffu) << 1 | (uint32_t)(ptotal < 255 ? ptotal : 255) << 20);
     }
     HSTAMP(43);
     if (DUAL) __syncthreads();  // (2) the main wave has left the dynamics scratch: the contact arrays may be stored over it
@@ -1499,7 +1502,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     const uint32_t limmask = (uint32_t)(__ballot(lsg != 0.0f) >> (grp * G)) & 0xffffu;
     const int nefc = 4 * ncon + __popc(limmask);
     // the Hessian is block diagonal by tree unless a contact joins the arm and the cube somewhere in this wave
-    const int cpl = S.coupled;  // bit 0: some contact joins the trees; bits 1 .. 16: contact c belongs to the second tree
+    const int cpl = S.coupled;  // bit 0: some contact joins the trees; bits 1 .. 16: contact c belongs to the second tree; 20 .. 27: see contacts_build
     const int hsplit = __any((cpl & 1) != 0) ? 0 : mdl_split;
     // Where no contact joins the two trees the problem SEPARATES -- f = f_A(a_A) + f_B(a_B), block-diagonal Hessian.  The line search
     // stays one per env, but a step is ACCEPTED tree by tree (below), so that each tree's own cost decreases monotonically: what the
@@ -1871,7 +1874,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       a.diag[(size_t)env * 4 + 0] = ncon;
       a.diag[(size_t)env * 4 + 1] = nefc;
       a.diag[(size_t)env * 4 + 2] = niter;
-      a.diag[(size_t)env * 4 + 3] = S.ncand;
+      a.diag[(size_t)env * 4 + 3] = S.ncand | (cpl >> 20 & 255) << 8;
     }
     STAMP(8);
     if (a.mode != 0) return 1;
@@ -1937,7 +1940,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       const bool bad = ((uint32_t)(__ballot(nf) >> (grp * G)) & 0xffffu) != 0u;
       bad_acc = bad_acc || bad;
       if (valid && lane == 0) {
-        a.diag[(size_t)env * 4 + 3] = S.ncand | (bad_acc ? 1 << 30 : 0);
+        a.diag[(size_t)env * 4 + 3] = S.ncand | (cpl >> 20 & 255) << 8 | (bad_acc ? 1 << 30 : 0);
         if (bad && a.early_stats) atomicAdd(a.early_stats, 1u);  // (word 0: env-steps that ended non-finite, since the last reset of the counters)
       }
     }

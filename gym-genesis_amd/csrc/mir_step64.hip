@@ -554,7 +554,7 @@ void mir_step64_kernel(StepArgs64 a) {
   // its own scratch (S.col), the contact arrays (S.con) and read-only state, so in the single-step instantiation it runs on
   // wave 1 next to the dynamics.
   auto collide = [&]() {
-    if (lane == 0) { S.ncon = 0; S.ncand = 0; }
+    if (lane == 0) { S.ncon = 0; S.ncand = 0; S.pad0 = 0; }
     if (lane < ngeom) {
       Q4 qb = ld4v(S.xquat[g_bodyl]);
       st3v(S.col.gpos[lane], ld3v(S.xpos[g_bodyl]) + qrot(qb, g_posl));
@@ -757,6 +757,7 @@ void mir_step64_kernel(StepArgs64 a) {
       // more candidate points than the capacity: the largest manifolds are thinned before any pair loses all of its points (the
       // rule is defined at oracle/orc_rigid.c: thin_manifolds; same code path as in the 16-lane kernel, one env per wave here)
       int total0 = (int)wsum((float)mycount);
+      if (lane == 0) S.pad0 = total0;  // (candidate points before the capacity is applied, for the diagnostics record)
       if (total0 > maxc) {
         for (int round = 0; round < 8; round++) {  // (a manifold holds at most 8 points)
           const int mx = (int)wmaxf((float)mycount);
@@ -1698,7 +1699,7 @@ void mir_step64_kernel(StepArgs64 a) {
       a.diag[(size_t)env * 4 + 1] = (int)(__builtin_readcyclecounter() - t_entry) | (coupled ? 1 << 30 : 0);
 #endif
 #endif
-      a.diag[(size_t)env * 4 + 3] = ncand;
+      a.diag[(size_t)env * 4 + 3] = ncand | (S.pad0 & 255) << 8;
     }
     if (a.mode != 0) break;
 
@@ -1739,7 +1740,7 @@ void mir_step64_kernel(StepArgs64 a) {
       const bool bad = __any(nf);
       bad_acc = bad_acc || bad;
       if (lane == 0) {
-        a.diag[(size_t)env * 4 + 3] = ncand | (bad_acc ? 1 << 30 : 0);
+        a.diag[(size_t)env * 4 + 3] = ncand | (S.pad0 & 255) << 8 | (bad_acc ? 1 << 30 : 0);
         if (bad && a.bad_count) atomicAdd(a.bad_count, 1u);
       }
     }

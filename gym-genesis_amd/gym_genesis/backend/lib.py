@@ -88,6 +88,8 @@ def load_library() -> C.CDLL:
     lib.mir_debug_spec_active.restype = C.c_int
     lib.mir_debug_early_mask_stats.argtypes = [vp, C.POINTER(C.c_uint32), i32, vp]
     lib.mir_debug_early_mask_stats.restype = C.c_int
+    lib.mir_get_diag4.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mir_get_diag4.restype = C.c_int
     lib.mir_get_bad.argtypes = [vp, vp, C.POINTER(C.c_uint32), i32, vp]
     lib.mir_get_bad.restype = C.c_int
     lib.mir_debug_raise_mask_flag.argtypes = [vp]
@@ -488,8 +490,14 @@ class MirScene(StepHelpers):
         """Switch the per-env solver diagnostics (ncon / nefc / niter, 16 B per env-step) on or off (mir_set_diag)."""
         self._check(self.lib.mir_set_diag(self.h, 1 if on else 0))
 
-    def get_diag(self):
+    def get_diag(self, points: bool = False):
+        """(ncon, nefc, niter) of the last step, int32 (B,) each; points=True adds the candidate contact points found before the
+        contact capacity was applied (mir_get_diag4: more than `max_contacts` = the manifolds were thinned)."""
         a, b, c = (self.empty(dtype=torch.int32) for _ in range(3))
+        if points:
+            d = self.empty(dtype=torch.int32)
+            self._check(self.lib.mir_get_diag4(self.h, _ptr(a), _ptr(b), _ptr(c), _ptr(d), self._stream()))
+            return a, b, c, d
         self._check(self.lib.mir_get_diag(self.h, _ptr(a), _ptr(b), _ptr(c), self._stream()))
         return a, b, c
 

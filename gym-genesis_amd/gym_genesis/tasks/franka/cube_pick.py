@@ -36,8 +36,13 @@ ENV_DIM = 11
 
 class FrankaCubePickBatch:
     def __init__(self, enable_pixels, observation_height, observation_width, num_envs, env_spacing,
-                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None, link_shape: str = "capsule"):
+                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None, link_shape: str = "capsule",
+                 contact_capacity: int = 16):
         # link_shape: collision stand-ins of links 1-7, "box" or "capsule" (models._add_franka); not a reference kwarg
+        # contact_capacity: contact points kept per env (not a reference kwarg; Genesis keeps 100+ pairs).  16 = the 16-lane kernel
+        # (manifolds thinned beyond that: 29 % of the env-steps of the reference's expert, same success rate -- tests/test_ref_expert.py);
+        # 17 .. 48 = the same scene on the wave-per-env kernel, never thinned by that policy, several times slower
+        self.contact_capacity = int(contact_capacity)
         self.enable_pixels = enable_pixels
         self.observation_height = observation_height
         self.observation_width = observation_width
@@ -63,6 +68,8 @@ class FrankaCubePickBatch:
         if self.enable_pixels and self.camera_capture_mode not in ("per_env", "global"):
             raise ValueError(f"Unknown camera_capture_mode: {self.camera_capture_mode}")  # cube_pick.py:177-178
         builder = models.franka_cube_pick_scene(link_shape=self.link_shape)
+        if self.contact_capacity != 16:
+            builder.opt["max_contacts"] = self.contact_capacity
         self._builder = builder
         self._mir = MirScene(builder.build(), self.num_envs)
         self._mir.set_diag(False)  # solver diagnostics (16 B per env-step) are a debugging aid: _mir.set_diag(True) to read them

@@ -324,6 +324,11 @@ int mir_get_links(MirHandle h, float* pos, float* quat, void* stream);
  * mir_get_diag is an error until they are switched on again.  On by default. */
 int mir_set_diag(MirHandle h, int32_t on);
 int mir_get_diag(MirHandle h, int32_t* ncon, int32_t* nefc, int32_t* niter, void* stream);
+/* mir_get_diag + ncand_points (B) i32, nullable: the contact points the narrowphase found BEFORE the scene's contact capacity was
+ * applied (MirOptions.max_contacts; 16 at most in the 16-lane kernel, 48 in the wave kernel).  ncand_points > capacity = the
+ * manifolds of that env-step were thinned (oracle/orc_rigid.c: thin_manifolds); the fraction of such env-steps is what bench.py and
+ * the reference-expert tests report as cap_hit_frac.  Saturates at 255. */
+int mir_get_diag4(MirHandle h, int32_t* ncon, int32_t* nefc, int32_t* niter, int32_t* ncand_points, void* stream);
 
 /* Divergence guard (the reference's users get Genesis's own error on a NaN state, scene.step() at
  * gym_genesis/tasks/franka/cube_pick.py:107,125).  While diagnostics are on, a step kernel flags every env whose integrated qpos / qvel

@@ -186,6 +186,12 @@ class Oracle:
         self.lib.orc_counts_batch(self.data, C.c_int(self.B), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
         return a, b, c
 
+    def ncand_all(self) -> np.ndarray:
+        """candidate contact points of every env's last collision pass, before the capacity was applied (orc_ncand_batch)"""
+        a = np.zeros(self.B, np.int32)
+        self.lib.orc_ncand_batch(self.data, C.c_int(self.B), a.ctypes.data_as(C.c_void_p))
+        return a
+
     def get_obs_all(self):
         """get_obs() in one call (orc_get_obs_batch)."""
         agent, env = np.zeros((self.B, self.agent_dim)), np.zeros((self.B, self.env_dim))

@@ -966,6 +966,7 @@ static void thin_manifolds(int* cnt, CPoint (*pts)[16], int npairs, int maxc) {
 
 static void orc_collide(const OrcModel* m, OrcData* d) {
   d->ncon = 0;
+  d->ncand = 0;
   if (!m->opt.enable_collision) return;
   int maxc = m->opt.max_contacts < ORC_NC ? m->opt.max_contacts : ORC_NC;
   /* pass 1: the narrowphase of every pair, in pair order */
@@ -992,6 +993,8 @@ static void orc_collide(const OrcModel* m, OrcData* d) {
     if (cnt > 0) { pcnt[np] = cnt; ppair[np] = pidx; np++; }
   }
   /* pass 2: fit the capacity, then the contact arrays in pair order */
+  d->ncand = 0;
+  for (int i = 0; i < np; i++) d->ncand += pcnt[i];
   thin_manifolds(pcnt, ppts, np, maxc);
   for (int i = 0; i < np; i++) {
     int g1 = m->pair_g1[ppair[i]], g2 = m->pair_g2[ppair[i]];
@@ -1714,6 +1717,9 @@ void orc_counts_batch(const OrcData* d, int B, int* ncon, int* nefc, int* niter)
     if (nefc) nefc[e] = d[e].nefc;
     if (niter) niter[e] = d[e].niter;
   }
+}
+void orc_ncand_batch(const OrcData* d, int B, int* ncand) {
+  for (int e = 0; e < B; e++) ncand[e] = d[e].ncand;
 }
 void orc_get_obs_batch(const OrcModel* m, const OrcData* d, int B, double* agent_pos, int agent_dim, double* env_state, int env_dim, double* reward,
                        unsigned char* terminated) {

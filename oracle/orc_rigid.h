@@ -99,6 +99,7 @@ typedef struct OrcData {
   int nefc;
   real J[ORC_NEFC][ORC_NV], aref[ORC_NEFC], efcD[ORC_NEFC], efcpos[ORC_NEFC], efcforce[ORC_NEFC];
   int niter;
+  int ncand; /* candidate contact points of the last collision pass BEFORE the capacity was applied (> max_contacts: thinning fired) */
   real dbg_imp[64], dbg_gn[64], dbg_alpha[64], dbg_ls[64]; /* per-iteration solver trace (dbg_ls: phi' evaluations of the line search) */
 } OrcData;
 
@@ -131,6 +132,7 @@ int orc_counts(const OrcData* d, int* ncon, int* nefc, int* niter);
 int orc_read_batch(const OrcModel* m, const OrcData* d, int B, int field, double* out, int stride);
 int orc_write_batch(const OrcModel* m, OrcData* d, int B, int field, const double* in, int stride);
 void orc_counts_batch(const OrcData* d, int B, int* ncon, int* nefc, int* niter);
+void orc_ncand_batch(const OrcData* d, int B, int* ncand);
 void orc_get_obs_batch(const OrcModel* m, const OrcData* d, int B, double* agent_pos, int agent_dim, double* env_state, int env_dim, double* reward,
                        unsigned char* terminated);
 /* independent articulated-body (Featherstone ABA) unconstrained forward dynamics, for cross-checks */
