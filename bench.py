@@ -711,10 +711,17 @@ def worker(args) -> int:
     def unpin():
         """Back to the affinity the process started with (the CPU baseline spreads over every core it may use)."""
         if free_cpus:
+            # EVERY thread of the process (an OpenMP pool or a runtime helper that already exists keeps the mask it was created
+            # with or moved to -- the rank's slice -- while `cores` below reports the whole machine)
             try:
-                os.sched_setaffinity(0, free_cpus)
-            except Exception:  # noqa: BLE001
-                pass
+                tids = [int(t) for t in os.listdir("/proc/self/task")]
+            except OSError:
+                tids = [0]
+            for tid in tids + [0]:
+                try:
+                    os.sched_setaffinity(tid, free_cpus)
+                except Exception:  # noqa: BLE001
+                    pass
 
     def host_thread_note() -> str:
         if placement["pinned_cpu"] is None:
@@ -767,27 +774,43 @@ def worker(args) -> int:
         from gym_genesis.sharding import make_copy_gather
         copy_gather, gather_note = make_copy_gather(S * flat, dev)
     last_seq = [0]
+    check_gather = [False]
     # the step kernels write straight into the gather's send buffer: the outputs of consecutive steps are consecutive rows of one
     # ring (4 chunks of S steps: two in flight, one being filled, one spare), a chunk = S contiguous rows, no concatenation
-    ring = task._mir.use_output_ring(4 * S, 9, 11) if gather else None
+    ring = task._mir.use_output_ring(4 * S, 9, 11) if gather else None   # (RING_CHUNKS x S rows)
     if not gather and args.output_ring > 0:
         task._mir.use_output_ring(args.output_ring, 9, 11)
-    chunk_parts: list = []
-    state = {"chunk": 0, "t": 0, "resets": 0}
+    RING_CHUNKS = 4
+    # `sent`: first row of the current ring chunk that has not been gathered yet, `row`: the row the latest step wrote (-1: none)
+    state = {"chunk": 0, "t": 0, "resets": 0, "sent": 0, "row": -1}
+    last_block = [None]
+    gather_stats = {"pushes": 0, "partial_pushes": 0, "lag_max": 0, "checks": 0, "checks_failed": 0}
 
     def flush():
-        """All-gather the outputs of the steps collected so far (async: overlaps the following steps)."""
-        if gather_on[0] and chunk_parts:
-            send = chunk_parts[0] if len(chunk_parts) == 1 else torch.cat(chunk_parts)
-            if copy_gather is not None:
-                last_seq[0] = copy_gather.push(send)   # device-to-device copies on the side stream: nothing to wait for here
-            else:
-                s = state["chunk"] & 1
-                if pending[s] is not None:
-                    pending[s].wait()
-                pending[s] = dist.all_gather_into_tensor(gathered[s][:pg_world * send.numel()], send, async_op=True)
-            state["chunk"] += 1
-            chunk_parts.clear()
+        """Gather the rows written since the last flush (a whole chunk of S steps in the loop; whatever there is at the end of a
+        timed region) -- asynchronously: the transfer overlaps the following steps."""
+        row, lo = state["row"], state["sent"]
+        if not gather_on[0] or row < lo:
+            return
+        send = ring[lo:row + 1].reshape(-1)   # rows of one ring chunk: one contiguous block, no concatenation
+        if copy_gather is not None:
+            last_seq[0] = copy_gather.push(send)   # device-to-device copies on the side streams: nothing to wait for here
+            # the step kernels are about to write the NEXT ring chunk: they wait (on the device) until the copies of the push that
+            # last read it -- RING_CHUNKS - 1 pushes ago at one push per chunk; every older push when partial chunks were sent --
+            # are through with it
+            for back in range(RING_CHUNKS - 1, RING_CHUNKS + 3):
+                copy_gather.wait_source(last_seq[0] - back)
+            gather_stats["lag_max"] = max(gather_stats["lag_max"], copy_gather.lag())
+        else:
+            s = state["chunk"] & 1
+            if pending[s] is not None:
+                pending[s].wait()
+            pending[s] = dist.all_gather_into_tensor(gathered[s][:pg_world * send.numel()], send, async_op=True)
+        last_block[0] = send
+        gather_stats["pushes"] += 1
+        gather_stats["partial_pushes"] += 1 if (row + 1 - lo) < S else 0
+        state["chunk"] += 1
+        state["sent"] = row + 1 if (row + 1) % S else ((row + 1) % (RING_CHUNKS * S))
 
     def api_loop(k: int):
         """k iterations of the README loop through GenesisEnv.step (README.md:32-43)."""
@@ -796,8 +819,10 @@ def worker(args) -> int:
             obs, reward, terminated, truncated, info = step(act_list[t % n])
             if gather_on[0]:
                 row = obs["agent_pos"].storage_offset() // flat   # the ring row this step's kernel wrote
-                if row % S == S - 1:                              # a chunk is complete: its S rows are one contiguous block
-                    chunk_parts.append(ring[row - S + 1:row + 1].reshape(-1))
+                if row % S == 0 or row != (state["row"] + 1) % (RING_CHUNKS * S):
+                    state["sent"] = row                           # a new chunk (or the rows in between were not part of a gather)
+                state["row"] = row
+                if row % S == S - 1:                              # a chunk is complete: its rows are one contiguous block
                     flush()
             t += 1
             if terminated.any() or truncated.any() or t % EPISODE_STEPS == 0:
@@ -826,6 +851,12 @@ def worker(args) -> int:
         if use_pg:
             dist.barrier()
         torch.cuda.synchronize(dev)
+        if copy_gather is not None and last_seq[0] and last_block[0] is not None and check_gather[0]:
+            # (outside the timed brackets' clock?  No: sync_all is the bracket.  The check is therefore switched on only for the
+            #  verification pass after the measurements, see below)
+            gather_stats["checks"] += 1
+            if not copy_gather.check_against_collective(last_seq[0], last_block[0]):
+                gather_stats["checks_failed"] += 1
 
     def max_over_ranks(x: float) -> float:
         if not use_pg:
@@ -881,6 +912,12 @@ def worker(args) -> int:
             task._mir.early_mask_stats(reset=True)
             api_walls, _ = measure(api_loop)
             walls = api_walls
+            if copy_gather is not None:
+                # one more region, NOT part of the measurement: its last gather is compared with all_gather_into_tensor of the same
+                # block on every rank (a torn or lagging copy path shows here, not only in the start-up verification)
+                check_gather[0] = True
+                timed(api_loop, K, False)
+                check_gather[0] = False
         # the early `terminated` bytes of exactly these launches (warm-up included): workgroup-launches that sent their bytes from inside the
         # solver loop, and how many of those the kernel's own check against the integrated state found wrong (a non-zero count would
         # also have failed the loop with MIR_E_MASK, include/mirigid.h: mir_step_begin)
@@ -910,6 +947,10 @@ def worker(args) -> int:
                                       (f"{args.dist_backend} all_gather of [agent_pos|environment_state|reward] of {S} steps per collective, "
                                        "overlapped with the following steps" + (f" (copy path not used: {gather_note})" if gather_note else ""))),
                        "gather_path": None if not gather else ("copy" if copy_gather is not None else "rccl"),
+                       "output_ring": (f"step outputs are rows of a reusable ring of {RING_CHUNKS * S} steps (the gather's send buffer): a step's "
+                                       "tensors are overwritten that many steps later; fresh tensors per step without a gather") if gather else
+                                      (f"ring of {args.output_ring} steps (--output-ring)" if args.output_ring > 0 else "none: fresh tensors every step"),
+                       "gather_stats": dict(gather_stats) if gather else None,
                        "terminated_sync_mode": task._mir.sync_mode, "split_step": int(getattr(task._mir, "split_step", 0)),
                        "early_terminated_bytes": bool(task._mir.early_mask),
                        "value_is": "mean over the repeated K-step regions (value_median_region: their median)",
@@ -938,13 +979,13 @@ def worker(args) -> int:
                 gather_on[0] = False
                 ng_walls, _ = measure(api_loop)
                 gather_on[0] = True
-                us_g = sorted(walls)[len(walls) // 2] * 1e6 / K
-                us_ng = sorted(ng_walls)[len(ng_walls) // 2] * 1e6 / K
+                us_g = sum(walls) * 1e6 / (len(walls) * K)          # (means over all regions: every region ends with a push)
+                us_ng = sum(ng_walls) * 1e6 / (len(ng_walls) * K)
                 out["gather_overhead_us"] = us_g - us_ng
                 out["no_gather"] = {"value": len(ng_walls) * K * B * world / sum(ng_walls), "value_median_region": K * B * world / sorted(ng_walls)[len(ng_walls) // 2],
-                                    "median_us_per_step": us_ng, "median_us_per_step_with_gather": us_g, "repeats": len(ng_walls),
+                                    "mean_us_per_step": us_ng, "mean_us_per_step_with_gather": us_g, "repeats": len(ng_walls),
                                     "note": "the headline loop with the observation gather switched off, measured right after the headline; "
-                                            "gather_overhead_us = difference of the median regions"}
+                                            "gather_overhead_us = difference of the mean us per step"}
             except Exception as e:  # noqa: BLE001
                 gather_on[0] = True
                 out["gather_overhead_us"] = None

@@ -424,6 +424,10 @@ int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_p
  * mir_p2p_enable makes `peer`'s memory addressable from `device` (idempotent). */
 int mir_p2p_enable(int32_t device, int32_t peer);
 int mir_p2p_push(void* const* dst, int32_t n, const void* src, uint64_t nbytes, void* const* flag_dst, const void* flag_src, void* stream);
+/* mir_p2p_push with one stream per destination (streams[i] carries destination i's block and then its word): the copies to different
+ * peers overlap.  nbytes = 0 sends the words only (the acknowledgements of the gather's flow control). */
+int mir_p2p_push_streams(void* const* dst, int32_t n, const void* src, uint64_t nbytes, void* const* flag_dst, const void* flag_src,
+                         void* const* streams);
 
 /* ---- debug aids (exported for the tests and tools/; not part of the drop-in surface) ---------------------------
  * mir_debug_profile_step: one step with phase timestamps (shader clock) of workgroup 0 into prof (32 x u64, device).

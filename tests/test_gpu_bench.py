@@ -48,6 +48,8 @@ def test_two_ranks_share_the_gpu_over_gloo():
     # gather as a number, and where the rank's threads were put
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
     assert isinstance(out["gather_overhead_us"], float) and out["no_gather"]["value"] > 0
+    gs = out["config"]["gather_stats"]   # (two ranks' copies into each other's buffers, checked against the collective at the end)
+    assert gs["pushes"] > 0 and gs["checks"] >= 1 and gs["checks_failed"] == 0
     if len(os.sched_getaffinity(0)) >= 4:
         assert "stepping thread on cpu" in out["config"]["host_thread"], out["config"]["host_thread"]
 
@@ -62,7 +64,12 @@ def test_first_rccl_run_one_rank_force_gather():
     assert out["n_gpus"] == 1 and cfg["world_size_observed"] == 1 and cfg["dist_backend"] == "nccl"
     assert cfg["gather_path"] == "copy" and out["value"] > 1e6
     assert isinstance(out["gather_overhead_us"], float) and abs(out["gather_overhead_us"]) < 50.0
-    assert out["no_gather"]["median_us_per_step"] > 0
+    assert out["no_gather"]["mean_us_per_step"] > 0
+    # every timed region ends with a push (partial chunks included), the last gather of a region was checked against the collective,
+    # and the ring of reused output rows is disclosed
+    gs = cfg["gather_stats"]
+    assert gs["pushes"] > 0 and gs["partial_pushes"] > 0 and gs["checks"] >= 1 and gs["checks_failed"] == 0
+    assert "ring" in cfg["output_ring"]
 
 
 
