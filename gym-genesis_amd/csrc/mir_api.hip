@@ -199,7 +199,6 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.model = h->dm;
     a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
     a.poses = o.poses ? h->poses : nullptr;
-    a.pose_cache = h->poses; a.fkvalid = h->pose_cache_on ? h->fkvalid : nullptr;
     a.early_stats = h->early_stats; a.no_early_mask = h->no_early_mask;
     a.term_bad = h->pin_dev ? reinterpret_cast<uint32_t*>(h->pin_dev + h->pin_flag_off + 16) : nullptr;
     a.term_wstride = h->term_wstride;
@@ -298,11 +297,10 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   HIPCHK(hipMalloc((void**)&h->scratch_row, row_bytes));
   if (h->kernel == 16) HIPCHK(hipMalloc((void**)&h->pre, B * K16_PRE_STRIDE * sizeof(float)));
   h->spec_pick = h->kernel == 16 && SpecPick::matches(h->hm) && !getenv("MIR_NO_SPEC");
-  h->pose_cache_on = !getenv("MIR_NO_POSE_CACHE");
   h->no_early_mask = getenv("MIR_NO_EARLY_MASK") ? 1 : 0;
   HIPCHK(hipMalloc((void**)&h->early_stats, early_words(h) * sizeof(uint32_t)));
   HIPCHK(hipMemset(h->early_stats, 0, early_words(h) * sizeof(uint32_t)));
-  if (h->kernel == 64 && !getenv("MIR_NO_ORDER")) {  // dispatch-order flags of the wave kernel (mir_step64.h): two buffers, padded to whole 64-byte reads
+  if (h->kernel == 64) {  // dispatch-order flags of the wave kernel (mir_step64.h): two buffers, padded to whole 64-byte reads
     h->cost_stride = (int)(((B + 63) / 64) * 64);
     HIPCHK(hipMalloc((void**)&h->cost, 2 * (size_t)h->cost_stride));
     HIPCHK(hipMemset(h->cost, 0, 2 * (size_t)h->cost_stride));
@@ -311,8 +309,8 @@ int create_device_state(MirScene* h, const GeomTab& gt, const float* row, size_t
   // 16-lane kernel: every workgroup (4 envs) owns a whole 64-byte line of the area.  Sixteen workgroups storing their 4 bytes into one
   // line -- sixteen partial writes over PCIe into a line the polling CPU holds -- cost the launch that follows 1.6 us and now and then
   // several (tools/probes/launch/late_enqueue3.hip: idle gap between two kernels 4.7 us with 16, 8 or 4 writers per line, 3.9 with two,
-  // 3.05 with one = as with no host stores at all); MIR_TERM_DENSE=1 keeps the dense layout
-  h->term_wstride = h->kernel == 16 ? (getenv("MIR_TERM_DENSE") ? 1 : 16) : 0;
+  // 3.05 with one = as with no host stores at all)
+  h->term_wstride = h->kernel == 16 ? 16 : 0;
   h->pin_flag_off = h->term_wstride ? ((B + 3) / 4) * 4 * (size_t)h->term_wstride : ((B + 63) / 64) * 64;
   h->pin_flag_off = (h->pin_flag_off + 63) / 64 * 64;
   const size_t pin_bytes = h->pin_flag_off + 64;

@@ -242,13 +242,9 @@ MIR_GJPD(6, 12)
 #undef MIR_GJPD
 // dispatch on the model's block split (0 = dense) and dof count; both must be wave-uniform
 __device__ __forceinline__ void gj_solve(float (&a)[G], float& b, int lane, int split, int nv) {
-#ifndef MIR_GJ_NO_DPP_ASM
   if (split == 9 && nv == 15) { gjpd_9_15<0>(a, b, lane); return; }
   if (split == 6 && nv == 12) { gjpd_6_12<0>(a, b, lane); return; }
-#endif
-  if (split == 9 && nv == 15) GJP<9, 15, 0>::run(a, b, lane);
-  else if (split == 6 && nv == 12) GJP<6, 12, 0>::run(a, b, lane);
-  else if (split == 9) GJ2<9, 0>::run(a, b, lane);
+  if (split == 9) GJ2<9, 0>::run(a, b, lane);
   else if (split == 6) GJ2<6, 0>::run(a, b, lane);
   else GJ<0>::run(a, b, lane);
 }

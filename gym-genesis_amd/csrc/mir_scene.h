@@ -23,7 +23,6 @@ struct MirScene {
   uint8_t* cost = nullptr;  // wave kernel: two buffers of per-env cost flags (B padded to 64 each) for the dispatch order, see mir_step64.h
   int cost_par = 0;         // which of the two the next single-step launch reads
   int cost_stride = 0;
-  int pose_cache_on = 1;    // 16-lane kernel: fused single-step launches open with the poses the previous one closed with (MIR_NO_POSE_CACHE=1: always FK)
   uint32_t* early_stats = nullptr;  // 16-lane kernel: [1] mismatches of the early terminated bytes, [2 + w] launches in which workgroup w sent early (mir_step.h)
   int no_early_mask = 0;    // MIR_NO_EARLY_MASK=1, or a mismatch was seen (MIR_E_MASK)
   int spec_pick = 0;        // 16-lane kernel: the compiled model matches SpecPick (mir_spec_pick.h) and MIR_NO_SPEC is unset: specialised instantiation
@@ -38,7 +37,7 @@ struct MirScene {
   uint8_t* pin_host;        // host address
   size_t pin_flag_off = 0;  // byte offset of the completion word behind the terminated area
   int term_wstride = 0;     // 16-lane kernel: 32-bit words between the terminated words of consecutive workgroups in the pinned area (16 = one
-                            // 64-byte line each, see mir_step_end; 1 = dense, MIR_TERM_DENSE=1); 0 = one byte per env (wave kernel)
+                            // 64-byte line each, see mir_step_end); 0 = one byte per env (wave kernel)
   uint8_t* pin_dev;         // the same memory as the device sees it
   uint32_t* done_ticket;    // device counter for the kernel-side completion (sync mode 2)
   uint32_t seq;             // sequence number of the completion word (sync modes 1 / 2, mir_debug_null_roundtrip)

@@ -12,8 +12,6 @@ struct StepArgs {
   float* target;  // (B, 16) indexed by dof
   float* qacc_ws; // (B, 16)
   float* poses;   // (B, 2, 16, 4) or null: link positions then quaternions written for the rasteriser (mode 2 only)
-  float* pose_cache;  // same buffer, always set: the poses a fused single-step launch closed with (read back by the next one when fkvalid)
-  int32_t* fkvalid;   // (B) 1 = pose_cache[env] holds the poses of the stored state; or null (cache off)
   const float* action;  // (B, nu) or null
   float* agent_pos;     // (B, 7+n_grip) or null
   float* env_state;     // (B, 11) or null

@@ -51,6 +51,8 @@
 #define MAXCON K16_MAX_CONTACT
 #define JST 52      /* floats per contact in Jb: 3 rows x 16 + 4 pad -> conflict-free ds_read_b128 across contact lanes */
 #define MSTR 20     /* row stride of M in LDS (floats): 16-byte aligned rows, conflict-free b128 row reads */
+#define JB_SKEW 8   /* see EnvLds::Jb_ */
+#define JBROW(Sx, c) (&(Sx).Jb_[(c) * JST + jbs])
 static_assert(MAXCON == G, "lane c owns contact c");
 
 // optional phase timestamps (debug): block 0, thread 0 records the shader clock at phase boundaries
@@ -127,11 +129,17 @@ struct EnvLds {
     };
     struct {
       ContactArrays con;
-      float Jb[MAXCON][JST];
+      // contact Jacobian rows, row c at Jb_[c * JST + jbs]: the rows of the ODD envs of a wave start JB_SKEW floats later.  An env's block
+      // is 2280 dwords = 8 mod 32 long, so the 16 consecutive dwords that the 16 lanes of two neighbouring envs read from the same
+      // row with one ds_read_b32 (banks = dword mod 32, two envs per 32-lane group) would overlap in 8 banks: every such read -- three
+      // per contact in the gradient loop of every Newton iteration -- took two LDS cycles instead of one.  The skew moves the odd env's
+      // rows to the other 16 banks; the space comes out of the slack of this half of the union.
+      float Jb_[MAXCON * JST + JB_SKEW];
     };
   };
 };
 static_assert(sizeof(ContactArrays) <= sizeof(DynScratch), "the contact arrays must not reach the collision staging area");
+static_assert(sizeof(ContactArrays) + (MAXCON * JST + JB_SKEW) * sizeof(float) <= sizeof(DynScratch) + sizeof(ColScratch), "the skewed Jacobian rows must fit the union");
 static_assert(EPB * sizeof(EnvLds) + sizeof(ModelTab) + K16_MAX_VERT * 16 <= 40960, "four workgroups per CU: 160 KB of LDS / 4 (hull vertices included)");
 
 // body-lane constants needed by forward kinematics
@@ -285,6 +293,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   const int lane = tid & (G - 1);
   const int row4 = (tid & ~(G - 1)) << 2;  // byte offset of this env's first lane in the wave (lane_gather)
   const int grp = tid >> 4;
+  const int jbs = (grp & 1) * JB_SKEW;  // (EnvLds::Jb_)
   const int env_raw = blockIdx.x * EPB + grp;
   const bool valid = env_raw < a.B;
   const int env = valid ? env_raw : a.B - 1;
@@ -325,7 +334,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       for (int u = 0; u < 4; u++) {
         const int c = c0 + u < nc ? c0 + u : c0;
         mk[u] = c0 + u < nc ? Sx.con.cmask[c][2] : 0u;  // (the contact's 4-dof chunks: the quads in which one of its bodies has a dof)
-        v[u] = ldv(&Sx.Jb[c][lane < 12 ? 16 * r + 4 * q : 0]);
+        v[u] = ldv(JBROW(Sx, c) + (lane < 12 ? 16 * r + 4 * q : 0));
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -355,7 +364,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       }
 #pragma unroll
       for (int u = 0; u < 4; u++)
-        if (lane < 12 && c0 + u < nc) stv(&Sx.Jb[c0 + u][16 * r + 4 * q], on[u] ? v[u] : f4{0, 0, 0, 0});
+        if (lane < 12 && c0 + u < nc) stv(JBROW(Sx, c0 + u) + 16 * r + 4 * q, on[u] ? v[u] : f4{0, 0, 0, 0});
     }
   };
   // DUAL: the closing FK is split between the waves when every free-joint body is a childless child of the world (wave-uniform)
@@ -366,11 +375,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   const int mdl_obj_qadr = SPEC ? SpecPick::obj_qadr : m->obj_qadr;
   const bool term_early = VARIANT != 1 && fk_free_leaf && mdl_obj_qadr >= 0;
   // ... and before the solver has converged where the mask provably cannot change any more (see mir_model.h: term_bound_ok)
-#ifdef MIR_NO_EARLY_CODE  /* (A/B builds: the early-mask code compiled out) */
-  constexpr bool term_bound = false;
-#else
   const bool term_bound = (VARIANT == 0 || VARIANT == 5) && term_early && m->term_bound_ok != 0 && a.term_host != nullptr && !a.no_early_mask;
-#endif
   const int term_zlane = SPEC ? SpecPick::term_zlane : m->term_zlane;
 
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
@@ -680,7 +685,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         const float sgn = (in2 ? 1.0f : 0.0f) - (in1 ? 1.0f : 0.0f); /* a dof moving both bodies cancels */ \
         const V3 r = v3(cp.x, cp.y, cp.z) - (in2 ? v3(r2.x, r2.y, r2.z) : v3(r1.x, r1.y, r1.z));            \
         const V3 vel = cross(cd_ang, r) + cd_lin;                                                           \
-        float* jb = &S.Jb[cc][0];                                                                           \
+        float* jb = JBROW(S, cc);                                                                           \
         /* (selects, not products: a lane that carries no dof holds stale LDS in cd_ang / cd_lin, and 0 x NaN is NaN) */ \
         jb[lane] = sgn != 0.0f ? sgn * dot(vel, v3(fn.x, fn.y, fn.z)) : 0.0f;                               \
         jb[16 + lane] = sgn != 0.0f ? sgn * dot(vel, v3(f1.x, f1.y, f1.z)) : 0.0f;                          \
@@ -824,7 +829,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
 #pragma unroll
     for (int j = 0; j < G; j++) hp[j] = 0.0f;
     for (int c = 0; c < ncon; c++) {
-      const float* jb = &S.Jb[c][0];
+      const float* jb = JBROW(S, c);
       const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
       const f4 mt = ldv(S.con.cmeta[c]);
       f4 xn[4], x1[4], x2[4];
@@ -926,27 +931,12 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // table, the other rows and the action), and the main wave finds the link poses ready when it reaches the first barrier.
       const float hq_lo = lane < a.qst ? a.qpos[(size_t)env * a.qst + lane] : 0.0f;
       const float hq_hi = lane + G < a.qst ? a.qpos[(size_t)env * a.qst + lane + G] : 0.0f;
-      // ... unless the previous launch was a fused step of the same env and nothing has touched its state since: then the poses it
-      // closed with are in the pose cache (fetched with the same batch of loads; group-uniform branch)
-      const bool use_cache = VARIANT == 0 && a.fkvalid != nullptr;
-      const int cvalid = use_cache ? a.fkvalid[env] : 0;
-      f4 cpos = {0, 0, 0, 0}, cquat = {0, 0, 0, 0};
-      if (use_cache) {
-        const float* p = a.pose_cache + ((size_t)env * 2 * G + lane) * 4;
-        cpos = *reinterpret_cast<const f4*>(p);
-        cquat = *reinterpret_cast<const f4*>(p + 4 * G);
-      }
       BodyK hk;
       fk_consts(hk);
       if (lane < a.qst) S.qpos[lane] = hq_lo;
       if (lane + G < a.qst) S.qpos[lane + G] = hq_hi;
-      if (cvalid != 0) {
-        if (lane < nb) { stv(S.xpos[lane], cpos); stv(S.xquat[lane], cquat); }
-        WSYNC();
-      } else {
-        WSYNC();
-        group_fk(S, lane, nb, hparents, hk, row4);
-      }
+      WSYNC();
+      group_fk(S, lane, nb, hparents, hk, row4);
     }
     HSTAMP(40);
     if (!ROT) __syncthreads();  // (1) link poses (this wave) and model table, velocities, targets (main wave) are in LDS
@@ -1147,21 +1137,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         for (int i = lane; i < qst; i += G) a.qpos[(size_t)env * qst + i] = S.qpos[i];
         a.qvel[(size_t)env * G + lane] = S.qvel[lane];
         a.qacc_ws[(size_t)env * G + lane] = S.qacc_ws[lane];
-        // the link poses of the state just stored: the fused single-step launch leaves them in the pose cache and opens with them
-        // instead of a forward kinematics (the collision wave's FK was what the main wave waited for at the first barrier); every
-        // other launch that advances the state marks the env's cache stale, as resets and state writes do (mir_api.hip)
-        if (a.fkvalid) {
-          if (VARIANT == 0) {
-            if (lane < nb) {
-              float* p = a.pose_cache + ((size_t)env * 2 * G + lane) * 4;
-              *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
-              *reinterpret_cast<f4*>(p + 4 * G) = ldv(S.xquat[lane]);
-            }
-            if (lane == 0) a.fkvalid[env] = 1;
-          } else if (lane == 0) {
-            a.fkvalid[env] = 0;
-          }
-        }
+        // (the wave kernel keeps the link poses of the stored state in HBM and opens with them; this kernel did too in round 3 --
+        //  +2.7 % on bare fused launches for 832 B per env-step, 3.7 x the algorithmic traffic instead of 1.7 x -- and does not any more)
       }
       if (a.action) a.target[(size_t)env * G + lane] = S.target[lane];
       // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------
@@ -1484,7 +1461,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     float aref[4] = {0, 0, 0, 0}, jar[4] = {0, 0, 0, 0};
     // the contact's Jacobian rows stay in the registers of its lane for the whole solve; J x products take x_j from the dof
     // lanes by DPP row broadcast (every lane of the row takes part)
-    const JRow jrow = jrow_load(&S.Jb[iscon ? lane : 0][0]);
+    const JRow jrow = jrow_load(JBROW(S, iscon ? lane : 0));
     float vn, v1, v2;
     jdot3_bc(jrow, S.qvel[lane], vn, v1, v2);
     if (iscon) {
@@ -1507,11 +1484,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     // Where no contact joins the two trees the problem SEPARATES -- f = f_A(a_A) + f_B(a_B), block-diagonal Hessian.  The line search
     // stays one per env, but a step is ACCEPTED tree by tree (below), so that each tree's own cost decreases monotonically: what the
     // early `terminated` bytes rely on.  `sep` is uniform over the env's row; an env that does not separate has every row in tree A.
-#ifdef MIR_AB_NOSEP  /* (A/B builds: the problem is never treated as separable) */
-    const bool sep = false;
-#else
     const bool sep = mdl_split > 0 && (cpl & 1) == 0;
-#endif
     const bool dofB = sep && lane >= mdl_split;               // this lane's dof, and its joint-limit row
     const bool conB = sep && ((cpl >> (1 + lane)) & 1) != 0;  // this lane's contact
     bool done = nefc == 0;
@@ -1619,7 +1592,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const int c = c0 + u < ncon ? c0 + u : c0;
-          const float* jb = &S.Jb[c][0];
+          const float* jb = JBROW(S, c);
           jn[u] = jb[lane]; j1[u] = jb[16 + lane]; j2[u] = jb[32 + lane];
           fb[u] = ldv(S.con.cfb[c]);
         }
@@ -1697,7 +1670,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       oldlact = lact;
       for (unsigned fm = flipmask; fm; fm &= fm - 1u) {  // (group-uniform trip count)
         const int c = __ffs(fm) - 1;
-        const float* jb = &S.Jb[c][0];
+        const float* jb = JBROW(S, c);
         // every read of this contact in one batch, before any arithmetic (one LDS round trip)
         const f4 fb = ldv(S.con.cfb[c]);
         const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];

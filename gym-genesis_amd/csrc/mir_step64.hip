@@ -1693,11 +1693,7 @@ void mir_step64_kernel(StepArgs64 a) {
 #endif
       a.diag[(size_t)env * 4 + 2] = niter;
 #ifdef MIR_PROFILE_SINGLE  /* (profiling build: cycles from this wave's entry to the end of its solve, and whether blocks coupled) */
-#ifdef MIR_PROFILE_COMP
-      a.diag[(size_t)env * 4 + 1] = (int)comp;
-#else
       a.diag[(size_t)env * 4 + 1] = (int)(__builtin_readcyclecounter() - t_entry) | (coupled ? 1 << 30 : 0);
-#endif
 #endif
       a.diag[(size_t)env * 4 + 3] = ncand | (S.pad0 & 255) << 8;
     }
