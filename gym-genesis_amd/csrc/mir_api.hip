@@ -431,6 +431,10 @@ int mir_create(const MirSceneSpec* spec, int32_t num_envs, int32_t device_id, Mi
     for (int g = 0; g < m.ngeom; g++) {
       gt.g_body[g] = m.g_body[g]; gt.g_type[g] = m.g_type[g];
       for (int k = 0; k < 3; k++) { gt.g_size[g][k] = m.g_size[g][k]; gt.g_pos[g][k] = m.g_pos[g][k]; }
+      if (m.g_type[g] == MIR_GEOM_HULL) {  // the rasteriser draws a hull as the bounding box of its vertices
+        gt.g_type[g] = MIR_GEOM_BOX;
+        for (int k = 0; k < 3; k++) gt.g_size[g][k] = m.g_bbox[g][k];
+      }
       for (int k = 0; k < 4; k++) gt.g_quat[g][k] = m.g_quat[g][k];
     }
   }

@@ -180,19 +180,40 @@ int mir_compile_model64(const MirSceneSpec* sp0, DevModel64* out, HostConsts* hc
   for (int g = 0; g < sp->ngeom; g++) {
     const MirGeomSpec& s = sp->geom[g];
     if (s.body < 0 || s.body >= nb) return fail(err, MIR_E_INVALID, "geom body out of range");
-    if (s.type != MIR_GEOM_PLANE && s.type != MIR_GEOM_BOX && s.type != MIR_GEOM_SPHERE && s.type != MIR_GEOM_CAPSULE)
+    if (s.type != MIR_GEOM_PLANE && s.type != MIR_GEOM_BOX && s.type != MIR_GEOM_SPHERE && s.type != MIR_GEOM_CAPSULE && s.type != MIR_GEOM_HULL)
       return fail(err, MIR_E_INVALID, "unsupported geom type");
-    if (s.type == MIR_GEOM_SPHERE || s.type == MIR_GEOM_CAPSULE) m.has_convex = 1;
+    if ((s.type == MIR_GEOM_SPHERE || s.type == MIR_GEOM_CAPSULE) && !(s.size[0] > 0)) return fail(err, MIR_E_INVALID, "sphere / capsule radius must be > 0");
+    if (s.type == MIR_GEOM_CAPSULE && !(s.size[1] >= 0)) return fail(err, MIR_E_INVALID, "capsule half length must be >= 0");
+    if (s.type == MIR_GEOM_SPHERE || s.type == MIR_GEOM_CAPSULE || s.type == MIR_GEOM_HULL) m.has_convex = 1;
     m.g_body[g] = s.body; m.g_type[g] = s.type;
     for (int k = 0; k < 3; k++) { m.g_size[g][k] = (float)s.size[k]; m.g_pos[g][k] = (float)s.pos[k]; }
     // bounding-sphere radius of the broadphase (box: half diagonal; sphere: radius; capsule: half length + radius), as in mir_compile.cpp
     m.g_size[g][3] = s.type == MIR_GEOM_SPHERE ? (float)s.size[0]
                      : (s.type == MIR_GEOM_CAPSULE ? (float)(s.size[0] + s.size[1])
                                                     : (float)std::sqrt(s.size[0] * s.size[0] + s.size[1] * s.size[1] + s.size[2] * s.size[2]));
+    if (s.type == MIR_GEOM_HULL) {
+      // vertex hull (the stand-in for the reference's mesh collision geometry, tasks/utils.py:372,561,732): size = (first vertex, count)
+      // in the scene's pool; the kernel reads (first vertex, count, bounding radius about the geom origin) from g_size[0..2]
+      const int v0 = (int)s.size[0], nvg = (int)s.size[1];
+      if (v0 < 0 || nvg < 4 || nvg > MIR_MAX_HULL_VERT || v0 + nvg > sp->nvert || sp->nvert > MIR_MAX_VERT)
+        return fail(err, MIR_E_INVALID, "hull geom: vertex range outside the scene's vertex pool (4 .. MIR_MAX_HULL_VERT vertices)");
+      float r2 = 0.0f;
+      for (int i = v0; i < v0 + nvg; i++) {
+        const float v[3] = {(float)sp->vert[i][0], (float)sp->vert[i][1], (float)sp->vert[i][2]};
+        r2 = fmaxf(r2, v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        for (int k = 0; k < 3; k++) m.g_bbox[g][k] = fmaxf(m.g_bbox[g][k], fabsf(v[k]));
+      }
+      m.g_size[g][2] = m.g_size[g][3] = sqrtf(r2);
+    }
     m.g_pos[g][3] = (float)s.friction;
     for (int k = 0; k < 4; k++) m.g_quat[g][k] = (float)s.quat[k];
     m.g_sol[g][0] = (float)s.solref[0]; m.g_sol[g][1] = (float)s.solref[1];
     for (int k = 0; k < 5; k++) m.g_sol[g][2 + k] = (float)s.solimp[k];
+  }
+  m.nvert = sp->nvert > 0 && sp->nvert <= MIR_MAX_VERT ? sp->nvert : 0;
+  for (int i = 0; i < m.nvert; i++) {
+    for (int k = 0; k < 3; k++) m.hverts[i][k] = (float)sp->vert[i][k];
+    m.hverts[i][3] = 0.0f;
   }
   auto moving_link = [&](int b) {
     while (b > 0 && m.b_jtype[b] == MIR_JNT_FIXED) b = m.b_parent[b];

@@ -62,7 +62,10 @@ struct DevModel64 {
    * whose inclusive chain sum is the velocity in front of dof l, [2] (lane = body) the body's last moving dof, [3] (lane = body)
    * the lane behind the body's subtree, -1 when the subtree ends with its 16-lane row */
   int32_t scanw[W64];
-  int32_t has_convex; /* the scene has sphere / capsule geoms: the launcher picks the instantiation with the convex narrowphase */
+  int32_t has_convex; /* the scene has sphere / capsule / hull geoms: the launcher picks the instantiation with the convex narrowphase */
+  int32_t nvert;      /* hull vertices in use (MIR_GEOM_HULL: g_size = first vertex, count, bounding radius) */
+  float hverts[MIR_MAX_VERT][4]; /* the scene's hull vertex pool, geom frames (16-byte rows: copied into LDS by the collision wave) */
+  float g_bbox[MIR_MAX_GEOM][3]; /* hull geoms: half extents of the vertices' bounding box (what the rasteriser draws) */
   int32_t fk_free_leaf; /* every free-joint body hangs off the world and carries no children: its pose is its qpos row (split closing FK) */
 };
 

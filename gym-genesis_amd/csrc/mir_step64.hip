@@ -310,7 +310,7 @@ struct Env64 {
 static_assert(sizeof(float[48][G]) <= sizeof(float[MIR_MAX_GEOM][4]) + sizeof(float[MIR_MAX_GEOM]) + sizeof(unsigned short[MIR_MAX_PAIR]) +
                                           sizeof(float[MIR_MAX_GEOM][8]) + sizeof(float[NB][8]), "Hessian hand-over fits the staged tables");
 static_assert(MIR_MAX_GEOM <= 256, "pair entries are 16 bits");
-static_assert(sizeof(Con64) >= 4 * 48 * sizeof(float), "the box-box clipping exchange lives in the contact arrays");
+static_assert(sizeof(Con64) >= 4 * 48 * sizeof(float) + MIR_MAX_VERT * 16, "the box-box clipping exchange and the hull vertex pool live in the contact arrays during the narrowphase");
 
 struct BodyK64 {
   int jtype, qadr;
@@ -465,6 +465,7 @@ void mir_step64_kernel(StepArgs64 a) {
 
   const int nb = m->nbody, nv = m->nv, nq = m->nq;
   const int ngeom = m->ngeom, npair = m->npair, max_contacts = m->max_contacts, enable_collision = m->enable_collision;
+  const int mdl_nvert = CONVEX ? m->nvert : 0;  // hull vertices of the scene (wave-uniform)
   const float dt = m->dt;
   const uint64_t lanemask = m->lanemask;
   // every scalar of the model that the step reads is fetched here, with the first batch of loads: a read through `m` further down
@@ -561,6 +562,14 @@ void mir_step64_kernel(StepArgs64 a) {
       st4v(S.col.gquat[lane], qmul(qb, g_quatl));
     }
     S.col.ccount[lane] = 0;
+    // hull vertices (MIR_GEOM_HULL, convex instantiation): the scene's pool, <= 96 rows of 16 bytes, is brought into the contact
+    // arrays' space for the duration of the narrowphase (they are written after it; the box-box routine's scratch is its first
+    // 768 bytes) -- there is no LDS left for a resident copy (40.6 of 40 KB per env), and the pool is the same for every env: L2
+    float* const hullp = reinterpret_cast<float*>(&S.con) + 48 * 4;
+    const int nvert = mdl_nvert;
+    if (CONVEX && nvert > 0) {
+      for (int i = lane; i < nvert; i += NL) stv(hullp + 4 * i, *reinterpret_cast<const f4*>(m->hverts[i]));
+    }
     WSYNC();
     int mycount = 0;
     int ncand = 0;
@@ -584,19 +593,20 @@ void mir_step64_kernel(StepArgs64 a) {
             float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
             if (CONVEX && t2 == MIR_GEOM_SPHERE) ext = h2.x;
             if (CONVEX && t2 == MIR_GEOM_CAPSULE) ext = h2.y * fabsf(dot(n, mcol(R2, 2))) + h2.x;
+            if (CONVEX && t2 == MIR_GEOM_HULL) ext = h2.z;  // (bounding sphere about the geom origin)
             hit = dot(c2 - ld3v(S.col.gpos[g1]), n) - ext < 0.0f;
           } else {
             V3 h1 = ld3(&S.gts[g1][1]);
             // bounding spheres (box: half diagonal; sphere: radius; capsule: half length + radius)
             float b1 = sqrtf(dot(h1, h1)), b2 = sqrtf(dot(h2, h2));
             if (CONVEX) {
-              b1 = t1 == MIR_GEOM_SPHERE ? h1.x : (t1 == MIR_GEOM_CAPSULE ? h1.x + h1.y : b1);
-              b2 = t2 == MIR_GEOM_SPHERE ? h2.x : (t2 == MIR_GEOM_CAPSULE ? h2.x + h2.y : b2);
+              b1 = t1 == MIR_GEOM_SPHERE ? h1.x : (t1 == MIR_GEOM_CAPSULE ? h1.x + h1.y : (t1 == MIR_GEOM_HULL ? h1.z : b1));
+              b2 = t2 == MIR_GEOM_SPHERE ? h2.x : (t2 == MIR_GEOM_CAPSULE ? h2.x + h2.y : (t2 == MIR_GEOM_HULL ? h2.z : b2));
             }
             float rs = b1 + b2;
             V3 dc = c2 - ld3v(S.col.gpos[g1]);
             hit = dot(dc, dc) <= rs * rs;
-            if (CONVEX && hit && (t1 == MIR_GEOM_BOX) != (t2 == MIR_GEOM_BOX)) {
+            if (CONVEX && hit && (t1 == MIR_GEOM_BOX) != (t2 == MIR_GEOM_BOX) && t1 != MIR_GEOM_HULL && t2 != MIR_GEOM_HULL) {
               // one box, one round geom: the round geom's CORE (centre, or the axis segment's bounding box in the box frame) against
               // the box itself (clamped distance <= radius), not bounding spheres -- the kitchen slab's is a metre wide, and link 1
               // stands a few centimetres above it for the whole episode: every such pair would run GJK every step
@@ -732,10 +742,44 @@ void mir_step64_kernel(StepArgs64 a) {
             }
             if (cnt) st3v(S.col.snorm[lane], n);
             S.col.ccount[lane] = cnt;
+          } else if (t1 == MIR_GEOM_PLANE && t2 == MIR_GEOM_HULL) {
+            // plane - hull: the penetrating vertices in index order, reduced to four like plane - box (support extremes, first
+            // index wins ties; oracle: plane_hull / reduce4; the same two lane-private passes as in the 16-lane kernel)
+            const M3 Rp = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
+            const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1), pp = ld3v(S.col.gpos[g1]), pc = ld3v(S.col.gpos[g2]);
+            const int v0 = (int)S.gts[g2][1], nvg = (int)S.gts[g2][2];
+            int npen = 0, pk0 = -1, pk1 = -1, pk2 = -1, pk3 = -1;
+            float uM = 0.0f, um = 0.0f, vM = 0.0f, vm = 0.0f;
+            for (int i = 0; i < nvg; i++) {
+              const V3 l = ld3v(hullp + 4 * (v0 + i));
+              const V3 rel = pc + l.x * mcol(R2, 0) + l.y * mcol(R2, 1) + l.z * mcol(R2, 2) - pp;
+              if (dot(rel, n) < 0.0f) {
+                const float u = dot(rel, eu), v = dot(rel, ev);
+                if (npen == 0 || u > uM) { uM = u; pk0 = i; }
+                if (npen == 0 || u < um) { um = u; pk1 = i; }
+                if (npen == 0 || v > vM) { vM = v; pk2 = i; }
+                if (npen == 0 || v < vm) { vm = v; pk3 = i; }
+                npen++;
+              }
+            }
+            int cnt = 0;
+            for (int i = 0; i < nvg && cnt < 4; i++) {
+              const V3 l = ld3v(hullp + 4 * (v0 + i));
+              const V3 w = pc + l.x * mcol(R2, 0) + l.y * mcol(R2, 1) + l.z * mcol(R2, 2);
+              const float d = dot(w - pp, n);
+              if (d < 0.0f && (npen <= 4 || i == pk0 || i == pk1 || i == pk2 || i == pk3)) {
+                const V3 c = w - (0.5f * d) * n;
+                stv(S.col.stage[lane][cnt], f4{c.x, c.y, c.z, d});
+                cnt++;
+              }
+            }
+            if (cnt) st3v(S.col.snorm[lane], n);
+            S.col.ccount[lane] = cnt;
           } else if (t1 != MIR_GEOM_PLANE && !(t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX)) {
             const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
-            const ShapeD A = {t1, ld3(&S.gts[g1][1]), ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), nullptr, 0};
-            const ShapeD B = {t2, ld3(&S.gts[g2][1]), ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), nullptr, 0};
+            const V3 z1 = ld3(&S.gts[g1][1]), z2 = ld3(&S.gts[g2][1]);
+            const ShapeD A = {t1, z1, ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), hullp + 4 * (t1 == MIR_GEOM_HULL ? (int)z1.x : 0), (int)z1.y};
+            const ShapeD B = {t2, z2, ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), hullp + 4 * (t2 == MIR_GEOM_HULL ? (int)z2.x : 0), (int)z2.y};
             f4 pt;
             V3 n;
             if (convex_pair(A, B, pt, n)) {

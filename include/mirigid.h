@@ -82,12 +82,13 @@ extern "C" {
                             * stand-in for the reference's mesh collision geometry (convex hulls of link meshes).  Support mapping
                             * = the vertex of largest projection, lowest index on ties.  Plane - hull: the penetrating vertices,
                             * reduced to four like plane - box; every other pair through GJK on the cores (the hull is its own core,
-                            * radius 0) and MPR.  16-lane kernel only. */
+                            * radius 0) and MPR.  Both step kernels: up to 40 vertices per scene in the 16-lane kernel, up to
+                            * MIR_MAX_VERT in the wave kernel (a scene with more than 40 goes there). */
 /* Narrowphase by pair type: plane-box / plane-sphere / plane-capsule in closed form (<= 4 / 1 / 2 points), box-box by
  * separating axes and face clipping (<= 8 points), every other convex pair by Minkowski Portal Refinement on the shapes'
  * support mappings (one point: deepest penetration) -- the default convex-convex path of Genesis.
- * Sphere and capsule geoms are supported by the 16-lanes-per-env kernel (the pick scenes); the wave-per-env kernel
- * (five-cube stack scenes) takes planes and boxes only. */
+ * Every geom type is supported by both step kernels (the wave-per-env kernel since round 3 for spheres and capsules, since
+ * round 4 for hulls). */
 
 /* dof control modes */
 #define MIR_CTRL_NONE 0

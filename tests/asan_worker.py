@@ -143,6 +143,7 @@ def host_compilers(specs):
         rcs.append((r & 255, r >> 8 & 255, r >> 16 & 1))
     assert rcs[0] == (0, 0, 1) or rcs[0][0] == 0, rcs       # the pick scene compiles for the 16-lane kernel and emits its literals
     assert all(a == 0 or b == 0 for a, b, _ in rcs), rcs    # every scene compiles for one of the two kernels
+    assert rcs[-1][1] == 0, rcs                               # the hull scene compiles for the wave kernel too (round 4)
     # a spec of garbage sizes must be refused, not walked over
     bad = type(specs[0]).from_buffer_copy(bytes(specs[0]))
     bad.nbody = 10 ** 6

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import orc
+from gym_genesis.backend import models
 from gym_genesis.backend import spec as S
 
 pytestmark = pytest.mark.gpu
@@ -183,9 +184,11 @@ def test_round_geoms_on_the_wave_kernel_settle_like_the_oracle():
     assert np.abs(qh[:, [2, 9, 16, 23]] - qo[:, [2, 9, 16, 23]]).max() < 2e-3   # resting heights
 
 
-def test_hull_contacts_match_the_oracle_pose_by_pose():
-    """Vertex-hull geoms (MIR_GEOM_HULL, 40 vertices in LDS: an 8-vertex cube and a 32-vertex ball) in the 16-lane kernel, one
-    forward evaluation at 512 random relative poses of a hull and a round body in mid-air (hull - sphere through GJK on the
+@pytest.mark.parametrize("kernel", [16, 64])
+def test_hull_contacts_match_the_oracle_pose_by_pose(kernel):
+    """Vertex-hull geoms (MIR_GEOM_HULL: an 8-vertex cube and a 32-vertex ball) in the 16-lane kernel (pool of 40 vertices beside the
+    model table) and in the wave kernel (pool of 96, brought into the contact arrays' space for the narrowphase; the same scenes are
+    sent there by a contact capacity of 48), one forward evaluation at 512 random relative poses of a hull and a round body in mid-air (hull - sphere through GJK on the
     polytope and the point, MPR when the centre dips into the hull): contact counts as the oracle's, constrained accelerations of the
     shallow contacts within 1e-3.  (Against a ROUND partner the closest feature pair is unique; two polytopes resting face to face
     have a whole polygon of closest points, and which of them a single-point narrowphase reports is decided by rounding.)"""
@@ -197,6 +200,8 @@ def test_hull_contacts_match_the_oracle_pose_by_pose():
         sb.add_body("b", 0, pos=(0.3, 0.0, 0.5), jtype=S.JNT_FREE, mass=0.3, inertia=S.sphere_inertia(0.3, 0.04))
         sb.add_geom("b", S.GEOM_SPHERE, size=(0.04, 0.0, 0.0))
         sb.task = dict(eef_body=1, obj_body=2, grip_dof=(), reward_z=0.1)
+        if kernel == 64:
+            sb.opt["max_contacts"] = 48
         spec = sb.build()
         B = 512
         rng = np.random.default_rng(11)
@@ -208,7 +213,7 @@ def test_hull_contacts_match_the_oracle_pose_by_pose():
         q[:, 3:7], q[:, 10:14] = _rand_quat(rng, B), _rand_quat(rng, B)
         v = rng.uniform(-0.2, 0.2, (B, 12)).astype(np.float32)
         sc, o = _mir(spec, B), orc.Oracle(spec, B)
-        assert sc.kernel == 16
+        assert sc.kernel == kernel
         sc.set_state(qpos=q, qvel=v, warmstart=np.zeros((B, 12), np.float32))
         _, _, _, qacc = (t.cpu().numpy() for t in sc.forward())
         ncon = sc.get_diag()[0].cpu().numpy()
@@ -231,14 +236,16 @@ def test_hull_contacts_match_the_oracle_pose_by_pose():
             worst = max(worst, np.abs(qacc[e] - qo).max() / max(1.0, np.abs(qo).max()))
             shallow += 1
         mism = int((nco != ncon).sum())
-        print(f"hull {kind_a} vs sphere: {int((nco > 0).sum())} contacts in {B} poses ({shallow} through GJK, {deep} through MPR), {mism} count mismatches, qacc rel err {worst:.2e}")
+        print(f"[kernel {kernel}] hull {kind_a} vs sphere: {int((nco > 0).sum())} contacts in {B} poses ({shallow} through GJK, {deep} through MPR), {mism} count mismatches, qacc rel err {worst:.2e}")
         assert mism <= 2 and (nco > 0).sum() > 100 and shallow > 50
         assert worst < 1e-3
 
 
-def _hull_scene(kind_a, kind_b):
+def _hull_scene(kind_a, kind_b, kernel=16):
     """plane + two free bodies: an 8-vertex cube (or the same cube as GEOM_BOX) and a 32-vertex ball."""
     sb = S.SceneBuilder()
+    if kernel == 64:
+        sb.opt["max_contacts"] = 48
     sb.add_geom(0, S.GEOM_PLANE)
     h = (0.03, 0.03, 0.03)
     sb.add_body("a", 0, pos=(-0.3, 0.0, 0.5), jtype=S.JNT_FREE, mass=0.3, inertia=S.box_inertia(0.3, h))
@@ -252,7 +259,8 @@ def _hull_scene(kind_a, kind_b):
     return sb.build()
 
 
-def test_hull_bodies_settle_on_the_plane_like_the_oracle():
+@pytest.mark.parametrize("kernel", [16, 64])
+def test_hull_bodies_settle_on_the_plane_like_the_oracle(kernel):
     """The cube given as its 8 corners and a 32-vertex ball dropped from random poses on the plane (plane - hull: the penetrating
     vertices, reduced to four like plane - box), 150 free-running steps against the oracle; and the cube given as its corners follows
     the GEOM_BOX cube of the same kernel bit for bit (the lane-private hull path and the 8-lane plane - box path do the same
@@ -264,10 +272,10 @@ def test_hull_bodies_settle_on_the_plane_like_the_oracle():
     pos[:, 1] = rng.uniform(-0.05, 0.05, (B, 3)) + [0.0, 0.0, 0.12]
     quat = np.stack([_rand_quat(rng, B), _rand_quat(rng, B)], 1).astype(np.float32)
     arm = np.zeros((B, 0), np.float32)
-    spec = _hull_scene("hull", "hull")
+    spec = _hull_scene("hull", "hull", kernel)
     sc, o = _mir(spec, B), orc.Oracle(spec, B)
-    assert sc.kernel == 16
-    ref = _mir(_hull_scene("box", "hull"), B)
+    assert sc.kernel == kernel
+    ref = _mir(_hull_scene("box", "hull", kernel), B)
     for x in (sc, o, ref):
         x.reset(pos, quat, arm)
     bufs = (sc.empty(sc.agent_dim), sc.empty(sc.env_dim), sc.empty(), sc.empty(dtype=torch.uint8))
@@ -280,7 +288,7 @@ def test_hull_bodies_settle_on_the_plane_like_the_oracle():
     qh, qo, qr = sc.get_state()[0].cpu().numpy(), o.state()[0], ref.get_state()[0].cpu().numpy()
     err = np.abs(qh - qo)[:, [0, 1, 2, 7, 8, 9]].max(1)
     ncon = sc.get_diag()[0].cpu().numpy()
-    print(f"hull bodies on the plane: after 21 steps L-inf {early:.2e}; after 150 steps position err median {np.median(err):.2e}, max {err.max():.2e}; contacts {ncon.min()}..{ncon.max()}; "
+    print(f"[kernel {kernel}] hull bodies on the plane: after 21 steps L-inf {early:.2e}; after 150 steps position err median {np.median(err):.2e}, max {err.max():.2e}; contacts {ncon.min()}..{ncon.max()}; "
           f"hull cube vs box cube {np.abs(qh[:, :7] - qr[:, :7]).max():.2e}")
     assert early < 1e-5
     assert np.median(err) < 1e-4 and err.max() < 5e-3
@@ -289,18 +297,89 @@ def test_hull_bodies_settle_on_the_plane_like_the_oracle():
     assert np.array_equal(qh[:, :7], qr[:, :7])                                                      # cube as corners == cube as box
 
 
-def test_hull_vertex_pool_beyond_the_kernel_capacity_is_refused():
-    """More hull vertices than the 16-lane kernel keeps in LDS (K16_MAX_VERT = 40): not simulated with anything else."""
-    from gym_genesis.backend.lib import MirError
-
+def test_hull_vertex_pool_beyond_the_16_lane_capacity_runs_on_the_wave_kernel():
+    """More hull vertices than the 16-lane kernel keeps in LDS (K16_MAX_VERT = 40): the scene goes to the wave kernel (96), which
+    round 3 refused hulls on.  Two 32-vertex balls dropped on the plane and on each other, against the oracle; beyond 96 vertices
+    the builder itself refuses."""
     sb = S.SceneBuilder()
     sb.add_geom(0, S.GEOM_PLANE)
     for i in range(2):
         sb.add_body(f"b{i}", 0, pos=(0.2 * i, 0, 0.1), jtype=S.JNT_FREE, mass=0.1, inertia=S.sphere_inertia(0.1, 0.04))
         sb.add_geom(f"b{i}", S.GEOM_HULL, vertices=S.icosphere_vertices(0.04, 1))
     sb.task = dict(eef_body=1, obj_body=2, grip_dof=(), reward_z=0.1)
-    with pytest.raises(MirError):
-        _mir(sb.build(), 4)
+    spec = sb.build()
+    B = 32
+    sc, o = _mir(spec, B), orc.Oracle(spec, B)
+    assert sc.kernel == 64
+    rng = np.random.default_rng(4)
+    pos = np.zeros((B, 2, 3), np.float32)
+    pos[:, 0] = rng.uniform(-0.02, 0.02, (B, 3)) + [0.0, 0.0, 0.08]
+    pos[:, 1] = pos[:, 0] + rng.uniform(-0.015, 0.015, (B, 3)) + [0.0, 0.0, 0.10]   # lands on the first ball, rolls off
+    quat = np.stack([_rand_quat(rng, B), _rand_quat(rng, B)], 1).astype(np.float32)
+    arm = np.zeros((B, 0), np.float32)
+    sc.reset(pos, quat, arm); o.reset(pos, quat, arm)
+    bufs = (sc.empty(sc.agent_dim), sc.empty(sc.env_dim), sc.empty(), sc.empty(dtype=torch.uint8))
+    for t in range(25):
+        sc.step_fused(None, *bufs)
+        o.step_batch(None)
+        if t == 7:   # (free fall and the first ball's touch-down on the plane; polytope on polytope later: a polygon of closest points)
+            early = np.abs(sc.get_state()[0].cpu().numpy() - o.state()[0]).max()
+    late = np.abs(sc.get_state()[0].cpu().numpy() - o.state()[0]).max()
+    print(f"two 32-vertex hulls on the wave kernel: L-inf after 8 steps {early:.2e}, after 25 steps {late:.2e}")
+    assert early < 5e-6 and late < 1e-3 and np.isfinite(sc.get_state()[0].cpu().numpy()).all()
+    with pytest.raises(ValueError):
+        for i in range(2):
+            sb.add_body(f"c{i}", 0, pos=(0.5, 0.2 * i, 0.1), jtype=S.JNT_FREE, mass=0.1, inertia=S.sphere_inertia(0.1, 0.04))
+            sb.add_geom(f"c{i}", S.GEOM_HULL, vertices=S.icosphere_vertices(0.04, 1))
+
+
+def test_hull_cubes_follow_box_cubes_bit_for_bit_in_the_franka_five_cube_scene():
+    """The stack tasks' robot and five free cubes (39 dofs: the wave kernel) with the cubes given as their 8 corners
+    (MIR_GEOM_HULL: the stand-in for the reference's mesh cubes, tasks/utils.py:372,561,732) and as GEOM_BOX, on the PLANE and
+    apart from each other: plane - hull keeps the penetrating vertices exactly as plane - box keeps the penetrating corners, so
+    the two scenes stay bit-identical over 150 steps of random arm targets.  (On the kitchen SLAB -- a box -- a hull cube would
+    rest on the one closest point GJK reports where the box cube gets a clipped face patch: not a parity case)"""
+    def scene(hull):
+        sb = models.franka_cube_stack_scene()
+        spec0 = sb.build()
+        # the five cubes' geoms: re-add them as hulls (same size, same body), everything else as it is
+        cube_geoms = [g for g in sb.geoms if sb.bodies[g["body"]]["name"] in models.STACK_CUBES]
+        assert len(cube_geoms) == 5 and all(g["type"] == S.GEOM_BOX for g in cube_geoms)
+        if hull:
+            for g in cube_geoms:
+                v0 = len(sb.verts)
+                verts = S.box_hull_vertices(tuple(g["size"][:3]))
+                sb.verts.extend(tuple(v) for v in verts)
+                g["type"] = S.GEOM_HULL
+                g["size"] = (float(v0), float(len(verts)), 0.0)
+        # drop the slab: the cubes rest on the floor plane
+        sb.geoms = [g for g in sb.geoms if not (g["type"] == S.GEOM_BOX and g["body"] == 0)]
+        return sb.build(), spec0
+
+    (spec_h, _), (spec_b, _) = scene(True), scene(False)
+    B = 64
+    sc, ref = _mir(spec_h, B), _mir(spec_b, B)
+    assert sc.kernel == 64 and ref.kernel == 64
+    rng = np.random.default_rng(2)
+    pos = np.zeros((B, 5, 3), np.float32)
+    for k in range(5):
+        pos[:, k] = rng.uniform(-0.02, 0.02, (B, 3)) + [0.45 + 0.09 * k, -0.3 + 0.15 * k, 0.06]
+    quat = np.stack([_rand_quat(rng, B) for _ in range(5)], 1).astype(np.float32)
+    arm = np.tile(np.asarray(models.FRANKA_HOME, np.float32), (B, 1))
+    for x in (sc, ref):
+        x.reset(pos, quat, arm)
+    b1 = (sc.empty(sc.agent_dim), sc.empty(sc.env_dim), sc.empty(), sc.empty(dtype=torch.uint8))
+    b2 = (ref.empty(ref.agent_dim), ref.empty(ref.env_dim), ref.empty(), ref.empty(dtype=torch.uint8))
+    acts = torch.as_tensor(arm[None] + rng.uniform(-0.3, 0.3, (150, B, 9)).astype(np.float32), device=sc.device)
+    for t in range(150):
+        sc.step_fused(acts[t], *b1)
+        ref.step_fused(acts[t], *b2)
+    for x, y in zip(sc.get_state(), ref.get_state()):
+        assert torch.equal(x, y)
+    for x, y in zip(b1, b2):
+        assert torch.equal(x, y)
+    ncon = sc.get_diag()[0].cpu().numpy()
+    assert (ncon >= 15).all()    # five cubes at rest on the plane: 20 points, a tilted one in transit fewer
 
 
 def _device_pairs(rows):
