@@ -577,10 +577,10 @@ void mir_step64_kernel(StepArgs64 a) {
     if (enable_collision) {
       // broadphase: bounding test per static candidate pair, ordered compaction of survivors (lane = pair)
       int base = 0;
-      bool any_plane = false, any_solid = false, any_slab = false;  // wave-uniform: which narrowphase loops have anything to do
+      bool any_plane = false, any_solid = false, any_slab = false, any_round = false;  // wave-uniform: which narrowphase loops have anything to do
       for (int p0 = 0; p0 < npair; p0 += NL) {
         int p = p0 + lane;
-        bool hit = false, planepair = false, slab = false;
+        bool hit = false, planepair = false, slab = false, roundpair = false;  // roundpair: the lane-private narrowphase takes it
         if (p < npair) {
           const int pr = (int)S.pairs[p];
           const int g1 = pr & 255, g2 = pr >> 8;
@@ -589,6 +589,7 @@ void mir_step64_kernel(StepArgs64 a) {
           M3 R2 = q2m(ld4v(S.col.gquat[g2]));
           V3 c2 = ld3v(S.col.gpos[g2]);
           const int t1 = __float_as_int(S.gts[g1][0]) & 255, t2 = __float_as_int(S.gts[g2][0]) & 255;
+          roundpair = CONVEX && (t1 == MIR_GEOM_PLANE ? t2 != MIR_GEOM_BOX : !(t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX));
           if (t1 == MIR_GEOM_PLANE) {
             V3 n = mcol(q2m(ld4v(S.col.gquat[g1])), 2);
             float ext = h2.x * fabsf(dot(n, mcol(R2, 0))) + h2.y * fabsf(dot(n, mcol(R2, 1))) + h2.z * fabsf(dot(n, mcol(R2, 2)));
@@ -661,6 +662,7 @@ void mir_step64_kernel(StepArgs64 a) {
         any_plane = any_plane || __ballot(hit && planepair) != 0ull;
         any_solid = any_solid || __ballot(hit && !planepair && !slab) != 0ull;
         any_slab = any_slab || __ballot(hit && slab) != 0ull;
+        any_round = any_round || __ballot(hit && roundpair) != 0ull;
       }
       ncand = base < NL ? base : NL;
       if (lane == 0) S.ncand = ncand;
@@ -753,6 +755,9 @@ void mir_step64_kernel(StepArgs64 a) {
         }
         WSYNC();
       }
+#ifdef MIR_PROFILE_SINGLE
+      if (a.prof && a.prof[33] == 77ull) STAMP(34);
+#endif
       // narrowphase, box-box: DPP row r takes candidates r, r + 4, ... (like plane-box).  The 15 separating axes sit on
       // lanes 0..14 of the row, the incident-face vertices on lanes 0..3 (box_box_row, mir_dev.h)
       if (any_solid) for (int k0 = 0; k0 < ncand; k0 += 4) {
@@ -773,10 +778,13 @@ void mir_step64_kernel(StepArgs64 a) {
         }
       }
       WSYNC();
+#ifdef MIR_PROFILE_SINGLE
+      if (a.prof && a.prof[33] == 77ull) STAMP(35);
+#endif
       if constexpr (CONVEX) {
         // narrowphase of the round shapes, LANE-PRIVATE: lane c takes candidate c (see mir_step.hip).  Lanes diverge here and
-        // reconverge at the end of the block.
-        if (lane < ncand) {
+        // reconverge at the end of the block.  (Skipped as a whole when no candidate has a round geom or a hull: wave-uniform.)
+        if (any_round && lane < ncand) {
           const int pr = (int)S.pairs[S.col.cand[lane] & 0xffff];
           const int g1 = pr & 255, g2 = pr >> 8;
           const int t1 = __float_as_int(S.gts[g1][0]) & 255, t2 = __float_as_int(S.gts[g2][0]) & 255;
@@ -849,6 +857,20 @@ void mir_step64_kernel(StepArgs64 a) {
         WSYNC();
       }
       mycount = S.col.ccount[lane];
+#ifdef MIR_PROFILE_SINGLE  /* (profiling build: candidates by narrowphase path, for tools/probes/cand_hist64.py) */
+      {
+        int kind = 0;
+        if (lane < ncand) {
+          const int cd = S.col.cand[lane];
+          const int pr = (int)S.pairs[cd & 0xffff];
+          const int t1 = __float_as_int(S.gts[pr & 255][0]) & 255, t2 = __float_as_int(S.gts[pr >> 8][0]) & 255;
+          kind = (cd >> 16) ? 1 : (t1 == MIR_GEOM_PLANE ? (t2 == MIR_GEOM_BOX ? 2 : 3) : ((t1 == MIR_GEOM_BOX && t2 == MIR_GEOM_BOX) ? 4 : 5));
+        }
+        const int n1 = __popcll(__ballot(kind == 1)), n2 = __popcll(__ballot(kind == 2)), n3 = __popcll(__ballot(kind == 3)), n4 = __popcll(__ballot(kind == 4)),
+                  n5 = __popcll(__ballot(kind == 5)), n5hit = __popcll(__ballot(kind == 5 && mycount > 0));
+        if (lane == 0) S.pad1 = n1 | n2 << 5 | n3 << 10 | n4 << 15 | n5 << 20 | n5hit << 25;
+      }
+#endif
     }
     STAMP(8);
     // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
@@ -1794,7 +1816,7 @@ void mir_step64_kernel(StepArgs64 a) {
 #endif
       a.diag[(size_t)env * 4 + 2] = niter;
 #ifdef MIR_PROFILE_SINGLE  /* (profiling build: cycles from this wave's entry to the end of its solve, and whether blocks coupled) */
-      a.diag[(size_t)env * 4 + 1] = (int)(__builtin_readcyclecounter() - t_entry) | (coupled ? 1 << 30 : 0);
+      a.diag[(size_t)env * 4 + 1] = a.prof && a.prof[33] == 77ull ? S.pad1 : ((int)(__builtin_readcyclecounter() - t_entry) | (coupled ? 1 << 30 : 0));
 #endif
       a.diag[(size_t)env * 4 + 3] = ncand | (S.pad0 & 255) << 8;
     }
