@@ -165,7 +165,12 @@ class CameraView:
         self._recording = True
 
     def stop_recording(self, save_to_filename=None, fps=60) -> None:
-        raise NotImplementedError("video recording (env.py:70-79) is outside the env.step() hot path (SURVEY.md 8)")
+        # (a stub that warns -- video encoding is outside the env.step() hot path; the caller's episode goes on)
+        import warnings
+
+        warnings.warn(f"video recording is not implemented by this backend: nothing was written to {save_to_filename!r} "
+                      "(reference: env.py:70-79 -> cam.stop_recording)", stacklevel=2)
+        self._recording = False
 
 
 class SceneView:

@@ -250,6 +250,11 @@ def test_pixels_contract_on_the_test_double(monkeypatch):
     # the camera sits at (3.5, 0, 2.5) looking at (0, 0, 0.5) with fov 30 (cube_pick.py:57-62)
     cam = env._env.cam
     assert cam.pos == (3.5, 0.0, 2.5) and cam.lookat == (0.0, 0.0, 0.5) and cam.fov == 30.0 and cam.res == (W, H)
+    # save_video (env.py:70-79): the reference's own warning, then the backend's stub warns that nothing is written; the env goes on
+    with pytest.warns(UserWarning) as rec:
+        env.save_video(save_video=True, file_name="episode.mp4")
+    assert any("not implemented" in str(w.message) for w in rec) and any("stops the camera recording" in str(w.message) for w in rec)
+    env.step(np.zeros((B, 9), np.float32))
 
 
 def test_seeded_reset_is_deterministic(env):
