@@ -784,6 +784,7 @@ def worker(args) -> int:
     # `sent`: first row of the current ring chunk that has not been gathered yet, `row`: the row the latest step wrote (-1: none)
     state = {"chunk": 0, "t": 0, "resets": 0, "sent": 0, "row": -1}
     last_block = [None]
+    readers = [[] for _ in range(RING_CHUNKS)]   # per ring chunk: the pushes that read it since it was last written
     gather_stats = {"pushes": 0, "partial_pushes": 0, "lag_max": 0, "checks": 0, "checks_failed": 0}
 
     def flush():
@@ -795,11 +796,15 @@ def worker(args) -> int:
         send = ring[lo:row + 1].reshape(-1)   # rows of one ring chunk: one contiguous block, no concatenation
         if copy_gather is not None:
             last_seq[0] = copy_gather.push(send)   # device-to-device copies on the side streams: nothing to wait for here
-            # the step kernels are about to write the NEXT ring chunk: they wait (on the device) until the copies of the push that
-            # last read it -- RING_CHUNKS - 1 pushes ago at one push per chunk; every older push when partial chunks were sent --
-            # are through with it
-            for back in range(RING_CHUNKS - 1, RING_CHUNKS + 3):
-                copy_gather.wait_source(last_seq[0] - back)
+            ch = lo // S
+            readers[ch].append(last_seq[0])
+            if (row + 1) % S == 0:
+                # the chunk is complete and the step kernels are about to write the NEXT ring chunk: they wait (on the device, the
+                # host goes on) until the copies of the pushes that read it on the previous lap are through with it
+                nxt = (ch + 1) % RING_CHUNKS
+                for sq in readers[nxt]:
+                    copy_gather.wait_source(sq)
+                readers[nxt].clear()
             gather_stats["lag_max"] = max(gather_stats["lag_max"], copy_gather.lag())
         else:
             s = state["chunk"] & 1

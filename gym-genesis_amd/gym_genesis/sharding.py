@@ -244,8 +244,15 @@ class CopyPathGather:
             torch.cuda.current_stream(self.device).wait_event(ev)
 
     def lag(self) -> int:
-        """pushes (among the last EVENT_DEPTH) whose copies have not all finished yet"""
-        return sum(1 for evs in self._events.values() if not all(ev.query() for ev in evs))
+        """pushes whose copies have not all finished yet, counted back from the newest (every stream completes its copies in order,
+        so the walk stops at the first finished push: one or two pushes' events in the steady state)"""
+        n = 0
+        for seq in range(self.pushes, max(self.pushes - self.EVENT_DEPTH, 0), -1):
+            evs = self._events.get(seq)
+            if evs is None or all(ev.query() for ev in evs):
+                break
+            n += 1
+        return n
 
     def _min_ack(self) -> int:
         with torch.cuda.stream(self._ack_stream):
@@ -287,10 +294,10 @@ class CopyPathGather:
     def release(self, seq: int) -> None:
         """This rank is done with gather `seq` (and all earlier ones): its word goes to every rank, behind whatever the caller's
         current stream has queued (the consumer's reads)."""
-        if seq <= self._released:
+        if seq <= self._released or seq <= self._seq_base:   # (already released; or older than the sequence table: long since overwritten)
             return
-        if seq - self._seq_base > self.SEQ_TABLE or seq <= self._seq_base:
-            raise ValueError("release: sequence number outside the current table")
+        if seq - self._seq_base > self.SEQ_TABLE:
+            raise ValueError("release: sequence number ahead of the pushes")
         cur = torch.cuda.current_stream(self.device)
         for st in self.streams:
             st.wait_stream(cur)
