@@ -381,6 +381,38 @@ __device__ __forceinline__ void condot3(const Env64& S, int c, const float* x, f
   if (b1 >= 0) segdot3(&S.Jb[c][1][0], x + 16 * b1, dn, d1, d2);
 }
 
+// J_c against THREE vectors in one pass over the contact's Jacobian segments (each product in condot3's own order of operations, so
+// the results are the same bits): the segment rows are read once instead of three times -- 24 of the 32 LDS reads of a segment are
+// Jacobian rows.  Used where the velocity, the smooth acceleration and the warm start meet the contact rows back to back.
+__device__ __forceinline__ void condot3x3(const Env64& S, int c, const float* x, const float* y, const float* z, float (&dx)[3], float (&dy)[3], float (&dz)[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) dx[k] = dy[k] = dz[k] = 0.0f;
+  const int bs[2] = {S.con.cblk[c][0], S.con.cblk[c][1]};
+#pragma unroll
+  for (int sgi = 0; sgi < 2; sgi++) {
+    const int b = bs[sgi];
+    if (b < 0) continue;
+    const float* jb = &S.Jb[c][sgi][0];
+    float ax[3] = {0, 0, 0}, ay[3] = {0, 0, 0}, az[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const f4 ja = ldv(jb + 4 * q), jbb = ldv(jb + 16 + 4 * q), jc = ldv(jb + 32 + 4 * q);
+      const f4 xv = ldv(x + 16 * b + 4 * q), yv = ldv(y + 16 * b + 4 * q), zv = ldv(z + 16 * b + 4 * q);
+      ax[0] += ja.x * xv.x + ja.y * xv.y + ja.z * xv.z + ja.w * xv.w;
+      ax[1] += jbb.x * xv.x + jbb.y * xv.y + jbb.z * xv.z + jbb.w * xv.w;
+      ax[2] += jc.x * xv.x + jc.y * xv.y + jc.z * xv.z + jc.w * xv.w;
+      ay[0] += ja.x * yv.x + ja.y * yv.y + ja.z * yv.z + ja.w * yv.w;
+      ay[1] += jbb.x * yv.x + jbb.y * yv.y + jbb.z * yv.z + jbb.w * yv.w;
+      ay[2] += jc.x * yv.x + jc.y * yv.y + jc.z * yv.z + jc.w * yv.w;
+      az[0] += ja.x * zv.x + ja.y * zv.y + ja.z * zv.z + ja.w * zv.w;
+      az[1] += jbb.x * zv.x + jbb.y * zv.y + jbb.z * zv.z + jbb.w * zv.w;
+      az[2] += jc.x * zv.x + jc.y * zv.y + jc.z * zv.z + jc.w * zv.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dx[k] += ax[k]; dy[k] += ay[k]; dz[k] += az[k]; }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SINGLE = one full step per launch without the rollout / autoreset / per-stage-output options: no step loop, hence none of
 // the scalar-register spills the loop structure forces (see mir_step.hip).
@@ -1399,9 +1431,11 @@ void mir_step64_kernel(StepArgs64 a) {
     const bool iscon = lane < ncon;
     float cmu = 0.0f, cD = 0.0f;
     float aref[4] = {0, 0, 0, 0}, jar[4] = {0, 0, 0, 0};
+    float cds[3] = {0, 0, 0}, cdw[3] = {0, 0, 0};  // J_c qacc_smooth, J_c warm start (used by the warm-start choice below)
     if (iscon) {
-      float vn, v1, v2;
-      condot3(S, lane, S.qvel, vn, v1, v2);
+      float cdv[3];
+      condot3x3(S, lane, S.qvel, S.qas, S.qacc_ws, cdv, cds, cdw);
+      const float vn = cdv[0], v1 = cdv[1], v2 = cdv[2];
       f4 mt = ldv(S.con.cmeta[lane]);
       cmu = mt.x; cD = mt.y;
       const float base = mt.z, bb = mt.w;
@@ -1427,9 +1461,7 @@ void mir_step64_kernel(StepArgs64 a) {
       }
       float js[4] = {0, 0, 0, 0}, jw[4] = {0, 0, 0, 0};
       if (iscon) {
-        float sn, s1, s2, wn, w1, w2;
-        condot3(S, lane, S.qas, sn, s1, s2);
-        condot3(S, lane, S.qacc_ws, wn, w1, w2);
+        const float sn = cds[0], s1 = cds[1], s2 = cds[2], wn = cdw[0], w1 = cdw[1], w2 = cdw[2];
         js[0] = sn + cmu * s1 - aref[0]; js[1] = sn - cmu * s1 - aref[1]; js[2] = sn + cmu * s2 - aref[2]; js[3] = sn - cmu * s2 - aref[3];
         jw[0] = wn + cmu * w1 - aref[0]; jw[1] = wn - cmu * w1 - aref[1]; jw[2] = wn + cmu * w2 - aref[2]; jw[3] = wn - cmu * w2 - aref[3];
 #pragma unroll
