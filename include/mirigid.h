@@ -260,7 +260,7 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  * once  |z_pred - reward_z| > 2 dt^2 ((1 + sqrt 2) |g|_w + 1 m/s^2) + 1e-5 m  holds for its four envs, where z_pred is the object's
  * height integrated from the current iterate and |g|_w^2 = sum_i w_i g_i^2 >= |g|^2_{Mt^-1} / mass over the dofs of the object's
  * block of the problem (all dofs while a contact joins it to the arm).  The solver's cost is 1-strongly convex in the Mt norm and
- * no accepted step raises it -- per tree, with per-tree line searches, when the problem separates -- so the final iterate is within
+ * no accepted step raises it -- per tree, steps being accepted tree by tree, when the problem separates -- so the final iterate is within
  * 2 |g|_{Mt^-1} of the current one whatever makes the solver stop; the bound is that with a 2.4 x margin for float32 evaluation.
  * The kernel still compares the bytes it sent with the integrated state.  A difference (none in any test or soak run) is counted
  * (mir_debug_early_mask_stats), raises a sticky word in pinned memory, and the NEXT mir_step_begin / mir_step_go / mir_step_end /
