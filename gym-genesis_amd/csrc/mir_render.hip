@@ -114,8 +114,10 @@ __device__ __forceinline__ float pack_rgb(const float* alb, float shade) {
 }
 
 // ---- per-(env, geom) primitive record (8 quads; every colour is final: albedo x shade, packed RGB8) ----
-//  q0 o' | type      q1 F' | xmin      q2 R' | xmax      q3 U' | ymin      q4 half extents | ymax
-//  box  : q5 = colours of the faces +x +y +z -x, q6 = -y -z
+//  plane: q0 o' | type      q1 F' | xmin      q2 R' | xmax      q3 U' | ymin      q4 half extents | ymax
+//  box  : six affine bounds A_i(x, y) = A0_i + x AX_i + y AY_i on the reciprocal depth (see the box branch below):
+//         q0 A0_0..2 | type + (nup << 8)   q1 AX_0..2 | xmin   q2 AY_0..2 | xmax   q3 A0_3..5 | ymin   q4 AX_3..5 | ymax   q7 AY_3..5
+//         q5 = colours of the faces behind the upper bounds 0 .. nup-1
 //  plane: q5 = Nu0 NuX NuY colour(even cell), q6 = Nv0 NvX NvY colour(odd cell), with the hit point's checker
 //         coordinate u/2 = (Nu0 + x NuX + y NuY) / d'z  (perspective-correct ratio of two affine functions)
 // BIN: one WAVE per env (lane = geom, ngeom <= 63) and the per-strip lists of the binned pixel kernel are written here as well
@@ -171,6 +173,8 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
   const float lk[3] = {dot(ax[0], L), dot(ax[1], L), dot(ax[2], L)};
   int xmin = 0, xmax = a.cam.W - 1, ymin = 0, ymax = a.cam.H - 1;
   f4 q5, q6;
+  float bA0[6], bAX[6], bAY[6];  // boxes: the six bounds, see below
+  int nup = 0;
   if (type == MIR_GEOM_BOX) {
     float pxmin = 3e38f, pxmax = -3e38f, pymin = 3e38f, pymax = -3e38f;
     int behind = 0;
@@ -189,10 +193,35 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
       xmin = max(0, (int)fmaxf(floorf(pxmin) - 1.0f, -1.0f)); xmax = min(a.cam.W - 1, (int)fminf(ceilf(pxmax) + 1.0f, 1e9f));
       ymin = max(0, (int)fmaxf(floorf(pymin) - 1.0f, -1.0f)); ymax = min(a.cam.H - 1, (int)fminf(ceilf(pymax) + 1.0f, 1e9f));
     }  // straddling the camera plane: keep the full screen
+    // The box as six bounds on w = 1 / t along the pixel's ray d' = F' + x R' + y U' (t = depth: F' is the unit view axis):
+    //   |o'_k + t d'_k| <= h_k   <=>   (h_k - o'_k) w >= d'_k   and   (h_k + o'_k) w >= -d'_k        (k = x, y, z)
+    // Dividing by the left factors, whose signs are properties of the BOX (which side of slab k the camera is on), every
+    // constraint is  w <= A(x, y)  (the slab face towards a camera outside slab k: where the ray may enter) or  w >= A(x, y)
+    // (every other face), with A affine in the pixel -- no reciprocal per pixel.  The ray hits iff max(lower) <= min(upper); it
+    // enters at w = min(upper), through the face that supplies the minimum.  Functions 0 .. nup-1 are the upper bounds (with their
+    // faces' colours in q5), nup .. 5 the lower ones; nup = 0 (camera inside the box) is never drawn.
     const float* alb = a.rgb[g];
-    q5 = f4{pack_rgb(alb, a.amb + a.dif * fmaxf(lk[0], 0.0f)), pack_rgb(alb, a.amb + a.dif * fmaxf(lk[1], 0.0f)),
-            pack_rgb(alb, a.amb + a.dif * fmaxf(lk[2], 0.0f)), pack_rgb(alb, a.amb + a.dif * fmaxf(-lk[0], 0.0f))};
-    q6 = f4{pack_rgb(alb, a.amb + a.dif * fmaxf(-lk[1], 0.0f)), pack_rgb(alb, a.amb + a.dif * fmaxf(-lk[2], 0.0f)), 0.0f, 0.0f};
+    const float oo[3] = {o.x, o.y, o.z}, hh[3] = {h.x, h.y, h.z};
+    const float d0[3] = {F.x, F.y, F.z}, dX[3] = {R.x, R.y, R.z}, dY[3] = {U.x, U.y, U.z};
+    float fc[6] = {0, 0, 0, 0, 0, 0}, ucol[3] = {0, 0, 0};
+    int fk[6] = {0, 0, 0, 0, 0, 0};
+    float lc[6];
+    int lkk[6], nl = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float dm = hh[k] - oo[k], dp = hh[k] + oo[k];  // dm < 0: beyond the +k face; dp < 0: beyond the -k face
+      const float c1 = 1.0f / (dm < 0.0f ? fminf(dm, -1e-20f) : fmaxf(dm, 1e-20f)), c2 = -1.0f / (dp < 0.0f ? fminf(dp, -1e-20f) : fmaxf(dp, 1e-20f));
+      const float cpos = pack_rgb(alb, a.amb + a.dif * fmaxf(lk[k], 0.0f)), cneg = pack_rgb(alb, a.amb + a.dif * fmaxf(-lk[k], 0.0f));
+      if (dm < 0.0f) { fc[nup] = c1; fk[nup] = k; ucol[nup] = cpos; nup++; lc[nl] = c2; lkk[nl] = k; nl++; }
+      else if (dp < 0.0f) { fc[nup] = c2; fk[nup] = k; ucol[nup] = cneg; nup++; lc[nl] = c1; lkk[nl] = k; nl++; }
+      else { lc[nl] = c1; lkk[nl] = k; nl++; lc[nl] = c2; lkk[nl] = k; nl++; }
+    }
+    for (int j = 0; j < nl; j++) { fc[nup + j] = lc[j]; fk[nup + j] = lkk[j]; }
+#pragma unroll
+    for (int j = 0; j < 6; j++) { bA0[j] = fc[j] * d0[fk[j]]; bAX[j] = fc[j] * dX[fk[j]]; bAY[j] = fc[j] * dY[fk[j]]; }
+    if (nup == 0) { xmin = 1; xmax = 0; ymin = 1; ymax = 0; }
+    q5 = f4{ucol[0], ucol[1], ucol[2], 0.0f};
+    q6 = f4{0.0f, 0.0f, 0.0f, 0.0f};
   } else {
     if (a.global_mode && e > 0) { xmin = 1; xmax = 0; ymin = 1; ymax = 0; }  // an unbounded plane is drawn once (env 0's)
     const float nl = o.z < 0.0f ? -lk[2] : lk[2];  // the side of the plane the camera is on
@@ -203,14 +232,23 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
   }
   if (valid) {
     f4* o4 = reinterpret_cast<f4*>(a.prims + (size_t)i * PREC);
-    o4[0] = f4{o.x, o.y, o.z, __int_as_float(type)};
-    o4[1] = f4{F.x, F.y, F.z, __int_as_float(xmin)};
-    o4[2] = f4{R.x, R.y, R.z, __int_as_float(xmax)};
-    o4[3] = f4{U.x, U.y, U.z, __int_as_float(ymin)};
-    o4[4] = f4{h.x, h.y, h.z, __int_as_float(ymax)};
+    if (type == MIR_GEOM_BOX) {
+      o4[0] = f4{bA0[0], bA0[1], bA0[2], __int_as_float(type | nup << 8)};
+      o4[1] = f4{bAX[0], bAX[1], bAX[2], __int_as_float(xmin)};
+      o4[2] = f4{bAY[0], bAY[1], bAY[2], __int_as_float(xmax)};
+      o4[3] = f4{bA0[3], bA0[4], bA0[5], __int_as_float(ymin)};
+      o4[4] = f4{bAX[3], bAX[4], bAX[5], __int_as_float(ymax)};
+      o4[7] = f4{bAY[3], bAY[4], bAY[5], 0.0f};
+    } else {
+      o4[0] = f4{o.x, o.y, o.z, __int_as_float(type)};
+      o4[1] = f4{F.x, F.y, F.z, __int_as_float(xmin)};
+      o4[2] = f4{R.x, R.y, R.z, __int_as_float(xmax)};
+      o4[3] = f4{U.x, U.y, U.z, __int_as_float(ymin)};
+      o4[4] = f4{h.x, h.y, h.z, __int_as_float(ymax)};
+      o4[7] = f4{0, 0, 0, 0};
+    }
     o4[5] = q5;
     o4[6] = q6;
-    o4[7] = f4{0, 0, 0, 0};
   }
   if (!BIN) return;
   // ---- per-strip primitive lists of the binned pixel kernel (per-env images with <= 63 primitives), built while the rectangles
@@ -240,30 +278,50 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
   }
 }
 
-// ray / box in the box frame on ONE region of a wave: the lane's 4 consecutive pixels (two packed pairs, image-plane x in xs)
-// of the row with image-plane y `ys`.  Shared by both pixel kernels, which therefore agree bit for bit.
-__device__ __forceinline__ void box_region(const f4 ro, const f4 rf, const f4 rr, const f4 ru, const f4 rh, const f4 q5, const f4 q6, float ys,
+// A box on ONE region of a wave: the lane's 4 consecutive pixels (two packed pairs, image-plane x in xs) of the row with image-plane
+// y `ys`.  Six packed FMAs per pixel pair for the bounds (the record's affine functions of the pixel), min3 / max3, two compares,
+// the face select -- ~15 VALU instructions per pixel and no reciprocal (the slab test in t this replaces: ~35 plus three
+// quarter-rate reciprocals).  `best` holds RECIPROCAL depths (larger = nearer; 0 = nothing).  Shared by both pixel kernels,
+// which therefore agree bit for bit.
+template <int NUP>
+__device__ __forceinline__ void box_bounds(const f4 a0, const f4 ax, const f4 ay, const f4 b0, const f4 bx, const f4 by, const f4 q5, float ys,
                                            const f2 (&xs)[2], f2 (&best)[2], unsigned (&col)[4]) {
-  const float ax = -rh.x - ro.x, bx = rh.x - ro.x, ay = -rh.y - ro.y, by = rh.y - ro.y, az = -rh.z - ro.z, bz = rh.z - ro.z;
-  const float ex = fmaf(ys, ru.x, rf.x), ey = fmaf(ys, ru.y, rf.y), ez = fmaf(ys, ru.z, rf.z);
+  const float e0 = fmaf(ys, ay.x, a0.x), e1 = fmaf(ys, ay.y, a0.y), e2 = fmaf(ys, ay.z, a0.z);
+  const float e3 = fmaf(ys, by.x, b0.x), e4 = fmaf(ys, by.y, b0.y), e5 = fmaf(ys, by.z, b0.z);
+  const unsigned c0 = __float_as_uint(q5.x), c1 = __float_as_uint(q5.y), c2 = __float_as_uint(q5.z);
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    const f2 dxp = xs[h] * rr.x + ex, dyp = xs[h] * rr.y + ey, dzp = xs[h] * rr.z + ez;
-    const f2 ix = rcp2(dxp), iy = rcp2(dyp), iz = rcp2(dzp);
-    const f2 x1 = ix * ax, x2 = ix * bx, y1 = iy * ay, y2 = iy * by, z1 = iz * az, z2 = iz * bz;
+    const f2 v0 = xs[h] * ax.x + e0, v1 = xs[h] * ax.y + e1, v2 = xs[h] * ax.z + e2;
+    const f2 v3 = xs[h] * bx.x + e3, v4 = xs[h] * bx.y + e4, v5 = xs[h] * bx.z + e5;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-      const float nx = fminf(x1[q], x2[q]), ny = fminf(y1[q], y2[q]), nz = fminf(z1[q], z2[q]);
-      const float tn = fmaxf(fmaxf(nx, ny), nz);
-      const float tf = fminf(fminf(fmaxf(x1[q], x2[q]), fmaxf(y1[q], y2[q])), fmaxf(z1[q], z2[q]));
-      const bool upd = tn <= tf && tn > 1e-6f && tn < best[h][q];
-      // the face whose slab entry is the latest; the ray enters through the face opposing its direction
-      const float cx = dxp[q] > 0.0f ? q5.w : q5.x, cy = dyp[q] > 0.0f ? q6.x : q5.y, cz = dzp[q] > 0.0f ? q6.y : q5.z;
-      const unsigned c = __float_as_uint(tn == nx ? cx : (tn == ny ? cy : cz));
-      best[h][q] = upd ? tn : best[h][q];
+      float hi, lo = fmaxf(fmaxf(v3[q], v4[q]), v5[q]);
+      unsigned c;
+      if constexpr (NUP == 3) {
+        hi = fminf(fminf(v0[q], v1[q]), v2[q]);
+        c = hi == v0[q] ? c0 : (hi == v1[q] ? c1 : c2);
+      } else if constexpr (NUP == 2) {
+        hi = fminf(v0[q], v1[q]);
+        lo = fmaxf(lo, v2[q]);
+        c = hi == v0[q] ? c0 : c1;
+      } else {
+        hi = v0[q];
+        lo = fmaxf(lo, fmaxf(v1[q], v2[q]));
+        c = c0;
+      }
+      const bool upd = lo <= hi && hi > best[h][q];
+      best[h][q] = upd ? hi : best[h][q];
       col[2 * h + q] = upd ? c : col[2 * h + q];
     }
   }
+}
+// (q0 .. q4, q7, q5 of a box record; the number of upper bounds is wave-uniform: a scalar branch)
+__device__ __forceinline__ void box_region(const f4 q0, const f4 q1, const f4 q2, const f4 q3, const f4 q4, const f4 q7, const f4 q5, float ys,
+                                           const f2 (&xs)[2], f2 (&best)[2], unsigned (&col)[4]) {
+  const int nup = __float_as_int(q0.w) >> 8;
+  if (nup == 3) box_bounds<3>(q0, q1, q2, q3, q4, q7, q5, ys, xs, best, col);
+  else if (nup == 2) box_bounds<2>(q0, q1, q2, q3, q4, q7, q5, ys, xs, best, col);
+  else box_bounds<1>(q0, q1, q2, q3, q4, q7, q5, ys, xs, best, col);
 }
 
 // a plane in the general position (depth-tested, any camera) on one region
@@ -271,16 +329,18 @@ __device__ __forceinline__ void plane_region(const f4 ro, const f4 rf, const f4 
                                              const f2 (&xs)[2], f2 (&best)[2], unsigned (&col)[4]) {
   const unsigned ceven = __float_as_uint(q5.w), codd = __float_as_uint(q6.w);
   const float ez = fmaf(ys, ru.z, rf.z), eu = fmaf(ys, q5.z, q5.x), ev = fmaf(ys, q6.z, q6.x);
+  const float nio = __builtin_amdgcn_rcpf(-ro.z);  // w = 1 / t = d'z / -o'z
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    const f2 iz = rcp2(xs[h] * rr.z + ez);
-    const f2 t = iz * (-ro.z);
+    const f2 dz = xs[h] * rr.z + ez;
+    const f2 iz = rcp2(dz);
+    const f2 w = dz * nio;
     const f2 u = (xs[h] * q5.y + eu) * iz, v = (xs[h] * q6.y + ev) * iz;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
-      const bool upd = t[q] > 1e-6f && t[q] < best[h][q];
-      best[h][q] = upd ? t[q] : best[h][q];
+      const bool upd = w[q] < 1e6f && w[q] > best[h][q];
+      best[h][q] = upd ? w[q] : best[h][q];
       col[2 * h + q] = upd ? (odd ? codd : ceven) : col[2 * h + q];
     }
   }
@@ -324,7 +384,7 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
     float ysr[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      best[r][0] = best[r][1] = f2{3e38f, 3e38f};
+      best[r][0] = best[r][1] = f2{0.0f, 0.0f};  // reciprocal depths: 0 = nothing drawn
       ysr[r] = a.y0 + (float)(prow + 2 * r) * a.dy;
 #pragma unroll
       for (int p = 0; p < 4; p++) col[r][p] = a.sky;
@@ -365,12 +425,13 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
         const f4 ro = rec[0], rf = rec[1], rr = rec[2], ru = rec[3], rh = rec[4], q5 = rec[5], q6 = rec[6];
         const int ymin = __float_as_int(ru.w), ymax = __float_as_int(rh.w);
         if (ymax < wy0 || ymin > wy0 + 7) continue;  // wave-uniform band cull (the strip cull covered x)
-        if (__float_as_int(ro.w) == MIR_GEOM_BOX) {
+        if ((__float_as_int(ro.w) & 255) == MIR_GEOM_BOX) {
+          const f4 q7 = rec[7];
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int wy = wy0 + 2 * r;  // wave-uniform region cull: rows wy, wy + 1
             if (ymax < wy || ymin > wy + 1) continue;
-            box_region(ro, rf, rr, ru, rh, q5, q6, ysr[r], xs, best[r], col[r]);
+            box_region(ro, rf, rr, ru, rh, q7, q5, ysr[r], xs, best[r], col[r]);
           }
         } else {
           const unsigned ceven = __float_as_uint(q5.w), codd = __float_as_uint(q6.w);
@@ -388,8 +449,9 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
               const float iz1 = __builtin_amdgcn_rcpf(ez);
               const float t1 = iz1 * (-ro.z);
               const bool vld = t1 > 1e-6f;
+              const float w1 = __builtin_amdgcn_rcpf(t1);
               if (first) {
-                const float tb = vld ? t1 : 3e38f;
+                const float tb = vld ? w1 : 0.0f;
                 const unsigned ca = vld ? ceven : a.sky, cb = vld ? codd : a.sky;
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
@@ -409,26 +471,14 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                   const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
-                  const bool upd = vld && t1 < best[r][h][q];
-                  best[r][h][q] = upd ? t1 : best[r][h][q];
+                  const bool upd = vld && w1 > best[r][h][q];
+                  best[r][h][q] = upd ? w1 : best[r][h][q];
                   col[r][2 * h + q] = upd ? (odd ? codd : ceven) : col[r][2 * h + q];
                 }
               }
               continue;
             }
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-              const f2 iz = rcp2(xs[h] * rr.z + ez);
-              const f2 t = iz * (-ro.z);
-              const f2 u = (xs[h] * q5.y + eu) * iz, v = (xs[h] * q6.y + ev) * iz;
-#pragma unroll
-              for (int q = 0; q < 2; q++) {
-                const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
-                const bool upd = t[q] > 1e-6f && t[q] < best[r][h][q];
-                best[r][h][q] = upd ? t[q] : best[r][h][q];
-                col[r][2 * h + q] = upd ? (odd ? codd : ceven) : col[r][2 * h + q];
-              }
-            }
+            plane_region(ro, rf, rr, ru, q5, q6, ysr[r], xs, best[r], col[r]);
           }
         }
       }
@@ -526,10 +576,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const bool touched = (cm[0] | cm[1] | cm[2] | cm[3]) != 0ull;
     if (touched) {
       const float ya = a.y0 + (float)(wy0 + (lane >> 3)) * a.dy;
-      float tb = 3e38f;
+      float tb = 0.0f;  // (reciprocal depth: 0 = nothing)
       if (floor) {  // the floor's depth on this lane's row: the same expressions as in the floor pass below
         const float t1 = __builtin_amdgcn_rcpf(fmaf(ya, f_uz, f_fz)) * (-f_oz);
-        tb = t1 > 1e-6f ? t1 : 3e38f;
+        tb = t1 > 1e-6f ? __builtin_amdgcn_rcpf(t1) : 0.0f;
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -542,7 +592,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             const int e = __builtin_amdgcn_readlane(ent, __builtin_ctzll(m));
             const cf4* rec = (const cf4*)(uintptr_t)(prims + (size_t)(e & 63) * PREC);
             const f4 ro = rec[0], rf = rec[1], rr = rec[2], ru = rec[3], q5 = rec[5], q6 = rec[6];
-            if (__float_as_int(ro.w) == MIR_GEOM_BOX) box_region(ro, rf, rr, ru, rec[4], q5, q6, ya, xsa, best, ca);
+            if ((__float_as_int(ro.w) & 255) == MIR_GEOM_BOX) box_region(ro, rf, rr, ru, rec[4], rec[7], q5, ya, xsa, best, ca);
             else plane_region(ro, rf, rr, ru, q5, q6, ya, xsa, best, ca);
           }
         }
