@@ -41,7 +41,7 @@
 #define TH 96   /* rows per workgroup strip (multiple of 32): walked as 128 x 32 sub-tiles */
 #endif
 #ifndef TH_BINNED
-#define TH_BINNED 160 /* strip height of the binned kernel (swept on MI355X at 1024 x 480 x 640: 96 -> 253, 160 / 256 -> 234, 480 -> 242 us) */
+#define TH_BINNED 256 /* strip height of the binned kernel (tools/probes/render_sweep.py, 1024 x 480 x 640 in the bench's state, XCD-contiguous walk, two boxes: 64 -> 220, 96 -> 195, 128 -> 187, 160 -> 185 / 195, 224 -> 200, 256 -> 180 / 196, 320 -> 207, 480 -> 209 us) */
 #endif
 #define PREC 32  /* floats per primitive record */
 #ifndef MIR_RENDER_NT
@@ -96,6 +96,7 @@ struct PixArgs {
   unsigned sky;          // packed RGB8
   int th;                // rows per workgroup strip (multiple of 32)
   const int* bins;       // binned kernel: (image, strip row, strip column, BINW) lists written by k_render_bin
+  int nsx, nsy, nwg;     // binned kernel: strips per image row / column, workgroups = images x nsx x nsy (1-D grid, see the kernel)
 };
 
 #define BINW 64  /* ints per strip list: header (count | floor flag << 8), then one packed entry per listed primitive */
@@ -528,11 +529,22 @@ __global__ __launch_bounds__(256) void mir_render_kernel(PixArgs a) {
 //     reciprocal per lane and row), it fills the pixels the boxes left (all of them in the bands no rectangle meets), and the
 //     boxes were depth-tested against its row depth.
 #define NOHIT 0xffffffffu
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void mir_render_binned(PixArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void mir_render_binned(PixArgs a) {
   __shared__ unsigned s_tile[4][8 * 128];  // per wave: 8 rows x 128 pixels of packed colours
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tx0 = blockIdx.x * TW, sy0 = blockIdx.y * a.th, img = blockIdx.z;
-  const int* bin = a.bins + (((size_t)img * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * BINW;
+  // XCD-contiguous walk.  Workgroups go to the 8 XCDs round robin by linear id; the workgroups of XCD j take the j-th eighth
+  // of the (image, strip row, strip column) sequence in order, so each XCD's L2 streams ONE contiguous range of the output
+  // (a dozen images at a time) instead of every eighth strip of all of it: tools/probes/render/store_probe.hip measures
+  // 173 -> 160 us for the bare store pattern of 1024 x 480 x 640 (a linear fill: 137 us in either order, 166 - 175 us when
+  // an XCD's pages are scattered).
+  const unsigned wid = blockIdx.x, wseq = (wid & 7u) * (gridDim.x >> 3) + (wid >> 3);
+  if (wseq >= (unsigned)a.nwg) return;
+  // (within an image the strips are taken in an order rotated by 7 per image: the strips that hold the robot would otherwise
+  //  come up with a fixed period in the XCD's dispatch sequence and pile onto the same few CUs)
+  const unsigned nst = (unsigned)(a.nsx * a.nsy), uimg = wseq / nst, st = (wseq % nst + 7u * uimg) % nst;
+  const unsigned ssx = st % (unsigned)a.nsx, ssy = st / (unsigned)a.nsx;
+  const int tx0 = ssx * TW, sy0 = ssy * a.th, img = uimg;
+  const int* bin = a.bins + ((size_t)uimg * nst + st) * BINW;
   const int ent = bin[lane];
   const int px = tx0 + 4 * (lane & 31);         // store layout: 4 pixels of rows prow + 2r
   const int pxa = tx0 + 4 * (lane & 7);         // box layout: 4 pixels of row wy0 + lane / 8, in the columns pxa + 32r
@@ -626,8 +638,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             const f2 u = (xs[h] * fq5.y + eu) * iz1, v = (xs[h] * fq6.y + ev) * iz1;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
+#ifdef MIR_PROBE_FLATFLOOR
+              fc[2 * h + q] = c0;
+#else
               const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
               fc[2 * h + q] = odd ? c1 : c0;
+#endif
             }
           }
         } else {
@@ -753,7 +769,8 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
       ba.nsx = nsx; ba.nsy = nsy; ba.nimg = nimg;
       hipLaunchKernelGGL(k_render_setup<true>, dim3((B * 64 + 255) / 256), dim3(256), 0, st, sa, ba);
       pa.bins = h->bins;
-      hipLaunchKernelGGL(mir_render_binned, dim3(nsx, nsy, nimg), dim3(256), 0, st, pa);
+      pa.nsx = nsx; pa.nsy = nsy; pa.nwg = nimg * nsx * nsy;
+      hipLaunchKernelGGL(mir_render_binned, dim3((unsigned)((pa.nwg + 7) & ~7)), dim3(256), 0, st, pa);
     } else {
       hipLaunchKernelGGL(k_render_setup<false>, dim3((B * ng + 255) / 256), dim3(256), 0, st, sa, BinArgs{});
       hipLaunchKernelGGL(mir_render_kernel, dim3((cam->width + TW - 1) / TW, (cam->height + pa.th - 1) / pa.th, nimg), dim3(256), 0, st, pa);

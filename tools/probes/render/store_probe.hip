@@ -21,10 +21,16 @@ __device__ __forceinline__ unsigned floor_col(const A& a, float xs, float eu, fl
 }
 
 // MODE 0: current pattern, dwordx3 per lane, 2 rows x 384 B per wave store.  ARITH 0: constant colour, 1: floor arithmetic
-template <int MODE, int ARITH>
+template <int MODE, int ARITH, int NT = 0>
 __global__ __launch_bounds__(256) void k(A a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int tx0 = blockIdx.x * 128, sy0 = blockIdx.y * 96, img = blockIdx.z;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (NT == 2) {  // XCD-contiguous: the workgroups of XCD j (linear id % 8 == j) walk the j-th eighth of the images in order
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), T = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned v = (id & 7u) * (T >> 3) + (id >> 3);
+    bx = v % gridDim.x; by = (v / gridDim.x) % gridDim.y; bz = v / (gridDim.x * gridDim.y);
+  }
+  const int tx0 = bx * 128, sy0 = by * 96, img = bz;
   uint8_t* ibase = a.px + (size_t)img * H * W * 3;
   if (MODE == 0) {
     const int px = tx0 + 4 * (lane & 31);
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(256) void k(A a) {
         }
         u3 v;
         v.x = c[0] | c[1] << 24; v.y = c[1] >> 8 | c[2] << 16; v.z = c[2] >> 16 | c[3] << 8;
-        *reinterpret_cast<u3*>(ibase + boff) = v;
+        if (NT == 1) __builtin_nontemporal_store(v, reinterpret_cast<u3*>(ibase + boff)); else *reinterpret_cast<u3*>(ibase + boff) = v;
       }
     }
   } else if (MODE == 1) {
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void k(A a) {
       const unsigned s8 = 8u * sh;
       v.x = __builtin_amdgcn_alignbit(d1, d0, s8); v.y = __builtin_amdgcn_alignbit(d2, d1, s8);
       v.z = __builtin_amdgcn_alignbit(d3, d2, s8); v.w = __builtin_amdgcn_alignbit(d4, d3, s8);
-      *reinterpret_cast<u4*>(ibase + off) = v;
+      if (NT == 1) __builtin_nontemporal_store(v, reinterpret_cast<u4*>(ibase + off)); else *reinterpret_cast<u4*>(ibase + off) = v;
     }
   } else if (MODE == 3) {
     // dwordx3 on a 256-px-wide strip: wave store = ONE row segment of 768 B (lane = 4 px), strip 256 x 48 rows
@@ -141,14 +147,60 @@ __global__ __launch_bounds__(256) void k(A a) {
   }
 }
 
-template <int MODE, int ARITH>
+template <int MODE, int ARITH, int NT = 0>
 float run(A a, int B, int n) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   dim3 g(5, 5, B);
-  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<MODE, ARITH>), g, dim3(256), 0, 0, a);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<MODE, ARITH, NT>), g, dim3(256), 0, 0, a);
   hipEventRecord(e0);
-  for (int i = 0; i < n; i++) hipLaunchKernelGGL((k<MODE, ARITH>), g, dim3(256), 0, 0, a);
+  for (int i = 0; i < n; i++) hipLaunchKernelGGL((k<MODE, ARITH, NT>), g, dim3(256), 0, 0, a);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms / n * 1e3f;
+}
+
+// persistent linear fill: G workgroups, each writing 4 KB per trip at stride G x 4 KB (what a fill kernel does)
+template <int CONSTANT>
+__global__ __launch_bounds__(256) void kp(uint8_t* px, size_t bytes, int per) {
+  for (size_t off = ((size_t)blockIdx.x * per) * 4096 + threadIdx.x * 16; off < bytes; off += (size_t)gridDim.x * per * 4096) {
+    for (int t = 0; t < per; t++) {
+      if (off + (size_t)t * 4096 < bytes) *reinterpret_cast<u4*>(px + off + (size_t)t * 4096) = CONSTANT ? u4{7u, 7u, 7u, 7u} : u4{(unsigned)off * 2654435761u, (unsigned)t * 40503u + threadIdx.x, 7u ^ (unsigned)(off >> 7), (unsigned)threadIdx.x * 2246822519u};
+    }
+  }
+}
+template <int CONSTANT>
+float runp(uint8_t* px, size_t bytes, int G, int per, int n) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kp<CONSTANT>, dim3(G), dim3(256), 0, 0, px, bytes, per);
+  hipEventRecord(e0);
+  for (int i = 0; i < n; i++) hipLaunchKernelGGL(kp<CONSTANT>, dim3(G), dim3(256), 0, 0, px, bytes, per);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms / n * 1e3f;
+}
+
+// one-shot linear fill like a framework's fill kernel: workgroup i writes chunk c(i) of `per` x 4 KB and exits.
+// MAP 0: c = i.  MAP 1: c = (i % 8) * (n / 8) + i / 8 (workgroups i, i+1, .. of the 8 XCDs write far apart; an XCD writes a contiguous eighth).
+// MAP 2: c = i with the low 3 bits rotated by (i >> 3) (page p goes to XCD (p + p / 8) % 8: every XCD sees every page residue)
+template <int MAP>
+__global__ __launch_bounds__(256) void k1(uint8_t* px, size_t bytes, int per, unsigned n) {
+  unsigned i = blockIdx.x, c = i;
+  if (MAP == 1) c = (i & 7u) * (n >> 3) + (i >> 3);
+  if (MAP == 2) c = (i & ~7u) | ((i + (i >> 3)) & 7u);
+  const size_t off = (size_t)c * per * 4096 + threadIdx.x * 16;
+  for (int t = 0; t < per; t++)
+    if (off + (size_t)t * 4096 < bytes) *reinterpret_cast<u4*>(px + off + (size_t)t * 4096) = u4{7u, 7u, (unsigned)t, (unsigned)threadIdx.x};
+}
+template <int MAP>
+float run1(uint8_t* px, size_t bytes, int per, int n) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const unsigned G = (unsigned)((bytes / 4096 / per) & ~7ull);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k1<MAP>, dim3(G), dim3(256), 0, 0, px, bytes, per, G);
+  hipEventRecord(e0);
+  for (int i = 0; i < n; i++) hipLaunchKernelGGL(k1<MAP>, dim3(G), dim3(256), 0, 0, px, bytes, per, G);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   return ms / n * 1e3f;
@@ -166,6 +218,20 @@ int main() {
   const double gb = bytes / 1e9;
 #define R(M, AR) { float us = run<M, AR>(a, B, 20); printf("mode %d arith %d: %7.1f us  %6.0f GB/s\n", M, AR, us, gb / us * 1e6); }
   R(0, 0) R(1, 0) R(2, 0) R(3, 0) R(0, 1) R(1, 1) R(2, 1)
+#define RN(M, AR) { float us = run<M, AR, 1>(a, B, 20); printf("mode %d arith %d nontemporal: %7.1f us  %6.0f GB/s\n", M, AR, us, gb / us * 1e6); }
+  RN(0, 0) RN(2, 0) RN(0, 1)
+#define RX(M, AR) { float us = run<M, AR, 2>(a, B, 20); printf("mode %d arith %d XCD-contiguous images: %7.1f us  %6.0f GB/s\n", M, AR, us, gb / us * 1e6); }
+  RX(0, 0) RX(0, 1) RX(1, 0)
+  for (int G : {2048, 16384}) for (int per : {9}) { float us = runp<0>(a.px, bytes, G, per, 20); printf("persistent linear, varied data, G=%d per=%d: %7.1f us %6.0f GB/s\n", G, per, us, gb / us * 1e6); us = runp<1>(a.px, bytes, G, per, 20); printf("persistent linear, constant data, G=%d per=%d: %7.1f us %6.0f GB/s\n", G, per, us, gb / us * 1e6); }
+  for (int per : {1, 2, 4, 9}) { float u0 = run1<0>(a.px, bytes, per, 20), u1 = run1<1>(a.px, bytes, per, 20), u2 = run1<2>(a.px, bytes, per, 20); printf("one-shot linear, %d x 4 KB per workgroup: in order %7.1f us %6.0f GB/s | XCD-contiguous eighths %7.1f us | rotated %7.1f us\n", per, u0, gb / u0 * 1e6, u1, u2); }
+  // does the PLACEMENT of the buffer matter?  (tools/probes/render_align.py: the rasteriser runs at 180 us into some allocations and at
+  // 213 us into others of the same process)  Five more allocations, the strided strip pattern and the linear ones on each.
+  for (int nb = 0; nb < 5; nb++) {
+    A b = a;
+    hipMalloc((void**)&b.px, bytes);
+    const float s0 = run<0, 1>(b, B, 20), sx = run<0, 1, 2>(b, B, 20), l1 = run1<0>(b.px, bytes, 1, 20), l9 = run1<0>(b.px, bytes, 9, 20);
+    printf("buffer %p: strips %7.1f us | strips, XCD-contiguous %7.1f us | one-shot linear 4 KB %7.1f us | 36 KB %7.1f us\n", (void*)b.px, s0, sx, l1, l9);
+  }
   // plain fill
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; i++) hipMemsetAsync(a.px, 7, bytes, 0);
