@@ -7,24 +7,28 @@
 //
 // MI355X mapping.  At B=1024, 480x640 the output is 943 MB per step, so the kernel is HBM-WRITE-bound
 // by construction; everything else is arranged to stay below that:
-//   * k_render_setup: world pose of every primitive from the step kernel's FK cache, the camera expressed in the
+//   * k_render_setup: world pose of every primitive from the step kernel's FK cache and the camera expressed in the
 //     primitive's frame (origin o', and the images F', R', U' of the camera basis, so a pixel's ray in that frame is
-//     d' = F' + x R' + y U': 6 FMAs, no matrix product), FINAL packed RGB8 colours per face (albedo x shade) or, for a
-//     plane, the two checker colours and the affine numerators of the perspective-correct checker coordinate, and a
-//     conservative screen rectangle.  128 B per primitive.  Per-env cameras (mir_render_cams) are resolved here too.
-//     For per-env images one WAVE handles an env (lane = geom) and also writes the per-strip primitive lists.
+//     d' = F' + x R' + y U').  A box becomes SIX AFFINE FUNCTIONS of the pixel that bound the reciprocal depth w = 1 / t of
+//     the ray inside it (upper bounds: the faces towards the camera, where it may enter; lower bounds: the others) with the
+//     FINAL packed RGB8 colours of the entry faces (albedo x shade); a plane keeps o', F', R', U', its two checker colours and
+//     the affine numerators of the perspective-correct checker coordinate.  Plus a conservative screen rectangle; 128 B per
+//     primitive.  Per-env cameras (mir_render_cams) are resolved here too.  For per-env images one WAVE handles an env
+//     (lane = geom) and also writes the per-strip primitive lists.
 //   * mir_render_binned (per-env images, the pixels observation): workgroup = 4 waves stacked on a 128-pixel-wide strip
-//     of 160 rows, walked as 128 x 32 sub-tiles, wave = a band of 128 x 8 pixels.  The strip's list arrives with one
+//     of 256 rows, walked as 128 x 32 sub-tiles, wave = a band of 128 x 8 pixels.  The strip's list arrives with one
 //     vector load (lane k = entry k); depth-tested primitives are drawn on 32 x 8-pixel regions (lane = 4 pixels of one
 //     row), only where the entry's row range and column mask say so, records by wave-uniform SCALAR loads; their colours
 //     move through a wave-private LDS tile into the store layout (regions of 128 x 2: lane = 4 consecutive pixels, one
 //     global_store_dwordx3 per lane and region = whole 128-byte lines, not waited for); the floor is drawn last, in
-//     the store layout, without a depth buffer.  1024 x 480 x 640: 227 us = 4.15 TB/s written (round 2: 335 us).
+//     the store layout, without a depth buffer.  The strips are walked XCD by XCD: the workgroups of one XCD stream one
+//     contiguous eighth of the output.  1024 x 480 x 640: 180 - 215 us = 4.4 - 5.2 TB/s written, depending on where the
+//     driver placed the output buffer (round 3: 245 - 257 us; round 2: 335 us).
 //   * mir_render_kernel (the global view of all envs, odd widths): the same tiling with the list culled per workgroup
 //     (ordered ballot compaction into LDS) and everything drawn in the store layout.
-//   * ray/box in the box frame is a 3-slab test; depth order is resolved per pixel (strict <, list in
-//     ascending primitive order => deterministic); the colour of a hit is selected at hit time from the
-//     record, so there is no shading pass and no per-pixel lookup.
+//   * ray / box is min(upper bounds) >= max(lower bounds) on those six functions: packed FMAs, min3 / max3, no reciprocal
+//     per pixel; depth order is resolved per pixel on w (strict >, list in ascending primitive order => deterministic);
+//     the colour of a hit is selected at hit time from the record, so there is no shading pass and no per-pixel lookup.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
