@@ -178,7 +178,7 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
   const float lk[3] = {dot(ax[0], L), dot(ax[1], L), dot(ax[2], L)};
   int xmin = 0, xmax = a.cam.W - 1, ymin = 0, ymax = a.cam.H - 1;
   f4 q5, q6;
-  float bA0[6], bAX[6], bAY[6];  // boxes: the six bounds, see below
+  float bA0[6], bAX[6], bAY[6], ucol[3] = {0, 0, 0};  // boxes: the six bounds, see below
   int nup = 0;
   if (type == MIR_GEOM_BOX) {
     float pxmin = 3e38f, pxmax = -3e38f, pymin = 3e38f, pymax = -3e38f;
@@ -208,22 +208,35 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
     const float* alb = a.rgb[g];
     const float oo[3] = {o.x, o.y, o.z}, hh[3] = {h.x, h.y, h.z};
     const float d0[3] = {F.x, F.y, F.z}, dX[3] = {R.x, R.y, R.z}, dY[3] = {U.x, U.y, U.z};
-    float fc[6] = {0, 0, 0, 0, 0, 0}, ucol[3] = {0, 0, 0};
-    int fk[6] = {0, 0, 0, 0, 0, 0};
-    float lc[6];
-    int lkk[6], nl = 0;
+    // per axis k: f1 = the bound that is the upper one when the camera is outside slab k (else the slab's second lower bound),
+    // f2 = the slab's (first) lower bound; as functions of the pixel: f * (F'_k, R'_k, U'_k)
+    float a1[3][3], a2[3][3], acol[3];
+    unsigned outm = 0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const float dm = hh[k] - oo[k], dp = hh[k] + oo[k];  // dm < 0: beyond the +k face; dp < 0: beyond the -k face
       const float c1 = 1.0f / (dm < 0.0f ? fminf(dm, -1e-20f) : fmaxf(dm, 1e-20f)), c2 = -1.0f / (dp < 0.0f ? fminf(dp, -1e-20f) : fmaxf(dp, 1e-20f));
-      const float cpos = pack_rgb(alb, a.amb + a.dif * fmaxf(lk[k], 0.0f)), cneg = pack_rgb(alb, a.amb + a.dif * fmaxf(-lk[k], 0.0f));
-      if (dm < 0.0f) { fc[nup] = c1; fk[nup] = k; ucol[nup] = cpos; nup++; lc[nl] = c2; lkk[nl] = k; nl++; }
-      else if (dp < 0.0f) { fc[nup] = c2; fk[nup] = k; ucol[nup] = cneg; nup++; lc[nl] = c1; lkk[nl] = k; nl++; }
-      else { lc[nl] = c1; lkk[nl] = k; nl++; lc[nl] = c2; lkk[nl] = k; nl++; }
+      const bool hi = dm < 0.0f;
+      const float f1 = hi ? c1 : c2, f2 = hi ? c2 : c1;
+      a1[k][0] = f1 * d0[k]; a1[k][1] = f1 * dX[k]; a1[k][2] = f1 * dY[k];
+      a2[k][0] = f2 * d0[k]; a2[k][1] = f2 * dX[k]; a2[k][2] = f2 * dY[k];
+      acol[k] = pack_rgb(alb, a.amb + a.dif * fmaxf(hi ? lk[k] : -lk[k], 0.0f));
+      outm |= (hi || dp < 0.0f) ? 1u << k : 0u;
     }
-    for (int j = 0; j < nl; j++) { fc[nup + j] = lc[j]; fk[nup + j] = lkk[j]; }
+    // the axes with the camera outside their slab first (a stable partition of x, y, z; six bits per case, no indexed memory)
+    const unsigned perm = (unsigned)((0x909612921924ull >> (6 * outm)) & 63ull);
+    nup = __popc(outm);
 #pragma unroll
-    for (int j = 0; j < 6; j++) { bA0[j] = fc[j] * d0[fk[j]]; bAX[j] = fc[j] * dX[fk[j]]; bAY[j] = fc[j] * dY[fk[j]]; }
+    for (int j = 0; j < 3; j++) {
+      const unsigned k = (perm >> (2 * j)) & 3u;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float v1 = k == 0 ? a1[0][c] : (k == 1 ? a1[1][c] : a1[2][c]), v2 = k == 0 ? a2[0][c] : (k == 1 ? a2[1][c] : a2[2][c]);
+        (c == 0 ? bA0 : (c == 1 ? bAX : bAY))[j] = v1;
+        (c == 0 ? bA0 : (c == 1 ? bAX : bAY))[3 + j] = v2;
+      }
+      ucol[j] = k == 0 ? acol[0] : (k == 1 ? acol[1] : acol[2]);
+    }
     if (nup == 0) { xmin = 1; xmax = 0; ymin = 1; ymax = 0; }
     q5 = f4{ucol[0], ucol[1], ucol[2], 0.0f};
     q6 = f4{0.0f, 0.0f, 0.0f, 0.0f};
