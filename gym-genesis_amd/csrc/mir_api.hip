@@ -193,17 +193,24 @@ struct Outs {
 int launch(MirScene* h, const Outs& o, void* stream) {
   int rc;
   if (o.phase != 1 && o.mode != 2) h->pre_valid = 0;  // (whatever this launch is, the state it leaves is not the one `pre` was made from)
+  // Link poses for the rasteriser.  Once a render has been asked for (poses_live), every launch that integrates also leaves the
+  // link poses of its final state in h->poses -- its closing forward kinematics has them -- so that a render behind a step needs
+  // no pose-refresh launch (6 us per 1024 envs).  poses_current: h->poses matches qpos for every env.
+  const bool integrates = o.mode == 0 && o.phase != 1;
+  const bool wr_poses = o.poses || (h->poses_live && integrates);
+  if (o.mode == 2 && o.poses) h->poses_current = 1;
+  else if (integrates) h->poses_current = (h->kernel == 64 || wr_poses) && !o.ar.episode_len;  // (an in-kernel reset moves envs after the closing FK)
   if (h->kernel == 16) {
     StepArgs a;
     memset(&a, 0, sizeof a);
     a.model = h->dm;
     a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
-    a.poses = o.poses ? h->poses : nullptr;
+    a.poses = wr_poses ? h->poses : nullptr;
     a.early_stats = h->early_stats; a.no_early_mask = h->no_early_mask;
     a.term_bad = h->pin_dev ? reinterpret_cast<uint32_t*>(h->pin_dev + h->pin_flag_off + 16) : nullptr;
     a.term_wstride = h->term_wstride;
     a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
-    a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0) | (h->spec_pick ? 4 : 0);
+    a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0) | ((h->spec_pick && !wr_poses) ? 4 : 0);
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
@@ -504,6 +511,7 @@ int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const fl
   }
   if (int rc = check_mask(h)) return rc;
   h->pre_valid = 0;
+  h->poses_current = 0;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_reset, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, obj_pos, obj_quat, arm_qpos, env_mask, h->fkvalid, h->B);
@@ -516,6 +524,7 @@ int mir_autoreset(MirHandle h, const uint8_t* terminated, int32_t* episode_len, 
   if (check(h)) return MIR_E_INVALID;
   if (!episode_len || !spawn_pool || !cursor || !obj_quat || !arm_qpos || pool_len <= 0) return set_err(MIR_E_INVALID, "mir_autoreset: null argument");
   h->pre_valid = 0;
+  h->poses_current = 0;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_autoreset, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, terminated, episode_len, max_len, spawn_pool, pool_len, cursor, obj_quat, arm_qpos, truncated_out, done_out,
@@ -1020,6 +1029,7 @@ int mir_get_state(MirHandle h, float* qpos, float* qvel, float* target, float* w
 int mir_set_state(MirHandle h, const float* qpos, const float* qvel, const float* target, const float* warmstart, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   h->pre_valid = 0;
+  h->poses_current = 0;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_copy_state, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, (float*)qpos, (float*)qvel, (float*)target, (float*)warmstart, h->fkvalid, h->B, 1);

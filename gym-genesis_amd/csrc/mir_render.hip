@@ -738,7 +738,8 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
       hipError_t e = hipMalloc((void**)&h->prims, (size_t)B * ng * PREC * sizeof(float));
       if (e != hipSuccess) { rc = mir_set_error(MIR_E_HIP, hipGetErrorString(e)); break; }
     }
-    if ((rc = mir_refresh_poses(h, stream)) != MIR_OK) break;
+    h->poses_live = 1;  // (from now on the step launches keep h->poses up to date themselves)
+    if (!h->poses_current && (rc = mir_refresh_poses(h, stream)) != MIR_OK) break;
     SetupArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.geom = h->dgeom; sa.poses = h->poses; sa.pst = h->pt.pst; sa.env_offset = env_offset; sa.prims = h->prims;

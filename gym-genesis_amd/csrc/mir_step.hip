@@ -1061,7 +1061,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   if (DUAL && !ROT) __syncthreads();  // (1) link poses from the collision wave; model table, velocities and targets from this one
   // (ROT: the loop below runs twice -- pass 0 is the second half of this step, pass 1 the first half of the next one)
   const int nsteps = ROT ? 2 : (SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0)));
-  if (VARIANT != 2) a.poses = nullptr;
+  // (the action-independent half alone integrates nothing; the scene-specialised instantiations -- the headline's -- stay free of the
+  //  store: launches that want poses take the generic-scene instantiation, see launch() in mir_api.hip)
+  if (PRE || SPEC) a.poses = nullptr;
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr;
 #ifndef MIR_PROFILE_SINGLE  /* (a profiling build keeps the phase stamps in the single-step instantiation: tools/phase_profile.py) */
     a.prof = nullptr;
@@ -1127,7 +1129,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       }
     }
     if (valid) {
-      if (a.poses && lane < nb) {  // (pose refresh for the rasteriser, mode 2 only)
+      if (a.poses && lane < nb) {  // (link poses for the rasteriser: the pose-refresh launch, and every integrating launch once a render has been asked for)
         float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
         *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
         *reinterpret_cast<f4*>(p + 4 * G) = ldv(S.xquat[lane]);
@@ -2045,8 +2047,8 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   const bool prof_blocks_single = a.prof != nullptr;
 #endif
   const bool single = a.mode == 0 && a.n_steps == 1 && !a.act_step && !a.rows_step && !a.ar.episode_len && !prof_blocks_single && !a.out_M && !a.out_bias &&
-                      !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.poses;
-  const bool plain_loop = a.mode == 0 && !a.poses && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
+                      !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat;
+  const bool plain_loop = a.mode == 0 && !a.prof && !a.out_M && !a.out_bias && !a.out_qas && !a.out_qacc && !a.out_xpos && !a.out_xquat && !a.agent_pos &&
                           !a.env_state && !a.reward && !a.terminated && !a.term_host && !a.done_ticket;
   if (a.phase == 2) {  // (the second half of a split step has no collision code in it: one instantiation serves every scene)
     hipLaunchKernelGGL((mir_step_kernel<4, 0>), dim3(blocks), dim3(64), 0, stream, a);

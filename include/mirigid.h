@@ -379,7 +379,10 @@ int mir_visual_sizeof(void);
  * as seen from `cam` in its own frame (env_offset ignored).  mode GLOBAL: pixels (H,W,3) u8, every env
  * drawn displaced by env_offset[e] (B,3 f32 device, NULL = all zero); plane geoms are drawn once.
  * cam / vis are host structs (copied into the launch).  pixels is a device pointer.  B x H x W x 3 may exceed 2^32 bytes (64-bit
- * image bases); MIR_E_CAPACITY when a single image reaches 2^32 bytes or a per-env call has more than 65535 images. */
+ * image bases); MIR_E_CAPACITY when a single image reaches 2^32 bytes or a per-env call has more than 65535 images.
+ * Link poses: from the first render on, every call that advances the state also leaves the link poses of its final state for the
+ * rasteriser, and a render queued behind it (same stream order as the calls that touched the state, as for every call on a handle)
+ * launches no forward kinematics of its own; behind mir_reset / mir_autoreset / mir_set_state it does. */
 int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, int32_t mode, const float* env_offset,
                uint8_t* pixels, void* stream);
 

@@ -269,3 +269,61 @@ def test_binned_kernel_equals_generic_kernel_bit_for_bit():
                 assert np.array_equal(img, ref), f"binned kernel differs from the generic one ({cam.width}x{cam.height}, strip rows {rows})"
             scene.debug_render_path()
             assert len(np.unique(ref.reshape(-1, 3), axis=0)) >= 2
+
+
+@pytest.mark.parametrize("kind", ["pick", "stack"])
+def test_render_behind_a_step_needs_no_pose_refresh_and_shows_the_same_image(kind):
+    """Once a render has been asked for, every integrating launch leaves the link poses of its final state for the rasteriser
+    (launch() in mir_api.hip) and mir_render skips its pose-refresh launch.  The images must be those of a twin that is given the
+    same state through mir_set_state (which invalidates the poses: its render refreshes them) -- bit for bit, after fused steps,
+    split / rotated steps, a K-step rollout, an in-kernel auto-reset, a masked reset and a state write."""
+    from gym_genesis.backend.lib import MirScene
+
+    B = 64
+    rng = np.random.RandomState(5)
+    if kind == "pick":
+        builder = models.franka_cube_pick_scene()
+        pos = np.stack([rng.uniform(0.45, 0.80, B), rng.uniform(-0.25, 0.25, B), np.full(B, 0.02)], 1).astype(np.float32)
+        quat = np.tile(np.array([0, 0, 0, 1], np.float32), (B, 1))
+        home = HOME
+        cam = make_camera(256, 192, (3.5, 0.0, 2.5), (0, 0, 0.5), 30)
+    else:
+        builder = models.franka_cube_stack_scene()
+        pos = np.zeros((B, 5, 3), np.float32)
+        pos[:, :, 0] = np.array([-0.3, -0.15, 0.0, 0.15, 0.3]) + rng.uniform(-0.03, 0.03, (B, 5))
+        pos[:, :, 1] = rng.uniform(-0.2, 0.2, (B, 5))
+        pos[:, :, 2] = models.STACK_CUBE_Z
+        quat = np.tile(np.array([0, 0, 0, 1], np.float32), (B, 5, 1))
+        home = HOME
+        cam = make_camera(256, 160, (1.2, 0.0, 1.6), (-0.2, 0.0, 0.75), 50)
+    vis = builder.visual()
+    a, b = MirScene(builder.build(), B), MirScene(builder.build(), B)
+    for sc in (a, b):
+        sc.reset(pos, quat, np.tile(home, (B, 1)))
+    acts = torch.as_tensor(rng.uniform(-1, 1, (40, B, a.nu)).astype(np.float32), device=a.device)
+    bufs = (a.empty(a.agent_dim), a.empty(a.env_dim), a.empty(), a.empty(dtype=torch.uint8))
+
+    def same(tag):
+        b.set_state(*[x.clone() for x in a.get_state()])
+        ia, ib = a.render(cam, vis, mode=0).cpu().numpy(), b.render(cam, vis, mode=0).cpu().numpy()
+        assert np.array_equal(ia, ib), f"{tag}: the image rendered from the step's own poses differs from a refreshed render"
+        return ia
+
+    first = same("first render")                     # (turns the hand-over on for `a`)
+    for t in range(5):
+        a.step_fused(acts[t], *bufs)
+    img = same("fused steps")
+    assert not np.array_equal(img, first)
+    for t in range(5, 12):                           # split / rotated launches (16-lane kernel), plain ones on the wave kernel
+        a.step_begin(acts[t], *bufs)
+        a.step_end()
+    same("step_begin / step_end")
+    a.set_pd_targets(acts[12])
+    a.step(3)
+    same("mir_step(3)")
+    mask = np.zeros(B, np.uint8); mask[::3] = 1
+    a.reset(pos, quat, np.tile(home, (B, 1)), env_mask=mask)
+    same("masked reset (no step behind it)")
+    for t in range(21, 24):
+        a.step_fused(acts[t], *bufs)
+    same("steps after the masked reset")
