@@ -8,8 +8,10 @@
 typedef unsigned u3 __attribute__((ext_vector_type(3)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+#ifndef W
 #define W 640
 #define H 480
+#endif
 
 struct A { uint8_t* px; float x0, dx, y0, dy, nu0, nux, nuy, nv0, nvx, nvy, fz, uz, oz; unsigned ce, co, sky; };
 
@@ -128,14 +130,14 @@ __global__ __launch_bounds__(256) void k(A a) {
       if (NT == 1) __builtin_nontemporal_store(v, reinterpret_cast<u4*>(ibase + off)); else *reinterpret_cast<u4*>(ibase + off) = v;
     }
   } else if (MODE == 3) {
-    // dwordx3 on a 256-px-wide strip: wave store = ONE row segment of 768 B (lane = 4 px), strip 256 x 48 rows
-    const int sx0 = (blockIdx.x & 1) * 256 + (blockIdx.x >> 1) * 512;  // 5 x 128 -> not a multiple of 256: probe only the pattern
-    const int px = (sx0 + 4 * lane) % W;
-    for (int ty0 = sy0; ty0 < sy0 + 96; ty0 += 32) {
-      const int prow = ty0 + 8 * wv;
+    // dwordx3 on a 256-px-wide strip: a wave store = ONE row segment of 768 B (lane = 4 px); wave = band of 256 x 4 rows.
+    // Needs W % 256 == 0 (-DW=768 -DH=400: the same 943.7 MB); grid.x = W / 256.
+    const int px = bx * 256 + 4 * lane;
+    for (int ty0 = sy0; ty0 < sy0 + 96; ty0 += 16) {
+      const int prow = ty0 + 4 * wv;
       unsigned boff = ((unsigned)prow * W + px) * 3u;
 #pragma unroll
-      for (int r = 0; r < 4; r++, boff += 3u * W) {   // 4 of the 8 rows (same store count per wave as mode 0)
+      for (int r = 0; r < 4; r++, boff += 3u * W) {
         unsigned c[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) c[p] = a.sky + lane;
@@ -151,7 +153,7 @@ template <int MODE, int ARITH, int NT = 0>
 float run(A a, int B, int n) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  dim3 g(5, 5, B);
+  dim3 g(MODE == 3 ? W / 256 : W / 128, H / 96, B);
   for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<MODE, ARITH, NT>), g, dim3(256), 0, 0, a);
   hipEventRecord(e0);
   for (int i = 0; i < n; i++) hipLaunchKernelGGL((k<MODE, ARITH, NT>), g, dim3(256), 0, 0, a);
@@ -217,7 +219,8 @@ int main() {
   a.ce = 0x00c8c8c8; a.co = 0x00505050; a.sky = 0x00e6b48c;
   const double gb = bytes / 1e9;
 #define R(M, AR) { float us = run<M, AR>(a, B, 20); printf("mode %d arith %d: %7.1f us  %6.0f GB/s\n", M, AR, us, gb / us * 1e6); }
-  R(0, 0) R(1, 0) R(2, 0) R(3, 0) R(0, 1) R(1, 1) R(2, 1)
+  R(0, 0) R(1, 0) R(2, 0) R(0, 1) R(1, 1) R(2, 1)
+  if (W % 256 == 0) R(3, 0)
 #define RN(M, AR) { float us = run<M, AR, 1>(a, B, 20); printf("mode %d arith %d nontemporal: %7.1f us  %6.0f GB/s\n", M, AR, us, gb / us * 1e6); }
   RN(0, 0) RN(2, 0) RN(0, 1)
 #define RX(M, AR) { float us = run<M, AR, 2>(a, B, 20); printf("mode %d arith %d XCD-contiguous images: %7.1f us  %6.0f GB/s\n", M, AR, us, gb / us * 1e6); }
@@ -230,7 +233,9 @@ int main() {
     A b = a;
     hipMalloc((void**)&b.px, bytes);
     const float s0 = run<0, 1>(b, B, 20), sx = run<0, 1, 2>(b, B, 20), l1 = run1<0>(b.px, bytes, 1, 20), l9 = run1<0>(b.px, bytes, 9, 20);
-    printf("buffer %p: strips %7.1f us | strips, XCD-contiguous %7.1f us | one-shot linear 4 KB %7.1f us | 36 KB %7.1f us\n", (void*)b.px, s0, sx, l1, l9);
+    printf("buffer %p: strips %7.1f us | strips, XCD-contiguous %7.1f us | one-shot linear 4 KB %7.1f us | 36 KB %7.1f us", (void*)b.px, s0, sx, l1, l9);
+    if (W % 256 == 0) printf(" | 128-px strips no arithmetic, XCD-contiguous %7.1f us | 256-px strips (768-byte pieces), XCD-contiguous %7.1f us", run<0, 0, 2>(b, B, 20), run<3, 0, 2>(b, B, 20));
+    printf("\n");
   }
   // plain fill
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
