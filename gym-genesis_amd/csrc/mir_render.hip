@@ -655,12 +655,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const f2 u = (xs[h] * fq5.y + eu) * iz1, v = (xs[h] * fq6.y + ev) * iz1;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-#ifdef MIR_PROBE_FLATFLOOR
-              fc[2 * h + q] = c0;
-#else
               const bool odd = (__builtin_amdgcn_fractf(u[q]) >= 0.5f) != (__builtin_amdgcn_fractf(v[q]) >= 0.5f);
               fc[2 * h + q] = odd ? c1 : c0;
-#endif
             }
           }
         } else {
