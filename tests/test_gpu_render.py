@@ -327,3 +327,38 @@ def test_render_behind_a_step_needs_no_pose_refresh_and_shows_the_same_image(kin
     for t in range(21, 24):
         a.step_fused(acts[t], *bufs)
     same("steps after the masked reset")
+
+
+def test_stack_scene_views_match_oracle():
+    """The five-cube scene on the kitchen slab, seen from cameras that stand INSIDE one or two of the slab's (and the cubes') slabs --
+    straight above the footprint, level with the slab's side, close over a cube -- against the oracle's ray caster.  These are the box
+    records with one and two upper bounds (camera outside one / two slabs only: mir_render.hip, k_render_setup)."""
+    from gym_genesis.backend.lib import MirScene
+
+    B = 4
+    b = models.franka_cube_stack_scene()
+    spec = b.build()
+    sc = MirScene(spec, B)
+    rng = np.random.RandomState(11)
+    pos = np.zeros((B, 5, 3), np.float32)
+    pos[:, :, 0] = np.array([-0.3, -0.15, 0.0, 0.15, 0.3]) + rng.uniform(-0.03, 0.03, (B, 5))
+    pos[:, :, 1] = rng.uniform(-0.2, 0.2, (B, 5))
+    pos[:, :, 2] = models.STACK_CUBE_Z
+    sc.reset(pos, np.tile(np.array([0, 0, 0, 1], np.float32), (B, 5, 1)), np.tile(HOME, (B, 1)))
+    acts = torch.as_tensor(HOME + rng.uniform(-0.5, 0.5, (10, B, 9)).astype(np.float32), device=sc.device)
+    for t in range(10):
+        sc.set_pd_targets(acts[t])
+        sc.step(1)
+    vis = b.visual()
+    xpos, xquat = (t.cpu().numpy() for t in sc.get_links())
+    z = float(models.STACK_CUBE_Z)
+    cams = [make_camera(256, 160, (0.0, 0.0, z + 1.8), (0.0, 0.0, z), 50, up=(1.0, 0.0, 0.0)),   # straight above: inside the x and y slabs of the slab
+            make_camera(200, 120, (1.6, 0.05, z - 0.03), (0.0, 0.0, z), 40),                        # level with the slab's top: inside its z slab (and y)
+            make_camera(160, 120, (0.02, 0.01, z + 0.25), (0.0, 0.0, z), 80, up=(1.0, 0.0, 0.0)),   # close over the middle cube
+            make_camera(320, 200, (1.2, 0.0, 1.6), (-0.2, 0.0, 0.75), 50)]                          # the task's own side view
+    for cam in cams:
+        img = sc.render(cam, vis, mode=0).cpu().numpy()
+        for e in range(B):
+            ref = orc.render_image(spec, cam, vis, xpos[e:e + 1], xquat[e:e + 1])
+            _compare(img[e], ref)
+        assert len(np.unique(img.reshape(-1, 3), axis=0)) > 4
