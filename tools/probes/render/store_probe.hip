@@ -24,7 +24,7 @@ __device__ __forceinline__ unsigned floor_col(const A& a, float xs, float eu, fl
 
 // MODE 0: current pattern, dwordx3 per lane, 2 rows x 384 B per wave store.  ARITH 0: constant colour, 1: floor arithmetic
 template <int MODE, int ARITH, int NT = 0>
-__global__ __launch_bounds__(256) void k(A a) {
+__global__ __launch_bounds__(MODE == 4 ? 64 * (W / 128) : 256) void k(A a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (NT == 2) {  // XCD-contiguous: the workgroups of XCD j (linear id % 8 == j) walk the j-th eighth of the images in order
@@ -129,6 +129,33 @@ __global__ __launch_bounds__(256) void k(A a) {
       v.z = __builtin_amdgcn_alignbit(d3, d2, s8); v.w = __builtin_amdgcn_alignbit(d4, d3, s8);
       if (NT == 1) __builtin_nontemporal_store(v, reinterpret_cast<u4*>(ibase + off)); else *reinterpret_cast<u4*>(ibase + off) = v;
     }
+  } else if (MODE == 4) {
+    // full-width workgroup: W / 128 waves side by side on the same 8 rows (wave = 128 x 8 band as in mode 0), walking down 96 rows:
+    // at any time the workgroup writes 8 whole rows (launch with W / 128 * 64 threads, grid.x = 1)
+    const int px = wv * 128 + 4 * (lane & 31);
+    for (int ty0 = sy0; ty0 < sy0 + 96; ty0 += 8) {
+      const int prow = ty0 + (lane >> 5);
+      unsigned boff = ((unsigned)prow * W + px) * 3u;
+#pragma unroll
+      for (int r = 0; r < 4; r++, boff += 6u * W) {
+        unsigned c[4];
+        if (ARITH) {
+          const float ys = a.y0 + (float)(prow + 2 * r) * a.dy;
+          const float ez = fmaf(ys, a.uz, a.fz), eu = fmaf(ys, a.nuy, a.nu0), ev = fmaf(ys, a.nvy, a.nv0);
+          const float iz1 = __builtin_amdgcn_rcpf(ez);
+          const bool vld = iz1 * (-a.oz) > 1e-6f;
+          const unsigned ca = vld ? a.ce : a.sky, cb = vld ? a.co : a.sky;
+#pragma unroll
+          for (int p = 0; p < 4; p++) c[p] = floor_col(a, a.x0 + (float)(px + p) * a.dx, eu, ev, iz1, ca, cb);
+        } else {
+#pragma unroll
+          for (int p = 0; p < 4; p++) c[p] = a.sky + lane;
+        }
+        u3 v;
+        v.x = c[0] | c[1] << 24; v.y = c[1] >> 8 | c[2] << 16; v.z = c[2] >> 16 | c[3] << 8;
+        *reinterpret_cast<u3*>(ibase + boff) = v;
+      }
+    }
   } else if (MODE == 3) {
     // dwordx3 on a 256-px-wide strip: a wave store = ONE row segment of 768 B (lane = 4 px); wave = band of 256 x 4 rows.
     // Needs W % 256 == 0 (-DW=768 -DH=400: the same 943.7 MB); grid.x = W / 256.
@@ -153,10 +180,11 @@ template <int MODE, int ARITH, int NT = 0>
 float run(A a, int B, int n) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  dim3 g(MODE == 3 ? W / 256 : W / 128, H / 96, B);
-  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<MODE, ARITH, NT>), g, dim3(256), 0, 0, a);
+  dim3 g(MODE == 3 ? W / 256 : (MODE == 4 ? 1 : W / 128), H / 96, B);
+  const dim3 blk(MODE == 4 ? 64 * (W / 128) : 256);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<MODE, ARITH, NT>), g, blk, 0, 0, a);
   hipEventRecord(e0);
-  for (int i = 0; i < n; i++) hipLaunchKernelGGL((k<MODE, ARITH, NT>), g, dim3(256), 0, 0, a);
+  for (int i = 0; i < n; i++) hipLaunchKernelGGL((k<MODE, ARITH, NT>), g, blk, 0, 0, a);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   return ms / n * 1e3f;
@@ -234,6 +262,7 @@ int main() {
     hipMalloc((void**)&b.px, bytes);
     const float s0 = run<0, 1>(b, B, 20), sx = run<0, 1, 2>(b, B, 20), l1 = run1<0>(b.px, bytes, 1, 20), l9 = run1<0>(b.px, bytes, 9, 20);
     printf("buffer %p: strips %7.1f us | strips, XCD-contiguous %7.1f us | one-shot linear 4 KB %7.1f us | 36 KB %7.1f us", (void*)b.px, s0, sx, l1, l9);
+    printf(" | full-width workgroups, XCD-contiguous: %7.1f us, with arithmetic %7.1f us", run<4, 0, 2>(b, B, 20), run<4, 1, 2>(b, B, 20));
     if (W % 256 == 0) printf(" | 128-px strips no arithmetic, XCD-contiguous %7.1f us | 256-px strips (768-byte pieces), XCD-contiguous %7.1f us", run<0, 0, 2>(b, B, 20), run<3, 0, 2>(b, B, 20));
     printf("\n");
   }
