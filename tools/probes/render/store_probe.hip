@@ -176,6 +176,62 @@ __global__ __launch_bounds__(MODE == 4 ? 64 * (W / 128) : 256) void k(A a) {
   }
 }
 
+// Work queue: resident waves take 128 x 8 bands from a per-XCD counter, in address order inside the XCD's eighth of the images
+// (image, band row, column): at any instant an XCD's waves write one compact, advancing window.  queue[8] zeroed before the launch.
+template <int ARITH>
+__global__ __launch_bounds__(256) void kq(A a, unsigned* queue, int nimg) {
+  const int lane = threadIdx.x & 63;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  const unsigned per_img = (H / 8) * (W / 128), chunk = (unsigned)((nimg + 7) / 8) * per_img;  // bands per XCD
+  // (a counter per XCD serialises: 38 400 atomics on one address = 3.5 ms.  Static round robin instead: wave s of the XCD's resident
+  //  waves takes bands s, s + S, s + 2 S, ... -- the workgroups of an XCD are those with blockIdx % 8 == its slot in the dispatch order)
+  (void)queue;
+  const unsigned S = (gridDim.x >> 3) * 4u, s0 = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);
+  xcc = blockIdx.x & 7u;
+  for (unsigned b = s0; b < chunk; b += S) {
+    const unsigned g = xcc * chunk + b, img = g / per_img, r = g % per_img;
+    if ((int)img >= nimg) break;
+    const int by = r / (W / 128), bx = r % (W / 128);
+    uint8_t* ibase = a.px + (size_t)img * H * W * 3;
+    const int px = bx * 128 + 4 * (lane & 31), prow = by * 8 + (lane >> 5);
+    unsigned boff = ((unsigned)prow * W + px) * 3u;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++, boff += 6u * W) {
+      unsigned c[4];
+      if (ARITH) {
+        const float ys = a.y0 + (float)(prow + 2 * rr) * a.dy;
+        const float ez = fmaf(ys, a.uz, a.fz), eu = fmaf(ys, a.nuy, a.nu0), ev = fmaf(ys, a.nvy, a.nv0);
+        const float iz1 = __builtin_amdgcn_rcpf(ez);
+        const bool vld = iz1 * (-a.oz) > 1e-6f;
+        const unsigned ca = vld ? a.ce : a.sky, cb = vld ? a.co : a.sky;
+#pragma unroll
+        for (int p = 0; p < 4; p++) c[p] = floor_col(a, a.x0 + (float)(px + p) * a.dx, eu, ev, iz1, ca, cb);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; p++) c[p] = a.sky + lane;
+      }
+      u3 v;
+      v.x = c[0] | c[1] << 24; v.y = c[1] >> 8 | c[2] << 16; v.z = c[2] >> 16 | c[3] << 8;
+      *reinterpret_cast<u3*>(ibase + boff) = v;
+    }
+  }
+}
+template <int ARITH>
+float runq(A a, int B, int n, int wgs) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  unsigned* q; hipMalloc((void**)&q, 32);
+  for (int i = 0; i < 3; i++) { hipMemsetAsync(q, 0, 32, 0); hipLaunchKernelGGL(kq<ARITH>, dim3(wgs), dim3(256), 0, 0, a, q, B); }
+  hipEventRecord(e0);
+  for (int i = 0; i < n; i++) { hipMemsetAsync(q, 0, 32, 0); hipLaunchKernelGGL(kq<ARITH>, dim3(wgs), dim3(256), 0, 0, a, q, B); }
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  hipFree(q);
+  return ms / n * 1e3f;
+}
+
 template <int MODE, int ARITH, int NT = 0>
 float run(A a, int B, int n) {
   hipEvent_t e0, e1;
@@ -262,6 +318,7 @@ int main() {
     hipMalloc((void**)&b.px, bytes);
     const float s0 = run<0, 1>(b, B, 20), sx = run<0, 1, 2>(b, B, 20), l1 = run1<0>(b.px, bytes, 1, 20), l9 = run1<0>(b.px, bytes, 9, 20);
     printf("buffer %p: strips %7.1f us | strips, XCD-contiguous %7.1f us | one-shot linear 4 KB %7.1f us | 36 KB %7.1f us", (void*)b.px, s0, sx, l1, l9);
+    printf(" | resident waves, bands round robin in address order per XCD (1536 / 3072 workgroups): %7.1f / %7.1f us, with arithmetic %7.1f / %7.1f us", runq<0>(b, B, 20, 1536), runq<0>(b, B, 20, 3072), runq<1>(b, B, 20, 1536), runq<1>(b, B, 20, 3072));
     printf(" | full-width workgroups, XCD-contiguous: %7.1f us, with arithmetic %7.1f us", run<4, 0, 2>(b, B, 20), run<4, 1, 2>(b, B, 20));
     if (W % 256 == 0) printf(" | 128-px strips no arithmetic, XCD-contiguous %7.1f us | 256-px strips (768-byte pieces), XCD-contiguous %7.1f us", run<0, 0, 2>(b, B, 20), run<3, 0, 2>(b, B, 20));
     printf("\n");
