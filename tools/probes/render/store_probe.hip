@@ -12,8 +12,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define W 640
 #define H 480
 #endif
+#ifndef THP
+#define THP 96 /* rows per workgroup strip (modes 0, 1, 3, 4); -DTHP=32: one band per wave */
+#endif
 
-struct A { uint8_t* px; float x0, dx, y0, dy, nu0, nux, nuy, nv0, nvx, nvy, fz, uz, oz; unsigned ce, co, sky; };
+struct A { uint8_t* px; float x0, dx, y0, dy, nu0, nux, nuy, nv0, nvx, nvy, fz, uz, oz; unsigned ce, co, sky; int th; /* rows per strip, mode 0 (0 = THP) */ };
 
 // floor colour of pixel (x, y) image-plane coords: row-constant reciprocal
 __device__ __forceinline__ unsigned floor_col(const A& a, float xs, float eu, float ev, float iz1, unsigned ca, unsigned cb) {
@@ -32,11 +35,12 @@ __global__ __launch_bounds__(MODE == 4 ? 64 * (W / 128) : 256) void k(A a) {
     const unsigned v = (id & 7u) * (T >> 3) + (id >> 3);
     bx = v % gridDim.x; by = (v / gridDim.x) % gridDim.y; bz = v / (gridDim.x * gridDim.y);
   }
-  const int tx0 = bx * 128, sy0 = by * 96, img = bz;
+  const int thr = (MODE == 0 && a.th) ? a.th : THP;
+  const int tx0 = bx * 128, sy0 = by * thr, img = bz;
   uint8_t* ibase = a.px + (size_t)img * H * W * 3;
   if (MODE == 0) {
     const int px = tx0 + 4 * (lane & 31);
-    for (int ty0 = sy0; ty0 < sy0 + 96; ty0 += 32) {
+    for (int ty0 = sy0; ty0 < sy0 + thr; ty0 += 32) {
       const int prow = ty0 + 8 * wv + (lane >> 5);
       unsigned boff = ((unsigned)prow * W + px) * 3u;
 #pragma unroll
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(MODE == 4 ? 64 * (W / 128) : 256) void k(A a) {
     const int b0 = 16 * lr;            // byte offset in the 384-B segment
     const int p0 = b0 / 3, sh = b0 % 3;  // first pixel touched, bytes of it already behind
     const int px = tx0 + p0;
-    for (int ty0 = sy0; ty0 < sy0 + 96; ty0 += 32) {
+    for (int ty0 = sy0; ty0 < sy0 + THP; ty0 += 32) {
       const int prow = ty0 + 8 * wv + rw;
       unsigned boff = ((unsigned)prow * W + tx0) * 3u + b0;
 #pragma unroll
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(MODE == 4 ? 64 * (W / 128) : 256) void k(A a) {
     // full-width workgroup: W / 128 waves side by side on the same 8 rows (wave = 128 x 8 band as in mode 0), walking down 96 rows:
     // at any time the workgroup writes 8 whole rows (launch with W / 128 * 64 threads, grid.x = 1)
     const int px = wv * 128 + 4 * (lane & 31);
-    for (int ty0 = sy0; ty0 < sy0 + 96; ty0 += 8) {
+    for (int ty0 = sy0; ty0 < sy0 + THP; ty0 += 8) {
       const int prow = ty0 + (lane >> 5);
       unsigned boff = ((unsigned)prow * W + px) * 3u;
 #pragma unroll
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(MODE == 4 ? 64 * (W / 128) : 256) void k(A a) {
     // dwordx3 on a 256-px-wide strip: a wave store = ONE row segment of 768 B (lane = 4 px); wave = band of 256 x 4 rows.
     // Needs W % 256 == 0 (-DW=768 -DH=400: the same 943.7 MB); grid.x = W / 256.
     const int px = bx * 256 + 4 * lane;
-    for (int ty0 = sy0; ty0 < sy0 + 96; ty0 += 16) {
+    for (int ty0 = sy0; ty0 < sy0 + THP; ty0 += 16) {
       const int prow = ty0 + 4 * wv;
       unsigned boff = ((unsigned)prow * W + px) * 3u;
 #pragma unroll
@@ -236,7 +240,7 @@ template <int MODE, int ARITH, int NT = 0>
 float run(A a, int B, int n) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  dim3 g(MODE == 3 ? W / 256 : (MODE == 4 ? 1 : W / 128), H / 96, B);
+  dim3 g(MODE == 3 ? W / 256 : (MODE == 4 ? 1 : W / 128), H / ((MODE == 0 && a.th) ? a.th : THP), B);
   const dim3 blk(MODE == 4 ? 64 * (W / 128) : 256);
   for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<MODE, ARITH, NT>), g, blk, 0, 0, a);
   hipEventRecord(e0);
@@ -302,6 +306,15 @@ int main() {
   a.fz = -0.496f; a.uz = 0.868f; a.oz = 2.5f; a.nu0 = 1.2f; a.nux = 0.0f; a.nuy = 3.1f; a.nv0 = 0.0f; a.nvx = 2.5f; a.nvy = 0.0f;
   a.ce = 0x00c8c8c8; a.co = 0x00505050; a.sky = 0x00e6b48c;
   const double gb = bytes / 1e9;
+  if (THP != 96) {  // strip-height variants: modes 0 and 4 only (mode 2's chunk arithmetic assumes 96 rows)
+    static_assert(H % THP == 0 && THP % 32 == 0, "strip height");
+    for (int nb = 0; nb < 3; nb++) {
+      A b = a;
+      hipMalloc((void**)&b.px, bytes);
+      printf("strips of %d rows, buffer %p: %7.1f us | XCD-contiguous %7.1f us, with arithmetic %7.1f us\n", THP, (void*)b.px, run<0, 0>(b, B, 20), run<0, 0, 2>(b, B, 20), run<0, 1, 2>(b, B, 20));
+    }
+    return 0;
+  }
 #define R(M, AR) { float us = run<M, AR>(a, B, 20); printf("mode %d arith %d: %7.1f us  %6.0f GB/s\n", M, AR, us, gb / us * 1e6); }
   R(0, 0) R(1, 0) R(2, 0) R(0, 1) R(1, 1) R(2, 1)
   if (W % 256 == 0) R(3, 0)
@@ -318,6 +331,7 @@ int main() {
     hipMalloc((void**)&b.px, bytes);
     const float s0 = run<0, 1>(b, B, 20), sx = run<0, 1, 2>(b, B, 20), l1 = run1<0>(b.px, bytes, 1, 20), l9 = run1<0>(b.px, bytes, 9, 20);
     printf("buffer %p: strips %7.1f us | strips, XCD-contiguous %7.1f us | one-shot linear 4 KB %7.1f us | 36 KB %7.1f us", (void*)b.px, s0, sx, l1, l9);
+    for (int th : {32, 96, 160, 480}) { A c = b; c.th = th; printf(" | %d-row strips XCD-contiguous %7.1f us", th, run<0, 1, 2>(c, B, 20)); }
     printf(" | resident waves, bands round robin in address order per XCD (1536 / 3072 workgroups): %7.1f / %7.1f us, with arithmetic %7.1f / %7.1f us", runq<0>(b, B, 20, 1536), runq<0>(b, B, 20, 3072), runq<1>(b, B, 20, 1536), runq<1>(b, B, 20, 3072));
     printf(" | full-width workgroups, XCD-contiguous: %7.1f us, with arithmetic %7.1f us", run<4, 0, 2>(b, B, 20), run<4, 1, 2>(b, B, 20));
     if (W % 256 == 0) printf(" | 128-px strips no arithmetic, XCD-contiguous %7.1f us | 256-px strips (768-byte pieces), XCD-contiguous %7.1f us", run<0, 0, 2>(b, B, 20), run<3, 0, 2>(b, B, 20));
