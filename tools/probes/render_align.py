@@ -27,10 +27,10 @@ for _ in range(200): task.cam.render_envs(out=warm)
 print("first buffer %x: %.1f us" % (warm.data_ptr(), t(warm)))
 pool = torch.empty(N + (64 << 20), dtype=torch.uint8, device=dev)
 print("pool base %x" % pool.data_ptr())
-for rep in range(2):
+for rep in range(1):
     for off in (0, 256, 1024, 4096, 8192, 32768, 65536, 1 << 20, (2 << 20) + 4096, 16 << 20, (32 << 20) + 12288):
         out = pool[off:off + N].view(B, H, W, 3)
         print("offset %9d: %.1f us" % (off, t(out)))
-bufs = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(4)]
+bufs = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4)]
 for b in bufs: print("separate buffer %x: %.1f us" % (b.data_ptr(), t(b)))
 print("first buffer again: %.1f us" % t(warm))
