@@ -35,6 +35,12 @@ __global__ __launch_bounds__(MODE == 4 ? 64 * (W / 128) : 256) void k(A a) {
     const unsigned v = (id & 7u) * (T >> 3) + (id >> 3);
     bx = v % gridDim.x; by = (v / gridDim.x) % gridDim.y; bz = v / (gridDim.x * gridDim.y);
   }
+  if (NT == 3) {  // image-interleaved: XCD j takes the images j, j + 8, j + 16, ... in order (streams one image apart, not one eighth apart)
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), S = gridDim.x * gridDim.y;
+    const unsigned j = id & 7u, k = id >> 3, img = (k / S) * 8u + j, st = k % S;
+    bx = st % gridDim.x; by = st / gridDim.x; bz = img;
+    if (bz >= (int)gridDim.z) return;
+  }
   const int thr = (MODE == 0 && a.th) ? a.th : THP;
   const int tx0 = bx * 128, sy0 = by * thr, img = bz;
   uint8_t* ibase = a.px + (size_t)img * H * W * 3;
@@ -331,6 +337,7 @@ int main() {
     hipMalloc((void**)&b.px, bytes);
     const float s0 = run<0, 1>(b, B, 20), sx = run<0, 1, 2>(b, B, 20), l1 = run1<0>(b.px, bytes, 1, 20), l9 = run1<0>(b.px, bytes, 9, 20);
     printf("buffer %p: strips %7.1f us | strips, XCD-contiguous %7.1f us | one-shot linear 4 KB %7.1f us | 36 KB %7.1f us", (void*)b.px, s0, sx, l1, l9);
+    printf(" | strips, XCD takes every eighth IMAGE %7.1f us", run<0, 1, 3>(b, B, 20));
     for (int th : {32, 96, 160, 480}) { A c = b; c.th = th; printf(" | %d-row strips XCD-contiguous %7.1f us", th, run<0, 1, 2>(c, B, 20)); }
     printf(" | resident waves, bands round robin in address order per XCD (1536 / 3072 workgroups): %7.1f / %7.1f us, with arithmetic %7.1f / %7.1f us", runq<0>(b, B, 20, 1536), runq<0>(b, B, 20, 3072), runq<1>(b, B, 20, 1536), runq<1>(b, B, 20, 3072));
     printf(" | full-width workgroups, XCD-contiguous: %7.1f us, with arithmetic %7.1f us", run<4, 0, 2>(b, B, 20), run<4, 1, 2>(b, B, 20));
