@@ -162,6 +162,27 @@ class StepHelpers:
             raise ValueError(f"action must have shape {(self.num_envs, dim)}, got {tuple(action.shape)}")
         return action
 
+    def stage_action(self, action, dim: int) -> int:
+        """Address of a (B, dim) float32 copy of a HOST action (NumPy array, list, CPU tensor) in pinned memory that the next step
+        launch reads IN PLACE over PCIe (147 KB for 4096 x 9: one more read in the kernel's first batch of loads) -- no copy
+        command, no device allocation.  `GenesisEnv.step(env.action_space.sample())` is how the reference is driven
+        (reference env.py:61); a pageable array sent through `tensor.to(device)` costs ~25 us per step.  Two buffers take turns:
+        a buffer is rewritten two steps later, and a step is closed (mir_step_end: the launch has read its action long before
+        its terminated bytes leave) before the next one begins.  Only for the begin / end step path (fast_step)."""
+        a = np.asarray(action.numpy() if isinstance(action, torch.Tensor) else action, dtype=np.float32)
+        if a.shape != (self.num_envs, dim):
+            raise ValueError(f"action must have shape {(self.num_envs, dim)}, got {tuple(a.shape)}")
+        ring = self.__dict__.get("_act_stage")
+        if ring is None or ring["dim"] != dim:
+            bufs = [torch.empty((self.num_envs, dim), dtype=torch.float32) for _ in range(2)]
+            if torch.device(self.device).type == "cuda":  # (the CPU test double reads the same address from plain memory)
+                bufs = [b.pin_memory() for b in bufs]
+            ring = self._act_stage = {"dim": dim, "np": [b.numpy() for b in bufs], "ptr": [b.data_ptr() for b in bufs], "bufs": bufs, "k": 0}
+        k = ring["k"]
+        ring["k"] = k ^ 1
+        np.copyto(ring["np"][k], a)
+        return ring["ptr"][k]
+
     def use_output_ring(self, steps: int, agent_dim: int, env_dim: int) -> torch.Tensor:
         """From now on the outputs of consecutive steps are consecutive ROWS of one preallocated (steps, B * (agent + env + 1)) float32
         buffer (row = [agent_pos (B, a) | environment_state (B, e) | reward (B)] of one step) instead of fresh allocations: the

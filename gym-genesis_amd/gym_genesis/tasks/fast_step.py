@@ -19,6 +19,7 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
     `coerce(action)` (optional) is the task's own pre-processing of an action that is not already a (B, action_dim) float32
     device tensor (e.g. the SO-101 tasks' reshape)."""
     go, prepare, alloc, end, as_action = mir.step_go_ptr, mir.step_prepare_ptrs, mir._alloc_outputs, mir.step_end_ptr, mir.as_action
+    stage = mir.stage_action  # host actions (NumPy, lists, CPU tensors): read by the launch in place from pinned memory
     B, dev, tensor, f32, tbool = task.num_envs, task.device, torch.Tensor, torch.float32, torch.bool
     shape = torch.Size((B, action_dim))
     np_empty, np_zeros, np_bool = np.empty, np.zeros, np.bool_
@@ -33,12 +34,17 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
                 and action.device == dev):
             if coerce is not None:
                 action = coerce(action)
-            action = as_action(action, action_dim)
+            if type(action) is tensor and action.device == dev:
+                aptr = as_action(action, action_dim).data_ptr()
+            else:
+                aptr = stage(action, action_dim)
+        else:
+            aptr = action.data_ptr()
         slot = fresh.pop(key, None)
         if slot is None:
             slot = alloc(agent_obs, env_obs)
             prepare(slot[1])
-        go(action.data_ptr())
+        go(aptr)
         # ---- the kernel is running: nothing below is on the critical path until end()
         try:
             outs = slot[0]
@@ -74,7 +80,13 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
                 and action.device == dev):
             if coerce is not None:
                 action = coerce(action)
-            action = as_action(action, action_dim)
+            if type(action) is tensor and action.device == dev:
+                action = as_action(action, action_dim)
+                aptr = action.data_ptr()
+            else:
+                aptr = stage(action, action_dim)
+        else:
+            aptr = action.data_ptr()
         h = hbox[0]
         slot = fresh.pop(key, None)
         if slot is None:
@@ -83,7 +95,7 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
             rc = fprepare(h, p[0], p[1], p[2], p[3])
             if rc:
                 check(rc)
-        rc = fgo(h, action.data_ptr(), raw_stream(devidx))
+        rc = fgo(h, aptr, raw_stream(devidx))
         if rc:
             check(rc)
         # ---- the kernel is running

@@ -463,3 +463,34 @@ def test_early_terminated_bytes_equal_the_integrated_mask(franka_spec, monkeypat
     assert early > 0.3 * 4 * 60 * (B // 4)   # (workgroup-launches that sent early; the rest converge at the first gradient and store after the integrator)
     for x, y in zip(sc.get_state(), ref.get_state()):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("robot", ["franka", "so101"])
+def test_numpy_actions_are_read_in_place_and_equal_device_actions(robot):
+    """GenesisEnv.step(numpy array) -- how the reference is driven (env.py:61, action_space.sample()) -- stages the action in pinned
+    memory that the launch reads in place (MirScene.stage_action).  Same trajectory, bit for bit, as the same actions given as device
+    tensors; the caller may scribble over its array as soon as step() returns; lists and CPU tensors take the same route."""
+    from gym_genesis.env import GenesisEnv
+
+    B = 256
+    a = GenesisEnv(task="cube_pick", robot=robot, num_envs=B)
+    b = GenesisEnv(task="cube_pick", robot=robot, num_envs=B)
+    a.reset(seed=3)
+    b.reset(seed=3)
+    dim = a.action_space.shape[-1]
+    rng = np.random.default_rng(9)
+    for t in range(40):
+        act = rng.uniform(-1, 1, (B, dim)).astype(np.float32)
+        if robot == "so101" and t % 2:
+            act = act.astype(np.float64)  # (any dtype NumPy converts)
+        dev_act = torch.as_tensor(act.astype(np.float32), device=a._env.device)
+        host_in = act.copy() if t % 3 else (torch.from_numpy(act.astype(np.float32)) if t % 2 else act.tolist())
+        oa, ra, ta, _, _ = a.step(host_in)
+        if isinstance(host_in, np.ndarray):
+            host_in[:] = 123.0  # the step has its own copy
+        ob, rb, tb, _, _ = b.step(dev_act)
+        assert np.array_equal(ta, tb)
+        assert torch.equal(ra, rb) and torch.equal(oa["agent_pos"], ob["agent_pos"]) and torch.equal(oa["environment_state"], ob["environment_state"]), f"step {t}"
+    with pytest.raises((ValueError, RuntimeError)):  # (the SO-101 task reshapes first: torch's error)
+        a.step(np.zeros((B, dim + 1), np.float32))
+    a.step(np.zeros((B, dim), np.float32))  # (the env stays usable)
