@@ -1147,12 +1147,14 @@ def secondary_rates(torch, dev, env, task, actions, B):
     n = 200
     env.reset(seed=0)
     acts_np = np.random.default_rng(5).uniform(-1, 1, (8, B, 9)).astype(np.float32)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for t in range(n):
+    for t in range(50):  # (the first call pins the two staging buffers: milliseconds)
         env.step(acts_np[t % 8])
     torch.cuda.synchronize(dev)
-    res["env_step_api_numpy_actions_rate"] = n * B / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for t in range(5 * n):
+        env.step(acts_np[t % 8])
+    torch.cuda.synchronize(dev)
+    res["env_step_api_numpy_actions_rate"] = 5 * n * B / (time.perf_counter() - t0)
 
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
