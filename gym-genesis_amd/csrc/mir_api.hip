@@ -479,6 +479,7 @@ int mir_destroy(MirHandle h) {
   if (h->prims) (void)hipFree(h->prims);
   if (h->cost) (void)hipFree(h->cost);
   if (h->bins) (void)hipFree(h->bins);
+  if (h->zbuf) (void)hipFree(h->zbuf);
   if (h->done_ticket) (void)hipFree(h->done_ticket);
   if (h->scratch_row) (void)hipFree(h->scratch_row);
   if (h->pre) (void)hipFree(h->pre);
