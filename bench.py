@@ -427,7 +427,24 @@ def pixels_bench(torch, dev, renders: int = 100):
     us_small = ev0.elapsed_time(ev1) * 1e3 / renders
     del small, env
     torch.cuda.empty_cache()
+    # the registry's DEFAULT pixel mode (camera_capture_mode="global", reference __init__.py:16; also GenesisEnv.render()): one 480x640
+    # image of all 4096 envs at their grid offsets
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=ENVS_PER_GPU, enable_pixels=True, observation_height=H, observation_width=W,
+                     camera_capture_mode="global")
+    env.reset(seed=0)
+    for _ in range(10):
+        env._env.cam.render_global()
+    torch.cuda.synchronize(dev)
+    ev0.record()
+    for _ in range(renders):
+        env._env.cam.render_global()
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us_global = ev0.elapsed_time(ev1) * 1e3 / renders
+    del env
+    torch.cuda.empty_cache()
     return {"workload": "CubePick-v0 robot=franka enable_pixels=True per_env 480x640 RGB8, num_envs=1024 (BASELINE configs[4])",
+            "global_view_480x640_num_envs_4096_us_per_render": us_global,
             "env_frames_per_s": B / (us * 1e-6), "us_per_render": us, "us_per_render_regions": regions, "fill_us_same_buffer": fill_us, "host_enqueue_us_per_render": sorted(host)[1], "dtype": "u8 out / f32 rays",
             "reduced_96x128_num_envs_4096": {"env_frames_per_s": Bs / (us_small * 1e-6), "us_per_render": us_small,
                                              "GBps": Bs * Hs * Ws * 3 / (us_small * 1e-6) / 1e9},
