@@ -44,17 +44,24 @@ class CubeStackBatch(StackTaskBase):
 
     def _wrist_camera(self):
         # camera frame = gripper rotation * Rx(-pi/2 + 0.8), at gripper pos + (0.09, 0, -0.08); an OpenGL camera looks
-        # along its -z with +y up; the image is then rotated by 180 degrees (:199-213)
-        pos = self.eef.get_pos() + torch.tensor([0.09, 0.0, -0.08], device=self.device)
-        w, x, y, z = self.eef.get_quat().unbind(1)
-        R = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], 1),
-                         torch.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], 1),
-                         torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1)], 1)  # (B,3,3)
-        a = -math.pi / 2 + 0.8
-        Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, math.cos(a), -math.sin(a)], [0.0, math.sin(a), math.cos(a)]], device=self.device)
-        Rc = R @ Rx
-        fwd, up = -Rc[:, :, 2], Rc[:, :, 1]
-        return pos, pos + fwd, up.contiguous(), True
+        # along its -z with +y up; the image is then rotated by 180 degrees (:199-213).  A camera rolled by 180 degrees about its
+        # view axis (up -> -up) draws exactly that rotated image, so there is no flip of 236 MB afterwards; the view direction and
+        # the up vector are the gripper's rotation of two constant vectors (one FK read, two cross products for both).
+        c = self.__dict__.get("_wrist_const")
+        if c is None:
+            a = -math.pi / 2 + 0.8
+            c = self._wrist_const = (torch.tensor([0.09, 0.0, -0.08], device=self.device),
+                                     torch.tensor([[[0.0, math.sin(a), -math.cos(a)],       # -Rx[:, 2]: the view direction
+                                                    [0.0, -math.cos(a), -math.sin(a)]]],   # -Rx[:, 1]: up, rolled by 180 degrees
+                                                  device=self.device))
+        xpos, xquat = self._mir.get_links()
+        q = xquat[:, self.eef.idx, :]
+        pos = xpos[:, self.eef.idx, :] + c[0]
+        w, u = q[:, :1].unsqueeze(1), q[:, 1:].unsqueeze(1).expand(-1, 2, -1)
+        v = c[1].expand_as(u)
+        t = 2.0 * torch.cross(u, v, dim=2)
+        d = v + w * t + torch.cross(u, t, dim=2)  # (B, 2, 3): q v q*
+        return pos, pos + d[:, 0], d[:, 1].contiguous(), False
 
     def _scene_builder(self):
         return models.so101_cube_stack_scene()
