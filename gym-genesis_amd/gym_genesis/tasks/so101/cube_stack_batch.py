@@ -77,16 +77,27 @@ class CubeStackBatch(StackTaskBase):
     def sample_spawn(self) -> np.ndarray:
         Bg, r = self.global_num_envs, self._random
         z = self.island_top_z + 0.02 + 0.001
-        p1, p2 = np.zeros((Bg, 3)), np.zeros((Bg, 3))
-        for e in range(Bg):  # rejection sampling, scalar draws (:72-86)
-            while True:
-                x1 = r.uniform(-0.3, -0.1)
-                y1 = r.uniform(-0.1, 0.1)
-                x2 = r.uniform(-0.3, -0.1)
-                y2 = r.uniform(-0.1, 0.1)
-                if ((x2 - x1) ** 2 + (y2 - y1) ** 2) ** 0.5 >= 0.06:
-                    p1[e], p2[e] = (x1, y1, z), (x2, y2, z)
-                    break
+        # Rejection sampling, four scalar draws per attempt (:72-86): x1, y1, x2, y2, accepted when the two cubes are 6 cm apart.
+        # An attempt consumes four doubles of the stream whatever its outcome, so attempt i IS draws 4 i .. 4 i + 3 and env e takes the
+        # e-th accepted attempt: the attempts are drawn and judged as arrays, and the stream is then put where the scalar loop would
+        # have left it (rewind, draw exactly what it consumed).  Same positions, same stream afterwards
+        # (tests/test_host_cpu.py), 16 ms -> 0.3 ms per reset at 4096 envs.
+        state = r.get_state()
+        m = Bg + Bg // 4 + 64
+        while True:
+            u = r.random_sample(4 * m).reshape(m, 4)
+            x1, y1 = -0.3 + (-0.1 - -0.3) * u[:, 0], -0.1 + (0.1 - -0.1) * u[:, 1]  # uniform(low, high) = low + (high - low) * sample
+            x2, y2 = -0.3 + (-0.1 - -0.3) * u[:, 2], -0.1 + (0.1 - -0.1) * u[:, 3]
+            ok = np.flatnonzero(np.power((x2 - x1) ** 2 + (y2 - y1) ** 2, 0.5) >= 0.06)
+            if len(ok) >= Bg:
+                break
+            r.set_state(state)
+            m *= 2
+        ok = ok[:Bg]
+        r.set_state(state)
+        r.random_sample(4 * (int(ok[-1]) + 1))
+        p1 = np.stack([x1[ok], y1[ok], np.full(Bg, z)], axis=1)
+        p2 = np.stack([x2[ok], y2[ok], np.full(Bg, z)], axis=1)
         cols = [p1, p2]
         for _ in range(3):  # distractors (:97-103)
             x = r.uniform(-0.35, 0.0, size=(Bg,))

@@ -310,3 +310,40 @@ def test_so101_pick_contract(monkeypatch):
     obs, reward, terminated, truncated, info = env.step(np.zeros((2, 6), np.float32))
     assert terminated.all() and (reward == 1).all()  # cube z ~0.72 > 0.1: the reference's threshold fires at once (:112)
     assert env.get_robot() is env._env.so_101 and env.get_cube() is env._env.cube
+
+
+def test_so101_stack_spawn_sampling_equals_the_scalar_rejection_loop():
+    """tasks/so101/cube_stack_batch.py draws the rejection-sampled cube pairs as arrays; positions and the state of the stream
+    afterwards must be those of the reference's scalar loop (cube_stack_batch.py:72-103)."""
+    import types
+
+    import numpy as np
+
+    from gym_genesis.tasks.so101.cube_stack_batch import CubeStackBatch as SO101CubeStackBatch
+
+    def scalar(Bg, r, z):
+        p1, p2 = np.zeros((Bg, 3)), np.zeros((Bg, 3))
+        for e in range(Bg):
+            while True:
+                x1 = r.uniform(-0.3, -0.1)
+                y1 = r.uniform(-0.1, 0.1)
+                x2 = r.uniform(-0.3, -0.1)
+                y2 = r.uniform(-0.1, 0.1)
+                if ((x2 - x1) ** 2 + (y2 - y1) ** 2) ** 0.5 >= 0.06:
+                    p1[e], p2[e] = (x1, y1, z), (x2, y2, z)
+                    break
+        cols = [p1, p2]
+        for _ in range(3):
+            x = r.uniform(-0.35, 0.0, size=(Bg,))
+            y = r.uniform(-0.2, 0.2, size=(Bg,))
+            cols.append(np.stack([x, y, np.full(Bg, z)], axis=1))
+        return np.stack(cols, axis=1).astype(np.float32)
+
+    for seed, Bg in ((0, 1), (1, 7), (2, 300), (3, 2048)):
+        ra, rb = np.random.RandomState(seed), np.random.RandomState(seed)
+        stub = types.SimpleNamespace(global_num_envs=Bg, _random=ra, island_top_z=0.7)
+        for _ in range(3):  # consecutive resets continue one stream
+            got = SO101CubeStackBatch.sample_spawn(stub)
+            want = scalar(Bg, rb, 0.7 + 0.02 + 0.001)
+            assert got.shape == (Bg, 5, 3) and np.array_equal(got, want)
+        assert ra.random_sample() == rb.random_sample()
