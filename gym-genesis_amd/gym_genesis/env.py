@@ -60,10 +60,12 @@ class GenesisEnv(Env):
         self.action_space = self._env.action_space
         self.scene = None
         # the two halves of the fast step path, looked up once (they sit in front of every launch, where the GPU idles)
-        fast = hasattr(self._env, "step_begin") and not self.enable_pixels and not getattr(self._env, "unbatched", False)
+        # (with pixels too: the renders of the observation are queued behind the step launch, and step_end() waits for that launch's
+        #  terminated bytes only -- not, as a `.cpu()` of the mask would, for the images)
+        fast = hasattr(self._env, "step_begin") and not getattr(self._env, "unbatched", False)
         self._begin = self._env.step_begin if fast else None
         self._end = self._env.step_end if fast else None
-        if fast and hasattr(self._env, "make_fast_step"):
+        if fast and not self.enable_pixels and hasattr(self._env, "make_fast_step"):
             # the state-only batched tasks supply the whole of step() as one flat function; bound on the instance, so
             # `env.step(a)` calls it without passing through this class's method
             self.step = self._env.make_fast_step()
