@@ -219,7 +219,7 @@ class StepHelpers:
         return outs, (base, base + 4 * agent_dim * B, base + 4 * (agent_dim + env_dim) * B, term.data_ptr())
 
     def step_fresh(self, action, agent_dim: int, env_dim: int, host_terminated: bool = False):
-        """One fused step into FRESH output tensors (callers may keep old observations, as with the reference):
+        """(`action`: anything as_action / stage_action accept.)  One fused step into FRESH output tensors (callers may keep old observations, as with the reference):
         returns (agent_pos, environment_state, reward, terminated u8).  With host_terminated the launch also delivers the
         terminated bytes to the host (step_begin); the caller must then close the step with step_end().
         The GPU idles while Python prepares a launch, so nothing that can wait is done before it: the output tensors of the
@@ -236,11 +236,14 @@ class StepHelpers:
                 self.step_prepare_ptrs(slot[1])
         outs, ptrs = slot
         if host_terminated:
-            self.step_go_ptr(action.data_ptr())
+            # (a HOST action -- NumPy, list, CPU tensor -- is staged in pinned memory and read in place: stage_action; the step is
+            #  closed by step_end() before the buffer comes round again)
+            on_dev = type(action) is torch.Tensor and action.device == torch.device(self.device)
+            self.step_go_ptr(self.as_action(action, self.nu).data_ptr() if on_dev else self.stage_action(action, self.nu))
             host = np.empty(self.num_envs, dtype=np.bool_)
             self._host_pending = (host, host.ctypes.data)
         else:
-            self.step_fused_ptrs(action.data_ptr(), ptrs)
+            self.step_fused_ptrs(self.as_action(action, self.nu).data_ptr(), ptrs)
         nxt = self._alloc_outputs(agent_dim, env_dim)  # (while the kernel runs)
         if host_terminated:
             self.step_prepare_ptrs(nxt[1])

@@ -185,14 +185,14 @@ class FrankaCubePickBatch:
     def step(self, action):
         # fresh output tensors per call, like the reference (callers may keep old observations)
         mir = self._mir
-        self._agent, self._envst, self._reward, self._term = mir.step_fresh(mir.as_action(action, AGENT_DIM), AGENT_DIM, ENV_DIM)
+        self._agent, self._envst, self._reward, self._term = mir.step_fresh(action, AGENT_DIM, ENV_DIM)
         return None, self._reward, None, self._pack_obs()
 
     def step_begin(self, action):
         """step() for GenesisEnv.step: the same launch also delivers `terminated` to the host; GenesisEnv prepares its other
         return values while the kernel runs and then collects the mask with step_end()."""
         mir = self._mir
-        self._agent, self._envst, self._reward, self._term = mir.step_fresh(mir.as_action(action, AGENT_DIM), AGENT_DIM, ENV_DIM,
+        self._agent, self._envst, self._reward, self._term = mir.step_fresh(action, AGENT_DIM, ENV_DIM,
                                                                             host_terminated=True)
         return None, self._reward, None, self._pack_obs()
 

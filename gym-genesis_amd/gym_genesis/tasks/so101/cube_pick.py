@@ -116,8 +116,8 @@ class CubePick:
         mir = self._mir
         if not isinstance(action, torch.Tensor):
             action = torch.as_tensor(np.asarray(action))
-        a = mir.as_action(action.reshape(self.num_envs, AGENT_DIM), AGENT_DIM)
-        self._agent, self._envst, self._reward, self._term = mir.step_fresh(a, AGENT_OBS, ENV_OBS, host_terminated=host_terminated)
+        self._agent, self._envst, self._reward, self._term = mir.step_fresh(action.reshape(self.num_envs, AGENT_DIM), AGENT_OBS, ENV_OBS,
+                                                                            host_terminated=host_terminated)
         return None, self._reward, None, self._pack_obs()
 
     def step_begin(self, action):

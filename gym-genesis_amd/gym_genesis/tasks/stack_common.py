@@ -152,7 +152,7 @@ class StackTaskBase:
 
     def step(self, action, host_terminated: bool = False):
         mir = self._mir
-        self._agent, self._envst, self._reward, self._term = mir.step_fresh(mir.as_action(action, self.AGENT_DIM), mir.agent_dim, ENV_OBS,
+        self._agent, self._envst, self._reward, self._term = mir.step_fresh(action, mir.agent_dim, ENV_OBS,
                                                                             host_terminated=host_terminated)
         return None, self._reward, None, self._pack_obs()
 
