@@ -133,7 +133,7 @@ class CubePick:
 
         def coerce(action):
             if not isinstance(action, torch.Tensor):
-                action = torch.as_tensor(np.asarray(action))
+                return np.asarray(action).reshape(self.num_envs, AGENT_DIM)  # (stays NumPy: staged in pinned memory by the step)
             return action.reshape(self.num_envs, AGENT_DIM)
 
         return make_fast_step(self, self._mir, AGENT_DIM, AGENT_OBS, ENV_OBS, coerce)
