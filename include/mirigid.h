@@ -233,7 +233,9 @@ int mir_step(MirHandle h, int32_t n_steps, void* stream);
  * targets <- action (B,nu); one physics step; agent_pos (B,agent_dim) = [eef_pos3, eef_quat4, grip_q]
  * (MIR_AGENT_EEF) or the scalar-joint qpos (MIR_AGENT_QPOS); env_state (B,env_dim) = [obj_pos3, obj_quat4,
  * eef-obj 3, |eef-obj| 1] (+ obj2_pos3 when task.obj2_body >= 0); reward (B) f32 by task.reward_mode;
- * terminated (B) u8 = reward == 1.  action may be NULL (keep current targets). */
+ * terminated (B) u8 = reward == 1.  action may be NULL (keep current targets).  action is read once, by the launch, with its first
+ * loads: it may also point into pinned host memory (hipHostMalloc / a pinned torch tensor), which the kernel then reads in place
+ * over PCIe -- the buffer must stay untouched until the launch has started (mir_step_end of the same step has returned). */
 int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward,
                    uint8_t* terminated, void* stream);
 
