@@ -465,16 +465,16 @@ def test_early_terminated_bytes_equal_the_integrated_mask(franka_spec, monkeypat
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("robot", ["franka", "so101"])
-def test_numpy_actions_are_read_in_place_and_equal_device_actions(robot):
+@pytest.mark.parametrize("task,robot", [("cube_pick", "franka"), ("cube_pick", "so101"), ("cube_stack", "franka"), ("cube_stack", "so101")])
+def test_numpy_actions_are_read_in_place_and_equal_device_actions(task, robot):
     """GenesisEnv.step(numpy array) -- how the reference is driven (env.py:61, action_space.sample()) -- stages the action in pinned
     memory that the launch reads in place (MirScene.stage_action).  Same trajectory, bit for bit, as the same actions given as device
     tensors; the caller may scribble over its array as soon as step() returns; lists and CPU tensors take the same route."""
     from gym_genesis.env import GenesisEnv
 
     B = 256
-    a = GenesisEnv(task="cube_pick", robot=robot, num_envs=B)
-    b = GenesisEnv(task="cube_pick", robot=robot, num_envs=B)
+    a = GenesisEnv(task=task, robot=robot, num_envs=B)
+    b = GenesisEnv(task=task, robot=robot, num_envs=B)
     a.reset(seed=3)
     b.reset(seed=3)
     dim = a.action_space.shape[-1]
