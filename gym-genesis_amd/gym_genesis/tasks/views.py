@@ -139,7 +139,15 @@ class CameraView:
             self.lookat = tuple(float(v) for v in np.asarray(lookat).ravel())
 
     def _spec(self, pos, lookat):
-        return self._make(self.res[0], self.res[1], pos, lookat, self.fov, self._up)
+        # (the ctypes struct of a pose is built once: the observation renders ask for the same few poses every step)
+        key = (tuple(pos), tuple(lookat))
+        cache = self.__dict__.setdefault("_specs", {})
+        spec = cache.get(key)
+        if spec is None:
+            if len(cache) > 64:
+                cache.clear()
+            spec = cache[key] = self._make(self.res[0], self.res[1], pos, lookat, self.fov, self._up)
+        return spec
 
     def render_global(self) -> torch.Tensor:
         """(H, W, 3) uint8 device tensor: every env at its grid offset, camera at its current pose."""
