@@ -197,6 +197,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
   // link poses of its final state in h->poses -- its closing forward kinematics has them -- so that a render behind a step needs
   // no pose-refresh launch (6 us per 1024 envs).  poses_current: h->poses matches qpos for every env.
   const bool integrates = o.mode == 0 && o.phase != 1;
+  if (integrates) h->state_version++;
   const bool wr_poses = o.poses || (h->poses_live && integrates);
   if (o.mode == 2 && o.poses) h->poses_current = 1;
   else if (integrates) h->poses_current = (h->kernel == 64 || wr_poses) && !o.ar.episode_len;  // (an in-kernel reset moves envs after the closing FK)
@@ -513,6 +514,7 @@ int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const fl
   if (int rc = check_mask(h)) return rc;
   h->pre_valid = 0;
   h->poses_current = 0;
+  h->state_version++;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_reset, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, obj_pos, obj_quat, arm_qpos, env_mask, h->fkvalid, h->B);
@@ -526,6 +528,7 @@ int mir_autoreset(MirHandle h, const uint8_t* terminated, int32_t* episode_len, 
   if (!episode_len || !spawn_pool || !cursor || !obj_quat || !arm_qpos || pool_len <= 0) return set_err(MIR_E_INVALID, "mir_autoreset: null argument");
   h->pre_valid = 0;
   h->poses_current = 0;
+  h->state_version++;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_autoreset, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, terminated, episode_len, max_len, spawn_pool, pool_len, cursor, obj_quat, arm_qpos, truncated_out, done_out,
@@ -817,6 +820,8 @@ int mir_debug_raise_mask_flag(MirHandle h) {
   *reinterpret_cast<volatile uint32_t*>(h->pin_host + h->pin_flag_off + 16) = 1u;
   return MIR_OK;
 }
+int mir_get_state_version(MirHandle h) { return h ? (int)(h->state_version & 0x7fffffffull) : MIR_E_INVALID; }
+
 int mir_get_early_mask(MirHandle h) { return check(h) ? MIR_E_INVALID : (h->no_early_mask ? 0 : 1); }
 
 int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream) {
@@ -1031,6 +1036,7 @@ int mir_set_state(MirHandle h, const float* qpos, const float* qvel, const float
   if (check(h)) return MIR_E_INVALID;
   h->pre_valid = 0;
   h->poses_current = 0;
+  h->state_version++;
   DeviceGuard guard(h->device);
   hipLaunchKernelGGL(k_copy_state, dim3(nblk((long)h->B * PW)), dim3(TPB), 0, (hipStream_t)stream, h->dpt, h->qpos, h->qvel, h->target,
                      h->qacc_ws, (float*)qpos, (float*)qvel, (float*)target, (float*)warmstart, h->fkvalid, h->B, 1);

@@ -96,6 +96,8 @@ def load_library() -> C.CDLL:
     lib.mir_debug_raise_mask_flag.restype = C.c_int
     lib.mir_get_early_mask.argtypes = [vp]
     lib.mir_get_early_mask.restype = C.c_int
+    lib.mir_get_state_version.argtypes = [vp]
+    lib.mir_get_state_version.restype = C.c_int
     lib.mir_render.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), i32, vp, vp, vp]
     lib.mir_render.restype = C.c_int
     lib.mir_visual_sizeof.restype = C.c_int
@@ -569,6 +571,11 @@ class MirScene(StepHelpers):
     def early_mask(self) -> bool:
         """True while mir_step_begin launches may send their terminated bytes early (mir_get_early_mask)."""
         return bool(self.lib.mir_get_early_mask(self.h))
+
+    @property
+    def state_version(self) -> int:
+        """mir_get_state_version: advances with every call that moves the bodies (steps, resets, state writes)."""
+        return int(self.lib.mir_get_state_version(self.h))
 
     def debug_render_path(self, generic: bool = False, strip_rows: int = 0) -> None:
         """mir_debug_render_path: force the generic pixel kernel / override the strip height for the following renders."""

@@ -151,7 +151,9 @@ class CameraView:
 
     def render_global(self) -> torch.Tensor:
         """(H, W, 3) uint8 device tensor: every env at its grid offset, camera at its current pose."""
-        return self._mir.render(self._spec(self.pos, self.lookat), self._vis, mode=1, env_offset=self._offsets)
+        img = self._mir.render(self._spec(self.pos, self.lookat), self._vis, mode=1, env_offset=self._offsets)
+        self._last_global = (getattr(self._mir, "state_version", None), self.pos, self.lookat, img)
+        return img
 
     def render_envs(self, pos=None, lookat=None, out=None) -> torch.Tensor:
         """(B, H, W, 3) uint8 device tensor: env i alone, seen from `pos` -> `lookat` relative to the env's origin
@@ -167,7 +169,12 @@ class CameraView:
     def render(self, rgb=True, depth=False, segmentation=False, normal=False):
         if depth or segmentation or normal:
             raise NotImplementedError("only the rgb output of cam.render() is on the reference's path (env.py:98)")
-        return self.render_global().cpu().numpy(), None, None, None
+        # (the reference's README loop calls env.render() right behind an env.step() whose pixels observation IS this image: nothing has
+        #  moved since -- mir_get_state_version -- so it is copied out, not drawn again; the caller gets a fresh array either way)
+        last = self.__dict__.get("_last_global")
+        ver = getattr(self._mir, "state_version", None)
+        img = last[3] if last is not None and ver is not None and last[:3] == (ver, self.pos, self.lookat) else self.render_global()
+        return img.cpu().numpy(), None, None, None
 
     def start_recording(self) -> None:  # cube_stack_kitchen_batch.py:111-113; video encoding is out of scope
         self._recording = True

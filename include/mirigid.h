@@ -385,6 +385,11 @@ int mir_visual_sizeof(void);
  * Link poses: from the first render on, every call that advances the state also leaves the link poses of its final state for the
  * rasteriser, and a render queued behind it (same stream order as the calls that touched the state, as for every call on a handle)
  * launches no forward kinematics of its own; behind mir_reset / mir_autoreset / mir_set_state it does. */
+/* A counter that every call which changes the positions of the bodies advances (steps, resets, state writes): two reads that return
+ * the same value bracket calls that left the scene as it was -- an image rendered in between is still the image of the scene.
+ * (>= 0: the counter modulo 2^31.) */
+int mir_get_state_version(MirHandle h);
+
 int mir_render(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* vis, int32_t mode, const float* env_offset,
                uint8_t* pixels, void* stream);
 

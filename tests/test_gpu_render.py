@@ -409,3 +409,36 @@ def test_camera_rolled_by_180_degrees_draws_the_rotated_image():
     diff = (r != torch.flip(a, dims=(1, 2))).any(dim=-1).float().mean().item()
     assert diff <= 1e-4, f"{diff:.2e} of the pixels differ between the rolled camera and the flipped image"
     assert len(torch.unique(a.reshape(-1, 3), dim=0)) > 4
+
+
+def test_render_reuses_the_observation_image_only_while_nothing_has_moved():
+    """GenesisEnv.render() behind an env.step() with global pixels copies out the image the observation holds (mir_get_state_version
+    says nothing moved); after a step, a reset, a state write or a camera move it draws again."""
+    from gym_genesis.env import GenesisEnv
+
+    B = 64
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, observation_height=120, observation_width=160,
+                     camera_capture_mode="global")
+    obs, _ = env.reset(seed=0)
+    mir, cam = env._env._mir, env._env.cam
+    v0 = mir.state_version
+    a = env.render()
+    assert np.array_equal(a, obs["pixels"].cpu().numpy()) and mir.state_version == v0
+    act = np.random.default_rng(0).uniform(-1, 1, (B, 9)).astype(np.float32)
+    for _ in range(30):
+        obs, *_ = env.step(act)
+    assert mir.state_version > v0
+    b = env.render()
+    assert np.array_equal(b, obs["pixels"].cpu().numpy()) and not np.array_equal(a, b)
+    b[:] = 0                                           # the caller's array is its own
+    assert np.array_equal(env.render(), obs["pixels"].cpu().numpy())
+    st = [x.clone() for x in mir.get_state()]
+    st[0][:, :7] += 0.3                                # a state write: the image must change
+    mir.set_state(*st)
+    c = env.render()
+    assert not np.array_equal(c, obs["pixels"].cpu().numpy())
+    cam.set_pose(pos=(5.0, 1.0, 3.0))                  # a camera move: drawn again from the new pose
+    d = env.render()
+    assert not np.array_equal(c, d)
+    env.reset()
+    assert not np.array_equal(env.render(), d)
