@@ -710,48 +710,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 // (drawn once: env 0's) and the sky and stores RGB8.  Same per-pixel expressions as box_bounds / plane_region / the floor path of
 // mir_render_kernel, so the two agree except where two surfaces tie in depth to the last bit (the tiled kernels keep the first one
 // in list order, the maximum here keeps the larger colour word).
+#define GLOBAL_BIG_BLOCKS 24 /* 32 x 8 blocks */
+#define GLOBAL_BIG_MAX 512
+#define GLOBAL_BIG_SPLIT 24
 struct SplatArgs {
   const float* prims;
   unsigned long long* zbuf;  // (H, W): w bits << 32 | packed RGB8, 0 = nothing
+  unsigned* big;             // [0] boxes with large rectangles this render, [1 ..] their indices (behind zbuf: cleared with it)
   uint8_t* pixels;
   int W, H, nprim, ngeom;
   float x0, dx, y0, dy;
   unsigned sky;
 };
 
-__global__ __launch_bounds__(256) void k_global_splat(SplatArgs a) {
-  // (a WAVE per box with the waves taking boxes round robin is twice as slow: 1.0 ms at 4096 envs -- the few boxes with large rectangles
-  //  decide, and they want lanes)
+// one box, the 32 x 8 blocks b = first, first + stride, ... of its rectangle (row-major), lane = pixel
+__device__ __forceinline__ void splat_box(const SplatArgs& a, const float* prim, int first, int stride, bool defer_big) {
   const int tid = threadIdx.x;
-  const cf4* rec = (const cf4*)(uintptr_t)(a.prims + (size_t)blockIdx.x * PREC);
+  const cf4* rec = (const cf4*)(uintptr_t)prim;
   const f4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
   const int tw = __float_as_int(q0.w);
   if ((tw & 255) != MIR_GEOM_BOX) return;
   const int xmin = __float_as_int(q1.w), xmax = min(__float_as_int(q2.w), a.W - 1), ymin = __float_as_int(q3.w), ymax = min(__float_as_int(q4.w), a.H - 1);
   if (xmin > xmax || ymin > ymax) return;
+  const int nbx = (xmax >> 5) - (xmin >> 5) + 1, nb = nbx * ((ymax >> 3) - (ymin >> 3) + 1);
+  if (defer_big && nb > GLOBAL_BIG_BLOCKS) {
+    // a box with a large rectangle (a slab close to the camera) would keep this one workgroup busy long after the others have
+    // left: it goes on a short list that k_global_splat_big spreads over GLOBAL_BIG_SPLIT workgroups each
+    __shared__ unsigned s_slot;
+    if (tid == 0) s_slot = atomicAdd(a.big, 1u);
+    __syncthreads();
+    if (s_slot < GLOBAL_BIG_MAX) {
+      if (tid == 0) a.big[1 + s_slot] = blockIdx.x;
+      return;
+    }
+  }
   const f4 q5 = rec[5], q7 = rec[7];
   const int nup = tw >> 8;
   const unsigned c0 = __float_as_uint(q5.x), c1 = __float_as_uint(q5.y), c2 = __float_as_uint(q5.z);
-  for (int by = ymin & ~7; by <= ymax; by += 8) {
-    const int py = by + (tid >> 5);
+  for (int blk = first; blk < nb; blk += stride) {
+    const int by = (ymin & ~7) + 8 * (blk / nbx), bx = (xmin & ~31) + 32 * (blk % nbx);
+    const int py = by + (tid >> 5), px = bx + (tid & 31);
+    if (px < xmin || px > xmax || py < ymin || py > ymax) continue;
     const float ys = a.y0 + (float)py * a.dy;
     const float e0 = fmaf(ys, q2.x, q0.x), e1 = fmaf(ys, q2.y, q0.y), e2 = fmaf(ys, q2.z, q0.z);
     const float e3 = fmaf(ys, q7.x, q3.x), e4 = fmaf(ys, q7.y, q3.y), e5 = fmaf(ys, q7.z, q3.z);
-    for (int bx = xmin & ~31; bx <= xmax; bx += 32) {
-      const int px = bx + (tid & 31);
-      if (px < xmin || px > xmax || py < ymin || py > ymax) continue;
-      const float xs = a.x0 + (float)px * a.dx;
-      const float v0 = fmaf(xs, q1.x, e0), v1 = fmaf(xs, q1.y, e1), v2 = fmaf(xs, q1.z, e2);
-      const float v3 = fmaf(xs, q4.x, e3), v4 = fmaf(xs, q4.y, e4), v5 = fmaf(xs, q4.z, e5);
-      float hi, lo = fmaxf(fmaxf(v3, v4), v5);
-      unsigned c;
-      if (nup == 3) { hi = fminf(fminf(v0, v1), v2); c = hi == v0 ? c0 : (hi == v1 ? c1 : c2); }
-      else if (nup == 2) { hi = fminf(v0, v1); lo = fmaxf(lo, v2); c = hi == v0 ? c0 : c1; }
-      else { hi = v0; lo = fmaxf(lo, fmaxf(v1, v2)); c = c0; }
-      if (lo <= hi && hi > 0.0f)
-        atomicMax(a.zbuf + (size_t)py * a.W + px, (unsigned long long)__float_as_uint(hi) << 32 | (unsigned long long)c);
-    }
+    const float xs = a.x0 + (float)px * a.dx;
+    const float v0 = fmaf(xs, q1.x, e0), v1 = fmaf(xs, q1.y, e1), v2 = fmaf(xs, q1.z, e2);
+    const float v3 = fmaf(xs, q4.x, e3), v4 = fmaf(xs, q4.y, e4), v5 = fmaf(xs, q4.z, e5);
+    float hi, lo = fmaxf(fmaxf(v3, v4), v5);
+    unsigned c;
+    if (nup == 3) { hi = fminf(fminf(v0, v1), v2); c = hi == v0 ? c0 : (hi == v1 ? c1 : c2); }
+    else if (nup == 2) { hi = fminf(v0, v1); lo = fmaxf(lo, v2); c = hi == v0 ? c0 : c1; }
+    else { hi = v0; lo = fmaxf(lo, fmaxf(v1, v2)); c = c0; }
+    if (lo <= hi && hi > 0.0f)
+      atomicMax(a.zbuf + (size_t)py * a.W + px, (unsigned long long)__float_as_uint(hi) << 32 | (unsigned long long)c);
   }
+}
+
+__global__ __launch_bounds__(256) void k_global_splat(SplatArgs a) {
+  // (a WAVE per box with the waves taking boxes round robin is twice as slow: 1.0 ms at 4096 envs -- the few boxes with large rectangles
+  //  decide, and they want lanes)
+  splat_box(a, a.prims + (size_t)blockIdx.x * PREC, 0, 1, true);
+}
+// grid (GLOBAL_BIG_MAX, GLOBAL_BIG_SPLIT): workgroup (e, s) takes every GLOBAL_BIG_SPLIT-th block of the e-th listed box
+__global__ __launch_bounds__(256) void k_global_splat_big(SplatArgs a) {
+  if (blockIdx.x >= min(a.big[0], (unsigned)GLOBAL_BIG_MAX)) return;
+  splat_box(a, a.prims + (size_t)a.big[1 + blockIdx.x] * PREC, blockIdx.y, GLOBAL_BIG_SPLIT, false);
 }
 
 // lane = 4 consecutive pixels of one row (one dwordx3 store when the width allows)
@@ -925,7 +949,7 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
       hipLaunchKernelGGL(mir_render_binned, dim3((unsigned)((pa.nwg + 7) & ~7)), dim3(256), 0, st, pa);
     } else if (mode == MIR_RENDER_GLOBAL && pa.nprim > 512 && !h->render_generic) {
       // the global view of many envs: one workgroup per box into a depth / colour buffer, then a resolve pass (see k_global_splat)
-      const size_t need = (size_t)cam->width * cam->height;
+      const size_t npix = (size_t)cam->width * cam->height, need = npix + (GLOBAL_BIG_MAX + 2) / 2 + 1;  // (+ the list of large boxes)
       if (need > h->zbuf_cap) {
         if (h->zbuf) (void)hipFree(h->zbuf);
         h->zbuf = nullptr; h->zbuf_cap = 0;
@@ -936,9 +960,10 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
       hipLaunchKernelGGL(k_render_setup<false>, dim3((B * ng + 255) / 256), dim3(256), 0, st, sa, BinArgs{});
       (void)hipMemsetAsync(h->zbuf, 0, need * sizeof(unsigned long long), st);
       SplatArgs sp;
-      sp.prims = h->prims; sp.zbuf = h->zbuf; sp.pixels = pixels; sp.W = cam->width; sp.H = cam->height; sp.nprim = pa.nprim; sp.ngeom = ng;
+      sp.prims = h->prims; sp.zbuf = h->zbuf; sp.big = reinterpret_cast<unsigned*>(h->zbuf + npix); sp.pixels = pixels; sp.W = cam->width; sp.H = cam->height; sp.nprim = pa.nprim; sp.ngeom = ng;
       sp.x0 = pa.x0; sp.dx = pa.dx; sp.y0 = pa.y0; sp.dy = pa.dy; sp.sky = pa.sky;
       hipLaunchKernelGGL(k_global_splat, dim3((unsigned)pa.nprim), dim3(256), 0, st, sp);
+      hipLaunchKernelGGL(k_global_splat_big, dim3(GLOBAL_BIG_MAX, GLOBAL_BIG_SPLIT), dim3(256), 0, st, sp);
       hipLaunchKernelGGL(k_global_resolve, dim3((cam->width + 255) / 256, (cam->height + 3) / 4), dim3(256), 0, st, sp);
     } else {
       hipLaunchKernelGGL(k_render_setup<false>, dim3((B * ng + 255) / 256), dim3(256), 0, st, sa, BinArgs{});
