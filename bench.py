@@ -443,8 +443,28 @@ def pixels_bench(torch, dev, renders: int = 100):
     us_global = ev0.elapsed_time(ev1) * 1e3 / renders
     del env
     torch.cuda.empty_cache()
+    # the reference README's own loop (README.md:28-44) through the registry's defaults (robot so101, global pixels): NumPy actions,
+    # env.step, env.render() every iteration; wall clock per iteration
+    import gym_genesis
+    import numpy as np
+    env = gym_genesis.make("gym_genesis/CubePick-v0", num_envs=ENVS_PER_GPU, enable_pixels=True)
+    env.reset(seed=0)
+    acts = np.random.default_rng(3).uniform(-1, 1, (ENVS_PER_GPU, 6)).astype(np.float32)
+    for _ in range(20):
+        env.step(acts)
+        env.render()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(renders):
+        env.step(acts)
+        env.render()
+    torch.cuda.synchronize(dev)
+    us_readme = (time.perf_counter() - t0) * 1e6 / renders
+    del env
+    torch.cuda.empty_cache()
     return {"workload": "CubePick-v0 robot=franka enable_pixels=True per_env 480x640 RGB8, num_envs=1024 (BASELINE configs[4])",
             "global_view_480x640_num_envs_4096_us_per_render": us_global,
+            "readme_loop_registry_defaults_num_envs_4096_us_per_iteration": us_readme,
             "env_frames_per_s": B / (us * 1e-6), "us_per_render": us, "us_per_render_regions": regions, "fill_us_same_buffer": fill_us, "host_enqueue_us_per_render": sorted(host)[1], "dtype": "u8 out / f32 rays",
             "reduced_96x128_num_envs_4096": {"env_frames_per_s": Bs / (us_small * 1e-6), "us_per_render": us_small,
                                              "GBps": Bs * Hs * Ws * 3 / (us_small * 1e-6) / 1e9},
