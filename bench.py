@@ -200,6 +200,8 @@ def parse_args(argv=None):
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for plumbing checks)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="plumbing check: let several ranks share a GPU (device = LOCAL_RANK %% device_count; use with --dist-backend gloo)")
+    ap.add_argument("--cpu-baseline-child", type=float, default=None, metavar="SECONDS",
+                    help="internal: run the CPU baseline in this (GPU-free) process for about SECONDS and print its JSON object")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="only spawn the ranks, rendezvous over gloo on CPU and print a line (no GPU, no physics)")
     return ap.parse_args(argv)
@@ -218,9 +220,60 @@ def launch_command(gpus: int, argv, port: int):
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+PREFLIGHT_CHILD = r'''
+import json, torch
+n = torch.cuda.device_count()
+print(json.dumps([[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(n)] for i in range(n)]))
+'''
+
+
+def preflight(gpus: int, oversubscribe: bool = False, device_count=None, peer_matrix=None, out=sys.stderr):
+    """Before any rank is started, in the launching parent (which never touches the GPU: the device count is read without
+    initialising HIP, the peer-access matrix by a short-lived child): one line per rank -- device, NUMA node of the GPU, the host
+    cores the rank will take (rank_cpu_plan), which peers its GPU can address (what the copy-path gather needs; without it the
+    ranks agree on the RCCL collective) -- and a verdict.  Returns 0 when every rank can be placed on a GPU of its own, 2 otherwise.
+    `device_count` / `peer_matrix` are injectable for the CPU tests."""
+    if device_count is None:
+        import torch
+        device_count = torch.cuda.device_count()
+    numa, cpus = gpu_numa_nodes(), numa_cpu_lists()
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = list(range(os.cpu_count() or 1))
+    if peer_matrix is None and device_count > 1:
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+            r = subprocess.run([sys.executable, "-c", PREFLIGHT_CHILD], capture_output=True, text=True, timeout=180, env=env)
+            peer_matrix = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+        except Exception:  # noqa: BLE001
+            peer_matrix = None
+    print(f"[bench preflight] {gpus} rank(s) requested, {device_count} GPU(s) visible, {len(allowed)} host core(s) allowed", file=out)
+    ok = True
+    for r in range(gpus):
+        dev = r if r < device_count else (r % device_count if (oversubscribe and device_count) else None)
+        mine, spin = rank_cpu_plan(r, gpus, allowed, numa, cpus)
+        node = numa[dev] if (numa and dev is not None and dev < len(numa)) else None
+        peers = "?" if (peer_matrix is None or dev is None or dev >= len(peer_matrix)) else "".join("1" if x else "0" for x in peer_matrix[dev])
+        where = "NONE (more ranks than GPUs)" if dev is None else f"cuda:{dev}" + (" (shared: --oversubscribe)" if r >= device_count else "")
+        print(f"[bench preflight]   rank {r}: device {where}, GPU NUMA node {'?' if node is None else node}, host cores "
+              f"{('%d-%d' % (mine[0], mine[-1])) if mine else 'left to the scheduler'} (stepping thread on {spin if spin is not None else '-'}), "
+              f"can address peers {peers}", file=out)
+        ok = ok and dev is not None
+    if not ok:
+        print(f"[bench preflight] FAILED: {gpus} ranks do not fit {device_count} GPU(s) (one rank per GPU; --oversubscribe shares GPUs for plumbing checks)", file=out)
+    elif peer_matrix is not None and gpus > 1 and not all(all(row[:gpus]) for row in peer_matrix[:gpus]) and not oversubscribe:
+        print("[bench preflight] note: not every GPU can address every peer -- the observation gather will use the RCCL collective (the ranks agree on it)", file=out)
+    return 0 if ok else 2
+
+
 def self_launch(args, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (this parent never touches the GPU,
     and nothing is exec'ed), pass their output through, exit with their code."""
+    if not args.selftest_launch:
+        rc = preflight(args.gpus, args.oversubscribe)
+        if rc != 0:
+            return rc
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
@@ -230,8 +283,11 @@ def self_launch(args, argv) -> int:
 
 
 # ---- secondary legs --------------------------------------------------------------------------------------------------
-def cpu_baseline(budget_s: float = 12.0):
-    """Time the float32 CPU port of the oracle (oracle/liborc32.so) on the host cores, same workload (kind "port")."""
+def cpu_baseline_child(budget_s: float) -> dict:
+    """Runs in a CHILD process of the bench (never touches the GPU; OMP_PROC_BIND=spread and OMP_PLACES=cores are in its environment
+    before the first OpenMP call): the float32 CPU port of the oracle (oracle/liborc32.so, kind "port") on the same workload.  The
+    OpenMP team size is calibrated first (the host may expose more cores than its CPU quota sustains): the best of three timed steps
+    per candidate; then five timed runs at the chosen size: value = their median, with min and max beside it."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
@@ -248,24 +304,40 @@ def cpu_baseline(budget_s: float = 12.0):
     pos = np.stack([rng.uniform(0.45, 0.80, B), rng.uniform(-0.25, 0.25, B), np.full(B, 0.02)], 1).astype(np.float32)
     o.reset(pos, np.tile(np.array([0, 0, 0, 1.0], np.float32), (B, 1)), np.tile(np.array(models.FRANKA_HOME, np.float32), (B, 1)))
     acts = np.random.default_rng(1234).uniform(-1, 1, (64, B, 9)).astype(np.float32)
-    # the host may expose more cores than its CPU quota sustains: calibrate the OpenMP team size
-    best, used = None, cores
+    best, used, k = None, cores, 0
     for nt in sorted({n for n in (4, 8, 16, 32, 64, 128, cores) if n <= cores}):
         o.step_batch(acts[0], nt)  # thread-pool / page-fault warm-up
+        dts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            o.step_batch(acts[1 + k % 63], nt)
+            dts.append(time.perf_counter() - t0)
+            k += 1
+        if best is None or min(dts) < best:
+            best, used = min(dts), nt
+    runs, per_run = [], max(4, min(400, int(budget_s / 5.0 / max(best, 1e-6))))
+    steps = 0
+    for _ in range(5):
         t0 = time.perf_counter()
-        o.step_batch(acts[1], nt)
-        o.step_batch(acts[2], nt)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, used = dt, nt
-    cores = used
-    steps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and steps < 2000:
-        o.step_batch(acts[steps % 64], cores)
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": steps * B / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps x {B} envs, same random-action workload, float32 C port of the oracle, OpenMP over envs"}
+        for _ in range(per_run):
+            o.step_batch(acts[steps % 64], used)
+            steps += 1
+        runs.append(per_run * B / (time.perf_counter() - t0))
+    runs.sort()
+    return {"value": runs[len(runs) // 2], "min": runs[0], "max": runs[-1], "unit": "env-steps/s", "cores": used, "threads": used, "kind": "port",
+            "sample": f"median of 5 runs x {per_run} steps x {B} envs, headline workload, f32 C port of the oracle, OpenMP (spread over cores)"}
+
+
+def cpu_baseline(budget_s: float = 12.0):
+    """The CPU baseline of the contract line, timed in a child process (cpu_baseline_child): OMP_PROC_BIND / OMP_PLACES must be set before
+    the first OpenMP call of a process, and this one has long made its own (torch) -- and has pinned its stepping thread."""
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_PROC_BIND"], env["OMP_PLACES"] = "spread", "cores"
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(budget_s)], env=env, capture_output=True, text=True,
+                       timeout=60.0 + 6.0 * budget_s)
+    if r.returncode != 0:
+        raise RuntimeError(f"cpu baseline child failed: {r.stderr[-400:]}")
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def stack_flops_per_env_step(envs: int = 32, steps: int = 40):
@@ -517,9 +589,41 @@ def grasp_bench(torch, dev):
             hits += int((pts > 16).sum().item())
             pts_max = max(pts_max, int(pts.max().item()))
     del env
-    return {"workload": "CubePick-v0 robot=franka scripted pick (hover, stabilize, descend, close, lift; 5 x 40 steps; IK-precomputed "
-                        "joint targets), num_envs=4096", "env_steps_per_s": B / (us * 1e-6), "us_per_step": us, "lifted_frac": success,
-            "max_contacts_last_step": ncon_max, "cap_hit_frac": hits / (200.0 * B), "max_candidate_points": pts_max, "contact_capacity": 16}
+
+    # the same 200 steps through GenesisEnv.step (host-visible `terminated` every step), with the manifolds thinned at 16 points (the
+    # default) and with exact contacts (GenesisEnv(..., exact_contacts=True): the envs with more than 16 candidate points are stepped
+    # by the wave kernel, 48 points, nothing thinned) -- median of five episodes each
+    def api_leg(exact: bool):
+        e = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False, exact_contacts=exact)
+        mir = e._env._mir
+        walls, lifted = [], 0.0
+        for rep in range(6):
+            e.reset(seed=0)
+            mir.exact_stats(reset=True)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            any_term = None
+            for tg in targets:
+                for _ in range(40):
+                    _, _, term, _, _ = e.step(tg)
+                    any_term = term if any_term is None else (any_term | term)
+            torch.cuda.synchronize(dev)
+            if rep:  # (the first episode warms up)
+                walls.append((time.perf_counter() - t0) / 200)
+            lifted = float(any_term.mean())
+        st = mir.exact_stats()
+        med = sorted(walls)[len(walls) // 2]
+        res = {"env_steps_per_s": B / med, "us_per_step": med * 1e6, "lifted_frac": lifted}
+        if exact:
+            res.update({"overflow_env_frac": st["overflow_env_steps"] / (200.0 * B), "overflow_step_frac": st["overflow_steps"] / 200.0,
+                        "overflow_envs_max": st["overflow_envs_max"]})
+        del e
+        return res
+
+    thin, exact = api_leg(False), api_leg(True)
+    return {"workload": "CubePick-v0 franka scripted pick, 5 x 40 steps, IK-precomputed joint targets, num_envs=4096", "env_steps_per_s": B / (us * 1e-6),
+            "us_per_step": us, "lifted_frac": success, "max_contacts_last_step": ncon_max, "cap_hit_frac": hits / (200.0 * B),
+            "max_candidate_points": pts_max, "contact_capacity": 16, "env_step_thinned": thin, "env_step_exact_contacts": exact}
 
 
 def box_links_bench(torch, dev, steps: int = 400):
@@ -660,6 +764,46 @@ def ik_bench(torch, dev, calls: int = 200):
             "env_solves_per_s": B / (us * 1e-6), "us_per_call": us, "converged_frac": float(((err[:, 0] < 5e-4) & (err[:, 1] < 5e-3)).float().mean().item())}
 
 
+def batch_sweep(torch, dev, f_step=None, sizes=(1024, 4096, 16384, 65536), n: int = 300):
+    """Secondary: what the 16-lane kernel does with other batches on ONE GPU -- the numbers under "latency / occupancy-bound".  Per batch:
+    the bare fused launch (HIP events: kernel us, env-steps/s), the loop through GenesisEnv.step (wall clock), and the fp32 vector
+    fraction F_step x B / kernel time / 157.3 TF.  At 4096 envs every env is resident at once (4 workgroups of 4 envs per CU); beyond
+    that the launch runs in rounds, and the rate says what the SIMDs give when they are never short of waves."""
+    from gym_genesis.env import GenesisEnv
+
+    rows = []
+    for Bs in sizes:
+        env = GenesisEnv(task="cube_pick", robot="franka", num_envs=Bs, enable_pixels=False)
+        task = env._env
+        env.reset(seed=0)
+        acts = torch.empty((8, Bs, 9), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=torch.Generator(device=dev).manual_seed(7))
+        al = list(acts.unbind(0))
+        for t in range(30):
+            task.step_raw(al[t % 8])
+        torch.cuda.synchronize(dev)
+        e0, e1 = _events(torch)
+        e0.record()
+        for t in range(n):
+            task.step_raw(al[t % 8])
+        e1.record()
+        torch.cuda.synchronize(dev)
+        k_us = e0.elapsed_time(e1) * 1e3 / n
+        env.reset(seed=0)
+        for t in range(30):
+            env.step(al[t % 8])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for t in range(n):
+            env.step(al[t % 8])
+        torch.cuda.synchronize(dev)
+        api_us = (time.perf_counter() - t0) * 1e6 / n
+        rows.append([Bs, k_us, Bs / (k_us * 1e-6), api_us, Bs / (api_us * 1e-6), ALGO_BYTES_PER_ENV_STEP * Bs / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     (f_step * Bs / (k_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS) if f_step else None])
+        del env, task
+    return {"cols": ["num_envs", "kernel_us", "bare_launch_rate", "env_step_us", "env_step_rate", "hbm_frac", "valu_frac"], "rows": rows,
+            "note": "fused launch by HIP events (gap included), GenesisEnv.step by wall clock; one GPU, franka pick, U(-1,1) targets"}
+
+
 def _profile_number(name: str, key: str):
     """A number measured offline with rocprofv3 PMC passes and committed under profiles/ (latest round first)."""
     for rnd in ("r4", "r3", "r2", "r1"):
@@ -681,6 +825,77 @@ def _guard(out: dict, key: str, fn, *a, **kw):
         out[key] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc(limit=3)}
         if isinstance(e, KeyboardInterrupt):
             raise
+
+
+# ---- the printed line ------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6000   # bytes: the driver keeps 8 KB tails of stdout; a longer line loses its HEAD (value, config) in the driver's record
+NOTE_LIMIT = 120    # characters per string (the prose lives in DESIGN.md)
+HEAD_KEYS = ("metric", "value", "unit", "value_median_region", "hot_path_rate", "api_over_hot_path", "early_mask_sent", "early_mask_mismatches",
+             "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+# what goes first when the line is still too long (least important first; dotted = nested key)
+DROP_ORDER = ("roofline_valu.F_step_per_kind", "roofline_valu.instruction_level", "roofline_valu.fused_launch", "sync_step_floor", "repeat_us_per_step",
+              "roofline.note", "roofline_fused_launch", "pixels.global_view", "pixels.readme_loop", "box_links", "ik", "no_gather", "config.obs_gather",
+              "config.output_ring", "config.value_is", "best_repeat_value", "timed_seconds_total", "timed_steps_total", "resets_in_loop", "roofline_valu",
+              "so101_pick", "pixels", "stack", "secondary", "scripted_grasp")
+
+
+def compact_line(out: dict, limit: int = LINE_LIMIT) -> dict:
+    """The dict that is printed: the contract keys and the figures the driver's record must show first (value, its median region, the
+    bare-launch rate, the early-mask counters -- flat, right behind `value`, and once more inside `config`), every string cut to
+    NOTE_LIMIT characters, traces and per-kind tables left to the full record (bench_line_full.json), and -- should the line still
+    exceed `limit` bytes -- secondary detail dropped in DROP_ORDER.  Never touches the contract keys."""
+    import copy
+    o = copy.deepcopy(out)
+    em = o.get("early_mask") if isinstance(o.get("early_mask"), dict) else {}
+    o["early_mask_sent"], o["early_mask_mismatches"] = em.get("sent"), em.get("mismatches")
+    if isinstance(o.get("config"), dict):
+        o["config"]["early_mask"] = {"sent": em.get("sent"), "mismatches": em.get("mismatches"), "workgroup_launches": em.get("workgroup_launches")}
+        for k in ("value_median_region", "hot_path_rate", "api_over_hot_path"):
+            o["config"][k] = o.get(k)
+    o.pop("early_mask", None)
+
+    def shrink(x, key=""):
+        if isinstance(x, dict):
+            return {k: shrink(v, k) for k, v in x.items() if k not in ("trace", "per_kind", "F_step_per_kind", "F_step_source")}
+        if isinstance(x, list):
+            return [shrink(v, key) for v in x]
+        if isinstance(x, float):
+            return float(f"{x:.6g}")
+        if isinstance(x, str) and len(x) > NOTE_LIMIT and key != "metric":
+            return x[:NOTE_LIMIT - 3] + "..."
+        return x
+
+    o = shrink(o)
+    o = {**{k: o[k] for k in HEAD_KEYS if k in o}, **{k: v for k, v in o.items() if k not in HEAD_KEYS}}
+    dropped = []
+    for path in DROP_ORDER:
+        if len(json.dumps(o)) <= limit - 40 * (len(dropped) + 1):   # (room for the list of what was dropped)
+            break
+        node, parts = o, path.split(".")
+        for part in parts[:-1]:
+            node = node.get(part) if isinstance(node, dict) else None
+        if isinstance(node, dict) and parts[-1] in node:
+            del node[parts[-1]]
+            dropped.append(path)
+    if dropped:
+        o["dropped_for_length"] = dropped
+    return o
+
+
+def print_line(out: dict) -> None:
+    """Rank 0: the full record to gpurun_out/bench_line_full.json (best effort), the compact line to stdout as the LAST line."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_line_full.json"), "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError:
+        pass
+    try:
+        line = json.dumps(compact_line(out))
+    except Exception:  # noqa: BLE001 (the line must be printed whatever the compaction runs into)
+        line = json.dumps(out)
+    print(line, flush=True)
 
 
 # ---- worker ----------------------------------------------------------------------------------------------------------
@@ -838,10 +1053,15 @@ def worker(args) -> int:
     if not gather and args.output_ring > 0:
         task._mir.use_output_ring(args.output_ring, 9, 11)
     RING_CHUNKS = 4
+    RING_ROWS = RING_CHUNKS * S
+    # (how many consecutive steps travel in one gather: S, the --gather-every of the headline; 1 in the `gather_every_1` regions --
+    #  SURVEY.md cfg 3's "all-gather obs each step" -- where a ring chunk is a single row; and which path carries it: [0] = the copy
+    #  path's object or None for the RCCL collective)
+    Sx, cg = [S], [copy_gather]
     # `sent`: first row of the current ring chunk that has not been gathered yet, `row`: the row the latest step wrote (-1: none)
     state = {"chunk": 0, "t": 0, "resets": 0, "sent": 0, "row": -1}
     last_block = [None]
-    readers = [[] for _ in range(RING_CHUNKS)]   # per ring chunk: the pushes that read it since it was last written
+    readers = [[] for _ in range(RING_ROWS)]   # per ring chunk (of Sx[0] rows): the pushes that read it since it was last written
     gather_stats = {"pushes": 0, "partial_pushes": 0, "lag_max": 0, "checks": 0, "checks_failed": 0}
 
     def flush():
@@ -851,18 +1071,19 @@ def worker(args) -> int:
         if not gather_on[0] or row < lo:
             return
         send = ring[lo:row + 1].reshape(-1)   # rows of one ring chunk: one contiguous block, no concatenation
-        if copy_gather is not None:
-            last_seq[0] = copy_gather.push(send)   # device-to-device copies on the side streams: nothing to wait for here
-            ch = lo // S
+        Sc = Sx[0]
+        if cg[0] is not None:
+            last_seq[0] = cg[0].push(send)   # device-to-device copies on the side streams: nothing to wait for here
+            ch = lo // Sc
             readers[ch].append(last_seq[0])
-            if (row + 1) % S == 0:
+            if (row + 1) % Sc == 0:
                 # the chunk is complete and the step kernels are about to write the NEXT ring chunk: they wait (on the device, the
                 # host goes on) until the copies of the pushes that read it on the previous lap are through with it
-                nxt = (ch + 1) % RING_CHUNKS
+                nxt = (ch + 1) % (RING_ROWS // Sc)
                 for sq in readers[nxt]:
-                    copy_gather.wait_source(sq)
+                    cg[0].wait_source(sq)
                 readers[nxt].clear()
-            gather_stats["lag_max"] = max(gather_stats["lag_max"], copy_gather.lag())
+            gather_stats["lag_max"] = max(gather_stats["lag_max"], cg[0].lag())
         else:
             s = state["chunk"] & 1
             if pending[s] is not None:
@@ -870,21 +1091,21 @@ def worker(args) -> int:
             pending[s] = dist.all_gather_into_tensor(gathered[s][:pg_world * send.numel()], send, async_op=True)
         last_block[0] = send
         gather_stats["pushes"] += 1
-        gather_stats["partial_pushes"] += 1 if (row + 1 - lo) < S else 0
+        gather_stats["partial_pushes"] += 1 if (row + 1 - lo) < Sc else 0
         state["chunk"] += 1
-        state["sent"] = row + 1 if (row + 1) % S else ((row + 1) % (RING_CHUNKS * S))
+        state["sent"] = row + 1 if (row + 1) % Sc else ((row + 1) % RING_ROWS)
 
     def api_loop(k: int):
         """k iterations of the README loop through GenesisEnv.step (README.md:32-43)."""
-        t, step, n = state["t"], env.step, N_ACT
+        t, step, n, Sc = state["t"], env.step, N_ACT, Sx[0]
         for _ in range(k):
             obs, reward, terminated, truncated, info = step(act_list[t % n])
             if gather_on[0]:
                 row = obs["agent_pos"].storage_offset() // flat   # the ring row this step's kernel wrote
-                if row % S == 0 or row != (state["row"] + 1) % (RING_CHUNKS * S):
+                if row % Sc == 0 or row != (state["row"] + 1) % RING_ROWS:
                     state["sent"] = row                           # a new chunk (or the rows in between were not part of a gather)
                 state["row"] = row
-                if row % S == S - 1:                              # a chunk is complete: its rows are one contiguous block
+                if row % Sc == Sc - 1:                            # a chunk is complete: its rows are one contiguous block
                     flush()
             t += 1
             if terminated.any() or truncated.any() or t % EPISODE_STEPS == 0:
@@ -907,17 +1128,17 @@ def worker(args) -> int:
             if p is not None:
                 p.wait()
                 pending[i] = None
-        if copy_gather is not None and last_seq[0]:
-            copy_gather.wait(last_seq[0])   # every rank's last block has landed HERE (the words of the earlier ones came first)
+        if cg[0] is not None and last_seq[0]:
+            cg[0].wait(last_seq[0])   # every rank's last block has landed HERE (the words of the earlier ones came first)
         torch.cuda.synchronize(dev)
         if use_pg:
             dist.barrier()
         torch.cuda.synchronize(dev)
-        if copy_gather is not None and last_seq[0] and last_block[0] is not None and check_gather[0]:
+        if cg[0] is not None and last_seq[0] and last_block[0] is not None and check_gather[0]:
             # (outside the timed brackets' clock?  No: sync_all is the bracket.  The check is therefore switched on only for the
             #  verification pass after the measurements, see below)
             gather_stats["checks"] += 1
-            if not copy_gather.check_against_collective(last_seq[0], last_block[0]):
+            if not cg[0].check_against_collective(last_seq[0], last_block[0]):
                 gather_stats["checks_failed"] += 1
 
     def max_over_ranks(x: float) -> float:
@@ -999,8 +1220,7 @@ def worker(args) -> int:
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "CubePick-v0 robot=franka num_envs=4096 per GPU, state-only obs, U(-1,1) joint-target actions resident in HBM, "
-                                   "README loop through GenesisEnv.step (NumPy bool terminated per step), reset-all every 200 steps",
+            "config": {"workload": "CubePick-v0 franka, 4096 envs/GPU, state obs, U(-1,1) targets in HBM, README loop via GenesisEnv.step, reset / 200 steps",
                        "num_envs_per_gpu": B, "global_num_envs": B * world, "parallelism": f"env-axis shard x{world}",
                        "world_size_observed": pg_world, "dist_backend": args.dist_backend if use_pg else None,
                        "obs_gather": ("none" if not gather else
@@ -1052,6 +1272,32 @@ def worker(args) -> int:
                 gather_on[0] = True
                 out["gather_overhead_us"] = None
                 out["no_gather"] = {"error": f"{type(e).__name__}: {e}"}
+        # ---- SURVEY.md cfg 3 to the letter: "all-gather obs each step".  The headline loop once more with ONE step per gather, over
+        # the copy path (when it is up) and over the collective (all ranks take these branches together) ------------------------------
+        if gather and api_walls is not None and not args.no_gather_ab and S > 1:
+            g1 = {}
+            for name, obj in (("copy", copy_gather), ("rccl", None)):
+                if name == "copy" and copy_gather is None:
+                    continue
+                try:
+                    sync_all()
+                    for lst in readers:
+                        lst.clear()
+                    state["sent"], state["row"] = 0, -1
+                    Sx[0], cg[0] = 1, obj
+                    w1, _ = measure(api_loop)
+                    us1 = sum(w1) * 1e6 / (len(w1) * K)
+                    g1[name] = {"value": len(w1) * K * B * world / sum(w1), "mean_us_per_step": us1,
+                                "overhead_us_vs_no_gather": (us1 - out["no_gather"]["mean_us_per_step"]) if "mean_us_per_step" in out.get("no_gather", {}) else None}
+                except Exception as e:  # noqa: BLE001
+                    g1[name] = {"error": f"{type(e).__name__}: {e}"}
+                finally:
+                    sync_all()
+                    for lst in readers:
+                        lst.clear()
+                    state["sent"], state["row"] = 0, -1
+                    Sx[0], cg[0] = S, copy_gather
+            out["gather_every_1"] = g1
         # ---- the bare fused launch over the same number of steps: hot_path_rate + kernel duration for the roofline ----
         try:
             state["t"] = 0
@@ -1139,6 +1385,9 @@ def worker(args) -> int:
             _guard(out, "roofline_valu", _valu)
         if rank == 0 and world == 1 and not args.core_only:
             _guard(out, "secondary", lambda: secondary_rates(torch, dev, env, task, actions, B))
+            if isinstance(out.get("secondary"), dict) and "error" not in out["secondary"]:
+                fs = out.get("roofline_valu", {}).get("F_step") if isinstance(out.get("roofline_valu"), dict) else None
+                _guard(out["secondary"], "batch_sweep", batch_sweep, torch, dev, fs)
             if not args.no_pixels:
                 _guard(out, "pixels", pixels_bench, torch, dev)
             if not args.no_stack:
@@ -1172,7 +1421,7 @@ def worker(args) -> int:
             except OSError:
                 pass
             sys.stdout.flush()
-            print(json.dumps(out), flush=True)
+            print_line(out)
     return rc
 
 
@@ -1239,6 +1488,9 @@ def secondary_rates(torch, dev, env, task, actions, B):
 def main(argv=None) -> int:
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
+    if args.cpu_baseline_child is not None:
+        print(json.dumps(cpu_baseline_child(args.cpu_baseline_child)), flush=True)
+        return 0
     if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args, argv)
     if args.selftest_launch:

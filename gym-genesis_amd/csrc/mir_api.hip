@@ -187,6 +187,9 @@ struct Outs {
   bool diag = true;
   bool poses = false;  // 16-lane kernel: also write the link poses into h->poses (the rasteriser reads them)
   int phase = 0;       // 16-lane kernel: 0 whole step, 1 / 2 the two halves of a split step (mir_step.h)
+  int exact = 0;       // 16-lane kernel: defer the envs with more candidate points than lanes (StepArgs::exact)
+  const int32_t* env_list = nullptr;  // 16-lane kernel, phase 1: serve the envs env_list[0 .. nlist) (StepArgs::env_list)
+  int nlist = 0;
   unsigned long long* prof = nullptr;  // 16-lane kernel only (debug)
 };
 
@@ -218,6 +221,8 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
     a.term_host = o.term_host; a.term_tag = o.term_tag; a.done_ticket = o.done_ticket; a.done_flag = o.done_flag; a.done_seq = o.done_seq;
     a.phase = o.phase; a.pre = h->pre;
+    a.exact = o.exact;
+    if (o.env_list) { a.env_list = o.env_list; a.B = o.nlist; }
     rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
   } else {
     StepArgs64 a;
@@ -485,6 +490,7 @@ int mir_destroy(MirHandle h) {
   if (h->scratch_row) (void)hipFree(h->scratch_row);
   if (h->pre) (void)hipFree(h->pre);
   if (h->pin_host) (void)hipHostFree(h->pin_host);
+  if (h->ovf_list_host) (void)hipHostFree(h->ovf_list_host);
   delete h;
   return MIR_OK;
 }
@@ -548,6 +554,14 @@ int mir_set_pd_targets(MirHandle h, const float* tgt, void* stream) {
 int mir_step(MirHandle h, int32_t n_steps, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   if (n_steps <= 0) return MIR_OK;
+  if (h->exact) {  // (exact contacts: every step is closed on the host, where the deferred envs are handed to the wave kernel)
+    for (int i = 0; i < n_steps; i++) {
+      int rc = mir_step_begin(h, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+      if (rc == MIR_OK) rc = mir_step_end(h, nullptr);
+      if (rc != MIR_OK) return rc;
+    }
+    return MIR_OK;
+  }
   DeviceGuard guard(h->device);
   Outs o;
   o.n_steps = n_steps;
@@ -556,6 +570,10 @@ int mir_step(MirHandle h, int32_t n_steps, void* stream) {
 
 int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
   if (check(h)) return MIR_E_INVALID;
+  if (h->exact) {  // (exact contacts: begin + end -- the call then waits for the step's terminated bytes)
+    const int rc = mir_step_begin(h, action, agent_pos, env_state, reward, terminated, stream);
+    return rc != MIR_OK ? rc : mir_step_end(h, nullptr);
+  }
   DeviceGuard guard(h->device);
   Outs o;
   o.action = action; o.agent_pos = agent_pos; o.env_state = env_state; o.reward = reward; o.terminated = terminated;
@@ -580,9 +598,10 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   o.action = action; o.agent_pos = agent_pos; o.env_state = env_state; o.reward = reward; o.terminated = terminated;
   o.term_host = h->pin_dev;
   const uint32_t seq = h->seq + 1u;
-  // The tag has a counter of its own that nothing else advances (h->seq is shared with mir_debug_null_roundtrip and wraps): 1 .. 127,
-  // never 0 (fresh memory), and a launch's tag differs from those of the 126 launches before it -- each of which overwrote every byte.
-  const uint32_t tag = h->tag % 127u + 1u;
+  // The tag has a counter of its own that nothing else advances (h->seq is shared with mir_debug_null_roundtrip and wraps): 1 .. 63,
+  // never 0 (fresh memory), and a launch's tag differs from those of the 62 launches before it -- each of which overwrote every byte.
+  // (Six bits: bit 7 of a byte says "deferred" -- exact contacts, StepArgs::exact.)
+  const uint32_t tag = h->tag % 63u + 1u;
   o.term_tag = tag;
   if (h->sync_mode == 2) { o.done_ticket = h->done_ticket; o.done_flag = flag_dev; o.done_seq = seq; }
   // split step: if the previous mir_step_begin left the action-independent half of THIS step in `pre` (same stream, nothing
@@ -593,6 +612,9 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   //  the waves; otherwise two launches)
   const bool rotated = have_pre && h->hm.fk_free_leaf != 0 && h->split_step != 2;
   o.phase = rotated ? 3 : (have_pre ? 2 : 0);
+  o.exact = h->exact;
+  h->pend_action = action;
+  h->pend_out[0] = agent_pos; h->pend_out[1] = env_state; h->pend_out[2] = reward; h->pend_out[3] = terminated;
   o.prof = h->dbg_prof;
   h->dbg_prof = nullptr;
   int rc = launch(h, o, stream);
@@ -637,6 +659,60 @@ int mir_step_go(MirHandle h, const float* action, void* stream) {
   return rc;
 }
 
+/* exact contacts: the n envs of h->ovf_list_host were deferred by the launch(es) of the pending mir_step_begin (their state rows are
+ * those of the step's start).  They are stepped here by the wave-per-env kernel in list mode -- the same scene compiled for it with 48
+ * contact points, reading and writing the 16-lane kernel's rows, the action and the output pointers of the pending step -- and their
+ * scratch rows for the NEXT step are recomputed by the action-independent half of the 16-lane kernel over the same list (it also
+ * decides whether they are deferred again).  Both launches go on the step's stream, behind the launch that deferred them; the
+ * terminated byte of list entry k arrives in ovf_term_host[k]. */
+static int exact_finish(MirScene* h, int n, uint8_t* terminated_host) {
+  DeviceGuard guard(h->device);
+  h->ex_ovf_steps++;
+  h->ex_ovf_envs += (unsigned long long)n;
+  if ((unsigned long long)n > h->ex_ovf_max) h->ex_ovf_max = (unsigned long long)n;
+  memset(h->ovf_term_host, 0, (size_t)n);  // (tags come round every 63 steps: a byte of an older step must not pass for this one's)
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  StepArgs64 a;
+  memset(&a, 0, sizeof a);
+  a.model = h->dm64;
+  a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
+  a.diag = h->diag_on ? h->diag : nullptr;
+  a.bad_count = h->early_stats;
+  a.B = n; a.nu = h->hm64.nu; a.convex = h->hm64.has_convex;
+  a.action = h->pend_action;
+  a.agent_pos = (float*)h->pend_out[0]; a.env_state = (float*)h->pend_out[1]; a.reward = (float*)h->pend_out[2]; a.terminated = (uint8_t*)h->pend_out[3];
+  a.term_host = h->ovf_term_dev; a.term_tag = h->tag;
+  a.mode = 0; a.n_steps = 1;
+  a.env_list = h->ovf_list_dev; a.lay16_qst = h->hm.qstride;
+  int rc = mir_launch_step64(&a, (hipStream_t)h->pending_stream);
+  if (rc != 0) return hip_fail((hipError_t)rc, "wave kernel launch (exact contacts)");
+  h->poses_current = 0;  // (the deferred envs' link poses were not written)
+  if (h->pre_valid) {  // (split step: the scratch rows of the coming step, for the envs that have only now reached its starting state)
+    Outs p;
+    p.phase = 1; p.diag = false; p.env_list = h->ovf_list_dev; p.nlist = n;
+    rc = launch(h, p, h->pending_stream);
+    if (rc != MIR_OK) return rc;
+  }
+  const uint8_t want = (uint8_t)h->tag;
+  unsigned long polls = 0;
+  for (int k = 0; k < n;) {
+    const uint8_t b = __atomic_load_n(h->ovf_term_host + k, __ATOMIC_RELAXED);
+    if ((uint8_t)(b >> 1) == want) {
+      if (terminated_host) terminated_host[h->ovf_list_host[k]] = b & 1u;
+      k++;
+      continue;
+    }
+    __builtin_ia32_pause();
+    if ((++polls & 0xfffffu) == 0) {
+      hipError_t e = hipStreamQuery((hipStream_t)h->pending_stream);
+      if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "mir_step_end: stream (exact contacts)");
+      if (e == hipSuccess && polls > 0x4000000u) return set_err(MIR_E_HIP, "mir_step_end: the wave launch finished without delivering its terminated bytes");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return MIR_OK;
+}
+
 int mir_step_end(MirHandle h, uint8_t* terminated_host) {
   if (check(h)) return MIR_E_INVALID;
   if (!h->pending) return set_err(MIR_E_INVALID, "mir_step_end without mir_step_begin");
@@ -653,13 +729,20 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
   } else if (h->sync_mode == 3 && h->term_wstride) {
     // 16-lane kernel: one 32-bit word (4 envs) per workgroup, `term_wstride` words apart; every byte carries this launch's tag.  One
     // pass: wait for a word, take its bits, go on to the next (the pointer stands still at the first workgroup that has not delivered)
-    const uint32_t want4 = 0x01010101u * (uint8_t)h->tag, tagm4 = 0x7f7f7f7fu;
+    // (exact contacts: bit 7 of a byte = the env was deferred by the launch -- collected here, stepped by exact_finish)
+    const uint32_t want4 = 0x01010101u * (uint8_t)h->tag, tagm4 = 0x3f3f3f3fu;
     const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(bytes);
     const size_t nwg = (B + 3) / 4, ws = (size_t)h->term_wstride;
     unsigned long polls = 0;
+    int ndefer = 0;
+    h->ex_steps++;
     for (size_t g = 0; g < nwg;) {
       uint32_t v = w[g * ws];
       if (((v >> 1) & tagm4) == want4) {
+        if ((v & 0x80808080u) && h->exact) {
+          for (size_t k = 0; k < 4 && 4 * g + k < B; k++)
+            if (v >> (8 * k + 7) & 1u) h->ovf_list_host[ndefer++] = (int32_t)(4 * g + k);
+        }
         if (terminated_host) {
           v &= 0x01010101u;
           memcpy(terminated_host + 4 * g, &v, 4 * g + 4 <= B ? 4 : B - 4 * g);
@@ -677,6 +760,7 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
       }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (ndefer) return exact_finish(h, ndefer, terminated_host);
     return MIR_OK;
   } else if (h->sync_mode == 3) {
     // the bytes announce themselves: wait until every one of them carries this launch's tag
@@ -684,14 +768,14 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
     // yet and touches every cache line once after the device's last write to it; polling the whole buffer instead was measured
     // slower -- the host keeps pulling lines the device is still writing)
     const uint8_t want = (uint8_t)h->tag;
-    const uint64_t want8 = 0x0101010101010101ull * want, tagm = 0x7f7f7f7f7f7f7f7full;
+    const uint64_t want8 = 0x0101010101010101ull * want, tagm = 0x3f3f3f3f3f3f3f3full;
     const volatile uint64_t* w8 = reinterpret_cast<const volatile uint64_t*>(bytes);
     const size_t nw = B / 8;
     size_t i = 0;  // in 8-byte words, then the tail bytes
     unsigned long polls = 0;
     while (i < nw + (B - nw * 8)) {
       const bool ok = i < nw ? (((w8[i] >> 1) & tagm) == want8)
-                             : ((uint8_t)(__atomic_load_n(bytes + nw * 8 + (i - nw), __ATOMIC_RELAXED) >> 1) == want);
+                             : ((uint8_t)((__atomic_load_n(bytes + nw * 8 + (i - nw), __ATOMIC_RELAXED) >> 1) & 0x3fu) == want);
       if (ok) { i++; continue; }
       __builtin_ia32_pause();
       if ((++polls & 0xfffffu) == 0) {
@@ -737,12 +821,53 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
 }
 
 int mir_get_sync_mode(MirHandle h) { return check(h) ? MIR_E_INVALID : h->sync_mode; }
+
+int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
+  if (check(h)) return MIR_E_INVALID;
+  if (h->pending) return set_err(MIR_E_INVALID, "mir_set_exact_contacts: a step is pending");
+  if (!on) { h->exact = 0; return MIR_OK; }
+  if (h->kernel != 16) return set_err(MIR_E_INVALID, "mir_set_exact_contacts: the scene already runs on the wave-per-env kernel (48 contact points, never thinned below that)");
+  if (h->sync_mode != 3 || !h->term_wstride) return set_err(MIR_E_INVALID, "mir_set_exact_contacts: needs the tagged terminated bytes (sync mode 3)");
+  if (!spec) return set_err(MIR_E_INVALID, "mir_set_exact_contacts: the scene's spec is needed once (it is compiled for the wave kernel)");
+  if (!h->ovf_list_host) {
+    // the same scene for the wave-per-env kernel, with that kernel's contact capacity
+    MirSceneSpec* s2 = new (std::nothrow) MirSceneSpec(*spec);
+    if (!s2) return set_err(MIR_E_INVALID, "out of host memory");
+    s2->opt.max_contacts = MIR_MAX_CONTACT;
+    HostConsts hc;
+    char err[256] = "";
+    const int rc = mir_compile_model64(s2, &h->hm64, &hc, err);
+    delete s2;
+    if (rc != MIR_OK) return set_err(rc, "mir_set_exact_contacts: %s", err);
+    if (h->hm64.nv != h->hm.nv || h->hm64.nq != h->hm.nq || h->hm64.nu != h->hm.nu || h->hm64.agent_dim != h->agent_dim || h->hm64.env_dim != h->env_dim)
+      return set_err(MIR_E_INVALID, "mir_set_exact_contacts: the spec is not the one this scene was created from");
+    DeviceGuard guard(h->device);
+    HIPCHK(hipMemcpy(h->dm64, &h->hm64, sizeof(DevModel64), hipMemcpyHostToDevice));
+    const size_t B = (size_t)h->B, bytes = B * sizeof(int32_t) + ((B + 63) / 64) * 64;
+    HIPCHK(hipHostMalloc((void**)&h->ovf_list_host, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h->ovf_list_host, 0, bytes);
+    HIPCHK(hipHostGetDevicePointer((void**)&h->ovf_list_dev, h->ovf_list_host, 0));
+    h->ovf_term_host = reinterpret_cast<uint8_t*>(h->ovf_list_host + B);
+    h->ovf_term_dev = reinterpret_cast<uint8_t*>(h->ovf_list_dev + B);
+  }
+  h->exact = 1;
+  return MIR_OK;
+}
+
+int mir_get_exact_contacts(MirHandle h) { return check(h) ? MIR_E_INVALID : h->exact; }
+
+int mir_get_exact_stats(MirHandle h, uint64_t* out4, int32_t reset) {
+  if (check(h) || !out4) return set_err(MIR_E_INVALID, "mir_get_exact_stats: null argument");
+  out4[0] = h->ex_steps; out4[1] = h->ex_ovf_steps; out4[2] = h->ex_ovf_envs; out4[3] = h->ex_ovf_max;
+  if (reset) h->ex_steps = h->ex_ovf_steps = h->ex_ovf_envs = h->ex_ovf_max = 0;
+  return MIR_OK;
+}
 /* debug aid (bench.py's roofline): n back-to-back launches of the rotated step kernel (what mir_step_begin launches in split mode 1)
  * cycling through n_actions action blocks of (B, nu) and without observation outputs, so that two events around the call time that kernel the way the fused one is
  * timed.  Advances the state by n steps. */
 extern "C" int mir_debug_rotated_launches(MirHandle h, const float* actions, int32_t n_actions, int32_t n, void* const* outputs, void* stream) {
   if (check(h)) return MIR_E_INVALID;
-  if (h->kernel != 16 || h->split_step != 1 || !h->hm.fk_free_leaf) return set_err(MIR_E_INVALID, "mir_debug_rotated_launches: the scene does not use rotated launches");
+  if (h->kernel != 16 || h->split_step != 1 || !h->hm.fk_free_leaf || h->exact) return set_err(MIR_E_INVALID, "mir_debug_rotated_launches: the scene does not use rotated launches (or exact contacts are on)");
   DeviceGuard guard(h->device);
   if (!(h->pre_valid && h->pre_stream == stream)) {
     Outs f; f.action = actions; f.diag = false;
@@ -827,6 +952,7 @@ int mir_get_early_mask(MirHandle h) { return check(h) ? MIR_E_INVALID : (h->no_e
 int mir_step_packed(MirHandle h, const float* action, float* rows, int32_t row_stride, void* stream) {
   if (check(h) || !rows) return set_err(MIR_E_INVALID, "mir_step_packed: null argument");
   if (row_stride < h->agent_dim + h->env_dim + 2) return set_err(MIR_E_INVALID, "mir_step_packed: row_stride too small");
+  if (h->exact) return set_err(MIR_E_INVALID, "mir_step_packed: not available with exact contacts (the step has to be closed on the host: mir_step_begin / mir_step_end)");
   DeviceGuard guard(h->device);
   Outs o;
   o.action = action; o.rows = rows; o.row_stride = row_stride;
@@ -837,6 +963,7 @@ int mir_rollout(MirHandle h, const float* actions, int32_t n_steps, float* rows,
   if (check(h) || !actions || !rows) return set_err(MIR_E_INVALID, "mir_rollout: null argument");
   if (n_steps <= 0) return MIR_OK;
   if (row_stride < h->agent_dim + h->env_dim + 2) return set_err(MIR_E_INVALID, "mir_rollout: row_stride too small");
+  if (h->exact) return set_err(MIR_E_INVALID, "mir_rollout: not available with exact contacts (every step has to be closed on the host)");
   DeviceGuard guard(h->device);
   Outs o;
   o.action = actions; o.rows = rows; o.row_stride = row_stride; o.n_steps = n_steps;
@@ -851,6 +978,7 @@ int mir_rollout_autoreset(MirHandle h, const float* actions, int32_t n_steps, fl
   if (!episode_len || !spawn_pool || !cursor || !obj_quat || !arm_qpos || pool_len <= 0) return set_err(MIR_E_INVALID, "mir_rollout_autoreset: null argument");
   if (n_steps <= 0) return MIR_OK;
   if (row_stride < h->agent_dim + h->env_dim + 3) return set_err(MIR_E_INVALID, "mir_rollout_autoreset: row_stride too small (needs the truncated column)");
+  if (h->exact) return set_err(MIR_E_INVALID, "mir_rollout_autoreset: not available with exact contacts (every step has to be closed on the host)");
   DeviceGuard guard(h->device);
   Outs o;
   o.action = actions; o.rows = rows; o.row_stride = row_stride; o.n_steps = n_steps;

@@ -60,6 +60,17 @@ struct MirScene {
   float* pre;
   int split_step, pre_valid;
   void* pre_stream;
+  // EXACT CONTACTS (mir_set_exact_contacts; 16-lane scenes): the launches of mir_step_begin defer every env whose candidate contact
+  // points exceed the 16-lane kernel's capacity (bit 7 of its terminated byte), and mir_step_end steps those envs on the wave kernel
+  // (hm64 / dm64 = the same scene compiled for it with 48 points) from the untouched state rows, then recomputes their scratch rows.
+  int exact;
+  int32_t* ovf_list_host;   // pinned, device-mapped: the deferred envs of the step being closed (B x i32), read in place by the two launches
+  int32_t* ovf_list_dev;
+  uint8_t* ovf_term_host;   // pinned: terminated byte of list entry k, tagged like the others (behind the list in the same allocation)
+  uint8_t* ovf_term_dev;
+  const float* pend_action; // arguments of the pending mir_step_begin (the wave launch of mir_step_end takes the same)
+  void* pend_out[4];
+  unsigned long long ex_steps, ex_ovf_steps, ex_ovf_envs, ex_ovf_max;  // steps closed / steps with deferred envs / deferred env-steps / most in one step
 };
 
 // library-internal helpers implemented in mir_api.hip

@@ -56,6 +56,14 @@ struct StepArgs {
   uint32_t* term_bad;  // device address of a pinned host word <- 1 when early bytes turned out wrong (checked by the next API call: MIR_E_MASK)
   int no_early_mask;  // MIR_NO_EARLY_MASK=1: the bytes always wait for the integrator
   int term_wstride;   // 32-bit words between the term_host words of consecutive workgroups (mir_scene.h)
+  // EXACT CONTACTS (mir_set_exact_contacts; single-step launches of the mir_step_begin path only).  An env whose narrowphase found
+  // more candidate points than this kernel's contact capacity -- the count travels in bits 20 .. 27 of the `coupled` word, through the
+  // scratch row of a split step too -- is DEFERRED: the launch stores nothing for it (state, targets, observations, diagnostics, the
+  // scratch row of the next step) and sets bit 7 of its host-visible terminated byte.  mir_step_end then steps exactly those envs on the
+  // wave-per-env kernel (48 points, no thinning) from the untouched state rows and recomputes their scratch rows (`env_list`).
+  int exact;
+  // phase 1 only: the launch serves the envs env_list[0 .. B) (B = the list's length) instead of envs 0 .. B; may point into pinned host memory
+  const int32_t* env_list;
 };
 #define K16_PRE_MROW 0     /* 16 lanes x 16: rows of the regularised mass matrix */
 #define K16_PRE_BIAS 256   /* 16: qfrc_bias */

@@ -296,7 +296,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   const int jbs = (grp & 1) * JB_SKEW;  // (EnvLds::Jb_)
   const int env_raw = blockIdx.x * EPB + grp;
   const bool valid = env_raw < a.B;
-  const int env = valid ? env_raw : a.B - 1;
+  int env = valid ? env_raw : a.B - 1;
+  // (exact contacts: the action-independent half for a LIST of envs -- the ones the wave kernel has just stepped; see StepArgs::env_list)
+  if constexpr (VARIANT == 3) { if (a.env_list) env = a.env_list[env]; }
   EnvLds& S = s_env[grp];
 
   // (SPEC: the headline scene's sizes and options are literals -- SpecPick, emitted by mir_compile into mir_spec_pick.h -- so
@@ -377,6 +379,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   // ... and before the solver has converged where the mask provably cannot change any more (see mir_model.h: term_bound_ok)
   const bool term_bound = (VARIANT == 0 || VARIANT == 5) && term_early && m->term_bound_ok != 0 && a.term_host != nullptr && !a.no_early_mask;
   const int term_zlane = SPEC ? SpecPick::term_zlane : m->term_zlane;
+  // exact contacts (StepArgs::exact): an env whose candidate contact points exceed this is DEFERRED to the wave kernel -- the launch
+  // computes on (its lanes cannot leave the wave) but stores nothing for it and flags its terminated byte (wave-uniform; never without the flag)
+  constexpr bool DEFER = VARIANT == 0 || VARIANT == 4 || VARIANT == 5;
+  const int defer_above = (DEFER && a.exact) ? (max_contacts < MAXCON ? max_contacts : MAXCON) : 0x7fffffff;
+  bool ovf_env = false;  // this lane's env is deferred: set where the step reads the `coupled` word (uniform over the env's row)
 
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
   // (lane = candidate).  Needs the link poses and the model table in LDS, nothing else: in the DUAL instantiation the second
@@ -896,6 +903,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       hk.axis = v3(h3.x, h3.y, h3.z);
     };
     const uint64_t hparents = m->parents;
+    bool ovf_h = false;  // (rotated launch, exact contacts: this env is deferred -- no scratch row of the next step is stored for it)
     if (ROT) {
       // rotated launch.  First, as in the fused launch, this wave hands the main wave the contact rows of the step it is solving
       // (here they come from the scratch row the previous launch left) and the all-rows-active Hessian accumulated from them
@@ -903,6 +911,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         const float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
         const f4 head = *reinterpret_cast<const f4*>(pre + K16_PRE_HEAD);
         const int nc = __float_as_int(head.x);
+        ovf_h = ((__float_as_int(head.y) >> 20) & 255) > defer_above;
         if (lane == 0) { S.ncon = nc; S.coupled = __float_as_int(head.y); S.ncand = 0; }
         if (lane < nc) stv(S.con.cmeta[lane], *reinterpret_cast<const f4*>(pre + K16_PRE_CMETA + 4 * lane));
         jrows_load(pre, nc, (uint64_t)__float_as_uint(head.z) | ((uint64_t)__float_as_uint(head.w) << 32), S);
@@ -952,7 +961,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       if (PRE || ROT) {
         // the action-independent half ends here: contact data and Jacobian rows go to the pre buffer (the all-active Hessian is
         // accumulated from them by this wave at the start of the launch that consumes them, while the main wave starts on the action)
-        if (valid) {
+        if (valid && !ovf_h) {
           float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
           const int nc = S.ncon;
           const uint64_t qm = jrows_store(pre, nc, S);
@@ -1119,16 +1128,17 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     // straight into pinned host memory (write-through, system scope), each byte = term | tag << 1; its trip over PCIe runs under the
     // state and observation stores below.  The tag changes from launch to launch, so the host recognises the bytes of THIS launch by
     // themselves (sync mode 3: no fence, no ticket, nothing waits).
-    const bool term_now = valid && above(S.xpos[ob][2], mdl_reward_z);
+    const bool term_now = valid && !ovf_env && above(S.xpos[ob][2], mdl_reward_z);
     if (VARIANT != 1 && a.term_host && !term_early) {
-      const unsigned long long tb = __ballot(term_now && lane == 0);
+      const unsigned long long tb = __ballot(term_now && lane == 0), db = __ballot(ovf_env && valid && lane == 0);
       if (tid == 0) {
-        const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
+        const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24 |
+                              (uint32_t)(db & 1u) << 7 | (uint32_t)(db >> 16 & 1u) << 15 | (uint32_t)(db >> 32 & 1u) << 23 | (uint32_t)(db >> 48 & 1u) << 31;
         __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + (size_t)blockIdx.x * a.term_wstride, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
-    if (valid) {
+    if (valid && !ovf_env) {  // (a deferred env -- exact contacts -- keeps the state it had: the wave kernel steps it from there)
       if (a.poses && lane < nb) {  // (link poses for the rasteriser: the pose-refresh launch, and every integrating launch once a render has been asked for)
         float* p = a.poses + ((size_t)env * 2 * G + lane) * 4;
         *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
@@ -1394,7 +1404,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         r0 = ldv(&S.M[lane][0]); r1 = ldv(&S.M[lane][4]); r2 = ldv(&S.M[lane][8]); r3 = ldv(&S.M[lane][12]);
       }
       if (pre_now) {
-        if (valid) {
+        if (valid && !ovf_env) {
           float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
           const f4 rq[4] = {r0, r1, r2, r3};
 #pragma unroll
@@ -1482,6 +1492,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     const int nefc = 4 * ncon + __popc(limmask);
     // the Hessian is block diagonal by tree unless a contact joins the arm and the cube somewhere in this wave
     const int cpl = S.coupled;  // bit 0: some contact joins the trees; bits 1 .. 16: contact c belongs to the second tree; 20 .. 27: see contacts_build
+    if (DEFER && (!ROT || step == 0)) ovf_env = ((cpl >> 20) & 255) > defer_above;  // (exact contacts: more candidate points than lanes)
     const int hsplit = __any((cpl & 1) != 0) ? 0 : mdl_split;
     // Where no contact joins the two trees the problem SEPARATES -- f = f_A(a_A) + f_B(a_B), block-diagonal Hessian.  The line search
     // stays one per env, but a step is ACCEPTED tree by tree (below), so that each tree's own cost decreases monotonically: what the
@@ -1626,10 +1637,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         const float az = lane_gather(row4 + (term_zlane << 2), qacc);
         const float zp = S.qpos[mdl_obj_qadr + 2] + dt * (S.qvel[term_zlane] + dt * az);
         const float slack = 2.0f * dt * dt * (2.4142137f * gm + 1.0f) + 1e-5f;
-        const bool decided = !valid || fabsf(zp - mdl_reward_z) > slack;
+        const bool decided = !valid || ovf_env || fabsf(zp - mdl_reward_z) > slack;  // (a deferred env's byte says so, whatever its height)
         if (!__any(!decided)) {
-          const unsigned long long tb = __ballot(valid && above(zp, mdl_reward_z) && lane == 0);
-          term_bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
+          const unsigned long long tb = __ballot(valid && !ovf_env && above(zp, mdl_reward_z) && lane == 0), db = __ballot(ovf_env && valid && lane == 0);
+          term_bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24 |
+                      (uint32_t)(db & 1u) << 7 | (uint32_t)(db >> 16 & 1u) << 15 | (uint32_t)(db >> 32 & 1u) << 23 | (uint32_t)(db >> 48 & 1u) << 31;
           if (tid == 0)
             __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + (size_t)blockIdx.x * a.term_wstride, term_bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1845,7 +1857,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     }
     if (DUAL && (!post_now || ROT) && !met4) __syncthreads();  // (4) (no Hessian was needed: the collision wave is let go)
     if (a.out_qacc && valid && isdof && step == 0) a.out_qacc[(size_t)env * nv + lane] = qacc;
-    if (a.diag && valid && lane == 0) {
+    if (a.diag && valid && !ovf_env && lane == 0) {
       a.diag[(size_t)env * 4 + 0] = ncon;
       a.diag[(size_t)env * 4 + 1] = nefc;
       a.diag[(size_t)env * 4 + 2] = niter;
@@ -1870,10 +1882,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // GenesisEnv.step's D->H copy of `terminated`, done by the kernel: see the epilogue; here ~1 us earlier, so that the trip
       // over PCIe is over when the launch ends
       WSYNC();
-      const bool tn = valid && above(S.qpos[mdl_obj_qadr + 2], mdl_reward_z);
-      const unsigned long long tb = __ballot(tn && lane == 0);
+      const bool tn = valid && !ovf_env && above(S.qpos[mdl_obj_qadr + 2], mdl_reward_z);
+      const unsigned long long tb = __ballot(tn && lane == 0), db = __ballot(ovf_env && valid && lane == 0);
       if (tid == 0) {
-        const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24;
+        const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24 |
+                              (uint32_t)(db & 1u) << 7 | (uint32_t)(db >> 16 & 1u) << 15 | (uint32_t)(db >> 32 & 1u) << 23 | (uint32_t)(db >> 48 & 1u) << 31;
         // (bytes that left from inside the solver loop are checked against the integrated state: a difference would mean the bound
         //  was violated -- it is counted, mir_debug_early_mask_stats, and the right bytes are stored over the wrong ones)
         if (!term_sent || bits != term_bits)
@@ -1911,10 +1924,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // divergence guard (diagnostics on): an env whose integrated state holds a NaN or an Inf is flagged in its
       // diagnostics record -- bit 30 of word 3, sticky over the steps of a rollout launch -- and counted; its `terminated` is False
       // (mir_dev.h: above()).  The other envs of the wave are not touched by it: every reduction and gather stays inside an env's row.
-      const bool nf = nonfinite(S.qpos[lane]) || (lane + G < qst && nonfinite(S.qpos[lane + G])) || nonfinite(S.qvel[lane]);
+      // (only the words of the rows that are ever written: a scene with nq <= 12 keeps stale LDS in S.qpos[qst .. 15] -- ADVICE r4)
+      const bool nf = (lane < qst && nonfinite(S.qpos[lane])) || (lane + G < qst && nonfinite(S.qpos[lane + G])) || nonfinite(S.qvel[lane]);
       const bool bad = ((uint32_t)(__ballot(nf) >> (grp * G)) & 0xffffu) != 0u;
       bad_acc = bad_acc || bad;
-      if (valid && lane == 0) {
+      if (valid && !ovf_env && lane == 0) {
         a.diag[(size_t)env * 4 + 3] = S.ncand | (cpl >> 20 & 255) << 8 | (bad_acc ? 1 << 30 : 0);
         if (bad && a.early_stats) atomicAdd(a.early_stats, 1u);  // (word 0: env-steps that ended non-finite, since the last reset of the counters)
       }

@@ -47,6 +47,13 @@ struct StepArgs64 {
   // swapped by the host: every workgroup of a launch sees the same snapshot, so the order is a permutation).
   const uint8_t* cost_in;
   uint8_t* cost_out;
+  // LIST MODE (exact contacts of a scene that lives on the 16-lane kernel: mir_set_exact_contacts, mir_step_end).  The launch serves the
+  // envs env_list[0 .. B) (B = the list's length, grid = B; the list may sit in pinned host memory) of a handle whose state rows are in
+  // the 16-LANE kernel's layout: qpos (B_handle, lay16_qst), qvel / target / qacc_ws (B_handle, 16) indexed by DOF (this kernel's own
+  // rows are 64 wide and indexed by lane).  Outputs and diagnostics go to the env's own rows; the host-visible terminated byte of list
+  // entry k goes to term_host[k].  No pose cache (poses / fkvalid null), no dispatch order (cost_in / cost_out null).
+  const int32_t* env_list;  // null = the envs 0 .. B of a handle of this kernel
+  int lay16_qst;            // list mode: row stride of qpos in the 16-lane layout (> 0); 0 = this kernel's own layout
 };
 
 extern "C" __attribute__((visibility("hidden"))) int mir_launch_step64(const StepArgs64* args, hipStream_t stream);

@@ -494,6 +494,28 @@ void mir_step64_kernel(StepArgs64 a) {
     }
     env = base + 64 * L + pos;
   }
+  // list mode (mir_step64.h): the workgroup serves list entry `slot`; state rows in the 16-lane kernel's layout
+  const int slot = blockIdx.x;
+  if (a.env_list) env = a.env_list[slot];
+  const bool lay16 = a.lay16_qst > 0;  // wave-uniform
+  // the state rows of the env, from LDS to HBM, in the layout of the handle (called where the step is integrated)
+  auto store_state = [&](Env64& Sx, int lane_, int dof16_, bool isdof_) {
+    if (lay16) {
+      const bool hasd = isdof_ && dof16_ >= 0;
+      if (a.mode == 0) {
+        if (lane_ < a.lay16_qst) a.qpos[(size_t)env * a.lay16_qst + lane_] = Sx.qpos[lane_];
+        if (hasd) { a.qvel[(size_t)env * 16 + dof16_] = Sx.qvel[lane_]; a.qacc_ws[(size_t)env * 16 + dof16_] = Sx.qacc_ws[lane_]; }
+      }
+      if (a.action && hasd) a.target[(size_t)env * 16 + dof16_] = Sx.target[lane_];
+    } else {
+      if (a.mode == 0) {
+        a.qpos[(size_t)env * K64_QSTRIDE + lane_] = Sx.qpos[lane_];
+        a.qvel[(size_t)env * NL + lane_] = Sx.qvel[lane_];
+        a.qacc_ws[(size_t)env * NL + lane_] = Sx.qacc_ws[lane_];
+      }
+      if (a.action) a.target[(size_t)env * NL + lane_] = Sx.target[lane_];
+    }
+  };
 
   const int nb = m->nbody, nv = m->nv, nq = m->nq;
   const int ngeom = m->ngeom, npair = m->npair, max_contacts = m->max_contacts, enable_collision = m->enable_collision;
@@ -539,6 +561,7 @@ void mir_step64_kernel(StepArgs64 a) {
   const float d_iw0 = m->d_invweight0[lane], d_lk = m->d_k[lane], d_lb = m->d_b[lane];
   const float d_si0 = m->d_solimp[lane][0], d_si1 = m->d_solimp[lane][1], d_si2 = m->d_solimp[lane][2], d_si3 = m->d_solimp[lane][3], d_si4 = m->d_solimp[lane][4];
   const int obs_qadr = m->obs_qadr[lane];
+  const int dof16 = m->d_dof[lane];  // (compact dof index of this lane, -1 for none: the row index of the 16-lane layout)
   // lane = geom: frame in its body, staged tables
   const int gl = lane < ngeom ? lane : 0;
   const int g_bodyl = m->g_body[gl];
@@ -561,13 +584,22 @@ void mir_step64_kernel(StepArgs64 a) {
   f4 cpos = {0, 0, 0, 0}, cquat = {0, 0, 0, 0};
   bool cached = false;
   if (!helper) {
-    q_in = a.qpos[(size_t)env * K64_QSTRIDE + lane]; qv_in = a.qvel[(size_t)env * NL + lane]; ws_in = a.qacc_ws[(size_t)env * NL + lane];
-    tg = a.target[(size_t)env * NL + lane];
+    if (lay16) {  // (the 16-lane kernel's rows: qpos by address, the rest by dof; lanes without a dof hold zeros, as this kernel's own rows do)
+      const bool hasd = isdof && dof16 >= 0;
+      q_in = lane < a.lay16_qst ? a.qpos[(size_t)env * a.lay16_qst + lane] : 0.0f;
+      qv_in = hasd ? a.qvel[(size_t)env * 16 + dof16] : 0.0f; ws_in = hasd ? a.qacc_ws[(size_t)env * 16 + dof16] : 0.0f;
+      tg = hasd ? a.target[(size_t)env * 16 + dof16] : 0.0f;
+    } else {
+      q_in = a.qpos[(size_t)env * K64_QSTRIDE + lane]; qv_in = a.qvel[(size_t)env * NL + lane]; ws_in = a.qacc_ws[(size_t)env * NL + lane];
+      tg = a.target[(size_t)env * NL + lane];
+    }
     au = (a.action && lane < a.nu) ? a.action[(size_t)env * a.nu + lane] : 0.0f;
-    // (the cached poses travel with their validity flag; (B, 2, 32, 4): the speculative read is in bounds)
-    const float* pose_p = a.poses + ((size_t)env * 2 * NB + (lane & (NB - 1))) * 4;
-    cpos = *reinterpret_cast<const f4*>(pose_p); cquat = *reinterpret_cast<const f4*>(pose_p + 4 * NB);
-    cached = a.fkvalid[env] != 0;  // wave-uniform
+    if (a.poses) {
+      // (the cached poses travel with their validity flag; (B, 2, 32, 4): the speculative read is in bounds)
+      const float* pose_p = a.poses + ((size_t)env * 2 * NB + (lane & (NB - 1))) * 4;
+      cpos = *reinterpret_cast<const f4*>(pose_p); cquat = *reinterpret_cast<const f4*>(pose_p + 4 * NB);
+      cached = a.fkvalid[env] != 0;  // wave-uniform
+    }
   }
   __builtin_amdgcn_sched_barrier(0);  // (nothing below may move in front of the loads above)
   if (!DUAL || helper) {
@@ -1900,7 +1932,7 @@ void mir_step64_kernel(StepArgs64 a) {
       // PCIe runs under them (see the 16-lane kernel)
       const V3 po = ld3(&S.qpos[obj_qadr]);
       const float r0 = reward_of(po, obj2_qadr >= 0 ? ld3(&S.qpos[obj2_qadr]) : po);
-      __hip_atomic_store(&a.term_host[env], (uint8_t)((r0 == 1.0f ? 1u : 0u) | a.term_tag << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&a.term_host[a.env_list ? slot : env], (uint8_t)((r0 == 1.0f ? 1u : 0u) | a.term_tag << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // kinematics of the new state: observations of this step, and the next step's starting poses
     if (fk_split) {
@@ -1910,12 +1942,7 @@ void mir_step64_kernel(StepArgs64 a) {
         st3v(S.xpos[lane], ld3(&S.qpos[bk.qadr]));
         st4v(S.xquat[lane], qnormalize(ld4(&S.qpos[bk.qadr + 3])));
       }
-      if (a.mode == 0) {
-        a.qpos[(size_t)env * K64_QSTRIDE + lane] = S.qpos[lane];
-        a.qvel[(size_t)env * NL + lane] = S.qvel[lane];
-        a.qacc_ws[(size_t)env * NL + lane] = S.qacc_ws[lane];
-      }
-      if (a.action) a.target[(size_t)env * NL + lane] = S.target[lane];
+      store_state(S, lane, dof16, isdof);
       WSYNC();
       __syncthreads();  // (6)
     } else {
@@ -1960,21 +1987,18 @@ void mir_step64_kernel(StepArgs64 a) {
   // (the host-visible terminated byte goes out first: its trip over PCIe runs under the stores below)
   const float rew = reward_now();
   if (lane == 0 && a.term_host && !term_early)
-    __hip_atomic_store(&a.term_host[env], (uint8_t)((rew == 1.0f ? 1u : 0u) | a.term_tag << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (lane < nb) {
-    float* p = a.poses + ((size_t)env * 2 * NB + lane) * 4;
-    *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
-    *reinterpret_cast<f4*>(p + 4 * NB) = ldv(S.xquat[lane]);
+    __hip_atomic_store(&a.term_host[a.env_list ? slot : env], (uint8_t)((rew == 1.0f ? 1u : 0u) | a.term_tag << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (a.poses) {  // (null in list mode: the handle's pose buffer has the 16-lane kernel's shape)
+    if (lane < nb) {
+      float* p = a.poses + ((size_t)env * 2 * NB + lane) * 4;
+      *reinterpret_cast<f4*>(p) = ldv(S.xpos[lane]);
+      *reinterpret_cast<f4*>(p + 4 * NB) = ldv(S.xquat[lane]);
+    }
+    if (lane == 0) a.fkvalid[env] = 1;
   }
-  if (lane == 0) a.fkvalid[env] = 1;
   // ---- store state ---------------------------------------------------------------------------------
   if (!fk_split) {  // (with the split closing FK the state rows left while wave 1 ran the kinematics)
-    if (a.mode == 0) {
-      a.qpos[(size_t)env * K64_QSTRIDE + lane] = S.qpos[lane];
-      a.qvel[(size_t)env * NL + lane] = S.qvel[lane];
-      a.qacc_ws[(size_t)env * NL + lane] = S.qacc_ws[lane];
-    }
-    if (a.action) a.target[(size_t)env * NL + lane] = S.target[lane];
+    store_state(S, lane, dof16, isdof);
   }
   (void)nq;
   // ---- observations (get_obs / compute_reward / terminated) ---------------------------------------

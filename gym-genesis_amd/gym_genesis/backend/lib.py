@@ -98,6 +98,12 @@ def load_library() -> C.CDLL:
     lib.mir_get_early_mask.restype = C.c_int
     lib.mir_get_state_version.argtypes = [vp]
     lib.mir_get_state_version.restype = C.c_int
+    lib.mir_set_exact_contacts.argtypes = [vp, C.POINTER(MirSceneSpec), i32]
+    lib.mir_set_exact_contacts.restype = C.c_int
+    lib.mir_get_exact_contacts.argtypes = [vp]
+    lib.mir_get_exact_contacts.restype = C.c_int
+    lib.mir_get_exact_stats.argtypes = [vp, C.POINTER(C.c_uint64), i32]
+    lib.mir_get_exact_stats.restype = C.c_int
     lib.mir_render.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), i32, vp, vp, vp]
     lib.mir_render.restype = C.c_int
     lib.mir_visual_sizeof.restype = C.c_int
@@ -171,7 +177,8 @@ class StepHelpers:
         (reference env.py:61); a pageable array sent through `tensor.to(device)` costs ~25 us per step.  Two buffers take turns:
         a buffer is rewritten two steps later, and a step is closed (mir_step_end: the launch has read its action long before
         its terminated bytes leave) before the next one begins.  Only for the begin / end step path (fast_step)."""
-        a = np.asarray(action.numpy() if isinstance(action, torch.Tensor) else action, dtype=np.float32)
+        # (a host tensor may carry requires_grad or be a subclass: detach; device tensors never come here -- see the callers)
+        a = np.asarray(action.detach().cpu().numpy() if isinstance(action, torch.Tensor) else action, dtype=np.float32)
         if a.shape != (self.num_envs, dim):
             raise ValueError(f"action must have shape {(self.num_envs, dim)}, got {tuple(a.shape)}")
         ring = self.__dict__.get("_act_stage")
@@ -240,8 +247,13 @@ class StepHelpers:
         if host_terminated:
             # (a HOST action -- NumPy, list, CPU tensor -- is staged in pinned memory and read in place: stage_action; the step is
             #  closed by step_end() before the buffer comes round again)
-            on_dev = type(action) is torch.Tensor and action.device == torch.device(self.device)
-            self.step_go_ptr(self.as_action(action, self.nu).data_ptr() if on_dev else self.stage_action(action, self.nu))
+            # (any tensor on a GPU -- this device or another, a subclass, a Parameter -- goes through as_action's .to(device); the
+            #  converted tensor stays alive in `action` until the launch is queued)
+            if isinstance(action, torch.Tensor) and action.is_cuda:
+                action = self.as_action(action, self.nu)
+                self.step_go_ptr(action.data_ptr())
+            else:
+                self.step_go_ptr(self.stage_action(action, self.nu))
             host = np.empty(self.num_envs, dtype=np.bool_)
             self._host_pending = (host, host.ctypes.data)
         else:
@@ -566,6 +578,22 @@ class MirScene(StepHelpers):
         out = (C.c_uint32 * 2)()
         self._check(self.lib.mir_debug_early_mask_stats(self.h, out, 1 if reset else 0, self._stream()))
         return int(out[0]), int(out[1])
+
+    def set_exact_contacts(self, on: bool = True) -> None:
+        """mir_set_exact_contacts: from now on the begin / end step path defers every env whose narrowphase finds more contact
+        points than the 16-lane kernel keeps (16) and steps it on the wave-per-env kernel instead (48 points, no thinning); the other
+        envs are computed as before.  step() / step_fused() then wait for their step; step_packed() / rollout*() are refused."""
+        self._check(self.lib.mir_set_exact_contacts(self.h, C.byref(self.spec), 1 if on else 0))
+
+    @property
+    def exact_contacts(self) -> bool:
+        return bool(self.lib.mir_get_exact_contacts(self.h))
+
+    def exact_stats(self, reset: bool = False) -> dict:
+        """mir_get_exact_stats: steps closed by step_end, steps that had deferred envs, deferred env-steps, most deferred envs in a step."""
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.mir_get_exact_stats(self.h, out, 1 if reset else 0))
+        return {"steps": int(out[0]), "overflow_steps": int(out[1]), "overflow_env_steps": int(out[2]), "overflow_envs_max": int(out[3])}
 
     @property
     def early_mask(self) -> bool:

@@ -119,6 +119,7 @@ class CopyPathGather:
     or IPC does not work falls back to the RCCL collective on every rank alike (make_copy_gather)."""
 
     SEQ_TABLE = 1 << 16
+    SEQ_KEEP = 64   # words kept BELOW the table's base after a rebase: a release() of a gather pushed just before the rebase finds its word
     NSLOT = 2
     EVENT_DEPTH = 64  # pushes whose read-completion events are kept (wait_source / lag look this far back)
 
@@ -135,7 +136,10 @@ class CopyPathGather:
             self.recv = torch.zeros((self.NSLOT, self.world, self.numel), dtype=dtype, device=device)
             self.flag = torch.zeros((self.NSLOT, self.world), dtype=torch.int32, device=device)
             self.ack = torch.zeros((self.world,), dtype=torch.int32, device=device)
-            self._seqs = torch.arange(1, self.SEQ_TABLE + 1, dtype=torch.int32, device=device)
+            # word i = sequence number _seq_base - SEQ_KEEP + 1 + i: the table reaches SEQ_KEEP numbers back behind its base, so that the
+            # consumer's release(k) still finds its word when push k + 1 has just rebased the table (it was dropped, the ack
+            # stayed at k - 1 and the next push timed out under flow control)
+            self._seqs = torch.arange(1 - self.SEQ_KEEP, self.SEQ_TABLE + 1, dtype=torch.int32, device=device)
             mine = (reduce_tensor(self.recv), reduce_tensor(self.flag), reduce_tensor(self.ack))
         except Exception as e:  # noqa: BLE001
             local_err, mine = e, None
@@ -216,11 +220,11 @@ class CopyPathGather:
             st.wait_stream(cur)   # the block's producer
         if self._lib is not None:
             rc = self._lib.mir_p2p_push_streams(self._dst[slot], self.world, block.data_ptr(), n * self._esz, self._fdst[slot],
-                                                self._seq_ptr + 4 * (k - self._seq_base), self._sptr)
+                                                self._seq_ptr + 4 * (k - self._seq_base + self.SEQ_KEEP), self._sptr)
             if rc != 0:
                 raise RuntimeError(f"mir_p2p_push_streams: {self._lib.mir_last_error().decode()}")
         else:
-            word = self._seqs[k - self._seq_base:k - self._seq_base + 1]
+            word = self._seqs[k - self._seq_base + self.SEQ_KEEP:k - self._seq_base + self.SEQ_KEEP + 1]
             for p, st in enumerate(self.streams):
                 with torch.cuda.stream(st):
                     self.peer_recv[p][slot, self.rank, :n].copy_(block.reshape(-1), non_blocking=True)
@@ -294,19 +298,21 @@ class CopyPathGather:
     def release(self, seq: int) -> None:
         """This rank is done with gather `seq` (and all earlier ones): its word goes to every rank, behind whatever the caller's
         current stream has queued (the consumer's reads)."""
-        if seq <= self._released or seq <= self._seq_base:   # (already released; or older than the sequence table: long since overwritten)
+        if seq <= self._released:
             return
+        if seq <= self._seq_base - self.SEQ_KEEP:   # (older than the table reaches back: only a consumer more than SEQ_KEEP gathers behind)
+            raise ValueError(f"release: gather {seq} is more than {self.SEQ_KEEP} behind the sequence table's base {self._seq_base}")
         if seq - self._seq_base > self.SEQ_TABLE:
             raise ValueError("release: sequence number ahead of the pushes")
         cur = torch.cuda.current_stream(self.device)
         for st in self.streams:
             st.wait_stream(cur)
         if self._lib is not None:
-            rc = self._lib.mir_p2p_push_streams(self._adst, self.world, self._seq_ptr, 0, self._adst, self._seq_ptr + 4 * (seq - 1 - self._seq_base), self._sptr)
+            rc = self._lib.mir_p2p_push_streams(self._adst, self.world, self._seq_ptr, 0, self._adst, self._seq_ptr + 4 * (seq - 1 - self._seq_base + self.SEQ_KEEP), self._sptr)
             if rc != 0:
                 raise RuntimeError(f"mir_p2p_push_streams: {self._lib.mir_last_error().decode()}")
         else:
-            word = self._seqs[seq - 1 - self._seq_base:seq - self._seq_base]
+            word = self._seqs[seq - 1 - self._seq_base + self.SEQ_KEEP:seq - self._seq_base + self.SEQ_KEEP]
             for p, st in enumerate(self.streams):
                 with torch.cuda.stream(st):
                     self.peer_ack[p][self.rank:self.rank + 1].copy_(word, non_blocking=True)

@@ -34,8 +34,9 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
                 and action.device == dev):
             if coerce is not None:
                 action = coerce(action)
-            if type(action) is tensor and action.device == dev:
-                aptr = as_action(action, action_dim).data_ptr()
+            if isinstance(action, tensor) and action.is_cuda:
+                action = as_action(action, action_dim)  # (kept alive in `action` until the launch is queued: alloc() below must not get its block)
+                aptr = action.data_ptr()
             else:
                 aptr = stage(action, action_dim)
         else:
@@ -80,7 +81,7 @@ def make_fast_step(task, mir, action_dim: int, agent_obs: int, env_obs: int, coe
                 and action.device == dev):
             if coerce is not None:
                 action = coerce(action)
-            if type(action) is tensor and action.device == dev:
+            if isinstance(action, tensor) and action.is_cuda:
                 action = as_action(action, action_dim)
                 aptr = action.data_ptr()
             else:

@@ -37,12 +37,17 @@ ENV_DIM = 11
 class FrankaCubePickBatch:
     def __init__(self, enable_pixels, observation_height, observation_width, num_envs, env_spacing,
                  camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None, link_shape: str = "capsule",
-                 contact_capacity: int = 16):
+                 contact_capacity: int = 16, exact_contacts: bool = False):
         # link_shape: collision stand-ins of links 1-7, "box" or "capsule" (models._add_franka); not a reference kwarg
         # contact_capacity: contact points kept per env (not a reference kwarg; Genesis keeps 100+ pairs).  16 = the 16-lane kernel
         # (manifolds thinned beyond that: 29 % of the env-steps of the reference's expert, same success rate -- tests/test_ref_expert.py);
         # 17 .. 48 = the same scene on the wave-per-env kernel, never thinned by that policy, several times slower
+        # exact_contacts (not a reference kwarg): keep the 16-lane kernel for the envs it serves exactly and hand the envs whose
+        # narrowphase finds more than 16 contact points -- only those, step by step -- to the wave-per-env kernel (48 points, no
+        # thinning): Genesis's own behaviour (every contact kept) at the 16-lane kernel's speed wherever no env overflows.
+        # reset() / step() / env.step() only; the device-side episode loop (rollout_autoreset) is refused by the library.
         self.contact_capacity = int(contact_capacity)
+        self.exact_contacts = bool(exact_contacts)
         self.enable_pixels = enable_pixels
         self.observation_height = observation_height
         self.observation_width = observation_width
@@ -73,6 +78,8 @@ class FrankaCubePickBatch:
         self._builder = builder
         self._mir = MirScene(builder.build(), self.num_envs)
         self._mir.set_diag(False)  # solver diagnostics (16 B per env-step) are a debugging aid: _mir.set_diag(True) to read them
+        if self.exact_contacts and self._mir.kernel == 16:
+            self._mir.set_exact_contacts(True)
         B, dev = self.num_envs, self._mir.device
         self.device = dev
         self.scene = SceneView(self._mir, env_spacing=self.env_spacing, global_num_envs=self.global_num_envs,

@@ -37,7 +37,9 @@ AGENT_OBS, ENV_OBS = 8, 11            # what get_obs() actually returns
 
 class CubePick:
     def __init__(self, enable_pixels, observation_height, observation_width, num_envs, env_spacing,
-                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None):
+                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None, exact_contacts: bool = False):
+        # exact_contacts (not a reference kwarg): see tasks/franka/cube_pick.py
+        self.exact_contacts = bool(exact_contacts)
         self.enable_pixels = enable_pixels
         self.observation_height = observation_height
         self.observation_width = observation_width
@@ -56,6 +58,8 @@ class CubePick:
         self._builder = builder
         self._mir = MirScene(builder.build(), self.num_envs)
         self._mir.set_diag(False)  # solver diagnostics (16 B per env-step) are a debugging aid: _mir.set_diag(True) to read them
+        if self.exact_contacts and self._mir.kernel == 16:
+            self._mir.set_exact_contacts(True)
         self.device = self._mir.device
         self.island_top_z = models.ISLAND_TOP_Z
         self.scene = SceneView(self._mir, env_spacing=env_spacing, global_num_envs=self.global_num_envs, offset=self.shard_lo)

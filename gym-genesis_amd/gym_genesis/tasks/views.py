@@ -140,7 +140,7 @@ class CameraView:
 
     def _spec(self, pos, lookat):
         # (the ctypes struct of a pose is built once: the observation renders ask for the same few poses every step)
-        key = (tuple(pos), tuple(lookat))
+        key = (tuple(pos), tuple(lookat), self.res, self.fov, self._up)
         cache = self.__dict__.setdefault("_specs", {})
         spec = cache.get(key)
         if spec is None:
@@ -152,7 +152,10 @@ class CameraView:
     def render_global(self) -> torch.Tensor:
         """(H, W, 3) uint8 device tensor: every env at its grid offset, camera at its current pose."""
         img = self._mir.render(self._spec(self.pos, self.lookat), self._vis, mode=1, env_offset=self._offsets)
-        self._last_global = (getattr(self._mir, "state_version", None), self.pos, self.lookat, img)
+        # (what render() may reuse: the image is the tensor handed out as observation['pixels'], so its in-place version counter is kept
+        #  too -- an edit by the caller, a normalisation or an overlay, makes render() draw again)
+        self._last_global = (getattr(self._mir, "state_version", None), self.pos, self.lookat, self.res, self.fov, self._up, id(self._vis),
+                             img, img._version)
         return img
 
     def render_envs(self, pos=None, lookat=None, out=None) -> torch.Tensor:
@@ -173,7 +176,9 @@ class CameraView:
         #  moved since -- mir_get_state_version -- so it is copied out, not drawn again; the caller gets a fresh array either way)
         last = self.__dict__.get("_last_global")
         ver = getattr(self._mir, "state_version", None)
-        img = last[3] if last is not None and ver is not None and last[:3] == (ver, self.pos, self.lookat) else self.render_global()
+        same = (last is not None and ver is not None and last[:7] == (ver, self.pos, self.lookat, self.res, self.fov, self._up, id(self._vis))
+                and last[7]._version == last[8])
+        img = last[7] if same else self.render_global()
         return img.cpu().numpy(), None, None, None
 
     def start_recording(self) -> None:  # cube_stack_kitchen_batch.py:111-113; video encoding is out of scope

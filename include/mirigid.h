@@ -250,7 +250,7 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  * mir_step_begin / mir_step_go / mir_reset, which wait for its bytes and drop them.  mir_step_end is otherwise the only entry point
  * of the library that waits for the device.
  * How the wait is done (mir_get_sync_mode; environment variable MIR_SYNC_MODE overrides at mir_create):
- *   3  (default) every terminated byte carries a 7-bit tag (1..127, a counter only mir_step_begin advances) that changes from
+ *   3  (default) every terminated byte carries a 6-bit tag (1..63, a counter only mir_step_begin advances) that changes from
  *      launch to launch; the host spins until all B bytes show the tag of this launch -- no fence, no flag, nothing in the kernel
  *      waits for the PCIe acknowledgement
  *   2  every wave waits for its host store, the kernel's last workgroup then writes a sequence word into pinned host memory
@@ -288,6 +288,24 @@ int mir_get_split_step(MirHandle h);
  * latest registration wins). */
 int mir_step_prepare(MirHandle h, float* agent_pos, float* env_state, float* reward, uint8_t* terminated);
 int mir_step_go(MirHandle h, const float* action, void* stream);
+
+/* EXACT CONTACTS for scenes on the 16-lane kernel (no reference counterpart: Genesis keeps every contact point of its 100+ candidate
+ * pairs -- RigidOptions at gym_genesis/tasks/franka/cube_pick.py:46 -- while the 16-lane kernel keeps 16 per env and thins the
+ * manifolds beyond that; the reference's own expert, examples/franka/pick_cube_state.py:33-41,86-88, drives 29 % of its env-steps
+ * there).  With the switch on, a step launched by mir_step_begin / mir_step_go DEFERS every env whose narrowphase found more than 16
+ * candidate points: the launch stores nothing for it and says so in bit 7 of its terminated byte; mir_step_end then steps exactly those
+ * envs on the wave-per-env kernel (the same scene compiled with MIR_MAX_CONTACT points, never thinned below that) from their untouched
+ * state rows, with the step's action and into the step's output pointers, recomputes their part of the split step's hand-over, and
+ * returns when their terminated bytes have arrived too.  An env that is not deferred is computed exactly as without the switch; a
+ * step without deferred envs launches nothing extra.  `spec`: the spec the scene was created from (compiled once more, for the wave
+ * kernel; may be NULL when switching back on).  While the switch is on, mir_step and mir_step_fused run as begin + end (they wait for the
+ * step), and mir_step_packed / mir_rollout / mir_rollout_autoreset return MIR_E_INVALID (their steps are never closed on the host).
+ * MIR_E_INVALID for scenes of the wave kernel (nothing to do) and for sync modes other than 3.
+ * mir_get_exact_stats: out4 = {steps closed by mir_step_end, steps that had deferred envs, deferred env-steps, most deferred envs in one
+ * step} since the last reset of the counters (reset != 0 clears them). */
+int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on);
+int mir_get_exact_contacts(MirHandle h);
+int mir_get_exact_stats(MirHandle h, uint64_t* out4, int32_t reset);
 
 /* Same step, but every output of an env lands in ONE packed float32 row
  * rows[e*row_stride + ...] = [agent_pos (agent_dim) | env_state (env_dim) | reward | terminated(0/1)]

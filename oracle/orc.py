@@ -28,9 +28,9 @@ _libs = {}
 
 
 def load(f32: bool = False, flops=False):
-    """liborc64.so (float64 oracle), liborc32.so (float32 port) or liborc_flops.so / liborc_flops_big.so (the float32 port with
+    """liborc64.so (float64 oracle), liborc32.so / liborc32_big.so (float32 port at the pick-task / full capacities; f32 = True / "big") or liborc_flops.so / liborc_flops_big.so (the float32 port with
     counted arithmetic at the pick-task / full capacities; flops = True / "big")."""
-    key = ("_flops_big" if flops == "big" else "_flops") if flops else ("32" if f32 else "64")
+    key = ("_flops_big" if flops == "big" else "_flops") if flops else (("32_big" if f32 == "big" else "32") if f32 else "64")
     if key == "64" and os.environ.get("ORC_SANITIZE"):  # (tests/test_sanitizers_cpu.py: the ASan + UBSan build, `make -C oracle asan`)
         key = "64_asan"
     if key not in _libs:
@@ -179,6 +179,14 @@ class Oracle:
         if got < 0:
             raise KeyError(field)
         return out[:, :got]
+
+    def write_all(self, field: int, vals) -> None:
+        """field `field` of every env from the rows of vals (B, n) in one call (orc_write_batch)"""
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        assert v.ndim == 2 and v.shape[0] == self.B
+        self.lib.orc_write_batch.restype = C.c_int
+        if self.lib.orc_write_batch(self.model, self.data, C.c_int(self.B), C.c_int(field), v.ctypes.data_as(C.c_void_p), C.c_int(v.shape[1])) < 0:
+            raise KeyError(field)
 
     def counts_all(self):
         """(ncon, nefc, niter) int32 arrays over the envs (orc_counts_batch)."""

@@ -9,7 +9,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gym-genesis_amd"))
-from gym_genesis.sharding import make_copy_gather  # noqa: E402
+from gym_genesis.sharding import CopyPathGather, make_copy_gather  # noqa: E402
 
 
 def pattern(n, k, r, dev):
@@ -77,6 +77,30 @@ def main() -> int:
     assert ahead_max <= fc.NSLOT, ahead_max
     torch.cuda.synchronize()
     dist.barrier()
+    # ---- (C) the sequence table rebased under flow control, in the overlapped pattern NSLOT = 2 exists for: push k + 1, THEN consume
+    # and release k.  With the table shrunk to 8 words the rebase comes every 8 pushes, right between a push and the release of the
+    # gather before it (that release was dropped, the ack stayed behind and the next push timed out after 30 s)
+    CopyPathGather.SEQ_TABLE, CopyPathGather.SEQ_KEEP = 8, 4
+    try:
+        rb, why = make_copy_gather(numel, dev, flow_control=True)
+        assert rb is not None, why
+        prev = None
+        for k in range(40):
+            seq = rb.push(pattern(numel, k, rank, dev), timeout_s=10.0)
+            if prev is not None:
+                rb.wait(prev, timeout_s=10.0)
+                got = rb.gathered(prev, numel).clone()
+                for r in range(world):
+                    assert torch.equal(got[r], pattern(numel, prev - 2, r, dev)), (rank, prev, r)
+                rb.release(prev)
+            prev = seq
+        rb.wait(prev, timeout_s=10.0)
+        rb.release(prev)
+        assert rb._seq_base >= 32, rb._seq_base   # (the table was rebased at least four times)
+        torch.cuda.synchronize()
+        dist.barrier()
+    finally:
+        CopyPathGather.SEQ_TABLE, CopyPathGather.SEQ_KEEP = 1 << 16, 64
     dist.destroy_process_group()
     if rank == 0:
         print("COPY_GATHER_OK", world, flush=True)

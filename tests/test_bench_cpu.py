@@ -93,3 +93,64 @@ def test_sysfs_probes_never_raise():
     nodes, cpus = bench.gpu_numa_nodes(), bench.numa_cpu_lists()
     assert nodes is None or isinstance(nodes, list)
     assert isinstance(cpus, dict)
+
+
+def test_compact_line_keeps_the_head_and_fits_the_drivers_tail():
+    """The printed line (bench.compact_line): what the driver's record must show comes first and in full, every string is short, and
+    secondary detail is dropped -- in a fixed order, listed in the line -- until it fits 6000 bytes."""
+    long = "x" * 900
+    out = {"metric": bench.METRIC, "value": 1.7e8, "unit": "env-steps/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 0.024,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "w", "host_thread": "pinned to cpu 3", "obs_gather": long},
+           "early_mask": {"sent": 123, "mismatches": 0, "workgroup_launches": 456, "note": long},
+           "value_median_region": 1.8e8, "hot_path_rate": 2.0e8, "api_over_hot_path": 0.85,
+           "roofline": {"bound": "hbm", "frac": 0.0117, "note": long, "trace": long},
+           "cpu_baseline": {"value": 1e6, "sample": long},
+           "sync_step_floor": {"note": long, "filler": ["y" * 100] * 30}, "repeat_us_per_step": {"min": 1.0, "filler": ["z" * 100] * 30},
+           "secondary": {"batch_sweep": {"rows": [[1024, 1.0]]}}, "scripted_grasp": {"env_step_exact_contacts": {"overflow_env_frac": 0.016}}}
+    c = bench.compact_line(out)
+    line = json.dumps(c)
+    assert len(line) <= bench.LINE_LIMIT
+    assert list(c)[:8] == ["metric", "value", "unit", "value_median_region", "hot_path_rate", "api_over_hot_path", "early_mask_sent", "early_mask_mismatches"]
+    assert c["early_mask_sent"] == 123 and c["early_mask_mismatches"] == 0 and c["config"]["early_mask"]["mismatches"] == 0
+    assert c["config"]["hot_path_rate"] == c["hot_path_rate"] and "trace" not in c["roofline"] and len(c["roofline"].get("note", "")) <= bench.NOTE_LIMIT
+    assert len(c["cpu_baseline"]["sample"]) <= bench.NOTE_LIMIT and len(c["config"]["obs_gather"]) <= bench.NOTE_LIMIT
+    assert c["dropped_for_length"][0] == "sync_step_floor" and "secondary" in c and "scripted_grasp" in c
+    assert out["early_mask"]["sent"] == 123 and "early_mask_sent" not in out   # (the full record is left as it was)
+
+
+def test_preflight_places_ranks_or_refuses():
+    """bench.preflight (the launching parent, before any rank exists): one line per rank with device, NUMA node, cores and peer
+    access; non-zero when the ranks do not fit the GPUs."""
+    import io
+
+    buf = io.StringIO()
+    assert bench.preflight(8, False, device_count=8, peer_matrix=[[True] * 8] * 8, out=buf) == 0
+    txt = buf.getvalue()
+    assert txt.count("rank ") == 8 and "cuda:7" in txt and "can address peers 11111111" in txt
+    buf = io.StringIO()
+    assert bench.preflight(4, False, device_count=1, peer_matrix=None, out=buf) == 2 and "FAILED" in buf.getvalue()
+    buf = io.StringIO()
+    assert bench.preflight(2, True, device_count=1, peer_matrix=None, out=buf) == 0 and "shared" in buf.getvalue()
+    buf = io.StringIO()
+    pm = [[True, False], [False, True]]
+    assert bench.preflight(2, False, device_count=2, peer_matrix=pm, out=buf) == 0 and "RCCL collective" in buf.getvalue()
+
+
+def test_more_ranks_than_gpus_is_refused_before_any_rank_starts():
+    """`python bench.py --gpus 3` in a container without GPUs: the parent's preflight prints the placement table and exits non-zero;
+    no rank is spawned."""
+    import torch
+
+    if torch.cuda.device_count() >= 3:
+        pytest.skip("three GPUs present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "0"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 2 and "[bench preflight] FAILED" in r.stderr and "rank 2: device NONE" in r.stderr
+
+
+def test_cpu_baseline_runs_in_a_child_with_bound_threads_and_reports_its_spread():
+    cb = bench.cpu_baseline(1.0)
+    assert cb["kind"] == "port" and cb["min"] <= cb["value"] <= cb["max"] and cb["threads"] == cb["cores"] >= 1 and cb["value"] > 1e4
+    assert "median of 5 runs" in cb["sample"]

@@ -494,3 +494,11 @@ def test_numpy_actions_are_read_in_place_and_equal_device_actions(task, robot):
     with pytest.raises((ValueError, RuntimeError)):  # (the SO-101 task reshapes first: torch's error)
         a.step(np.zeros((B, dim + 1), np.float32))
     a.step(np.zeros((B, dim), np.float32))  # (the env stays usable)
+    #  tensors that are not plain float32 tensors on the device: a Parameter on the device, a float64 device tensor, a CPU
+    # tensor that requires grad -- all accepted, like the reference's permissive action handling
+    b.step(np.zeros((B, dim), np.float32))  # (in step with `a` again)
+    act = torch.zeros((B, dim), dtype=torch.float32, device=a._env.device)
+    for odd in (torch.nn.Parameter(act.clone()), act.double(), torch.zeros((B, dim), requires_grad=True)):
+        oa, ra, ta, _, _ = a.step(odd)
+        ob, rb, tb, _, _ = b.step(act)
+        assert np.array_equal(ta, tb) and torch.equal(oa["agent_pos"], ob["agent_pos"])

@@ -11,16 +11,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(*flags, timeout=900):
+def _run(*flags, timeout=900, raw=False):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, env=env, timeout=timeout)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     last = r.stdout.strip().splitlines()[-1]
-    return json.loads(last)
+    return (json.loads(last), last, r.stderr) if raw else json.loads(last)
 
 
 def test_driver_command_prints_the_contract_line():
-    out = _run("--gpus", "1", "--steps", "20", "--warmup", "5")
+    out, line, _ = _run("--gpus", "1", "--steps", "20", "--warmup", "5", raw=True)
+    # the driver keeps 8 KB tails: the line must fit with room to spare, and what its record has to show comes FIRST, in full
+    assert len(line) <= 6000, len(line)
+    keys = list(out)
+    assert keys[:8] == ["metric", "value", "unit", "value_median_region", "hot_path_rate", "api_over_hot_path", "early_mask_sent", "early_mask_mismatches"]
+    assert keys.index("config") < keys.index("roofline") < keys.index("cpu_baseline") < 22
+    assert out["early_mask_mismatches"] == 0 and out["early_mask_sent"] > 0
+    cfg = out["config"]
+    assert cfg["early_mask"]["mismatches"] == 0 and cfg["value_median_region"] == out["value_median_region"] and cfg["hot_path_rate"] == out["hot_path_rate"]
+
+    def strings(x):
+        if isinstance(x, dict):
+            for k, v in x.items():
+                if k != "metric":
+                    yield from strings(v)
+        elif isinstance(x, list):
+            for v in x:
+                yield from strings(v)
+        elif isinstance(x, str):
+            yield x
+    assert max(len(t) for t in strings(out)) <= 120
+    assert os.path.exists(os.path.join(ROOT, "gpurun_out", "bench_line_full.json"))   # (the uncut record)
     assert out["metric"].startswith("env-steps/sec") and out["unit"] == "env-steps/s" and out["n_gpus"] == 1
     assert out["steps"] == 20 and out["warmup"] == 5 and out["higher_is_better"] is True and out["vs_baseline"] is None
     assert out["value"] > 1e6 and out["path"] == "GenesisEnv.step"
@@ -31,6 +52,12 @@ def test_driver_command_prints_the_contract_line():
     assert abs(rf["achieved"] - 489.0 * 4096 / (rf["kernel_us"] * 1e-6) / 1e9) < 1e-6 * rf["achieved"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "env-steps/s"
+    assert cb["min"] <= cb["value"] <= cb["max"] and cb["threads"] == cb["cores"] and cb["max"] <= 1.25 * cb["min"], cb   # (five runs at one team size)
+    sweep = out["secondary"]["batch_sweep"]
+    assert [r[0] for r in sweep["rows"]] == [1024, 4096, 16384, 65536] and sweep["cols"][:3] == ["num_envs", "kernel_us", "bare_launch_rate"]
+    assert all(r[2] > 1e6 and r[4] > 1e6 and 0 < r[6] < 1 for r in sweep["rows"])
+    gx = out["scripted_grasp"]["env_step_exact_contacts"]
+    assert gx["overflow_env_frac"] > 0.005 and gx["env_steps_per_s"] > 1e7 and abs(gx["lifted_frac"] - out["scripted_grasp"]["env_step_thinned"]["lifted_frac"]) < 0.05
     for key in ("secondary", "pixels", "scripted_grasp", "box_links", "so101_pick", "stack", "ik"):
         assert key in out and "error" not in out[key], (key, out.get(key))
     assert out["hot_path_rate"] >= out["value"] * 0.9
@@ -48,6 +75,9 @@ def test_two_ranks_share_the_gpu_over_gloo():
     # gather as a number, and where the rank's threads were put
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
     assert isinstance(out["gather_overhead_us"], float) and out["no_gather"]["value"] > 0
+    # SURVEY.md cfg 3's "all-gather obs each step": the same loop with one step per gather, over the copy path and over the collective
+    g1 = out["gather_every_1"]
+    assert g1["copy"]["value"] > 0 and g1["rccl"]["value"] > 0 and isinstance(g1["copy"]["overhead_us_vs_no_gather"], float)
     gs = out["config"]["gather_stats"]   # (two ranks' copies into each other's buffers, checked against the collective at the end)
     assert gs["pushes"] > 0 and gs["checks"] >= 1 and gs["checks_failed"] == 0
     if len(os.sched_getaffinity(0)) >= 4:
@@ -65,6 +95,8 @@ def test_first_rccl_run_one_rank_force_gather():
     assert cfg["gather_path"] == "copy" and out["value"] > 1e6
     assert isinstance(out["gather_overhead_us"], float) and abs(out["gather_overhead_us"]) < 50.0
     assert out["no_gather"]["mean_us_per_step"] > 0
+    g1 = out["gather_every_1"]   # (one step per gather, both paths, through RCCL at world 1)
+    assert g1["copy"]["value"] > 1e6 and g1["rccl"]["value"] > 1e6
     # every timed region ends with a push (partial chunks included), the last gather of a region was checked against the collective,
     # and the ring of reused output rows is disclosed
     gs = cfg["gather_stats"]

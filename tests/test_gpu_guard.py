@@ -148,3 +148,27 @@ def test_wave_kernel_flags_a_non_finite_env():
     assert b1[77] == 1 and b1.sum() == 1 and n1 == 4 and t1[77] == 0
     for x, y in zip(s0, s1):
         assert np.array_equal(x[others], y[others])
+
+
+def test_guard_is_silent_on_a_scene_whose_qpos_row_is_shorter_than_16_words():
+    """One free box on the plane: nq = 7, the 16-lane kernel's qpos row is 8 words and lanes 8 .. 15 of S.qpos are never written.
+    With every CU's LDS poisoned with NaN patterns (the autouse fixture) the guard must stay silent (it read all 16)."""
+    from gym_genesis.backend import spec as S
+    from gym_genesis.backend.lib import MirScene
+
+    sb = S.SceneBuilder()
+    sb.add_geom(0, S.GEOM_PLANE)
+    sb.add_body("box", 0, pos=(0.0, 0.0, 0.3), jtype=S.JNT_FREE, mass=0.2, inertia=S.box_inertia(0.2, (0.03, 0.03, 0.03)))
+    sb.add_geom("box", S.GEOM_BOX, size=(0.03, 0.03, 0.03))
+    sb.task = dict(eef_body=1, obj_body=1, grip_dof=(), reward_z=0.1)
+    B = 256
+    sc = MirScene(sb.build(), B)
+    assert sc.kernel == 16 and sc.nq == 7
+    sc.set_diag(True)
+    sc.get_bad(reset=True)
+    for _ in range(60):   # (falls, lands, rests)
+        sc.step(1)
+        bad, n = sc.get_bad()
+        assert not bad.any() and n == 0
+    q = sc.get_state()[0]
+    assert torch.isfinite(q).all() and (q[:, 2] - 0.03).abs().max() < 5e-3

@@ -430,8 +430,11 @@ def test_render_reuses_the_observation_image_only_while_nothing_has_moved():
     assert mir.state_version > v0
     b = env.render()
     assert np.array_equal(b, obs["pixels"].cpu().numpy()) and not np.array_equal(a, b)
+    b0 = b.copy()
     b[:] = 0                                           # the caller's array is its own
     assert np.array_equal(env.render(), obs["pixels"].cpu().numpy())
+    obs["pixels"].div_(2, rounding_mode="floor")       # an in-place edit of the observation: render() draws the scene again
+    assert np.array_equal(env.render(), b0) and not np.array_equal(b0, obs["pixels"].cpu().numpy())
     st = [x.clone() for x in mir.get_state()]
     st[0][:, :7] += 0.3                                # a state write: the image must change
     mir.set_state(*st)
