@@ -833,10 +833,10 @@ NOTE_LIMIT = 120    # characters per string (the prose lives in DESIGN.md)
 HEAD_KEYS = ("metric", "value", "unit", "value_median_region", "hot_path_rate", "api_over_hot_path", "early_mask_sent", "early_mask_mismatches",
              "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 # what goes first when the line is still too long (least important first; dotted = nested key)
-DROP_ORDER = ("roofline_valu.F_step_per_kind", "roofline_valu.instruction_level", "roofline_valu.fused_launch", "sync_step_floor", "repeat_us_per_step",
-              "roofline.note", "roofline_fused_launch", "pixels.global_view", "pixels.readme_loop", "box_links", "ik", "no_gather", "config.obs_gather",
-              "config.output_ring", "config.value_is", "best_repeat_value", "timed_seconds_total", "timed_steps_total", "resets_in_loop", "roofline_valu",
-              "so101_pick", "pixels", "stack", "secondary", "scripted_grasp")
+DROP_ORDER = ("roofline_valu.instruction_level", "roofline_valu.fused_launch", "stack.roofline_valu.instruction_level", "sync_step_floor", "repeat_us_per_step",
+              "roofline.note", "roofline_fused_launch", "stack.roofline_valu", "pixels.reduced_96x128_num_envs_4096", "pixels.us_per_render_regions",
+              "config.obs_gather", "config.output_ring", "config.value_is", "no_gather", "best_repeat_value", "roofline_valu", "pixels.roofline", "stack.roofline",
+              "box_links", "ik", "so101_pick", "pixels", "stack", "secondary", "scripted_grasp")
 
 
 def compact_line(out: dict, limit: int = LINE_LIMIT) -> dict:
@@ -854,18 +854,23 @@ def compact_line(out: dict, limit: int = LINE_LIMIT) -> dict:
             o["config"][k] = o.get(k)
     o.pop("early_mask", None)
 
-    def shrink(x, key=""):
+    def shrink(x, key="", leg=False):
+        # (inside the secondary legs the prose goes altogether -- workloads and notes are in the docstrings and in DESIGN.md -- and
+        #  numbers keep five digits)
         if isinstance(x, dict):
-            return {k: shrink(v, k) for k, v in x.items() if k not in ("trace", "per_kind", "F_step_per_kind", "F_step_source")}
+            gone = ("trace", "per_kind", "F_step_per_kind", "F_step_source") + (("workload", "note", "source", "dtype", "sample") if leg else ())
+            return {k: shrink(v, k, leg) for k, v in x.items() if k not in gone}
         if isinstance(x, list):
-            return [shrink(v, key) for v in x]
+            return [shrink(v, key, leg) for v in x]
         if isinstance(x, float):
-            return float(f"{x:.6g}")
+            return float(f"{x:.5g}" if leg else f"{x:.7g}")
         if isinstance(x, str) and len(x) > NOTE_LIMIT and key != "metric":
             return x[:NOTE_LIMIT - 3] + "..."
         return x
 
-    o = shrink(o)
+    LEGS = ("secondary", "pixels", "scripted_grasp", "box_links", "so101_pick", "stack", "ik", "roofline_valu", "roofline_fused_launch", "sync_step_floor",
+            "no_gather", "gather_every_1", "repeat_us_per_step")
+    o = {k: shrink(v, k, k in LEGS) for k, v in o.items()}
     o = {**{k: o[k] for k in HEAD_KEYS if k in o}, **{k: v for k, v in o.items() if k not in HEAD_KEYS}}
     dropped = []
     for path in DROP_ORDER:
@@ -1093,7 +1098,9 @@ def worker(args) -> int:
         gather_stats["pushes"] += 1
         gather_stats["partial_pushes"] += 1 if (row + 1 - lo) < Sc else 0
         state["chunk"] += 1
-        state["sent"] = row + 1 if (row + 1) % Sc else ((row + 1) % RING_ROWS)
+        # (never wrapped here: RING_ROWS = "everything up to the end of the ring has gone, nothing is pending"; the step that writes row 0
+        #  starts a new chunk and sets it -- a wrapped 0 made the closing flush of a region that ended on the ring's last row send the ring)
+        state["sent"] = row + 1
 
     def api_loop(k: int):
         """k iterations of the README loop through GenesisEnv.step (README.md:32-43)."""

@@ -132,6 +132,14 @@ __device__ __forceinline__ float gsum(float v) {  // all-reduce sum over the row
   v += row_ror<8>(v);
   return v;
 }
+// ... and the same sum as ONE value for the whole row: lane 0's.  The butterfly above gives every lane the sum in an association of
+// its own (lane i adds (v_i + v_i-1) + (v_i-2 + v_i-3) ..., lane i + 1 pairs the terms differently), so two lanes of a row may hold
+// sums that differ in the last bit -- harmless in arithmetic, fatal in a DECISION that every lane of the env takes for itself: the
+// line search of an env stopped one evaluation earlier on lanes 1 and 9 than on the others (|phi'| one ulp on either side of its
+// tolerance), two dofs and one contact took a different step length, and the next gradient sent a resting cube spinning (3e-4 rad
+// in one step, 2 envs of 1024 on the reference expert's second step; found by the state-parity check of
+// tests/test_gpu_exact_contacts.py).  Everything that feeds a comparison uses this one.
+__device__ __forceinline__ float gsum_u(float v) { return row_bcast<0>(gsum(v)); }
 __device__ __forceinline__ float gmaxf(float v) {  // all-reduce max over the row
   v = fmaxf(v, row_ror<1>(v));
   v = fmaxf(v, row_ror<2>(v));

@@ -1531,8 +1531,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       }
       // (one reduction per tree: the sign of the summed cost DIFFERENCES decides)
       const float d_df = d_ws - d_sm, k_df = k_ws - k_sm;
-      bool usewsA = gsum((dofB ? 0.0f : d_df) + (conB ? 0.0f : k_df)) < 0.0f, usewsB = usewsA;
-      if (__any(sep)) usewsB = gsum((dofB ? d_df : 0.0f) + (conB ? k_df : 0.0f)) < 0.0f;  // (wave-uniform)
+      // (gsum_u: one value per env -- every lane must take the same decision, see mir_dev.h)
+      bool usewsA = gsum_u((dofB ? 0.0f : d_df) + (conB ? 0.0f : k_df)) < 0.0f, usewsB = usewsA;
+      if (__any(sep)) usewsB = gsum_u((dofB ? d_df : 0.0f) + (conB ? k_df : 0.0f)) < 0.0f;  // (wave-uniform)
       const bool usewsd = dofB ? usewsB : usewsA, usewsc = conB ? usewsB : usewsA;
       qacc = usewsd ? ws : qas;
       ljar = usewsd ? ljw : ljs;
@@ -1651,7 +1652,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
           STAMP(30);
         }
       }
-      const float gn = sqrtf(gsum(g * g)), gw = sqrtf(gsum(gfw * g * g));
+      const float gn = sqrtf(gsum_u(g * g)), gw = sqrtf(gsum_u(gfw * g * g));
       if (!done && (scale * gn < tol || gw < gfl)) done = true;
       if (it == 0) STAMP(14);
       ITSTAMP(it, 2);
@@ -1736,7 +1737,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // alpha = 1: the evaluation at alpha = 0 (a full pass over the rows and two reductions) is not spent; the search starts
       // at 1 with the bracket [0, ?) and phi'(0) = g . s as the scale of its stopping rule
       const float svmv = sv * mv, svb = sv * (Ma - qfs);
-      const float A = gsum(svmv), Bq = gsum(svb), g0 = gsum(sv * g);
+      const float A = gsum_u(svmv), Bq = gsum_u(svb), g0 = gsum_u(sv * g);
       bool lsdone = done || g0 >= 0.0f;
       float alpha = lsdone ? 0.0f : 1.0f, lo = 0.0f, hi = -1.0f;
       // improvement of a step alpha s from the 1-D model (exact: phi is piecewise quadratic) and the number of rows whose sign it
@@ -1747,7 +1748,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       float pimc = 0.0f, piml = 0.0f, crsc = 0.0f, crsl = 0.0f;  // this lane's share at the last evaluation: contact rows / limit row
       auto step_gain = [&](float al, float& gain, float& ncr) __attribute__((always_inline)) {
         step_rows(al, jar[0], jar[1], jar[2], jar[3], jv[0], jv[1], jv[2], jv[3], cD, ljar, ljv, lD, lsg, pimc, piml, crsc, crsl);
-        gain = gsum(pimc + piml) - (0.5f * al * al * A + al * Bq);
+        gain = gsum_u(pimc + piml) - (0.5f * al * al * A + al * Bq);
         ncr = gsum(crsc + crsl);  // (the two reductions are independent and overlap)
       };
       // The full Newton step first.  Where it crosses no row boundary it IS the minimiser along s; where it does, it is taken as it
@@ -1769,7 +1770,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
           const float x = ljar + alpha * ljv;
           if (x < 0.0f) { pg += lD * ljv * x; ph += lD * ljv * ljv; }
         }
-        const float gg = gsum(pg) + alpha * A + Bq, hh = gsum(ph) + A;
+        const float gg = gsum_u(pg) + alpha * A + Bq, hh = gsum_u(ph) + A;
         // From the fifth evaluation on (rare) also the magnitude of the
         // terms phi' is summed from: at the root they cancel and what is left is rounding noise of about an epsilon of
         // that magnitude, which no evaluation can resolve (same rule as the oracle)
@@ -1779,7 +1780,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
           for (int r = 0; r < 4; r++)
             if (jar[r] + alpha * jv[r] < 0.0f) pa += cD * fabsf(jv[r]) * (fabsf(jar[r]) + fabsf(alpha * jv[r]));
           if (ljar + alpha * ljv < 0.0f) pa += lD * fabsf(ljv) * (fabsf(ljar) + fabsf(alpha * ljv));
-          floorg = 4.0f * 1.1920929e-7f * (gsum(pa) + fabsf(alpha * A) + fabsf(Bq));
+          floorg = 4.0f * 1.1920929e-7f * (gsum_u(pa) + fabsf(alpha * A) + fabsf(Bq));
         }
         if (!lsdone) {
           if (fabsf(gg) <= fmaxf(1e-6f * fabsf(g0), floorg)) lsdone = true;
@@ -1813,8 +1814,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       const bool need = sep && ncross != 0.0f && alpha != 0.0f;
       bool partial = false;  // one tree moves, the other was held back: the env is not finished whatever the moving tree's gain says
       if (__any(need)) {  // (wave-uniform; an env's result does not depend on its neighbours: only `need` envs use the sums)
-        const float AB = gsum(dofB ? svmv : 0.0f), BB = gsum(dofB ? svb : 0.0f);
-        const float gainB = gsum((conB ? pimc : 0.0f) + (dofB ? piml : 0.0f)) - (0.5f * alpha * alpha * AB + alpha * BB);
+        const float AB = gsum_u(dofB ? svmv : 0.0f), BB = gsum_u(dofB ? svb : 0.0f);
+        const float gainB = gsum_u((conB ? pimc : 0.0f) + (dofB ? piml : 0.0f)) - (0.5f * alpha * alpha * AB + alpha * BB);
         const float gainA = improvement - gainB;
         const bool okA = gainA > 0.0f, okB = gainB > 0.0f;
         if (need && !(okA && okB)) {  // (rare: an exact search on the sum usually lowers both terms)
@@ -1851,6 +1852,15 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         const float gnew = fabsf(1.0f - alpha) * gn, gwnew = fabsf(1.0f - alpha) * gw;
         if (!done && ncross == 0.0f && (scale * gnew < tol || gwnew < gfl)) done = true;
       }
+#ifdef MIR_DEBUG_TRACE
+      /* developer aid (make EXTRA=-DMIR_DEBUG_TRACE; tools/solver_trace.py): the solver's per-lane state at the end of every Newton
+       * iteration of env prof[255], as floats behind the 256 stamp slots of the buffer given to mir_debug_profile_step */
+      if (a.prof && valid && env == (int)a.prof[255] && it < 8) {
+        float* tr = reinterpret_cast<float*>(a.prof + 256) + (it * G + lane) * 16;
+        tr[0] = qacc; tr[1] = jar[0]; tr[2] = jar[1]; tr[3] = jar[2]; tr[4] = jar[3]; tr[5] = (float)prevbits; tr[6] = g; tr[7] = sv;
+        tr[8] = alpha; tr[9] = ald; tr[10] = alc; tr[11] = improvement; tr[12] = ncross; tr[13] = done ? 1.0f : 0.0f; tr[14] = (float)flipmask; tr[15] = partial ? 1.0f : 0.0f;
+      }
+#endif
       WSYNC();
       if (it == 0) STAMP(21);
       ITSTAMP(it, 7);
