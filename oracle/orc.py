@@ -27,10 +27,12 @@ def build_oracle() -> None:
 _libs = {}
 
 
-def load(f32: bool = False, flops=False):
+def load(f32: bool = False, flops=False, variant=None):
     """liborc64.so (float64 oracle), liborc32.so / liborc32_big.so (float32 port at the pick-task / full capacities; f32 = True / "big") or liborc_flops.so / liborc_flops_big.so (the float32 port with
     counted arithmetic at the pick-task / full capacities; flops = True / "big")."""
     key = ("_flops_big" if flops == "big" else "_flops") if flops else (("32_big" if f32 == "big" else "32") if f32 else "64")
+    if variant == "norules":  # (the float64 oracle without the stopping rules it shares with the kernels: `make -C oracle norules`)
+        key = "64_norules"
     if key == "64" and os.environ.get("ORC_SANITIZE"):  # (tests/test_sanitizers_cpu.py: the ASan + UBSan build, `make -C oracle asan`)
         key = "64_asan"
     if key not in _libs:
@@ -40,6 +42,8 @@ def load(f32: bool = False, flops=False):
         if not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(s) for s in srcs):
             if key == "64_asan":
                 subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "asan"], stdout=subprocess.DEVNULL)
+            elif key == "64_norules":
+                subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "norules"], stdout=subprocess.DEVNULL)
             else:
                 build_oracle()
         lib = C.CDLL(path)
@@ -52,8 +56,8 @@ def load(f32: bool = False, flops=False):
 class Oracle:
     """One compiled model + a batch of per-env data blocks."""
 
-    def __init__(self, spec, num_envs: int = 1, f32: bool = False, flops=False):
-        self.lib = load(f32, flops)
+    def __init__(self, spec, num_envs: int = 1, f32: bool = False, flops=False, variant=None):
+        self.lib = load(f32, flops, variant)
         self.spec = spec
         self.B = num_envs
         self.model = C.create_string_buffer(self.lib.orc_sizeof_model())

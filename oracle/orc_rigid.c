@@ -34,8 +34,17 @@
 #define LS_RELTOL ((real)1e-4) /* x ls_tolerance 0.01 = 1e-6 |phi'(0)|: the float32 kernels' rule */
 #else
 #define REAL_EPS ((real)2.220446049250313e-16)
+#ifdef ORC_NO_RULES /* (see below) */
+#define LS_RELTOL ((real)1e-12)
+#else
 #define LS_RELTOL ((real)1e-6)
 #endif
+#endif
+/* ORC_NO_RULES (liborc64_norules.so, `make -C oracle norules`; tests/test_oracle_rules.py): the float64 oracle WITHOUT the stopping
+ * rules it shares with the float32 kernels by construction -- the rounding floor of the gradient, the stagnation rule built on it,
+ * the rounding floor of the line search's phi' (from the fifth evaluation on) and the looser relative tolerance of the search.  In
+ * float64 none of them should ever bind before the tolerance does: the test solves the same states with and without them and finds
+ * the same acceleration. */
 #define MINIMP ((real)0.0001)
 #define MAXIMP ((real)0.9999)
 #define F32(x) ((real)(float)(x)) /* the product stores model constants, dt and gravity in float32: same inputs */
@@ -1180,6 +1189,9 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
   real gfloor = 0;
   for (int i = 0; i < nv; i++) gfloor += Ma[i] * Ma[i] + d->qfrc_smooth[i] * d->qfrc_smooth[i];
   gfloor = 16 * (sizeof(real) == 4 ? (real)5.96e-8 : (real)1.11e-16) * (real)sqrt((double)gfloor);
+#ifdef ORC_NO_RULES
+  gfloor = 0;
+#endif
   real gprev = 0;
   for (int it = 0; it < m->opt.iterations; it++) {
     /* gradient, forces, Hessian */
@@ -1239,6 +1251,9 @@ static void orc_solve(const OrcModel* m, OrcData* d) {
       }
       {
         real tolg = (real)m->opt.ls_tolerance * (real)fabs((double)g0) * LS_RELTOL, floorg = ls >= 4 ? 4 * REAL_EPS * gabs : 0; /* (from the fifth evaluation on, as the kernels) */
+#ifdef ORC_NO_RULES
+        floorg = 0;
+#endif
         if ((real)fabs((double)g) <= (tolg > floorg ? tolg : floorg) + MINVAL) break;
       }
       if (g < 0) lo = alpha; else hi = alpha;
