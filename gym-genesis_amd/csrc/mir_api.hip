@@ -895,6 +895,19 @@ extern "C" int mir_debug_rotated_launches(MirHandle h, const float* actions, int
   return MIR_OK;
 }
 
+/* debug aid (tools/probes/resident_steps.py): n steps in ONE launch on the real step body, every workgroup going
+ * through its steps at its own pace (no launch boundary, no grid-wide wait for the slowest env of a step) -- what a launch that stays
+ * resident over several env.step() calls would cost per step at best (raw-launch semantics: the actions of all n steps are resident,
+ * nothing is handed to the host, no outputs).  It is the rollout launch without rows.  actions (n, B, nu). */
+extern "C" int mir_debug_resident_steps(MirHandle h, const float* actions, int32_t n, void* stream) {
+  if (check(h) || !actions || n <= 0) return set_err(MIR_E_INVALID, "mir_debug_resident_steps: bad argument");
+  if (h->exact) return set_err(MIR_E_INVALID, "mir_debug_resident_steps: not available with exact contacts");
+  DeviceGuard guard(h->device);
+  Outs o;
+  o.action = actions; o.n_steps = n; o.act_step = (long)h->B * h->nu; o.diag = false;
+  return launch(h, o, stream);
+}
+
 int mir_get_split_step(MirHandle h) { return check(h) ? MIR_E_INVALID : (h->sync_mode == 2 ? 0 : h->split_step); }
 int mir_debug_spec_active(MirHandle h) { return check(h) ? MIR_E_INVALID : h->spec_pick; }
 int mir_debug_early_mask_stats(MirHandle h, uint32_t* out2, int32_t reset, void* stream) {

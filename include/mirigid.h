@@ -476,6 +476,9 @@ int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* o
  * mir_step_fused), with the four device outputs of a mir_step_go launch (not its host-visible bytes): lets two events time that kernel the way the fused one is timed (bench.py's roofline).  Advances the state
  * by n steps. */
 int mir_debug_rotated_launches(MirHandle h, const float* actions, int32_t n_actions, int32_t n, void* const* outputs, void* stream);
+/* n steps in ONE launch, every workgroup through its steps at its own pace, actions (n, B, nu) resident, no outputs: the floor under
+ * a launch that would stay resident over several env.step() calls (tools/probes/resident_steps.py).  Advances the state by n steps. */
+int mir_debug_resident_steps(MirHandle h, const float* actions, int32_t n, void* stream);
 int mir_debug_poison_lds(int device_id, void* stream);
 int mir_debug_copy_rows(const float* src, float* dst, int64_t n_floats, int device_id, void* stream);
 /* the kernels' convex narrowphase on n pairs given directly (device arrays): in (n,22) = type1, size1[3], pos1[3], quat1[4] wxyz,
