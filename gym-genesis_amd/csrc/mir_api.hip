@@ -491,6 +491,8 @@ int mir_destroy(MirHandle h) {
   if (h->pre) (void)hipFree(h->pre);
   if (h->pin_host) (void)hipHostFree(h->pin_host);
   if (h->ovf_list_host) (void)hipHostFree(h->ovf_list_host);
+  if (h->ovf_event) (void)hipEventDestroy((hipEvent_t)h->ovf_event);
+  if (h->ovf_stream) (void)hipStreamDestroy((hipStream_t)h->ovf_stream);
   delete h;
   return MIR_OK;
 }
@@ -615,6 +617,7 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   o.exact = h->exact;
   h->pend_action = action;
   h->pend_out[0] = agent_pos; h->pend_out[1] = env_state; h->pend_out[2] = reward; h->pend_out[3] = terminated;
+  h->pend_rotated = rotated ? 1 : 0;
   o.prof = h->dbg_prof;
   h->dbg_prof = nullptr;
   int rc = launch(h, o, stream);
@@ -663,8 +666,12 @@ int mir_step_go(MirHandle h, const float* action, void* stream) {
  * those of the step's start).  They are stepped here by the wave-per-env kernel in list mode -- the same scene compiled for it with 48
  * contact points, reading and writing the 16-lane kernel's rows, the action and the output pointers of the pending step -- and their
  * scratch rows for the NEXT step are recomputed by the action-independent half of the 16-lane kernel over the same list (it also
- * decides whether they are deferred again).  Both launches go on the step's stream, behind the launch that deferred them; the
- * terminated byte of list entry k arrives in ovf_term_host[k]. */
+ * decides whether they are deferred again).  The terminated byte of list entry k arrives in ovf_term_host[k].
+ * Both launches go on a stream of the library's own, BESIDE the launch that deferred these envs (which is still running its second
+ * half: the host is here because that launch's terminated bytes -- early bytes -- have arrived): that launch stores nothing for
+ * them, and everything queued before it on the step's stream has finished, or it would not be running.  The step's stream then
+ * waits for an event recorded behind the two launches, so that whatever the caller queues after mir_step_end -- the next step, a
+ * policy network reading the observations -- comes after them. */
 static int exact_finish(MirScene* h, int n, uint8_t* terminated_host) {
   DeviceGuard guard(h->device);
   h->ex_ovf_steps++;
@@ -684,14 +691,22 @@ static int exact_finish(MirScene* h, int n, uint8_t* terminated_host) {
   a.term_host = h->ovf_term_dev; a.term_tag = h->tag;
   a.mode = 0; a.n_steps = 1;
   a.env_list = h->ovf_list_dev; a.lay16_qst = h->hm.qstride;
-  int rc = mir_launch_step64(&a, (hipStream_t)h->pending_stream);
+  // (not beside a step that was launched as two kernels -- a fused launch, or the second half alone, followed by the first half of the
+  //  next step for ALL envs: that second kernel writes the scratch rows of the deferred envs too, from their old state, and must come
+  //  BEFORE the one below that writes them from the new state: stream order does that)
+  void* const side = (h->ovf_stream && h->pend_rotated) ? h->ovf_stream : h->pending_stream;
+  int rc = mir_launch_step64(&a, (hipStream_t)side);
   if (rc != 0) return hip_fail((hipError_t)rc, "wave kernel launch (exact contacts)");
   h->poses_current = 0;  // (the deferred envs' link poses were not written)
   if (h->pre_valid) {  // (split step: the scratch rows of the coming step, for the envs that have only now reached its starting state)
     Outs p;
     p.phase = 1; p.diag = false; p.env_list = h->ovf_list_dev; p.nlist = n;
-    rc = launch(h, p, h->pending_stream);
+    rc = launch(h, p, side);
     if (rc != MIR_OK) return rc;
+  }
+  if (side != h->pending_stream) {
+    HIPCHK(hipEventRecord((hipEvent_t)h->ovf_event, (hipStream_t)side));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)h->pending_stream, (hipEvent_t)h->ovf_event, 0));
   }
   const uint8_t want = (uint8_t)h->tag;
   unsigned long polls = 0;
@@ -849,6 +864,15 @@ int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
     HIPCHK(hipHostGetDevicePointer((void**)&h->ovf_list_dev, h->ovf_list_host, 0));
     h->ovf_term_host = reinterpret_cast<uint8_t*>(h->ovf_list_host + B);
     h->ovf_term_dev = reinterpret_cast<uint8_t*>(h->ovf_list_dev + B);
+    if (!getenv("MIR_EXACT_ONE_STREAM")) {  // (the side stream of exact_finish; MIR_EXACT_ONE_STREAM=1: everything on the step's stream)
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      hipStream_t st = nullptr;
+      hipEvent_t ev = nullptr;
+      HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+      HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      h->ovf_stream = st; h->ovf_event = ev;
+    }
   }
   h->exact = 1;
   return MIR_OK;

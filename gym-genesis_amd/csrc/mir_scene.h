@@ -68,8 +68,11 @@ struct MirScene {
   int32_t* ovf_list_dev;
   uint8_t* ovf_term_host;   // pinned: terminated byte of list entry k, tagged like the others (behind the list in the same allocation)
   uint8_t* ovf_term_dev;
+  void* ovf_stream;         // hipStream_t of the library's own: the two launches for the deferred envs run beside the launch that deferred them
+  void* ovf_event;          // hipEvent_t: recorded behind them; the step's stream waits for it before anything queued after mir_step_end
   const float* pend_action; // arguments of the pending mir_step_begin (the wave launch of mir_step_end takes the same)
   void* pend_out[4];
+  int pend_rotated;         // the pending step is ONE rotated launch (else: a launch followed by the first half of the next step for all envs)
   unsigned long long ex_steps, ex_ovf_steps, ex_ovf_envs, ex_ovf_max;  // steps closed / steps with deferred envs / deferred env-steps / most in one step
 };
 
