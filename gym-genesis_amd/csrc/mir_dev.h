@@ -125,21 +125,27 @@ __device__ __forceinline__ float lane_gather(int src4, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src4, __builtin_bit_cast(int, v)));
 }
 __device__ __forceinline__ int lane_gather(int src4, int v) { return __builtin_amdgcn_ds_bpermute(src4, v); }
-__device__ __forceinline__ float gsum(float v) {  // all-reduce sum over the row
-  v += row_ror<1>(v);
-  v += row_ror<2>(v);
-  v += row_ror<4>(v);
-  v += row_ror<8>(v);
+// All-reduce sum over the row, THE SAME VALUE IN EVERY LANE, bit for bit.  Every stage pairs the lanes by an involution -- the
+// row's mirror image, the mirror image of each half, then the neighbours inside a quad and the pairs of a quad -- so that the two
+// lanes of a pair add the same two numbers (a + b and b + a: floating-point addition commutes), and by induction all sixteen lanes
+// end with the same sum.  The rotation butterfly this replaces (four `row_ror` adds) gave every lane the sum in an association of
+// its own: two lanes of a row could hold sums that differ in the last bit -- harmless in arithmetic, fatal in a DECISION that every
+// lane of the env takes for itself.  The line search of an env stopped one evaluation earlier on lanes 1 and 9 than on the others
+// (|phi'| one ulp on either side of its tolerance), two dofs and one contact took a different step length, and the next gradient
+// sent a resting cube spinning: 3e-4 rad in one step, 2 envs of 1024 on the reference expert's second step (found by the
+// state-parity check of tests/test_gpu_exact_contacts.py; tools/solver_trace.py shows it lane by lane).  Same four DPP adds as before.
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float gsum(float v) {
+  v += row_dpp<0x140>(v);  // row_mirror: lane i <-> 15 - i
+  v += row_dpp<0x141>(v);  // row_half_mirror: lane i <-> 7 - i inside each half
+  v += row_dpp<0xB1>(v);   // quad_perm [1, 0, 3, 2]: lane i <-> i ^ 1
+  v += row_dpp<0x4E>(v);   // quad_perm [2, 3, 0, 1]: lane i <-> i ^ 2
   return v;
 }
-// ... and the same sum as ONE value for the whole row: lane 0's.  The butterfly above gives every lane the sum in an association of
-// its own (lane i adds (v_i + v_i-1) + (v_i-2 + v_i-3) ..., lane i + 1 pairs the terms differently), so two lanes of a row may hold
-// sums that differ in the last bit -- harmless in arithmetic, fatal in a DECISION that every lane of the env takes for itself: the
-// line search of an env stopped one evaluation earlier on lanes 1 and 9 than on the others (|phi'| one ulp on either side of its
-// tolerance), two dofs and one contact took a different step length, and the next gradient sent a resting cube spinning (3e-4 rad
-// in one step, 2 envs of 1024 on the reference expert's second step; found by the state-parity check of
-// tests/test_gpu_exact_contacts.py).  Everything that feeds a comparison uses this one.
-__device__ __forceinline__ float gsum_u(float v) { return row_bcast<0>(gsum(v)); }
+__device__ __forceinline__ float gsum_u(float v) { return gsum(v); }  // (the name the decision-feeding sums were given when gsum was not uniform)
 __device__ __forceinline__ float gmaxf(float v) {  // all-reduce max over the row
   v = fmaxf(v, row_ror<1>(v));
   v = fmaxf(v, row_ror<2>(v));

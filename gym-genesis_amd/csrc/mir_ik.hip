@@ -275,3 +275,24 @@ extern "C" int mir_inverse_kinematics(MirHandle h, int32_t link_body, const floa
   if (e != hipSuccess) return mir_set_error(MIR_E_HIP, hipGetErrorString(e));
   return MIR_OK;
 }
+
+/* debug aid (tests/test_gpu_api.py): the row all-reduce of mir_dev.h on n_rows rows of 16 floats -- out[r][l] = what lane l of row r
+ * holds after gsum.  Every lane of a row must hold the same bits: decisions of the 16-lane kernel's solver are taken per lane. */
+namespace {
+__global__ __launch_bounds__(64) void k_debug_row_sum(const float* __restrict__ in, float* __restrict__ out, int n_rows) {
+  const int i = blockIdx.x * 64 + threadIdx.x;       // (whole waves: the DPP reads need every lane of the row present)
+  const float v = i < n_rows * 16 ? in[i] : 0.0f;
+  const float s = gsum(v);
+  if (i < n_rows * 16) out[i] = s;
+}
+}  // namespace
+extern "C" int mir_debug_row_sum(const float* in, float* out, int32_t n_rows, int device_id, void* stream) {
+  if (!in || !out || n_rows <= 0) return mir_set_error(MIR_E_INVALID, "mir_debug_row_sum: bad argument");
+  int prev = -1;
+  const bool sw = hipGetDevice(&prev) == hipSuccess && prev != device_id && hipSetDevice(device_id) == hipSuccess;
+  hipLaunchKernelGGL(k_debug_row_sum, dim3((n_rows * 16 + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, n_rows);
+  const hipError_t e = hipGetLastError();
+  if (sw) (void)hipSetDevice(prev);
+  return e == hipSuccess ? MIR_OK : mir_set_error(MIR_E_HIP, hipGetErrorString(e));
+}
+

@@ -479,6 +479,9 @@ int mir_debug_rotated_launches(MirHandle h, const float* actions, int32_t n_acti
 /* n steps in ONE launch, every workgroup through its steps at its own pace, actions (n, B, nu) resident, no outputs: the floor under
  * a launch that would stay resident over several env.step() calls (tools/probes/resident_steps.py).  Advances the state by n steps. */
 int mir_debug_resident_steps(MirHandle h, const float* actions, int32_t n, void* stream);
+/* the 16-lane kernel's row all-reduce on n_rows rows of 16 floats (device arrays): out[r][l] = lane l's result for row r.  Every lane
+ * of a row must hold the same bits (the solver's per-lane decisions rest on it: tests/test_gpu_api.py). */
+int mir_debug_row_sum(const float* in, float* out, int32_t n_rows, int device_id, void* stream);
 int mir_debug_poison_lds(int device_id, void* stream);
 int mir_debug_copy_rows(const float* src, float* dst, int64_t n_floats, int device_id, void* stream);
 /* the kernels' convex narrowphase on n pairs given directly (device arrays): in (n,22) = type1, size1[3], pos1[3], quat1[4] wxyz,

@@ -502,3 +502,30 @@ def test_numpy_actions_are_read_in_place_and_equal_device_actions(task, robot):
         oa, ra, ta, _, _ = a.step(odd)
         ob, rb, tb, _, _ = b.step(act)
         assert np.array_equal(ta, tb) and torch.equal(oa["agent_pos"], ob["agent_pos"])
+
+
+def test_row_all_reduce_gives_every_lane_the_same_bits():
+    """The 16-lane kernel's solver takes its decisions -- converged? line search finished? step accepted? -- in every lane of an env
+    from sums over the env's 16 lanes: the lanes must hold the SAME sum, to the bit (mir_dev.h: gsum; with the rotation butterfly it
+    replaced, two lanes of a row could differ in the last bit, and an env's lanes stopped their line search at different evaluations).
+    4096 rows of wide dynamic range and mixed signs: identical bits across each row, and the float64 sum within float32 rounding."""
+    import ctypes as C
+
+    from gym_genesis.backend import lib
+
+    L = lib.load_library()
+    L.mir_debug_row_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p]
+    L.mir_debug_row_sum.restype = C.c_int
+    rng = np.random.default_rng(0)
+    n = 4096
+    x = (rng.normal(size=(n, 16)) * 10.0 ** rng.uniform(-6, 6, (n, 16))).astype(np.float32)
+    x[::7, 5:] *= -1.0
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xin, out = torch.as_tensor(x, device=dev), torch.empty((n, 16), dtype=torch.float32, device=dev)
+    assert L.mir_debug_row_sum(C.c_void_p(xin.data_ptr()), C.c_void_p(out.data_ptr()), n, dev.index, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    o = out.cpu().numpy()
+    bits = o.view(np.uint32)
+    assert (bits == bits[:, :1]).all(), f"{int((bits != bits[:, :1]).any(1).sum())} rows hold different sums in different lanes"
+    ref = x.astype(np.float64).sum(1)
+    assert np.abs(o[:, 0] - ref).max() <= 16 * 6e-8 * np.abs(x.astype(np.float64)).sum(1).max()
+    assert (np.abs(o[:, 0] - ref) <= 16 * 6e-8 * np.abs(x.astype(np.float64)).sum(1)).all()
