@@ -409,7 +409,7 @@ def valu_roofline(fl: dict, kernel_us: float, kernel: str, B: int, sq_profile: s
                    "HBM figure is near 1"}
     try:
         sq = None
-        for rnd in ("r4", "r3", "r2"):  # (the latest committed counter pass of this kernel)
+        for rnd in ("r5", "r4", "r3", "r2"):  # (the latest committed counter pass of this kernel)
             path = os.path.join(ROOT, "profiles", rnd, sq_profile)
             if os.path.exists(path):
                 with open(path) as f:
@@ -806,7 +806,7 @@ def batch_sweep(torch, dev, f_step=None, sizes=(1024, 4096, 16384, 65536), n: in
 
 def _profile_number(name: str, key: str):
     """A number measured offline with rocprofv3 PMC passes and committed under profiles/ (latest round first)."""
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, name)) as f:
                 v = json.load(f).get(key)
