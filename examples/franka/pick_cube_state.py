@@ -86,9 +86,13 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=os.path.join("data", "cube_pick_state.npz"))
     ap.add_argument("--stages", choices=("reference", "tuned"), default="reference")
+    ap.add_argument("--exact-contacts", action="store_true",
+                    help="keep every contact point (Genesis's behaviour): the envs whose narrowphase finds more than the 16-lane kernel's 16 -- "
+                         "27 %% of this expert's env-steps, fingertips pressed on the floor around the cube -- are stepped by the wave-per-env kernel "
+                         "instead of being thinned (DESIGN.md 5b)")
     args = ap.parse_args()
 
-    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=args.num_envs, enable_pixels=False)
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=args.num_envs, enable_pixels=False, exact_contacts=args.exact_contacts)
     env.reset(seed=args.seed)
     feats = {k: [] for k in ("observation.state", "observation.environment_state", "action", "episode_index", "frame_index")}
     kept = 0
