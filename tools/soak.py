@@ -1,7 +1,10 @@
 """Soak of every task on the device: thousands of random-action env.steps with the README loop's resets, the divergence guard
 (mir_get_bad) and the early-mask counters switched on.  Prints, per task: env-steps run, env-steps flagged non-finite (must be 0),
 early-mask mismatches (must be 0), the largest contact / candidate-point counts and iteration counts seen.
-Usage (GPU box): python3 tools/soak.py [steps]"""
+With `exact` as second argument the two pick tasks run with exact contacts (deferred envs on the wave kernel) and with
+joint targets of twice the range, so that the arm ploughs into the floor and the cube and envs are deferred all the time; the counters
+of mir_get_exact_stats are printed.
+Usage (GPU box): python3 tools/soak.py [steps] [exact]"""
 import os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(root, "gym-genesis_amd")]
@@ -9,10 +12,11 @@ import numpy as np, torch
 from gym_genesis.env import GenesisEnv
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+EXACT = len(sys.argv) > 2 and sys.argv[2] == "exact"
 B = 4096
 ok = True
-for task, robot in (("cube_pick", "franka"), ("cube_pick", "so101"), ("cube_stack", "franka"), ("cube_stack", "so101")):
-    env = GenesisEnv(task=task, robot=robot, num_envs=B, enable_pixels=False)
+for task, robot in ((("cube_pick", "franka"), ("cube_pick", "so101")) if EXACT else (("cube_pick", "franka"), ("cube_pick", "so101"), ("cube_stack", "franka"), ("cube_stack", "so101"))):
+    env = GenesisEnv(task=task, robot=robot, num_envs=B, enable_pixels=False, **({"exact_contacts": True} if EXACT else {}))
     mir = env._env._mir
     mir.set_diag(True)
     mir.get_bad(reset=True)
@@ -27,6 +31,8 @@ for task, robot in (("cube_pick", "franka"), ("cube_pick", "so101"), ("cube_stac
     terminated_seen = 0
     for t in range(STEPS):
         a = torch.empty((B, n_act), device=dev).uniform_(-1, 1, generator=g)
+        if EXACT:
+            a = a * 2.0
         if task == "cube_stack" and home is not None:
             a = a + home[:, :n_act]
         obs, rew, term, trunc, info = env.step(a)
@@ -43,6 +49,8 @@ for task, robot in (("cube_pick", "franka"), ("cube_pick", "so101"), ("cube_stac
     finite = all(bool(torch.isfinite(x).all()) for x in mir.get_state()[:2])
     print(f"{task:10s} {robot:6s} kernel {mir.kernel}: {STEPS * B} env-steps, non-finite env-steps {nbad}, state finite {finite}, early-mask sent {early[0]} "
           f"mismatches {early[1]}, terminated env-steps {terminated_seen}, max contacts {mx['ncon']} candidate points {mx['points']} iterations {mx['niter']}")
+    if EXACT:
+        print("           exact contacts:", mir.exact_stats())
     ok = ok and nbad == 0 and finite and early[1] == 0
     del env
 print("SOAK_OK" if ok else "SOAK_FAILED")
