@@ -201,10 +201,15 @@ class FrankaCubePickBatch:
         mir = self._mir
         self._agent, self._envst, self._reward, self._term = mir.step_fresh(action, AGENT_DIM, ENV_DIM,
                                                                             host_terminated=True)
+        if self.exact_contacts and self.enable_pixels:
+            # (exact contacts: a deferred env is stepped by the launches of mir_step_end -- the images of the observation, drawn by
+            #  _pack_obs below, must come behind them: the step is closed first and step_end() hands the mask over)
+            self._closed_term = mir.step_end()
         return None, self._reward, None, self._pack_obs()
 
     def step_end(self) -> np.ndarray:
-        return self._mir.step_end()
+        closed = self.__dict__.pop("_closed_term", None)
+        return closed if closed is not None else self._mir.step_end()
 
     def make_fast_step(self):
         """The whole of GenesisEnv.step as one flat closure (tasks/fast_step.py)."""

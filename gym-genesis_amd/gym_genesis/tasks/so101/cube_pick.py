@@ -122,6 +122,9 @@ class CubePick:
             action = torch.as_tensor(np.asarray(action))
         self._agent, self._envst, self._reward, self._term = mir.step_fresh(action.reshape(self.num_envs, AGENT_DIM), AGENT_OBS, ENV_OBS,
                                                                             host_terminated=host_terminated)
+        if host_terminated and self.exact_contacts and self.enable_pixels:
+            # (exact contacts: the images must be drawn behind the launches of mir_step_end that step the deferred envs: see the Franka task)
+            self._closed_term = mir.step_end()
         return None, self._reward, None, self._pack_obs()
 
     def step_begin(self, action):
@@ -129,7 +132,8 @@ class CubePick:
         return self.step(action, host_terminated=True)
 
     def step_end(self) -> np.ndarray:
-        return self._mir.step_end()
+        closed = self.__dict__.pop("_closed_term", None)
+        return closed if closed is not None else self._mir.step_end()
 
     def make_fast_step(self):
         """The whole of GenesisEnv.step as one flat closure (tasks/fast_step.py)."""

@@ -297,7 +297,9 @@ int mir_step_go(MirHandle h, const float* action, void* stream);
  * envs on the wave-per-env kernel (the same scene compiled with MIR_MAX_CONTACT points, never thinned below that) from their untouched
  * state rows, with the step's action and into the step's output pointers, recomputes their part of the split step's hand-over, and
  * returns when their terminated bytes have arrived too.  An env that is not deferred is computed exactly as without the switch; a
- * step without deferred envs launches nothing extra.  `spec`: the spec the scene was created from (compiled once more, for the wave
+ * step without deferred envs launches nothing extra.  The state rows, outputs and link poses of a deferred env are those of the step
+ * only once mir_step_end has returned: anything queued between mir_step_begin and mir_step_end -- a mir_render of the observation's
+ * images, say -- sees its OLD rows (the task classes close the step before they draw).  `spec`: the spec the scene was created from (compiled once more, for the wave
  * kernel; may be NULL when switching back on).  While the switch is on, mir_step and mir_step_fused run as begin + end (they wait for the
  * step), and mir_step_packed / mir_rollout / mir_rollout_autoreset return MIR_E_INVALID (their steps are never closed on the host).
  * MIR_E_INVALID for scenes of the wave kernel (nothing to do) and for sync modes other than 3.

@@ -321,3 +321,32 @@ def test_entry_points_under_the_switch(franka_spec):
     assert w.kernel == 64
     with pytest.raises(MirError):
         w.set_exact_contacts(True)
+
+
+def test_pixels_behind_a_step_with_deferred_envs_show_the_stepped_state():
+    """enable_pixels with exact contacts: the images of the observation are drawn behind the step -- for a deferred env behind the wave
+    kernel's launch on the side stream, whose link poses the 16-lane launch did not write (the render refreshes them).  The pixels of
+    every env equal a fresh render of the state the step left, and the state equals the state-only env's."""
+    from gym_genesis.env import GenesisEnv
+
+    n = 64
+    kw = dict(task="cube_pick", robot="franka", num_envs=n, exact_contacts=True)
+    a = GenesisEnv(enable_pixels=True, observation_height=96, observation_width=128, camera_capture_mode="per_env", strip_environment_state=False, **kw)
+    b = GenesisEnv(enable_pixels=False, **kw)
+    a.reset(seed=3); b.reset(seed=3)
+    pos, acts = _grasp_workload(n, seed=9)
+    quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]]).repeat(n, 1)
+    home = torch.tensor(HOME).repeat(n, 1)
+    for e in (a, b):
+        e._env._mir.reset(pos, quat, home)
+        e._env._mir.exact_stats(reset=True)
+    deferred_frames = 0
+    for t in range(100, 140):   # (the close stage: pads on the cube, fingertips on the floor)
+        act = torch.as_tensor(acts[t], device=a._env.device)
+        oa, ra, ta, _, _ = a.step(act)
+        ob, rb, tb, _, _ = b.step(act)
+        assert np.array_equal(ta, tb) and torch.equal(oa["agent_pos"], ob["agent_pos"])
+        fresh = a._env.cam.render_envs()
+        assert torch.equal(oa["pixels"], fresh), f"step {t}: the observation's images are not those of the stepped state"
+        deferred_frames = a._env._mir.exact_stats()["overflow_env_steps"]
+    assert deferred_frames > 0 and a._env._mir.exact_stats() == b._env._mir.exact_stats()
