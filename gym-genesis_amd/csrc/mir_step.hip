@@ -388,6 +388,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
   // (lane = candidate).  Needs the link poses and the model table in LDS, nothing else: in the DUAL instantiation the second
   // wave of the workgroup runs it while the first one does the smooth dynamics.
+  // (more candidate PAIRS passed the broadphase than the row has lanes: the pairs beyond the 16th were dropped.  Never seen on the
+  //  reference's scenes -- the contact counts agree with the oracle's, which has no such limit, in every parity test -- but with exact
+  //  contacts such an env must go to the wave kernel (64 candidates) like one with too many points: its count is reported saturated)
+  bool pair_ovf = false;
   auto collide_detect = [&]() -> int {
   if (lane == 0) { S.ncon = 0; S.ncand = 0; }
   for (int g = lane; g < ngeom; g += G) {
@@ -526,6 +530,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       base += __popc(gm);
     }
     const int ncand = base < G ? base : G;
+    pair_ovf = base > G;
     if (lane == 0) S.ncand = ncand;
     WSYNC();
     STAMP(12);
@@ -720,7 +725,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     totf += row_shr<4>(totf);
     totf += row_shr<8>(totf);
     int total0 = (int)row_bcast<15>(totf);
-    ptotal = total0;  // (candidate points before the capacity is applied: more than max_contacts says the manifolds were thinned)
+    ptotal = pair_ovf ? 255 : total0;  // (candidate points before the capacity is applied: more than max_contacts says the manifolds were thinned)
     if (__any(total0 > maxc)) {
       WSYNC();  // (the staging area was written by other lanes of the row)
       for (int round = 0; round < 8; round++) {  // (a manifold holds at most 8 points)

@@ -350,3 +350,49 @@ def test_pixels_behind_a_step_with_deferred_envs_show_the_stepped_state():
         assert torch.equal(oa["pixels"], fresh), f"step {t}: the observation's images are not those of the stepped state"
         deferred_frames = a._env._mir.exact_stats()["overflow_env_steps"]
     assert deferred_frames > 0 and a._env._mir.exact_stats() == b._env._mir.exact_stats()
+
+
+def test_more_candidate_pairs_than_lanes_defers_too():
+    """The 16-lane kernel's other capacity: 16 candidate PAIRS (lane = candidate); what passes the broadphase beyond that is dropped.
+    Two rigid combs of eleven small boxes, one lying on the floor, the other resting on it tooth on tooth: 22 touching pairs.  With exact
+    contacts such an env reports its candidate-point count saturated and goes to the wave kernel (64 candidates, 48 points): every step
+    of every env equals the same scene on the wave kernel bit for bit."""
+    from gym_genesis.backend import spec as S
+    from gym_genesis.backend.lib import MirScene
+
+    def comb(cap):
+        sb = S.SceneBuilder()
+        sb.add_geom(0, S.GEOM_PLANE)
+        for name, z in (("a", 0.02), ("b", 0.0595)):
+            sb.add_body(name, 0, pos=(0.0, 0.0, z), jtype=S.JNT_FREE, mass=0.55, inertia=S.box_inertia(0.55, (0.27, 0.02, 0.02)))
+            for i in range(11):
+                sb.add_geom(name, S.GEOM_BOX, size=(0.02, 0.02, 0.02), pos=(0.05 * (i - 5), 0.0, 0.0))
+        sb.task = dict(eef_body=1, obj_body=2, grip_dof=(), reward_z=0.1)
+        sb.opt["max_contacts"] = cap
+        return sb.build()
+
+    n = 64
+    sc, wave = MirScene(comb(16), n), MirScene(comb(48), n)
+    assert sc.kernel == 16 and wave.kernel == 64
+    sc.set_exact_contacts(True)
+    sc.set_diag(True)
+    rng = np.random.default_rng(2)
+    q = np.zeros((n, 14), np.float32)
+    q[:, 2], q[:, 9] = 0.0199, 0.0595
+    q[:, 7:9] = rng.uniform(-0.003, 0.003, (n, 2))
+    q[:, 3], q[:, 10] = 1.0, 1.0
+    for s_ in (sc, wave):
+        s_.set_state(qpos=q, qvel=np.zeros((n, 12), np.float32), warmstart=np.zeros((n, 12), np.float32))
+    b0, b2 = _bufs(sc), _bufs(wave)
+    sc.exact_stats(reset=True)
+    for t in range(30):
+        st = sc.get_state()
+        wave.set_state(*st)
+        sc.step_begin(None, *b0); sc.step_end()
+        wave.step_fused(None, *b2)
+        pts = sc.get_diag(points=True)[3]
+        for x, z in zip(list(b0) + list(sc.get_state()), list(b2) + list(wave.get_state())):
+            assert torch.equal(x, z), f"step {t}: an env with more than 16 candidate pairs differs from the wave-kernel scene"
+    st = sc.exact_stats()
+    assert st["overflow_env_steps"] == 30 * n and int(pts.min()) > 16
+    assert torch.isfinite(sc.get_state()[0]).all() and float(sc.get_state()[0][:, 9].min()) > 0.05   # (the upper comb stays on the lower one)
