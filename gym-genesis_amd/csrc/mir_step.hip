@@ -478,6 +478,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         }
       }
       npl = off < K16_MAX_PAIR ? off : K16_MAX_PAIR;
+      pair_ovf = off > K16_MAX_PAIR;  // (more overlapping AABB pairs than the list holds: as for the candidates below)
       WSYNC();
     }
     // broadphase: bounding test per candidate pair (static list, or the sweep's survivors), ordered compaction
@@ -530,7 +531,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       base += __popc(gm);
     }
     const int ncand = base < G ? base : G;
-    pair_ovf = base > G;
+    pair_ovf = pair_ovf || base > G;
     if (lane == 0) S.ncand = ncand;
     WSYNC();
     STAMP(12);
