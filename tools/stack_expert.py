@@ -7,9 +7,15 @@ sys.path.insert(0, os.path.join(_R, "gym-genesis_amd"))
 from gym_genesis.env import GenesisEnv
 
 
-def run(B=64, seed=0, verbose=True, grasp_dz=0.062, place_dz=0.106, speed=0.004):
+def run(B=64, seed=0, verbose=True, grasp_dz=0.062, place_dz=0.106, speed=0.004, record=None):
+    """record: a dict that receives the scene spec, the state after reset (qpos, qvel, target, warmstart as NumPy) and the list of
+    actions (for the teacher-forced state-parity test of tests/test_gpu_stack.py)"""
     env = GenesisEnv(task="cube_stack", robot="franka", num_envs=B)
     obs, _ = env.reset(seed=seed)
+    if record is not None:
+        record["spec"] = env._env._mir.spec
+        record["state0"] = [x.cpu().numpy() for x in env._env._mir.get_state()]
+        record["actions"] = []
     robot, dev = env.get_robot(), obs["agent_pos"].device
     eef = robot.get_link("hand")
     quat = torch.tensor([0, 1, 0, 0], dtype=torch.float32, device=dev).expand(B, -1)
@@ -28,6 +34,8 @@ def run(B=64, seed=0, verbose=True, grasp_dz=0.062, place_dz=0.106, speed=0.004)
             cur = cur + d * torch.clamp(speed / dist, max=1.0)
             q = robot.inverse_kinematics(link=eef, pos=cur, quat=quat)
             act = torch.cat([q[:, :7], torch.full((B, 2), grip, device=dev)], 1)
+            if record is not None:
+                record["actions"].append(act.cpu().numpy())
             obs, reward, term, trunc, info = env.step(act)
             success |= reward == 1
     final = (reward == 1)
