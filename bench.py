@@ -316,16 +316,20 @@ def cpu_baseline_child(budget_s: float) -> dict:
         if best is None or min(dts) < best:
             best, used = min(dts), nt
     runs, per_run = [], max(4, min(400, int(budget_s / 5.0 / max(best, 1e-6))))
-    steps = 0
+    # every run times the SAME steps: the scene is put back to one snapshot first (consecutive stretches of one trajectory differ in
+    # their contacts and Newton iterations by more than the host's timing noise: 1.65 between the fastest and the slowest stretch)
+    snap = [(f, o.read_all(f, 64)) for f in (orc.F_QPOS, orc.F_QVEL, orc.F_QACC_WS)]
     for _ in range(5):
+        for f, v in snap:
+            o.write_all(f, v)
         t0 = time.perf_counter()
-        for _ in range(per_run):
-            o.step_batch(acts[steps % 64], used)
-            steps += 1
+        for i in range(per_run):
+            o.step_batch(acts[i % 64], used)
         runs.append(per_run * B / (time.perf_counter() - t0))
+    order = [round(r) for r in runs]
     runs.sort()
-    return {"value": runs[len(runs) // 2], "min": runs[0], "max": runs[-1], "unit": "env-steps/s", "cores": used, "threads": used, "kind": "port",
-            "sample": f"median of 5 runs x {per_run} steps x {B} envs, headline workload, f32 C port of the oracle, OpenMP (spread over cores)"}
+    return {"value": runs[len(runs) // 2], "min": runs[0], "max": runs[-1], "runs_in_order": order, "unit": "env-steps/s", "cores": used, "threads": used, "kind": "port",
+            "sample": f"median of 5 runs of the same {per_run} steps x {B} envs, headline workload, f32 C port of the oracle, OpenMP"}
 
 
 def cpu_baseline(budget_s: float = 12.0):
@@ -858,7 +862,7 @@ def compact_line(out: dict, limit: int = LINE_LIMIT) -> dict:
         # (inside the secondary legs the prose goes altogether -- workloads and notes are in the docstrings and in DESIGN.md -- and
         #  numbers keep five digits)
         if isinstance(x, dict):
-            gone = ("trace", "per_kind", "F_step_per_kind", "F_step_source") + (("workload", "note", "source", "dtype", "sample") if leg else ())
+            gone = ("trace", "per_kind", "F_step_per_kind", "F_step_source", "runs_in_order") + (("workload", "note", "source", "dtype", "sample") if leg else ())
             return {k: shrink(v, k, leg) for k, v in x.items() if k not in gone}
         if isinstance(x, list):
             return [shrink(v, key, leg) for v in x]

@@ -402,6 +402,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   }
   WSYNC();
   STAMP(11);
+  HSTAMP(58);
   int mycount = 0;
   if (enable_collision) {
     int npl = npair;  // pairs that reach the bounding test below
@@ -535,15 +536,21 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     if (lane == 0) S.ncand = ncand;
     WSYNC();
     STAMP(12);
+    HSTAMP(59);
     // narrowphase, plane-box: one candidate at a time, its 8 box corners on lanes 0..7 of the group
     // (wave-uniform loop: the DPP/ballot selection below needs all lanes present)
-    for (int k = 0; k < G; k++) {
-      const bool act = k < ncand;
-      if (!__any(act)) break;
-      const int pr = act ? S.col.cand[k] : 0;
+    // (every env takes ITS next candidate of the kind in a trip -- the lists of the four envs of a wave hold them at different
+    // positions -- so a wave makes as many trips as its busiest env has such candidates, not one per position of their union)
+    const int prl = lane < ncand ? S.col.cand[lane] : 0;
+    const bool planel = lane < ncand && (prl >> 16 & 255) == MIR_GEOM_PLANE && (!CONVEX || (prl >> 24) == MIR_GEOM_BOX);
+    const bool boxl = lane < ncand && (prl >> 16 & 255) != MIR_GEOM_PLANE && (!CONVEX || ((prl >> 16 & 255) == MIR_GEOM_BOX && (prl >> 24) == MIR_GEOM_BOX));
+    uint32_t planem = (uint32_t)(__ballot(planel) >> (grp * G)) & 0xffffu, boxm = (uint32_t)(__ballot(boxl) >> (grp * G)) & 0xffffu;
+    while (__any(planem != 0u)) {
+      const bool isplane = planem != 0u;
+      const int k = isplane ? __ffs(planem) - 1 : 0;
+      planem &= planem - 1u;
+      const int pr = isplane ? S.col.cand[k] : 0;
       const int g1 = pr & 255, g2 = pr >> 8 & 255;
-      const bool isplane = act && (pr >> 16 & 255) == MIR_GEOM_PLANE && (!CONVEX || (pr >> 24) == MIR_GEOM_BOX);
-      if (!__any(isplane)) continue;
       const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
       const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
       const M3 R2 = q2m(ld4v(S.col.gquat[g2]));
@@ -580,13 +587,13 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     }
     // narrowphase, box-box: one candidate at a time on the whole row (box_box_row, mir_dev.h): the 15 separating axes
     // on lanes 0..14, the incident-face vertices on lanes 0..3
-    for (int k = 0; k < G; k++) {
-      const bool act = k < ncand;
-      if (!__any(act)) break;
-      const int pr = act ? S.col.cand[k] : 0;
+    HSTAMP(60);
+    while (__any(boxm != 0u)) {
+      const bool isbox = boxm != 0u;
+      const int k = isbox ? __ffs(boxm) - 1 : 0;
+      boxm &= boxm - 1u;
+      const int pr = isbox ? S.col.cand[k] : 0;
       const int g1 = pr & 255, g2 = pr >> 8 & 255;
-      const bool isbox = act && (pr >> 16 & 255) != MIR_GEOM_PLANE && (!CONVEX || ((pr >> 16 & 255) == MIR_GEOM_BOX && (pr >> 24) == MIR_GEOM_BOX));
-      if (!__any(isbox)) continue;
       if (isbox) {  // whole rows
         const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
         const BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
@@ -595,6 +602,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         if (lane == k) mycount = cnt;
       }
     }
+    HSTAMP(61);
     if constexpr (CONVEX) {
       // narrowphase of the round shapes, LANE-PRIVATE: lane c takes candidate c.  Plane - sphere / capsule in closed form
       // (one / two points at half depth), every other pair that is not box - box through GJK on the cores, MPR when the

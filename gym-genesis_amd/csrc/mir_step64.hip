@@ -734,14 +734,32 @@ void mir_step64_kernel(StepArgs64 a) {
       STAMP(6);
       // narrowphase, plane-box: DPP row r takes candidates r, r + 4, ...; the 8 box corners on lanes 0..7 of the row
       // (skipped as a whole when no candidate has a plane: on the kitchen slab nothing reaches the floor)
-      if (any_plane) for (int k0 = 0; k0 < ncand; k0 += 4) {
-        const int k = k0 + blk;
-        const bool act = k < ncand;
-        const int pr = act ? (int)S.pairs[S.col.cand[k] & 0xffff] : 0;
+      // (round 5: the candidates of the kind are ranked first, and trip t serves the ranks 4t .. 4t + 3 -- as many trips as a quarter of
+      // their number, where positions r, r + 4, ... made one trip per group of four list positions that held any)
+      unsigned long long kindm = 0ull;  // (wave-uniform: the walk below is scalar work)
+      auto kth_of_row = [&]() -> int {  // takes the four lowest candidates off the mask: row r gets the r-th of them, or -1
+        int k = -1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int kr = kindm ? __ffsll(kindm) - 1 : -1;
+          kindm &= kindm - 1ull;
+          if (blk == r) k = kr;
+        }
+        return k;
+      };
+      if (any_plane) {
+        bool mine = false;
+        if (lane < ncand) {
+          const int prl = (int)S.pairs[S.col.cand[lane] & 0xffff];
+          mine = (__float_as_int(S.gts[prl & 255][0]) & 255) == MIR_GEOM_PLANE && (!CONVEX || (__float_as_int(S.gts[prl >> 8][0]) & 255) == MIR_GEOM_BOX);
+        }
+        kindm = __ballot(mine);
+      }
+      while (kindm) {
+        const int k = kth_of_row();
+        const bool isplane = k >= 0;
+        const int pr = isplane ? (int)S.pairs[S.col.cand[k] & 0xffff] : 0;
         const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isplane = act && (__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_PLANE &&
-                             (!CONVEX || (__float_as_int(S.gts[g2][0]) & 255) == MIR_GEOM_BOX);
-        if (!__any(isplane)) continue;
         const M3 Rp = q2m(ld4v(S.col.gquat[g1]));
         const V3 n = mcol(Rp, 2), eu = mcol(Rp, 0), ev = mcol(Rp, 1);
         const M3 R2 = q2m(ld4v(S.col.gquat[g2]));
@@ -824,15 +842,20 @@ void mir_step64_kernel(StepArgs64 a) {
 #endif
       // narrowphase, box-box: DPP row r takes candidates r, r + 4, ... (like plane-box).  The 15 separating axes sit on
       // lanes 0..14 of the row, the incident-face vertices on lanes 0..3 (box_box_row, mir_dev.h)
-      if (any_solid) for (int k0 = 0; k0 < ncand; k0 += 4) {
-        const int k = k0 + blk;
-        const bool actk = k < ncand;
-        const int cd = actk ? S.col.cand[k] : 0;
-        const int pr = actk ? (int)S.pairs[cd & 0xffff] : 0;
+      if (any_solid) {
+        bool mine = false;
+        if (lane < ncand && (S.col.cand[lane] >> 16) == 0) {
+          const int prl = (int)S.pairs[S.col.cand[lane] & 0xffff];
+          const int t1l = __float_as_int(S.gts[prl & 255][0]) & 255, t2l = __float_as_int(S.gts[prl >> 8][0]) & 255;
+          mine = t1l != MIR_GEOM_PLANE && (!CONVEX || (t1l == MIR_GEOM_BOX && t2l == MIR_GEOM_BOX));
+        }
+        kindm = __ballot(mine);
+      }
+      while (kindm) {
+        const int k = kth_of_row();
+        const bool isbox = k >= 0;
+        const int pr = isbox ? (int)S.pairs[S.col.cand[k] & 0xffff] : 0;
         const int g1 = pr & 255, g2 = pr >> 8;
-        const bool isbox = actk && (cd >> 16) == 0 && (__float_as_int(S.gts[g1][0]) & 255) != MIR_GEOM_PLANE &&
-                           (!CONVEX || ((__float_as_int(S.gts[g1][0]) & 255) == MIR_GEOM_BOX && (__float_as_int(S.gts[g2][0]) & 255) == MIR_GEOM_BOX));
-        if (!__any(isbox)) continue;
         if (isbox) {  // whole rows
           const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
           const BoxG A = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3(&S.gts[g1][1])};

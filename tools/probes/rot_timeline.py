@@ -20,7 +20,7 @@ acts = [torch.empty((B, 9), device=task.device).uniform_(-1, 1, generator=g) for
 NAMES = {24: "w0 entry", 0: "w0 state loaded", 1: "w0 table ready", 48: "w0 prologue done", 6: "w0 rows done (newton init next)", 7: "w0 newton init done",
          16: "w0 it0 start", 51: "w0 at (4)", 53: "w0 past (4)", 8: "w0 newton done", 30: "w0 TERMINATED BYTES STORED", 9: "w0 integrated",
          25: "w0 exit", 11: "w0 [next] fk/poses in", 12: "w0 [next] crb", 13: "w0 [next] rne+M", 5: "w0 [next] dyn done", 10: "w0 [next] top of pass",
-         54: "w1 rows loaded = at (3)", 55: "w1 hessian done = at (4)", 56: "w1 past (5)", 57: "w1 closing fk done = at (6)", 40: "w1 [next] past (1)",
+         54: "w1 rows loaded = at (3)", 55: "w1 hessian done = at (4)", 56: "w1 past (5)", 57: "w1 closing fk done = at (6)", 58: "w1 [next] geoms placed", 59: "w1 [next] broadphase done", 60: "w1 [next] plane-box done", 61: "w1 [next] box-box done", 40: "w1 [next] past (1)",
          41: "w1 [next] inertias out", 42: "w1 [next] detection done", 45: "w1 [next] contacts done", 46: "w1 [next] past (3)", 47: "w1 [next] rows stored",
          43: "w1 [next] 43", 44: "w1 [next] 44", 49: "w0 49", 50: "w0 50", 52: "w0 52", 3: "w0 3", 4: "w0 4", 2: "w0 2", 32: "w0 32", 33: "w0 33", 34: "w0 34", 35: "w0 35",
          22: "w0 22", 23: "w0 23", 14: "w0 it0 14", 15: "w0 it0 15", 17: "w0 it0 17", 18: "w0 it0 18", 19: "w0 it0 19", 20: "w0 it0 20", 21: "w0 it0 end"}
@@ -37,7 +37,7 @@ for rep in range(40):
     if p[24] == 0:
         continue
     n += 1
-    for k in list(range(0, 26)) + [30] + list(range(32, 36)) + list(range(40, 58)):
+    for k in list(range(0, 26)) + [30] + list(range(32, 36)) + list(range(40, 62)):
         if p[k] > 0:
             acc.setdefault(k, []).append(p[k] - p[24])
     for it in range(8):
