@@ -37,9 +37,11 @@ class GenesisEnv(Env):
 
     def __init__(self, task, robot="so101", enable_pixels=False, observation_height=480, observation_width=640,
                  num_envs=1, env_spacing=(1.0, 1.0), render_mode=None, camera_capture_mode="per_env",
-                 strip_environment_state=True, shard: Optional[Tuple[int, int]] = None, **task_kwargs):
-        # (shard and task_kwargs are additions to the reference signature: the env-axis shard of this process, and options of
-        # this backend's scene restatement, e.g. link_shape="capsule" for the Franka pick task)
+                 strip_environment_state=True, shard: Optional[Tuple[int, int]] = None, record_video: bool = False, **task_kwargs):
+        # (shard, record_video and task_kwargs are additions to the reference signature: the env-axis shard of this process; whether
+        # reset() starts the camera recording that save_video() writes -- the reference always does with pixels, here it is asked
+        # for, because the recorded frames stay alive and the README loop then runs 6-25 % slower; and options of this
+        # backend's scene restatement, e.g. link_shape="capsule" for the Franka pick task)
         super().__init__()
         self.task = task
         self.robot = robot
@@ -54,6 +56,7 @@ class GenesisEnv(Env):
         self._task_kwargs = task_kwargs
         self.num_envs = num_envs
         self._env = self._make_env_task(task)
+        self._env.record_video = bool(record_video)
         # local shard size when sharded; the unbatched tasks (num_envs = 0) keep 0 like the reference (env.py:56,65)
         self.num_envs = 0 if getattr(self._env, "unbatched", False) else self._env.num_envs
         self.observation_space = self._env.observation_space
@@ -116,7 +119,13 @@ class GenesisEnv(Env):
         if self.enable_pixels and save_video:
             warnings.warn("Calling `save_video()` stops the camera recording; no further frames can be recorded.",
                           stacklevel=2)
-            self._env.cam.stop_recording(save_to_filename=file_name, fps=fps)
+            # (the three-camera stack tasks have no `cam`: the reference raises AttributeError there; the top view is saved here)
+            cam = getattr(self._env, "cam", None) or self._env.cam_top
+            if not getattr(cam, "recording", False):
+                warnings.warn(f"no recording is running (GenesisEnv(..., record_video=True) starts one at every reset): nothing was "
+                              f"written to {file_name!r}", stacklevel=2)
+                return
+            cam.stop_recording(save_to_filename=file_name, fps=fps)
 
     def get_obs(self):
         return self._env.get_obs()

@@ -143,6 +143,8 @@ class FrankaCubePickBatch:
         pos = self._mir.staged(self.sample_spawn()[self.shard_lo:self.shard_hi])  # (pinned: the reset kernel reads it in place)
         self._mir.reset(pos, self._quat, self._home)  # set_pos/set_quat/set_qpos(zero_velocity) + PD targets = home
         self._mir.step(1)                             # the reference consumes one physics step in reset()
+        if self.enable_pixels and getattr(self, "record_video", False):
+            self.cam.start_recording()                # cube_pick.py:109-110
         return self.get_obs()
 
     def reset_masked(self, env_mask):

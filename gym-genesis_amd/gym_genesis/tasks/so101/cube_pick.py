@@ -114,6 +114,8 @@ class CubePick:
     def reset(self):
         pos = self._mir.staged(self.sample_spawn()[self.shard_lo:self.shard_hi])  # (pinned: the reset kernel reads it in place)
         self._mir.reset(pos, self._quat, self._zero)  # no scene.step() here (so101/cube_pick.py:81)
+        if self.enable_pixels and getattr(self, "record_video", False):
+            self.cam.start_recording()                # so101/cube_pick.py:83-84
         return self.get_obs()
 
     def step(self, action, host_terminated: bool = False):

@@ -114,6 +114,9 @@ class StackTaskBase:
         pos = self._mir.staged(self.sample_spawn()[self.shard_lo:self.shard_hi])  # (pinned: the reset kernel reads it in place)
         self._mir.reset(pos, self._quat, self._home)  # set_pos/set_quat x5 + set_qpos(zero_velocity) + PD targets = home
         self._mir.step(1)                             # both references consume one physics step in reset()
+        if self.enable_pixels and getattr(self, "record_video", False):  # cube_stack_kitchen_batch.py:110-113, so101/cube_stack_batch.py:114-117
+            for cam in (self.cam_top, self.cam_side, self.cam_wrist):
+                cam.start_recording()
         return self.get_obs()
 
     def reset_masked(self, env_mask):

@@ -156,6 +156,7 @@ class CameraView:
         #  too -- an edit by the caller, a normalisation or an overlay, makes render() draw again)
         self._last_global = (getattr(self._mir, "state_version", None), self.pos, self.lookat, self.res, self.fov, self._up, id(self._vis),
                              img, img._version)
+        self._record(img)
         return img
 
     def render_envs(self, pos=None, lookat=None, out=None) -> torch.Tensor:
@@ -178,19 +179,61 @@ class CameraView:
         ver = getattr(self._mir, "state_version", None)
         same = (last is not None and ver is not None and last[:7] == (ver, self.pos, self.lookat, self.res, self.fov, self._up, id(self._vis))
                 and last[7]._version == last[8])
-        img = last[7] if same else self.render_global()
+        if same:
+            img = last[7]
+            self._record(img)  # (a frame per call, as in Genesis)
+        else:
+            img = self.render_global()
         return img.cpu().numpy(), None, None, None
 
-    def start_recording(self) -> None:  # cube_stack_kitchen_batch.py:111-113; video encoding is out of scope
+    # ---- recording (cam.start_recording() at reset -- the reference: always with pixels, cube_pick.py:109-110; here: when the env was
+    # made with record_video=True, see env.py; env.save_video -> cam.stop_recording: env.py:71-79).  Genesis appends the image of every cam.render() while a recording runs.  Here the GLOBAL renders are recorded --
+    # render() and the `global` pixels observation -- as references to the device tensors they returned (no copy, nothing on the
+    # env.step() path); the per-env observation images (one launch for all envs, into a reused buffer) are not: the reference's B
+    # separate renders of a moving camera make no film either.  At most `max_recorded_frames` are kept (the newest).
+    max_recorded_frames = 1024
+
+    @property
+    def recording(self) -> bool:
+        return bool(self.__dict__.get("_recording"))
+
+    def start_recording(self) -> None:
         self._recording = True
+        self._frames = []
+        self._frames_dropped = 0
+
+    def _record(self, img) -> None:
+        if self.__dict__.get("_recording"):
+            fr = self._frames
+            fr.append((img, getattr(img, "_version", None)))
+            if len(fr) > self.max_recorded_frames:
+                del fr[0]
+                self._frames_dropped += 1
 
     def stop_recording(self, save_to_filename=None, fps=60) -> None:
-        # (a stub that warns -- video encoding is outside the env.step() hot path; the caller's episode goes on)
+        """Ends the recording and writes it: `.mp4` as Motion-JPEG in an ISO media file, `.gif` (tasks/video.py: this image has no H.264
+        encoder).  No file name: the frames are dropped, like Genesis."""
         import warnings
 
-        warnings.warn(f"video recording is not implemented by this backend: nothing was written to {save_to_filename!r} "
-                      "(reference: env.py:70-79 -> cam.stop_recording)", stacklevel=2)
-        self._recording = False
+        frames, dropped = self.__dict__.get("_frames") or [], self.__dict__.get("_frames_dropped", 0)
+        was_on = bool(self.__dict__.get("_recording"))
+        self._recording, self._frames, self._frames_dropped = False, [], 0
+        if not was_on:
+            raise RuntimeError("stop_recording() without start_recording(): reset the env with enable_pixels=True first")
+        if save_to_filename is None:
+            return
+        if dropped:
+            warnings.warn(f"the recording keeps the last {self.max_recorded_frames} frames: {dropped} older ones were dropped", stacklevel=2)
+        if not frames:
+            warnings.warn(f"no global render since the recording started: nothing was written to {save_to_filename!r}", stacklevel=2)
+            return
+        edited = sum(1 for f, v in frames if v is not None and f._version != v)
+        if edited:  # (frames are references to the tensors handed out as observations, not copies)
+            warnings.warn(f"{edited} recorded frames were modified in place after they were handed out: the file shows them as they are now",
+                          stacklevel=2)
+        from .video import write_video
+
+        write_video(save_to_filename, [f.cpu().numpy() if hasattr(f, "cpu") else np.asarray(f) for f, _ in frames], fps)
 
 
 class SceneView:

@@ -445,3 +445,52 @@ def test_render_reuses_the_observation_image_only_while_nothing_has_moved():
     assert not np.array_equal(c, d)
     env.reset()
     assert not np.array_equal(env.render(), d)
+
+
+def test_recording_from_reset_to_save_video(tmp_path):
+    """cam.start_recording() at reset, a frame per global render (the `global` pixels observation of every step, env.render()),
+    env.save_video -> an mp4 of Motion-JPEG frames (tasks/video.py) that decodes to the observations (env.py:71-79, cube_pick.py:109-110);
+    nothing is copied while recording: the frames are the observation tensors."""
+    import warnings
+    from gym_genesis.env import GenesisEnv
+    from gym_genesis.tasks.video import read_mjpeg_mp4
+
+    B = 64
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, observation_height=120, observation_width=160,
+                     camera_capture_mode="global", record_video=True)
+    obs, _ = env.reset(seed=0)
+    want = [obs["pixels"]]
+    act = np.random.default_rng(0).uniform(-1, 1, (B, 9)).astype(np.float32)
+    for _ in range(5):
+        obs, *_ = env.step(act)
+        want.append(obs["pixels"])
+    want.append(torch.from_numpy(env.render()))          # (the reused image: a frame of its own, as in Genesis)
+    cam = env._env.cam
+    assert len(cam._frames) == 7 and all(f.data_ptr() == w.data_ptr() for (f, _), w in zip(cam._frames[:6], want))
+    path = str(tmp_path / "episode.mp4")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        env.save_video(save_video=True, file_name=path, fps=60)
+    assert len(rec) == 1 and "stops the camera recording" in str(rec[0].message)
+    frames, fps, wh = read_mjpeg_mp4(path)
+    assert len(frames) == 7 and fps == 60.0 and wh == (160, 120)
+    for got, w in zip(frames, want):
+        assert np.abs(got.astype(int) - w.cpu().numpy().astype(int)).mean() < 4.0
+    # the cap: only the newest frames are kept
+    env.reset()
+    cam.max_recorded_frames = 3
+    for _ in range(5):
+        env.step(act)
+    assert len(cam._frames) == 3 and cam._frames_dropped == 3
+    with pytest.warns(UserWarning, match="older ones were dropped"):
+        cam.stop_recording(save_to_filename=str(tmp_path / "tail.mp4"), fps=30)
+    assert len(read_mjpeg_mp4(str(tmp_path / "tail.mp4"))[0]) == 3
+    # the three-camera stack tasks: save_video writes the top view (the reference has no `cam` there and raises AttributeError)
+    env = GenesisEnv(task="cube_stack", robot="franka", num_envs=4, enable_pixels=True, observation_height=96, observation_width=128,
+                     camera_capture_mode="global", record_video=True)
+    env.reset(seed=0)
+    env.step(np.zeros((4, 9), np.float32))
+    with pytest.warns(UserWarning):
+        env.save_video(save_video=True, file_name=str(tmp_path / "stack.mp4"))
+    frames, _, wh = read_mjpeg_mp4(str(tmp_path / "stack.mp4"))
+    assert len(frames) == 2 and wh == (128, 96)

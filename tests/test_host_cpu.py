@@ -223,7 +223,7 @@ def test_env_accessors_and_errors(env):
     assert GenesisEnv.metadata == {"render_modes": ["rgb_array"], "render_fps": 50}     # env.py:15
 
 
-def test_pixels_contract_on_the_test_double(monkeypatch):
+def test_pixels_contract_on_the_test_double(monkeypatch, tmp_path):
     """enable_pixels=True: obs keys, shapes, dtypes and error behaviour of the reference (cube_pick.py:70-84,159-180,
     env.py:97-98), host logic only (the images come from the oracle ray caster through the test double)."""
     import fake_scene
@@ -233,7 +233,7 @@ def test_pixels_contract_on_the_test_double(monkeypatch):
     monkeypatch.setattr(cube_pick, "MirScene", fake_scene.OracleScene)
     B, H, W = 2, 24, 32
     env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, observation_height=H, observation_width=W,
-                     camera_capture_mode="per_env")
+                     camera_capture_mode="per_env", record_video=True)
     obs, _ = env.reset(seed=0)
     assert set(obs) == {"agent_pos", "pixels"}                                           # strip_environment_state default
     assert tuple(obs["pixels"].shape) == (B, H, W, 3) and obs["pixels"].dtype == torch.uint8
@@ -242,7 +242,7 @@ def test_pixels_contract_on_the_test_double(monkeypatch):
     assert isinstance(frame, np.ndarray) and frame.shape == (H, W, 3) and frame.dtype == np.uint8
     assert env.get_cams() is env._env.cam                                                # cube_pick.py:69-72
     env2 = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, observation_height=H, observation_width=W,
-                      camera_capture_mode="global", strip_environment_state=False)
+                      camera_capture_mode="global", strip_environment_state=False, record_video=True)
     obs2, _ = env2.reset(seed=0)
     assert set(obs2) == {"agent_pos", "environment_state", "pixels"} and tuple(obs2["pixels"].shape) == (H, W, 3)
     with pytest.raises(ValueError):
@@ -250,11 +250,36 @@ def test_pixels_contract_on_the_test_double(monkeypatch):
     # the camera sits at (3.5, 0, 2.5) looking at (0, 0, 0.5) with fov 30 (cube_pick.py:57-62)
     cam = env._env.cam
     assert cam.pos == (3.5, 0.0, 2.5) and cam.lookat == (0.0, 0.0, 0.5) and cam.fov == 30.0 and cam.res == (W, H)
-    # save_video (env.py:70-79): the reference's own warning, then the backend's stub warns that nothing is written; the env goes on
-    with pytest.warns(UserWarning) as rec:
-        env.save_video(save_video=True, file_name="episode.mp4")
-    assert any("not implemented" in str(w.message) for w in rec) and any("stops the camera recording" in str(w.message) for w in rec)
+    # save_video (env.py:70-79): with record_video=True the recording started at reset() (cube_pick.py:109-110) holds the global renders since -- the one
+    # env.render() above, two more here -- and is written as Motion-JPEG in an mp4 (tasks/video.py); the env goes on afterwards
+    from gym_genesis.tasks.video import read_mjpeg_mp4
     env.step(np.zeros((B, 9), np.float32))
+    f2 = env.render()
+    f3 = env.render()
+    path = str(tmp_path / "episode.mp4")
+    with pytest.warns(UserWarning, match="stops the camera recording"):
+        env.save_video(save_video=True, file_name=path, fps=30)
+    frames, fps, wh = read_mjpeg_mp4(path)
+    assert len(frames) == 3 and fps == 30.0 and wh == (W, H) and all(f.shape == (H, W, 3) for f in frames)
+    for got, want in zip(frames, (frame, f2, f3)):   # (JPEG at quality 90: a few grey levels on these flat-shaded images)
+        assert np.abs(got.astype(int) - want.astype(int)).mean() < 4.0
+    env.save_video(save_video=False, file_name=str(tmp_path / "never.mp4"))          # (save_video=False: nothing happens, env.py:72)
+    assert not (tmp_path / "never.mp4").exists()
+    with pytest.raises(RuntimeError):                                                 # (the recording was stopped above)
+        env._env.cam.stop_recording(save_to_filename=path)
+    env.step(np.zeros((B, 9), np.float32))
+    # the `global` pixels observation IS a global render: every step of env2 added a frame; a .gif works too
+    env2.step(np.zeros((B, 9), np.float32))
+    with pytest.warns(UserWarning):
+        env2.save_video(save_video=True, file_name=str(tmp_path / "episode.gif"), fps=20)
+    from PIL import Image
+    assert Image.open(str(tmp_path / "episode.gif")).n_frames == 2
+    # without record_video (the default: recorded frames stay alive, which costs the README loop 6-25 %) save_video says what to do
+    env3 = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, observation_height=H, observation_width=W)
+    env3.reset(seed=0)
+    with pytest.warns(UserWarning, match="record_video=True"):
+        env3.save_video(save_video=True, file_name=str(tmp_path / "none.mp4"))
+    assert not (tmp_path / "none.mp4").exists()
 
 
 def test_seeded_reset_is_deterministic(env):
