@@ -153,4 +153,4 @@ def test_more_ranks_than_gpus_is_refused_before_any_rank_starts():
 def test_cpu_baseline_runs_in_a_child_with_bound_threads_and_reports_its_spread():
     cb = bench.cpu_baseline(1.0)
     assert cb["kind"] == "port" and cb["min"] <= cb["value"] <= cb["max"] and cb["threads"] == cb["cores"] >= 1 and cb["value"] > 1e4
-    assert "median of 5 runs" in cb["sample"]
+    assert "best of 5 runs" in cb["sample"] and cb["value"] == cb["max"] >= cb["median"] >= cb["min"]
