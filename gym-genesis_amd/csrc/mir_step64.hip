@@ -837,9 +837,6 @@ void mir_step64_kernel(StepArgs64 a) {
         }
         WSYNC();
       }
-#ifdef MIR_PROFILE_SINGLE
-      if (a.prof && a.prof[33] == 77ull) STAMP(34);
-#endif
       // narrowphase, box-box: DPP row r takes candidates r, r + 4, ... (like plane-box).  The 15 separating axes sit on
       // lanes 0..14 of the row, the incident-face vertices on lanes 0..3 (box_box_row, mir_dev.h)
       if (any_solid) {
@@ -851,6 +848,10 @@ void mir_step64_kernel(StepArgs64 a) {
         }
         kindm = __ballot(mine);
       }
+#ifdef MIR_PROFILE_SINGLE
+      STAMP(36);
+      if (a.prof && blockIdx.x == 0 && lane == 0) a.prof[38] = (unsigned long long)__popcll(kindm);
+#endif
       while (kindm) {
         const int k = kth_of_row();
         const bool isbox = k >= 0;
@@ -864,10 +865,10 @@ void mir_step64_kernel(StepArgs64 a) {
           if (l16 == 0) S.col.ccount[k] = cnt;
         }
       }
-      WSYNC();
 #ifdef MIR_PROFILE_SINGLE
-      if (a.prof && a.prof[33] == 77ull) STAMP(35);
+      STAMP(37);
 #endif
+      WSYNC();
       if constexpr (CONVEX) {
         // narrowphase of the round shapes, LANE-PRIVATE: lane c takes candidate c (see mir_step.hip).  Lanes diverge here and
         // reconverge at the end of the block.  (Skipped as a whole when no candidate has a round geom or a hull: wave-uniform.)

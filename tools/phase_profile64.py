@@ -36,7 +36,7 @@ n = 20
 dual = np.zeros(12)
 fine = np.zeros(6)
 for r in range(n):
-    prof = torch.zeros(32, dtype=torch.int64, device=sc.device)
+    prof = torch.zeros(48, dtype=torch.int64, device=sc.device)
     sc._check(sc.lib.mir_debug_profile_step(sc.h, C.c_void_p(prof.data_ptr()), sc._stream()))
     torch.cuda.synchronize()
     p = prof.cpu().numpy().astype(np.float64)
@@ -47,6 +47,8 @@ for r in range(n):
         p[6] = p[7] = p[8] = p[5]
         fine += np.array([p[20] - p[11], p[21] - p[20], p[22] - p[21], p[12] - p[22], p[23] - p[12], p[29] - p[28]])
     acc += np.diff(p[:20])
+    if p[36] > 0 and r == 0: print(  # (stamps 36 - 38: around the loop of the 15-axis routine, its candidate count)
+        f'   box-box loop: {p[37]-p[36]:.0f} cycles for {int(p[38])} candidates of the 15-axis routine ({(int(p[38]) + 3) // 4} trips)')
     if p[30] > 0: print(f'   it0: H walk {p[30]-p[13]:.0f}, coupled_solve {p[31]-p[30]:.0f} cycles') if r == 0 else None
 acc /= n
 if dual.any():

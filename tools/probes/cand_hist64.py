@@ -26,5 +26,5 @@ cnt = np.stack([(w >> s) & 31 for s in (0, 5, 10, 15, 20, 25)], 1)
 print(robot, "candidates per env (mean / max):", {n: (round(float(cnt[:, i].mean()), 2), int(cnt[:, i].max())) for i, n in enumerate(names)})
 print("envs with at least one box-box routine call %.3f, with at least one convex call %.3f" % ((cnt[:, 3] > 0).mean(), (cnt[:, 4] > 0).mean()))
 p = prof.cpu().numpy().astype(np.float64)
-print("workgroup 0, collision wave: broadphase end -> plane-box end %.0f | slab path %.0f | box-box loop %.0f | convex block + bookkeeping %.0f | kinds of env 0: %s" % (
-    p[7] - p[6], p[34] - p[7], p[35] - p[34], p[8] - p[35], cnt[0].tolist()))
+print("workgroup 0, collision wave: broadphase end -> plane-box end %.0f | slab path %.0f | box-box loop %.0f (%d candidates) | convex block + bookkeeping %.0f | kinds of env 0: %s" % (
+    p[7] - p[6], p[36] - p[7], p[37] - p[36], int(p[38]), p[8] - p[37], cnt[0].tolist()))
