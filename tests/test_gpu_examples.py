@@ -35,6 +35,28 @@ def test_expert_collection(tmp_path, monkeypatch, script, env_dim, min_frac):
     assert d["episode_index"].max() == kept - 1 and np.isfinite(d["observation.state"]).all()
 
 
+def test_image_expert_collection_writes_one_video_per_successful_env(tmp_path, monkeypatch):
+    """examples/franka/pick_cube_image.py (the reference's pick_cube_image.py: the same expert with per-env pixels): the frames of the
+    whole batch stay on the device, the envs that lifted the cube become one Motion-JPEG .mp4 each + the LeRobot-named features."""
+    sys.path.insert(0, os.path.join(ROOT, "gym-genesis_amd"))
+    from gym_genesis.tasks.video import read_mjpeg_mp4
+
+    out = str(tmp_path / "img")
+    monkeypatch.setattr(sys, "argv", ["pick_cube_image", "--num-envs", "8", "--episodes", "1", "--stages", "tuned", "--height", "96", "--width", "128",
+                                      "--out", out])
+    kept = _load("pick_cube_image").main()
+    assert kept >= 6, kept
+    d = np.load(os.path.join(out, "episodes.npz"))
+    assert d["action"].shape == (kept * 200, 9) and d["observation.state"].shape == (kept * 200, 9) and d["episode_index"].max() == kept - 1
+    vids = sorted(os.listdir(os.path.join(out, "videos")))
+    assert vids == [f"episode_{k:06d}.mp4" for k in range(kept)]
+    frames, fps, wh = read_mjpeg_mp4(os.path.join(out, "videos", vids[0]))
+    assert len(frames) == 200 and fps == 60.0 and wh == (128, 96)
+    # the arm moves and the cube goes up: first and last frame differ, consecutive ones hardly
+    f = np.stack(frames).astype(int)
+    assert np.abs(f[-1] - f[0]).mean() > 5 * np.abs(f[101] - f[100]).mean() > 0
+
+
 def test_step_outputs_are_fresh_tensors_on_the_device():
     """GenesisEnv.step() hands out new tensors every call (the next call's outputs are allocated while the kernel runs):
     what the caller keeps from one step is not touched by later steps."""
