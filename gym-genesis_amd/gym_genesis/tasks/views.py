@@ -219,7 +219,11 @@ class CameraView:
         was_on = bool(self.__dict__.get("_recording"))
         self._recording, self._frames, self._frames_dropped = False, [], 0
         if not was_on:
-            raise RuntimeError("stop_recording() without start_recording(): reset the env with enable_pixels=True first")
+            # (the reference's collectors call cam.stop_recording("top.mp4") after every episode -- so_101/collect_task_stack_cube_batch.py:
+            #  199-201 -- and its tasks start a recording at every reset; here that takes record_video=True: the loop goes on)
+            warnings.warn(f"no recording is running (GenesisEnv(..., record_video=True) starts one at every reset, or call "
+                          f"cam.start_recording()): nothing was written to {save_to_filename!r}", stacklevel=2)
+            return
         if save_to_filename is None:
             return
         if dropped:
