@@ -12,4 +12,9 @@ for B in (1024, 4096):
     for _ in range(200):
         obs, r, term, trunc, info = env.step(a); img = env.render()
     torch.cuda.synchronize(); t2 = time.perf_counter()
+    frames = []
+    for _ in range(200):
+        obs, r, term, trunc, info = env.step(a); frames.append(env.render())   # (a caller that keeps the frames: every array is new memory)
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    print(f"B={B}: the README loop with the frames kept {1e6*(t3-t2)/200:.0f} us per iteration")
     print(f"B={B} global pixels: env.step {1e6*(t1-t0)/200:.0f} us | env.step + env.render() (the README loop) {1e6*(t2-t1)/200:.0f} us; pixels {tuple(obs['pixels'].shape)} {obs['pixels'].device}")
