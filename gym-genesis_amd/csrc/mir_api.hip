@@ -486,6 +486,7 @@ int mir_destroy(MirHandle h) {
   if (h->cost) (void)hipFree(h->cost);
   if (h->bins) (void)hipFree(h->bins);
   if (h->zbuf) (void)hipFree(h->zbuf);
+  if (h->vis) (void)hipFree(h->vis);
   if (h->done_ticket) (void)hipFree(h->done_ticket);
   if (h->scratch_row) (void)hipFree(h->scratch_row);
   if (h->pre) (void)hipFree(h->pre);

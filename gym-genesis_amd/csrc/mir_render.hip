@@ -74,6 +74,7 @@ struct Cam {
   int W, H;
 };
 
+#define GLOBAL_ITEMS_MAX 32 /* work items per box of the global splat: an entry = box index (22 bits) | item << 22 | (items - 1) << 27 */
 struct SetupArgs {
   const GeomTab* geom;
   const float* poses;       // (B, 2, pst, 4) FK cache
@@ -90,6 +91,7 @@ struct SetupArgs {
   float chk[2][3];
   float amb, dif, inv_chk;
   int B, ngeom, global_mode;
+  unsigned* vis;            // global view of many envs: the boxes that can be on screen are LISTED here ([0] = count), the others skipped
 };
 
 struct PixArgs {
@@ -172,6 +174,21 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
   const V3 rel = cp - c;
   const float* gs = m->g_size[g];
   const V3 h = gtype == MIR_GEOM_SPHERE ? V3{gs[0], gs[0], gs[0]} : (gtype == MIR_GEOM_CAPSULE ? V3{gs[0], gs[0], gs[0] + gs[1]} : V3{gs[0], gs[1], gs[2]});
+  if constexpr (!BIN) {
+    // The global view of thousands of envs shows a few dozen of them (the camera stands inside the grid: 99 % of the boxes are beside or
+    // behind it).  A box whose bounding sphere lies outside the view pyramid is dropped HERE, before its corners and bounds are worked
+    // out and without a record: the splat kernel walks the list of the others (a.vis), nobody reads the records of these.  Conservative:
+    // every point p of the sphere has |p_x| >= |x_c| - r and p_z <= z_c + r.
+    if (a.vis && type == MIR_GEOM_BOX) {
+      const float r = sqrtf(dot(h, h));
+      const float zc = -dot(rel, cf), xc = fabsf(dot(rel, cr)), yc = fabsf(dot(rel, cu));
+      if (zc + r <= 1e-3f || xc - r > (zc + r) * a.cam.tanx || yc - r > (zc + r) * a.cam.tany) {
+        // (k_global_resolve looks through env 0's records for the planes: the type word must say "box" even here)
+        if (e == 0) reinterpret_cast<f4*>(a.prims + (size_t)i * PREC)[0] = f4{0.0f, 0.0f, 0.0f, __int_as_float(MIR_GEOM_BOX)};
+        return;
+      }
+    }
+  }
   const V3 o = {dot(ax[0], rel), dot(ax[1], rel), dot(ax[2], rel)};
   const V3 F = {dot(ax[0], cf), dot(ax[1], cf), dot(ax[2], cf)}, R = {dot(ax[0], cr), dot(ax[1], cr), dot(ax[2], cr)};
   const V3 U = {dot(ax[0], cu), dot(ax[1], cu), dot(ax[2], cu)};
@@ -290,6 +307,16 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
     }
     o4[5] = q5;
     o4[6] = q6;
+  }
+  if constexpr (!BIN) {
+    if (a.vis && type == MIR_GEOM_BOX && xmin <= xmax && ymin <= ymax) {
+      // work items of k_global_splat: the 32 x 8 blocks of the rectangle in up to GLOBAL_ITEMS_MAX interleaved shares of about four
+      // (a slab close to the camera covers hundreds of blocks and must not keep one workgroup busy after the others have left)
+      const int nb = ((xmax >> 5) - (xmin >> 5) + 1) * ((ymax >> 3) - (ymin >> 3) + 1);
+      const unsigned n = (unsigned)min(GLOBAL_ITEMS_MAX, (nb + 3) >> 2);
+      const unsigned at = atomicAdd(a.vis, n);
+      for (unsigned k = 0; k < n; k++) a.vis[1u + at + k] = (unsigned)i | k << 22 | (n - 1u) << 27;  // (i < 2^22: checked by mir_render)
+    }
   }
   if (!BIN) return;
   // ---- per-strip primitive lists of the binned pixel kernel (per-env images with <= 63 primitives), built while the rectangles
@@ -704,19 +731,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 
 // ---- the global view of MANY envs (camera_capture_mode="global", the registry's default; GenesisEnv.render()) ------------------------
 // One image, B x ngeom primitives, each a few hundred pixels of it.  The tiled kernels walk a tile's whole primitive list: 25 workgroups
-// of a 480 x 640 image each cull 82 000 records of 4096 envs -- 17.8 ms.  Here every BOX is drawn by a workgroup of its own over its own
-// screen rectangle (lane = pixel of a 32 x 8 block) into a 64-bit depth / colour buffer with atomic max on  w << 32 | colour
+// of a 480 x 640 image each cull 82 000 records of 4096 envs -- 17.8 ms.  Here k_render_setup lists the boxes that can be on screen as work
+// items (a box's screen rectangle in shares of about four 32 x 8 blocks) and every item is drawn by a workgroup (lane = pixel of a
+// block) into a 64-bit depth / colour buffer with atomic max on  w << 32 | colour
 // (w = reciprocal depth > 0: its float bits order like unsigned integers), then one pass resolves the buffer against the planes
 // (drawn once: env 0's) and the sky and stores RGB8.  Same per-pixel expressions as box_bounds / plane_region / the floor path of
 // mir_render_kernel, so the two agree except where two surfaces tie in depth to the last bit (the tiled kernels keep the first one
 // in list order, the maximum here keeps the larger colour word).
-#define GLOBAL_BIG_BLOCKS 24 /* 32 x 8 blocks */
-#define GLOBAL_BIG_MAX 512
-#define GLOBAL_BIG_SPLIT 24
 struct SplatArgs {
   const float* prims;
   unsigned long long* zbuf;  // (H, W): w bits << 32 | packed RGB8, 0 = nothing
-  unsigned* big;             // [0] boxes with large rectangles this render, [1 ..] their indices (behind zbuf: cleared with it)
+  unsigned* vis;             // [0] work items, [1 ..] box index | share << 22 | (shares - 1) << 27 (written by k_render_setup; count reset by k_global_resolve)
   uint8_t* pixels;
   int W, H, nprim, ngeom;
   float x0, dx, y0, dy;
@@ -724,7 +749,8 @@ struct SplatArgs {
 };
 
 // one box, the 32 x 8 blocks b = first, first + stride, ... of its rectangle (row-major), lane = pixel
-__device__ __forceinline__ void splat_box(const SplatArgs& a, const float* prim, int first, int stride, bool defer_big) {
+__device__ __forceinline__ void splat_box(const SplatArgs& a, unsigned iprim, int first, int stride) {
+  const float* prim = a.prims + (size_t)iprim * PREC;
   const int tid = threadIdx.x;
   const cf4* rec = (const cf4*)(uintptr_t)prim;
   const f4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
@@ -733,17 +759,6 @@ __device__ __forceinline__ void splat_box(const SplatArgs& a, const float* prim,
   const int xmin = __float_as_int(q1.w), xmax = min(__float_as_int(q2.w), a.W - 1), ymin = __float_as_int(q3.w), ymax = min(__float_as_int(q4.w), a.H - 1);
   if (xmin > xmax || ymin > ymax) return;
   const int nbx = (xmax >> 5) - (xmin >> 5) + 1, nb = nbx * ((ymax >> 3) - (ymin >> 3) + 1);
-  if (defer_big && nb > GLOBAL_BIG_BLOCKS) {
-    // a box with a large rectangle (a slab close to the camera) would keep this one workgroup busy long after the others have
-    // left: it goes on a short list that k_global_splat_big spreads over GLOBAL_BIG_SPLIT workgroups each
-    __shared__ unsigned s_slot;
-    if (tid == 0) s_slot = atomicAdd(a.big, 1u);
-    __syncthreads();
-    if (s_slot < GLOBAL_BIG_MAX) {
-      if (tid == 0) a.big[1 + s_slot] = blockIdx.x;
-      return;
-    }
-  }
   const f4 q5 = rec[5], q7 = rec[7];
   const int nup = tw >> 8;
   const unsigned c0 = __float_as_uint(q5.x), c1 = __float_as_uint(q5.y), c2 = __float_as_uint(q5.z);
@@ -767,19 +782,24 @@ __device__ __forceinline__ void splat_box(const SplatArgs& a, const float* prim,
   }
 }
 
+#define GLOBAL_SPLAT_GRID 2048
 __global__ __launch_bounds__(256) void k_global_splat(SplatArgs a) {
   // (a WAVE per box with the waves taking boxes round robin is twice as slow: 1.0 ms at 4096 envs -- the few boxes with large rectangles
-  //  decide, and they want lanes)
-  splat_box(a, a.prims + (size_t)blockIdx.x * PREC, 0, 1, true);
-}
-// grid (GLOBAL_BIG_MAX, GLOBAL_BIG_SPLIT): workgroup (e, s) takes every GLOBAL_BIG_SPLIT-th block of the e-th listed box
-__global__ __launch_bounds__(256) void k_global_splat_big(SplatArgs a) {
-  if (blockIdx.x >= min(a.big[0], (unsigned)GLOBAL_BIG_MAX)) return;
-  splat_box(a, a.prims + (size_t)a.big[1 + blockIdx.x] * PREC, blockIdx.y, GLOBAL_BIG_SPLIT, false);
+  //  decide, and they want lanes.)  The workgroups walk the LIST of work items k_render_setup made of the boxes that can be on screen:
+  //  one workgroup per box of the scene was 57 000 workgroups at 4096 envs, 99 % of which found an empty rectangle and left (15.7 us
+  //  of dispatch), plus a second launch for the boxes with large rectangles (4.6 us).
+  const unsigned n = a.vis[0];
+  for (unsigned k = blockIdx.x; k < n; k += GLOBAL_SPLAT_GRID) {
+    const unsigned it = a.vis[1 + k];
+    splat_box(a, it & 0x3fffffu, (int)(it >> 22 & 31u), (int)(it >> 27) + 1);
+  }
 }
 
 // lane = 4 consecutive pixels of one row (one dwordx3 store when the width allows)
 __global__ __launch_bounds__(256) void k_global_resolve(SplatArgs a) {
+  // The buffer is handed back CLEAN: every key read here is zeroed again (the few that were written: most pixels show the floor), and
+  // the work-item count goes back to zero -- the next render starts without a memset of 2.4 MB (a launch of 5 us).
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.vis[0] = 0u;  // (the list's entries are overwritten before they are read)
   const int px = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, py = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (px >= a.W || py >= a.H) return;
   const float ys = a.y0 + (float)py * a.dy;
@@ -788,6 +808,7 @@ __global__ __launch_bounds__(256) void k_global_resolve(SplatArgs a) {
 #pragma unroll
   for (int p = 0; p < 4; p++) {
     const unsigned long long key = px + p < a.W ? a.zbuf[(size_t)py * a.W + px + p] : 0ull;
+    if (key) a.zbuf[(size_t)py * a.W + px + p] = 0ull;
     best[p] = __uint_as_float((unsigned)(key >> 32));
     col[p] = key ? (unsigned)key : a.sky;
   }
@@ -913,7 +934,7 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
       for (int k = 0; k < 3; k++) sa.rgb[g][k] = (float)vis->geom_rgb[g][k];
     sa.amb = (float)vis->ambient; sa.dif = (float)vis->diffuse; sa.inv_chk = (float)(1.0 / vis->checker_size);
     for (int k = 0; k < 3; k++) { sa.chk[0][k] = (float)vis->checker_rgb[0][k]; sa.chk[1][k] = (float)vis->checker_rgb[1][k]; }
-    sa.B = B; sa.ngeom = ng; sa.global_mode = mode == MIR_RENDER_GLOBAL;
+    sa.B = B; sa.ngeom = ng; sa.global_mode = mode == MIR_RENDER_GLOBAL; sa.vis = nullptr;
     PixArgs pa;
     memset(&pa, 0, sizeof pa);
     pa.prims = h->prims; pa.pixels = pixels; pa.W = cam->width; pa.H = cam->height;
@@ -949,21 +970,33 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
       hipLaunchKernelGGL(mir_render_binned, dim3((unsigned)((pa.nwg + 7) & ~7)), dim3(256), 0, st, pa);
     } else if (mode == MIR_RENDER_GLOBAL && pa.nprim > 512 && !h->render_generic) {
       // the global view of many envs: one workgroup per box into a depth / colour buffer, then a resolve pass (see k_global_splat)
-      const size_t npix = (size_t)cam->width * cam->height, need = npix + (GLOBAL_BIG_MAX + 2) / 2 + 1;  // (+ the list of large boxes)
+      const size_t npix = (size_t)cam->width * cam->height, need = npix;
       if (need > h->zbuf_cap) {
         if (h->zbuf) (void)hipFree(h->zbuf);
         h->zbuf = nullptr; h->zbuf_cap = 0;
         hipError_t e = hipMalloc((void**)&h->zbuf, need * sizeof(unsigned long long));
         if (e != hipSuccess) { rc = mir_set_error(MIR_E_HIP, hipGetErrorString(e)); break; }
         h->zbuf_cap = need;
+        // cleared ONCE: k_global_resolve leaves the pixels and the list of large boxes clean behind every render (whatever the camera's
+        // resolution: it zeroes exactly what that render wrote)
+        (void)hipMemsetAsync(h->zbuf, 0, need * sizeof(unsigned long long), st);
       }
+      const size_t vneed = (size_t)GLOBAL_ITEMS_MAX * pa.nprim + 1;  // (the worst case: every box fills the screen; touched only where written)
+      if (pa.nprim >= (1 << 22)) { rc = mir_set_error(MIR_E_CAPACITY, "mir_render: more than 2^22 primitives in a global view"); break; }
+      if (vneed > h->vis_cap) {
+        if (h->vis) (void)hipFree(h->vis);
+        h->vis = nullptr; h->vis_cap = 0;
+        hipError_t e = hipMalloc((void**)&h->vis, vneed * sizeof(unsigned));
+        if (e != hipSuccess) { rc = mir_set_error(MIR_E_HIP, hipGetErrorString(e)); break; }
+        h->vis_cap = vneed;
+        (void)hipMemsetAsync(h->vis, 0, sizeof(unsigned), st);  // (the count; k_global_resolve puts it back to zero behind every render)
+      }
+      sa.vis = h->vis;
       hipLaunchKernelGGL(k_render_setup<false>, dim3((B * ng + 255) / 256), dim3(256), 0, st, sa, BinArgs{});
-      (void)hipMemsetAsync(h->zbuf, 0, need * sizeof(unsigned long long), st);
       SplatArgs sp;
-      sp.prims = h->prims; sp.zbuf = h->zbuf; sp.big = reinterpret_cast<unsigned*>(h->zbuf + npix); sp.pixels = pixels; sp.W = cam->width; sp.H = cam->height; sp.nprim = pa.nprim; sp.ngeom = ng;
+      sp.prims = h->prims; sp.zbuf = h->zbuf; sp.vis = h->vis; sp.pixels = pixels; sp.W = cam->width; sp.H = cam->height; sp.nprim = pa.nprim; sp.ngeom = ng;
       sp.x0 = pa.x0; sp.dx = pa.dx; sp.y0 = pa.y0; sp.dy = pa.dy; sp.sky = pa.sky;
-      hipLaunchKernelGGL(k_global_splat, dim3((unsigned)pa.nprim), dim3(256), 0, st, sp);
-      hipLaunchKernelGGL(k_global_splat_big, dim3(GLOBAL_BIG_MAX, GLOBAL_BIG_SPLIT), dim3(256), 0, st, sp);
+      hipLaunchKernelGGL(k_global_splat, dim3(GLOBAL_SPLAT_GRID), dim3(256), 0, st, sp);
       hipLaunchKernelGGL(k_global_resolve, dim3((cam->width + 255) / 256, (cam->height + 3) / 4), dim3(256), 0, st, sp);
     } else {
       hipLaunchKernelGGL(k_render_setup<false>, dim3((B * ng + 255) / 256), dim3(256), 0, st, sa, BinArgs{});

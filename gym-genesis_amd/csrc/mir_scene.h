@@ -33,6 +33,8 @@ struct MirScene {
   int render_generic = 0;   // force the generic pixel kernel (mir_debug_render_path)
   unsigned long long* zbuf = nullptr;  // depth / colour buffer of the global view of many envs (mir_render.hip, k_global_splat)
   size_t zbuf_cap = 0;
+  unsigned* vis = nullptr;         // [0] boxes with a non-empty screen rectangle this render, [1 ..] their indices (k_render_setup -> k_global_splat)
+  size_t vis_cap = 0;
   unsigned long long state_version = 0;  // bumped by every call that changes qpos (launches that integrate, resets, state writes): mir_get_state_version
   int poses_live = 0;       // a render has been asked for: step launches also leave their final link poses in `poses` (mir_api.hip, launch())
   int poses_current = 0;    // `poses` matches qpos for every env (cleared by resets and state writes): mir_render skips the pose-refresh launch

@@ -1,5 +1,5 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, "gym-genesis_amd")
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gym-genesis_amd"))
 from gym_genesis.env import GenesisEnv
 for B in (1024, 4096):
     env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, camera_capture_mode="global")
