@@ -60,16 +60,29 @@ class EntityView:
     def get_qpos(self) -> torch.Tensor:
         return self.get_dofs_position()
 
+    def _cols(self, t: torch.Tensor) -> torch.Tensor:
+        """Columns `_qcols` of a (B, n) tensor: a slice when they are a run (every scene built here), else through an index tensor kept on
+        the device (a Python list as index is uploaded by every call: a synchronous copy in front of the launch)."""
+        qc = self._qcols
+        if qc == list(range(qc[0], qc[0] + len(qc))):
+            return t[:, qc[0]:qc[0] + len(qc)]
+        ix = self.__dict__.get("_qcols_t")
+        if ix is None or ix.device != t.device:
+            ix = self._qcols_t = torch.as_tensor(qc, dtype=torch.long, device=t.device)
+        return t.index_select(1, ix)
+
     def inverse_kinematics(self, link, pos=None, quat=None, init_qpos=None, envs_idx=None, return_error=False, **opts):
         """``robot.inverse_kinematics(link=eef, pos=(B,3), quat=(B,4), init_qpos=..., envs_idx=...)`` -> (B, n_dofs)
         (/root/reference/examples/franka/pick_cube_state.py:46-51).  One batched launch for all envs; `envs_idx` selects
         the rows returned (and addressed by pos / quat / init_qpos) as in Genesis.  `pos` is required (a quat-only target
-        is not on the reference's path)."""
+        is not on the reference's path).  (The reference's experts pass full-batch targets with `envs_idx=arange(B)` on every step of
+        their loops: that case costs the launch and one row gather -- no scatter, no clone, no index upload.)"""
         if pos is None:
             raise ValueError("inverse_kinematics needs a target position")
         mir = self._mir
         B = mir.num_envs
         idx = None if envs_idx is None else torch.as_tensor(envs_idx, device=mir.device).long().reshape(-1)
+        scattered = [False]
 
         def full(t, k):
             if t is None:
@@ -79,23 +92,27 @@ class EntityView:
                 return t
             out = torch.zeros((B, k), dtype=torch.float32, device=mir.device)
             out[idx] = t
+            scattered[0] = True
             return out
 
         p, q = full(pos, 3), full(quat, 4)
-        if q is not None and idx is not None and q.shape[0] == B:
-            q = q.clone()
-            q[:, 0] += (q.abs().sum(1) == 0).float()  # unaddressed rows: identity, so normalisation stays finite
+        if q is not None and scattered[0]:
+            q[:, 0] += (q.abs().sum(1) == 0).float()  # unaddressed rows: identity, so normalisation stays finite (q is full()'s own tensor)
         init = None
         if init_qpos is not None:
+            qc = self._qcols
+            iq = torch.as_tensor(init_qpos, dtype=torch.float32, device=mir.device).reshape(-1, len(qc))
             cur = mir.get_state()[0][:, :mir.n_arm].clone()
-            cur[:, self._qcols] = full(init_qpos, len(self._qcols)) if (idx is None or torch.as_tensor(init_qpos).shape[0] == B) else cur[:, self._qcols]
-            if idx is not None and torch.as_tensor(init_qpos).reshape(-1, len(self._qcols)).shape[0] != B:
-                cur[idx[:, None], torch.as_tensor(self._qcols, device=mir.device)[None, :]] = torch.as_tensor(
-                    init_qpos, dtype=torch.float32, device=mir.device).reshape(-1, len(self._qcols))
+            if idx is not None and iq.shape[0] != B:
+                cur[idx[:, None], torch.as_tensor(qc, device=mir.device)[None, :]] = iq
+            elif qc == list(range(qc[0], qc[0] + len(qc))):
+                cur[:, qc[0]:qc[0] + len(qc)] = iq
+            else:
+                cur[:, qc] = iq
             init = cur
         res = mir.inverse_kinematics(link.idx, p, q, init, return_error=return_error, **opts)
         qout, err = (res if return_error else (res, None))
-        qout = qout[:, self._qcols]
+        qout = self._cols(qout).contiguous()
         if idx is not None:
             qout = qout[idx]
             err = None if err is None else err[idx]
