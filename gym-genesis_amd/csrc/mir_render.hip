@@ -74,6 +74,7 @@ struct Cam {
   int W, H;
 };
 
+#define VIS_HDR 3u /* words in front of the work items: [0] their count, [1] [2] bit g set = geom g is a plane (env 0's planes are drawn by k_global_resolve) */
 #define GLOBAL_ITEMS_MAX 32 /* work items per box of the global splat: an entry = box index (22 bits) | item << 22 | (items - 1) << 27 */
 struct SetupArgs {
   const GeomTab* geom;
@@ -182,11 +183,7 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
     if (a.vis && type == MIR_GEOM_BOX) {
       const float r = sqrtf(dot(h, h));
       const float zc = -dot(rel, cf), xc = fabsf(dot(rel, cr)), yc = fabsf(dot(rel, cu));
-      if (zc + r <= 1e-3f || xc - r > (zc + r) * a.cam.tanx || yc - r > (zc + r) * a.cam.tany) {
-        // (k_global_resolve looks through env 0's records for the planes: the type word must say "box" even here)
-        if (e == 0) reinterpret_cast<f4*>(a.prims + (size_t)i * PREC)[0] = f4{0.0f, 0.0f, 0.0f, __int_as_float(MIR_GEOM_BOX)};
-        return;
-      }
+      if (zc + r <= 1e-3f || xc - r > (zc + r) * a.cam.tanx || yc - r > (zc + r) * a.cam.tany) return;
     }
   }
   const V3 o = {dot(ax[0], rel), dot(ax[1], rel), dot(ax[2], rel)};
@@ -282,6 +279,7 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
     q6 = f4{0.0f, 0.0f, 0.0f, 0.0f};
   } else {
     if (a.global_mode && e > 0) { xmin = 1; xmax = 0; ymin = 1; ymax = 0; }  // an unbounded plane is drawn once (env 0's)
+    if constexpr (!BIN) { if (a.vis && e == 0) atomicOr(a.vis + 1 + (g >> 5), 1u << (g & 31)); }
     const float nl = o.z < 0.0f ? -lk[2] : lk[2];  // the side of the plane the camera is on
     const float sh = a.amb + a.dif * fmaxf(nl, 0.0f);
     const float s = 0.5f * a.inv_chk;
@@ -315,7 +313,7 @@ __global__ void k_render_setup(SetupArgs a, BinArgs bn) {
       const int nb = ((xmax >> 5) - (xmin >> 5) + 1) * ((ymax >> 3) - (ymin >> 3) + 1);
       const unsigned n = (unsigned)min(GLOBAL_ITEMS_MAX, (nb + 3) >> 2);
       const unsigned at = atomicAdd(a.vis, n);
-      for (unsigned k = 0; k < n; k++) a.vis[1u + at + k] = (unsigned)i | k << 22 | (n - 1u) << 27;  // (i < 2^22: checked by mir_render)
+      for (unsigned k = 0; k < n; k++) a.vis[VIS_HDR + at + k] = (unsigned)i | k << 22 | (n - 1u) << 27;  // (i < 2^22: checked by mir_render)
     }
   }
   if (!BIN) return;
@@ -741,7 +739,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 struct SplatArgs {
   const float* prims;
   unsigned long long* zbuf;  // (H, W): w bits << 32 | packed RGB8, 0 = nothing
-  unsigned* vis;             // [0] work items, [1 ..] box index | share << 22 | (shares - 1) << 27 (written by k_render_setup; count reset by k_global_resolve)
+  unsigned* vis;             // [0] work items, [1] [2] mask of the plane geoms, [VIS_HDR ..] box index | share << 22 | (shares - 1) << 27 (k_render_setup)
   uint8_t* pixels;
   int W, H, nprim, ngeom;
   float x0, dx, y0, dy;
@@ -790,7 +788,7 @@ __global__ __launch_bounds__(256) void k_global_splat(SplatArgs a) {
   //  of dispatch), plus a second launch for the boxes with large rectangles (4.6 us).
   const unsigned n = a.vis[0];
   for (unsigned k = blockIdx.x; k < n; k += GLOBAL_SPLAT_GRID) {
-    const unsigned it = a.vis[1 + k];
+    const unsigned it = a.vis[VIS_HDR + k];
     splat_box(a, it & 0x3fffffu, (int)(it >> 22 & 31u), (int)(it >> 27) + 1);
   }
 }
@@ -812,7 +810,10 @@ __global__ __launch_bounds__(256) void k_global_resolve(SplatArgs a) {
     best[p] = __uint_as_float((unsigned)(key >> 32));
     col[p] = key ? (unsigned)key : a.sky;
   }
-  for (int g = 0; g < a.ngeom; g++) {  // the planes: env 0's records (the others carry an empty rectangle)
+  // the planes: env 0's records (the others carry an empty rectangle), by the mask the setup kernel left -- looking through all of env 0's
+  // records for them was a dozen dependent scalar loads in front of every pixel
+  for (unsigned long long pm = (unsigned long long)a.vis[1] | (unsigned long long)a.vis[2] << 32; pm; pm &= pm - 1ull) {
+    const int g = __builtin_ctzll(pm);
     const cf4* rec = (const cf4*)(uintptr_t)(a.prims + (size_t)g * PREC);
     const f4 ro = rec[0], rf = rec[1], rr = rec[2], ru = rec[3], rh = rec[4];
     if ((__float_as_int(ro.w) & 255) == MIR_GEOM_BOX || __float_as_int(rf.w) > __float_as_int(rr.w) || __float_as_int(ru.w) > __float_as_int(rh.w)) continue;
@@ -981,7 +982,7 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
         // resolution: it zeroes exactly what that render wrote)
         (void)hipMemsetAsync(h->zbuf, 0, need * sizeof(unsigned long long), st);
       }
-      const size_t vneed = (size_t)GLOBAL_ITEMS_MAX * pa.nprim + 1;  // (the worst case: every box fills the screen; touched only where written)
+      const size_t vneed = (size_t)GLOBAL_ITEMS_MAX * pa.nprim + VIS_HDR;  // (the worst case: every box fills the screen; touched only where written)
       if (pa.nprim >= (1 << 22)) { rc = mir_set_error(MIR_E_CAPACITY, "mir_render: more than 2^22 primitives in a global view"); break; }
       if (vneed > h->vis_cap) {
         if (h->vis) (void)hipFree(h->vis);
@@ -989,7 +990,9 @@ static int render_impl(MirHandle h, const MirCameraSpec* cam, const MirVisualSpe
         hipError_t e = hipMalloc((void**)&h->vis, vneed * sizeof(unsigned));
         if (e != hipSuccess) { rc = mir_set_error(MIR_E_HIP, hipGetErrorString(e)); break; }
         h->vis_cap = vneed;
-        (void)hipMemsetAsync(h->vis, 0, sizeof(unsigned), st);  // (the count; k_global_resolve puts it back to zero behind every render)
+        // (the item count -- k_global_resolve puts it back to zero behind every render -- and the mask of the scene's planes, a property
+        //  of the scene that the setup kernel ORs in again with every render)
+        (void)hipMemsetAsync(h->vis, 0, VIS_HDR * sizeof(unsigned), st);
       }
       sa.vis = h->vis;
       hipLaunchKernelGGL(k_render_setup<false>, dim3((B * ng + 255) / 256), dim3(256), 0, st, sa, BinArgs{});
