@@ -203,18 +203,44 @@ class CameraView:
             img = self.render_global()
         return self._to_host(img), None, None, None
 
+    _PIN_MAX = 8  # pinned image buffers a camera lends out at a time
+
     def _to_host(self, img) -> np.ndarray:
-        """A fresh NumPy array of a device image: through a pinned buffer of the camera's own and one host memcpy.  `img.cpu()` copies into
-        pageable memory -- 67 us per 480 x 640 image when the caller drops the frames, 224 us when it keeps them (every array is then new
-        pages the driver has to fault in and pin); this way 60 / 74 us (tools/probes/readme_loop_time.py)."""
+        """A fresh NumPy array of a device image.  The array IS a pinned buffer the device copies into (27 us for 480 x 640): the camera
+        lends out up to `_PIN_MAX` of them and takes one back when its array is garbage-collected (`weakref.finalize`; a view keeps its
+        base alive, so nothing the caller still holds is ever reused) -- the README loop drops each frame before it asks for the next and
+        never pays a host memcpy.  A caller that keeps more frames than that gets copies from a staging buffer (60 - 74 us; `img.cpu()`,
+        which this replaces, copies into pageable memory: 67 us per image when the frames are dropped, 224 us when they are kept and
+        every array is new pages the driver has to fault in and pin)."""
         if not img.is_cuda:
             return img.cpu().numpy()
-        pin = self.__dict__.get("_pin")
-        if pin is None or pin.shape != img.shape or pin.dtype != img.dtype:
-            pin = self._pin = torch.empty(img.shape, dtype=img.dtype).pin_memory()
-        pin.copy_(img, non_blocking=True)
+        import weakref
+
+        d = self.__dict__
+        key = (tuple(img.shape), img.dtype)
+        if d.get("_pin_key") != key:
+            d["_pin_key"], d["_pin_pool"], d["_pin_stage"] = key, [], None   # (buffers of another size still out die with their arrays)
+        pool = d["_pin_pool"]
+        buf = pool.pop() if pool else (torch.empty(img.shape, dtype=img.dtype, pin_memory=True) if d.get("_pin_out", 0) < self._PIN_MAX else None)
+        if buf is None:
+            stage = d.get("_pin_stage")
+            if stage is None:
+                stage = d["_pin_stage"] = torch.empty(img.shape, dtype=img.dtype, pin_memory=True)
+            stage.copy_(img, non_blocking=True)
+            torch.cuda.current_stream(img.device).synchronize()
+            return stage.numpy().copy()
+        buf.copy_(img, non_blocking=True)
         torch.cuda.current_stream(img.device).synchronize()
-        return pin.numpy().copy()
+        arr = buf.numpy()
+        d["_pin_out"] = d.get("_pin_out", 0) + 1
+        weakref.finalize(arr, self._pin_back, buf, key)
+        return arr
+
+    def _pin_back(self, buf, key) -> None:
+        d = self.__dict__
+        d["_pin_out"] = d.get("_pin_out", 1) - 1
+        if d.get("_pin_key") == key and len(d["_pin_pool"]) < self._PIN_MAX:
+            d["_pin_pool"].append(buf)
 
     # ---- recording (cam.start_recording() at reset -- the reference: always with pixels, cube_pick.py:109-110; here: when the env was
     # made with record_video=True, see env.py; env.save_video -> cam.stop_recording: env.py:71-79).  Genesis appends the image of every cam.render() while a recording runs.  Here the GLOBAL renders are recorded --

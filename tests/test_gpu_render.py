@@ -502,3 +502,41 @@ def test_recording_from_reset_to_save_video(tmp_path):
         env.save_video(save_video=True, file_name=str(tmp_path / "stack.mp4"))
     frames, _, wh = read_mjpeg_mp4(str(tmp_path / "stack.mp4"))
     assert len(frames) == 2 and wh == (128, 96)
+
+
+def test_render_arrays_are_lent_pinned_buffers_that_are_never_reused_while_held():
+    """env.render() returns the pinned buffer the device copied into (no host memcpy); the camera takes a buffer back only when its
+    array has been garbage-collected, and a caller that holds more than the camera lends gets ordinary copies: whatever is held stays
+    as it was."""
+    import gc
+    from gym_genesis.env import GenesisEnv
+
+    B = 64
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=True, observation_height=120, observation_width=160,
+                     camera_capture_mode="global")
+    env.reset(seed=0)
+    cam = env._env.cam
+    act = np.random.default_rng(0).uniform(-1, 1, (B, 9)).astype(np.float32)
+    held, want = [], []
+    for k in range(12):                                   # more than _PIN_MAX = 8 frames held at once
+        obs, *_ = env.step(act)
+        held.append(env.render())
+        want.append(obs["pixels"].cpu().numpy().copy())
+    assert cam._pin_out == cam._PIN_MAX and len({h.ctypes.data for h in held}) == 12
+    for _ in range(5):                                    # later renders touch none of them
+        env.step(act); env.render()
+    assert all(np.array_equal(h, w) for h, w in zip(held, want))
+    view = held[0][10:20]                                 # a view keeps its buffer on loan
+    first = held[0].ctypes.data
+    del held[0]
+    gc.collect()
+    assert cam._pin_out == cam._PIN_MAX and np.array_equal(view, want[0][10:20])
+    env.step(act)
+    x = env.render()
+    assert x.ctypes.data != first and np.array_equal(view, want[0][10:20])
+    del view, held, x
+    gc.collect()
+    assert cam._pin_out == 0 and len(cam._pin_pool) == cam._PIN_MAX
+    env.step(act)
+    y = env.render()                                      # a returned buffer is lent again
+    assert cam._pin_out == 1 and len(cam._pin_pool) == cam._PIN_MAX - 1
