@@ -1084,9 +1084,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   if (DUAL && !ROT) __syncthreads();  // (1) link poses from the collision wave; model table, velocities and targets from this one
   // (ROT: the loop below runs twice -- pass 0 is the second half of this step, pass 1 the first half of the next one)
   const int nsteps = ROT ? 2 : (SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0)));
-  // (the action-independent half alone integrates nothing.  The scene-specialised instantiations store poses too since round 5: a test of
-  //  the pointer where the store would be costs the headline nothing measurable, and the pixel modes keep the faster instantiation)
-  if (PRE) a.poses = nullptr;
+  // (the action-independent half alone integrates nothing.  Of the scene-specialised instantiations the ROTATED launch stores poses too
+  //  since round 5 -- the pointer test costs it nothing measurable, and the steps of the pixel modes keep the faster instantiation; the
+  //  fused launch lost 2 % to the same code, so a fused launch that wants poses takes the generic-scene instantiation: launch() in mir_api.hip)
+  if (PRE || (SPEC && !ROT)) a.poses = nullptr;
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr;
 #ifndef MIR_PROFILE_SINGLE  /* (a profiling build keeps the phase stamps in the single-step instantiation: tools/phase_profile.py) */
     a.prof = nullptr;
