@@ -186,7 +186,7 @@ struct Outs {
   AutoResetArgs ar = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
   bool diag = true;
   bool poses = false;  // 16-lane kernel: also write the link poses into h->poses (the rasteriser reads them)
-  int phase = 0;       // 16-lane kernel: 0 whole step, 1 / 2 the two halves of a split step (mir_step.h)
+  int phase = 0;       // 16-lane kernel: 0 whole step, 1 / 2 the two halves of a split step, 3 rotated, 4 the list instantiation of exact contacts (mir_step.h)
   int exact = 0;       // 16-lane kernel: defer the envs with more candidate points than lanes (StepArgs::exact)
   const int32_t* env_list = nullptr;  // 16-lane kernel, phase 1: serve the envs env_list[0 .. nlist) (StepArgs::env_list)
   int nlist = 0;
@@ -195,15 +195,17 @@ struct Outs {
 
 int launch(MirScene* h, const Outs& o, void* stream) {
   int rc;
-  if (o.phase != 1 && o.mode != 2) h->pre_valid = 0;  // (whatever this launch is, the state it leaves is not the one `pre` was made from)
+  // (phase 4 -- the list instantiation of exact contacts -- steps the envs the pending step's launch deferred and writes THEIR scratch
+  //  rows for the state it leaves: it completes that launch, the handle's bookkeeping is the pending step's)
+  if (o.phase != 1 && o.phase != 4 && o.mode != 2) h->pre_valid = 0;  // (whatever this launch is, the state it leaves is not the one `pre` was made from)
   // Link poses for the rasteriser.  Once a render has been asked for (poses_live), every launch that integrates also leaves the
   // link poses of its final state in h->poses -- its closing forward kinematics has them -- so that a render behind a step needs
   // no pose-refresh launch (6 us per 1024 envs).  poses_current: h->poses matches qpos for every env.
   const bool integrates = o.mode == 0 && o.phase != 1;
-  if (integrates) h->state_version++;
+  if (integrates && o.phase != 4) h->state_version++;
   const bool wr_poses = o.poses || (h->poses_live && integrates);
   if (o.mode == 2 && o.poses) h->poses_current = 1;
-  else if (integrates) h->poses_current = (h->kernel == 64 || wr_poses) && !o.ar.episode_len;  // (an in-kernel reset moves envs after the closing FK)
+  else if (integrates && o.phase != 4) h->poses_current = (h->kernel == 64 || wr_poses) && !o.ar.episode_len;  // (an in-kernel reset moves envs after the closing FK)
   if (h->kernel == 16) {
     StepArgs a;
     memset(&a, 0, sizeof a);
@@ -214,7 +216,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.term_bad = h->pin_dev ? reinterpret_cast<uint32_t*>(h->pin_dev + h->pin_flag_off + 16) : nullptr;
     a.term_wstride = h->term_wstride;
     a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
-    a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0) | ((h->spec_pick && (!wr_poses || o.phase == 3)) ? 4 : 0);
+    a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0) | ((h->spec_pick && (!wr_poses || o.phase == 3 || o.phase == 4)) ? 4 : 0);
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
@@ -223,6 +225,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.phase = o.phase; a.pre = h->pre;
     a.exact = o.exact;
     if (o.env_list) { a.env_list = o.env_list; a.B = o.nlist; }
+    if (o.phase == 4) a.term_wstride = 1;  // (the terminated byte of list entry k is byte k of term_host)
     rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
   } else {
     StepArgs64 a;
@@ -616,6 +619,13 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   const bool rotated = have_pre && h->hm.fk_free_leaf != 0 && h->split_step != 2;
   o.phase = rotated ? 3 : (have_pre ? 2 : 0);
   o.exact = h->exact;
+  // (exact contacts, ADVICE r5: the launches for the deferred envs of an earlier step ran on the library's side stream, and only the stream
+  //  of THAT step was made to wait for them; a step on another stream waits for them here -- state rows, scratch rows and the pinned
+  //  list are theirs until then)
+  if (h->ovf_event_live && h->ovf_waited_stream != stream) {
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)h->ovf_event, 0));
+    h->ovf_waited_stream = stream;
+  }
   h->pend_action = action;
   h->pend_out[0] = agent_pos; h->pend_out[1] = env_state; h->pend_out[2] = reward; h->pend_out[3] = terminated;
   h->pend_rotated = rotated ? 1 : 0;
@@ -664,57 +674,27 @@ int mir_step_go(MirHandle h, const float* action, void* stream) {
 }
 
 /* exact contacts: the n envs of h->ovf_list_host were deferred by the launch(es) of the pending mir_step_begin (their state rows are
- * those of the step's start).  They are stepped here by the wave-per-env kernel in list mode -- the same scene compiled for it with 48
- * contact points, reading and writing the 16-lane kernel's rows, the action and the output pointers of the pending step -- and their
- * scratch rows for the NEXT step are recomputed by the action-independent half of the 16-lane kernel over the same list (it also
- * decides whether they are deferred again).  The terminated byte of list entry k arrives in ovf_term_host[k].
- * Both launches go on a stream of the library's own, BESIDE the launch that deferred these envs (which is still running its second
+ * those of the step's start).  They are stepped here by the LIST INSTANTIATION of the 16-lane kernel (mir_step.hip, VARIANT 6: three
+ * contacts per lane, 48 points, four envs per workgroup) -- one launch that takes the action and the output pointers of the pending
+ * step, stores state, observations and the terminated byte of list entry k into ovf_term_host[k], and then writes the envs' scratch
+ * rows for the NEXT step (which also say whether they are deferred again).  An env beyond THAT kernel's capacity (more than 48 points,
+ * or more than 16 candidate pairs: its byte comes back with bit 7 set, nothing stored) goes on a second list and takes the route every
+ * deferred env took in round 5: the wave-per-env kernel in list mode (the same scene compiled for it, 64 candidates, reading and
+ * writing the 16-lane kernel's rows) followed by the action-independent half of the 16-lane kernel over that list.  MIR_EXACT_WAVE=1
+ * (read by mir_set_exact_contacts), or a scene without the split closing FK, sends every deferred env that way.
+ * The launches go on a stream of the library's own, BESIDE the launch that deferred these envs (which is still running its second
  * half: the host is here because that launch's terminated bytes -- early bytes -- have arrived): that launch stores nothing for
  * them, and everything queued before it on the step's stream has finished, or it would not be running.  The step's stream then
- * waits for an event recorded behind the two launches, so that whatever the caller queues after mir_step_end -- the next step, a
+ * waits for an event recorded behind them, so that whatever the caller queues after mir_step_end -- the next step, a
  * policy network reading the observations -- comes after them. */
-static int exact_finish(MirScene* h, int n, uint8_t* terminated_host) {
-  DeviceGuard guard(h->device);
-  h->ex_ovf_steps++;
-  h->ex_ovf_envs += (unsigned long long)n;
-  if ((unsigned long long)n > h->ex_ovf_max) h->ex_ovf_max = (unsigned long long)n;
-  memset(h->ovf_term_host, 0, (size_t)n);  // (tags come round every 63 steps: a byte of an older step must not pass for this one's)
-  __atomic_thread_fence(__ATOMIC_RELEASE);
-  StepArgs64 a;
-  memset(&a, 0, sizeof a);
-  a.model = h->dm64;
-  a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
-  a.diag = h->diag_on ? h->diag : nullptr;
-  a.bad_count = h->early_stats;
-  a.B = n; a.nu = h->hm64.nu; a.convex = h->hm64.has_convex;
-  a.action = h->pend_action;
-  a.agent_pos = (float*)h->pend_out[0]; a.env_state = (float*)h->pend_out[1]; a.reward = (float*)h->pend_out[2]; a.terminated = (uint8_t*)h->pend_out[3];
-  a.term_host = h->ovf_term_dev; a.term_tag = h->tag;
-  a.mode = 0; a.n_steps = 1;
-  a.env_list = h->ovf_list_dev; a.lay16_qst = h->hm.qstride;
-  // (not beside a step that was launched as two kernels -- a fused launch, or the second half alone, followed by the first half of the
-  //  next step for ALL envs: that second kernel writes the scratch rows of the deferred envs too, from their old state, and must come
-  //  BEFORE the one below that writes them from the new state: stream order does that)
-  void* const side = (h->ovf_stream && h->pend_rotated) ? h->ovf_stream : h->pending_stream;
-  int rc = mir_launch_step64(&a, (hipStream_t)side);
-  if (rc != 0) return hip_fail((hipError_t)rc, "wave kernel launch (exact contacts)");
-  h->poses_current = 0;  // (the deferred envs' link poses were not written)
-  if (h->pre_valid) {  // (split step: the scratch rows of the coming step, for the envs that have only now reached its starting state)
-    Outs p;
-    p.phase = 1; p.diag = false; p.env_list = h->ovf_list_dev; p.nlist = n;
-    rc = launch(h, p, side);
-    if (rc != MIR_OK) return rc;
-  }
-  if (side != h->pending_stream) {
-    HIPCHK(hipEventRecord((hipEvent_t)h->ovf_event, (hipStream_t)side));
-    HIPCHK(hipStreamWaitEvent((hipStream_t)h->pending_stream, (hipEvent_t)h->ovf_event, 0));
-  }
+static int exact_wait(MirScene* h, const uint8_t* term, const int32_t* list, int n, uint8_t* terminated_host, int32_t* again, int* n_again) {
   const uint8_t want = (uint8_t)h->tag;
   unsigned long polls = 0;
   for (int k = 0; k < n;) {
-    const uint8_t b = __atomic_load_n(h->ovf_term_host + k, __ATOMIC_RELAXED);
-    if ((uint8_t)(b >> 1) == want) {
-      if (terminated_host) terminated_host[h->ovf_list_host[k]] = b & 1u;
+    const uint8_t b = __atomic_load_n(term + k, __ATOMIC_RELAXED);
+    if ((uint8_t)((b >> 1) & 0x3fu) == want) {
+      if ((b & 0x80u) && again) again[(*n_again)++] = list[k];
+      else if (terminated_host) terminated_host[list[k]] = b & 1u;
       k++;
       continue;
     }
@@ -722,10 +702,83 @@ static int exact_finish(MirScene* h, int n, uint8_t* terminated_host) {
     if ((++polls & 0xfffffu) == 0) {
       hipError_t e = hipStreamQuery((hipStream_t)h->pending_stream);
       if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "mir_step_end: stream (exact contacts)");
-      if (e == hipSuccess && polls > 0x4000000u) return set_err(MIR_E_HIP, "mir_step_end: the wave launch finished without delivering its terminated bytes");
+      if (e == hipSuccess && polls > 0x4000000u) return set_err(MIR_E_HIP, "mir_step_end: the launch for the deferred envs finished without delivering its terminated bytes");
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return MIR_OK;
+}
+
+static int exact_finish(MirScene* h, int n, uint8_t* terminated_host) {
+  DeviceGuard guard(h->device);
+  h->ex_ovf_steps++;
+  h->ex_ovf_envs += (unsigned long long)n;
+  if ((unsigned long long)n > h->ex_ovf_max) h->ex_ovf_max = (unsigned long long)n;
+  // (not beside a step that was launched as two kernels -- a fused launch, or the second half alone, followed by the first half of the
+  //  next step for ALL envs: that second kernel writes the scratch rows of the deferred envs too, from their old state, and must come
+  //  BEFORE the one below that writes them from the new state: stream order does that)
+  void* const side = (h->ovf_stream && h->pend_rotated) ? h->ovf_stream : h->pending_stream;
+  const size_t B = (size_t)h->B;
+  int32_t* const list2_host = reinterpret_cast<int32_t*>(h->ovf_term_host + (B + 63) / 64 * 64);
+  int32_t* const list2_dev = reinterpret_cast<int32_t*>(h->ovf_term_dev + (B + 63) / 64 * 64);
+  uint8_t* const term2_host = reinterpret_cast<uint8_t*>(list2_host + B);
+  uint8_t* const term2_dev = reinterpret_cast<uint8_t*>(list2_dev + B);
+  const int32_t* wlist_host = h->ovf_list_host;
+  const int32_t* wlist_dev = h->ovf_list_dev;
+  const uint8_t* wterm_host = h->ovf_term_host;
+  uint8_t* wterm_dev = h->ovf_term_dev;
+  int nw = n;  // envs for the wave-per-env kernel
+  if (h->exact_big) {
+    memset(h->ovf_term_host, 0, (size_t)n);  // (tags come round every 63 steps: a byte of an older step must not pass for this one's)
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    Outs o;
+    o.action = h->pend_action;
+    o.agent_pos = (float*)h->pend_out[0]; o.env_state = (float*)h->pend_out[1]; o.reward = (float*)h->pend_out[2]; o.terminated = (uint8_t*)h->pend_out[3];
+    o.term_host = h->ovf_term_dev; o.term_tag = h->tag;
+    o.phase = 4; o.env_list = h->ovf_list_dev; o.nlist = n;
+    o.prof = h->dbg_prof_list;
+    h->dbg_prof_list = nullptr;
+    int rc = launch(h, o, side);
+    if (rc != MIR_OK) return rc;
+    h->ex_big_envs += (unsigned long long)n;
+    nw = 0;
+    rc = exact_wait(h, h->ovf_term_host, h->ovf_list_host, n, terminated_host, list2_host, &nw);
+    if (rc != MIR_OK) return rc;
+    wlist_host = list2_host; wlist_dev = list2_dev; wterm_host = term2_host; wterm_dev = term2_dev;
+  }
+  if (nw) {
+    memset(const_cast<uint8_t*>(wterm_host), 0, (size_t)nw);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    StepArgs64 a;
+    memset(&a, 0, sizeof a);
+    a.model = h->dm64;
+    a.qpos = h->qpos; a.qvel = h->qvel; a.target = h->target; a.qacc_ws = h->qacc_ws;
+    a.diag = h->diag_on ? h->diag : nullptr;
+    a.bad_count = h->early_stats;
+    a.B = nw; a.nu = h->hm64.nu; a.convex = h->hm64.has_convex;
+    a.action = h->pend_action;
+    a.agent_pos = (float*)h->pend_out[0]; a.env_state = (float*)h->pend_out[1]; a.reward = (float*)h->pend_out[2]; a.terminated = (uint8_t*)h->pend_out[3];
+    a.term_host = wterm_dev; a.term_tag = h->tag;
+    a.mode = 0; a.n_steps = 1;
+    a.env_list = wlist_dev; a.lay16_qst = h->hm.qstride;
+    h->ex_wave_envs += (unsigned long long)nw;
+    int rc = mir_launch_step64(&a, (hipStream_t)side);
+    if (rc != 0) return hip_fail((hipError_t)rc, "wave kernel launch (exact contacts)");
+    h->poses_current = 0;  // (these envs' link poses were not written)
+    if (h->pre_valid) {  // (split step: the scratch rows of the coming step, for the envs that have only now reached its starting state)
+      Outs p;
+      p.phase = 1; p.diag = false; p.env_list = wlist_dev; p.nlist = nw;
+      rc = launch(h, p, side);
+      if (rc != MIR_OK) return rc;
+    }
+  }
+  if (side != h->pending_stream) {
+    HIPCHK(hipEventRecord((hipEvent_t)h->ovf_event, (hipStream_t)side));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)h->pending_stream, (hipEvent_t)h->ovf_event, 0));
+    h->ovf_event_live = 1;
+    h->ovf_waited_stream = h->pending_stream;
+  }
+  if (nw) return exact_wait(h, wterm_host, wlist_host, nw, terminated_host, nullptr, nullptr);
   return MIR_OK;
 }
 
@@ -859,7 +912,9 @@ int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
       return set_err(MIR_E_INVALID, "mir_set_exact_contacts: the spec is not the one this scene was created from");
     DeviceGuard guard(h->device);
     HIPCHK(hipMemcpy(h->dm64, &h->hm64, sizeof(DevModel64), hipMemcpyHostToDevice));
-    const size_t B = (size_t)h->B, bytes = B * sizeof(int32_t) + ((B + 63) / 64) * 64;
+    // [list of the deferred envs (B x i32) | their terminated bytes (B, padded to 64)] twice: the envs the list instantiation could not
+    // hold either go on the second list (exact_finish)
+    const size_t B = (size_t)h->B, bytes = 2 * (B * sizeof(int32_t) + ((B + 63) / 64) * 64);
     HIPCHK(hipHostMalloc((void**)&h->ovf_list_host, bytes, hipHostMallocMapped | hipHostMallocCoherent));
     memset(h->ovf_list_host, 0, bytes);
     HIPCHK(hipHostGetDevicePointer((void**)&h->ovf_list_dev, h->ovf_list_host, 0));
@@ -875,7 +930,10 @@ int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
       h->ovf_stream = st; h->ovf_event = ev;
     }
   }
-  h->exact = 1;
+  // the list instantiation of the 16-lane kernel takes the deferred envs where the scene has the split closing forward kinematics (every
+  // free body a childless child of the world: the reference's scenes); MIR_EXACT_WAVE=1: the wave-per-env kernel takes them all (round 5)
+  h->exact_big = (h->hm.fk_free_leaf != 0 && !(getenv("MIR_EXACT_WAVE") && atoi(getenv("MIR_EXACT_WAVE")) != 0)) ? 1 : 0;
+  h->exact = on == 2 ? 2 : 1;
   return MIR_OK;
 }
 
@@ -884,7 +942,13 @@ int mir_get_exact_contacts(MirHandle h) { return check(h) ? MIR_E_INVALID : h->e
 int mir_get_exact_stats(MirHandle h, uint64_t* out4, int32_t reset) {
   if (check(h) || !out4) return set_err(MIR_E_INVALID, "mir_get_exact_stats: null argument");
   out4[0] = h->ex_steps; out4[1] = h->ex_ovf_steps; out4[2] = h->ex_ovf_envs; out4[3] = h->ex_ovf_max;
-  if (reset) h->ex_steps = h->ex_ovf_steps = h->ex_ovf_envs = h->ex_ovf_max = 0;
+  if (reset) h->ex_steps = h->ex_ovf_steps = h->ex_ovf_envs = h->ex_ovf_max = h->ex_big_envs = h->ex_wave_envs = 0;
+  return MIR_OK;
+}
+
+int mir_get_exact_route(MirHandle h, uint64_t* out2) {
+  if (check(h) || !out2) return set_err(MIR_E_INVALID, "mir_get_exact_route: null argument");
+  out2[0] = h->ex_big_envs; out2[1] = h->ex_wave_envs;
   return MIR_OK;
 }
 /* debug aid (bench.py's roofline): n back-to-back launches of the rotated step kernel (what mir_step_begin launches in split mode 1)
@@ -1036,6 +1100,12 @@ int mir_debug_profile_step(MirHandle h, unsigned long long* prof16, void* stream
 
 /* debug aid for -DMIR_PROFILE_SINGLE builds (tools/probes/rot_timeline.py): the next mir_step_begin launch -- whichever kernel the
  * split-step protocol picks for it -- leaves its shader-clock stamps in prof (device memory, 160 x u64, slot 29 = workgroup). */
+/* (the same for the next launch of the list instantiation of exact contacts: tools/probes/list_timeline.py) */
+extern "C" int mir_debug_profile_next_list_step(MirHandle h, unsigned long long* prof) {
+  if (check(h)) return MIR_E_INVALID;
+  h->dbg_prof_list = prof;
+  return MIR_OK;
+}
 extern "C" int mir_debug_profile_next_step(MirHandle h, unsigned long long* prof) {
   if (check(h)) return MIR_E_INVALID;
   h->dbg_prof = prof;

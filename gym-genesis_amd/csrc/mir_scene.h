@@ -56,6 +56,7 @@ struct MirScene {
   void* prep[4];            // output pointers registered by mir_step_prepare for the next mir_step_go
   int prepared;
   unsigned long long* dbg_prof = nullptr;  // (mir_debug_profile_next_step: shader-clock stamps of the next mir_step_begin launch)
+  unsigned long long* dbg_prof_list = nullptr;  // (mir_debug_profile_next_list_step: of the next launch of the list instantiation, exact contacts)
   // split step of the GenesisEnv.step path (16-lane kernel; MIR_SPLIT_STEP=0 switches it off): mir_step_begin launches the
   // action-independent half of the NEXT step right behind the current one; `pre_valid` says that `pre` holds that half for the
   // state as it is now (any other launch or state write clears it), `pre_stream` the stream it was launched on
@@ -65,7 +66,12 @@ struct MirScene {
   // EXACT CONTACTS (mir_set_exact_contacts; 16-lane scenes): the launches of mir_step_begin defer every env whose candidate contact
   // points exceed the 16-lane kernel's capacity (bit 7 of its terminated byte), and mir_step_end steps those envs on the wave kernel
   // (hm64 / dm64 = the same scene compiled for it with 48 points) from the untouched state rows, then recomputes their scratch rows.
-  int exact;
+  int exact;                // 0 off, 1 on, 2 (tests) every env is deferred: the whole batch takes the list instantiation
+  int exact_big;            // the deferred envs take the list instantiation of the 16-lane kernel (three contacts per lane); 0: the wave-per-env kernel (MIR_EXACT_WAVE=1)
+  int ovf_event_live;       // ovf_event has been recorded on the side stream behind launches the NEXT step must come after
+  void* ovf_waited_stream;  // the stream that has been made to wait for it
+  unsigned long long ex_big_envs;  // deferred env-steps handed to the list instantiation (those it deferred again included)
+  unsigned long long ex_wave_envs; // env-steps stepped by the wave-per-env kernel
   int32_t* ovf_list_host;   // pinned, device-mapped: the deferred envs of the step being closed (B x i32), read in place by the two launches
   int32_t* ovf_list_dev;
   uint8_t* ovf_term_host;   // pinned: terminated byte of list entry k, tagged like the others (behind the list in the same allocation)

@@ -48,20 +48,21 @@
 #include "mir_dev.h"
 #include "mir_convex.h"
 #define EPB 4       /* envs per block */
-#define MAXCON K16_MAX_CONTACT
 #define JST 52      /* floats per contact in Jb: 3 rows x 16 + 4 pad -> conflict-free ds_read_b128 across contact lanes */
 #define MSTR 20     /* row stride of M in LDS (floats): 16-byte aligned rows, conflict-free b128 row reads */
 #define JB_SKEW 8   /* see EnvLds::Jb_ */
 #define JBROW(Sx, c) (&(Sx).Jb_[(c) * JST + jbs])
-static_assert(MAXCON == G, "lane c owns contact c");
+static_assert(K16_MAX_CONTACT == G, "lane c owns contact c (one contact per lane; the list instantiation for exact contacts keeps CPL = 3 per lane)");
 
 // optional phase timestamps (debug): block 0, thread 0 records the shader clock at phase boundaries
 #ifdef MIR_PROFILE_SINGLE
 /* profiling build: the block to stamp is chosen by the host (slot 63 of the buffer), and every Newton iteration gets its own
  * eight slots from 64 on (tools/phase_profile.py) */
-#define STAMP(k) do { if (a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
+/* (prof_mute: the list instantiation's second pass -- the next step's action-independent half -- leaves the first pass's stamps alone and
+ *  stamps its own end: slot 140 the main wave, 141 the collision wave) */
+#define STAMP(k) do { if (a.prof && !prof_mute && (int)blockIdx.x == prof_blk && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
 #define ITSTAMP(it, k) do { if ((it) < 8) STAMP(64 + 8 * (it) + (k)); } while (0)
-#define HSTAMP(k) do { if (a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 64) a.prof[k] = __builtin_readcyclecounter(); } while (0)
+#define HSTAMP(k) do { if (a.prof && !prof_mute && (int)blockIdx.x == prof_blk && threadIdx.x == 64) a.prof[k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define HSTAMP(k) do { } while (0)
 #define STAMP(k) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[k] = __builtin_readcyclecounter(); } while (0)
@@ -84,10 +85,11 @@ struct DynScratch {
   float cinert[G][12], crb[G][12];
   float cvel[G][8], cfrc[G][8];
 };
-struct ColScratch {
+template <int CPL>
+struct ColScratchT {
   float gpos[K16_MAX_GEOM][4], gquat[K16_MAX_GEOM][4];
   int cand[G];
-  int cmap[G];                    // contact slot -> candidate lane * 8 + point index
+  int cmap[G * CPL];              // contact slot -> candidate lane * 8 + point index
   union {
     float stage[G][8][4];         // narrowphase output per candidate pair: pos, dist
     struct {                      // sweep-and-prune scratch (dead before the narrowphase writes `stage`)
@@ -102,33 +104,44 @@ struct ColScratch {
   int count[G];                   // contact points found per candidate (handed from the collision wave to the main wave)
   float clip[48];                 // polygon clipping scratch of the box-box routine (one row)
 };
-static_assert(sizeof(((ColScratch*)nullptr)->sap) <= sizeof(((ColScratch*)nullptr)->stage), "SAP scratch must fit under the staging area");
-struct ContactArrays {
-  float cpos[MAXCON][4];          // pos, dist
+static_assert(sizeof(((ColScratchT<1>*)nullptr)->sap) <= sizeof(((ColScratchT<1>*)nullptr)->stage), "SAP scratch must fit under the staging area");
+// CPL = contacts per lane: 1 everywhere but in the list instantiation for exact contacts (VARIANT 6), where lane c owns contacts
+// c, c + 16, c + 32 (capacity 48 = MIR_MAX_CONTACT, what the wave-per-env kernel holds).
+template <int CPL>
+struct ContactArraysT {
+  static constexpr int MAXCON = G * CPL;
+  float cpos[MAXCON][4];          // pos, dist.  CPL > 1: ALSO the per-iteration base forces (cfb below) -- the positions are dead once the Jacobian rows are built
   float cfrm[MAXCON][12];         // normal, t1, t2 (4-padded)
   float cmeta[MAXCON][4];         // mu, D, k*imp*dist stash / unused, b stash
   float cref[MAXCON][8];          // reference points of body1 / body2 trees (4-padded)
   unsigned cmask[MAXCON][4];      // dof masks of body1, body2, chunk mask, pad
-  float cfb[MAXCON][4];           // per-iteration base forces (n, t1, t2), active-row flags (as int bits)
+  float cfb[CPL == 1 ? MAXCON : 1][4];  // per-iteration base forces (n, t1, t2), active-row flags (as int bits); CPL > 1: see cpos
 };
-struct EnvLds {
+// (CPL > 1 only: bit c of conB[s] = contact 16 s + c moves dofs of the second tree only -- CPL == 1 keeps those flags in bits 1 .. 16 of
+//  `coupled` and has no such words: an empty base, the env block of the one-contact-per-lane instantiations is unchanged)
+template <int CPL> struct ConBWords { int conB[CPL]; int conB_pad[(4 - CPL % 4) % 4]; };
+template <> struct ConBWords<1> {};
+template <int CPL>
+struct EnvLdsT : ConBWords<CPL> {
+  static constexpr int MAXCON = G * CPL;
   float qpos[20], qvel[G], target[G], qacc_ws[G];
   float xpos[G][4], xquat[G][4];
   float cdof[G][8];               // ang(3) pad lin(3) pad
   float M[G][MSTR];
   int ncon, ncand, coupled /* some contact joins the two kinematic trees: the Newton Hessian is not block diagonal */;
-  int cin_ready;  // two-wave instantiations: the collision wave has stored the body inertias of this step (main wave spins on it)
+  int cin_ready;  // two-wave instantiations: the collision wave has stored the body inertias of this step (main wave spins on it; VARIANT 6: of pass cin_ready - 1)
   // Phase-aliased working set.  `dyn` (smooth dynamics) and `col` (collision detection) are live AT THE SAME TIME in the
   // single-step instantiation, where a second wave of the workgroup detects collisions while the first one does the dynamics;
-  // the contact arrays and the contact Jacobians take the place of both afterwards (con never overlaps col: the contact
-  // finishing reads the staging area while it writes con; Jb does, and is written after col is dead).
+  // the contact arrays and the contact Jacobians take the place of both afterwards (CPL == 1: con never overlaps col -- the contact
+  // finishing reads the staging area while it writes con; Jb does, and is written after col is dead.  CPL > 1: con reaches into col;
+  // the contact finishing there computes all of a lane's contacts into registers first, and stores behind barrier (2)).
   union {
     struct {
       DynScratch dyn;
-      ColScratch col;
+      ColScratchT<CPL> col;
     };
     struct {
-      ContactArrays con;
+      ContactArraysT<CPL> con;
       // contact Jacobian rows, row c at Jb_[c * JST + jbs]: the rows of the ODD envs of a wave start JB_SKEW floats later.  An env's block
       // is 2280 dwords = 8 mod 32 long, so the 16 consecutive dwords that the 16 lanes of two neighbouring envs read from the same
       // row with one ds_read_b32 (banks = dword mod 32, two envs per 32-lane group) would overlap in 8 banks: every such read -- three
@@ -138,9 +151,12 @@ struct EnvLds {
     };
   };
 };
-static_assert(sizeof(ContactArrays) <= sizeof(DynScratch), "the contact arrays must not reach the collision staging area");
-static_assert(sizeof(ContactArrays) + (MAXCON * JST + JB_SKEW) * sizeof(float) <= sizeof(DynScratch) + sizeof(ColScratch), "the skewed Jacobian rows must fit the union");
+typedef EnvLdsT<1> EnvLds;
+static_assert(sizeof(EnvLds) == 2280 * 4, "the env block of the one-contact-per-lane instantiations (JB_SKEW above counts on 2280 dwords = 8 mod 32)");
+static_assert(sizeof(ContactArraysT<1>) <= sizeof(DynScratch), "the contact arrays must not reach the collision staging area");
+static_assert(sizeof(ContactArraysT<1>) + (G * JST + JB_SKEW) * sizeof(float) <= sizeof(DynScratch) + sizeof(ColScratchT<1>), "the skewed Jacobian rows must fit the union");
 static_assert(EPB * sizeof(EnvLds) + sizeof(ModelTab) + K16_MAX_VERT * 16 <= 40960, "four workgroups per CU: 160 KB of LDS / 4 (hull vertices included)");
+static_assert(EPB * sizeof(EnvLdsT<3>) + sizeof(ModelTab) + K16_MAX_VERT * 16 <= 81920, "the list instantiation (three contacts per lane): two workgroups per CU");
 
 // body-lane constants needed by forward kinematics
 struct BodyK {
@@ -157,8 +173,8 @@ struct BodyK {
 // `row4` = byte offset of the group's first lane in the wave (64 x group).
 // SKIPFREE: free-joint bodies are left out (neither read nor written): in the two-wave instantiation the closing FK runs on the
 // collision wave while the main wave is still integrating the free bodies' quaternions, and writes their poses itself.
-template <bool SKIPFREE = false>
-__device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t parents, const BodyK& k, int row4) {
+template <bool SKIPFREE = false, class ENV>
+__device__ __forceinline__ void group_fk(ENV& S, int lane, int nb, uint64_t parents, const BodyK& k, int row4) {
   V3 P = v3(0, 0, 0);
   Q4 Qx = Q4{1, 0, 0, 0};
   int anc = 0;
@@ -202,11 +218,9 @@ __device__ __forceinline__ void group_fk(EnvLds& S, int lane, int nb, uint64_t p
 // number of its rows whose sign the step changes.  With a = min(x, 0) the cost of a row is 1/2 D a^2 and its change
 // 1/2 D (a1 - a0)(a1 + a0), where a1 - a0 is the step d itself while the row stays active: never a difference of squares (a step
 // below the resolution of jar must yield a correctly tiny improvement, not an absorbed one).
-__device__ __forceinline__ void step_rows(float al, float j0, float j1, float j2, float j3, float v0, float v1, float v2, float v3, float cD, float ljar, float ljv,
-                                          float lD, float lsg, float& pimc, float& piml, float& crossc, float& crossl) {
-  // (the contact rows' share and the limit row's share are returned apart: where the problem separates by tree, the lane's contact
-  //  and its dof may belong to different trees)
-  const float jr[4] = {j0, j1, j2, j3}, vr[4] = {v0, v1, v2, v3};
+// (the contact rows' share and the limit row's share are returned apart: where the problem separates by tree, the lane's contact
+//  and its dof may belong to different trees; _c = the four pyramid rows of one contact, _l = the lane's joint-limit row)
+__device__ __forceinline__ void step_rows_c(float al, const float (&jr)[4], const float (&vr)[4], float cD, float& pimc, float& crossc) {
   pimc = 0.0f;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -214,15 +228,17 @@ __device__ __forceinline__ void step_rows(float al, float j0, float j1, float j2
     const float a0 = fminf(x0, 0.0f), a1 = fminf(x1, 0.0f);
     pimc -= 0.5f * cD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0);
   }
+  crossc = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; r++) crossc += ((jr[r] < 0.0f) != (jr[r] + al * vr[r] < 0.0f)) ? 1.0f : 0.0f;
+}
+__device__ __forceinline__ void step_rows_l(float al, float ljar, float ljv, float lD, float lsg, float& piml, float& crossl) {
   {
     const float x0 = ljar, d = al * ljv, x1 = x0 + d;
     const float a0 = fminf(x0, 0.0f), a1 = fminf(x1, 0.0f);
     piml = -(0.5f * lD * ((x0 < 0.0f && x1 < 0.0f) ? d : a1 - a0) * (a1 + a0));
   }
   crossl = ((ljar < 0.0f) != (ljar + al * ljv < 0.0f)) && lsg != 0.0f ? 1.0f : 0.0f;
-  crossc = 0.0f;
-#pragma unroll
-  for (int r = 0; r < 4; r++) crossc += ((jr[r] < 0.0f) != (jr[r] + al * vr[r] < 0.0f)) ? 1.0f : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -251,20 +267,34 @@ __device__ __forceinline__ void step_rows(float al, float j0, float j1, float j2
 // half -- everything the two waves do up to the contact Jacobians -- whose results go to the `pre` buffer instead of staying in
 // LDS; 4 picks them up and runs the rest on one wave (all-rows-active Hessian included).  The host launches 3 for the NEXT step
 // right behind the current step, so that it runs while the host is between two env.step() calls.
-template <int VARIANT, int FEAT>
-__global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3 || VARIANT == 5) ? 128 : 64)
-__attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))) void mir_step_kernel(StepArgs a) {
+// VARIANT 6 (CPL = 3) = the LIST instantiation for EXACT CONTACTS: the envs of StepArgs::env_list -- the ones a launch of the
+// mir_step_begin path deferred because their narrowphase found more candidate points than lanes -- take the WHOLE step here (the
+// fused launch's pass: two waves, dynamics beside collision detection) with three contacts per lane, capacity 48 = MIR_MAX_CONTACT
+// (Genesis keeps every point of its candidate pairs: /root/reference/gym_genesis/tasks/franka/cube_pick.py:46), store state, targets,
+// observations and their terminated bytes (byte k of StepArgs::term_host for list entry k), and then run the action-independent half
+// of the NEXT step like the rotated launch's second pass, into the env's scratch row: one launch instead of the wave-per-env kernel
+// on the list followed by VARIANT 3 on the list, four envs per workgroup instead of one.  80 KB of LDS per workgroup, two workgroups
+// per CU, one wave per SIMD with the whole register file.  An env with more than 48 points or more than 16 candidate pairs is
+// deferred AGAIN (bit 7 of its byte; nothing stored): the wave-per-env kernel (64 candidates) stays the fallback for those.
+template <int VARIANT, int FEAT, int CPL = 1>
+__global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3 || VARIANT == 5 || VARIANT == 6) ? 128 : 64)
+__attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VARIANT == 6 ? 1 : 10)))) void mir_step_kernel(StepArgs a) {
   // VARIANT 5 = both halves in one launch, ROTATED: first the action-dependent half of THIS step (from the pre buffer), then the
   // action-independent half of the NEXT one (into the pre buffer).  The host sees `terminated` after the first half; the second
   // runs while it is between two env.step() calls, without a second launch, a second prologue or a second forward kinematics
   // (the closing FK of this step is the opening FK of the next).  Needs the split closing FK (fk_free_leaf scenes).
   constexpr bool ROT = VARIANT == 5;
+  constexpr bool BIGV = VARIANT == 6;  // fused pass, outputs, then the action-independent half of the next step (the list instantiation)
   constexpr bool PRE = VARIANT == 3, POST = VARIANT == 4;
-  constexpr bool SINGLE = VARIANT == 0 || PRE || POST || ROT;
-  constexpr bool DUAL = VARIANT == 0 || PRE || ROT;
-  static_assert(JST == 52 && K16_PRE_STRIDE >= K16_PRE_JB + JST * MAXCON, "pre-buffer layout");
+  constexpr bool SINGLE = VARIANT == 0 || PRE || POST || ROT || BIGV;
+  constexpr bool DUAL = VARIANT == 0 || PRE || ROT || BIGV;
+  constexpr int MAXCON = G * CPL;
+  static_assert(CPL == 1 || BIGV, "several contacts per lane: the list instantiation only");
+  static_assert(JST == 52 && K16_PRE_STRIDE >= K16_PRE_JB + JST * K16_MAX_CONTACT, "pre-buffer layout");
+  typedef EnvLdsT<CPL> EnvLds;
   constexpr bool CONVEX = (FEAT & 1) != 0, SAP = (FEAT & 2) != 0, SPEC = (FEAT & 4) != 0;
   __shared__ __attribute__((aligned(16))) EnvLds s_env[EPB];
+#define CFB(Sx, c) (CPL == 1 ? (Sx).con.cfb[CPL == 1 ? (c) : 0] : (Sx).con.cpos[c])
   __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
   // hull vertices (MIR_GEOM_HULL), convex instantiations only: what is left of the workgroup's 40 KB
   __shared__ __attribute__((aligned(16))) float s_hull[(FEAT & 1) ? K16_MAX_VERT : 1][4];
@@ -276,6 +306,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
 #else
   const int prof_blk = 0;
 #endif
+  [[maybe_unused]] bool prof_mute = false;
   STAMP(24);
   if (a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 0) a.prof[26] = __builtin_amdgcn_s_memrealtime();
   // Prologue: EVERY global read of the launch -- model table, per-lane constants, state rows, action, cached poses -- is
@@ -298,14 +329,15 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   const bool valid = env_raw < a.B;
   int env = valid ? env_raw : a.B - 1;
   // (exact contacts: the action-independent half for a LIST of envs -- the ones the wave kernel has just stepped; see StepArgs::env_list)
-  if constexpr (VARIANT == 3) { if (a.env_list) env = a.env_list[env]; }
+  if constexpr (VARIANT == 3 || BIGV) { if (a.env_list) env = a.env_list[env]; }
   EnvLds& S = s_env[grp];
 
   // (SPEC: the headline scene's sizes and options are literals -- SpecPick, emitted by mir_compile into mir_spec_pick.h -- so
   // `lane < nv`, the one-trip geom / pair loops and the solver dispatch fold at compile time)
   const int nb = SPEC ? SpecPick::nbody : m->nbody, nv = SPEC ? SpecPick::nv : m->nv, qst = a.qst;
   const int ngeom = SPEC ? SpecPick::ngeom : m->ngeom, npair = SPEC ? SpecPick::npair : m->npair;
-  const int max_contacts = SPEC ? SpecPick::max_contacts : m->max_contacts, enable_collision = SPEC ? SpecPick::enable_collision : m->enable_collision;
+  // (the list instantiation for exact contacts holds MIR_MAX_CONTACT points whatever capacity the scene gives the other launches)
+  const int max_contacts = BIGV ? MAXCON : (SPEC ? SpecPick::max_contacts : m->max_contacts), enable_collision = SPEC ? SpecPick::enable_collision : m->enable_collision;
   const float dt = m->dt;
   // Every scalar of the model that the step reads is fetched HERE, with the first batch of loads.  A read through `m` further
   // down cannot be hoisted by the compiler above the wave fences that separate the phases, so it would sit where it is used
@@ -381,8 +413,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   const int term_zlane = SPEC ? SpecPick::term_zlane : m->term_zlane;
   // exact contacts (StepArgs::exact): an env whose candidate contact points exceed this is DEFERRED to the wave kernel -- the launch
   // computes on (its lanes cannot leave the wave) but stores nothing for it and flags its terminated byte (wave-uniform; never without the flag)
-  constexpr bool DEFER = VARIANT == 0 || VARIANT == 4 || VARIANT == 5;
-  const int defer_above = (DEFER && a.exact) ? (max_contacts < MAXCON ? max_contacts : MAXCON) : 0x7fffffff;
+  // (StepArgs::exact == 2, a test switch: EVERY env is deferred -- the whole batch then takes the list instantiation; the list
+  //  instantiation itself defers what exceeds ITS capacity, to the wave-per-env kernel)
+  constexpr bool DEFER = VARIANT == 0 || VARIANT == 4 || VARIANT == 5 || BIGV;
+  const int defer_above = BIGV ? MAXCON : ((DEFER && a.exact) ? (a.exact == 2 ? -1 : (max_contacts < MAXCON ? max_contacts : MAXCON)) : 0x7fffffff);
   bool ovf_env = false;  // this lane's env is deferred: set where the step reads the `coupled` word (uniform over the env's row)
 
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
@@ -717,7 +751,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
 #undef MIR_JCOL
     }
   };
-  auto contacts_build = [&](int mycount) {
+  // (shared_jac: the main wave takes every other pair of contacts of the Jacobian build -- barrier (2b) -- where the action-independent
+  //  half is all the launch has left to do.  Returns the candidate points before the capacity was applied, 255 = saturated.)
+  auto contacts_build = [&](int mycount, bool shared_jac) -> int {
   STAMP(13);
   // ordered compaction of the contact points: exclusive prefix over candidate lanes (convergent code)
   const int maxc = max_contacts < MAXCON ? max_contacts : MAXCON;
@@ -781,65 +817,94 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     // scratch, which does not overlap the contact arrays)
     // (computed first, stored second: in the DUAL instantiation the contact arrays overlay the dynamics scratch of the main
     // wave, so the collision wave does the arithmetic while that wave is still busy and stores after the barrier)
-    const bool mine = lane < ncon_new;
-    const int k = lane;
-    f4 pd = {0, 0, 0, 0}, meta = {0, 0, 0, 0};
-    V3 n = v3(0, 0, 0), t1 = n, t2 = n, ref1 = n, ref2 = n;
-    uint32_t dm1 = 0u, dm2 = 0u, chunks = 0u;
-    if (mine) {
-      const int mp = S.col.cmap[k];
-      const int cl = mp >> 3, ci = mp & 7;
-      const int pr = S.col.cand[cl];
-      const int g1 = pr & 255, g2 = pr >> 8 & 255;
-      n = ld3v(S.col.snorm[cl]);
-      t1 = fabsf(n.y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
-      t1 = t1 - dot(n, t1) * n;
-      t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
-      t2 = cross(n, t1);
-      const float mu = fmaxf(T.g_pos[g1][3], T.g_pos[g2][3]);
-      const f4 s1a = ldv(&T.g_sol[g1][0]), s1b = ldv(&T.g_sol[g1][4]), s2a = ldv(&T.g_sol[g2][0]), s2b = ldv(&T.g_sol[g2][4]);
-      const float sr0 = 0.5f * (s1a.x + s2a.x), sr1 = 0.5f * (s1a.y + s2a.y);
-      const float si[5] = {0.5f * (s1a.z + s2a.z), 0.5f * (s1a.w + s2a.w), 0.5f * (s1b.x + s2b.x), 0.5f * (s1b.y + s2b.y), 0.5f * (s1b.z + s2b.z)};
-      const int b1 = T.g_info[g1][0], b2 = T.g_info[g2][0];
-      const float wsum = T.b_invw[b1] + T.b_invw[b2];
-      const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
-      const float tc = fmaxf(sr0, 2.0f * dt);
-      const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
-      dm1 = (uint32_t)T.b_info[b1][0]; dm2 = (uint32_t)T.b_info[b2][0];
-      const uint32_t inv = dm1 | dm2;
-      chunks = ((inv & 0xfu) ? 1u : 0u) | ((inv & 0xf0u) ? 2u : 0u) | ((inv & 0xf00u) ? 4u : 0u) | ((inv & 0xf000u) ? 8u : 0u);
-      ref1 = ld3v(S.xpos[T.b_info[b1][1]]); ref2 = ld3v(S.xpos[T.b_info[b2][1]]);
-      pd = ldv(S.col.stage[cl][ci]);
-      const float dist = pd.w;
-      const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
-      const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
-      meta = f4{mu, 1.0f / Rr, -kk * imp * dist, bb};
+    // (CPL > 1: lane c finishes contacts c, c + 16, c + 32 one after the other, all of them into registers before the first store:
+    //  the contact arrays of that instantiation reach into the staging area)
+    bool mine[CPL];
+    f4 pd[CPL], meta[CPL];
+    V3 n[CPL], t1[CPL], t2[CPL], ref1[CPL], ref2[CPL];
+    uint32_t dm1[CPL], dm2[CPL], chunks[CPL];
+#pragma unroll
+    for (int sl = 0; sl < CPL; sl++) {
+      const int k = lane + G * sl;
+      mine[sl] = k < ncon_new;
+      pd[sl] = f4{0, 0, 0, 0}; meta[sl] = f4{0, 0, 0, 0};
+      n[sl] = v3(0, 0, 0); t1[sl] = n[sl]; t2[sl] = n[sl]; ref1[sl] = n[sl]; ref2[sl] = n[sl];
+      dm1[sl] = 0u; dm2[sl] = 0u; chunks[sl] = 0u;
+      if (mine[sl]) {
+        const int mp = S.col.cmap[k];
+        const int cl = mp >> 3, ci = mp & 7;
+        const int pr = S.col.cand[cl];
+        const int g1 = pr & 255, g2 = pr >> 8 & 255;
+        n[sl] = ld3v(S.col.snorm[cl]);
+        V3 ta = fabsf(n[sl].y) < 0.5f ? v3(0, 1, 0) : v3(0, 0, 1);  // same frame construction as the oracle
+        ta = ta - dot(n[sl], ta) * n[sl];
+        ta = __builtin_amdgcn_rsqf(dot(ta, ta)) * ta;
+        t1[sl] = ta;
+        t2[sl] = cross(n[sl], ta);
+        const float mu = fmaxf(T.g_pos[g1][3], T.g_pos[g2][3]);
+        const f4 s1a = ldv(&T.g_sol[g1][0]), s1b = ldv(&T.g_sol[g1][4]), s2a = ldv(&T.g_sol[g2][0]), s2b = ldv(&T.g_sol[g2][4]);
+        const float sr0 = 0.5f * (s1a.x + s2a.x), sr1 = 0.5f * (s1a.y + s2a.y);
+        const float si[5] = {0.5f * (s1a.z + s2a.z), 0.5f * (s1a.w + s2a.w), 0.5f * (s1b.x + s2b.x), 0.5f * (s1b.y + s2b.y), 0.5f * (s1b.z + s2b.z)};
+        const int b1 = T.g_info[g1][0], b2 = T.g_info[g2][0];
+        const float wsum = T.b_invw[b1] + T.b_invw[b2];
+        const float dmax = fminf(fmaxf(si[1], 1e-4f), 0.9999f);
+        const float tc = fmaxf(sr0, 2.0f * dt);
+        const float kk = 1.0f / (dmax * dmax * tc * tc * sr1 * sr1), bb = 2.0f / (dmax * tc);
+        dm1[sl] = (uint32_t)T.b_info[b1][0]; dm2[sl] = (uint32_t)T.b_info[b2][0];
+        const uint32_t inv = dm1[sl] | dm2[sl];
+        chunks[sl] = ((inv & 0xfu) ? 1u : 0u) | ((inv & 0xf0u) ? 2u : 0u) | ((inv & 0xf00u) ? 4u : 0u) | ((inv & 0xf000u) ? 8u : 0u);
+        ref1[sl] = ld3v(S.xpos[T.b_info[b1][1]]); ref2[sl] = ld3v(S.xpos[T.b_info[b2][1]]);
+        pd[sl] = ldv(S.col.stage[cl][ci]);
+        const float dist = pd[sl].w;
+        const float imp = impedance(si[0], si[1], si[2], si[3], si[4], dist);
+        const float Rr = fmaxf(2.0f * mu * mu * (1.0f - imp) / imp * wsum * (1.0f + mu * mu), 1e-15f);
+        meta[sl] = f4{mu, 1.0f / Rr, -kk * imp * dist, bb};
+      }
     }
     {  // does any contact of the env move dofs of both trees?  (bit 0; bits 1 .. 16: contact c moves dofs of the second tree only --
        // what the tree-wise parts of the solver need to know about a contact when the problem separates; bits 20 .. 27: candidate
        // points before the capacity was applied, for the diagnostics record -- the word travels with the scratch row of a split step)
-      const uint32_t low = (1u << mdl_split) - 1u, both = dm1 | dm2;
-      const unsigned long long cb = __ballot(mine && (both & low) != 0u && (both & ~low) != 0u);
-      const unsigned long long tb = __ballot(mine && (both & low) == 0u);
-      if (lane == 0) S.coupled = (int)(((uint32_t)(cb >> (grp * G)) & 0xffffu ? 1u : 0u) | ((uint32_t)(tb >> (grp * G)) & 0xffffu) << 1 | (uint32_t)(ptotal < 255 ? ptotal : 255) << 20);
+       // (CPL > 1: the second-tree flags of contacts 16 s + c also in S.conB[s])
+      const uint32_t low = (1u << mdl_split) - 1u;
+      bool cpl_any = false;
+      uint32_t tbw[CPL];
+#pragma unroll
+      for (int sl = 0; sl < CPL; sl++) {
+        const uint32_t both = dm1[sl] | dm2[sl];
+        cpl_any = cpl_any || (mine[sl] && (both & low) != 0u && (both & ~low) != 0u);
+        tbw[sl] = (uint32_t)(__ballot(mine[sl] && (both & low) == 0u) >> (grp * G)) & 0xffffu;
+      }
+      const unsigned long long cb = __ballot(cpl_any);
+      if (lane == 0) {
+        S.coupled = (int)(((uint32_t)(cb >> (grp * G)) & 0xffffu ? 1u : 0u) | tbw[0] << 1 | (uint32_t)(ptotal < 255 ? ptotal : 255) << 20);
+        if constexpr (CPL > 1) {
+#pragma unroll
+          for (int sl = 0; sl < CPL; sl++) S.conB[sl] = (int)tbw[sl];
+        }
+      }
     }
     HSTAMP(43);
     if (DUAL) __syncthreads();  // (2) the main wave has left the dynamics scratch: the contact arrays may be stored over it
     HSTAMP(44);
-    if (mine) {
-      stv(S.con.cpos[k], pd);
-      st3v(&S.con.cfrm[k][0], n); st3v(&S.con.cfrm[k][4], t1); st3v(&S.con.cfrm[k][8], t2);
-      stv(S.con.cmeta[k], meta);
-      st3v(&S.con.cref[k][0], ref1); st3v(&S.con.cref[k][4], ref2);
-      S.con.cmask[k][0] = dm1; S.con.cmask[k][1] = dm2; S.con.cmask[k][2] = chunks; S.con.cmask[k][3] = 0u;
+#pragma unroll
+    for (int sl = 0; sl < CPL; sl++) {
+      const int k = lane + G * sl;
+      if (mine[sl]) {
+        stv(S.con.cpos[k], pd[sl]);
+        st3v(&S.con.cfrm[k][0], n[sl]); st3v(&S.con.cfrm[k][4], t1[sl]); st3v(&S.con.cfrm[k][8], t2[sl]);
+        stv(S.con.cmeta[k], meta[sl]);
+        st3v(&S.con.cref[k][0], ref1[sl]); st3v(&S.con.cref[k][4], ref2[sl]);
+        S.con.cmask[k][0] = dm1[sl]; S.con.cmask[k][1] = dm2[sl]; S.con.cmask[k][2] = chunks[sl]; S.con.cmask[k][3] = 0u;
+      }
     }
   }
   WSYNC();  // col scratch is dead from here on (Jb may overwrite it)
   STAMP(5);
   // (where this half is all the launch has left to do -- the pre half of a split step -- the main wave takes every other pair
   //  of contacts of the Jacobian build: barrier (2b) hands it the contact arrays stored just above)
-  if (PRE || ROT) { __syncthreads(); jac_build(0, 4); }
+  if (shared_jac) { __syncthreads(); jac_build(0, 4); }
   else jac_build(0, 2);
+  return ptotal;
   };
   // J^T D J with EVERY pyramid row of every contact active (lane = dof row, 16 columns), summed from zero in contact order.  The
   // Newton loop starts its incremental Hessian from Mt + this: resting and gripping contacts have all four rows active, and the
@@ -898,13 +963,13 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   };
   if (DUAL && wave == 1) {
     // (lane constants of the body inertia: quads 0, 4, 5, 6 of LaneK16)
-    auto helper_cinert = [&]() {
+    auto helper_cinert = [&](int pass_no) {
       const f4 h0 = *reinterpret_cast<const f4*>(m->lanek_t[0][lane]), h4 = *reinterpret_cast<const f4*>(m->lanek_t[4][lane]);
       const f4 h5 = *reinterpret_cast<const f4*>(m->lanek_t[5][lane]), h6 = *reinterpret_cast<const f4*>(m->lanek_t[6][lane]);
       const float hib[6] = {h5.x, h5.y, h5.z, h5.w, h6.x, h6.y};
       cinert_store(lane < nb && lane > 0, hib, v3(h4.x, h4.y, h4.z), h4.w, __float_as_int(h0.z));
       WSYNC();
-      if (lane == 0) __hip_atomic_store(&S.cin_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_store(&S.cin_ready, pass_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // the four quads of lane constants the forward kinematics needs (fetched again for the closing FK: nothing is kept live
     // through the collision phase)
@@ -964,28 +1029,38 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     HSTAMP(40);
     if (!ROT) __syncthreads();  // (1) link poses (this wave) and model table, velocities, targets (main wave) are in LDS
     HSTAMP(41);
-    helper_cinert();
+    // the action-independent half ends with the contact data and the Jacobian rows in the pre buffer (the all-active Hessian is
+    // accumulated from them by this wave at the start of the launch that consumes them, while the main wave starts on the action)
+    auto pre_store = [&]() {
+      if (valid && !ovf_h) {
+        float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
+        const int nc = S.ncon;
+        if (CPL == 1 || nc <= K16_MAX_CONTACT) {
+          const uint64_t qm = jrows_store(pre, nc, S);
+          if (lane == 0) *reinterpret_cast<f4*>(pre + K16_PRE_HEAD) = f4{__int_as_float(nc), __int_as_float(S.coupled), __uint_as_float((uint32_t)qm), __uint_as_float((uint32_t)(qm >> 32))};
+          if (lane < nc) *reinterpret_cast<f4*>(pre + K16_PRE_CMETA + 4 * lane) = ldv(S.con.cmeta[lane]);
+        } else if (lane == 0) {
+          // (the list instantiation: more points than a scratch row holds -- the launch that reads the row defers the env again on the
+          //  count in the head word, bits 20 .. 27, and never looks at the rest)
+          *reinterpret_cast<f4*>(pre + K16_PRE_HEAD) = f4{__int_as_float(0), __int_as_float(S.coupled), 0.0f, 0.0f};
+        }
+      }
+#ifdef MIR_PROFILE_SINGLE
+      // (debug: wall clock of the last exit among the workgroups on the watched one's XCD = the end of the launch)
+      if (a.prof && threadIdx.x == 64 && (blockIdx.x & 7) == (unsigned)(prof_blk & 7)) atomicMax(&a.prof[31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+    };
+    helper_cinert(1);
     const int cnt = collide_detect();
     HSTAMP(42);
-    contacts_build(cnt);  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
+    const int pts0 = contacts_build(cnt, PRE || ROT);  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
+    if (BIGV) ovf_h = pts0 > defer_above;  // (beyond this instantiation's capacity too: nothing is stored for the env, the wave-per-env kernel takes it)
     HSTAMP(45);
     __syncthreads();  // (3) contact arrays and base Jacobians handed to the main wave
     HSTAMP(46);
     {
       if (PRE || ROT) {
-        // the action-independent half ends here: contact data and Jacobian rows go to the pre buffer (the all-active Hessian is
-        // accumulated from them by this wave at the start of the launch that consumes them, while the main wave starts on the action)
-        if (valid && !ovf_h) {
-          float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
-          const int nc = S.ncon;
-          const uint64_t qm = jrows_store(pre, nc, S);
-          if (lane == 0) *reinterpret_cast<f4*>(pre + K16_PRE_HEAD) = f4{__int_as_float(nc), __int_as_float(S.coupled), __uint_as_float((uint32_t)qm), __uint_as_float((uint32_t)(qm >> 32))};
-          if (lane < nc) *reinterpret_cast<f4*>(pre + K16_PRE_CMETA + 4 * lane) = ldv(S.con.cmeta[lane]);
-        }
-#ifdef MIR_PROFILE_SINGLE
-        // (debug: wall clock of the last exit among the workgroups on the watched one's XCD = the end of the launch)
-        if (a.prof && threadIdx.x == 64 && (blockIdx.x & 7) == (unsigned)(prof_blk & 7)) atomicMax(&a.prof[31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
+        pre_store();
         return;
       }
       float hp[G];
@@ -1003,6 +1078,20 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       __syncthreads();  // (5) the main wave has integrated the jointed dofs
       group_fk<true>(S, lane, nb, hparents, hk, row4);
       __syncthreads();  // (6) link poses of the new state handed to the main wave
+    }
+    if constexpr (BIGV) {
+      // the list instantiation goes on like the rotated launch: the closing FK above is the opening FK of the next step, whose
+      // action-independent half follows (host side: only scenes with the split closing FK take this instantiation)
+      HSTAMP(142);
+      prof_mute = true;
+      helper_cinert(2);
+      const int cnt2 = collide_detect();
+      contacts_build(cnt2, true);
+      __syncthreads();  // (3) of the second pass
+      pre_store();
+#ifdef MIR_PROFILE_SINGLE
+      if (a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 64) a.prof[141] = __builtin_readcyclecounter();
+#endif
     }
     return;
   }
@@ -1083,11 +1172,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
   STAMP(48);
   if (DUAL && !ROT) __syncthreads();  // (1) link poses from the collision wave; model table, velocities and targets from this one
   // (ROT: the loop below runs twice -- pass 0 is the second half of this step, pass 1 the first half of the next one)
-  const int nsteps = ROT ? 2 : (SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0)));
+  const int nsteps = (ROT || BIGV) ? 2 : (SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0)));
   // (the action-independent half alone integrates nothing.  Of the scene-specialised instantiations the ROTATED launch stores poses too
   //  since round 5 -- the pointer test costs it nothing measurable, and the steps of the pixel modes keep the faster instantiation; the
   //  fused launch lost 2 % to the same code, so a fused launch that wants poses takes the generic-scene instantiation: launch() in mir_api.hip)
-  if (PRE || (SPEC && !ROT)) a.poses = nullptr;
+  if (PRE || (SPEC && !ROT && !BIGV)) a.poses = nullptr;
   if (SINGLE) { a.mode = 0; a.act_step = 0; a.rows_step = 0; a.ar.episode_len = nullptr; a.out_M = a.out_bias = a.out_qas = a.out_qacc = a.out_xpos = a.out_xquat = nullptr;
 #ifndef MIR_PROFILE_SINGLE  /* (a profiling build keeps the phase stamps in the single-step instantiation: tools/phase_profile.py) */
     a.prof = nullptr;
@@ -1220,7 +1309,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     if (step > 0 && a.action && a.act_step) {
       if (isdof && d_uadr >= 0) S.target[lane] = a.action[(size_t)step * a.act_step + (size_t)env * a.nu + d_uadr];
     }
-    const bool post_now = POST || (ROT && step == 0), pre_now = PRE || (ROT && step == 1);
+    const bool post_now = POST || (ROT && step == 0), pre_now = PRE || ((ROT || BIGV) && step == 1);
+    if (BIGV && step == 1) prof_mute = true;
     float qfrc_bias = 0.0f, qfs = 0.0f;
     if (!post_now) {
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
@@ -1291,7 +1381,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // (2) composite inertia: suffix sums of the body inertias over the row, minus the suffix behind the subtree
       {
         if (DUAL) {  // (the body inertias come from the collision wave: long since there, as a rule)
-          while (__hip_atomic_load(&S.cin_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+          while (__hip_atomic_load(&S.cin_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (BIGV ? step + 1 : 1)) __builtin_amdgcn_s_sleep(1);
         }
         float* ci = S.dyn.cinert[lane];
         f4 c0 = ldv(ci), c1 = ldv(ci + 4), c2 = ldv(ci + 8);
@@ -1430,6 +1520,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         __syncthreads();  // (2b) the collision wave has stored the contact arrays: this wave builds every other pair of Jacobian rows
         jac_build(2, 4);
         __syncthreads();  // (3) every Jacobian row of the coming step is in LDS: the collision wave stores them
+#ifdef MIR_PROFILE_SINGLE
+        if (BIGV && a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 0) a.prof[140] = __builtin_readcyclecounter();
+#endif
         return 2;
       }
       mrow[0] = r0.x; mrow[1] = r0.y; mrow[2] = r0.z; mrow[3] = r0.w; mrow[4] = r1.x; mrow[5] = r1.y; mrow[6] = r1.z; mrow[7] = r1.w;
@@ -1457,7 +1550,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     // (DUAL: the collision wave does all of it, detection since the first barrier, the rest since the second)
     if (!DUAL && !POST) {
       const int mc = collide_detect();
-      contacts_build(mc);
+      contacts_build(mc, false);
     }
 
     // joint-limit rows: lane = dof, lane-private
@@ -1483,22 +1576,41 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     STAMP(52);
     const int ncon = S.ncon;
     // contact rows, lane = contact, lane-private: aref_r = -b (J_r qvel) - k imp dist
-    const bool iscon = lane < ncon;
-    float cmu = 0.0f, cD = 0.0f;
-    float aref[4] = {0, 0, 0, 0}, jar[4] = {0, 0, 0, 0};
+    // (CPL > 1, the list instantiation: lane c owns contacts c + 16 s, s < CPL -- every contact quantity below once per slot, the sums
+    //  over a lane's slots in slot order; a slot that holds no contact anywhere in the wave is skipped, and an empty slot adds exact
+    //  zeros: with at most 16 contacts the arithmetic is that of the one-contact-per-lane instantiations)
+    bool iscon[CPL];
+    float cmu[CPL], cD[CPL];
+    float aref[CPL][4], jar[CPL][4];
+#pragma unroll
+    for (int sl = 0; sl < CPL; sl++) {
+      iscon[sl] = lane + G * sl < ncon;
+      cmu[sl] = 0.0f; cD[sl] = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) { aref[sl][r] = 0.0f; jar[sl][r] = 0.0f; }
+    }
     // the contact's Jacobian rows stay in the registers of its lane for the whole solve; J x products take x_j from the dof
     // lanes by DPP row broadcast (every lane of the row takes part)
-    const JRow jrow = jrow_load(JBROW(S, iscon ? lane : 0));
-    float vn, v1, v2;
-    jdot3_bc(jrow, S.qvel[lane], vn, v1, v2);
-    if (iscon) {
-      f4 mt = ldv(S.con.cmeta[lane]);
-      cmu = mt.x; cD = mt.y;
-      const float base = mt.z, bb = mt.w;
-      aref[0] = base - bb * (vn + cmu * v1);
-      aref[1] = base - bb * (vn - cmu * v1);
-      aref[2] = base - bb * (vn + cmu * v2);
-      aref[3] = base - bb * (vn - cmu * v2);
+    // (CPL > 1: slot 0's rows only -- the other slots' are read from LDS where they are used, twelve 16-byte reads per product)
+    const JRow jrow = jrow_load(JBROW(S, iscon[0] ? lane : 0));
+    auto jd3 = [&](int sl, float x, float& dn, float& d1, float& d2) __attribute__((always_inline)) {
+      if (sl == 0) jdot3_bc(jrow, x, dn, d1, d2);
+      else jdot3_bc(jrow_load(JBROW(S, iscon[sl] ? lane + G * sl : 0)), x, dn, d1, d2);
+    };
+#pragma unroll
+    for (int sl = 0; sl < CPL; sl++) {
+      if (sl > 0 && !__any(iscon[sl])) continue;  // (wave-uniform)
+      float vn, v1, v2;
+      jd3(sl, S.qvel[lane], vn, v1, v2);
+      if (iscon[sl]) {
+        f4 mt = ldv(S.con.cmeta[lane + G * sl]);
+        cmu[sl] = mt.x; cD[sl] = mt.y;
+        const float base = mt.z, bb = mt.w;
+        aref[sl][0] = base - bb * (vn + cmu[sl] * v1);
+        aref[sl][1] = base - bb * (vn - cmu[sl] * v1);
+        aref[sl][2] = base - bb * (vn + cmu[sl] * v2);
+        aref[sl][3] = base - bb * (vn - cmu[sl] * v2);
+      }
     }
     STAMP(6);
 
@@ -1514,7 +1626,12 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     // early `terminated` bytes rely on.  `sep` is uniform over the env's row; an env that does not separate has every row in tree A.
     const bool sep = mdl_split > 0 && (cpl & 1) == 0;
     const bool dofB = sep && lane >= mdl_split;               // this lane's dof, and its joint-limit row
-    const bool conB = sep && ((cpl >> (1 + lane)) & 1) != 0;  // this lane's contact
+    bool conB[CPL];                                           // this lane's contact(s)
+    conB[0] = sep && ((cpl >> (1 + lane)) & 1) != 0;
+    if constexpr (CPL > 1) {
+#pragma unroll
+      for (int sl = 1; sl < CPL; sl++) conB[sl] = sep && ((S.conB[sl] >> lane) & 1) != 0;
+    }
     bool done = nefc == 0;
     float qacc = qas, Ma = 0.0f, ljar = 0.0f;
     {
@@ -1525,35 +1642,51 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       const float ws = S.qacc_ws[lane];
       const float dq = isdof ? ws - qas : 0.0f;
       float d_ws = 0.5f * rowdot_bc(mrow, dq) * dq, d_sm = 0.0f;  // this lane's dof: Gauss term + limit row
-      float k_ws = 0.0f, k_sm = 0.0f;                              // this lane's contact: its four rows
       const float ljs = lsg * qas - laref, ljw = lsg * ws - laref;
       if (lsg != 0.0f) {
         if (ljs < 0.0f) d_sm += 0.5f * lD * ljs * ljs;
         if (ljw < 0.0f) d_ws += 0.5f * lD * ljw * ljw;
       }
-      float js[4] = {0, 0, 0, 0}, jw[4] = {0, 0, 0, 0};
-      float sn, s1, s2, wn, w1, w2;
-      jdot3_bc(jrow, qas, sn, s1, s2);
-      jdot3_bc(jrow, ws, wn, w1, w2);
-      if (iscon) {
-        js[0] = sn + cmu * s1 - aref[0]; js[1] = sn - cmu * s1 - aref[1]; js[2] = sn + cmu * s2 - aref[2]; js[3] = sn - cmu * s2 - aref[3];
-        jw[0] = wn + cmu * w1 - aref[0]; jw[1] = wn - cmu * w1 - aref[1]; jw[2] = wn + cmu * w2 - aref[2]; jw[3] = wn - cmu * w2 - aref[3];
+      float js[CPL][4], jw[CPL][4], k_df[CPL];  // this lane's contact(s): the four rows at either start, the cost difference
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          if (js[r] < 0.0f) k_sm += 0.5f * cD * js[r] * js[r];
-          if (jw[r] < 0.0f) k_ws += 0.5f * cD * jw[r] * jw[r];
+      for (int sl = 0; sl < CPL; sl++) {
+        float k_ws = 0.0f, k_sm = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { js[sl][r] = 0.0f; jw[sl][r] = 0.0f; }
+        if (sl == 0 || __any(iscon[sl])) {  // (wave-uniform)
+          float sn, s1, s2, wn, w1, w2;
+          jd3(sl, qas, sn, s1, s2);
+          jd3(sl, ws, wn, w1, w2);
+          if (iscon[sl]) {
+            const float mu = cmu[sl];
+            js[sl][0] = sn + mu * s1 - aref[sl][0]; js[sl][1] = sn - mu * s1 - aref[sl][1]; js[sl][2] = sn + mu * s2 - aref[sl][2]; js[sl][3] = sn - mu * s2 - aref[sl][3];
+            jw[sl][0] = wn + mu * w1 - aref[sl][0]; jw[sl][1] = wn - mu * w1 - aref[sl][1]; jw[sl][2] = wn + mu * w2 - aref[sl][2]; jw[sl][3] = wn - mu * w2 - aref[sl][3];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              if (js[sl][r] < 0.0f) k_sm += 0.5f * cD[sl] * js[sl][r] * js[sl][r];
+              if (jw[sl][r] < 0.0f) k_ws += 0.5f * cD[sl] * jw[sl][r] * jw[sl][r];
+            }
+          }
         }
+        k_df[sl] = k_ws - k_sm;
       }
       // (one reduction per tree: the sign of the summed cost DIFFERENCES decides)
-      const float d_df = d_ws - d_sm, k_df = k_ws - k_sm;
+      const float d_df = d_ws - d_sm;
+      float dfA = (dofB ? 0.0f : d_df) + (conB[0] ? 0.0f : k_df[0]), dfB = (dofB ? d_df : 0.0f) + (conB[0] ? k_df[0] : 0.0f);
+#pragma unroll
+      for (int sl = 1; sl < CPL; sl++) { dfA += conB[sl] ? 0.0f : k_df[sl]; dfB += conB[sl] ? k_df[sl] : 0.0f; }
       // (gsum_u: one value per env -- every lane must take the same decision, see mir_dev.h)
-      bool usewsA = gsum_u((dofB ? 0.0f : d_df) + (conB ? 0.0f : k_df)) < 0.0f, usewsB = usewsA;
-      if (__any(sep)) usewsB = gsum_u((dofB ? d_df : 0.0f) + (conB ? k_df : 0.0f)) < 0.0f;  // (wave-uniform)
-      const bool usewsd = dofB ? usewsB : usewsA, usewsc = conB ? usewsB : usewsA;
+      bool usewsA = gsum_u(dfA) < 0.0f, usewsB = usewsA;
+      if (__any(sep)) usewsB = gsum_u(dfB) < 0.0f;  // (wave-uniform)
+      const bool usewsd = dofB ? usewsB : usewsA;
       qacc = usewsd ? ws : qas;
       ljar = usewsd ? ljw : ljs;
 #pragma unroll
-      for (int r = 0; r < 4; r++) jar[r] = usewsc ? jw[r] : js[r];
+      for (int sl = 0; sl < CPL; sl++) {
+        const bool usewsc = conB[sl] ? usewsB : usewsA;
+#pragma unroll
+        for (int r = 0; r < 4; r++) jar[sl][r] = usewsc ? jw[sl][r] : js[sl][r];
+      }
       const float Mab = rowdot_bc(mrow, qacc);
       Ma = isdof ? Mab : 0.0f;
     }
@@ -1585,7 +1718,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
     // (the weight of this lane's gradient entry in the bound, object mass folded in: fetched here, used after the first gradient)
     float d_gw = 0.0f;
     if (term_bound) d_gw = m->lanek_t[11][lane][3];
-    unsigned prevbits = 0u;  // contact lane: flags written in the previous iteration
+    unsigned prevbits[CPL];  // contact lane: flags written in the previous iteration
+#pragma unroll
+    for (int sl = 0; sl < CPL; sl++) prevbits[sl] = 0u;
     float gprev = 0.0f;
     bool met4 = false;
     for (int it = 0; it < mdl_iterations; it++) {
@@ -1593,23 +1728,28 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // ---- forces of the active rows; base-force triple and active flags to LDS for the dof lanes
       float lact = (lsg != 0.0f && ljar < 0.0f) ? lD : 0.0f;
       const float lf = -lact * ljar;
-      bool flipped = false;  // contact lane: some pyramid row changed sides since the Hessian last saw this contact
-      if (iscon) {
-        float f[4];
-        unsigned bits = 0;
+      // the env's flipped contacts -- some pyramid row changed sides since the Hessian last saw the contact -- as a bit mask in every
+      // one of its lanes: the Hessian update walks those only
+      unsigned flipmask[CPL];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const bool on = jar[r] < 0.0f;
-          f[r] = on ? -cD * jar[r] : 0.0f;
-          bits |= on ? (1u << r) : 0u;
+      for (int sl = 0; sl < CPL; sl++) {
+        bool flipped = false;
+        if (iscon[sl]) {
+          float f[4];
+          unsigned bits = 0;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const bool on = jar[sl][r] < 0.0f;
+            f[r] = on ? -cD[sl] * jar[sl][r] : 0.0f;
+            bits |= on ? (1u << r) : 0u;
+          }
+          // w = new flags | previous flags << 4, as an exactly representable small float
+          stv(CFB(S, lane + G * sl), f4{f[0] + f[1] + f[2] + f[3], cmu[sl] * (f[0] - f[1]), cmu[sl] * (f[2] - f[3]), (float)(bits | (prevbits[sl] << 4))});
+          flipped = bits != (it == 0 ? 15u : prevbits[sl]);  // (the Hessian starts from all rows active)
+          prevbits[sl] = bits;
         }
-        // w = new flags | previous flags << 4, as an exactly representable small float
-        stv(S.con.cfb[lane], f4{f[0] + f[1] + f[2] + f[3], cmu * (f[0] - f[1]), cmu * (f[2] - f[3]), (float)(bits | (prevbits << 4))});
-        flipped = bits != (it == 0 ? 15u : prevbits);  // (the Hessian starts from all rows active)
-        prevbits = bits;
+        flipmask[sl] = (unsigned)(__ballot(flipped) >> (tid & 48)) & 0xffffu;
       }
-      // the env's flipped contacts as a bit mask in every one of its lanes: the Hessian update walks those only
-      const unsigned flipmask = (unsigned)(__ballot(flipped) >> (tid & 48)) & 0xffffu;
       WSYNC();
       if (it == 0) STAMP(16);
       ITSTAMP(it, 0);
@@ -1623,7 +1763,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
           const int c = c0 + u < ncon ? c0 + u : c0;
           const float* jb = JBROW(S, c);
           jn[u] = jb[lane]; j1[u] = jb[16 + lane]; j2[u] = jb[32 + lane];
-          fb[u] = ldv(S.con.cfb[c]);
+          fb[u] = ldv(CFB(S, c));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1698,11 +1838,13 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         for (int j = 0; j < G; j++) hkeep[j] += j == lane ? lact - oldlact : 0.0f;
       }
       oldlact = lact;
-      for (unsigned fm = flipmask; fm; fm &= fm - 1u) {  // (group-uniform trip count)
-        const int c = __ffs(fm) - 1;
+#pragma unroll
+      for (int sl = 0; sl < CPL; sl++)
+      for (unsigned fm = flipmask[sl]; fm; fm &= fm - 1u) {  // (group-uniform trip count; contact order: slot by slot)
+        const int c = __ffs(fm) - 1 + G * sl;
         const float* jb = JBROW(S, c);
         // every read of this contact in one batch, before any arithmetic (one LDS round trip)
-        const f4 fb = ldv(S.con.cfb[c]);
+        const f4 fb = ldv(CFB(S, c));
         const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
         const f4 mt = ldv(S.con.cmeta[c]);
         f4 xn[4], x1[4], x2[4];
@@ -1739,11 +1881,15 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       const float mvb = rowdot_bc(mrow, sv);
       const float mv = isdof ? mvb : 0.0f;
       const float ljv = lsg * sv;
-      float jv[4] = {0, 0, 0, 0};
-      {
+      float jv[CPL][4];
+#pragma unroll
+      for (int sl = 0; sl < CPL; sl++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) jv[sl][r] = 0.0f;
+        if (sl > 0 && !__any(iscon[sl])) continue;  // (wave-uniform)
         float xn, x1, x2;
-        jdot3_bc(jrow, sv, xn, x1, x2);  // (every lane of the row takes part in the broadcasts)
-        if (iscon) { jv[0] = xn + cmu * x1; jv[1] = xn - cmu * x1; jv[2] = xn + cmu * x2; jv[3] = xn - cmu * x2; }
+        jd3(sl, sv, xn, x1, x2);  // (every lane of the row takes part in the broadcasts)
+        if (iscon[sl]) { jv[sl][0] = xn + cmu[sl] * x1; jv[sl][1] = xn - cmu[sl] * x1; jv[sl][2] = xn + cmu[sl] * x2; jv[sl][3] = xn - cmu[sl] * x2; }
       }
       if (it == 0) STAMP(19);
       ITSTAMP(it, 5);
@@ -1760,11 +1906,18 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       // step below the resolution of jar must yield a (correctly) tiny improvement, not an absorbed one
       // (with a = min(x, 0) the cost of a row is 1/2 D a^2, and its change 1/2 D (a1 - a0)(a1 + a0); a1 - a0 is the step d
       //  itself while the row stays active)
-      float pimc = 0.0f, piml = 0.0f, crsc = 0.0f, crsl = 0.0f;  // this lane's share at the last evaluation: contact rows / limit row
+      float pimc[CPL], piml = 0.0f, crsc[CPL], crsl = 0.0f;  // this lane's share at the last evaluation: contact rows (per slot) / limit row
+#pragma unroll
+      for (int sl = 0; sl < CPL; sl++) { pimc[sl] = 0.0f; crsc[sl] = 0.0f; }
       auto step_gain = [&](float al, float& gain, float& ncr) __attribute__((always_inline)) {
-        step_rows(al, jar[0], jar[1], jar[2], jar[3], jv[0], jv[1], jv[2], jv[3], cD, ljar, ljv, lD, lsg, pimc, piml, crsc, crsl);
-        gain = gsum_u(pimc + piml) - (0.5f * al * al * A + al * Bq);
-        ncr = gsum(crsc + crsl);  // (the two reductions are independent and overlap)
+#pragma unroll
+        for (int sl = 0; sl < CPL; sl++) step_rows_c(al, jar[sl], jv[sl], cD[sl], pimc[sl], crsc[sl]);
+        float pc = pimc[0], cc = crsc[0];
+#pragma unroll
+        for (int sl = 1; sl < CPL; sl++) { pc += pimc[sl]; cc += crsc[sl]; }
+        step_rows_l(al, ljar, ljv, lD, lsg, piml, crsl);
+        gain = gsum_u(pc + piml) - (0.5f * al * al * A + al * Bq);
+        ncr = gsum(cc + crsl);  // (the two reductions are independent and overlap)
       };
       // The full Newton step first.  Where it crosses no row boundary it IS the minimiser along s; where it does, it is taken as it
       // is when it realises at least a quarter of the decrease the quadratic piece at alpha = 0 predicts for it (-g0 / 2): the
@@ -1777,9 +1930,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       for (int ls = 1; ls < mdl_ls_iterations && __any(!lsdone); ls++) {  // (ls counts evaluations of phi', the one at 0 included)
         float pg = 0.0f, ph = 0.0f, pa = 0.0f;
 #pragma unroll
+        for (int sl = 0; sl < CPL; sl++)
+#pragma unroll
         for (int r = 0; r < 4; r++) {
-          const float x = jar[r] + alpha * jv[r];
-          if (x < 0.0f) { pg += cD * jv[r] * x; ph += cD * jv[r] * jv[r]; }
+          const float x = jar[sl][r] + alpha * jv[sl][r];
+          if (x < 0.0f) { pg += cD[sl] * jv[sl][r] * x; ph += cD[sl] * jv[sl][r] * jv[sl][r]; }
         }
         {
           const float x = ljar + alpha * ljv;
@@ -1792,8 +1947,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         float floorg = 0.0f;
         if (ls >= 4) {  // wave-uniform
 #pragma unroll
+          for (int sl = 0; sl < CPL; sl++)
+#pragma unroll
           for (int r = 0; r < 4; r++)
-            if (jar[r] + alpha * jv[r] < 0.0f) pa += cD * fabsf(jv[r]) * (fabsf(jar[r]) + fabsf(alpha * jv[r]));
+            if (jar[sl][r] + alpha * jv[sl][r] < 0.0f) pa += cD[sl] * fabsf(jv[sl][r]) * (fabsf(jar[sl][r]) + fabsf(alpha * jv[sl][r]));
           if (ljar + alpha * ljv < 0.0f) pa += lD * fabsf(ljv) * (fabsf(ljar) + fabsf(alpha * ljv));
           floorg = 4.0f * 1.1920929e-7f * (gsum_u(pa) + fabsf(alpha * A) + fabsf(Bq));
         }
@@ -1825,23 +1982,31 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       //     -g_T . s_T, and falls by -g_T . s_T (alpha - alpha^2 / 2) > 0 at the alpha = 1 the search then returns: nothing to check;
       //   * some row does: tree B's share of the exact 1-D model -- three masked reductions over the lane shares of the last
       //     evaluation, still in registers -- and tree A's = the rest, each accepted on its own sign.
-      float ald = alpha, alc = alpha;  // the step length this lane's dof / its contact takes
+      float ald = alpha, alc[CPL];  // the step length this lane's dof / its contact(s) take
+#pragma unroll
+      for (int sl = 0; sl < CPL; sl++) alc[sl] = alpha;
       const bool need = sep && ncross != 0.0f && alpha != 0.0f;
       bool partial = false;  // one tree moves, the other was held back: the env is not finished whatever the moving tree's gain says
       if (__any(need)) {  // (wave-uniform; an env's result does not depend on its neighbours: only `need` envs use the sums)
         const float AB = gsum_u(dofB ? svmv : 0.0f), BB = gsum_u(dofB ? svb : 0.0f);
-        const float gainB = gsum_u((conB ? pimc : 0.0f) + (dofB ? piml : 0.0f)) - (0.5f * alpha * alpha * AB + alpha * BB);
+        float pB = conB[0] ? pimc[0] : 0.0f;
+#pragma unroll
+        for (int sl = 1; sl < CPL; sl++) pB += conB[sl] ? pimc[sl] : 0.0f;
+        const float gainB = gsum_u(pB + (dofB ? piml : 0.0f)) - (0.5f * alpha * alpha * AB + alpha * BB);
         const float gainA = improvement - gainB;
         const bool okA = gainA > 0.0f, okB = gainB > 0.0f;
         if (need && !(okA && okB)) {  // (rare: an exact search on the sum usually lowers both terms)
           ald = (dofB ? okB : okA) ? alpha : 0.0f;
-          alc = (conB ? okB : okA) ? alpha : 0.0f;
+#pragma unroll
+          for (int sl = 0; sl < CPL; sl++) alc[sl] = (conB[sl] ? okB : okA) ? alpha : 0.0f;
           improvement = (okA ? gainA : 0.0f) + (okB ? gainB : 0.0f);
           partial = okA != okB;
         }
       }
       if (!need && !(improvement > 0.0f)) {  // (one tree, or a crossing-free step at the rounding floor of the model)
-        ald = alc = 0.0f;
+        ald = 0.0f;
+#pragma unroll
+        for (int sl = 0; sl < CPL; sl++) alc[sl] = 0.0f;
         improvement = 0.0f;
       }
       // float32 resolution: if no dof's acceleration changes, or the gradient has stopped shrinking
@@ -1857,7 +2022,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
         Ma += ald * mv;
         ljar += ald * ljv;
 #pragma unroll
-        for (int r = 0; r < 4; r++) jar[r] += alc * jv[r];
+        for (int sl = 0; sl < CPL; sl++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) jar[sl][r] += alc[sl] * jv[sl][r];
         niter = it + 1;
         if (!partial && scale * improvement < tol) done = true;
       }
@@ -1872,8 +2039,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
        * iteration of env prof[255], as floats behind the 256 stamp slots of the buffer given to mir_debug_profile_step */
       if (a.prof && valid && env == (int)a.prof[255] && it < 8) {
         float* tr = reinterpret_cast<float*>(a.prof + 256) + (it * G + lane) * 16;
-        tr[0] = qacc; tr[1] = jar[0]; tr[2] = jar[1]; tr[3] = jar[2]; tr[4] = jar[3]; tr[5] = (float)prevbits; tr[6] = g; tr[7] = sv;
-        tr[8] = alpha; tr[9] = ald; tr[10] = alc; tr[11] = improvement; tr[12] = ncross; tr[13] = done ? 1.0f : 0.0f; tr[14] = (float)flipmask; tr[15] = partial ? 1.0f : 0.0f;
+        tr[0] = qacc; tr[1] = jar[0][0]; tr[2] = jar[0][1]; tr[3] = jar[0][2]; tr[4] = jar[0][3]; tr[5] = (float)prevbits[0]; tr[6] = g; tr[7] = sv;
+        tr[8] = alpha; tr[9] = ald; tr[10] = alc[0]; tr[11] = improvement; tr[12] = ncross; tr[13] = done ? 1.0f : 0.0f; tr[14] = (float)flipmask[0]; tr[15] = partial ? 1.0f : 0.0f;
       }
 #endif
       WSYNC();
@@ -2006,10 +2173,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : 10))
       WSYNC();
       if (__any(done)) group_fk(S, lane, nb, parents, bk, row4);
     }
-    if (ROT && step == 0) emit_outputs();
+    if ((ROT || BIGV) && step == 0) emit_outputs();
     return 0;
   };  // step_body
-  if constexpr (ROT) {
+  if constexpr (ROT || BIGV) {
     if (step_body(std::integral_constant<int, 0>{}) == 0) step_body(std::integral_constant<int, 1>{});
   } else if constexpr (SINGLE) {
     if (step_body(std::integral_constant<int, 0>{}) == 2) return;
@@ -2061,6 +2228,7 @@ template <int FEAT>
 static void launch_feat(const StepArgs& a, int blocks, int single, int plain_loop, hipStream_t stream) {
   if (a.phase == 1) hipLaunchKernelGGL((mir_step_kernel<3, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 3) hipLaunchKernelGGL((mir_step_kernel<5, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 4) hipLaunchKernelGGL((mir_step_kernel<6, FEAT, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
   else if constexpr ((FEAT & 4) == 0) hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
@@ -2069,7 +2237,7 @@ extern "C" __attribute__((visibility("hidden"))) int mir_launch_step_convex(cons
   StepArgs a = *args;
   const int blocks = (a.B + EPB - 1) / EPB;
   // the headline scene's instantiation (features bit 2: mir_create found SpecPick::matches); the everything-variant stays generic
-  if ((a.features & 4) && (a.phase == 1 || a.phase == 3 || single || plain_loop)) launch_feat<5>(a, blocks, single, plain_loop, stream);
+  if ((a.features & 4) && (a.phase == 1 || a.phase == 3 || a.phase == 4 || single || plain_loop)) launch_feat<5>(a, blocks, single, plain_loop, stream);
   else if (a.features & 2) launch_feat<3>(a, blocks, single, plain_loop, stream);  // sweep-and-prune scenes carry the convex code too
   else launch_feat<1>(a, blocks, single, plain_loop, stream);
   return (int)hipGetLastError();
@@ -2096,6 +2264,7 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   if (a.features) return mir_launch_step_convex(&a, single, plain_loop, stream);
   if (a.phase == 1) hipLaunchKernelGGL((mir_step_kernel<3, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 3) hipLaunchKernelGGL((mir_step_kernel<5, 0>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 4) hipLaunchKernelGGL((mir_step_kernel<6, 0, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, 0>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, 0>), dim3(blocks), dim3(64), 0, stream, a);

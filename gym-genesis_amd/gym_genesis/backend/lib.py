@@ -104,6 +104,8 @@ def load_library() -> C.CDLL:
     lib.mir_get_exact_contacts.restype = C.c_int
     lib.mir_get_exact_stats.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     lib.mir_get_exact_stats.restype = C.c_int
+    lib.mir_get_exact_route.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.mir_get_exact_route.restype = C.c_int
     lib.mir_render.argtypes = [vp, C.POINTER(MirCameraSpec), C.POINTER(MirVisualSpec), i32, vp, vp, vp]
     lib.mir_render.restype = C.c_int
     lib.mir_visual_sizeof.restype = C.c_int
@@ -248,9 +250,11 @@ class StepHelpers:
             # (a HOST action -- NumPy, list, CPU tensor -- is staged in pinned memory and read in place: stage_action; the step is
             #  closed by step_end() before the buffer comes round again)
             # (any tensor on a GPU -- this device or another, a subclass, a Parameter -- goes through as_action's .to(device); the
-            #  converted tensor stays alive in `action` until the launch is queued)
+            #  converted tensor is held until step_end() has returned: with exact contacts the launches for the deferred envs read the
+            #  action AGAIN from there, on the library's side stream -- ADVICE r5; include/mirigid.h: mir_set_exact_contacts)
             if isinstance(action, torch.Tensor) and action.is_cuda:
                 action = self.as_action(action, self.nu)
+                self._pend_action_ref = action
                 self.step_go_ptr(action.data_ptr())
             else:
                 self.step_go_ptr(self.stage_action(action, self.nu))
@@ -412,6 +416,7 @@ class MirScene(StepHelpers):
         self._check(self.lib.mir_step_begin(self.h, _ptr(action), _ptr(agent_pos), _ptr(env_state), _ptr(reward),
                                             _ptr(terminated), self._stream()))
         self._host_pending = None
+        self._pend_action_ref = action  # (read again by the launches of step_end() when exact contacts are on)
 
     def step_prepare_ptrs(self, ptrs) -> None:
         rc = self.lib.mir_step_prepare(self.h, ptrs[0], ptrs[1], ptrs[2], ptrs[3])
@@ -444,6 +449,7 @@ class MirScene(StepHelpers):
             pend = (host, host.ctypes.data)
         self._host_pending = None
         rc = self.lib.mir_step_end(self.h, pend[1])
+        self._pend_action_ref = None
         if rc:
             self._check(rc)
         return pend[0]
@@ -451,6 +457,7 @@ class MirScene(StepHelpers):
     def step_end_ptr(self, host_ptr: int) -> None:
         """mir_step_end into a caller-provided host array (address): the flat fast path of GenesisEnv.step."""
         rc = self.lib.mir_step_end(self.h, host_ptr)
+        self._pend_action_ref = None
         if rc:
             self._check(rc)
 
@@ -579,11 +586,19 @@ class MirScene(StepHelpers):
         self._check(self.lib.mir_debug_early_mask_stats(self.h, out, 1 if reset else 0, self._stream()))
         return int(out[0]), int(out[1])
 
-    def set_exact_contacts(self, on: bool = True) -> None:
+    def set_exact_contacts(self, on=True) -> None:
         """mir_set_exact_contacts: from now on the begin / end step path defers every env whose narrowphase finds more contact
-        points than the 16-lane kernel keeps (16) and steps it on the wave-per-env kernel instead (48 points, no thinning); the other
-        envs are computed as before.  step() / step_fused() then wait for their step; step_packed() / rollout*() are refused."""
-        self._check(self.lib.mir_set_exact_contacts(self.h, C.byref(self.spec), 1 if on else 0))
+        points than the 16-lane kernel keeps (16) and steps it with 48 points, never thinned below that -- on the list instantiation of
+        the 16-lane kernel (three contacts per lane), on the wave-per-env kernel what exceeds that too; the other envs are computed as
+        before.  step() / step_fused() then wait for their step; step_packed() / rollout*() are refused.
+        on="all" (tests): EVERY env of every step takes the deferred envs' route -- the twin a deferred env is compared with."""
+        self._check(self.lib.mir_set_exact_contacts(self.h, C.byref(self.spec), 2 if on == "all" else (1 if on else 0)))
+
+    def exact_route(self) -> dict:
+        """mir_get_exact_route: deferred env-steps handed to the list instantiation / env-steps stepped by the wave-per-env kernel."""
+        out = (C.c_uint64 * 2)()
+        self._check(self.lib.mir_get_exact_route(self.h, out))
+        return {"list_env_steps": int(out[0]), "wave_env_steps": int(out[1])}
 
     @property
     def exact_contacts(self) -> bool:

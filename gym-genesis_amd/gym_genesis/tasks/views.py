@@ -14,15 +14,29 @@ import numpy as np
 import torch
 
 
+def _rows(t: torch.Tensor, envs_idx) -> torch.Tensor:
+    """The rows `envs_idx` of a batch-first tensor, as Genesis's getters return them (`envs_idx=None`: all envs).  The reference's
+    SO-101 expert asks for `robot.get_qpos(envs_idx=np.arange(B))` and `get_link("gripper").get_pos(envs_idx=torch.arange(B))`
+    (/root/reference/examples/so_101/collect_task_stack_cube_batch.py:73,86,90): NumPy, torch (any device) and lists are accepted."""
+    if envs_idx is None:
+        return t
+    if not (isinstance(envs_idx, torch.Tensor) and envs_idx.is_cuda):
+        host = np.asarray(envs_idx.cpu() if isinstance(envs_idx, torch.Tensor) else envs_idx).reshape(-1)
+        if host.size == t.shape[0] and np.array_equal(host, np.arange(t.shape[0])):
+            return t  # (the experts' arange(B): no gather, no upload)
+        envs_idx = host
+    return t.index_select(0, torch.as_tensor(envs_idx, device=t.device).long().reshape(-1))
+
+
 class LinkView:
     def __init__(self, mir, body_index: int, name: str):
         self._mir, self.idx, self.name = mir, body_index, name
 
-    def get_pos(self) -> torch.Tensor:
-        return self._mir.get_links()[0][:, self.idx, :].contiguous()
+    def get_pos(self, envs_idx=None) -> torch.Tensor:
+        return _rows(self._mir.get_links()[0][:, self.idx, :].contiguous(), envs_idx)
 
-    def get_quat(self) -> torch.Tensor:
-        return self._mir.get_links()[1][:, self.idx, :].contiguous()
+    def get_quat(self, envs_idx=None) -> torch.Tensor:
+        return _rows(self._mir.get_links()[1][:, self.idx, :].contiguous(), envs_idx)
 
 
 class EntityView:
@@ -45,20 +59,27 @@ class EntityView:
     def get_link(self, name: str) -> LinkView:
         return LinkView(self._mir, self._b.body_index(name), name)
 
-    def get_pos(self) -> torch.Tensor:
-        return self._mir.get_links()[0][:, self.root, :].contiguous()
+    def get_pos(self, envs_idx=None) -> torch.Tensor:
+        return _rows(self._mir.get_links()[0][:, self.root, :].contiguous(), envs_idx)
 
-    def get_quat(self) -> torch.Tensor:
-        return self._mir.get_links()[1][:, self.root, :].contiguous()
+    def get_quat(self, envs_idx=None) -> torch.Tensor:
+        return _rows(self._mir.get_links()[1][:, self.root, :].contiguous(), envs_idx)
 
-    def get_dofs_position(self) -> torch.Tensor:
-        return self._mir.get_state()[0][:, self._qcols].contiguous()
+    def get_dofs_position(self, dofs_idx_local=None, envs_idx=None) -> torch.Tensor:
+        q = self._mir.get_state()[0][:, self._qcols].contiguous()
+        if dofs_idx_local is not None:
+            q = q[:, [int(i) for i in np.asarray(dofs_idx_local).ravel()]].contiguous()
+        return _rows(q, envs_idx)
 
-    def get_dofs_velocity(self) -> torch.Tensor:
-        return self._mir.get_state()[1][:, self.dof_idx].contiguous()
+    def get_dofs_velocity(self, dofs_idx_local=None, envs_idx=None) -> torch.Tensor:
+        v = self._mir.get_state()[1][:, self.dof_idx].contiguous()
+        if dofs_idx_local is not None:
+            v = v[:, [int(i) for i in np.asarray(dofs_idx_local).ravel()]].contiguous()
+        return _rows(v, envs_idx)
 
-    def get_qpos(self) -> torch.Tensor:
-        return self.get_dofs_position()
+    def get_qpos(self, envs_idx=None) -> torch.Tensor:
+        """(`robot.get_qpos(envs_idx=np.arange(B))`: /root/reference/examples/so_101/collect_task_stack_cube_batch.py:73,90)"""
+        return self.get_dofs_position(envs_idx=envs_idx)
 
     def _cols(self, t: torch.Tensor) -> torch.Tensor:
         """Columns `_qcols` of a (B, n) tensor: a slice when they are a run (every scene built here), else through an index tensor kept on
@@ -82,22 +103,22 @@ class EntityView:
         mir = self._mir
         B = mir.num_envs
         idx = None if envs_idx is None else torch.as_tensor(envs_idx, device=mir.device).long().reshape(-1)
-        scattered = [False]
 
         def full(t, k):
+            """-> (tensor of B rows, owned): owned = a tensor made here (rows scattered to `idx`), which may be edited in place; a
+            full-batch argument comes back as it is -- possibly the caller's own tensor, never written"""
             if t is None:
-                return None
+                return None, False
             t = torch.as_tensor(t, dtype=torch.float32, device=mir.device).reshape(-1, k)
             if idx is None or t.shape[0] == B:
-                return t
+                return t, False
             out = torch.zeros((B, k), dtype=torch.float32, device=mir.device)
             out[idx] = t
-            scattered[0] = True
-            return out
+            return out, True
 
-        p, q = full(pos, 3), full(quat, 4)
-        if q is not None and scattered[0]:
-            q[:, 0] += (q.abs().sum(1) == 0).float()  # unaddressed rows: identity, so normalisation stays finite (q is full()'s own tensor)
+        (p, _), (q, q_owned) = full(pos, 3), full(quat, 4)
+        if q is not None and q_owned:
+            q[:, 0] += (q.abs().sum(1) == 0).float()  # unaddressed rows: identity, so normalisation stays finite
         init = None
         if init_qpos is not None:
             qc = self._qcols

@@ -294,9 +294,14 @@ int mir_step_go(MirHandle h, const float* action, void* stream);
  * manifolds beyond that; the reference's own expert, examples/franka/pick_cube_state.py:33-41,86-88, drives 29 % of its env-steps
  * there).  With the switch on, a step launched by mir_step_begin / mir_step_go DEFERS every env whose narrowphase found more than 16
  * candidate points: the launch stores nothing for it and says so in bit 7 of its terminated byte; mir_step_end then steps exactly those
- * envs on the wave-per-env kernel (the same scene compiled with MIR_MAX_CONTACT points, never thinned below that) from their untouched
- * state rows, with the step's action and into the step's output pointers, recomputes their part of the split step's hand-over, and
- * returns when their terminated bytes have arrived too.  An env that is not deferred is computed exactly as without the switch; a
+ * envs with MIR_MAX_CONTACT points, never thinned below that, from their untouched state rows, with the step's action and into the
+ * step's output pointers, recomputes their part of the split step's hand-over, and returns when their terminated bytes have arrived
+ * too.  Since round 6 they take ONE launch of the 16-lane kernel's list instantiation (three contacts per lane, four envs per
+ * workgroup, the next step's hand-over included); an env beyond THAT capacity too -- more than 48 points (thinned to 48 as before) or
+ * more than 16 candidate geom pairs -- goes to the wave-per-env kernel (the same scene compiled for it; 64 candidate pairs) as every
+ * deferred env did in round 5 (MIR_EXACT_WAVE=1 in the environment at the time of the call: all of them still do).
+ * `action` of the pending mir_step_begin / mir_step_go is read AGAIN by those launches: with the switch on it must stay valid, and
+ * unchanged, until mir_step_end has returned; and the next mir_step_begin may name another stream (it is made to wait for them).  An env that is not deferred is computed exactly as without the switch; a
  * step without deferred envs launches nothing extra.  The state rows, outputs and link poses of a deferred env are those of the step
  * only once mir_step_end has returned: anything queued between mir_step_begin and mir_step_end -- a mir_render of the observation's
  * images, say -- sees its OLD rows (the task classes close the step before they draw).  `spec`: the spec the scene was created from (compiled once more, for the wave
@@ -304,10 +309,14 @@ int mir_step_go(MirHandle h, const float* action, void* stream);
  * step), and mir_step_packed / mir_rollout / mir_rollout_autoreset return MIR_E_INVALID (their steps are never closed on the host).
  * MIR_E_INVALID for scenes of the wave kernel (nothing to do) and for sync modes other than 3.
  * mir_get_exact_stats: out4 = {steps closed by mir_step_end, steps that had deferred envs, deferred env-steps, most deferred envs in one
- * step} since the last reset of the counters (reset != 0 clears them). */
+ * step} since the last reset of the counters (reset != 0 clears them).  mir_get_exact_route: out2 = {deferred env-steps handed to the
+ * list instantiation, env-steps stepped by the wave-per-env kernel} over the same period.
+ * on = 2 (tests): every env of every step is deferred, i.e. the whole batch is stepped by the launches that otherwise serve the
+ * deferred envs only -- the twin the parity tests compare a deferred env with, bit for bit. */
 int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on);
 int mir_get_exact_contacts(MirHandle h);
 int mir_get_exact_stats(MirHandle h, uint64_t* out4, int32_t reset);
+int mir_get_exact_route(MirHandle h, uint64_t* out2);
 
 /* Same step, but every output of an env lands in ONE packed float32 row
  * rows[e*row_stride + ...] = [agent_pos (agent_dim) | env_state (env_dim) | reward | terminated(0/1)]
@@ -472,6 +481,9 @@ int mir_debug_profile_step(MirHandle h, unsigned long long* prof, void* stream);
 /* profiling builds (-DMIR_PROFILE_SINGLE): the next mir_step_begin / mir_step_go launch -- whichever kernel the split-step protocol
  * picks -- leaves its stamps in prof (160 x u64, device; slot 63 = workgroup to watch) */
 int mir_debug_profile_next_step(MirHandle h, unsigned long long* prof);
+/* ... and the next launch of the LIST INSTANTIATION of exact contacts (mir_step_end of a step with deferred envs): prof 160 x u64; the
+ * first pass's stamps as above, slots 140 / 141 / 142 = end of the second pass on the main / the collision wave, its start */
+int mir_debug_profile_next_list_step(MirHandle h, unsigned long long* prof);
 int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* out_us);
 /* n back-to-back launches of the rotated step kernel (split mode 1), cycling through n_actions (B, nu) action blocks, without
  * observation outputs -- or, with outputs = {agent_pos, env_state, reward, terminated} (device pointers, shapes as in

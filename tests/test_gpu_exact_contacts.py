@@ -2,15 +2,18 @@
 
 Genesis keeps every contact point of its candidate pairs (RigidOptions at /root/reference/gym_genesis/tasks/franka/cube_pick.py:46);
 the 16-lane kernel keeps 16 per env and thins the manifolds beyond that -- in 29 % of the env-steps of the reference's own expert
-(/root/reference/examples/franka/pick_cube_state.py:33-41,86-88).  With the switch on, a step DEFERS exactly the envs whose
-narrowphase found more than 16 points; mir_step_end steps those on the wave-per-env kernel (48 points, never thinned here) and
-recomputes their half of the split step's hand-over.  What is checked:
+(/root/reference/examples/franka/pick_cube_state.py:33-41,86-88).  With the switch on (the default of the pick tasks since round 6), a
+step DEFERS exactly the envs whose narrowphase found more than 16 points; mir_step_end steps those with 48 points, never thinned here --
+on the LIST INSTANTIATION of the 16-lane kernel (three contacts per lane; round 5: on the wave-per-env kernel, which is still where an
+env with more than 16 candidate pairs goes, and every deferred env under MIR_EXACT_WAVE=1) -- which also writes their half of the split
+step's hand-over.  What is checked:
 
   * the reference's expert at 4096 envs: teacher-forced on all 200 steps against the float64 oracle AT CAPACITY 48 -- joint state
     of every env, deferred ones included, and the host masks bit for bit;
   * free-running on the rotated launches (the path GenesisEnv.step takes): on every step every env is bit-identical to one of two
     teacher-forced twins -- the plain 16-lane scene where the env was not deferred (no thinning there: the same computation), the
-    all-wave-kernel scene (contact_capacity = 48) where it was;
+    scene whose EVERY env takes the deferred envs' route (set_exact_contacts("all")) where it was; and that twin stays within float32
+    rounding of the same scene on the wave-per-env kernel (contact_capacity = 48), last round's twin;
   * a workload without overflow: switch on == switch off, bit for bit, nothing extra launched;
   * the entry points that cannot close their steps on the host are refused, the others wait.
 """
@@ -155,37 +158,50 @@ def test_reference_expert_4096_exact_contacts_teacher_forced_against_the_capacit
 
 def _free_running_against_twins(franka_spec, n, want_split):
     """Scripted grasp at n envs, switch on, free-running.  Before every step the state goes to two twins (a state write: fused launches
-    there): the plain 16-lane scene and the pick scene on the wave kernel (contact_capacity = 48).  After the step every env's outputs
-    and state rows equal the plain twin's where it was not deferred and the wave twin's where it was.  -> counters"""
+    there): the plain 16-lane scene, and the scene whose every env takes the route of the deferred ones -- the list instantiation of the
+    16-lane kernel (under MIR_EXACT_WAVE=1: the pick scene on the wave kernel, contact_capacity = 48).  After the step every env's
+    outputs and state rows equal the plain twin's where it was not deferred and the other twin's where it was.  A third scene, the pick
+    scene on the wave kernel, says how far the list instantiation is from last round's route (float32 rounding).  -> counters"""
     from gym_genesis.backend.lib import MirScene
 
     sc = MirScene(franka_spec, n)
     sc.set_exact_contacts(True)
+    via_wave = os.environ.get("MIR_EXACT_WAVE", "0") not in ("", "0")
     plain, wave = MirScene(franka_spec, n), MirScene(_spec48(), n)
+    if via_wave:
+        twin = wave
+    else:
+        twin = MirScene(franka_spec, n)
+        twin.set_exact_contacts("all")
     assert sc.kernel == 16 and plain.kernel == 16 and wave.kernel == 64 and sc.split_step == want_split
-    for s in (sc, plain, wave):
+    for s in (sc, plain, wave, twin):
         s.set_diag(True)
     pos, acts = _grasp_workload(n)
     quat = np.tile(np.array([0, 0, 0, 1], np.float32), (n, 1))
     arm = np.tile(HOME, (n, 1))
     sc.reset(pos, quat, arm)
-    b0, b1, b2 = _bufs(sc), _bufs(plain), _bufs(wave)
+    b0, b1, b2, b3 = _bufs(sc), _bufs(plain), _bufs(twin), _bufs(wave)
     dacts = torch.as_tensor(acts, device=sc.device)
     sc.exact_stats(reset=True)
     n_def = steps_def = 0
     lifted = np.zeros(n, bool)
+    far = []
     for t in range(acts.shape[0]):
         st = sc.get_state()
-        for tw in (plain, wave):
+        for tw in {plain, twin, wave}:
             tw.set_state(*st)
         sc.step_begin(dacts[t], *b0); h0 = sc.step_end()
         plain.step_fused(dacts[t], *b1)
-        wave.step_fused(dacts[t], *b2)
+        twin.step_fused(dacts[t], *b2)
+        if twin is not wave:
+            wave.step_fused(dacts[t], *b3)
         dfr = sc.get_diag(points=True)[3] > 16           # (a deferred env's record is the wave kernel's: its count of the same state)
         # (the 16-lane kernel defers on ITS count; at make / break the two narrowphases may differ by a point: such an env is in
         #  neither class by the counts alone -- it is recognised by which twin it equals, below)
         n_def += int(dfr.sum()); steps_def += int(dfr.any())
-        s0, s1, s2 = sc.get_state(), plain.get_state(), wave.get_state()
+        s0, s1, s2 = sc.get_state(), plain.get_state(), twin.get_state()
+        if twin is not wave and bool(dfr.any()):
+            far.append((s2[0] - wave.get_state()[0]).abs().max(1).values[dfr].cpu().numpy())
         eq_plain = torch.ones(n, dtype=torch.bool, device=sc.device)
         eq_wave = torch.ones(n, dtype=torch.bool, device=sc.device)
         for x, y, z in zip(list(b0) + list(s0), list(b1) + list(s1), list(b2) + list(s2)):
@@ -193,9 +209,19 @@ def _free_running_against_twins(franka_spec, n, want_split):
             eq_wave &= (x == z).reshape(n, -1).all(1)
         assert bool((eq_plain | eq_wave).all()), f"step {t}: {int((~(eq_plain | eq_wave)).sum())} envs equal neither twin"
         assert bool(eq_plain[~dfr].all()) or int((~eq_plain[~dfr]).sum()) <= 2, f"step {t}: envs that were not deferred differ from the plain 16-lane scene"
-        assert bool(eq_wave[dfr].all()), f"step {t}: a deferred env differs from the wave-kernel scene"
+        assert bool(eq_wave[dfr].all()), f"step {t}: a deferred env differs from the scene whose every env takes the deferred envs' route"
         assert np.array_equal(h0, b0[3].cpu().numpy().astype(bool))
         lifted |= h0
+    route = sc.exact_route()
+    if via_wave:
+        assert route["list_env_steps"] == 0 and route["wave_env_steps"] == sc.exact_stats()["overflow_env_steps"]
+    else:
+        # (this workload stays under 48 points and 16 candidate pairs: nothing reaches the wave-per-env kernel)
+        assert route["list_env_steps"] == sc.exact_stats()["overflow_env_steps"] and route["wave_env_steps"] == 0
+        far = np.concatenate(far)
+        print(f"\n[list instantiation against the wave-per-env kernel, same state, same action, one step, {far.size} deferred env-steps] qpos L-inf "
+              f"median {np.median(far):.1e} 0.99 {np.quantile(far, 0.99):.1e} 0.9999 {np.quantile(far, 0.9999):.1e} max {far.max():.1e}")
+        assert np.quantile(far, 0.99) < 5e-6 and np.quantile(far, 0.9999) < 2e-4
     return sc.exact_stats(), n_def, steps_def, lifted
 
 
@@ -209,10 +235,12 @@ def test_free_running_rotated_launches_every_env_equals_its_twin_bit_for_bit(fra
     assert lifted.mean() > 0.9
 
 
-@pytest.mark.parametrize("var,val,split", [("MIR_SPLIT_STEP", "0", 0), ("MIR_SPLIT_STEP", "2", 2), ("MIR_NO_EARLY_MASK", "1", 1), ("MIR_EXACT_ONE_STREAM", "1", 1)])
+@pytest.mark.parametrize("var,val,split", [("MIR_SPLIT_STEP", "0", 0), ("MIR_SPLIT_STEP", "2", 2), ("MIR_NO_EARLY_MASK", "1", 1), ("MIR_EXACT_ONE_STREAM", "1", 1),
+                                           ("MIR_EXACT_WAVE", "1", 1)])
 def test_every_launch_kind_defers_the_same_way(franka_spec, monkeypatch, var, val, split):
     """The other ways a step is launched -- one fused launch per step, the split step as two launches, terminated bytes that wait for
-    the integrator, the deferred envs' launches on the step's own stream -- at 512 envs: every env of every step equals its twin."""
+    the integrator, the deferred envs' launches on the step's own stream, the deferred envs on the wave-per-env kernel (round 5's route,
+    the fallback of this round's) -- at 512 envs: every env of every step equals its twin."""
     monkeypatch.setenv(var, val)
     st, n_def, steps_def, lifted = _free_running_against_twins(franka_spec, 512, split)
     assert abs(st["overflow_env_steps"] - n_def) <= 10 and n_def > 100 and st["steps"] == 200 and lifted.mean() > 0.9
@@ -222,8 +250,8 @@ def test_so101_scene_with_a_low_capacity_random_actions_every_env_equals_its_twi
     """The other articulation (BASELINE configs[3]) and another way to overflow: the SO-101 pick scene with the capacity of the
     16-lane kernel set to 4 points -- the cube resting on the slab -- and random joint targets: whenever the arm touches the slab or the
     cube the env overflows.  Switch on, rotated launches.  Every env of every step equals the plain scene (capacity 4) where it was not
-    deferred and the same scene on the wave kernel (capacity 48) where it was -- envs with 5 .. 16 points included, which the 16-lane
-    kernel could have held."""
+    deferred and the same scene with every env on the deferred envs' route (the list instantiation, capacity 48) where it was -- envs
+    with 5 .. 16 points included, which the 16-lane kernel could have held."""
     from gym_genesis.backend.lib import MirScene
 
     def spec(cap):
@@ -233,9 +261,10 @@ def test_so101_scene_with_a_low_capacity_random_actions_every_env_equals_its_twi
 
     n = 2048
     monkeypatch.setenv("MIR_SPLIT_STEP", "1")
-    sc, plain, wave = MirScene(spec(4), n), MirScene(spec(4), n), MirScene(spec(48), n)
+    sc, plain, wave = MirScene(spec(4), n), MirScene(spec(4), n), MirScene(spec(4), n)
     sc.set_exact_contacts(True)
-    assert sc.kernel == 16 and plain.kernel == 16 and wave.kernel == 64
+    wave.set_exact_contacts("all")
+    assert sc.kernel == 16 and plain.kernel == 16 and wave.kernel == 16
     for s_ in (sc, plain, wave):
         s_.set_diag(True)
     rng = np.random.RandomState(4)
@@ -256,9 +285,10 @@ def test_so101_scene_with_a_low_capacity_random_actions_every_env_equals_its_twi
         n_def += int(dfr.sum())
         for x, y, z in zip(list(b0) + list(sc.get_state()), list(b1) + list(plain.get_state()), list(b2) + list(wave.get_state())):
             assert torch.equal(x[~dfr], y[~dfr]), f"step {t}: an env that was not deferred differs from the plain scene"
-            assert torch.equal(x[dfr], z[dfr]), f"step {t}: a deferred env differs from the wave-kernel scene"
+            assert torch.equal(x[dfr], z[dfr]), f"step {t}: a deferred env differs from the scene whose every env takes the deferred envs' route"
         assert np.array_equal(h0, b0[3].cpu().numpy().astype(bool))
     st = sc.exact_stats()
+    assert sc.exact_route() == {"list_env_steps": st["overflow_env_steps"], "wave_env_steps": 0}
     print(f"\n[exact contacts, SO-101 at capacity 4 x {n}, random targets] deferred env-steps {n_def} of {200 * n} in {st['overflow_steps']} of 200 steps")
     assert abs(st["overflow_env_steps"] - n_def) <= 20 and n_def > 300
 
@@ -394,5 +424,7 @@ def test_more_candidate_pairs_than_lanes_defers_too():
         for x, z in zip(list(b0) + list(sc.get_state()), list(b2) + list(wave.get_state())):
             assert torch.equal(x, z), f"step {t}: an env with more than 16 candidate pairs differs from the wave-kernel scene"
     st = sc.exact_stats()
+    # (the list instantiation has 16 candidate lanes too: it hands every one of these envs on to the wave-per-env kernel)
+    assert sc.exact_route() == {"list_env_steps": 30 * n, "wave_env_steps": 30 * n}
     assert st["overflow_env_steps"] == 30 * n and int(pts.min()) > 16
     assert torch.isfinite(sc.get_state()[0]).all() and float(sc.get_state()[0][:, 9].min()) > 0.05   # (the upper comb stays on the lower one)
