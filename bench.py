@@ -1249,6 +1249,7 @@ def worker(args) -> int:
                        "gather_stats": dict(gather_stats) if gather else None,
                        "terminated_sync_mode": task._mir.sync_mode, "split_step": int(getattr(task._mir, "split_step", 0)),
                        "early_terminated_bytes": bool(task._mir.early_mask),
+                       "exact_contacts": bool(getattr(task._mir, "exact_contacts", False)),
                        "value_is": "mean over the repeated K-step regions (value_median_region: their median)",
                        "host_thread": host_thread_note()},
             "early_mask": {"sent": em_sent, "mismatches": em_bad, "workgroup_launches": (len(walls) * K + W) * ((B + 3) // 4) if api_walls is not None else 0,
@@ -1316,6 +1317,12 @@ def worker(args) -> int:
         try:
             state["t"] = 0
             task.reset()
+            # (what follows -- bare fused launches, device-side rollouts, the kernel timing of the roofline -- has no host in it to close a
+            #  step on: those legs run with exact contacts switched OFF, at the 16-point capacity; mir_rollout* / mir_step_packed are
+            #  refused with the switch on.  The headline loop above ran with the task's default: on.)
+            if getattr(task._mir, "exact_contacts", False):
+                out["config"]["exact_contacts_headline_loop"] = dict(task._mir.exact_stats(), **task._mir.exact_route())
+                task._mir.set_exact_contacts(False)
             raw_walls, raw_evs = (walls, evs) if api_walls is None else measure(raw_loop)
             n_launch = len(raw_walls) * K
             kernel_us = sum(raw_evs) * 1e3 / n_launch  # HIP events on the launching stream, per launch

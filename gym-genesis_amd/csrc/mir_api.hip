@@ -188,6 +188,7 @@ struct Outs {
   bool poses = false;  // 16-lane kernel: also write the link poses into h->poses (the rasteriser reads them)
   int phase = 0;       // 16-lane kernel: 0 whole step, 1 / 2 the two halves of a split step, 3 rotated, 4 the list instantiation of exact contacts (mir_step.h)
   int exact = 0;       // 16-lane kernel: defer the envs with more candidate points than lanes (StepArgs::exact)
+  int over_cap = 0;    // 16-lane kernel, phase 4 / 5 (StepArgs::over_cap)
   const int32_t* env_list = nullptr;  // 16-lane kernel, phase 1: serve the envs env_list[0 .. nlist) (StepArgs::env_list)
   int nlist = 0;
   unsigned long long* prof = nullptr;  // 16-lane kernel only (debug)
@@ -216,14 +217,14 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.term_bad = h->pin_dev ? reinterpret_cast<uint32_t*>(h->pin_dev + h->pin_flag_off + 16) : nullptr;
     a.term_wstride = h->term_wstride;
     a.diag = (o.diag && h->diag_on) ? h->diag : nullptr;
-    a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0) | ((h->spec_pick && (!wr_poses || o.phase == 3 || o.phase == 4)) ? 4 : 0);
+    a.B = h->B; a.qst = h->hm.qstride; a.nu = h->hm.nu; a.features = (h->hm.has_convex ? 1 : 0) | (h->hm.use_sap ? 3 : 0) | ((h->spec_pick && (!wr_poses || o.phase >= 3)) ? 4 : 0);
     a.action = o.action; a.agent_pos = o.agent_pos; a.env_state = o.env_state; a.reward = o.reward; a.terminated = o.terminated;
     a.out_M = o.out_M; a.out_bias = o.out_bias; a.out_qas = o.out_qas; a.out_qacc = o.out_qacc; a.out_xpos = o.out_xpos; a.out_xquat = o.out_xquat;
     a.rows = o.rows; a.row_stride = o.row_stride; a.mode = o.mode; a.n_steps = o.n_steps; a.prof = o.prof;
     a.act_step = o.act_step; a.rows_step = o.rows_step; a.ar = o.ar;
     a.term_host = o.term_host; a.term_tag = o.term_tag; a.done_ticket = o.done_ticket; a.done_flag = o.done_flag; a.done_seq = o.done_seq;
     a.phase = o.phase; a.pre = h->pre;
-    a.exact = o.exact;
+    a.exact = o.exact; a.over_cap = o.over_cap;
     if (o.env_list) { a.env_list = o.env_list; a.B = o.nlist; }
     if (o.phase == 4) a.term_wstride = 1;  // (the terminated byte of list entry k is byte k of term_host)
     rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
@@ -525,6 +526,7 @@ int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const fl
   }
   if (int rc = check_mask(h)) return rc;
   h->pre_valid = 0;
+  if (!env_mask) h->heavy = 0;  // (exact contacts: a full reset ends a heavy phase -- every env is back at its start)
   h->poses_current = 0;
   h->state_version++;
   DeviceGuard guard(h->device);
@@ -605,20 +607,27 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   o.term_host = h->pin_dev;
   const uint32_t seq = h->seq + 1u;
   // The tag has a counter of its own that nothing else advances (h->seq is shared with mir_debug_null_roundtrip and wraps): 1 .. 63,
-  // never 0 (fresh memory), and a launch's tag differs from those of the 62 launches before it -- each of which overwrote every byte.
-  // (Six bits: bit 7 of a byte says "deferred" -- exact contacts, StepArgs::exact.)
-  const uint32_t tag = h->tag % 63u + 1u;
+  // never 0 (fresh memory), and a launch's tag differs from those of the 30 launches before it -- each of which overwrote every byte.
+  // (Five bits: bit 7 of a byte says "deferred" -- exact contacts, StepArgs::exact -- and bit 6 "more points than the one-contact-per-lane
+  //  kernel holds", from the launches that step the whole batch with three contacts per lane, StepArgs::over_cap.)
+  const uint32_t tag = h->tag % 31u + 1u;
   o.term_tag = tag;
   if (h->sync_mode == 2) { o.done_ticket = h->done_ticket; o.done_flag = flag_dev; o.done_seq = seq; }
   // split step: if the previous mir_step_begin left the action-independent half of THIS step in `pre` (same stream, nothing
   // touched the state since), only the other half is launched now
-  const bool split = h->split_step && h->sync_mode != 2;
+  // exact contacts, HEAVY phase (mir_step_end decides): most envs of the last step had more points than the one-contact-per-lane kernel
+  // holds, so the whole batch takes the three-contacts-per-lane instantiation's first pass in ONE launch (mir_step.hip: VARIANT 7) -- no
+  // launch that defers, no list launch behind it, no scratch rows (the first light step afterwards is launched like the one behind a reset)
+  const bool heavy = h->exact && h->exact_big && h->heavy && h->sync_mode == 3;
+  const bool split = h->split_step && h->sync_mode != 2 && !heavy;
   const bool have_pre = split && h->pre_valid && h->pre_stream == stream;
   // (one rotated launch -- this step's second half, then the next step's first half -- where the closing FK can be shared between
   //  the waves; otherwise two launches)
   const bool rotated = have_pre && h->hm.fk_free_leaf != 0 && h->split_step != 2;
-  o.phase = rotated ? 3 : (have_pre ? 2 : 0);
+  o.phase = heavy ? 5 : (rotated ? 3 : (have_pre ? 2 : 0));
   o.exact = h->exact;
+  if (heavy) { o.over_cap = h->hm.max_contacts < K16_MAX_CONTACT ? h->hm.max_contacts : K16_MAX_CONTACT; h->ex_heavy_steps++; }
+  h->pend_heavy = heavy ? 1 : 0;
   // (exact contacts, ADVICE r5: the launches for the deferred envs of an earlier step ran on the library's side stream, and only the stream
   //  of THAT step was made to wait for them; a step on another stream waits for them here -- state rows, scratch rows and the pinned
   //  list are theirs until then)
@@ -692,7 +701,7 @@ static int exact_wait(MirScene* h, const uint8_t* term, const int32_t* list, int
   unsigned long polls = 0;
   for (int k = 0; k < n;) {
     const uint8_t b = __atomic_load_n(term + k, __ATOMIC_RELAXED);
-    if ((uint8_t)((b >> 1) & 0x3fu) == want) {
+    if ((uint8_t)((b >> 1) & 0x1fu) == want) {
       if ((b & 0x80u) && again) again[(*n_again)++] = list[k];
       else if (terminated_host) terminated_host[list[k]] = b & 1u;
       k++;
@@ -728,7 +737,11 @@ static int exact_finish(MirScene* h, int n, uint8_t* terminated_host) {
   const uint8_t* wterm_host = h->ovf_term_host;
   uint8_t* wterm_dev = h->ovf_term_dev;
   int nw = n;  // envs for the wave-per-env kernel
-  if (h->exact_big) {
+  if (h->pend_heavy) {
+    // (a heavy step: these envs were beyond the three-contacts-per-lane capacity already -- straight to the wave-per-env kernel; the
+    //  statistics of a heavy step count the envs above the one-contact-per-lane capacity, mir_step_end)
+    h->ex_ovf_steps--; h->ex_ovf_envs -= (unsigned long long)n;
+  } else if (h->exact_big) {
     memset(h->ovf_term_host, 0, (size_t)n);  // (tags come round every 63 steps: a byte of an older step must not pass for this one's)
     __atomic_thread_fence(__ATOMIC_RELEASE);
     Outs o;
@@ -799,11 +812,11 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
     // 16-lane kernel: one 32-bit word (4 envs) per workgroup, `term_wstride` words apart; every byte carries this launch's tag.  One
     // pass: wait for a word, take its bits, go on to the next (the pointer stands still at the first workgroup that has not delivered)
     // (exact contacts: bit 7 of a byte = the env was deferred by the launch -- collected here, stepped by exact_finish)
-    const uint32_t want4 = 0x01010101u * (uint8_t)h->tag, tagm4 = 0x3f3f3f3fu;
+    const uint32_t want4 = 0x01010101u * (uint8_t)h->tag, tagm4 = 0x1f1f1f1fu;
     const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(bytes);
     const size_t nwg = (B + 3) / 4, ws = (size_t)h->term_wstride;
     unsigned long polls = 0;
-    int ndefer = 0;
+    int ndefer = 0, nover = 0;
     h->ex_steps++;
     for (size_t g = 0; g < nwg;) {
       uint32_t v = w[g * ws];
@@ -812,6 +825,7 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
           for (size_t k = 0; k < 4 && 4 * g + k < B; k++)
             if (v >> (8 * k + 7) & 1u) h->ovf_list_host[ndefer++] = (int32_t)(4 * g + k);
         }
+        nover += __builtin_popcount(v & 0x40404040u);
         if (terminated_host) {
           v &= 0x01010101u;
           memcpy(terminated_host + 4 * g, &v, 4 * g + 4 <= B ? 4 : B - 4 * g);
@@ -829,6 +843,15 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
       }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (h->exact && h->exact_big) {
+      // light -> heavy when this step deferred at least heavy_enter envs; heavy -> light when fewer than heavy_leave had more points than
+      // the one-contact-per-lane kernel holds (MIR_EXACT_HEAVY="enter,leave"; enter <= 0: never heavy).  The cost model behind the
+      // defaults: a light step with a deferred list costs launch + list launch, a heavy one two rounds of the bigger kernel.
+      if (h->pend_heavy) { h->ex_ovf_envs += (unsigned long long)nover; if (nover) h->ex_ovf_steps++; if ((unsigned long long)nover > h->ex_ovf_max) h->ex_ovf_max = nover; }
+      const int cnt = h->pend_heavy ? nover : ndefer;
+      if (!h->heavy && h->heavy_enter > 0 && cnt >= h->heavy_enter) h->heavy = 1;
+      else if (h->heavy && cnt < h->heavy_leave) h->heavy = 0;
+    }
     if (ndefer) return exact_finish(h, ndefer, terminated_host);
     return MIR_OK;
   } else if (h->sync_mode == 3) {
@@ -837,14 +860,14 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
     // yet and touches every cache line once after the device's last write to it; polling the whole buffer instead was measured
     // slower -- the host keeps pulling lines the device is still writing)
     const uint8_t want = (uint8_t)h->tag;
-    const uint64_t want8 = 0x0101010101010101ull * want, tagm = 0x3f3f3f3f3f3f3f3full;
+    const uint64_t want8 = 0x0101010101010101ull * want, tagm = 0x1f1f1f1f1f1f1f1full;
     const volatile uint64_t* w8 = reinterpret_cast<const volatile uint64_t*>(bytes);
     const size_t nw = B / 8;
     size_t i = 0;  // in 8-byte words, then the tail bytes
     unsigned long polls = 0;
     while (i < nw + (B - nw * 8)) {
       const bool ok = i < nw ? (((w8[i] >> 1) & tagm) == want8)
-                             : ((uint8_t)((__atomic_load_n(bytes + nw * 8 + (i - nw), __ATOMIC_RELAXED) >> 1) & 0x3fu) == want);
+                             : ((uint8_t)((__atomic_load_n(bytes + nw * 8 + (i - nw), __ATOMIC_RELAXED) >> 1) & 0x1fu) == want);
       if (ok) { i++; continue; }
       __builtin_ia32_pause();
       if ((++polls & 0xfffffu) == 0) {
@@ -934,6 +957,14 @@ int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
   // free body a childless child of the world: the reference's scenes); MIR_EXACT_WAVE=1: the wave-per-env kernel takes them all (round 5)
   h->exact_big = (h->hm.fk_free_leaf != 0 && !(getenv("MIR_EXACT_WAVE") && atoi(getenv("MIR_EXACT_WAVE")) != 0)) ? 1 : 0;
   h->exact = on == 2 ? 2 : 1;
+  h->heavy = 0;
+  h->heavy_enter = (h->B + 15) / 16; h->heavy_leave = (h->B + 31) / 32;  // (6 % / 3 % of the batch)
+  if (const char* e = getenv("MIR_EXACT_HEAVY")) {
+    int a = 0, b = 0;
+    const int k = sscanf(e, "%d,%d", &a, &b);
+    if (k >= 1) { h->heavy_enter = a; h->heavy_leave = k >= 2 ? b : a / 2; }
+  }
+  if (on == 2) h->heavy_enter = 0;  // (the twin of the tests: every env on the list instantiation, every step)
   return MIR_OK;
 }
 
@@ -942,13 +973,13 @@ int mir_get_exact_contacts(MirHandle h) { return check(h) ? MIR_E_INVALID : h->e
 int mir_get_exact_stats(MirHandle h, uint64_t* out4, int32_t reset) {
   if (check(h) || !out4) return set_err(MIR_E_INVALID, "mir_get_exact_stats: null argument");
   out4[0] = h->ex_steps; out4[1] = h->ex_ovf_steps; out4[2] = h->ex_ovf_envs; out4[3] = h->ex_ovf_max;
-  if (reset) h->ex_steps = h->ex_ovf_steps = h->ex_ovf_envs = h->ex_ovf_max = h->ex_big_envs = h->ex_wave_envs = 0;
+  if (reset) h->ex_steps = h->ex_ovf_steps = h->ex_ovf_envs = h->ex_ovf_max = h->ex_big_envs = h->ex_wave_envs = h->ex_heavy_steps = 0;
   return MIR_OK;
 }
 
 int mir_get_exact_route(MirHandle h, uint64_t* out2) {
   if (check(h) || !out2) return set_err(MIR_E_INVALID, "mir_get_exact_route: null argument");
-  out2[0] = h->ex_big_envs; out2[1] = h->ex_wave_envs;
+  out2[0] = h->ex_big_envs; out2[1] = h->ex_wave_envs; out2[2] = h->ex_heavy_steps;
   return MIR_OK;
 }
 /* debug aid (bench.py's roofline): n back-to-back launches of the rotated step kernel (what mir_step_begin launches in split mode 1)

@@ -68,6 +68,10 @@ struct MirScene {
   // (hm64 / dm64 = the same scene compiled for it with 48 points) from the untouched state rows, then recomputes their scratch rows.
   int exact;                // 0 off, 1 on, 2 (tests) every env is deferred: the whole batch takes the list instantiation
   int exact_big;            // the deferred envs take the list instantiation of the 16-lane kernel (three contacts per lane); 0: the wave-per-env kernel (MIR_EXACT_WAVE=1)
+  int heavy;                // the coming mir_step_begin steps the WHOLE batch with three contacts per lane (one launch: mir_step.hip VARIANT 7); decided by mir_step_end
+  int heavy_enter, heavy_leave;  // thresholds of that decision, in envs (MIR_EXACT_HEAVY)
+  int pend_heavy;           // the pending step is such a launch
+  unsigned long long ex_heavy_steps;
   int ovf_event_live;       // ovf_event has been recorded on the side stream behind launches the NEXT step must come after
   void* ovf_waited_stream;  // the stream that has been made to wait for it
   unsigned long long ex_big_envs;  // deferred env-steps handed to the list instantiation (those it deferred again included)

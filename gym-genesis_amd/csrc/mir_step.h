@@ -46,6 +46,8 @@ struct StepArgs {
   // split step (GenesisEnv.step path): `phase` 0 = whole step; 1 = the ACTION-INDEPENDENT half of the coming step only (poses,
   // dynamics, collision, contact arrays, Jacobians) written to `pre`; 2 = the rest of the step, read from
   // `pre`.  3 = 2 followed by 1 (of the next step) in one launch.  `pre`: K16_PRE_STRIDE floats per env.
+  // 4 = the LIST instantiation of exact contacts (three contacts per lane, capacity 48): the whole step for the envs of `env_list`,
+  // then 1 for them; 5 = its first pass alone for the whole batch (mir_step.hip: VARIANT 6 / 7).
   int phase;
   float* pre;
   // [0] env-steps that ended with a non-finite state (divergence guard, counted while diag is set; mir_get_bad);
@@ -62,6 +64,7 @@ struct StepArgs {
   // scratch row of the next step) and sets bit 7 of its host-visible terminated byte.  mir_step_end then steps exactly those envs on the
   // wave-per-env kernel (48 points, no thinning) from the untouched state rows and recomputes their scratch rows (`env_list`).
   int exact;
+  int over_cap;  // phase 4 / 5 (three contacts per lane): bit 6 of an env's terminated byte says that it had more candidate points than this (0: never set)
   // phase 1 only: the launch serves the envs env_list[0 .. B) (B = the list's length) instead of envs 0 .. B; may point into pinned host memory
   const int32_t* env_list;
 };

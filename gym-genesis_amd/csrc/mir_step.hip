@@ -119,7 +119,11 @@ struct ContactArraysT {
 };
 // (CPL > 1 only: bit c of conB[s] = contact 16 s + c moves dofs of the second tree only -- CPL == 1 keeps those flags in bits 1 .. 16 of
 //  `coupled` and has no such words: an empty base, the env block of the one-contact-per-lane instantiations is unchanged)
-template <int CPL> struct ConBWords { int conB[CPL]; int conB_pad[(4 - CPL % 4) % 4]; };
+//  Also CPL > 1 only: what the two waves need to SHARE the narrowphase's box - box trips -- the main wave idles at barrier (2) while the
+//  collision wave takes one 5 k-cycle trip after the other, five of them where both fingertips stand on the floor around a cube held by
+//  the pads: `bp_ready` (the collision wave has published the candidate list of pass bp_ready - 1), `bb_done` (the main wave has
+//  stored the contact points and counts of ITS trips), a polygon-clipping scratch of the main wave's own.)
+template <int CPL> struct ConBWords { int conB[CPL]; int bp_ready, bb_done; int conB_pad[(8 - (CPL + 2) % 4) % 4 + 0]; float clip2[48]; };
 template <> struct ConBWords<1> {};
 template <int CPL>
 struct EnvLdsT : ConBWords<CPL> {
@@ -276,15 +280,21 @@ __device__ __forceinline__ void step_rows_l(float al, float ljar, float ljv, flo
 // on the list followed by VARIANT 3 on the list, four envs per workgroup instead of one.  80 KB of LDS per workgroup, two workgroups
 // per CU, one wave per SIMD with the whole register file.  An env with more than 48 points or more than 16 candidate pairs is
 // deferred AGAIN (bit 7 of its byte; nothing stored): the wave-per-env kernel (64 candidates) stays the fallback for those.
+// VARIANT 7 (CPL = 3) = the same first pass ALONE, for the whole batch (no list, the regular terminated words): what mir_step_begin
+// launches INSTEAD of the one-contact-per-lane kernel while most envs would be deferred anyway (the reference's expert holds 70 % of
+// its envs above 16 points through its two grasp stages): one launch per step instead of a launch that computes garbage for the
+// deferred majority followed by the list launch for them.  Bit 6 of a byte: the env had more points than StepArgs::over_cap (what
+// the host decides on when to go back).
 template <int VARIANT, int FEAT, int CPL = 1>
-__global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3 || VARIANT == 5 || VARIANT == 6) ? 128 : 64)
-__attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VARIANT == 6 ? 1 : 10)))) void mir_step_kernel(StepArgs a) {
+__global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3 || VARIANT >= 5) ? 128 : 64)
+__attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VARIANT >= 6 ? 1 : 10)))) void mir_step_kernel(StepArgs a) {
   // VARIANT 5 = both halves in one launch, ROTATED: first the action-dependent half of THIS step (from the pre buffer), then the
   // action-independent half of the NEXT one (into the pre buffer).  The host sees `terminated` after the first half; the second
   // runs while it is between two env.step() calls, without a second launch, a second prologue or a second forward kinematics
   // (the closing FK of this step is the opening FK of the next).  Needs the split closing FK (fk_free_leaf scenes).
   constexpr bool ROT = VARIANT == 5;
-  constexpr bool BIGV = VARIANT == 6;  // fused pass, outputs, then the action-independent half of the next step (the list instantiation)
+  constexpr bool BIGV = VARIANT == 6 || VARIANT == 7;  // three contacts per lane: the whole step in one pass (two waves, as VARIANT 0) ...
+  constexpr bool BIG2 = VARIANT == 6;                  // ... then the outputs, then the action-independent half of the next step (the list instantiation)
   constexpr bool PRE = VARIANT == 3, POST = VARIANT == 4;
   constexpr bool SINGLE = VARIANT == 0 || PRE || POST || ROT || BIGV;
   constexpr bool DUAL = VARIANT == 0 || PRE || ROT || BIGV;
@@ -418,6 +428,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
   constexpr bool DEFER = VARIANT == 0 || VARIANT == 4 || VARIANT == 5 || BIGV;
   const int defer_above = BIGV ? MAXCON : ((DEFER && a.exact) ? (a.exact == 2 ? -1 : (max_contacts < MAXCON ? max_contacts : MAXCON)) : 0x7fffffff);
   bool ovf_env = false;  // this lane's env is deferred: set where the step reads the `coupled` word (uniform over the env's row)
+  bool over_env = false; // (three contacts per lane: the env had more candidate points than StepArgs::over_cap -- bit 6 of its terminated byte)
 
   // ---- collision detection: geom poses, broadphase, narrowphase into the staging area; returns this lane's point count
   // (lane = candidate).  Needs the link poses and the model table in LDS, nothing else: in the DUAL instantiation the second
@@ -426,7 +437,56 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
   //  reference's scenes -- the contact counts agree with the oracle's, which has no such limit, in every parity test -- but with exact
   //  contacts such an env must go to the wave kernel (64 candidates) like one with too many points: its count is reported saturated)
   bool pair_ovf = false;
-  auto collide_detect = [&]() -> int {
+  // narrowphase, box-box: one candidate at a time on the whole row (box_box_row, mir_dev.h): the 15 separating axes on lanes 0..14, the
+  // incident-face vertices on lanes 0..3.  `bm`: the env's candidates to take, one bit per list position; the point count goes to the
+  // candidate's lane (the collision wave's own trips) or to S.col.count (the main wave's, three contacts per lane).
+  auto box_trips = [&](uint32_t bm, float* clipbuf, int& mycount, bool to_lds) {
+    while (__any(bm != 0u)) {
+      const bool isbox = bm != 0u;
+      const int k = isbox ? __ffs(bm) - 1 : 0;
+      bm &= bm - 1u;
+      const int pr = isbox ? S.col.cand[k] : 0;
+      const int g1 = pr & 255, g2 = pr >> 8 & 255;
+      if (isbox) {  // whole rows
+        const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
+        const BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
+        const BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
+        const int cnt = box_box_row(B1, B2, lane, tid, grp * G, S.col.stage[k], S.col.snorm[k], clipbuf);
+        if (to_lds) { if (lane == 0) S.col.count[k] = cnt; }
+        else if (lane == k) mycount = cnt;
+      }
+    }
+  };
+  // the set bits of m dealt out alternately: first, third, ... to a, second, fourth, ... to b
+  auto split_alternate = [](uint32_t m, uint32_t& a_, uint32_t& b_) {
+    a_ = 0u; b_ = 0u;
+    bool odd = false;
+    while (m) {
+      const uint32_t low = m & (0u - m);
+      if (odd) b_ |= low; else a_ |= low;
+      m ^= low;
+      odd = !odd;
+    }
+  };
+  // which candidates of the env go through the 15-axis routine (lane = list position; the same expression in both waves)
+  auto box_candidates = [&](int ncand) -> uint32_t {
+    const int prl = lane < ncand ? S.col.cand[lane] : 0;
+    const bool boxl = lane < ncand && (prl >> 16 & 255) != MIR_GEOM_PLANE && (!CONVEX || ((prl >> 16 & 255) == MIR_GEOM_BOX && (prl >> 24) == MIR_GEOM_BOX));
+    return (uint32_t)(__ballot(boxl) >> (grp * G)) & 0xffffu;
+  };
+  // (three contacts per lane) the main wave's share of the box - box trips: it has finished the smooth dynamics and would wait at barrier (2)
+  auto box_share = [&](int pass_no) {
+    if constexpr (CPL > 1) {
+      while (__hip_atomic_load(&S.bp_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < pass_no) __builtin_amdgcn_s_sleep(1);
+      uint32_t otherA, mineB;
+      split_alternate(box_candidates(S.ncand), otherA, mineB);
+      int unused = 0;
+      box_trips(mineB, S.clip2, unused, true);
+      WSYNC();
+      if (lane == 0) __hip_atomic_store(&S.bb_done, pass_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+  auto collide_detect = [&](int pass_no) -> int {
   if (lane == 0) { S.ncon = 0; S.ncand = 0; }
   for (int g = lane; g < ngeom; g += G) {
     int gb = T.g_info[g][0];
@@ -577,8 +637,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     // positions -- so a wave makes as many trips as its busiest env has such candidates, not one per position of their union)
     const int prl = lane < ncand ? S.col.cand[lane] : 0;
     const bool planel = lane < ncand && (prl >> 16 & 255) == MIR_GEOM_PLANE && (!CONVEX || (prl >> 24) == MIR_GEOM_BOX);
-    const bool boxl = lane < ncand && (prl >> 16 & 255) != MIR_GEOM_PLANE && (!CONVEX || ((prl >> 16 & 255) == MIR_GEOM_BOX && (prl >> 24) == MIR_GEOM_BOX));
-    uint32_t planem = (uint32_t)(__ballot(planel) >> (grp * G)) & 0xffffu, boxm = (uint32_t)(__ballot(boxl) >> (grp * G)) & 0xffffu;
+    uint32_t planem = (uint32_t)(__ballot(planel) >> (grp * G)) & 0xffffu, boxm = box_candidates(ncand);
     while (__any(planem != 0u)) {
       const bool isplane = planem != 0u;
       const int k = isplane ? __ffs(planem) - 1 : 0;
@@ -622,19 +681,16 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     // narrowphase, box-box: one candidate at a time on the whole row (box_box_row, mir_dev.h): the 15 separating axes
     // on lanes 0..14, the incident-face vertices on lanes 0..3
     HSTAMP(60);
-    while (__any(boxm != 0u)) {
-      const bool isbox = boxm != 0u;
-      const int k = isbox ? __ffs(boxm) - 1 : 0;
-      boxm &= boxm - 1u;
-      const int pr = isbox ? S.col.cand[k] : 0;
-      const int g1 = pr & 255, g2 = pr >> 8 & 255;
-      if (isbox) {  // whole rows
-        const M3 R1 = q2m(ld4v(S.col.gquat[g1])), R2 = q2m(ld4v(S.col.gquat[g2]));
-        const BoxG B1 = {ld3v(S.col.gpos[g1]), mcol(R1, 0), mcol(R1, 1), mcol(R1, 2), ld3v(T.g_size[g1])};
-        const BoxG B2 = {ld3v(S.col.gpos[g2]), mcol(R2, 0), mcol(R2, 1), mcol(R2, 2), ld3v(T.g_size[g2])};
-        const int cnt = box_box_row(B1, B2, lane, tid, grp * G, S.col.stage[k], S.col.snorm[k], S.col.clip);
-        if (lane == k) mycount = cnt;
-      }
+    if constexpr (BIGV) {
+      // (three contacts per lane: every other trip of an env is the main wave's -- box_share, below; its counts come back through LDS)
+      if (lane == 0) __hip_atomic_store(&S.bp_ready, pass_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      uint32_t mineA, otherB;
+      split_alternate(boxm, mineA, otherB);
+      box_trips(mineA, S.col.clip, mycount, false);
+      while (__hip_atomic_load(&S.bb_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < pass_no) __builtin_amdgcn_s_sleep(1);
+      if ((otherB >> lane) & 1u) mycount = S.col.count[lane];
+    } else {
+      box_trips(boxm, S.col.clip, mycount, false);
     }
     HSTAMP(61);
     if constexpr (CONVEX) {
@@ -1051,9 +1107,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
 #endif
     };
     helper_cinert(1);
-    const int cnt = collide_detect();
+    const int cnt = collide_detect(1);
     HSTAMP(42);
-    const int pts0 = contacts_build(cnt, PRE || ROT);  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
+    const int pts0 = contacts_build(cnt, PRE || ROT || BIGV);  // (three contacts per lane: the main wave shares the Jacobian build in every pass)  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
     if (BIGV) ovf_h = pts0 > defer_above;  // (beyond this instantiation's capacity too: nothing is stored for the env, the wave-per-env kernel takes it)
     HSTAMP(45);
     __syncthreads();  // (3) contact arrays and base Jacobians handed to the main wave
@@ -1079,13 +1135,13 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       group_fk<true>(S, lane, nb, hparents, hk, row4);
       __syncthreads();  // (6) link poses of the new state handed to the main wave
     }
-    if constexpr (BIGV) {
+    if constexpr (BIG2) {
       // the list instantiation goes on like the rotated launch: the closing FK above is the opening FK of the next step, whose
       // action-independent half follows (host side: only scenes with the split closing FK take this instantiation)
       HSTAMP(142);
       prof_mute = true;
       helper_cinert(2);
-      const int cnt2 = collide_detect();
+      const int cnt2 = collide_detect(2);
       contacts_build(cnt2, true);
       __syncthreads();  // (3) of the second pass
       pre_store();
@@ -1159,6 +1215,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
   if (lane == 0) {
     if (!ROT) { S.ncon = 0; S.ncand = 0; }  // (rotated launch: the collision wave is writing this step's contact count meanwhile)
     S.cin_ready = 0;
+    if constexpr (CPL > 1) { S.bp_ready = 0; S.bb_done = 0; }
   }
   WSYNC();
 
@@ -1172,7 +1229,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
   STAMP(48);
   if (DUAL && !ROT) __syncthreads();  // (1) link poses from the collision wave; model table, velocities and targets from this one
   // (ROT: the loop below runs twice -- pass 0 is the second half of this step, pass 1 the first half of the next one)
-  const int nsteps = (ROT || BIGV) ? 2 : (SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0)));
+  const int nsteps = (ROT || BIG2) ? 2 : (SINGLE ? 1 : (a.mode == 0 ? a.n_steps : (a.mode == 1 ? 1 : 0)));
   // (the action-independent half alone integrates nothing.  Of the scene-specialised instantiations the ROTATED launch stores poses too
   //  since round 5 -- the pointer test costs it nothing measurable, and the steps of the pixel modes keep the faster instantiation; the
   //  fused launch lost 2 % to the same code, so a fused launch that wants poses takes the generic-scene instantiation: launch() in mir_api.hip)
@@ -1234,10 +1291,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     // themselves (sync mode 3: no fence, no ticket, nothing waits).
     const bool term_now = valid && !ovf_env && above(S.xpos[ob][2], mdl_reward_z);
     if (VARIANT != 1 && a.term_host && !term_early) {
-      const unsigned long long tb = __ballot(term_now && lane == 0), db = __ballot(ovf_env && valid && lane == 0);
+      const unsigned long long tb = __ballot(term_now && lane == 0), db = __ballot(ovf_env && valid && lane == 0), ob = BIGV ? __ballot(over_env && valid && lane == 0) : 0ull;
       if (tid == 0) {
         const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24 |
-                              (uint32_t)(db & 1u) << 7 | (uint32_t)(db >> 16 & 1u) << 15 | (uint32_t)(db >> 32 & 1u) << 23 | (uint32_t)(db >> 48 & 1u) << 31;
+                              (uint32_t)(db & 1u) << 7 | (uint32_t)(db >> 16 & 1u) << 15 | (uint32_t)(db >> 32 & 1u) << 23 | (uint32_t)(db >> 48 & 1u) << 31 |
+                              (uint32_t)(ob & 1u) << 6 | (uint32_t)(ob >> 16 & 1u) << 14 | (uint32_t)(ob >> 32 & 1u) << 22 | (uint32_t)(ob >> 48 & 1u) << 30;
         __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + (size_t)blockIdx.x * a.term_wstride, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -1309,8 +1367,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     if (step > 0 && a.action && a.act_step) {
       if (isdof && d_uadr >= 0) S.target[lane] = a.action[(size_t)step * a.act_step + (size_t)env * a.nu + d_uadr];
     }
-    const bool post_now = POST || (ROT && step == 0), pre_now = PRE || ((ROT || BIGV) && step == 1);
-    if (BIGV && step == 1) prof_mute = true;
+    const bool post_now = POST || (ROT && step == 0), pre_now = PRE || ((ROT || BIG2) && step == 1);
+    if (BIG2 && step == 1) prof_mute = true;
     float qfrc_bias = 0.0f, qfs = 0.0f;
     if (!post_now) {
     // motion subspaces (lane = dof) and body inertias about the tree reference point (lane = body)
@@ -1483,6 +1541,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     }  // !post_now
     WSYNC();
     STAMP(3);
+    if (BIGV && !post_now) box_share(step + 1);
     STAMP(49);
     if (DUAL && !post_now) __syncthreads();  // (2) this wave is done with the dynamics scratch (M is in its own area, the rest in registers)
     // qacc_smooth = Mt^-1 qfrc_smooth: Gauss-Jordan on register rows
@@ -1521,7 +1580,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
         jac_build(2, 4);
         __syncthreads();  // (3) every Jacobian row of the coming step is in LDS: the collision wave stores them
 #ifdef MIR_PROFILE_SINGLE
-        if (BIGV && a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 0) a.prof[140] = __builtin_readcyclecounter();
+        if (BIG2 && a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 0) a.prof[140] = __builtin_readcyclecounter();
 #endif
         return 2;
       }
@@ -1549,7 +1608,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     // ======================= collision detection, contact arrays, contact Jacobians ==============
     // (DUAL: the collision wave does all of it, detection since the first barrier, the rest since the second)
     if (!DUAL && !POST) {
-      const int mc = collide_detect();
+      const int mc = collide_detect(1);
       contacts_build(mc, false);
     }
 
@@ -1571,6 +1630,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       }
     }
     WSYNC();
+    if (BIGV) {  // (three contacts per lane: every other pair of contacts of the Jacobian build, as in the action-independent half)
+      __syncthreads();  // (2b)
+      jac_build(2, 4);
+    }
     STAMP(50);
     if (DUAL && (!post_now || ROT)) __syncthreads();  // (3) contact arrays and base Jacobians are in LDS
     STAMP(52);
@@ -1620,6 +1683,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     // the Hessian is block diagonal by tree unless a contact joins the arm and the cube somewhere in this wave
     const int cpl = S.coupled;  // bit 0: some contact joins the trees; bits 1 .. 16: contact c belongs to the second tree; 20 .. 27: see contacts_build
     if (DEFER && (!ROT || step == 0)) ovf_env = ((cpl >> 20) & 255) > defer_above;  // (exact contacts: more candidate points than lanes)
+    if (BIGV) over_env = a.over_cap > 0 && ((cpl >> 20) & 255) > a.over_cap;
     const int hsplit = __any((cpl & 1) != 0) ? 0 : mdl_split;
     // Where no contact joins the two trees the problem SEPARATES -- f = f_A(a_A) + f_B(a_B), block-diagonal Hessian.  The line search
     // stays one per env, but a step is ACCEPTED tree by tree (below), so that each tree's own cost decreases monotonically: what the
@@ -2075,10 +2139,11 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       // over PCIe is over when the launch ends
       WSYNC();
       const bool tn = valid && !ovf_env && above(S.qpos[mdl_obj_qadr + 2], mdl_reward_z);
-      const unsigned long long tb = __ballot(tn && lane == 0), db = __ballot(ovf_env && valid && lane == 0);
+      const unsigned long long tb = __ballot(tn && lane == 0), db = __ballot(ovf_env && valid && lane == 0), ob = BIGV ? __ballot(over_env && valid && lane == 0) : 0ull;
       if (tid == 0) {
         const uint32_t bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24 |
-                              (uint32_t)(db & 1u) << 7 | (uint32_t)(db >> 16 & 1u) << 15 | (uint32_t)(db >> 32 & 1u) << 23 | (uint32_t)(db >> 48 & 1u) << 31;
+                              (uint32_t)(db & 1u) << 7 | (uint32_t)(db >> 16 & 1u) << 15 | (uint32_t)(db >> 32 & 1u) << 23 | (uint32_t)(db >> 48 & 1u) << 31 |
+                              (uint32_t)(ob & 1u) << 6 | (uint32_t)(ob >> 16 & 1u) << 14 | (uint32_t)(ob >> 32 & 1u) << 22 | (uint32_t)(ob >> 48 & 1u) << 30;
         // (bytes that left from inside the solver loop are checked against the integrated state: a difference would mean the bound
         //  was violated -- it is counted, mir_debug_early_mask_stats, and the right bytes are stored over the wrong ones)
         if (!term_sent || bits != term_bits)
@@ -2173,10 +2238,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       WSYNC();
       if (__any(done)) group_fk(S, lane, nb, parents, bk, row4);
     }
-    if ((ROT || BIGV) && step == 0) emit_outputs();
+    if ((ROT || BIG2) && step == 0) emit_outputs();
     return 0;
   };  // step_body
-  if constexpr (ROT || BIGV) {
+  if constexpr (ROT || BIG2) {
     if (step_body(std::integral_constant<int, 0>{}) == 0) step_body(std::integral_constant<int, 1>{});
   } else if constexpr (SINGLE) {
     if (step_body(std::integral_constant<int, 0>{}) == 2) return;
@@ -2229,6 +2294,7 @@ static void launch_feat(const StepArgs& a, int blocks, int single, int plain_loo
   if (a.phase == 1) hipLaunchKernelGGL((mir_step_kernel<3, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 3) hipLaunchKernelGGL((mir_step_kernel<5, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 4) hipLaunchKernelGGL((mir_step_kernel<6, FEAT, 3>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 5) hipLaunchKernelGGL((mir_step_kernel<7, FEAT, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
   else if constexpr ((FEAT & 4) == 0) hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
@@ -2237,7 +2303,7 @@ extern "C" __attribute__((visibility("hidden"))) int mir_launch_step_convex(cons
   StepArgs a = *args;
   const int blocks = (a.B + EPB - 1) / EPB;
   // the headline scene's instantiation (features bit 2: mir_create found SpecPick::matches); the everything-variant stays generic
-  if ((a.features & 4) && (a.phase == 1 || a.phase == 3 || a.phase == 4 || single || plain_loop)) launch_feat<5>(a, blocks, single, plain_loop, stream);
+  if ((a.features & 4) && (a.phase == 1 || a.phase == 3 || a.phase == 4 || a.phase == 5 || single || plain_loop)) launch_feat<5>(a, blocks, single, plain_loop, stream);
   else if (a.features & 2) launch_feat<3>(a, blocks, single, plain_loop, stream);  // sweep-and-prune scenes carry the convex code too
   else launch_feat<1>(a, blocks, single, plain_loop, stream);
   return (int)hipGetLastError();
@@ -2265,6 +2331,7 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   if (a.phase == 1) hipLaunchKernelGGL((mir_step_kernel<3, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 3) hipLaunchKernelGGL((mir_step_kernel<5, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 4) hipLaunchKernelGGL((mir_step_kernel<6, 0, 3>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 5) hipLaunchKernelGGL((mir_step_kernel<7, 0, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, 0>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, 0>), dim3(blocks), dim3(64), 0, stream, a);

@@ -37,15 +37,20 @@ ENV_DIM = 11
 class FrankaCubePickBatch:
     def __init__(self, enable_pixels, observation_height, observation_width, num_envs, env_spacing,
                  camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None, link_shape: str = "capsule",
-                 contact_capacity: int = 16, exact_contacts: bool = False):
+                 contact_capacity: int = 16, exact_contacts: bool = True):
         # link_shape: collision stand-ins of links 1-7, "box" or "capsule" (models._add_franka); not a reference kwarg
         # contact_capacity: contact points kept per env (not a reference kwarg; Genesis keeps 100+ pairs).  16 = the 16-lane kernel
         # (manifolds thinned beyond that: 29 % of the env-steps of the reference's expert, same success rate -- tests/test_ref_expert.py);
         # 17 .. 48 = the same scene on the wave-per-env kernel, never thinned by that policy, several times slower
-        # exact_contacts (not a reference kwarg): keep the 16-lane kernel for the envs it serves exactly and hand the envs whose
-        # narrowphase finds more than 16 contact points -- only those, step by step -- to the wave-per-env kernel (48 points, no
-        # thinning): Genesis's own behaviour (every contact kept) at the 16-lane kernel's speed wherever no env overflows.
-        # reset() / step() / env.step() only; the device-side episode loop (rollout_autoreset) is refused by the library.
+        # exact_contacts (not a reference kwarg; DEFAULT ON since round 6): Genesis keeps every contact point of its candidate pairs
+        # (RigidOptions at /root/reference/gym_genesis/tasks/franka/cube_pick.py:46).  The 16-lane kernel serves the envs with at most 16
+        # points exactly; the envs whose narrowphase finds more -- only those, step by step -- are stepped with 48 points, never thinned,
+        # by its three-contacts-per-lane instantiation.  A workload that never exceeds 16 points (the headline's random
+        # targets) computes the same bits at the same speed with the switch on or off.  exact_contacts=False is the SPEED KNOB: manifolds
+        # thinned to 16 points (oracle/orc_rigid.c: thin_manifolds), e.g. 48 instead of ~100 us per env.step on the reference's expert
+        # at 4096 envs, same success rate (tests/test_ref_expert.py) but other trajectories from the first thinned step on.
+        # reset() / step() / env.step() only; the device-side episode loops (rollout_autoreset, step_packed) have no host in them to
+        # close a step on and are refused by the library while the switch is on (set_exact_contacts(False) first).
         self.contact_capacity = int(contact_capacity)
         self.exact_contacts = bool(exact_contacts)
         self.enable_pixels = enable_pixels
@@ -165,6 +170,15 @@ class FrankaCubePickBatch:
         Spawn positions come from the task RandomState as in reset() (x block then y block per draw),
         `pool_len` draws ahead; env e's k-th re-spawn uses draw k % pool_len."""
         B, dev = self.num_envs, self.device
+        if getattr(self._mir, "exact_contacts", False):
+            # (exact contacts close every step on the host -- that is where the envs with more than 16 contact points are handed on;
+            #  this loop has no host in it: it runs with the manifolds thinned to the 16-lane kernel's 16 points)
+            import warnings
+
+            warnings.warn("enable_autoreset(): the device-resident episode loop runs with exact_contacts switched off (contact manifolds "
+                          "thinned to 16 points per env); GenesisEnv(..., exact_contacts=False) says so up front", stacklevel=2)
+            self._mir.set_exact_contacts(False)
+            self.exact_contacts = False
         pool = np.stack([self.sample_spawn()[self.shard_lo:self.shard_hi] for _ in range(pool_len)])
         self._spawn_pool = torch.from_numpy(pool).to(dev).contiguous()
         self._cursor = torch.zeros((B,), dtype=torch.int32, device=dev)

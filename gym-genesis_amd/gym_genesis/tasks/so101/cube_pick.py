@@ -37,7 +37,7 @@ AGENT_OBS, ENV_OBS = 8, 11            # what get_obs() actually returns
 
 class CubePick:
     def __init__(self, enable_pixels, observation_height, observation_width, num_envs, env_spacing,
-                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None, exact_contacts: bool = False):
+                 camera_capture_mode, strip_environment_state, shard: Optional[Tuple[int, int]] = None, exact_contacts: bool = True):
         # exact_contacts (not a reference kwarg): see tasks/franka/cube_pick.py
         self.exact_contacts = bool(exact_contacts)
         self.enable_pixels = enable_pixels

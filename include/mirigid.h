@@ -250,7 +250,7 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  * mir_step_begin / mir_step_go / mir_reset, which wait for its bytes and drop them.  mir_step_end is otherwise the only entry point
  * of the library that waits for the device.
  * How the wait is done (mir_get_sync_mode; environment variable MIR_SYNC_MODE overrides at mir_create):
- *   3  (default) every terminated byte carries a 6-bit tag (1..63, a counter only mir_step_begin advances) that changes from
+ *   3  (default) every terminated byte carries a 5-bit tag (1..31 in bits 1 .. 5, a counter only mir_step_begin advances; bits 6 and 7: exact contacts) that changes from
  *      launch to launch; the host spins until all B bytes show the tag of this launch -- no fence, no flag, nothing in the kernel
  *      waits for the PCIe acknowledgement
  *   2  every wave waits for its host store, the kernel's last workgroup then writes a sequence word into pinned host memory
@@ -309,14 +309,18 @@ int mir_step_go(MirHandle h, const float* action, void* stream);
  * step), and mir_step_packed / mir_rollout / mir_rollout_autoreset return MIR_E_INVALID (their steps are never closed on the host).
  * MIR_E_INVALID for scenes of the wave kernel (nothing to do) and for sync modes other than 3.
  * mir_get_exact_stats: out4 = {steps closed by mir_step_end, steps that had deferred envs, deferred env-steps, most deferred envs in one
- * step} since the last reset of the counters (reset != 0 clears them).  mir_get_exact_route: out2 = {deferred env-steps handed to the
- * list instantiation, env-steps stepped by the wave-per-env kernel} over the same period.
+ * step} since the last reset of the counters (reset != 0 clears them).  mir_get_exact_route: out3 = {deferred env-steps handed to the
+ * list instantiation, env-steps stepped by the wave-per-env kernel, HEAVY steps} over the same period.  A heavy step: while at least
+ * 1 / 16 of the envs are above 16 points (and until fewer than 1 / 32 are; MIR_EXACT_HEAVY="enter,leave" in envs, enter <= 0: never)
+ * the whole batch is stepped by ONE launch of the three-contacts-per-lane instantiation instead of a launch that defers most envs and
+ * a list launch behind it (an env with at most 16 points is computed there bit for bit as by the one-contact-per-lane kernel); the
+ * statistics count its envs above 16 points as deferred.
  * on = 2 (tests): every env of every step is deferred, i.e. the whole batch is stepped by the launches that otherwise serve the
  * deferred envs only -- the twin the parity tests compare a deferred env with, bit for bit. */
 int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on);
 int mir_get_exact_contacts(MirHandle h);
 int mir_get_exact_stats(MirHandle h, uint64_t* out4, int32_t reset);
-int mir_get_exact_route(MirHandle h, uint64_t* out2);
+int mir_get_exact_route(MirHandle h, uint64_t* out3);
 
 /* Same step, but every output of an env lands in ONE packed float32 row
  * rows[e*row_stride + ...] = [agent_pos (agent_dim) | env_state (env_dim) | reward | terminated(0/1)]

@@ -30,7 +30,7 @@ def test_expert_collection(tmp_path, monkeypatch, script, env_dim, min_frac):
     assert kept >= int(min_frac * 32), kept
     d = np.load(out)
     n = d["action"].shape[0]
-    assert n == kept * (200 if script.startswith("pick") else 470)
+    assert n == kept * (200 if script.startswith("pick") else 391)   # (the reference's stack expert: 3 x 77 + 2 x 80 joint targets)
     assert d["observation.state"].shape == (n, 9) and d["observation.environment_state"].shape == (n, env_dim)
     assert d["episode_index"].max() == kept - 1 and np.isfinite(d["observation.state"]).all()
 
