@@ -40,6 +40,7 @@ struct IkArgs {
   int arm_qadr[MIR_MAX_DOF]; // qpos address of scalar joint k in the scene row
   float* qpos_out;           // (B,n_arm)
   float* err_out;            // (B,2) or null
+  int32_t* iters_out;        // (B) or null: iterations the env took (debug: mir_debug_ik_iters)
   int B, max_iters, respect_limits;
   float inv_pos_tol, inv_rot_tol;
   float damping2, pos_tol, rot_tol, max_step;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
   const bool userot = a.target_quat != nullptr;
   const Q4 tq = userot ? qnormalize(ld4(a.target_quat + (size_t)env * 4)) : Q4{1, 0, 0, 0};
   bool done = false;
-  int stall = 0;
+  int stall = 0, my_iters = 0;
   float epn = 0.0f, ern = 0.0f, mprev = 0.0f;
   for (int it = 0; it <= a.max_iters; it++) {
     // ---- local transform of my chain element (identity off the chain) ...
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
     for (int r = 0; r < 6; r++) dq += J[r] * y[r];
     const float big = gmaxf(fabsf(dq));
     const float sc = big > a.max_step ? a.max_step / big : 1.0f;
+    if (!done) my_iters = it + 1;
     if (moving && !done) {
       q += sc * dq;
       if (lim) q = fminf(fmaxf(q, lo), hi);
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
     WSYNC();
   }
   if (valid && moving) a.qpos_out[(size_t)env * a.n_arm + qc] = q;
+  if (valid && a.iters_out && lane == 0) a.iters_out[env] = my_iters;
   if (valid && a.err_out && lane == 0) {
     a.err_out[(size_t)env * 2] = epn;
     a.err_out[(size_t)env * 2 + 1] = ern;
@@ -264,6 +267,7 @@ extern "C" int mir_inverse_kinematics(MirHandle h, int32_t link_body, const floa
   }
   a.target_pos = target_pos; a.target_quat = target_quat; a.init_qpos = init_qpos; a.scene_qpos = h->qpos;
   a.qst = h->pt.qst; a.n_arm = narm; a.qpos_out = qpos_out; a.err_out = err_out; a.B = h->B;
+  a.iters_out = h->dbg_ik_iters;
   a.max_iters = o.max_iters; a.respect_limits = o.respect_joint_limit;
   a.damping2 = (float)(o.damping * o.damping); a.pos_tol = (float)o.pos_tol; a.rot_tol = (float)o.rot_tol; a.inv_pos_tol = (float)(1.0 / o.pos_tol); a.inv_rot_tol = (float)(1.0 / o.rot_tol); a.max_step = (float)o.max_step;
   int prev = -1;
@@ -273,6 +277,14 @@ extern "C" int mir_inverse_kinematics(MirHandle h, int32_t link_body, const floa
   hipError_t e = hipGetLastError();
   if (prev != h->device && prev >= 0) (void)hipSetDevice(prev);
   if (e != hipSuccess) return mir_set_error(MIR_E_HIP, hipGetErrorString(e));
+  return MIR_OK;
+}
+
+/* debug aid (tools/probes/ik_iters.py): every following mir_inverse_kinematics call also writes the iterations each env took into
+ * iters (B x i32, device; NULL switches it off) */
+extern "C" int mir_debug_ik_iters(MirHandle h, int32_t* iters) {
+  if (!h) return mir_set_error(MIR_E_INVALID, "null MirHandle");
+  h->dbg_ik_iters = iters;
   return MIR_OK;
 }
 

@@ -56,6 +56,7 @@ struct MirScene {
   void* prep[4];            // output pointers registered by mir_step_prepare for the next mir_step_go
   int prepared;
   unsigned long long* dbg_prof = nullptr;  // (mir_debug_profile_next_step: shader-clock stamps of the next mir_step_begin launch)
+  int32_t* dbg_ik_iters = nullptr;  // (mir_debug_ik_iters)
   unsigned long long* dbg_prof_list = nullptr;  // (mir_debug_profile_next_list_step: of the next launch of the list instantiation, exact contacts)
   // split step of the GenesisEnv.step path (16-lane kernel; MIR_SPLIT_STEP=0 switches it off): mir_step_begin launches the
   // action-independent half of the NEXT step right behind the current one; `pre_valid` says that `pre` holds that half for the

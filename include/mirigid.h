@@ -488,6 +488,8 @@ int mir_debug_profile_next_step(MirHandle h, unsigned long long* prof);
 /* ... and the next launch of the LIST INSTANTIATION of exact contacts (mir_step_end of a step with deferred envs): prof 160 x u64; the
  * first pass's stamps as above, slots 140 / 141 / 142 = end of the second pass on the main / the collision wave, its start */
 int mir_debug_profile_next_list_step(MirHandle h, unsigned long long* prof);
+/* every following mir_inverse_kinematics call also writes the iterations each env took into iters (B x i32, device; NULL: off) */
+int mir_debug_ik_iters(MirHandle h, int32_t* iters);
 int mir_debug_null_roundtrip(MirHandle h, int32_t iters, void* stream, double* out_us);
 /* n back-to-back launches of the rotated step kernel (split mode 1), cycling through n_actions (B, nu) action blocks, without
  * observation outputs -- or, with outputs = {agent_pos, env_state, reward, terminated} (device pointers, shapes as in
