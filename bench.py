@@ -1113,6 +1113,8 @@ def worker(args) -> int:
         """k iterations of the README loop through GenesisEnv.step (README.md:32-43)."""
         t, step, n, Sc = state["t"], env.step, N_ACT, Sx[0]
         for _ in range(k):
+            if kill_at is not None and t >= kill_at:
+                os._exit(17)   # (tests/test_gpu_bench.py: a rank that dies in the middle of a timed region -- MIR_BENCH_KILL_RANK="rank:step")
             obs, reward, terminated, truncated, info = step(act_list[t % n])
             if gather_on[0]:
                 row = obs["agent_pos"].storage_offset() // flat   # the ring row this step's kernel wrote
@@ -1126,6 +1128,12 @@ def worker(args) -> int:
                 env.reset()
                 state["resets"] += 1
         state["t"] = t
+
+    kill_at = None
+    if os.environ.get("MIR_BENCH_KILL_RANK"):
+        kr, _, ks = os.environ["MIR_BENCH_KILL_RANK"].partition(":")
+        if int(kr) == rank:
+            kill_at = int(ks or 0)
 
     def raw_loop(k: int):
         """k bare fused launches into persistent buffers (no host hand-over, no reset: every launch in the bracket is one
@@ -1243,6 +1251,7 @@ def worker(args) -> int:
                                       (f"{args.dist_backend} all_gather of [agent_pos|environment_state|reward] of {S} steps per collective, "
                                        "overlapped with the following steps" + (f" (copy path not used: {gather_note})" if gather_note else ""))),
                        "gather_path": None if not gather else ("copy" if copy_gather is not None else "rccl"),
+                       "gather_note": (gather_note[:110] or None) if gather else None,   # (why the copy path was not taken, when it was asked for)
                        "output_ring": (f"step outputs are rows of a reusable ring of {RING_CHUNKS * S} steps (the gather's send buffer): a step's "
                                        "tensors are overwritten that many steps later; fresh tensors per step without a gather") if gather else
                                       (f"ring of {args.output_ring} steps (--output-ring)" if args.output_ring > 0 else "none: fresh tensors every step"),

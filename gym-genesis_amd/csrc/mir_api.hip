@@ -1250,6 +1250,12 @@ extern "C" int mir_debug_poison_lds(int device_id, void* stream) {
 }
 
 int mir_p2p_enable(int32_t device, int32_t peer) {
+  // (dry-run switch of the multi-GPU tests: MIR_P2P_FORCE_FAIL = "all", or the RANK -- torch.distributed.run's variable -- whose calls
+  //  are to fail; the caller, sharding.CopyPathGather, then agrees with the other ranks on the collective instead)
+  if (const char* f = getenv("MIR_P2P_FORCE_FAIL")) {
+    const char* r = getenv("RANK");
+    if (!strcmp(f, "all") || (r && !strcmp(f, r))) return set_err(MIR_E_HIP, "mir_p2p_enable: forced to fail (MIR_P2P_FORCE_FAIL)");
+  }
   if (device == peer) return MIR_OK;
   DeviceGuard guard(device);
   int can = 0;

@@ -79,9 +79,13 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
   const Q4 tq = userot ? qnormalize(ld4(a.target_quat + (size_t)env * 4)) : Q4{1, 0, 0, 0};
   bool done = false;
   int stall = 0, my_iters = 0;
-  float epn = 0.0f, ern = 0.0f, mprev = 0.0f;
+  // the ACCEPTED iterate (Levenberg - Marquardt acceptance, include/mirigid.h): this lane's joint angle, Jacobian column; the env's
+  // task-space error and scaled error (identical in all of its lanes: they are computed from the same LDS reads)
+  float q_acc = q, lam2 = a.damping2, m_acc = 0.0f, epn = 0.0f, ern = 0.0f;
+  const float lam2_min = a.damping2 * (1.0f / 256.0f), lam2_max = a.damping2 * 64.0f;
+  float J[6] = {0, 0, 0, 0, 0, 0}, e[6] = {0, 0, 0, 0, 0, 0};
   for (int it = 0; it <= a.max_iters; it++) {
-    // ---- local transform of my chain element (identity off the chain) ...
+    // ---- local transform of my chain element (identity off the chain) at the CANDIDATE q ...
     V3 P = v3(0, 0, 0);
     Q4 Qx = Q4{1, 0, 0, 0};
     if (onchain) {
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
       }
     }
     WSYNC();
-    // ---- task-space error (every lane, redundantly)
+    // ---- task-space error of the candidate (every lane, redundantly)
     const V3 pe = ld3v(S.xpos[n - 1]);
     const Q4 qe = ld4v(S.xquat[n - 1]);
     const V3 ep = tp - pe;
@@ -131,41 +135,48 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
       const float k = sn > 1e-9f ? ang / sn : 2.0f;
       er = v3(k * d.x, k * d.y, k * d.z);
     }
-    epn = sqrtf(dot(ep, ep));
-    ern = sqrtf(dot(er, er));
-    if (!done && epn < a.pos_tol && ern < a.rot_tol) done = true;
-    if (it == a.max_iters) break;
-    // stagnation (a target beyond the joint limits or the reach): the scaled error did not drop by 1 % in three consecutive
-    // iterations (mirigid.h; the oracle applies the same rule).  Without it the few unreachable targets of a batch ran all
-    // max_iters iterations and set the time of the whole launch.
+    const float epn_c = sqrtf(dot(ep, ep)), ern_c = sqrtf(dot(er, er));
+    const float metric = epn_c * a.inv_pos_tol + ern_c * a.inv_rot_tol;
     if (!done) {
-      const float metric = epn * a.inv_pos_tol + ern * a.inv_rot_tol;
-      stall = (it > 0 && metric > 0.99f * mprev) ? stall + 1 : 0;
-      mprev = metric;
-      if (stall >= 3) done = true;
+      if (it == 0 || metric < m_acc) {
+        // accepted: the damping relaxes; stagnation = an accepted step that gained less than 1 % (a target beyond the joint limits
+        // or the reach: without the rule the few unreachable targets of a batch set the time of the whole launch)
+        if (it > 0) {
+          stall = metric > 0.99f * m_acc ? stall + 1 : 0;
+          lam2 = fmaxf(lam2 * 0.25f, lam2_min);
+        }
+        m_acc = metric; epn = epn_c; ern = ern_c;
+        e[0] = ep.x; e[1] = ep.y; e[2] = ep.z; e[3] = er.x; e[4] = er.y; e[5] = er.z;
+        q_acc = q;
+        // my Jacobian column at the accepted iterate (joint frame = my world pose)
+        V3 jv = v3(0, 0, 0), jw = v3(0, 0, 0);
+        if (moving) {
+          const V3 axw = qrot(ld4v(S.xquat[lane]), baxis);
+          if (jt == MIR_JNT_REVOLUTE) { jw = axw; jv = cross(axw, pe - ld3v(S.xpos[lane])); }
+          else jv = axw;
+        }
+        J[0] = jv.x; J[1] = jv.y; J[2] = jv.z; J[3] = userot ? jw.x : 0.0f; J[4] = userot ? jw.y : 0.0f; J[5] = userot ? jw.z : 0.0f;
+      } else {
+        // rejected (the scaled error did not fall): back to the accepted iterate with eight times the damping; a stalled iteration
+        stall++;
+        lam2 = fminf(lam2 * 8.0f, lam2_max);
+      }
+      if ((epn < a.pos_tol && ern < a.rot_tol) || stall >= 3) done = true;
     }
+    if (it == a.max_iters) break;
     if (!__any(!done)) break;
-    // ---- my Jacobian column (joint frame = my world pose)
-    V3 jv = v3(0, 0, 0), jw = v3(0, 0, 0);
-    if (moving) {
-      const V3 axw = qrot(ld4v(S.xquat[lane]), baxis);
-      if (jt == MIR_JNT_REVOLUTE) { jw = axw; jv = cross(axw, pe - ld3v(S.xpos[lane])); }
-      else jv = axw;
-    }
-    const float J[6] = {jv.x, jv.y, jv.z, userot ? jw.x : 0.0f, userot ? jw.y : 0.0f, userot ? jw.z : 0.0f};
-    // ---- A = J J^T + lambda^2 I in every lane
+    // ---- A = J J^T + lambda^2 I in every lane (J, e: the accepted iterate's)
     float A[6][6];
 #pragma unroll
     for (int r = 0; r < 6; r++)
 #pragma unroll
       for (int c = 0; c <= r; c++) {
-        const float v = gsum(J[r] * J[c]) + (r == c ? a.damping2 : 0.0f);
+        const float v = gsum(J[r] * J[c]) + (r == c ? lam2 : 0.0f);
         A[r][c] = v;
         A[c][r] = v;
       }
     // ---- y = A^-1 e (Cholesky, SPD by the damping)
-    const float e[6] = {ep.x, ep.y, ep.z, er.x, er.y, er.z};
-    float L[6][6], y[6], il[6];  // il = 1 / L[c][c]: one reciprocal (+ a Newton step) per column instead of a division per use
+    float L[6][6], y[6], il[6];  // il = 1 / L[c][c]: one reciprocal per column instead of a division per use
 #pragma unroll
     for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -202,12 +213,14 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
     const float big = gmaxf(fabsf(dq));
     const float sc = big > a.max_step ? a.max_step / big : 1.0f;
     if (!done) my_iters = it + 1;
+    q = q_acc;
     if (moving && !done) {
-      q += sc * dq;
+      q = q_acc + sc * dq;
       if (lim) q = fminf(fmaxf(q, lo), hi);
     }
     WSYNC();
   }
+  q = q_acc;
   if (valid && moving) a.qpos_out[(size_t)env * a.n_arm + qc] = q;
   if (valid && a.iters_out && lane == 0) a.iters_out[env] = my_iters;
   if (valid && a.err_out && lane == 0) {

@@ -176,8 +176,8 @@ class CopyPathGather:
             except (ImportError, OSError, AttributeError):
                 lib = None
             if lib is not None:
-                for t in self.peer_recv:
-                    if t.device.index != device.index and lib.mir_p2p_enable(device.index, t.device.index) != 0:
+                for t in self.peer_recv:   # (a peer on this rank's own device -- ranks sharing a GPU in the plumbing tests -- needs nothing: the call says so)
+                    if lib.mir_p2p_enable(device.index, t.device.index) != 0:
                         raise RuntimeError(lib.mir_last_error().decode())
                 vp = lambda xs: (C.c_void_p * self.world)(*xs)  # noqa: E731
                 # destination addresses of this rank's block / word in every rank's buffers, per slot; of its ack word

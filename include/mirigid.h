@@ -438,11 +438,16 @@ int mir_render_cams(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* 
  *      examples/franka/pick_cube_state.py:46-51, examples/franka/stack_cube_state.py:78-83
  * Genesis's IK lives in the external package; this is a damped-least-squares solver on the scene's own kinematics,
  * defined here and restated independently by the oracle (oracle/orc_rigid.c: orc_ik):
- *   repeat up to max_iters:  e = [p* - p ; rotvec(q* q^-1)]   (rotation part dropped when target_quat == NULL);
- *     stop the env when |e_pos| < pos_tol and |e_rot| < rot_tol, or when |e_pos|/pos_tol + |e_rot|/rot_tol has not dropped by
- *     1 % in three consecutive iterations (a target beyond the joint limits or the reach);  J = 6 x n geometric Jacobian of the chain;
- *     dq = J^T (J J^T + damping^2 I)^-1 e, scaled down so that max |dq_i| <= max_step;  q += dq;
- *     q clamped to the joint ranges (respect_joint_limit).
+ *   q_acc = the seed, lambda^2 = damping^2;  repeat up to max_iters, with q the candidate (the seed at first):
+ *     e = [p* - p(q) ; rotvec(q* q(q)^-1)]   (rotation part dropped when target_quat == NULL), m = |e_pos|/pos_tol + |e_rot|/rot_tol;
+ *     the candidate is ACCEPTED when m fell below the accepted iterate's (always at first): q_acc = q, its e and its 6 x n geometric
+ *     Jacobian J of the chain are kept, lambda^2 <- max(lambda^2 / 4, damping^2 / 256), and the step is STALLED when m fell by less than
+ *     1 %; otherwise it is REJECTED: lambda^2 <- min(8 lambda^2, 64 damping^2), also stalled (Levenberg - Marquardt, round 6: fixed damping
+ *     crept for 32 iterations towards targets whose Jacobian has a small singular value, and a handful of such envs set the time of
+ *     every launch).  Stop the env when |e_pos| < pos_tol and |e_rot| < rot_tol at the accepted iterate, or after three stalled
+ *     iterations in a row (a target beyond the joint limits or the reach);
+ *     dq = J^T (J J^T + lambda^2 I)^-1 e of the accepted iterate, scaled down so that max |dq_i| <= max_step;  q = q_acc + dq,
+ *     clamped to the joint ranges (respect_joint_limit).  The result is q_acc.
  * Only the scalar joints on the chain world -> link move; every other entry of the result is the seed. */
 typedef struct MirIkOptions {
   int32_t max_iters;           /* default 32 */

@@ -169,8 +169,9 @@ class Oracle:
         q = np.ascontiguousarray(init_q, dtype=np.float64).reshape(self.B, -1).copy()
         err = np.zeros((self.B, 2))
         self.lib.orc_ik.restype = C.c_int
+        self.ik_iters = np.zeros(self.B, np.int32)  # (iterations each env took in the last call)
         for e in range(self.B):
-            self.lib.orc_ik(self.model, C.c_int(link), tp[e].ctypes.data_as(C.c_void_p), tq[e].ctypes.data_as(C.c_void_p) if tq is not None else None,
+            self.ik_iters[e] = self.lib.orc_ik(self.model, C.c_int(link), tp[e].ctypes.data_as(C.c_void_p), tq[e].ctypes.data_as(C.c_void_p) if tq is not None else None,
                             q[e].ctypes.data_as(C.c_void_p), C.c_int(max_iters), C.c_double(damping), C.c_double(pos_tol), C.c_double(rot_tol),
                             C.c_double(max_step), C.c_int(1 if respect_limits else 0), err[e].ctypes.data_as(C.c_void_p))
         return q, err

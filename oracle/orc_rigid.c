@@ -1547,6 +1547,8 @@ void orc_get_obs(const OrcModel* m, const OrcData* d, double* agent_pos, double*
  * q_io (n_arm): scalar joints in body order, seed in / solution out.  err2: |e_pos|, |e_rot| at exit. */
 int orc_ik(const OrcModel* m, int link, const double* target_pos, const double* target_quat /* nullable */, double* q_io,
            int max_iters, double damping, double pos_tol, double rot_tol, double max_step, int respect_limits, double* err2) {
+  /* include/mirigid.h states the iteration (damped least squares with the Levenberg - Marquardt acceptance rule of round 6);
+   * mir_ik.hip applies the same.  Returns the iterations taken (>= 0), -1 when out of memory. */
   OrcData* d = (OrcData*)malloc(sizeof(OrcData));
   if (!d) return -1;
   orc_init_data(m, d);
@@ -1561,9 +1563,14 @@ int orc_ik(const OrcModel* m, int link, const double* target_pos, const double* 
     double nn = sqrt(target_quat[0] * target_quat[0] + target_quat[1] * target_quat[1] + target_quat[2] * target_quat[2] + target_quat[3] * target_quat[3]);
     for (int k = 0; k < 4; k++) tq[k] = target_quat[k] / nn;
   }
-  double epn = 0, ern = 0, mprev = 0;
-  int stall = 0;
+  /* the ACCEPTED iterate: joint angles, its task-space error, its Jacobian, its scaled error */
+  double q_acc[ORC_NB], e_acc[6] = {0}, J[6][ORC_NB], m_acc = 0, epn = 0, ern = 0;
+  double lam2 = damping * damping;
+  const double lam2_min = lam2 / 256.0, lam2_max = lam2 * 64.0;
+  int stall = 0, iters = 0;
+  for (int j = 0; j < nj; j++) q_acc[j] = q_io[j];
   for (int it = 0; it <= max_iters; it++) {
+    /* the candidate q_io: forward kinematics, task-space error */
     for (int j = 0; j < nj; j++) d->qpos[m->qadr[jb[j]]] = (real)q_io[j];
     orc_fk(m, d);
     double ep[3], er[3] = {0, 0, 0};
@@ -1578,41 +1585,47 @@ int orc_ik(const OrcModel* m, int link, const double* target_pos, const double* 
       double kk = sn > 1e-9 ? 2.0 * atan2(sn, dq[0]) / sn : 2.0;
       for (int k = 0; k < 3; k++) er[k] = kk * dq[1 + k];
     }
-    epn = sqrt(ep[0] * ep[0] + ep[1] * ep[1] + ep[2] * ep[2]);
-    ern = sqrt(er[0] * er[0] + er[1] * er[1] + er[2] * er[2]);
-    if ((epn < pos_tol && ern < rot_tol) || it == max_iters) break;
-    /* stagnation (a target beyond the joint limits or the reach): the scaled error did not drop by 1 % in three
-     * consecutive iterations -- mirigid.h states the rule, mir_ik.hip applies the same */
-    {
-      double metric = epn / pos_tol + ern / rot_tol;
-      stall = (it > 0 && metric > 0.99 * mprev) ? stall + 1 : 0;
-      mprev = metric;
-      if (stall >= 3) break;
-    }
-    /* Jacobian columns of the chain joints */
-    double J[6][ORC_NB];
-    for (int j = 0; j < nj; j++) {
-      int b = jb[j];
-      for (int r = 0; r < 6; r++) J[r][j] = 0;
-      if (!onchain[b]) continue;
-      double ax[3];
-      for (int r = 0; r < 3; r++) ax[r] = (double)d->xmat[b][3 * r] * (double)m->axis[b][0] + (double)d->xmat[b][3 * r + 1] * (double)m->axis[b][1] + (double)d->xmat[b][3 * r + 2] * (double)m->axis[b][2];
-      if (m->jtype[b] == MIR_JNT_REVOLUTE) {
-        double rr[3] = {(double)d->xpos[link][0] - (double)d->xpos[b][0], (double)d->xpos[link][1] - (double)d->xpos[b][1], (double)d->xpos[link][2] - (double)d->xpos[b][2]};
-        J[0][j] = ax[1] * rr[2] - ax[2] * rr[1]; J[1][j] = ax[2] * rr[0] - ax[0] * rr[2]; J[2][j] = ax[0] * rr[1] - ax[1] * rr[0];
-        if (target_quat) { J[3][j] = ax[0]; J[4][j] = ax[1]; J[5][j] = ax[2]; }
-      } else {
-        J[0][j] = ax[0]; J[1][j] = ax[1]; J[2][j] = ax[2];
+    const double epn_c = sqrt(ep[0] * ep[0] + ep[1] * ep[1] + ep[2] * ep[2]), ern_c = sqrt(er[0] * er[0] + er[1] * er[1] + er[2] * er[2]);
+    const double metric = epn_c / pos_tol + ern_c / rot_tol;
+    if (it == 0 || metric < m_acc) {
+      /* accepted: the damping relaxes; stagnation = an accepted step that gained less than 1 % */
+      if (it > 0) {
+        stall = metric > 0.99 * m_acc ? stall + 1 : 0;
+        lam2 = lam2 * 0.25 > lam2_min ? lam2 * 0.25 : lam2_min;
       }
+      m_acc = metric; epn = epn_c; ern = ern_c;
+      for (int k = 0; k < 3; k++) { e_acc[k] = ep[k]; e_acc[3 + k] = er[k]; }
+      for (int j = 0; j < nj; j++) q_acc[j] = q_io[j];
+      /* Jacobian columns of the chain joints at the accepted iterate */
+      for (int j = 0; j < nj; j++) {
+        int b = jb[j];
+        for (int r = 0; r < 6; r++) J[r][j] = 0;
+        if (!onchain[b]) continue;
+        double ax[3];
+        for (int r = 0; r < 3; r++) ax[r] = (double)d->xmat[b][3 * r] * (double)m->axis[b][0] + (double)d->xmat[b][3 * r + 1] * (double)m->axis[b][1] + (double)d->xmat[b][3 * r + 2] * (double)m->axis[b][2];
+        if (m->jtype[b] == MIR_JNT_REVOLUTE) {
+          double rr[3] = {(double)d->xpos[link][0] - (double)d->xpos[b][0], (double)d->xpos[link][1] - (double)d->xpos[b][1], (double)d->xpos[link][2] - (double)d->xpos[b][2]};
+          J[0][j] = ax[1] * rr[2] - ax[2] * rr[1]; J[1][j] = ax[2] * rr[0] - ax[0] * rr[2]; J[2][j] = ax[0] * rr[1] - ax[1] * rr[0];
+          if (target_quat) { J[3][j] = ax[0]; J[4][j] = ax[1]; J[5][j] = ax[2]; }
+        } else {
+          J[0][j] = ax[0]; J[1][j] = ax[1]; J[2][j] = ax[2];
+        }
+      }
+    } else {
+      /* rejected (the scaled error did not fall): back to the accepted iterate with eight times the damping; counts as a stalled iteration */
+      stall++;
+      lam2 = lam2 * 8.0 < lam2_max ? lam2 * 8.0 : lam2_max;
     }
+    if ((epn < pos_tol && ern < rot_tol) || it == max_iters || stall >= 3) break;
+    iters = it + 1;
     double A[6][7];
     for (int r = 0; r < 6; r++) {
       for (int c = 0; c < 6; c++) {
-        double s = r == c ? damping * damping : 0.0;
-        for (int j = 0; j < nj; j++) s += J[r][j] * J[c][j];
-        A[r][c] = s;
+        double s2 = r == c ? lam2 : 0.0;
+        for (int j = 0; j < nj; j++) s2 += J[r][j] * J[c][j];
+        A[r][c] = s2;
       }
-      A[r][6] = r < 3 ? ep[r] : er[r - 3];
+      A[r][6] = e_acc[r];
     }
     for (int c = 0; c < 6; c++) { /* Gaussian elimination, partial pivoting */
       int p = c;
@@ -1634,8 +1647,9 @@ int orc_ik(const OrcModel* m, int link, const double* target_pos, const double* 
     double sc = big > max_step ? max_step / big : 1.0;
     for (int j = 0; j < nj; j++) {
       int b = jb[j];
+      q_io[j] = q_acc[j];
       if (!onchain[b]) continue;
-      q_io[j] += sc * dqv[j];
+      q_io[j] = q_acc[j] + sc * dqv[j];
       int dofi = m->dofadr[b];
       if (respect_limits && m->dof_limited[dofi]) {
         if (q_io[j] < (double)m->range[dofi][0]) q_io[j] = (double)m->range[dofi][0];
@@ -1643,9 +1657,10 @@ int orc_ik(const OrcModel* m, int link, const double* target_pos, const double* 
       }
     }
   }
+  for (int j = 0; j < nj; j++) q_io[j] = q_acc[j];
   if (err2) { err2[0] = epn; err2[1] = ern; }
   free(d);
-  return 0;
+  return iters;
 }
 
 /* ------------------------------------------------------------------ accessors */

@@ -114,3 +114,39 @@ def test_rccl_collective_path_still_runs():
     out = _run("--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo", "--oversubscribe", "--envs-per-gpu", "512", "--min-time", "0.1",
                "--gather-every", "4", "--gather-path", "rccl", "--no-cpu-baseline")
     assert out["n_gpus"] == 2 and out["config"]["gather_path"] == "rccl" and "gloo all_gather" in out["config"]["obs_gather"]
+
+
+def test_copy_path_that_cannot_map_a_peer_falls_back_to_the_collective_on_every_rank():
+    """Dry run of the first multi-GPU launch: `mir_p2p_enable` is made to fail on ONE of two ranks
+    (MIR_P2P_FORCE_FAIL=1: rank 1's calls).  The ranks agree -- the failing one must not skip a collective the other is inside of --
+    on the RCCL / gloo collective, the run finishes with rc 0, and the line says which path it took and why."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["MIR_P2P_FORCE_FAIL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo", "--oversubscribe",
+                        "--envs-per-gpu", "512", "--min-time", "0.1", "--gather-every", "4", "--gather-path", "copy", "--no-cpu-baseline", "--no-pixels", "--no-stack"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and cfg["world_size_observed"] == 2 and out["value"] > 0
+    assert cfg["gather_path"] == "rccl", cfg
+    assert cfg["gather_note"] and "mapping the peers' buffers failed on some rank" in cfg["gather_note"], cfg["gather_note"]
+
+
+def test_a_rank_that_dies_mid_region_takes_the_run_down_promptly():
+    """ rank 1 of two exits in the middle of a timed region (MIR_BENCH_KILL_RANK=1:40): the launcher ends the
+    other rank, the command returns non-zero well inside the gather's and the process group's time-outs, prints no result line, and
+    nothing is restarted."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["MIR_BENCH_KILL_RANK"] = "1:40"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo", "--oversubscribe",
+                        "--envs-per-gpu", "512", "--min-time", "0.1", "--gather-every", "4", "--no-cpu-baseline", "--no-pixels", "--no-stack"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    took = time.time() - t0
+    assert r.returncode != 0 and took < 240, (r.returncode, took, r.stderr[-2000:])
+    assert not any(line.startswith('{"metric"') for line in r.stdout.splitlines())
+    assert "exitcode" in r.stderr and "17" in r.stderr, r.stderr[-3000:]   # (torch.distributed.run's failure summary names the rank that died)
+    assert r.stderr.count("rank(s) requested") == 1   # (one launch: nothing was started again)

@@ -80,6 +80,34 @@ def test_two_rank_shard_equals_single_process(b_global, pass_num_envs):
         assert np.array_equal(got[r], ref), f"rank {r}: gathered rows differ from the unsharded run"
 
 
+def test_eight_rank_unequal_shards_equal_single_process():
+    """BASELINE configs[2]'s world size on CPU: eight gloo ranks, 37 envs (shards of 4 and 5), the global reset stream sliced per rank;
+    the rows every rank gathers equal the unsharded run bit for bit."""
+    _paths()
+    from gym_genesis.sharding import shard_bounds
+
+    world, b_global = 8, 37
+    sizes = [shard_bounds(b_global, r, world)[1] - shard_bounds(b_global, r, world)[0] for r in range(world)]
+    assert sorted(set(sizes)) == [4, 5] and sum(sizes) == b_global
+    actions = np.random.default_rng(1).uniform(-1, 1, (STEPS, b_global, 9)).astype(np.float32)
+    ref = _run(None, actions, b_global).numpy()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, actions, q, b_global, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ref.shape == (STEPS, b_global, 22)
+    for r in range(world):
+        assert np.array_equal(got[r], ref), f"rank {r}: gathered rows differ from the unsharded run"
+
+
 def test_pack_unpack_roundtrip():
     _paths()
     from gym_genesis.sharding import pack_rows, shard_bounds, unpack_rows
