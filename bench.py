@@ -564,6 +564,7 @@ def grasp_bench(torch, dev):
     env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
     obs, _ = env.reset(seed=0)
     task = env._env
+    _bare_launches(task)
     task._mir.set_diag(True)
     robot, cube = env.get_robot(), obs["environment_state"][:, :3].clone()
     eef = robot.get_link("hand")
@@ -633,6 +634,59 @@ def grasp_bench(torch, dev):
             "max_candidate_points": pts_max, "contact_capacity": 16, "env_step_thinned": thin, "env_step_exact_contacts": exact}
 
 
+def _bare_launches(task):
+    """The legs that time BARE launches (task.step_raw back to back, device-side rollouts) have no host in them to close a step on: they
+    run with exact contacts switched off (the pick tasks' default is on since round 6; mir_step_fused would otherwise wait for every
+    step's terminated bytes, and mir_rollout* are refused).  Returns whether the switch was on."""
+    was = bool(getattr(task._mir, "exact_contacts", False))
+    if was:
+        task._mir.set_exact_contacts(False)
+    return was
+
+
+def ref_expert_bench(torch, dev, episodes: int = 2):
+    """Secondary: the reference's own expert (/root/reference/examples/franka/pick_cube_state.py:16-54,86-88 as restated
+    in examples/franka/pick_cube_state.py: IK every step, the hand pressed to 3 cm above the cube -- 27 % of its env-steps above 16
+    contact points) at 4096 envs: microseconds INSIDE env.step() per call and per loop iteration, with every contact kept (the
+    task's default) and with the manifolds thinned at 16 points (exact_contacts=False)."""
+    import importlib.util
+
+    from gym_genesis.env import GenesisEnv
+
+    spec = importlib.util.spec_from_file_location("pick_cube_state", os.path.join(ROOT, "examples", "franka", "pick_cube_state.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    B = ENVS_PER_GPU
+    res = {"workload": "reference expert (pick_cube_state.py), 5 x 40 steps, IK every step, num_envs=4096"}
+    for key, kw in (("exact_contacts", {}), ("thinned", {"exact_contacts": False})):
+        env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False, **kw)
+        mir = env._env._mir
+        in_step, loop = [], []
+        for ep in range(episodes + 1):  # (the first episode warms up)
+            obs, _ = env.reset(seed=ep)
+            mir.exact_stats(reset=True)
+            torch.cuda.synchronize(dev)
+            t_in, ok = 0.0, None
+            t0 = time.perf_counter()
+            for stage in ex.STAGES:
+                for _ in range(40):
+                    a = ex.expert_policy(env.get_robot(), obs, stage)
+                    ta = time.perf_counter()
+                    obs, reward, term, trunc, info = env.step(a)
+                    t_in += time.perf_counter() - ta
+                    ok = term if ok is None else (ok | term)
+            torch.cuda.synchronize(dev)
+            if ep:
+                in_step.append(t_in / 200 * 1e6); loop.append((time.perf_counter() - t0) / 200 * 1e6)
+        st = mir.exact_stats()
+        res[key] = {"env_step_us": sorted(in_step)[len(in_step) // 2], "loop_us": sorted(loop)[len(loop) // 2], "lifted_frac": float(ok.mean()),
+                    "overflow_env_frac": st["overflow_env_steps"] / (200.0 * B), "overflow_step_frac": st["overflow_steps"] / 200.0}
+        if key == "exact_contacts":
+            res[key].update(mir.exact_route())
+        del env
+    return res
+
+
 def box_links_bench(torch, dev, steps: int = 400):
     """Secondary: the headline workload with links 1-7 of the Panda as round 1's boxes (GenesisEnv(..., link_shape="box")): the
     instantiation of the step kernel WITHOUT the convex narrowphase (the default scene has capsule links and runs the
@@ -643,6 +697,7 @@ def box_links_bench(torch, dev, steps: int = 400):
     env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False, link_shape="box")
     env.reset(seed=0)
     task = env._env
+    _bare_launches(task)
     gen = torch.Generator(device=dev).manual_seed(1234)
     acts = torch.empty((256, B, 9), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
     for t in range(20):
@@ -669,6 +724,7 @@ def so101_bench(torch, dev, steps: int = 400):
     env = GenesisEnv(task="cube_pick", robot="so101", num_envs=B, enable_pixels=False)
     env.reset(seed=0)
     task = env._env
+    was_exact = _bare_launches(task)
     gen = torch.Generator(device=dev).manual_seed(77)
     acts = torch.empty((256, B, task._zero.shape[1]), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
     for t in range(20):
@@ -681,7 +737,10 @@ def so101_bench(torch, dev, steps: int = 400):
     ev1.record()
     torch.cuda.synchronize(dev)
     us = ev0.elapsed_time(ev1) * 1e3 / steps
-    # the same through GenesisEnv.step
+    # the same through GenesisEnv.step (the task's default: exact contacts on)
+    if was_exact:
+        task._mir.set_exact_contacts(True)
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for t in range(200):
         env.step(acts[t % 256])
@@ -757,9 +816,16 @@ def ik_bench(torch, dev, calls: int = 200):
     target = (obs["environment_state"][:, :3] + torch.tensor([0.0, 0.0, 0.25], device=dev)).contiguous()
     quat = torch.tensor([0.0, 1.0, 0.0, 0.0], device=dev).repeat(B, 1)
     hand = task.eef.idx
+    import ctypes as C
+    iters = torch.zeros(B, dtype=torch.int32, device=dev)
+    lib = task._mir.lib
+    lib.mir_debug_ik_iters.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mir_debug_ik_iters(task._mir.h, C.c_void_p(iters.data_ptr()))
     for _ in range(5):
         q, err = task._mir.inverse_kinematics(hand, target, quat, return_error=True)
     torch.cuda.synchronize(dev)
+    it = iters.cpu().numpy()
+    lib.mir_debug_ik_iters(task._mir.h, None)
     ev0, ev1 = _events(torch)
     ev0.record()
     for _ in range(calls):
@@ -767,11 +833,19 @@ def ik_bench(torch, dev, calls: int = 200):
     ev1.record()
     torch.cuda.synchronize(dev)
     us = ev0.elapsed_time(ev1) * 1e3 / calls
-    return {"workload": "robot.inverse_kinematics(hand, pos, quat) from the home pose, num_envs=4096, <= 32 damped-least-squares iterations",
-            "env_solves_per_s": B / (us * 1e-6), "us_per_call": us, "converged_frac": float(((err[:, 0] < 5e-4) & (err[:, 1] < 5e-3)).float().mean().item())}
+    # fp32 vector roofline: ~1.7 kflop per env and iteration, counted once (10-link chain: forward kinematics 600, error 60, nine Jacobian
+    # columns 380, J J^T 360, the 6 x 6 solve 150, J^T y 100, clamps 30) -- the kernel forms J J^T and solves it in EVERY lane of the env's
+    # row, which is not counted; the launch lasts as long as its slowest wave (`iters_wave_max`), the chip idles behind the mean
+    f_iter = 1.7e3
+    flops = f_iter * float(it.sum())
+    return {"workload": "robot.inverse_kinematics(hand, pos, quat) from the home pose, num_envs=4096, <= 32 Levenberg-Marquardt iterations",
+            "env_solves_per_s": B / (us * 1e-6), "us_per_call": us, "converged_frac": float(((err[:, 0] < 5e-4) & (err[:, 1] < 5e-3)).float().mean().item()),
+            "iters_mean": float(it.mean()), "iters_wave_max": int(it.max()),
+            "roofline_valu": {"bound": "valu_fp32", "achieved": flops / (us * 1e-6) / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": flops / (us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS, "flop_per_env_iteration": f_iter}}
 
 
-def batch_sweep(torch, dev, f_step=None, sizes=(1024, 4096, 16384, 65536), n: int = 300):
+def batch_sweep(torch, dev, f_step=None, sizes=(1024, 4096, 16384, 32768, 65536), n: int = 300):
     """Secondary: what the 16-lane kernel does with other batches on ONE GPU -- the numbers under "latency / occupancy-bound".  Per batch:
     the bare fused launch (HIP events: kernel us, env-steps/s), the loop through GenesisEnv.step (wall clock), and the fp32 vector
     fraction F_step x B / kernel time / 157.3 TF.  At 4096 envs every env is resident at once (4 workgroups of 4 envs per CU); beyond
@@ -783,6 +857,7 @@ def batch_sweep(torch, dev, f_step=None, sizes=(1024, 4096, 16384, 65536), n: in
         env = GenesisEnv(task="cube_pick", robot="franka", num_envs=Bs, enable_pixels=False)
         task = env._env
         env.reset(seed=0)
+        was_exact = _bare_launches(task)
         acts = torch.empty((8, Bs, 9), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=torch.Generator(device=dev).manual_seed(7))
         al = list(acts.unbind(0))
         for t in range(30):
@@ -795,6 +870,24 @@ def batch_sweep(torch, dev, f_step=None, sizes=(1024, 4096, 16384, 65536), n: in
         e1.record()
         torch.cuda.synchronize(dev)
         k_us = e0.elapsed_time(e1) * 1e3 / n
+        # the SINGLE-WAVE instantiation on the same batch: 16-step rollout launches run the step-loop instantiation --
+        # one wave per workgroup does dynamics AND collision, 4 waves per CU instead of 8 -- with the state staying on the chip
+        ro_rate = None
+        try:
+            rows16 = torch.zeros((8, Bs, 9 + 11 + 2), dtype=torch.float32, device=dev)
+            task._mir.rollout(acts[:8], rows16)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(max(2, n // 40)):
+                task._mir.rollout(acts[:8], rows16)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ro_rate = max(2, n // 40) * 8 * Bs / (e0.elapsed_time(e1) * 1e-3)
+            del rows16
+        except Exception:  # noqa: BLE001
+            pass
+        if was_exact:
+            task._mir.set_exact_contacts(True)
         env.reset(seed=0)
         for t in range(30):
             env.step(al[t % 8])
@@ -805,15 +898,15 @@ def batch_sweep(torch, dev, f_step=None, sizes=(1024, 4096, 16384, 65536), n: in
         torch.cuda.synchronize(dev)
         api_us = (time.perf_counter() - t0) * 1e6 / n
         rows.append([Bs, k_us, Bs / (k_us * 1e-6), api_us, Bs / (api_us * 1e-6), ALGO_BYTES_PER_ENV_STEP * Bs / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     (f_step * Bs / (k_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS) if f_step else None])
+                     (f_step * Bs / (k_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS) if f_step else None, ro_rate])
         del env, task
-    return {"cols": ["num_envs", "kernel_us", "bare_launch_rate", "env_step_us", "env_step_rate", "hbm_frac", "valu_frac"], "rows": rows,
+    return {"cols": ["num_envs", "kernel_us", "bare_launch_rate", "env_step_us", "env_step_rate", "hbm_frac", "valu_frac", "single_wave_rollout8_rate"], "rows": rows,
             "note": "fused launch by HIP events (gap included), GenesisEnv.step by wall clock; one GPU, franka pick, U(-1,1) targets"}
 
 
 def _profile_number(name: str, key: str):
     """A number measured offline with rocprofv3 PMC passes and committed under profiles/ (latest round first)."""
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, name)) as f:
                 v = json.load(f).get(key)
@@ -843,7 +936,7 @@ HEAD_KEYS = ("metric", "value", "unit", "value_median_region", "hot_path_rate", 
 DROP_ORDER = ("roofline_valu.instruction_level", "roofline_valu.fused_launch", "stack.roofline_valu.instruction_level", "sync_step_floor", "repeat_us_per_step",
               "roofline.note", "roofline_fused_launch", "stack.roofline_valu", "pixels.reduced_96x128_num_envs_4096", "pixels.us_per_render_regions",
               "config.obs_gather", "config.output_ring", "config.value_is", "no_gather", "best_repeat_value", "roofline_valu", "pixels.roofline", "stack.roofline",
-              "box_links", "ik", "so101_pick", "pixels", "stack", "secondary", "scripted_grasp")
+              "box_links", "ik", "so101_pick", "pixels", "stack", "secondary", "scripted_grasp", "ref_expert")
 
 
 def compact_line(out: dict, limit: int = LINE_LIMIT) -> dict:
@@ -875,7 +968,7 @@ def compact_line(out: dict, limit: int = LINE_LIMIT) -> dict:
             return x[:NOTE_LIMIT - 3] + "..."
         return x
 
-    LEGS = ("secondary", "pixels", "scripted_grasp", "box_links", "so101_pick", "stack", "ik", "roofline_valu", "roofline_fused_launch", "sync_step_floor",
+    LEGS = ("secondary", "pixels", "scripted_grasp", "ref_expert", "box_links", "so101_pick", "stack", "ik", "roofline_valu", "roofline_fused_launch", "sync_step_floor",
             "no_gather", "gather_every_1", "repeat_us_per_step")
     o = {k: shrink(v, k, k in LEGS) for k, v in o.items()}
     o = {**{k: o[k] for k in HEAD_KEYS if k in o}, **{k: v for k, v in o.items() if k not in HEAD_KEYS}}
@@ -1426,6 +1519,7 @@ def worker(args) -> int:
                 _guard(out, "so101_pick", so101_bench, torch, dev)
                 _guard(out, "stack", stack_bench, torch, dev)
                 _guard(out, "ik", ik_bench, torch, dev)
+                _guard(out, "ref_expert", ref_expert_bench, torch, dev)
         # (rank 0 of any world size: the other ranks wait at the final barrier, their host cores idle)
         if rank == 0 and not (args.no_cpu_baseline or args.core_only):
             _guard(out, "cpu_baseline", cpu_baseline)

@@ -54,11 +54,16 @@ def test_driver_command_prints_the_contract_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "env-steps/s"
     assert cb["min"] <= cb["median"] <= cb["value"] == cb["max"] and cb["threads"] == cb["cores"], cb   # (best of five runs of the same steps; the spread is the shared host's)
     sweep = out["secondary"]["batch_sweep"]
-    assert [r[0] for r in sweep["rows"]] == [1024, 4096, 16384, 65536] and sweep["cols"][:3] == ["num_envs", "kernel_us", "bare_launch_rate"]
+    assert [r[0] for r in sweep["rows"]] == [1024, 4096, 16384, 32768, 65536] and sweep["cols"][:3] == ["num_envs", "kernel_us", "bare_launch_rate"]
+    assert sweep["cols"][7] == "single_wave_rollout8_rate" and all(r[7] and r[7] > 1e6 for r in sweep["rows"])
     assert all(r[2] > 1e6 and r[4] > 1e6 and 0 < r[6] < 1 for r in sweep["rows"])
     gx = out["scripted_grasp"]["env_step_exact_contacts"]
     assert gx["overflow_env_frac"] > 0.005 and gx["env_steps_per_s"] > 1e7 and abs(gx["lifted_frac"] - out["scripted_grasp"]["env_step_thinned"]["lifted_frac"]) < 0.05
-    for key in ("secondary", "pixels", "scripted_grasp", "box_links", "so101_pick", "stack", "ik"):
+    rx = out["ref_expert"]   # (both figures in the line -- every contact kept, the default, and the thinned speed knob)
+    assert rx["exact_contacts"]["env_step_us"] > 0 and rx["thinned"]["env_step_us"] > 0 and rx["exact_contacts"]["overflow_env_frac"] > 0.1
+    assert abs(rx["exact_contacts"]["lifted_frac"] - rx["thinned"]["lifted_frac"]) < 0.06 and cfg["exact_contacts"] is True
+    assert out["ik"]["roofline_valu"]["frac"] > 0 and out["ik"]["iters_wave_max"] <= 32
+    for key in ("secondary", "pixels", "scripted_grasp", "ref_expert", "box_links", "so101_pick", "stack", "ik"):
         assert key in out and "error" not in out[key], (key, out.get(key))
     assert out["hot_path_rate"] >= out["value"] * 0.9
     assert out["value_median_region"] >= out["value"] * 0.8 and out["config"]["host_thread"].startswith("pinned to cpu")
