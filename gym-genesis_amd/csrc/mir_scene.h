@@ -72,6 +72,10 @@ struct MirScene {
   int heavy;                // the coming mir_step_begin steps the WHOLE batch with three contacts per lane (one launch: mir_step.hip VARIANT 7); decided by mir_step_end
   int heavy_enter, heavy_leave;  // thresholds of that decision, in envs (MIR_EXACT_HEAVY)
   int pend_heavy;           // the pending step is such a launch
+  int32_t* perm_host[2];    // pinned, device-mapped: the order in which a heavy launch serves the envs (the ones above 16 points first), double-buffered
+  int32_t* perm_dev[2];
+  int perm_next, pend_perm; // which of the two the next heavy launch takes / the pending one took (-1: the identity)
+  int heavy_sort;           // MIR_EXACT_HEAVY_SORT=0: never permute
   unsigned long long ex_heavy_steps;
   int ovf_event_live;       // ovf_event has been recorded on the side stream behind launches the NEXT step must come after
   void* ovf_waited_stream;  // the stream that has been made to wait for it
