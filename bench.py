@@ -228,8 +228,10 @@ print(json.dumps([[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j
 
 
 def preflight(gpus: int, oversubscribe: bool = False, device_count=None, peer_matrix=None, out=sys.stderr):
-    """Before any rank is started, in the launching parent (which never touches the GPU: the device count is read without
-    initialising HIP, the peer-access matrix by a short-lived child): one line per rank -- device, NUMA node of the GPU, the host
+    """Before any rank is started, in the launching parent: one line per rank.  The parent starts children only and exec's nothing; the
+    peer-access matrix comes from a short-lived child, the device count from torch.cuda.device_count() -- which reads it without
+    initialising HIP where amdsmi is present and falls back to hipGetDeviceCount where it is not (harmless here, nothing is
+    exec'ed from this process, but "never touches the GPU" was too strong): one line per rank -- device, NUMA node of the GPU, the host
     cores the rank will take (rank_cpu_plan), which peers its GPU can address (what the copy-path gather needs; without it the
     ranks agree on the RCCL collective) -- and a verdict.  Returns 0 when every rank can be placed on a GPU of its own, 2 otherwise.
     `device_count` / `peer_matrix` are injectable for the CPU tests."""
