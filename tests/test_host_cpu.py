@@ -373,3 +373,77 @@ def test_so101_stack_spawn_sampling_equals_the_scalar_rejection_loop():
             want = scalar(Bg, rb, 0.7 + 0.02 + 0.001)
             assert got.shape == (Bg, 5, 3) and np.array_equal(got, want)
         assert ra.random_sample() == rb.random_sample()
+
+
+# ---------------------------------------------------------------- the getters as the reference's experts call them (round 6)
+def test_getters_take_envs_idx_like_genesis(env):
+    """`robot.get_qpos(envs_idx=np.arange(B))`, `robot.get_link("hand").get_pos(envs_idx=torch.arange(B))`
+    (/root/reference/examples/franka/stack_cube_state.py:57,76; examples/so_101/collect_task_stack_cube_batch.py:73,86,90): NumPy, torch and
+    list indices, the identity without a gather, a subset in the order asked for."""
+    B = 3
+    env.reset(seed=0)
+    robot, link = env.get_robot(), env.get_robot().get_link("hand")
+    q, p, quat = robot.get_qpos(), link.get_pos(), link.get_quat()
+    assert q.shape == (B, 9) and p.shape == (B, 3) and quat.shape == (B, 4)
+    for idx in (np.arange(B), torch.arange(B), list(range(B))):
+        assert torch.equal(robot.get_qpos(envs_idx=idx), q) and torch.equal(link.get_pos(envs_idx=idx), p) and torch.equal(link.get_quat(envs_idx=idx), quat)
+    sub = [2, 0]
+    assert torch.equal(robot.get_qpos(envs_idx=sub), q[sub]) and torch.equal(link.get_pos(envs_idx=np.array(sub)), p[sub])
+    assert torch.equal(robot.get_dofs_position(dofs_idx_local=[7, 8], envs_idx=torch.tensor(sub)), q[sub][:, 7:9])
+    assert torch.equal(robot.get_dofs_velocity(envs_idx=sub), robot.get_dofs_velocity()[sub])
+    assert torch.equal(env.get_cube().get_pos(envs_idx=sub), env.get_cube().get_pos()[sub])
+
+
+def test_inverse_kinematics_never_writes_a_callers_tensor(env):
+    """rows addressed through `envs_idx` are scattered into tensors of the wrapper's own; a full-batch argument handed in beside
+    them -- the caller's tensor -- is read, never edited (an all-zero quaternion row used to be turned into the identity IN PLACE)."""
+    B = 3
+    obs, _ = env.reset(seed=0)
+    robot = env.get_robot()
+    eef = robot.get_link("hand")
+    pos_sub = obs["environment_state"][[2, 0], :3] + torch.tensor([0.0, 0.0, 0.2])
+    quat_full = torch.tensor([[0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]])   # row 1 is not addressed
+    keep = quat_full.clone()
+    v0 = quat_full._version
+    q = robot.inverse_kinematics(link=eef, pos=pos_sub, quat=quat_full, envs_idx=[2, 0])
+    assert q.shape == (2, 9) and torch.isfinite(q).all()
+    assert torch.equal(quat_full, keep) and quat_full._version == v0
+    # scattered quaternions: the rows nobody addressed become the identity inside the wrapper's own tensor
+    q2 = robot.inverse_kinematics(link=eef, pos=pos_sub, quat=keep[[2, 0]], envs_idx=[2, 0])
+    assert torch.allclose(q, q2)
+
+
+def _example(rel):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(os.path.basename(rel)[:-3], os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("robot,rel,steps,dim", [("franka", "examples/franka/stack_cube_state.py", 391, 9),
+                                                 ("so101", "examples/so_101/collect_task_stack_cube_batch.py", 360, 6)])
+def test_reference_stack_experts_run_on_the_test_double(monkeypatch, robot, rel, steps, dim):
+    """The reference's two batched stack experts, restated constant for constant (examples/), drive the env end to end on the CPU test
+    double: path lengths as in the reference (3 x 77 + 2 x 80 joint targets for the Franka, 5 x 70 + 10 for the SO-101), finite
+    states, the gripper schedule of the grasp stage (open, then closing over its last five targets)."""
+    import fake_scene
+    from gym_genesis.env import GenesisEnv
+    from gym_genesis.tasks import stack_common
+
+    monkeypatch.setattr(stack_common, "MirScene", fake_scene.OracleScene)
+    ex = _example(rel)
+    env = GenesisEnv(task="cube_stack", robot=robot, num_envs=2, enable_pixels=False, strip_environment_state=False)
+    obs, _ = env.reset(seed=1)
+    policy = ex.expert_policy if robot == "franka" else ex.expert_policy_v2
+    grasp = policy(env.get_robot(), obs, "grasp")
+    assert len(grasp) == (77 if robot == "franka" else 70) and grasp[0].shape == (2, dim)
+    opened, closed = (0.04, -0.02) if robot == "franka" else (0.5, 0.1)
+    assert all(abs(float(a[0, -1]) - opened) < 1e-6 for a in grasp[:-5])
+    assert abs(float(grasp[-5][0, -1]) - opened) < 1e-6 and opened > float(grasp[-1][0, -1]) > closed   # alpha = 0 .. 4 / 5
+    out = ex.run_episode(env, obs)
+    acts = out[2] if robot == "franka" else out[1]
+    assert acts.shape == (steps, 2, dim) and all(np.isfinite(x).all() for x in out)
+    with pytest.raises(ValueError):
+        policy(env.get_robot(), obs, "no such stage")
