@@ -1306,6 +1306,7 @@ def worker(args) -> int:
     try:
         # ---- headline: the loop through GenesisEnv.step ---------------------------------------------------------------
         if args.core_only and args.raw_only:
+            _bare_launches(task)   # (bare launches only: exact contacts off, see below)
             walls, evs = measure(raw_loop)
             api_walls = None
         else:
