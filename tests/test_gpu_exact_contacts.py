@@ -249,6 +249,44 @@ def test_every_launch_kind_defers_the_same_way(franka_spec, monkeypatch, var, va
     assert abs(st["overflow_env_steps"] - n_def) <= 10 and n_def > 100 and st["steps"] == 200 and lifted.mean() > 0.9
 
 
+def test_heavy_phase_from_the_first_overflow_on_and_a_batch_that_is_not_a_multiple_of_four(franka_spec, monkeypatch):
+    """MIR_EXACT_HEAVY=1,1: the whole batch goes to the three-contacts-per-lane launch from the step after the first deferred env until no
+    env is above 16 points -- with the envs served in sorted order (the ones above 16 points first), 30 envs: the last workgroup holds
+    two.  Every env of every step equals its twin (an env with at most 16 points is the one-contact-per-lane kernel's bit for bit)."""
+    from gym_genesis.backend.lib import MirScene
+
+    monkeypatch.setenv("MIR_SPLIT_STEP", "1")
+    monkeypatch.setenv("MIR_EXACT_HEAVY", "1,1")
+    n = 30
+    sc, plain, twin = MirScene(franka_spec, n), MirScene(franka_spec, n), MirScene(franka_spec, n)
+    sc.set_exact_contacts(True)
+    twin.set_exact_contacts("all")
+    for s_ in (sc, plain, twin):
+        s_.set_diag(True)
+    pos, acts = _grasp_workload(32)
+    pos, acts = pos[:n], acts[:, :n]
+    sc.reset(pos, np.tile(np.array([0, 0, 0, 1], np.float32), (n, 1)), np.tile(HOME, (n, 1)))
+    b0, b1, b2 = _bufs(sc), _bufs(plain), _bufs(twin)
+    dacts = torch.as_tensor(acts, device=sc.device)
+    sc.exact_stats(reset=True)
+    n_def = 0
+    for t in range(acts.shape[0]):
+        st = sc.get_state()
+        for tw in (plain, twin):
+            tw.set_state(*st)
+        sc.step_begin(dacts[t], *b0); h0 = sc.step_end()
+        plain.step_fused(dacts[t], *b1)
+        twin.step_fused(dacts[t], *b2)
+        dfr = sc.get_diag(points=True)[3] > 16
+        n_def += int(dfr.sum())
+        for x, y, z in zip(list(b0) + list(sc.get_state()), list(b1) + list(plain.get_state()), list(b2) + list(twin.get_state())):
+            assert torch.equal(x[~dfr], y[~dfr]), f"step {t}: an env with at most 16 points differs from the plain scene"
+            assert torch.equal(x[dfr], z[dfr]), f"step {t}: an env above 16 points differs from its twin"
+        assert np.array_equal(h0, b0[3].cpu().numpy().astype(bool))
+    st, r = sc.exact_stats(), sc.exact_route()
+    assert n_def > 20 and st["overflow_env_steps"] == n_def and r["heavy_steps"] > 3 and r["wave_env_steps"] == 0, (n_def, st, r)
+
+
 def test_so101_scene_with_a_low_capacity_random_actions_every_env_equals_its_twin_bit_for_bit(monkeypatch):
     """The other articulation (BASELINE configs[3]) and another way to overflow: the SO-101 pick scene with the capacity of the
     16-lane kernel set to 4 points -- the cube resting on the slab -- and random joint targets: whenever the arm touches the slab or the
