@@ -191,7 +191,6 @@ struct Outs {
   int over_cap = 0;    // 16-lane kernel, phase 4 / 5 (StepArgs::over_cap)
   const int32_t* env_list = nullptr;  // 16-lane kernel, phase 1: serve the envs env_list[0 .. nlist) (StepArgs::env_list)
   int nlist = 0;
-  uint32_t* next_host = nullptr;      // 16-lane kernel, phases 3 / 4 (StepArgs::next_host)
   unsigned long long* prof = nullptr;  // 16-lane kernel only (debug)
 };
 
@@ -227,7 +226,6 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.phase = o.phase; a.pre = h->pre;
     a.exact = o.exact; a.over_cap = o.over_cap;
     if (o.env_list) { a.env_list = o.env_list; a.B = o.nlist; }
-    a.next_host = o.next_host;
     if (o.phase == 4) a.term_wstride = 1;  // (the terminated byte of list entry k is byte k of term_host)
     rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
   } else {
@@ -498,9 +496,6 @@ int mir_destroy(MirHandle h) {
   if (h->pre) (void)hipFree(h->pre);
   if (h->pin_host) (void)hipHostFree(h->pin_host);
   if (h->ovf_list_host) (void)hipHostFree(h->ovf_list_host);
-  if (h->next_host) (void)hipHostFree(h->next_host);
-  if (h->main_event) (void)hipEventDestroy((hipEvent_t)h->main_event);
-  free(h->listed);
   if (h->ovf_event) (void)hipEventDestroy((hipEvent_t)h->ovf_event);
   if (h->ovf_stream) (void)hipStreamDestroy((hipStream_t)h->ovf_stream);
   delete h;
@@ -531,7 +526,7 @@ int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const fl
   }
   if (int rc = check_mask(h)) return rc;
   h->pre_valid = 0;
-  if (!env_mask) { h->heavy = 0; h->perm_next = -1; h->ovf_run = 0; }  // (exact contacts: a full reset ends a heavy phase -- every env is back at its start)
+  if (!env_mask) { h->heavy = 0; h->perm_next = -1; }  // (exact contacts: a full reset ends a heavy phase -- every env is back at its start)
   h->poses_current = 0;
   h->state_version++;
   DeviceGuard guard(h->device);
@@ -597,12 +592,6 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  * into the handle's pinned host buffer and arranges for a completion word; mir_step_end blocks until that launch has finished and
  * copies the B bytes to the caller's plain host array -- `terminated = is_success.detach().cpu().numpy()` (env.py:64) without a
  * separate copy command.  The host is free between the two calls (the Python side allocates the next outputs there). */
-static int early_launch(MirScene* h, uint32_t prev_tag, uint32_t tag, void* stream, bool have_event);
-// (developer aid, MIR_EXACT_TIMING=1: host time stamps of a step with lists, in us since its mir_step_begin, to stderr)
-static double now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
-static double g_t0 = 0.0, g_tb[8];
-static int g_timing = -1;
-#define TSTAMP(i) do { if (g_timing > 0) g_tb[i] = now_us() - g_t0; } while (0)
 int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   // a step left open (an exception between the two calls on the Python side) is closed here: its bytes are waited for and dropped
@@ -623,7 +612,6 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   //  kernel holds", from the launches that step the whole batch with three contacts per lane, StepArgs::over_cap.)
   const uint32_t tag = h->tag % 31u + 1u;
   o.term_tag = tag;
-  const uint32_t prev_tag = h->tag;
   if (h->sync_mode == 2) { o.done_ticket = h->done_ticket; o.done_flag = flag_dev; o.done_seq = seq; }
   // split step: if the previous mir_step_begin left the action-independent half of THIS step in `pre` (same stream, nothing
   // touched the state since), only the other half is launched now
@@ -656,48 +644,16 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   h->pend_action = action;
   h->pend_out[0] = agent_pos; h->pend_out[1] = env_state; h->pend_out[2] = reward; h->pend_out[3] = terminated;
   h->pend_rotated = rotated ? 1 : 0;
-  // exact contacts, known a step ahead: the envs this step will defer -- the previous launches said so (mir_scene.h: next_host) -- take
-  // the list instantiation NOW, on the side stream, beside the main launch
-  h->pend_early = 0;
-  h->cur_nlb = 0;
-  if (g_timing < 0) g_timing = (getenv("MIR_EXACT_TIMING") && atoi(getenv("MIR_EXACT_TIMING")) != 0) ? 1 : 0;
-  if (g_timing > 0) { g_t0 = now_us(); for (int i = 0; i < 8; i++) g_tb[i] = 0.0; }
-  // The main launch goes out FIRST (the chip is full with it: 1024 workgroups on 1024 LDS slots; a list launch in front of it pushes some
-  // of them into a second round, and with them the step's terminated bytes): the list launch follows while it runs and takes the slots of
-  // the first workgroups that finish.
-  const bool early_mode = h->exact == 1 && h->exact_big && h->early && rotated && !heavy && h->ovf_stream != nullptr;
-  const bool early_now = early_mode && h->early == 1 && h->ovf_run && h->next_ok && h->next_stream == stream;
-  bool have_event = false;
-  if (early_now) {
-    // (the previous main launch must have finished before the list launch starts: an event behind it, unless the stream has drained)
-    const hipError_t qe = hipStreamQuery((hipStream_t)stream);
-    if (qe != hipSuccess && qe != hipErrorNotReady) return hip_fail(qe, "mir_step_begin: stream (exact contacts)");
-    if (qe == hipErrorNotReady) {
-      (void)hipGetLastError();
-      HIPCHK(hipEventRecord((hipEvent_t)h->main_event, (hipStream_t)stream));
-      have_event = true;
-    }
-  }
-  if (early_mode) o.next_host = h->next_dev;
   o.prof = h->dbg_prof;
   h->dbg_prof = nullptr;
-  TSTAMP(1);
   int rc = launch(h, o, stream);
   if (rc != MIR_OK) return rc;
-  TSTAMP(2);
   // the launch that carries the tag is queued: from here on the step is pending whatever happens to the calls behind it
   h->seq = seq;
   h->tag = tag;
   h->pending = 1;
   h->pending_stream = stream;
   if (rotated) h->pre_valid = 1;  // (launch() cleared it; the same launch has refilled `pre` for the state it leaves)
-  if (early_now) {
-    rc = early_launch(h, prev_tag, tag, stream, have_event);  // (reads the PREVIOUS launches' next-step bytes: before next_ok is updated)
-    TSTAMP(5);
-    if (rc != MIR_OK) return rc;
-  }
-  h->next_ok = early_mode ? 1 : 0;
-  h->next_stream = stream;
   if (h->sync_mode == 1) {
     hipError_t e = hipStreamWriteValue32((hipStream_t)stream, flag_dev, seq, 0);
     if (e != hipSuccess) { (void)hipGetLastError(); h->sync_mode = 0; }  // not supported on this stack: wait on the stream instead
@@ -746,7 +702,7 @@ int mir_step_go(MirHandle h, const float* action, void* stream) {
  * them, and everything queued before it on the step's stream has finished, or it would not be running.  The step's stream then
  * waits for an event recorded behind them, so that whatever the caller queues after mir_step_end -- the next step, a
  * policy network reading the observations -- comes after them. */
-static int exact_wait(MirScene* h, const uint8_t* term, const int32_t* list, int n, uint8_t* terminated_host, int32_t* again, int* n_again, int* n_over) {
+static int exact_wait(MirScene* h, const uint8_t* term, const int32_t* list, int n, uint8_t* terminated_host, int32_t* again, int* n_again) {
   const uint8_t want = (uint8_t)h->tag;
   unsigned long polls = 0;
   for (int k = 0; k < n;) {
@@ -754,7 +710,6 @@ static int exact_wait(MirScene* h, const uint8_t* term, const int32_t* list, int
     if ((uint8_t)((b >> 1) & 0x1fu) == want) {
       if ((b & 0x80u) && again) again[(*n_again)++] = list[k];
       else if (terminated_host) terminated_host[list[k]] = b & 1u;
-      if (n_over && (b & 0xc0u)) (*n_over)++;
       k++;
       continue;
     }
@@ -769,93 +724,11 @@ static int exact_wait(MirScene* h, const uint8_t* term, const int32_t* list, int
   return MIR_OK;
 }
 
-/* one launch of the list instantiation for the n envs of ring buffer b, on `side`; `known_ahead`: the launch says which of its envs the
- * next step defers (they stay on the list without an action-independent half of their own) */
-static int list_launch(MirScene* h, int b, int n, uint32_t tag, bool known_ahead, void* side) {
-  memset(h->lb_term_host[b], 0, (size_t)n);  // (tags come round every 31 steps: a byte of an older step must not pass for this one's)
-  if (known_ahead) memset(h->lb_next_host[b], 0, ((size_t)n + 3) / 4 * 4);
-  __atomic_thread_fence(__ATOMIC_RELEASE);
-  Outs o;
-  o.action = h->pend_action;
-  o.agent_pos = (float*)h->pend_out[0]; o.env_state = (float*)h->pend_out[1]; o.reward = (float*)h->pend_out[2]; o.terminated = (uint8_t*)h->pend_out[3];
-  o.term_host = h->lb_term_dev[b]; o.term_tag = tag;
-  o.phase = 4; o.env_list = h->lb_list_dev[b]; o.nlist = n;
-  if (known_ahead) { o.over_cap = h->cap16; o.next_host = reinterpret_cast<uint32_t*>(h->lb_next_dev[b]); }
-  o.prof = h->dbg_prof_list;
-  h->dbg_prof_list = nullptr;
-  h->lb_n[b] = n;
-  h->ex_big_envs += (unsigned long long)n;
-  return launch(h, o, side);
-}
-
-/* mir_step_begin, exact contacts known a step ahead: collect the envs the previous step's launches flagged -- the main launch's word per
- * workgroup, the byte per entry of its list launches -- and launch the list instantiation for them on the side stream, behind the previous
- * main launch (an event on the step's stream) and behind the earlier list launches (stream order).  The main launch that follows defers
- * them on their scratch rows' head words as it always did; mir_step_end knows them by h->listed. */
-static int early_launch(MirScene* h, uint32_t prev_tag, uint32_t tag, void* stream, bool have_event) {
-  const int b = h->lb_cur;
-  int32_t* const list = h->lb_list_host[b];
-  const size_t B = (size_t)h->B, nwg = (B + 3) / 4;
-  const uint32_t want4 = 0x01010101u * (uint8_t)prev_tag, tagm4 = 0x1f1f1f1fu;  // (the bytes of the PREVIOUS step's launches)
-  const volatile uint32_t* w = h->next_host;
-  unsigned long polls = 0;
-  int n = 0;
-  for (size_t g = 0; g < nwg;) {
-    const uint32_t v = w[g];
-    if (((v >> 1) & tagm4) == want4) {
-      if (v & 0x01010101u)
-        for (size_t k = 0; k < 4 && 4 * g + k < B; k++)
-          if ((v >> (8 * k) & 0x81u) == 1u) list[n++] = (int32_t)(4 * g + k);
-      g++;
-      continue;
-    }
-    __builtin_ia32_pause();
-    if ((++polls & 0xfffffu) == 0) {
-      hipError_t e = hipStreamQuery((hipStream_t)stream);
-      if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "mir_step_begin: stream (exact contacts)");
-      if (e == hipSuccess && polls > 0x4000000u) return set_err(MIR_E_HIP, "mir_step_begin: the previous launch finished without saying which envs this step defers");
-    }
-  }
-  for (int i = 0; i < h->prev_nlb; i++) {
-    const int pb = h->prev_lb[i];
-    const uint8_t* nx = h->lb_next_host[pb];
-    const uint8_t want = (uint8_t)prev_tag;
-    for (int k = 0; k < h->lb_n[pb];) {
-      const uint8_t v = __atomic_load_n(nx + k, __ATOMIC_RELAXED);
-      if ((uint8_t)((v >> 1) & 0x1fu) == want) {
-        if ((v & 0x81u) == 1u) list[n++] = h->lb_list_host[pb][k];
-        k++;
-        continue;
-      }
-      __builtin_ia32_pause();
-      if ((++polls & 0xfffffu) == 0) {
-        hipError_t e = hipStreamQuery((hipStream_t)h->ovf_stream);
-        if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "mir_step_begin: side stream (exact contacts)");
-        if (e == hipSuccess && polls > 0x4000000u) return set_err(MIR_E_HIP, "mir_step_begin: a list launch finished without saying which of its envs this step defers");
-      }
-    }
-  }
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  TSTAMP(0);
-  if (!n) return MIR_OK;
-  // (the list launch reads rows the previous main launch wrote: the side stream waits for the event recorded behind that launch, in front
-  //  of this step's -- unless the step's stream had drained by then, a host-bound loop)
-  if (have_event) HIPCHK(hipStreamWaitEvent((hipStream_t)h->ovf_stream, (hipEvent_t)h->main_event, 0));
-  const int rc = list_launch(h, b, n, tag, true, h->ovf_stream);
-  if (rc != MIR_OK) return rc;
-  for (int k = 0; k < n; k++) h->listed[list[k]] = 1;
-  h->lb_cur = (b + 1) & 3;
-  h->cur_lb[h->cur_nlb++] = b;
-  h->pend_early = n;
-  h->ex_early_envs += (unsigned long long)n;
-  return MIR_OK;
-}
-
-/* n_late envs (ring buffer h->lb_cur, filled by mir_step_end) were deferred by the pending step's main launch without having been
- * flagged a step ahead; h->pend_early more are on the list launched by mir_step_begin.  The late ones take a launch of the list
- * instantiation now; then the bytes of both lists are waited for; what exceeded that instantiation too goes to the wave-per-env kernel. */
-static int exact_finish(MirScene* h, int n_late, uint8_t* terminated_host) {
+static int exact_finish(MirScene* h, int n, uint8_t* terminated_host) {
   DeviceGuard guard(h->device);
+  h->ex_ovf_steps++;
+  h->ex_ovf_envs += (unsigned long long)n;
+  if ((unsigned long long)n > h->ex_ovf_max) h->ex_ovf_max = (unsigned long long)n;
   // (not beside a step that was launched as two kernels -- a fused launch, or the second half alone, followed by the first half of the
   //  next step for ALL envs: that second kernel writes the scratch rows of the deferred envs too, from their old state, and must come
   //  BEFORE the one below that writes them from the new state: stream order does that)
@@ -865,46 +738,32 @@ static int exact_finish(MirScene* h, int n_late, uint8_t* terminated_host) {
   int32_t* const list2_dev = reinterpret_cast<int32_t*>(h->ovf_term_dev + (B + 63) / 64 * 64);
   uint8_t* const term2_host = reinterpret_cast<uint8_t*>(list2_host + B);
   uint8_t* const term2_dev = reinterpret_cast<uint8_t*>(list2_dev + B);
-  const int32_t* wlist_host = h->lb_list_host[h->lb_cur];
-  const int32_t* wlist_dev = h->lb_list_dev[h->lb_cur];
-  const uint8_t* wterm_host = h->lb_term_host[h->lb_cur];
-  uint8_t* wterm_dev = h->lb_term_dev[h->lb_cur];
-  int nw = n_late;  // envs for the wave-per-env kernel
-  int n_over = 0;   // env-steps above the one-contact-per-lane capacity among the listed ones
-  const bool known_ahead = h->next_ok != 0;  // (the main launch of this step wrote next-step bytes: the list launches do too)
+  const int32_t* wlist_host = h->ovf_list_host;
+  const int32_t* wlist_dev = h->ovf_list_dev;
+  const uint8_t* wterm_host = h->ovf_term_host;
+  uint8_t* wterm_dev = h->ovf_term_dev;
+  int nw = n;  // envs for the wave-per-env kernel
   if (h->pend_heavy) {
     // (a heavy step: these envs were beyond the three-contacts-per-lane capacity already -- straight to the wave-per-env kernel; the
     //  statistics of a heavy step count the envs above the one-contact-per-lane capacity, mir_step_end)
+    h->ex_ovf_steps--; h->ex_ovf_envs -= (unsigned long long)n;
   } else if (h->exact_big) {
-    if (n_late) {
-      const int b = h->lb_cur;
-      const int rc = list_launch(h, b, n_late, h->tag, known_ahead, side);
-      if (rc != MIR_OK) return rc;
-      h->lb_cur = (b + 1) & 3;
-      h->cur_lb[h->cur_nlb++] = b;
-    }
+    memset(h->ovf_term_host, 0, (size_t)n);  // (tags come round every 63 steps: a byte of an older step must not pass for this one's)
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    Outs o;
+    o.action = h->pend_action;
+    o.agent_pos = (float*)h->pend_out[0]; o.env_state = (float*)h->pend_out[1]; o.reward = (float*)h->pend_out[2]; o.terminated = (uint8_t*)h->pend_out[3];
+    o.term_host = h->ovf_term_dev; o.term_tag = h->tag;
+    o.phase = 4; o.env_list = h->ovf_list_dev; o.nlist = n;
+    o.prof = h->dbg_prof_list;
+    h->dbg_prof_list = nullptr;
+    int rc = launch(h, o, side);
+    if (rc != MIR_OK) return rc;
+    h->ex_big_envs += (unsigned long long)n;
     nw = 0;
-    for (int i = 0; i < h->cur_nlb; i++) {
-      const int b = h->cur_lb[i];
-      int over = 0;
-      const int rc = exact_wait(h, h->lb_term_host[b], h->lb_list_host[b], h->lb_n[b], terminated_host, list2_host, &nw, &over);
-      if (rc != MIR_OK) return rc;
-      // (a list launched without over_cap sets no bit 6: every one of its envs was deferred on its count)
-      n_over += known_ahead ? over : h->lb_n[b];
-    }
-    TSTAMP(4);
-    if (h->pend_early) {
-      const int32_t* el = h->lb_list_host[h->cur_lb[0]];
-      for (int k = 0; k < h->pend_early; k++) h->listed[el[k]] = 0;
-    }
+    rc = exact_wait(h, h->ovf_term_host, h->ovf_list_host, n, terminated_host, list2_host, &nw);
+    if (rc != MIR_OK) return rc;
     wlist_host = list2_host; wlist_dev = list2_dev; wterm_host = term2_host; wterm_dev = term2_dev;
-  } else {
-    n_over = n_late;
-  }
-  if (!h->pend_heavy && n_over) {
-    h->ex_ovf_steps++;
-    h->ex_ovf_envs += (unsigned long long)n_over;
-    if ((unsigned long long)n_over > h->ex_ovf_max) h->ex_ovf_max = (unsigned long long)n_over;
   }
   if (nw) {
     memset(const_cast<uint8_t*>(wterm_host), 0, (size_t)nw);
@@ -938,11 +797,7 @@ static int exact_finish(MirScene* h, int n_late, uint8_t* terminated_host) {
     h->ovf_event_live = 1;
     h->ovf_waited_stream = h->pending_stream;
   }
-  // (the next mir_step_begin reads the next-step bytes of this step's list launches)
-  h->prev_nlb = known_ahead ? h->cur_nlb : 0;
-  for (int i = 0; i < h->prev_nlb; i++) h->prev_lb[i] = h->cur_lb[i];
-  h->ovf_run = 1;
-  if (nw) return exact_wait(h, wterm_host, wlist_host, nw, terminated_host, nullptr, nullptr, nullptr);
+  if (nw) return exact_wait(h, wterm_host, wlist_host, nw, terminated_host, nullptr, nullptr);
   return MIR_OK;
 }
 
@@ -968,7 +823,6 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
     const size_t nwg = (B + 3) / 4, ws = (size_t)h->term_wstride;
     unsigned long polls = 0;
     int ndefer = 0, nover = 0;
-    int32_t* const late = h->exact ? h->lb_list_host[h->lb_cur] : nullptr;
     h->ex_steps++;
     // (a launch of a heavy phase may have served the envs in a permuted order: byte k of workgroup g is env pp[4 g + k])
     const int32_t* const pp = (h->exact && h->pend_perm >= 0) ? h->perm_host[h->pend_perm] : nullptr;
@@ -977,10 +831,7 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
       if (((v >> 1) & tagm4) == want4) {
         if ((v & 0x80808080u) && h->exact) {
           for (size_t k = 0; k < 4 && 4 * g + k < B; k++)
-            if (v >> (8 * k + 7) & 1u) {
-              const int32_t e = pp ? pp[4 * g + k] : (int32_t)(4 * g + k);
-              if (!h->pend_early || !h->listed[e]) late[ndefer++] = e;  // (an env on the early list was flagged a step ahead: its launch is running)
-            }
+            if (v >> (8 * k + 7) & 1u) h->ovf_list_host[ndefer++] = pp ? pp[4 * g + k] : (int32_t)(4 * g + k);
         }
         nover += __builtin_popcount(v & 0x40404040u);
         if (terminated_host) {
@@ -1009,7 +860,7 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
       // the one-contact-per-lane kernel holds (MIR_EXACT_HEAVY="enter,leave"; enter <= 0: never heavy).  The cost model behind the
       // defaults: a light step with a deferred list costs launch + list launch, a heavy one two rounds of the bigger kernel.
       if (h->pend_heavy) { h->ex_ovf_envs += (unsigned long long)nover; if (nover) h->ex_ovf_steps++; if ((unsigned long long)nover > h->ex_ovf_max) h->ex_ovf_max = nover; }
-      const int cnt = h->pend_heavy ? nover : ndefer + h->pend_early;
+      const int cnt = h->pend_heavy ? nover : ndefer;
       if (!h->heavy && h->heavy_enter > 0 && cnt >= h->heavy_enter) h->heavy = 1;
       else if (h->heavy && cnt < h->heavy_leave) h->heavy = 0;
       // the order of the NEXT heavy launch: the envs that were above 16 points in this step first (bit 6 of a heavy launch's bytes, bit
@@ -1033,16 +884,7 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
         h->perm_next = nxt;
       }
     }
-    TSTAMP(3);
-    if (ndefer || h->pend_early) {
-      const int rc = exact_finish(h, ndefer, terminated_host);
-      if (g_timing > 0)
-        fprintf(stderr, "[exact timing] early %d late %d main %d | collected %.1f, list launched %.1f, main launched %.1f, main bytes %.1f, list bytes %.1f, closed %.1f us\n", h->pend_early, ndefer,
-                h->B, g_tb[0], g_tb[5], g_tb[2], g_tb[3], g_tb[4], now_us() - g_t0);
-      return rc;
-    }
-    h->ovf_run = 0;
-    h->prev_nlb = 0;
+    if (ndefer) return exact_finish(h, ndefer, terminated_host);
     return MIR_OK;
   } else if (h->sync_mode == 3) {
     // the bytes announce themselves: wait until every one of them carries this launch's tag
@@ -1107,8 +949,6 @@ int mir_get_sync_mode(MirHandle h) { return check(h) ? MIR_E_INVALID : h->sync_m
 int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
   if (check(h)) return MIR_E_INVALID;
   if (h->pending) return set_err(MIR_E_INVALID, "mir_set_exact_contacts: a step is pending");
-  h->pre_valid = 0;  // (the scratch rows of envs that stay on a list say "deferred" and nothing else: they mean something to the launches of this mode only)
-  h->ovf_run = 0; h->next_ok = 0;
   if (!on) { h->exact = 0; return MIR_OK; }
   if (h->kernel != 16) return set_err(MIR_E_INVALID, "mir_set_exact_contacts: the scene already runs on the wave-per-env kernel (48 contact points, never thinned below that)");
   if (h->sync_mode != 3 || !h->term_wstride) return set_err(MIR_E_INVALID, "mir_set_exact_contacts: needs the tagged terminated bytes (sync mode 3)");
@@ -1154,32 +994,6 @@ int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
       h->ovf_stream = st; h->ovf_event = ev;
     }
   }
-  if (!h->next_host) {
-    // next-step words of the main launch + the ring of four list buffers (mir_scene.h)
-    DeviceGuard guard(h->device);
-    const size_t B = (size_t)h->B, nwb = ((B + 3) / 4 * 4 + 63) / 64 * 64, pad = (B + 63) / 64 * 64, one = B * sizeof(int32_t) + 2 * pad;
-    uint8_t* base = nullptr;
-    uint8_t* dbase = nullptr;
-    HIPCHK(hipHostMalloc((void**)&base, nwb + 4 * one, hipHostMallocMapped | hipHostMallocCoherent));
-    memset(base, 0, nwb + 4 * one);
-    HIPCHK(hipHostGetDevicePointer((void**)&dbase, base, 0));
-    h->next_host = reinterpret_cast<uint32_t*>(base); h->next_dev = reinterpret_cast<uint32_t*>(dbase);
-    for (int i = 0; i < 4; i++) {
-      uint8_t* hb = base + nwb + (size_t)i * one;
-      uint8_t* db = dbase + nwb + (size_t)i * one;
-      h->lb_list_host[i] = reinterpret_cast<int32_t*>(hb); h->lb_list_dev[i] = reinterpret_cast<int32_t*>(db);
-      h->lb_term_host[i] = hb + B * sizeof(int32_t); h->lb_term_dev[i] = db + B * sizeof(int32_t);
-      h->lb_next_host[i] = h->lb_term_host[i] + pad; h->lb_next_dev[i] = h->lb_term_dev[i] + pad;
-      h->lb_n[i] = 0;
-    }
-    h->listed = static_cast<uint8_t*>(calloc(B ? B : 1, 1));
-    if (!h->listed) return set_err(MIR_E_INVALID, "out of host memory");
-    hipEvent_t ev = nullptr;
-    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    h->main_event = ev;
-  }
-  h->lb_cur = 0; h->cur_nlb = 0; h->prev_nlb = 0; h->pend_early = 0; h->ovf_run = 0; h->next_ok = 0;
-  h->cap16 = h->hm.max_contacts < K16_MAX_CONTACT ? h->hm.max_contacts : K16_MAX_CONTACT;
   // the list instantiation of the 16-lane kernel takes the deferred envs where the scene has the split closing forward kinematics (every
   // free body a childless child of the world: the reference's scenes); MIR_EXACT_WAVE=1: the wave-per-env kernel takes them all (round 5)
   h->exact_big = (h->hm.fk_free_leaf != 0 && !(getenv("MIR_EXACT_WAVE") && atoi(getenv("MIR_EXACT_WAVE")) != 0)) ? 1 : 0;
@@ -1193,14 +1007,6 @@ int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
     const int k = sscanf(e, "%d,%d", &a, &b);
     if (k >= 1) { h->heavy_enter = a; h->heavy_leave = k >= 2 ? b : a / 2; }
   }
-  // known a step ahead (MIR_EXACT_EARLY=0: never): the flagged envs' launch goes out with mir_step_begin.  The heavy phase is then only
-  // entered on request (MIR_EXACT_HEAVY): a list launch beside the main launch costs the light envs 40 KB x 21 us of a CU each instead of
-  // the 80 KB x 35 us the three-contacts-per-lane launch of the whole batch does.
-  h->early = (h->exact_big && h->ovf_stream && on != 2) ? (getenv("MIR_EXACT_EARLY") ? atoi(getenv("MIR_EXACT_EARLY")) : 1) : 0;  // (2: the envs stay on the list, no launch at mir_step_begin)
-  // (with the list launch beside the main launch a step with a list of n envs costs about one pass of the list instantiation as long as
-  //  its n / 4 workgroups find slots as the main launch's first workgroups finish; the heavy phase -- two rounds of the bigger kernel for
-  //  the whole batch -- pays from about a quarter of the batch on)
-  if (h->early && !getenv("MIR_EXACT_HEAVY")) { h->heavy_enter = (h->B + 3) / 4; h->heavy_leave = (h->B + 7) / 8; }
   if (on == 2) h->heavy_enter = 0;  // (the twin of the tests: every env on the list instantiation, every step)
   return MIR_OK;
 }
@@ -1210,13 +1016,13 @@ int mir_get_exact_contacts(MirHandle h) { return check(h) ? MIR_E_INVALID : h->e
 int mir_get_exact_stats(MirHandle h, uint64_t* out4, int32_t reset) {
   if (check(h) || !out4) return set_err(MIR_E_INVALID, "mir_get_exact_stats: null argument");
   out4[0] = h->ex_steps; out4[1] = h->ex_ovf_steps; out4[2] = h->ex_ovf_envs; out4[3] = h->ex_ovf_max;
-  if (reset) h->ex_steps = h->ex_ovf_steps = h->ex_ovf_envs = h->ex_ovf_max = h->ex_big_envs = h->ex_wave_envs = h->ex_heavy_steps = h->ex_early_envs = 0;
+  if (reset) h->ex_steps = h->ex_ovf_steps = h->ex_ovf_envs = h->ex_ovf_max = h->ex_big_envs = h->ex_wave_envs = h->ex_heavy_steps = 0;
   return MIR_OK;
 }
 
 int mir_get_exact_route(MirHandle h, uint64_t* out2) {
   if (check(h) || !out2) return set_err(MIR_E_INVALID, "mir_get_exact_route: null argument");
-  out2[0] = h->ex_big_envs; out2[1] = h->ex_wave_envs; out2[2] = h->ex_heavy_steps; out2[3] = h->ex_early_envs;
+  out2[0] = h->ex_big_envs; out2[1] = h->ex_wave_envs; out2[2] = h->ex_heavy_steps;
   return MIR_OK;
 }
 /* debug aid (bench.py's roofline): n back-to-back launches of the rotated step kernel (what mir_step_begin launches in split mode 1)

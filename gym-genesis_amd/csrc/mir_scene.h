@@ -91,31 +91,6 @@ struct MirScene {
   void* pend_out[4];
   int pend_rotated;         // the pending step is ONE rotated launch (else: a launch followed by the first half of the next step for all envs)
   unsigned long long ex_steps, ex_ovf_steps, ex_ovf_envs, ex_ovf_max;  // steps closed / steps with deferred envs / deferred env-steps / most in one step
-  // EXACT CONTACTS, KNOWN A STEP AHEAD (round 6, mir_api.hip: early_collect).  A rotated launch ends with the collision detection of the
-  // NEXT step, so it can say which envs that step will defer: one tagged byte per env in `next_host` (a word per workgroup, pinned).  The
-  // list instantiation says the same for its envs (`lb_next`).  mir_step_begin reads them and launches the list instantiation for those
-  // envs on the side stream BESIDE the step's main launch (an "early list") instead of behind its terminated bytes; the envs above 16
-  // points STAY on the list from step to step without an action-independent half of their own (mir_step.hip: stay_h).
-  int early;                // the mechanism is on (list instantiation + side stream; MIR_EXACT_EARLY=0 switches it off)
-  int ovf_run;              // the step closed last had envs on a list: the next mir_step_begin consults the next-step bytes
-  int next_ok;              // ... and the pending / last main launch wrote them (a rotated launch with next_host set)
-  void* next_stream;        // the stream of that launch
-  uint32_t* next_host;      // pinned, device-mapped: (B + 3) / 4 words, contiguous
-  uint32_t* next_dev;
-  // a ring of four list buffers [list (B x i32) | terminated bytes (B, padded to 64) | next-step bytes (B, padded to 64)]: a step uses at
-  // most two (the early list of mir_step_begin, the late list of mir_step_end), and the next mir_step_begin reads the next-step bytes of both
-  int32_t* lb_list_host[4]; int32_t* lb_list_dev[4];
-  uint8_t* lb_term_host[4]; uint8_t* lb_term_dev[4];
-  uint8_t* lb_next_host[4]; uint8_t* lb_next_dev[4];
-  int lb_n[4];
-  int lb_cur;               // the buffer the next list takes
-  int cur_lb[2], cur_nlb;   // buffers of the pending step's list launches (early first)
-  int prev_lb[2], prev_nlb; // ... of the step closed last, when `ovf_run`
-  int pend_early;           // envs on the pending step's early list
-  int cap16;                // the one-contact-per-lane kernel's capacity as the launches see it (min(max_contacts, 16))
-  uint8_t* listed;          // (B) host: the env is on the pending step's early list
-  void* main_event;         // hipEvent_t: recorded on the step's stream behind the previous main launch, in front of this step's: an early list launch on the side stream waits for it
-  unsigned long long ex_early_envs;  // env-steps on early lists
 };
 
 // library-internal helpers implemented in mir_api.hip

@@ -67,10 +67,6 @@ struct StepArgs {
   int over_cap;  // phase 4 / 5 (three contacts per lane): bit 6 of an env's terminated byte says that it had more candidate points than this (0: never set)
   // phase 1 only: the launch serves the envs env_list[0 .. B) (B = the list's length) instead of envs 0 .. B; may point into pinned host memory
   const int32_t* env_list;
-  // exact contacts, phases 3 / 4: device address of pinned host words, one per workgroup -- byte k = what the NEXT step will do with the
-  // workgroup's env k (bit 0: defer it, it has more candidate points than the one-contact-per-lane kernel holds / it stays on the list;
-  // bit 7: no statement; bits 1 .. 5: term_tag) -- or null (mir_step.hip: next_emit)
-  uint32_t* next_host;
 };
 #define K16_PRE_MROW 0     /* 16 lanes x 16: rows of the regularised mass matrix */
 #define K16_PRE_BIAS 256   /* 16: qfrc_bias */

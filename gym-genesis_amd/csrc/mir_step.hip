@@ -1106,47 +1106,19 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       if (a.prof && threadIdx.x == 64 && (blockIdx.x & 7) == (unsigned)(prof_blk & 7)) atomicMax(&a.prof[31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
     };
-    // exact contacts, KNOWN A STEP AHEAD (StepArgs::next_host): the launch that ends with the action-independent half of the next step
-    // tells the host which envs that step will defer -- one tagged byte per env, a word per workgroup, in pinned memory (bit 0: more
-    // candidate points than the one-contact-per-lane kernel holds; bit 7: no statement -- the env was deferred by THIS launch, its rows
-    // are another launch's business) -- so that mir_step_begin can launch the list instantiation for them BESIDE the step's main launch
-    // instead of behind its terminated bytes.
-    auto next_emit = [&](bool flag, bool na) {
-      if (a.next_host) {
-        const unsigned long long fb = __ballot(flag && !na && valid && lane == 0), nb_ = __ballot(na && valid && lane == 0);
-        if (tid == 0) {
-          const uint32_t bits = (uint32_t)(fb & 1u) | (uint32_t)(fb >> 16 & 1u) << 8 | (uint32_t)(fb >> 32 & 1u) << 16 | (uint32_t)(fb >> 48 & 1u) << 24 |
-                                (uint32_t)(nb_ & 1u) << 7 | (uint32_t)(nb_ >> 16 & 1u) << 15 | (uint32_t)(nb_ >> 32 & 1u) << 23 | (uint32_t)(nb_ >> 48 & 1u) << 31;
-          __hip_atomic_store(a.next_host + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-    };
-    // (the list instantiation: an env that had more points than StepArgs::over_cap at the START of this step STAYS on the list for the
-    //  next one -- no action-independent half is computed for it here, its scratch row says "deferred" -- and a workgroup all of whose
-    //  envs stay leaves after the first pass.  An env with at most 16 points is stepped by this instantiation bit for bit as by the
-    //  one-contact-per-lane kernel, so staying a step too long changes nothing but the cost.)
-    bool stay_h = false;
-    auto stay_head = [&]() {
-      if (valid && stay_h && lane == 0)
-        *reinterpret_cast<f4*>(a.pre + (size_t)env * K16_PRE_STRIDE + K16_PRE_HEAD) = f4{__int_as_float(0), __int_as_float((int)(255u << 20)), 0.0f, 0.0f};
-    };
     helper_cinert(1);
     const int cnt = collide_detect(1);
     HSTAMP(42);
     const int pts0 = contacts_build(cnt, PRE || ROT || BIGV);  // (three contacts per lane: the main wave shares the Jacobian build in every pass)  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
     if (BIGV) ovf_h = pts0 > defer_above;  // (beyond this instantiation's capacity too: nothing is stored for the env, the wave-per-env kernel takes it)
-    if (BIG2) stay_h = a.over_cap > 0 && pts0 > a.over_cap && !ovf_h;
-    const bool skip2 = BIG2 && !__any(valid && !ovf_h && !stay_h);  // (wave-uniform; the main wave decides the same from the `coupled` word)
     HSTAMP(45);
     __syncthreads();  // (3) contact arrays and base Jacobians handed to the main wave
     HSTAMP(46);
     {
       if (PRE || ROT) {
-        if (ROT) next_emit(pts0 > defer_above, ovf_h);
         pre_store();
         return;
       }
-      if (BIG2 && skip2) { next_emit(stay_h, ovf_h); stay_head(); }
       float hp[G];
       hess_full(hp, S.ncon);
 #pragma unroll
@@ -1166,16 +1138,13 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     if constexpr (BIG2) {
       // the list instantiation goes on like the rotated launch: the closing FK above is the opening FK of the next step, whose
       // action-independent half follows (host side: only scenes with the split closing FK take this instantiation)
-      if (skip2) return;  // (every env of the workgroup stays on the list: see stay_h)
       HSTAMP(142);
       prof_mute = true;
       helper_cinert(2);
       const int cnt2 = collide_detect(2);
-      const int pts1 = contacts_build(cnt2, true);
+      contacts_build(cnt2, true);
       __syncthreads();  // (3) of the second pass
-      next_emit(stay_h || (a.over_cap > 0 && pts1 > a.over_cap), ovf_h);
-      if (stay_h) stay_head();
-      else pre_store();
+      pre_store();
 #ifdef MIR_PROFILE_SINGLE
       if (a.prof && (int)blockIdx.x == prof_blk && threadIdx.x == 64) a.prof[141] = __builtin_readcyclecounter();
 #endif
@@ -2273,12 +2242,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     return 0;
   };  // step_body
   if constexpr (ROT || BIG2) {
-    if (step_body(std::integral_constant<int, 0>{}) == 0) {
-      // (the list instantiation: a workgroup all of whose envs stay on the list -- or are beyond this instantiation too -- has no
-      //  action-independent half to compute; the collision wave decides the same from the same count)
-      if (BIG2 && !__any(valid && !ovf_env && !over_env)) return;
-      step_body(std::integral_constant<int, 1>{});
-    }
+    if (step_body(std::integral_constant<int, 0>{}) == 0) step_body(std::integral_constant<int, 1>{});
   } else if constexpr (SINGLE) {
     if (step_body(std::integral_constant<int, 0>{}) == 2) return;
     emit_outputs();
