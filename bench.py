@@ -840,7 +840,7 @@ def ik_bench(torch, dev, calls: int = 200):
     # row, which is not counted; the launch lasts as long as its slowest wave (`iters_wave_max`), the chip idles behind the mean
     f_iter = 1.7e3
     flops = f_iter * float(it.sum())
-    return {"workload": "robot.inverse_kinematics(hand, pos, quat) from the home pose, num_envs=4096, <= 32 Levenberg-Marquardt iterations",
+    return {"workload": "robot.inverse_kinematics(hand, pos, quat) from the home pose, num_envs=4096, <= 20 Levenberg-Marquardt iterations",
             "env_solves_per_s": B / (us * 1e-6), "us_per_call": us, "converged_frac": float(((err[:, 0] < 5e-4) & (err[:, 1] < 5e-3)).float().mean().item()),
             "iters_mean": float(it.mean()), "iters_wave_max": int(it.max()),
             "roofline_valu": {"bound": "valu_fp32", "achieved": flops / (us * 1e-6) / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

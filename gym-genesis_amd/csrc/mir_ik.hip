@@ -6,7 +6,7 @@
 //
 // Mapping: like the pick kernel, 16 lanes per env (4 envs per wave64, one DPP row each); lane j owns element j of the
 // kinematic chain world -> link (<= 16 bodies): its local joint transform, its world pose (prefix of the chain by a log-step DPP
-// scan: no depth-serial barriers, no LDS round trips), its Jacobian column.  J J^T + lambda^2 I (6 x 6, symmetric: 21 DPP row
+// scan: no depth-serial barriers, no LDS at all since round 6), its Jacobian column.  J J^T + lambda^2 I (6 x 6, symmetric: 21 DPP row
 // reductions) ends up in every lane's registers and each lane solves it redundantly (Cholesky, fully unrolled), so the
 // update dq_j = J_j . y needs no further communication.  The chain description travels in the kernel arguments
 // (built on the host per call: the link is a run-time argument).
@@ -40,26 +40,28 @@ struct IkArgs {
   int arm_qadr[MIR_MAX_DOF]; // qpos address of scalar joint k in the scene row
   float* qpos_out;           // (B,n_arm)
   float* err_out;            // (B,2) or null
-  int32_t* iters_out;        // (B) or null: iterations the env took (debug: mir_debug_ik_iters)
+  int32_t* iters_out;        // (rows) or null: iterations the row took (debug: mir_debug_ik_iters)
+  // rows (mir_inverse_kinematics_rows): row k of the outputs belongs to env env_idx[k] (null: env k); the inputs are addressed by row,
+  // or by env (the *_by_env flags), the quaternion possibly ONE for all rows; init_qpos holds init_ncols columns from init_col0 on
+  const long long* env_idx;
+  int n_rows, pos_by_env, quat_by_env, quat_one, init_by_env, init_col0, init_ncols;
   int B, max_iters, respect_limits;
   float inv_pos_tol, inv_rot_tol;
   float damping2, pos_tol, rot_tol, max_step;
 };
 
-struct IkLds {
-  float xpos[G][4], xquat[G][4];
-};
-
 __device__ __forceinline__ Q4 qconj(Q4 q) { return {q.w, -q.x, -q.y, -q.z}; }
 
 __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
-  __shared__ __attribute__((aligned(16))) IkLds s_env[4];
   const int tid = threadIdx.x, lane = tid & 15, grp = tid >> 4;
-  const int env_raw = blockIdx.x * 4 + grp;
-  const bool valid = env_raw < a.B;
-  const int env = valid ? env_raw : a.B - 1;
-  IkLds& S = s_env[grp];
+  const int row_raw = blockIdx.x * 4 + grp;
+  const bool valid = row_raw < a.n_rows;
+  const int row = valid ? row_raw : a.n_rows - 1;
+  int env = a.env_idx ? (int)a.env_idx[row] : row;
+  env = env < 0 ? 0 : (env >= a.B ? a.B - 1 : env);  // (an index outside the batch is clamped, not followed: the caller's side checks it)
+  const int prow = a.pos_by_env ? env : row, qrow = a.quat_one ? 0 : (a.quat_by_env ? env : row), irow = a.init_by_env ? env : row;
   const int n = a.ch.n;
+  const int eef4 = ((tid & ~15) + n - 1) << 2;  // (lane_gather address of the chain's last element in this env's row)
   const bool onchain = lane < n;
   const int jt = onchain ? a.ch.jtype[lane] : MIR_JNT_FIXED, qc = onchain ? a.ch.qcol[lane] : -1;
   const V3 bpos = ld3(a.ch.pos[lane]), baxis = ld3(a.ch.axis[lane]);
@@ -68,19 +70,23 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
   const float lo = a.ch.lo[lane], hi = a.ch.hi[lane];
   const bool lim = moving && a.ch.limited[lane] && a.respect_limits;
   // seed: every scalar joint (the result keeps the seed outside the chain)
+  auto seed = [&](int k) -> float {
+    const bool from_init = a.init_qpos && k >= a.init_col0 && k < a.init_col0 + a.init_ncols;
+    return from_init ? a.init_qpos[(size_t)irow * a.init_ncols + (k - a.init_col0)] : a.scene_qpos[(size_t)env * a.qst + a.arm_qadr[k]];
+  };
   for (int k = lane; k < a.n_arm; k += G) {
-    const float v = a.init_qpos ? a.init_qpos[(size_t)env * a.n_arm + k] : a.scene_qpos[(size_t)env * a.qst + a.arm_qadr[k]];
-    if (valid) a.qpos_out[(size_t)env * a.n_arm + k] = v;
+    const float v = seed(k);
+    if (valid) a.qpos_out[(size_t)row * a.n_arm + k] = v;
   }
   float q = 0.0f;
-  if (moving) q = a.init_qpos ? a.init_qpos[(size_t)env * a.n_arm + qc] : a.scene_qpos[(size_t)env * a.qst + a.arm_qadr[qc]];
-  const V3 tp = ld3(a.target_pos + (size_t)env * 3);
+  if (moving) q = seed(qc);
+  const V3 tp = ld3(a.target_pos + (size_t)prow * 3);
   const bool userot = a.target_quat != nullptr;
-  const Q4 tq = userot ? qnormalize(ld4(a.target_quat + (size_t)env * 4)) : Q4{1, 0, 0, 0};
+  const Q4 tq = userot ? qnormalize(ld4(a.target_quat + (size_t)qrow * 4)) : Q4{1, 0, 0, 0};
   bool done = false;
   int stall = 0, my_iters = 0;
   // the ACCEPTED iterate (Levenberg - Marquardt acceptance, include/mirigid.h): this lane's joint angle, Jacobian column; the env's
-  // task-space error and scaled error (identical in all of its lanes: they are computed from the same LDS reads)
+  // task-space error and scaled error (identical in all of its lanes: they are computed from the same gathered values)
   float q_acc = q, lam2 = a.damping2, m_acc = 0.0f, epn = 0.0f, ern = 0.0f;
   const float lam2_min = a.damping2 * (1.0f / 256.0f), lam2_max = a.damping2 * 64.0f;
   float J[6] = {0, 0, 0, 0, 0, 0}, e[6] = {0, 0, 0, 0, 0, 0};
@@ -116,15 +122,11 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
       IK_SCAN_STEP(4)
       IK_SCAN_STEP(8)
 #undef IK_SCAN_STEP
-      if (onchain) {
-        st3v(S.xpos[lane], P);
-        st4v(S.xquat[lane], Qx);
-      }
     }
-    WSYNC();
-    // ---- task-space error of the candidate (every lane, redundantly)
-    const V3 pe = ld3v(S.xpos[n - 1]);
-    const Q4 qe = ld4v(S.xquat[n - 1]);
+    // ---- task-space error of the candidate (every lane, redundantly): the pose of the chain's last element comes over the crossbar
+    // (seven lane gathers, one trip; round 5 went through LDS: a store, a fence and a load per iteration of a chain that is all latency)
+    const V3 pe = v3(lane_gather(eef4, P.x), lane_gather(eef4, P.y), lane_gather(eef4, P.z));
+    const Q4 qe = Q4{lane_gather(eef4, Qx.w), lane_gather(eef4, Qx.x), lane_gather(eef4, Qx.y), lane_gather(eef4, Qx.z)};
     const V3 ep = tp - pe;
     V3 er = v3(0, 0, 0);
     if (userot) {
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
         // my Jacobian column at the accepted iterate (joint frame = my world pose)
         V3 jv = v3(0, 0, 0), jw = v3(0, 0, 0);
         if (moving) {
-          const V3 axw = qrot(ld4v(S.xquat[lane]), baxis);
-          if (jt == MIR_JNT_REVOLUTE) { jw = axw; jv = cross(axw, pe - ld3v(S.xpos[lane])); }
+          const V3 axw = qrot(Qx, baxis);
+          if (jt == MIR_JNT_REVOLUTE) { jw = axw; jv = cross(axw, pe - P); }
           else jv = axw;
         }
         J[0] = jv.x; J[1] = jv.y; J[2] = jv.z; J[3] = userot ? jw.x : 0.0f; J[4] = userot ? jw.y : 0.0f; J[5] = userot ? jw.z : 0.0f;
@@ -218,22 +220,24 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
       q = q_acc + sc * dq;
       if (lim) q = fminf(fmaxf(q, lo), hi);
     }
-    WSYNC();
   }
   q = q_acc;
-  if (valid && moving) a.qpos_out[(size_t)env * a.n_arm + qc] = q;
-  if (valid && a.iters_out && lane == 0) a.iters_out[env] = my_iters;
+  if (valid && moving) a.qpos_out[(size_t)row * a.n_arm + qc] = q;
+  if (valid && a.iters_out && lane == 0) a.iters_out[row] = my_iters;
   if (valid && a.err_out && lane == 0) {
-    a.err_out[(size_t)env * 2] = epn;
-    a.err_out[(size_t)env * 2 + 1] = ern;
+    a.err_out[(size_t)row * 2] = epn;
+    a.err_out[(size_t)row * 2 + 1] = ern;
   }
 }
 
 }  // namespace
 
-extern "C" int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_pos, const float* target_quat, const float* init_qpos,
-                                      const MirIkOptions* opt, float* qpos_out, float* err_out, void* stream) {
+extern "C" int mir_inverse_kinematics_rows(MirHandle h, int32_t link_body, const MirIkRows* rows, const float* target_pos, const float* target_quat,
+                                           const float* init_qpos, const MirIkOptions* opt, float* qpos_out, float* err_out, void* stream) {
   if (!h || !target_pos || !qpos_out) return mir_set_error(MIR_E_INVALID, "mir_inverse_kinematics: null argument");
+  if (rows && (rows->n_rows < 0 || (rows->flags & ~(uint32_t)(MIR_IK_POS_BY_ENV | MIR_IK_QUAT_BY_ENV | MIR_IK_QUAT_ONE | MIR_IK_INIT_BY_ENV))))
+    return mir_set_error(MIR_E_INVALID, "mir_inverse_kinematics_rows: bad row description");
+  if (rows && rows->n_rows == 0) return MIR_OK;
   if (link_body <= 0 || link_body >= h->nbody) return mir_set_error(MIR_E_INVALID, "mir_inverse_kinematics: link out of range");
   IkArgs a;
   memset(&a, 0, sizeof a);
@@ -273,24 +277,40 @@ extern "C" int mir_inverse_kinematics(MirHandle h, int32_t link_body, const floa
     a.ch.jtype[i] = jt;
     a.ch.qcol[i] = col_of_body[b];
   }
-  MirIkOptions o = {32, 1, 0.05, 5e-4, 5e-3, 0.5};
+  MirIkOptions o = {20, 1, 0.05, 5e-4, 5e-3, 0.5};
   if (opt) {
     o = *opt;
     if (o.max_iters <= 0 || !(o.damping > 0.0) || !(o.max_step > 0.0)) return mir_set_error(MIR_E_INVALID, "mir_inverse_kinematics: bad options");
   }
   a.target_pos = target_pos; a.target_quat = target_quat; a.init_qpos = init_qpos; a.scene_qpos = h->qpos;
   a.qst = h->pt.qst; a.n_arm = narm; a.qpos_out = qpos_out; a.err_out = err_out; a.B = h->B;
+  a.n_rows = h->B; a.init_col0 = 0; a.init_ncols = narm;
+  if (rows) {
+    a.env_idx = reinterpret_cast<const long long*>(rows->env_idx);
+    a.n_rows = rows->env_idx ? rows->n_rows : h->B;
+    a.pos_by_env = (rows->flags & MIR_IK_POS_BY_ENV) ? 1 : 0; a.quat_by_env = (rows->flags & MIR_IK_QUAT_BY_ENV) ? 1 : 0;
+    a.quat_one = (rows->flags & MIR_IK_QUAT_ONE) ? 1 : 0; a.init_by_env = (rows->flags & MIR_IK_INIT_BY_ENV) ? 1 : 0;
+    if (rows->init_ncols > 0) {
+      if (rows->init_col0 < 0 || rows->init_col0 + rows->init_ncols > narm) return mir_set_error(MIR_E_INVALID, "mir_inverse_kinematics_rows: init columns outside the joint row");
+      a.init_col0 = rows->init_col0; a.init_ncols = rows->init_ncols;
+    }
+  }
   a.iters_out = h->dbg_ik_iters;
   a.max_iters = o.max_iters; a.respect_limits = o.respect_joint_limit;
   a.damping2 = (float)(o.damping * o.damping); a.pos_tol = (float)o.pos_tol; a.rot_tol = (float)o.rot_tol; a.inv_pos_tol = (float)(1.0 / o.pos_tol); a.inv_rot_tol = (float)(1.0 / o.rot_tol); a.max_step = (float)o.max_step;
   int prev = -1;
   (void)hipGetDevice(&prev);
   if (prev != h->device) (void)hipSetDevice(h->device);
-  hipLaunchKernelGGL(mir_ik_kernel, dim3((h->B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mir_ik_kernel, dim3((a.n_rows + 3) / 4), dim3(64), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   if (prev != h->device && prev >= 0) (void)hipSetDevice(prev);
   if (e != hipSuccess) return mir_set_error(MIR_E_HIP, hipGetErrorString(e));
   return MIR_OK;
+}
+
+extern "C" int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_pos, const float* target_quat, const float* init_qpos,
+                                      const MirIkOptions* opt, float* qpos_out, float* err_out, void* stream) {
+  return mir_inverse_kinematics_rows(h, link_body, nullptr, target_pos, target_quat, init_qpos, opt, qpos_out, err_out, stream);
 }
 
 /* debug aid (tools/probes/ik_iters.py): every following mir_inverse_kinematics call also writes the iterations each env took into

@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .spec import IK_DEFAULTS, MIR_VERSION, MirCameraSpec, MirDims, MirIkOptions, MirSceneSpec, MirVisualSpec
+from .spec import IK_DEFAULTS, MIR_VERSION, MirCameraSpec, MirDims, MirIkOptions, MirIkRows, MirSceneSpec, MirVisualSpec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libmirigid.so"))
@@ -113,6 +113,8 @@ def load_library() -> C.CDLL:
     lib.mir_render_cams.restype = C.c_int
     lib.mir_inverse_kinematics.argtypes = [vp, i32, vp, vp, vp, C.POINTER(MirIkOptions), vp, vp, vp]
     lib.mir_inverse_kinematics.restype = C.c_int
+    lib.mir_inverse_kinematics_rows.argtypes = [vp, i32, C.POINTER(MirIkRows), vp, vp, vp, C.POINTER(MirIkOptions), vp, vp, vp]
+    lib.mir_inverse_kinematics_rows.restype = C.c_int
     for name in ("mir_create", "mir_destroy", "mir_get_dims", "mir_get_model_consts", "mir_reset", "mir_autoreset", "mir_set_pd_targets",
                  "mir_step", "mir_step_fused", "mir_get_obs", "mir_get_state", "mir_set_state", "mir_get_links",
                  "mir_get_diag", "mir_forward"):
@@ -645,4 +647,21 @@ class MirScene(StepHelpers):
         out, err = self.empty(self.n_arm), self.empty(2)
         self._check(self.lib.mir_inverse_kinematics(self.h, int(link_body), _ptr(p), _ptr(q), _ptr(init), C.byref(o), _ptr(out), _ptr(err),
                                                     self._stream()))
+        return (out, err) if return_error else out
+
+    def inverse_kinematics_rows(self, link_body: int, pos, quat, init_qpos, env_idx, flags: int, init_col0: int = 0, init_ncols: int = 0,
+                                return_error: bool = False, **opts):
+        """mir_inverse_kinematics_rows: the solver for the rows `env_idx` (int64 device tensor, or None: every env) in ONE launch.
+        pos / quat / init_qpos: contiguous float32 device tensors addressed as `flags` say (spec.IK_*); -> (n_rows, n_arm)[, (n_rows, 2)]."""
+        n = self.num_envs if env_idx is None else int(env_idx.numel())
+        o = self.__dict__.get("_ik_default")
+        if opts or o is None:
+            o = MirIkOptions(**{**IK_DEFAULTS, **opts})
+            if not opts:
+                self._ik_default = o
+        rows = MirIkRows(None if env_idx is None else env_idx.data_ptr(), n, int(flags), int(init_col0), int(init_ncols))
+        out = torch.empty((n, self.n_arm), dtype=torch.float32, device=self.device)
+        err = torch.empty((n, 2), dtype=torch.float32, device=self.device) if return_error else None
+        self._check(self.lib.mir_inverse_kinematics_rows(self.h, int(link_body), C.byref(rows), _ptr(pos), _ptr(quat), _ptr(init_qpos), C.byref(o),
+                                                         _ptr(out), _ptr(err), self._stream()))
         return (out, err) if return_error else out

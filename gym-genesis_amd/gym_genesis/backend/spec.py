@@ -181,7 +181,20 @@ class MirIkOptions(C.Structure):
     ]
 
 
-IK_DEFAULTS = dict(max_iters=32, respect_joint_limit=1, damping=0.05, pos_tol=5e-4, rot_tol=5e-3, max_step=0.5)
+class MirIkRows(C.Structure):
+    """include/mirigid.h: MirIkRows (mir_inverse_kinematics_rows)"""
+    _fields_ = [
+        ("env_idx", C.c_void_p),
+        ("n_rows", C.c_int32),
+        ("flags", C.c_uint32),
+        ("init_col0", C.c_int32),
+        ("init_ncols", C.c_int32),
+    ]
+
+
+IK_POS_BY_ENV, IK_QUAT_BY_ENV, IK_QUAT_ONE, IK_INIT_BY_ENV = 1, 2, 4, 8
+
+IK_DEFAULTS = dict(max_iters=20, respect_joint_limit=1, damping=0.05, pos_tol=5e-4, rot_tol=5e-3, max_step=0.5)
 
 RENDER_PER_ENV, RENDER_GLOBAL = 0, 1
 

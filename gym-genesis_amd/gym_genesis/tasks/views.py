@@ -28,6 +28,13 @@ def _rows(t: torch.Tensor, envs_idx) -> torch.Tensor:
     return t.index_select(0, torch.as_tensor(envs_idx, device=t.device).long().reshape(-1))
 
 
+# robot.inverse_kinematics as ONE launch (mir_inverse_kinematics_rows); False: the full-batch launch with torch scatter / gather around it
+IK_ROWS = True
+# (an index outside the batch is clamped by the kernel; checking it here would cost a device -> host synchronisation per call)
+CHECK_IK_IDX = False
+from ..backend.spec import IK_INIT_BY_ENV, IK_POS_BY_ENV, IK_QUAT_BY_ENV, IK_QUAT_ONE  # noqa: E402
+
+
 class LinkView:
     def __init__(self, mir, body_index: int, name: str):
         self._mir, self.idx, self.name = mir, body_index, name
@@ -103,6 +110,34 @@ class EntityView:
         mir = self._mir
         B = mir.num_envs
         idx = None if envs_idx is None else torch.as_tensor(envs_idx, device=mir.device).long().reshape(-1)
+        qc = self._qcols
+        if IK_ROWS and hasattr(mir, "inverse_kinematics_rows") and qc == list(range(qc[0], qc[0] + len(qc))):
+            # ONE launch (mir_inverse_kinematics_rows): the kernel addresses targets and seeds by row or by env itself and writes row k for
+            # env envs_idx[k] -- what the scatter / clone / gather around the full-batch launch below did with five torch kernels
+            n = B if idx is None else int(idx.numel())
+
+            def arg(t, k, by_env_flag):
+                t = torch.as_tensor(t, dtype=torch.float32, device=mir.device)
+                if k == 4 and (t.numel() == 4 or (t.dim() == 2 and t.stride(0) == 0)):  # (one quaternion, e.g. `.expand(B, -1)`: read in place)
+                    return (t.reshape(-1, 4)[0] if t.numel() == 4 else t[0]).contiguous(), IK_QUAT_ONE
+                t = t.reshape(-1, k).contiguous()
+                if t.shape[0] == B:
+                    return t, by_env_flag
+                if t.shape[0] != n:
+                    raise ValueError(f"inverse_kinematics: expected {n} or {B} rows of {k}, got {tuple(t.shape)}")
+                return t, 0
+
+            p, fp = arg(pos, 3, IK_POS_BY_ENV)
+            q, fq = (None, 0) if quat is None else arg(quat, 4, IK_QUAT_BY_ENV)
+            iq, fi = (None, 0) if init_qpos is None else arg(init_qpos, len(qc), IK_INIT_BY_ENV)
+            if CHECK_IK_IDX and idx is not None and bool(((idx < 0) | (idx >= B)).any()):
+                raise IndexError("inverse_kinematics: envs_idx outside the batch")
+            res = mir.inverse_kinematics_rows(link.idx, p, q, iq, None if idx is None else idx.contiguous(), fp | fq | fi, qc[0], len(qc) if iq is not None else 0,
+                                              return_error=return_error, **opts)
+            qout, err = (res if return_error else (res, None))
+            if len(qc) != qout.shape[1]:
+                qout = qout[:, qc[0]:qc[0] + len(qc)].contiguous()
+            return (qout, err) if return_error else qout
 
         def full(t, k):
             """-> (tensor of B rows, owned): owned = a tensor made here (rows scattered to `idx`), which may be edited in place; a

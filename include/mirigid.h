@@ -450,7 +450,7 @@ int mir_render_cams(MirHandle h, const MirCameraSpec* cam, const MirVisualSpec* 
  *     clamped to the joint ranges (respect_joint_limit).  The result is q_acc.
  * Only the scalar joints on the chain world -> link move; every other entry of the result is the seed. */
 typedef struct MirIkOptions {
-  int32_t max_iters;           /* default 32 */
+  int32_t max_iters;           /* default 20 (Genesis's max_solver_iters, recalled: the package is not in /root/reference; 32 until round 6) */
   int32_t respect_joint_limit; /* default 1 */
   double damping;              /* default 0.05 */
   double pos_tol, rot_tol;     /* defaults 5e-4 m, 5e-3 rad */
@@ -462,6 +462,28 @@ typedef struct MirIkOptions {
  * final |e_pos|, |e_rot|.  The scene state is not modified. */
 int mir_inverse_kinematics(MirHandle h, int32_t link_body, const float* target_pos, const float* target_quat, const float* init_qpos,
                            const MirIkOptions* opt, float* qpos_out, float* err_out, void* stream);
+
+/* The same solver for a LIST OF ROWS: robot.inverse_kinematics(link, pos, quat, init_qpos=..., envs_idx=idx) as the reference's experts
+ * call it on every step of their loops (examples/franka/pick_cube_state.py:46-51 with envs_idx = arange(B) and ONE quaternion expanded
+ * to the batch; examples/so_101/collect_task_stack_cube_batch.py:90-95 with init_qpos of the arm's columns) in ONE launch -- no
+ * scatter of the targets to batch rows in front of it, no gather of the result rows behind it.  Row k of qpos_out (n_rows, n_arm) /
+ * err_out (n_rows, 2) belongs to env env_idx[k] (int64, device; NULL: n_rows = num_envs, row k = env k; an index outside the batch is
+ * clamped).  flags say how the inputs are addressed: by row k -- (n_rows, .) arrays -- unless MIR_IK_POS_BY_ENV / MIR_IK_QUAT_BY_ENV /
+ * MIR_IK_INIT_BY_ENV ((num_envs, .) arrays, row of the env); MIR_IK_QUAT_ONE: target_quat is one quaternion for every row.
+ * init_qpos holds init_ncols columns of the joint row starting at init_col0 (0, 0: all n_arm columns); the other joints are seeded from
+ * the scene state.  rows == NULL: mir_inverse_kinematics. */
+#define MIR_IK_POS_BY_ENV 1u
+#define MIR_IK_QUAT_BY_ENV 2u
+#define MIR_IK_QUAT_ONE 4u
+#define MIR_IK_INIT_BY_ENV 8u
+typedef struct MirIkRows {
+  const int64_t* env_idx;  /* device, n_rows entries, or NULL */
+  int32_t n_rows;
+  uint32_t flags;
+  int32_t init_col0, init_ncols;
+} MirIkRows;
+int mir_inverse_kinematics_rows(MirHandle h, int32_t link_body, const MirIkRows* rows, const float* target_pos, const float* target_quat,
+                                const float* init_qpos, const MirIkOptions* opt, float* qpos_out, float* err_out, void* stream);
 
 /* ---- multi-GPU observation gather on the copy path (no reference counterpart: README.md:41-48 is single-device) ----
  * One process per GPU; every rank owns a receive buffer that the other ranks have mapped through HIP IPC (the host side does the

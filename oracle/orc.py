@@ -160,7 +160,7 @@ class Oracle:
                                  term[e:e + 1].ctypes.data_as(C.c_void_p))
         return agent, env, rew, term
 
-    def ik(self, link: int, target_pos, target_quat=None, init_q=None, max_iters=32, damping=0.05, pos_tol=5e-4, rot_tol=5e-3,
+    def ik(self, link: int, target_pos, target_quat=None, init_q=None, max_iters=20, damping=0.05, pos_tol=5e-4, rot_tol=5e-3,
            max_step=0.5, respect_limits=True):
         """Damped-least-squares IK of include/mirigid.h on the oracle's own kinematics, one env at a time.
         target_pos (B,3), target_quat (B,4) or None, init_q (B,n_arm).  Returns (q (B,n_arm), err (B,2))."""

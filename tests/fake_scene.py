@@ -148,7 +148,7 @@ class OracleScene(StepHelpers):
 
     def inverse_kinematics(self, link_body, pos, quat=None, init_qpos=None, return_error=False, **opts):
         init = self.get_state()[0][:, :self.n_arm].numpy() if init_qpos is None else self._np(init_qpos)
-        kw = dict(max_iters=opts.get("max_iters", 32), damping=opts.get("damping", 0.05), pos_tol=opts.get("pos_tol", 5e-4),
+        kw = dict(max_iters=opts.get("max_iters", 20), damping=opts.get("damping", 0.05), pos_tol=opts.get("pos_tol", 5e-4),
                   rot_tol=opts.get("rot_tol", 5e-3), max_step=opts.get("max_step", 0.5), respect_limits=bool(opts.get("respect_joint_limit", 1)))
         q, err = self.o.ik(int(link_body), self._np(pos), None if quat is None else self._np(quat), init, **kw)
         q, err = torch.from_numpy(q.astype(np.float32)), torch.from_numpy(err.astype(np.float32))

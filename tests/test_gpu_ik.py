@@ -92,3 +92,56 @@ def test_expert_pick_and_stack_end_to_end_on_device():
     final, ever = stack_expert.run(B=32, seed=1, verbose=False, grasp_dz=0.058, place_dz=0.104)
     assert final > 0.8, f"only {final:.2f} of the envs ended with cube_1 stacked on cube_2"
     print(f"expert pick-and-stack with on-device IK: {final * 100:.0f} % stacked at the end ({ever * 100:.0f} % at some point)")
+
+
+def test_ik_rows_one_launch_equals_the_full_batch_launch_bit_for_bit():
+    """robot.inverse_kinematics as the reference's experts call it (envs_idx = arange(B) with one quaternion expanded to the batch,
+    /root/reference/examples/franka/pick_cube_state.py:46-51; init_qpos chained, envs_idx a tensor or a NumPy array,
+    /root/reference/examples/so_101/collect_task_stack_cube_batch.py:90-95) is ONE launch of mir_inverse_kinematics_rows; the same
+    arguments through the full-batch launch with torch scatter / gather around it (round 5's wrapper) give the same bits -- for every way
+    the arguments can be addressed: by env, by row of a subset, a permutation of the batch, a broadcast quaternion, seeds for the arm's
+    columns."""
+    from gym_genesis.env import GenesisEnv
+    from gym_genesis.tasks import views
+
+    B = 256
+    env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False)
+    obs, _ = env.reset(seed=3)
+    robot = env.get_robot()
+    eef = robot.get_link("hand")
+    dev = obs["agent_pos"].device
+    g = torch.Generator(device="cpu").manual_seed(0)
+    cube = obs["environment_state"][:, :3]
+    pos_full = (cube + torch.tensor([0.0, 0.0, 0.2], device=dev)).contiguous()
+    one = torch.tensor([0.0, 1.0, 0.0, 0.0], device=dev)
+    quat_full = one.repeat(B, 1)
+    quat_full[:, 1] += 0.1 * torch.rand(B, generator=g).to(dev)   # (not normalised: the kernel normalises)
+    seed_full = robot.get_qpos() + 0.05 * torch.rand(B, 9, generator=g).to(dev)
+    sub = torch.tensor([5, 0, 200, 17, 255, 3, 3], device=dev)     # (a repeated index: two rows of the same env)
+    perm = torch.randperm(B, generator=g).to(dev)
+    cases = [
+        dict(pos=pos_full, quat=one.expand(B, -1), envs_idx=torch.arange(B, device=dev)),
+        dict(pos=pos_full, quat=quat_full),
+        dict(pos=pos_full, quat=None, init_qpos=seed_full),
+        dict(pos=pos_full[sub], quat=quat_full[sub], envs_idx=sub),
+        dict(pos=pos_full, quat=one, envs_idx=sub, init_qpos=seed_full[sub]),
+        dict(pos=pos_full[sub], quat=quat_full, envs_idx=sub.cpu().numpy(), init_qpos=seed_full),
+        dict(pos=pos_full, quat=quat_full, envs_idx=perm, init_qpos=seed_full),
+        dict(pos=pos_full.cpu().numpy(), quat=[0.0, 1.0, 0.0, 0.0], envs_idx=list(range(B))),
+    ]
+    for i, kw in enumerate(cases):
+        views.IK_ROWS = True
+        q1, e1 = robot.inverse_kinematics(link=eef, return_error=True, **kw)
+        views.IK_ROWS = False
+        try:
+            kw2 = dict(kw)
+            if kw2.get("quat") is not None and torch.as_tensor(kw2["quat"]).numel() == 4:   # (the old wrapper wants a row per env / per index)
+                n = B if kw2.get("envs_idx") is None else len(kw2["envs_idx"])
+                kw2["quat"] = torch.as_tensor(kw2["quat"], dtype=torch.float32, device=dev).reshape(1, 4).repeat(n, 1)
+            q0, e0 = robot.inverse_kinematics(link=eef, return_error=True, **kw2)
+        finally:
+            views.IK_ROWS = True
+        assert q1.shape == q0.shape and torch.equal(q1, q0), f"case {i}: joint rows differ"
+        assert torch.equal(e1, e0), f"case {i}: errors differ"
+    with pytest.raises(ValueError):
+        robot.inverse_kinematics(link=eef, pos=pos_full[:5], quat=one, envs_idx=sub)
