@@ -163,14 +163,15 @@ class Oracle:
     def ik(self, link: int, target_pos, target_quat=None, init_q=None, max_iters=20, damping=0.05, pos_tol=5e-4, rot_tol=5e-3,
            max_step=0.5, respect_limits=True):
         """Damped-least-squares IK of include/mirigid.h on the oracle's own kinematics, one env at a time.
-        target_pos (B,3), target_quat (B,4) or None, init_q (B,n_arm).  Returns (q (B,n_arm), err (B,2))."""
-        tp = np.ascontiguousarray(target_pos, dtype=np.float64).reshape(self.B, 3)
-        tq = None if target_quat is None else np.ascontiguousarray(target_quat, dtype=np.float64).reshape(self.B, 4)
-        q = np.ascontiguousarray(init_q, dtype=np.float64).reshape(self.B, -1).copy()
-        err = np.zeros((self.B, 2))
+        target_pos (n,3), target_quat (n,4) or None, init_q (n,n_arm).  Returns (q (n,n_arm), err (n,2))."""
+        tp = np.ascontiguousarray(target_pos, dtype=np.float64).reshape(-1, 3)
+        n = tp.shape[0]   # (the solver reads the model only: any number of rows -- the test double's mir_inverse_kinematics_rows passes len(envs_idx))
+        tq = None if target_quat is None else np.ascontiguousarray(target_quat, dtype=np.float64).reshape(n, 4)
+        q = np.ascontiguousarray(init_q, dtype=np.float64).reshape(n, -1).copy()
+        err = np.zeros((n, 2))
         self.lib.orc_ik.restype = C.c_int
-        self.ik_iters = np.zeros(self.B, np.int32)  # (iterations each env took in the last call)
-        for e in range(self.B):
+        self.ik_iters = np.zeros(n, np.int32)  # (iterations each row took in the last call)
+        for e in range(n):
             self.ik_iters[e] = self.lib.orc_ik(self.model, C.c_int(link), tp[e].ctypes.data_as(C.c_void_p), tq[e].ctypes.data_as(C.c_void_p) if tq is not None else None,
                             q[e].ctypes.data_as(C.c_void_p), C.c_int(max_iters), C.c_double(damping), C.c_double(pos_tol), C.c_double(rot_tol),
                             C.c_double(max_step), C.c_int(1 if respect_limits else 0), err[e].ctypes.data_as(C.c_void_p))

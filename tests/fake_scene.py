@@ -154,5 +154,29 @@ class OracleScene(StepHelpers):
         q, err = torch.from_numpy(q.astype(np.float32)), torch.from_numpy(err.astype(np.float32))
         return (q, err) if return_error else q
 
+    def inverse_kinematics_rows(self, link_body, pos, quat, init_qpos, env_idx, flags, init_col0=0, init_ncols=0, return_error=False, **opts):
+        """include/mirigid.h: mir_inverse_kinematics_rows, restated with NumPy indexing around the oracle's solver: row k belongs to env
+        env_idx[k]; pos / quat / init_qpos are addressed by row unless their *_BY_ENV flag is set (1 / 2 / 8), quat may be ONE quaternion
+        (4); init_qpos holds init_ncols columns from init_col0 on, the other joints are seeded from the scene state."""
+        B = self.num_envs
+        idx = np.arange(B) if env_idx is None else np.clip(self._np(env_idx).astype(np.int64).reshape(-1), 0, B - 1)
+        n = idx.size
+        P = self._np(pos).reshape(-1, 3)
+        P = P[idx] if flags & 1 else P[:n]
+        Q = None
+        if quat is not None:
+            Qa = self._np(quat).reshape(-1, 4)
+            Q = np.tile(Qa[:1], (n, 1)) if flags & 4 else (Qa[idx] if flags & 2 else Qa[:n])
+        seed = self.get_state()[0][:, :self.n_arm].numpy()[idx].copy()
+        if init_qpos is not None:
+            nc = init_ncols or self.n_arm
+            I = self._np(init_qpos).reshape(-1, nc)
+            seed[:, init_col0:init_col0 + nc] = I[idx] if flags & 8 else I[:n]
+        kw = dict(max_iters=opts.get("max_iters", 20), damping=opts.get("damping", 0.05), pos_tol=opts.get("pos_tol", 5e-4),
+                  rot_tol=opts.get("rot_tol", 5e-3), max_step=opts.get("max_step", 0.5), respect_limits=bool(opts.get("respect_joint_limit", 1)))
+        q, err = self.o.ik(int(link_body), P, Q, seed, **kw)
+        q, err = torch.from_numpy(q.astype(np.float32)), torch.from_numpy(err.astype(np.float32))
+        return (q, err) if return_error else q
+
     def close(self):
         pass

@@ -413,6 +413,48 @@ def test_inverse_kinematics_never_writes_a_callers_tensor(env):
     assert torch.allclose(q, q2)
 
 
+def test_inverse_kinematics_one_launch_equals_the_scatter_gather_wrapper(env):
+    """robot.inverse_kinematics hands its arguments to mir_inverse_kinematics_rows as they come -- by row of `envs_idx`, by env, one
+    quaternion for all, seeds for the arm's columns (gym_genesis/tasks/views.py) -- instead of scattering them to batch rows around the
+    full-batch launch; on the test double both routes run the oracle's solver: the same rows come back, for every way of addressing."""
+    from gym_genesis.tasks import views
+
+    obs, _ = env.reset(seed=0)
+    robot = env.get_robot()
+    eef = robot.get_link("hand")
+    B = obs["agent_pos"].shape[0]
+    pos_full = obs["environment_state"][:, :3] + torch.tensor([0.0, 0.0, 0.2])
+    one = torch.tensor([0.0, 1.0, 0.0, 0.0])
+    quat_full = one.repeat(B, 1) + torch.tensor([[0.0, 0.0, 0.05 * e, 0.0] for e in range(B)])
+    seed_full = robot.get_qpos() + 0.02 * torch.arange(B * 9, dtype=torch.float32).reshape(B, 9) / (B * 9)
+    sub = [2, 0]   # (fewer rows than envs: an argument with B rows is addressed by env, as in Genesis)
+    cases = [dict(pos=pos_full, quat=one.expand(B, -1), envs_idx=torch.arange(B)),
+             dict(pos=pos_full, quat=quat_full, init_qpos=seed_full),
+             dict(pos=pos_full[sub], quat=quat_full[sub], envs_idx=sub),
+             dict(pos=pos_full, quat=one, envs_idx=np.array(sub), init_qpos=seed_full[sub]),
+             dict(pos=pos_full[sub], quat=quat_full, envs_idx=torch.tensor(sub), init_qpos=seed_full),
+             dict(pos=pos_full.numpy(), quat=None, envs_idx=[1])]
+    calls = []
+    real = env._env._mir.inverse_kinematics_rows
+    env._env._mir.inverse_kinematics_rows = lambda *a, **k: (calls.append(a[5]), real(*a, **k))[1]
+    try:
+        for i, kw in enumerate(cases):
+            views.IK_ROWS = True
+            q1, e1 = robot.inverse_kinematics(link=eef, return_error=True, **kw)
+            views.IK_ROWS = False
+            kw2 = dict(kw)
+            if kw2.get("quat") is not None and torch.as_tensor(kw2["quat"]).numel() == 4:
+                n = B if kw2.get("envs_idx") is None else len(kw2["envs_idx"])
+                kw2["quat"] = one.reshape(1, 4).repeat(n, 1)
+            q0, e0 = robot.inverse_kinematics(link=eef, return_error=True, **kw2)
+            assert q1.shape == q0.shape and torch.equal(q1, q0) and torch.equal(e1, e0), f"case {i}"
+    finally:
+        views.IK_ROWS = True
+        del env._env._mir.inverse_kinematics_rows
+    # the flags each case was launched with: pos by env | one quaternion; pos + quat + init by env; all by row; ...
+    assert calls == [1 | 4, 1 | 2 | 8, 0, 1 | 4, 2 | 8, 1], calls
+
+
 def _example(rel):
     import importlib.util
 
