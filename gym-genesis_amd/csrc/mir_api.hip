@@ -198,11 +198,11 @@ int launch(MirScene* h, const Outs& o, void* stream) {
   int rc;
   // (phase 4 -- the list instantiation of exact contacts -- steps the envs the pending step's launch deferred and writes THEIR scratch
   //  rows for the state it leaves: it completes that launch, the handle's bookkeeping is the pending step's)
-  if (o.phase != 1 && o.phase != 4 && o.mode != 2) h->pre_valid = 0;  // (whatever this launch is, the state it leaves is not the one `pre` was made from)
+  if (o.phase != 1 && o.phase != 7 && o.phase != 4 && o.mode != 2) h->pre_valid = 0;  // (whatever this launch is, the state it leaves is not the one `pre` was made from)
   // Link poses for the rasteriser.  Once a render has been asked for (poses_live), every launch that integrates also leaves the
   // link poses of its final state in h->poses -- its closing forward kinematics has them -- so that a render behind a step needs
   // no pose-refresh launch (6 us per 1024 envs).  poses_current: h->poses matches qpos for every env.
-  const bool integrates = o.mode == 0 && o.phase != 1;
+  const bool integrates = o.mode == 0 && o.phase != 1 && o.phase != 7;
   if (integrates && o.phase != 4) h->state_version++;
   const bool wr_poses = o.poses || (h->poses_live && integrates);
   if (o.mode == 2 && o.poses) h->poses_current = 1;
@@ -225,6 +225,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.term_host = o.term_host; a.term_tag = o.term_tag; a.done_ticket = o.done_ticket; a.done_flag = o.done_flag; a.done_seq = o.done_seq;
     a.phase = o.phase; a.pre = h->pre;
     a.exact = o.exact; a.over_cap = o.over_cap;
+    a.pre_big = (o.phase == 4 || o.phase == 6 || o.phase == 7) ? h->pre_big : nullptr;
     if (o.env_list) { a.env_list = o.env_list; a.B = o.nlist; }
     if (o.phase == 4) a.term_wstride = 1;  // (the terminated byte of list entry k is byte k of term_host)
     rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
@@ -494,6 +495,8 @@ int mir_destroy(MirHandle h) {
   if (h->done_ticket) (void)hipFree(h->done_ticket);
   if (h->scratch_row) (void)hipFree(h->scratch_row);
   if (h->pre) (void)hipFree(h->pre);
+  if (h->pre_big) (void)hipFree(h->pre_big);
+  if (h->main_event) (void)hipEventDestroy((hipEvent_t)h->main_event);
   if (h->pin_host) (void)hipHostFree(h->pin_host);
   if (h->ovf_list_host) (void)hipHostFree(h->ovf_list_host);
   if (h->ovf_event) (void)hipEventDestroy((hipEvent_t)h->ovf_event);
@@ -526,7 +529,7 @@ int mir_reset(MirHandle h, const float* obj_pos, const float* obj_quat, const fl
   }
   if (int rc = check_mask(h)) return rc;
   h->pre_valid = 0;
-  if (!env_mask) { h->heavy = 0; h->perm_next = -1; }  // (exact contacts: a full reset ends a heavy phase -- every env is back at its start)
+  if (!env_mask) { h->heavy = 0; h->perm_next = -1; h->bigmode = 0; }  // (exact contacts: a full reset ends a heavy phase -- every env is back at its start)
   h->poses_current = 0;
   h->state_version++;
   DeviceGuard guard(h->device);
@@ -592,6 +595,7 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  * into the handle's pinned host buffer and arranges for a completion word; mir_step_end blocks until that launch has finished and
  * copies the B bytes to the caller's plain host array -- `terminated = is_success.detach().cpu().numpy()` (env.py:64) without a
  * separate copy command.  The host is free between the two calls (the Python side allocates the next outputs there). */
+static double wall_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   // a step left open (an exception between the two calls on the Python side) is closed here: its bytes are waited for and dropped
@@ -618,14 +622,32 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   // exact contacts, HEAVY phase (mir_step_end decides): most envs of the last step had more points than the one-contact-per-lane kernel
   // holds, so the whole batch takes the three-contacts-per-lane instantiation's first pass in ONE launch (mir_step.hip: VARIANT 7) -- no
   // launch that defers, no list launch behind it, no scratch rows (the first light step afterwards is launched like the one behind a reset)
-  const bool heavy = h->exact && h->exact_big && h->heavy && h->sync_mode == 3;
+  // exact contacts, an OVERFLOW RUN of a HOST-BOUND loop (mir_scene.h): the step as TWO launches of the three-contacts-per-lane
+  // instantiation for the whole batch -- second half (-> terminated bytes), then, on the side stream, the first half of the next step,
+  // which runs beside whatever the caller queues between two steps (the policy, its IK).  Costs GPU time (rows through HBM, two rounds of
+  // workgroups twice) and saves time to the bytes: taken when the GPU is WAITING for this call -- the step's stream has drained -- and
+  // otherwise the heavy phase / the list launch behind the bytes, which cost less GPU time.
+  bool bigrot = false;
+  if (h->exact == 1 && h->exact_big && h->bigmode && h->pre_big != nullptr && h->sync_mode == 3 && h->ovf_stream && h->split_step && h->pre_valid &&
+      h->pre_stream == stream && h->hm.fk_free_leaf != 0) {
+    // (does the caller leave the first-half launch room to hide?  The time it spent between mir_step_end's return and this call: the
+    //  policy and its IK in the reference's expert loop, ~90 us; a loop that does nothing between two steps, 2 - 5 us)
+    if (h->big_on == 2) bigrot = true;  // (MIR_EXACT_BIG=2: whenever the rows are there)
+    else bigrot = h->t_end_us > 0.0 && wall_us() - h->t_end_us >= h->big_gap_us;
+  }
+  const bool heavy = h->exact && h->exact_big && h->heavy && h->sync_mode == 3 && !bigrot;
   const bool split = h->split_step && h->sync_mode != 2 && !heavy;
   const bool have_pre = split && h->pre_valid && h->pre_stream == stream;
   // (one rotated launch -- this step's second half, then the next step's first half -- where the closing FK can be shared between
   //  the waves; otherwise two launches)
-  const bool rotated = have_pre && h->hm.fk_free_leaf != 0 && h->split_step != 2;
-  o.phase = heavy ? 5 : (rotated ? 3 : (have_pre ? 2 : 0));
+  const bool rotated = have_pre && h->hm.fk_free_leaf != 0 && h->split_step != 2 && !bigrot;
+  o.phase = heavy ? 5 : (bigrot ? 6 : (rotated ? 3 : (have_pre ? 2 : 0)));
   o.exact = h->exact;
+  if (bigrot) {
+    o.over_cap = h->hm.max_contacts < K16_MAX_CONTACT ? h->hm.max_contacts : K16_MAX_CONTACT;
+    h->ex_big_steps++;
+  }
+  h->pend_big = bigrot ? 1 : 0;
   h->pend_perm = -1;
   if (heavy) {
     o.over_cap = h->hm.max_contacts < K16_MAX_CONTACT ? h->hm.max_contacts : K16_MAX_CONTACT;
@@ -633,6 +655,9 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
     // (the envs in the order mir_step_end left: the ones above 16 points first -- workgroups of like cost, the expensive ones early)
     if (h->perm_next >= 0) { o.env_list = h->perm_dev[h->perm_next]; o.nlist = h->B; h->pend_perm = h->perm_next; }
   }
+  // (a step of an overflow run serves the envs in the order mir_step_end left too: the ones above 16 points first -- their workgroups are
+  //  the long ones, and the step's terminated bytes wait for the last of them)
+  if (bigrot && h->perm_next >= 0) { o.env_list = h->perm_dev[h->perm_next]; o.nlist = h->B; h->pend_perm = h->perm_next; }
   h->pend_heavy = heavy ? 1 : 0;
   // (exact contacts, ADVICE r5: the launches for the deferred envs of an earlier step ran on the library's side stream, and only the stream
   //  of THAT step was made to wait for them; a step on another stream waits for them here -- state rows, scratch rows and the pinned
@@ -661,8 +686,22 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   if (split && !rotated) {
     // ... and the action-independent half of the NEXT step goes out right behind it: it runs while the host is between two calls
     Outs p;
-    p.phase = 1; p.diag = false;
-    rc = launch(h, p, stream);
+    p.phase = bigrot ? 7 : 1; p.diag = false;
+    if (bigrot && !(getenv("MIR_EXACT_BIG_SIDE") && atoi(getenv("MIR_EXACT_BIG_SIDE")) == 0)) {
+      // (... on the side stream, behind the launch above: beside the caller's work between two steps; the next mir_step_begin -- and the
+      //  launches for envs this step defers -- come behind it through ovf_event)
+      if (h->pend_perm >= 0) { p.env_list = h->perm_dev[h->pend_perm]; p.nlist = h->B; }
+      HIPCHK(hipEventRecord((hipEvent_t)h->main_event, (hipStream_t)stream));
+      HIPCHK(hipStreamWaitEvent((hipStream_t)h->ovf_stream, (hipEvent_t)h->main_event, 0));
+      rc = launch(h, p, h->ovf_stream);
+      if (rc != MIR_OK) return rc;
+      HIPCHK(hipEventRecord((hipEvent_t)h->ovf_event, (hipStream_t)h->ovf_stream));
+      h->ovf_event_live = 1;
+      h->ovf_waited_stream = reinterpret_cast<void*>(~(uintptr_t)0);  // (no stream has been made to wait yet -- the null stream is a stream)
+    } else {
+      if (bigrot && h->pend_perm >= 0) { p.env_list = h->perm_dev[h->pend_perm]; p.nlist = h->B; }
+      rc = launch(h, p, stream);
+    }
     if (rc != MIR_OK) return rc;  // (the step itself is queued and pending: the caller may still close it, or the next begin does)
     h->pre_valid = 1;
     h->pre_stream = stream;
@@ -732,7 +771,7 @@ static int exact_finish(MirScene* h, int n, uint8_t* terminated_host) {
   // (not beside a step that was launched as two kernels -- a fused launch, or the second half alone, followed by the first half of the
   //  next step for ALL envs: that second kernel writes the scratch rows of the deferred envs too, from their old state, and must come
   //  BEFORE the one below that writes them from the new state: stream order does that)
-  void* const side = (h->ovf_stream && h->pend_rotated) ? h->ovf_stream : h->pending_stream;
+  void* const side = (h->ovf_stream && (h->pend_rotated || h->pend_big)) ? h->ovf_stream : h->pending_stream;  // (pend_big: behind the first-half launch, which is there)
   const size_t B = (size_t)h->B;
   int32_t* const list2_host = reinterpret_cast<int32_t*>(h->ovf_term_host + (B + 63) / 64 * 64);
   int32_t* const list2_dev = reinterpret_cast<int32_t*>(h->ovf_term_dev + (B + 63) / 64 * 64);
@@ -748,6 +787,9 @@ static int exact_finish(MirScene* h, int n, uint8_t* terminated_host) {
     //  statistics of a heavy step count the envs above the one-contact-per-lane capacity, mir_step_end)
     h->ex_ovf_steps--; h->ex_ovf_envs -= (unsigned long long)n;
   } else if (h->exact_big) {
+    // (a step of an overflow run: envs whose big row the launch before could not write -- the fused pass of the list instantiation, which
+    //  hands on what is beyond its capacity too; the step's statistics come from bit 6 of the bytes, mir_step_end)
+    if (h->pend_big) { h->ex_ovf_steps--; h->ex_ovf_envs -= (unsigned long long)n; }
     memset(h->ovf_term_host, 0, (size_t)n);  // (tags come round every 63 steps: a byte of an older step must not pass for this one's)
     __atomic_thread_fence(__ATOMIC_RELEASE);
     Outs o;
@@ -859,7 +901,12 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
       // light -> heavy when this step deferred at least heavy_enter envs; heavy -> light when fewer than heavy_leave had more points than
       // the one-contact-per-lane kernel holds (MIR_EXACT_HEAVY="enter,leave"; enter <= 0: never heavy).  The cost model behind the
       // defaults: a light step with a deferred list costs launch + list launch, a heavy one two rounds of the bigger kernel.
-      if (h->pend_heavy) { h->ex_ovf_envs += (unsigned long long)nover; if (nover) h->ex_ovf_steps++; if ((unsigned long long)nover > h->ex_ovf_max) h->ex_ovf_max = nover; }
+      if (h->pend_heavy || h->pend_big) { h->ex_ovf_envs += (unsigned long long)nover; if (nover) h->ex_ovf_steps++; if ((unsigned long long)nover > h->ex_ovf_max) h->ex_ovf_max = nover; }
+      // an overflow run starts behind the first step that deferred an env and ends with the first of its steps in which no env is above 16 points
+      if (h->big_on) {
+        if (!h->bigmode && ndefer > 0) h->bigmode = 1;
+        else if (h->pend_big && nover == 0 && ndefer == 0) h->bigmode = 0;
+      }
       const int cnt = h->pend_heavy ? nover : ndefer;
       if (!h->heavy && h->heavy_enter > 0 && cnt >= h->heavy_enter) h->heavy = 1;
       else if (h->heavy && cnt < h->heavy_leave) h->heavy = 0;
@@ -869,10 +916,10 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
       // sorted, 30 % of them are done in half the time, and the expensive ones are dispatched first (the words are in this core's
       // cache: the loop above has just read them)
       h->perm_next = -1;
-      if (h->heavy && h->heavy_sort) {
+      if ((h->heavy || h->bigmode) && h->heavy_sort) {
         const int nxt = h->pend_perm == 0 ? 1 : 0;
         int32_t* const out = h->perm_host[nxt];
-        const uint32_t bit = h->pend_heavy ? 0x40u : 0x80u;
+        const uint32_t bit = (h->pend_heavy || h->pend_big) ? 0x40u : 0x80u;
         size_t nh = 0, nl = B;
         for (size_t g = 0; g < nwg; g++) {
           const uint32_t v = w[g * ws];
@@ -883,6 +930,11 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
         }
         h->perm_next = nxt;
       }
+    }
+    if (h->big_on) {
+      const int rc = ndefer ? exact_finish(h, ndefer, terminated_host) : MIR_OK;
+      h->t_end_us = wall_us();
+      return rc;
     }
     if (ndefer) return exact_finish(h, ndefer, terminated_host);
     return MIR_OK;
@@ -997,6 +1049,24 @@ int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
   // the list instantiation of the 16-lane kernel takes the deferred envs where the scene has the split closing forward kinematics (every
   // free body a childless child of the world: the reference's scenes); MIR_EXACT_WAVE=1: the wave-per-env kernel takes them all (round 5)
   h->exact_big = (h->hm.fk_free_leaf != 0 && !(getenv("MIR_EXACT_WAVE") && atoi(getenv("MIR_EXACT_WAVE")) != 0)) ? 1 : 0;
+  // (1, the default: when the caller spent at least MIR_EXACT_BIG_GAP microseconds -- 40 -- between the last mir_step_end and this
+  //  mir_step_begin: the two launches of such a step take a third more GPU time than the heavy phase's one -- rows through HBM, less
+  //  overlap of the two waves -- which a loop with nothing between its steps pays in full; 2: whenever the rows are there; 0: never)
+  h->big_on = (h->exact_big && on != 2 && h->ovf_stream) ? (getenv("MIR_EXACT_BIG") ? atoi(getenv("MIR_EXACT_BIG")) : 1) : 0;
+  h->big_gap_us = getenv("MIR_EXACT_BIG_GAP") ? atof(getenv("MIR_EXACT_BIG_GAP")) : 40.0;
+  h->t_end_us = 0.0;
+  h->bigmode = 0;
+  if (h->big_on && !h->main_event) {
+    DeviceGuard guard(h->device);
+    hipEvent_t ev = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    h->main_event = ev;
+  }
+  if (h->big_on && !h->pre_big) {
+    DeviceGuard guard(h->device);
+    HIPCHK(hipMalloc((void**)&h->pre_big, (size_t)h->B * K48_STRIDE * sizeof(float)));
+    HIPCHK(hipMemset(h->pre_big, 0, (size_t)h->B * K48_STRIDE * sizeof(float)));
+  }
   h->exact = on == 2 ? 2 : 1;
   h->heavy = 0;
   h->perm_next = -1; h->pend_perm = -1;
@@ -1016,13 +1086,13 @@ int mir_get_exact_contacts(MirHandle h) { return check(h) ? MIR_E_INVALID : h->e
 int mir_get_exact_stats(MirHandle h, uint64_t* out4, int32_t reset) {
   if (check(h) || !out4) return set_err(MIR_E_INVALID, "mir_get_exact_stats: null argument");
   out4[0] = h->ex_steps; out4[1] = h->ex_ovf_steps; out4[2] = h->ex_ovf_envs; out4[3] = h->ex_ovf_max;
-  if (reset) h->ex_steps = h->ex_ovf_steps = h->ex_ovf_envs = h->ex_ovf_max = h->ex_big_envs = h->ex_wave_envs = h->ex_heavy_steps = 0;
+  if (reset) h->ex_steps = h->ex_ovf_steps = h->ex_ovf_envs = h->ex_ovf_max = h->ex_big_envs = h->ex_wave_envs = h->ex_heavy_steps = h->ex_big_steps = 0;
   return MIR_OK;
 }
 
 int mir_get_exact_route(MirHandle h, uint64_t* out2) {
   if (check(h) || !out2) return set_err(MIR_E_INVALID, "mir_get_exact_route: null argument");
-  out2[0] = h->ex_big_envs; out2[1] = h->ex_wave_envs; out2[2] = h->ex_heavy_steps;
+  out2[0] = h->ex_big_envs; out2[1] = h->ex_wave_envs; out2[2] = h->ex_heavy_steps; out2[3] = h->ex_big_steps;
   return MIR_OK;
 }
 /* debug aid (bench.py's roofline): n back-to-back launches of the rotated step kernel (what mir_step_begin launches in split mode 1)

@@ -47,7 +47,8 @@ struct StepArgs {
   // dynamics, collision, contact arrays, Jacobians) written to `pre`; 2 = the rest of the step, read from
   // `pre`.  3 = 2 followed by 1 (of the next step) in one launch.  `pre`: K16_PRE_STRIDE floats per env.
   // 4 = the LIST instantiation of exact contacts (three contacts per lane, capacity 48): the whole step for the envs of `env_list`,
-  // then 1 for them; 5 = its first pass alone for the whole batch (mir_step.hip: VARIANT 6 / 7).
+  // then 1 for them; 5 = its first pass alone for the whole batch (mir_step.hip: VARIANT 6 / 7); 6 / 7 = 2 / 1 with three contacts per lane
+  // (VARIANT 9 / 10: the two launches of a step of an overflow run -- rows of up to 48 contacts through `pre_big`).
   int phase;
   float* pre;
   // [0] env-steps that ended with a non-finite state (divergence guard, counted while diag is set; mir_get_bad);
@@ -67,7 +68,17 @@ struct StepArgs {
   int over_cap;  // phase 4 / 5 (three contacts per lane): bit 6 of an env's terminated byte says that it had more candidate points than this (0: never set)
   // phase 1 only: the launch serves the envs env_list[0 .. B) (B = the list's length) instead of envs 0 .. B; may point into pinned host memory
   const int32_t* env_list;
+  // EXACT CONTACTS, phases 4 / 6 (three contacts per lane): K48_STRIDE floats per env -- the scratch row of an env whose NEXT step has 17 .. 48
+  // contacts (head, row constants and unpacked Jacobian rows of all of them; the mass-matrix rows and the bias force stay in `pre`).  The
+  // head of the env's row in `pre` then holds ncon = 0, the count in the `coupled` word and K48_MAGIC in its third word: a launch of the
+  // one-contact-per-lane kernel defers the env on the count, phase 6 picks the big row up.  Null: such rows are not written.
+  float* pre_big;
 };
+#define K48_HEAD 0    /* ncon, second-tree flags of contacts 16 .. 31, of 32 .. 47 (int bits), pad */
+#define K48_CMETA 4   /* MIR_MAX_CONTACT x 4 */
+#define K48_JB (K48_CMETA + 4 * MIR_MAX_CONTACT) /* MIR_MAX_CONTACT rows of 48 floats (n, t1, t2 x 16 dofs) */
+#define K48_STRIDE (((K48_JB + 48 * MIR_MAX_CONTACT) + 15) / 16 * 16)
+#define K48_MAGIC 0x42494721 /* "BIG!" */
 #define K16_PRE_MROW 0     /* 16 lanes x 16: rows of the regularised mass matrix */
 #define K16_PRE_BIAS 256   /* 16: qfrc_bias */
 #define K16_PRE_HEAD 272   /* ncon, coupled (int bits), 2 pad */

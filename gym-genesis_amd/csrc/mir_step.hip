@@ -292,10 +292,18 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
   // action-independent half of the NEXT one (into the pre buffer).  The host sees `terminated` after the first half; the second
   // runs while it is between two env.step() calls, without a second launch, a second prologue or a second forward kinematics
   // (the closing FK of this step is the opening FK of the next).  Needs the split closing FK (fk_free_leaf scenes).
-  constexpr bool ROT = VARIANT == 5;
-  constexpr bool BIGV = VARIANT == 6 || VARIANT == 7;  // three contacts per lane: the whole step in one pass (two waves, as VARIANT 0) ...
+  constexpr bool ROT = VARIANT == 5 || VARIANT == 8 || VARIANT == 9;
+  // VARIANT 9 / 10 (CPL = 3) = the two halves of a step with three contacts per lane, as TWO launches: what mir_step_begin launches for
+  // the whole batch while some env is above 16 points (an OVERFLOW RUN).  9 = the second half of this step from the scratch rows -- an
+  // env with 17 .. 48 contacts has its row in StepArgs::pre_big, written by the launch before -- up to the outputs and the terminated
+  // bytes (the rotated launch's first pass, then it returns); 10 = the first half of the next step with the 48-point capacity (VARIANT 3
+  // with three contacts per lane).  The bytes of EVERY env leave after a solver pass -- two rounds of short workgroups -- instead of
+  // after two rounds of whole steps (the heavy phase) or a fused pass of the list instantiation behind the main launch's bytes; the first
+  // halves run while the host is between two env.step calls.  (8 = both in one rotated launch: measured, no better than the heavy phase
+  // -- the second round's bytes wait for the first round's first halves -- and not instantiated.)
+  constexpr bool BIGV = VARIANT >= 6 && VARIANT <= 10;  // three contacts per lane: the whole step in one pass (two waves, as VARIANT 0) ...
   constexpr bool BIG2 = VARIANT == 6;                  // ... then the outputs, then the action-independent half of the next step (the list instantiation)
-  constexpr bool PRE = VARIANT == 3, POST = VARIANT == 4;
+  constexpr bool PRE = VARIANT == 3 || VARIANT == 10, POST = VARIANT == 4;
   constexpr bool SINGLE = VARIANT == 0 || PRE || POST || ROT || BIGV;
   constexpr bool DUAL = VARIANT == 0 || PRE || ROT || BIGV;
   constexpr int MAXCON = G * CPL;
@@ -409,6 +417,33 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
 #pragma unroll
       for (int u = 0; u < 4; u++)
         if (lane < 12 && c0 + u < nc) stv(JBROW(Sx, c0 + u) + 16 * r + 4 * q, on[u] ? v[u] : f4{0, 0, 0, 0});
+    }
+  };
+  // ... and the BIG rows (three contacts per lane): the Jacobian rows of nc <= 48 contacts unpacked, 48 floats each, twelve lanes an f4
+  // each, four contacts per trip
+  auto bigrows_store = [&](float* big, int nc, auto& Sx) {
+    const int r = lane >> 2, q = lane & 3;
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+      f4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = ldv(JBROW(Sx, c0 + u < nc ? c0 + u : c0) + (lane < 12 ? 16 * r + 4 * q : 0));
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (lane < 12 && c0 + u < nc) *reinterpret_cast<f4*>(big + K48_JB + 48 * (c0 + u) + 16 * r + 4 * q) = v[u];
+    }
+  };
+  // (twelve contacts per trip: the loads of a trip are in flight together, and a trip is an HBM round trip on the critical path of the
+  //  launch's second half -- the solver waits for these rows; four per trip made it twelve round trips at 48 contacts)
+  auto bigrows_load = [&](const float* big, int nc, auto& Sx) {
+    const int r = lane >> 2, q = lane & 3;
+    for (int c0 = 0; c0 < nc; c0 += 12) {
+      f4 v[12];
+#pragma unroll
+      for (int u = 0; u < 12; u++) v[u] = *reinterpret_cast<const f4*>(big + K48_JB + 48 * (c0 + u < nc ? c0 + u : c0) + (lane < 12 ? 16 * r + 4 * q : 0));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 12; u++)
+        if (lane < 12 && c0 + u < nc) stv(JBROW(Sx, c0 + u) + 16 * r + 4 * q, v[u]);
     }
   };
   // DUAL: the closing FK is split between the waves when every free-joint body is a childless child of the world (wave-uniform)
@@ -1045,11 +1080,39 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       {
         const float* pre = a.pre + (size_t)env * K16_PRE_STRIDE;
         const f4 head = *reinterpret_cast<const f4*>(pre + K16_PRE_HEAD);
-        const int nc = __float_as_int(head.x);
-        ovf_h = ((__float_as_int(head.y) >> 20) & 255) > defer_above;
-        if (lane == 0) { S.ncon = nc; S.coupled = __float_as_int(head.y); S.ncand = 0; }
-        if (lane < nc) stv(S.con.cmeta[lane], *reinterpret_cast<const f4*>(pre + K16_PRE_CMETA + 4 * lane));
-        jrows_load(pre, nc, (uint64_t)__float_as_uint(head.z) | ((uint64_t)__float_as_uint(head.w) << 32), S);
+        int nc = __float_as_int(head.x);
+        int cplw = __float_as_int(head.y);
+        const int pts_h = (cplw >> 20) & 255;
+        // (three contacts per lane: an env above 16 points has its row in pre_big -- if the launch before wrote one: the tail of a
+        //  one-contact-per-lane launch cannot, and an env beyond 48 points has none either; such an env is deferred -- its count
+        //  saturated in the word the main wave reads -- and takes the fused pass of the list instantiation behind this launch)
+        bool big_h = false;
+        if constexpr (CPL > 1) {
+          big_h = pts_h > K16_MAX_CONTACT && pts_h <= MAXCON && __float_as_int(head.z) == K48_MAGIC && a.pre_big != nullptr;
+          // (a row in `pre` is complete when it holds as many contacts as the narrowphase found points: the tail of a one-contact-per-lane
+          //  launch thins beyond ITS capacity -- the scene's, possibly below 16 -- and the env is then deferred here too)
+          if (!big_h && nc != pts_h) { cplw |= 255 << 20; nc = 0; }
+        }
+        ovf_h = ((cplw >> 20) & 255) > defer_above;
+        if constexpr (CPL > 1) {
+          const float* big = a.pre_big + (size_t)env * K48_STRIDE;
+          f4 h2 = {0, 0, 0, 0};
+          if (big_h) { h2 = *reinterpret_cast<const f4*>(big + K48_HEAD); nc = __float_as_int(h2.x); }
+          if (lane == 0) { S.ncon = nc; S.coupled = cplw; S.ncand = 0; S.conB[0] = (cplw >> 1) & 0xffff; S.conB[1] = __float_as_int(h2.y); S.conB[2] = __float_as_int(h2.z); }
+          if (big_h) {
+#pragma unroll
+            for (int sl = 0; sl < CPL; sl++)
+              if (lane + G * sl < nc) stv(S.con.cmeta[lane + G * sl], *reinterpret_cast<const f4*>(big + K48_CMETA + 4 * (lane + G * sl)));
+            bigrows_load(big, nc, S);
+          } else {
+            if (lane < nc) stv(S.con.cmeta[lane], *reinterpret_cast<const f4*>(pre + K16_PRE_CMETA + 4 * lane));
+            jrows_load(pre, nc, (uint64_t)__float_as_uint(head.z) | ((uint64_t)__float_as_uint(head.w) << 32), S);
+          }
+        } else {
+          if (lane == 0) { S.ncon = nc; S.coupled = cplw; S.ncand = 0; }
+          if (lane < nc) stv(S.con.cmeta[lane], *reinterpret_cast<const f4*>(pre + K16_PRE_CMETA + 4 * lane));
+          jrows_load(pre, nc, (uint64_t)__float_as_uint(head.z) | ((uint64_t)__float_as_uint(head.w) << 32), S);
+        }
         WSYNC();
         HSTAMP(54);
         __syncthreads();  // (3) contact rows of this step are in LDS
@@ -1069,6 +1132,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       group_fk<true>(S, lane, nb, hparents, hk, row4);
       HSTAMP(57);
       __syncthreads();  // (6) link poses of the new state handed to the main wave
+      if (VARIANT == 9) return;  // (the second half alone: the first half of the next step is the next launch)
     } else {
       // The collision wave opens the launch with the FORWARD KINEMATICS of the stored state: it needs one row of qpos and four of
       // the twelve quads of lane constants, so its loads are back sooner than the main wave's (which also brings in the model
@@ -1095,10 +1159,23 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
           const uint64_t qm = jrows_store(pre, nc, S);
           if (lane == 0) *reinterpret_cast<f4*>(pre + K16_PRE_HEAD) = f4{__int_as_float(nc), __int_as_float(S.coupled), __uint_as_float((uint32_t)qm), __uint_as_float((uint32_t)(qm >> 32))};
           if (lane < nc) *reinterpret_cast<f4*>(pre + K16_PRE_CMETA + 4 * lane) = ldv(S.con.cmeta[lane]);
-        } else if (lane == 0) {
-          // (the list instantiation: more points than a scratch row holds -- the launch that reads the row defers the env again on the
-          //  count in the head word, bits 20 .. 27, and never looks at the rest)
-          *reinterpret_cast<f4*>(pre + K16_PRE_HEAD) = f4{__int_as_float(0), __int_as_float(S.coupled), 0.0f, 0.0f};
+        } else {
+          // (three contacts per lane: more points than a scratch row holds -- a launch of the one-contact-per-lane kernel that reads the
+          //  row defers the env on the count in the head word, bits 20 .. 27, and never looks at the rest; the contacts themselves go
+          //  to the env's BIG row where the count is within this instantiation's capacity: the rotated launch with three contacts per
+          //  lane picks them up, K48_MAGIC in the head says they are there)
+          const bool bigok = CPL > 1 && a.pre_big != nullptr && ((S.coupled >> 20) & 255) <= MAXCON;
+          if constexpr (CPL > 1) {
+            if (bigok) {
+              float* big = a.pre_big + (size_t)env * K48_STRIDE;
+              bigrows_store(big, nc, S);
+#pragma unroll
+              for (int sl = 0; sl < CPL; sl++)
+                if (lane + G * sl < nc) *reinterpret_cast<f4*>(big + K48_CMETA + 4 * (lane + G * sl)) = ldv(S.con.cmeta[lane + G * sl]);
+              if (lane == 0) *reinterpret_cast<f4*>(big + K48_HEAD) = f4{__int_as_float(nc), __int_as_float(S.conB[1]), __int_as_float(S.conB[2]), 0.0f};
+            }
+          }
+          if (lane == 0) *reinterpret_cast<f4*>(pre + K16_PRE_HEAD) = f4{__int_as_float(0), __int_as_float(S.coupled), __int_as_float(bigok ? K48_MAGIC : 0), 0.0f};
         }
       }
 #ifdef MIR_PROFILE_SINGLE
@@ -1110,7 +1187,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     const int cnt = collide_detect(1);
     HSTAMP(42);
     const int pts0 = contacts_build(cnt, PRE || ROT || BIGV);  // (three contacts per lane: the main wave shares the Jacobian build in every pass)  // (barrier (2) sits inside, between the arithmetic and the stores of the contact arrays)
-    if (BIGV) ovf_h = pts0 > defer_above;  // (beyond this instantiation's capacity too: nothing is stored for the env, the wave-per-env kernel takes it)
+    if (BIGV && !ROT && !PRE) ovf_h = pts0 > defer_above;  // (beyond this instantiation's capacity too: nothing is stored for the env, the wave-per-env kernel takes it)
     HSTAMP(45);
     __syncthreads();  // (3) contact arrays and base Jacobians handed to the main wave
     HSTAMP(46);
@@ -1439,7 +1516,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       // (2) composite inertia: suffix sums of the body inertias over the row, minus the suffix behind the subtree
       {
         if (DUAL) {  // (the body inertias come from the collision wave: long since there, as a rule)
-          while (__hip_atomic_load(&S.cin_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (BIGV ? step + 1 : 1)) __builtin_amdgcn_s_sleep(1);
+          while (__hip_atomic_load(&S.cin_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < ((BIGV && !ROT) ? step + 1 : 1)) __builtin_amdgcn_s_sleep(1);
         }
         float* ci = S.dyn.cinert[lane];
         f4 c0 = ldv(ci), c1 = ldv(ci + 4), c2 = ldv(ci + 8);
@@ -1541,7 +1618,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     }  // !post_now
     WSYNC();
     STAMP(3);
-    if (BIGV && !post_now) box_share(step + 1);
+    if (BIGV && !post_now) box_share(ROT ? 1 : step + 1);
     STAMP(49);
     if (DUAL && !post_now) __syncthreads();  // (2) this wave is done with the dynamics scratch (M is in its own area, the rest in registers)
     // qacc_smooth = Mt^-1 qfrc_smooth: Gauss-Jordan on register rows
@@ -1630,7 +1707,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       }
     }
     WSYNC();
-    if (BIGV) {  // (three contacts per lane: every other pair of contacts of the Jacobian build, as in the action-independent half)
+    if (BIGV && !post_now) {  // (three contacts per lane: every other pair of contacts of the Jacobian build, as in the action-independent half)
       __syncthreads();  // (2b)
       jac_build(2, 4);
     }
@@ -2241,7 +2318,9 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     if ((ROT || BIG2) && step == 0) emit_outputs();
     return 0;
   };  // step_body
-  if constexpr (ROT || BIG2) {
+  if constexpr (VARIANT == 9) {
+    step_body(std::integral_constant<int, 0>{});  // (the outputs leave at its end)
+  } else if constexpr (ROT || BIG2) {
     if (step_body(std::integral_constant<int, 0>{}) == 0) step_body(std::integral_constant<int, 1>{});
   } else if constexpr (SINGLE) {
     if (step_body(std::integral_constant<int, 0>{}) == 2) return;
@@ -2295,6 +2374,8 @@ static void launch_feat(const StepArgs& a, int blocks, int single, int plain_loo
   else if (a.phase == 3) hipLaunchKernelGGL((mir_step_kernel<5, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 4) hipLaunchKernelGGL((mir_step_kernel<6, FEAT, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 5) hipLaunchKernelGGL((mir_step_kernel<7, FEAT, 3>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 6) hipLaunchKernelGGL((mir_step_kernel<9, FEAT, 3>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 7) hipLaunchKernelGGL((mir_step_kernel<10, FEAT, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
   else if constexpr ((FEAT & 4) == 0) hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
@@ -2303,7 +2384,7 @@ extern "C" __attribute__((visibility("hidden"))) int mir_launch_step_convex(cons
   StepArgs a = *args;
   const int blocks = (a.B + EPB - 1) / EPB;
   // the headline scene's instantiation (features bit 2: mir_create found SpecPick::matches); the everything-variant stays generic
-  if ((a.features & 4) && (a.phase == 1 || a.phase == 3 || a.phase == 4 || a.phase == 5 || single || plain_loop)) launch_feat<5>(a, blocks, single, plain_loop, stream);
+  if ((a.features & 4) && (a.phase == 1 || a.phase == 3 || a.phase == 4 || a.phase == 5 || a.phase == 6 || a.phase == 7 || single || plain_loop)) launch_feat<5>(a, blocks, single, plain_loop, stream);
   else if (a.features & 2) launch_feat<3>(a, blocks, single, plain_loop, stream);  // sweep-and-prune scenes carry the convex code too
   else launch_feat<1>(a, blocks, single, plain_loop, stream);
   return (int)hipGetLastError();
@@ -2332,6 +2413,8 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   else if (a.phase == 3) hipLaunchKernelGGL((mir_step_kernel<5, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 4) hipLaunchKernelGGL((mir_step_kernel<6, 0, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 5) hipLaunchKernelGGL((mir_step_kernel<7, 0, 3>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 6) hipLaunchKernelGGL((mir_step_kernel<9, 0, 3>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 7) hipLaunchKernelGGL((mir_step_kernel<10, 0, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, 0>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, 0>), dim3(blocks), dim3(64), 0, stream, a);

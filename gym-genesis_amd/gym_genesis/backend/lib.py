@@ -598,9 +598,9 @@ class MirScene(StepHelpers):
 
     def exact_route(self) -> dict:
         """mir_get_exact_route: deferred env-steps handed to the list instantiation / env-steps stepped by the wave-per-env kernel."""
-        out = (C.c_uint64 * 3)()
+        out = (C.c_uint64 * 4)()
         self._check(self.lib.mir_get_exact_route(self.h, out))
-        return {"list_env_steps": int(out[0]), "wave_env_steps": int(out[1]), "heavy_steps": int(out[2])}
+        return {"list_env_steps": int(out[0]), "wave_env_steps": int(out[1]), "heavy_steps": int(out[2]), "big_steps": int(out[3])}
 
     @property
     def exact_contacts(self) -> bool:

@@ -320,7 +320,7 @@ int mir_step_go(MirHandle h, const float* action, void* stream);
 int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on);
 int mir_get_exact_contacts(MirHandle h);
 int mir_get_exact_stats(MirHandle h, uint64_t* out4, int32_t reset);
-int mir_get_exact_route(MirHandle h, uint64_t* out3);
+int mir_get_exact_route(MirHandle h, uint64_t* out4);
 
 /* Same step, but every output of an env lands in ONE packed float32 row
  * rows[e*row_stride + ...] = [agent_pos (agent_dim) | env_state (env_dim) | reward | terminated(0/1)]

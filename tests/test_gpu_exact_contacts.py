@@ -219,8 +219,13 @@ def _free_running_against_twins(franka_spec, n, want_split):
         # (this workload stays under 48 points and 16 candidate pairs: nothing reaches the wave-per-env kernel; in a HEAVY phase -- at
         #  least 1 / 16 of the envs above 16 points -- the whole batch takes one launch of the three-contacts-per-lane instantiation and
         #  there is no list)
+        #  (an OVERFLOW RUN -- the default on the rotated launches since the second session of round 6: from the step after the first
+        #   deferral the whole batch takes the rotated launch with three contacts per lane, and only the envs whose 48-point scratch row
+        #   the launch before could not write go through the list)
         assert route["list_env_steps"] <= sc.exact_stats()["overflow_env_steps"] and route["wave_env_steps"] == 0
-        assert route["list_env_steps"] == sc.exact_stats()["overflow_env_steps"] or route["heavy_steps"] > 0
+        assert route["list_env_steps"] == sc.exact_stats()["overflow_env_steps"] or route["heavy_steps"] > 0 or route["big_steps"] > 0
+        if want_split == 1 and not any(os.environ.get(k) for k in ("MIR_EXACT_ONE_STREAM", "MIR_EXACT_WAVE")) and os.environ.get("MIR_EXACT_BIG", "1") != "0":
+            assert route["big_steps"] > 0 and route["heavy_steps"] == 0, route   # (this loop spends milliseconds between two steps)
         far = np.concatenate(far)
         print(f"\n[list instantiation against the wave-per-env kernel, same state, same action, one step, {far.size} deferred env-steps] qpos L-inf "
               f"median {np.median(far):.1e} 0.99 {np.quantile(far, 0.99):.1e} 0.9999 {np.quantile(far, 0.9999):.1e} max {far.max():.1e}")
@@ -239,11 +244,12 @@ def test_free_running_rotated_launches_every_env_equals_its_twin_bit_for_bit(fra
 
 
 @pytest.mark.parametrize("var,val,split", [("MIR_SPLIT_STEP", "0", 0), ("MIR_SPLIT_STEP", "2", 2), ("MIR_NO_EARLY_MASK", "1", 1), ("MIR_EXACT_ONE_STREAM", "1", 1),
-                                           ("MIR_EXACT_WAVE", "1", 1)])
+                                           ("MIR_EXACT_WAVE", "1", 1), ("MIR_EXACT_BIG", "0", 1)])
 def test_every_launch_kind_defers_the_same_way(franka_spec, monkeypatch, var, val, split):
     """The other ways a step is launched -- one fused launch per step, the split step as two launches, terminated bytes that wait for
     the integrator, the deferred envs' launches on the step's own stream, the deferred envs on the wave-per-env kernel (round 5's route,
-    the fallback of this round's) -- at 512 envs: every env of every step equals its twin."""
+    the fallback of this round's), list launches and heavy phase even in a loop that leaves room between its steps (MIR_EXACT_BIG=0; the
+    default takes the two-launch steps of an overflow run in these loops) -- at 512 envs: every env of every step equals its twin."""
     monkeypatch.setenv(var, val)
     st, n_def, steps_def, lifted = _free_running_against_twins(franka_spec, 512, split)
     assert abs(st["overflow_env_steps"] - n_def) <= 10 and n_def > 100 and st["steps"] == 200 and lifted.mean() > 0.9
@@ -257,6 +263,7 @@ def test_heavy_phase_from_the_first_overflow_on_and_a_batch_that_is_not_a_multip
 
     monkeypatch.setenv("MIR_SPLIT_STEP", "1")
     monkeypatch.setenv("MIR_EXACT_HEAVY", "1,1")
+    monkeypatch.setenv("MIR_EXACT_BIG", "0")   # (this loop spends milliseconds between two steps: it would otherwise take the two-launch steps of an overflow run)
     n = 30
     sc, plain, twin = MirScene(franka_spec, n), MirScene(franka_spec, n), MirScene(franka_spec, n)
     sc.set_exact_contacts(True)
@@ -287,7 +294,8 @@ def test_heavy_phase_from_the_first_overflow_on_and_a_batch_that_is_not_a_multip
     assert n_def > 20 and st["overflow_env_steps"] == n_def and r["heavy_steps"] > 3 and r["wave_env_steps"] == 0, (n_def, st, r)
 
 
-def test_so101_scene_with_a_low_capacity_random_actions_every_env_equals_its_twin_bit_for_bit(monkeypatch):
+@pytest.mark.parametrize("big", [False, True])
+def test_so101_scene_with_a_low_capacity_random_actions_every_env_equals_its_twin_bit_for_bit(monkeypatch, big):
     """The other articulation (BASELINE configs[3]) and another way to overflow: the SO-101 pick scene with the capacity of the
     16-lane kernel set to 4 points -- the cube resting on the slab -- and random joint targets: whenever the arm touches the slab or the
     cube the env overflows.  Switch on, rotated launches.  Every env of every step equals the plain scene (capacity 4) where it was not
@@ -302,6 +310,7 @@ def test_so101_scene_with_a_low_capacity_random_actions_every_env_equals_its_twi
 
     n = 2048
     monkeypatch.setenv("MIR_SPLIT_STEP", "1")
+    monkeypatch.setenv("MIR_EXACT_BIG", "2" if big else "0")   # (the overflow steps as two launches for the whole batch: the generic-scene instantiations of them)
     sc, plain, wave = MirScene(spec(4), n), MirScene(spec(4), n), MirScene(spec(4), n)
     sc.set_exact_contacts(True)
     wave.set_exact_contacts("all")
@@ -329,7 +338,9 @@ def test_so101_scene_with_a_low_capacity_random_actions_every_env_equals_its_twi
             assert torch.equal(x[dfr], z[dfr]), f"step {t}: a deferred env differs from the scene whose every env takes the deferred envs' route"
         assert np.array_equal(h0, b0[3].cpu().numpy().astype(bool))
     st = sc.exact_stats()
-    assert sc.exact_route() == {"list_env_steps": st["overflow_env_steps"], "wave_env_steps": 0, "heavy_steps": 0}
+    r = sc.exact_route()
+    assert r["wave_env_steps"] == 0 and r["heavy_steps"] == 0 and 0 < r["list_env_steps"] <= st["overflow_env_steps"], (r, st)
+    assert (r["big_steps"] > 0 and r["list_env_steps"] < st["overflow_env_steps"]) if big else (r["big_steps"] == 0 and r["list_env_steps"] == st["overflow_env_steps"]), (r, st)
     print(f"\n[exact contacts, SO-101 at capacity 4 x {n}, random targets] deferred env-steps {n_def} of {200 * n} in {st['overflow_steps']} of 200 steps")
     assert abs(st["overflow_env_steps"] - n_def) <= 20 and n_def > 300
 
@@ -469,6 +480,50 @@ def test_more_candidate_pairs_than_lanes_defers_too():
     # (the list instantiation has 16 candidate lanes too: it hands every one of these envs on to the wave-per-env kernel)
     # (... the first step through the list instantiation; every env above 16 points starts a heavy phase, whose launches send them there too)
     r = sc.exact_route()
-    assert r["wave_env_steps"] == 30 * n and r["list_env_steps"] == n and r["heavy_steps"] == 29
+    # (an overflow run: every step after the first is the rotated launch with three contacts per lane, which defers these envs again --
+    #  they have no 48-point row -- to the list instantiation, which hands them on; MIR_EXACT_HEAVY set: the first step through the list
+    #  instantiation, then a heavy phase whose launches send them to the wave-per-env kernel directly)
+    assert r["wave_env_steps"] == 30 * n and r["list_env_steps"] + n * r["heavy_steps"] == 30 * n and r["big_steps"] + r["heavy_steps"] == 29, r
     assert st["overflow_env_steps"] == 30 * n and int(pts.min()) > 16
     assert torch.isfinite(sc.get_state()[0]).all() and float(sc.get_state()[0][:, 9].min()) > 0.05   # (the upper comb stays on the lower one)
+
+
+def test_tight_loop_every_route_gives_the_same_trajectory(monkeypatch):
+    """GenesisEnv.step back to back WITHOUT a host synchronisation between the steps (the scripted grasp at 4096 envs, 200 steps): the
+    launches of consecutive steps overlap on the device -- the list launches and the first-half launches of an overflow run on the side
+    stream, the next step's launch behind them through events.  Whatever route the overflow steps take -- list launches behind the bytes
+    and the heavy phase (MIR_EXACT_BIG=0), the two-launch steps of an overflow run whenever the rows are there (2), or the library's
+    own choice by whether the GPU was waiting for the call (1, the default) -- every observation of every step is the same bits.
+    (Found a missing stream wait when the first-half launch moved to the side stream: the null stream is a stream.)"""
+    from gym_genesis.env import GenesisEnv
+
+    dev = torch.device("cuda", 0)
+    pos, acts = _grasp_workload(B)
+    quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]]).repeat(B, 1)
+    home = torch.tensor(HOME).repeat(B, 1)
+    dacts = torch.as_tensor(acts, device=dev)
+    ref = None
+    for mode in ("0", "2", "1"):
+        monkeypatch.setenv("MIR_EXACT_BIG", mode)
+        env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False, exact_contacts=True)
+        env.reset(seed=0)
+        mir = env._env._mir
+        mir.reset(pos, quat, home)
+        mir.exact_stats(reset=True)
+        out = []
+        for t in range(dacts.shape[0]):
+            o, r, term, _, _ = env.step(dacts[t])
+            out.append(torch.cat([o["agent_pos"], o["environment_state"], r[:, None]], 1))
+        torch.cuda.synchronize()
+        out = torch.stack(out)
+        st, route = mir.exact_stats(), mir.exact_route()
+        print(f"\n[tight loop, MIR_EXACT_BIG={mode}] {st} {route}")
+        assert st["overflow_env_steps"] > 1000
+        if mode == "0":
+            ref, ref_st = out, st
+            assert route["big_steps"] == 0
+        else:
+            assert st == ref_st and (mode != "2" or route["big_steps"] > 0)
+            bad = (out != ref).flatten(1).any(1)
+            assert not bool(bad.any()), f"MIR_EXACT_BIG={mode}: first differing step {int(torch.nonzero(bad)[0])}"
+        del env

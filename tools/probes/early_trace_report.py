@@ -9,7 +9,7 @@ with open(sys.argv[1]) as f:
 rows.sort()
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 main = [(s, e) for s, e, n, q in rows if "mir_step_kernel<5" in n]
-lst = [(s, e) for s, e, n, q in rows if "mir_step_kernel<6" in n]
+lst = [(s, e) for s, e, n, q in rows if "mir_step_kernel<6" in n or "mir_step_kernel<9" in n]
 print(f"{len(main)} main launches, {len(lst)} list launches")
 if len(sys.argv) > 3 and sys.argv[3] == "timeline":
     first = lst[-N][0] - 200000 if len(lst) >= N else rows[0][0]
