@@ -660,8 +660,20 @@ def ref_expert_bench(torch, dev, episodes: int = 2):
     spec.loader.exec_module(ex)
     B = ENVS_PER_GPU
     res = {"workload": "reference expert (pick_cube_state.py), 5 x 40 steps, IK every step, num_envs=4096"}
-    for key, kw in (("exact_contacts", {}), ("thinned", {"exact_contacts": False})):
-        env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False, **kw)
+    # (exact_contacts: the task's default, whose overflow steps are TWO launches in a loop that leaves room between its steps -- this one
+    #  does: the policy and its IK; exact_contacts_one_launch: MIR_EXACT_BIG=0, the list launches / heavy phase a tight loop gets)
+    for key, kw in (("exact_contacts", {}), ("exact_contacts_one_launch", {}), ("thinned", {"exact_contacts": False})):
+        old_big = os.environ.get("MIR_EXACT_BIG")
+        if key == "exact_contacts_one_launch":
+            os.environ["MIR_EXACT_BIG"] = "0"
+        try:
+            env = GenesisEnv(task="cube_pick", robot="franka", num_envs=B, enable_pixels=False, **kw)
+        finally:
+            if key == "exact_contacts_one_launch":
+                if old_big is None:
+                    os.environ.pop("MIR_EXACT_BIG", None)
+                else:
+                    os.environ["MIR_EXACT_BIG"] = old_big
         mir = env._env._mir
         in_step, loop = [], []
         for ep in range(episodes + 1):  # (the first episode warms up)
@@ -683,7 +695,7 @@ def ref_expert_bench(torch, dev, episodes: int = 2):
         st = mir.exact_stats()
         res[key] = {"env_step_us": sorted(in_step)[len(in_step) // 2], "loop_us": sorted(loop)[len(loop) // 2], "lifted_frac": float(ok.mean()),
                     "overflow_env_frac": st["overflow_env_steps"] / (200.0 * B), "overflow_step_frac": st["overflow_steps"] / 200.0}
-        if key == "exact_contacts":
+        if key != "thinned":
             res[key].update(mir.exact_route())
         del env
     return res

@@ -1001,6 +1001,10 @@ int mir_get_sync_mode(MirHandle h) { return check(h) ? MIR_E_INVALID : h->sync_m
 int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
   if (check(h)) return MIR_E_INVALID;
   if (h->pending) return set_err(MIR_E_INVALID, "mir_set_exact_contacts: a step is pending");
+  // (a scratch row whose head says "above 16 points, the contacts are elsewhere" means something to the launches of this mode only: the
+  //  next step starts from the state, not from the rows)
+  h->pre_valid = 0;
+  h->bigmode = 0;
   if (!on) { h->exact = 0; return MIR_OK; }
   if (h->kernel != 16) return set_err(MIR_E_INVALID, "mir_set_exact_contacts: the scene already runs on the wave-per-env kernel (48 contact points, never thinned below that)");
   if (h->sync_mode != 3 || !h->term_wstride) return set_err(MIR_E_INVALID, "mir_set_exact_contacts: needs the tagged terminated bytes (sync mode 3)");
