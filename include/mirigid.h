@@ -309,12 +309,19 @@ int mir_step_go(MirHandle h, const float* action, void* stream);
  * step), and mir_step_packed / mir_rollout / mir_rollout_autoreset return MIR_E_INVALID (their steps are never closed on the host).
  * MIR_E_INVALID for scenes of the wave kernel (nothing to do) and for sync modes other than 3.
  * mir_get_exact_stats: out4 = {steps closed by mir_step_end, steps that had deferred envs, deferred env-steps, most deferred envs in one
- * step} since the last reset of the counters (reset != 0 clears them).  mir_get_exact_route: out3 = {deferred env-steps handed to the
- * list instantiation, env-steps stepped by the wave-per-env kernel, HEAVY steps} over the same period.  A heavy step: while at least
+ * step} since the last reset of the counters (reset != 0 clears them).  mir_get_exact_route: out4 = {deferred env-steps handed to the
+ * list instantiation, env-steps stepped by the wave-per-env kernel, HEAVY steps, steps of overflow runs as two launches} over the same period.  A heavy step: while at least
  * 1 / 16 of the envs are above 16 points (and until fewer than 1 / 32 are; MIR_EXACT_HEAVY="enter,leave" in envs, enter <= 0: never)
  * the whole batch is stepped by ONE launch of the three-contacts-per-lane instantiation instead of a launch that defers most envs and
  * a list launch behind it (an env with at most 16 points is computed there bit for bit as by the one-contact-per-lane kernel); the
  * statistics count its envs above 16 points as deferred.
+ * OVERFLOW RUNS in a loop that leaves room between two steps (second session of round 6): when the caller spent at least 40 us
+ * (MIR_EXACT_BIG_GAP) between mir_step_end's return and this mir_step_begin -- a policy, its IK -- a step of a run (from the step after
+ * one that deferred envs until a step in which no env is above 16 points) is TWO launches of the three-contacts-per-lane instantiation for
+ * the whole batch: the second half of the step from the scratch rows up to the outputs and the terminated bytes, on `stream`; and the first
+ * half of the next step on the library's side stream, beside whatever the caller queues on `stream` next (the next mir_step_begin is made
+ * to wait for it).  Same results bit for bit; less time inside the two calls, a third more GPU time per step.  MIR_EXACT_BIG=0: never
+ * (heavy phase / list launches), 2: whenever the rows are there.  out4[3] of mir_get_exact_route counts such steps.
  * on = 2 (tests): every env of every step is deferred, i.e. the whole batch is stepped by the launches that otherwise serve the
  * deferred envs only -- the twin the parity tests compare a deferred env with, bit for bit. */
 int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on);
