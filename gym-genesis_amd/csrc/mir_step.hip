@@ -316,6 +316,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
   __shared__ __attribute__((aligned(16))) ModelTab T;  // dynamically indexed model tables, one copy per workgroup
   // hull vertices (MIR_GEOM_HULL), convex instantiations only: what is left of the workgroup's 40 KB
   __shared__ __attribute__((aligned(16))) float s_hull[(FEAT & 1) ? K16_MAX_VERT : 1][4];
+  // three contacts per lane: the collision wave HELPS in the Newton loop (it would wait at barrier (5) meanwhile) -- the contacts of the
+  // slots above the first are its share of the gradient and of the Hessian update.  [0] request (iteration + 1, -1 = the loop is over),
+  // [1] its gradient share of that iteration is in LDS, [2] its Hessian share is (see helper_newton)
+  __shared__ int s_help[CPL > 1 ? 4 : 1];
   const DevModel* __restrict__ m = a.model;
   const int tid = threadIdx.x & 63;   // lane within the wave
   const int wave = threadIdx.x >> 6;  // 0 = main wave; 1 = collision wave (DUAL only)
@@ -1024,6 +1028,88 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       }
     }
   };
+  // one contact's signed contribution to the Hessian row of this lane (lane = dof): the change of its pyramid's 3 x 3 weight between the
+  // row flags `old` and `bits` (the expressions of the incremental update in the Newton loop, which the helper wave runs for the slots
+  // above the first)
+  auto hess_flip = [&](float (&hk)[G], int c, bool first_it) __attribute__((always_inline)) {
+    const float* jb = JBROW(S, c);
+    const f4 fb = ldv(CFB(S, c));
+    const float jn = jb[lane], j1 = jb[16 + lane], j2 = jb[32 + lane];
+    const f4 mt = ldv(S.con.cmeta[c]);
+    f4 xn[4], x1[4], x2[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { xn[q] = ldv(jb + 4 * q); x1[q] = ldv(jb + 16 + 4 * q); x2[q] = ldv(jb + 32 + 4 * q); }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned both = (unsigned)fb.w;
+    const unsigned bits = both & 15u, old = first_it ? 15u : both >> 4;
+    const float mu = mt.x, D = mt.y;
+    const float a0 = D * (float)((int)(bits & 1u) - (int)(old & 1u)), a1 = D * (float)((int)(bits >> 1 & 1u) - (int)(old >> 1 & 1u));
+    const float a2 = D * (float)((int)(bits >> 2 & 1u) - (int)(old >> 2 & 1u)), a3 = D * (float)((int)(bits >> 3 & 1u) - (int)(old >> 3 & 1u));
+    const float w0 = a0 + a1 + a2 + a3, w1 = mu * (a0 - a1), w2 = mu * (a2 - a3), w3 = mu * mu * (a0 + a1), w4 = mu * mu * (a2 + a3);
+    const float tn = jn * w0 + j1 * w1 + j2 * w2, t1 = jn * w1 + j1 * w3, t2 = jn * w2 + j2 * w4;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      hk[4 * q + 0] += tn * xn[q].x + t1 * x1[q].x + t2 * x2[q].x;
+      hk[4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
+      hk[4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
+      hk[4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
+    }
+  };
+  // (three contacts per lane) where the helper wave leaves its shares: the Hessian rows in the 1 KB of xpos | xquat | cdof (dead between
+  // the Jacobian build and the closing FK), the gradient entry in the spare floats of this lane's M row
+  auto help_hrow = [&]() -> float* { return &S.xpos[0][0] + 16 * lane; };
+  static_assert(sizeof(((EnvLds*)nullptr)->xpos) + sizeof(((EnvLds*)nullptr)->xquat) + sizeof(((EnvLds*)nullptr)->cdof) == G * G * sizeof(float), "xpos | xquat | cdof (declared in this order): 256 floats");
+  // The helper wave's side of the Newton loop (called behind barrier (4)): for request k = iteration + 1 -- from the second iteration on
+  // the gradient share first (contacts 16 .. ncon in contact order), then the Hessian share (the flipped contacts among them).  An env
+  // with at most 16 contacts gets exact zeros from here: it is computed as by the one-contact-per-lane kernel.
+  auto helper_newton = [&]() {
+    if constexpr (CPL > 1) {
+      for (int k = 1;; k++) {
+        int r;
+        while ((r = __hip_atomic_load(&s_help[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 0 && r < k) __builtin_amdgcn_s_sleep(1);
+        if (r < 0) break;
+        const int ncon = S.ncon;
+        if (k > 1) {
+          float gp = 0.0f;
+          for (int c0 = G; c0 < ncon; c0 += 4) {
+            float jn[4], j1[4], j2[4];
+            f4 fb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int c = c0 + u < ncon ? c0 + u : c0;
+              const float* jb = JBROW(S, c);
+              jn[u] = jb[lane]; j1[u] = jb[16 + lane]; j2[u] = jb[32 + lane];
+              fb[u] = ldv(CFB(S, c));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+              if (c0 + u < ncon) gp -= jn[u] * fb[u].x + j1[u] * fb[u].y + j2[u] * fb[u].z;
+          }
+          S.M[lane][G] = gp;
+          WSYNC();
+          if (tid == 0) __hip_atomic_store(&s_help[1], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        float hd[G];
+#pragma unroll
+        for (int j = 0; j < G; j++) hd[j] = 0.0f;
+#pragma unroll
+        for (int sl = 1; sl < CPL; sl++) {
+          bool flipped = false;
+          if (lane + G * sl < ncon) {
+            const unsigned both = (unsigned)CFB(S, lane + G * sl)[3];
+            flipped = (both & 15u) != (k == 1 ? 15u : both >> 4);
+          }
+          for (unsigned fm = (unsigned)(__ballot(flipped) >> (tid & 48)) & 0xffffu; fm; fm &= fm - 1u) hess_flip(hd, __ffs(fm) - 1 + G * sl, k == 1);
+        }
+        float* hr = help_hrow();
+#pragma unroll
+        for (int q = 0; q < 4; q++) stv(hr + 4 * q, f4{hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]});
+        WSYNC();
+        if (tid == 0) __hip_atomic_store(&s_help[2], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  };
   // body inertia about the tree reference point, in the world frame (lane = body): needs the link poses only.  In the two-wave
   // instantiations the collision wave computes it in front of its detection (it has ~1.8 k cycles of slack before the second
   // barrier, the main wave none) and raises S.cin_ready; the main wave picks it up where the composite inertias start.
@@ -1122,6 +1208,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
         for (int q = 0; q < 4; q++) stv(&S.M[lane][4 * q], f4{hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]});
         HSTAMP(55);
         __syncthreads();  // (4) all-rows-active Hessian handed to the main wave
+        helper_newton();
       }
       // then the closing FK of the step the main wave is finishing -- which is the opening FK of the step whose
       // action-independent half follows
@@ -1203,6 +1290,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     }
     HSTAMP(47);
     __syncthreads();  // (4) all-rows-active Hessian handed to the main wave
+    helper_newton();
     if (fksplit) {
       // the closing forward kinematics of the jointed bodies, beside the main wave's quaternion integration of the free bodies
       // and its state stores (the four quads of lane constants are fetched again: nothing of the opening FK was kept in registers)
@@ -1294,6 +1382,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     S.cin_ready = 0;
     if constexpr (CPL > 1) { S.bp_ready = 0; S.bb_done = 0; }
   }
+  if constexpr (CPL > 1) { if (tid == 0) { s_help[0] = 0; s_help[1] = 0; s_help[2] = 0; } }
   WSYNC();
 
   // ======================= forward kinematics =================================================
@@ -1892,16 +1981,20 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
         flipmask[sl] = (unsigned)(__ballot(flipped) >> (tid & 48)) & 0xffffu;
       }
       WSYNC();
+      if constexpr (CPL > 1) {  // (the helper wave starts on its shares of this iteration; of the first one behind barrier (4))
+        if (it > 0 && tid == 0) __hip_atomic_store(&s_help[0], it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       if (it == 0) STAMP(16);
       ITSTAMP(it, 0);
       // ---- gradient first (cheap): convergence is decided before any Hessian work
       float g = isdof ? Ma - qfs - lsg * lf : 0.0f;
-      for (int c0 = 0; c0 < ncon; c0 += 4) {  // four contacts per trip: one batch of reads, then the sums in contact order
+      const int ncon_g = (CPL > 1 && it > 0 && ncon > G) ? G : ncon;  // (three contacts per lane, from the second iteration on: the contacts above 16 are the helper wave's)
+      for (int c0 = 0; c0 < ncon_g; c0 += 4) {  // four contacts per trip: one batch of reads, then the sums in contact order
         float jn[4], j1[4], j2[4];
         f4 fb[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int c = c0 + u < ncon ? c0 + u : c0;
+          const int c = c0 + u < ncon_g ? c0 + u : c0;
           const float* jb = JBROW(S, c);
           jn[u] = jb[lane]; j1[u] = jb[16 + lane]; j2[u] = jb[32 + lane];
           fb[u] = ldv(CFB(S, c));
@@ -1909,7 +2002,13 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 4; u++)
-          if (c0 + u < ncon) g -= jn[u] * fb[u].x + j1[u] * fb[u].y + j2[u] * fb[u].z;
+          if (c0 + u < ncon_g) g -= jn[u] * fb[u].x + j1[u] * fb[u].y + j2[u] * fb[u].z;
+      }
+      if constexpr (CPL > 1) {
+        if (it > 0) {  // (the helper wave's share: exact zero for an env with at most 16 contacts)
+          while (__hip_atomic_load(&s_help[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1) __builtin_amdgcn_s_sleep(1);
+          g += S.M[lane][G];
+        }
       }
       if (!isdof) g = 0.0f;
       if (it == 0) STAMP(17);
@@ -1960,6 +2059,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
           __syncthreads();  // (4)
           STAMP(53);
           met4 = true;
+          if constexpr (CPL > 1) { if (tid == 0) __hip_atomic_store(&s_help[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const f4 v = ldv(&S.M[lane][4 * q]);
@@ -1979,6 +2079,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
         for (int j = 0; j < G; j++) hkeep[j] += j == lane ? lact - oldlact : 0.0f;
       }
       oldlact = lact;
+      if constexpr (CPL == 1) {
 #pragma unroll
       for (int sl = 0; sl < CPL; sl++)
       for (unsigned fm = flipmask[sl]; fm; fm &= fm - 1u) {  // (group-uniform trip count; contact order: slot by slot)
@@ -2005,6 +2106,18 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
           hkeep[4 * q + 1] += tn * xn[q].y + t1 * x1[q].y + t2 * x2[q].y;
           hkeep[4 * q + 2] += tn * xn[q].z + t1 * x1[q].z + t2 * x2[q].z;
           hkeep[4 * q + 3] += tn * xn[q].w + t1 * x1[q].w + t2 * x2[q].w;
+        }
+      }
+      } else {
+        // (three contacts per lane: this wave takes the flipped contacts of the first slot, the helper wave those of the others --
+        //  its rows are added behind this wave's own, exact zeros for an env with at most 16 contacts)
+        for (unsigned fm = flipmask[0]; fm; fm &= fm - 1u) hess_flip(hkeep, __ffs(fm) - 1, it == 0);
+        while (__hip_atomic_load(&s_help[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1) __builtin_amdgcn_s_sleep(1);
+        const float* hr = help_hrow();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const f4 v = ldv(hr + 4 * q);
+          hkeep[4 * q] += v.x; hkeep[4 * q + 1] += v.y; hkeep[4 * q + 2] += v.z; hkeep[4 * q + 3] += v.w;
         }
       }
       float hrow[G];
@@ -2189,6 +2302,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       ITSTAMP(it, 7);
     }
     if (DUAL && (!post_now || ROT) && !met4) __syncthreads();  // (4) (no Hessian was needed: the collision wave is let go)
+    if constexpr (CPL > 1) { if (tid == 0) __hip_atomic_store(&s_help[0], -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }  // (the helper wave leaves the Newton loop)
     if (a.out_qacc && valid && isdof && step == 0) a.out_qacc[(size_t)env * nv + lane] = qacc;
     if (a.diag && valid && !ovf_env && lane == 0) {
       a.diag[(size_t)env * 4 + 0] = ncon;
