@@ -1064,6 +1064,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
   // with at most 16 contacts gets exact zeros from here: it is computed as by the one-contact-per-lane kernel.
   auto helper_newton = [&]() {
     if constexpr (CPL > 1) {
+      if (!__any(S.ncon > G)) return;  // (no env of the workgroup has a contact above the first slot: the main wave does not ask -- the same test there)
       for (int k = 1;; k++) {
         int r;
         while ((r = __hip_atomic_load(&s_help[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 0 && r < k) __builtin_amdgcn_s_sleep(1);
@@ -1953,6 +1954,8 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     for (int sl = 0; sl < CPL; sl++) prevbits[sl] = 0u;
     float gprev = 0.0f;
     bool met4 = false;
+    // (three contacts per lane: the helper wave takes part in the Newton loop when some env of the workgroup has contacts above the first slot)
+    [[maybe_unused]] const bool use_help = CPL > 1 && __any(ncon > G);
     for (int it = 0; it < mdl_iterations; it++) {
       if (!__any(!done)) break;
       // ---- forces of the active rows; base-force triple and active flags to LDS for the dof lanes
@@ -1982,13 +1985,13 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       }
       WSYNC();
       if constexpr (CPL > 1) {  // (the helper wave starts on its shares of this iteration; of the first one behind barrier (4))
-        if (it > 0 && tid == 0) __hip_atomic_store(&s_help[0], it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (use_help && it > 0 && tid == 0) __hip_atomic_store(&s_help[0], it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       if (it == 0) STAMP(16);
       ITSTAMP(it, 0);
       // ---- gradient first (cheap): convergence is decided before any Hessian work
       float g = isdof ? Ma - qfs - lsg * lf : 0.0f;
-      const int ncon_g = (CPL > 1 && it > 0 && ncon > G) ? G : ncon;  // (three contacts per lane, from the second iteration on: the contacts above 16 are the helper wave's)
+      const int ncon_g = (CPL > 1 && use_help && it > 0 && ncon > G) ? G : ncon;  // (three contacts per lane, from the second iteration on: the contacts above 16 are the helper wave's)
       for (int c0 = 0; c0 < ncon_g; c0 += 4) {  // four contacts per trip: one batch of reads, then the sums in contact order
         float jn[4], j1[4], j2[4];
         f4 fb[4];
@@ -2005,7 +2008,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
           if (c0 + u < ncon_g) g -= jn[u] * fb[u].x + j1[u] * fb[u].y + j2[u] * fb[u].z;
       }
       if constexpr (CPL > 1) {
-        if (it > 0) {  // (the helper wave's share: exact zero for an env with at most 16 contacts)
+        if (use_help && it > 0) {  // (the helper wave's share: exact zero for an env with at most 16 contacts)
           while (__hip_atomic_load(&s_help[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1) __builtin_amdgcn_s_sleep(1);
           g += S.M[lane][G];
         }
@@ -2059,7 +2062,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
           __syncthreads();  // (4)
           STAMP(53);
           met4 = true;
-          if constexpr (CPL > 1) { if (tid == 0) __hip_atomic_store(&s_help[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+          if constexpr (CPL > 1) { if (use_help && tid == 0) __hip_atomic_store(&s_help[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const f4 v = ldv(&S.M[lane][4 * q]);
@@ -2112,12 +2115,14 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
         // (three contacts per lane: this wave takes the flipped contacts of the first slot, the helper wave those of the others --
         //  its rows are added behind this wave's own, exact zeros for an env with at most 16 contacts)
         for (unsigned fm = flipmask[0]; fm; fm &= fm - 1u) hess_flip(hkeep, __ffs(fm) - 1, it == 0);
-        while (__hip_atomic_load(&s_help[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1) __builtin_amdgcn_s_sleep(1);
-        const float* hr = help_hrow();
+        if (use_help) {
+          while (__hip_atomic_load(&s_help[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1) __builtin_amdgcn_s_sleep(1);
+          const float* hr = help_hrow();
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const f4 v = ldv(hr + 4 * q);
-          hkeep[4 * q] += v.x; hkeep[4 * q + 1] += v.y; hkeep[4 * q + 2] += v.z; hkeep[4 * q + 3] += v.w;
+          for (int q = 0; q < 4; q++) {
+            const f4 v = ldv(hr + 4 * q);
+            hkeep[4 * q] += v.x; hkeep[4 * q + 1] += v.y; hkeep[4 * q + 2] += v.z; hkeep[4 * q + 3] += v.w;
+          }
         }
       }
       float hrow[G];
