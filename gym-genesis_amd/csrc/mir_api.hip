@@ -622,11 +622,11 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   // exact contacts, HEAVY phase (mir_step_end decides): most envs of the last step had more points than the one-contact-per-lane kernel
   // holds, so the whole batch takes the three-contacts-per-lane instantiation's first pass in ONE launch (mir_step.hip: VARIANT 7) -- no
   // launch that defers, no list launch behind it, no scratch rows (the first light step afterwards is launched like the one behind a reset)
-  // exact contacts, an OVERFLOW RUN of a HOST-BOUND loop (mir_scene.h): the step as TWO launches of the three-contacts-per-lane
-  // instantiation for the whole batch -- second half (-> terminated bytes), then, on the side stream, the first half of the next step,
-  // which runs beside whatever the caller queues between two steps (the policy, its IK).  Costs GPU time (rows through HBM, two rounds of
-  // workgroups twice) and saves time to the bytes: taken when the GPU is WAITING for this call -- the step's stream has drained -- and
-  // otherwise the heavy phase / the list launch behind the bytes, which cost less GPU time.
+  // exact contacts, an OVERFLOW RUN in a loop that leaves room between two steps (mir_scene.h): the step as TWO launches of the
+  // three-contacts-per-lane instantiation for the whole batch -- second half (-> terminated bytes), then, on the side stream, the first
+  // half of the next step, which runs beside whatever the caller queues between two steps (the policy, its IK).  Costs GPU time (rows
+  // through HBM, two rounds of workgroups twice) and saves time to the bytes; otherwise the heavy phase / the list launch behind the
+  // bytes, which cost less GPU time.
   bool bigrot = false;
   if (h->exact == 1 && h->exact_big && h->bigmode && h->pre_big != nullptr && h->sync_mode == 3 && h->ovf_stream && h->split_step && h->pre_valid &&
       h->pre_stream == stream && h->hm.fk_free_leaf != 0) {
@@ -687,7 +687,7 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
     // ... and the action-independent half of the NEXT step goes out right behind it: it runs while the host is between two calls
     Outs p;
     p.phase = bigrot ? 7 : 1; p.diag = false;
-    if (bigrot && !(getenv("MIR_EXACT_BIG_SIDE") && atoi(getenv("MIR_EXACT_BIG_SIDE")) == 0)) {
+    if (bigrot && h->big_side) {
       // (... on the side stream, behind the launch above: beside the caller's work between two steps; the next mir_step_begin -- and the
       //  launches for envs this step defers -- come behind it through ovf_event)
       if (h->pend_perm >= 0) { p.env_list = h->perm_dev[h->pend_perm]; p.nlist = h->B; }
@@ -1058,6 +1058,7 @@ int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
   //  overlap of the two waves -- which a loop with nothing between its steps pays in full; 2: whenever the rows are there; 0: never)
   h->big_on = (h->exact_big && on != 2 && h->ovf_stream) ? (getenv("MIR_EXACT_BIG") ? atoi(getenv("MIR_EXACT_BIG")) : 1) : 0;
   h->big_gap_us = getenv("MIR_EXACT_BIG_GAP") ? atof(getenv("MIR_EXACT_BIG_GAP")) : 40.0;
+  h->big_side = !(getenv("MIR_EXACT_BIG_SIDE") && atoi(getenv("MIR_EXACT_BIG_SIDE")) == 0);  // (0, a test switch: the first-half launch on the step's stream)
   h->t_end_us = 0.0;
   h->bigmode = 0;
   if (h->big_on && !h->main_event) {

@@ -91,15 +91,17 @@ struct MirScene {
   void* pend_out[4];
   int pend_rotated;         // the pending step is ONE rotated launch (else: a launch followed by the first half of the next step for all envs)
   unsigned long long ex_steps, ex_ovf_steps, ex_ovf_envs, ex_ovf_max;  // steps closed / steps with deferred envs / deferred env-steps / most in one step
-  // OVERFLOW RUNS on the rotated launch with three contacts per lane (mir_step.hip VARIANT 8, StepArgs::phase 6): from the step after one
-  // that deferred envs until a step in which no env is above 16 points, mir_step_begin steps the WHOLE batch with that launch -- the
-  // second half from the scratch rows (an env with 17 .. 48 contacts has its row in pre_big), then the first half of the next step with
-  // the 48-point capacity.  An env whose row the launch before could not write (the first step of a run: the one-contact-per-lane
-  // tail found it above 16 points) is deferred once more and takes the fused pass of the list instantiation.
+  // OVERFLOW RUNS as two launches per step (mir_step.hip VARIANT 9 / 10, StepArgs::phase 6 / 7): from the step after one that
+  // deferred envs until a step in which no env is above 16 points, a mir_step_begin that finds the caller left room between two steps steps
+  // the WHOLE batch with the three-contacts-per-lane instantiation -- the second half from the scratch rows (an env with 17 .. 48 contacts has
+  // its row in pre_big) on the step's stream, then the first half of the next step with the 48-point capacity on the side stream.  An env
+  // whose row the launch before could not write (the first step of a run: the one-contact-per-lane tail found it above 16 points) is
+  // deferred once more and takes the fused pass of the list instantiation.
   float* pre_big;           // (B, K48_STRIDE) device
   int big_on;               // MIR_EXACT_BIG: 0 never (the heavy phase / list launches of the first session), 1 when the caller leaves room between two steps (default), 2 always
-  int bigmode;              // the coming mir_step_begin takes that launch (decided by mir_step_end)
-  int pend_big;             // the pending step is such a launch
+  int bigmode;              // a run is on: the coming mir_step_begin may take the two launches (decided by mir_step_end)
+  int big_side;             // the first-half launch goes on the side stream (MIR_EXACT_BIG_SIDE=0, a test switch: on the step's stream)
+  int pend_big;             // the pending step was launched that way
   unsigned long long ex_big_steps;
   double t_end_us, big_gap_us;  // wall clock of the last mir_step_end's return; what the caller must spend between two steps for the two-launch steps to be taken
   void* main_event;         // hipEvent_t: recorded behind the second-half launch of such a step (the side stream's first-half launch waits for it)
