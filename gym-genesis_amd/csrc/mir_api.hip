@@ -191,6 +191,7 @@ struct Outs {
   int over_cap = 0;    // 16-lane kernel, phase 4 / 5 (StepArgs::over_cap)
   const int32_t* env_list = nullptr;  // 16-lane kernel, phase 1: serve the envs env_list[0 .. nlist) (StepArgs::env_list)
   int nlist = 0;
+  uint32_t* next_host = nullptr;      // 16-lane kernel, phase 7 (StepArgs::next_host)
   unsigned long long* prof = nullptr;  // 16-lane kernel only (debug)
 };
 
@@ -203,7 +204,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
   // link poses of its final state in h->poses -- its closing forward kinematics has them -- so that a render behind a step needs
   // no pose-refresh launch (6 us per 1024 envs).  poses_current: h->poses matches qpos for every env.
   const bool integrates = o.mode == 0 && o.phase != 1 && o.phase != 7;
-  if (integrates && o.phase != 4) h->state_version++;
+  if (integrates && o.phase != 4 && o.phase != 8) h->state_version++;  // (phase 8: the second list of a step whose first list has counted)
   const bool wr_poses = o.poses || (h->poses_live && integrates);
   if (o.mode == 2 && o.poses) h->poses_current = 1;
   else if (integrates && o.phase != 4) h->poses_current = (h->kernel == 64 || wr_poses) && !o.ar.episode_len;  // (an in-kernel reset moves envs after the closing FK)
@@ -226,6 +227,7 @@ int launch(MirScene* h, const Outs& o, void* stream) {
     a.phase = o.phase; a.pre = h->pre;
     a.exact = o.exact; a.over_cap = o.over_cap;
     a.pre_big = (o.phase == 4 || o.phase == 6 || o.phase == 7) ? h->pre_big : nullptr;
+    a.next_host = o.next_host;
     if (o.env_list) { a.env_list = o.env_list; a.B = o.nlist; }
     if (o.phase == 4) a.term_wstride = 1;  // (the terminated byte of list entry k is byte k of term_host)
     rc = mir_launch_step(&a, h->hm.max_contacts, (hipStream_t)stream);
@@ -497,6 +499,8 @@ int mir_destroy(MirHandle h) {
   if (h->pre) (void)hipFree(h->pre);
   if (h->pre_big) (void)hipFree(h->pre_big);
   if (h->main_event) (void)hipEventDestroy((hipEvent_t)h->main_event);
+  if (h->light_event) (void)hipEventDestroy((hipEvent_t)h->light_event);
+  if (h->next_host) (void)hipHostFree(h->next_host);
   if (h->pin_host) (void)hipHostFree(h->pin_host);
   if (h->ovf_list_host) (void)hipHostFree(h->ovf_list_host);
   if (h->ovf_event) (void)hipEventDestroy((hipEvent_t)h->ovf_event);
@@ -596,6 +600,50 @@ int mir_step_fused(MirHandle h, const float* action, float* agent_pos, float* en
  * copies the B bytes to the caller's plain host array -- `terminated = is_success.detach().cpu().numpy()` (env.py:64) without a
  * separate copy command.  The host is free between the two calls (the Python side allocates the next outputs there). */
 static double wall_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+// (developer aid, MIR_EXACT_TIMING=1: host time stamps of the steps of an overflow run, microseconds since mir_step_begin's entry, to stderr)
+static int g_timing = -1;
+static double g_t0 = 0.0, g_ts[6];
+#define TSTAMP(i) do { if (g_timing > 0) g_ts[i] = wall_us() - g_t0; } while (0)
+
+/* A step of an overflow run whose predecessor's first-half launch has said which envs are above the one-contact-per-lane capacity NOW
+ * (h->next_host, tagged h->rt_tag, in the order of perm_host[h->rt_perm]): the order of this step's launches -- those envs first, padded to
+ * whole workgroups with others, then the rest -- into perm_host[*buf]; *nh = how many go to the three-contacts-per-lane list. */
+static int split_lists(MirScene* h, int* buf, int* nh_out) {
+  const size_t B = (size_t)h->B, nwg = (B + 3) / 4;
+  const uint32_t want4 = 0x01010101u * (uint8_t)h->rt_tag, tagm4 = 0x1f1f1f1fu;
+  const int32_t* const pp = h->rt_perm >= 0 ? h->perm_host[h->rt_perm] : nullptr;
+  const volatile uint32_t* w = h->next_host;
+  // (straight into the pinned order: the envs above the capacity from the front, the others from the back)
+  const int nxt = h->rt_perm == 0 ? 1 : 0;
+  int32_t* const out = h->perm_host[nxt];
+  size_t nh = 0, lo = B;
+  unsigned long polls = 0;
+  for (size_t g = 0; g < nwg;) {
+    const uint32_t v = w[g];
+    if (((v >> 1) & tagm4) == want4) {
+      for (size_t k = 0; k < 4 && 4 * g + k < B; k++) {
+        const int32_t e = pp ? pp[4 * g + k] : (int32_t)(4 * g + k);
+        if (v >> (8 * k) & 1u) out[nh++] = e; else out[--lo] = e;
+      }
+      g++;
+      continue;
+    }
+    __builtin_ia32_pause();
+    if ((++polls & 0xfffffu) == 0) {
+      hipError_t e = hipStreamQuery((hipStream_t)h->ovf_stream);
+      if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "mir_step_begin: side stream (exact contacts)");
+      if (e == hipSuccess && polls > 0x4000000u) return set_err(MIR_E_HIP, "mir_step_begin: the first-half launch finished without saying which envs are above 16 points");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  // (whole workgroups: the first of the others join the list of the bigger instantiation, which steps an env with few contacts to the same
+  //  bits -- they sit right behind it in the array already)
+  while ((nh & 3) && nh < B) nh++;
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  *buf = nxt;
+  *nh_out = (int)nh;
+  return MIR_OK;
+}
 int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* env_state, float* reward, uint8_t* terminated, void* stream) {
   if (check(h)) return MIR_E_INVALID;
   // a step left open (an exception between the two calls on the Python side) is closed here: its bytes are waited for and dropped
@@ -627,6 +675,8 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   // half of the next step, which runs beside whatever the caller queues between two steps (the policy, its IK).  Costs GPU time (rows
   // through HBM, two rounds of workgroups twice) and saves time to the bytes; otherwise the heavy phase / the list launch behind the
   // bytes, which cost less GPU time.
+  if (g_timing < 0) g_timing = (getenv("MIR_EXACT_TIMING") && atoi(getenv("MIR_EXACT_TIMING")) != 0) ? 1 : 0;
+  if (g_timing > 0) { g_t0 = wall_us(); for (int i = 0; i < 6; i++) g_ts[i] = 0.0; }
   bool bigrot = false;
   if (h->exact == 1 && h->exact_big && h->bigmode && h->pre_big != nullptr && h->sync_mode == 3 && h->ovf_stream && h->split_step && h->pre_valid &&
       h->pre_stream == stream && h->hm.fk_free_leaf != 0) {
@@ -657,7 +707,19 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   }
   // (a step of an overflow run serves the envs in the order mir_step_end left too: the ones above 16 points first -- their workgroups are
   //  the long ones, and the step's terminated bytes wait for the last of them)
-  if (bigrot && h->perm_next >= 0) { o.env_list = h->perm_dev[h->perm_next]; o.nlist = h->B; h->pend_perm = h->perm_next; }
+  int nh_split = -1;  // (>= 0: the step's second half goes out as two lists, perm[0 .. nh) and perm[nh .. B))
+  const int rt_ok_prev = h->rt_ok;
+  h->rt_ok = 0;
+  if (bigrot && rt_ok_prev && h->big_side && h->next_host && h->big_lists) {
+    int buf = -1;
+    if (int rc = split_lists(h, &buf, &nh_split)) return rc;
+    h->pend_perm = buf;
+    if (nh_split == 0 || nh_split >= h->B) {  // (one list after all)
+      o.phase = nh_split == 0 ? 8 : 6;
+      o.env_list = h->perm_dev[buf]; o.nlist = h->B;
+      nh_split = -1;
+    }
+  } else if (bigrot && h->perm_next >= 0) { o.env_list = h->perm_dev[h->perm_next]; o.nlist = h->B; h->pend_perm = h->perm_next; }
   h->pend_heavy = heavy ? 1 : 0;
   // (exact contacts, ADVICE r5: the launches for the deferred envs of an earlier step ran on the library's side stream, and only the stream
   //  of THAT step was made to wait for them; a step on another stream waits for them here -- state rows, scratch rows and the pinned
@@ -671,8 +733,30 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
   h->pend_rotated = rotated ? 1 : 0;
   o.prof = h->dbg_prof;
   h->dbg_prof = nullptr;
-  int rc = launch(h, o, stream);
+  int rc;
+  if (nh_split >= 0) {
+    // the envs above 16 points on the three-contacts-per-lane instantiation (80 KB workgroups, the long ones: first, on the step's stream),
+    // the others in ONE round of the one-contact-per-lane kernel's 40 KB workgroups on the side stream; the step's stream waits for those
+    Outs oh = o, ol = o;
+    oh.env_list = h->perm_dev[h->pend_perm]; oh.nlist = nh_split;
+    ol.phase = 8; ol.over_cap = 0; ol.prof = nullptr;
+    ol.env_list = h->perm_dev[h->pend_perm] + nh_split; ol.nlist = h->B - nh_split;
+    ol.term_host = h->pin_dev + (size_t)(nh_split / 4) * h->term_wstride * sizeof(uint32_t);
+    // (the side stream's launch reads the caller's action too: behind whatever produced it on the step's stream)
+    HIPCHK(hipEventRecord((hipEvent_t)h->main_event, (hipStream_t)stream));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)h->ovf_stream, (hipEvent_t)h->main_event, 0));
+    rc = launch(h, oh, stream);
+    if (rc != MIR_OK) return rc;
+    rc = launch(h, ol, h->ovf_stream);
+    if (rc == MIR_OK) {
+      HIPCHK(hipEventRecord((hipEvent_t)h->light_event, (hipStream_t)h->ovf_stream));
+      HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)h->light_event, 0));
+    }
+  } else {
+    rc = launch(h, o, stream);
+  }
   if (rc != MIR_OK) return rc;
+  TSTAMP(0);
   // the launch that carries the tag is queued: from here on the step is pending whatever happens to the calls behind it
   h->seq = seq;
   h->tag = tag;
@@ -691,10 +775,17 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
       // (... on the side stream, behind the launch above: beside the caller's work between two steps; the next mir_step_begin -- and the
       //  launches for envs this step defers -- come behind it through ovf_event)
       if (h->pend_perm >= 0) { p.env_list = h->perm_dev[h->pend_perm]; p.nlist = h->B; }
+      if (h->next_host) {  // (... and says which envs the next step finds above the one-contact-per-lane capacity: split_lists)
+        memset(h->next_host, 0, ((size_t)h->B + 3) / 4 * sizeof(uint32_t));  // (tags come round every 31 steps)
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        p.next_host = h->next_dev; p.term_tag = tag;
+        p.over_cap = h->hm.max_contacts < K16_MAX_CONTACT ? h->hm.max_contacts : K16_MAX_CONTACT;
+      }
       HIPCHK(hipEventRecord((hipEvent_t)h->main_event, (hipStream_t)stream));
       HIPCHK(hipStreamWaitEvent((hipStream_t)h->ovf_stream, (hipEvent_t)h->main_event, 0));
       rc = launch(h, p, h->ovf_stream);
       if (rc != MIR_OK) return rc;
+      if (h->next_host) { h->rt_ok = 1; h->rt_perm = h->pend_perm; h->rt_tag = tag; }
       HIPCHK(hipEventRecord((hipEvent_t)h->ovf_event, (hipStream_t)h->ovf_stream));
       h->ovf_event_live = 1;
       h->ovf_waited_stream = reinterpret_cast<void*>(~(uintptr_t)0);  // (no stream has been made to wait yet -- the null stream is a stream)
@@ -706,6 +797,7 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
     h->pre_valid = 1;
     h->pre_stream = stream;
   }
+  TSTAMP(1);
   return MIR_OK;
 }
 
@@ -865,6 +957,7 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
     const size_t nwg = (B + 3) / 4, ws = (size_t)h->term_wstride;
     unsigned long polls = 0;
     int ndefer = 0, nover = 0;
+    TSTAMP(2);
     h->ex_steps++;
     // (a launch of a heavy phase may have served the envs in a permuted order: byte k of workgroup g is env pp[4 g + k])
     const int32_t* const pp = (h->exact && h->pend_perm >= 0) ? h->perm_host[h->pend_perm] : nullptr;
@@ -897,6 +990,7 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
       }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    TSTAMP(3);
     if (h->exact && h->exact_big) {
       // light -> heavy when this step deferred at least heavy_enter envs; heavy -> light when fewer than heavy_leave had more points than
       // the one-contact-per-lane kernel holds (MIR_EXACT_HEAVY="enter,leave"; enter <= 0: never heavy).  The cost model behind the
@@ -916,7 +1010,7 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
       // sorted, 30 % of them are done in half the time, and the expensive ones are dispatched first (the words are in this core's
       // cache: the loop above has just read them)
       h->perm_next = -1;
-      if ((h->heavy || h->bigmode) && h->heavy_sort) {
+      if ((h->heavy || h->bigmode) && h->heavy_sort && !(h->pend_big && h->rt_ok && !h->heavy)) {  // (rt_ok: the next step of the run takes its order from the first-half launch's words)
         const int nxt = h->pend_perm == 0 ? 1 : 0;
         int32_t* const out = h->perm_host[nxt];
         const uint32_t bit = (h->pend_heavy || h->pend_big) ? 0x40u : 0x80u;
@@ -934,6 +1028,9 @@ int mir_step_end(MirHandle h, uint8_t* terminated_host) {
     if (h->big_on) {
       const int rc = ndefer ? exact_finish(h, ndefer, terminated_host) : MIR_OK;
       h->t_end_us = wall_us();
+      if (g_timing > 0 && (h->pend_big || ndefer))
+        fprintf(stderr, "[exact timing] two launches %d, above 16 points %d, deferred %d | main launch queued %.1f, mir_step_begin returns %.1f, mir_step_end called %.1f, "
+                "last byte %.1f, mir_step_end returns %.1f us\n", h->pend_big, nover, ndefer, g_ts[0], g_ts[1], g_ts[2], g_ts[3], h->t_end_us - g_t0);
       return rc;
     }
     if (ndefer) return exact_finish(h, ndefer, terminated_host);
@@ -1058,15 +1155,22 @@ int mir_set_exact_contacts(MirHandle h, const MirSceneSpec* spec, int32_t on) {
   //  overlap of the two waves -- which a loop with nothing between its steps pays in full; 2: whenever the rows are there; 0: never)
   h->big_on = (h->exact_big && on != 2 && h->ovf_stream) ? (getenv("MIR_EXACT_BIG") ? atoi(getenv("MIR_EXACT_BIG")) : 1) : 0;
   h->big_gap_us = getenv("MIR_EXACT_BIG_GAP") ? atof(getenv("MIR_EXACT_BIG_GAP")) : 40.0;
+  h->big_lists = !(getenv("MIR_EXACT_BIG_LISTS") && atoi(getenv("MIR_EXACT_BIG_LISTS")) == 0);  // (0: the second half always as one launch for the whole batch)
   h->big_side = !(getenv("MIR_EXACT_BIG_SIDE") && atoi(getenv("MIR_EXACT_BIG_SIDE")) == 0);  // (0, a test switch: the first-half launch on the step's stream)
   h->t_end_us = 0.0;
   h->bigmode = 0;
   if (h->big_on && !h->main_event) {
     DeviceGuard guard(h->device);
-    hipEvent_t ev = nullptr;
+    hipEvent_t ev = nullptr, ev2 = nullptr;
     HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    h->main_event = ev;
+    HIPCHK(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
+    h->main_event = ev; h->light_event = ev2;
+    const size_t nb = (((size_t)h->B + 3) / 4 * sizeof(uint32_t) + 63) / 64 * 64;
+    HIPCHK(hipHostMalloc((void**)&h->next_host, nb, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h->next_host, 0, nb);
+    HIPCHK(hipHostGetDevicePointer((void**)&h->next_dev, h->next_host, 0));
   }
+  h->rt_ok = 0;
   if (h->big_on && !h->pre_big) {
     DeviceGuard guard(h->device);
     HIPCHK(hipMalloc((void**)&h->pre_big, (size_t)h->B * K48_STRIDE * sizeof(float)));

@@ -105,6 +105,15 @@ struct MirScene {
   unsigned long long ex_big_steps;
   double t_end_us, big_gap_us;  // wall clock of the last mir_step_end's return; what the caller must spend between two steps for the two-launch steps to be taken
   void* main_event;         // hipEvent_t: recorded behind the second-half launch of such a step (the side stream's first-half launch waits for it)
+  // ... and its second half as TWO LISTS once the first-half launch of the step before has said which envs are above 16 points NOW
+  // (StepArgs::next_host): those on the three-contacts-per-lane instantiation on the step's stream, the others -- one round of 40 KB
+  // workgroups -- on the rotated launch's first pass (VARIANT 11) on the side stream
+  uint32_t* next_host;      // pinned, device-mapped: (B + 3) / 4 words
+  uint32_t* next_dev;
+  int big_lists;            // (MIR_EXACT_BIG_LISTS=0: never)
+  int rt_ok, rt_perm;       // the first-half launch of the step before wrote them, serving the envs through perm_host[rt_perm] (-1: in order)
+  uint32_t rt_tag;          // ... with this tag
+  void* light_event;        // hipEvent_t behind the list launch on the side stream: the step's stream waits for it
 };
 
 // library-internal helpers implemented in mir_api.hip

@@ -48,7 +48,8 @@ struct StepArgs {
   // `pre`.  3 = 2 followed by 1 (of the next step) in one launch.  `pre`: K16_PRE_STRIDE floats per env.
   // 4 = the LIST instantiation of exact contacts (three contacts per lane, capacity 48): the whole step for the envs of `env_list`,
   // then 1 for them; 5 = its first pass alone for the whole batch (mir_step.hip: VARIANT 6 / 7); 6 / 7 = 2 / 1 with three contacts per lane
-  // (VARIANT 9 / 10: the two launches of a step of an overflow run -- rows of up to 48 contacts through `pre_big`).
+  // (VARIANT 9 / 10: the two launches of a step of an overflow run -- rows of up to 48 contacts through `pre_big`); 8 = 3's first pass
+  // alone for a list of envs (VARIANT 11: the envs of such a step that are at most at 16 points).
   int phase;
   float* pre;
   // [0] env-steps that ended with a non-finite state (divergence guard, counted while diag is set; mir_get_bad);
@@ -73,6 +74,9 @@ struct StepArgs {
   // head of the env's row in `pre` then holds ncon = 0, the count in the `coupled` word and K48_MAGIC in its third word: a launch of the
   // one-contact-per-lane kernel defers the env on the count, phase 6 picks the big row up.  Null: such rows are not written.
   float* pre_big;
+  // phase 7: device address of pinned host words, one per workgroup -- byte k = term_tag << 1 | (the NEXT step finds the workgroup's env k
+  // with more candidate points than over_cap) -- or null
+  uint32_t* next_host;
 };
 #define K48_HEAD 0    /* ncon, second-tree flags of contacts 16 .. 31, of 32 .. 47 (int bits), pad */
 #define K48_CMETA 4   /* MIR_MAX_CONTACT x 4 */

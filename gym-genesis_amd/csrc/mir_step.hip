@@ -287,12 +287,15 @@ __device__ __forceinline__ void step_rows_l(float al, float ljar, float ljv, flo
 // the host decides on when to go back).
 template <int VARIANT, int FEAT, int CPL = 1>
 __global__ __launch_bounds__((VARIANT == 0 || VARIANT == 3 || VARIANT >= 5) ? 128 : 64)
-__attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VARIANT >= 6 ? 1 : 10)))) void mir_step_kernel(StepArgs a) {
+__attribute__((amdgpu_waves_per_eu((VARIANT == 5 || VARIANT == 11) ? 2 : 1, (VARIANT == 5 || VARIANT == 11) ? 2 : (VARIANT >= 6 ? 1 : 10)))) void mir_step_kernel(StepArgs a) {
   // VARIANT 5 = both halves in one launch, ROTATED: first the action-dependent half of THIS step (from the pre buffer), then the
   // action-independent half of the NEXT one (into the pre buffer).  The host sees `terminated` after the first half; the second
   // runs while it is between two env.step() calls, without a second launch, a second prologue or a second forward kinematics
   // (the closing FK of this step is the opening FK of the next).  Needs the split closing FK (fk_free_leaf scenes).
-  constexpr bool ROT = VARIANT == 5 || VARIANT == 8 || VARIANT == 9;
+  constexpr bool ROT = VARIANT == 5 || VARIANT == 8 || VARIANT == 9 || VARIANT == 11;
+  // (VARIANT 11, CPL = 1 = the rotated launch's first pass alone for a LIST of envs: the second half of the step for the envs of an
+  //  overflow run that are at most at 16 points -- one round of 40 KB workgroups beside VARIANT 9's list of the others)
+  constexpr bool FIRSTONLY = VARIANT == 9 || VARIANT == 11;
   // VARIANT 9 / 10 (CPL = 3) = the two halves of a step with three contacts per lane, as TWO launches: what mir_step_begin launches for
   // the whole batch while some env is above 16 points (an OVERFLOW RUN).  9 = the second half of this step from the scratch rows -- an
   // env with 17 .. 48 contacts has its row in StepArgs::pre_big, written by the launch before -- up to the outputs and the terminated
@@ -351,7 +354,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
   const bool valid = env_raw < a.B;
   int env = valid ? env_raw : a.B - 1;
   // (exact contacts: the action-independent half for a LIST of envs -- the ones the wave kernel has just stepped; see StepArgs::env_list)
-  if constexpr (VARIANT == 3 || BIGV) { if (a.env_list) env = a.env_list[env]; }
+  if constexpr (VARIANT == 3 || VARIANT == 11 || BIGV) { if (a.env_list) env = a.env_list[env]; }
   EnvLds& S = s_env[grp];
 
   // (SPEC: the headline scene's sizes and options are literals -- SpecPick, emitted by mir_compile into mir_spec_pick.h -- so
@@ -458,13 +461,15 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
   const int mdl_obj_qadr = SPEC ? SpecPick::obj_qadr : m->obj_qadr;
   const bool term_early = VARIANT != 1 && fk_free_leaf && mdl_obj_qadr >= 0;
   // ... and before the solver has converged where the mask provably cannot change any more (see mir_model.h: term_bound_ok)
-  const bool term_bound = (VARIANT == 0 || VARIANT == 5) && term_early && m->term_bound_ok != 0 && a.term_host != nullptr && !a.no_early_mask;
+  // (VARIANT 9, the second-half launch of an overflow run: two rounds of workgroups, and the step's bytes wait for the second round's --
+  //  from inside the solver loop they leave at the first gradient instead of behind the last Newton iteration of 17 - 48 contacts)
+  const bool term_bound = (VARIANT == 0 || VARIANT == 5 || VARIANT == 9 || VARIANT == 11) && term_early && m->term_bound_ok != 0 && a.term_host != nullptr && !a.no_early_mask;
   const int term_zlane = SPEC ? SpecPick::term_zlane : m->term_zlane;
   // exact contacts (StepArgs::exact): an env whose candidate contact points exceed this is DEFERRED to the wave kernel -- the launch
   // computes on (its lanes cannot leave the wave) but stores nothing for it and flags its terminated byte (wave-uniform; never without the flag)
   // (StepArgs::exact == 2, a test switch: EVERY env is deferred -- the whole batch then takes the list instantiation; the list
   //  instantiation itself defers what exceeds ITS capacity, to the wave-per-env kernel)
-  constexpr bool DEFER = VARIANT == 0 || VARIANT == 4 || VARIANT == 5 || BIGV;
+  constexpr bool DEFER = VARIANT == 0 || VARIANT == 4 || VARIANT == 5 || VARIANT == 11 || BIGV;
   const int defer_above = BIGV ? MAXCON : ((DEFER && a.exact) ? (a.exact == 2 ? -1 : (max_contacts < MAXCON ? max_contacts : MAXCON)) : 0x7fffffff);
   bool ovf_env = false;  // this lane's env is deferred: set where the step reads the `coupled` word (uniform over the env's row)
   bool over_env = false; // (three contacts per lane: the env had more candidate points than StepArgs::over_cap -- bit 6 of its terminated byte)
@@ -1220,7 +1225,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
       group_fk<true>(S, lane, nb, hparents, hk, row4);
       HSTAMP(57);
       __syncthreads();  // (6) link poses of the new state handed to the main wave
-      if (VARIANT == 9) return;  // (the second half alone: the first half of the next step is the next launch)
+      if (FIRSTONLY) return;  // (the second half alone: the first half of the next step is the next launch)
     } else {
       // The collision wave opens the launch with the FORWARD KINEMATICS of the stored state: it needs one row of qpos and four of
       // the twelve quads of lane constants, so its loads are back sooner than the main wave's (which also brings in the model
@@ -1281,6 +1286,16 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     HSTAMP(46);
     {
       if (PRE || ROT) {
+        // (the first-half launch of an overflow run tells the host which envs the next step finds above the one-contact-per-lane capacity
+        //  -- a tagged byte per env, a word per workgroup, in pinned memory -- so that its second half can go out as two lists: those on
+        //  the three-contacts-per-lane instantiation, the others in one round of the one-contact-per-lane kernel's workgroups)
+        if (VARIANT == 10 && a.next_host) {
+          const unsigned long long fb = __ballot(valid && pts0 > a.over_cap && lane == 0);
+          if (tid == 0) {
+            const uint32_t bits = (uint32_t)(fb & 1u) | (uint32_t)(fb >> 16 & 1u) << 8 | (uint32_t)(fb >> 32 & 1u) << 16 | (uint32_t)(fb >> 48 & 1u) << 24;
+            __hip_atomic_store(a.next_host + blockIdx.x, bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
         pre_store();
         return;
       }
@@ -2039,8 +2054,10 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
         const bool decided = !valid || ovf_env || fabsf(zp - mdl_reward_z) > slack;  // (a deferred env's byte says so, whatever its height)
         if (!__any(!decided)) {
           const unsigned long long tb = __ballot(valid && !ovf_env && above(zp, mdl_reward_z) && lane == 0), db = __ballot(ovf_env && valid && lane == 0);
+          const unsigned long long ob = BIGV ? __ballot(over_env && valid && lane == 0) : 0ull;  // (three contacts per lane: bit 6, as in the bytes behind the integrator)
           term_bits = (uint32_t)(tb & 1u) | (uint32_t)(tb >> 16 & 1u) << 8 | (uint32_t)(tb >> 32 & 1u) << 16 | (uint32_t)(tb >> 48 & 1u) << 24 |
-                      (uint32_t)(db & 1u) << 7 | (uint32_t)(db >> 16 & 1u) << 15 | (uint32_t)(db >> 32 & 1u) << 23 | (uint32_t)(db >> 48 & 1u) << 31;
+                      (uint32_t)(db & 1u) << 7 | (uint32_t)(db >> 16 & 1u) << 15 | (uint32_t)(db >> 32 & 1u) << 23 | (uint32_t)(db >> 48 & 1u) << 31 |
+                      (uint32_t)(ob & 1u) << 6 | (uint32_t)(ob >> 16 & 1u) << 14 | (uint32_t)(ob >> 32 & 1u) << 22 | (uint32_t)(ob >> 48 & 1u) << 30;
           if (tid == 0)
             __hip_atomic_store(reinterpret_cast<uint32_t*>(a.term_host) + (size_t)blockIdx.x * a.term_wstride, term_bits | (a.term_tag << 1) * 0x01010101u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2437,7 +2454,7 @@ __attribute__((amdgpu_waves_per_eu(VARIANT == 5 ? 2 : 1, VARIANT == 5 ? 2 : (VAR
     if ((ROT || BIG2) && step == 0) emit_outputs();
     return 0;
   };  // step_body
-  if constexpr (VARIANT == 9) {
+  if constexpr (FIRSTONLY) {
     step_body(std::integral_constant<int, 0>{});  // (the outputs leave at its end)
   } else if constexpr (ROT || BIG2) {
     if (step_body(std::integral_constant<int, 0>{}) == 0) step_body(std::integral_constant<int, 1>{});
@@ -2495,6 +2512,7 @@ static void launch_feat(const StepArgs& a, int blocks, int single, int plain_loo
   else if (a.phase == 5) hipLaunchKernelGGL((mir_step_kernel<7, FEAT, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 6) hipLaunchKernelGGL((mir_step_kernel<9, FEAT, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 7) hipLaunchKernelGGL((mir_step_kernel<10, FEAT, 3>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 8) hipLaunchKernelGGL((mir_step_kernel<11, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, FEAT>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
   else if constexpr ((FEAT & 4) == 0) hipLaunchKernelGGL((mir_step_kernel<2, FEAT>), dim3(blocks), dim3(64), 0, stream, a);
@@ -2503,7 +2521,7 @@ extern "C" __attribute__((visibility("hidden"))) int mir_launch_step_convex(cons
   StepArgs a = *args;
   const int blocks = (a.B + EPB - 1) / EPB;
   // the headline scene's instantiation (features bit 2: mir_create found SpecPick::matches); the everything-variant stays generic
-  if ((a.features & 4) && (a.phase == 1 || a.phase == 3 || a.phase == 4 || a.phase == 5 || a.phase == 6 || a.phase == 7 || single || plain_loop)) launch_feat<5>(a, blocks, single, plain_loop, stream);
+  if ((a.features & 4) && (a.phase == 1 || a.phase == 3 || a.phase == 4 || a.phase == 5 || a.phase == 6 || a.phase == 7 || a.phase == 8 || single || plain_loop)) launch_feat<5>(a, blocks, single, plain_loop, stream);
   else if (a.features & 2) launch_feat<3>(a, blocks, single, plain_loop, stream);  // sweep-and-prune scenes carry the convex code too
   else launch_feat<1>(a, blocks, single, plain_loop, stream);
   return (int)hipGetLastError();
@@ -2534,6 +2552,7 @@ extern "C" int mir_launch_step(const StepArgs* args, int max_contacts_lds, hipSt
   else if (a.phase == 5) hipLaunchKernelGGL((mir_step_kernel<7, 0, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 6) hipLaunchKernelGGL((mir_step_kernel<9, 0, 3>), dim3(blocks), dim3(128), 0, stream, a);
   else if (a.phase == 7) hipLaunchKernelGGL((mir_step_kernel<10, 0, 3>), dim3(blocks), dim3(128), 0, stream, a);
+  else if (a.phase == 8) hipLaunchKernelGGL((mir_step_kernel<11, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (single) hipLaunchKernelGGL((mir_step_kernel<0, 0>), dim3(blocks), dim3(128), 0, stream, a);
   else if (plain_loop) hipLaunchKernelGGL((mir_step_kernel<1, 0>), dim3(blocks), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((mir_step_kernel<2, 0>), dim3(blocks), dim3(64), 0, stream, a);
