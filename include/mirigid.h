@@ -320,7 +320,9 @@ int mir_step_go(MirHandle h, const float* action, void* stream);
  * one that deferred envs until a step in which no env is above 16 points) is TWO launches of the three-contacts-per-lane instantiation for
  * the whole batch: the second half of the step from the scratch rows up to the outputs and the terminated bytes, on `stream`; and the first
  * half of the next step on the library's side stream, beside whatever the caller queues on `stream` next (the next mir_step_begin is made
- * to wait for it).  Same results bit for bit; less time inside the two calls, a third more GPU time per step.  MIR_EXACT_BIG=0: never
+ * to wait for it) -- the second half as two list launches once the first half has said which envs are above 16 points: those on the
+ * three-contacts-per-lane instantiation, the others in one round of the one-contact-per-lane kernel's workgroups on the side stream.
+ * Same results bit for bit; less time inside the two calls, a third more GPU time per step.  MIR_EXACT_BIG=0: never
  * (heavy phase / list launches), 2: whenever the rows are there.  out4[3] of mir_get_exact_route counts such steps.
  * on = 2 (tests): every env of every step is deferred, i.e. the whole batch is stepped by the launches that otherwise serve the
  * deferred envs only -- the twin the parity tests compare a deferred env with, bit for bit. */
