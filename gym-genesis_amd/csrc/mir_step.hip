@@ -34,7 +34,9 @@
 //     everything (per-stage outputs, pose refresh, profiling stamps); <3> / <4> the action-independent / action-dependent half
 //     of a step through a scratch row in HBM, <5> the ROTATED launch of GenesisEnv.step -- <4> of this step followed by <3> of
 //     the next in one kernel, so that the host has its `terminated` after half a step and the rest runs while it is between two
-//     calls.  One step body serves all of them; built with -ffp-contract=on so that they agree bit for bit.
+//     calls; with three contacts per lane (CPL = 3, exact contacts) <6> the whole step + the next step's <3> for a list of envs, <7> the
+//     whole step for the batch (heavy phase), <9> / <10> the two halves as two launches (overflow runs), and <11> (CPL = 1) <5>'s first
+//     pass alone for a list.  One step body serves all of them; built with -ffp-contract=on so that they agree bit for bit.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
