@@ -255,15 +255,19 @@ def test_every_launch_kind_defers_the_same_way(franka_spec, monkeypatch, var, va
     assert abs(st["overflow_env_steps"] - n_def) <= 10 and n_def > 100 and st["steps"] == 200 and lifted.mean() > 0.9
 
 
-def test_heavy_phase_from_the_first_overflow_on_and_a_batch_that_is_not_a_multiple_of_four(franka_spec, monkeypatch):
+@pytest.mark.parametrize("route", ["heavy", "two_launches"])
+def test_heavy_phase_from_the_first_overflow_on_and_a_batch_that_is_not_a_multiple_of_four(franka_spec, monkeypatch, route):
     """MIR_EXACT_HEAVY=1,1: the whole batch goes to the three-contacts-per-lane launch from the step after the first deferred env until no
     env is above 16 points -- with the envs served in sorted order (the ones above 16 points first), 30 envs: the last workgroup holds
     two.  Every env of every step equals its twin (an env with at most 16 points is the one-contact-per-lane kernel's bit for bit)."""
     from gym_genesis.backend.lib import MirScene
 
     monkeypatch.setenv("MIR_SPLIT_STEP", "1")
-    monkeypatch.setenv("MIR_EXACT_HEAVY", "1,1")
-    monkeypatch.setenv("MIR_EXACT_BIG", "0")   # (this loop spends milliseconds between two steps: it would otherwise take the two-launch steps of an overflow run)
+    if route == "heavy":
+        monkeypatch.setenv("MIR_EXACT_HEAVY", "1,1")
+        monkeypatch.setenv("MIR_EXACT_BIG", "0")   # (this loop spends milliseconds between two steps: it would otherwise take the two-launch steps of an overflow run)
+    else:   # (the same 30 envs through the overflow runs' two launches, their second half as two lists padded to whole workgroups)
+        monkeypatch.setenv("MIR_EXACT_BIG", "2")
     n = 30
     sc, plain, twin = MirScene(franka_spec, n), MirScene(franka_spec, n), MirScene(franka_spec, n)
     sc.set_exact_contacts(True)
@@ -291,7 +295,7 @@ def test_heavy_phase_from_the_first_overflow_on_and_a_batch_that_is_not_a_multip
             assert torch.equal(x[dfr], z[dfr]), f"step {t}: an env above 16 points differs from its twin"
         assert np.array_equal(h0, b0[3].cpu().numpy().astype(bool))
     st, r = sc.exact_stats(), sc.exact_route()
-    assert n_def > 20 and st["overflow_env_steps"] == n_def and r["heavy_steps"] > 3 and r["wave_env_steps"] == 0, (n_def, st, r)
+    assert n_def > 20 and st["overflow_env_steps"] == n_def and r["wave_env_steps"] == 0 and (r["heavy_steps"] > 3 if route == "heavy" else r["big_steps"] > 3), (n_def, st, r)
 
 
 @pytest.mark.parametrize("big", [False, True])
