@@ -531,3 +531,43 @@ def test_tight_loop_every_route_gives_the_same_trajectory(monkeypatch):
             bad = (out != ref).flatten(1).any(1)
             assert not bool(bad.any()), f"MIR_EXACT_BIG={mode}: first differing step {int(torch.nonzero(bad)[0])}"
         del env
+
+
+def test_the_route_of_an_overflow_step_follows_what_the_caller_does_between_two_steps(monkeypatch):
+    """The default (MIR_EXACT_BIG=1): a step of an overflow run is two launches -- second half, then the first half of the next step on the
+    side stream -- when the caller spent at least 40 us between mir_step_end's return and mir_step_begin (the reference's expert: its policy
+    and IK), and the list launches / heavy phase when it did not (those cost less GPU time).  The scripted grasp at 512 envs, once with
+    nothing between the steps and once with 150 us of host work: the first takes no two-launch step, the second takes them through its
+    overflow runs; both end in the same bits."""
+    import time
+
+    from gym_genesis.env import GenesisEnv
+
+    monkeypatch.delenv("MIR_EXACT_BIG", raising=False)
+    n = 512
+    pos, acts = _grasp_workload(n)
+    quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]]).repeat(n, 1)
+    home = torch.tensor(HOME).repeat(n, 1)
+    finals, routes = [], []
+    for pause in (0.0, 150e-6):
+        env = GenesisEnv(task="cube_pick", robot="franka", num_envs=n, enable_pixels=False, exact_contacts=True)
+        env.reset(seed=0)
+        mir = env._env._mir
+        mir.reset(pos, quat, home)
+        mir.exact_stats(reset=True)
+        dacts = torch.as_tensor(acts, device=mir.device)
+        for t in range(dacts.shape[0]):
+            env.step(dacts[t])
+            if pause:
+                t0 = time.perf_counter()
+                while time.perf_counter() - t0 < pause:
+                    pass
+        torch.cuda.synchronize()
+        finals.append([x.clone() for x in mir.get_state()[:2]])
+        routes.append((mir.exact_stats(), mir.exact_route()))
+        del env
+    (st0, r0), (st1, r1) = routes
+    print(f"\n[route by the caller's gap] tight loop {r0}; 150 us between the steps {r1}")
+    assert st0 == st1 and st0["overflow_env_steps"] > 100
+    assert r0["big_steps"] == 0 and r1["big_steps"] >= st1["overflow_steps"] - 8, (r0, r1, st1)
+    assert all(torch.equal(a, b) for a, b in zip(*finals))
