@@ -742,11 +742,12 @@ int mir_step_begin(MirHandle h, const float* action, float* agent_pos, float* en
     ol.phase = 8; ol.over_cap = 0; ol.prof = nullptr;
     ol.env_list = h->perm_dev[h->pend_perm] + nh_split; ol.nlist = h->B - nh_split;
     ol.term_host = h->pin_dev + (size_t)(nh_split / 4) * h->term_wstride * sizeof(uint32_t);
-    // (the side stream's launch reads the caller's action too: behind whatever produced it on the step's stream)
+    // (the side stream's launch reads the caller's action too: behind whatever produced it on the step's stream -- an event recorded
+    //  there IN FRONT of the first list's launch, or the second list would wait for the first)
     HIPCHK(hipEventRecord((hipEvent_t)h->main_event, (hipStream_t)stream));
-    HIPCHK(hipStreamWaitEvent((hipStream_t)h->ovf_stream, (hipEvent_t)h->main_event, 0));
     rc = launch(h, oh, stream);
     if (rc != MIR_OK) return rc;
+    HIPCHK(hipStreamWaitEvent((hipStream_t)h->ovf_stream, (hipEvent_t)h->main_event, 0));
     rc = launch(h, ol, h->ovf_stream);
     if (rc == MIR_OK) {
       HIPCHK(hipEventRecord((hipEvent_t)h->light_event, (hipStream_t)h->ovf_stream));
