@@ -118,9 +118,9 @@ __global__ __launch_bounds__(64) void mir_ik_kernel(IkArgs a) {
         }                                                                                                        \
       }
       IK_SCAN_STEP(1)
-      IK_SCAN_STEP(2)
-      IK_SCAN_STEP(4)
-      IK_SCAN_STEP(8)
+      if (n > 2) IK_SCAN_STEP(2)
+      if (n > 4) IK_SCAN_STEP(4)
+      if (n > 8) IK_SCAN_STEP(8)  // (the Panda's chain to the hand is eight elements once its fixed base link is folded into joint 1: host side)
 #undef IK_SCAN_STEP
     }
     // ---- task-space error of the candidate (every lane, redundantly): the pose of the chain's last element comes over the crossbar
@@ -276,6 +276,43 @@ extern "C" int mir_inverse_kinematics_rows(MirHandle h, int32_t link_body, const
     if (jt == MIR_JNT_FREE) return mir_set_error(MIR_E_INVALID, "mir_inverse_kinematics: the link hangs off a free body");
     a.ch.jtype[i] = jt;
     a.ch.qcol[i] = col_of_body[b];
+  }
+  // A FIXED element in front of another one is a constant: folded into that element's base transform (pos' = p_f + R_f pos, quat' = q_f quat)
+  // the chain is one element shorter -- for the Panda's hand nine become eight, and the kernel's prefix scan three steps instead of four.
+  {
+    auto qmul_h = [](const double* p, const double* q, double* r) {
+      r[0] = p[0] * q[0] - p[1] * q[1] - p[2] * q[2] - p[3] * q[3]; r[1] = p[0] * q[1] + p[1] * q[0] + p[2] * q[3] - p[3] * q[2];
+      r[2] = p[0] * q[2] - p[1] * q[3] + p[2] * q[0] + p[3] * q[1]; r[3] = p[0] * q[3] + p[1] * q[2] - p[2] * q[1] + p[3] * q[0];
+    };
+    int m_ = 0;
+    bool carry = false;
+    double cp[3] = {0, 0, 0}, cq[4] = {1, 0, 0, 0};  // the fixed elements folded so far, waiting for the next element
+    for (int i = 0; i < n; i++) {
+      double p[3] = {a.ch.pos[i][0], a.ch.pos[i][1], a.ch.pos[i][2]}, q[4] = {a.ch.quat[i][0], a.ch.quat[i][1], a.ch.quat[i][2], a.ch.quat[i][3]};
+      if (carry) {  // this element's base transform behind the carried one
+        const double v[4] = {0, p[0], p[1], p[2]};
+        double t[4], cqc[4] = {cq[0], -cq[1], -cq[2], -cq[3]}, rv[4], nq[4];
+        qmul_h(cq, v, t); qmul_h(t, cqc, rv);
+        p[0] = cp[0] + rv[1]; p[1] = cp[1] + rv[2]; p[2] = cp[2] + rv[3];
+        qmul_h(cq, q, nq);
+        for (int k = 0; k < 4; k++) q[k] = nq[k];
+        carry = false;
+      }
+      const bool fixed_inner = a.ch.jtype[i] == MIR_JNT_FIXED && i < n - 1;
+      if (fixed_inner) {
+        for (int k = 0; k < 3; k++) cp[k] = p[k];
+        for (int k = 0; k < 4; k++) cq[k] = q[k];
+        carry = true;
+        continue;
+      }
+      a.ch.jtype[m_] = a.ch.jtype[i]; a.ch.qcol[m_] = a.ch.qcol[i];
+      a.ch.lo[m_] = a.ch.lo[i]; a.ch.hi[m_] = a.ch.hi[i]; a.ch.limited[m_] = a.ch.limited[i];
+      for (int k = 0; k < 3; k++) { a.ch.pos[m_][k] = (float)p[k]; a.ch.axis[m_][k] = a.ch.axis[i][k]; }
+      for (int k = 0; k < 4; k++) a.ch.quat[m_][k] = (float)q[k];
+      m_++;
+    }
+    for (int i = m_; i < n; i++) { a.ch.jtype[i] = MIR_JNT_FIXED; a.ch.qcol[i] = -1; a.ch.limited[i] = 0; }
+    a.ch.n = m_;
   }
   MirIkOptions o = {20, 1, 0.05, 5e-4, 5e-3, 0.5};
   if (opt) {
