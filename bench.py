@@ -852,7 +852,39 @@ def ik_bench(torch, dev, calls: int = 200):
     # row, which is not counted; the launch lasts as long as its slowest wave (`iters_wave_max`), the chip idles behind the mean
     f_iter = 1.7e3
     flops = f_iter * float(it.sum())
+    # ... and the call as the reference's expert makes it (examples/franka/pick_cube_state.py: one robot.inverse_kinematics per env.step,
+    # envs_idx = arange(B), one quaternion expanded to the batch): HIP events around the wrapper, median per stage of its five stages
+    expert_call_us = None
+    try:
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("pick_cube_state", os.path.join(ROOT, "examples", "franka", "pick_cube_state.py"))
+        ex = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ex)
+        obs, _ = env.reset(seed=0)
+        robot = env.get_robot()
+        eef = robot.get_link("hand")
+        q1 = torch.tensor([0, 1, 0, 0], dtype=torch.float32, device=dev).expand(B, -1)
+        idx = torch.arange(B, device=dev)
+        e0, e1 = _events(torch)
+        expert_call_us = []
+        for stage in ex.STAGES:
+            dz = 0.115 if stage in ("hover", "stabilize") else (0.03 if stage == "grasp" else 0.25)
+            us_stage = []
+            for _ in range(40):
+                tgt = obs["environment_state"][:, :3] + torch.tensor([0.0, 0.0, dz], device=dev)
+                torch.cuda.synchronize(dev)
+                e0.record()
+                robot.inverse_kinematics(link=eef, pos=tgt, quat=q1, envs_idx=idx)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                us_stage.append(e0.elapsed_time(e1) * 1e3)
+                obs, *_ = env.step(ex.expert_policy(robot, obs, stage))
+            expert_call_us.append(round(sorted(us_stage)[len(us_stage) // 2], 1))
+    except Exception as e:  # (a secondary figure: never the reason the leg fails)
+        expert_call_us = f"failed: {type(e).__name__}: {e}"[:100]
     return {"workload": "robot.inverse_kinematics(hand, pos, quat) from the home pose, num_envs=4096, <= 20 Levenberg-Marquardt iterations",
+            "expert_call_us_by_stage": expert_call_us,
             "env_solves_per_s": B / (us * 1e-6), "us_per_call": us, "converged_frac": float(((err[:, 0] < 5e-4) & (err[:, 1] < 5e-3)).float().mean().item()),
             "iters_mean": float(it.mean()), "iters_wave_max": int(it.max()),
             "roofline_valu": {"bound": "valu_fp32", "achieved": flops / (us * 1e-6) / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
